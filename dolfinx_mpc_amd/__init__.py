@@ -1,0 +1,39 @@
+"""dolfinx_mpc_amd -- MI355X-native constrained finite-element assembly.
+
+Drop-in for the hot path of dolfinx_mpc (``assemble_matrix``,
+``assemble_vector``, ``apply_lifting`` and the ``MultiPointConstraint`` data
+they read; python/src/dolfinx_mpc/__init__.py:11-25 exports the same names).
+Everything else of dolfinx_mpc (constraint builders on unstructured meshes,
+solvers, I/O) is out of scope; see DESIGN.md.
+"""
+
+from .assemble_matrix import (
+    assemble_matrix,
+    assemble_matrix_nest,
+    create_matrix,
+    create_matrix_nest,
+    create_sparsity_pattern,
+)
+from .assemble_vector import (
+    apply_lifting,
+    assemble_vector,
+    assemble_vector_nest,
+    create_vector_nest,
+    set_bc,
+)
+from .multipointconstraint import MPCData, MultiPointConstraint
+
+__all__ = [
+    "assemble_matrix",
+    "create_matrix_nest",
+    "assemble_matrix_nest",
+    "assemble_vector",
+    "apply_lifting",
+    "assemble_vector_nest",
+    "create_vector_nest",
+    "MultiPointConstraint",
+    "MPCData",
+    "create_sparsity_pattern",
+    "create_matrix",
+    "set_bc",
+]

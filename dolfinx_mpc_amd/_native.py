@@ -1,0 +1,254 @@
+"""ctypes binding of libmpcx.so (C ABI in include/mpcx.h).
+
+This is the only door to the compute path: there is no Python or CPU fallback.
+If the library is missing or was not built, importing the assembly functions
+fails loudly.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmpcx.so")
+
+
+class KernelT(C.Structure):
+    _fields_ = [
+        ("form", C.c_int32),
+        ("celltype", C.c_int32),
+        ("degree", C.c_int32),
+        ("bs", C.c_int32),
+        ("fn_id", C.c_int32),
+        ("coeff_degree", C.c_int32),
+        ("nq", C.c_int32),
+        ("nqf", C.c_int32),
+        ("qpts", C.c_void_p),
+        ("qwts", C.c_void_p),
+        ("fqpts", C.c_void_p),
+        ("fqwts", C.c_void_p),
+    ]
+
+
+class MpcT(C.Structure):
+    _fields_ = [
+        ("is_slave", C.c_void_p),
+        ("masters_offsets", C.c_void_p),
+        ("masters", C.c_void_p),
+        ("coeffs", C.c_void_p),
+    ]
+
+
+class RowBlockPlanT(C.Structure):
+    _fields_ = [
+        ("num_blocks", C.c_int32),
+        ("max_rows", C.c_int32),
+        ("max_nnz", C.c_int32),
+        ("block_row0", C.c_void_p),
+        ("block_ent_off", C.c_void_p),
+        ("block_ents", C.c_void_p),
+    ]
+
+
+class MatrixArgs(C.Structure):
+    _fields_ = [
+        ("nrows", C.c_int32),
+        ("rowptr", C.c_void_p),
+        ("cols", C.c_void_p),
+        ("vals", C.c_void_p),
+        ("kernel", KernelT),
+        ("x", C.c_void_p),
+        ("x_dofmap", C.c_void_p),
+        ("nv", C.c_int32),
+        ("estride", C.c_int32),
+        ("n_entities", C.c_int64),
+        ("entities", C.c_void_p),
+        ("entities0", C.c_void_p),
+        ("entities1", C.c_void_p),
+        ("coeffs", C.c_void_p),
+        ("cstride", C.c_int32),
+        ("constants", C.c_void_p),
+        ("dofmap0", C.c_void_p),
+        ("nd0", C.c_int32),
+        ("bs0", C.c_int32),
+        ("dofmap1", C.c_void_p),
+        ("nd1", C.c_int32),
+        ("bs1", C.c_int32),
+        ("bc0", C.c_void_p),
+        ("bc1", C.c_void_p),
+        ("mpc0", MpcT),
+        ("mpc1", MpcT),
+        ("slave_entities", C.c_void_p),
+        ("n_slave_entities", C.c_int64),
+        ("algorithm", C.c_int32),
+        ("store_mode", C.c_int32),
+        ("plan", RowBlockPlanT),
+        ("stream", C.c_void_p),
+    ]
+
+
+class VectorArgs(C.Structure):
+    _fields_ = [
+        ("b", C.c_void_p),
+        ("num_dofs", C.c_int32),
+        ("kernel", KernelT),
+        ("x", C.c_void_p),
+        ("x_dofmap", C.c_void_p),
+        ("nv", C.c_int32),
+        ("estride", C.c_int32),
+        ("n_entities", C.c_int64),
+        ("entities", C.c_void_p),
+        ("entities0", C.c_void_p),
+        ("coeffs", C.c_void_p),
+        ("cstride", C.c_int32),
+        ("constants", C.c_void_p),
+        ("dofmap", C.c_void_p),
+        ("nd", C.c_int32),
+        ("bs", C.c_int32),
+        ("mpc", MpcT),
+        ("stream", C.c_void_p),
+    ]
+
+
+class LiftingArgs(C.Structure):
+    _fields_ = [
+        ("b", C.c_void_p),
+        ("num_dofs", C.c_int32),
+        ("kernel", KernelT),
+        ("x", C.c_void_p),
+        ("x_dofmap", C.c_void_p),
+        ("nv", C.c_int32),
+        ("estride", C.c_int32),
+        ("n_entities", C.c_int64),
+        ("entities", C.c_void_p),
+        ("entities0", C.c_void_p),
+        ("entities1", C.c_void_p),
+        ("coeffs", C.c_void_p),
+        ("cstride", C.c_int32),
+        ("constants", C.c_void_p),
+        ("dofmap0", C.c_void_p),
+        ("nd0", C.c_int32),
+        ("bs0", C.c_int32),
+        ("dofmap1", C.c_void_p),
+        ("nd1", C.c_int32),
+        ("bs1", C.c_int32),
+        ("bc_markers1", C.c_void_p),
+        ("bc_values1", C.c_void_p),
+        ("x0", C.c_void_p),
+        ("scale", C.c_double),
+        ("lift_entities", C.c_void_p),
+        ("n_lift_entities", C.c_int64),
+        ("mpc0", MpcT),
+        ("stream", C.c_void_p),
+    ]
+
+
+# every symbol include/mpcx.h declares
+EXPORTS = [
+    "mpcx_assemble_matrix",
+    "mpcx_add_diagonal",
+    "mpcx_assemble_vector",
+    "mpcx_apply_lifting",
+    "mpcx_backsubstitution",
+    "mpcx_homogenize",
+    "mpcx_mpc_finalize",
+    "mpcx_cell_to_slaves",
+    "mpcx_pattern_build",
+    "mpcx_pattern_nnz",
+    "mpcx_pattern_nrows",
+    "mpcx_pattern_copy",
+    "mpcx_pattern_free",
+    "mpcx_rowblock_plan_build",
+    "mpcx_rowblock_plan_num_blocks",
+    "mpcx_rowblock_plan_num_ents",
+    "mpcx_rowblock_plan_copy",
+    "mpcx_rowblock_plan_free",
+    "mpcx_last_error",
+    "mpcx_version",
+    "mpcx_device_count",
+]
+
+_lib = None
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def lib() -> C.CDLL:
+    """Load libmpcx.so; raise if it has not been built (``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            f"{_LIB_PATH} not found: the HIP backend has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
+        )
+    L = C.CDLL(_LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    L.mpcx_assemble_matrix.argtypes = [C.POINTER(MatrixArgs)]
+    L.mpcx_assemble_matrix.restype = C.c_int
+    L.mpcx_assemble_vector.argtypes = [C.POINTER(VectorArgs)]
+    L.mpcx_assemble_vector.restype = C.c_int
+    L.mpcx_apply_lifting.argtypes = [C.POINTER(LiftingArgs)]
+    L.mpcx_apply_lifting.restype = C.c_int
+    L.mpcx_add_diagonal.argtypes = [i32, vp, vp, vp, vp, i64, dbl, vp]
+    L.mpcx_add_diagonal.restype = C.c_int
+    L.mpcx_backsubstitution.argtypes = [vp, vp, i64, C.POINTER(MpcT), vp]
+    L.mpcx_backsubstitution.restype = C.c_int
+    L.mpcx_homogenize.argtypes = [vp, vp, i64, vp]
+    L.mpcx_homogenize.restype = C.c_int
+    L.mpcx_mpc_finalize.argtypes = [i32, i32, i32] + [vp] * 12
+    L.mpcx_mpc_finalize.restype = C.c_int
+    L.mpcx_cell_to_slaves.argtypes = [i64, i32, i32, vp, vp, vp, vp]
+    L.mpcx_cell_to_slaves.restype = i64
+    L.mpcx_pattern_build.argtypes = [i64, vp, i32, i32, i32, vp, i32, i32, i32] + [vp] * 8 + [i32]
+    L.mpcx_pattern_build.restype = vp
+    L.mpcx_pattern_nnz.argtypes = [vp]
+    L.mpcx_pattern_nnz.restype = i64
+    L.mpcx_pattern_nrows.argtypes = [vp]
+    L.mpcx_pattern_nrows.restype = i32
+    L.mpcx_pattern_copy.argtypes = [vp, vp, vp]
+    L.mpcx_pattern_copy.restype = C.c_int
+    L.mpcx_pattern_free.argtypes = [vp]
+    L.mpcx_pattern_free.restype = None
+    L.mpcx_rowblock_plan_build.argtypes = [i32, vp, i32, i32, i64, i32, vp, vp, i32, i32, i32]
+    L.mpcx_rowblock_plan_build.restype = vp
+    L.mpcx_rowblock_plan_num_blocks.argtypes = [vp]
+    L.mpcx_rowblock_plan_num_blocks.restype = i32
+    L.mpcx_rowblock_plan_num_ents.argtypes = [vp]
+    L.mpcx_rowblock_plan_num_ents.restype = i64
+    L.mpcx_rowblock_plan_copy.argtypes = [vp, vp, vp, vp]
+    L.mpcx_rowblock_plan_copy.restype = C.c_int
+    L.mpcx_rowblock_plan_free.argtypes = [vp]
+    L.mpcx_rowblock_plan_free.restype = None
+    L.mpcx_last_error.argtypes = []
+    L.mpcx_last_error.restype = C.c_char_p
+    L.mpcx_version.argtypes = []
+    L.mpcx_version.restype = C.c_int
+    L.mpcx_device_count.argtypes = []
+    L.mpcx_device_count.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str):
+    """Native return codes -> RuntimeError, like nanobind turns the reference's
+    std::runtime_error into RuntimeError."""
+    if rc != 0:
+        msg = lib().mpcx_last_error().decode()
+        raise RuntimeError(f"{what} failed ({rc}): {msg}")
+
+
+def require_gpu():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "dolfinx_mpc_amd needs a HIP device (MI355X / gfx950): torch.cuda.is_available() is False "
+            "and there is no CPU fallback for the assembly path."
+        )
+    return torch.device("cuda", torch.cuda.current_device())

@@ -1,0 +1,240 @@
+"""``assemble_matrix`` / ``create_matrix`` / ``create_sparsity_pattern`` with the
+reference's signatures (python/src/dolfinx_mpc/assemble_matrix.py:21-146),
+dispatching to the HIP kernels through the C ABI (include/mpcx.h)."""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence, Union
+
+import numpy as np
+
+from . import _device as D
+from . import _native
+from .fem import DirichletBC, Form
+from .la import MPCMatrix
+from .multipointconstraint import MultiPointConstraint
+
+_ALG = {"auto": 0, "atomic": 1, "rowblock": 2}
+
+# LDS budget of one row block: max_nnz * (8 B value + 4 B column) + row offsets
+ROWBLOCK_MAX_NNZ = int(os.environ.get("MPCX_ROWBLOCK_MAX_NNZ", 5120))
+ROWBLOCK_MAX_ROWS = int(os.environ.get("MPCX_ROWBLOCK_MAX_ROWS", 1024))
+
+
+def _pair(constraint):
+    if isinstance(constraint, MultiPointConstraint):
+        return constraint, constraint
+    assert len(constraint) == 2
+    return constraint[0], constraint[1]
+
+
+def create_sparsity_pattern(form: Form, mpc: Union[MultiPointConstraint, Sequence[MultiPointConstraint]],
+                            num_threads: int = 0):
+    """MPC sparsity pattern as scalar CSR ``(rowptr, cols)`` with sorted columns:
+    the pattern cpp/utils.h:381-496 inserts into a dolfinx SparsityPattern,
+    after ``finalize()`` (python/src/dolfinx_mpc/assemble_matrix.py:68-88)."""
+    mpc0, mpc1 = _pair(mpc)
+    mpc0._not_finalized()
+    mpc1._not_finalized()
+    if form.rank != 2:
+        raise RuntimeError("Cannot create sparsity pattern. Form is not a bilinear form")
+    V0, V1 = mpc0.function_space, mpc1.function_space
+    L = _native.lib()
+    p = _native._ptr
+    dm0, dm1 = V0.dofmap.list, V1.dofmap.list
+    assert dm0.shape[0] == dm1.shape[0]
+    if num_threads <= 0:
+        num_threads = min(os.cpu_count() or 1, 16)
+    h = L.mpcx_pattern_build(
+        dm0.shape[0], p(dm0), dm0.shape[1], V0.dofmap.bs, V0.dofmap.index_map.size_local, p(dm1), dm1.shape[1],
+        V1.dofmap.bs, V1.dofmap.index_map.size_local,
+        p(mpc0.cell_to_slaves.offsets), p(mpc0.cell_to_slaves.array), p(mpc0.masters.offsets), p(mpc0.masters.array),
+        p(mpc1.cell_to_slaves.offsets), p(mpc1.cell_to_slaves.array), p(mpc1.masters.offsets), p(mpc1.masters.array),
+        num_threads,
+    )
+    if not h:
+        raise RuntimeError("mpcx_pattern_build failed: " + L.mpcx_last_error().decode())
+    try:
+        rowptr = np.empty(L.mpcx_pattern_nrows(h) + 1, dtype=np.int32)
+        cols = np.empty(L.mpcx_pattern_nnz(h), dtype=np.int32)
+        L.mpcx_pattern_copy(h, p(rowptr), p(cols))
+    finally:
+        L.mpcx_pattern_free(h)
+    return rowptr, cols
+
+
+def create_matrix(form: Form, mpc0: MultiPointConstraint, mpc1: Optional[MultiPointConstraint] = None) -> MPCMatrix:
+    """python/src/dolfinx_mpc/mpc.cpp:321-344 ``cpp.mpc.create_matrix``."""
+    mpc1 = mpc0 if mpc1 is None else mpc1
+    rowptr, cols = create_sparsity_pattern(form, (mpc0, mpc1))
+    return MPCMatrix(rowptr, cols, mpc1.function_space.num_dofs)
+
+
+def _slave_entities(form: Form, i: int, mpc0, mpc1):
+    """entity indices of integral i whose cell holds a slave of mpc0 or mpc1."""
+    key = ("slave_ents", id(form), i, id(mpc1))
+    if key not in mpc0._cache:
+        cells = form.integrals[i].cells
+        n0 = np.diff(mpc0.cell_to_slaves.offsets)[cells]
+        n1 = np.diff(mpc1.cell_to_slaves.offsets)[cells]
+        idx = np.flatnonzero((n0 > 0) | (n1 > 0)).astype(np.int32)
+        mpc0._cache[key] = (idx, D._to_dev(idx, _native.require_gpu()))
+    return mpc0._cache[key]
+
+
+def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0):
+    key = (id(form), i, ROWBLOCK_MAX_NNZ, ROWBLOCK_MAX_ROWS)
+    if key not in A._plans:
+        L = _native.lib()
+        p = _native._ptr
+        integ = form.integrals[i]
+        ents = np.ascontiguousarray(integ.entities.astype(np.int32).reshape(-1))
+        dm = V0.dofmap.list
+        h = L.mpcx_rowblock_plan_build(A.shape[0], p(A.rowptr), ROWBLOCK_MAX_ROWS, ROWBLOCK_MAX_NNZ,
+                                       integ.num_entities, integ.estride, p(ents), p(dm), dm.shape[1], V0.dofmap.bs, 1)
+        if not h:
+            raise RuntimeError("mpcx_rowblock_plan_build failed: " + L.mpcx_last_error().decode())
+        try:
+            nb = L.mpcx_rowblock_plan_num_blocks(h)
+            row0 = np.empty(nb + 1, dtype=np.int32)
+            off = np.empty(nb + 1, dtype=np.int64)
+            ents_b = np.empty(L.mpcx_rowblock_plan_num_ents(h), dtype=np.int32)
+            L.mpcx_rowblock_plan_copy(h, p(row0), p(off), p(ents_b))
+        finally:
+            L.mpcx_rowblock_plan_free(h)
+        dev = A.device
+        t = (D._to_dev(row0, dev), D._to_dev(off, dev), D._to_dev(ents_b, dev))
+        max_rows = int(np.diff(row0).max())
+        max_nnz = int(np.diff(A.rowptr[row0].astype(np.int64)).max())
+        s = _native.RowBlockPlanT(nb, max_rows, max_nnz, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr())
+        A._plans[key] = (s, t, {"num_blocks": nb, "num_ents": int(ents_b.size)})
+    return A._plans[key]
+
+
+def assemble_matrix(
+    form: Form,
+    constraint: Union[MultiPointConstraint, Sequence[MultiPointConstraint]],
+    bcs: Optional[Sequence[DirichletBC]] = None,
+    diagval: float = 1,
+    A: Optional[MPCMatrix] = None,
+    num_threads: Optional[int] = 1,
+    algorithm: Optional[str] = None,
+) -> MPCMatrix:
+    """Assemble a bilinear form into a CSR matrix with multi point constraints
+    and Dirichlet conditions (python/src/dolfinx_mpc/assemble_matrix.py:21-65).
+
+    Args:
+        form: the bilinear form
+        constraint: the multi point constraint (or a (row, col) pair)
+        bcs: Dirichlet boundary conditions
+        diagval: value set on the diagonal for slave and Dirichlet dofs
+        A: matrix to assemble into (created with the MPC pattern if None)
+        num_threads: accepted for API compatibility (host set-up threads)
+        algorithm: "atomic" | "rowblock" | None (= env MPCX_MATRIX_ALG or "auto")
+    """
+    import torch
+
+    bcs = [] if bcs is None else list(bcs)
+    if isinstance(constraint, MultiPointConstraint):
+        assert form.function_spaces[0] is form.function_spaces[1]
+    mpc0, mpc1 = _pair(constraint)
+    if form.rank != 2:
+        raise RuntimeError("assemble_matrix needs a bilinear form")
+    _native.require_gpu()
+    L = _native.lib()
+    if A is None:
+        A = create_matrix(form, mpc0, mpc1)
+    alg = _ALG[(algorithm or os.environ.get("MPCX_MATRIX_ALG", "auto")).lower()]
+    if alg == 0:
+        alg = 1
+
+    V0, V1 = form.function_spaces
+    md = D.mesh_device(form.mesh)
+    s0, s1 = D.space_device(V0), D.space_device(V1)
+    _, bc0 = D.bc_markers(V0, bcs, form._device)
+    _, bc1 = D.bc_markers(V1, bcs, form._device)
+    m0, _k0 = mpc0._device()
+    m1, _k1 = mpc1._device()
+    stream = D.stream_ptr()
+
+    zeroed = False
+    for i, integ in enumerate(form.integrals):
+        if integ.itype not in ("cell", "exterior_facet"):
+            raise RuntimeError("Not implemented yet")  # cpp/assemble_matrix.cpp:658-659
+        idv = D.integral_device(form, i)
+        _, slave_ents = _slave_entities(form, i, mpc0, mpc1)
+        a = _native.MatrixArgs()
+        a.nrows = A.shape[0]
+        a.rowptr, a.cols, a.vals = A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), A.vals.data_ptr()
+        a.kernel = idv["kernel"]
+        a.x, a.x_dofmap, a.nv = md["x"].data_ptr(), md["x_dofmap"].data_ptr(), form.mesh.geometry.dofmap.shape[1]
+        a.estride, a.n_entities = integ.estride, integ.num_entities
+        a.entities = a.entities0 = a.entities1 = idv["entities"].data_ptr()
+        a.coeffs = D.ptr(idv["coeffs"])
+        a.cstride = 0 if integ.coeffs is None else integ.coeffs.shape[1]
+        a.constants = D.ptr(idv["constants"])
+        a.dofmap0, a.nd0, a.bs0 = s0["dofmap"].data_ptr(), V0.element_ndofs, V0.dofmap.bs
+        a.dofmap1, a.nd1, a.bs1 = s1["dofmap"].data_ptr(), V1.element_ndofs, V1.dofmap.bs
+        a.bc0, a.bc1 = D.ptr(bc0), D.ptr(bc1)
+        a.mpc0, a.mpc1 = m0, m1
+        a.slave_entities, a.n_slave_entities = slave_ents.data_ptr(), slave_ents.numel()
+        a.algorithm = alg
+        a.stream = stream
+        if alg == 2:
+            plan, _keep, _info = _rowblock_plan(A, form, i, V0)
+            a.plan = plan
+            # the first integral's row blocks overwrite every value: no memset pass
+            a.store_mode = 1 if not zeroed else 0
+            zeroed = True
+        elif not zeroed:
+            A.zeroEntries()  # python/src/dolfinx_mpc/assemble_matrix.py:51
+            zeroed = True
+        _native.check(L.mpcx_assemble_matrix(C.byref(a)), "mpcx_assemble_matrix")
+    if not zeroed:
+        A.zeroEntries()
+
+    # slave diagonal, cpp/assemble_matrix.cpp:711-724 (only when mpc0.V == mpc1.V)
+    if mpc0.function_space is mpc1.function_space:
+        _, t = mpc0._device()
+        ns = mpc0.num_local_slaves
+        _native.check(
+            L.mpcx_add_diagonal(A.shape[0], A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), A.vals.data_ptr(),
+                                t["slaves"].data_ptr(), ns, float(diagval), stream),
+            "mpcx_add_diagonal",
+        )
+    # Dirichlet diagonal: dolfinx insert_diagonal, python/src/dolfinx_mpc/assemble_matrix.py:59-62
+    if form.function_spaces[0] is form.function_spaces[1]:
+        for bc in bcs:
+            if not V0.contains(bc.function_space):
+                continue
+            key = ("bcdofs", str(A.device), id(bc))
+            if key not in form._device:
+                form._device[key] = D._to_dev(bc.dof_indices()[0], A.device)
+            dofs = form._device[key]
+            _native.check(
+                L.mpcx_add_diagonal(A.shape[0], A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), A.vals.data_ptr(),
+                                    dofs.data_ptr(), dofs.numel(), float(diagval), stream),
+                "mpcx_add_diagonal",
+            )
+    A.assemble()
+    return A
+
+
+def create_matrix_nest(a: Sequence[Sequence[Optional[Form]]], constraints: Sequence[MultiPointConstraint]):
+    """python/src/dolfinx_mpc/assemble_matrix.py:91-117: block (i, j) uses
+    (constraints[i], constraints[j]); ``None`` blocks are skipped."""
+    assert len(constraints) == len(a)
+    return [[None if blk is None else create_matrix(blk, constraints[i], constraints[j]) for j, blk in enumerate(row)]
+            for i, row in enumerate(a)]
+
+
+def assemble_matrix_nest(A, a, constraints, bcs: Sequence[DirichletBC] = (), diagval: float = 1,
+                         num_threads: Optional[int] = 1):
+    """python/src/dolfinx_mpc/assemble_matrix.py:120-146"""
+    for i, a_row in enumerate(a):
+        for j, a_block in enumerate(a_row):
+            if a_block is not None:
+                assemble_matrix(a_block, (constraints[i], constraints[j]), bcs=bcs, diagval=diagval, A=A[i][j],
+                                num_threads=num_threads)

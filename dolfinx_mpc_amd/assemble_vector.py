@@ -1,0 +1,166 @@
+"""``assemble_vector`` / ``apply_lifting`` with the reference's signatures
+(python/src/dolfinx_mpc/assemble_vector.py:25-147) on the HIP backend."""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _device as D
+from . import _native
+from .fem import DirichletBC, Form
+from .la import Vector, create_vector
+from .multipointconstraint import MultiPointConstraint
+
+
+def assemble_vector(form: Form, constraint: MultiPointConstraint, b: Optional[Vector] = None,
+                    num_threads: Optional[int] = 1) -> Vector:
+    """Assemble a linear form into ``b`` with the multi point constraint applied
+    (python/src/dolfinx_mpc/assemble_vector.py:79-104): ``b`` is created on the
+    MPC function space if None, zeroed, then accumulated into."""
+    if form.rank != 1:
+        raise RuntimeError("assemble_vector needs a linear form")
+    constraint._not_finalized()
+    _native.require_gpu()
+    L = _native.lib()
+    V = form.function_spaces[0]
+    if b is None:
+        b = create_vector(constraint.function_space)
+    b.set(0.0)
+    md = D.mesh_device(form.mesh)
+    sd = D.space_device(V)
+    m, _keep = constraint._device()
+    for i, integ in enumerate(form.integrals):
+        if integ.itype not in ("cell", "exterior_facet"):
+            raise RuntimeError("Interior facet integrals currently not supported")
+        idv = D.integral_device(form, i)
+        a = _native.VectorArgs()
+        a.b, a.num_dofs = b.array.data_ptr(), b.size
+        a.kernel = idv["kernel"]
+        a.x, a.x_dofmap, a.nv = md["x"].data_ptr(), md["x_dofmap"].data_ptr(), form.mesh.geometry.dofmap.shape[1]
+        a.estride, a.n_entities = integ.estride, integ.num_entities
+        a.entities = a.entities0 = idv["entities"].data_ptr()
+        a.coeffs = D.ptr(idv["coeffs"])
+        a.cstride = 0 if integ.coeffs is None else integ.coeffs.shape[1]
+        a.constants = D.ptr(idv["constants"])
+        a.dofmap, a.nd, a.bs = sd["dofmap"].data_ptr(), V.element_ndofs, V.dofmap.bs
+        a.mpc = m
+        a.stream = D.stream_ptr()
+        _native.check(L.mpcx_assemble_vector(C.byref(a)), "mpcx_assemble_vector")
+    return b
+
+
+def _lift_entities(form: Form, i: int, markers: np.ndarray, V1, cache: dict, key):
+    """compact list of entities with a bc-marked column dof (cpp/lifting.h:93-109)."""
+    if key not in cache:
+        integ = form.integrals[i]
+        dofs = V1.dofmap.list[integ.cells]  # (n, nd) blocked
+        bs = V1.dofmap.bs
+        hit = np.zeros(dofs.shape[0], dtype=bool)
+        for k in range(bs):
+            hit |= markers[dofs * bs + k].any(axis=1)
+        idx = np.flatnonzero(hit).astype(np.int32)
+        cache[key] = (idx, D._to_dev(idx, _native.require_gpu()))
+    return cache[key]
+
+
+def apply_lifting(
+    b: Vector,
+    form: Sequence[Optional[Form]],
+    bcs: Sequence[Sequence[DirichletBC]],
+    constraint: MultiPointConstraint,
+    x0: Optional[Sequence[Vector]] = None,
+    scale: float = 1.0,
+    num_threads: Optional[int] = 1,
+):
+    """b <- b - scale * K^T A_j (g_j - x0_j)
+    (python/src/dolfinx_mpc/assemble_vector.py:25-76, cpp/lifting.h:441-483)."""
+    import torch
+
+    if isinstance(scale, np.generic):
+        scale = scale.item()
+    x0 = [] if x0 is None else list(x0)
+    form = list(form)
+    if len(x0) > 0 and len(x0) != len(form):
+        raise RuntimeError("Mismatch in size between x0 and bilinear form in assembler.")
+    if len(form) != len(bcs):
+        raise RuntimeError("Mismatch in size between a and bcs in assembler.")
+    if all(f is None for f in form):
+        return
+    constraint._not_finalized()
+    dev = _native.require_gpu()
+    L = _native.lib()
+    m, _keep = constraint._device()
+    for j, aj in enumerate(form):
+        if aj is None or len(bcs[j]) == 0:
+            continue
+        V0, V1 = aj.function_spaces
+        # bc markers / values over the column space, cpp/lifting.h:166-180
+        key = ("lift", str(dev), tuple(id(bc) for bc in bcs[j]))
+        if key not in aj._device:
+            markers = np.zeros(V1.num_dofs, dtype=np.int8)
+            values = np.zeros(V1.num_dofs, dtype=np.float64)
+            for bc in bcs[j]:
+                bc.mark_dofs(markers)
+                bc.set(values, None, 1.0)
+            aj._device[key] = (markers, D._to_dev(markers, dev), D._to_dev(values, dev))
+        markers, d_markers, d_values = aj._device[key]
+        md = D.mesh_device(aj.mesh)
+        s0, s1 = D.space_device(V0), D.space_device(V1)
+        x0j = None
+        if len(x0) > 0:
+            x0j = x0[j].array if hasattr(x0[j], "array") else x0[j]
+        for i, integ in enumerate(aj.integrals):
+            if integ.itype not in ("cell", "exterior_facet"):
+                raise RuntimeError("Interior facet integrals currently not supported")
+            idv = D.integral_device(aj, i)
+            _, lift = _lift_entities(aj, i, markers, V1, aj._device, key + ("ents", i))
+            a = _native.LiftingArgs()
+            a.b, a.num_dofs = b.array.data_ptr(), b.size
+            a.kernel = idv["kernel"]
+            a.x, a.x_dofmap, a.nv = md["x"].data_ptr(), md["x_dofmap"].data_ptr(), aj.mesh.geometry.dofmap.shape[1]
+            a.estride, a.n_entities = integ.estride, integ.num_entities
+            a.entities = a.entities0 = a.entities1 = idv["entities"].data_ptr()
+            a.coeffs = D.ptr(idv["coeffs"])
+            a.cstride = 0 if integ.coeffs is None else integ.coeffs.shape[1]
+            a.constants = D.ptr(idv["constants"])
+            a.dofmap0, a.nd0, a.bs0 = s0["dofmap"].data_ptr(), V0.element_ndofs, V0.dofmap.bs
+            a.dofmap1, a.nd1, a.bs1 = s1["dofmap"].data_ptr(), V1.element_ndofs, V1.dofmap.bs
+            a.bc_markers1, a.bc_values1 = d_markers.data_ptr(), d_values.data_ptr()
+            a.x0 = None if x0j is None else x0j.data_ptr()
+            a.scale = float(scale)
+            a.lift_entities, a.n_lift_entities = lift.data_ptr(), lift.numel()
+            a.mpc0 = m
+            a.stream = D.stream_ptr()
+            _native.check(L.mpcx_apply_lifting(C.byref(a)), "mpcx_apply_lifting")
+
+
+def set_bc(b: Vector, bcs: Sequence[DirichletBC], x0: Optional[Vector] = None, scale: float = 1.0):
+    """dolfinx ``set_bc`` (bench_periodic.py:109): b[bc dofs] = scale * (g - x0)."""
+    import torch
+
+    for bc in bcs:
+        dofs = bc.dof_indices()[0]
+        vals = np.zeros(b.size, dtype=np.float64)
+        bc.set(vals, None, 1.0)
+        idx = torch.from_numpy(dofs.astype(np.int64)).to(b.array.device)
+        g = torch.from_numpy(vals[dofs]).to(b.array.device)
+        if x0 is not None:
+            g = g - x0.array[idx]
+        b.array[idx] = scale * g
+
+
+def create_vector_nest(L: Sequence[Form], constraints: Sequence[MultiPointConstraint]):
+    """python/src/dolfinx_mpc/assemble_vector.py:107-127"""
+    assert len(constraints) == len(L)
+    return [create_vector(c.function_space) for c in constraints]
+
+
+def assemble_vector_nest(b, L: Sequence[Form], constraints: Sequence[MultiPointConstraint],
+                         num_threads: Optional[int] = 1):
+    """python/src/dolfinx_mpc/assemble_vector.py:130-147"""
+    assert len(constraints) == len(L)
+    for i, L_row in enumerate(L):
+        assemble_vector(L_row, constraints[i], b=b[i], num_threads=num_threads)

@@ -1,0 +1,437 @@
+// Device element kernels for gfx950: the role FFCx-generated tabulate_tensor
+// plays in the reference (called at cpp/assemble_matrix.cpp:505-506,
+// cpp/assemble_vector.cpp:180-181, cpp/lifting.h:268-270).  Everything is
+// compile-time sized so the element tensor lives in VGPRs.
+//
+// Conventions (Basix/UFC): reference simplex vertices (0,..),(1,0,..),(0,1,..);
+// facet i opposite vertex i; P2 dofs = vertices then edges
+// tet edges (2,3)(1,3)(1,2)(0,3)(0,2)(0,1), triangle edges (1,2)(0,2)(0,1).
+// coordinate_dofs are [nv][3] (3 components always, assemble_matrix.cpp:499).
+#pragma once
+#include "mpcx.h"
+#include <hip/hip_runtime.h>
+
+namespace mpcx
+{
+
+template <int TDIM, int DEG>
+struct Lagrange
+{
+  static constexpr int NV = TDIM + 1;
+  static constexpr int NE = TDIM == 3 ? 6 : 3;
+  static constexpr int ND = DEG == 1 ? NV : NV + NE;
+
+  __device__ static inline void edge(int e, int& a, int& b)
+  {
+    if constexpr (TDIM == 3)
+    {
+      constexpr int E[6][2] = {{2, 3}, {1, 3}, {1, 2}, {0, 3}, {0, 2}, {0, 1}};
+      a = E[e][0];
+      b = E[e][1];
+    }
+    else
+    {
+      constexpr int E[3][2] = {{1, 2}, {0, 2}, {0, 1}};
+      a = E[e][0];
+      b = E[e][1];
+    }
+  }
+
+  // phi[ND], dphi[ND][TDIM] (reference gradients)
+  __device__ static inline void eval(const double (&X)[3], double (&phi)[ND], double (&dphi)[ND][TDIM])
+  {
+    double lam[NV];
+    lam[0] = 1.0;
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d)
+    {
+      lam[0] -= X[d];
+      lam[d + 1] = X[d];
+    }
+    // dlam[i][d] = (i == d+1) - (i == 0)
+    if constexpr (DEG == 1)
+    {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+      {
+        phi[i] = lam[i];
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d)
+          dphi[i][d] = (i == 0) ? -1.0 : (i == d + 1 ? 1.0 : 0.0);
+      }
+    }
+    else
+    {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+      {
+        phi[i] = lam[i] * (2.0 * lam[i] - 1.0);
+        const double s = 4.0 * lam[i] - 1.0;
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d)
+          dphi[i][d] = (i == 0) ? -s : (i == d + 1 ? s : 0.0);
+      }
+#pragma unroll
+      for (int e = 0; e < NE; ++e)
+      {
+        int a, b;
+        edge(e, a, b);
+        phi[NV + e] = 4.0 * lam[a] * lam[b];
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d)
+        {
+          const double da = (a == 0) ? -1.0 : (a == d + 1 ? 1.0 : 0.0);
+          const double db = (b == 0) ? -1.0 : (b == d + 1 ? 1.0 : 0.0);
+          dphi[NV + e][d] = 4.0 * (lam[a] * db + lam[b] * da);
+        }
+      }
+    }
+  }
+};
+
+// Affine map: K = J^-1 (K[d][a] = dX_d/dx_a), detJ
+template <int TDIM>
+__device__ inline void affine_geometry(const double* cd, double (&K)[TDIM][TDIM], double& detJ)
+{
+  if constexpr (TDIM == 2)
+  {
+    const double J00 = cd[3] - cd[0], J01 = cd[6] - cd[0];
+    const double J10 = cd[4] - cd[1], J11 = cd[7] - cd[1];
+    const double det = J00 * J11 - J01 * J10;
+    detJ = det;
+    K[0][0] = J11 / det;
+    K[0][1] = -J01 / det;
+    K[1][0] = -J10 / det;
+    K[1][1] = J00 / det;
+  }
+  else
+  {
+    const double J00 = cd[3] - cd[0], J01 = cd[6] - cd[0], J02 = cd[9] - cd[0];
+    const double J10 = cd[4] - cd[1], J11 = cd[7] - cd[1], J12 = cd[10] - cd[1];
+    const double J20 = cd[5] - cd[2], J21 = cd[8] - cd[2], J22 = cd[11] - cd[2];
+    const double c00 = J11 * J22 - J12 * J21;
+    const double c01 = J12 * J20 - J10 * J22;
+    const double c02 = J10 * J21 - J11 * J20;
+    const double det = J00 * c00 + J01 * c01 + J02 * c02;
+    detJ = det;
+    K[0][0] = c00 / det;
+    K[0][1] = (J02 * J21 - J01 * J22) / det;
+    K[0][2] = (J01 * J12 - J02 * J11) / det;
+    K[1][0] = c01 / det;
+    K[1][1] = (J00 * J22 - J02 * J20) / det;
+    K[1][2] = (J02 * J10 - J00 * J12) / det;
+    K[2][0] = c02 / det;
+    K[2][1] = (J01 * J20 - J00 * J21) / det;
+    K[2][2] = (J00 * J11 - J01 * J10) / det;
+  }
+}
+
+template <int TDIM>
+__device__ inline void push_forward(const double* cd, const double (&X)[3], double (&x)[3])
+{
+  double l0 = 1.0;
+#pragma unroll
+  for (int d = 0; d < TDIM; ++d)
+    l0 -= X[d];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+  {
+    double v = l0 * cd[i];
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d)
+      v += X[d] * cd[3 * (d + 1) + i];
+    x[i] = v;
+  }
+}
+
+// analytic right-hand sides; ids shared with dolfinx_mpc_amd/fem.py
+__device__ inline double eval_fn(int fn_id, const double (&x)[3], int comp, const double* c)
+{
+  switch (fn_id)
+  {
+  case 0:
+    return 1.0;
+  case 1:
+  {
+    // python/benchmarks/bench_periodic.py:85-89
+    const double dx = x[0] - 0.9, dy = x[1] - 0.5, dz = x[2] - 0.1;
+    return x[0] * sin(5.0 * 3.14159265358979323846 * x[1])
+           + 1.0 * exp(-(dx * dx + dy * dy + dz * dz) / 0.02);
+  }
+  case 2:
+    return sin(2.0 * 3.14159265358979323846 * x[0]) * sin(3.14159265358979323846 * x[1])
+           + 0.3 * (comp + 1);
+  case 3:
+    return 1.0 + 2.0 * x[0] + 3.0 * x[1] * x[1] - x[2] * x[2] * x[2] + x[0] * x[1] * x[2]
+           + 0.5 * comp * x[0];
+  case 4:
+    return (comp + 1) * (1.0 + x[0] - 2.0 * x[1] + 0.5 * x[2]);
+  case 5:
+    return c[1 + comp]; // constants = [scale, g_0, g_1, ...]
+  default:
+    return 0.0;
+  }
+}
+
+// Reference point + weight of quadrature point q of a cell or facet rule.
+template <int TDIM, bool FACET>
+struct QuadPoint
+{
+  double fscale = 0.0;
+  double fv[TDIM][TDIM]; // reference coords of the facet vertices
+
+  __device__ inline void init_facet(const double* cd, int lf)
+  {
+    if constexpr (FACET)
+    {
+      double pv[TDIM][3];
+#pragma unroll
+      for (int a = 0; a < TDIM; ++a)
+      {
+        // facet lf = all vertices except lf, ascending
+        const int v = a < lf ? a : a + 1;
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d)
+          fv[a][d] = (v == d + 1) ? 1.0 : 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          pv[a][i] = cd[3 * v + i];
+      }
+      if constexpr (TDIM == 3)
+      {
+        const double e1x = pv[1][0] - pv[0][0], e1y = pv[1][1] - pv[0][1], e1z = pv[1][2] - pv[0][2];
+        const double e2x = pv[2][0] - pv[0][0], e2y = pv[2][1] - pv[0][1], e2z = pv[2][2] - pv[0][2];
+        const double cx = e1y * e2z - e1z * e2y, cy = e1z * e2x - e1x * e2z, cz = e1x * e2y - e1y * e2x;
+        fscale = sqrt(cx * cx + cy * cy + cz * cz);
+      }
+      else
+      {
+        const double ex = pv[1][0] - pv[0][0], ey = pv[1][1] - pv[0][1], ez = pv[1][2] - pv[0][2];
+        fscale = sqrt(ex * ex + ey * ey + ez * ez);
+      }
+    }
+  }
+
+  __device__ inline double point(const mpcx_kernel_t& k, int q, double adet, double (&X)[3]) const
+  {
+    X[0] = X[1] = X[2] = 0.0;
+    if constexpr (FACET)
+    {
+      const double* s = k.fqpts + q * (TDIM - 1);
+      double l0 = 1.0;
+#pragma unroll
+      for (int d = 0; d < TDIM - 1; ++d)
+        l0 -= s[d];
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d)
+      {
+        double v = l0 * fv[0][d];
+#pragma unroll
+        for (int a = 1; a < TDIM; ++a)
+          v += s[a - 1] * fv[a][d];
+        X[d] = v;
+      }
+      return k.fqwts[q] * fscale;
+    }
+    else
+    {
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d)
+        X[d] = k.qpts[q * TDIM + d];
+      return k.qwts[q] * adet;
+    }
+  }
+};
+
+template <int TDIM>
+__device__ inline double eval_coefficient(int coeff_degree, const double* w, const double (&X)[3])
+{
+  if (coeff_degree == 1)
+  {
+    double phi[Lagrange<TDIM, 1>::ND], dphi[Lagrange<TDIM, 1>::ND][TDIM];
+    Lagrange<TDIM, 1>::eval(X, phi, dphi);
+    double v = 0.0;
+#pragma unroll
+    for (int i = 0; i < Lagrange<TDIM, 1>::ND; ++i)
+      v += w[i] * phi[i];
+    return v;
+  }
+  else
+  {
+    double phi[Lagrange<TDIM, 2>::ND], dphi[Lagrange<TDIM, 2>::ND][TDIM];
+    Lagrange<TDIM, 2>::eval(X, phi, dphi);
+    double v = 0.0;
+#pragma unroll
+    for (int i = 0; i < Lagrange<TDIM, 2>::ND; ++i)
+      v += w[i] * phi[i];
+    return v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Generic element operator.  A is [N][N] (rank 2) or [N] (rank 1), row-major,
+// blocked dof index i*BS + k, accumulated into a zeroed buffer like UFCx.
+// ---------------------------------------------------------------------------
+template <int TDIM_, int DEG_, int BS_, int FORM_>
+struct ElementOp
+{
+  static constexpr int TDIM = TDIM_;
+  static constexpr int DEG = DEG_;
+  static constexpr int BS = BS_;
+  static constexpr int FORM = FORM_;
+  using L = Lagrange<TDIM, DEG>;
+  static constexpr int NV = TDIM + 1;
+  static constexpr int ND = L::ND;
+  static constexpr int N = ND * BS;
+  static constexpr bool FACET = (FORM == MPCX_FORM_FACET_MASS || FORM == MPCX_FORM_FACET_SOURCE);
+  static constexpr bool RANK1 = (FORM == MPCX_FORM_SOURCE || FORM == MPCX_FORM_FACET_SOURCE);
+  static constexpr int SIZE = RANK1 ? N : N * N;
+
+  __device__ static inline void tabulate(double (&A)[SIZE], const double* w, const double* c,
+                                         const double (&cd)[NV * 3], int lf, const mpcx_kernel_t& k)
+  {
+#pragma unroll
+    for (int i = 0; i < SIZE; ++i)
+      A[i] = 0.0;
+
+    // P1 simplex Laplacian: constant gradients, one point is exact
+    if constexpr (FORM == MPCX_FORM_STIFFNESS && DEG == 1 && BS == 1)
+    {
+      if (k.coeff_degree == 0)
+      {
+        double K[TDIM][TDIM], detJ;
+        affine_geometry<TDIM>(cd, K, detJ);
+        const double vol = fabs(detJ) * (TDIM == 3 ? 1.0 / 6.0 : 0.5) * (c ? c[0] : 1.0);
+        double G[NV][TDIM];
+#pragma unroll
+        for (int a = 0; a < TDIM; ++a)
+        {
+          double s = 0.0;
+#pragma unroll
+          for (int d = 0; d < TDIM; ++d)
+          {
+            G[d + 1][a] = K[d][a];
+            s += K[d][a];
+          }
+          G[0][a] = -s;
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+          for (int j = 0; j < NV; ++j)
+          {
+            double dot = 0.0;
+#pragma unroll
+            for (int a = 0; a < TDIM; ++a)
+              dot += G[i][a] * G[j][a];
+            A[i * NV + j] = vol * dot;
+          }
+        return;
+      }
+    }
+
+    double K[TDIM][TDIM], detJ;
+    affine_geometry<TDIM>(cd, K, detJ);
+    const double adet = fabs(detJ);
+    const double c0 = (c && FORM != MPCX_FORM_ELASTICITY) ? c[0] : 1.0;
+    QuadPoint<TDIM, FACET> qp;
+    qp.init_facet(cd, lf);
+    const int nq = FACET ? k.nqf : k.nq;
+    for (int q = 0; q < nq; ++q)
+    {
+      double X[3];
+      const double wq = qp.point(k, q, adet, X);
+      double phi[ND], dphi[ND][TDIM];
+      L::eval(X, phi, dphi);
+      double s = wq * c0;
+      if (k.coeff_degree > 0 && FORM != MPCX_FORM_ELASTICITY)
+        s *= eval_coefficient<TDIM>(k.coeff_degree, w, X);
+
+      if constexpr (FORM == MPCX_FORM_MASS || FORM == MPCX_FORM_FACET_MASS)
+      {
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+#pragma unroll
+          for (int j = 0; j < ND; ++j)
+          {
+            const double v = s * phi[i] * phi[j];
+#pragma unroll
+            for (int b = 0; b < BS; ++b)
+              A[(i * BS + b) * N + (j * BS + b)] += v;
+          }
+      }
+      else if constexpr (RANK1)
+      {
+        double x[3];
+        push_forward<TDIM>(cd, X, x);
+#pragma unroll
+        for (int b = 0; b < BS; ++b)
+        {
+          const double f = s * eval_fn(k.fn_id, x, b, c);
+#pragma unroll
+          for (int i = 0; i < ND; ++i)
+            A[i * BS + b] += f * phi[i];
+        }
+      }
+      else
+      {
+        // physical gradients
+        double g[ND][TDIM];
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+#pragma unroll
+          for (int a = 0; a < TDIM; ++a)
+          {
+            double v = 0.0;
+#pragma unroll
+            for (int d = 0; d < TDIM; ++d)
+              v += K[d][a] * dphi[i][d];
+            g[i][a] = v;
+          }
+        if constexpr (FORM == MPCX_FORM_STIFFNESS)
+        {
+#pragma unroll
+          for (int i = 0; i < ND; ++i)
+#pragma unroll
+            for (int j = 0; j < ND; ++j)
+            {
+              double dot = 0.0;
+#pragma unroll
+              for (int a = 0; a < TDIM; ++a)
+                dot += g[i][a] * g[j][a];
+#pragma unroll
+              for (int b = 0; b < BS; ++b)
+                A[(i * BS + b) * N + (j * BS + b)] += s * dot;
+            }
+        }
+        else if constexpr (FORM == MPCX_FORM_ELASTICITY)
+        {
+          static_assert(FORM != MPCX_FORM_ELASTICITY || BS == TDIM, "elasticity needs bs == tdim");
+          const double mu = c[0], lmbda = c[1];
+#pragma unroll
+          for (int i = 0; i < ND; ++i)
+#pragma unroll
+            for (int j = 0; j < ND; ++j)
+            {
+              double dot = 0.0;
+#pragma unroll
+              for (int a = 0; a < TDIM; ++a)
+                dot += g[i][a] * g[j][a];
+#pragma unroll
+              for (int a = 0; a < BS; ++a)
+#pragma unroll
+                for (int b = 0; b < BS; ++b)
+                {
+                  double v = mu * g[i][b] * g[j][a] + lmbda * g[i][a] * g[j][b];
+                  if (a == b)
+                    v += mu * dot;
+                  A[(i * BS + a) * N + (j * BS + b)] += wq * v;
+                }
+            }
+        }
+      }
+    }
+  }
+};
+
+} // namespace mpcx

@@ -1,0 +1,416 @@
+// Host-side set-up for the MI355X constrained-assembly backend: the data the
+// kernels read.  Restates (not copies) the reference's one-off builders on
+// flat arrays:
+//   cpp/MultiPointConstraint.h:36-126   -> mpcx_mpc_finalize
+//   cpp/mpc_helpers.h:19-94             -> mpcx_cell_to_slaves
+//   cpp/utils.h:381-496 (+finalize)     -> mpcx_pattern_*
+// plus the row-block plan used by the LDS-privatised matrix kernel.
+#include "mpcx.h"
+#include "mpcx_internal.h"
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace
+{
+thread_local std::string g_error;
+}
+
+void mpcx_set_error(const std::string& msg) { g_error = msg; }
+
+extern "C" const char* mpcx_last_error(void) { return g_error.c_str(); }
+extern "C" int mpcx_version(void) { return MPCX_VERSION; }
+
+// ---------------------------------------------------------------------------
+extern "C" int mpcx_mpc_finalize(int32_t num_dofs, int32_t num_owned_dofs, int32_t num_slaves,
+                                 const int32_t* slaves, const int64_t* masters,
+                                 const double* coeffs, const int32_t* owners,
+                                 const int32_t* offsets, int8_t* is_slave,
+                                 int32_t* sorted_slaves, int32_t* num_local_slaves,
+                                 int32_t* masters_offsets, int32_t* masters_out,
+                                 double* coeffs_out, int32_t* owners_out)
+{
+  // slave marker over all local dofs
+  std::fill_n(is_slave, num_dofs, int8_t(0));
+  for (int32_t i = 0; i < num_slaves; ++i)
+  {
+    if (slaves[i] < 0 || slaves[i] >= num_dofs)
+    {
+      mpcx_set_error("mpcx_mpc_finalize: slave index out of range");
+      return -1;
+    }
+    is_slave[slaves[i]] = 1;
+  }
+  // adjacency with one node per local dof; only slaves have links
+  std::vector<int32_t> num_masters(num_dofs, 0);
+  for (int32_t i = 0; i < num_slaves; ++i)
+    num_masters[slaves[i]] = offsets[i + 1] - offsets[i];
+  masters_offsets[0] = 0;
+  for (int32_t d = 0; d < num_dofs; ++d)
+    masters_offsets[d + 1] = masters_offsets[d] + num_masters[d];
+  std::fill(num_masters.begin(), num_masters.end(), 0);
+  for (int32_t i = 0; i < num_slaves; ++i)
+  {
+    const int32_t s = slaves[i];
+    for (int32_t j = offsets[i]; j < offsets[i + 1]; ++j)
+    {
+      const int32_t pos = masters_offsets[s] + num_masters[s]++;
+      if (masters[j] < 0 || masters[j] >= num_dofs)
+      {
+        mpcx_set_error("mpcx_mpc_finalize: master index out of range (single-process backend: "
+                       "global master index must equal a local dof)");
+        return -2;
+      }
+      masters_out[pos] = static_cast<int32_t>(masters[j]);
+      coeffs_out[pos] = coeffs[j];
+      owners_out[pos] = owners[j];
+    }
+  }
+  // sorted slave list and the number of owned slaves
+  int32_t c = 0, nloc = 0;
+  for (int32_t d = 0; d < num_dofs; ++d)
+    if (is_slave[d])
+    {
+      sorted_slaves[c++] = d;
+      if (d < num_owned_dofs)
+        ++nloc;
+    }
+  *num_local_slaves = nloc;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int64_t mpcx_cell_to_slaves(int64_t num_cells, int32_t nd, int32_t bs,
+                                       const int32_t* dofmap, const int8_t* is_slave,
+                                       int32_t* c2s_offsets, int32_t* c2s)
+{
+  // The reference inverts a dof->cells map whose nodes are visited in
+  // ascending dof order, so each cell's slaves come out sorted by dof.
+  int64_t total = 0;
+  int32_t tmp[256];
+  if (nd * bs > 256)
+  {
+    mpcx_set_error("mpcx_cell_to_slaves: element too large");
+    return -1;
+  }
+  c2s_offsets[0] = 0;
+  for (int64_t c = 0; c < num_cells; ++c)
+  {
+    int n = 0;
+    const int32_t* dofs = dofmap + c * nd;
+    for (int i = 0; i < nd; ++i)
+      for (int k = 0; k < bs; ++k)
+      {
+        const int32_t d = dofs[i] * bs + k;
+        if (is_slave[d])
+          tmp[n++] = d;
+      }
+    if (c2s && n)
+    {
+      std::sort(tmp, tmp + n);
+      std::copy(tmp, tmp + n, c2s + total);
+    }
+    total += n;
+    if (total > INT32_MAX)
+    {
+      mpcx_set_error("mpcx_cell_to_slaves: more than 2^31 links");
+      return -2;
+    }
+    c2s_offsets[c + 1] = static_cast<int32_t>(total);
+  }
+  return total;
+}
+
+// ---------------------------------------------------------------------------
+namespace
+{
+struct Pattern
+{
+  int32_t nrows = 0;
+  std::vector<int32_t> rowptr;
+  std::vector<int32_t> cols;
+};
+
+template <typename F>
+void parallel_ranges(int64_t n, int nthreads, F&& f)
+{
+  nthreads = std::max(1, nthreads);
+  if (nthreads == 1 || n < 4096)
+  {
+    f(0, int64_t(0), n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  for (int t = 0; t < nthreads; ++t)
+  {
+    const int64_t lo = n * t / nthreads, hi = n * (t + 1) / nthreads;
+    pool.emplace_back([&f, t, lo, hi]() { f(t, lo, hi); });
+  }
+  for (auto& th : pool)
+    th.join();
+}
+} // namespace
+
+extern "C" void* mpcx_pattern_build(int64_t num_cells, const int32_t* dofmap0, int32_t nd0,
+                                    int32_t bs0, int32_t num_blocks0, const int32_t* dofmap1,
+                                    int32_t nd1, int32_t bs1, int32_t num_blocks1,
+                                    const int32_t* c2s_offsets0, const int32_t* c2s0,
+                                    const int32_t* masters_offsets0, const int32_t* masters0,
+                                    const int32_t* c2s_offsets1, const int32_t* c2s1,
+                                    const int32_t* masters_offsets1, const int32_t* masters1,
+                                    int32_t num_threads)
+{
+  (void)num_blocks1;
+  // 1. row-block -> cells adjacency: every cell for each of its row blocks,
+  //    plus, for cells holding row slaves, every master block of those slaves
+  //    (the `flattened_masters` rows of cpp/utils.h:484-488).
+  std::vector<int64_t> adj_off(size_t(num_blocks0) + 1, 0);
+  for (int64_t c = 0; c < num_cells; ++c)
+  {
+    const int32_t* d = dofmap0 + c * nd0;
+    for (int i = 0; i < nd0; ++i)
+      ++adj_off[d[i] + 1];
+    for (int32_t p = c2s_offsets0[c]; p < c2s_offsets0[c + 1]; ++p)
+    {
+      const int32_t s = c2s0[p];
+      for (int32_t q = masters_offsets0[s]; q < masters_offsets0[s + 1]; ++q)
+        ++adj_off[masters0[q] / bs0 + 1];
+    }
+  }
+  for (int32_t r = 0; r < num_blocks0; ++r)
+    adj_off[r + 1] += adj_off[r];
+  const int64_t nadj = adj_off[num_blocks0];
+  if (nadj > INT32_MAX * int64_t(4))
+  {
+    mpcx_set_error("mpcx_pattern_build: adjacency too large");
+    return nullptr;
+  }
+  std::vector<int32_t> adj(nadj);
+  {
+    std::vector<int64_t> cur(adj_off.begin(), adj_off.end() - 1);
+    for (int64_t c = 0; c < num_cells; ++c)
+    {
+      const int32_t* d = dofmap0 + c * nd0;
+      for (int i = 0; i < nd0; ++i)
+        adj[cur[d[i]]++] = static_cast<int32_t>(c);
+      for (int32_t p = c2s_offsets0[c]; p < c2s_offsets0[c + 1]; ++p)
+      {
+        const int32_t s = c2s0[p];
+        for (int32_t q = masters_offsets0[s]; q < masters_offsets0[s + 1]; ++q)
+          adj[cur[masters0[q] / bs0]++] = static_cast<int32_t>(c);
+      }
+    }
+  }
+
+  // 2. per row block: union of the column sets of its cells
+  const int nt = std::max(1, num_threads);
+  std::vector<std::vector<int32_t>> tcols(nt);
+  std::vector<int32_t> row_count(size_t(num_blocks0), 0);
+  std::vector<int64_t> tlo(nt + 1, 0);
+  parallel_ranges(num_blocks0, nt,
+                  [&](int t, int64_t lo, int64_t hi)
+                  {
+                    tlo[t] = lo;
+                    std::vector<int32_t>& out = tcols[t];
+                    std::vector<int32_t> buf;
+                    for (int64_t r = lo; r < hi; ++r)
+                    {
+                      buf.clear();
+                      for (int64_t a = adj_off[r]; a < adj_off[r + 1]; ++a)
+                      {
+                        const int64_t c = adj[a];
+                        const int32_t* d = dofmap1 + c * nd1;
+                        buf.insert(buf.end(), d, d + nd1);
+                        for (int32_t p = c2s_offsets1[c]; p < c2s_offsets1[c + 1]; ++p)
+                        {
+                          const int32_t s = c2s1[p];
+                          for (int32_t q = masters_offsets1[s]; q < masters_offsets1[s + 1]; ++q)
+                            buf.push_back(masters1[q] / bs1);
+                        }
+                      }
+                      std::sort(buf.begin(), buf.end());
+                      buf.erase(std::unique(buf.begin(), buf.end()), buf.end());
+                      row_count[r] = static_cast<int32_t>(buf.size());
+                      out.insert(out.end(), buf.begin(), buf.end());
+                    }
+                  });
+  adj.clear();
+  adj.shrink_to_fit();
+
+  // 3. expand blocks to a scalar CSR
+  auto* P = new Pattern;
+  const int64_t nrows = int64_t(num_blocks0) * bs0;
+  if (nrows > INT32_MAX)
+  {
+    mpcx_set_error("mpcx_pattern_build: too many rows");
+    delete P;
+    return nullptr;
+  }
+  P->nrows = static_cast<int32_t>(nrows);
+  P->rowptr.resize(nrows + 1);
+  int64_t nnz = 0;
+  P->rowptr[0] = 0;
+  for (int32_t r = 0; r < num_blocks0; ++r)
+    for (int k = 0; k < bs0; ++k)
+    {
+      nnz += int64_t(row_count[r]) * bs1;
+      if (nnz > INT32_MAX)
+      {
+        mpcx_set_error("mpcx_pattern_build: nnz exceeds 2^31-1 (shard the mesh)");
+        delete P;
+        return nullptr;
+      }
+      P->rowptr[size_t(r) * bs0 + k + 1] = static_cast<int32_t>(nnz);
+    }
+  P->cols.resize(nnz);
+  // block-row start inside each thread's buffer
+  std::vector<int64_t> blk_start(size_t(num_blocks0) + 1, 0);
+  for (int32_t r = 0; r < num_blocks0; ++r)
+    blk_start[r + 1] = blk_start[r] + row_count[r];
+  // thread t's buffer starts at block row tlo[t]
+  parallel_ranges(num_blocks0, nt,
+                  [&](int t, int64_t lo, int64_t hi)
+                  {
+                    const std::vector<int32_t>& in = tcols[t];
+                    const int64_t base = blk_start[lo];
+                    for (int64_t r = lo; r < hi; ++r)
+                    {
+                      const int32_t* cb = in.data() + (blk_start[r] - base);
+                      const int32_t n = row_count[r];
+                      for (int k = 0; k < bs0; ++k)
+                      {
+                        int32_t* dst = P->cols.data() + P->rowptr[r * bs0 + k];
+                        for (int32_t j = 0; j < n; ++j)
+                          for (int l = 0; l < bs1; ++l)
+                            *dst++ = cb[j] * bs1 + l;
+                      }
+                    }
+                  });
+  return P;
+}
+
+extern "C" int64_t mpcx_pattern_nnz(void* p) { return static_cast<Pattern*>(p)->cols.size(); }
+extern "C" int32_t mpcx_pattern_nrows(void* p) { return static_cast<Pattern*>(p)->nrows; }
+extern "C" int mpcx_pattern_copy(void* p, int32_t* rowptr, int32_t* cols)
+{
+  auto* P = static_cast<Pattern*>(p);
+  std::memcpy(rowptr, P->rowptr.data(), P->rowptr.size() * sizeof(int32_t));
+  std::memcpy(cols, P->cols.data(), P->cols.size() * sizeof(int32_t));
+  return 0;
+}
+extern "C" void mpcx_pattern_free(void* p) { delete static_cast<Pattern*>(p); }
+
+// ---------------------------------------------------------------------------
+namespace
+{
+struct RowBlockPlan
+{
+  std::vector<int32_t> block_row0;
+  std::vector<int64_t> block_ent_off;
+  std::vector<int32_t> block_ents;
+};
+} // namespace
+
+extern "C" void* mpcx_rowblock_plan_build(int32_t nrows, const int32_t* rowptr, int32_t max_rows,
+                                          int32_t max_nnz, int64_t n_entities, int32_t estride,
+                                          const int32_t* entities0, const int32_t* dofmap0,
+                                          int32_t nd0, int32_t bs0, int32_t num_threads)
+{
+  (void)num_threads;
+  auto* P = new RowBlockPlan;
+  // greedy contiguous partition, boundaries on dof-block (bs0) multiples
+  P->block_row0.push_back(0);
+  int32_t r0 = 0;
+  while (r0 < nrows)
+  {
+    int32_t r1 = r0;
+    while (r1 < nrows)
+    {
+      const int32_t rn = std::min(r1 + bs0, nrows);
+      if (rn - r0 > max_rows || rowptr[rn] - rowptr[r0] > max_nnz)
+        break;
+      r1 = rn;
+    }
+    if (r1 == r0)
+    {
+      mpcx_set_error("mpcx_rowblock_plan_build: a single dof block exceeds the block capacity");
+      delete P;
+      return nullptr;
+    }
+    P->block_row0.push_back(r1);
+    r0 = r1;
+  }
+  const int32_t nb = static_cast<int32_t>(P->block_row0.size()) - 1;
+  // dof block -> row block
+  const int32_t ndb = nrows / bs0;
+  std::vector<int32_t> blk_of(ndb);
+  for (int32_t b = 0; b < nb; ++b)
+    for (int32_t r = P->block_row0[b] / bs0; r < P->block_row0[b + 1] / bs0; ++r)
+      blk_of[r] = b;
+  // count, then fill (entities ascending inside each block)
+  P->block_ent_off.assign(size_t(nb) + 1, 0);
+  int32_t seen[64];
+  if (nd0 > 64)
+  {
+    mpcx_set_error("mpcx_rowblock_plan_build: element too large");
+    delete P;
+    return nullptr;
+  }
+  for (int pass = 0; pass < 2; ++pass)
+  {
+    std::vector<int64_t> cur;
+    if (pass == 1)
+    {
+      for (int32_t b = 0; b < nb; ++b)
+        P->block_ent_off[b + 1] += P->block_ent_off[b];
+      P->block_ents.resize(P->block_ent_off[nb]);
+      cur.assign(P->block_ent_off.begin(), P->block_ent_off.end() - 1);
+    }
+    for (int64_t e = 0; e < n_entities; ++e)
+    {
+      const int64_t c = entities0[e * estride];
+      const int32_t* d = dofmap0 + c * nd0;
+      int ns = 0;
+      for (int i = 0; i < nd0; ++i)
+      {
+        const int32_t b = blk_of[d[i]];
+        bool dup = false;
+        for (int k = 0; k < ns; ++k)
+          dup |= (seen[k] == b);
+        if (!dup)
+        {
+          seen[ns++] = b;
+          if (pass == 0)
+            ++P->block_ent_off[b + 1];
+          else
+            P->block_ents[cur[b]++] = static_cast<int32_t>(e);
+        }
+      }
+    }
+  }
+  return P;
+}
+
+extern "C" int32_t mpcx_rowblock_plan_num_blocks(void* p)
+{
+  return static_cast<int32_t>(static_cast<RowBlockPlan*>(p)->block_row0.size()) - 1;
+}
+extern "C" int64_t mpcx_rowblock_plan_num_ents(void* p)
+{
+  return static_cast<int64_t>(static_cast<RowBlockPlan*>(p)->block_ents.size());
+}
+extern "C" int mpcx_rowblock_plan_copy(void* p, int32_t* block_row0, int64_t* block_ent_off,
+                                       int32_t* block_ents)
+{
+  auto* P = static_cast<RowBlockPlan*>(p);
+  std::memcpy(block_row0, P->block_row0.data(), P->block_row0.size() * sizeof(int32_t));
+  std::memcpy(block_ent_off, P->block_ent_off.data(), P->block_ent_off.size() * sizeof(int64_t));
+  std::memcpy(block_ents, P->block_ents.data(), P->block_ents.size() * sizeof(int32_t));
+  return 0;
+}
+extern "C" void mpcx_rowblock_plan_free(void* p) { delete static_cast<RowBlockPlan*>(p); }

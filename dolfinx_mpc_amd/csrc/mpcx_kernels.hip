@@ -1,0 +1,671 @@
+// HIP kernels (gfx950 / CDNA4) for constrained finite-element assembly.
+//
+// What the reference does serially per MPI rank -- cpp/assemble_matrix.cpp:488
+// (cells), :343 (exterior facets), cpp/assemble_vector.cpp:65,
+// cpp/lifting.h:77 -- is done here with one thread per integration entity:
+//   gather coordinates -> element tensor in VGPRs -> Dirichlet mask ->
+//   slave mask -> scatter-add into a pre-built CSR / vector.
+// The K^T A_e K elimination of cpp/assemble_matrix.cpp:99-268 is split the way
+// the reference's numba assembler splits it (numba/assemble_matrix.py:100):
+// the bulk kernel handles every entity with slave rows/cols masked out, and a
+// second kernel over the compact list of slave entities adds the master
+// row/column contributions.  All arithmetic is fp64; the path is HBM-bound
+// (no dense contraction), so there is no MFMA here.
+#include "mpcx.h"
+#include "mpcx_elements.hpp"
+#include "mpcx_internal.h"
+
+#include <hip/hip_runtime.h>
+#include <string>
+
+namespace mpcx
+{
+
+__device__ inline void atomic_add_f64(double* p, double v)
+{
+  // hardware global_atomic_add_f64 (device scope): rows may be touched from any XCD
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// position of `col` in the sorted row [lo, hi) of the CSR, or -1
+__device__ inline int csr_find(const int32_t* __restrict__ cols, int lo, int hi, int col)
+{
+  const int end = hi;
+  while (lo < hi)
+  {
+    const int mid = (lo + hi) >> 1;
+    if (cols[mid] < col)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return (lo < end && cols[lo] == col) ? lo : -1;
+}
+
+template <int NV>
+__device__ inline void gather_coords(const double* __restrict__ x, const int32_t* __restrict__ x_dofmap,
+                                     int64_t cell, double (&cd)[NV * 3])
+{
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+  {
+    const int64_t v = x_dofmap[cell * NV + i];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      cd[3 * i + k] = x[3 * v + k];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Bulk matrix kernel, atomic scatter.  cpp/assemble_matrix.cpp:488-547 with the
+// slave rows/cols of Ae zeroed (:165-178) for every entity.
+// ---------------------------------------------------------------------------
+template <class Op>
+__global__ void __launch_bounds__(256) matrix_atomic_kernel(mpcx_matrix_args_t a)
+{
+  constexpr int N = Op::N, ND = Op::ND, BS = Op::BS, NV = Op::NV;
+  const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= a.n_entities)
+    return;
+  const int64_t l = e * a.estride;
+  const int64_t cell = a.entities[l];
+  const int64_t cell0 = a.entities0[l];
+  const int64_t cell1 = a.entities1[l];
+  const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
+
+  double cd[NV * 3];
+  gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
+  double Ae[N * N];
+  Op::tabulate(Ae, a.coeffs ? a.coeffs + e * a.cstride : nullptr, a.constants, cd, lf, a.kernel);
+
+  int32_t rows[N], colsd[N];
+  bool rmask[N], cmask[N];
+#pragma unroll
+  for (int i = 0; i < ND; ++i)
+  {
+    const int32_t d0 = a.dofmap0[cell0 * ND + i];
+    const int32_t d1 = a.dofmap1[cell1 * ND + i];
+#pragma unroll
+    for (int k = 0; k < BS; ++k)
+    {
+      const int32_t r = d0 * BS + k, c = d1 * BS + k;
+      rows[i * BS + k] = r;
+      colsd[i * BS + k] = c;
+      rmask[i * BS + k] = (a.bc0 && a.bc0[r]) || a.mpc0.is_slave[r];
+      cmask[i * BS + k] = (a.bc1 && a.bc1[c]) || a.mpc1.is_slave[c];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+  {
+    if (rmask[i])
+      continue;
+    const int lo = a.rowptr[rows[i]], hi = a.rowptr[rows[i] + 1];
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+    {
+      if (cmask[j])
+        continue;
+      const int pos = csr_find(a.cols, lo, hi, colsd[j]);
+      if (pos >= 0)
+        atomic_add_f64(a.vals + pos, Ae[i * N + j]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Master contributions of slave entities: cpp/assemble_matrix.cpp:182-267.
+// One thread per slave entity; Ae is indexed dynamically (scratch), which is
+// fine for the <1 % of entities that reach this kernel.
+// ---------------------------------------------------------------------------
+template <class Op>
+__global__ void __launch_bounds__(64) matrix_mpc_kernel(mpcx_matrix_args_t a)
+{
+  constexpr int N = Op::N, ND = Op::ND, BS = Op::BS, NV = Op::NV;
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= a.n_slave_entities)
+    return;
+  const int64_t e = a.slave_entities[t];
+  const int64_t l = e * a.estride;
+  const int64_t cell = a.entities[l];
+  const int64_t cell0 = a.entities0[l];
+  const int64_t cell1 = a.entities1[l];
+  const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
+
+  double cd[NV * 3];
+  gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
+  double Ae[N * N];
+  Op::tabulate(Ae, a.coeffs ? a.coeffs + e * a.cstride : nullptr, a.constants, cd, lf, a.kernel);
+
+  int32_t rows[N], colsd[N];
+  bool rbc[N], cbc[N], rsl[N], csl[N];
+  for (int i = 0; i < ND; ++i)
+  {
+    const int32_t d0 = a.dofmap0[cell0 * ND + i];
+    const int32_t d1 = a.dofmap1[cell1 * ND + i];
+    for (int k = 0; k < BS; ++k)
+    {
+      const int32_t r = d0 * BS + k, c = d1 * BS + k;
+      rows[i * BS + k] = r;
+      colsd[i * BS + k] = c;
+      rbc[i * BS + k] = a.bc0 && a.bc0[r];
+      cbc[i * BS + k] = a.bc1 && a.bc1[c];
+      rsl[i * BS + k] = a.mpc0.is_slave[r];
+      csl[i * BS + k] = a.mpc1.is_slave[c];
+    }
+  }
+  // Dirichlet rows/cols are zeroed before the MPC modification (:510-533)
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j)
+      if (rbc[i] || cbc[j])
+        Ae[i * N + j] = 0.0;
+
+  // row masters (:214-246)
+  for (int p = 0; p < N; ++p)
+  {
+    if (!rsl[p])
+      continue;
+    for (int mi = a.mpc0.masters_offsets[rows[p]]; mi < a.mpc0.masters_offsets[rows[p] + 1]; ++mi)
+    {
+      const int32_t m = a.mpc0.masters[mi];
+      const double ci = a.mpc0.coeffs[mi];
+      const int lo = a.rowptr[m], hi = a.rowptr[m + 1];
+      for (int q = 0; q < N; ++q)
+      {
+        if (csl[q])
+        {
+          // master-master term uses the un-stripped original (:239-245)
+          for (int mj = a.mpc1.masters_offsets[colsd[q]]; mj < a.mpc1.masters_offsets[colsd[q] + 1]; ++mj)
+          {
+            const int pos = csr_find(a.cols, lo, hi, a.mpc1.masters[mj]);
+            if (pos >= 0)
+              atomic_add_f64(a.vals + pos, ci * a.mpc1.coeffs[mj] * Ae[p * N + q]);
+          }
+        }
+        else if (!cbc[q])
+        {
+          // stripped row: slave-slave entries removed (:226-236)
+          const int pos = csr_find(a.cols, lo, hi, colsd[q]);
+          if (pos >= 0)
+            atomic_add_f64(a.vals + pos, ci * Ae[p * N + q]);
+        }
+      }
+    }
+  }
+  // column masters (:251-267)
+  for (int q = 0; q < N; ++q)
+  {
+    if (!csl[q])
+      continue;
+    for (int mj = a.mpc1.masters_offsets[colsd[q]]; mj < a.mpc1.masters_offsets[colsd[q] + 1]; ++mj)
+    {
+      const int32_t m = a.mpc1.masters[mj];
+      const double cj = a.mpc1.coeffs[mj];
+      for (int p = 0; p < N; ++p)
+      {
+        if (rsl[p] || rbc[p])
+          continue;
+        const int pos = csr_find(a.cols, a.rowptr[rows[p]], a.rowptr[rows[p] + 1], m);
+        if (pos >= 0)
+          atomic_add_f64(a.vals + pos, cj * Ae[p * N + q]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Bulk matrix kernel, LDS-privatised row blocks.  One workgroup owns a
+// contiguous range of CSR rows: their values and column indices live in LDS,
+// every entity touching the block is evaluated (redundantly across blocks),
+// only rows inside the block are kept, and the finished values are written to
+// HBM once.  No device-scope atomics.
+// ---------------------------------------------------------------------------
+template <class Op>
+__global__ void __launch_bounds__(512) matrix_rowblock_kernel(mpcx_matrix_args_t a)
+{
+  constexpr int N = Op::N, ND = Op::ND, BS = Op::BS, NV = Op::NV;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int b = blockIdx.x;
+  const int r0 = a.plan.block_row0[b], r1 = a.plan.block_row0[b + 1];
+  const int nnz0 = a.rowptr[r0];
+  const int nnzb = a.rowptr[r1] - nnz0;
+  double* s_vals = reinterpret_cast<double*>(smem);
+  int32_t* s_cols = reinterpret_cast<int32_t*>(s_vals + a.plan.max_nnz);
+  int32_t* s_rowptr = s_cols + a.plan.max_nnz;
+
+  for (int i = threadIdx.x; i < nnzb; i += blockDim.x)
+  {
+    s_vals[i] = 0.0;
+    s_cols[i] = a.cols[nnz0 + i];
+  }
+  for (int i = threadIdx.x; i <= r1 - r0; i += blockDim.x)
+    s_rowptr[i] = a.rowptr[r0 + i] - nnz0;
+  __syncthreads();
+
+  const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  for (int64_t t = e0 + threadIdx.x; t < e1; t += blockDim.x)
+  {
+    const int64_t e = a.plan.block_ents[t];
+    const int64_t l = e * a.estride;
+    const int64_t cell = a.entities[l];
+    const int64_t cell0 = a.entities0[l];
+    const int64_t cell1 = a.entities1[l];
+    const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
+
+    double cd[NV * 3];
+    gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
+    double Ae[N * N];
+    Op::tabulate(Ae, a.coeffs ? a.coeffs + e * a.cstride : nullptr, a.constants, cd, lf, a.kernel);
+
+    int32_t rows[N], colsd[N];
+    bool rmask[N], cmask[N];
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+    {
+      const int32_t d0 = a.dofmap0[cell0 * ND + i];
+      const int32_t d1 = a.dofmap1[cell1 * ND + i];
+#pragma unroll
+      for (int k = 0; k < BS; ++k)
+      {
+        const int32_t r = d0 * BS + k, c = d1 * BS + k;
+        rows[i * BS + k] = r;
+        colsd[i * BS + k] = c;
+        rmask[i * BS + k] = r < r0 || r >= r1 || (a.bc0 && a.bc0[r]) || a.mpc0.is_slave[r];
+        cmask[i * BS + k] = (a.bc1 && a.bc1[c]) || a.mpc1.is_slave[c];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+    {
+      if (rmask[i])
+        continue;
+      const int lo = s_rowptr[rows[i] - r0], hi = s_rowptr[rows[i] - r0 + 1];
+#pragma unroll
+      for (int j = 0; j < N; ++j)
+      {
+        if (cmask[j])
+          continue;
+        const int pos = csr_find(s_cols, lo, hi, colsd[j]);
+        if (pos >= 0)
+          __hip_atomic_fetch_add(s_vals + pos, Ae[i * N + j], __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+  __syncthreads();
+  if (a.store_mode)
+    for (int i = threadIdx.x; i < nnzb; i += blockDim.x)
+      a.vals[nnz0 + i] = s_vals[i];
+  else
+    for (int i = threadIdx.x; i < nnzb; i += blockDim.x)
+      a.vals[nnz0 + i] += s_vals[i];
+}
+
+// ---------------------------------------------------------------------------
+__global__ void add_diagonal_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                    double* vals, const int32_t* __restrict__ dofs, int64_t n, double diagval)
+{
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const int32_t d = dofs[i];
+  const int pos = csr_find(cols, rowptr[d], rowptr[d + 1], d);
+  if (pos >= 0)
+    atomic_add_f64(vals + pos, diagval);
+}
+
+// ---------------------------------------------------------------------------
+// Vector kernel: cpp/assemble_vector.cpp:65-90 + modify_mpc_vec
+// (cpp/assemble_vector.h:35-69).
+// ---------------------------------------------------------------------------
+template <class Op>
+__global__ void __launch_bounds__(256) vector_kernel(mpcx_vector_args_t a)
+{
+  constexpr int N = Op::N, ND = Op::ND, BS = Op::BS, NV = Op::NV;
+  const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= a.n_entities)
+    return;
+  const int64_t l = e * a.estride;
+  const int64_t cell = a.entities[l];
+  const int64_t cell0 = a.entities0[l];
+  const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
+  double cd[NV * 3];
+  gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
+  double be[N];
+  Op::tabulate(be, a.coeffs ? a.coeffs + e * a.cstride : nullptr, a.constants, cd, lf, a.kernel);
+#pragma unroll
+  for (int i = 0; i < ND; ++i)
+  {
+    const int32_t d0 = a.dofmap[cell0 * ND + i];
+#pragma unroll
+    for (int k = 0; k < BS; ++k)
+    {
+      const int32_t d = d0 * BS + k;
+      double v = be[i * BS + k];
+      if (a.mpc.is_slave[d])
+      {
+        const int m0 = a.mpc.masters_offsets[d], m1 = a.mpc.masters_offsets[d + 1];
+        for (int mi = m0; mi < m1; ++mi)
+          atomic_add_f64(a.b + a.mpc.masters[mi], a.mpc.coeffs[mi] * v);
+        if (m1 > m0)
+          v = 0.0; // be[slave] is cleared inside the master loop (assemble_vector.h:65)
+      }
+      if (v != 0.0)
+        atomic_add_f64(a.b + d, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Lifting kernel: cpp/lifting.h:77-133 over the compact list of entities that
+// have a bc-marked column dof; Ae is the raw kernel output (:267-272).
+// ---------------------------------------------------------------------------
+template <class Op>
+__global__ void __launch_bounds__(256) lifting_kernel(mpcx_lifting_args_t a)
+{
+  constexpr int N = Op::N, ND = Op::ND, BS = Op::BS, NV = Op::NV;
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= a.n_lift_entities)
+    return;
+  const int64_t e = a.lift_entities[t];
+  const int64_t l = e * a.estride;
+  const int64_t cell = a.entities[l];
+  const int64_t cell0 = a.entities0[l];
+  const int64_t cell1 = a.entities1[l];
+  const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
+  double cd[NV * 3];
+  gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
+  double Ae[N * N];
+  Op::tabulate(Ae, a.coeffs ? a.coeffs + e * a.cstride : nullptr, a.constants, cd, lf, a.kernel);
+  double be[N];
+#pragma unroll
+  for (int m = 0; m < N; ++m)
+    be[m] = 0.0;
+#pragma unroll
+  for (int j = 0; j < ND; ++j)
+  {
+    const int32_t d1 = a.dofmap1[cell1 * ND + j];
+#pragma unroll
+    for (int k = 0; k < BS; ++k)
+    {
+      const int32_t jj = d1 * BS + k;
+      if (a.bc_markers1[jj])
+      {
+        const double g = a.scale * (a.bc_values1[jj] - (a.x0 ? a.x0[jj] : 0.0));
+#pragma unroll
+        for (int m = 0; m < N; ++m)
+          be[m] -= Ae[m * N + j * BS + k] * g;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < ND; ++i)
+  {
+    const int32_t d0 = a.dofmap0[cell0 * ND + i];
+#pragma unroll
+    for (int k = 0; k < BS; ++k)
+    {
+      const int32_t d = d0 * BS + k;
+      double v = be[i * BS + k];
+      if (a.mpc0.is_slave[d])
+      {
+        const int m0 = a.mpc0.masters_offsets[d], m1 = a.mpc0.masters_offsets[d + 1];
+        for (int mi = m0; mi < m1; ++mi)
+          atomic_add_f64(a.b + a.mpc0.masters[mi], a.mpc0.coeffs[mi] * v);
+        if (m1 > m0)
+          v = 0.0;
+      }
+      if (v != 0.0)
+        atomic_add_f64(a.b + d, v);
+    }
+  }
+}
+
+// cpp/MultiPointConstraint.h:129-145.  Slaves whose masters are themselves
+// slaves are not resolved (same as the reference's sequential loop only when
+// no master is a slave).
+__global__ void backsubstitution_kernel(double* u, const int32_t* __restrict__ slaves, int64_t n, mpcx_mpc_t mpc)
+{
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const int32_t s = slaves[i];
+  double v = 0.0;
+  for (int mi = mpc.masters_offsets[s]; mi < mpc.masters_offsets[s + 1]; ++mi)
+    v += mpc.coeffs[mi] * u[mpc.masters[mi]];
+  u[s] = v;
+}
+
+__global__ void homogenize_kernel(double* u, const int32_t* __restrict__ slaves, int64_t n)
+{
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n)
+    u[slaves[i]] = 0.0;
+}
+
+// ---------------------------------------------------------------------------
+// dispatch
+// ---------------------------------------------------------------------------
+inline int check(hipError_t err, const char* what)
+{
+  if (err != hipSuccess)
+  {
+    mpcx_set_error(std::string(what) + ": " + hipGetErrorString(err));
+    return -100;
+  }
+  return 0;
+}
+
+inline unsigned grid_for(int64_t n, int block) { return static_cast<unsigned>((n + block - 1) / block); }
+
+template <class Op>
+int launch_matrix(const mpcx_matrix_args_t& a)
+{
+  hipStream_t stream = static_cast<hipStream_t>(a.stream);
+  int alg = a.algorithm;
+  if (alg == MPCX_ALG_AUTO)
+    alg = a.plan.num_blocks > 0 ? MPCX_ALG_ROWBLOCK : MPCX_ALG_ATOMIC;
+  if (a.n_entities > 0)
+  {
+    if (alg == MPCX_ALG_ROWBLOCK)
+    {
+      if (a.plan.num_blocks <= 0)
+      {
+        mpcx_set_error("mpcx_assemble_matrix: row-block algorithm needs a plan");
+        return -3;
+      }
+      const size_t lds = size_t(a.plan.max_nnz) * 12 + size_t(a.plan.max_rows + 1) * 4;
+      if (lds > 160 * 1024)
+      {
+        mpcx_set_error("mpcx_assemble_matrix: row-block plan exceeds 160 KiB of LDS");
+        return -4;
+      }
+      if (int rc = check(hipFuncSetAttribute(reinterpret_cast<const void*>(matrix_rowblock_kernel<Op>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)),
+                         "hipFuncSetAttribute"))
+        return rc;
+      hipLaunchKernelGGL(matrix_rowblock_kernel<Op>, dim3(a.plan.num_blocks), dim3(512), lds, stream, a);
+    }
+    else
+    {
+      hipLaunchKernelGGL(matrix_atomic_kernel<Op>, dim3(grid_for(a.n_entities, 256)), dim3(256), 0, stream, a);
+    }
+    if (int rc = check(hipGetLastError(), "matrix kernel launch"))
+      return rc;
+  }
+  if (a.n_slave_entities > 0)
+  {
+    hipLaunchKernelGGL(matrix_mpc_kernel<Op>, dim3(grid_for(a.n_slave_entities, 64)), dim3(64), 0, stream, a);
+    if (int rc = check(hipGetLastError(), "matrix mpc kernel launch"))
+      return rc;
+  }
+  return 0;
+}
+
+template <class Op>
+int launch_vector(const mpcx_vector_args_t& a)
+{
+  if (a.n_entities == 0)
+    return 0;
+  hipLaunchKernelGGL(vector_kernel<Op>, dim3(grid_for(a.n_entities, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(a.stream), a);
+  return check(hipGetLastError(), "vector kernel launch");
+}
+
+template <class Op>
+int launch_lifting(const mpcx_lifting_args_t& a)
+{
+  if (a.n_lift_entities == 0)
+    return 0;
+  hipLaunchKernelGGL(lifting_kernel<Op>, dim3(grid_for(a.n_lift_entities, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(a.stream), a);
+  return check(hipGetLastError(), "lifting kernel launch");
+}
+
+// (cell, degree, bs) combinations compiled in
+#define MPCX_FOR_SPACES(X, FORM)                                                                   \
+  if (k.celltype == MPCX_CELL_TETRAHEDRON && k.degree == 1 && k.bs == 1)                           \
+    return X<ElementOp<3, 1, 1, FORM>>(a);                                                         \
+  if (k.celltype == MPCX_CELL_TETRAHEDRON && k.degree == 2 && k.bs == 1)                           \
+    return X<ElementOp<3, 2, 1, FORM>>(a);                                                         \
+  if (k.celltype == MPCX_CELL_TRIANGLE && k.degree == 1 && k.bs == 1)                              \
+    return X<ElementOp<2, 1, 1, FORM>>(a);                                                         \
+  if (k.celltype == MPCX_CELL_TRIANGLE && k.degree == 2 && k.bs == 1)                              \
+    return X<ElementOp<2, 2, 1, FORM>>(a);                                                         \
+  if (k.celltype == MPCX_CELL_TETRAHEDRON && k.degree == 1 && k.bs == 3)                           \
+    return X<ElementOp<3, 1, 3, FORM>>(a);                                                         \
+  if (k.celltype == MPCX_CELL_TRIANGLE && k.degree == 1 && k.bs == 2)                              \
+    return X<ElementOp<2, 1, 2, FORM>>(a);
+
+#define MPCX_FOR_VECTOR_SPACES(X, FORM)                                                            \
+  if (k.celltype == MPCX_CELL_TETRAHEDRON && k.degree == 1 && k.bs == 3)                           \
+    return X<ElementOp<3, 1, 3, FORM>>(a);                                                         \
+  if (k.celltype == MPCX_CELL_TRIANGLE && k.degree == 1 && k.bs == 2)                              \
+    return X<ElementOp<2, 1, 2, FORM>>(a);
+
+int unsupported(const mpcx_kernel_t& k)
+{
+  mpcx_set_error("unsupported element kernel: form " + std::to_string(k.form) + " celltype "
+                 + std::to_string(k.celltype) + " degree " + std::to_string(k.degree) + " bs "
+                 + std::to_string(k.bs));
+  return -10;
+}
+
+} // namespace mpcx
+
+using namespace mpcx;
+
+extern "C" int mpcx_assemble_matrix(const mpcx_matrix_args_t* args)
+{
+  const mpcx_matrix_args_t& a = *args;
+  const mpcx_kernel_t& k = a.kernel;
+  if (a.nd0 != a.nd1 || a.bs0 != a.bs1)
+  {
+    mpcx_set_error("mpcx_assemble_matrix: rectangular blocks not built in yet");
+    return -11;
+  }
+  switch (k.form)
+  {
+  case MPCX_FORM_STIFFNESS:
+    MPCX_FOR_SPACES(launch_matrix, MPCX_FORM_STIFFNESS)
+    break;
+  case MPCX_FORM_MASS:
+    MPCX_FOR_SPACES(launch_matrix, MPCX_FORM_MASS)
+    break;
+  case MPCX_FORM_FACET_MASS:
+    MPCX_FOR_SPACES(launch_matrix, MPCX_FORM_FACET_MASS)
+    break;
+  case MPCX_FORM_ELASTICITY:
+    MPCX_FOR_VECTOR_SPACES(launch_matrix, MPCX_FORM_ELASTICITY)
+    break;
+  default:
+    break;
+  }
+  return unsupported(k);
+}
+
+extern "C" int mpcx_assemble_vector(const mpcx_vector_args_t* args)
+{
+  const mpcx_vector_args_t& a = *args;
+  const mpcx_kernel_t& k = a.kernel;
+  switch (k.form)
+  {
+  case MPCX_FORM_SOURCE:
+    MPCX_FOR_SPACES(launch_vector, MPCX_FORM_SOURCE)
+    break;
+  case MPCX_FORM_FACET_SOURCE:
+    MPCX_FOR_SPACES(launch_vector, MPCX_FORM_FACET_SOURCE)
+    break;
+  default:
+    break;
+  }
+  return unsupported(k);
+}
+
+extern "C" int mpcx_apply_lifting(const mpcx_lifting_args_t* args)
+{
+  const mpcx_lifting_args_t& a = *args;
+  const mpcx_kernel_t& k = a.kernel;
+  if (a.nd0 != a.nd1 || a.bs0 != a.bs1)
+  {
+    mpcx_set_error("mpcx_apply_lifting: rectangular blocks not built in yet");
+    return -11;
+  }
+  switch (k.form)
+  {
+  case MPCX_FORM_STIFFNESS:
+    MPCX_FOR_SPACES(launch_lifting, MPCX_FORM_STIFFNESS)
+    break;
+  case MPCX_FORM_MASS:
+    MPCX_FOR_SPACES(launch_lifting, MPCX_FORM_MASS)
+    break;
+  case MPCX_FORM_FACET_MASS:
+    MPCX_FOR_SPACES(launch_lifting, MPCX_FORM_FACET_MASS)
+    break;
+  case MPCX_FORM_ELASTICITY:
+    MPCX_FOR_VECTOR_SPACES(launch_lifting, MPCX_FORM_ELASTICITY)
+    break;
+  default:
+    break;
+  }
+  return unsupported(k);
+}
+
+extern "C" int mpcx_add_diagonal(int32_t nrows, const int32_t* rowptr, const int32_t* cols,
+                                 double* vals, const int32_t* dofs, int64_t n, double diagval,
+                                 void* stream)
+{
+  (void)nrows;
+  if (n == 0)
+    return 0;
+  hipLaunchKernelGGL(add_diagonal_kernel, dim3(grid_for(n, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), rowptr, cols, vals, dofs, n, diagval);
+  return check(hipGetLastError(), "add_diagonal launch");
+}
+
+extern "C" int mpcx_backsubstitution(double* u, const int32_t* slaves, int64_t num_slaves,
+                                     const mpcx_mpc_t* mpc, void* stream)
+{
+  if (num_slaves == 0)
+    return 0;
+  hipLaunchKernelGGL(backsubstitution_kernel, dim3(grid_for(num_slaves, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), u, slaves, num_slaves, *mpc);
+  return check(hipGetLastError(), "backsubstitution launch");
+}
+
+extern "C" int mpcx_homogenize(double* u, const int32_t* slaves, int64_t num_slaves, void* stream)
+{
+  if (num_slaves == 0)
+    return 0;
+  hipLaunchKernelGGL(homogenize_kernel, dim3(grid_for(num_slaves, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), u, slaves, num_slaves);
+  return check(hipGetLastError(), "homogenize launch");
+}
+
+extern "C" int mpcx_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess)
+    return 0;
+  return n;
+}

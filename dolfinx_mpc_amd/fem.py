@@ -1,0 +1,322 @@
+"""Flat-array stand-ins for the DOLFINx objects the reference's hot path reads.
+
+``FunctionSpace``/``DofMap``/``IndexMap``/``DirichletBC``/``Form`` expose only
+what cpp/assemble_matrix.cpp, cpp/assemble_vector.cpp and cpp/lifting.h consume
+(``dofmap.cell_dofs``, ``index_map.size_local``, ``bs``, bc markers/values,
+integration domains, packed coefficients and constants).  Single process:
+``num_ghosts == 0`` and local == global numbering.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+
+from .mesh import Mesh
+from .quadrature import facet_cell_name, make_quadrature
+
+# form kinds (shared numbering with include/mpcx.h)
+FORM_STIFFNESS = 0
+FORM_MASS = 1
+FORM_SOURCE = 2
+FORM_ELASTICITY = 3
+FORM_FACET_MASS = 4
+FORM_FACET_SOURCE = 5
+
+CELL_TRIANGLE = 1
+CELL_TETRAHEDRON = 2
+_CELL_ID = {"triangle": CELL_TRIANGLE, "tetrahedron": CELL_TETRAHEDRON}
+
+# analytic right-hand sides (evaluated at physical quadrature points)
+FN_ONE = 0
+FN_BENCH_PERIODIC = 1  # python/benchmarks/bench_periodic.py:85-89
+FN_SIN2D = 2
+FN_POLY3 = 3
+FN_LINEAR = 4
+FN_CONSTANT_VEC = 5  # f = constants[1:1+bs] (constants[0] is the scale)
+
+_FN_DEGREE = {FN_ONE: 0, FN_BENCH_PERIODIC: 4, FN_SIN2D: 4, FN_POLY3: 3, FN_LINEAR: 1, FN_CONSTANT_VEC: 0}
+
+
+class IndexMap:
+    def __init__(self, size_local: int, num_ghosts: int = 0):
+        self.size_local = int(size_local)
+        self.num_ghosts = int(num_ghosts)
+        self.size_global = int(size_local)
+        self.local_range = (0, int(size_local))
+
+
+class DofMap:
+    def __init__(self, cell_dofs: np.ndarray, num_blocks: int, bs: int):
+        self.list = np.ascontiguousarray(cell_dofs, dtype=np.int32)  # (num_cells, nd) blocked dofs
+        self.index_map = IndexMap(num_blocks)
+        self.index_map_bs = int(bs)
+        self.bs = int(bs)
+
+    def cell_dofs(self, c: int) -> np.ndarray:
+        return self.list[c]
+
+
+def _lagrange_ndofs(cell_name: str, degree: int) -> int:
+    return {("tetrahedron", 1): 4, ("tetrahedron", 2): 10, ("triangle", 1): 3, ("triangle", 2): 6}[(cell_name, degree)]
+
+
+class FunctionSpace:
+    """Lagrange P1/P2 space, optionally blocked (``shape=(bs,)``)."""
+
+    def __init__(self, mesh: Mesh, element=("Lagrange", 1), shape: Optional[tuple] = None):
+        family, degree = element[0], int(element[1])
+        if family not in ("Lagrange", "CG", "P"):
+            raise NotImplementedError(f"element family {family}")
+        if degree not in (1, 2):
+            raise NotImplementedError("only Lagrange degree 1 and 2")
+        self.mesh = mesh
+        self.degree = degree
+        bs = 1 if not shape else int(shape[0])
+        if degree == 1:
+            cell_dofs = mesh.geometry.dofmap.copy()
+            nblocks = mesh.num_nodes
+        else:
+            cell_edges, _ = mesh.edges()
+            cell_dofs = np.concatenate([mesh.geometry.dofmap, cell_edges + mesh.num_nodes], axis=1)
+            nblocks = mesh.num_nodes + int(cell_edges.max()) + 1
+        self.dofmap = DofMap(cell_dofs, nblocks, bs)
+        self._dof_coords = None
+        self._device = {}
+
+    @property
+    def element_ndofs(self) -> int:
+        return self.dofmap.list.shape[1]
+
+    @property
+    def num_dofs(self) -> int:
+        """unrolled local (+ghost) dofs"""
+        m = self.dofmap.index_map
+        return (m.size_local + m.num_ghosts) * self.dofmap.index_map_bs
+
+    def tabulate_dof_coordinates(self) -> np.ndarray:
+        if self._dof_coords is None:
+            x = self.mesh.geometry.x
+            if self.degree == 1:
+                self._dof_coords = x
+            else:
+                _, ev = self.mesh.edges()
+                self._dof_coords = np.concatenate([x, 0.5 * (x[ev[:, 0]] + x[ev[:, 1]])], axis=0)
+        return self._dof_coords
+
+    def contains(self, other: "FunctionSpace") -> bool:
+        return other is self
+
+
+def functionspace(mesh: Mesh, element, shape: Optional[tuple] = None) -> FunctionSpace:
+    if len(element) == 3 and shape is None:
+        shape = element[2]
+    return FunctionSpace(mesh, element[:2], shape)
+
+
+class _Vector:
+    def __init__(self, n: int):
+        self.array = np.zeros(n, dtype=np.float64)
+
+
+class Function:
+    """Nodal coefficient (packed per cell like dolfinx ``pack_coefficients``,
+    cpp/assemble_matrix.cpp:587-589)."""
+
+    def __init__(self, V: FunctionSpace):
+        self.function_space = V
+        self.x = _Vector(V.num_dofs)
+
+    def interpolate(self, f: Callable[[np.ndarray], np.ndarray]):
+        V = self.function_space
+        vals = np.asarray(f(V.tabulate_dof_coordinates().T), dtype=np.float64)
+        bs = V.dofmap.bs
+        if bs == 1:
+            self.x.array[:] = vals.reshape(-1)
+        else:
+            self.x.array[:] = vals.reshape(bs, -1).T.reshape(-1)
+
+
+class DirichletBC:
+    """Dirichlet condition on blocked dofs (all components, or one ``component``).
+
+    Provides what cpp/assemble_matrix.cpp:688-705 and cpp/lifting.h:166-180 use:
+    ``mark_dofs`` and ``set``.
+    """
+
+    def __init__(self, value, dofs: np.ndarray, V: FunctionSpace, component: Optional[int] = None):
+        self.function_space = V
+        bs = V.dofmap.bs
+        dofs = np.asarray(dofs, dtype=np.int32).reshape(-1)
+        if component is None:
+            self._dofs = (dofs[:, None] * bs + np.arange(bs, dtype=np.int32)[None, :]).reshape(-1)
+        else:
+            self._dofs = dofs * bs + int(component)
+        self._dofs = np.ascontiguousarray(self._dofs, dtype=np.int32)
+        self.value = value
+
+    def dof_indices(self):
+        return self._dofs, self._dofs.size
+
+    def mark_dofs(self, markers: np.ndarray):
+        markers[self._dofs] = 1
+
+    def set(self, values: np.ndarray, x0=None, alpha: float = 1.0):
+        v = self.value
+        if isinstance(v, Function):
+            g = v.x.array[self._dofs]
+        else:
+            v = np.asarray(v, dtype=np.float64)
+            if v.ndim == 0:
+                g = np.full(self._dofs.size, float(v))
+            else:
+                bs = self.function_space.dofmap.bs
+                g = v.reshape(-1)[self._dofs % bs] if v.size == bs else v.reshape(-1)[self._dofs]
+        values[self._dofs] = alpha * g
+
+
+def dirichletbc(value, dofs, V: FunctionSpace, component: Optional[int] = None) -> DirichletBC:
+    return DirichletBC(value, dofs, V, component)
+
+
+def locate_dofs_geometrical(V: FunctionSpace, marker: Callable[[np.ndarray], np.ndarray]) -> np.ndarray:
+    """Blocked dofs whose coordinate satisfies ``marker(x)``, x of shape (3, n)
+    (python/benchmarks/bench_periodic.py:57)."""
+    x = V.tabulate_dof_coordinates()
+    return np.flatnonzero(np.asarray(marker(x.T), dtype=bool)).astype(np.int32)
+
+
+@dataclass
+class KernelSpec:
+    """Description of one element kernel (stands in for an FFCx ``tabulate_tensor``)."""
+
+    form: int
+    celltype: int
+    degree: int
+    bs: int
+    fn_id: int = 0
+    coeff_degree: int = 0
+    qpts: np.ndarray = field(default_factory=lambda: np.zeros((0, 3)))
+    qwts: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    fqpts: np.ndarray = field(default_factory=lambda: np.zeros((0, 2)))
+    fqwts: np.ndarray = field(default_factory=lambda: np.zeros(0))
+
+
+@dataclass
+class Integral:
+    itype: str  # "cell" | "exterior_facet"
+    entities: np.ndarray  # cells int32[n] or (cell, local_facet) int32[n, 2]
+    kernel: KernelSpec
+    coeffs: Optional[np.ndarray] = None  # float64[n, cstride]
+    constants: Optional[np.ndarray] = None
+
+    @property
+    def estride(self) -> int:
+        return 1 if self.itype == "cell" else 2
+
+    @property
+    def num_entities(self) -> int:
+        return self.entities.shape[0]
+
+    @property
+    def cells(self) -> np.ndarray:
+        return self.entities if self.itype == "cell" else self.entities[:, 0]
+
+
+class Form:
+    """Compiled-form stand-in: ``rank``, ``function_spaces``, integrals."""
+
+    def __init__(self, function_spaces: Sequence[FunctionSpace], integrals: Sequence[Integral]):
+        self.function_spaces = list(function_spaces)
+        self.rank = len(self.function_spaces)
+        self.integrals = list(integrals)
+        self.mesh = self.function_spaces[0].mesh
+        self._device = {}
+
+    def __add__(self, other: "Form") -> "Form":
+        assert self.rank == other.rank
+        for a, b in zip(self.function_spaces, other.function_spaces):
+            assert a is b
+        return Form(self.function_spaces, self.integrals + other.integrals)
+
+
+def _pack_coefficient(coefficient: Optional[Function], cells: np.ndarray):
+    if coefficient is None:
+        return None, 0
+    Vc = coefficient.function_space
+    assert Vc.dofmap.bs == 1, "only scalar coefficients"
+    return np.ascontiguousarray(coefficient.x.array[Vc.dofmap.list[cells]]), Vc.degree
+
+
+def _cells_or_all(mesh: Mesh, cells) -> np.ndarray:
+    if cells is None:
+        return np.arange(mesh.num_cells, dtype=np.int32)
+    return np.ascontiguousarray(cells, dtype=np.int32)
+
+
+def _constants(c):
+    return None if c is None else np.atleast_1d(np.asarray(c, dtype=np.float64)).copy()
+
+
+def _cell_kernel(V: FunctionSpace, form: int, qdeg: int, fn_id: int = 0, coeff_degree: int = 0) -> KernelSpec:
+    name = V.mesh.cell_name
+    q, w = make_quadrature(name, qdeg)
+    return KernelSpec(form, _CELL_ID[name], V.degree, V.dofmap.bs, fn_id, coeff_degree, q, w)
+
+
+def _facet_kernel(V: FunctionSpace, form: int, qdeg: int, fn_id: int = 0) -> KernelSpec:
+    name = V.mesh.cell_name
+    q, w = make_quadrature(facet_cell_name(name), qdeg)
+    return KernelSpec(form, _CELL_ID[name], V.degree, V.dofmap.bs, fn_id, 0, fqpts=q, fqwts=w)
+
+
+def form_stiffness(V, constant=None, coefficient: Optional[Function] = None, cells=None) -> Form:
+    """a(u, v) = c * w * inner(grad(u), grad(v)) dx  (bench_periodic.py:84;
+    test_mpc_pipeline.py:45 with coefficient and constant)."""
+    cells = _cells_or_all(V.mesh, cells)
+    w, cd = _pack_coefficient(coefficient, cells)
+    k = _cell_kernel(V, FORM_STIFFNESS, 2 * (V.degree - 1) + cd, coeff_degree=cd)
+    return Form([V, V], [Integral("cell", cells, k, w, _constants(constant))])
+
+
+def form_mass(V, constant=None, coefficient: Optional[Function] = None, cells=None) -> Form:
+    cells = _cells_or_all(V.mesh, cells)
+    w, cd = _pack_coefficient(coefficient, cells)
+    k = _cell_kernel(V, FORM_MASS, 2 * V.degree + cd, coeff_degree=cd)
+    return Form([V, V], [Integral("cell", cells, k, w, _constants(constant))])
+
+
+def form_elasticity(V, mu: float, lmbda: float, cells=None) -> Form:
+    """a(u, v) = inner(sigma(u), grad(v)) dx, sigma = 2 mu eps(u) + lambda tr(eps(u)) I
+    (python/benchmarks/bench_contact_3D.py:257-269)."""
+    assert V.dofmap.bs == V.mesh.tdim
+    cells = _cells_or_all(V.mesh, cells)
+    k = _cell_kernel(V, FORM_ELASTICITY, 2 * (V.degree - 1))
+    return Form([V, V], [Integral("cell", cells, k, None, np.array([mu, lmbda], dtype=np.float64))])
+
+
+def form_source(V, fn_id: int = FN_ONE, constant=None, coefficient: Optional[Function] = None, cells=None,
+                quadrature_degree: Optional[int] = None) -> Form:
+    """L(v) = c * w * inner(f, v) dx with analytic f (bench_periodic.py:85-91).
+    Non-polynomial f: estimated degree +2 per UFL's rule -> P1: 5."""
+    cells = _cells_or_all(V.mesh, cells)
+    w, cd = _pack_coefficient(coefficient, cells)
+    fdeg = _FN_DEGREE[fn_id]
+    qdeg = V.degree + fdeg + cd if quadrature_degree is None else quadrature_degree
+    k = _cell_kernel(V, FORM_SOURCE, qdeg, fn_id, cd)
+    return Form([V], [Integral("cell", cells, k, w, _constants(constant))])
+
+
+def form_facet_mass(V, facets: np.ndarray, constant=None) -> Form:
+    """a(u, v) = c * inner(u, v) ds over the given exterior facets."""
+    k = _facet_kernel(V, FORM_FACET_MASS, 2 * V.degree)
+    return Form([V, V], [Integral("exterior_facet", np.ascontiguousarray(facets, dtype=np.int32), k, None, _constants(constant))])
+
+
+def form_facet_source(V, facets: np.ndarray, fn_id: int = FN_ONE, constant=None) -> Form:
+    """L(v) = c * inner(f, v) ds (python/tests/test_surface_integral.py:64-66 traction term)."""
+    fdeg = _FN_DEGREE[fn_id]
+    k = _facet_kernel(V, FORM_FACET_SOURCE, V.degree + fdeg, fn_id)
+    return Form([V], [Integral("exterior_facet", np.ascontiguousarray(facets, dtype=np.int32), k, None, _constants(constant))])

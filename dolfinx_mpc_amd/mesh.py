@@ -1,0 +1,173 @@
+"""Structured simplicial meshes as flat arrays.
+
+The reference receives these arrays from DOLFINx (``mesh.geometry.x``,
+``mesh.geometry.dofmaps[0]``; read at cpp/assemble_matrix.cpp:465-470 and
+python/src/dolfinx_mpc/numba/assemble_matrix.py:85-86).  DOLFINx is not
+available here, so the generators below define our own connectivity and
+numbering; geometry is always stored with 3 components
+per node (cpp/assemble_matrix.cpp:473, 499).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+# local facets: facet i is opposite vertex i (Basix/UFC convention)
+TET_FACETS = np.array([[1, 2, 3], [0, 2, 3], [0, 1, 3], [0, 1, 2]], dtype=np.int32)
+TRI_FACETS = np.array([[1, 2], [0, 2], [0, 1]], dtype=np.int32)
+# local edges
+TET_EDGES = np.array([[2, 3], [1, 3], [1, 2], [0, 3], [0, 2], [0, 1]], dtype=np.int32)
+TRI_EDGES = np.array([[1, 2], [0, 2], [0, 1]], dtype=np.int32)
+
+# Kuhn split of the unit cube into 6 tets sharing the diagonal v0-v7;
+# cube corner b has bit0 = x, bit1 = y, bit2 = z.
+_KUHN = np.array(
+    [[0, 1, 3, 7], [0, 1, 7, 5], [0, 5, 7, 4], [0, 3, 2, 7], [0, 6, 4, 7], [0, 2, 6, 7]], dtype=np.int64
+)
+
+
+@dataclass
+class Geometry:
+    x: np.ndarray  # (num_nodes, 3) float64
+    dofmap: np.ndarray  # (num_cells, nv) int32
+
+
+class Mesh:
+    """Single-process mesh: affine simplices, one geometry dofmap."""
+
+    def __init__(self, x: np.ndarray, cells: np.ndarray, cell_name: str):
+        assert cell_name in ("triangle", "tetrahedron")
+        self.geometry = Geometry(np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(cells, dtype=np.int32))
+        self.cell_name = cell_name
+        self.tdim = 3 if cell_name == "tetrahedron" else 2
+        self._exterior_facets = None
+        self._edges = None
+        self._device = {}
+
+    @property
+    def num_cells(self) -> int:
+        return self.geometry.dofmap.shape[0]
+
+    @property
+    def num_nodes(self) -> int:
+        return self.geometry.x.shape[0]
+
+    # -- topology helpers (small meshes only) -------------------------------
+    def exterior_facets(self) -> np.ndarray:
+        """(cell, local_facet) pairs of all boundary facets, stride-2 layout of
+        the reference's exterior-facet domains (cpp/assemble_matrix.cpp:343-348)."""
+        if self._exterior_facets is None:
+            cells = self.geometry.dofmap.astype(np.int64)
+            lf = TET_FACETS if self.tdim == 3 else TRI_FACETS
+            nc, nf = cells.shape[0], lf.shape[0]
+            fv = np.sort(cells[:, lf], axis=2).reshape(nc * nf, -1)  # (nc*nf, tdim)
+            nn = self.num_nodes
+            key = fv[:, 0]
+            for k in range(1, fv.shape[1]):
+                key = key * nn + fv[:, k]
+            _, inv, cnt = np.unique(key, return_inverse=True, return_counts=True)
+            ext = np.flatnonzero(cnt[inv] == 1)
+            out = np.empty((ext.size, 2), dtype=np.int32)
+            out[:, 0] = ext // nf
+            out[:, 1] = ext % nf
+            self._exterior_facets = out
+        return self._exterior_facets
+
+    def facet_midpoints(self, facets: np.ndarray) -> np.ndarray:
+        lf = TET_FACETS if self.tdim == 3 else TRI_FACETS
+        verts = self.geometry.dofmap[facets[:, 0]][np.arange(facets.shape[0])[:, None], lf[facets[:, 1]]]
+        return self.geometry.x[verts].mean(axis=1)
+
+    def locate_exterior_facets(self, marker) -> np.ndarray:
+        """Boundary facets whose midpoint satisfies ``marker(x)`` (x is (3, n))."""
+        f = self.exterior_facets()
+        mid = self.facet_midpoints(f)
+        return np.ascontiguousarray(f[np.asarray(marker(mid.T), dtype=bool)])
+
+    def edges(self):
+        """Global edge numbering: returns (cell_edges (nc, ne) int32, edge_vertices (nE, 2))."""
+        if self._edges is None:
+            cells = self.geometry.dofmap.astype(np.int64)
+            le = TET_EDGES if self.tdim == 3 else TRI_EDGES
+            ev = np.sort(cells[:, le], axis=2).reshape(-1, 2)
+            key = ev[:, 0] * self.num_nodes + ev[:, 1]
+            uniq, inv = np.unique(key, return_inverse=True)
+            edge_vertices = np.stack([uniq // self.num_nodes, uniq % self.num_nodes], axis=1)
+            self._edges = (inv.reshape(cells.shape[0], le.shape[0]).astype(np.int32), edge_vertices)
+        return self._edges
+
+
+def _tile_permutation(n1: tuple, tile: tuple) -> np.ndarray:
+    """old node index -> new node index, numbering nodes tile by tile
+    (x fastest inside a tile, tiles x fastest)."""
+    nx1, ny1, nz1 = n1
+    tx, ty, tz = tile
+    k, j, i = np.meshgrid(np.arange(nz1), np.arange(ny1), np.arange(nx1), indexing="ij")
+    ntx, nty = -(-nx1 // tx), -(-ny1 // ty)
+    tid = ((k // tz) * nty + (j // ty)) * ntx + (i // tx)
+    loc = ((k % tz) * ty + (j % ty)) * tx + (i % tx)
+    key = tid.astype(np.int64) * (tx * ty * tz) + loc
+    order = np.argsort(key.ravel(), kind="stable")  # new -> old
+    perm = np.empty_like(order)
+    perm[order] = np.arange(order.size)
+    return perm  # old -> new
+
+
+def create_box(p0, p1, n, cell_type: str = "tetrahedron", reorder: tuple | None = None) -> Mesh:
+    """Box mesh of ``n = (nx, ny, nz)`` cubes, each split into 6 tets.
+
+    Node index ``(k*(ny+1) + j)*(nx+1) + i`` (x fastest); cells follow cube
+    order (x fastest), 6 consecutive tets per cube.  ``reorder=(tx,ty,tz)``
+    renumbers nodes and cells tile by tile (DOLFINx also reorders for locality;
+    numbering is not part of the reference's contract).
+    """
+    assert cell_type == "tetrahedron"
+    nx, ny, nz = n
+    xs = np.linspace(p0[0], p1[0], nx + 1)
+    ys = np.linspace(p0[1], p1[1], ny + 1)
+    zs = np.linspace(p0[2], p1[2], nz + 1)
+    Z, Y, X = np.meshgrid(zs, ys, xs, indexing="ij")
+    x = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    base = ((k * (ny + 1) + j) * (nx + 1) + i).ravel().astype(np.int64)
+    corner = np.empty((base.size, 8), dtype=np.int64)
+    for b in range(8):
+        corner[:, b] = base + (b & 1) + ((b >> 1) & 1) * (nx + 1) + ((b >> 2) & 1) * (nx + 1) * (ny + 1)
+    cells = corner[:, _KUHN].reshape(-1, 4)
+    if reorder is not None:
+        perm = _tile_permutation((nx + 1, ny + 1, nz + 1), reorder)
+        xn = np.empty_like(x)
+        xn[perm] = x
+        x = xn
+        cells = perm[cells]
+        # cells tile by tile as well (tile of the cube's lower corner)
+        cperm = _tile_permutation((nx, ny, nz), reorder)  # old cube -> new cube
+        order = np.argsort(cperm, kind="stable")  # new cube -> old cube
+        cells = cells.reshape(-1, 6, 4)[order].reshape(-1, 4)
+    return Mesh(x, cells.astype(np.int32), "tetrahedron")
+
+
+def create_unit_cube(nx: int, ny: int, nz: int, cell_type: str = "tetrahedron", reorder=None) -> Mesh:
+    """python/benchmarks/bench_periodic.py:43 ``create_unit_cube(comm, N, N, N, ct)``."""
+    return create_box((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), (nx, ny, nz), cell_type, reorder)
+
+
+def create_rectangle(p0, p1, n, cell_type: str = "triangle") -> Mesh:
+    assert cell_type == "triangle"
+    nx, ny = n
+    xs = np.linspace(p0[0], p1[0], nx + 1)
+    ys = np.linspace(p0[1], p1[1], ny + 1)
+    Y, X = np.meshgrid(ys, xs, indexing="ij")
+    x = np.stack([X.ravel(), Y.ravel(), np.zeros(X.size)], axis=1)
+    j, i = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
+    v0 = (j * (nx + 1) + i).ravel().astype(np.int64)
+    v1, v2, v3 = v0 + 1, v0 + nx + 1, v0 + nx + 2
+    cells = np.stack([np.stack([v0, v1, v3], axis=1), np.stack([v0, v3, v2], axis=1)], axis=1).reshape(-1, 3)
+    return Mesh(x, cells.astype(np.int32), "triangle")
+
+
+def create_unit_square(nx: int, ny: int, cell_type: str = "triangle") -> Mesh:
+    """python/tests/test_matrix_assembly.py:30 ``create_unit_square(comm, 5, 3, ct)``."""
+    return create_rectangle((0.0, 0.0), (1.0, 1.0), (nx, ny), cell_type)

@@ -1,0 +1,332 @@
+"""``MultiPointConstraint`` with the reference's API surface
+(python/src/dolfinx_mpc/multipointconstraint.py:87-631), backed by flat arrays.
+
+``finalize()`` produces what cpp/MultiPointConstraint.h:36-126 produces
+(``is_slave``, sorted ``slaves``, slave->masters/coeffs/owners adjacency over
+all local dofs, ``cell_to_slaves``) through the native host routines
+``mpcx_mpc_finalize`` / ``mpcx_cell_to_slaves``; device mirrors are created
+lazily for the HIP kernels.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _native
+from .fem import DirichletBC, FunctionSpace
+
+
+class AdjacencyList:
+    """Minimal ``dolfinx.graph.AdjacencyList``: ``array``, ``offsets``, ``links``."""
+
+    def __init__(self, array: np.ndarray, offsets: np.ndarray):
+        self.array = array
+        self.offsets = offsets
+
+    @property
+    def num_nodes(self) -> int:
+        return self.offsets.size - 1
+
+    def links(self, i: int) -> np.ndarray:
+        return self.array[self.offsets[i] : self.offsets[i + 1]]
+
+    def num_links(self, i: int) -> int:
+        return int(self.offsets[i + 1] - self.offsets[i])
+
+
+class MPCData:
+    """python/src/dolfinx_mpc/multipointconstraint.py:44-84"""
+
+    def __init__(self, slaves, masters, coeffs, owners, offsets):
+        self.slaves = np.asarray(slaves, dtype=np.int32)
+        self.masters = np.asarray(masters, dtype=np.int64)
+        self.coeffs = np.asarray(coeffs)
+        self.owners = np.asarray(owners, dtype=np.int32)
+        self.offsets = np.asarray(offsets, dtype=np.int32)
+
+
+class MultiPointConstraint:
+    """Hold data for multi point constraint relationships.
+
+    Args:
+        V: The function space
+        dtype: scalar type; only float64 is built into the HIP backend
+    """
+
+    def __init__(self, V: FunctionSpace, dtype=np.float64):
+        if np.dtype(dtype) != np.float64:
+            raise NotImplementedError("the HIP backend is built for float64 only")
+        self._slaves = np.array([], dtype=np.int32)
+        self._masters = np.array([], dtype=np.int64)
+        self._coeffs = np.array([], dtype=dtype)
+        self._owners = np.array([], dtype=np.int32)
+        self._offsets = np.array([0], dtype=np.int32)
+        self.V = V
+        self.finalized = False
+        self._dtype = dtype
+        self._dev = None
+        self._cache = {}
+
+    # -- building -------------------------------------------------------------
+    def add_constraint(self, V: FunctionSpace, slaves, masters, coeffs, owners, offsets):
+        """Add constraint given by numpy arrays
+        (python/src/dolfinx_mpc/multipointconstraint.py:118-153): local slave
+        dofs, global master dofs, coefficients, owners, offsets."""
+        assert V is self.V
+        self._already_finalized()
+        slaves = np.asarray(slaves, dtype=np.int32)
+        if len(slaves) > 0:
+            offsets = np.asarray(offsets, dtype=np.int32)
+            self._offsets = np.append(self._offsets, offsets[1:] + len(self._masters)).astype(np.int32)
+            self._slaves = np.append(self._slaves, slaves).astype(np.int32)
+            self._masters = np.append(self._masters, np.asarray(masters, dtype=np.int64)).astype(np.int64)
+            self._coeffs = np.array(np.append(self._coeffs, coeffs), dtype=self._dtype)
+            self._owners = np.append(self._owners, np.asarray(owners, dtype=np.int32)).astype(np.int32)
+
+    def add_constraint_from_mpc_data(self, V: FunctionSpace, mpc_data: MPCData):
+        self._already_finalized()
+        self.add_constraint(V, mpc_data.slaves, mpc_data.masters, mpc_data.coeffs, mpc_data.owners, mpc_data.offsets)
+
+    def finalize(self) -> None:
+        """Finalize the constraint (python/src/dolfinx_mpc/multipointconstraint.py:169-223)."""
+        self._already_finalized()
+        L = _native.lib()
+        V = self.V
+        nd = V.num_dofs
+        imap = V.dofmap.index_map
+        nowned = imap.size_local * V.dofmap.index_map_bs
+        ns = self._slaves.size
+        nm = self._masters.size
+        slaves = np.ascontiguousarray(self._slaves, dtype=np.int32)
+        masters = np.ascontiguousarray(self._masters, dtype=np.int64)
+        coeffs = np.ascontiguousarray(self._coeffs, dtype=np.float64)
+        owners = np.ascontiguousarray(self._owners, dtype=np.int32)
+        offsets = np.ascontiguousarray(self._offsets, dtype=np.int32)
+        assert offsets.size == ns + 1 and offsets[-1] == nm and coeffs.size == nm and owners.size == nm
+        is_slave = np.zeros(nd, dtype=np.int8)
+        sorted_slaves = np.zeros(ns, dtype=np.int32)
+        nloc = C.c_int32(0)
+        moff = np.zeros(nd + 1, dtype=np.int32)
+        mloc = np.zeros(nm, dtype=np.int32)
+        cout = np.zeros(nm, dtype=np.float64)
+        oout = np.zeros(nm, dtype=np.int32)
+        p = _native._ptr
+        rc = L.mpcx_mpc_finalize(nd, nowned, ns, p(slaves), p(masters), p(coeffs), p(owners), p(offsets),
+                                 p(is_slave), p(sorted_slaves), C.cast(C.byref(nloc), C.c_void_p), p(moff),
+                                 p(mloc), p(cout), p(oout))
+        _native.check(rc, "mpcx_mpc_finalize")
+        # duplicates in the user's slave list collapse in the marker
+        nuniq = int(is_slave.sum())
+        self._is_slave = is_slave
+        self._sorted_slaves = sorted_slaves[:nuniq].copy()
+        self._num_local_slaves = int(nloc.value)
+        self._master_map = AdjacencyList(mloc, moff)
+        self._coeff_map = AdjacencyList(cout, moff)
+        self._owner_map = AdjacencyList(oout, moff)
+        # cell -> slaves (owned cells)
+        dm = V.dofmap.list
+        nc = dm.shape[0]
+        c2s_off = np.zeros(nc + 1, dtype=np.int32)
+        total = L.mpcx_cell_to_slaves(nc, dm.shape[1], V.dofmap.bs, p(dm), p(is_slave), p(c2s_off), None)
+        if total < 0:
+            _native.check(int(total), "mpcx_cell_to_slaves")
+        c2s = np.zeros(int(total), dtype=np.int32)
+        total = L.mpcx_cell_to_slaves(nc, dm.shape[1], V.dofmap.bs, p(dm), p(is_slave), p(c2s_off), p(c2s))
+        self._cell_to_slaves = AdjacencyList(c2s, c2s_off)
+        # single process: the extended function space is V itself
+        # (cpp/mpc_helpers.h:165-168)
+        self.finalized = True
+        del (self._slaves, self._masters, self._coeffs, self._owners, self._offsets)
+
+    # -- convenience builders (structured / matching meshes only) --------------
+    def create_periodic_constraint_geometrical(
+        self,
+        V: FunctionSpace,
+        indicator: Callable[[np.ndarray], np.ndarray],
+        relation: Callable[[np.ndarray], np.ndarray],
+        bcs: Sequence[DirichletBC],
+        scale: float = 1.0,
+        tol: float = 1e-8,
+    ):
+        """u(x_i) = scale * u(relation(x_i)) for dofs with indicator(x_i)
+        (python/src/dolfinx_mpc/multipointconstraint.py:282-340).  The general
+        builder (cpp/PeriodicConstraint.h) does point location and basis
+        evaluation; this backend only handles meshes whose mapped slave nodes
+        coincide with master nodes (one master, coefficient ``scale``)."""
+        from scipy.spatial import cKDTree
+
+        assert V is self.V
+        x = V.tabulate_dof_coordinates()
+        bs = V.dofmap.bs
+        blocks = np.flatnonzero(np.asarray(indicator(x.T), dtype=bool))
+        is_bc = np.zeros(V.num_dofs, dtype=np.int8)
+        for bc in bcs:
+            bc.mark_dofs(is_bc)
+        xm = np.asarray(relation(x[blocks].T)).T
+        dist, mblk = cKDTree(x).query(xm)
+        if blocks.size and dist.max() > tol:
+            raise NotImplementedError(
+                "periodic constraint on non-matching nodes needs basis evaluation at the mapped "
+                "point (cpp/PeriodicConstraint.h:170-222): out of scope of this backend"
+            )
+        slaves = (blocks[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)
+        masters = (mblk[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)
+        # slaves under a Dirichlet condition are dropped (cpp/utils.h:1459-1496)
+        keep = is_bc[slaves] == 0
+        slaves, masters = slaves[keep], masters[keep]
+        n = slaves.size
+        self.add_constraint(V, slaves.astype(np.int32), masters.astype(np.int64), np.full(n, scale, dtype=np.float64),
+                            np.zeros(n, dtype=np.int32), np.arange(n + 1, dtype=np.int32))
+
+    def create_general_constraint(self, slave_master_dict: Dict[bytes, Dict[bytes, float]],
+                                  subspace_slave: Optional[int] = None, subspace_master: Optional[int] = None):
+        """python/src/dolfinx_mpc/multipointconstraint.py:342-398 /
+        dictcondition.py: {slave point bytes: {master point bytes: coeff}}."""
+        from scipy.spatial import cKDTree
+
+        V = self.V
+        x = V.tabulate_dof_coordinates()
+        tree = cKDTree(x)
+        bs = V.dofmap.bs
+        dim = len(np.frombuffer(next(iter(slave_master_dict)), dtype=np.float64))
+
+        def find(pt_bytes):
+            pt = np.zeros(3)
+            pt[:dim] = np.frombuffer(pt_bytes, dtype=np.float64)
+            d, i = tree.query(pt)
+            if d > 1e-8:
+                raise ValueError(f"no dof at point {pt}")
+            return int(i)
+
+        slaves, masters, coeffs, offsets = [], [], [], [0]
+        for sp, md in slave_master_dict.items():
+            sblk = find(sp)
+            scomps = range(bs) if subspace_slave is None else [subspace_slave]
+            for k in scomps:
+                slaves.append(sblk * bs + k)
+                for mp, c in md.items():
+                    mcomp = k if subspace_master is None else subspace_master
+                    masters.append(find(mp) * bs + mcomp)
+                    coeffs.append(c)
+                offsets.append(len(masters))
+        self.add_constraint(V, np.array(slaves, dtype=np.int32), np.array(masters, dtype=np.int64),
+                            np.array(coeffs, dtype=np.float64), np.zeros(len(masters), dtype=np.int32),
+                            np.array(offsets, dtype=np.int32))
+
+    def create_slip_constraint(self, V: FunctionSpace, blocks: np.ndarray, normals: np.ndarray,
+                               bcs: Sequence[DirichletBC] = ()):
+        """u.n = 0 on the given dof blocks (cpp/SlipConstraint.h:115-166): slave =
+        component with the largest |n_i|, masters = the other components of the
+        same block, c_i = -n_i / n_s (no tolerance filter on zero coefficients)."""
+        assert V is self.V
+        bs = V.dofmap.bs
+        is_bc = np.zeros(V.num_dofs, dtype=np.int8)
+        for bc in bcs:
+            bc.mark_dofs(is_bc)
+        slaves, masters, coeffs, offsets = [], [], [], [0]
+        for blk, n in zip(np.asarray(blocks), np.asarray(normals)):
+            s = int(np.argmax(np.abs(n[:bs])))
+            sd = blk * bs + s
+            if is_bc[sd]:
+                continue
+            slaves.append(sd)
+            for k in range(bs):
+                if k != s:
+                    masters.append(blk * bs + k)
+                    coeffs.append(-n[k] / n[s])
+            offsets.append(len(masters))
+        self.add_constraint(V, np.array(slaves, dtype=np.int32), np.array(masters, dtype=np.int64),
+                            np.array(coeffs, dtype=np.float64), np.zeros(len(masters), dtype=np.int32),
+                            np.array(offsets, dtype=np.int32))
+
+    # -- accessors (python/src/dolfinx_mpc/multipointconstraint.py:503-584) ----
+    @property
+    def is_slave(self) -> np.ndarray:
+        self._not_finalized()
+        return self._is_slave
+
+    @property
+    def slaves(self) -> np.ndarray:
+        self._not_finalized()
+        return self._sorted_slaves
+
+    @property
+    def masters(self) -> AdjacencyList:
+        self._not_finalized()
+        return self._master_map
+
+    def coefficients(self):
+        self._not_finalized()
+        return self._coeff_map.array, self._coeff_map.offsets
+
+    @property
+    def owners(self) -> AdjacencyList:
+        self._not_finalized()
+        return self._owner_map
+
+    @property
+    def num_local_slaves(self) -> int:
+        self._not_finalized()
+        return self._num_local_slaves
+
+    @property
+    def cell_to_slaves(self) -> AdjacencyList:
+        self._not_finalized()
+        return self._cell_to_slaves
+
+    @property
+    def function_space(self) -> FunctionSpace:
+        self._not_finalized()
+        return self.V
+
+    # -- device mirror ----------------------------------------------------------
+    def _device(self):
+        """(MpcT struct, keep-alive tensors, slaves tensor) on the current HIP device."""
+        self._not_finalized()
+        if self._dev is None:
+            import torch
+
+            dev = _native.require_gpu()
+            t = {
+                "is_slave": torch.from_numpy(self._is_slave).to(dev),
+                "moff": torch.from_numpy(self._master_map.offsets).to(dev),
+                "masters": torch.from_numpy(self._master_map.array).to(dev),
+                "coeffs": torch.from_numpy(self._coeff_map.array).to(dev),
+                "slaves": torch.from_numpy(self._sorted_slaves).to(dev),
+            }
+            s = _native.MpcT(t["is_slave"].data_ptr(), t["moff"].data_ptr(), t["masters"].data_ptr(),
+                             t["coeffs"].data_ptr())
+            self._dev = (s, t)
+        return self._dev
+
+    # -- post-solve (python/src/dolfinx_mpc/multipointconstraint.py:586-617) ----
+    def backsubstitution(self, u) -> None:
+        """u[slave] = sum_k c_k u[master_k] on a device vector (``Vector`` or torch tensor)."""
+        import torch
+
+        arr = u.array if hasattr(u, "array") else u
+        s, t = self._device()
+        L = _native.lib()
+        rc = L.mpcx_backsubstitution(arr.data_ptr(), t["slaves"].data_ptr(), t["slaves"].numel(), C.byref(s),
+                                     torch.cuda.current_stream().cuda_stream)
+        _native.check(rc, "mpcx_backsubstitution")
+
+    def homogenize(self, u) -> None:
+        import torch
+
+        arr = u.array if hasattr(u, "array") else u
+        _, t = self._device()
+        rc = _native.lib().mpcx_homogenize(arr.data_ptr(), t["slaves"].data_ptr(), t["slaves"].numel(),
+                                           torch.cuda.current_stream().cuda_stream)
+        _native.check(rc, "mpcx_homogenize")
+
+    def _already_finalized(self):
+        if self.finalized:
+            raise RuntimeError("MultiPointConstraint has already been finalized")
+
+    def _not_finalized(self):
+        if not self.finalized:
+            raise RuntimeError("MultiPointConstraint has not been finalized")

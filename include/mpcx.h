@@ -1,0 +1,262 @@
+/*
+ * mpcx.h -- C ABI of libmpcx.so, the MI355X (gfx950) constrained-assembly
+ * backend for dolfinx_mpc's hot path.
+ *
+ * Plain pointers and sizes only.  Pointers marked DEVICE must be HIP device
+ * pointers (hipMalloc / torch CUDA tensors); pointers marked HOST are ordinary
+ * host memory.  All kernels are launched on the hipStream_t passed as
+ * `stream` (NULL = default stream) and are asynchronous: the caller
+ * synchronises.  Every function returns 0 on success, <0 on error; the message
+ * is available from mpcx_last_error().
+ *
+ * Each entry point cites the reference interface (relative to the
+ * dolfinx_mpc repository) it replaces.  INTEGRATION.md shows the binding a
+ * dolfinx_mpc maintainer would add.
+ */
+#ifndef MPCX_H
+#define MPCX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPCX_VERSION 1
+
+/* ---- form kinds / cell types (element kernels replacing the FFCx-generated
+ *      tabulate_tensor, cpp/assemble_matrix.cpp:438-439) ------------------- */
+enum {
+  MPCX_FORM_STIFFNESS = 0,
+  MPCX_FORM_MASS = 1,
+  MPCX_FORM_SOURCE = 2,
+  MPCX_FORM_ELASTICITY = 3,
+  MPCX_FORM_FACET_MASS = 4,
+  MPCX_FORM_FACET_SOURCE = 5
+};
+enum { MPCX_CELL_TRIANGLE = 1, MPCX_CELL_TETRAHEDRON = 2 };
+
+/* algorithms for the matrix scatter */
+enum {
+  MPCX_ALG_AUTO = 0,
+  MPCX_ALG_ATOMIC = 1,  /* thread-per-entity, CSR binary search, device atomics */
+  MPCX_ALG_ROWBLOCK = 2 /* LDS-privatised row blocks, each value written once */
+};
+
+/* Built-in element kernel: (form, cell, degree, block size) + quadrature table.
+ * The table is data (FFCx bakes it into generated code). */
+typedef struct
+{
+  int32_t form;
+  int32_t celltype;
+  int32_t degree;
+  int32_t bs;
+  int32_t fn_id;
+  int32_t coeff_degree;
+  int32_t nq;
+  int32_t nqf;
+  const double* qpts;  /* DEVICE [nq][tdim] */
+  const double* qwts;  /* DEVICE [nq] */
+  const double* fqpts; /* DEVICE [nqf][tdim-1] */
+  const double* fqwts; /* DEVICE [nqf] */
+} mpcx_kernel_t;
+
+/* Finalized constraint as the kernels read it: the accessors of
+ * cpp/MultiPointConstraint.h:155-199 (is_slave, masters, coefficients) as
+ * flat arrays.  masters_offsets spans all local dofs (non-slaves have no
+ * links), exactly like the reference adjacency lists. */
+typedef struct
+{
+  const int8_t* is_slave;         /* DEVICE [num_dofs] */
+  const int32_t* masters_offsets; /* DEVICE [num_dofs + 1] */
+  const int32_t* masters;         /* DEVICE local unrolled dofs */
+  const double* coeffs;           /* DEVICE */
+} mpcx_mpc_t;
+
+/* Optional row-block plan (MPCX_ALG_ROWBLOCK), built by mpcx_rowblock_plan_*. */
+typedef struct
+{
+  int32_t num_blocks;
+  int32_t max_rows;             /* max rows per block */
+  int32_t max_nnz;              /* max nnz per block  */
+  const int32_t* block_row0;    /* DEVICE [num_blocks + 1] first row of block */
+  const int64_t* block_ent_off; /* DEVICE [num_blocks + 1] into block_ents */
+  const int32_t* block_ents;    /* DEVICE entity indices touching the block */
+} mpcx_rowblock_plan_t;
+
+/* ------------------------------------------------------------------------
+ * mpcx_assemble_matrix: replaces dolfinx_mpc::assemble_matrix
+ * (cpp/assemble_matrix.h:28-43; cpp/assemble_matrix.cpp:417-548 cells,
+ * :271-415 exterior facets, :99-268 modify_mpc_cell) for ONE integral of the
+ * form, ADDing into the values of a pre-built CSR whose pattern is
+ * create_sparsity_pattern's (cpp/utils.h:381-496).  The two PETSc insertion
+ * callbacks of python/src/dolfinx_mpc/mpc.cpp:284-287 become direct
+ * scatter-adds into `vals`.
+ * ---------------------------------------------------------------------- */
+typedef struct
+{
+  /* CSR, scalar (unrolled) rows/cols, columns sorted per row */
+  int32_t nrows;
+  const int32_t* rowptr; /* DEVICE [nrows+1] */
+  const int32_t* cols;   /* DEVICE [nnz] */
+  double* vals;          /* DEVICE [nnz], accumulated into */
+  mpcx_kernel_t kernel;
+  /* geometry: Geometry::x padded to 3 comps, one dofmap (cpp/assemble_matrix.cpp:462-470) */
+  const double* x;         /* DEVICE [num_nodes][3] */
+  const int32_t* x_dofmap; /* DEVICE [num_cells][nv] */
+  int32_t nv;
+  /* integration domain: Form::domain / domain_arg (cpp/assemble_matrix.cpp:625-630) */
+  int32_t estride;          /* 1 cells, 2 (cell, local_facet) */
+  int64_t n_entities;
+  const int32_t* entities;  /* DEVICE [n_entities*estride] */
+  const int32_t* entities0; /* DEVICE, test-space cells (same layout) */
+  const int32_t* entities1; /* DEVICE, trial-space cells */
+  const double* coeffs;     /* DEVICE [n_entities][cstride] packed coefficients, or NULL */
+  int32_t cstride;
+  const double* constants;  /* DEVICE packed constants, or NULL */
+  /* dofmaps (blocked) */
+  const int32_t* dofmap0; int32_t nd0; int32_t bs0;
+  const int32_t* dofmap1; int32_t nd1; int32_t bs1;
+  /* Dirichlet markers over unrolled dofs, NULL when no bc (cpp/assemble_matrix.cpp:688-705) */
+  const int8_t* bc0;
+  const int8_t* bc1;
+  mpcx_mpc_t mpc0; /* rows */
+  mpcx_mpc_t mpc1; /* cols */
+  /* entity indices (into the domain) whose cell holds a slave of mpc0 or mpc1:
+   * compact form of cell_to_slaves (cpp/mpc_helpers.h:19-94) */
+  const int32_t* slave_entities; /* DEVICE */
+  int64_t n_slave_entities;
+  int32_t algorithm;
+  int32_t store_mode; /* rowblock: 1 = block values overwrite vals (no prior zeroing needed) */
+  mpcx_rowblock_plan_t plan;
+  void* stream;
+} mpcx_matrix_args_t;
+
+int mpcx_assemble_matrix(const mpcx_matrix_args_t* args);
+
+/* vals[pos(d,d)] += diagval for d in dofs.  Replaces the slave-diagonal loop
+ * of cpp/assemble_matrix.cpp:711-724 and dolfinx insert_diagonal called at
+ * python/src/dolfinx_mpc/assemble_matrix.py:59-62. */
+int mpcx_add_diagonal(int32_t nrows, const int32_t* rowptr, const int32_t* cols,
+                      double* vals, const int32_t* dofs, int64_t n,
+                      double diagval, void* stream);
+
+/* ------------------------------------------------------------------------
+ * mpcx_assemble_vector: replaces dolfinx_mpc::assemble_vector
+ * (cpp/assemble_vector.h:77-81, cpp/assemble_vector.cpp:34-91, modify_mpc_vec
+ * cpp/assemble_vector.h:35-69) for one integral; accumulates into b (not
+ * zeroed, like the reference).
+ * ---------------------------------------------------------------------- */
+typedef struct
+{
+  double* b; /* DEVICE [num_dofs] */
+  int32_t num_dofs;
+  mpcx_kernel_t kernel;
+  const double* x; const int32_t* x_dofmap; int32_t nv;
+  int32_t estride; int64_t n_entities;
+  const int32_t* entities; const int32_t* entities0;
+  const double* coeffs; int32_t cstride; const double* constants;
+  const int32_t* dofmap; int32_t nd; int32_t bs;
+  mpcx_mpc_t mpc;
+  void* stream;
+} mpcx_vector_args_t;
+
+int mpcx_assemble_vector(const mpcx_vector_args_t* args);
+
+/* ------------------------------------------------------------------------
+ * mpcx_apply_lifting: replaces impl::apply_lifting for one integral of one
+ * form a[j] (cpp/lifting.h:45-134, :243-397):
+ *    b <- b - scale * K^T A_j (g_j - x0_j)
+ * `lift_entities` is the compact list of entity indices with a bc-marked
+ * column dof (the `has_bc` test of cpp/lifting.h:93-109 hoisted to set-up).
+ * ---------------------------------------------------------------------- */
+typedef struct
+{
+  double* b; int32_t num_dofs;
+  mpcx_kernel_t kernel;
+  const double* x; const int32_t* x_dofmap; int32_t nv;
+  int32_t estride; int64_t n_entities;
+  const int32_t* entities; const int32_t* entities0; const int32_t* entities1;
+  const double* coeffs; int32_t cstride; const double* constants;
+  const int32_t* dofmap0; int32_t nd0; int32_t bs0;
+  const int32_t* dofmap1; int32_t nd1; int32_t bs1;
+  const int8_t* bc_markers1; /* DEVICE, cpp/lifting.h:166-180 */
+  const double* bc_values1;  /* DEVICE */
+  const double* x0;          /* DEVICE or NULL (=> 0, cpp/lifting.h:295) */
+  double scale;
+  const int32_t* lift_entities; int64_t n_lift_entities; /* DEVICE */
+  mpcx_mpc_t mpc0;
+  void* stream;
+} mpcx_lifting_args_t;
+
+int mpcx_apply_lifting(const mpcx_lifting_args_t* args);
+
+/* MultiPointConstraint::backsubstitution / homogenize
+ * (cpp/MultiPointConstraint.h:129-152) on a device vector. */
+int mpcx_backsubstitution(double* u, const int32_t* slaves, int64_t num_slaves,
+                          const mpcx_mpc_t* mpc, void* stream);
+int mpcx_homogenize(double* u, const int32_t* slaves, int64_t num_slaves, void* stream);
+
+/* ------------------------------------------------------------------------
+ * HOST set-up routines (no GPU needed).
+ * ---------------------------------------------------------------------- */
+
+/* MultiPointConstraint constructor, cpp/MultiPointConstraint.h:36-126, single
+ * process (global master index == local index, owners kept verbatim).
+ * Outputs are caller-allocated:
+ *   is_slave[num_dofs], sorted_slaves[num_slaves], masters_offsets[num_dofs+1],
+ *   masters_out/coeffs_out/owners_out[offsets[num_slaves]]. */
+int mpcx_mpc_finalize(int32_t num_dofs, int32_t num_owned_dofs, int32_t num_slaves,
+                      const int32_t* slaves, const int64_t* masters,
+                      const double* coeffs, const int32_t* owners,
+                      const int32_t* offsets, int8_t* is_slave,
+                      int32_t* sorted_slaves, int32_t* num_local_slaves,
+                      int32_t* masters_offsets, int32_t* masters_out,
+                      double* coeffs_out, int32_t* owners_out);
+
+/* create_cell_to_dofs_map, cpp/mpc_helpers.h:19-94.  Call with c2s == NULL to
+ * fill c2s_offsets[num_cells+1] and get the total; then again with c2s
+ * allocated.  Returns total number of links (>=0) or <0. */
+int64_t mpcx_cell_to_slaves(int64_t num_cells, int32_t nd, int32_t bs,
+                            const int32_t* dofmap, const int8_t* is_slave,
+                            int32_t* c2s_offsets, int32_t* c2s);
+
+/* create_sparsity_pattern, cpp/utils.h:381-496 (+ finalize): block pattern
+ *   rows(c) x (cols(c) U masters(col-slaves(c)))  U
+ *   masters(row-slaves(c)) x (cols(c) U masters(col-slaves(c)))   for all cells c
+ * expanded to scalar CSR with sorted columns.  Returns an opaque handle. */
+void* mpcx_pattern_build(int64_t num_cells, const int32_t* dofmap0, int32_t nd0,
+                         int32_t bs0, int32_t num_blocks0, const int32_t* dofmap1,
+                         int32_t nd1, int32_t bs1, int32_t num_blocks1,
+                         const int32_t* c2s_offsets0, const int32_t* c2s0,
+                         const int32_t* masters_offsets0, const int32_t* masters0,
+                         const int32_t* c2s_offsets1, const int32_t* c2s1,
+                         const int32_t* masters_offsets1, const int32_t* masters1,
+                         int32_t num_threads);
+int64_t mpcx_pattern_nnz(void* pattern);
+int32_t mpcx_pattern_nrows(void* pattern);
+int mpcx_pattern_copy(void* pattern, int32_t* rowptr, int32_t* cols);
+void mpcx_pattern_free(void* pattern);
+
+/* Row-block plan for MPCX_ALG_ROWBLOCK: contiguous row ranges with at most
+ * max_rows rows / max_nnz nonzeros, and for each block the entities whose
+ * test-space cell has a dof in it.  Returns an opaque handle. */
+void* mpcx_rowblock_plan_build(int32_t nrows, const int32_t* rowptr, int32_t max_rows,
+                               int32_t max_nnz, int64_t n_entities, int32_t estride,
+                               const int32_t* entities0, const int32_t* dofmap0,
+                               int32_t nd0, int32_t bs0, int32_t num_threads);
+int32_t mpcx_rowblock_plan_num_blocks(void* plan);
+int64_t mpcx_rowblock_plan_num_ents(void* plan);
+int mpcx_rowblock_plan_copy(void* plan, int32_t* block_row0, int64_t* block_ent_off,
+                            int32_t* block_ents);
+void mpcx_rowblock_plan_free(void* plan);
+
+/* misc */
+const char* mpcx_last_error(void);
+int mpcx_version(void);
+int mpcx_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCX_H */

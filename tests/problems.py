@@ -1,0 +1,340 @@
+"""Problem definitions shared by the oracle tests, the golden-fixture generator
+and the GPU parity tests.  Each case mirrors a configuration of the reference's
+own test-suite or benchmark (cited per case); the constraint is kept as the
+raw ``add_constraint`` arrays (python/src/dolfinx_mpc/multipointconstraint.py:118-153)
+so that the oracle and the product finalize it independently.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+from scipy.spatial import cKDTree
+
+from dolfinx_mpc_amd import fem
+from dolfinx_mpc_amd.mesh import create_unit_cube, create_unit_square
+
+
+@dataclass
+class Case:
+    name: str
+    V: fem.FunctionSpace
+    a: Optional[fem.Form]
+    L: Optional[fem.Form]
+    bcs: list
+    raw: tuple  # (slaves i32, masters i64, coeffs f64, owners i32, offsets i32)
+    x0: Optional[np.ndarray] = None
+    scale: float = 1.0
+    diagval: float = 1.0
+
+    @property
+    def mesh(self):
+        return self.V.mesh
+
+
+def l2b(li):
+    return np.array(li, dtype=np.float64).tobytes()
+
+
+def dict_constraint_raw(V, s_m_c: Dict[bytes, Dict[bytes, float]], subspace_slave=None, subspace_master=None):
+    """python/src/dolfinx_mpc/dictcondition.py semantics on matching nodes."""
+    x = V.tabulate_dof_coordinates()
+    tree = cKDTree(x)
+    bs = V.dofmap.bs
+
+    def find(b):
+        p = np.zeros(3)
+        v = np.frombuffer(b, dtype=np.float64)
+        p[: v.size] = v
+        d, i = tree.query(p)
+        assert d < 1e-9, f"no dof at {p}"
+        return int(i)
+
+    slaves, masters, coeffs, offsets = [], [], [], [0]
+    for sp, md in s_m_c.items():
+        sb = find(sp)
+        for k in range(bs) if subspace_slave is None else [subspace_slave]:
+            slaves.append(sb * bs + k)
+            for mp, c in md.items():
+                masters.append(find(mp) * bs + (k if subspace_master is None else subspace_master))
+                coeffs.append(c)
+            offsets.append(len(masters))
+    return (np.array(slaves, dtype=np.int32), np.array(masters, dtype=np.int64), np.array(coeffs, dtype=np.float64),
+            np.zeros(len(masters), dtype=np.int32), np.array(offsets, dtype=np.int32))
+
+
+def periodic_raw(V, bcs, scale=1.0):
+    """slave (1, y, z) <- scale * master (0, y, z), bc dofs removed
+    (python/benchmarks/bench_periodic.py:60-81)."""
+    x = V.tabulate_dof_coordinates()
+    bs = V.dofmap.bs
+    is_bc = np.zeros(V.num_dofs, dtype=np.int8)
+    for bc in bcs:
+        bc.mark_dofs(is_bc)
+    blocks = np.flatnonzero(np.isclose(x[:, 0], 1.0))
+    xm = x[blocks].copy()
+    xm[:, 0] = 1.0 - xm[:, 0]
+    d, mb = cKDTree(x).query(xm)
+    assert d.max() < 1e-10
+    slaves = (blocks[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)
+    masters = (mb[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)
+    keep = is_bc[slaves] == 0
+    slaves, masters = slaves[keep], masters[keep]
+    n = slaves.size
+    return (slaves.astype(np.int32), masters.astype(np.int64), np.full(n, scale), np.zeros(n, dtype=np.int32),
+            np.arange(n + 1, dtype=np.int32))
+
+
+def empty_raw():
+    z = np.zeros(0, dtype=np.int32)
+    return (z, np.zeros(0, dtype=np.int64), np.zeros(0), z, np.zeros(1, dtype=np.int32))
+
+
+def _walls_yz(x):
+    return np.isclose(x[1], 0) | np.isclose(x[1], 1) | np.isclose(x[2], 0) | np.isclose(x[2], 1)
+
+
+# --------------------------------------------------------------------------
+def case_square_dict(degree=1, master_point=(1, 1), n=(5, 3)) -> Case:
+    """python/tests/test_matrix_assembly.py:23-57 / test_vector_assembly.py:22-63"""
+    mesh = create_unit_square(*n)
+    V = fem.functionspace(mesh, ("Lagrange", degree))
+    s_m_c = {l2b([1, 0]): {l2b([0, 1]): 0.43, l2b([1, 1]): 0.11}, l2b([0, 0]): {l2b(list(master_point)): 0.69}}
+    return Case(f"square_dict_p{degree}_m{master_point[0]}{master_point[1]}_{n[0]}x{n[1]}", V, fem.form_stiffness(V),
+                fem.form_source(V, fem.FN_SIN2D), [], dict_constraint_raw(V, s_m_c))
+
+
+def case_same_cell(degree=1, master_point=(1, 1)) -> Case:
+    """python/tests/test_matrix_assembly.py:61-102 (slaves sharing a cell)"""
+    return case_square_dict(degree, master_point, n=(1, 8))
+
+
+def case_lifting() -> Case:
+    """python/tests/test_lifting.py:19-122: non-zero Dirichlet value next to a slave"""
+    mesh = create_unit_square(1, 1)
+    V = fem.functionspace(mesh, ("Lagrange", 1))
+    u_bc = fem.Function(V)
+    u_bc.x.array[:] = 2.3
+    dofs = fem.locate_dofs_geometrical(V, lambda x: np.isclose(x[0], 1))
+    bc = fem.dirichletbc(u_bc, dofs, V)
+    s_m_c = {l2b([0, 0]): {l2b([0, 1]): 1}}
+    return Case("lifting_1x1", V, fem.form_stiffness(V), fem.form_source(V, fem.FN_SIN2D), [bc],
+                dict_constraint_raw(V, s_m_c))
+
+
+def case_pipeline(master_point=(1, 1)) -> Case:
+    """python/tests/test_mpc_pipeline.py:26-112: coefficients and constants in the forms"""
+    mesh = create_unit_square(3, 5)
+    V = fem.functionspace(mesh, ("Lagrange", 1))
+    g = fem.Function(V)
+    g.interpolate(lambda x: np.sin(x[0]) * x[1])
+    h = fem.Function(V)
+    h.interpolate(lambda x: 2 + x[1] * x[0])
+    a = fem.form_stiffness(V, constant=1.5, coefficient=g)
+    L = fem.form_source(V, fem.FN_SIN2D, constant=2.0, coefficient=h)
+    s_m_c = {l2b([1, 0]): {l2b([0, 1]): 0.43, l2b([1, 1]): 0.11}, l2b([0, 0]): {l2b(list(master_point)): 0.69}}
+    return Case(f"pipeline_m{master_point[0]}{master_point[1]}", V, a, L, [], dict_constraint_raw(V, s_m_c))
+
+
+def case_vector_poisson(slave_space=0, master_space=1, n=(4, 2)) -> Case:
+    """python/tests/test_vector_poisson.py:25-133: blocked space, sub-space constraint, bc"""
+    mesh = create_unit_square(*n)
+    V = fem.functionspace(mesh, ("Lagrange", 1, (2,)))
+    dofs = fem.locate_dofs_geometrical(V, lambda x: np.isclose(x[0], 0) & np.isclose(x[1], 0))
+    bc = fem.dirichletbc(0.0, dofs, V)
+    s_m_c = {l2b([1, 0]): {l2b([1, 1]): 0.1, l2b([0.5, 1]): 0.3}}
+    return Case(f"vector_poisson_s{slave_space}m{master_space}", V, fem.form_stiffness(V),
+                fem.form_source(V, fem.FN_LINEAR), [bc], dict_constraint_raw(V, s_m_c, slave_space, master_space))
+
+
+def case_surface_integral(N=4) -> Case:
+    """python/tests/test_surface_integral.py:26-144: elasticity + traction on ds(top)"""
+    mesh = create_unit_square(N, N)
+    V = fem.functionspace(mesh, ("Lagrange", 1, (2,)))
+    dofs = fem.locate_dofs_geometrical(V, lambda x: np.isclose(x[0], 0))
+    bc = fem.dirichletbc(0.0, dofs, V)
+    E, nu = 1.0e2, 0.0
+    mu, lmbda = E / (2.0 * (1.0 + nu)), E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu))
+    top = mesh.locate_exterior_facets(lambda x: np.isclose(x[1], 1))
+    a = fem.form_elasticity(V, mu, lmbda)
+    L = fem.form_facet_source(V, top, fem.FN_CONSTANT_VEC, constant=[1.0, 0.0, -9.81e2])
+    s_m_c = {l2b([1, i / N]): {l2b([1, 1]): 0.8} for i in range(1, N)}
+    return Case(f"surface_integral_{N}", V, a, L, [bc], dict_constraint_raw(V, s_m_c, 1, 1))
+
+
+def case_integration_domains() -> Case:
+    """python/tests/test_integration_domains.py:23-133: several cell sub-domains"""
+    mesh = create_unit_square(15, 5)
+    V = fem.functionspace(mesh, ("Lagrange", 1))
+    mid = mesh.geometry.x[mesh.geometry.dofmap].mean(axis=1)
+    left = np.flatnonzero(mid[:, 0] < 0.5).astype(np.int32)
+    right = np.flatnonzero(mid[:, 0] >= 0.5).astype(np.int32)
+    a = fem.form_stiffness(V, constant=1.0, cells=left) + fem.form_stiffness(V, constant=2.0, cells=right) \
+        + fem.form_mass(V, constant=0.3)
+    L = fem.form_source(V, fem.FN_SIN2D, constant=1.0, cells=left) + fem.form_source(V, fem.FN_ONE, constant=2.0, cells=right)
+    dofs = fem.locate_dofs_geometrical(V, lambda x: np.isclose(x[1], 0))
+    bc = fem.dirichletbc(0.0, dofs, V)
+    # periodic pairs x=1 -> x=0 (test uses N+1 pairs via a dict)
+    return Case("integration_domains", V, a, L, [bc], periodic_raw(V, [bc]))
+
+
+def case_facet_mass() -> Case:
+    """exterior-facet integrals in A (python/tests/test_surface_integral.py:148-219 style Robin term)"""
+    mesh = create_unit_square(4, 4)
+    V = fem.functionspace(mesh, ("Lagrange", 1))
+    right = mesh.locate_exterior_facets(lambda x: np.isclose(x[0], 1))
+    a = fem.form_stiffness(V) + fem.form_facet_mass(V, right, constant=3.0)
+    L = fem.form_source(V, fem.FN_SIN2D) + fem.form_facet_source(V, right, fem.FN_LINEAR, constant=0.5)
+    s_m_c = {l2b([1, 0.5]): {l2b([0, 0.5]): 0.7, l2b([0, 0.75]): 0.2}, l2b([1, 0.25]): {l2b([1, 0.75]): -0.4}}
+    return Case("facet_mass", V, a, L, [], dict_constraint_raw(V, s_m_c))
+
+
+def case_cube_periodic(N=4, degree=1, bc_value=0.0, reorder=None) -> Case:
+    """python/benchmarks/bench_periodic.py:35-110 (BASELINE configs 1/2 at small N)"""
+    mesh = create_unit_cube(N, N, N, reorder=reorder)
+    V = fem.functionspace(mesh, ("Lagrange", degree))
+    dofs = fem.locate_dofs_geometrical(V, _walls_yz)
+    bc = fem.dirichletbc(bc_value, dofs, V)
+    tag = "" if reorder is None else "_tiled"
+    return Case(f"cube_periodic_p{degree}_n{N}_bc{bc_value:g}{tag}", V, fem.form_stiffness(V),
+                fem.form_source(V, fem.FN_BENCH_PERIODIC), [bc], periodic_raw(V, [bc]))
+
+
+def case_cube_elasticity_slip(N=3) -> Case:
+    """vector P1 tets, slip constraint u.n = 0 on x=1 with a tilted normal
+    (cpp/SlipConstraint.h:115-166 output shape: 1 slave + bs-1 same-block masters)"""
+    mesh = create_unit_cube(N, N, N)
+    V = fem.functionspace(mesh, ("Lagrange", 1, (3,)))
+    x = V.tabulate_dof_coordinates()
+    dofs = fem.locate_dofs_geometrical(V, lambda x: np.isclose(x[0], 0))
+    bc = fem.dirichletbc(np.array([0.0, 0.1, -0.2]), dofs, V)
+    nrm = np.array([1.0, 0.3, -0.2])
+    nrm /= np.linalg.norm(nrm)
+    blocks = np.flatnonzero(np.isclose(x[:, 0], 1.0))
+    slaves, masters, coeffs, offsets = [], [], [], [0]
+    for b in blocks:
+        s = int(np.argmax(np.abs(nrm)))
+        slaves.append(b * 3 + s)
+        for k in range(3):
+            if k != s:
+                masters.append(b * 3 + k)
+                coeffs.append(-nrm[k] / nrm[s])
+        offsets.append(len(masters))
+    raw = (np.array(slaves, dtype=np.int32), np.array(masters, dtype=np.int64), np.array(coeffs),
+           np.zeros(len(masters), dtype=np.int32), np.array(offsets, dtype=np.int32))
+    a = fem.form_elasticity(V, 1.0e3 / 2, 0.0)  # bench_contact_3D.py:257-269: E=1e3, nu=0
+    L = fem.form_source(V, fem.FN_LINEAR)
+    return Case(f"cube_elasticity_slip_n{N}", V, a, L, [bc], raw)
+
+
+def case_cube_contact_like(N=3) -> Case:
+    """several masters per slave (contact-like, cpp/ContactConstraint.h:908-1174 output shape):
+    every interior node of x=1 is tied to three nodes of x=0 with barycentric-like weights"""
+    mesh = create_unit_cube(N, N, N)
+    V = fem.functionspace(mesh, ("Lagrange", 1))
+    x = V.tabulate_dof_coordinates()
+    tree = cKDTree(x)
+    h = 1.0 / N
+    slaves, masters, coeffs, offsets = [], [], [], [0]
+    for d in np.flatnonzero(np.isclose(x[:, 0], 1.0)):
+        y, z = x[d, 1], x[d, 2]
+        if y < h / 2 or y > 1 - h / 2 or z < h / 2 or z > 1 - h / 2:
+            continue
+        slaves.append(d)
+        for (dy, dz, w) in ((0, 0, 0.5), (-h, 0, 0.3), (0, h, 0.2)):
+            _, m = tree.query([0.0, y + dy, z + dz])
+            masters.append(int(m))
+            coeffs.append(w)
+        offsets.append(len(masters))
+    raw = (np.array(slaves, dtype=np.int32), np.array(masters, dtype=np.int64), np.array(coeffs),
+           np.zeros(len(masters), dtype=np.int32), np.array(offsets, dtype=np.int32))
+    # Dirichlet dofs may be neither slaves nor masters: masters have z >= h
+    dofs = fem.locate_dofs_geometrical(V, lambda x: np.isclose(x[2], 0))
+    bc = fem.dirichletbc(1.7, dofs, V)
+    return Case(f"cube_contact_like_n{N}", V, fem.form_stiffness(V) + fem.form_mass(V, constant=0.1),
+                fem.form_source(V, fem.FN_POLY3), [bc], raw)
+
+
+def all_small_cases() -> List[Callable[[], Case]]:
+    return [
+        lambda: case_square_dict(1, (1, 1)),
+        lambda: case_square_dict(1, (0, 1)),
+        lambda: case_square_dict(2, (1, 1)),
+        lambda: case_square_dict(2, (0, 1)),
+        lambda: case_same_cell(1, (1, 1)),
+        lambda: case_same_cell(2, (0, 1)),
+        case_lifting,
+        lambda: case_pipeline((1, 1)),
+        lambda: case_pipeline((0, 1)),
+        lambda: case_vector_poisson(0, 0),
+        lambda: case_vector_poisson(0, 1),
+        lambda: case_vector_poisson(1, 0),
+        lambda: case_surface_integral(4),
+        case_integration_domains,
+        case_facet_mass,
+        lambda: case_cube_periodic(4, 1, 0.0),
+        lambda: case_cube_periodic(3, 2, 0.0),
+        lambda: case_cube_periodic(4, 1, 2.3),
+        lambda: case_cube_periodic(4, 1, 0.0, reorder=(2, 2, 2)),
+        lambda: case_cube_elasticity_slip(3),
+        lambda: case_cube_contact_like(3),
+    ]
+
+
+# --------------------------------------------------------------------------
+def oracle_mpc(po, case: Case):
+    return po.OracleMPC.from_raw(case.V, *case.raw)
+
+
+def oracle_outputs(po, case: Case, fast=False):
+    """Everything the reference pipeline produces up to the solve
+    (python/benchmarks/bench_periodic.py:95-109): A, b (assembled), b after lifting."""
+    mpc = oracle_mpc(po, case)
+    out = {}
+    if case.a is not None:
+        out["A"] = po.assemble_matrix(case.a, mpc, bcs=case.bcs, diagval=case.diagval, fast=fast)
+    if case.L is not None:
+        b = po.assemble_vector(case.L, mpc, fast=fast)
+        out["b"] = b.copy()
+        if case.a is not None and case.bcs:
+            x0 = None if case.x0 is None else [case.x0]
+            po.apply_lifting(b, [case.a], [case.bcs], mpc, x0=x0, scale=case.scale, fast=fast)
+            out["b_lifted"] = b.copy()
+    return out
+
+
+def product_mpc(case: Case):
+    import dolfinx_mpc_amd as dm
+
+    mpc = dm.MultiPointConstraint(case.V)
+    mpc.add_constraint(case.V, *case.raw)
+    mpc.finalize()
+    return mpc
+
+
+def product_outputs(case: Case, algorithm=None):
+    """Same pipeline through the public API on the GPU (HIP kernels via the C ABI)."""
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd.la import Vector
+
+    mpc = product_mpc(case)
+    out = {}
+    if case.a is not None:
+        A = dm.assemble_matrix(case.a, mpc, bcs=case.bcs, diagval=case.diagval, algorithm=algorithm)
+        out["A"] = A.to_scipy()
+    if case.L is not None:
+        b = dm.assemble_vector(case.L, mpc)
+        out["b"] = b.numpy().copy()
+        if case.a is not None and case.bcs:
+            x0 = None
+            if case.x0 is not None:
+                import torch
+
+                v = Vector(case.V.num_dofs)
+                v.array.copy_(torch.from_numpy(case.x0))
+                x0 = [v]
+            dm.apply_lifting(b, [case.a], [case.bcs], mpc, x0=x0, scale=case.scale)
+            out["b_lifted"] = b.numpy().copy()
+    return out
