@@ -1,0 +1,285 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the constrained-assembly hot path.
+
+Workload (BASELINE.json configs[1]; python/benchmarks/bench_periodic.py:35-110):
+periodic-BC Poisson, P1 tets on the N^3 unit cube (N=256 by default:
+100 663 296 cells, 16 974 593 dofs, 65 025 slaves), fp64.
+
+One "step" = assemble_matrix (into the cached MPC-pattern CSR) + assemble_vector,
+inputs resident in HBM.  metric = Ndof / (t_matrix + t_vector).  apply_lifting is
+timed separately (as the reference's timers do).
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling, every
+rank assembles its own N^3 box of a (N, N, N*world) mesh and exchanges the
+partial sums of the interface-plane rows with its z-neighbours over RCCL.
+Rank 0 prints ONE JSON line.
+"""
+
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def log(*a):
+    if int(os.environ.get("RANK", 0)) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def build_problem(N: int, reorder, zslab=(0, 1)):
+    """mesh, space, bc, constraint, forms of the periodic Poisson benchmark."""
+    from dolfinx_mpc_amd import MultiPointConstraint, fem
+    from dolfinx_mpc_amd.mesh import create_box
+
+    t = time.time()
+    z0, z1 = zslab
+    mesh = create_box((0.0, 0.0, float(z0)), (1.0, 1.0, float(z1)), (N, N, N * (z1 - z0)), "tetrahedron", reorder)
+    V = fem.functionspace(mesh, ("Lagrange", 1))
+    log(f"mesh: {mesh.num_cells} cells, {V.num_dofs} dofs ({time.time() - t:.1f}s)")
+
+    t = time.time()
+
+    def dirichletboundary(x):  # bench_periodic.py:49-55 (global walls y,z in {0,1})
+        return np.isclose(x[1], 0) | np.isclose(x[1], 1) | np.isclose(x[2], 0) | np.isclose(x[2], 1)
+
+    bdofs = fem.locate_dofs_geometrical(V, dirichletboundary)
+    bc = fem.dirichletbc(0.0, bdofs, V)
+    mpc = MultiPointConstraint(V)
+
+    def periodic_relation(x):  # bench_periodic.py:63-68
+        out = np.zeros(x.shape)
+        out[0] = 1 - x[0]
+        out[1] = x[1]
+        out[2] = x[2]
+        return out
+
+    mpc.create_periodic_constraint_geometrical(V, lambda x: np.isclose(x[0], 1), periodic_relation, [bc])
+    mpc.finalize()
+    log(f"constraint: {mpc.slaves.size} slaves ({time.time() - t:.1f}s)")
+    a = fem.form_stiffness(V)
+    L = fem.form_source(V, fem.FN_BENCH_PERIODIC)
+    return mesh, V, bc, mpc, a, L
+
+
+def cpu_baseline(sample_n: int):
+    """The oracle (C restatement of the reference's serial loops) timed on one
+    host core on a bounded sample: the same workload at N = sample_n."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import pyoracle as po
+    from problems import case_cube_periodic, oracle_mpc
+
+    case = case_cube_periodic(sample_n, 1, 0.0)
+    mpc = oracle_mpc(po, case)
+    pattern = po.create_pattern(case.a, mpc, mpc)
+    po.assemble_matrix(case.a, mpc, bcs=case.bcs, pattern=pattern, fast=True)  # warm
+    t0 = time.perf_counter()
+    po.assemble_matrix(case.a, mpc, bcs=case.bcs, pattern=pattern, fast=True)
+    t1 = time.perf_counter()
+    po.assemble_vector(case.L, mpc, fast=True)
+    t2 = time.perf_counter()
+    ndofs = case.V.num_dofs
+    return {
+        "value": ndofs / (t2 - t0),
+        "unit": "DoFs/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"same workload at N={sample_n} ({case.mesh.num_cells} cells, {ndofs} dofs): "
+                  f"matrix {t1 - t0:.2f}s + vector {t2 - t1:.2f}s, oracle/mpc_oracle.c -O3, 1 thread",
+        "t_matrix_s": t1 - t0,
+        "t_vector_s": t2 - t1,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=int(os.environ.get("MPCX_BENCH_N", 256)))
+    ap.add_argument("--alg", default=os.environ.get("MPCX_MATRIX_ALG", "rowblock"))
+    ap.add_argument("--tile", type=int, nargs=3, default=[8, 8, 8], help="node/cell tile of the numbering")
+    ap.add_argument("--no-tile", action="store_true")
+    ap.add_argument("--cpu-sample-n", type=int, default=96)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--setup-only", action="store_true", help="host set-up only (no GPU), for timing the plan")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    N = args.n
+    reorder = None if args.no_tile else tuple(args.tile)
+
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import _native
+    am = sys.modules["dolfinx_mpc_amd.assemble_matrix"]  # the module (the package re-exports the function)
+
+    t_setup = time.time()
+    mesh, V, bc, mpc, a, L = build_problem(N, reorder, zslab=(rank, rank + 1) if world > 1 else (0, 1))
+    t = time.time()
+    rowptr, cols = dm.create_sparsity_pattern(a, mpc)
+    log(f"pattern: nnz {cols.size} ({time.time() - t:.1f}s)")
+    if args.setup_only:
+        log(f"host set-up total {time.time() - t_setup:.1f}s")
+        return
+
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from dolfinx_mpc_amd.la import MPCMatrix, create_vector
+
+    A = MPCMatrix(rowptr, cols, V.num_dofs)
+    b = create_vector(V)
+    bcs = [bc]
+
+    exchange = None
+    if world > 1:
+        from dolfinx_mpc_amd.distributed import SlabExchange
+
+        exchange = SlabExchange(mesh, V, A, rank, world)
+
+    def step_matrix():
+        dm.assemble_matrix(a, mpc, bcs=bcs, A=A, algorithm=args.alg)
+        if exchange is not None:
+            exchange.reduce_matrix(A)
+
+    def step_vector():
+        dm.assemble_vector(L, mpc, b=b)
+        if exchange is not None:
+            exchange.reduce_vector(b)
+
+    t = time.time()
+    step_matrix()
+    step_vector()
+    torch.cuda.synchronize()
+    log(f"first step incl. plan build + uploads: {time.time() - t:.1f}s; host set-up total {time.time() - t_setup:.1f}s")
+
+    for _ in range(args.warmup):
+        step_matrix()
+        step_vector()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- the timed region: exactly K steps --------------------------------
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        step_matrix()
+        ev[k][1].record()
+        step_vector()
+        ev[k][2].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    t_mat = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    t_vec = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+
+    # ---- per-kernel timing of the dominant (bulk matrix) kernel, HIP events on
+    #      the launch stream ----------------------------------------------------
+    Lib = _native.lib()
+    alg_id = am._ALG[args.alg]
+    margs, _keep = am.matrix_args(a, 0, A, mpc, mpc, bcs, alg_id, store_mode=1 if alg_id == 2 else 0,
+                                  with_mpc_kernel=False)
+    reps = max(args.steps, 5)
+    kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for s, e in kev:
+        s.record()
+        _native.check(Lib.mpcx_assemble_matrix(C.byref(margs)), "mpcx_assemble_matrix")
+        e.record()
+    torch.cuda.synchronize()
+    t_bulk = float(np.mean([s.elapsed_time(e) for s, e in kev]))
+    # lifting, separately
+    lev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+    for s, e in lev:
+        s.record()
+        dm.apply_lifting(b, [a], [bcs], mpc)
+        e.record()
+    torch.cuda.synchronize()
+    t_lift = float(np.mean([s.elapsed_time(e) for s, e in lev[1:]]))
+    # restore a consistent A/b
+    step_matrix()
+    step_vector()
+    torch.cuda.synchronize()
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ndofs_rank = V.num_dofs
+    # every rank owns its box minus the shared top plane (owned by the upper neighbour's... lower rank)
+    ndofs_total = ndofs_rank * world - (world - 1) * (N + 1) ** 2
+    nc, nv, nd = mesh.num_cells, 4, 4
+    alg_bytes = 4 * nv * nc + 4 * nd * nc + 24 * mesh.num_nodes + 8 * cols.size + 2 * V.num_dofs
+    peak = 8000.0  # GB/s, HBM3E spec (MI355X_MICROARCH.md)
+    achieved = alg_bytes / (t_bulk * 1e-3) / 1e9
+    out = {
+        "metric": "assembled DoFs/sec (matrix+vector), periodic Poisson P1 256^3",
+        "value": ndofs_total * args.steps / elapsed,
+        "unit": "DoFs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"periodic-BC Poisson, P1 tets, {N}^3 unit cube per GPU, fp64 (BASELINE configs[1])",
+            "cells_per_gpu": int(nc),
+            "dofs_per_gpu": int(ndofs_rank),
+            "slaves_per_gpu": int(mpc.slaves.size),
+            "nnz_per_gpu": int(cols.size),
+            "matrix_algorithm": args.alg,
+            "numbering_tile": None if reorder is None else list(reorder),
+            "parallelism": f"z-slab x{world}" if world > 1 else "single GPU",
+        },
+        "timings_ms": {"assemble_matrix": t_mat, "assemble_vector": t_vec, "apply_lifting": t_lift,
+                       "matrix_bulk_kernel": t_bulk},
+        "roofline": {
+            "kernel": f"matrix_{args.alg}_kernel<P1 tet stiffness>",
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": peak,
+            "unit": "GB/s",
+            "frac": achieved / peak,
+            "traffic": None,
+            "algorithmic_bytes": int(alg_bytes),
+            "launch_ms": t_bulk,
+        },
+    }
+    if not args.no_cpu_baseline:
+        log("timing the CPU baseline (oracle, 1 core) ...")
+        out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -187,6 +187,14 @@ def lib() -> C.CDLL:
             f"{_LIB_PATH} not found: the HIP backend has not been built "
             "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
         )
+    # One HIP runtime per process: torch ships its own libamdhip64.so and owns
+    # the device allocations/streams we are handed, so make sure that copy is
+    # the one libmpcx.so's NEEDED libamdhip64.so.7 resolves to (same SONAME).
+    import torch
+
+    hip_rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(hip_rt):
+        C.CDLL(hip_rt, mode=C.RTLD_GLOBAL)
     L = C.CDLL(_LIB_PATH)
     vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     L.mpcx_assemble_matrix.argtypes = [C.POINTER(MatrixArgs)]

@@ -113,6 +113,46 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0):
     return A._plans[key]
 
 
+def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, store_mode: int = 0,
+                with_mpc_kernel: bool = True):
+    """Fill the C-ABI argument block of ``mpcx_assemble_matrix`` for integral i."""
+    V0, V1 = form.function_spaces
+    integ = form.integrals[i]
+    md = D.mesh_device(form.mesh)
+    s0, s1 = D.space_device(V0), D.space_device(V1)
+    _, bc0 = D.bc_markers(V0, bcs, form._device)
+    _, bc1 = D.bc_markers(V1, bcs, form._device)
+    m0, k0 = mpc0._device()
+    m1, k1 = mpc1._device()
+    idv = D.integral_device(form, i)
+    _, slave_ents = _slave_entities(form, i, mpc0, mpc1)
+    a = _native.MatrixArgs()
+    a.nrows = A.shape[0]
+    a.rowptr, a.cols, a.vals = A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), A.vals.data_ptr()
+    a.kernel = idv["kernel"]
+    a.x, a.x_dofmap, a.nv = md["x"].data_ptr(), md["x_dofmap"].data_ptr(), form.mesh.geometry.dofmap.shape[1]
+    a.estride, a.n_entities = integ.estride, integ.num_entities
+    a.entities = a.entities0 = a.entities1 = idv["entities"].data_ptr()
+    a.coeffs = D.ptr(idv["coeffs"])
+    a.cstride = 0 if integ.coeffs is None else integ.coeffs.shape[1]
+    a.constants = D.ptr(idv["constants"])
+    a.dofmap0, a.nd0, a.bs0 = s0["dofmap"].data_ptr(), V0.element_ndofs, V0.dofmap.bs
+    a.dofmap1, a.nd1, a.bs1 = s1["dofmap"].data_ptr(), V1.element_ndofs, V1.dofmap.bs
+    a.bc0, a.bc1 = D.ptr(bc0), D.ptr(bc1)
+    a.mpc0, a.mpc1 = m0, m1
+    a.slave_entities = slave_ents.data_ptr()
+    a.n_slave_entities = slave_ents.numel() if with_mpc_kernel else 0
+    a.algorithm = alg
+    a.store_mode = store_mode
+    a.stream = D.stream_ptr()
+    keep = [md, s0, s1, bc0, bc1, k0, k1, idv, slave_ents]
+    if alg == 2:
+        plan, pk, _info = _rowblock_plan(A, form, i, V0)
+        a.plan = plan
+        keep.append(pk)
+    return a, keep
+
+
 def assemble_matrix(
     form: Form,
     constraint: Union[MultiPointConstraint, Sequence[MultiPointConstraint]],
@@ -151,46 +191,21 @@ def assemble_matrix(
         alg = 1
 
     V0, V1 = form.function_spaces
-    md = D.mesh_device(form.mesh)
-    s0, s1 = D.space_device(V0), D.space_device(V1)
-    _, bc0 = D.bc_markers(V0, bcs, form._device)
-    _, bc1 = D.bc_markers(V1, bcs, form._device)
-    m0, _k0 = mpc0._device()
-    m1, _k1 = mpc1._device()
     stream = D.stream_ptr()
-
     zeroed = False
     for i, integ in enumerate(form.integrals):
         if integ.itype not in ("cell", "exterior_facet"):
             raise RuntimeError("Not implemented yet")  # cpp/assemble_matrix.cpp:658-659
-        idv = D.integral_device(form, i)
-        _, slave_ents = _slave_entities(form, i, mpc0, mpc1)
-        a = _native.MatrixArgs()
-        a.nrows = A.shape[0]
-        a.rowptr, a.cols, a.vals = A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), A.vals.data_ptr()
-        a.kernel = idv["kernel"]
-        a.x, a.x_dofmap, a.nv = md["x"].data_ptr(), md["x_dofmap"].data_ptr(), form.mesh.geometry.dofmap.shape[1]
-        a.estride, a.n_entities = integ.estride, integ.num_entities
-        a.entities = a.entities0 = a.entities1 = idv["entities"].data_ptr()
-        a.coeffs = D.ptr(idv["coeffs"])
-        a.cstride = 0 if integ.coeffs is None else integ.coeffs.shape[1]
-        a.constants = D.ptr(idv["constants"])
-        a.dofmap0, a.nd0, a.bs0 = s0["dofmap"].data_ptr(), V0.element_ndofs, V0.dofmap.bs
-        a.dofmap1, a.nd1, a.bs1 = s1["dofmap"].data_ptr(), V1.element_ndofs, V1.dofmap.bs
-        a.bc0, a.bc1 = D.ptr(bc0), D.ptr(bc1)
-        a.mpc0, a.mpc1 = m0, m1
-        a.slave_entities, a.n_slave_entities = slave_ents.data_ptr(), slave_ents.numel()
-        a.algorithm = alg
-        a.stream = stream
         if alg == 2:
-            plan, _keep, _info = _rowblock_plan(A, form, i, V0)
-            a.plan = plan
             # the first integral's row blocks overwrite every value: no memset pass
-            a.store_mode = 1 if not zeroed else 0
+            store_mode = 0 if zeroed else 1
             zeroed = True
-        elif not zeroed:
-            A.zeroEntries()  # python/src/dolfinx_mpc/assemble_matrix.py:51
-            zeroed = True
+        else:
+            store_mode = 0
+            if not zeroed:
+                A.zeroEntries()  # python/src/dolfinx_mpc/assemble_matrix.py:51
+                zeroed = True
+        a, _keep = matrix_args(form, i, A, mpc0, mpc1, bcs, alg, store_mode)
         _native.check(L.mpcx_assemble_matrix(C.byref(a)), "mpcx_assemble_matrix")
     if not zeroed:
         A.zeroEntries()

@@ -166,7 +166,15 @@ class MultiPointConstraint:
         for bc in bcs:
             bc.mark_dofs(is_bc)
         xm = np.asarray(relation(x[blocks].T)).T
-        dist, mblk = cKDTree(x).query(xm)
+        if blocks.size == 0:
+            return
+        # only dofs inside the bounding box of the mapped points can be masters
+        lo, hi = xm.min(axis=0) - tol, xm.max(axis=0) + tol
+        cand = np.flatnonzero(np.all((x >= lo) & (x <= hi), axis=1))
+        if cand.size == 0:
+            raise NotImplementedError("no dof at the mapped slave coordinates (non-matching meshes are out of scope)")
+        dist, loc = cKDTree(x[cand]).query(xm)
+        mblk = cand[loc]
         if blocks.size and dist.max() > tol:
             raise NotImplementedError(
                 "periodic constraint on non-matching nodes needs basis evaluation at the mapped "
