@@ -1,0 +1,275 @@
+"""CPU tests of the product's host logic (no GPU compute):
+
+* libmpcx.so loads and exports every symbol include/mpcx.h declares;
+* native MultiPointConstraint finalize / cell_to_slaves / sparsity pattern /
+  row-block plan against the oracle's numpy restatements of
+  cpp/MultiPointConstraint.h:36-126, cpp/mpc_helpers.h:19-94, cpp/utils.h:381-496;
+* API behaviour mirrored from python/src/dolfinx_mpc/multipointconstraint.py
+  (add_constraint concatenation, finalize once, accessors) and the error
+  conventions of SURVEY.md section 8b;
+* the product fails loudly without a GPU (no CPU fallback).
+"""
+
+import os
+import re
+
+import numpy as np
+import pytest
+
+import dolfinx_mpc_amd as dm
+from dolfinx_mpc_amd import _native, fem
+from dolfinx_mpc_amd.mesh import create_unit_cube, create_unit_square
+from problems import all_small_cases, case_cube_periodic, l2b, oracle_mpc, product_mpc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _native.lib()
+    header = open(os.path.join(ROOT, "include", "mpcx.h")).read()
+    declared = set(re.findall(r"\b(mpcx_[a-z_0-9]+)\s*\(", header))
+    assert declared, "no declarations found"
+    assert declared == set(_native.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), f"libmpcx.so does not export {name}"
+    assert L.mpcx_version() == 1
+
+
+def test_ctypes_structs_match_header_field_order():
+    header = open(os.path.join(ROOT, "include", "mpcx.h")).read()
+
+    def fields(struct_name):
+        end = re.search(r"\}\s*" + struct_name + ";", header).start()
+        start = header.rfind("typedef struct", 0, end)
+        body = header[header.index("{", start) + 1 : end]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if decl:
+                names.append(re.findall(r"([A-Za-z_0-9]+)\s*$", decl)[0])
+        return names
+
+    assert fields("mpcx_kernel_t") == [f[0] for f in _native.KernelT._fields_]
+    assert fields("mpcx_mpc_t") == [f[0] for f in _native.MpcT._fields_]
+    assert fields("mpcx_rowblock_plan_t") == [f[0] for f in _native.RowBlockPlanT._fields_]
+    assert fields("mpcx_matrix_args_t") == [f[0] for f in _native.MatrixArgs._fields_]
+    assert fields("mpcx_vector_args_t") == [f[0] for f in _native.VectorArgs._fields_]
+    assert fields("mpcx_lifting_args_t") == [f[0] for f in _native.LiftingArgs._fields_]
+
+
+CASES = all_small_cases()
+
+
+@pytest.mark.parametrize("make", CASES, ids=[f"case{i}" for i in range(len(CASES))])
+def test_finalize_c2s_pattern_match_oracle(oracle, make):
+    case = make()
+    mpc = product_mpc(case)
+    om = oracle_mpc(oracle, case)
+    assert np.array_equal(mpc.is_slave, om.is_slave)
+    assert np.array_equal(mpc.slaves, om.slaves)
+    assert mpc.num_local_slaves == om.num_local_slaves
+    assert np.array_equal(mpc.masters.offsets, om.masters_offsets)
+    assert np.array_equal(mpc.masters.array, om.masters)
+    assert np.array_equal(mpc.coefficients()[0], om.coeffs)
+    assert np.array_equal(mpc.coefficients()[1], om.masters_offsets)
+    assert np.array_equal(mpc.cell_to_slaves.offsets, om.c2s_offsets)
+    assert np.array_equal(mpc.cell_to_slaves.array, om.c2s)
+    if case.a is not None:
+        rp, cl = dm.create_sparsity_pattern(case.a, mpc)
+        rp2, cl2 = oracle.create_pattern(case.a, om, om)
+        assert np.array_equal(rp, rp2) and np.array_equal(cl, cl2)
+        # sorted, unique columns per row
+        for r in range(rp.size - 1):
+            row = cl[rp[r] : rp[r + 1]]
+            assert np.all(np.diff(row) > 0)
+
+
+def test_pattern_threads_and_rectangular_pair(oracle):
+    case = case_cube_periodic(4, 1, 0.0)
+    mpc = product_mpc(case)
+    p1 = dm.create_sparsity_pattern(case.a, mpc, num_threads=1)
+    p8 = dm.create_sparsity_pattern(case.a, mpc, num_threads=8)
+    assert np.array_equal(p1[0], p8[0]) and np.array_equal(p1[1], p8[1])
+    # (mpc, empty) pair: python/tests/test_rectangular_assembly.py style row/col constraints
+    emp = dm.MultiPointConstraint(case.V)
+    emp.finalize()
+    rp, cl = dm.create_sparsity_pattern(case.a, (mpc, emp))
+    om, oe = oracle_mpc(oracle, case), oracle.OracleMPC.empty(case.V)
+    rp2, cl2 = oracle.create_pattern(case.a, om, oe)
+    assert np.array_equal(rp, rp2) and np.array_equal(cl, cl2)
+
+
+def test_rowblock_plan_covers_every_entity_row_pair():
+    case = case_cube_periodic(5, 1, 0.0, reorder=(4, 4, 4))
+    mpc = product_mpc(case)
+    rowptr, cols = dm.create_sparsity_pattern(case.a, mpc)
+    L = _native.lib()
+    p = _native._ptr
+    dmap = case.V.dofmap.list
+    ents = np.arange(dmap.shape[0], dtype=np.int32)
+    for max_rows, max_nnz in ((64, 600), (1000, 5120), (7, 100)):
+        h = L.mpcx_rowblock_plan_build(rowptr.size - 1, p(rowptr), max_rows, max_nnz, ents.size, 1, p(ents), p(dmap),
+                                       dmap.shape[1], 1, 1)
+        assert h
+        nb = L.mpcx_rowblock_plan_num_blocks(h)
+        row0 = np.empty(nb + 1, dtype=np.int32)
+        off = np.empty(nb + 1, dtype=np.int64)
+        be = np.empty(L.mpcx_rowblock_plan_num_ents(h), dtype=np.int32)
+        L.mpcx_rowblock_plan_copy(h, p(row0), p(off), p(be))
+        L.mpcx_rowblock_plan_free(h)
+        assert row0[0] == 0 and row0[-1] == rowptr.size - 1 and np.all(np.diff(row0) > 0)
+        assert np.diff(row0).max() <= max_rows and np.diff(rowptr[row0]).max() <= max_nnz
+        blk_of = np.repeat(np.arange(nb), np.diff(row0))
+        # every (entity, block of one of its dofs) pair appears exactly once
+        want = set()
+        for e in ents:
+            for b in set(blk_of[dmap[e]]):
+                want.add((int(b), int(e)))
+        got = set()
+        for b in range(nb):
+            lst = be[off[b] : off[b + 1]]
+            assert np.all(np.diff(lst) > 0)
+            got.update((b, int(e)) for e in lst)
+        assert got == want
+
+
+def test_add_constraint_concatenation_and_finalize_once():
+    """python/src/dolfinx_mpc/multipointconstraint.py:118-153, 619-631"""
+    mesh = create_unit_square(4, 4)
+    V = fem.functionspace(mesh, ("Lagrange", 1))
+    mpc = dm.MultiPointConstraint(V)
+    with pytest.raises(RuntimeError, match="has not been finalized"):
+        _ = mpc.slaves
+    mpc.add_constraint(V, np.array([3], dtype=np.int32), np.array([0, 1], dtype=np.int64), np.array([0.5, 0.25]),
+                       np.zeros(2, dtype=np.int32), np.array([0, 2], dtype=np.int32))
+    mpc.add_constraint(V, np.array([7, 5], dtype=np.int32), np.array([2, 4, 6], dtype=np.int64), np.array([1.0, 2.0, 3.0]),
+                       np.zeros(3, dtype=np.int32), np.array([0, 1, 3], dtype=np.int32))
+    # empty additions are ignored
+    mpc.add_constraint(V, np.array([], dtype=np.int32), np.array([], dtype=np.int64), np.array([]),
+                       np.array([], dtype=np.int32), np.array([0], dtype=np.int32))
+    assert np.array_equal(mpc._offsets, [0, 2, 3, 5])
+    mpc.finalize()
+    assert np.array_equal(mpc.slaves, [3, 5, 7])
+    assert np.array_equal(mpc.masters.links(3), [0, 1])
+    assert np.array_equal(mpc.masters.links(7), [2])
+    assert np.array_equal(mpc.masters.links(5), [4, 6])
+    assert mpc.masters.num_links(0) == 0
+    c, off = mpc.coefficients()
+    assert np.array_equal(c[off[5] : off[6]], [2.0, 3.0])
+    assert mpc.num_local_slaves == 3 and mpc.function_space is V
+    with pytest.raises(RuntimeError, match="already been finalized"):
+        mpc.finalize()
+    with pytest.raises(RuntimeError, match="already been finalized"):
+        mpc.add_constraint(V, np.array([1], dtype=np.int32), np.array([0], dtype=np.int64), np.array([1.0]),
+                           np.zeros(1, dtype=np.int32), np.array([0, 1], dtype=np.int32))
+    with pytest.raises(NotImplementedError):
+        dm.MultiPointConstraint(V, dtype=np.complex128)
+
+
+def test_finalize_rejects_bad_indices():
+    mesh = create_unit_square(2, 2)
+    V = fem.functionspace(mesh, ("Lagrange", 1))
+    mpc = dm.MultiPointConstraint(V)
+    mpc.add_constraint(V, np.array([1], dtype=np.int32), np.array([10**6], dtype=np.int64), np.array([1.0]),
+                       np.zeros(1, dtype=np.int32), np.array([0, 1], dtype=np.int32))
+    with pytest.raises(RuntimeError, match="master index out of range"):
+        mpc.finalize()
+
+
+def test_convenience_builders_match_raw_arrays(oracle):
+    from problems import case_cube_elasticity_slip, case_square_dict, case_vector_poisson, periodic_raw
+
+    # general (dict) constraint
+    case = case_square_dict(2, (0, 1))
+    mpc = dm.MultiPointConstraint(case.V)
+    mpc.create_general_constraint({l2b([1, 0]): {l2b([0, 1]): 0.43, l2b([1, 1]): 0.11}, l2b([0, 0]): {l2b([0, 1]): 0.69}})
+    mpc.finalize()
+    om = oracle_mpc(oracle, case)
+    assert np.array_equal(mpc.slaves, om.slaves) and np.array_equal(mpc.masters.array, om.masters)
+    assert np.array_equal(mpc.coefficients()[0], om.coeffs)
+    # sub-space variant
+    case = case_vector_poisson(1, 0)
+    mpc = dm.MultiPointConstraint(case.V)
+    mpc.create_general_constraint({l2b([1, 0]): {l2b([1, 1]): 0.1, l2b([0.5, 1]): 0.3}}, 1, 0)
+    mpc.finalize()
+    om = oracle_mpc(oracle, case)
+    assert np.array_equal(mpc.slaves, om.slaves) and np.array_equal(mpc.masters.array, om.masters)
+    # periodic, geometrical
+    case = case_cube_periodic(3, 2, 0.0)
+    mpc = dm.MultiPointConstraint(case.V)
+
+    def rel(x):
+        out = x.copy()
+        out[0] = 1 - x[0]
+        return out
+
+    mpc.create_periodic_constraint_geometrical(case.V, lambda x: np.isclose(x[0], 1), rel, case.bcs)
+    mpc.finalize()
+    om = oracle_mpc(oracle, case)
+    assert np.array_equal(mpc.slaves, om.slaves) and np.array_equal(mpc.masters.array, om.masters)
+    with pytest.raises(NotImplementedError):
+        m2 = dm.MultiPointConstraint(case.V)
+        m2.create_periodic_constraint_geometrical(case.V, lambda x: np.isclose(x[0], 1),
+                                                  lambda x: x * np.array([[0.0], [0.937], [1.0]]), case.bcs)
+    # slip
+    case = case_cube_elasticity_slip(3)
+    x = case.V.tabulate_dof_coordinates()
+    blocks = np.flatnonzero(np.isclose(x[:, 0], 1.0))
+    nrm = np.array([1.0, 0.3, -0.2])
+    nrm /= np.linalg.norm(nrm)
+    mpc = dm.MultiPointConstraint(case.V)
+    mpc.create_slip_constraint(case.V, blocks, np.tile(nrm, (blocks.size, 1)))
+    mpc.finalize()
+    om = oracle_mpc(oracle, case)
+    assert np.array_equal(mpc.slaves, om.slaves) and np.array_equal(mpc.masters.array, om.masters)
+    assert np.allclose(mpc.coefficients()[0], om.coeffs)
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device the assembly path must raise, not fall back."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    case = case_cube_periodic(2, 1, 0.0)
+    mpc = product_mpc(case)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dm.assemble_matrix(case.a, mpc, bcs=case.bcs)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dm.assemble_vector(case.L, mpc)
+    src = ""
+    pkg = os.path.join(ROOT, "dolfinx_mpc_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                src += open(os.path.join(dirpath, f)).read()
+    assert "pyoracle" not in src and "mpc_oracle" not in src and "import oracle" not in src
+
+
+def test_form_errors_mirror_reference():
+    case = case_cube_periodic(2, 1, 0.0)
+    mpc = product_mpc(case)
+    with pytest.raises(RuntimeError, match="not a bilinear form"):
+        dm.create_sparsity_pattern(case.L, mpc)
+    unfinal = dm.MultiPointConstraint(case.V)
+    with pytest.raises(RuntimeError, match="has not been finalized"):
+        dm.create_sparsity_pattern(case.a, unfinal)
+
+
+def test_mesh_generators_counts_and_tiling():
+    n = 4
+    m = create_unit_cube(n, n, n)
+    assert m.num_cells == 6 * n**3 and m.num_nodes == (n + 1) ** 3
+    vol = np.abs(np.linalg.det(m.geometry.x[m.geometry.dofmap[:, 1:]] - m.geometry.x[m.geometry.dofmap[:, :1]])) / 6
+    assert vol.sum() == pytest.approx(1.0)
+    mt = create_unit_cube(n, n, n, reorder=(2, 2, 2))
+    # same set of cells (as coordinate sets), different numbering
+    def key(mesh):
+        c = mesh.geometry.x[mesh.geometry.dofmap].reshape(mesh.num_cells, -1)
+        return np.sort(np.round(c * 64).astype(np.int64) @ (7 ** np.arange(12) % 1000003))
+    assert np.array_equal(key(m), key(mt))
+    assert len(m.exterior_facets()) == 12 * n * n
+    V2 = fem.functionspace(m, ("Lagrange", 2))
+    E = 3 * n * (n + 1) ** 2 + 3 * n * n * (n + 1) + n**3
+    assert V2.num_dofs == (n + 1) ** 3 + E == (2 * n + 1) ** 3
