@@ -38,21 +38,26 @@ def log(*a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def build_problem(N: int, reorder, zslab=(0, 1)):
-    """mesh, space, bc, constraint, forms of the periodic Poisson benchmark."""
+def build_problem(N: int, reorder, rank=0, world=1):
+    """mesh, space, bc, constraint, forms of the periodic Poisson benchmark.
+    world > 1: rank's z-slab of the (N, N, N*world) mesh on [0,1]^2 x [0,world]."""
     from dolfinx_mpc_amd import MultiPointConstraint, fem
+    from dolfinx_mpc_amd.distributed import create_slab_mesh
     from dolfinx_mpc_amd.mesh import create_box
 
     t = time.time()
-    z0, z1 = zslab
-    mesh = create_box((0.0, 0.0, float(z0)), (1.0, 1.0, float(z1)), (N, N, N * (z1 - z0)), "tetrahedron", reorder)
+    if world == 1:
+        mesh = create_box((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), (N, N, N), "tetrahedron", reorder)
+    else:
+        mesh = create_slab_mesh(N, rank, world, reorder)
+    zmax = float(world)
     V = fem.functionspace(mesh, ("Lagrange", 1))
     log(f"mesh: {mesh.num_cells} cells, {V.num_dofs} dofs ({time.time() - t:.1f}s)")
 
     t = time.time()
 
     def dirichletboundary(x):  # bench_periodic.py:49-55 (global walls y,z in {0,1})
-        return np.isclose(x[1], 0) | np.isclose(x[1], 1) | np.isclose(x[2], 0) | np.isclose(x[2], 1)
+        return np.isclose(x[1], 0) | np.isclose(x[1], 1) | np.isclose(x[2], 0) | np.isclose(x[2], zmax)
 
     bdofs = fem.locate_dofs_geometrical(V, dirichletboundary)
     bc = fem.dirichletbc(0.0, bdofs, V)
@@ -127,7 +132,7 @@ def main():
     am = sys.modules["dolfinx_mpc_amd.assemble_matrix"]  # the module (the package re-exports the function)
 
     t_setup = time.time()
-    mesh, V, bc, mpc, a, L = build_problem(N, reorder, zslab=(rank, rank + 1) if world > 1 else (0, 1))
+    mesh, V, bc, mpc, a, L = build_problem(N, reorder, rank, world)
     t = time.time()
     rowptr, cols = dm.create_sparsity_pattern(a, mpc)
     log(f"pattern: nnz {cols.size} ({time.time() - t:.1f}s)")
@@ -151,7 +156,7 @@ def main():
     if world > 1:
         from dolfinx_mpc_amd.distributed import SlabExchange
 
-        exchange = SlabExchange(mesh, V, A, rank, world)
+        exchange = SlabExchange(mesh, rowptr, cols, rank, world, device=torch.device("cuda", local_rank))
 
     def step_matrix():
         dm.assemble_matrix(a, mpc, bcs=bcs, A=A, algorithm=args.alg)
@@ -230,9 +235,9 @@ def main():
         return
 
     ndofs_rank = V.num_dofs
-    # every rank owns its box minus the shared top plane (owned by the upper neighbour's... lower rank)
-    ndofs_total = ndofs_rank * world - (world - 1) * (N + 1) ** 2
-    nc, nv, nd = mesh.num_cells, 4, 4
+    # global dof count of the (N, N, N*world) mesh: interface planes counted once
+    ndofs_total = (N + 1) ** 2 * (N * world + 1)
+    nc, nv, nd = mesh.num_owned_cells, 4, 4
     alg_bytes = 4 * nv * nc + 4 * nd * nc + 24 * mesh.num_nodes + 8 * cols.size + 2 * V.num_dofs
     peak = 8000.0  # GB/s, HBM3E spec (MI355X_MICROARCH.md)
     achieved = alg_bytes / (t_bulk * 1e-3) / 1e9

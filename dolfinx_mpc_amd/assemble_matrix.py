@@ -48,8 +48,8 @@ def create_sparsity_pattern(form: Form, mpc: Union[MultiPointConstraint, Sequenc
     if num_threads <= 0:
         num_threads = min(os.cpu_count() or 1, 16)
     h = L.mpcx_pattern_build(
-        dm0.shape[0], p(dm0), dm0.shape[1], V0.dofmap.bs, V0.dofmap.index_map.size_local, p(dm1), dm1.shape[1],
-        V1.dofmap.bs, V1.dofmap.index_map.size_local,
+        dm0.shape[0], p(dm0), dm0.shape[1], V0.dofmap.bs, V0.num_dofs // V0.dofmap.bs, p(dm1), dm1.shape[1],
+        V1.dofmap.bs, V1.num_dofs // V1.dofmap.bs,
         p(mpc0.cell_to_slaves.offsets), p(mpc0.cell_to_slaves.array), p(mpc0.masters.offsets), p(mpc0.masters.array),
         p(mpc1.cell_to_slaves.offsets), p(mpc1.cell_to_slaves.array), p(mpc1.masters.offsets), p(mpc1.masters.array),
         num_threads,
@@ -226,7 +226,8 @@ def assemble_matrix(
                 continue
             key = ("bcdofs", str(A.device), id(bc))
             if key not in form._device:
-                form._device[key] = D._to_dev(bc.dof_indices()[0], A.device)
+                dofs_h, nowned = bc.dof_indices()  # owned dofs only, like dolfinx insert_diagonal
+                form._device[key] = D._to_dev(dofs_h[:nowned], A.device)
             dofs = form._device[key]
             _native.check(
                 L.mpcx_add_diagonal(A.shape[0], A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), A.vals.data_ptr(),

@@ -49,9 +49,9 @@ class IndexMap:
 
 
 class DofMap:
-    def __init__(self, cell_dofs: np.ndarray, num_blocks: int, bs: int):
+    def __init__(self, cell_dofs: np.ndarray, num_blocks: int, bs: int, num_ghosts: int = 0):
         self.list = np.ascontiguousarray(cell_dofs, dtype=np.int32)  # (num_cells, nd) blocked dofs
-        self.index_map = IndexMap(num_blocks)
+        self.index_map = IndexMap(num_blocks, num_ghosts)
         self.index_map_bs = int(bs)
         self.bs = int(bs)
 
@@ -75,14 +75,18 @@ class FunctionSpace:
         self.mesh = mesh
         self.degree = degree
         bs = 1 if not shape else int(shape[0])
+        nghost = 0
         if degree == 1:
             cell_dofs = mesh.geometry.dofmap.copy()
-            nblocks = mesh.num_nodes
+            nblocks = mesh.num_owned_nodes
+            nghost = mesh.num_nodes - mesh.num_owned_nodes
         else:
+            if mesh.num_owned_nodes != mesh.num_nodes:
+                raise NotImplementedError("P2 spaces on partitioned meshes")
             cell_edges, _ = mesh.edges()
             cell_dofs = np.concatenate([mesh.geometry.dofmap, cell_edges + mesh.num_nodes], axis=1)
             nblocks = mesh.num_nodes + int(cell_edges.max()) + 1
-        self.dofmap = DofMap(cell_dofs, nblocks, bs)
+        self.dofmap = DofMap(cell_dofs, nblocks, bs, nghost)
         self._dof_coords = None
         self._device = {}
 
@@ -158,7 +162,13 @@ class DirichletBC:
         self.value = value
 
     def dof_indices(self):
-        return self._dofs, self._dofs.size
+        """(unrolled dofs, number of owned ones first) like dolfinx DirichletBC.dof_indices"""
+        V = self.function_space
+        nowned = V.dofmap.index_map.size_local * V.dofmap.index_map_bs
+        owned = self._dofs < nowned
+        if not owned.all():
+            self._dofs = np.concatenate([self._dofs[owned], self._dofs[~owned]])
+        return self._dofs, int(owned.sum())
 
     def mark_dofs(self, markers: np.ndarray):
         markers[self._dofs] = 1
@@ -252,7 +262,8 @@ def _pack_coefficient(coefficient: Optional[Function], cells: np.ndarray):
 
 def _cells_or_all(mesh: Mesh, cells) -> np.ndarray:
     if cells is None:
-        return np.arange(mesh.num_cells, dtype=np.int32)
+        # owned cells only, like a DOLFINx Form's default cell domain
+        return np.arange(mesh.num_owned_cells, dtype=np.int32)
     return np.ascontiguousarray(cells, dtype=np.int32)
 
 

@@ -45,6 +45,10 @@ class Mesh:
         self._exterior_facets = None
         self._edges = None
         self._device = {}
+        # single process by default; dolfinx_mpc_amd.distributed.create_slab_mesh overrides
+        self.num_owned_nodes = self.geometry.x.shape[0]
+        self.num_owned_cells = self.geometry.dofmap.shape[0]
+        self.node_global = None
 
     @property
     def num_cells(self) -> int:

@@ -263,8 +263,8 @@ def _ents(integ):
 
 def create_pattern(form, mpc0: OracleMPC, mpc1: OracleMPC):
     V0, V1 = mpc0.V, mpc1.V
-    return sparsity_pattern_np(V0.dofmap.list, V0.dofmap.bs, V0.dofmap.index_map.size_local, V1.dofmap.list,
-                               V1.dofmap.bs, V1.dofmap.index_map.size_local, mpc0.as_dict(), mpc1.as_dict())
+    return sparsity_pattern_np(V0.dofmap.list, V0.dofmap.bs, V0.dofmap.index_map.size_local + V0.dofmap.index_map.num_ghosts, V1.dofmap.list,
+                               V1.dofmap.bs, V1.dofmap.index_map.size_local + V1.dofmap.index_map.num_ghosts, mpc0.as_dict(), mpc1.as_dict())
 
 
 def assemble_matrix(form, mpc0: OracleMPC, mpc1: OracleMPC = None, bcs=(), diagval=1.0, pattern=None, fast=False,
@@ -308,7 +308,8 @@ def assemble_matrix(form, mpc0: OracleMPC, mpc1: OracleMPC = None, bcs=(), diagv
     if same_space:
         for bc in bcs:
             if V0.contains(bc.function_space):
-                dofs = np.ascontiguousarray(bc.dof_indices()[0], dtype=np.int32)
+                d_all, nowned = bc.dof_indices()
+                dofs = np.ascontiguousarray(d_all[:nowned], dtype=np.int32)
                 L.oracle_insert_diagonal(C.byref(csr), _p(dofs), dofs.size, float(diagval))
     if csr.missing:
         raise RuntimeError(f"oracle: {csr.missing} insertions outside the pattern")

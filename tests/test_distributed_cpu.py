@@ -1,0 +1,171 @@
+"""world_size-2 / 3 gloo tests (CPU) of the multi-GPU partition and the
+interface-row exchange (dolfinx_mpc_amd/distributed.py).  The per-rank local
+assembly is done by the CPU oracle here (the HIP kernels need a GPU); what is
+under test is the host logic the N>1 path adds: slab meshes with owned/ghost
+numbering, the integration domain (owned cells), owned-only diagonals, and the
+neighbour exchange + scatter-add.  The result (owned rows, in global numbering)
+must equal a single-process assembly of the global mesh."""
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _problem(mesh, world, N):
+    from dolfinx_mpc_amd import fem
+    from problems import periodic_raw
+
+    V = fem.functionspace(mesh, ("Lagrange", 1))
+    zmax = float(world)
+    dofs = fem.locate_dofs_geometrical(
+        V, lambda x: np.isclose(x[1], 0) | np.isclose(x[1], 1) | np.isclose(x[2], 0) | np.isclose(x[2], zmax))
+    bc = fem.dirichletbc(0.7, dofs, V)
+    raw = periodic_raw(V, [bc])
+    return V, bc, raw, fem.form_stiffness(V), fem.form_source(V, fem.FN_BENCH_PERIODIC)
+
+
+def _worker(rank, world, port, N, reorder, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    from dolfinx_mpc_amd.distributed import SlabExchange, create_slab_mesh
+    from oracle import pyoracle as po
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mesh = create_slab_mesh(N, rank, world, reorder)
+    V, bc, raw, a, L = _problem(mesh, world, N)
+    mpc = po.OracleMPC.from_raw(V, *raw)
+    pattern = po.create_pattern(a, mpc, mpc)
+    A = po.assemble_matrix(a, mpc, bcs=[bc], pattern=pattern)  # owned cells, owned-only diagonals
+    b = po.assemble_vector(L, mpc)
+    po.apply_lifting(b, [a], [[bc]], mpc)
+    ex = SlabExchange(mesh, pattern[0], pattern[1], rank, world)
+    vals = torch.from_numpy(A.data.copy())
+    bt = torch.from_numpy(b.copy())
+    ex.reduce_matrix(vals)
+    ex.reduce_vector(bt)
+    A = scipy.sparse.csr_matrix((vals.numpy(), A.indices, A.indptr), shape=A.shape)
+    g = mesh.node_global
+    nown = mesh.num_owned_nodes
+    Aown = A[:nown].tocoo()
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), row=g[Aown.row], col=g[Aown.col], val=Aown.data,
+             brow=g[:nown], bval=bt.numpy()[:nown], nslaves=mpc.num_local_slaves)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,N,reorder", [(2, 4, None), (2, 4, (2, 2, 2)), (3, 3, (2, 2, 2))])
+def test_slab_partition_matches_global_assembly(oracle, tmp_path, world, N, reorder):
+    import torch.multiprocessing as mp
+
+    from dolfinx_mpc_amd.mesh import create_box
+
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, N, reorder, str(tmp_path)), nprocs=world, join=True)
+
+    gmesh = create_box((0, 0, 0), (1, 1, float(world)), (N, N, N * world))
+    V, bc, raw, a, L = _problem(gmesh, world, N)
+    mpc = oracle.OracleMPC.from_raw(V, *raw)
+    Aref = oracle.assemble_matrix(a, mpc, bcs=[bc])
+    bref = oracle.assemble_vector(L, mpc)
+    oracle.apply_lifting(bref, [a], [[bc]], mpc)
+
+    n = V.num_dofs
+    rows, cols, vals, brow, bval, nsl = [], [], [], [], [], 0
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        rows.append(d["row"]), cols.append(d["col"]), vals.append(d["val"])
+        brow.append(d["brow"]), bval.append(d["bval"])
+        nsl += int(d["nslaves"])
+    A = scipy.sparse.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsr()
+    # every row is owned exactly once
+    assert np.array_equal(np.sort(np.concatenate(brow)), np.arange(n))
+    assert nsl == mpc.num_local_slaves
+    assert abs(A - Aref).max() < 1e-12 * abs(Aref).max()
+    b = np.zeros(n)
+    b[np.concatenate(brow)] = np.concatenate(bval)
+    assert np.allclose(b, bref, rtol=0, atol=1e-13 * abs(bref).max())
+
+
+def _gpu_worker(rank, world, port, N, reorder, outdir):
+    """Same as _worker but the local assembly runs through the HIP kernels (both
+    ranks share cuda:0; transport is gloo with host staging because RCCL refuses
+    two ranks on one device)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd.distributed import SlabExchange, create_slab_mesh
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mesh = create_slab_mesh(N, rank, world, reorder)
+    V, bc, raw, a, L = _problem(mesh, world, N)
+    mpc = dm.MultiPointConstraint(V)
+    mpc.add_constraint(V, *raw)
+    mpc.finalize()
+    A = dm.assemble_matrix(a, mpc, bcs=[bc], algorithm="rowblock")
+    b = dm.assemble_vector(L, mpc)
+    dm.apply_lifting(b, [a], [[bc]], mpc)
+    ex = SlabExchange(mesh, A.rowptr, A.cols, rank, world, device=torch.device("cuda", 0))
+    ex.reduce_matrix(A)
+    ex.reduce_vector(b)
+    torch.cuda.synchronize()
+    S = A.to_scipy()
+    g = mesh.node_global
+    nown = mesh.num_owned_nodes
+    Aown = S[:nown].tocoo()
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), row=g[Aown.row], col=g[Aown.col], val=Aown.data,
+             brow=g[:nown], bval=b.numpy()[:nown], nslaves=mpc.num_local_slaves)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_slab_partition_gpu_kernels_two_ranks(oracle, tmp_path):
+    import torch.multiprocessing as mp
+
+    from dolfinx_mpc_amd.mesh import create_box
+
+    world, N, reorder = 2, 6, (4, 4, 4)
+    port = _free_port()
+    mp.spawn(_gpu_worker, args=(world, port, N, reorder, str(tmp_path)), nprocs=world, join=True)
+    gmesh = create_box((0, 0, 0), (1, 1, float(world)), (N, N, N * world))
+    V, bc, raw, a, L = _problem(gmesh, world, N)
+    mpc = oracle.OracleMPC.from_raw(V, *raw)
+    Aref = oracle.assemble_matrix(a, mpc, bcs=[bc])
+    bref = oracle.assemble_vector(L, mpc)
+    oracle.apply_lifting(bref, [a], [[bc]], mpc)
+    n = V.num_dofs
+    rows, cols, vals, brow, bval = [], [], [], [], []
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        rows.append(d["row"]), cols.append(d["col"]), vals.append(d["val"])
+        brow.append(d["brow"]), bval.append(d["bval"])
+    A = scipy.sparse.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsr()
+    assert abs(A - Aref).max() < 1e-12 * abs(Aref).max()
+    b = np.zeros(n)
+    b[np.concatenate(brow)] = np.concatenate(bval)
+    assert np.allclose(b, bref, rtol=0, atol=1e-12 * abs(bref).max())
