@@ -46,9 +46,11 @@ class RowBlockPlanT(C.Structure):
         ("num_blocks", C.c_int32),
         ("max_rows", C.c_int32),
         ("max_nnz", C.c_int32),
+        ("max_pad", C.c_int32),
         ("block_row0", C.c_void_p),
         ("block_ent_off", C.c_void_p),
         ("block_ents", C.c_void_p),
+        ("row_pad_off", C.c_void_p),
     ]
 
 
@@ -85,6 +87,8 @@ class MatrixArgs(C.Structure):
         ("algorithm", C.c_int32),
         ("store_mode", C.c_int32),
         ("plan", RowBlockPlanT),
+        ("mdofmap0", C.c_void_p),
+        ("mdofmap1", C.c_void_p),
         ("stream", C.c_void_p),
     ]
 
@@ -148,6 +152,7 @@ class LiftingArgs(C.Structure):
 # every symbol include/mpcx.h declares
 EXPORTS = [
     "mpcx_assemble_matrix",
+    "mpcx_mask_dofmap",
     "mpcx_add_diagonal",
     "mpcx_assemble_vector",
     "mpcx_apply_lifting",
@@ -223,13 +228,15 @@ def lib() -> C.CDLL:
     L.mpcx_pattern_copy.restype = C.c_int
     L.mpcx_pattern_free.argtypes = [vp]
     L.mpcx_pattern_free.restype = None
-    L.mpcx_rowblock_plan_build.argtypes = [i32, vp, i32, i32, i64, i32, vp, vp, i32, i32, i32]
+    L.mpcx_mask_dofmap.argtypes = [vp, i64, i32, vp, vp, vp, vp]
+    L.mpcx_mask_dofmap.restype = C.c_int
+    L.mpcx_rowblock_plan_build.argtypes = [i32, vp, i32, i32, i64, i32, vp, vp, i32, i32, vp, i32, i32]
     L.mpcx_rowblock_plan_build.restype = vp
     L.mpcx_rowblock_plan_num_blocks.argtypes = [vp]
     L.mpcx_rowblock_plan_num_blocks.restype = i32
     L.mpcx_rowblock_plan_num_ents.argtypes = [vp]
     L.mpcx_rowblock_plan_num_ents.restype = i64
-    L.mpcx_rowblock_plan_copy.argtypes = [vp, vp, vp, vp]
+    L.mpcx_rowblock_plan_copy.argtypes = [vp, vp, vp, vp, vp]
     L.mpcx_rowblock_plan_copy.restype = C.c_int
     L.mpcx_rowblock_plan_free.argtypes = [vp]
     L.mpcx_rowblock_plan_free.restype = None

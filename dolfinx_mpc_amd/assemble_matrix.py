@@ -19,8 +19,8 @@ from .multipointconstraint import MultiPointConstraint
 _ALG = {"auto": 0, "atomic": 1, "rowblock": 2}
 
 # LDS budget of one row block: max_nnz * (8 B value + 4 B column) + row offsets
-ROWBLOCK_MAX_NNZ = int(os.environ.get("MPCX_ROWBLOCK_MAX_NNZ", 5120))
-ROWBLOCK_MAX_ROWS = int(os.environ.get("MPCX_ROWBLOCK_MAX_ROWS", 1024))
+ROWBLOCK_MAX_NNZ = int(os.environ.get("MPCX_ROWBLOCK_MAX_NNZ", 4608))
+ROWBLOCK_MAX_ROWS = int(os.environ.get("MPCX_ROWBLOCK_MAX_ROWS", 256))
 
 
 def _pair(constraint):
@@ -92,8 +92,13 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0):
         integ = form.integrals[i]
         ents = np.ascontiguousarray(integ.entities.astype(np.int32).reshape(-1))
         dm = V0.dofmap.list
+        # numbering hint: first row of every tile of a tiled P1 numbering
+        hints = None
+        if V0.degree == 1 and form.mesh.node_tile_offsets is not None:
+            hints = np.ascontiguousarray(form.mesh.node_tile_offsets.astype(np.int32) * V0.dofmap.bs)
         h = L.mpcx_rowblock_plan_build(A.shape[0], p(A.rowptr), ROWBLOCK_MAX_ROWS, ROWBLOCK_MAX_NNZ,
-                                       integ.num_entities, integ.estride, p(ents), p(dm), dm.shape[1], V0.dofmap.bs, 1)
+                                       integ.num_entities, integ.estride, p(ents), p(dm), dm.shape[1], V0.dofmap.bs,
+                                       None if hints is None else p(hints), 0 if hints is None else hints.size, 1)
         if not h:
             raise RuntimeError("mpcx_rowblock_plan_build failed: " + L.mpcx_last_error().decode())
         try:
@@ -101,16 +106,43 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0):
             row0 = np.empty(nb + 1, dtype=np.int32)
             off = np.empty(nb + 1, dtype=np.int64)
             ents_b = np.empty(L.mpcx_rowblock_plan_num_ents(h), dtype=np.int32)
-            L.mpcx_rowblock_plan_copy(h, p(row0), p(off), p(ents_b))
+            pad_off = np.empty(A.shape[0], dtype=np.int32)
+            L.mpcx_rowblock_plan_copy(h, p(row0), p(off), p(ents_b), p(pad_off))
         finally:
             L.mpcx_rowblock_plan_free(h)
         dev = A.device
-        t = (D._to_dev(row0, dev), D._to_dev(off, dev), D._to_dev(ents_b, dev))
+        t = (D._to_dev(row0, dev), D._to_dev(off, dev), D._to_dev(ents_b, dev), D._to_dev(pad_off, dev))
         max_rows = int(np.diff(row0).max())
         max_nnz = int(np.diff(A.rowptr[row0].astype(np.int64)).max())
-        s = _native.RowBlockPlanT(nb, max_rows, max_nnz, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr())
-        A._plans[key] = (s, t, {"num_blocks": nb, "num_ents": int(ents_b.size)})
+        last = row0[1:] - 1  # last row of each block: padded size = its offset + its padded length
+        max_pad = int((pad_off[last] + ((np.diff(A.rowptr)[last] + 3) & ~3)).max())
+        if np.diff(A.rowptr).max() > 1020:
+            raise RuntimeError("row-block algorithm: a row has more than 1020 nonzeros; use algorithm='atomic'")
+        s = _native.RowBlockPlanT(nb, max_rows, max_nnz, max_pad, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
+                                  t[3].data_ptr())
+        A._plans[key] = (s, t, {"num_blocks": nb, "num_ents": int(ents_b.size), "max_rows": max_rows,
+                                "max_nnz": max_nnz, "max_pad": max_pad})
     return A._plans[key]
+
+
+def _masked_dofmap(form: Form, V, bc_dev, mpc, which: int):
+    """dofmap with the Dirichlet/slave mask folded into bits 28.. (device, cached
+    per (space, bcs, constraint)): replaces the marker gathers of
+    cpp/assemble_matrix.cpp:511-533 and the is_slave look-ups in the bulk kernel."""
+    import torch
+
+    key = ("mdof", which, id(V), id(mpc), None if bc_dev is None else bc_dev.data_ptr())
+    if key not in form._device:
+        if V.num_dofs // V.dofmap.bs >= (1 << 28):
+            raise RuntimeError("row-block algorithm: more than 2^28 dof blocks per GPU; shard the mesh")
+        sd = D.space_device(V)
+        _, t = mpc._device()
+        out = torch.empty_like(sd["dofmap"])
+        rc = _native.lib().mpcx_mask_dofmap(sd["dofmap"].data_ptr(), sd["dofmap"].numel(), V.dofmap.bs, D.ptr(bc_dev),
+                                            t["is_slave"].data_ptr(), out.data_ptr(), D.stream_ptr())
+        _native.check(rc, "mpcx_mask_dofmap")
+        form._device[key] = out
+    return form._device[key]
 
 
 def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, store_mode: int = 0,
@@ -149,7 +181,10 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
     if alg == 2:
         plan, pk, _info = _rowblock_plan(A, form, i, V0)
         a.plan = plan
-        keep.append(pk)
+        md0 = _masked_dofmap(form, V0, bc0, mpc0, 0)
+        md1 = md0 if (V1 is V0 and mpc1 is mpc0 and bc1 is bc0) else _masked_dofmap(form, V1, bc1, mpc1, 1)
+        a.mdofmap0, a.mdofmap1 = md0.data_ptr(), md1.data_ptr()
+        keep += [pk, md0, md1]
     return a, keep
 
 

@@ -9,6 +9,7 @@
 // coordinate_dofs are [nv][3] (3 components always, assemble_matrix.cpp:499).
 #pragma once
 #include "mpcx.h"
+#include "mpcx_fastmath.hpp"
 #include <hip/hip_runtime.h>
 
 namespace mpcx
@@ -154,13 +155,12 @@ __device__ inline double eval_fn(int fn_id, const double (&x)[3], int comp, cons
   case 1:
   {
     // python/benchmarks/bench_periodic.py:85-89
+    // sin(5 pi y) = sinpi(5 y): exact range reduction, no pi rounding in the argument
     const double dx = x[0] - 0.9, dy = x[1] - 0.5, dz = x[2] - 0.1;
-    return x[0] * sin(5.0 * 3.14159265358979323846 * x[1])
-           + 1.0 * exp(-(dx * dx + dy * dy + dz * dz) / 0.02);
+    return x[0] * fast_sinpi(5.0 * x[1]) + 1.0 * fast_exp(-(dx * dx + dy * dy + dz * dz) / 0.02);
   }
   case 2:
-    return sin(2.0 * 3.14159265358979323846 * x[0]) * sin(3.14159265358979323846 * x[1])
-           + 0.3 * (comp + 1);
+    return fast_sinpi(2.0 * x[0]) * fast_sinpi(x[1]) + 0.3 * (comp + 1);
   case 3:
     return 1.0 + 2.0 * x[0] + 3.0 * x[1] * x[1] - x[2] * x[2] * x[2] + x[0] * x[1] * x[2]
            + 0.5 * comp * x[0];

@@ -313,19 +313,24 @@ struct RowBlockPlan
   std::vector<int32_t> block_row0;
   std::vector<int64_t> block_ent_off;
   std::vector<int32_t> block_ents;
+  std::vector<int32_t> row_pad_off;
 };
 } // namespace
 
 extern "C" void* mpcx_rowblock_plan_build(int32_t nrows, const int32_t* rowptr, int32_t max_rows,
                                           int32_t max_nnz, int64_t n_entities, int32_t estride,
                                           const int32_t* entities0, const int32_t* dofmap0,
-                                          int32_t nd0, int32_t bs0, int32_t num_threads)
+                                          int32_t nd0, int32_t bs0, const int32_t* row_hints,
+                                          int32_t n_hints, int32_t num_threads)
 {
   (void)num_threads;
   auto* P = new RowBlockPlan;
-  // greedy contiguous partition, boundaries on dof-block (bs0) multiples
+  // greedy contiguous partition, boundaries on dof-block (bs0) multiples; a
+  // block is cut at the last hinted row (tile start of the numbering) inside
+  // its capacity window so that blocks do not straddle tiles
   P->block_row0.push_back(0);
   int32_t r0 = 0;
+  int32_t h = 0; // first hint > r0
   while (r0 < nrows)
   {
     int32_t r1 = r0;
@@ -342,10 +347,32 @@ extern "C" void* mpcx_rowblock_plan_build(int32_t nrows, const int32_t* rowptr, 
       delete P;
       return nullptr;
     }
+    if (row_hints && r1 < nrows)
+    {
+      while (h < n_hints && row_hints[h] <= r0)
+        ++h;
+      int32_t cut = -1;
+      for (int32_t k = h; k < n_hints && row_hints[k] <= r1; ++k)
+        cut = row_hints[k];
+      if (cut > r0 && cut % bs0 == 0)
+        r1 = cut;
+    }
     P->block_row0.push_back(r1);
     r0 = r1;
   }
   const int32_t nb = static_cast<int32_t>(P->block_row0.size()) - 1;
+  // padded column offset of every row inside its block (each row padded to a
+  // multiple of 4 column slots: 16-byte LDS reads)
+  P->row_pad_off.resize(nrows);
+  for (int32_t b = 0; b < nb; ++b)
+  {
+    int32_t off = 0;
+    for (int32_t r = P->block_row0[b]; r < P->block_row0[b + 1]; ++r)
+    {
+      P->row_pad_off[r] = off;
+      off += (rowptr[r + 1] - rowptr[r] + 3) & ~3;
+    }
+  }
   // dof block -> row block
   const int32_t ndb = nrows / bs0;
   std::vector<int32_t> blk_of(ndb);
@@ -405,9 +432,10 @@ extern "C" int64_t mpcx_rowblock_plan_num_ents(void* p)
   return static_cast<int64_t>(static_cast<RowBlockPlan*>(p)->block_ents.size());
 }
 extern "C" int mpcx_rowblock_plan_copy(void* p, int32_t* block_row0, int64_t* block_ent_off,
-                                       int32_t* block_ents)
+                                       int32_t* block_ents, int32_t* row_pad_off)
 {
   auto* P = static_cast<RowBlockPlan*>(p);
+  std::memcpy(row_pad_off, P->row_pad_off.data(), P->row_pad_off.size() * sizeof(int32_t));
   std::memcpy(block_row0, P->block_row0.data(), P->block_row0.size() * sizeof(int32_t));
   std::memcpy(block_ent_off, P->block_ent_off.data(), P->block_ent_off.size() * sizeof(int64_t));
   std::memcpy(block_ents, P->block_ents.data(), P->block_ents.size() * sizeof(int32_t));

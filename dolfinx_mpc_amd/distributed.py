@@ -70,6 +70,13 @@ def create_slab_mesh(N: int, rank: int, world: int, reorder=None) -> Mesh:
     gk, gj, gi = node_plane, np.tile(np.repeat(np.arange(ny1), nx1), nz1), np.tile(np.arange(nx1), ny1 * nz1)
     node_global = ((gk.astype(np.int64) * ny1 + gj) * nx1 + gi)[order]
     mesh = Mesh(x[order], cells.astype(np.int32), "tetrahedron")
+    if reorder is not None:
+        from .mesh import _tile_ids, _tile_starts
+
+        # keep owned / ghost groups apart in the hint (ghost group gets its own tile ids)
+        tid = _tile_ids((nx1, ny1, nz1), reorder).astype(np.int64)
+        tid = np.where(owned_node, tid, tid + tid.max() + 1)
+        mesh.node_tile_offsets = _tile_starts(tid[order])
     mesh.num_owned_nodes = int(owned_node.sum())
     mesh.num_owned_cells = int(owned_cube.sum()) * 6
     mesh.node_global = node_global

@@ -49,6 +49,8 @@ class Mesh:
         self.num_owned_nodes = self.geometry.x.shape[0]
         self.num_owned_cells = self.geometry.dofmap.shape[0]
         self.node_global = None
+        # first node of every tile when the numbering is tiled (hint for row blocks)
+        self.node_tile_offsets = None
 
     @property
     def num_cells(self) -> int:
@@ -119,6 +121,20 @@ def _tile_permutation(n1: tuple, tile: tuple) -> np.ndarray:
     return perm  # old -> new
 
 
+def _tile_ids(n1: tuple, tile: tuple) -> np.ndarray:
+    """tile id of every node of the (nx1, ny1, nz1) grid, lexicographic node order"""
+    nx1, ny1, nz1 = n1
+    tx, ty, tz = tile
+    k, j, i = np.meshgrid(np.arange(nz1), np.arange(ny1), np.arange(nx1), indexing="ij")
+    ntx, nty = -(-nx1 // tx), -(-ny1 // ty)
+    return (((k // tz) * nty + (j // ty)) * ntx + (i // tx)).ravel()
+
+
+def _tile_starts(tid_new: np.ndarray) -> np.ndarray:
+    """first node of every run of equal tile id (numbering hint for row blocks)"""
+    return np.concatenate([[0], np.flatnonzero(np.diff(tid_new) != 0) + 1]).astype(np.int32)
+
+
 def create_box(p0, p1, n, cell_type: str = "tetrahedron", reorder: tuple | None = None) -> Mesh:
     """Box mesh of ``n = (nx, ny, nz)`` cubes, each split into 6 tets.
 
@@ -150,7 +166,12 @@ def create_box(p0, p1, n, cell_type: str = "tetrahedron", reorder: tuple | None 
         cperm = _tile_permutation((nx, ny, nz), reorder)  # old cube -> new cube
         order = np.argsort(cperm, kind="stable")  # new cube -> old cube
         cells = cells.reshape(-1, 6, 4)[order].reshape(-1, 4)
-    return Mesh(x, cells.astype(np.int32), "tetrahedron")
+        tid_new = np.empty(perm.size, dtype=np.int64)
+        tid_new[perm] = _tile_ids((nx + 1, ny + 1, nz + 1), reorder)
+    mesh = Mesh(x, cells.astype(np.int32), "tetrahedron")
+    if reorder is not None:
+        mesh.node_tile_offsets = _tile_starts(tid_new)
+    return mesh
 
 
 def create_unit_cube(nx: int, ny: int, nz: int, cell_type: str = "tetrahedron", reorder=None) -> Mesh:

@@ -79,9 +79,11 @@ typedef struct
   int32_t num_blocks;
   int32_t max_rows;             /* max rows per block */
   int32_t max_nnz;              /* max nnz per block  */
+  int32_t max_pad;              /* max padded column slots per block (rows padded to 4) */
   const int32_t* block_row0;    /* DEVICE [num_blocks + 1] first row of block */
   const int64_t* block_ent_off; /* DEVICE [num_blocks + 1] into block_ents */
   const int32_t* block_ents;    /* DEVICE entity indices touching the block */
+  const int32_t* row_pad_off;   /* DEVICE [nrows] padded column offset of the row inside its block */
 } mpcx_rowblock_plan_t;
 
 /* ------------------------------------------------------------------------
@@ -129,10 +131,20 @@ typedef struct
   int32_t algorithm;
   int32_t store_mode; /* rowblock: 1 = block values overwrite vals (no prior zeroing needed) */
   mpcx_rowblock_plan_t plan;
+  /* rowblock: dofmaps with the "masked" flag (Dirichlet or slave, per component k)
+   * folded into bit 28+k of each blocked dof: no marker gathers in the kernel */
+  const int32_t* mdofmap0; /* DEVICE [num_cells][nd0] */
+  const int32_t* mdofmap1; /* DEVICE [num_cells][nd1] */
   void* stream;
 } mpcx_matrix_args_t;
 
 int mpcx_assemble_matrix(const mpcx_matrix_args_t* args);
+
+/* Set-up for MPCX_ALG_ROWBLOCK: out[i] = dofmap[i] | (masked(dof, k) << (28 + k)),
+ * masked = Dirichlet-marked (bc may be NULL) or slave.  All pointers DEVICE,
+ * n = num_cells * nd, dof blocks must be < 2^28, bs <= 3. */
+int mpcx_mask_dofmap(const int32_t* dofmap, int64_t n, int32_t bs, const int8_t* bc,
+                     const int8_t* is_slave, int32_t* out, void* stream);
 
 /* vals[pos(d,d)] += diagval for d in dofs.  Replaces the slave-diagonal loop
  * of cpp/assemble_matrix.cpp:711-724 and dolfinx insert_diagonal called at
@@ -240,15 +252,19 @@ void mpcx_pattern_free(void* pattern);
 
 /* Row-block plan for MPCX_ALG_ROWBLOCK: contiguous row ranges with at most
  * max_rows rows / max_nnz nonzeros, and for each block the entities whose
- * test-space cell has a dof in it.  Returns an opaque handle. */
+ * test-space cell has a dof in it.  `row_hints` (sorted row indices, may be
+ * NULL) are preferred cut positions, e.g. the first row of each numbering tile.
+ * Returns an opaque handle. */
 void* mpcx_rowblock_plan_build(int32_t nrows, const int32_t* rowptr, int32_t max_rows,
                                int32_t max_nnz, int64_t n_entities, int32_t estride,
                                const int32_t* entities0, const int32_t* dofmap0,
-                               int32_t nd0, int32_t bs0, int32_t num_threads);
+                               int32_t nd0, int32_t bs0, const int32_t* row_hints,
+                               int32_t n_hints, int32_t num_threads);
 int32_t mpcx_rowblock_plan_num_blocks(void* plan);
 int64_t mpcx_rowblock_plan_num_ents(void* plan);
+/* row_pad_off: caller-allocated [nrows] */
 int mpcx_rowblock_plan_copy(void* plan, int32_t* block_row0, int64_t* block_ent_off,
-                            int32_t* block_ents);
+                            int32_t* block_ents, int32_t* row_pad_off);
 void mpcx_rowblock_plan_free(void* plan);
 
 /* misc */
