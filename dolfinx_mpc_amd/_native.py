@@ -46,11 +46,10 @@ class RowBlockPlanT(C.Structure):
         ("num_blocks", C.c_int32),
         ("max_rows", C.c_int32),
         ("max_nnz", C.c_int32),
-        ("max_pad", C.c_int32),
         ("block_row0", C.c_void_p),
         ("block_ent_off", C.c_void_p),
         ("block_ents", C.c_void_p),
-        ("row_pad_off", C.c_void_p),
+        ("ent_offs", C.c_void_p),
     ]
 
 
@@ -153,6 +152,7 @@ class LiftingArgs(C.Structure):
 EXPORTS = [
     "mpcx_assemble_matrix",
     "mpcx_mask_dofmap",
+    "mpcx_scatter_offsets",
     "mpcx_add_diagonal",
     "mpcx_assemble_vector",
     "mpcx_apply_lifting",
@@ -230,13 +230,15 @@ def lib() -> C.CDLL:
     L.mpcx_pattern_free.restype = None
     L.mpcx_mask_dofmap.argtypes = [vp, i64, i32, vp, vp, vp, vp]
     L.mpcx_mask_dofmap.restype = C.c_int
+    L.mpcx_scatter_offsets.argtypes = [vp, vp, i32, i64, vp, vp, vp, i32, i32, vp, i32, i32, vp, vp, vp]
+    L.mpcx_scatter_offsets.restype = C.c_int
     L.mpcx_rowblock_plan_build.argtypes = [i32, vp, i32, i32, i64, i32, vp, vp, i32, i32, vp, i32, i32]
     L.mpcx_rowblock_plan_build.restype = vp
     L.mpcx_rowblock_plan_num_blocks.argtypes = [vp]
     L.mpcx_rowblock_plan_num_blocks.restype = i32
     L.mpcx_rowblock_plan_num_ents.argtypes = [vp]
     L.mpcx_rowblock_plan_num_ents.restype = i64
-    L.mpcx_rowblock_plan_copy.argtypes = [vp, vp, vp, vp, vp]
+    L.mpcx_rowblock_plan_copy.argtypes = [vp, vp, vp, vp]
     L.mpcx_rowblock_plan_copy.restype = C.c_int
     L.mpcx_rowblock_plan_free.argtypes = [vp]
     L.mpcx_rowblock_plan_free.restype = None

@@ -106,22 +106,33 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0):
             row0 = np.empty(nb + 1, dtype=np.int32)
             off = np.empty(nb + 1, dtype=np.int64)
             ents_b = np.empty(L.mpcx_rowblock_plan_num_ents(h), dtype=np.int32)
-            pad_off = np.empty(A.shape[0], dtype=np.int32)
-            L.mpcx_rowblock_plan_copy(h, p(row0), p(off), p(ents_b), p(pad_off))
+            L.mpcx_rowblock_plan_copy(h, p(row0), p(off), p(ents_b))
         finally:
             L.mpcx_rowblock_plan_free(h)
         dev = A.device
-        t = (D._to_dev(row0, dev), D._to_dev(off, dev), D._to_dev(ents_b, dev), D._to_dev(pad_off, dev))
+        # 8-bit scatter offsets of every (entity, local row, local col), built on the device
+        import torch
+
+        V1 = form.function_spaces[1]
+        s0, s1 = D.space_device(V0), D.space_device(V1)
+        idv = D.integral_device(form, i)
+        offs = torch.empty(integ.num_entities * V0.element_ndofs * V1.element_ndofs, dtype=torch.uint8, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        rc = L.mpcx_scatter_offsets(A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), integ.estride, integ.num_entities,
+                                    idv["entities"].data_ptr(), idv["entities"].data_ptr(), s0["dofmap"].data_ptr(),
+                                    V0.element_ndofs, V0.dofmap.bs, s1["dofmap"].data_ptr(), V1.element_ndofs,
+                                    V1.dofmap.bs, offs.data_ptr(), flag.data_ptr(), D.stream_ptr())
+        _native.check(rc, "mpcx_scatter_offsets")
+        if int(flag.item()) != 0:
+            raise RuntimeError("row-block algorithm: a CSR row holds more than 255 column blocks before one of the "
+                               "entity's columns (or a column is missing from the pattern); use algorithm='atomic'")
+        t = (D._to_dev(row0, dev), D._to_dev(off, dev), D._to_dev(ents_b, dev), offs)
         max_rows = int(np.diff(row0).max())
         max_nnz = int(np.diff(A.rowptr[row0].astype(np.int64)).max())
-        last = row0[1:] - 1  # last row of each block: padded size = its offset + its padded length
-        max_pad = int((pad_off[last] + ((np.diff(A.rowptr)[last] + 3) & ~3)).max())
-        if np.diff(A.rowptr).max() > 1020:
-            raise RuntimeError("row-block algorithm: a row has more than 1020 nonzeros; use algorithm='atomic'")
-        s = _native.RowBlockPlanT(nb, max_rows, max_nnz, max_pad, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
+        s = _native.RowBlockPlanT(nb, max_rows, max_nnz, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
                                   t[3].data_ptr())
         A._plans[key] = (s, t, {"num_blocks": nb, "num_ents": int(ents_b.size), "max_rows": max_rows,
-                                "max_nnz": max_nnz, "max_pad": max_pad})
+                                "max_nnz": max_nnz})
     return A._plans[key]
 
 

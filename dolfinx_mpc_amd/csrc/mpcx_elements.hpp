@@ -100,10 +100,11 @@ __device__ inline void affine_geometry(const double* cd, double (&K)[TDIM][TDIM]
     const double J10 = cd[4] - cd[1], J11 = cd[7] - cd[1];
     const double det = J00 * J11 - J01 * J10;
     detJ = det;
-    K[0][0] = J11 / det;
-    K[0][1] = -J01 / det;
-    K[1][0] = -J10 / det;
-    K[1][1] = J00 / det;
+    const double inv = 1.0 / det;
+    K[0][0] = J11 * inv;
+    K[0][1] = -J01 * inv;
+    K[1][0] = -J10 * inv;
+    K[1][1] = J00 * inv;
   }
   else
   {
@@ -115,15 +116,57 @@ __device__ inline void affine_geometry(const double* cd, double (&K)[TDIM][TDIM]
     const double c02 = J10 * J21 - J11 * J20;
     const double det = J00 * c00 + J01 * c01 + J02 * c02;
     detJ = det;
-    K[0][0] = c00 / det;
-    K[0][1] = (J02 * J21 - J01 * J22) / det;
-    K[0][2] = (J01 * J12 - J02 * J11) / det;
-    K[1][0] = c01 / det;
-    K[1][1] = (J00 * J22 - J02 * J20) / det;
-    K[1][2] = (J02 * J10 - J00 * J12) / det;
-    K[2][0] = c02 / det;
-    K[2][1] = (J01 * J20 - J00 * J21) / det;
-    K[2][2] = (J00 * J11 - J01 * J10) / det;
+    const double inv = 1.0 / det; // one division; the products differ from x/det by <= 1 ulp
+    K[0][0] = c00 * inv;
+    K[0][1] = (J02 * J21 - J01 * J22) * inv;
+    K[0][2] = (J01 * J12 - J02 * J11) * inv;
+    K[1][0] = c01 * inv;
+    K[1][1] = (J00 * J22 - J02 * J20) * inv;
+    K[1][2] = (J02 * J10 - J00 * J12) * inv;
+    K[2][0] = c02 * inv;
+    K[2][1] = (J01 * J20 - J00 * J21) * inv;
+    K[2][2] = (J00 * J11 - J01 * J10) * inv;
+  }
+}
+
+// det(J) * grad(lambda_i) (cofactor rows; row 0 = minus the sum of the others)
+template <int TDIM>
+__device__ inline void cofactor_gradients(const double* cd, double (&G)[TDIM + 1][TDIM], double& det)
+{
+  if constexpr (TDIM == 2)
+  {
+    const double J00 = cd[3] - cd[0], J01 = cd[6] - cd[0];
+    const double J10 = cd[4] - cd[1], J11 = cd[7] - cd[1];
+    det = J00 * J11 - J01 * J10;
+    G[1][0] = J11;
+    G[1][1] = -J01;
+    G[2][0] = -J10;
+    G[2][1] = J00;
+  }
+  else
+  {
+    const double J00 = cd[3] - cd[0], J01 = cd[6] - cd[0], J02 = cd[9] - cd[0];
+    const double J10 = cd[4] - cd[1], J11 = cd[7] - cd[1], J12 = cd[10] - cd[1];
+    const double J20 = cd[5] - cd[2], J21 = cd[8] - cd[2], J22 = cd[11] - cd[2];
+    G[1][0] = J11 * J22 - J12 * J21;
+    G[1][1] = J02 * J21 - J01 * J22;
+    G[1][2] = J01 * J12 - J02 * J11;
+    G[2][0] = J12 * J20 - J10 * J22;
+    G[2][1] = J00 * J22 - J02 * J20;
+    G[2][2] = J02 * J10 - J00 * J12;
+    G[3][0] = J10 * J21 - J11 * J20;
+    G[3][1] = J01 * J20 - J00 * J21;
+    G[3][2] = J00 * J11 - J01 * J10;
+    det = J00 * G[1][0] + J01 * G[2][0] + J02 * G[3][0];
+  }
+#pragma unroll
+  for (int a = 0; a < TDIM; ++a)
+  {
+    double s = 0.0;
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d)
+      s += G[d + 1][a];
+    G[0][a] = -s;
   }
 }
 
@@ -299,32 +342,21 @@ struct ElementOp
     {
       if (k.coeff_degree == 0)
       {
-        double K[TDIM][TDIM], detJ;
-        affine_geometry<TDIM>(cd, K, detJ);
-        const double vol = fabs(detJ) * (TDIM == 3 ? 1.0 / 6.0 : 0.5) * (c ? c[0] : 1.0);
-        double G[NV][TDIM];
-#pragma unroll
-        for (int a = 0; a < TDIM; ++a)
-        {
-          double s = 0.0;
-#pragma unroll
-          for (int d = 0; d < TDIM; ++d)
-          {
-            G[d + 1][a] = K[d][a];
-            s += K[d][a];
-          }
-          G[0][a] = -s;
-        }
+        // A_ij = |T| grad(l_i).grad(l_j) with grad(l_{d+1}) = cof_d / det:
+        // A_ij = cof_i.cof_j / (d! |det|) -- one division, symmetric
+        double G[NV][TDIM], det;
+        cofactor_gradients<TDIM>(cd, G, det);
+        const double s = (c ? c[0] : 1.0) / ((TDIM == 3 ? 6.0 : 2.0) * fabs(det));
 #pragma unroll
         for (int i = 0; i < NV; ++i)
 #pragma unroll
-          for (int j = 0; j < NV; ++j)
+          for (int j = i; j < NV; ++j)
           {
             double dot = 0.0;
 #pragma unroll
             for (int a = 0; a < TDIM; ++a)
               dot += G[i][a] * G[j][a];
-            A[i * NV + j] = vol * dot;
+            A[i * NV + j] = A[j * NV + i] = s * dot;
           }
         return;
       }

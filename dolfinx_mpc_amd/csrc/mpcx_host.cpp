@@ -313,7 +313,6 @@ struct RowBlockPlan
   std::vector<int32_t> block_row0;
   std::vector<int64_t> block_ent_off;
   std::vector<int32_t> block_ents;
-  std::vector<int32_t> row_pad_off;
 };
 } // namespace
 
@@ -361,18 +360,6 @@ extern "C" void* mpcx_rowblock_plan_build(int32_t nrows, const int32_t* rowptr, 
     r0 = r1;
   }
   const int32_t nb = static_cast<int32_t>(P->block_row0.size()) - 1;
-  // padded column offset of every row inside its block (each row padded to a
-  // multiple of 4 column slots: 16-byte LDS reads)
-  P->row_pad_off.resize(nrows);
-  for (int32_t b = 0; b < nb; ++b)
-  {
-    int32_t off = 0;
-    for (int32_t r = P->block_row0[b]; r < P->block_row0[b + 1]; ++r)
-    {
-      P->row_pad_off[r] = off;
-      off += (rowptr[r + 1] - rowptr[r] + 3) & ~3;
-    }
-  }
   // dof block -> row block
   const int32_t ndb = nrows / bs0;
   std::vector<int32_t> blk_of(ndb);
@@ -432,10 +419,9 @@ extern "C" int64_t mpcx_rowblock_plan_num_ents(void* p)
   return static_cast<int64_t>(static_cast<RowBlockPlan*>(p)->block_ents.size());
 }
 extern "C" int mpcx_rowblock_plan_copy(void* p, int32_t* block_row0, int64_t* block_ent_off,
-                                       int32_t* block_ents, int32_t* row_pad_off)
+                                       int32_t* block_ents)
 {
   auto* P = static_cast<RowBlockPlan*>(p);
-  std::memcpy(row_pad_off, P->row_pad_off.data(), P->row_pad_off.size() * sizeof(int32_t));
   std::memcpy(block_row0, P->block_row0.data(), P->block_row0.size() * sizeof(int32_t));
   std::memcpy(block_ent_off, P->block_ent_off.data(), P->block_ent_off.size() * sizeof(int64_t));
   std::memcpy(block_ents, P->block_ents.data(), P->block_ents.size() * sizeof(int32_t));

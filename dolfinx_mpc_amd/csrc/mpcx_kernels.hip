@@ -15,6 +15,7 @@
 #include "mpcx_elements.hpp"
 #include "mpcx_internal.h"
 
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <string>
 
@@ -215,29 +216,27 @@ __global__ void __launch_bounds__(64) matrix_mpc_kernel(mpcx_matrix_args_t a)
 
 // ---------------------------------------------------------------------------
 // Bulk matrix kernel, LDS-privatised row blocks.  One workgroup owns a
-// contiguous range of CSR rows: their values live in LDS (compact), their
-// column indices too (each row padded to a multiple of 4 so that a row is read
-// with 16-byte LDS loads); every entity touching the block is evaluated
-// (redundantly across blocks), only rows inside the block are kept, and the
-// finished values are written to HBM once, coalesced.  No device atomics.
-//
-// Position of column c in a sorted row = #(entries < c): counted with integer
-// compares over the wide reads instead of a binary search (4 ds_read_b128 per
-// P1 row instead of ~20 dependent ds_read_b32).
-//
-// The Dirichlet/slave mask arrives folded into the dofmap (bit 28+k of the
-// blocked dof = "row/col of component k is masked"), so the kernel does no
-// marker gathers at all.
+// contiguous range of CSR rows whose values live in LDS; every entity touching
+// the block is evaluated (redundantly across blocks), only rows inside the
+// block are kept, and the finished values are written to HBM once, coalesced.
+// No device atomics, no searching:
+//  * the position of every (local row, local col) pair inside its CSR row is a
+//    precomputed 8-bit offset (plan.ent_offs, ND0*ND1 bytes per entity, read
+//    coalesced) -- the same role PETSc's per-row column search plays behind
+//    MatSetValuesLocal in the reference, hoisted to set-up;
+//  * the Dirichlet/slave mask arrives folded into the dofmap (bit 28+k of the
+//    blocked dof = "row/col of component k is masked"), so there are no marker
+//    gathers either.
 // ---------------------------------------------------------------------------
 constexpr int MPCX_MASK_SHIFT = 28;
 constexpr int MPCX_DOF_MASK = (1 << MPCX_MASK_SHIFT) - 1;
-constexpr int ROWBLOCK_THREADS = 256;
+constexpr int ROWBLOCK_MAX_THREADS = 1024;
 
 template <class Op>
-__global__ void __launch_bounds__(ROWBLOCK_THREADS) matrix_rowblock_kernel(mpcx_matrix_args_t a)
+__global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(mpcx_matrix_args_t a)
 {
   constexpr int N = Op::N, ND = Op::ND, BS = Op::BS, NV = Op::NV;
-  constexpr int NT = ROWBLOCK_THREADS;
+  const int NT = blockDim.x;
   extern __shared__ __align__(16) unsigned char smem[];
   // XCD-aware order: workgroup w runs on XCD w % 8 (observed placement, speed
   // only); give each XCD a contiguous run of row blocks so neighbouring blocks
@@ -252,35 +251,15 @@ __global__ void __launch_bounds__(ROWBLOCK_THREADS) matrix_rowblock_kernel(mpcx_
   const int nrow = r1 - r0;
   const int nnz0 = a.rowptr[r0];
   const int nnzb = a.rowptr[r1] - nnz0;
-  double* s_vals = reinterpret_cast<double*>(smem);                                  // [max_nnz] compact
-  int32_t* s_cols = reinterpret_cast<int32_t*>(s_vals + ((a.plan.max_nnz + 1) & ~1)); // [max_pad] padded rows
-  int2* s_row = reinterpret_cast<int2*>(s_cols + a.plan.max_pad);                    // [max_rows] {lo, pad<<8|nchunks}
-  int32_t* s_tmp = reinterpret_cast<int32_t*>(s_vals);                               // staging of the compact columns
+  double* s_vals = reinterpret_cast<double*>(smem);                        // [max_nnz]
+  int32_t* s_rowlo = reinterpret_cast<int32_t*>(s_vals + a.plan.max_nnz); // [max_rows]
 
-  // 1. coalesced load of the block's column indices, then row-wise re-layout
-  for (int i = tid; i < nnzb; i += NT)
-    s_tmp[i] = a.cols[nnz0 + i];
-  for (int rl = tid; rl < nrow; rl += NT)
-  {
-    const int lo = a.rowptr[r0 + rl] - nnz0;
-    const int len = a.rowptr[r0 + rl + 1] - nnz0 - lo;
-    s_row[rl] = make_int2(lo, (a.plan.row_pad_off[r0 + rl] << 8) | ((len + 3) >> 2));
-  }
-  __syncthreads();
-  for (int rl = tid; rl < nrow; rl += NT)
-  {
-    const int2 info = s_row[rl];
-    const int pb = info.y >> 8, nch = info.y & 255;
-    const int len = (rl + 1 < nrow ? s_row[rl + 1].x : nnzb) - info.x;
-    for (int k = 0; k < nch * 4; ++k)
-      s_cols[pb + k] = k < len ? s_tmp[info.x + k] : 0x7fffffff;
-  }
-  __syncthreads();
   for (int i = tid; i < nnzb; i += NT)
     s_vals[i] = 0.0;
+  for (int rl = tid; rl < nrow; rl += NT)
+    s_rowlo[rl] = a.rowptr[r0 + rl] - nnz0;
   __syncthreads();
 
-  // 2. entities touching the block
   const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
   for (int64_t t = e0 + tid; t < e1; t += NT)
   {
@@ -291,60 +270,101 @@ __global__ void __launch_bounds__(ROWBLOCK_THREADS) matrix_rowblock_kernel(mpcx_
     const int64_t cell1 = a.entities1[l];
     const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
 
+    // scatter offsets of this entity (ND*ND bytes, contiguous)
+    uint8_t off[ND * ND];
+    {
+      const uint8_t* po = a.plan.ent_offs + e * (ND * ND);
+      if constexpr ((ND * ND) % 16 == 0)
+      {
+#pragma unroll
+        for (int w = 0; w < ND * ND / 16; ++w)
+        {
+          const uint4 v = reinterpret_cast<const uint4*>(po)[w];
+          const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            off[16 * w + q] = (u[q >> 2] >> (8 * (q & 3))) & 0xff;
+        }
+      }
+      else
+      {
+#pragma unroll
+        for (int q = 0; q < ND * ND; ++q)
+          off[q] = po[q];
+      }
+    }
+
     double cd[NV * 3];
     gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
     double Ae[N * N];
     Op::tabulate(Ae, a.coeffs ? a.coeffs + e * a.cstride : nullptr, a.constants, cd, lf, a.kernel);
 
-    int32_t rows[N], colsd[N];
-    bool rmask[N], cmask[N];
+    int32_t m0[ND], m1[ND];
 #pragma unroll
     for (int i = 0; i < ND; ++i)
     {
-      const int32_t m0 = a.mdofmap0[cell0 * ND + i];
-      const int32_t m1 = a.mdofmap1[cell1 * ND + i];
+      m0[i] = a.mdofmap0[cell0 * ND + i];
+      m1[i] = a.mdofmap1[cell1 * ND + i];
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+    {
 #pragma unroll
       for (int k = 0; k < BS; ++k)
       {
-        const int32_t r = (m0 & MPCX_DOF_MASK) * BS + k, c = (m1 & MPCX_DOF_MASK) * BS + k;
-        rows[i * BS + k] = r;
-        colsd[i * BS + k] = c;
-        rmask[i * BS + k] = r < r0 || r >= r1 || ((m0 >> (MPCX_MASK_SHIFT + k)) & 1);
-        cmask[i * BS + k] = (m1 >> (MPCX_MASK_SHIFT + k)) & 1;
+        const int r = (m0[i] & MPCX_DOF_MASK) * BS + k;
+        if (r < r0 || r >= r1 || ((m0[i] >> (MPCX_MASK_SHIFT + k)) & 1))
+          continue;
+        const int base = s_rowlo[r - r0];
+#pragma unroll
+        for (int j = 0; j < ND; ++j)
+        {
+#pragma unroll
+          for (int q = 0; q < BS; ++q)
+          {
+            if ((m1[j] >> (MPCX_MASK_SHIFT + q)) & 1)
+              continue;
+            __hip_atomic_fetch_add(s_vals + base + int(off[i * ND + j]) * BS + q, Ae[(i * BS + k) * N + j * BS + q],
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
       }
-    }
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-    {
-      if (rmask[i])
-        continue;
-      const int2 info = s_row[rows[i] - r0];
-      const int pb = info.y >> 8, nch = info.y & 255;
-      int cnt[N];
-#pragma unroll
-      for (int j = 0; j < N; ++j)
-        cnt[j] = info.x;
-      for (int c = 0; c < nch; ++c)
-      {
-        const int4 v = *reinterpret_cast<const int4*>(s_cols + pb + 4 * c);
-#pragma unroll
-        for (int j = 0; j < N; ++j)
-          cnt[j] += (v.x < colsd[j]) + (v.y < colsd[j]) + (v.z < colsd[j]) + (v.w < colsd[j]);
-      }
-#pragma unroll
-      for (int j = 0; j < N; ++j)
-        if (!cmask[j])
-          __hip_atomic_fetch_add(s_vals + cnt[j], Ae[i * N + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
   __syncthreads();
-  // 3. one coalesced write of the finished block
+  // one coalesced write of the finished block
   if (a.store_mode)
     for (int i = tid; i < nnzb; i += NT)
       a.vals[nnz0 + i] = s_vals[i];
   else
     for (int i = tid; i < nnzb; i += NT)
       a.vals[nnz0 + i] += s_vals[i];
+}
+
+// scatter-offset table (set-up kernel, one thread per (entity, local row block))
+__global__ void scatter_offsets_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                       int estride, int64_t n_entities, const int32_t* __restrict__ entities0,
+                                       const int32_t* __restrict__ entities1, const int32_t* __restrict__ dofmap0,
+                                       int nd0, int bs0, const int32_t* __restrict__ dofmap1, int nd1, int bs1,
+                                       uint8_t* __restrict__ out, int32_t* overflow)
+{
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n_entities * nd0)
+    return;
+  const int64_t e = t / nd0;
+  const int i = int(t - e * nd0);
+  const int64_t cell0 = entities0[e * estride], cell1 = entities1[e * estride];
+  const int r = dofmap0[cell0 * nd0 + i] * bs0;
+  const int lo = rowptr[r], hi = rowptr[r + 1];
+  for (int j = 0; j < nd1; ++j)
+  {
+    const int c = dofmap1[cell1 * nd1 + j] * bs1;
+    const int pos = csr_find(cols, lo, hi, c);
+    const int o = pos < 0 ? 256 : (pos - lo) / bs1;
+    if (o > 255)
+      atomicOr(overflow, 1);
+    out[(e * nd0 + i) * nd1 + j] = uint8_t(o);
+  }
 }
 
 // dofmap with the mask folded in (set-up kernel, one thread per dofmap entry)
@@ -588,8 +608,12 @@ int launch_matrix(const mpcx_matrix_args_t& a)
         mpcx_set_error("mpcx_assemble_matrix: row-block algorithm needs masked dofmaps (mpcx_mask_dofmap)");
         return -5;
       }
-      const size_t lds = size_t((a.plan.max_nnz + 1) & ~1) * 8 + size_t(a.plan.max_pad) * 4
-                         + size_t(a.plan.max_rows) * 8;
+      if (!a.plan.ent_offs)
+      {
+        mpcx_set_error("mpcx_assemble_matrix: row-block plan lacks the scatter-offset table (mpcx_scatter_offsets)");
+        return -5;
+      }
+      const size_t lds = size_t(a.plan.max_nnz) * 8 + size_t(a.plan.max_rows) * 4;
       if (lds > 160 * 1024)
       {
         mpcx_set_error("mpcx_assemble_matrix: row-block plan exceeds 160 KiB of LDS");
@@ -600,7 +624,15 @@ int launch_matrix(const mpcx_matrix_args_t& a)
                          "hipFuncSetAttribute"))
         return rc;
       const unsigned grid = 8u * unsigned((a.plan.num_blocks + 7) / 8);
-      hipLaunchKernelGGL(matrix_rowblock_kernel<Op>, dim3(grid), dim3(ROWBLOCK_THREADS), lds, stream, a);
+      // LDS admits 2 blocks per CU at the default plan size; 512 threads each
+      // = 4 waves per SIMD, what the kernel's register count allows
+      const int threads = []
+      {
+        const char* e = std::getenv("MPCX_ROWBLOCK_THREADS");
+        const int t = e ? std::atoi(e) : 512;
+        return (t == 128 || t == 256 || t == 512 || t == 1024) ? t : 512;
+      }();
+      hipLaunchKernelGGL(matrix_rowblock_kernel<Op>, dim3(grid), dim3(threads), lds, stream, a);
     }
     else
     {
@@ -792,6 +824,20 @@ extern "C" int mpcx_mask_dofmap(const int32_t* dofmap, int64_t n, int32_t bs, co
   hipLaunchKernelGGL(mask_dofmap_kernel, dim3(grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      dofmap, n, bs, bc, is_slave, out);
   return check(hipGetLastError(), "mask_dofmap launch");
+}
+
+extern "C" int mpcx_scatter_offsets(const int32_t* rowptr, const int32_t* cols, int32_t estride,
+                                    int64_t n_entities, const int32_t* entities0,
+                                    const int32_t* entities1, const int32_t* dofmap0, int32_t nd0,
+                                    int32_t bs0, const int32_t* dofmap1, int32_t nd1, int32_t bs1,
+                                    uint8_t* ent_offs, int32_t* overflow, void* stream)
+{
+  if (n_entities == 0)
+    return 0;
+  hipLaunchKernelGGL(scatter_offsets_kernel, dim3(grid_for(n_entities * nd0, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), rowptr, cols, estride, n_entities, entities0, entities1,
+                     dofmap0, nd0, bs0, dofmap1, nd1, bs1, ent_offs, overflow);
+  return check(hipGetLastError(), "scatter_offsets launch");
 }
 
 extern "C" int mpcx_device_count(void)

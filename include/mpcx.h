@@ -79,11 +79,14 @@ typedef struct
   int32_t num_blocks;
   int32_t max_rows;             /* max rows per block */
   int32_t max_nnz;              /* max nnz per block  */
-  int32_t max_pad;              /* max padded column slots per block (rows padded to 4) */
   const int32_t* block_row0;    /* DEVICE [num_blocks + 1] first row of block */
   const int64_t* block_ent_off; /* DEVICE [num_blocks + 1] into block_ents */
   const int32_t* block_ents;    /* DEVICE entity indices touching the block */
-  const int32_t* row_pad_off;   /* DEVICE [nrows] padded column offset of the row inside its block */
+  /* DEVICE [n_entities][nd0][nd1] uint8: position of block column dofs1[j] inside
+   * block row dofs0[i] of the CSR, counted in blocks from the row start
+   * (mpcx_scatter_offsets); the scalar entry (i*bs0+k, j*bs1+l) lives at
+   * rowptr[dofs0[i]*bs0+k] + off*bs1 + l */
+  const uint8_t* ent_offs;
 } mpcx_rowblock_plan_t;
 
 /* ------------------------------------------------------------------------
@@ -145,6 +148,16 @@ int mpcx_assemble_matrix(const mpcx_matrix_args_t* args);
  * n = num_cells * nd, dof blocks must be < 2^28, bs <= 3. */
 int mpcx_mask_dofmap(const int32_t* dofmap, int64_t n, int32_t bs, const int8_t* bc,
                      const int8_t* is_slave, int32_t* out, void* stream);
+
+/* Set-up for MPCX_ALG_ROWBLOCK: the uint8 scatter-offset table described at
+ * mpcx_rowblock_plan_t::ent_offs.  All pointers DEVICE.  *overflow (DEVICE int32,
+ * zeroed by the caller) is set non-zero if an offset does not fit in 8 bits or
+ * a column is missing from the pattern. */
+int mpcx_scatter_offsets(const int32_t* rowptr, const int32_t* cols, int32_t estride,
+                         int64_t n_entities, const int32_t* entities0,
+                         const int32_t* entities1, const int32_t* dofmap0, int32_t nd0,
+                         int32_t bs0, const int32_t* dofmap1, int32_t nd1, int32_t bs1,
+                         uint8_t* ent_offs, int32_t* overflow, void* stream);
 
 /* vals[pos(d,d)] += diagval for d in dofs.  Replaces the slave-diagonal loop
  * of cpp/assemble_matrix.cpp:711-724 and dolfinx insert_diagonal called at
@@ -262,9 +275,8 @@ void* mpcx_rowblock_plan_build(int32_t nrows, const int32_t* rowptr, int32_t max
                                int32_t n_hints, int32_t num_threads);
 int32_t mpcx_rowblock_plan_num_blocks(void* plan);
 int64_t mpcx_rowblock_plan_num_ents(void* plan);
-/* row_pad_off: caller-allocated [nrows] */
 int mpcx_rowblock_plan_copy(void* plan, int32_t* block_row0, int64_t* block_ent_off,
-                            int32_t* block_ents, int32_t* row_pad_off);
+                            int32_t* block_ents);
 void mpcx_rowblock_plan_free(void* plan);
 
 /* misc */

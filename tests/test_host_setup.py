@@ -119,17 +119,10 @@ def test_rowblock_plan_covers_every_entity_row_pair():
         row0 = np.empty(nb + 1, dtype=np.int32)
         off = np.empty(nb + 1, dtype=np.int64)
         be = np.empty(L.mpcx_rowblock_plan_num_ents(h), dtype=np.int32)
-        pad = np.empty(rowptr.size - 1, dtype=np.int32)
-        L.mpcx_rowblock_plan_copy(h, p(row0), p(off), p(be), p(pad))
+        L.mpcx_rowblock_plan_copy(h, p(row0), p(off), p(be))
         L.mpcx_rowblock_plan_free(h)
         assert row0[0] == 0 and row0[-1] == rowptr.size - 1 and np.all(np.diff(row0) > 0)
         assert np.diff(row0).max() <= max_rows and np.diff(rowptr[row0]).max() <= max_nnz
-        # padded offsets: rows padded to multiples of 4 column slots, restarting per block
-        for bidx in range(nb):
-            o = 0
-            for r in range(row0[bidx], row0[bidx + 1]):
-                assert pad[r] == o
-                o += (rowptr[r + 1] - rowptr[r] + 3) // 4 * 4
         if use_hints and max_rows == 64 and max_nnz == 2000:
             # capacity >= one 4x4x4 tile: every block is a union of whole tiles
             assert set(row0.tolist()) <= set(hints.tolist()) | {rowptr.size - 1}
