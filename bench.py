@@ -78,6 +78,22 @@ def build_problem(N: int, reorder, rank=0, world=1):
     return mesh, V, bc, mpc, a, L
 
 
+def measured_traffic(path: str, kernel_substr: str, N: int):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC
+    passes (FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 correction
+    2*FETCH_SIZE, see tools/collect_pmc.py); None if not collected for this N."""
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if d.get("_workload_n") != N:
+        return None
+    for name, c in d.items():
+        if isinstance(c, dict) and kernel_substr in name and "hbm_bytes_per_launch" in c:
+            return int(c["hbm_bytes_per_launch"])
+    return None
+
+
 def cpu_baseline(sample_n: int):
     """The oracle (C restatement of the reference's serial loops) timed on one
     host core on a bounded sample: the same workload at N = sample_n."""
@@ -119,6 +135,8 @@ def main():
     ap.add_argument("--cpu-sample-n", type=int, default=96)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--setup-only", action="store_true", help="host set-up only (no GPU), for timing the plan")
+    ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "pmc_latest.json"),
+                    help="rocprofv3 PMC summary (tools/collect_pmc.py) of the same workload: source of roofline.traffic")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -273,7 +291,7 @@ def main():
             "peak": peak,
             "unit": "GB/s",
             "frac": achieved / peak,
-            "traffic": None,
+            "traffic": measured_traffic(args.pmc_json, f"matrix_{args.alg}_kernel", N),
             "algorithmic_bytes": int(alg_bytes),
             "launch_ms": t_bulk,
         },

@@ -50,6 +50,10 @@ def integral_device(form: Form, i: int):
             "fqpts": _to_dev(k.fqpts.astype(np.float64).reshape(-1), dev),
             "fqwts": _to_dev(k.fqwts.astype(np.float64), dev),
         }
+        # cell integral over cells 0..n-1 in order: the kernels skip the indirection
+        ident = integ.itype == "cell" and integ.entities.size > 0 and int(integ.entities[0]) == 0 and \
+            int(integ.entities[-1]) == integ.entities.size - 1 and bool(np.all(np.diff(integ.entities) == 1))
+        d["entities_ptr"] = None if ident else d["entities"].data_ptr()
         d["kernel"] = _native.KernelT(
             k.form, k.celltype, k.degree, k.bs, k.fn_id, k.coeff_degree, int(k.qwts.size), int(k.fqwts.size),
             d["qpts"].data_ptr(), d["qwts"].data_ptr(), d["fqpts"].data_ptr(), d["fqwts"].data_ptr(),

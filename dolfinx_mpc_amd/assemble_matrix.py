@@ -19,8 +19,10 @@ from .multipointconstraint import MultiPointConstraint
 _ALG = {"auto": 0, "atomic": 1, "rowblock": 2}
 
 # LDS budget of one row block: max_nnz * (8 B value + 4 B column) + row offsets
-ROWBLOCK_MAX_NNZ = int(os.environ.get("MPCX_ROWBLOCK_MAX_NNZ", 4608))
-ROWBLOCK_MAX_ROWS = int(os.environ.get("MPCX_ROWBLOCK_MAX_ROWS", 256))
+# (measured on MI355X, tools/sweep_rowblock.py: 512 rows x 9216 nnz = 76 KB of LDS
+# -> 2 workgroups of 512 threads per CU is the fastest shape for P1)
+ROWBLOCK_MAX_NNZ = int(os.environ.get("MPCX_ROWBLOCK_MAX_NNZ", 9216))
+ROWBLOCK_MAX_ROWS = int(os.environ.get("MPCX_ROWBLOCK_MAX_ROWS", 512))
 
 
 def _pair(constraint):
@@ -175,7 +177,7 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
     a.kernel = idv["kernel"]
     a.x, a.x_dofmap, a.nv = md["x"].data_ptr(), md["x_dofmap"].data_ptr(), form.mesh.geometry.dofmap.shape[1]
     a.estride, a.n_entities = integ.estride, integ.num_entities
-    a.entities = a.entities0 = a.entities1 = idv["entities"].data_ptr()
+    a.entities = a.entities0 = a.entities1 = idv["entities_ptr"]
     a.coeffs = D.ptr(idv["coeffs"])
     a.cstride = 0 if integ.coeffs is None else integ.coeffs.shape[1]
     a.constants = D.ptr(idv["constants"])

@@ -41,7 +41,7 @@ def assemble_vector(form: Form, constraint: MultiPointConstraint, b: Optional[Ve
         a.kernel = idv["kernel"]
         a.x, a.x_dofmap, a.nv = md["x"].data_ptr(), md["x_dofmap"].data_ptr(), form.mesh.geometry.dofmap.shape[1]
         a.estride, a.n_entities = integ.estride, integ.num_entities
-        a.entities = a.entities0 = idv["entities"].data_ptr()
+        a.entities = a.entities0 = idv["entities_ptr"]
         a.coeffs = D.ptr(idv["coeffs"])
         a.cstride = 0 if integ.coeffs is None else integ.coeffs.shape[1]
         a.constants = D.ptr(idv["constants"])
@@ -122,7 +122,7 @@ def apply_lifting(
             a.kernel = idv["kernel"]
             a.x, a.x_dofmap, a.nv = md["x"].data_ptr(), md["x_dofmap"].data_ptr(), aj.mesh.geometry.dofmap.shape[1]
             a.estride, a.n_entities = integ.estride, integ.num_entities
-            a.entities = a.entities0 = a.entities1 = idv["entities"].data_ptr()
+            a.entities = a.entities0 = a.entities1 = idv["entities_ptr"]
             a.coeffs = D.ptr(idv["coeffs"])
             a.cstride = 0 if integ.coeffs is None else integ.coeffs.shape[1]
             a.constants = D.ptr(idv["constants"])

@@ -200,7 +200,8 @@ __device__ inline double eval_fn(int fn_id, const double (&x)[3], int comp, cons
     // python/benchmarks/bench_periodic.py:85-89
     // sin(5 pi y) = sinpi(5 y): exact range reduction, no pi rounding in the argument
     const double dx = x[0] - 0.9, dy = x[1] - 0.5, dz = x[2] - 0.1;
-    return x[0] * fast_sinpi(5.0 * x[1]) + 1.0 * fast_exp(-(dx * dx + dy * dy + dz * dz) / 0.02);
+    // (1/0.02 rounds to 50.0: the product differs from the quotient by <= 1 ulp of the exponent)
+    return x[0] * fast_sinpi(5.0 * x[1]) + 1.0 * fast_exp(-(dx * dx + dy * dy + dz * dz) * (1.0 / 0.02));
   }
   case 2:
     return fast_sinpi(2.0 * x[0]) * fast_sinpi(x[1]) + 0.3 * (comp + 1);
@@ -315,7 +316,9 @@ __device__ inline double eval_coefficient(int coeff_degree, const double* w, con
 // Generic element operator.  A is [N][N] (rank 2) or [N] (rank 1), row-major,
 // blocked dof index i*BS + k, accumulated into a zeroed buffer like UFCx.
 // ---------------------------------------------------------------------------
-template <int TDIM_, int DEG_, int BS_, int FORM_>
+// FN_ >= 0 fixes the analytic source function at compile time (the switch of
+// eval_fn folds away inside the quadrature loop); FN_ = -1 reads kernel.fn_id.
+template <int TDIM_, int DEG_, int BS_, int FORM_, int FN_ = -1>
 struct ElementOp
 {
   static constexpr int TDIM = TDIM_;
@@ -399,7 +402,7 @@ struct ElementOp
 #pragma unroll
         for (int b = 0; b < BS; ++b)
         {
-          const double f = s * eval_fn(k.fn_id, x, b, c);
+          const double f = s * eval_fn(FN_ >= 0 ? FN_ : k.fn_id, x, b, c);
 #pragma unroll
           for (int i = 0; i < ND; ++i)
             A[i * BS + b] += f * phi[i];

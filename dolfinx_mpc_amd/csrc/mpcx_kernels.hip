@@ -69,9 +69,9 @@ __global__ void __launch_bounds__(256) matrix_atomic_kernel(mpcx_matrix_args_t a
   if (e >= a.n_entities)
     return;
   const int64_t l = e * a.estride;
-  const int64_t cell = a.entities[l];
-  const int64_t cell0 = a.entities0[l];
-  const int64_t cell1 = a.entities1[l];
+  const int64_t cell = (a.entities ? a.entities[l] : e);
+  const int64_t cell0 = (a.entities0 ? a.entities0[l] : e);
+  const int64_t cell1 = (a.entities1 ? a.entities1[l] : e);
   const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
 
   double cd[NV * 3];
@@ -128,9 +128,9 @@ __global__ void __launch_bounds__(64) matrix_mpc_kernel(mpcx_matrix_args_t a)
     return;
   const int64_t e = a.slave_entities[t];
   const int64_t l = e * a.estride;
-  const int64_t cell = a.entities[l];
-  const int64_t cell0 = a.entities0[l];
-  const int64_t cell1 = a.entities1[l];
+  const int64_t cell = (a.entities ? a.entities[l] : e);
+  const int64_t cell0 = (a.entities0 ? a.entities0[l] : e);
+  const int64_t cell1 = (a.entities1 ? a.entities1[l] : e);
   const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
 
   double cd[NV * 3];
@@ -260,60 +260,93 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
     s_rowlo[rl] = a.rowptr[r0 + rl] - nnz0;
   __syncthreads();
 
-  const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
-  for (int64_t t = e0 + tid; t < e1; t += NT)
+  // per-entity index data: everything that is read through the entity index
+  struct Ent
+  {
+    int64_t e;
+    int lf;
+    int32_t xd[NV];
+    int32_t m0[ND], m1[ND];
+    uint8_t off[ND * ND];
+  };
+  auto load_ent = [&](int64_t t, Ent& E)
   {
     const int64_t e = a.plan.block_ents[t];
     const int64_t l = e * a.estride;
-    const int64_t cell = a.entities[l];
-    const int64_t cell0 = a.entities0[l];
-    const int64_t cell1 = a.entities1[l];
-    const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
-
-    // scatter offsets of this entity (ND*ND bytes, contiguous)
-    uint8_t off[ND * ND];
-    {
-      const uint8_t* po = a.plan.ent_offs + e * (ND * ND);
-      if constexpr ((ND * ND) % 16 == 0)
-      {
+    const int64_t cell = (a.entities ? a.entities[l] : e);
+    const int64_t cell0 = (a.entities0 ? a.entities0[l] : e);
+    const int64_t cell1 = (a.entities1 ? a.entities1[l] : e);
+    E.e = e;
+    E.lf = a.estride == 2 ? a.entities[l + 1] : 0;
 #pragma unroll
-        for (int w = 0; w < ND * ND / 16; ++w)
-        {
-          const uint4 v = reinterpret_cast<const uint4*>(po)[w];
-          const unsigned u[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int q = 0; q < 16; ++q)
-            off[16 * w + q] = (u[q >> 2] >> (8 * (q & 3))) & 0xff;
-        }
-      }
-      else
-      {
-#pragma unroll
-        for (int q = 0; q < ND * ND; ++q)
-          off[q] = po[q];
-      }
-    }
-
-    double cd[NV * 3];
-    gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
-    double Ae[N * N];
-    Op::tabulate(Ae, a.coeffs ? a.coeffs + e * a.cstride : nullptr, a.constants, cd, lf, a.kernel);
-
-    int32_t m0[ND], m1[ND];
+    for (int i = 0; i < NV; ++i)
+      E.xd[i] = a.x_dofmap[cell * NV + i];
 #pragma unroll
     for (int i = 0; i < ND; ++i)
     {
-      m0[i] = a.mdofmap0[cell0 * ND + i];
-      m1[i] = a.mdofmap1[cell1 * ND + i];
+      E.m0[i] = a.mdofmap0[cell0 * ND + i];
+      E.m1[i] = a.mdofmap1[cell1 * ND + i];
     }
+    // scatter offsets of this entity (ND*ND bytes, contiguous)
+    const uint8_t* po = a.plan.ent_offs + e * (ND * ND);
+    if constexpr ((ND * ND) % 16 == 0)
+    {
+#pragma unroll
+      for (int w = 0; w < ND * ND / 16; ++w)
+      {
+        const uint4 v = reinterpret_cast<const uint4*>(po)[w];
+        const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          E.off[16 * w + q] = (u[q >> 2] >> (8 * (q & 3))) & 0xff;
+      }
+    }
+    else
+    {
+#pragma unroll
+      for (int q = 0; q < ND * ND; ++q)
+        E.off[q] = po[q];
+    }
+  };
+
+  // Software pipeline (small elements): the index data of the next entity is
+  // requested while the current one is computed, so each iteration waits for one
+  // memory round trip (the coordinate gather) instead of three dependent ones.
+  constexpr bool PREFETCH = (ND * ND <= 16);
+  const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  int64_t t = e0 + tid;
+  Ent cur;
+  if (PREFETCH && t < e1)
+    load_ent(t, cur);
+  for (; t < e1; t += NT)
+  {
+    if constexpr (!PREFETCH)
+      load_ent(t, cur);
+    double cd[NV * 3];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+    {
+      const int64_t v = cur.xd[i];
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        cd[3 * i + k] = a.x[3 * v + k];
+    }
+    Ent nxt = cur;
+    if constexpr (PREFETCH)
+    {
+      if (t + NT < e1)
+        load_ent(t + NT, nxt);
+    }
+    double Ae[N * N];
+    Op::tabulate(Ae, a.coeffs ? a.coeffs + cur.e * a.cstride : nullptr, a.constants, cd, cur.lf, a.kernel);
 #pragma unroll
     for (int i = 0; i < ND; ++i)
     {
 #pragma unroll
       for (int k = 0; k < BS; ++k)
       {
-        const int r = (m0[i] & MPCX_DOF_MASK) * BS + k;
-        if (r < r0 || r >= r1 || ((m0[i] >> (MPCX_MASK_SHIFT + k)) & 1))
+        const int r = (cur.m0[i] & MPCX_DOF_MASK) * BS + k;
+        if (r < r0 || r >= r1 || ((cur.m0[i] >> (MPCX_MASK_SHIFT + k)) & 1))
           continue;
         const int base = s_rowlo[r - r0];
 #pragma unroll
@@ -322,14 +355,17 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
 #pragma unroll
           for (int q = 0; q < BS; ++q)
           {
-            if ((m1[j] >> (MPCX_MASK_SHIFT + q)) & 1)
+            if ((cur.m1[j] >> (MPCX_MASK_SHIFT + q)) & 1)
               continue;
-            __hip_atomic_fetch_add(s_vals + base + int(off[i * ND + j]) * BS + q, Ae[(i * BS + k) * N + j * BS + q],
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(s_vals + base + int(cur.off[i * ND + j]) * BS + q,
+                                   Ae[(i * BS + k) * N + j * BS + q], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
           }
         }
       }
     }
+    if constexpr (PREFETCH)
+      cur = nxt;
   }
   __syncthreads();
   // one coalesced write of the finished block
@@ -434,8 +470,8 @@ __global__ void __launch_bounds__(VectorCfg<Op::N>::NT) vector_kernel(mpcx_vecto
   if (e < a.n_entities)
   {
     const int64_t l = e * a.estride;
-    const int64_t cell = a.entities[l];
-    const int64_t cell0 = a.entities0[l];
+    const int64_t cell = (a.entities ? a.entities[l] : e);
+    const int64_t cell0 = (a.entities0 ? a.entities0[l] : e);
     const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
     double cd[NV * 3];
     gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
@@ -498,9 +534,9 @@ __global__ void __launch_bounds__(256) lifting_kernel(mpcx_lifting_args_t a)
     return;
   const int64_t e = a.lift_entities[t];
   const int64_t l = e * a.estride;
-  const int64_t cell = a.entities[l];
-  const int64_t cell0 = a.entities0[l];
-  const int64_t cell1 = a.entities1[l];
+  const int64_t cell = (a.entities ? a.entities[l] : e);
+  const int64_t cell0 = (a.entities0 ? a.entities0[l] : e);
+  const int64_t cell1 = (a.entities1 ? a.entities1[l] : e);
   const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
   double cd[NV * 3];
   gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
@@ -740,6 +776,9 @@ extern "C" int mpcx_assemble_vector(const mpcx_vector_args_t* args)
   switch (k.form)
   {
   case MPCX_FORM_SOURCE:
+    // the periodic benchmark's right-hand side (bench_periodic.py:85-91) gets its own instantiation
+    if (k.celltype == MPCX_CELL_TETRAHEDRON && k.degree == 1 && k.bs == 1 && k.fn_id == 1)
+      return launch_vector<ElementOp<3, 1, 1, MPCX_FORM_SOURCE, 1>>(a);
     MPCX_FOR_SPACES(launch_vector, MPCX_FORM_SOURCE)
     break;
   case MPCX_FORM_FACET_SOURCE:

@@ -113,7 +113,7 @@ typedef struct
   /* integration domain: Form::domain / domain_arg (cpp/assemble_matrix.cpp:625-630) */
   int32_t estride;          /* 1 cells, 2 (cell, local_facet) */
   int64_t n_entities;
-  const int32_t* entities;  /* DEVICE [n_entities*estride] */
+  const int32_t* entities;  /* DEVICE [n_entities*estride]; NULL (all three, estride 1) = entity i is cell i */
   const int32_t* entities0; /* DEVICE, test-space cells (same layout) */
   const int32_t* entities1; /* DEVICE, trial-space cells */
   const double* coeffs;     /* DEVICE [n_entities][cstride] packed coefficients, or NULL */
