@@ -230,6 +230,8 @@ __global__ void __launch_bounds__(64) matrix_mpc_kernel(mpcx_matrix_args_t a)
 // ---------------------------------------------------------------------------
 constexpr int MPCX_MASK_SHIFT = 28;
 constexpr int MPCX_DOF_MASK = (1 << MPCX_MASK_SHIFT) - 1;
+// launch bound 1024 caps the kernel at 128 VGPRs = 4 waves/SIMD; measured faster
+// (2.25 ms) than the spill-free 150-VGPR build at 3 waves/SIMD (2.56 ms).
 constexpr int ROWBLOCK_MAX_THREADS = 1024;
 
 template <class Op>
@@ -267,7 +269,7 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
     int lf;
     int32_t xd[NV];
     int32_t m0[ND], m1[ND];
-    uint8_t off[ND * ND];
+    uint32_t ow[(ND * ND + 3) / 4]; // scatter offsets, 4 per word (unpacked at use: v_bfe_u32)
   };
   auto load_ent = [&](int64_t t, Ent& E)
   {
@@ -279,13 +281,33 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
     E.e = e;
     E.lf = a.estride == 2 ? a.entities[l + 1] : 0;
 #pragma unroll
-    for (int i = 0; i < NV; ++i)
-      E.xd[i] = a.x_dofmap[cell * NV + i];
-#pragma unroll
     for (int i = 0; i < ND; ++i)
     {
       E.m0[i] = a.mdofmap0[cell0 * ND + i];
       E.m1[i] = a.mdofmap1[cell1 * ND + i];
+    }
+    // x_dofmap == NULL: the caller found the geometry dofmap identical to the
+    // (P1) test-space dofmap, so the nodes are the dof blocks already in hand
+    if constexpr (NV == ND)
+    {
+      if (a.x_dofmap)
+      {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+          E.xd[i] = a.x_dofmap[cell * NV + i];
+      }
+      else
+      {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+          E.xd[i] = E.m0[i] & MPCX_DOF_MASK;
+      }
+    }
+    else
+    {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        E.xd[i] = a.x_dofmap[cell * NV + i];
     }
     // scatter offsets of this entity (ND*ND bytes, contiguous)
     const uint8_t* po = a.plan.ent_offs + e * (ND * ND);
@@ -295,17 +317,24 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
       for (int w = 0; w < ND * ND / 16; ++w)
       {
         const uint4 v = reinterpret_cast<const uint4*>(po)[w];
-        const unsigned u[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-          E.off[16 * w + q] = (u[q >> 2] >> (8 * (q & 3))) & 0xff;
+        E.ow[4 * w] = v.x;
+        E.ow[4 * w + 1] = v.y;
+        E.ow[4 * w + 2] = v.z;
+        E.ow[4 * w + 3] = v.w;
       }
     }
     else
     {
 #pragma unroll
-      for (int q = 0; q < ND * ND; ++q)
-        E.off[q] = po[q];
+      for (int w = 0; w < (ND * ND + 3) / 4; ++w)
+      {
+        uint32_t u = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (4 * w + q < ND * ND)
+            u |= uint32_t(po[4 * w + q]) << (8 * q);
+        E.ow[w] = u;
+      }
     }
   };
 
@@ -357,7 +386,7 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
           {
             if ((cur.m1[j] >> (MPCX_MASK_SHIFT + q)) & 1)
               continue;
-            __hip_atomic_fetch_add(s_vals + base + int(cur.off[i * ND + j]) * BS + q,
+            __hip_atomic_fetch_add(s_vals + base + int((cur.ow[(i * ND + j) >> 2] >> (8 * ((i * ND + j) & 3))) & 0xff) * BS + q,
                                    Ae[(i * BS + k) * N + j * BS + q], __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_WORKGROUP);
           }
@@ -655,19 +684,17 @@ int launch_matrix(const mpcx_matrix_args_t& a)
         mpcx_set_error("mpcx_assemble_matrix: row-block plan exceeds 160 KiB of LDS");
         return -4;
       }
-      if (int rc = check(hipFuncSetAttribute(reinterpret_cast<const void*>(matrix_rowblock_kernel<Op>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)),
-                         "hipFuncSetAttribute"))
-        return rc;
       const unsigned grid = 8u * unsigned((a.plan.num_blocks + 7) / 8);
-      // LDS admits 2 blocks per CU at the default plan size; 512 threads each
-      // = 4 waves per SIMD, what the kernel's register count allows
       const int threads = []
       {
         const char* e = std::getenv("MPCX_ROWBLOCK_THREADS");
         const int t = e ? std::atoi(e) : 512;
-        return (t == 128 || t == 256 || t == 512 || t == 1024) ? t : 512;
+        return (t >= 64 && t <= 1024 && t % 64 == 0) ? t : 512;
       }();
+      if (int rc = check(hipFuncSetAttribute(reinterpret_cast<const void*>(matrix_rowblock_kernel<Op>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)),
+                         "hipFuncSetAttribute"))
+        return rc;
       hipLaunchKernelGGL(matrix_rowblock_kernel<Op>, dim3(grid), dim3(threads), lds, stream, a);
     }
     else

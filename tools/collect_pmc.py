@@ -31,7 +31,7 @@ GROUPS = [
 
 
 def main():
-    out = sys.argv[1]
+    out = os.path.abspath(sys.argv[1])
     N = sys.argv[2] if len(sys.argv) > 2 else "256"
     os.makedirs(out, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
