@@ -88,7 +88,6 @@ class MatrixArgs(C.Structure):
         ("plan", RowBlockPlanT),
         ("mdofmap0", C.c_void_p),
         ("mdofmap1", C.c_void_p),
-        ("x_dofmap_is_dofmap0", C.c_int32),
         ("stream", C.c_void_p),
     ]
 

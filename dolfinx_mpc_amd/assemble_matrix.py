@@ -211,8 +211,8 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
         md1 = md0 if (V1 is V0 and mpc1 is mpc0 and bc1 is bc0) else _masked_dofmap(form, V1, bc1, mpc1, 1)
         a.mdofmap0, a.mdofmap1 = md0.data_ptr(), md1.data_ptr()
         keep += [pk, md0, md1]
-        # the bulk kernel then takes the nodes from the dofmap it already reads
-        a.x_dofmap_is_dofmap0 = 1 if _geometry_aliases_dofmap(form.mesh, V0) else 0
+        if _geometry_aliases_dofmap(form.mesh, V0):
+            a.x_dofmap = None  # the kernel takes the nodes from the dofmap it already reads
     return a, keep
 
 

@@ -286,11 +286,11 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
       E.m0[i] = a.mdofmap0[cell0 * ND + i];
       E.m1[i] = a.mdofmap1[cell1 * ND + i];
     }
-    // x_dofmap_is_dofmap0: the caller found the geometry dofmap identical to the
+    // x_dofmap == NULL: the caller found the geometry dofmap identical to the
     // (P1) test-space dofmap, so the nodes are the dof blocks already in hand
     if constexpr (NV == ND)
     {
-      if (!a.x_dofmap_is_dofmap0)
+      if (a.x_dofmap)
       {
 #pragma unroll
         for (int i = 0; i < NV; ++i)

@@ -108,7 +108,7 @@ typedef struct
   mpcx_kernel_t kernel;
   /* geometry: Geometry::x padded to 3 comps, one dofmap (cpp/assemble_matrix.cpp:462-470) */
   const double* x;         /* DEVICE [num_nodes][3] */
-  const int32_t* x_dofmap; /* DEVICE [num_cells][nv] */
+  const int32_t* x_dofmap; /* DEVICE [num_cells][nv]; rowblock only: NULL = identical to dofmap0 (P1, same cells) */
   int32_t nv;
   /* integration domain: Form::domain / domain_arg (cpp/assemble_matrix.cpp:625-630) */
   int32_t estride;          /* 1 cells, 2 (cell, local_facet) */
@@ -138,9 +138,6 @@ typedef struct
    * folded into bit 28+k of each blocked dof: no marker gathers in the kernel */
   const int32_t* mdofmap0; /* DEVICE [num_cells][nd0] */
   const int32_t* mdofmap1; /* DEVICE [num_cells][nd1] */
-  /* rowblock: non-zero if x_dofmap and dofmap0 hold the same table (P1 space numbered
-   * like the geometry): the kernel then reads it once */
-  int32_t x_dofmap_is_dofmap0;
   void* stream;
 } mpcx_matrix_args_t;
 
