@@ -158,19 +158,6 @@ def _masked_dofmap(form: Form, V, bc_dev, mpc, which: int):
     return form._device[key]
 
 
-def _geometry_aliases_dofmap(mesh, V) -> bool:
-    """True when the geometry dofmap and the (P1) space dofmap are the same table
-    (our generators; DOLFINx numbers them independently).  Then the row-block
-    kernel reads one table instead of two.  MPCX_NO_DOFMAP_ALIAS=1 disables it."""
-    if os.environ.get("MPCX_NO_DOFMAP_ALIAS"):
-        return False
-    key = ("alias", id(V))
-    if key not in mesh._device:
-        mesh._device[key] = bool(V.degree == 1 and V.dofmap.list.shape == mesh.geometry.dofmap.shape
-                                 and np.array_equal(V.dofmap.list, mesh.geometry.dofmap))
-    return mesh._device[key]
-
-
 def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, store_mode: int = 0,
                 with_mpc_kernel: bool = True):
     """Fill the C-ABI argument block of ``mpcx_assemble_matrix`` for integral i."""
@@ -211,8 +198,6 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
         md1 = md0 if (V1 is V0 and mpc1 is mpc0 and bc1 is bc0) else _masked_dofmap(form, V1, bc1, mpc1, 1)
         a.mdofmap0, a.mdofmap1 = md0.data_ptr(), md1.data_ptr()
         keep += [pk, md0, md1]
-        if _geometry_aliases_dofmap(form.mesh, V0):
-            a.x_dofmap = None  # the kernel takes the nodes from the dofmap it already reads
     return a, keep
 
 

@@ -286,29 +286,9 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
       E.m0[i] = a.mdofmap0[cell0 * ND + i];
       E.m1[i] = a.mdofmap1[cell1 * ND + i];
     }
-    // x_dofmap == NULL: the caller found the geometry dofmap identical to the
-    // (P1) test-space dofmap, so the nodes are the dof blocks already in hand
-    if constexpr (NV == ND)
-    {
-      if (a.x_dofmap)
-      {
 #pragma unroll
-        for (int i = 0; i < NV; ++i)
-          E.xd[i] = a.x_dofmap[cell * NV + i];
-      }
-      else
-      {
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-          E.xd[i] = E.m0[i] & MPCX_DOF_MASK;
-      }
-    }
-    else
-    {
-#pragma unroll
-      for (int i = 0; i < NV; ++i)
-        E.xd[i] = a.x_dofmap[cell * NV + i];
-    }
+    for (int i = 0; i < NV; ++i)
+      E.xd[i] = a.x_dofmap[cell * NV + i];
     // scatter offsets of this entity (ND*ND bytes, contiguous)
     const uint8_t* po = a.plan.ent_offs + e * (ND * ND);
     if constexpr ((ND * ND) % 16 == 0)

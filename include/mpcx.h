@@ -108,7 +108,7 @@ typedef struct
   mpcx_kernel_t kernel;
   /* geometry: Geometry::x padded to 3 comps, one dofmap (cpp/assemble_matrix.cpp:462-470) */
   const double* x;         /* DEVICE [num_nodes][3] */
-  const int32_t* x_dofmap; /* DEVICE [num_cells][nv]; rowblock only: NULL = identical to dofmap0 (P1, same cells) */
+  const int32_t* x_dofmap; /* DEVICE [num_cells][nv] */
   int32_t nv;
   /* integration domain: Form::domain / domain_arg (cpp/assemble_matrix.cpp:625-630) */
   int32_t estride;          /* 1 cells, 2 (cell, local_facet) */
