@@ -40,7 +40,10 @@ def main():
         cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + g.split() + ["-d", out, "-o", "p_" + name, "--",
                                                                       sys.executable, os.path.join(ROOT, "tools", "profile_kernels.py"), N, "2"]
         with open(os.path.join(out, f"log_{name}.txt"), "w") as fh:
-            subprocess.run(cmd, stdout=fh, stderr=subprocess.STDOUT, env=env, cwd="/tmp")
+            try:
+                subprocess.run(cmd, stdout=fh, stderr=subprocess.STDOUT, env=env, cwd="/tmp", timeout=240)
+            except subprocess.TimeoutExpired:
+                fh.write("\nTIMEOUT\n")
     summary = {}
     for f in sorted(glob.glob(os.path.join(out, "p_*_results.db"))):
         cur = sqlite3.connect(f).cursor()
