@@ -55,7 +55,8 @@ def integral_device(form: Form, i: int):
             int(integ.entities[-1]) == integ.entities.size - 1 and bool(np.all(np.diff(integ.entities) == 1))
         d["entities_ptr"] = None if ident else d["entities"].data_ptr()
         d["kernel"] = _native.KernelT(
-            k.form, k.celltype, k.degree, k.bs, k.fn_id, k.coeff_degree, int(k.qwts.size), int(k.fqwts.size),
+            k.form, k.celltype, k.degree, k.bs, k.degree1 or k.degree, k.bs1 or k.bs, k.fn_id, k.coeff_degree,
+            int(k.qwts.size), int(k.fqwts.size),
             d["qpts"].data_ptr(), d["qwts"].data_ptr(), d["fqpts"].data_ptr(), d["fqwts"].data_ptr(),
         )
         form._device[key] = d

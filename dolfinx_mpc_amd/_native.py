@@ -21,6 +21,8 @@ class KernelT(C.Structure):
         ("celltype", C.c_int32),
         ("degree", C.c_int32),
         ("bs", C.c_int32),
+        ("degree1", C.c_int32),
+        ("bs1", C.c_int32),
         ("fn_id", C.c_int32),
         ("coeff_degree", C.c_int32),
         ("nq", C.c_int32),

@@ -313,25 +313,52 @@ __device__ inline double eval_coefficient(int coeff_degree, const double* w, con
 }
 
 // ---------------------------------------------------------------------------
-// Generic element operator.  A is [N][N] (rank 2) or [N] (rank 1), row-major,
-// blocked dof index i*BS + k, accumulated into a zeroed buffer like UFCx.
+// Generic element operator for a (test, trial) pair of Lagrange spaces.
+//
+// Test space: degree DEG0, block size BS0 (rows); trial space: DEG1, BS1 (cols);
+// blocked dof index i*BS + k, row-major, like a UFCx tabulate_tensor output.
+// Storage of the tensor A:
+//   rank 1 (SOURCE, FACET_SOURCE)           : [N0]
+//   component-diagonal forms with BS0 > 1
+//   (STIFFNESS, MASS, FACET_MASS: entry
+//   ((i,a),(j,b)) = delta_ab S_ij)            : the scalar [ND0][ND1] matrix S only
+//   everything else                          : [N0][N1]
+// get(A, p, q) hides the difference.  FN_ >= 0 fixes the analytic source
+// function at compile time; FN_ = -1 reads kernel.fn_id.
 // ---------------------------------------------------------------------------
-// FN_ >= 0 fixes the analytic source function at compile time (the switch of
-// eval_fn folds away inside the quadrature loop); FN_ = -1 reads kernel.fn_id.
-template <int TDIM_, int DEG_, int BS_, int FORM_, int FN_ = -1>
+template <int TDIM_, int DEG0_, int BS0_, int DEG1_, int BS1_, int FORM_, int FN_ = -1>
 struct ElementOp
 {
   static constexpr int TDIM = TDIM_;
-  static constexpr int DEG = DEG_;
-  static constexpr int BS = BS_;
   static constexpr int FORM = FORM_;
-  using L = Lagrange<TDIM, DEG>;
+  using L0 = Lagrange<TDIM, DEG0_>;
+  using L1 = Lagrange<TDIM, DEG1_>;
   static constexpr int NV = TDIM + 1;
-  static constexpr int ND = L::ND;
-  static constexpr int N = ND * BS;
+  static constexpr int ND0 = L0::ND, ND1 = L1::ND;
+  static constexpr int BS0 = BS0_, BS1 = BS1_;
+  static constexpr int N0 = ND0 * BS0, N1 = ND1 * BS1;
   static constexpr bool FACET = (FORM == MPCX_FORM_FACET_MASS || FORM == MPCX_FORM_FACET_SOURCE);
   static constexpr bool RANK1 = (FORM == MPCX_FORM_SOURCE || FORM == MPCX_FORM_FACET_SOURCE);
-  static constexpr int SIZE = RANK1 ? N : N * N;
+  static constexpr bool SQUARE = (DEG0_ == DEG1_ && BS0_ == BS1_);
+  static constexpr bool DIAG
+      = (FORM == MPCX_FORM_STIFFNESS || FORM == MPCX_FORM_MASS || FORM == MPCX_FORM_FACET_MASS) && BS0 > 1;
+  static constexpr int SIZE = RANK1 ? N0 : (DIAG ? ND0 * ND1 : N0 * N1);
+  static_assert(!(FORM == MPCX_FORM_STIFFNESS || FORM == MPCX_FORM_MASS || FORM == MPCX_FORM_FACET_MASS
+                  || FORM == MPCX_FORM_ELASTICITY)
+                    || SQUARE,
+                "form needs test space == trial space");
+  static_assert(FORM != MPCX_FORM_ELASTICITY || BS0 == TDIM, "elasticity needs bs == tdim");
+  static_assert(FORM != MPCX_FORM_DIV_TEST || (BS0 == TDIM && BS1 == 1), "div(v) p: vector test, scalar trial");
+  static_assert(FORM != MPCX_FORM_DIV_TRIAL || (BS0 == 1 && BS1 == TDIM), "div(u) q: scalar test, vector trial");
+
+  // entry (p, q) of the element matrix, p = i*BS0 + a, q = j*BS1 + b
+  __device__ static inline double get(const double (&A)[SIZE], int p, int q)
+  {
+    if constexpr (DIAG)
+      return (p % BS0) == (q % BS1) ? A[(p / BS0) * ND1 + q / BS1] : 0.0;
+    else
+      return A[p * N1 + q];
+  }
 
   __device__ static inline void tabulate(double (&A)[SIZE], const double* w, const double* c,
                                          const double (&cd)[NV * 3], int lf, const mpcx_kernel_t& k)
@@ -341,7 +368,7 @@ struct ElementOp
       A[i] = 0.0;
 
     // P1 simplex Laplacian: constant gradients, one point is exact
-    if constexpr (FORM == MPCX_FORM_STIFFNESS && DEG == 1 && BS == 1)
+    if constexpr (FORM == MPCX_FORM_STIFFNESS && DEG0_ == 1)
     {
       if (k.coeff_degree == 0)
       {
@@ -376,44 +403,40 @@ struct ElementOp
     {
       double X[3];
       const double wq = qp.point(k, q, adet, X);
-      double phi[ND], dphi[ND][TDIM];
-      L::eval(X, phi, dphi);
+      double phi[ND0], dphi[ND0][TDIM];
+      L0::eval(X, phi, dphi);
       double s = wq * c0;
       if (k.coeff_degree > 0 && FORM != MPCX_FORM_ELASTICITY)
         s *= eval_coefficient<TDIM>(k.coeff_degree, w, X);
 
       if constexpr (FORM == MPCX_FORM_MASS || FORM == MPCX_FORM_FACET_MASS)
       {
+        // scalar matrix S (expanded per component by get() when BS0 > 1)
 #pragma unroll
-        for (int i = 0; i < ND; ++i)
+        for (int i = 0; i < ND0; ++i)
 #pragma unroll
-          for (int j = 0; j < ND; ++j)
-          {
-            const double v = s * phi[i] * phi[j];
-#pragma unroll
-            for (int b = 0; b < BS; ++b)
-              A[(i * BS + b) * N + (j * BS + b)] += v;
-          }
+          for (int j = 0; j < ND1; ++j)
+            A[i * ND1 + j] += s * phi[i] * phi[j];
       }
       else if constexpr (RANK1)
       {
         double x[3];
         push_forward<TDIM>(cd, X, x);
 #pragma unroll
-        for (int b = 0; b < BS; ++b)
+        for (int b = 0; b < BS0; ++b)
         {
           const double f = s * eval_fn(FN_ >= 0 ? FN_ : k.fn_id, x, b, c);
 #pragma unroll
-          for (int i = 0; i < ND; ++i)
-            A[i * BS + b] += f * phi[i];
+          for (int i = 0; i < ND0; ++i)
+            A[i * BS0 + b] += f * phi[i];
         }
       }
       else
       {
-        // physical gradients
-        double g[ND][TDIM];
+        // physical gradients of the test basis
+        double g[ND0][TDIM];
 #pragma unroll
-        for (int i = 0; i < ND; ++i)
+        for (int i = 0; i < ND0; ++i)
 #pragma unroll
           for (int a = 0; a < TDIM; ++a)
           {
@@ -426,44 +449,73 @@ struct ElementOp
         if constexpr (FORM == MPCX_FORM_STIFFNESS)
         {
 #pragma unroll
-          for (int i = 0; i < ND; ++i)
+          for (int i = 0; i < ND0; ++i)
 #pragma unroll
-            for (int j = 0; j < ND; ++j)
+            for (int j = 0; j < ND1; ++j)
             {
               double dot = 0.0;
 #pragma unroll
               for (int a = 0; a < TDIM; ++a)
                 dot += g[i][a] * g[j][a];
-#pragma unroll
-              for (int b = 0; b < BS; ++b)
-                A[(i * BS + b) * N + (j * BS + b)] += s * dot;
+              A[i * ND1 + j] += s * dot;
             }
         }
         else if constexpr (FORM == MPCX_FORM_ELASTICITY)
         {
-          static_assert(FORM != MPCX_FORM_ELASTICITY || BS == TDIM, "elasticity needs bs == tdim");
           const double mu = c[0], lmbda = c[1];
 #pragma unroll
-          for (int i = 0; i < ND; ++i)
+          for (int i = 0; i < ND0; ++i)
 #pragma unroll
-            for (int j = 0; j < ND; ++j)
+            for (int j = 0; j < ND1; ++j)
             {
               double dot = 0.0;
 #pragma unroll
               for (int a = 0; a < TDIM; ++a)
                 dot += g[i][a] * g[j][a];
 #pragma unroll
-              for (int a = 0; a < BS; ++a)
+              for (int a = 0; a < BS0; ++a)
 #pragma unroll
-                for (int b = 0; b < BS; ++b)
+                for (int b = 0; b < BS1; ++b)
                 {
                   double v = mu * g[i][b] * g[j][a] + lmbda * g[i][a] * g[j][b];
                   if (a == b)
                     v += mu * dot;
-                  A[(i * BS + a) * N + (j * BS + b)] += wq * v;
+                  A[(i * BS0 + a) * N1 + (j * BS1 + b)] += wq * v;
                 }
             }
         }
+        else if constexpr (FORM == MPCX_FORM_DIV_TEST)
+        {
+          // A[(i,a)][j] = c0 * int psi_j d_a(phi_i): test = vector space, trial = scalar
+          double psi[ND1], dpsi[ND1][TDIM];
+          L1::eval(X, psi, dpsi);
+#pragma unroll
+          for (int i = 0; i < ND0; ++i)
+#pragma unroll
+            for (int a = 0; a < BS0; ++a)
+#pragma unroll
+              for (int j = 0; j < ND1; ++j)
+                A[(i * BS0 + a) * N1 + j] += s * g[i][a] * psi[j];
+        }
+      }
+      if constexpr (FORM == MPCX_FORM_DIV_TRIAL)
+      {
+        // A[i][(j,b)] = c0 * int psi_i d_b(phi_j): test = scalar space, trial = vector
+        double vphi[ND1], dvphi[ND1][TDIM];
+        L1::eval(X, vphi, dvphi);
+#pragma unroll
+        for (int j = 0; j < ND1; ++j)
+#pragma unroll
+          for (int b = 0; b < BS1; ++b)
+          {
+            double gjb = 0.0;
+#pragma unroll
+            for (int d = 0; d < TDIM; ++d)
+              gjb += K[d][b] * dvphi[j][d];
+#pragma unroll
+            for (int i = 0; i < ND0; ++i)
+              A[i * N1 + j * BS1 + b] += s * phi[i] * gjb;
+          }
       }
     }
   }

@@ -9,8 +9,9 @@
 // the reference's numba assembler splits it (numba/assemble_matrix.py:100):
 // the bulk kernel handles every entity with slave rows/cols masked out, and a
 // second kernel over the compact list of slave entities adds the master
-// row/column contributions.  All arithmetic is fp64; the path is HBM-bound
-// (no dense contraction), so there is no MFMA here.
+// row/column contributions.  Test and trial spaces may differ (rectangular
+// blocks, cpp/assemble_matrix.cpp:537-541).  All arithmetic is fp64; the path is
+// HBM-bound (no dense contraction), so there is no MFMA here.
 #include "mpcx.h"
 #include "mpcx_elements.hpp"
 #include "mpcx_internal.h"
@@ -64,7 +65,8 @@ __device__ inline void gather_coords(const double* __restrict__ x, const int32_t
 template <class Op>
 __global__ void __launch_bounds__(256) matrix_atomic_kernel(mpcx_matrix_args_t a)
 {
-  constexpr int N = Op::N, ND = Op::ND, BS = Op::BS, NV = Op::NV;
+  constexpr int N0 = Op::N0, N1 = Op::N1, ND0 = Op::ND0, ND1 = Op::ND1, BS0 = Op::BS0, BS1 = Op::BS1,
+                NV = Op::NV;
   const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (e >= a.n_entities)
     return;
@@ -76,40 +78,54 @@ __global__ void __launch_bounds__(256) matrix_atomic_kernel(mpcx_matrix_args_t a
 
   double cd[NV * 3];
   gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
-  double Ae[N * N];
+  double Ae[Op::SIZE];
   Op::tabulate(Ae, a.coeffs ? a.coeffs + e * a.cstride : nullptr, a.constants, cd, lf, a.kernel);
 
-  int32_t rows[N], colsd[N];
-  bool rmask[N], cmask[N];
+  int32_t rows[N0], colsd[N1];
+  bool rmask[N0], cmask[N1];
 #pragma unroll
-  for (int i = 0; i < ND; ++i)
+  for (int i = 0; i < ND0; ++i)
   {
-    const int32_t d0 = a.dofmap0[cell0 * ND + i];
-    const int32_t d1 = a.dofmap1[cell1 * ND + i];
+    const int32_t d0 = a.dofmap0[cell0 * ND0 + i];
 #pragma unroll
-    for (int k = 0; k < BS; ++k)
+    for (int k = 0; k < BS0; ++k)
     {
-      const int32_t r = d0 * BS + k, c = d1 * BS + k;
-      rows[i * BS + k] = r;
-      colsd[i * BS + k] = c;
-      rmask[i * BS + k] = (a.bc0 && a.bc0[r]) || a.mpc0.is_slave[r];
-      cmask[i * BS + k] = (a.bc1 && a.bc1[c]) || a.mpc1.is_slave[c];
+      const int32_t r = d0 * BS0 + k;
+      rows[i * BS0 + k] = r;
+      rmask[i * BS0 + k] = (a.bc0 && a.bc0[r]) || a.mpc0.is_slave[r];
     }
   }
 #pragma unroll
-  for (int i = 0; i < N; ++i)
+  for (int j = 0; j < ND1; ++j)
   {
-    if (rmask[i])
-      continue;
-    const int lo = a.rowptr[rows[i]], hi = a.rowptr[rows[i] + 1];
+    const int32_t d1 = a.dofmap1[cell1 * ND1 + j];
 #pragma unroll
-    for (int j = 0; j < N; ++j)
+    for (int k = 0; k < BS1; ++k)
     {
-      if (cmask[j])
+      const int32_t c = d1 * BS1 + k;
+      colsd[j * BS1 + k] = c;
+      cmask[j * BS1 + k] = (a.bc1 && a.bc1[c]) || a.mpc1.is_slave[c];
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < N0; ++p)
+  {
+    if (rmask[p])
+      continue;
+    const int lo = a.rowptr[rows[p]], hi = a.rowptr[rows[p] + 1];
+#pragma unroll
+    for (int q = 0; q < N1; ++q)
+    {
+      if (cmask[q])
         continue;
-      const int pos = csr_find(a.cols, lo, hi, colsd[j]);
+      if constexpr (Op::DIAG)
+      {
+        if ((p % BS0) != (q % BS1))
+          continue; // structurally zero entry of a component-diagonal form
+      }
+      const int pos = csr_find(a.cols, lo, hi, colsd[q]);
       if (pos >= 0)
-        atomic_add_f64(a.vals + pos, Ae[i * N + j]);
+        atomic_add_f64(a.vals + pos, Op::get(Ae, p, q));
     }
   }
 }
@@ -122,7 +138,8 @@ __global__ void __launch_bounds__(256) matrix_atomic_kernel(mpcx_matrix_args_t a
 template <class Op>
 __global__ void __launch_bounds__(64) matrix_mpc_kernel(mpcx_matrix_args_t a)
 {
-  constexpr int N = Op::N, ND = Op::ND, BS = Op::BS, NV = Op::NV;
+  constexpr int N0 = Op::N0, N1 = Op::N1, ND0 = Op::ND0, ND1 = Op::ND1, BS0 = Op::BS0, BS1 = Op::BS1,
+                NV = Op::NV;
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= a.n_slave_entities)
     return;
@@ -135,34 +152,38 @@ __global__ void __launch_bounds__(64) matrix_mpc_kernel(mpcx_matrix_args_t a)
 
   double cd[NV * 3];
   gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
-  double Ae[N * N];
+  double Ae[Op::SIZE];
   Op::tabulate(Ae, a.coeffs ? a.coeffs + e * a.cstride : nullptr, a.constants, cd, lf, a.kernel);
 
-  int32_t rows[N], colsd[N];
-  bool rbc[N], cbc[N], rsl[N], csl[N];
-  for (int i = 0; i < ND; ++i)
+  int32_t rows[N0], colsd[N1];
+  bool rbc[N0], cbc[N1], rsl[N0], csl[N1];
+  for (int i = 0; i < ND0; ++i)
   {
-    const int32_t d0 = a.dofmap0[cell0 * ND + i];
-    const int32_t d1 = a.dofmap1[cell1 * ND + i];
-    for (int k = 0; k < BS; ++k)
+    const int32_t d0 = a.dofmap0[cell0 * ND0 + i];
+    for (int k = 0; k < BS0; ++k)
     {
-      const int32_t r = d0 * BS + k, c = d1 * BS + k;
-      rows[i * BS + k] = r;
-      colsd[i * BS + k] = c;
-      rbc[i * BS + k] = a.bc0 && a.bc0[r];
-      cbc[i * BS + k] = a.bc1 && a.bc1[c];
-      rsl[i * BS + k] = a.mpc0.is_slave[r];
-      csl[i * BS + k] = a.mpc1.is_slave[c];
+      const int32_t r = d0 * BS0 + k;
+      rows[i * BS0 + k] = r;
+      rbc[i * BS0 + k] = a.bc0 && a.bc0[r];
+      rsl[i * BS0 + k] = a.mpc0.is_slave[r];
+    }
+  }
+  for (int j = 0; j < ND1; ++j)
+  {
+    const int32_t d1 = a.dofmap1[cell1 * ND1 + j];
+    for (int k = 0; k < BS1; ++k)
+    {
+      const int32_t c = d1 * BS1 + k;
+      colsd[j * BS1 + k] = c;
+      cbc[j * BS1 + k] = a.bc1 && a.bc1[c];
+      csl[j * BS1 + k] = a.mpc1.is_slave[c];
     }
   }
   // Dirichlet rows/cols are zeroed before the MPC modification (:510-533)
-  for (int i = 0; i < N; ++i)
-    for (int j = 0; j < N; ++j)
-      if (rbc[i] || cbc[j])
-        Ae[i * N + j] = 0.0;
+  auto entry = [&](int p, int q) -> double { return (rbc[p] || cbc[q]) ? 0.0 : Op::get(Ae, p, q); };
 
   // row masters (:214-246)
-  for (int p = 0; p < N; ++p)
+  for (int p = 0; p < N0; ++p)
   {
     if (!rsl[p])
       continue;
@@ -171,8 +192,9 @@ __global__ void __launch_bounds__(64) matrix_mpc_kernel(mpcx_matrix_args_t a)
       const int32_t m = a.mpc0.masters[mi];
       const double ci = a.mpc0.coeffs[mi];
       const int lo = a.rowptr[m], hi = a.rowptr[m + 1];
-      for (int q = 0; q < N; ++q)
+      for (int q = 0; q < N1; ++q)
       {
+        const double v = entry(p, q);
         if (csl[q])
         {
           // master-master term uses the un-stripped original (:239-245)
@@ -180,7 +202,7 @@ __global__ void __launch_bounds__(64) matrix_mpc_kernel(mpcx_matrix_args_t a)
           {
             const int pos = csr_find(a.cols, lo, hi, a.mpc1.masters[mj]);
             if (pos >= 0)
-              atomic_add_f64(a.vals + pos, ci * a.mpc1.coeffs[mj] * Ae[p * N + q]);
+              atomic_add_f64(a.vals + pos, ci * a.mpc1.coeffs[mj] * v);
           }
         }
         else if (!cbc[q])
@@ -188,13 +210,13 @@ __global__ void __launch_bounds__(64) matrix_mpc_kernel(mpcx_matrix_args_t a)
           // stripped row: slave-slave entries removed (:226-236)
           const int pos = csr_find(a.cols, lo, hi, colsd[q]);
           if (pos >= 0)
-            atomic_add_f64(a.vals + pos, ci * Ae[p * N + q]);
+            atomic_add_f64(a.vals + pos, ci * v);
         }
       }
     }
   }
   // column masters (:251-267)
-  for (int q = 0; q < N; ++q)
+  for (int q = 0; q < N1; ++q)
   {
     if (!csl[q])
       continue;
@@ -202,13 +224,13 @@ __global__ void __launch_bounds__(64) matrix_mpc_kernel(mpcx_matrix_args_t a)
     {
       const int32_t m = a.mpc1.masters[mj];
       const double cj = a.mpc1.coeffs[mj];
-      for (int p = 0; p < N; ++p)
+      for (int p = 0; p < N0; ++p)
       {
         if (rsl[p] || rbc[p])
           continue;
         const int pos = csr_find(a.cols, a.rowptr[rows[p]], a.rowptr[rows[p] + 1], m);
         if (pos >= 0)
-          atomic_add_f64(a.vals + pos, cj * Ae[p * N + q]);
+          atomic_add_f64(a.vals + pos, cj * entry(p, q));
       }
     }
   }
@@ -237,7 +259,8 @@ constexpr int ROWBLOCK_MAX_THREADS = 1024;
 template <class Op>
 __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(mpcx_matrix_args_t a)
 {
-  constexpr int N = Op::N, ND = Op::ND, BS = Op::BS, NV = Op::NV;
+  constexpr int ND0 = Op::ND0, ND1 = Op::ND1, BS0 = Op::BS0, BS1 = Op::BS1, NV = Op::NV;
+  constexpr int NOFF = ND0 * ND1;
   const int NT = blockDim.x;
   extern __shared__ __align__(16) unsigned char smem[];
   // XCD-aware order: workgroup w runs on XCD w % 8 (observed placement, speed
@@ -268,8 +291,8 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
     int64_t e;
     int lf;
     int32_t xd[NV];
-    int32_t m0[ND], m1[ND];
-    uint32_t ow[(ND * ND + 3) / 4]; // scatter offsets, 4 per word (unpacked at use: v_bfe_u32)
+    int32_t m0[ND0], m1[ND1];
+    uint32_t ow[(NOFF + 3) / 4]; // scatter offsets, 4 per word (unpacked at use: v_bfe_u32)
   };
   auto load_ent = [&](int64_t t, Ent& E)
   {
@@ -281,20 +304,20 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
     E.e = e;
     E.lf = a.estride == 2 ? a.entities[l + 1] : 0;
 #pragma unroll
-    for (int i = 0; i < ND; ++i)
-    {
-      E.m0[i] = a.mdofmap0[cell0 * ND + i];
-      E.m1[i] = a.mdofmap1[cell1 * ND + i];
-    }
+    for (int i = 0; i < ND0; ++i)
+      E.m0[i] = a.mdofmap0[cell0 * ND0 + i];
+#pragma unroll
+    for (int j = 0; j < ND1; ++j)
+      E.m1[j] = a.mdofmap1[cell1 * ND1 + j];
 #pragma unroll
     for (int i = 0; i < NV; ++i)
       E.xd[i] = a.x_dofmap[cell * NV + i];
-    // scatter offsets of this entity (ND*ND bytes, contiguous)
-    const uint8_t* po = a.plan.ent_offs + e * (ND * ND);
-    if constexpr ((ND * ND) % 16 == 0)
+    // scatter offsets of this entity (ND0*ND1 bytes, contiguous)
+    const uint8_t* po = a.plan.ent_offs + e * NOFF;
+    if constexpr (NOFF % 16 == 0)
     {
 #pragma unroll
-      for (int w = 0; w < ND * ND / 16; ++w)
+      for (int w = 0; w < NOFF / 16; ++w)
       {
         const uint4 v = reinterpret_cast<const uint4*>(po)[w];
         E.ow[4 * w] = v.x;
@@ -303,15 +326,21 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
         E.ow[4 * w + 3] = v.w;
       }
     }
+    else if constexpr (NOFF % 4 == 0)
+    {
+#pragma unroll
+      for (int w = 0; w < NOFF / 4; ++w)
+        E.ow[w] = reinterpret_cast<const uint32_t*>(po)[w];
+    }
     else
     {
 #pragma unroll
-      for (int w = 0; w < (ND * ND + 3) / 4; ++w)
+      for (int w = 0; w < (NOFF + 3) / 4; ++w)
       {
         uint32_t u = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          if (4 * w + q < ND * ND)
+          if (4 * w + q < NOFF)
             u |= uint32_t(po[4 * w + q]) << (8 * q);
         E.ow[w] = u;
       }
@@ -321,7 +350,7 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
   // Software pipeline (small elements): the index data of the next entity is
   // requested while the current one is computed, so each iteration waits for one
   // memory round trip (the coordinate gather) instead of three dependent ones.
-  constexpr bool PREFETCH = (ND * ND <= 16);
+  constexpr bool PREFETCH = (NOFF <= 16);
   const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
   int64_t t = e0 + tid;
   Ent cur;
@@ -346,29 +375,34 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
       if (t + NT < e1)
         load_ent(t + NT, nxt);
     }
-    double Ae[N * N];
+    double Ae[Op::SIZE];
     Op::tabulate(Ae, a.coeffs ? a.coeffs + cur.e * a.cstride : nullptr, a.constants, cd, cur.lf, a.kernel);
 #pragma unroll
-    for (int i = 0; i < ND; ++i)
+    for (int i = 0; i < ND0; ++i)
     {
 #pragma unroll
-      for (int k = 0; k < BS; ++k)
+      for (int k = 0; k < BS0; ++k)
       {
-        const int r = (cur.m0[i] & MPCX_DOF_MASK) * BS + k;
+        const int r = (cur.m0[i] & MPCX_DOF_MASK) * BS0 + k;
         if (r < r0 || r >= r1 || ((cur.m0[i] >> (MPCX_MASK_SHIFT + k)) & 1))
           continue;
         const int base = s_rowlo[r - r0];
 #pragma unroll
-        for (int j = 0; j < ND; ++j)
+        for (int j = 0; j < ND1; ++j)
         {
+          const int off = int((cur.ow[(i * ND1 + j) >> 2] >> (8 * ((i * ND1 + j) & 3))) & 0xff) * BS1;
 #pragma unroll
-          for (int q = 0; q < BS; ++q)
+          for (int q = 0; q < BS1; ++q)
           {
+            if constexpr (Op::DIAG)
+            {
+              if (k != q)
+                continue; // structurally zero
+            }
             if ((cur.m1[j] >> (MPCX_MASK_SHIFT + q)) & 1)
               continue;
-            __hip_atomic_fetch_add(s_vals + base + int((cur.ow[(i * ND + j) >> 2] >> (8 * ((i * ND + j) & 3))) & 0xff) * BS + q,
-                                   Ae[(i * BS + k) * N + j * BS + q], __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(s_vals + base + off + q, Op::get(Ae, i * BS0 + k, j * BS1 + q),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
         }
       }
@@ -456,16 +490,16 @@ __global__ void add_diagonal_kernel(const int32_t* __restrict__ rowptr, const in
 template <int N>
 struct VectorCfg
 {
-  static constexpr int NT = N <= 4 ? 256 : 128;                       // threads per workgroup
-  static constexpr int LOG2H = N <= 4 ? 11 : (N <= 16 ? 12 : 13);     // table size >= 2 * NT * N
+  static constexpr int NT = N <= 4 ? 256 : (N <= 16 ? 128 : 64); // threads per workgroup
+  static constexpr int LOG2H = N <= 4 ? 11 : 12;                  // table size >= 2 * NT * N (<= 48 KB)
   static constexpr int H = 1 << LOG2H;
-  static_assert(H >= 2 * NT * N || N > 16, "hash table too small");
+  static_assert(H >= 2 * NT * N, "hash table too small");
 };
 
 template <class Op>
-__global__ void __launch_bounds__(VectorCfg<Op::N>::NT) vector_kernel(mpcx_vector_args_t a)
+__global__ void __launch_bounds__(VectorCfg<Op::N0>::NT) vector_kernel(mpcx_vector_args_t a)
 {
-  constexpr int N = Op::N, ND = Op::ND, BS = Op::BS, NV = Op::NV;
+  constexpr int N = Op::N0, ND = Op::ND0, BS = Op::BS0, NV = Op::NV;
   constexpr int NT = VectorCfg<N>::NT, H = VectorCfg<N>::H, LOG2H = VectorCfg<N>::LOG2H;
   __shared__ int32_t s_key[H];
   __shared__ double s_val[H];
@@ -535,9 +569,9 @@ __global__ void __launch_bounds__(VectorCfg<Op::N>::NT) vector_kernel(mpcx_vecto
 // have a bc-marked column dof; Ae is the raw kernel output (:267-272).
 // ---------------------------------------------------------------------------
 template <class Op>
-__global__ void __launch_bounds__(256) lifting_kernel(mpcx_lifting_args_t a)
+__global__ void __launch_bounds__(128) lifting_kernel(mpcx_lifting_args_t a)
 {
-  constexpr int N = Op::N, ND = Op::ND, BS = Op::BS, NV = Op::NV;
+  constexpr int N0 = Op::N0, ND0 = Op::ND0, ND1 = Op::ND1, BS0 = Op::BS0, BS1 = Op::BS1, NV = Op::NV;
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= a.n_lift_entities)
     return;
@@ -549,38 +583,39 @@ __global__ void __launch_bounds__(256) lifting_kernel(mpcx_lifting_args_t a)
   const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
   double cd[NV * 3];
   gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
-  double Ae[N * N];
+  double Ae[Op::SIZE];
   Op::tabulate(Ae, a.coeffs ? a.coeffs + e * a.cstride : nullptr, a.constants, cd, lf, a.kernel);
-  double be[N];
+  double be[N0];
 #pragma unroll
-  for (int m = 0; m < N; ++m)
+  for (int m = 0; m < N0; ++m)
     be[m] = 0.0;
 #pragma unroll
-  for (int j = 0; j < ND; ++j)
+  for (int j = 0; j < ND1; ++j)
   {
-    const int32_t d1 = a.dofmap1[cell1 * ND + j];
+    const int32_t d1 = a.dofmap1[cell1 * ND1 + j];
 #pragma unroll
-    for (int k = 0; k < BS; ++k)
+    for (int k = 0; k < BS1; ++k)
     {
-      const int32_t jj = d1 * BS + k;
+      const int32_t jj = d1 * BS1 + k;
       if (a.bc_markers1[jj])
       {
         const double g = a.scale * (a.bc_values1[jj] - (a.x0 ? a.x0[jj] : 0.0));
 #pragma unroll
-        for (int m = 0; m < N; ++m)
-          be[m] -= Ae[m * N + j * BS + k] * g;
+        for (int m = 0; m < N0; ++m)
+          be[m] -= Op::get(Ae, m, j * BS1 + k) * g;
       }
     }
   }
+  // slaves are applied against the row dofmap (cpp/lifting.h:117-127)
 #pragma unroll
-  for (int i = 0; i < ND; ++i)
+  for (int i = 0; i < ND0; ++i)
   {
-    const int32_t d0 = a.dofmap0[cell0 * ND + i];
+    const int32_t d0 = a.dofmap0[cell0 * ND0 + i];
 #pragma unroll
-    for (int k = 0; k < BS; ++k)
+    for (int k = 0; k < BS0; ++k)
     {
-      const int32_t d = d0 * BS + k;
-      double v = be[i * BS + k];
+      const int32_t d = d0 * BS0 + k;
+      double v = be[i * BS0 + k];
       if (a.mpc0.is_slave[d])
       {
         const int m0 = a.mpc0.masters_offsets[d], m1 = a.mpc0.masters_offsets[d + 1];
@@ -635,6 +670,11 @@ inline unsigned grid_for(int64_t n, int block) { return static_cast<unsigned>((n
 template <class Op>
 int launch_matrix(const mpcx_matrix_args_t& a)
 {
+  if (a.nd0 != Op::ND0 || a.nd1 != Op::ND1 || a.bs0 != Op::BS0 || a.bs1 != Op::BS1 || a.nv != Op::NV)
+  {
+    mpcx_set_error("mpcx_assemble_matrix: dofmap shapes do not match the element kernel");
+    return -12;
+  }
   hipStream_t stream = static_cast<hipStream_t>(a.stream);
   int alg = a.algorithm;
   if (alg == MPCX_ALG_AUTO)
@@ -696,9 +736,14 @@ int launch_matrix(const mpcx_matrix_args_t& a)
 template <class Op>
 int launch_vector(const mpcx_vector_args_t& a)
 {
+  if (a.nd != Op::ND0 || a.bs != Op::BS0 || a.nv != Op::NV)
+  {
+    mpcx_set_error("mpcx_assemble_vector: dofmap shape does not match the element kernel");
+    return -12;
+  }
   if (a.n_entities == 0)
     return 0;
-  constexpr int NT = VectorCfg<Op::N>::NT;
+  constexpr int NT = VectorCfg<Op::N0>::NT;
   hipLaunchKernelGGL(vector_kernel<Op>, dim3(grid_for(a.n_entities, NT)), dim3(NT), 0,
                      static_cast<hipStream_t>(a.stream), a);
   return check(hipGetLastError(), "vector kernel launch");
@@ -707,39 +752,69 @@ int launch_vector(const mpcx_vector_args_t& a)
 template <class Op>
 int launch_lifting(const mpcx_lifting_args_t& a)
 {
+  if (a.nd0 != Op::ND0 || a.nd1 != Op::ND1 || a.bs0 != Op::BS0 || a.bs1 != Op::BS1 || a.nv != Op::NV)
+  {
+    mpcx_set_error("mpcx_apply_lifting: dofmap shapes do not match the element kernel");
+    return -12;
+  }
   if (a.n_lift_entities == 0)
     return 0;
-  hipLaunchKernelGGL(lifting_kernel<Op>, dim3(grid_for(a.n_lift_entities, 256)), dim3(256), 0,
+  hipLaunchKernelGGL(lifting_kernel<Op>, dim3(grid_for(a.n_lift_entities, 128)), dim3(128), 0,
                      static_cast<hipStream_t>(a.stream), a);
   return check(hipGetLastError(), "lifting kernel launch");
 }
 
-// (cell, degree, bs) combinations compiled in
+inline bool is_space(const mpcx_kernel_t& k, int cell, int deg, int bs)
+{
+  return k.celltype == cell && k.degree == deg && k.bs == bs && k.degree1 == deg && k.bs1 == bs;
+}
+
+// square (test == trial) scalar and P1-vector spaces compiled in
 #define MPCX_FOR_SPACES(X, FORM)                                                                   \
-  if (k.celltype == MPCX_CELL_TETRAHEDRON && k.degree == 1 && k.bs == 1)                           \
-    return X<ElementOp<3, 1, 1, FORM>>(a);                                                         \
-  if (k.celltype == MPCX_CELL_TETRAHEDRON && k.degree == 2 && k.bs == 1)                           \
-    return X<ElementOp<3, 2, 1, FORM>>(a);                                                         \
-  if (k.celltype == MPCX_CELL_TRIANGLE && k.degree == 1 && k.bs == 1)                              \
-    return X<ElementOp<2, 1, 1, FORM>>(a);                                                         \
-  if (k.celltype == MPCX_CELL_TRIANGLE && k.degree == 2 && k.bs == 1)                              \
-    return X<ElementOp<2, 2, 1, FORM>>(a);                                                         \
-  if (k.celltype == MPCX_CELL_TETRAHEDRON && k.degree == 1 && k.bs == 3)                           \
-    return X<ElementOp<3, 1, 3, FORM>>(a);                                                         \
-  if (k.celltype == MPCX_CELL_TRIANGLE && k.degree == 1 && k.bs == 2)                              \
-    return X<ElementOp<2, 1, 2, FORM>>(a);
+  if (is_space(k, MPCX_CELL_TETRAHEDRON, 1, 1))                                                    \
+    return X<ElementOp<3, 1, 1, 1, 1, FORM>>(a);                                                   \
+  if (is_space(k, MPCX_CELL_TETRAHEDRON, 2, 1))                                                    \
+    return X<ElementOp<3, 2, 1, 2, 1, FORM>>(a);                                                   \
+  if (is_space(k, MPCX_CELL_TRIANGLE, 1, 1))                                                       \
+    return X<ElementOp<2, 1, 1, 1, 1, FORM>>(a);                                                   \
+  if (is_space(k, MPCX_CELL_TRIANGLE, 2, 1))                                                       \
+    return X<ElementOp<2, 2, 1, 2, 1, FORM>>(a);                                                   \
+  if (is_space(k, MPCX_CELL_TETRAHEDRON, 1, 3))                                                    \
+    return X<ElementOp<3, 1, 3, 1, 3, FORM>>(a);                                                   \
+  if (is_space(k, MPCX_CELL_TRIANGLE, 1, 2))                                                       \
+    return X<ElementOp<2, 1, 2, 1, 2, FORM>>(a);
+
+// P2 vector spaces (Taylor-Hood velocity): component-diagonal forms and sources only
+#define MPCX_FOR_P2_VECTOR_SPACES(X, FORM)                                                         \
+  if (is_space(k, MPCX_CELL_TETRAHEDRON, 2, 3))                                                    \
+    return X<ElementOp<3, 2, 3, 2, 3, FORM>>(a);                                                   \
+  if (is_space(k, MPCX_CELL_TRIANGLE, 2, 2))                                                       \
+    return X<ElementOp<2, 2, 2, 2, 2, FORM>>(a);
 
 #define MPCX_FOR_VECTOR_SPACES(X, FORM)                                                            \
-  if (k.celltype == MPCX_CELL_TETRAHEDRON && k.degree == 1 && k.bs == 3)                           \
-    return X<ElementOp<3, 1, 3, FORM>>(a);                                                         \
-  if (k.celltype == MPCX_CELL_TRIANGLE && k.degree == 1 && k.bs == 2)                              \
-    return X<ElementOp<2, 1, 2, FORM>>(a);
+  if (is_space(k, MPCX_CELL_TETRAHEDRON, 1, 3))                                                    \
+    return X<ElementOp<3, 1, 3, 1, 3, FORM>>(a);                                                   \
+  if (is_space(k, MPCX_CELL_TRIANGLE, 1, 2))                                                       \
+    return X<ElementOp<2, 1, 2, 1, 2, FORM>>(a);
+
+// velocity (P2 vector) x pressure (P1) blocks of Taylor-Hood
+#define MPCX_FOR_DIV_TEST(X)                                                                       \
+  if (k.celltype == MPCX_CELL_TETRAHEDRON && k.degree == 2 && k.bs == 3 && k.degree1 == 1 && k.bs1 == 1) \
+    return X<ElementOp<3, 2, 3, 1, 1, MPCX_FORM_DIV_TEST>>(a);                                     \
+  if (k.celltype == MPCX_CELL_TRIANGLE && k.degree == 2 && k.bs == 2 && k.degree1 == 1 && k.bs1 == 1) \
+    return X<ElementOp<2, 2, 2, 1, 1, MPCX_FORM_DIV_TEST>>(a);
+#define MPCX_FOR_DIV_TRIAL(X)                                                                      \
+  if (k.celltype == MPCX_CELL_TETRAHEDRON && k.degree == 1 && k.bs == 1 && k.degree1 == 2 && k.bs1 == 3) \
+    return X<ElementOp<3, 1, 1, 2, 3, MPCX_FORM_DIV_TRIAL>>(a);                                    \
+  if (k.celltype == MPCX_CELL_TRIANGLE && k.degree == 1 && k.bs == 1 && k.degree1 == 2 && k.bs1 == 2) \
+    return X<ElementOp<2, 1, 1, 2, 2, MPCX_FORM_DIV_TRIAL>>(a);
 
 int unsupported(const mpcx_kernel_t& k)
 {
   mpcx_set_error("unsupported element kernel: form " + std::to_string(k.form) + " celltype "
-                 + std::to_string(k.celltype) + " degree " + std::to_string(k.degree) + " bs "
-                 + std::to_string(k.bs));
+                 + std::to_string(k.celltype) + " test (degree " + std::to_string(k.degree) + ", bs "
+                 + std::to_string(k.bs) + ") trial (degree " + std::to_string(k.degree1) + ", bs "
+                 + std::to_string(k.bs1) + ")");
   return -10;
 }
 
@@ -751,24 +826,27 @@ extern "C" int mpcx_assemble_matrix(const mpcx_matrix_args_t* args)
 {
   const mpcx_matrix_args_t& a = *args;
   const mpcx_kernel_t& k = a.kernel;
-  if (a.nd0 != a.nd1 || a.bs0 != a.bs1)
-  {
-    mpcx_set_error("mpcx_assemble_matrix: rectangular blocks not built in yet");
-    return -11;
-  }
   switch (k.form)
   {
   case MPCX_FORM_STIFFNESS:
     MPCX_FOR_SPACES(launch_matrix, MPCX_FORM_STIFFNESS)
+    MPCX_FOR_P2_VECTOR_SPACES(launch_matrix, MPCX_FORM_STIFFNESS)
     break;
   case MPCX_FORM_MASS:
     MPCX_FOR_SPACES(launch_matrix, MPCX_FORM_MASS)
+    MPCX_FOR_P2_VECTOR_SPACES(launch_matrix, MPCX_FORM_MASS)
     break;
   case MPCX_FORM_FACET_MASS:
     MPCX_FOR_SPACES(launch_matrix, MPCX_FORM_FACET_MASS)
     break;
   case MPCX_FORM_ELASTICITY:
     MPCX_FOR_VECTOR_SPACES(launch_matrix, MPCX_FORM_ELASTICITY)
+    break;
+  case MPCX_FORM_DIV_TEST:
+    MPCX_FOR_DIV_TEST(launch_matrix)
+    break;
+  case MPCX_FORM_DIV_TRIAL:
+    MPCX_FOR_DIV_TRIAL(launch_matrix)
     break;
   default:
     break;
@@ -784,9 +862,10 @@ extern "C" int mpcx_assemble_vector(const mpcx_vector_args_t* args)
   {
   case MPCX_FORM_SOURCE:
     // the periodic benchmark's right-hand side (bench_periodic.py:85-91) gets its own instantiation
-    if (k.celltype == MPCX_CELL_TETRAHEDRON && k.degree == 1 && k.bs == 1 && k.fn_id == 1)
-      return launch_vector<ElementOp<3, 1, 1, MPCX_FORM_SOURCE, 1>>(a);
+    if (is_space(k, MPCX_CELL_TETRAHEDRON, 1, 1) && k.fn_id == 1)
+      return launch_vector<ElementOp<3, 1, 1, 1, 1, MPCX_FORM_SOURCE, 1>>(a);
     MPCX_FOR_SPACES(launch_vector, MPCX_FORM_SOURCE)
+    MPCX_FOR_P2_VECTOR_SPACES(launch_vector, MPCX_FORM_SOURCE)
     break;
   case MPCX_FORM_FACET_SOURCE:
     MPCX_FOR_SPACES(launch_vector, MPCX_FORM_FACET_SOURCE)
@@ -801,24 +880,27 @@ extern "C" int mpcx_apply_lifting(const mpcx_lifting_args_t* args)
 {
   const mpcx_lifting_args_t& a = *args;
   const mpcx_kernel_t& k = a.kernel;
-  if (a.nd0 != a.nd1 || a.bs0 != a.bs1)
-  {
-    mpcx_set_error("mpcx_apply_lifting: rectangular blocks not built in yet");
-    return -11;
-  }
   switch (k.form)
   {
   case MPCX_FORM_STIFFNESS:
     MPCX_FOR_SPACES(launch_lifting, MPCX_FORM_STIFFNESS)
+    MPCX_FOR_P2_VECTOR_SPACES(launch_lifting, MPCX_FORM_STIFFNESS)
     break;
   case MPCX_FORM_MASS:
     MPCX_FOR_SPACES(launch_lifting, MPCX_FORM_MASS)
+    MPCX_FOR_P2_VECTOR_SPACES(launch_lifting, MPCX_FORM_MASS)
     break;
   case MPCX_FORM_FACET_MASS:
     MPCX_FOR_SPACES(launch_lifting, MPCX_FORM_FACET_MASS)
     break;
   case MPCX_FORM_ELASTICITY:
     MPCX_FOR_VECTOR_SPACES(launch_lifting, MPCX_FORM_ELASTICITY)
+    break;
+  case MPCX_FORM_DIV_TEST:
+    MPCX_FOR_DIV_TEST(launch_lifting)
+    break;
+  case MPCX_FORM_DIV_TRIAL:
+    MPCX_FOR_DIV_TRIAL(launch_lifting)
     break;
   default:
     break;

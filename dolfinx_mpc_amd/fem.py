@@ -24,6 +24,8 @@ FORM_SOURCE = 2
 FORM_ELASTICITY = 3
 FORM_FACET_MASS = 4
 FORM_FACET_SOURCE = 5
+FORM_DIV_TEST = 6  # c * p div(v): vector test space, scalar trial space
+FORM_DIV_TRIAL = 7  # c * div(u) q: scalar test space, vector trial space
 
 CELL_TRIANGLE = 1
 CELL_TETRAHEDRON = 2
@@ -212,6 +214,8 @@ class KernelSpec:
     qwts: np.ndarray = field(default_factory=lambda: np.zeros(0))
     fqpts: np.ndarray = field(default_factory=lambda: np.zeros((0, 2)))
     fqwts: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    degree1: int = 0  # trial space (0 = same as test space)
+    bs1: int = 0
 
 
 @dataclass
@@ -306,6 +310,25 @@ def form_elasticity(V, mu: float, lmbda: float, cells=None) -> Form:
     cells = _cells_or_all(V.mesh, cells)
     k = _cell_kernel(V, FORM_ELASTICITY, 2 * (V.degree - 1))
     return Form([V, V], [Integral("cell", cells, k, None, np.array([mu, lmbda], dtype=np.float64))])
+
+
+def form_div_test(V, Q, constant=-1.0, cells=None) -> Form:
+    """a(p, v) = c * p div(v) dx, rows = V (vector), cols = Q (scalar): the ``a01`` block
+    of python/tests/test_stokes_channelflow.py:77-80 with c = -1."""
+    assert V.mesh is Q.mesh and V.dofmap.bs == V.mesh.tdim and Q.dofmap.bs == 1
+    cells = _cells_or_all(V.mesh, cells)
+    k = _cell_kernel(V, FORM_DIV_TEST, V.degree - 1 + Q.degree)
+    k.degree1, k.bs1 = Q.degree, 1
+    return Form([V, Q], [Integral("cell", cells, k, None, _constants(constant))])
+
+
+def form_div_trial(Q, V, constant=-1.0, cells=None) -> Form:
+    """a(u, q) = c * div(u) q dx, rows = Q (scalar), cols = V (vector): the ``a10`` block."""
+    assert V.mesh is Q.mesh and V.dofmap.bs == V.mesh.tdim and Q.dofmap.bs == 1
+    cells = _cells_or_all(Q.mesh, cells)
+    k = _cell_kernel(Q, FORM_DIV_TRIAL, V.degree - 1 + Q.degree)
+    k.degree1, k.bs1 = V.degree, V.dofmap.bs
+    return Form([Q, V], [Integral("cell", cells, k, None, _constants(constant))])
 
 
 def form_source(V, fn_id: int = FN_ONE, constant=None, coefficient: Optional[Function] = None, cells=None,

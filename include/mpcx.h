@@ -32,7 +32,9 @@ enum {
   MPCX_FORM_SOURCE = 2,
   MPCX_FORM_ELASTICITY = 3,
   MPCX_FORM_FACET_MASS = 4,
-  MPCX_FORM_FACET_SOURCE = 5
+  MPCX_FORM_FACET_SOURCE = 5,
+  MPCX_FORM_DIV_TEST = 6,  /* a(p, v) = c * p div(v) dx: vector test space, scalar trial space */
+  MPCX_FORM_DIV_TRIAL = 7  /* a(u, q) = c * div(u) q dx: scalar test space, vector trial space */
 };
 enum { MPCX_CELL_TRIANGLE = 1, MPCX_CELL_TETRAHEDRON = 2 };
 
@@ -49,8 +51,10 @@ typedef struct
 {
   int32_t form;
   int32_t celltype;
-  int32_t degree;
-  int32_t bs;
+  int32_t degree;  /* test space: Lagrange degree */
+  int32_t bs;      /* test space: block size */
+  int32_t degree1; /* trial space (= degree for square forms and rank-1 forms) */
+  int32_t bs1;
   int32_t fn_id;
   int32_t coeff_degree;
   int32_t nq;

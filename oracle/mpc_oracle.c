@@ -359,6 +359,38 @@ void oracle_tabulate_generic(double* A, const double* w, const double* c,
         }
       break;
     }
+    case ORACLE_FORM_DIV_TEST:
+    case ORACLE_FORM_DIV_TRIAL:
+    {
+      /* rectangular Taylor-Hood blocks (python/tests/test_stokes_channelflow.py:77-80):
+       * DIV_TEST  a(p, v) = c0 p div(v): rows (i,a) of the vector space, cols j of the scalar space
+       * DIV_TRIAL a(u, q) = c0 div(u) q: rows i of the scalar space, cols (j,b) of the vector space */
+      const int nd1 = lagrange_ndofs(kd->celltype, kd->degree1);
+      const int bs1 = kd->bs1;
+      const int n1 = nd1 * bs1;
+      double psi[MAX_ND], dpsi[MAX_ND * 3];
+      lagrange_basis(kd->celltype, kd->degree1, X, psi, dpsi);
+      if (kd->form == ORACLE_FORM_DIV_TEST)
+      {
+        for (int i = 0; i < nd; ++i)
+          for (int a = 0; a < bs; ++a)
+            for (int j = 0; j < nd1; ++j)
+              A[(i * bs + a) * n1 + j] += s * gphi[i][a] * psi[j];
+      }
+      else
+      {
+        for (int j = 0; j < nd1; ++j)
+          for (int b = 0; b < bs1; ++b)
+          {
+            double gjb = 0.0;
+            for (int d = 0; d < tdim; ++d)
+              gjb += g.K[d][b] * dpsi[j * tdim + d];
+            for (int i = 0; i < nd; ++i)
+              A[i * n1 + j * bs1 + b] += s * phi[i] * gjb;
+          }
+      }
+      break;
+    }
     default:
       break;
     }

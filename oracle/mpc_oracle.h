@@ -44,7 +44,9 @@ enum {
   ORACLE_FORM_SOURCE = 2,    /* L = c0 * w * f.v dx, f analytic (fn_id) */
   ORACLE_FORM_ELASTICITY = 3,/* a = inner(sigma(u), grad(v)) dx, c = [mu, lambda] */
   ORACLE_FORM_FACET_MASS = 4,  /* a = c0 * u.v ds */
-  ORACLE_FORM_FACET_SOURCE = 5 /* L = c0 * f.v ds */
+  ORACLE_FORM_FACET_SOURCE = 5, /* L = c0 * f.v ds */
+  ORACLE_FORM_DIV_TEST = 6,     /* a = c0 * p div(v) dx (vector test, scalar trial) */
+  ORACLE_FORM_DIV_TRIAL = 7     /* a = c0 * div(u) q dx (scalar test, vector trial) */
 };
 
 /* cell types */
@@ -58,6 +60,8 @@ typedef struct
   int32_t celltype;
   int32_t degree;       /* Lagrange degree of test (=trial) space, 1 or 2 */
   int32_t bs;           /* block size (components) */
+  int32_t degree1;      /* trial space degree / block size (rectangular forms only) */
+  int32_t bs1;
   int32_t fn_id;        /* analytic function for SOURCE forms */
   int32_t coeff_degree; /* 0: no coefficient; 1/2: Lagrange coefficient packed in w */
   int32_t nq;           /* cell rule: number of points */

@@ -37,6 +37,8 @@ class _Desc(C.Structure):
         ("celltype", C.c_int32),
         ("degree", C.c_int32),
         ("bs", C.c_int32),
+        ("degree1", C.c_int32),
+        ("bs1", C.c_int32),
         ("fn_id", C.c_int32),
         ("coeff_degree", C.c_int32),
         ("nq", C.c_int32),
@@ -240,7 +242,8 @@ class OracleMPC:
 
 def _desc(k):
     keep = [np.ascontiguousarray(a, dtype=np.float64) for a in (k.qpts, k.qwts, k.fqpts, k.fqwts)]
-    d = _Desc(k.form, k.celltype, k.degree, k.bs, k.fn_id, k.coeff_degree, keep[1].size, keep[3].size,
+    d = _Desc(k.form, k.celltype, k.degree, k.bs, getattr(k, "degree1", 0) or k.degree, getattr(k, "bs1", 0) or k.bs,
+              k.fn_id, k.coeff_degree, keep[1].size, keep[3].size,
               _p(keep[0]), _p(keep[1]), _p(keep[2]), _p(keep[3]))
     return d, keep
 
@@ -386,15 +389,18 @@ def homogenize(mpc: OracleMPC, u):
 
 def tabulate_one(kernel, coordinate_dofs, w=None, c=None, local_facet=0, which=0):
     """element tensor of one cell (known-answer tests)."""
-    n = {(1, 1): 3, (1, 2): 6, (2, 1): 4, (2, 2): 10}[(kernel.celltype, kernel.degree)] * kernel.bs
+    ndofs = {(1, 1): 3, (1, 2): 6, (2, 1): 4, (2, 2): 10}
+    n = ndofs[(kernel.celltype, kernel.degree)] * kernel.bs
+    d1, b1 = getattr(kernel, "degree1", 0) or kernel.degree, getattr(kernel, "bs1", 0) or kernel.bs
+    n1 = ndofs[(kernel.celltype, d1)] * b1
     rank1 = kernel.form in (2, 5)
-    A = np.zeros(n if rank1 else n * n, dtype=np.float64)
+    A = np.zeros(n if rank1 else n * n1, dtype=np.float64)
     d, keep = _desc(kernel)
     cd = np.ascontiguousarray(coordinate_dofs, dtype=np.float64)
     w = None if w is None else np.ascontiguousarray(w, dtype=np.float64)
     c = None if c is None else np.ascontiguousarray(c, dtype=np.float64)
     lib().oracle_tabulate_one(which, _p(A), _p(w), _p(c), _p(cd), local_facet, C.byref(d))
-    return A if rank1 else A.reshape(n, n)
+    return A if rank1 else A.reshape(n, n1)
 
 
 # ---------------------------------------------------------------------------

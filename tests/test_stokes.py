@@ -1,0 +1,149 @@
+"""Taylor-Hood Stokes blocks with a slip constraint on the velocity space
+(BASELINE config 3 at toy size; python/tests/test_stokes_channelflow.py:77-81 forms,
+python/tests/test_rectangular_assembly.py nest assembly with (mpc_i, mpc_j)):
+
+    a00 = inner(grad u, grad v) dx   (P2^d x P2^d, component-diagonal 30x30 / 12x12)
+    a01 = -p div v dx                (P2^d x P1, rectangular)
+    a10 = -div u q dx                (P1 x P2^d)
+
+CPU: the oracle's rectangular blocks obey  A_ij_mpc[free_i, free_j] == K_i^T A_ij K_j.
+GPU (-m gpu): HIP kernels == oracle for every block, both scatter algorithms,
+and for the lifted right-hand sides.
+"""
+
+import numpy as np
+import pytest
+import scipy.sparse
+
+from dolfinx_mpc_amd import fem
+from dolfinx_mpc_amd.mesh import create_unit_cube, create_unit_square
+from problems import empty_raw
+
+
+def _stokes(dim, n):
+    mesh = create_unit_cube(n, n, n) if dim == 3 else create_unit_square(n, n)
+    V = fem.functionspace(mesh, ("Lagrange", 2, (dim,)))
+    Q = fem.functionspace(mesh, ("Lagrange", 1))
+    x = V.tabulate_dof_coordinates()
+    # inflow profile on x = 0 (non-zero Dirichlet), no-slip on y = 0
+    inflow = fem.Function(V)
+    inflow.interpolate(lambda x: np.stack([x[1] * (1 - x[1])] + [0 * x[1]] * (dim - 1)))
+    bc_in = fem.dirichletbc(inflow, fem.locate_dofs_geometrical(V, lambda x: np.isclose(x[0], 0)), V)
+    bc_wall = fem.dirichletbc(0.0, fem.locate_dofs_geometrical(V, lambda x: np.isclose(x[1], 0) & ~np.isclose(x[0], 0)), V)
+    bcs = [bc_in, bc_wall]
+    is_bc = np.zeros(V.num_dofs, dtype=np.int8)
+    for bc in bcs:
+        bc.mark_dofs(is_bc)
+    # slip u.n = 0 on y = 1 with a tilted normal (cpp/SlipConstraint.h:115-166 output shape)
+    nrm = np.array([0.25, 1.0, -0.15])[:dim]
+    nrm /= np.linalg.norm(nrm)
+    slaves, masters, coeffs, offsets = [], [], [], [0]
+    for b in np.flatnonzero(np.isclose(x[:, 1], 1.0)):
+        s = int(np.argmax(np.abs(nrm)))
+        if is_bc[b * dim + s] or any(is_bc[b * dim + k] for k in range(dim)):
+            continue
+        slaves.append(b * dim + s)
+        for k in range(dim):
+            if k != s:
+                masters.append(b * dim + k)
+                coeffs.append(-nrm[k] / nrm[s])
+        offsets.append(len(masters))
+    raw_v = (np.array(slaves, dtype=np.int32), np.array(masters, dtype=np.int64), np.array(coeffs),
+             np.zeros(len(masters), dtype=np.int32), np.array(offsets, dtype=np.int32))
+    forms = {
+        (0, 0): fem.form_stiffness(V),
+        (0, 1): fem.form_div_test(V, Q, constant=-1.0),
+        (1, 0): fem.form_div_trial(Q, V, constant=-1.0),
+    }
+    L0 = fem.form_source(V, fem.FN_LINEAR)
+    return V, Q, bcs, raw_v, forms, L0
+
+
+def _oracle_blocks(po, dim, n):
+    V, Q, bcs, raw_v, forms, L0 = _stokes(dim, n)
+    mv = po.OracleMPC.from_raw(V, *raw_v)
+    mq = po.OracleMPC.from_raw(Q, *empty_raw())
+    mpcs = [mv, mq]
+    out = {}
+    for (i, j), f in forms.items():
+        out[(i, j)] = po.assemble_matrix(f, mpcs[i], mpcs[j], bcs=bcs)
+    b0 = po.assemble_vector(L0, mv)
+    po.apply_lifting(b0, [forms[(0, 0)]], [bcs], mv)
+    b1 = np.zeros(Q.num_dofs)
+    po.apply_lifting(b1, [forms[(1, 0)]], [bcs], mq)  # b1 -= A10 g
+    out["b0"], out["b1"] = b0, b1
+    return (V, Q, bcs, raw_v, forms, L0), mpcs, out
+
+
+@pytest.mark.parametrize("dim,n", [(2, 3), (3, 2)])
+def test_oracle_rectangular_identities(oracle, dim, n):
+    po = oracle
+    (V, Q, bcs, raw_v, forms, L0), (mv, mq), out = _oracle_blocks(po, dim, n)
+    ev, eq = po.OracleMPC.empty(V), po.OracleMPC.empty(Q)
+    K = po.gather_transformation_matrix(mv)
+    free = np.flatnonzero(mv.is_slave == 0)
+    # a00
+    A00 = po.assemble_matrix(forms[(0, 0)], ev, ev, bcs=bcs)
+    po.compare_mpc_lhs(A00, out[(0, 0)], mv, atol=5e-12 * max(1, abs(A00).max()))
+    # a01: rows constrained, columns not -> K^T A01
+    A01 = po.assemble_matrix(forms[(0, 1)], ev, eq, bcs=bcs)
+    assert abs(K.T @ A01 - out[(0, 1)].tocsr()[free, :]).max() < 5e-12
+    assert abs(out[(0, 1)].tocsr()[mv.slaves]).sum() == 0  # slave rows empty, no diagonal in an off-diagonal block
+    # a10: columns constrained -> A10 K
+    A10 = po.assemble_matrix(forms[(1, 0)], eq, ev, bcs=bcs)
+    assert abs(A10 @ K - out[(1, 0)].tocsr()[:, free]).max() < 5e-12
+    assert abs(out[(1, 0)].tocsr()[:, mv.slaves]).sum() == 0
+    # a10 == a01^T without constraints and bcs
+    assert abs(po.assemble_matrix(forms[(1, 0)], eq, ev) - po.assemble_matrix(forms[(0, 1)], ev, eq).T).max() < 1e-13
+    # div of a linear field: sum_q A10[q, :] u = -int div(u) = -trace * |domain|
+    x = V.tabulate_dof_coordinates()
+    u = np.zeros(V.num_dofs)
+    grad = np.array([[0.3, -1.0, 0.2], [0.5, 0.7, 0.1], [-0.4, 0.6, -1.1]])[:dim, :dim]
+    for k in range(dim):
+        u[k::dim] = x[:, :dim] @ grad[k]
+    A10_free = po.assemble_matrix(forms[(1, 0)], eq, ev)
+    assert (A10_free @ u).sum() == pytest.approx(-np.trace(grad), rel=1e-12)
+    # right-hand sides
+    b0 = po.assemble_vector(L0, ev)
+    po.apply_lifting(b0, [forms[(0, 0)]], [bcs], ev)
+    po.compare_mpc_rhs(b0, out["b0"], mv)
+
+
+def _product_blocks(dim, n, alg):
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd.la import create_vector
+
+    V, Q, bcs, raw_v, forms, L0 = _stokes(dim, n)
+    mv = dm.MultiPointConstraint(V)
+    mv.add_constraint(V, *raw_v)
+    mv.finalize()
+    mq = dm.MultiPointConstraint(Q)
+    mq.finalize()
+    mpcs = [mv, mq]
+    a = [[forms.get((i, j)) for j in range(2)] for i in range(2)]
+    A = dm.create_matrix_nest(a, mpcs)
+    for i in range(2):
+        for j in range(2):
+            if a[i][j] is not None:
+                dm.assemble_matrix(a[i][j], (mpcs[i], mpcs[j]), bcs=bcs, A=A[i][j], algorithm=alg)
+    out = {(i, j): A[i][j].to_scipy() for i in range(2) for j in range(2) if A[i][j] is not None}
+    b0 = dm.assemble_vector(L0, mv)
+    dm.apply_lifting(b0, [forms[(0, 0)]], [bcs], mv)
+    b1 = create_vector(Q)
+    dm.apply_lifting(b1, [forms[(1, 0)]], [bcs], mq)
+    out["b0"], out["b1"] = b0.numpy(), b1.numpy()
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alg", ["atomic", "rowblock"])
+@pytest.mark.parametrize("dim,n", [(2, 3), (3, 2)])
+def test_gpu_stokes_blocks_match_oracle(oracle, dim, n, alg):
+    _, _, ref = _oracle_blocks(oracle, dim, n)
+    out = _product_blocks(dim, n, alg)
+    for key in [(0, 0), (0, 1), (1, 0)]:
+        assert np.array_equal(out[key].indptr, ref[key].indptr) and np.array_equal(out[key].indices, ref[key].indices)
+        scale = max(1.0, abs(ref[key]).max())
+        assert abs(out[key].data - ref[key].data).max() <= 1e-12 * scale, key
+    for key in ("b0", "b1"):
+        assert abs(out[key] - ref[key]).max() <= 1e-12 * max(1.0, abs(ref[key]).max()), key
