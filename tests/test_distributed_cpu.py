@@ -49,7 +49,8 @@ def _worker(rank, world, port, N, reorder, outdir):
     from dolfinx_mpc_amd.distributed import SlabExchange, create_slab_mesh
     from oracle import pyoracle as po
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # file rendezvous inside the test's tmp dir: no port to race for
+    dist.init_process_group("gloo", init_method=f"file://{outdir}/rendezvous", rank=rank, world_size=world)
     mesh = create_slab_mesh(N, rank, world, reorder)
     V, bc, raw, a, L = _problem(mesh, world, N)
     mpc = po.OracleMPC.from_raw(V, *raw)
@@ -120,7 +121,8 @@ def _gpu_worker(rank, world, port, N, reorder, outdir):
     from dolfinx_mpc_amd.distributed import SlabExchange, create_slab_mesh
 
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # file rendezvous inside the test's tmp dir: no port to race for
+    dist.init_process_group("gloo", init_method=f"file://{outdir}/rendezvous", rank=rank, world_size=world)
     mesh = create_slab_mesh(N, rank, world, reorder)
     V, bc, raw, a, L = _problem(mesh, world, N)
     mpc = dm.MultiPointConstraint(V)
