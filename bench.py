@@ -161,9 +161,16 @@ def main():
     import torch
     import torch.distributed as dist
 
-    torch.cuda.set_device(local_rank)
+    # MPCX_DIST_BACKEND=gloo lets several ranks share one GPU (smoke test of the N>1 path
+    # on a 1-GPU box); the real runs use RCCL ("nccl"), one rank per GPU
+    backend = os.environ.get("MPCX_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     from dolfinx_mpc_amd.la import MPCMatrix, create_vector
 
     A = MPCMatrix(rowptr, cols, V.num_dofs)
@@ -174,7 +181,7 @@ def main():
     if world > 1:
         from dolfinx_mpc_amd.distributed import SlabExchange
 
-        exchange = SlabExchange(mesh, rowptr, cols, rank, world, device=torch.device("cuda", local_rank))
+        exchange = SlabExchange(mesh, rowptr, cols, rank, world, device=torch.device("cuda", dev_index))
 
     def step_matrix():
         dm.assemble_matrix(a, mpc, bcs=bcs, A=A, algorithm=args.alg)
@@ -214,7 +221,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     t_mat = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
