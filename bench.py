@@ -303,7 +303,7 @@ def main():
             "launch_ms": t_bulk,
         },
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
         log("timing the CPU baseline (oracle, 1 core) ...")
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n)
     print(json.dumps(out), flush=True)
