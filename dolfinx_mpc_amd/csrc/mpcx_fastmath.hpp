@@ -19,40 +19,29 @@
 namespace mpcx
 {
 
-// sin(pi * t), |t| < 2^30
+// sin(pi * t), |t| < 2^30.  r = t - rint(t) in [-1/2, 1/2] exactly, one odd
+// polynomial in r (Taylor coefficients (-1)^k pi^(2k+1)/(2k+1)!, truncation
+// < 2e-18), leading term split as r*PI_HI + r*PI_LO: ~17 fp64 instructions
+// against ~32 for a quarter-range sin/cos pair.
 MPCX_HD inline double fast_sinpi(double t)
 {
-  const double n = std::rint(2.0 * t);
-  const double r = std::fma(-0.5, n, t); // exact, |r| <= 1/4
-  const int q = static_cast<int>(n);
-  // x = pi * r in two pieces
-  const double PI_HI = 3.141592653589793116, PI_LO = 1.2246467991473532e-16;
-  const double x = r * PI_HI;
-  const double xlo = std::fma(r, PI_HI, -x) + r * PI_LO;
-  const double x2 = x * x;
-  // sin(x)/x and cos(x), |x| <= pi/4
-  double s = -1.0 / 1307674368000.0;
-  s = std::fma(s, x2, 1.0 / 6227020800.0);
-  s = std::fma(s, x2, -1.0 / 39916800.0);
-  s = std::fma(s, x2, 1.0 / 362880.0);
-  s = std::fma(s, x2, -1.0 / 5040.0);
-  s = std::fma(s, x2, 1.0 / 120.0);
-  s = std::fma(s, x2, -1.0 / 6.0);
-  s = std::fma(s * x2, x, x); // x + x^3 * (...)
-  double c = 1.0 / 20922789888000.0;
-  c = std::fma(c, x2, -1.0 / 87178291200.0);
-  c = std::fma(c, x2, 1.0 / 479001600.0);
-  c = std::fma(c, x2, -1.0 / 3628800.0);
-  c = std::fma(c, x2, 1.0 / 40320.0);
-  c = std::fma(c, x2, -1.0 / 720.0);
-  c = std::fma(c, x2, 1.0 / 24.0);
-  c = std::fma(c, x2, -0.5);
-  c = std::fma(c, x2, 1.0);
-  // first-order correction for the low part of x
-  const double sv = std::fma(xlo, c, s);
-  const double cv = std::fma(-xlo, s, c);
-  const double v = (q & 1) ? cv : sv;
-  return (q & 2) ? -v : v;
+  const double n = std::rint(t);
+  const double r = t - n; // exact
+  const double r2 = r * r;
+  double p = 0x1.2877020d52cf0p-31;       // pi^21/21!
+  p = std::fma(p, r2, -0x1.8a404211f9547p-26);
+  p = std::fma(p, r2, 0x1.aaec32af93359p-21);
+  p = std::fma(p, r2, -0x1.6fadb9f155744p-16);
+  p = std::fma(p, r2, 0x1.e8f434d018d63p-12);
+  p = std::fma(p, r2, -0x1.e3074fde8871fp-8);
+  p = std::fma(p, r2, 0x1.50783487ee782p-4);
+  p = std::fma(p, r2, -0x1.32d2cce62bd86p-1);
+  p = std::fma(p, r2, 0x1.466bc6775aae2p+1);
+  p = std::fma(p, r2, -0x1.4abbce625be53p+2); // -pi^3/6
+  const double PI_HI = 0x1.921fb54442d18p+1, PI_LO = 1.2246467991473532e-16;
+  const double tl = std::fma(r2, p, PI_LO);
+  const double v = std::fma(r, PI_HI, r * tl);
+  return (static_cast<long long>(n) & 1) ? -v : v;
 }
 
 // exp(y); underflows to 0 / overflows to inf through ldexp
