@@ -85,21 +85,23 @@ def create_slab_mesh(N: int, rank: int, world: int, reorder=None) -> Mesh:
 
 
 class SlabExchange:
-    """Ghost-row reduction for a P1 space on a slab mesh: rank r sends the
+    """Ghost-row reduction for a (blocked) P1 space on a slab mesh: rank r sends the
     partial sums of its top-plane (ghost) rows to rank r+1, which adds them to
     its owned bottom-plane rows.  The value buffers are packed / scattered with
     index tensors built once; positions are matched through global (row, col)
     keys exchanged at set-up."""
 
-    def __init__(self, mesh: Mesh, rowptr: np.ndarray, cols: np.ndarray, rank: int, world: int, device=None):
+    def __init__(self, mesh: Mesh, rowptr: np.ndarray, cols: np.ndarray, rank: int, world: int, device=None,
+                 bs: int = 1):
         import torch
         import torch.distributed as dist
 
         self.rank, self.world = rank, world
         self.device = device
-        g = mesh.node_global
         N = mesh.slab[0]
-        plane = g // ((N + 1) * (N + 1))
+        # unrolled dofs of a (blocked) P1 space: dof = node * bs + component
+        g = (mesh.node_global[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)
+        plane = np.repeat(mesh.node_global // ((N + 1) * (N + 1)), bs)
         self.send_to = rank + 1 if rank + 1 < world else None
         self.recv_from = rank - 1 if rank > 0 else None
         # ---- what I send: every entry of my top-plane rows -------------------
@@ -108,7 +110,7 @@ class SlabExchange:
         cnt = rowptr[top + 1] - rowptr[top]
         pos = (np.repeat(rowptr[top].astype(np.int64) - np.concatenate([[0], np.cumsum(cnt)[:-1]]), cnt)
                + np.arange(int(cnt.sum()))) if top.size else np.zeros(0, dtype=np.int64)
-        nglob = (N + 1) * (N + 1) * (N * world + 1)
+        nglob = (N + 1) * (N + 1) * (N * world + 1) * bs
         keys = np.repeat(g[top], cnt).astype(np.int64) * nglob + g[cols[pos]] if top.size else np.zeros(0, dtype=np.int64)
         o = np.argsort(keys, kind="stable")
         self.send_pos = pos[o]

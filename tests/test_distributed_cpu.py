@@ -25,20 +25,28 @@ def _free_port():
     return p
 
 
-def _problem(mesh, world, N):
+def _problem(mesh, world, N, kind="poisson"):
+    """poisson: BASELINE config 2's problem on the slab; elasticity: vector P1 (bs = 3)
+    elasticity with a periodic tie of every component (BASELINE config 4's tensor shapes)."""
     from dolfinx_mpc_amd import fem
     from problems import periodic_raw
 
-    V = fem.functionspace(mesh, ("Lagrange", 1))
     zmax = float(world)
-    dofs = fem.locate_dofs_geometrical(
-        V, lambda x: np.isclose(x[1], 0) | np.isclose(x[1], 1) | np.isclose(x[2], 0) | np.isclose(x[2], zmax))
-    bc = fem.dirichletbc(0.7, dofs, V)
-    raw = periodic_raw(V, [bc])
-    return V, bc, raw, fem.form_stiffness(V), fem.form_source(V, fem.FN_BENCH_PERIODIC)
+    if kind == "poisson":
+        V = fem.functionspace(mesh, ("Lagrange", 1))
+        dofs = fem.locate_dofs_geometrical(
+            V, lambda x: np.isclose(x[1], 0) | np.isclose(x[1], 1) | np.isclose(x[2], 0) | np.isclose(x[2], zmax))
+        bc = fem.dirichletbc(0.7, dofs, V)
+        raw = periodic_raw(V, [bc])
+        return V, bc, raw, fem.form_stiffness(V), fem.form_source(V, fem.FN_BENCH_PERIODIC)
+    V = fem.functionspace(mesh, ("Lagrange", 1, (3,)))
+    dofs = fem.locate_dofs_geometrical(V, lambda x: np.isclose(x[1], 0) | np.isclose(x[2], zmax))
+    bc = fem.dirichletbc(np.array([0.0, 0.1, -0.2]), dofs, V)
+    raw = periodic_raw(V, [bc], scale=0.8)
+    return V, bc, raw, fem.form_elasticity(V, 500.0, 300.0), fem.form_source(V, fem.FN_LINEAR)
 
 
-def _worker(rank, world, port, N, reorder, outdir):
+def _worker(rank, world, port, N, reorder, outdir, kind="poisson"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -52,20 +60,21 @@ def _worker(rank, world, port, N, reorder, outdir):
     # file rendezvous inside the test's tmp dir: no port to race for
     dist.init_process_group("gloo", init_method=f"file://{outdir}/rendezvous", rank=rank, world_size=world)
     mesh = create_slab_mesh(N, rank, world, reorder)
-    V, bc, raw, a, L = _problem(mesh, world, N)
+    V, bc, raw, a, L = _problem(mesh, world, N, kind)
+    bs = V.dofmap.bs
     mpc = po.OracleMPC.from_raw(V, *raw)
     pattern = po.create_pattern(a, mpc, mpc)
     A = po.assemble_matrix(a, mpc, bcs=[bc], pattern=pattern)  # owned cells, owned-only diagonals
     b = po.assemble_vector(L, mpc)
     po.apply_lifting(b, [a], [[bc]], mpc)
-    ex = SlabExchange(mesh, pattern[0], pattern[1], rank, world)
+    ex = SlabExchange(mesh, pattern[0], pattern[1], rank, world, bs=bs)
     vals = torch.from_numpy(A.data.copy())
     bt = torch.from_numpy(b.copy())
     ex.reduce_matrix(vals)
     ex.reduce_vector(bt)
     A = scipy.sparse.csr_matrix((vals.numpy(), A.indices, A.indptr), shape=A.shape)
-    g = mesh.node_global
-    nown = mesh.num_owned_nodes
+    g = (mesh.node_global[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)  # global unrolled dofs
+    nown = mesh.num_owned_nodes * bs
     Aown = A[:nown].tocoo()
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), row=g[Aown.row], col=g[Aown.col], val=Aown.data,
              brow=g[:nown], bval=bt.numpy()[:nown], nslaves=mpc.num_local_slaves)
@@ -73,17 +82,18 @@ def _worker(rank, world, port, N, reorder, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,N,reorder", [(2, 4, None), (2, 4, (2, 2, 2)), (3, 3, (2, 2, 2))])
-def test_slab_partition_matches_global_assembly(oracle, tmp_path, world, N, reorder):
+@pytest.mark.parametrize("world,N,reorder,kind", [(2, 4, None, "poisson"), (2, 4, (2, 2, 2), "poisson"),
+                                                   (3, 3, (2, 2, 2), "poisson"), (2, 3, (2, 2, 2), "elasticity")])
+def test_slab_partition_matches_global_assembly(oracle, tmp_path, world, N, reorder, kind):
     import torch.multiprocessing as mp
 
     from dolfinx_mpc_amd.mesh import create_box
 
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, N, reorder, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, N, reorder, str(tmp_path), kind), nprocs=world, join=True)
 
     gmesh = create_box((0, 0, 0), (1, 1, float(world)), (N, N, N * world))
-    V, bc, raw, a, L = _problem(gmesh, world, N)
+    V, bc, raw, a, L = _problem(gmesh, world, N, kind)
     mpc = oracle.OracleMPC.from_raw(V, *raw)
     Aref = oracle.assemble_matrix(a, mpc, bcs=[bc])
     bref = oracle.assemble_vector(L, mpc)
