@@ -1,0 +1,186 @@
+"""BASELINE config 2 at FULL size (P1, 256^3: 100 663 296 cells, 16 974 593 dofs) on
+the GPU, checked through size-independent properties (the oracle takes minutes at
+this size, so direct comparison is done at the small sizes of test_gpu_parity.py):
+
+1. two independent scatter algorithms (device atomics vs LDS row blocks) agree;
+2. slave and Dirichlet rows AND columns hold exactly `diagval` on the diagonal
+   (python/src/dolfinx_mpc/assemble_matrix.py:59-62);
+3. symmetry of K^T A K:  x^T A y == y^T A x;
+4. exactness: with Dirichlet data g = 1 + 2y - z (affine, x-periodic) and f = 0 the
+   discrete solution is g itself, so on every free row
+        (A_mpc u)_i == (apply_lifting(0))_i     with u = g  on non-slave dofs
+   -- this ties assemble_matrix, the MPC elimination and apply_lifting together;
+5. sum(b) == sum over cells and quadrature points of w |detJ| f(x_q) (basis functions
+   sum to one; the periodic move has coefficient 1), b[slaves] == 0.
+
+MPCX_FULLSIZE_N overrides N (default 256).
+"""
+
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N = int(os.environ.get("MPCX_FULLSIZE_N", 256))
+
+
+@pytest.fixture(scope="module")
+def problem():
+    import torch
+
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import fem
+    from dolfinx_mpc_amd.mesh import create_unit_cube
+
+    mesh = create_unit_cube(N, N, N, reorder=(8, 8, 8))
+    V = fem.functionspace(mesh, ("Lagrange", 1))
+    walls = fem.locate_dofs_geometrical(
+        V, lambda x: np.isclose(x[1], 0) | np.isclose(x[1], 1) | np.isclose(x[2], 0) | np.isclose(x[2], 1))
+    g = fem.Function(V)
+    g.interpolate(lambda x: 1.0 + 2.0 * x[1] - x[2])
+    bc = fem.dirichletbc(g, walls, V)
+    mpc = dm.MultiPointConstraint(V)
+
+    def rel(x):
+        out = x.copy()
+        out[0] = 1 - x[0]
+        return out
+
+    mpc.create_periodic_constraint_geometrical(V, lambda x: np.isclose(x[0], 1), rel, [bc])
+    mpc.finalize()
+    if N == 256:
+        assert mesh.num_cells == 100663296 and V.num_dofs == 16974593 and mpc.slaves.size == 65025
+    a = fem.form_stiffness(V)
+    L = fem.form_source(V, fem.FN_BENCH_PERIODIC)
+    A = dm.assemble_matrix(a, mpc, bcs=[bc], algorithm="rowblock")
+    torch.cuda.synchronize()
+    return dict(mesh=mesh, V=V, bc=bc, g=g, mpc=mpc, a=a, L=L, A=A)
+
+
+def _rowids(A):
+    import torch
+
+    counts = (A.d_rowptr[1:] - A.d_rowptr[:-1]).to(torch.int64)
+    return torch.repeat_interleave(torch.arange(A.shape[0], device=A.device), counts)
+
+
+def _spmv(A, rowid, x):
+    import torch
+
+    y = torch.zeros(A.shape[0], dtype=torch.float64, device=A.device)
+    y.index_add_(0, rowid, A.vals * x[A.d_cols.to(torch.int64)])
+    return y
+
+
+def test_atomic_and_rowblock_agree(problem):
+    import torch
+
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd.la import MPCMatrix
+
+    p = problem
+    B = MPCMatrix(p["A"].rowptr, p["A"].cols, p["V"].num_dofs)
+    dm.assemble_matrix(p["a"], p["mpc"], bcs=[p["bc"]], A=B, algorithm="atomic")
+    scale = float(p["A"].vals.abs().max())
+    diff = float((p["A"].vals - B.vals).abs().max())
+    assert diff <= 1e-12 * scale, (diff, scale)
+    del B
+    torch.cuda.empty_cache()
+
+
+def test_constrained_rows_and_columns_are_identity(problem):
+    import torch
+
+    p = problem
+    A = p["A"]
+    n = A.shape[0]
+    marked = torch.zeros(n, dtype=torch.bool, device=A.device)
+    marked[torch.from_numpy(p["mpc"].slaves.astype(np.int64)).to(A.device)] = True
+    marked[torch.from_numpy(p["bc"].dof_indices()[0].astype(np.int64)).to(A.device)] = True
+    nmarked = int(marked.sum())
+    rowid = _rowids(A)
+    cols = A.d_cols.to(torch.int64)
+    in_row = marked[rowid]
+    in_col = marked[cols]
+    diag = rowid == cols
+    # every stored entry in a marked row or column is zero unless it is the diagonal, which is 1
+    off = (in_row | in_col) & ~diag
+    assert float(A.vals[off].abs().max()) == 0.0
+    d = A.vals[diag & in_row]
+    assert d.numel() == nmarked and bool((d == 1.0).all())
+
+
+def test_symmetry(problem):
+    import torch
+
+    A = problem["A"]
+    gen = torch.Generator(device=A.device).manual_seed(7)
+    x = torch.rand(A.shape[0], dtype=torch.float64, device=A.device, generator=gen) - 0.5
+    y = torch.rand(A.shape[0], dtype=torch.float64, device=A.device, generator=gen) - 0.5
+    rowid = _rowids(A)
+    xAy = float(torch.dot(x, _spmv(A, rowid, y)))
+    yAx = float(torch.dot(y, _spmv(A, rowid, x)))
+    scale = float(torch.dot(x.abs(), _spmv_abs(A, rowid, y.abs())))
+    assert abs(xAy - yAx) <= 1e-12 * scale
+
+
+def _spmv_abs(A, rowid, x):
+    import torch
+
+    y = torch.zeros(A.shape[0], dtype=torch.float64, device=A.device)
+    y.index_add_(0, rowid, A.vals.abs() * x[A.d_cols.to(torch.int64)])
+    return y
+
+
+def test_affine_solution_is_reproduced_through_lifting(problem):
+    import torch
+
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd.la import create_vector
+
+    p = problem
+    A, V, mpc, bc = p["A"], p["V"], p["mpc"], p["bc"]
+    b = create_vector(V)
+    dm.apply_lifting(b, [p["a"]], [[bc]], mpc)  # b = -K^T A g
+    u = torch.from_numpy(p["g"].x.array.copy()).to(A.device)
+    rowid = _rowids(A)
+    r = _spmv(A, rowid, u) - b.array
+    free = torch.ones(A.shape[0], dtype=torch.bool, device=A.device)
+    free[torch.from_numpy(mpc.slaves.astype(np.int64)).to(A.device)] = False
+    free[torch.from_numpy(bc.dof_indices()[0].astype(np.int64)).to(A.device)] = False
+    scale = float(_spmv_abs(A, rowid, u.abs()).max())
+    assert float(r[free].abs().max()) <= 1e-11 * scale, (float(r[free].abs().max()), scale)
+
+
+def test_vector_sum_and_slave_entries(problem):
+    import torch
+
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd.quadrature import make_quadrature
+
+    p = problem
+    b = dm.assemble_vector(p["L"], p["mpc"])
+    dev = b.array.device
+    sl = torch.from_numpy(p["mpc"].slaves.astype(np.int64)).to(dev)
+    assert float(b.array[sl].abs().max()) == 0.0
+    # direct evaluation of sum_cells sum_q w_q |detJ| f(x_q), chunked over cells
+    q, w = make_quadrature("tetrahedron", 5)
+    X = torch.from_numpy(q).to(dev)
+    W = torch.from_numpy(w).to(dev)
+    phi = torch.cat([1 - X.sum(dim=1, keepdim=True), X], dim=1)  # (nq, 4)
+    xg = torch.from_numpy(p["mesh"].geometry.x).to(dev)
+    cells = torch.from_numpy(p["mesh"].geometry.dofmap).to(dev).to(torch.int64)
+    total = 0.0
+    chunk = 4_000_000
+    for s in range(0, cells.shape[0], chunk):
+        c = xg[cells[s : s + chunk]]  # (m, 4, 3)
+        J = c[:, 1:, :] - c[:, :1, :]
+        det = torch.linalg.det(J).abs()
+        xq = torch.einsum("qv,mvd->mqd", phi, c)
+        f = xq[..., 0] * torch.sin(5.0 * np.pi * xq[..., 1]) + torch.exp(
+            -((xq[..., 0] - 0.9) ** 2 + (xq[..., 1] - 0.5) ** 2 + (xq[..., 2] - 0.1) ** 2) / 0.02)
+        total += float((f * W[None, :]).sum(dim=1).mul(det).sum())
+    got = float(b.array.sum())
+    assert abs(got - total) <= 1e-11 * max(1.0, abs(total)), (got, total)
