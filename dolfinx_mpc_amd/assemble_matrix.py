@@ -198,6 +198,14 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
         md1 = md0 if (V1 is V0 and mpc1 is mpc0 and bc1 is bc0) else _masked_dofmap(form, V1, bc1, mpc1, 1)
         a.mdofmap0, a.mdofmap1 = md0.data_ptr(), md1.data_ptr()
         keep += [pk, md0, md1]
+        if not os.environ.get("MPCX_NO_XPAD4"):
+            if "x4" not in md:
+                import torch
+
+                x4 = torch.zeros((md["x"].shape[0], 4), dtype=torch.float64, device=md["x"].device)
+                x4[:, :3] = md["x"]
+                md["x4"] = x4
+            a.x_pad4 = md["x4"].data_ptr()
     return a, keep
 
 
@@ -236,7 +244,14 @@ def assemble_matrix(
         A = create_matrix(form, mpc0, mpc1)
     alg = _ALG[(algorithm or os.environ.get("MPCX_MATRIX_ALG", "auto")).lower()]
     if alg == 0:
-        alg = 1
+        # "auto": LDS row blocks (each value written once) when a plan can be built for every
+        # integral, device atomics otherwise (rows with more than 255 column blocks, tiny LDS...)
+        alg = 2
+        try:
+            for i in range(len(form.integrals)):
+                _rowblock_plan(A, form, i, form.function_spaces[0])
+        except RuntimeError:
+            alg = 1
 
     V0, V1 = form.function_spaces
     stream = D.stream_ptr()
