@@ -90,7 +90,6 @@ class MatrixArgs(C.Structure):
         ("plan", RowBlockPlanT),
         ("mdofmap0", C.c_void_p),
         ("mdofmap1", C.c_void_p),
-        ("x_pad4", C.c_void_p),
         ("stream", C.c_void_p),
     ]
 

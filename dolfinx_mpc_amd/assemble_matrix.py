@@ -198,14 +198,6 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
         md1 = md0 if (V1 is V0 and mpc1 is mpc0 and bc1 is bc0) else _masked_dofmap(form, V1, bc1, mpc1, 1)
         a.mdofmap0, a.mdofmap1 = md0.data_ptr(), md1.data_ptr()
         keep += [pk, md0, md1]
-        if not os.environ.get("MPCX_NO_XPAD4"):
-            if "x4" not in md:
-                import torch
-
-                x4 = torch.zeros((md["x"].shape[0], 4), dtype=torch.float64, device=md["x"].device)
-                x4[:, :3] = md["x"]
-                md["x4"] = x4
-            a.x_pad4 = md["x4"].data_ptr()
     return a, keep
 
 

@@ -361,29 +361,13 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
     if constexpr (!PREFETCH)
       load_ent(t, cur);
     double cd[NV * 3];
-    if (a.x_pad4)
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
     {
-      // coordinates padded to 4 doubles per node: two 16-byte loads instead of three 8-byte ones
+      const int64_t v = cur.xd[i];
 #pragma unroll
-      for (int i = 0; i < NV; ++i)
-      {
-        const double2* px = reinterpret_cast<const double2*>(a.x_pad4 + 4 * int64_t(cur.xd[i]));
-        const double2 lo = px[0], hi = px[1];
-        cd[3 * i] = lo.x;
-        cd[3 * i + 1] = lo.y;
-        cd[3 * i + 2] = hi.x;
-      }
-    }
-    else
-    {
-#pragma unroll
-      for (int i = 0; i < NV; ++i)
-      {
-        const int64_t v = cur.xd[i];
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-          cd[3 * i + k] = a.x[3 * v + k];
-      }
+      for (int k = 0; k < 3; ++k)
+        cd[3 * i + k] = a.x[3 * v + k];
     }
     Ent nxt = cur;
     if constexpr (PREFETCH)

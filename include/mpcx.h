@@ -142,9 +142,6 @@ typedef struct
    * folded into bit 28+k of each blocked dof: no marker gathers in the kernel */
   const int32_t* mdofmap0; /* DEVICE [num_cells][nd0] */
   const int32_t* mdofmap1; /* DEVICE [num_cells][nd1] */
-  /* rowblock, optional: the coordinates padded to 4 doubles per node (16-byte aligned
-   * gathers); NULL = use x */
-  const double* x_pad4;    /* DEVICE [num_nodes][4] */
   void* stream;
 } mpcx_matrix_args_t;
 
