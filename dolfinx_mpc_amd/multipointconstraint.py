@@ -11,7 +11,7 @@ lazily for the HIP kernels.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Callable, Dict, List, Optional, Sequence
+from typing import Callable, Dict, Optional, Sequence
 
 import numpy as np
 

@@ -6,7 +6,6 @@ sin(pi t) relative to max(|value|, tiny) on the benchmark's argument range, and
 
 import os
 import subprocess
-import sys
 
 import numpy as np
 

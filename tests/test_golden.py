@@ -8,7 +8,6 @@ import os
 
 import numpy as np
 import pytest
-import scipy.sparse
 
 from problems import all_small_cases, case_cube_periodic, oracle_outputs, product_outputs
 

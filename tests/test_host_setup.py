@@ -184,7 +184,7 @@ def test_finalize_rejects_bad_indices():
 
 
 def test_convenience_builders_match_raw_arrays(oracle):
-    from problems import case_cube_elasticity_slip, case_square_dict, case_vector_poisson, periodic_raw
+    from problems import case_cube_elasticity_slip, case_square_dict, case_vector_poisson
 
     # general (dict) constraint
     case = case_square_dict(2, (0, 1))

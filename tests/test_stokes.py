@@ -13,7 +13,6 @@ and for the lifted right-hand sides.
 
 import numpy as np
 import pytest
-import scipy.sparse
 
 from dolfinx_mpc_amd import fem
 from dolfinx_mpc_amd.mesh import create_unit_cube, create_unit_square
