@@ -257,6 +257,18 @@ def case_cube_contact_like(N=3) -> Case:
                 fem.form_source(V, fem.FN_POLY3), [bc], raw)
 
 
+def case_lifting_x0_scale_diagval() -> Case:
+    """apply_lifting with x0 and scale != 1 (cpp/lifting.h:292-298: be -= Ae[:, j] * scale * (g_j - x0_j)),
+    as a Newton step would call it (python/src/dolfinx_mpc/problem.py:265), and diagval != 1."""
+    case = case_cube_periodic(3, 1, 1.3)
+    rng = np.random.default_rng(42)
+    case.x0 = rng.standard_normal(case.V.num_dofs)
+    case.scale = -0.75
+    case.diagval = 2.5
+    case.name = "lifting_x0_scale_diagval"
+    return case
+
+
 def all_small_cases() -> List[Callable[[], Case]]:
     return [
         lambda: case_square_dict(1, (1, 1)),
@@ -280,6 +292,7 @@ def all_small_cases() -> List[Callable[[], Case]]:
         lambda: case_cube_periodic(4, 1, 0.0, reorder=(2, 2, 2)),
         lambda: case_cube_elasticity_slip(3),
         lambda: case_cube_contact_like(3),
+        case_lifting_x0_scale_diagval,
     ]
 
 
