@@ -92,16 +92,24 @@ class SlabExchange:
     keys exchanged at set-up."""
 
     def __init__(self, mesh: Mesh, rowptr: np.ndarray, cols: np.ndarray, rank: int, world: int, device=None,
-                 bs: int = 1):
+                 bs: int = 1, space=None):
+        """``space``: the (row == column) function space; default = P1 on ``mesh`` with block size ``bs``.
+        P2 spaces carry their own global ids / planes (FunctionSpace._p2_on_slab)."""
         import torch
         import torch.distributed as dist
 
         self.rank, self.world = rank, world
         self.device = device
         N = mesh.slab[0]
-        # unrolled dofs of a (blocked) P1 space: dof = node * bs + component
-        g = (mesh.node_global[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)
-        plane = np.repeat(mesh.node_global // ((N + 1) * (N + 1)), bs)
+        if space is not None:
+            bs = space.dofmap.bs
+            blk_global, blk_plane = space.dof_global, space.dof_plane
+        else:
+            blk_global = mesh.node_global
+            blk_plane = mesh.node_global // ((N + 1) * (N + 1))
+        # unrolled dofs: dof = block * bs + component
+        g = (blk_global[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)
+        plane = np.repeat(blk_plane, bs)
         self.send_to = rank + 1 if rank + 1 < world else None
         self.recv_from = rank - 1 if rank > 0 else None
         # ---- what I send: every entry of my top-plane rows -------------------
@@ -110,11 +118,12 @@ class SlabExchange:
         cnt = rowptr[top + 1] - rowptr[top]
         pos = (np.repeat(rowptr[top].astype(np.int64) - np.concatenate([[0], np.cumsum(cnt)[:-1]]), cnt)
                + np.arange(int(cnt.sum()))) if top.size else np.zeros(0, dtype=np.int64)
-        nglob = (N + 1) * (N + 1) * (N * world + 1) * bs
-        keys = np.repeat(g[top], cnt).astype(np.int64) * nglob + g[cols[pos]] if top.size else np.zeros(0, dtype=np.int64)
-        o = np.argsort(keys, kind="stable")
+        # entries ordered by (global row, global col)
+        k_row = np.repeat(g[top], cnt).astype(np.int64) if top.size else np.zeros(0, dtype=np.int64)
+        k_col = g[cols[pos]].astype(np.int64) if top.size else np.zeros(0, dtype=np.int64)
+        o = np.lexsort((k_col, k_row))
         self.send_pos = pos[o]
-        send_keys = keys[o]
+        send_keys = np.concatenate([k_row[o], k_col[o]])  # [rows..., cols...]
         self.send_rows = top
         # ---- key exchange (set-up only) -------------------------------------
         # RCCL moves device buffers; gloo (CPU tests) moves host buffers
@@ -148,12 +157,19 @@ class SlabExchange:
         # ---- where received values go in my CSR / vector ----------------------
         if self.recv_from is not None:
             kr = k_recv.cpu().numpy()
-            grow, gcol = kr // nglob, kr % nglob
-            inv = np.full(nglob, -1, dtype=np.int64)
-            inv[g] = np.arange(g.size)
-            lrow, lcol = inv[grow], inv[gcol]
-            if (lrow < 0).any() or (lcol < 0).any():
-                raise RuntimeError("SlabExchange: received a row/column this rank does not hold")
+            grow, gcol = kr[: kr.size // 2], kr[kr.size // 2 :]
+            # global id -> local dof by sorted search (no dense inverse table)
+            gorder = np.argsort(g, kind="stable")
+            gsorted = g[gorder]
+
+            def to_local(q):
+                p = np.searchsorted(gsorted, q)
+                p = np.minimum(p, gsorted.size - 1)
+                if (gsorted[p] != q).any():
+                    raise RuntimeError("SlabExchange: received a row/column this rank does not hold")
+                return gorder[p]
+
+            lrow, lcol = to_local(grow), to_local(gcol)
             # vectorised binary search per entry inside its row
             lo = rowptr[lrow].astype(np.int64)
             hi = rowptr[lrow + 1].astype(np.int64)
@@ -169,7 +185,7 @@ class SlabExchange:
             if (cols[np.minimum(lo, cols.size - 1)] != lcol).any():
                 raise RuntimeError("SlabExchange: received an entry outside the local sparsity pattern")
             self.recv_pos = lo
-            self.recv_rows = inv[r_recv.cpu().numpy()]
+            self.recv_rows = to_local(r_recv.cpu().numpy())
         else:
             self.recv_pos = np.zeros(0, dtype=np.int64)
             self.recv_rows = np.zeros(0, dtype=np.int64)

@@ -65,6 +65,18 @@ def _lagrange_ndofs(cell_name: str, degree: int) -> int:
     return {("tetrahedron", 1): 4, ("tetrahedron", 2): 10, ("triangle", 1): 3, ("triangle", 2): 6}[(cell_name, degree)]
 
 
+def kuhn_edge_global_ids(ga: np.ndarray, gb: np.ndarray, n1: int, num_global_nodes: int) -> np.ndarray:
+    """Global id of the edges (ga, gb) of the structured Kuhn mesh whose global node id is
+    (k*n1 + j)*n1 + i: every edge runs from its lower node in one of 7 directions
+    (1,0,0) (0,1,0) (0,0,1) (1,1,0) (0,1,1) (1,0,1) (1,1,1), so id = Gn + 7*lower + direction."""
+    g0, g1 = np.minimum(ga, gb).astype(np.int64), np.maximum(ga, gb).astype(np.int64)
+    d = g1 - g0
+    code = {1: 0, n1: 1, n1 * n1: 2, n1 + 1: 3, n1 * n1 + n1: 4, n1 * n1 + 1: 5, n1 * n1 + n1 + 1: 6}
+    ud = np.unique(d)
+    direction = np.array([code[int(v)] for v in ud])[np.searchsorted(ud, d)]
+    return num_global_nodes + 7 * g0 + direction
+
+
 class FunctionSpace:
     """Lagrange P1/P2 space, optionally blocked (``shape=(bs,)``)."""
 
@@ -78,19 +90,64 @@ class FunctionSpace:
         self.degree = degree
         bs = 1 if not shape else int(shape[0])
         nghost = 0
+        self._dof_coords = None
+        # partitioned meshes (dolfinx_mpc_amd.distributed): global id and lowest node
+        # plane of every dof block, used by the interface exchange
+        self.dof_global = None
+        self.dof_plane = None
         if degree == 1:
             cell_dofs = mesh.geometry.dofmap.copy()
             nblocks = mesh.num_owned_nodes
             nghost = mesh.num_nodes - mesh.num_owned_nodes
-        else:
-            if mesh.num_owned_nodes != mesh.num_nodes:
-                raise NotImplementedError("P2 spaces on partitioned meshes")
+            if mesh.node_global is not None:
+                N = mesh.slab[0]
+                self.dof_global = mesh.node_global
+                self.dof_plane = mesh.node_global // ((N + 1) * (N + 1))
+        elif mesh.num_owned_nodes == mesh.num_nodes:
             cell_edges, _ = mesh.edges()
             cell_dofs = np.concatenate([mesh.geometry.dofmap, cell_edges + mesh.num_nodes], axis=1)
             nblocks = mesh.num_nodes + int(cell_edges.max()) + 1
+        else:
+            cell_dofs, nblocks, nghost = self._p2_on_slab(mesh)
         self.dofmap = DofMap(cell_dofs, nblocks, bs, nghost)
-        self._dof_coords = None
         self._device = {}
+
+    def _p2_on_slab(self, mesh: Mesh):
+        """P2 dofs on a z-slab mesh: an edge dof belongs to the rank that owns the lower of
+        its two node planes (the only rank whose cells touch a vertical edge; the same rule as
+        for nodes when the edge lies in a plane).  Numbering: owned nodes, owned edges, ghost
+        nodes, ghost edges.  Global edge id = Gn + 7 * (lower global node) + direction."""
+        N, rank, world = mesh.slab
+        n1 = N + 1
+        cell_edges, ev = mesh.edges()
+        g = mesh.node_global
+        plane = g // (n1 * n1)
+        edge_global = kuhn_edge_global_ids(g[ev[:, 0]], g[ev[:, 1]], n1, n1 * n1 * (N * world + 1))
+        edge_plane = np.minimum(plane[ev[:, 0]], plane[ev[:, 1]])
+        last = rank == world - 1
+
+        def owned(p):
+            return (p >= rank * N) & ((p < (rank + 1) * N) | (last & (p == (rank + 1) * N)))
+
+        eo = owned(edge_plane)
+        n_on, n_nodes = mesh.num_owned_nodes, mesh.num_nodes
+        n_oe = int(eo.sum())
+        edge_new = np.empty(ev.shape[0], dtype=np.int64)
+        edge_new[eo] = n_on + np.arange(n_oe)
+        edge_new[~eo] = n_on + n_oe + (n_nodes - n_on) + np.arange(ev.shape[0] - n_oe)
+        node_new = np.arange(n_nodes, dtype=np.int64)
+        node_new[n_on:] += n_oe
+        cell_dofs = np.concatenate([node_new[mesh.geometry.dofmap], edge_new[cell_edges]], axis=1)
+        ntot = n_nodes + ev.shape[0]
+        self.dof_global = np.empty(ntot, dtype=np.int64)
+        self.dof_plane = np.empty(ntot, dtype=np.int64)
+        self.dof_global[node_new], self.dof_plane[node_new] = g, plane
+        self.dof_global[edge_new], self.dof_plane[edge_new] = edge_global, edge_plane
+        x = mesh.geometry.x
+        self._dof_coords = np.empty((ntot, 3))
+        self._dof_coords[node_new] = x
+        self._dof_coords[edge_new] = 0.5 * (x[ev[:, 0]] + x[ev[:, 1]])
+        return cell_dofs, n_on + n_oe, ntot - n_on - n_oe
 
     @property
     def element_ndofs(self) -> int:

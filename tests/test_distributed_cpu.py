@@ -39,6 +39,14 @@ def _problem(mesh, world, N, kind="poisson"):
         bc = fem.dirichletbc(0.7, dofs, V)
         raw = periodic_raw(V, [bc])
         return V, bc, raw, fem.form_stiffness(V), fem.form_source(V, fem.FN_BENCH_PERIODIC)
+    if kind == "p2":
+        # BASELINE config 5's space: periodic Poisson, P2
+        V = fem.functionspace(mesh, ("Lagrange", 2))
+        dofs = fem.locate_dofs_geometrical(
+            V, lambda x: np.isclose(x[1], 0) | np.isclose(x[1], 1) | np.isclose(x[2], 0) | np.isclose(x[2], zmax))
+        bc = fem.dirichletbc(-0.4, dofs, V)
+        raw = periodic_raw(V, [bc])
+        return V, bc, raw, fem.form_stiffness(V), fem.form_source(V, fem.FN_POLY3)
     V = fem.functionspace(mesh, ("Lagrange", 1, (3,)))
     dofs = fem.locate_dofs_geometrical(V, lambda x: np.isclose(x[1], 0) | np.isclose(x[2], zmax))
     bc = fem.dirichletbc(np.array([0.0, 0.1, -0.2]), dofs, V)
@@ -67,14 +75,14 @@ def _worker(rank, world, port, N, reorder, outdir, kind="poisson"):
     A = po.assemble_matrix(a, mpc, bcs=[bc], pattern=pattern)  # owned cells, owned-only diagonals
     b = po.assemble_vector(L, mpc)
     po.apply_lifting(b, [a], [[bc]], mpc)
-    ex = SlabExchange(mesh, pattern[0], pattern[1], rank, world, bs=bs)
+    ex = SlabExchange(mesh, pattern[0], pattern[1], rank, world, space=V)
     vals = torch.from_numpy(A.data.copy())
     bt = torch.from_numpy(b.copy())
     ex.reduce_matrix(vals)
     ex.reduce_vector(bt)
     A = scipy.sparse.csr_matrix((vals.numpy(), A.indices, A.indptr), shape=A.shape)
-    g = (mesh.node_global[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)  # global unrolled dofs
-    nown = mesh.num_owned_nodes * bs
+    g = (V.dof_global[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)  # global unrolled dof ids
+    nown = V.dofmap.index_map.size_local * bs
     Aown = A[:nown].tocoo()
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), row=g[Aown.row], col=g[Aown.col], val=Aown.data,
              brow=g[:nown], bval=bt.numpy()[:nown], nslaves=mpc.num_local_slaves)
@@ -83,7 +91,8 @@ def _worker(rank, world, port, N, reorder, outdir, kind="poisson"):
 
 
 @pytest.mark.parametrize("world,N,reorder,kind", [(2, 4, None, "poisson"), (2, 4, (2, 2, 2), "poisson"),
-                                                   (3, 3, (2, 2, 2), "poisson"), (2, 3, (2, 2, 2), "elasticity")])
+                                                   (3, 3, (2, 2, 2), "poisson"), (2, 3, (2, 2, 2), "elasticity"),
+                                                   (2, 3, (2, 2, 2), "p2"), (3, 2, None, "p2")])
 def test_slab_partition_matches_global_assembly(oracle, tmp_path, world, N, reorder, kind):
     import torch.multiprocessing as mp
 
@@ -100,11 +109,30 @@ def test_slab_partition_matches_global_assembly(oracle, tmp_path, world, N, reor
     oracle.apply_lifting(bref, [a], [[bc]], mpc)
 
     n = V.num_dofs
+    # global ids of the reference (single-process) numbering: nodes are numbered lexicographically,
+    # P2 edges get the same structured id the slab spaces use
+    bs = V.dofmap.bs
+    if V.degree == 1:
+        gkey = np.arange(V.num_dofs // bs, dtype=np.int64)
+    else:
+        from dolfinx_mpc_amd.fem import kuhn_edge_global_ids
+
+        _, ev = gmesh.edges()
+        gkey = np.concatenate([np.arange(gmesh.num_nodes, dtype=np.int64),
+                               kuhn_edge_global_ids(ev[:, 0], ev[:, 1], N + 1, gmesh.num_nodes)])
+    gkey = (gkey[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)
+    order = np.argsort(gkey)
+
+    def to_ref(q):  # global id -> index in the reference numbering
+        p = np.searchsorted(gkey[order], q)
+        assert np.array_equal(gkey[order][p], q)
+        return order[p]
+
     rows, cols, vals, brow, bval, nsl = [], [], [], [], [], 0
     for r in range(world):
         d = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
-        rows.append(d["row"]), cols.append(d["col"]), vals.append(d["val"])
-        brow.append(d["brow"]), bval.append(d["bval"])
+        rows.append(to_ref(d["row"])), cols.append(to_ref(d["col"])), vals.append(d["val"])
+        brow.append(to_ref(d["brow"])), bval.append(d["bval"])
         nsl += int(d["nslaves"])
     A = scipy.sparse.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsr()
     # every row is owned exactly once
