@@ -52,6 +52,7 @@ class RowBlockPlanT(C.Structure):
         ("block_ent_off", C.c_void_p),
         ("block_ents", C.c_void_p),
         ("ent_offs", C.c_void_p),
+        ("ent_pattern", C.c_void_p),
     ]
 
 
@@ -172,6 +173,7 @@ EXPORTS = [
     "mpcx_rowblock_plan_num_ents",
     "mpcx_rowblock_plan_copy",
     "mpcx_rowblock_plan_free",
+    "mpcx_compress_offsets",
     "mpcx_last_error",
     "mpcx_version",
     "mpcx_device_count",
@@ -244,6 +246,8 @@ def lib() -> C.CDLL:
     L.mpcx_rowblock_plan_copy.restype = C.c_int
     L.mpcx_rowblock_plan_free.argtypes = [vp]
     L.mpcx_rowblock_plan_free.restype = None
+    L.mpcx_compress_offsets.argtypes = [vp, i64, i32, i32, vp, vp]
+    L.mpcx_compress_offsets.restype = i32
     L.mpcx_last_error.argtypes = []
     L.mpcx_last_error.restype = C.c_char_p
     L.mpcx_version.argtypes = []

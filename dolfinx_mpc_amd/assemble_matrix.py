@@ -23,6 +23,8 @@ _ALG = {"auto": 0, "atomic": 1, "rowblock": 2}
 # -> 2 workgroups of 512 threads per CU is the fastest shape for P1)
 ROWBLOCK_MAX_NNZ = int(os.environ.get("MPCX_ROWBLOCK_MAX_NNZ", 9216))
 ROWBLOCK_MAX_ROWS = int(os.environ.get("MPCX_ROWBLOCK_MAX_ROWS", 512))
+# scatter-offset rows are dictionary-compressed when at most this many are distinct (table stays cache resident)
+MAX_OFFSET_PATTERNS = 4096
 
 
 def _pair(constraint):
@@ -128,13 +130,26 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0):
         if int(flag.item()) != 0:
             raise RuntimeError("row-block algorithm: a CSR row holds more than 255 column blocks before one of the "
                                "entity's columns (or a column is missing from the pattern); use algorithm='atomic'")
-        t = (D._to_dev(row0, dev), D._to_dev(off, dev), D._to_dev(ents_b, dev), offs)
+        # dictionary compression: structured / tiled meshes have few distinct offset rows, so the
+        # kernel reads a 2-byte id per entity plus a cache-resident table instead of nd0*nd1 bytes
+        noff = V0.element_ndofs * V1.element_ndofs
+        pattern = None
+        npat = -1
+        if not os.environ.get("MPCX_NO_OFFSET_DICT") and integ.num_entities > 0:
+            offs_h = offs.cpu().numpy()
+            ids = np.empty(integ.num_entities, dtype=np.uint16)
+            table = np.empty(MAX_OFFSET_PATTERNS * noff, dtype=np.uint8)
+            npat = L.mpcx_compress_offsets(p(offs_h), integ.num_entities, noff, MAX_OFFSET_PATTERNS, p(ids), p(table))
+            if npat > 0:
+                offs = D._to_dev(table[: npat * noff].copy(), dev)
+                pattern = D._to_dev(ids.view(np.int16), dev)  # torch has no uint16 on every build: same bits
+        t = (D._to_dev(row0, dev), D._to_dev(off, dev), D._to_dev(ents_b, dev), offs, pattern)
         max_rows = int(np.diff(row0).max())
         max_nnz = int(np.diff(A.rowptr[row0].astype(np.int64)).max())
         s = _native.RowBlockPlanT(nb, max_rows, max_nnz, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
-                                  t[3].data_ptr())
+                                  t[3].data_ptr(), D.ptr(pattern))
         A._plans[key] = (s, t, {"num_blocks": nb, "num_ents": int(ents_b.size), "max_rows": max_rows,
-                                "max_nnz": max_nnz})
+                                "max_nnz": max_nnz, "offset_patterns": npat})
     return A._plans[key]
 
 

@@ -428,3 +428,43 @@ extern "C" int mpcx_rowblock_plan_copy(void* p, int32_t* block_row0, int64_t* bl
   return 0;
 }
 extern "C" void mpcx_rowblock_plan_free(void* p) { delete static_cast<RowBlockPlan*>(p); }
+
+// ---------------------------------------------------------------------------
+// Dictionary compression of the scatter-offset table: distinct rows -> ids.
+extern "C" int32_t mpcx_compress_offsets(const uint8_t* rows, int64_t n, int32_t noff, int32_t max_patterns,
+                                         uint16_t* pattern_ids, uint8_t* table)
+{
+  if (max_patterns > 65536)
+    max_patterns = 65536;
+  // open-addressing hash set over the rows already copied into `table`
+  constexpr int LOG2 = 18;
+  std::vector<int32_t> slots(size_t(1) << LOG2, -1);
+  int32_t npat = 0;
+  for (int64_t e = 0; e < n; ++e)
+  {
+    const uint8_t* r = rows + e * noff;
+    uint64_t h = 1469598103934665603ull; // FNV-1a
+    for (int k = 0; k < noff; ++k)
+      h = (h ^ r[k]) * 1099511628211ull;
+    size_t s = size_t(h >> (64 - LOG2));
+    int32_t id;
+    for (;;)
+    {
+      id = slots[s];
+      if (id < 0)
+      {
+        if (npat >= max_patterns)
+          return -1;
+        id = npat++;
+        std::memcpy(table + size_t(id) * noff, r, size_t(noff));
+        slots[s] = id;
+        break;
+      }
+      if (std::memcmp(table + size_t(id) * noff, r, size_t(noff)) == 0)
+        break;
+      s = (s + 1) & ((size_t(1) << LOG2) - 1);
+    }
+    pattern_ids[e] = static_cast<uint16_t>(id);
+  }
+  return npat;
+}

@@ -312,8 +312,9 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
 #pragma unroll
     for (int i = 0; i < NV; ++i)
       E.xd[i] = a.x_dofmap[cell * NV + i];
-    // scatter offsets of this entity (ND0*ND1 bytes, contiguous)
-    const uint8_t* po = a.plan.ent_offs + e * NOFF;
+    // scatter offsets of this entity (ND0*ND1 bytes, contiguous): its own row of the
+    // table, or -- dictionary-compressed plan -- the shared row its 2-byte pattern id selects
+    const uint8_t* po = a.plan.ent_offs + (a.plan.ent_pattern ? int64_t(a.plan.ent_pattern[e]) : e) * NOFF;
     if constexpr (NOFF % 16 == 0)
     {
 #pragma unroll

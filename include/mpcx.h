@@ -91,6 +91,11 @@ typedef struct
    * (mpcx_scatter_offsets); the scalar entry (i*bs0+k, j*bs1+l) lives at
    * rowptr[dofs0[i]*bs0+k] + off*bs1 + l */
   const uint8_t* ent_offs;
+  /* Optional dictionary compression of ent_offs (mpcx_compress_offsets): ent_offs then is
+   * the table of DISTINCT offset rows [num_patterns][nd0*nd1] and ent_pattern[e] (uint16)
+   * selects the row of entity e; NULL = ent_offs is indexed by the entity directly.
+   * Structured / tiled meshes have a few hundred distinct rows: 2 B per entity instead of nd0*nd1. */
+  const uint16_t* ent_pattern;
 } mpcx_rowblock_plan_t;
 
 /* ------------------------------------------------------------------------
@@ -282,6 +287,12 @@ int64_t mpcx_rowblock_plan_num_ents(void* plan);
 int mpcx_rowblock_plan_copy(void* plan, int32_t* block_row0, int64_t* block_ent_off,
                             int32_t* block_ents);
 void mpcx_rowblock_plan_free(void* plan);
+
+/* HOST: dictionary-compress n rows of `noff` bytes (the scatter-offset table copied to the
+ * host).  pattern_ids[n] (uint16) and table[max_patterns*noff] are caller-allocated.
+ * Returns the number of distinct rows, or -1 if there are more than max_patterns (<= 65536). */
+int32_t mpcx_compress_offsets(const uint8_t* rows, int64_t n, int32_t noff, int32_t max_patterns,
+                              uint16_t* pattern_ids, uint8_t* table);
 
 /* misc */
 const char* mpcx_last_error(void);

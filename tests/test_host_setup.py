@@ -279,3 +279,22 @@ def test_mesh_generators_counts_and_tiling():
     V2 = fem.functionspace(m, ("Lagrange", 2))
     E = 3 * n * (n + 1) ** 2 + 3 * n * n * (n + 1) + n**3
     assert V2.num_dofs == (n + 1) ** 3 + E == (2 * n + 1) ** 3
+
+
+def test_compress_offsets_dictionary():
+    L = _native.lib()
+    p = _native._ptr
+    rng = np.random.default_rng(3)
+    base = rng.integers(0, 30, size=(37, 16), dtype=np.uint8)
+    pick = rng.integers(0, 37, size=5000)
+    rows = np.ascontiguousarray(base[pick])
+    ids = np.empty(rows.shape[0], dtype=np.uint16)
+    table = np.empty(64 * 16, dtype=np.uint8)
+    n = L.mpcx_compress_offsets(p(rows), rows.shape[0], 16, 64, p(ids), p(table))
+    assert n == np.unique(base[np.unique(pick)], axis=0).shape[0]
+    assert np.array_equal(table[: n * 16].reshape(n, 16)[ids], rows)
+    # too many distinct rows -> -1 (caller keeps the uncompressed table)
+    many = np.ascontiguousarray(rng.integers(0, 255, size=(500, 9), dtype=np.uint8))
+    ids = np.empty(500, dtype=np.uint16)
+    table = np.empty(16 * 9, dtype=np.uint8)
+    assert L.mpcx_compress_offsets(p(many), 500, 9, 16, p(ids), p(table)) == -1
