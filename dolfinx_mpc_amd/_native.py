@@ -53,10 +53,6 @@ class RowBlockPlanT(C.Structure):
         ("block_ents", C.c_void_p),
         ("ent_offs", C.c_void_p),
         ("ent_pattern", C.c_void_p),
-        ("slot_xdofs", C.c_void_p),
-        ("slot_mdofs0", C.c_void_p),
-        ("slot_mdofs1", C.c_void_p),
-        ("slot_pattern", C.c_void_p),
     ]
 
 

@@ -135,7 +135,7 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0):
         noff = V0.element_ndofs * V1.element_ndofs
         pattern = None
         npat = -1
-        if not os.environ.get("MPCX_NO_OFFSET_DICT") and integ.num_entities > 0:
+        if os.environ.get("MPCX_OFFSET_DICT") and integ.num_entities > 0:
             offs_h = offs.cpu().numpy()
             ids = np.empty(integ.num_entities, dtype=np.uint16)
             table = np.empty(MAX_OFFSET_PATTERNS * noff, dtype=np.uint8)
@@ -213,27 +213,6 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
         md1 = md0 if (V1 is V0 and mpc1 is mpc0 and bc1 is bc0) else _masked_dofmap(form, V1, bc1, mpc1, 1)
         a.mdofmap0, a.mdofmap1 = md0.data_ptr(), md1.data_ptr()
         keep += [pk, md0, md1]
-        if pk[4] is not None and not os.environ.get("MPCX_NO_SLOT_PACK"):
-            # slot-packed copies of the per-entity index data (pure streaming in the kernel)
-            skey = ("slots", id(A), i, md0.data_ptr(), md1.data_ptr())
-            if skey not in form._device:
-                import torch
-
-                slot_ent = pk[2].to(torch.int64)  # block_ents
-                ent = idv["entities"].view(-1, integ.estride)[:, 0].to(torch.int64)
-                cells = ent.index_select(0, slot_ent)
-                del ent
-                sx = md["x_dofmap"].index_select(0, cells)
-                sm0 = md0.index_select(0, cells)
-                sm1 = None if md1 is md0 else md1.index_select(0, cells)
-                sp = pk[4].index_select(0, slot_ent)
-                del cells, slot_ent
-                form._device[skey] = (sx, sm0, sm1, sp)
-            sx, sm0, sm1, sp = form._device[skey]
-            a.plan.slot_xdofs, a.plan.slot_mdofs0 = sx.data_ptr(), sm0.data_ptr()
-            a.plan.slot_mdofs1 = D.ptr(sm1)
-            a.plan.slot_pattern = sp.data_ptr()
-            keep += [sx, sm0, sm1, sp]
     return a, keep
 
 

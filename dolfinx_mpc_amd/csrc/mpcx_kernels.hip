@@ -297,59 +297,25 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
   auto load_ent = [&](int64_t t, Ent& E)
   {
     const uint8_t* po;
-    if (a.plan.slot_xdofs)
-    {
-      // slot-packed plan: everything is indexed by the slot t itself (pure streaming);
-      // the entity index is only needed for coefficients / facet numbers
-      const bool need_e = a.coeffs != nullptr || a.estride == 2;
-      const int64_t e = need_e ? int64_t(a.plan.block_ents[t]) : 0;
-      E.e = e;
-      E.lf = a.estride == 2 ? a.entities[e * 2 + 1] : 0;
+    const int64_t e = a.plan.block_ents[t];
+    const int64_t l = e * a.estride;
+    const int64_t cell = (a.entities ? a.entities[l] : e);
+    const int64_t cell0 = (a.entities0 ? a.entities0[l] : e);
+    const int64_t cell1 = (a.entities1 ? a.entities1[l] : e);
+    E.e = e;
+    E.lf = a.estride == 2 ? a.entities[l + 1] : 0;
 #pragma unroll
-      for (int i = 0; i < ND0; ++i)
-        E.m0[i] = a.plan.slot_mdofs0[t * ND0 + i];
-      if (a.plan.slot_mdofs1)
-      {
+    for (int i = 0; i < ND0; ++i)
+      E.m0[i] = a.mdofmap0[cell0 * ND0 + i];
 #pragma unroll
-        for (int j = 0; j < ND1; ++j)
-          E.m1[j] = a.plan.slot_mdofs1[t * ND1 + j];
-      }
-      else
-      {
-        if constexpr (ND0 == ND1)
-        {
+    for (int j = 0; j < ND1; ++j)
+      E.m1[j] = a.mdofmap1[cell1 * ND1 + j];
 #pragma unroll
-          for (int j = 0; j < ND1; ++j)
-            E.m1[j] = E.m0[j];
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < NV; ++i)
-        E.xd[i] = a.plan.slot_xdofs[t * NV + i];
-      po = a.plan.ent_offs + int64_t(a.plan.slot_pattern[t]) * NOFF;
-    }
-    else
-    {
-      const int64_t e = a.plan.block_ents[t];
-      const int64_t l = e * a.estride;
-      const int64_t cell = (a.entities ? a.entities[l] : e);
-      const int64_t cell0 = (a.entities0 ? a.entities0[l] : e);
-      const int64_t cell1 = (a.entities1 ? a.entities1[l] : e);
-      E.e = e;
-      E.lf = a.estride == 2 ? a.entities[l + 1] : 0;
-#pragma unroll
-      for (int i = 0; i < ND0; ++i)
-        E.m0[i] = a.mdofmap0[cell0 * ND0 + i];
-#pragma unroll
-      for (int j = 0; j < ND1; ++j)
-        E.m1[j] = a.mdofmap1[cell1 * ND1 + j];
-#pragma unroll
-      for (int i = 0; i < NV; ++i)
-        E.xd[i] = a.x_dofmap[cell * NV + i];
-      // scatter offsets of this entity (ND0*ND1 bytes, contiguous): its own row of the
-      // table, or -- dictionary-compressed plan -- the shared row its 2-byte pattern id selects
-      po = a.plan.ent_offs + (a.plan.ent_pattern ? int64_t(a.plan.ent_pattern[e]) : e) * NOFF;
-    }
+    for (int i = 0; i < NV; ++i)
+      E.xd[i] = a.x_dofmap[cell * NV + i];
+    // scatter offsets of this entity (ND0*ND1 bytes, contiguous): its own row of the
+    // table, or -- dictionary-compressed plan -- the shared row its 2-byte pattern id selects
+    po = a.plan.ent_offs + (a.plan.ent_pattern ? int64_t(a.plan.ent_pattern[e]) : e) * NOFF;
     if constexpr (NOFF % 16 == 0)
     {
 #pragma unroll

@@ -60,6 +60,16 @@ def test_config1_cube32(oracle, alg):
     oracle.compare_mpc_lhs(A_org, out["A"], mpc)
 
 
+def test_dictionary_compressed_plan(oracle, monkeypatch):
+    """Opt-in plan variant (MPCX_OFFSET_DICT=1): 2-byte pattern ids + table of distinct
+    scatter-offset rows (mpcx_compress_offsets) must give the same matrix."""
+    monkeypatch.setenv("MPCX_OFFSET_DICT", "1")
+    case = case_cube_periodic(12, 1, 0.0)
+    ref = oracle_outputs(oracle, case, fast=True)
+    out = product_outputs(case, algorithm="rowblock")
+    _close(out["A"].data, ref["A"].data, RTOL_A, "A (dictionary plan)")
+
+
 def test_repeated_assembly_into_same_matrix(oracle):
     """A given -> zeroed and re-assembled (python/src/dolfinx_mpc/assemble_matrix.py:49-51)."""
     import dolfinx_mpc_amd as dm
