@@ -30,7 +30,14 @@ def space_device(V: FunctionSpace):
     dev = _native.require_gpu()
     key = str(dev)
     if key not in V._device:
-        V._device[key] = {"dofmap": _to_dev(V.dofmap.list, dev)}
+        xd = V.mesh.geometry.dofmap
+        dm = V.dofmap.list
+        if dm.shape == xd.shape and np.array_equal(dm, xd):
+            # P1: dofs are numbered like the nodes -> ONE device array for both maps; the row-block
+            # kernel sees dofmap0 == x_dofmap and skips the second 16 B/entity read
+            V._device[key] = {"dofmap": mesh_device(V.mesh)["x_dofmap"]}
+        else:
+            V._device[key] = {"dofmap": _to_dev(dm, dev)}
     return V._device[key]
 
 

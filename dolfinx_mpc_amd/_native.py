@@ -12,7 +12,8 @@ import os
 
 import numpy as np
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmpcx.so")
+# MPCX_LIBRARY: alternative build of the same ABI (kernel experiments, tools/ablate.sh)
+_LIB_PATH = os.environ.get("MPCX_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmpcx.so")
 
 
 class KernelT(C.Structure):

@@ -113,6 +113,16 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0):
             L.mpcx_rowblock_plan_copy(h, p(row0), p(off), p(ents_b))
         finally:
             L.mpcx_rowblock_plan_free(h)
+        il = int(os.environ.get("MPCX_PLAN_INTERLEAVE", 0))
+        if il > 1:
+            # experiment: lanes of one wave take entities `il` apart (fewer same-address LDS atomics)
+            g = 64 * il
+            for bb in range(nb):
+                lo, hi = int(off[bb]), int(off[bb + 1])
+                nfull = (hi - lo) // g * g
+                if nfull:
+                    v = ents_b[lo:lo + nfull].reshape(-1, 64, il)
+                    ents_b[lo:lo + nfull] = v.transpose(0, 2, 1).reshape(-1)
         dev = A.device
         # 8-bit scatter offsets of every (entity, local row, local col), built on the device
         import torch

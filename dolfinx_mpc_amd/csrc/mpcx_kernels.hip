@@ -256,7 +256,11 @@ constexpr int MPCX_DOF_MASK = (1 << MPCX_MASK_SHIFT) - 1;
 // (2.25 ms) than the spill-free 150-VGPR build at 3 waves/SIMD (2.56 ms).
 constexpr int ROWBLOCK_MAX_THREADS = 1024;
 
-template <class Op>
+// LEAN: square form on one space whose dofmap IS the geometry dofmap (P1 on an affine mesh: the
+// host passes one device array for both), integral over all cells (entities == NULL), no facets:
+// per entity only the masked dofmap row and the scatter offsets are read, and the thread keeps
+// three entities in flight.  Everything else takes the general path.
+template <class Op, bool LEAN>
 __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(mpcx_matrix_args_t a)
 {
   constexpr int ND0 = Op::ND0, ND1 = Op::ND1, BS0 = Op::BS0, BS1 = Op::BS1, NV = Op::NV;
@@ -288,34 +292,41 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
   // per-entity index data: everything that is read through the entity index
   struct Ent
   {
-    int64_t e;
+    int32_t e;
     int lf;
     int32_t xd[NV];
     int32_t m0[ND0], m1[ND1];
     uint32_t ow[(NOFF + 3) / 4]; // scatter offsets, 4 per word (unpacked at use: v_bfe_u32)
   };
-  auto load_ent = [&](int64_t t, Ent& E)
+  auto load_ent = [&](int64_t e, Ent& E)
   {
-    const uint8_t* po;
-    const int64_t e = a.plan.block_ents[t];
-    const int64_t l = e * a.estride;
-    const int64_t cell = (a.entities ? a.entities[l] : e);
-    const int64_t cell0 = (a.entities0 ? a.entities0[l] : e);
-    const int64_t cell1 = (a.entities1 ? a.entities1[l] : e);
     E.e = e;
-    E.lf = a.estride == 2 ? a.entities[l + 1] : 0;
+    if constexpr (LEAN)
+    {
 #pragma unroll
-    for (int i = 0; i < ND0; ++i)
-      E.m0[i] = a.mdofmap0[cell0 * ND0 + i];
+      for (int i = 0; i < ND0; ++i)
+        E.m0[i] = a.mdofmap0[e * ND0 + i];
+    }
+    else
+    {
+      const int64_t l = e * a.estride;
+      const int64_t cell = (a.entities ? a.entities[l] : e);
+      const int64_t cell0 = (a.entities0 ? a.entities0[l] : e);
+      const int64_t cell1 = (a.entities1 ? a.entities1[l] : e);
+      E.lf = a.estride == 2 ? a.entities[l + 1] : 0;
 #pragma unroll
-    for (int j = 0; j < ND1; ++j)
-      E.m1[j] = a.mdofmap1[cell1 * ND1 + j];
+      for (int i = 0; i < ND0; ++i)
+        E.m0[i] = a.mdofmap0[cell0 * ND0 + i];
 #pragma unroll
-    for (int i = 0; i < NV; ++i)
-      E.xd[i] = a.x_dofmap[cell * NV + i];
+      for (int j = 0; j < ND1; ++j)
+        E.m1[j] = a.mdofmap1[cell1 * ND1 + j];
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        E.xd[i] = a.x_dofmap[cell * NV + i];
+    }
     // scatter offsets of this entity (ND0*ND1 bytes, contiguous): its own row of the
     // table, or -- dictionary-compressed plan -- the shared row its 2-byte pattern id selects
-    po = a.plan.ent_offs + (a.plan.ent_pattern ? int64_t(a.plan.ent_pattern[e]) : e) * NOFF;
+    const uint8_t* po = a.plan.ent_offs + (a.plan.ent_pattern ? int64_t(a.plan.ent_pattern[e]) : e) * NOFF;
     if constexpr (NOFF % 16 == 0)
     {
 #pragma unroll
@@ -348,51 +359,40 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
       }
     }
   };
-
-  // Software pipeline (small elements): the index data of the next entity is
-  // requested while the current one is computed, so each iteration waits for one
-  // memory round trip (the coordinate gather) instead of three dependent ones.
-  constexpr bool PREFETCH = (NOFF <= 16);
-  const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
-  int64_t t = e0 + tid;
-  Ent cur;
-  if (PREFETCH && t < e1)
-    load_ent(t, cur);
-  for (; t < e1; t += NT)
+  auto load_coords = [&](const Ent& E, double (&cd)[NV * 3])
   {
-    if constexpr (!PREFETCH)
-      load_ent(t, cur);
-    double cd[NV * 3];
 #pragma unroll
     for (int i = 0; i < NV; ++i)
     {
-      const int64_t v = cur.xd[i];
+      int64_t v;
+      if constexpr (LEAN)
+        v = E.m0[i < ND0 ? i : 0] & MPCX_DOF_MASK;
+      else
+        v = E.xd[i];
 #pragma unroll
       for (int k = 0; k < 3; ++k)
         cd[3 * i + k] = a.x[3 * v + k];
     }
-    Ent nxt = cur;
-    if constexpr (PREFETCH)
-    {
-      if (t + NT < e1)
-        load_ent(t + NT, nxt);
-    }
+  };
+  // element tensor of one entity, rows of this block added into the LDS copy of the block
+  auto accumulate = [&](const Ent& E, const double (&cd)[NV * 3])
+  {
     double Ae[Op::SIZE];
-    Op::tabulate(Ae, a.coeffs ? a.coeffs + cur.e * a.cstride : nullptr, a.constants, cd, cur.lf, a.kernel);
+    Op::tabulate(Ae, a.coeffs ? a.coeffs + E.e * a.cstride : nullptr, a.constants, cd, LEAN ? 0 : E.lf, a.kernel);
 #pragma unroll
     for (int i = 0; i < ND0; ++i)
     {
 #pragma unroll
       for (int k = 0; k < BS0; ++k)
       {
-        const int r = (cur.m0[i] & MPCX_DOF_MASK) * BS0 + k;
-        if (r < r0 || r >= r1 || ((cur.m0[i] >> (MPCX_MASK_SHIFT + k)) & 1))
+        const int r = (E.m0[i] & MPCX_DOF_MASK) * BS0 + k;
+        if (r < r0 || r >= r1 || ((E.m0[i] >> (MPCX_MASK_SHIFT + k)) & 1))
           continue;
         const int base = s_rowlo[r - r0];
 #pragma unroll
         for (int j = 0; j < ND1; ++j)
         {
-          const int off = int((cur.ow[(i * ND1 + j) >> 2] >> (8 * ((i * ND1 + j) & 3))) & 0xff) * BS1;
+          const int off = int((E.ow[(i * ND1 + j) >> 2] >> (8 * ((i * ND1 + j) & 3))) & 0xff) * BS1;
 #pragma unroll
           for (int q = 0; q < BS1; ++q)
           {
@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
               if (k != q)
                 continue; // structurally zero
             }
-            if ((cur.m1[j] >> (MPCX_MASK_SHIFT + q)) & 1)
+            if (((LEAN ? E.m0[j < ND0 ? j : 0] : E.m1[j]) >> (MPCX_MASK_SHIFT + q)) & 1)
               continue;
             __hip_atomic_fetch_add(s_vals + base + off + q, Op::get(Ae, i * BS0 + k, j * BS1 + q),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -409,8 +409,46 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
         }
       }
     }
-    if constexpr (PREFETCH)
+  };
+
+  const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  const int32_t* __restrict__ ents = a.plan.block_ents;
+  int64_t t = e0 + tid;
+  if constexpr (NOFF <= 16)
+  {
+    // Software pipeline (small elements): while one entity is computed, the index data (masked dofmap row, scatter
+    // offsets) of the next one and the entity index of the one after it are in flight, so the only
+    // round trip an iteration waits for is its own coordinate gather.  (A third stage that also
+    // prefetched the next coordinates needs > 128 VGPRs and spills: 7.5 ms instead of 2.0 ms.)
+    Ent cur;
+    int32_t i1 = 0;
+    if (t < e1)
+      load_ent(ents[t], cur);
+    if (t + NT < e1)
+      i1 = ents[t + NT];
+    for (; t < e1; t += NT)
+    {
+      double cd[NV * 3];
+      load_coords(cur, cd);
+      Ent nxt = cur;
+      if (t + NT < e1)
+        load_ent(i1, nxt);
+      if (t + 2 * NT < e1)
+        i1 = ents[t + 2 * NT];
+      accumulate(cur, cd);
       cur = nxt;
+    }
+  }
+  else
+  {
+    for (; t < e1; t += NT)
+    {
+      Ent cur;
+      double cd[NV * 3];
+      load_ent(ents[t], cur);
+      load_coords(cur, cd);
+      accumulate(cur, cd);
+    }
   }
   __syncthreads();
   // one coalesced write of the finished block
@@ -713,11 +751,27 @@ int launch_matrix(const mpcx_matrix_args_t& a)
         const int t = e ? std::atoi(e) : 512;
         return (t >= 64 && t <= 1024 && t % 64 == 0) ? t : 512;
       }();
-      if (int rc = check(hipFuncSetAttribute(reinterpret_cast<const void*>(matrix_rowblock_kernel<Op>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)),
-                         "hipFuncSetAttribute"))
+      auto launch = [&](auto kernel) -> int
+      {
+        if (int rc = check(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)),
+                           "hipFuncSetAttribute"))
+          return rc;
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, stream, a);
+        return 0;
+      };
+      constexpr bool CAN_LEAN = Op::SQUARE && !Op::FACET && Op::NV == Op::ND0;
+      bool lean = false;
+      if constexpr (CAN_LEAN)
+        lean = a.estride == 1 && !a.entities && !a.entities0 && !a.entities1 && a.mdofmap1 == a.mdofmap0
+               && a.x_dofmap == a.dofmap0 && !std::getenv("MPCX_NO_LEAN");
+      int rc = 0;
+      if constexpr (CAN_LEAN)
+        rc = lean ? launch(matrix_rowblock_kernel<Op, true>) : launch(matrix_rowblock_kernel<Op, false>);
+      else
+        rc = launch(matrix_rowblock_kernel<Op, false>);
+      if (rc)
         return rc;
-      hipLaunchKernelGGL(matrix_rowblock_kernel<Op>, dim3(grid), dim3(threads), lds, stream, a);
     }
     else
     {
