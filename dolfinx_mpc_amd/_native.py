@@ -92,6 +92,7 @@ class MatrixArgs(C.Structure):
         ("plan", RowBlockPlanT),
         ("mdofmap0", C.c_void_p),
         ("mdofmap1", C.c_void_p),
+        ("lean", C.c_int32),
         ("stream", C.c_void_p),
     ]
 
@@ -233,9 +234,9 @@ def lib() -> C.CDLL:
     L.mpcx_pattern_copy.restype = C.c_int
     L.mpcx_pattern_free.argtypes = [vp]
     L.mpcx_pattern_free.restype = None
-    L.mpcx_mask_dofmap.argtypes = [vp, i64, i32, vp, vp, vp, vp]
+    L.mpcx_mask_dofmap.argtypes = [vp, i64, i32, i32, vp, vp, i32, vp, vp]
     L.mpcx_mask_dofmap.restype = C.c_int
-    L.mpcx_scatter_offsets.argtypes = [vp, vp, i32, i64, vp, vp, vp, i32, i32, vp, i32, i32, vp, vp, vp]
+    L.mpcx_scatter_offsets.argtypes = [vp, vp, i32, i64, vp, vp, vp, i32, i32, vp, i32, i32, i32, vp, vp, vp]
     L.mpcx_scatter_offsets.restype = C.c_int
     L.mpcx_rowblock_plan_build.argtypes = [i32, vp, i32, i32, i64, i32, vp, vp, i32, i32, vp, i32, i32]
     L.mpcx_rowblock_plan_build.restype = vp

@@ -88,8 +88,8 @@ def _slave_entities(form: Form, i: int, mpc0, mpc1):
     return mpc0._cache[key]
 
 
-def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0):
-    key = (id(form), i, ROWBLOCK_MAX_NNZ, ROWBLOCK_MAX_ROWS)
+def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False):
+    key = (id(form), i, ROWBLOCK_MAX_NNZ, ROWBLOCK_MAX_ROWS, lean)
     if key not in A._plans:
         L = _native.lib()
         p = _native._ptr
@@ -113,16 +113,6 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0):
             L.mpcx_rowblock_plan_copy(h, p(row0), p(off), p(ents_b))
         finally:
             L.mpcx_rowblock_plan_free(h)
-        il = int(os.environ.get("MPCX_PLAN_INTERLEAVE", 0))
-        if il > 1:
-            # experiment: lanes of one wave take entities `il` apart (fewer same-address LDS atomics)
-            g = 64 * il
-            for bb in range(nb):
-                lo, hi = int(off[bb]), int(off[bb + 1])
-                nfull = (hi - lo) // g * g
-                if nfull:
-                    v = ents_b[lo:lo + nfull].reshape(-1, 64, il)
-                    ents_b[lo:lo + nfull] = v.transpose(0, 2, 1).reshape(-1)
         dev = A.device
         # 8-bit scatter offsets of every (entity, local row, local col), built on the device
         import torch
@@ -135,7 +125,7 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0):
         rc = L.mpcx_scatter_offsets(A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), integ.estride, integ.num_entities,
                                     idv["entities"].data_ptr(), idv["entities"].data_ptr(), s0["dofmap"].data_ptr(),
                                     V0.element_ndofs, V0.dofmap.bs, s1["dofmap"].data_ptr(), V1.element_ndofs,
-                                    V1.dofmap.bs, offs.data_ptr(), flag.data_ptr(), D.stream_ptr())
+                                    V1.dofmap.bs, int(lean), offs.data_ptr(), flag.data_ptr(), D.stream_ptr())
         _native.check(rc, "mpcx_scatter_offsets")
         if int(flag.item()) != 0:
             raise RuntimeError("row-block algorithm: a CSR row holds more than 255 column blocks before one of the "
@@ -163,21 +153,22 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0):
     return A._plans[key]
 
 
-def _masked_dofmap(form: Form, V, bc_dev, mpc, which: int):
+def _masked_dofmap(form: Form, V, bc_dev, mpc, which: int, rotate: bool = False):
     """dofmap with the Dirichlet/slave mask folded into bits 28.. (device, cached
     per (space, bcs, constraint)): replaces the marker gathers of
     cpp/assemble_matrix.cpp:511-533 and the is_slave look-ups in the bulk kernel."""
     import torch
 
-    key = ("mdof", which, id(V), id(mpc), None if bc_dev is None else bc_dev.data_ptr())
+    key = ("mdof", which, id(V), id(mpc), None if bc_dev is None else bc_dev.data_ptr(), rotate)
     if key not in form._device:
         if V.num_dofs // V.dofmap.bs >= (1 << 28):
             raise RuntimeError("row-block algorithm: more than 2^28 dof blocks per GPU; shard the mesh")
         sd = D.space_device(V)
         _, t = mpc._device()
         out = torch.empty_like(sd["dofmap"])
-        rc = _native.lib().mpcx_mask_dofmap(sd["dofmap"].data_ptr(), sd["dofmap"].numel(), V.dofmap.bs, D.ptr(bc_dev),
-                                            t["is_slave"].data_ptr(), out.data_ptr(), D.stream_ptr())
+        rc = _native.lib().mpcx_mask_dofmap(sd["dofmap"].data_ptr(), sd["dofmap"].shape[0], sd["dofmap"].shape[1],
+                                            V.dofmap.bs, D.ptr(bc_dev), t["is_slave"].data_ptr(), int(rotate),
+                                            out.data_ptr(), D.stream_ptr())
         _native.check(rc, "mpcx_mask_dofmap")
         form._device[key] = out
     return form._device[key]
@@ -217,10 +208,15 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
     a.stream = D.stream_ptr()
     keep = [md, s0, s1, bc0, bc1, k0, k1, idv, slave_ents]
     if alg == 2:
-        plan, pk, _info = _rowblock_plan(A, form, i, V0)
+        # lean path (include/mpcx.h, mpcx_matrix_args_t::lean): square P1-type form over all cells
+        same = V1 is V0 and mpc1 is mpc0 and bc1 is bc0
+        lean = (same and s0["dofmap"] is md["x_dofmap"] and idv["entities_ptr"] is None and integ.estride == 1
+                and integ.coeffs is None and not os.environ.get("MPCX_NO_LEAN"))
+        plan, pk, _info = _rowblock_plan(A, form, i, V0, lean)
         a.plan = plan
-        md0 = _masked_dofmap(form, V0, bc0, mpc0, 0)
-        md1 = md0 if (V1 is V0 and mpc1 is mpc0 and bc1 is bc0) else _masked_dofmap(form, V1, bc1, mpc1, 1)
+        a.lean = int(lean)
+        md0 = _masked_dofmap(form, V0, bc0, mpc0, 0, lean)
+        md1 = md0 if same else _masked_dofmap(form, V1, bc1, mpc1, 1)
         a.mdofmap0, a.mdofmap1 = md0.data_ptr(), md1.data_ptr()
         keep += [pk, md0, md1]
     return a, keep

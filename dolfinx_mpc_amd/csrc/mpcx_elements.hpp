@@ -396,6 +396,72 @@ struct ElementOp
     affine_geometry<TDIM>(cd, K, detJ);
     const double adet = fabs(detJ);
     const double c0 = (c && FORM != MPCX_FORM_ELASTICITY) ? c[0] : 1.0;
+    // P1 source term over cells without a coefficient: affine map x = x0 + J X (TDIM fma per
+    // coordinate) and moment sums S = sum f w, S_d = sum f w X_d, from which the four basis
+    // integrals follow (l_0 = 1 - sum X_d): ~7 fp64 instructions less per quadrature point
+    // than the generic loop below
+    if constexpr (FORM == MPCX_FORM_SOURCE && DEG0_ == 1)
+    {
+      if (k.coeff_degree == 0)
+      {
+        double J[3][TDIM];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int d = 0; d < TDIM; ++d)
+            J[r][d] = cd[3 * (d + 1) + r] - cd[r];
+        const double sd = c0 * adet;
+        double S[BS0], SX[BS0][TDIM];
+#pragma unroll
+        for (int b = 0; b < BS0; ++b)
+        {
+          S[b] = 0.0;
+#pragma unroll
+          for (int d = 0; d < TDIM; ++d)
+            SX[b][d] = 0.0;
+        }
+        for (int q = 0; q < k.nq; ++q)
+        {
+          double X[TDIM], x[3];
+#pragma unroll
+          for (int d = 0; d < TDIM; ++d)
+            X[d] = k.qpts[q * TDIM + d];
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+          {
+            double v = cd[r];
+#pragma unroll
+            for (int d = 0; d < TDIM; ++d)
+              v = fma(J[r][d], X[d], v);
+            x[r] = v;
+          }
+          const double wq = k.qwts[q] * sd;
+#pragma unroll
+          for (int b = 0; b < BS0; ++b)
+          {
+            const double f = wq * eval_fn(FN_ >= 0 ? FN_ : k.fn_id, x, b, c);
+            S[b] += f;
+#pragma unroll
+            for (int d = 0; d < TDIM; ++d)
+              SX[b][d] = fma(f, X[d], SX[b][d]);
+          }
+        }
+#pragma unroll
+        for (int b = 0; b < BS0; ++b)
+        {
+          double s0 = S[b];
+#pragma unroll
+          for (int d = 0; d < TDIM; ++d)
+          {
+            s0 -= SX[b][d];
+            A[(d + 1) * BS0 + b] = SX[b][d];
+          }
+          A[b] = s0;
+        }
+        return;
+      }
+    }
+
     QuadPoint<TDIM, FACET> qp;
     qp.init_facet(cd, lf);
     const int nq = FACET ? k.nqf : k.nq;

@@ -460,12 +460,18 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
       a.vals[nnz0 + i] += s_vals[i];
 }
 
+// Per-cell rotation of the local (vertex) numbering used by the lean row-block path: cell c lists
+// its local dofs in the order (i + c mod nd) mod nd.  Neighbouring cells (the lanes of one wave)
+// that share a matrix entry then reach it at different instructions, which removes most
+// same-address LDS atomic conflicts (e.g. the 6 tets round a cube diagonal: 6-way -> 2-way).
+__host__ __device__ inline int rotated_local(int i, int64_t cell, int nd) { return int((i + cell % nd) % nd); }
+
 // scatter-offset table (set-up kernel, one thread per (entity, local row block))
 __global__ void scatter_offsets_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
                                        int estride, int64_t n_entities, const int32_t* __restrict__ entities0,
                                        const int32_t* __restrict__ entities1, const int32_t* __restrict__ dofmap0,
                                        int nd0, int bs0, const int32_t* __restrict__ dofmap1, int nd1, int bs1,
-                                       uint8_t* __restrict__ out, int32_t* overflow)
+                                       int rotate, uint8_t* __restrict__ out, int32_t* overflow)
 {
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= n_entities * nd0)
@@ -473,11 +479,11 @@ __global__ void scatter_offsets_kernel(const int32_t* __restrict__ rowptr, const
   const int64_t e = t / nd0;
   const int i = int(t - e * nd0);
   const int64_t cell0 = entities0[e * estride], cell1 = entities1[e * estride];
-  const int r = dofmap0[cell0 * nd0 + i] * bs0;
+  const int r = dofmap0[cell0 * nd0 + (rotate ? rotated_local(i, cell0, nd0) : i)] * bs0;
   const int lo = rowptr[r], hi = rowptr[r + 1];
   for (int j = 0; j < nd1; ++j)
   {
-    const int c = dofmap1[cell1 * nd1 + j] * bs1;
+    const int c = dofmap1[cell1 * nd1 + (rotate ? rotated_local(j, cell1, nd1) : j)] * bs1;
     const int pos = csr_find(cols, lo, hi, c);
     const int o = pos < 0 ? 256 : (pos - lo) / bs1;
     if (o > 255)
@@ -487,14 +493,20 @@ __global__ void scatter_offsets_kernel(const int32_t* __restrict__ rowptr, const
 }
 
 // dofmap with the mask folded in (set-up kernel, one thread per dofmap entry)
-__global__ void mask_dofmap_kernel(const int32_t* __restrict__ dofmap, int64_t n, int bs,
-                                   const int8_t* __restrict__ bc, const int8_t* __restrict__ is_slave,
+__global__ void mask_dofmap_kernel(const int32_t* __restrict__ dofmap, int64_t n, int nd, int bs,
+                                   const int8_t* __restrict__ bc, const int8_t* __restrict__ is_slave, int rotate,
                                    int32_t* __restrict__ out)
 {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n)
     return;
-  const int32_t d = dofmap[i];
+  int64_t src = i;
+  if (rotate)
+  {
+    const int64_t cell = i / nd;
+    src = cell * nd + rotated_local(int(i - cell * nd), cell, nd);
+  }
+  const int32_t d = dofmap[src];
   int32_t m = d;
   for (int k = 0; k < bs; ++k)
   {
@@ -548,7 +560,7 @@ __global__ void __launch_bounds__(VectorCfg<Op::N0>::NT) vector_kernel(mpcx_vect
     s_key[i] = -1;
     s_val[i] = 0.0;
   }
-  __syncthreads();
+  fastmath_init_lds(); // table of the analytic right-hand sides; ends in the barrier the hash needs too
   const int64_t e = int64_t(blockIdx.x) * NT + threadIdx.x;
   if (e < a.n_entities)
   {
@@ -738,7 +750,9 @@ int launch_matrix(const mpcx_matrix_args_t& a)
         mpcx_set_error("mpcx_assemble_matrix: row-block plan lacks the scatter-offset table (mpcx_scatter_offsets)");
         return -5;
       }
-      const size_t lds = size_t(a.plan.max_nnz) * 8 + size_t(a.plan.max_rows) * 4;
+      size_t lds = size_t(a.plan.max_nnz) * 8 + size_t(a.plan.max_rows) * 4;
+      if (const char* e = std::getenv("MPCX_ROWBLOCK_MIN_LDS")) // experiment: cap workgroups per CU
+        lds = std::max(lds, size_t(std::atoi(e)));
       if (lds > 160 * 1024)
       {
         mpcx_set_error("mpcx_assemble_matrix: row-block plan exceeds 160 KiB of LDS");
@@ -761,10 +775,20 @@ int launch_matrix(const mpcx_matrix_args_t& a)
         return 0;
       };
       constexpr bool CAN_LEAN = Op::SQUARE && !Op::FACET && Op::NV == Op::ND0;
-      bool lean = false;
-      if constexpr (CAN_LEAN)
-        lean = a.estride == 1 && !a.entities && !a.entities0 && !a.entities1 && a.mdofmap1 == a.mdofmap0
-               && a.x_dofmap == a.dofmap0 && !std::getenv("MPCX_NO_LEAN");
+      const bool lean = a.lean != 0;
+      if (lean)
+      {
+        bool ok = false;
+        if constexpr (CAN_LEAN)
+          ok = a.estride == 1 && !a.entities && !a.entities0 && !a.entities1 && a.mdofmap1 == a.mdofmap0
+               && a.x_dofmap == a.dofmap0 && !a.coeffs;
+        if (!ok)
+        {
+          mpcx_set_error("mpcx_assemble_matrix: lean row-block path needs a square P1-type form over all cells "
+                         "without coefficients, dofmap0 == x_dofmap and mdofmap1 == mdofmap0");
+          return -8;
+        }
+      }
       int rc = 0;
       if constexpr (CAN_LEAN)
         rc = lean ? launch(matrix_rowblock_kernel<Op, true>) : launch(matrix_rowblock_kernel<Op, false>);
@@ -995,9 +1019,11 @@ extern "C" int mpcx_homogenize(double* u, const int32_t* slaves, int64_t num_sla
   return check(hipGetLastError(), "homogenize launch");
 }
 
-extern "C" int mpcx_mask_dofmap(const int32_t* dofmap, int64_t n, int32_t bs, const int8_t* bc,
-                                const int8_t* is_slave, int32_t* out, void* stream)
+extern "C" int mpcx_mask_dofmap(const int32_t* dofmap, int64_t num_cells, int32_t nd, int32_t bs,
+                                const int8_t* bc, const int8_t* is_slave, int32_t rotate, int32_t* out,
+                                void* stream)
 {
+  const int64_t n = num_cells * nd;
   if (n == 0)
     return 0;
   if (bs > 3)
@@ -1006,7 +1032,7 @@ extern "C" int mpcx_mask_dofmap(const int32_t* dofmap, int64_t n, int32_t bs, co
     return -6;
   }
   hipLaunchKernelGGL(mask_dofmap_kernel, dim3(grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     dofmap, n, bs, bc, is_slave, out);
+                     dofmap, n, nd, bs, bc, is_slave, rotate, out);
   return check(hipGetLastError(), "mask_dofmap launch");
 }
 
@@ -1014,13 +1040,13 @@ extern "C" int mpcx_scatter_offsets(const int32_t* rowptr, const int32_t* cols, 
                                     int64_t n_entities, const int32_t* entities0,
                                     const int32_t* entities1, const int32_t* dofmap0, int32_t nd0,
                                     int32_t bs0, const int32_t* dofmap1, int32_t nd1, int32_t bs1,
-                                    uint8_t* ent_offs, int32_t* overflow, void* stream)
+                                    int32_t rotate, uint8_t* ent_offs, int32_t* overflow, void* stream)
 {
   if (n_entities == 0)
     return 0;
   hipLaunchKernelGGL(scatter_offsets_kernel, dim3(grid_for(n_entities * nd0, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), rowptr, cols, estride, n_entities, entities0, entities1,
-                     dofmap0, nd0, bs0, dofmap1, nd1, bs1, ent_offs, overflow);
+                     dofmap0, nd0, bs0, dofmap1, nd1, bs1, rotate, ent_offs, overflow);
   return check(hipGetLastError(), "scatter_offsets launch");
 }
 

@@ -148,26 +148,34 @@ typedef struct
    * folded into bit 28+k of each blocked dof: no marker gathers in the kernel */
   const int32_t* mdofmap0; /* DEVICE [num_cells][nd0] */
   const int32_t* mdofmap1; /* DEVICE [num_cells][nd1] */
+  /* rowblock, lean path (P1-type square forms over all cells, no coefficients): the caller
+   * guarantees dofmap0 == x_dofmap (ONE device array: dofs numbered like the mesh nodes),
+   * mdofmap1 == mdofmap0, entities == NULL, and built mdofmap0 and plan.ent_offs with
+   * rotate = 1; the kernel then reads only mdofmap0 + ent_offs per entity and takes the
+   * geometry nodes from mdofmap0.  Checked; violating calls are rejected. */
+  int32_t lean;
   void* stream;
 } mpcx_matrix_args_t;
 
 int mpcx_assemble_matrix(const mpcx_matrix_args_t* args);
 
-/* Set-up for MPCX_ALG_ROWBLOCK: out[i] = dofmap[i] | (masked(dof, k) << (28 + k)),
- * masked = Dirichlet-marked (bc may be NULL) or slave.  All pointers DEVICE,
- * n = num_cells * nd, dof blocks must be < 2^28, bs <= 3. */
-int mpcx_mask_dofmap(const int32_t* dofmap, int64_t n, int32_t bs, const int8_t* bc,
-                     const int8_t* is_slave, int32_t* out, void* stream);
+/* Set-up for MPCX_ALG_ROWBLOCK: out[c][i] = d | (masked(d, k) << (28 + k)) with d = dofmap[c][i],
+ * masked = Dirichlet-marked (bc may be NULL) or slave.  All pointers DEVICE, dof blocks must be
+ * < 2^28, bs <= 3.  rotate != 0 (lean path, see mpcx_matrix_args_t::lean): cell c lists its local
+ * dofs in the rotated order d = dofmap[c][(i + c mod nd) mod nd]. */
+int mpcx_mask_dofmap(const int32_t* dofmap, int64_t num_cells, int32_t nd, int32_t bs, const int8_t* bc,
+                     const int8_t* is_slave, int32_t rotate, int32_t* out, void* stream);
 
 /* Set-up for MPCX_ALG_ROWBLOCK: the uint8 scatter-offset table described at
  * mpcx_rowblock_plan_t::ent_offs.  All pointers DEVICE.  *overflow (DEVICE int32,
  * zeroed by the caller) is set non-zero if an offset does not fit in 8 bits or
- * a column is missing from the pattern. */
+ * a column is missing from the pattern.  rotate != 0: local rows and columns of the cell c an
+ * entity lies in are listed in the rotated order of mpcx_mask_dofmap. */
 int mpcx_scatter_offsets(const int32_t* rowptr, const int32_t* cols, int32_t estride,
                          int64_t n_entities, const int32_t* entities0,
                          const int32_t* entities1, const int32_t* dofmap0, int32_t nd0,
                          int32_t bs0, const int32_t* dofmap1, int32_t nd1, int32_t bs1,
-                         uint8_t* ent_offs, int32_t* overflow, void* stream);
+                         int32_t rotate, uint8_t* ent_offs, int32_t* overflow, void* stream);
 
 /* vals[pos(d,d)] += diagval for d in dofs.  Replaces the slave-diagonal loop
  * of cpp/assemble_matrix.cpp:711-724 and dolfinx insert_diagonal called at
