@@ -116,6 +116,11 @@ class VectorArgs(C.Structure):
         ("nd", C.c_int32),
         ("bs", C.c_int32),
         ("mpc", MpcT),
+        ("algorithm", C.c_int32),
+        ("plan", RowBlockPlanT),
+        ("mdofmap", C.c_void_p),
+        ("slave_entities", C.c_void_p),
+        ("n_slave_entities", C.c_int64),
         ("stream", C.c_void_p),
     ]
 

@@ -4,6 +4,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import numpy as np
@@ -15,11 +16,58 @@ from .la import Vector, create_vector
 from .multipointconstraint import MultiPointConstraint
 
 
+_ALG = {"auto": 0, "atomic": 1, "rowblock": 2}
+# rows of b one workgroup owns in LDS (8 B each); the entity lists follow the matrix plan's shape
+VECTOR_BLOCK_ROWS = int(os.environ.get("MPCX_VECTOR_BLOCK_ROWS", 512))
+
+
+def _vector_plan(form: Form, i: int, V):
+    """Row blocks of b and the entities touching each (mpcx_rowblock_plan_build on a
+    one-entry-per-row pattern), cached per integral."""
+    key = ("vplan", i, VECTOR_BLOCK_ROWS)
+    if key not in form._device:
+        L = _native.lib()
+        p = _native._ptr
+        integ = form.integrals[i]
+        ents = np.ascontiguousarray(integ.entities.astype(np.int32).reshape(-1))
+        dm = V.dofmap.list
+        nrows = V.num_dofs
+        rowptr = np.arange(nrows + 1, dtype=np.int32)
+        hints = None
+        if V.degree == 1 and form.mesh.node_tile_offsets is not None:
+            hints = np.ascontiguousarray(form.mesh.node_tile_offsets.astype(np.int32) * V.dofmap.bs)
+        h = L.mpcx_rowblock_plan_build(nrows, p(rowptr), VECTOR_BLOCK_ROWS, VECTOR_BLOCK_ROWS, integ.num_entities,
+                                       integ.estride, p(ents), p(dm), dm.shape[1], V.dofmap.bs,
+                                       None if hints is None else p(hints), 0 if hints is None else hints.size, 1)
+        if not h:
+            raise RuntimeError("mpcx_rowblock_plan_build failed: " + L.mpcx_last_error().decode())
+        try:
+            nb = L.mpcx_rowblock_plan_num_blocks(h)
+            row0 = np.empty(nb + 1, dtype=np.int32)
+            off = np.empty(nb + 1, dtype=np.int64)
+            ents_b = np.empty(L.mpcx_rowblock_plan_num_ents(h), dtype=np.int32)
+            L.mpcx_rowblock_plan_copy(h, p(row0), p(off), p(ents_b))
+        finally:
+            L.mpcx_rowblock_plan_free(h)
+        dev = _native.require_gpu()
+        t = (D._to_dev(row0, dev), D._to_dev(off, dev), D._to_dev(ents_b, dev))
+        max_rows = int(np.diff(row0).max()) if nb > 0 else 0
+        plan = _native.RowBlockPlanT(nb, max_rows, max_rows, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
+                                     None, None)
+        form._device[key] = (plan, t)
+    return form._device[key]
+
+
 def assemble_vector(form: Form, constraint: MultiPointConstraint, b: Optional[Vector] = None,
-                    num_threads: Optional[int] = 1) -> Vector:
+                    num_threads: Optional[int] = 1, algorithm: Optional[str] = None) -> Vector:
     """Assemble a linear form into ``b`` with the multi point constraint applied
     (python/src/dolfinx_mpc/assemble_vector.py:79-104): ``b`` is created on the
-    MPC function space if None, zeroed, then accumulated into."""
+    MPC function space if None, zeroed, then accumulated into.
+
+    ``algorithm``: "atomic" (LDS hash per workgroup + one device atomic per distinct dof),
+    "rowblock" (LDS row blocks, no device atomics: faster for cheap integrands, slower when
+    the quadrature dominates because entities on block borders are evaluated once per block)
+    or "auto" (default: row blocks for rules of <= 4 points); env MPCX_VECTOR_ALG."""
     if form.rank != 1:
         raise RuntimeError("assemble_vector needs a linear form")
     constraint._not_finalized()
@@ -29,6 +77,7 @@ def assemble_vector(form: Form, constraint: MultiPointConstraint, b: Optional[Ve
     if b is None:
         b = create_vector(constraint.function_space)
     b.set(0.0)
+    alg = _ALG[(algorithm or os.environ.get("MPCX_VECTOR_ALG", "auto")).lower()]
     md = D.mesh_device(form.mesh)
     sd = D.space_device(V)
     m, _keep = constraint._device()
@@ -47,8 +96,24 @@ def assemble_vector(form: Form, constraint: MultiPointConstraint, b: Optional[Ve
         a.constants = D.ptr(idv["constants"])
         a.dofmap, a.nd, a.bs = sd["dofmap"].data_ptr(), V.element_ndofs, V.dofmap.bs
         a.mpc = m
+        a.algorithm = 1
+        keep = []
+        # auto: row blocks for cheap integrands (few quadrature points), the hash kernel otherwise
+        nq = integ.kernel.qwts.size if integ.itype == "cell" else integ.kernel.fqwts.size
+        if (alg == 2 or (alg == 0 and nq <= 4)) and integ.num_entities > 0:
+            from .assemble_matrix import _masked_dofmap, _slave_entities
+
+            plan, pk = _vector_plan(form, i, V)
+            md0 = _masked_dofmap(form, V, None, constraint, 0)  # slave flag only: bcs do not touch b here
+            _, slave_ents = _slave_entities(form, i, constraint, constraint)
+            a.algorithm = 2
+            a.plan = plan
+            a.mdofmap = md0.data_ptr()
+            a.slave_entities, a.n_slave_entities = slave_ents.data_ptr(), slave_ents.numel()
+            keep = [pk, md0, slave_ents]
         a.stream = D.stream_ptr()
         _native.check(L.mpcx_assemble_vector(C.byref(a)), "mpcx_assemble_vector")
+        del keep
     return b
 
 

@@ -420,6 +420,9 @@ struct ElementOp
           for (int d = 0; d < TDIM; ++d)
             SX[b][d] = 0.0;
         }
+        // two points per trip: the scalar loads of the rule and the LDS table read of fast_exp
+        // of one point overlap with the arithmetic of the other
+#pragma unroll 2
         for (int q = 0; q < k.nq; ++q)
         {
           double X[TDIM], x[3];

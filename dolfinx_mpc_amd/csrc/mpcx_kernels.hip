@@ -617,6 +617,164 @@ __global__ void __launch_bounds__(VectorCfg<Op::N0>::NT) vector_kernel(mpcx_vect
 }
 
 // ---------------------------------------------------------------------------
+// Row-block vector kernel: the vector counterpart of matrix_rowblock_kernel.  A workgroup owns
+// the rows [block_row0[b], block_row0[b+1]) of b in LDS, walks the entities touching them
+// (entities on block borders are evaluated by every block they touch), adds the rows it owns
+// with ds_add_f64 and adds the finished range to b once, coalesced -- no device atomics (the
+// hash kernel above needs ~0.8 device atomics per cell, ~30 G/s at the memory side: 2.9 ms of
+// its 3.7 ms at 256^3 do not depend on the quadrature; its arithmetic hides underneath).  Here
+// the arithmetic is exposed and entities on block borders are evaluated once per block
+// (x1.375): 2.0 ms + 0.22 ms per quadrature point at 256^3, i.e. faster for cheap integrands
+// (<= 4 points), slower for the 14-point benchmark right-hand side -- "auto" picks by that.
+// Measured and rejected: listing every entity once (owner block) and sending foreign rows with
+// device atomics (2.8 ms + 0.11 ms/point), and longer entity runs per hash table (the loop form
+// costs the hash kernel its overlap: 5.2 ms).  Rows of slave dofs are skipped here (flag in
+// the masked dofmap) and handled by vector_mpc_kernel.
+// ---------------------------------------------------------------------------
+template <class Op>
+__global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) vector_rowblock_kernel(mpcx_vector_args_t a)
+{
+  constexpr int N = Op::N0, ND = Op::ND0, BS = Op::BS0, NV = Op::NV;
+  const int NT = blockDim.x;
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* s_b = reinterpret_cast<double*>(smem); // [max_rows]
+  const int nb = a.plan.num_blocks;
+  const int per = (nb + 7) >> 3;
+  const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3); // contiguous runs of blocks per XCD
+  const int tid = threadIdx.x;
+  const int r0 = b < nb ? a.plan.block_row0[b] : 0, r1 = b < nb ? a.plan.block_row0[b + 1] : 0;
+  for (int i = tid; i < r1 - r0; i += NT)
+    s_b[i] = 0.0;
+  fastmath_init_lds(); // ends in a barrier
+  if (b >= nb)
+    return;
+
+  struct Ent
+  {
+    int32_t e;
+    int lf;
+    int32_t xd[NV];
+    int32_t m[ND];
+  };
+  // P1 on an affine mesh: dofmap and geometry dofmap are one device array -> one read
+  bool alias = false;
+  if constexpr (NV == ND)
+    alias = (a.x_dofmap == a.dofmap) && (a.entities0 == a.entities);
+  auto load_ent = [&](int64_t e, Ent& E)
+  {
+    const int64_t l = e * a.estride;
+    const int64_t cell = (a.entities ? a.entities[l] : e);
+    const int64_t cell0 = (a.entities0 ? a.entities0[l] : e);
+    E.e = int32_t(e);
+    E.lf = a.estride == 2 ? a.entities[l + 1] : 0;
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+      E.m[i] = a.mdofmap[cell0 * ND + i];
+    if (alias)
+    {
+      if constexpr (NV == ND)
+      {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+          E.xd[i] = E.m[i] & MPCX_DOF_MASK;
+      }
+    }
+    else
+    {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        E.xd[i] = a.x_dofmap[cell * NV + i];
+    }
+  };
+
+  const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  const int32_t* __restrict__ ents = a.plan.block_ents;
+  int64_t t = e0 + tid;
+  // same software pipeline as the matrix kernel: index data one entity ahead, entity index two
+  Ent cur;
+  int32_t i1 = 0;
+  if (t < e1)
+    load_ent(ents[t], cur);
+  if (t + NT < e1)
+    i1 = ents[t + NT];
+  for (; t < e1; t += NT)
+  {
+    double cd[NV * 3];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+    {
+      const int64_t v = cur.xd[i];
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        cd[3 * i + k] = a.x[3 * v + k];
+    }
+    Ent nxt = cur;
+    if (t + NT < e1)
+      load_ent(i1, nxt);
+    if (t + 2 * NT < e1)
+      i1 = ents[t + 2 * NT];
+    double be[N];
+    Op::tabulate(be, a.coeffs ? a.coeffs + int64_t(cur.e) * a.cstride : nullptr, a.constants, cd, cur.lf, a.kernel);
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+    {
+#pragma unroll
+      for (int k = 0; k < BS; ++k)
+      {
+        const int r = (cur.m[i] & MPCX_DOF_MASK) * BS + k;
+        if ((cur.m[i] >> (MPCX_MASK_SHIFT + k)) & 1)
+          continue;
+        if (r >= r0 && r < r1)
+          __hip_atomic_fetch_add(s_b + (r - r0), be[i * BS + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    cur = nxt;
+  }
+  __syncthreads();
+  for (int i = tid; i < r1 - r0; i += NT)
+    a.b[r0 + i] += s_b[i];
+}
+
+// Slave rows of the entities that have any (modify_mpc_vec, cpp/assemble_vector.h:35-69):
+// b[master] += coeff * be[slave]; a slave without masters keeps its own row.
+template <class Op>
+__global__ void __launch_bounds__(64) vector_mpc_kernel(mpcx_vector_args_t a)
+{
+  constexpr int N = Op::N0, ND = Op::ND0, BS = Op::BS0, NV = Op::NV;
+  fastmath_init_lds();
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= a.n_slave_entities)
+    return;
+  const int64_t e = a.slave_entities[t];
+  const int64_t l = e * a.estride;
+  const int64_t cell = (a.entities ? a.entities[l] : e);
+  const int64_t cell0 = (a.entities0 ? a.entities0[l] : e);
+  const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
+  double cd[NV * 3];
+  gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
+  double be[N];
+  Op::tabulate(be, a.coeffs ? a.coeffs + e * a.cstride : nullptr, a.constants, cd, lf, a.kernel);
+#pragma unroll
+  for (int i = 0; i < ND; ++i)
+  {
+    const int32_t d0 = a.dofmap[cell0 * ND + i];
+#pragma unroll
+    for (int k = 0; k < BS; ++k)
+    {
+      const int32_t d = d0 * BS + k;
+      if (!a.mpc.is_slave[d])
+        continue;
+      const double v = be[i * BS + k];
+      const int m0 = a.mpc.masters_offsets[d], m1 = a.mpc.masters_offsets[d + 1];
+      for (int mi = m0; mi < m1; ++mi)
+        atomic_add_f64(a.b + a.mpc.masters[mi], a.mpc.coeffs[mi] * v);
+      if (m1 == m0)
+        atomic_add_f64(a.b + d, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Lifting kernel: cpp/lifting.h:77-133 over the compact list of entities that
 // have a bc-marked column dof; Ae is the raw kernel output (:267-272).
 // ---------------------------------------------------------------------------
@@ -750,9 +908,7 @@ int launch_matrix(const mpcx_matrix_args_t& a)
         mpcx_set_error("mpcx_assemble_matrix: row-block plan lacks the scatter-offset table (mpcx_scatter_offsets)");
         return -5;
       }
-      size_t lds = size_t(a.plan.max_nnz) * 8 + size_t(a.plan.max_rows) * 4;
-      if (const char* e = std::getenv("MPCX_ROWBLOCK_MIN_LDS")) // experiment: cap workgroups per CU
-        lds = std::max(lds, size_t(std::atoi(e)));
+      const size_t lds = size_t(a.plan.max_nnz) * 8 + size_t(a.plan.max_rows) * 4;
       if (lds > 160 * 1024)
       {
         mpcx_set_error("mpcx_assemble_matrix: row-block plan exceeds 160 KiB of LDS");
@@ -823,9 +979,40 @@ int launch_vector(const mpcx_vector_args_t& a)
   }
   if (a.n_entities == 0)
     return 0;
+  hipStream_t stream = static_cast<hipStream_t>(a.stream);
+  int alg = a.algorithm;
+  if (alg == MPCX_ALG_AUTO)
+    alg = a.plan.num_blocks > 0 ? MPCX_ALG_ROWBLOCK : MPCX_ALG_ATOMIC;
+  if (alg == MPCX_ALG_ROWBLOCK)
+  {
+    if (a.plan.num_blocks <= 0 || !a.mdofmap)
+    {
+      mpcx_set_error("mpcx_assemble_vector: row-block algorithm needs a plan and the slave-masked dofmap");
+      return -3;
+    }
+    const size_t lds = size_t(a.plan.max_rows) * 8;
+    if (lds > 96 * 1024)
+    {
+      mpcx_set_error("mpcx_assemble_vector: row-block plan exceeds the LDS budget");
+      return -4;
+    }
+    const unsigned grid = 8u * unsigned((a.plan.num_blocks + 7) / 8);
+    if (int rc = check(hipFuncSetAttribute(reinterpret_cast<const void*>(vector_rowblock_kernel<Op>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)),
+                       "hipFuncSetAttribute"))
+      return rc;
+    hipLaunchKernelGGL(vector_rowblock_kernel<Op>, dim3(grid), dim3(512), lds, stream, a);
+    if (int rc = check(hipGetLastError(), "vector row-block kernel launch"))
+      return rc;
+    if (a.n_slave_entities > 0)
+    {
+      hipLaunchKernelGGL(vector_mpc_kernel<Op>, dim3(grid_for(a.n_slave_entities, 64)), dim3(64), 0, stream, a);
+      return check(hipGetLastError(), "vector mpc kernel launch");
+    }
+    return 0;
+  }
   constexpr int NT = VectorCfg<Op::N0>::NT;
-  hipLaunchKernelGGL(vector_kernel<Op>, dim3(grid_for(a.n_entities, NT)), dim3(NT), 0,
-                     static_cast<hipStream_t>(a.stream), a);
+  hipLaunchKernelGGL(vector_kernel<Op>, dim3(grid_for(a.n_entities, NT)), dim3(NT), 0, stream, a);
   return check(hipGetLastError(), "vector kernel launch");
 }
 

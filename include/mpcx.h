@@ -201,6 +201,18 @@ typedef struct
   const double* coeffs; int32_t cstride; const double* constants;
   const int32_t* dofmap; int32_t nd; int32_t bs;
   mpcx_mpc_t mpc;
+  /* MPCX_ALG_ATOMIC: LDS hash per workgroup + one device atomic per distinct dof.
+   * MPCX_ALG_ROWBLOCK: a workgroup owns a contiguous range of rows of b in LDS (plan: row blocks
+   * and entity lists from mpcx_rowblock_plan_build, ent_offs unused) and adds it to b once,
+   * without atomics; rows of slave dofs are skipped there and a second kernel over
+   * `slave_entities` sends them to their masters (cpp/assemble_vector.h:35-69).
+   * MPCX_ALG_AUTO: rowblock if a plan is given (the caller decides: row blocks pay off for
+   * cheap integrands, see vector_rowblock_kernel). */
+  int32_t algorithm;
+  mpcx_rowblock_plan_t plan;
+  const int32_t* mdofmap;        /* DEVICE [num_cells][nd]: slave flag in bit 28+k (mpcx_mask_dofmap, bc = NULL) */
+  const int32_t* slave_entities; /* DEVICE entity indices whose cell holds a slave */
+  int64_t n_slave_entities;
   void* stream;
 } mpcx_vector_args_t;
 

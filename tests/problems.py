@@ -338,7 +338,7 @@ def product_outputs(case: Case, algorithm=None):
         A = dm.assemble_matrix(case.a, mpc, bcs=case.bcs, diagval=case.diagval, algorithm=algorithm)
         out["A"] = A.to_scipy()
     if case.L is not None:
-        b = dm.assemble_vector(case.L, mpc)
+        b = dm.assemble_vector(case.L, mpc, algorithm=algorithm)
         out["b"] = b.numpy().copy()
         if case.a is not None and case.bcs:
             x0 = None
