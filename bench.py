@@ -303,6 +303,20 @@ def main():
             "launch_ms": t_bulk,
         },
     }
+    # second kernel of the step, both bounds: compulsory bytes B_b over the assemble_vector
+    # time, and the fp64 arithmetic of the 14-point source loop (82 flop per point in the ISA:
+    # 35 fma/fmac, 9 mul, 3 add) against the fp64 vector peak
+    nq = int(L.integrals[0].kernel.qwts.size)
+    vec_bytes = 4 * nv * nc + 4 * nd * nc + 24 * mesh.num_nodes + 9 * V.num_dofs
+    out["roofline_vector"] = {
+        "kernel": "vector_kernel<P1 tet source, f of bench_periodic.py>",
+        "hbm": {"achieved": vec_bytes / (t_vec * 1e-3) / 1e9, "peak": peak, "unit": "GB/s",
+                "frac": vec_bytes / (t_vec * 1e-3) / 1e9 / peak, "algorithmic_bytes": int(vec_bytes)},
+        "fp64_valu": {"achieved": 82.0 * nq * nc / (t_vec * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                      "frac": 82.0 * nq * nc / (t_vec * 1e-3) / 1e12 / 78.6, "quadrature_points": nq},
+        "launch_ms": t_vec,
+        "note": "longer than the matrix kernel; neither bound is reached: see DESIGN.md section 5",
+    }
     if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
         log("timing the CPU baseline (oracle, 1 core) ...")
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n)
