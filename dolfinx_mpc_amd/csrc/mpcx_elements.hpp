@@ -201,7 +201,7 @@ __device__ inline double eval_fn(int fn_id, const double (&x)[3], int comp, cons
     // sin(5 pi y) = sinpi(5 y): exact range reduction, no pi rounding in the argument
     const double dx = x[0] - 0.9, dy = x[1] - 0.5, dz = x[2] - 0.1;
     // (1/0.02 rounds to 50.0: the product differs from the quotient by <= 1 ulp of the exponent)
-    return x[0] * fast_sinpi(5.0 * x[1]) + 1.0 * fast_exp(-(dx * dx + dy * dy + dz * dz) * (1.0 / 0.02));
+    return x[0] * fast_sinpi(5.0 * x[1]) + 1.0 * fast_exp_nonpos(-(dx * dx + dy * dy + dz * dz) * (1.0 / 0.02));
   }
   case 2:
     return fast_sinpi(2.0 * x[0]) * fast_sinpi(x[1]) + 0.3 * (comp + 1);

@@ -7,6 +7,7 @@
 // cell, which makes the vector kernel VALU-bound otherwise.
 #pragma once
 #include <cmath>
+#include <cstring>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -21,6 +22,25 @@
 
 namespace mpcx
 {
+
+// bit helpers (__builtin_memcpy compiles to register moves on host and device)
+MPCX_HD inline double flip_sign(double v, unsigned sign_in_bit31)
+{
+  unsigned long long u;
+  __builtin_memcpy(&u, &v, 8);
+  u ^= static_cast<unsigned long long>(sign_in_bit31 & 0x80000000u) << 32;
+  __builtin_memcpy(&v, &u, 8);
+  return v;
+}
+// v * 2^m for normal v and a normal result (|m| small enough): add m to the exponent field
+MPCX_HD inline double scale_pow2(double v, int m)
+{
+  long long u;
+  __builtin_memcpy(&u, &v, 8);
+  u += static_cast<long long>(m) << 52;
+  __builtin_memcpy(&v, &u, 8);
+  return v;
+}
 
 // sin(pi * t), |t| < 2^30.  r = t - rint(t) in [-1/2, 1/2] exactly, one odd
 // polynomial in r (Taylor coefficients (-1)^k pi^(2k+1)/(2k+1)!, truncation
@@ -44,7 +64,8 @@ MPCX_HD inline double fast_sinpi(double t)
   const double PI_HI = 0x1.921fb54442d18p+1, PI_LO = 1.2246467991473532e-16;
   const double tl = std::fma(r2, p, PI_LO);
   const double v = std::fma(r, PI_HI, r * tl);
-  return (static_cast<int>(n) & 1) ? -v : v;
+  // odd n: flip the sign bit (integer xor on the high word instead of a compare/select pair)
+  return flip_sign(v, static_cast<unsigned>(static_cast<int>(n)) << 31);
 }
 
 // 2^(j/64), j = 0..63, correctly rounded
@@ -111,6 +132,31 @@ MPCX_HD inline double fast_exp(double y)
   p = std::fma(p, r, 1.0);
   const double v = std::fma(T, p * r, T);
   return under ? 0.0 : std::ldexp(v, k >> 6);
+}
+
+// exp(y) for y <= 0 (Gaussians): one clamp, and 2^m goes into the exponent field of the table
+// value with an integer add.  Results below 2^-1021 (y < -707.7) are flushed to 0 instead of
+// going through the denormals; otherwise identical to fast_exp.
+MPCX_HD inline double fast_exp_nonpos(double y)
+{
+  const double INV = 0x1.71547652b82fep+6;
+  const double L_HI = 0x1.62e42fee00000p-7, L_LO = 0x1.a39ef35793c76p-39;
+  y = y < -708.0 ? -708.0 : y; // exp(-708) = 3.3e-308, still normal after the scaling below
+  const double n = std::rint(y * INV);
+  double r = std::fma(-n, L_HI, y);
+  r = std::fma(-n, L_LO, r);
+  const int k = static_cast<int>(n);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double T = scale_pow2(exp2_table_lds()[k & 63], k >> 6);
+#else
+  const double T = scale_pow2(EXP2_64[k & 63], k >> 6);
+#endif
+  double p = 1.0 / 120.0;
+  p = std::fma(p, r, 1.0 / 24.0);
+  p = std::fma(p, r, 1.0 / 6.0);
+  p = std::fma(p, r, 0.5);
+  p = std::fma(p, r, 1.0);
+  return std::fma(T, p * r, T);
 }
 
 } // namespace mpcx

@@ -23,7 +23,7 @@ int main(int argc, char** argv)
   for (int i = 0; i < n; ++i)
   {
     double t = lo + (hi - lo) * ((i + 0.37) / n);
-    double v = which == 0 ? mpcx::fast_sinpi(t) : mpcx::fast_exp(t);
+    double v = which == 0 ? mpcx::fast_sinpi(t) : (which == 1 ? mpcx::fast_exp(t) : mpcx::fast_exp_nonpos(t));
     printf("%.17g %.17g\n", t, v);
   }
   return 0;
@@ -74,3 +74,20 @@ def test_fast_exp(tmp_path):
     # deep underflow goes to zero, no NaN
     t3, v3 = _run(tmp_path, 1, -2000.0, -800.0, 50)
     assert np.all(v3 == 0.0)
+
+
+def test_fast_exp_nonpos(tmp_path):
+    """the Gaussian variant (y <= 0, exponent spliced into the table value): same accuracy down to
+    the flush threshold, exact 0-free tail, 1 at 0"""
+    t, v = _run(tmp_path, 2, -700.0, 0.0, 200001)
+    import mpmath
+
+    mpmath.mp.dps = 40
+    ref = np.array([float(mpmath.exp(mpmath.mpf(x))) for x in t[::97]])
+    rel = np.abs(v[::97] - ref) / ref
+    assert rel.max() < 2.0 * np.finfo(np.float64).eps, rel.max()
+    assert (np.abs(v - np.exp(t)) / np.exp(t)).max() < 4.5e-16
+    t2, v2 = _run(tmp_path, 2, -5000.0, -709.0, 40)
+    assert np.all((v2 >= 0.0) & (v2 < 1e-307))
+    t3, v3 = _run(tmp_path, 2, -1e-300, 0.0, 3)
+    assert np.all(v3 == 1.0)
