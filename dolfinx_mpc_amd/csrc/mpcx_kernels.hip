@@ -518,6 +518,114 @@ __global__ void mask_dofmap_kernel(const int32_t* __restrict__ dofmap, int64_t n
 }
 
 // ---------------------------------------------------------------------------
+// Sparsity pattern on the device (create_sparsity_pattern, cpp/utils.h:381-496; same result as
+// the host builder mpcx_pattern_build).  Three steps:
+//   1. row-block -> cells adjacency: every cell under each of its row blocks and under the
+//      master blocks of its row slaves (count, scan by the caller, fill);
+//   2. per row block: union of the column blocks of its cells (+ the master blocks of their
+//      column slaves), kept as a sorted duplicate-free list in LDS (one row per thread);
+//   3. the same walk again, writing the list expanded to the scalar CSR.
+// ---------------------------------------------------------------------------
+__global__ void pattern_adj_kernel(int64_t num_cells, const int32_t* __restrict__ dofmap0, int nd0, int bs0,
+                                   const int32_t* __restrict__ c2s_off, const int32_t* __restrict__ c2s,
+                                   const int32_t* __restrict__ m_off, const int32_t* __restrict__ masters,
+                                   const int64_t* __restrict__ adj_off, int32_t* __restrict__ counter,
+                                   int32_t* __restrict__ adj)
+{
+  const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (c >= num_cells)
+    return;
+  auto visit = [&](int32_t blk)
+  {
+    const int32_t k = atomicAdd(counter + blk, 1);
+    if (adj) // second pass: place the cell
+      adj[adj_off[blk] + k] = int32_t(c);
+  };
+  for (int i = 0; i < nd0; ++i)
+    visit(dofmap0[c * nd0 + i]);
+  for (int32_t p = c2s_off[c]; p < c2s_off[c + 1]; ++p)
+  {
+    const int32_t s = c2s[p];
+    for (int32_t q = m_off[s]; q < m_off[s + 1]; ++q)
+      visit(masters[q] / bs0);
+  }
+}
+
+constexpr int PATTERN_MAX_ROW = 128; // distinct column blocks per row block held in LDS
+constexpr int PATTERN_THREADS = 64;
+
+template <bool FILL>
+__global__ void __launch_bounds__(PATTERN_THREADS)
+pattern_rows_kernel(int32_t num_blocks0, const int64_t* __restrict__ adj_off, const int32_t* __restrict__ adj,
+                    const int32_t* __restrict__ dofmap1, int nd1, int bs1, const int32_t* __restrict__ c2s_off,
+                    const int32_t* __restrict__ c2s, const int32_t* __restrict__ m_off,
+                    const int32_t* __restrict__ masters, int32_t* __restrict__ row_count,
+                    const int32_t* __restrict__ rowptr, int bs0, int32_t* __restrict__ cols,
+                    int32_t* __restrict__ overflow)
+{
+  // list of thread t: s_list[k * PATTERN_THREADS + t] (bank-conflict-free across the wave)
+  __shared__ int32_t s_list[PATTERN_MAX_ROW * PATTERN_THREADS];
+  const int tid = threadIdx.x;
+  const int64_t r = int64_t(blockIdx.x) * PATTERN_THREADS + tid;
+  if (r >= num_blocks0)
+    return;
+  int n = 0;
+  bool over = false;
+  auto insert = [&](int32_t x)
+  {
+    int lo = 0, hi = n; // first position with list[pos] >= x
+    while (lo < hi)
+    {
+      const int mid = (lo + hi) >> 1;
+      if (s_list[mid * PATTERN_THREADS + tid] < x)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    if (lo < n && s_list[lo * PATTERN_THREADS + tid] == x)
+      return;
+    if (n == PATTERN_MAX_ROW)
+    {
+      over = true;
+      return;
+    }
+    for (int k = n; k > lo; --k)
+      s_list[k * PATTERN_THREADS + tid] = s_list[(k - 1) * PATTERN_THREADS + tid];
+    s_list[lo * PATTERN_THREADS + tid] = x;
+    ++n;
+  };
+  for (int64_t a = adj_off[r]; a < adj_off[r + 1]; ++a)
+  {
+    const int64_t c = adj[a];
+    for (int j = 0; j < nd1; ++j)
+      insert(dofmap1[c * nd1 + j]);
+    for (int32_t p = c2s_off[c]; p < c2s_off[c + 1]; ++p)
+    {
+      const int32_t s = c2s[p];
+      for (int32_t q = m_off[s]; q < m_off[s + 1]; ++q)
+        insert(masters[q] / bs1);
+    }
+  }
+  if (over)
+    atomicOr(overflow, 1);
+  if constexpr (!FILL)
+    row_count[r] = n;
+  else
+  {
+    for (int k = 0; k < bs0; ++k)
+    {
+      int32_t* dst = cols + rowptr[r * bs0 + k];
+      for (int j = 0; j < n; ++j)
+      {
+        const int32_t cb = s_list[j * PATTERN_THREADS + tid];
+        for (int l = 0; l < bs1; ++l)
+          dst[j * bs1 + l] = cb * bs1 + l;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 __global__ void add_diagonal_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
                                     double* vals, const int32_t* __restrict__ dofs, int64_t n, double diagval)
 {
@@ -1235,6 +1343,41 @@ extern "C" int mpcx_scatter_offsets(const int32_t* rowptr, const int32_t* cols, 
                      static_cast<hipStream_t>(stream), rowptr, cols, estride, n_entities, entities0, entities1,
                      dofmap0, nd0, bs0, dofmap1, nd1, bs1, rotate, ent_offs, overflow);
   return check(hipGetLastError(), "scatter_offsets launch");
+}
+
+extern "C" int mpcx_pattern_device_adjacency(int64_t num_cells, const int32_t* dofmap0, int32_t nd0, int32_t bs0,
+                                             const int32_t* c2s_offsets0, const int32_t* c2s0,
+                                             const int32_t* masters_offsets0, const int32_t* masters0,
+                                             const int64_t* adj_off, int32_t* counter, int32_t* adj, void* stream)
+{
+  if (num_cells == 0)
+    return 0;
+  hipLaunchKernelGGL(pattern_adj_kernel, dim3(grid_for(num_cells, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), num_cells, dofmap0, nd0, bs0, c2s_offsets0, c2s0,
+                     masters_offsets0, masters0, adj_off, counter, adj);
+  return check(hipGetLastError(), "pattern_adj launch");
+}
+
+extern "C" int mpcx_pattern_device_rows(int32_t num_blocks0, const int64_t* adj_off, const int32_t* adj,
+                                        const int32_t* dofmap1, int32_t nd1, int32_t bs1,
+                                        const int32_t* c2s_offsets1, const int32_t* c2s1,
+                                        const int32_t* masters_offsets1, const int32_t* masters1,
+                                        int32_t* row_count, const int32_t* rowptr, int32_t bs0, int32_t* cols,
+                                        int32_t* overflow, void* stream)
+{
+  if (num_blocks0 == 0)
+    return 0;
+  const dim3 grid(grid_for(num_blocks0, PATTERN_THREADS));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (cols)
+    hipLaunchKernelGGL(pattern_rows_kernel<true>, grid, dim3(PATTERN_THREADS), 0, st, num_blocks0, adj_off, adj,
+                       dofmap1, nd1, bs1, c2s_offsets1, c2s1, masters_offsets1, masters1, row_count, rowptr, bs0,
+                       cols, overflow);
+  else
+    hipLaunchKernelGGL(pattern_rows_kernel<false>, grid, dim3(PATTERN_THREADS), 0, st, num_blocks0, adj_off, adj,
+                       dofmap1, nd1, bs1, c2s_offsets1, c2s1, masters_offsets1, masters1, row_count, rowptr, bs0,
+                       cols, overflow);
+  return check(hipGetLastError(), "pattern_rows launch");
 }
 
 extern "C" int mpcx_device_count(void)

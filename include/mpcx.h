@@ -293,6 +293,28 @@ int32_t mpcx_pattern_nrows(void* pattern);
 int mpcx_pattern_copy(void* pattern, int32_t* rowptr, int32_t* cols);
 void mpcx_pattern_free(void* pattern);
 
+/* The same pattern built on the DEVICE (all pointers DEVICE).  Protocol:
+ *   1. mpcx_pattern_device_adjacency(adj = NULL, counter zeroed [num_blocks0]) counts the cells
+ *      under every row block (its cells + the cells whose row slaves have a master in it);
+ *   2. the caller scans counter into adj_off (int64 [num_blocks0 + 1]), zeroes counter, allocates
+ *      adj (int32 [adj_off[num_blocks0]]) and calls it again to place the cells;
+ *   3. mpcx_pattern_device_rows(cols = NULL) writes the number of distinct column blocks of
+ *      every row block to row_count; the caller expands it to the scalar rowptr
+ *      (row r*bs0+k holds row_count[r]*bs1 entries) and allocates cols;
+ *   4. mpcx_pattern_device_rows(cols != NULL) writes the sorted columns.
+ * *overflow (zeroed by the caller) is set if a row block has more than 128 distinct column
+ * blocks: use the host builder then. */
+int mpcx_pattern_device_adjacency(int64_t num_cells, const int32_t* dofmap0, int32_t nd0, int32_t bs0,
+                                  const int32_t* c2s_offsets0, const int32_t* c2s0,
+                                  const int32_t* masters_offsets0, const int32_t* masters0,
+                                  const int64_t* adj_off, int32_t* counter, int32_t* adj, void* stream);
+int mpcx_pattern_device_rows(int32_t num_blocks0, const int64_t* adj_off, const int32_t* adj,
+                             const int32_t* dofmap1, int32_t nd1, int32_t bs1,
+                             const int32_t* c2s_offsets1, const int32_t* c2s1,
+                             const int32_t* masters_offsets1, const int32_t* masters1,
+                             int32_t* row_count, const int32_t* rowptr, int32_t bs0, int32_t* cols,
+                             int32_t* overflow, void* stream);
+
 /* Row-block plan for MPCX_ALG_ROWBLOCK: contiguous row ranges with at most
  * max_rows rows / max_nnz nonzeros, and for each block the entities whose
  * test-space cell has a dof in it.  `row_hints` (sorted row indices, may be

@@ -70,6 +70,24 @@ def test_dictionary_compressed_plan(oracle, monkeypatch):
     _close(out["A"].data, ref["A"].data, RTOL_A, "A (dictionary plan)")
 
 
+@pytest.mark.parametrize("make", CASES + [lambda: case_cube_periodic(9, 2, 0.0), lambda: case_cube_periodic(20, 1, 0.0)],
+                         ids=[f"case{i}" for i in range(len(CASES) + 2)])
+def test_device_pattern_equals_host_pattern(make):
+    """create_sparsity_pattern(where="device") (mpcx_pattern_device_*) == the threaded host builder,
+    bit for bit."""
+    import dolfinx_mpc_amd as dm
+
+    case = make()
+    if case.a is None:
+        pytest.skip("no bilinear form")
+    mpc = product_mpc(case)
+    rp_h, cols_h = dm.create_sparsity_pattern(case.a, mpc, where="host")
+    rp_d, cols_d = dm.create_sparsity_pattern(case.a, mpc, where="device")
+    assert rp_d.dtype == np.int32 and cols_d.dtype == np.int32
+    assert np.array_equal(rp_h, rp_d)
+    assert np.array_equal(cols_h, cols_d)
+
+
 def test_repeated_assembly_into_same_matrix(oracle):
     """A given -> zeroed and re-assembled (python/src/dolfinx_mpc/assemble_matrix.py:49-51)."""
     import dolfinx_mpc_amd as dm

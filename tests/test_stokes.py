@@ -121,6 +121,12 @@ def _product_blocks(dim, n, alg):
     mpcs = [mv, mq]
     a = [[forms.get((i, j)) for j in range(2)] for i in range(2)]
     A = dm.create_matrix_nest(a, mpcs)
+    # rectangular blocks with two different constraints: device pattern == host pattern
+    for i in range(2):
+        for j in range(2):
+            if a[i][j] is not None:
+                rp, cols = dm.create_sparsity_pattern(a[i][j], (mpcs[i], mpcs[j]), where="device")
+                assert np.array_equal(rp, A[i][j].rowptr) and np.array_equal(cols, A[i][j].cols), (i, j)
     for i in range(2):
         for j in range(2):
             if a[i][j] is not None:
