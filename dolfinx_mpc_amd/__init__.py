@@ -22,6 +22,7 @@ from .assemble_vector import (
     set_bc,
 )
 from .multipointconstraint import MPCData, MultiPointConstraint
+from .problem import LinearProblem
 
 __all__ = [
     "assemble_matrix",
@@ -36,4 +37,5 @@ __all__ = [
     "create_sparsity_pattern",
     "create_matrix",
     "set_bc",
+    "LinearProblem",
 ]

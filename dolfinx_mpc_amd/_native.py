@@ -183,6 +183,10 @@ EXPORTS = [
     "mpcx_rowblock_plan_copy",
     "mpcx_rowblock_plan_free",
     "mpcx_compress_offsets",
+    "mpcx_spmv",
+    "mpcx_inverse_diagonal",
+    "mpcx_cg_start",
+    "mpcx_cg_step",
     "mpcx_last_error",
     "mpcx_version",
     "mpcx_device_count",
@@ -261,6 +265,14 @@ def lib() -> C.CDLL:
     L.mpcx_rowblock_plan_free.restype = None
     L.mpcx_compress_offsets.argtypes = [vp, i64, i32, i32, vp, vp]
     L.mpcx_compress_offsets.restype = i32
+    L.mpcx_spmv.argtypes = [i32, vp, vp, vp, vp, vp, vp]
+    L.mpcx_spmv.restype = C.c_int
+    L.mpcx_inverse_diagonal.argtypes = [i32, vp, vp, vp, vp, vp]
+    L.mpcx_inverse_diagonal.restype = C.c_int
+    L.mpcx_cg_start.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.mpcx_cg_start.restype = C.c_int
+    L.mpcx_cg_step.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]
+    L.mpcx_cg_step.restype = C.c_int
     L.mpcx_last_error.argtypes = []
     L.mpcx_last_error.restype = C.c_char_p
     L.mpcx_version.argtypes = []

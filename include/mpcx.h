@@ -337,6 +337,30 @@ void mpcx_rowblock_plan_free(void* plan);
 int32_t mpcx_compress_offsets(const uint8_t* rows, int64_t n, int32_t noff, int32_t max_patterns,
                               uint16_t* pattern_ids, uint8_t* table);
 
+/* ------------------------------------------------------------------------
+ * The caller of the assembly path on the device: what
+ * python/src/dolfinx_mpc/problem.py LinearProblem.solve does with PETSc KSP, for the assembled
+ * CSR matrix (symmetric positive definite after the MPC reduction: identity rows for slaves and
+ * Dirichlet dofs).  All pointers DEVICE.
+ *   mpcx_spmv:             y = A x
+ *   mpcx_inverse_diagonal: dinv[r] = 1 / A[r,r] (1 where the diagonal is absent or zero)
+ *   mpcx_cg_start:         x = 0, r = b, z = dinv r, p = z; scal[8] (device doubles) holds the
+ *                          running scalars: [0,1] r.z, [2,3] p.Ap, [4,5] r.r (ping-pong by
+ *                          iteration parity), [6] b.b
+ *   mpcx_cg_step(k):       iteration k = 0, 1, ...: Ap = A p (+ p.Ap), x += alpha p,
+ *                          r -= alpha Ap, z = dinv r (+ r.z, r.r), p = z + beta p; no host round
+ *                          trip; |r|^2 after the step is scal[4 + ((k + 1) & 1)]
+ * ---------------------------------------------------------------------- */
+int mpcx_spmv(int32_t nrows, const int32_t* rowptr, const int32_t* cols, const double* vals,
+              const double* x, double* y, void* stream);
+int mpcx_inverse_diagonal(int32_t nrows, const int32_t* rowptr, const int32_t* cols, const double* vals,
+                          double* dinv, void* stream);
+int mpcx_cg_start(int32_t n, const double* dinv, const double* b, double* x, double* r, double* z,
+                  double* p, double* scal, void* stream);
+int mpcx_cg_step(int32_t n, const int32_t* rowptr, const int32_t* cols, const double* vals,
+                 const double* dinv, double* x, double* r, double* z, double* p, double* Ap,
+                 double* scal, int32_t k, void* stream);
+
 /* misc */
 const char* mpcx_last_error(void);
 int mpcx_version(void);

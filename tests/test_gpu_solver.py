@@ -1,0 +1,69 @@
+"""SpMV / CG / LinearProblem on the device against scipy on the same
+assembled system.  Tolerances: SpMV 1e-13 relative to |A||x| (different summation order);
+the CG solution to 1e-8 relative (iterative solve to rtol 1e-12 of a system whose condition
+number is O(h^-2))."""
+
+import numpy as np
+import pytest
+
+from problems import case_cube_elasticity_slip, case_cube_periodic, product_mpc
+
+pytestmark = pytest.mark.gpu
+
+
+def _host_backsubstitute(mpc, x):
+    x = x.copy()
+    off, m = mpc.masters.offsets, mpc.masters.array
+    c = mpc.coefficients()[0]
+    for s in mpc.slaves:
+        x[s] = sum(c[q] * x[m[q]] for q in range(off[s], off[s + 1]))
+    return x
+
+
+def test_spmv_matches_scipy():
+    import torch
+
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd.la import Vector
+    from dolfinx_mpc_amd.problem import spmv
+
+    case = case_cube_periodic(9, 2, 0.0)  # P2: rows of very different lengths
+    mpc = product_mpc(case)
+    A = dm.assemble_matrix(case.a, mpc, bcs=case.bcs)
+    rng = np.random.default_rng(3)
+    xh = rng.standard_normal(A.shape[1])
+    x = Vector(A.shape[1])
+    x.array.copy_(torch.from_numpy(xh))
+    y = spmv(A, x).numpy()
+    As = A.to_scipy()
+    ref = As @ xh
+    bound = 1e-13 * (abs(As) @ abs(xh)).max()
+    assert abs(y - ref).max() <= bound
+
+
+@pytest.mark.parametrize("make", [lambda: case_cube_periodic(10, 1, 0.3), lambda: case_cube_periodic(5, 2, 0.0),
+                                  lambda: case_cube_elasticity_slip(4)], ids=["p1-periodic", "p2-periodic", "elasticity-slip"])
+def test_linear_problem_matches_direct_solve(make):
+    import scipy.sparse.linalg as spla
+
+    from dolfinx_mpc_amd.problem import LinearProblem
+
+    case = make()
+    mpc = product_mpc(case)
+    prob = LinearProblem(case.a, case.L, mpc, case.bcs, solver_options={"rtol": 1e-13, "max_it": 20000})
+    u = prob.solve()
+    assert prob.info["converged"] and prob.info["residual_norm"] <= 1e-13 * prob.info["b_norm"]
+    A, b = prob.A.to_scipy(), prob.b.numpy()
+    x = spla.spsolve(A.tocsc(), b)
+    x[mpc.slaves] = 0.0
+    x = _host_backsubstitute(mpc, x)
+    got = u.x.array
+    assert abs(got - x).max() <= 1e-8 * max(1.0, abs(x).max())
+    # the constraint holds on the returned function: u[slave] = sum c u[master]
+    assert abs(got - _host_backsubstitute(mpc, got)).max() <= 1e-14 * max(1.0, abs(got).max())
+    # Dirichlet values are met
+    for bc in case.bcs:
+        vals = np.zeros_like(got)
+        bc.set(vals, None, 1.0)
+        dofs = bc.dof_indices()[0]
+        assert abs(got[dofs] - vals[dofs]).max() <= 1e-12
