@@ -259,6 +259,19 @@ def main():
             dist.destroy_process_group()
         return
 
+    # achievable HBM bandwidth on this device: device-to-device copy of 2 GiB, read + write
+    probe = torch.empty(1 << 28, dtype=torch.float64, device="cuda")
+    probe2 = torch.empty_like(probe)
+    probe2.copy_(probe)
+    pe = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    pe[0].record()
+    for _ in range(5):
+        probe2.copy_(probe)
+    pe[1].record()
+    torch.cuda.synchronize()
+    copy_gbs = 5 * 2 * probe.numel() * 8 / (pe[0].elapsed_time(pe[1]) * 1e-3) / 1e9
+    del probe, probe2
+
     ndofs_rank = V.num_dofs
     # global dof count of the (N, N, N*world) mesh: interface planes counted once
     ndofs_total = (N + 1) ** 2 * (N * world + 1)
@@ -301,6 +314,8 @@ def main():
             "traffic": measured_traffic(args.pmc_json, f"matrix_{args.alg}_kernel", N),
             "algorithmic_bytes": int(alg_bytes),
             "launch_ms": t_bulk,
+            "copy_probe_GBs": copy_gbs,  # what a plain device copy reaches on this box
+            "frac_of_copy_probe": achieved / copy_gbs,
         },
     }
     # second kernel of the step, both bounds: compulsory bytes B_b over the assemble_vector

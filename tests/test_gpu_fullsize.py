@@ -184,3 +184,25 @@ def test_vector_sum_and_slave_entries(problem):
         total += float((f * W[None, :]).sum(dim=1).mul(det).sum())
     got = float(b.array.sum())
     assert abs(got - total) <= 1e-11 * max(1.0, abs(total)), (got, total)
+
+
+def test_full_solve_reproduces_affine_data(problem):
+    """End to end at full size: Laplace problem (zero source) with the affine Dirichlet data
+    g = 1 + 2y - z on the four walls and the periodic constraint in x.  g does not depend on x,
+    P1 reproduces affine functions, so the constrained discrete solution IS g: assembled
+    matrix, lifting, set_bc, the device CG and the backsubstitution of the slaves must return
+    it (to the accuracy the iterative solve is run to)."""
+    from dolfinx_mpc_amd import fem
+    from dolfinx_mpc_amd.problem import LinearProblem
+
+    p = problem
+    V, mpc, bc = p["V"], p["mpc"], p["bc"]
+    L0 = fem.form_source(V, fem.FN_ONE, constant=0.0)
+    prob = LinearProblem(p["a"], L0, mpc, [bc], solver_options={"rtol": 1e-11, "max_it": 20000, "check_every": 50})
+    u = prob.solve().x.array
+    g = p["g"].x.array
+    assert prob.info["converged"]
+    assert abs(u - g).max() <= 1e-7, abs(u - g).max()
+    # periodicity of the returned function: slave value == master value (one master, coefficient 1)
+    m = mpc.masters.array[mpc.masters.offsets[mpc.slaves]]
+    assert abs(u[mpc.slaves] - u[m]).max() == 0.0
