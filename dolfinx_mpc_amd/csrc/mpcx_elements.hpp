@@ -351,6 +351,110 @@ struct ElementOp
   static_assert(FORM != MPCX_FORM_DIV_TEST || (BS0 == TDIM && BS1 == 1), "div(v) p: vector test, scalar trial");
   static_assert(FORM != MPCX_FORM_DIV_TRIAL || (BS0 == 1 && BS1 == TDIM), "div(u) q: scalar test, vector trial");
 
+  // LAZY operators: the element tensor does not fit the register budget of the row-block kernel
+  // (P1 elasticity: 144 entries = 288 VGPRs), but its entries have a closed form in a compact
+  // context -- `prepare` fills the context once per entity, `entry` evaluates one entry where it
+  // is scattered.  The thread-per-entity kernels keep using `tabulate`.
+  //   P1 elasticity:  gradients + |T| mu, |T| lambda
+  //   P2 stiffness (scalar, or component-diagonal on a blocked space), no coefficient:
+  //                   G_kl = |T| grad(l_k).grad(l_l) of the barycentric coordinates; with
+  //                   int l_a = |T|/4, int l_a l_b = |T| (1 + d_ab)/20 every entry is a fixed
+  //                   combination of at most four G_kl
+  static constexpr bool LAZY_ELASTICITY = (FORM == MPCX_FORM_ELASTICITY && DEG0_ == 1);
+  static constexpr bool LAZY_P2_STIFFNESS = (FORM == MPCX_FORM_STIFFNESS && DEG0_ == 2 && DEG1_ == 2);
+  static constexpr bool LAZY = LAZY_ELASTICITY || LAZY_P2_STIFFNESS;
+  struct Lazy
+  {
+    double g[NV][LAZY_P2_STIFFNESS ? NV : TDIM]; // elasticity: physical gradients; P2: G_kl
+    double smu, sla;                             // |T| mu, |T| lambda / P2: scale c0, unused
+  };
+  // may the row-block kernel take the lazy path for this kernel descriptor?
+  __device__ __host__ static inline bool lazy_applies(const mpcx_kernel_t& k)
+  {
+    return LAZY_ELASTICITY || (LAZY_P2_STIFFNESS && k.coeff_degree == 0);
+  }
+  __device__ static inline void prepare(Lazy& L, const double* c, const double (&cd)[NV * 3])
+  {
+    if constexpr (LAZY_ELASTICITY)
+    {
+      double K[TDIM][TDIM], detJ;
+      affine_geometry<TDIM>(cd, K, detJ);
+      const double vol = fabs(detJ) * (TDIM == 3 ? 1.0 / 6.0 : 0.5);
+      L.smu = vol * c[0];
+      L.sla = vol * c[1];
+#pragma unroll
+      for (int a = 0; a < TDIM; ++a)
+      {
+        double s = 0.0;
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d)
+        {
+          L.g[d + 1][a] = K[d][a];
+          s += K[d][a];
+        }
+        L.g[0][a] = -s;
+      }
+    }
+    else
+    {
+      // cof_k = det * grad(l_k):  G_kl = |T| grad(l_k).grad(l_l) = cof_k.cof_l / (d! |det|)
+      double C[NV][TDIM], det;
+      cofactor_gradients<TDIM>(cd, C, det);
+      const double s = (c ? c[0] : 1.0) / ((TDIM == 3 ? 6.0 : 2.0) * fabs(det));
+#pragma unroll
+      for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int l = k; l < NV; ++l)
+        {
+          double dot = 0.0;
+#pragma unroll
+          for (int d = 0; d < TDIM; ++d)
+            dot += C[k][d] * C[l][d];
+          L.g[k][l] = L.g[l][k] = s * dot;
+        }
+      L.smu = L.sla = 0.0;
+    }
+  }
+  __device__ static inline double entry(const Lazy& L, int i, int a, int j, int b)
+  {
+    if constexpr (LAZY_ELASTICITY)
+    {
+      // A[(i,a),(j,b)] = |T| (mu g_i^b g_j^a + lambda g_i^a g_j^b + delta_ab mu g_i.g_j)
+      double v = L.smu * L.g[i][b] * L.g[j][a] + L.sla * L.g[i][a] * L.g[j][b];
+      if (a == b)
+      {
+        double dot = 0.0;
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d)
+          dot += L.g[i][d] * L.g[j][d];
+        v += L.smu * dot;
+      }
+      return v;
+    }
+    else
+    {
+      if (a != b)
+        return 0.0; // component-diagonal
+      using LG = Lagrange<TDIM, 2>;
+      // int l_a = m1 |T|, int l_a l_b = (1 + d_ab) m2 |T| on a TDIM-simplex
+      constexpr double m1 = 1.0 / (TDIM + 1), m2 = 1.0 / ((TDIM + 1) * (TDIM + 2));
+      auto d = [](int x, int y) { return x == y ? 2.0 : 1.0; }; // 1 + delta
+      if (i < NV && j < NV) // vertex-vertex: int (4 l_i - 1)(4 l_j - 1) G_ij
+        return (16.0 * d(i, j) * m2 - 8.0 * m1 + 1.0) * L.g[i][j];
+      if (i < NV || j < NV) // vertex v, edge (p, q): int (4 l_v - 1) 4 (l_p G_vq + l_q G_vp)
+      {
+        const int v = i < NV ? i : j, e = (i < NV ? j : i) - NV;
+        int p, q;
+        LG::edge(e, p, q);
+        return 4.0 * ((4.0 * d(v, p) * m2 - m1) * L.g[v][q] + (4.0 * d(v, q) * m2 - m1) * L.g[v][p]);
+      }
+      int p, q, r, t; // edge (p, q), edge (r, t): int 16 (l_p grad l_q + l_q grad l_p).(l_r grad l_t + l_t grad l_r)
+      LG::edge(i - NV, p, q);
+      LG::edge(j - NV, r, t);
+      return 16.0 * m2 * (d(p, r) * L.g[q][t] + d(p, t) * L.g[q][r] + d(q, r) * L.g[p][t] + d(q, t) * L.g[p][r]);
+    }
+  }
+
   // entry (p, q) of the element matrix, p = i*BS0 + a, q = j*BS1 + b
   __device__ static inline double get(const double (&A)[SIZE], int p, int q)
   {

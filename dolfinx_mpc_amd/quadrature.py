@@ -62,6 +62,25 @@ def _tet14():
     return np.array(pts), np.array(wts)
 
 
+def _tet24():
+    """Keast's 24-point rule of degree 6 (positive weights): three orbits (a, a, a, 1-3a) and
+    one orbit (a, a, b, 1-2a-b); exact to 4e-16 on every monomial of degree <= 6
+    (tests/test_oracle_kernels.py)."""
+    import itertools
+
+    pts, wts = [], []
+    for a, w in ((0.2146028712591521, 0.0399227502581679), (0.0406739585346113, 0.0100772110553207),
+                 (0.3223378901422757, 0.0553571815436544)):
+        for perm in sorted(set(itertools.permutations((a, a, a, 1.0 - 3.0 * a)))):
+            pts.append(perm[1:])
+            wts.append(w)
+    a, b, w = 0.0636610018750175, 0.2696723314583159, 0.0482142857142857
+    for perm in sorted(set(itertools.permutations((a, a, b, 1.0 - 2.0 * a - b)))):
+        pts.append(perm[1:])
+        wts.append(w)
+    return np.array(pts), np.array(wts) / 6.0
+
+
 def make_quadrature(cell_name: str, degree: int):
     """Return (points (nq, tdim), weights (nq,)) exact for polynomials of ``degree``."""
     degree = max(int(degree), 0)
@@ -73,6 +92,8 @@ def make_quadrature(cell_name: str, degree: int):
             return np.array([[a, a, a], [b, a, a], [a, b, a], [a, a, b]]), np.full(4, 1.0 / 24.0)
         if degree <= 5:
             return _tet14()
+        if degree == 6:
+            return _tet24()
         return _collapsed_tet(degree)
     if cell_name == "triangle":
         if degree <= 1:
