@@ -362,7 +362,12 @@ struct ElementOp
   //                   combination of at most four G_kl
   static constexpr bool LAZY_ELASTICITY = (FORM == MPCX_FORM_ELASTICITY && DEG0_ == 1);
   static constexpr bool LAZY_P2_STIFFNESS = (FORM == MPCX_FORM_STIFFNESS && DEG0_ == 2 && DEG1_ == 2);
-  static constexpr bool LAZY = LAZY_ELASTICITY || LAZY_P2_STIFFNESS;
+  //   Taylor-Hood coupling blocks (P2^d x P1): int psi_j d_a(phi_i) from the gradients and the
+  //                   same barycentric integrals
+  static constexpr bool LAZY_DIV_TEST = (FORM == MPCX_FORM_DIV_TEST && DEG0_ == 2 && DEG1_ == 1);
+  static constexpr bool LAZY_DIV_TRIAL = (FORM == MPCX_FORM_DIV_TRIAL && DEG0_ == 1 && DEG1_ == 2);
+  static constexpr bool LAZY_DIV = LAZY_DIV_TEST || LAZY_DIV_TRIAL;
+  static constexpr bool LAZY = LAZY_ELASTICITY || LAZY_P2_STIFFNESS || LAZY_DIV;
   struct Lazy
   {
     double g[NV][LAZY_P2_STIFFNESS ? NV : TDIM]; // elasticity: physical gradients; P2: G_kl
@@ -371,17 +376,25 @@ struct ElementOp
   // may the row-block kernel take the lazy path for this kernel descriptor?
   __device__ __host__ static inline bool lazy_applies(const mpcx_kernel_t& k)
   {
-    return LAZY_ELASTICITY || (LAZY_P2_STIFFNESS && k.coeff_degree == 0);
+    return LAZY_ELASTICITY || ((LAZY_P2_STIFFNESS || LAZY_DIV) && k.coeff_degree == 0);
   }
   __device__ static inline void prepare(Lazy& L, const double* c, const double (&cd)[NV * 3])
   {
-    if constexpr (LAZY_ELASTICITY)
+    if constexpr (LAZY_ELASTICITY || LAZY_DIV)
     {
       double K[TDIM][TDIM], detJ;
       affine_geometry<TDIM>(cd, K, detJ);
       const double vol = fabs(detJ) * (TDIM == 3 ? 1.0 / 6.0 : 0.5);
-      L.smu = vol * c[0];
-      L.sla = vol * c[1];
+      if constexpr (LAZY_DIV)
+      {
+        L.smu = vol * (c ? c[0] : 1.0); // c0 |T|
+        L.sla = 0.0;
+      }
+      else
+      {
+        L.smu = vol * c[0];
+        L.sla = vol * c[1];
+      }
 #pragma unroll
       for (int a = 0; a < TDIM; ++a)
       {
@@ -430,6 +443,21 @@ struct ElementOp
         v += L.smu * dot;
       }
       return v;
+    }
+    else if constexpr (LAZY_DIV)
+    {
+      // DIV_TEST: A[(i,a)][j] = c0 int psi_j d_a(phi_i); DIV_TRIAL: A[i][(j,b)] = c0 int psi_i d_b(phi_j)
+      // (phi: P2 velocity basis, psi: P1 pressure basis).  With v = the P2 index, s = the P1 index,
+      // x = the component: vertex v: g_v^x int l_s (4 l_v - 1); edge (p,q): 4 int l_s (l_p g_q^x + l_q g_p^x)
+      using LG = Lagrange<TDIM, 2>;
+      constexpr double m1 = 1.0 / (TDIM + 1), m2 = 1.0 / ((TDIM + 1) * (TDIM + 2));
+      auto d = [](int x, int y) { return x == y ? 2.0 : 1.0; };
+      const int v = LAZY_DIV_TEST ? i : j, sidx = LAZY_DIV_TEST ? j : i, x = LAZY_DIV_TEST ? a : b;
+      if (v < NV)
+        return L.smu * (4.0 * d(sidx, v) * m2 - m1) * L.g[v][x];
+      int p, q;
+      LG::edge(v - NV, p, q);
+      return L.smu * 4.0 * m2 * (d(sidx, p) * L.g[q][x] + d(sidx, q) * L.g[p][x]);
     }
     else
     {
