@@ -367,7 +367,11 @@ struct ElementOp
   static constexpr bool LAZY_DIV_TEST = (FORM == MPCX_FORM_DIV_TEST && DEG0_ == 2 && DEG1_ == 1);
   static constexpr bool LAZY_DIV_TRIAL = (FORM == MPCX_FORM_DIV_TRIAL && DEG0_ == 1 && DEG1_ == 2);
   static constexpr bool LAZY_DIV = LAZY_DIV_TEST || LAZY_DIV_TRIAL;
-  static constexpr bool LAZY = LAZY_ELASTICITY || LAZY_P2_STIFFNESS || LAZY_DIV;
+  //   P1 stiffness:   cofactor rows C_k = det grad(l_k) and s = c0 / (d! |det|): A_ij = s C_i.C_j.  The 16
+  //                   entries would fit, but without them the kernel needs 64 VGPRs instead of 128
+  //                   (no spills, twice the waves per SIMD)
+  static constexpr bool LAZY_P1_STIFFNESS = (FORM == MPCX_FORM_STIFFNESS && DEG0_ == 1 && DEG1_ == 1);
+  static constexpr bool LAZY = LAZY_ELASTICITY || LAZY_P2_STIFFNESS || LAZY_DIV || LAZY_P1_STIFFNESS;
   struct Lazy
   {
     double g[NV][LAZY_P2_STIFFNESS ? NV : TDIM]; // elasticity: physical gradients; P2: G_kl
@@ -376,7 +380,7 @@ struct ElementOp
   // may the row-block kernel take the lazy path for this kernel descriptor?
   __device__ __host__ static inline bool lazy_applies(const mpcx_kernel_t& k)
   {
-    return LAZY_ELASTICITY || ((LAZY_P2_STIFFNESS || LAZY_DIV) && k.coeff_degree == 0);
+    return LAZY_ELASTICITY || ((LAZY_P2_STIFFNESS || LAZY_DIV || LAZY_P1_STIFFNESS) && k.coeff_degree == 0);
   }
   __device__ static inline void prepare(Lazy& L, const double* c, const double (&cd)[NV * 3])
   {
@@ -407,6 +411,13 @@ struct ElementOp
         }
         L.g[0][a] = -s;
       }
+    }
+    else if constexpr (LAZY_P1_STIFFNESS)
+    {
+      double det;
+      cofactor_gradients<TDIM>(cd, L.g, det);
+      L.smu = (c ? c[0] : 1.0) / ((TDIM == 3 ? 6.0 : 2.0) * fabs(det));
+      L.sla = 0.0;
     }
     else
     {
@@ -443,6 +454,16 @@ struct ElementOp
         v += L.smu * dot;
       }
       return v;
+    }
+    else if constexpr (LAZY_P1_STIFFNESS)
+    {
+      if (a != b)
+        return 0.0; // component-diagonal on blocked spaces
+      double dot = 0.0;
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d)
+        dot += L.g[i][d] * L.g[j][d];
+      return L.smu * dot;
     }
     else if constexpr (LAZY_DIV)
     {

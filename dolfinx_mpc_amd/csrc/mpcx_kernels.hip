@@ -16,6 +16,7 @@
 #include "mpcx_elements.hpp"
 #include "mpcx_internal.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <string>
@@ -1036,11 +1037,13 @@ int launch_matrix(const mpcx_matrix_args_t& a)
         return -4;
       }
       const unsigned grid = 8u * unsigned((a.plan.num_blocks + 7) / 8);
-      const int threads = []
+      // threads per workgroup (two workgroups per CU by the LDS budget of the plan): chosen per kernel
+      // below, MPCX_ROWBLOCK_THREADS overrides
+      const int env_threads = []
       {
         const char* e = std::getenv("MPCX_ROWBLOCK_THREADS");
-        const int t = e ? std::atoi(e) : 512;
-        return (t >= 64 && t <= 1024 && t % 64 == 0) ? t : 512;
+        const int t = e ? std::atoi(e) : 0;
+        return (t >= 64 && t <= 1024 && t % 64 == 0) ? t : 0;
       }();
       auto launch = [&](auto kernel) -> int
       {
@@ -1048,6 +1051,16 @@ int launch_matrix(const mpcx_matrix_args_t& a)
                                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)),
                            "hipFuncSetAttribute"))
           return rc;
+        int threads = env_threads;
+        if (threads == 0)
+        {
+          hipFuncAttributes attr;
+          if (int rc = check(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kernel)), "hipFuncGetAttributes"))
+            return rc;
+          // 512 threads (2 x 8 waves per CU) unless the kernel is light enough for 2 x 12 waves AND runs
+          // the pipelined small-element loop: P1 stiffness 1.96 -> 1.81 ms; P2 and elasticity lose with 768
+          threads = (attr.numRegs <= 64 && Op::ND0 * Op::ND1 <= 16) ? 768 : 512;
+        }
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, stream, a);
         return 0;
       };
