@@ -149,10 +149,17 @@ def main():
     from dolfinx_mpc_amd import _native
     am = sys.modules["dolfinx_mpc_amd.assemble_matrix"]  # the module (the package re-exports the function)
 
+    # one rank = one GPU: select it before anything touches the device (the sparsity pattern is
+    # built there when a GPU is present)
+    import torch
+
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+
     t_setup = time.time()
     mesh, V, bc, mpc, a, L = build_problem(N, reorder, rank, world)
     t = time.time()
-    rowptr, cols = dm.create_sparsity_pattern(a, mpc)
+    rowptr, cols = dm.create_sparsity_pattern(a, mpc, where="host" if args.setup_only else None)
     log(f"pattern: nnz {cols.size} ({time.time() - t:.1f}s)")
     if args.setup_only:
         log(f"host set-up total {time.time() - t_setup:.1f}s")
