@@ -167,8 +167,8 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False):
         dm = V0.dofmap.list
         # numbering hint: first row of every tile of a tiled P1 numbering
         hints = None
-        if V0.degree == 1 and form.mesh.node_tile_offsets is not None:
-            hints = np.ascontiguousarray(form.mesh.node_tile_offsets.astype(np.int32) * V0.dofmap.bs)
+        if V0.dof_tile_offsets is not None:
+            hints = np.ascontiguousarray(V0.dof_tile_offsets.astype(np.int32) * V0.dofmap.bs)
         h = L.mpcx_rowblock_plan_build(A.shape[0], p(A.rowptr), ROWBLOCK_MAX_ROWS, ROWBLOCK_MAX_NNZ,
                                        integ.num_entities, integ.estride, p(ents), p(dm), dm.shape[1], V0.dofmap.bs,
                                        None if hints is None else p(hints), 0 if hints is None else hints.size, 1)

@@ -95,8 +95,10 @@ class FunctionSpace:
         # plane of every dof block, used by the interface exchange
         self.dof_global = None
         self.dof_plane = None
+        self.dof_tile_offsets = None  # first dof block of every tile of a tiled numbering (hint for row blocks)
         if degree == 1:
             cell_dofs = mesh.geometry.dofmap.copy()
+            self.dof_tile_offsets = mesh.node_tile_offsets
             nblocks = mesh.num_owned_nodes
             nghost = mesh.num_nodes - mesh.num_owned_nodes
             if mesh.node_global is not None:
@@ -104,9 +106,24 @@ class FunctionSpace:
                 self.dof_global = mesh.node_global
                 self.dof_plane = mesh.node_global // ((N + 1) * (N + 1))
         elif mesh.num_owned_nodes == mesh.num_nodes:
-            cell_edges, _ = mesh.edges()
+            cell_edges, ev = mesh.edges()
             cell_dofs = np.concatenate([mesh.geometry.dofmap, cell_edges + mesh.num_nodes], axis=1)
             nblocks = mesh.num_nodes + int(cell_edges.max()) + 1
+            if mesh.node_tile_offsets is not None:
+                # tiled numbering: an edge dof is numbered next to its lower end node instead of after
+                # all nodes, so that the dofs of a spatial tile form one contiguous range (row blocks of
+                # the assembly kernels, distinct dofs per workgroup) -- numbering is not part of the
+                # reference's contract (DOLFINx reorders dofs for locality as well)
+                nn = mesh.num_nodes
+                owner = np.concatenate([np.arange(nn, dtype=np.int64), np.minimum(ev[:, 0], ev[:, 1]).astype(np.int64)])
+                kind = np.concatenate([np.zeros(nn, dtype=np.int8), np.ones(ev.shape[0], dtype=np.int8)])
+                order = np.lexsort((kind, owner))  # old ids in new order
+                new_of_old = np.empty(order.size, dtype=np.int64)
+                new_of_old[order] = np.arange(order.size)
+                cell_dofs = new_of_old[cell_dofs]
+                x = mesh.geometry.x
+                self._dof_coords = np.concatenate([x, 0.5 * (x[ev[:, 0]] + x[ev[:, 1]])], axis=0)[order]
+                self.dof_tile_offsets = new_of_old[mesh.node_tile_offsets]
         else:
             cell_dofs, nblocks, nghost = self._p2_on_slab(mesh)
         self.dofmap = DofMap(cell_dofs, nblocks, bs, nghost)

@@ -290,6 +290,7 @@ def all_small_cases() -> List[Callable[[], Case]]:
         lambda: case_cube_periodic(3, 2, 0.0),
         lambda: case_cube_periodic(4, 1, 2.3),
         lambda: case_cube_periodic(4, 1, 0.0, reorder=(2, 2, 2)),
+        lambda: case_cube_periodic(4, 2, 0.0, reorder=(2, 2, 2)),  # P2 with the tile-wise dof numbering
         lambda: case_cube_elasticity_slip(3),
         lambda: case_cube_contact_like(3),
         case_lifting_x0_scale_diagval,
