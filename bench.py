@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--no-tile", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=96)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-allcores", type=int, default=0, metavar="P",
+                    help="additionally time the oracle on P forked workers (oracle/cpu_parallel.py); off by default")
     ap.add_argument("--setup-only", action="store_true", help="host set-up only (no GPU), for timing the plan")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "pmc_latest.json"),
                     help="rocprofv3 PMC summary (tools/collect_pmc.py) of the same workload: source of roofline.traffic")
@@ -342,6 +344,17 @@ def main():
     if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
         log("timing the CPU baseline (oracle, 1 core) ...")
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n)
+        if args.cpu_allcores > 0:
+            # the way the reference is deployed: one serial loop per MPI rank over its cells (SURVEY 8d ii);
+            # fresh interpreter so that nothing forks with a live HIP runtime
+            import subprocess
+
+            r = subprocess.run([sys.executable, "-m", "oracle.cpu_parallel", str(args.cpu_sample_n), str(args.cpu_allcores)],
+                               cwd=ROOT, capture_output=True, text=True, timeout=900)
+            if r.returncode == 0:
+                out["cpu_baseline_allcores"] = json.loads(r.stdout.strip().splitlines()[-1])
+            else:
+                log("oracle.cpu_parallel failed: " + r.stderr[-300:])
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -271,7 +271,7 @@ def create_pattern(form, mpc0: OracleMPC, mpc1: OracleMPC):
 
 
 def assemble_matrix(form, mpc0: OracleMPC, mpc1: OracleMPC = None, bcs=(), diagval=1.0, pattern=None, fast=False,
-                    same_space=None):
+                    same_space=None, out_vals=None):
     """Restates python/src/dolfinx_mpc/assemble_matrix.py:43-65 +
     cpp/assemble_matrix.cpp:662-726 on the oracle; returns scipy CSR."""
     L = lib()
@@ -280,7 +280,10 @@ def assemble_matrix(form, mpc0: OracleMPC, mpc1: OracleMPC = None, bcs=(), diagv
     rowptr, cols = create_pattern(form, mpc0, mpc1) if pattern is None else pattern
     rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
     cols = np.ascontiguousarray(cols, dtype=np.int32)
-    vals = np.zeros(cols.size, dtype=np.float64)
+    # out_vals: caller-owned value array (zeroed here); the values are then returned as that array
+    # instead of a scipy matrix (oracle/cpu_parallel.py: workers write into shared memory)
+    vals = np.zeros(cols.size, dtype=np.float64) if out_vals is None else out_vals
+    vals[:] = 0.0
     csr = _Csr(rowptr.size - 1, _p(rowptr), _p(cols), _p(vals), 0)
     bc0 = bc1 = None
     for bc in bcs:
@@ -316,6 +319,8 @@ def assemble_matrix(form, mpc0: OracleMPC, mpc1: OracleMPC = None, bcs=(), diagv
                 L.oracle_insert_diagonal(C.byref(csr), _p(dofs), dofs.size, float(diagval))
     if csr.missing:
         raise RuntimeError(f"oracle: {csr.missing} insertions outside the pattern")
+    if out_vals is not None:
+        return vals
     return scipy.sparse.csr_matrix((vals, cols, rowptr), shape=(rowptr.size - 1, V1.num_dofs))
 
 
