@@ -661,17 +661,28 @@ __global__ void add_diagonal_kernel(const int32_t* __restrict__ rowptr, const in
 // workgroup first merges its contributions per destination dof in an LDS hash
 // table (consecutive entities share most of their dofs) and issues one device
 // atomic per distinct dof.  Slave entries go straight to their masters.
+#ifndef MPCX_VECTOR_LOG2H_LARGE
+#define MPCX_VECTOR_LOG2H_LARGE 10
+#endif
 template <int N>
 struct VectorCfg
 {
   static constexpr int NT = N <= 4 ? 256 : (N <= 16 ? 128 : 64); // threads per workgroup
-  static constexpr int LOG2H = N <= 4 ? 11 : 12;                  // table size >= 2 * NT * N (<= 48 KB)
+  // table size: >= 2 * NT * N for small elements (can never fill up); larger elements get the table their
+  // occupancy allows (48 KB per 2-wave workgroup left 6 waves per CU) and entries that find no slot
+  // within the probe limit go to memory directly
+  static constexpr int LOG2H = N <= 4 ? 11 : MPCX_VECTOR_LOG2H_LARGE;
   static constexpr int H = 1 << LOG2H;
-  static_assert(H >= 2 * NT * N, "hash table too small");
+  static constexpr int PROBES = N <= 4 ? H : 32;
+  // minimum waves per SIMD the register allocation is cut for: the P1 source loop runs faster on 5 waves
+  // with 96 VGPRs and 28 spills than on 4 waves with 126 VGPRs (3.63 -> 3.34 ms); 6 waves lose (4.13 ms)
+  static constexpr int WAVES = N <= 4 ? 5 : 1;
+  static_assert(N > 4 || H >= 2 * NT * N, "hash table too small");
 };
 
 template <class Op>
-__global__ void __launch_bounds__(VectorCfg<Op::N0>::NT) vector_kernel(mpcx_vector_args_t a)
+__global__ void __launch_bounds__(VectorCfg<Op::N0>::NT) __attribute__((amdgpu_waves_per_eu(VectorCfg<Op::N0>::WAVES)))
+vector_kernel(mpcx_vector_args_t a)
 {
   constexpr int N = Op::N0, ND = Op::ND0, BS = Op::BS0, NV = Op::NV;
   constexpr int NT = VectorCfg<N>::NT, H = VectorCfg<N>::H, LOG2H = VectorCfg<N>::LOG2H;
@@ -713,9 +724,11 @@ __global__ void __launch_bounds__(VectorCfg<Op::N0>::NT) vector_kernel(mpcx_vect
         }
         if (v != 0.0)
         {
-          // open addressing, linear probing; the table can hold every entry of the workgroup
+          // open addressing, linear probing (bounded: see VectorCfg)
           unsigned h = (unsigned(d) * 2654435761u) >> (32 - LOG2H);
-          for (int probe = 0; probe < H; ++probe)
+          int probe = 0;
+#pragma nounroll
+          for (; probe < VectorCfg<N>::PROBES; ++probe)
           {
             const int32_t old = atomicCAS(&s_key[h], -1, d);
             if (old == -1 || old == d)
@@ -725,6 +738,8 @@ __global__ void __launch_bounds__(VectorCfg<Op::N0>::NT) vector_kernel(mpcx_vect
             }
             h = (h + 1) & (H - 1);
           }
+          if (probe == VectorCfg<N>::PROBES)
+            atomic_add_f64(a.b + d, v);
         }
       }
     }
