@@ -100,9 +100,9 @@ def assemble_vector(form: Form, constraint: MultiPointConstraint, b: Optional[Ve
         keep = []
         # auto: row blocks for cheap integrands (few quadrature points), the hash kernel otherwise
         nq = integ.kernel.qwts.size if integ.itype == "cell" else integ.kernel.fqwts.size
-        # (P2 with a tile-wise numbering: the hash kernel's per-cell part is 5x the P1 cost, row blocks win
-        # up to ~16 points: 0.80 vs 1.04 ms at 14 points, 1.20 vs 1.08 ms at 24, 96^3)
-        nq_max = 16 if (V.degree == 2 and V.dof_tile_offsets is not None) else 4
+        # (P2 with a tile-wise numbering, 96^3: hash kernel 0.71 ms whatever the rule, row blocks 0.46 ms at
+        # 4 points, 0.85 ms at 14)
+        nq_max = 8 if (V.degree == 2 and V.dof_tile_offsets is not None) else 4
         if (alg == 2 or (alg == 0 and nq <= nq_max)) and integ.num_entities > 0:
             from .assemble_matrix import _masked_dofmap, _slave_entities
 
