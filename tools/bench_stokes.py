@@ -11,7 +11,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
 import dolfinx_mpc_amd as dm  # noqa: E402
+import test_stokes  # noqa: E402
+from dolfinx_mpc_amd.mesh import create_unit_cube  # noqa: E402
 from test_stokes import _stokes  # noqa: E402
+
+# tiled numbering (what the benchmark meshes use); the test helper builds the plain one
+if not os.environ.get("MPCX_STOKES_UNTILED"):
+    test_stokes.create_unit_cube = lambda *a: create_unit_cube(*a, reorder=(8, 8, 8))
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 V, Q, bcs, raw_v, forms, L0 = _stokes(3, n)
