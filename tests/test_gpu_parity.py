@@ -88,6 +88,30 @@ def test_device_pattern_equals_host_pattern(make):
     assert np.array_equal(cols_h, cols_d)
 
 
+def test_single_master_long_row_fallbacks(oracle):
+    """A master row with hundreds of columns (353 at N = 12): the device pattern builder hands over
+    to the host builder (same result) and every matrix algorithm matches the oracle (the long row
+    only receives master contributions, which go through matrix_mpc_kernel)."""
+    import dolfinx_mpc_amd as dm
+    from problems import case_cube_single_master
+
+    case = case_cube_single_master(12)
+    ref = oracle_outputs(oracle, case, fast=True)
+    mpc = product_mpc(case)
+    rp_h, cols_h = dm.create_sparsity_pattern(case.a, mpc, where="host")
+    assert np.diff(rp_h).max() > 255
+    rp_d, cols_d = dm.create_sparsity_pattern(case.a, mpc, where="device")
+    assert np.array_equal(rp_h, rp_d) and np.array_equal(cols_h, cols_d)
+    assert np.array_equal(rp_h, ref["A"].indptr) and np.array_equal(cols_h, ref["A"].indices)
+    A = dm.assemble_matrix(case.a, mpc, bcs=case.bcs)  # auto
+    _close(A.to_scipy().data, ref["A"].data, RTOL_A, "A (auto)")
+    for alg in ("rowblock", "atomic"):
+        A = dm.assemble_matrix(case.a, mpc, bcs=case.bcs, A=A, algorithm=alg)
+        _close(A.to_scipy().data, ref["A"].data, RTOL_A, "A " + alg)
+    b = dm.assemble_vector(case.L, mpc)
+    _close(b.numpy(), ref["b"], RTOL_B, "b")
+
+
 def test_repeated_assembly_into_same_matrix(oracle):
     """A given -> zeroed and re-assembled (python/src/dolfinx_mpc/assemble_matrix.py:49-51)."""
     import dolfinx_mpc_amd as dm
