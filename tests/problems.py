@@ -269,7 +269,7 @@ def case_lifting_x0_scale_diagval() -> Case:
     return case
 
 
-def case_cube_single_master(N=12) -> Case:
+def case_cube_single_master(N=12, master_point=(0.5, 0.5, 0.5)) -> Case:
     """Every free node of the face x = 1 is a slave of ONE master node (rigid-link style, like the
     dictcondition tests with a shared master): the master's row collects the columns of all slave
     cells -- more than 128 column blocks: the device pattern builder falls back to the host one."""
@@ -278,7 +278,7 @@ def case_cube_single_master(N=12) -> Case:
     x = V.tabulate_dof_coordinates()
     bc = fem.dirichletbc(0.5, fem.locate_dofs_geometrical(V, lambda x: np.isclose(x[0], 0)), V)
     slaves = np.flatnonzero(np.isclose(x[:, 0], 1.0)).astype(np.int32)
-    master = int(np.argmin(np.linalg.norm(x - np.array([0.5, 0.5, 0.5]), axis=1)))
+    master = int(np.argmin(np.linalg.norm(x - np.array(master_point), axis=1)))
     n = slaves.size
     raw = (slaves, np.full(n, master, dtype=np.int64), np.linspace(0.2, 1.3, n), np.zeros(n, dtype=np.int32),
            np.arange(n + 1, dtype=np.int32))

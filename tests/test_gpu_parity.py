@@ -112,6 +112,22 @@ def test_single_master_long_row_fallbacks(oracle):
     _close(b.numpy(), ref["b"], RTOL_B, "b")
 
 
+def test_rowblock_offset_overflow_falls_back_to_atomic(oracle):
+    """The master sits at the end of its own 342-entry row: the 8-bit scatter offsets of its cells
+    overflow, algorithm="rowblock" says so and "auto" assembles with the atomic kernel."""
+    import dolfinx_mpc_amd as dm
+    from problems import case_cube_single_master
+
+    case = case_cube_single_master(12, (11 / 12, 1.0, 1.0))
+    ref = oracle_outputs(oracle, case, fast=True)
+    mpc = product_mpc(case)
+    with pytest.raises(RuntimeError, match="row-block algorithm"):
+        dm.assemble_matrix(case.a, mpc, bcs=case.bcs, algorithm="rowblock")
+    A = dm.assemble_matrix(case.a, mpc, bcs=case.bcs)  # auto
+    assert np.array_equal(A.rowptr, ref["A"].indptr) and np.array_equal(A.cols, ref["A"].indices)
+    _close(A.to_scipy().data, ref["A"].data, RTOL_A, "A (auto -> atomic)")
+
+
 def test_repeated_assembly_into_same_matrix(oracle):
     """A given -> zeroed and re-assembled (python/src/dolfinx_mpc/assemble_matrix.py:49-51)."""
     import dolfinx_mpc_amd as dm
