@@ -128,6 +128,38 @@ def test_rowblock_offset_overflow_falls_back_to_atomic(oracle):
     _close(A.to_scipy().data, ref["A"].data, RTOL_A, "A (auto -> atomic)")
 
 
+@pytest.mark.parametrize("alg", ["atomic", "rowblock", None])
+def test_empty_integration_domain(oracle, alg):
+    """No entities: the matrix holds only the slave / Dirichlet diagonal, the vector is zero,
+    lifting does nothing (the reference loops simply do not execute)."""
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import fem
+
+    case = case_cube_periodic(4, 1, 0.7)
+    V = case.V
+    none = np.zeros(0, dtype=np.int32)
+    a0 = fem.form_stiffness(V, cells=none)
+    L0 = fem.form_source(V, fem.FN_POLY3, cells=none)
+    mpc = product_mpc(case)
+    A = dm.assemble_matrix(a0, mpc, bcs=case.bcs, diagval=2.0, algorithm=alg)
+    As = A.to_scipy()
+    expect = np.zeros(V.num_dofs)
+    expect[mpc.slaves[: mpc.num_local_slaves]] = 2.0
+    for bc in case.bcs:
+        expect[bc.dof_indices()[0]] += 2.0
+    assert np.array_equal(As.diagonal(), expect)
+    assert abs(As - scipy_diag(expect)).max() == 0.0
+    b = dm.assemble_vector(L0, mpc, algorithm=alg)
+    dm.apply_lifting(b, [a0], [case.bcs], mpc)
+    assert np.all(b.numpy() == 0.0)
+
+
+def scipy_diag(d):
+    import scipy.sparse
+
+    return scipy.sparse.diags(d).tocsr()
+
+
 def test_repeated_assembly_into_same_matrix(oracle):
     """A given -> zeroed and re-assembled (python/src/dolfinx_mpc/assemble_matrix.py:49-51)."""
     import dolfinx_mpc_amd as dm
