@@ -23,6 +23,10 @@ _ALG = {"auto": 0, "atomic": 1, "rowblock": 2}
 # -> 2 workgroups of 512 threads per CU is the fastest shape for P1)
 ROWBLOCK_MAX_NNZ = int(os.environ.get("MPCX_ROWBLOCK_MAX_NNZ", 9216))
 ROWBLOCK_MAX_ROWS = int(os.environ.get("MPCX_ROWBLOCK_MAX_ROWS", 512))
+# the lean scalar P1 kernel needs 64 VGPRs only: half-size blocks (half tiles of an 8x8x8 numbering) put
+# four workgroups of 512 threads on a CU -- 1.75 ms against 1.82 ms at config 2 (sweep in DESIGN.md section 5)
+ROWBLOCK_LIGHT_MAX_NNZ = int(os.environ.get("MPCX_ROWBLOCK_MAX_NNZ", 4608))
+ROWBLOCK_LIGHT_MAX_ROWS = int(os.environ.get("MPCX_ROWBLOCK_MAX_ROWS", 256))
 # scatter-offset rows are dictionary-compressed when at most this many are distinct (table stays cache resident)
 MAX_OFFSET_PATTERNS = 4096
 
@@ -158,7 +162,10 @@ def _slave_entities(form: Form, i: int, mpc0, mpc1):
 
 
 def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False):
-    key = (id(form), i, ROWBLOCK_MAX_NNZ, ROWBLOCK_MAX_ROWS, lean)
+    light = lean and V0.dofmap.bs == 1 and V0.element_ndofs <= 4
+    max_rows_cap, max_nnz_cap = ((ROWBLOCK_LIGHT_MAX_ROWS, ROWBLOCK_LIGHT_MAX_NNZ) if light
+                                 else (ROWBLOCK_MAX_ROWS, ROWBLOCK_MAX_NNZ))
+    key = (id(form), i, max_nnz_cap, max_rows_cap, lean)
     if key not in A._plans:
         L = _native.lib()
         p = _native._ptr
@@ -169,7 +176,7 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False):
         hints = None
         if V0.dof_tile_offsets is not None:
             hints = np.ascontiguousarray(V0.dof_tile_offsets.astype(np.int32) * V0.dofmap.bs)
-        h = L.mpcx_rowblock_plan_build(A.shape[0], p(A.rowptr), ROWBLOCK_MAX_ROWS, ROWBLOCK_MAX_NNZ,
+        h = L.mpcx_rowblock_plan_build(A.shape[0], p(A.rowptr), max_rows_cap, max_nnz_cap,
                                        integ.num_entities, integ.estride, p(ents), p(dm), dm.shape[1], V0.dofmap.bs,
                                        None if hints is None else p(hints), 0 if hints is None else hints.size, 1)
         if not h:

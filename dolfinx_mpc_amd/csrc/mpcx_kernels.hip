@@ -1073,8 +1073,9 @@ int launch_matrix(const mpcx_matrix_args_t& a)
           if (int rc = check(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kernel)), "hipFuncGetAttributes"))
             return rc;
           // 512 threads (2 x 8 waves per CU) unless the kernel is light enough for 2 x 12 waves AND runs
-          // the pipelined small-element loop: P1 stiffness 1.96 -> 1.81 ms; P2 and elasticity lose with 768
-          threads = (attr.numRegs <= 64 && Op::ND0 * Op::ND1 <= 16) ? 768 : 512;
+          // the pipelined small-element loop on full-size blocks: P1 stiffness 1.96 -> 1.81 ms (P2 and elasticity
+          // lose with 768); the host picks half-size blocks for that kernel, four 512-thread workgroups per CU
+          threads = (attr.numRegs <= 64 && Op::ND0 * Op::ND1 <= 16 && a.plan.max_rows > 256) ? 768 : 512;
         }
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, stream, a);
         return 0;

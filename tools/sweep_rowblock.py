@@ -29,6 +29,7 @@ for tile in tiles:
     alg_bytes = 4 * 4 * nc + 4 * 4 * nc + 24 * mesh.num_nodes + 8 * cols.size + 2 * V.num_dofs
     for max_rows, max_nnz in ((128, 2304), (256, 4608), (512, 9216)):
         am.ROWBLOCK_MAX_ROWS, am.ROWBLOCK_MAX_NNZ = max_rows, max_nnz
+        am.ROWBLOCK_LIGHT_MAX_ROWS, am.ROWBLOCK_LIGHT_MAX_NNZ = max_rows, max_nnz
         for threads in (256, 384, 512, 768):
             os.environ["MPCX_ROWBLOCK_THREADS"] = str(threads)
             margs, keep = am.matrix_args(a, 0, A, mpc, mpc, [bc], 2, store_mode=1, with_mpc_kernel=False)
