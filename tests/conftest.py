@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the host set-up routines live in the same shared library as the kernels: build it once if a fresh
+    # checkout has not run __graft_entry__.build() yet (hipcc cross-compiles gfx950 without a GPU)
+    lib = os.path.join(ROOT, "dolfinx_mpc_amd", "libmpcx.so")
+    if not os.path.exists(lib):
+        import __graft_entry__
+
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")
