@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
     if constexpr (LAZY)
       Op::prepare(lz, a.constants, cd);
     else
-      Op::tabulate(Ae, a.coeffs ? a.coeffs + E.e * a.cstride : nullptr, a.constants, cd, LEAN ? 0 : E.lf, a.kernel);
+      Op::tabulate(Ae, a.coeffs ? a.coeffs + int64_t(E.e) * a.cstride : nullptr, a.constants, cd, LEAN ? 0 : E.lf, a.kernel);
 #pragma unroll
     for (int i = 0; i < ND0; ++i)
     {
