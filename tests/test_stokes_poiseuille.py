@@ -1,0 +1,123 @@
+"""The reference's known-answer test for the Stokes blocks (python/tests/test_stokes_channelflow.py:30-173):
+Taylor-Hood on the unit cube, no-slip walls y in {0, 1}, periodic in x and z for velocity AND pressure
+(two different constraints on the rectangular blocks), body force (1, 0, 0).  The exact solution is the
+Poiseuille profile u = (y (1 - y) / 2, 0, 0), p = const, which P2 represents exactly -- so the constrained
+discrete solution must reproduce it to solver accuracy.
+
+The reference solves with MINRES + fieldsplit; here the assembled blocks are put into one scipy matrix,
+the pressure slaves (empty rows: there is no a11 block) and one pressure dof (the constant) are removed,
+and the rest is solved directly; slaves are then back-substituted (python/tests/...:147-149).
+"""
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from dolfinx_mpc_amd import fem
+from dolfinx_mpc_amd.mesh import create_unit_cube
+
+
+def _problem(n):
+    mesh = create_unit_cube(n, n, n)
+    V = fem.functionspace(mesh, ("Lagrange", 2, (3,)))
+    Q = fem.functionspace(mesh, ("Lagrange", 1))
+    walls = fem.locate_dofs_geometrical(V, lambda x: np.isclose(x[1], 0) | np.isclose(x[1], 1))
+    bc = fem.dirichletbc(np.zeros(3), walls, V)
+
+    def periodic_boundary(x):  # test_stokes_channelflow.py:49-50
+        return np.isclose(x[0], 1) | np.isclose(x[2], 1)
+
+    def periodic_map(x):  # :52-56
+        out = x.copy()
+        out[0][np.isclose(x[0], 1)] -= 1
+        out[2][np.isclose(x[2], 1)] -= 1
+        return out
+
+    forms = {
+        (0, 0): fem.form_stiffness(V),  # mu = 1
+        (0, 1): fem.form_div_test(V, Q, constant=-1.0),
+        (1, 0): fem.form_div_trial(Q, V, constant=-1.0),
+    }
+    L0 = fem.form_source(V, fem.FN_CONSTANT_VEC, constant=np.array([1.0, 1.0, 0.0, 0.0]))  # f = (dp/dx, 0, 0)
+    return V, Q, bc, periodic_boundary, periodic_map, forms, L0
+
+
+def _raw_periodic(V, indicator, relation, bcs):
+    """(slaves, masters, coeffs, owners, offsets) exactly as MultiPointConstraint.
+    create_periodic_constraint_geometrical builds them (matching nodes, bc dofs dropped)."""
+    import dolfinx_mpc_amd as dm
+
+    captured = {}
+
+    class _Probe(dm.MultiPointConstraint):
+        def add_constraint(self, V, slaves, masters, coeffs, owners, offsets):
+            captured["raw"] = (slaves, masters, coeffs, owners, offsets)
+
+    _Probe(V).create_periodic_constraint_geometrical(V, indicator, relation, bcs)
+    return captured["raw"]
+
+
+def _solve_and_check(V, Q, A00, A01, A10, b0, slaves_u, masters_u, slaves_p, masters_p):
+    nu, npq = V.num_dofs, Q.num_dofs
+    K = sp.bmat([[A00, A01], [A10, None]], format="csr")
+    rhs = np.concatenate([b0, np.zeros(npq)])
+    keep = np.ones(nu + npq, dtype=bool)
+    keep[nu + slaves_p] = False  # empty rows/cols
+    free_p = np.setdiff1d(np.arange(npq), slaves_p)
+    keep[nu + free_p[0]] = False  # pressure constant
+    idx = np.flatnonzero(keep)
+    sol = np.zeros(nu + npq)
+    sol[idx] = spla.spsolve(K[idx][:, idx].tocsc(), rhs[idx])
+    u, p = sol[:nu], sol[nu:]
+    u[slaves_u] = u[masters_u]  # one master, coefficient 1
+    p[slaves_p] = p[masters_p]
+    x = V.tabulate_dof_coordinates()
+    exact = np.zeros((x.shape[0], 3))
+    exact[:, 0] = 0.5 * x[:, 1] * (1.0 - x[:, 1])
+    err = np.linalg.norm(u - exact.reshape(-1))
+    assert err < 1e-10, err
+    assert np.ptp(p) < 1e-9  # constant pressure
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_oracle_poiseuille(oracle, n):
+    po = oracle
+    V, Q, bc, ind, rel, forms, L0 = _problem(n)
+    raw_u, raw_p = _raw_periodic(V, ind, rel, [bc]), _raw_periodic(Q, ind, rel, [])
+    mu, mp = po.OracleMPC.from_raw(V, *raw_u), po.OracleMPC.from_raw(Q, *raw_p)
+    A00 = po.assemble_matrix(forms[(0, 0)], mu, mu, bcs=[bc])
+    A01 = po.assemble_matrix(forms[(0, 1)], mu, mp, bcs=[bc])
+    A10 = po.assemble_matrix(forms[(1, 0)], mp, mu, bcs=[bc])
+    b0 = po.assemble_vector(L0, mu)
+    po.apply_lifting(b0, [forms[(0, 0)]], [[bc]], mu)
+    b0[bc.dof_indices()[0]] = 0.0  # set_bc with homogeneous values
+    _solve_and_check(V, Q, A00, A01, A10, b0, raw_u[0], raw_u[1].astype(np.int64), raw_p[0], raw_p[1].astype(np.int64))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alg", ["rowblock", "atomic"])
+def test_gpu_poiseuille(alg):
+    import dolfinx_mpc_amd as dm
+
+    n = 3
+    V, Q, bc, ind, rel, forms, L0 = _problem(n)
+    mu = dm.MultiPointConstraint(V)
+    mu.create_periodic_constraint_geometrical(V, ind, rel, [bc])
+    mu.finalize()
+    mp = dm.MultiPointConstraint(Q)
+    mp.create_periodic_constraint_geometrical(Q, ind, rel, [])
+    mp.finalize()
+    mpcs = [mu, mp]
+    a = [[forms[(0, 0)], forms[(0, 1)]], [forms[(1, 0)], None]]
+    A = dm.create_matrix_nest(a, mpcs)
+    for i in range(2):
+        for j in range(2):
+            if a[i][j] is not None:
+                dm.assemble_matrix(a[i][j], (mpcs[i], mpcs[j]), bcs=[bc], A=A[i][j], algorithm=alg)
+    b0 = dm.assemble_vector(L0, mu, algorithm=alg)
+    dm.apply_lifting(b0, [forms[(0, 0)]], [[bc]], mu)
+    dm.set_bc(b0, [bc])
+    mast = lambda m: m.masters.array[m.masters.offsets[m.slaves]].astype(np.int64)  # noqa: E731
+    _solve_and_check(V, Q, A[0][0].to_scipy(), A[0][1].to_scipy(), A[1][0].to_scipy(), b0.numpy(),
+                     mu.slaves, mast(mu), mp.slaves, mast(mp))
