@@ -18,7 +18,11 @@
  * The element kernels stand in for FFCx-generated tabulate_tensor functions
  * (third party, absent): PARITY UNPINNED for absolute element-tensor values;
  * they are written FFCx-style (quadrature loops over tabulated bases) and
- * pinned by closed-form answers in tests/test_oracle_kernels.py.
+ * pinned by closed-form answers in tests/test_oracle_kernels.py.  The MPC
+ * algebra is pinned by the reference's own identities (A_mpc = K^T A K,
+ * b_mpc = K^T b: tests/test_oracle_identities.py) and by the one absolute
+ * known answer its tests hold, the Poiseuille flow of
+ * python/tests/test_stokes_channelflow.py (tests/test_stokes_poiseuille.py).
  */
 #include "mpc_oracle.h"
 
