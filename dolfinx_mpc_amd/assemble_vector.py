@@ -149,6 +149,21 @@ def apply_lifting(
 
     if isinstance(scale, np.generic):
         scale = scale.item()
+    if isinstance(b, (list, tuple)):
+        # nest: b = [b_i], form = [[a_ij]], constraint = [mpc_i]; bcs are grouped by the column space they
+        # live in (dolfinx bcs_by_block), assemble_vector.py:51-62
+        rows, cons = [list(r) for r in form], list(constraint)
+        if len(rows) != len(b) or len(cons) != len(b):
+            raise RuntimeError("Mismatch in size between b, a and the constraints in assembler.")
+        blocks = list(bcs)
+        if len(blocks) == 0 or isinstance(blocks[0], DirichletBC):
+            blocks = []
+            for j in range(len(rows[0])):
+                Vj = next((r[j].function_spaces[1] for r in rows if r[j] is not None), None)
+                blocks.append([bc for bc in bcs if Vj is not None and Vj.contains(bc.function_space)])
+        for b_sub, a_sub, mpc_i in zip(b, rows, cons):
+            apply_lifting(b_sub, a_sub, blocks, mpc_i, x0=x0, scale=scale, num_threads=num_threads)
+        return
     x0 = [] if x0 is None else list(x0)
     form = list(form)
     if len(x0) > 0 and len(x0) != len(form):
@@ -231,4 +246,7 @@ def assemble_vector_nest(b, L: Sequence[Form], constraints: Sequence[MultiPointC
     """python/src/dolfinx_mpc/assemble_vector.py:130-147"""
     assert len(constraints) == len(L)
     for i, L_row in enumerate(L):
-        assemble_vector(L_row, constraints[i], b=b[i], num_threads=num_threads)
+        if L_row is None:  # the reference passes ufl.ZeroBaseForm here: the sub-vector is zeroed
+            b[i].set(0.0)
+        else:
+            assemble_vector(L_row, constraints[i], b=b[i], num_threads=num_threads)
