@@ -183,6 +183,8 @@ EXPORTS = [
     "mpcx_rowblock_plan_copy",
     "mpcx_rowblock_plan_free",
     "mpcx_compress_offsets",
+    "mpcx_gather_f64",
+    "mpcx_scatter_add_f64",
     "mpcx_spmv",
     "mpcx_inverse_diagonal",
     "mpcx_cg_start",
@@ -265,6 +267,10 @@ def lib() -> C.CDLL:
     L.mpcx_rowblock_plan_free.restype = None
     L.mpcx_compress_offsets.argtypes = [vp, i64, i32, i32, vp, vp]
     L.mpcx_compress_offsets.restype = i32
+    L.mpcx_gather_f64.argtypes = [vp, vp, i64, vp, vp]
+    L.mpcx_gather_f64.restype = C.c_int
+    L.mpcx_scatter_add_f64.argtypes = [vp, vp, i64, vp, vp]
+    L.mpcx_scatter_add_f64.restype = C.c_int
     L.mpcx_spmv.argtypes = [i32, vp, vp, vp, vp, vp, vp]
     L.mpcx_spmv.restype = C.c_int
     L.mpcx_inverse_diagonal.argtypes = [i32, vp, vp, vp, vp, vp]

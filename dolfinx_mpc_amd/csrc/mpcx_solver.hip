@@ -201,12 +201,46 @@ __global__ void inverse_diagonal_kernel(int32_t nrows, const int32_t* __restrict
   dinv[r] = d != 0.0 ? 1.0 / d : 1.0;
 }
 
+// pack / unpack of the interface rows exchanged between z-slabs (dolfinx_mpc_amd/distributed.py)
+__global__ void gather_f64_kernel(const double* __restrict__ v, const int64_t* __restrict__ idx, int64_t n,
+                                  double* __restrict__ out)
+{
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n)
+    out[i] = v[idx[i]];
+}
+__global__ void scatter_add_f64_kernel(double* __restrict__ v, const int64_t* __restrict__ idx, int64_t n,
+                                       const double* __restrict__ in)
+{
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n)
+    atomicAdd(v + idx[i], in[i]); // an index may occur more than once
+}
+
 inline unsigned stream_grid(int64_t n) // grid-stride kernels: enough workgroups to fill 256 CUs
 {
   const int64_t g = (n + 255) / 256;
   return unsigned(g < 8192 ? (g > 0 ? g : 1) : 8192);
 }
 } // namespace
+
+extern "C" int mpcx_gather_f64(const double* values, const int64_t* idx, int64_t n, double* out, void* stream)
+{
+  if (n == 0)
+    return 0;
+  hipLaunchKernelGGL(gather_f64_kernel, dim3(grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), values,
+                     idx, n, out);
+  return check(hipGetLastError(), "gather_f64 launch");
+}
+
+extern "C" int mpcx_scatter_add_f64(double* values, const int64_t* idx, int64_t n, const double* in, void* stream)
+{
+  if (n == 0)
+    return 0;
+  hipLaunchKernelGGL(scatter_add_f64_kernel, dim3(grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     values, idx, n, in);
+  return check(hipGetLastError(), "scatter_add_f64 launch");
+}
 
 extern "C" int mpcx_spmv(int32_t nrows, const int32_t* rowptr, const int32_t* cols, const double* vals,
                          const double* x, double* y, void* stream)

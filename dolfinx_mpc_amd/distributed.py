@@ -206,7 +206,21 @@ class SlabExchange:
 
         dev = values.device
         stage_cpu = dist.get_backend() == "gloo" and dev.type == "cuda"
-        sbuf = values.index_select(0, self._idx(send_idx, dev)) if self.send_to is not None else None
+        on_gpu = dev.type == "cuda"
+        if on_gpu:
+            from . import _device as D
+            from . import _native
+
+            lib, st = _native.lib(), D.stream_ptr()
+        sbuf = None
+        if self.send_to is not None:
+            idx = self._idx(send_idx, dev)
+            if on_gpu:  # library kernels for the data path (64-bit indexing)
+                sbuf = torch.empty(idx.numel(), dtype=values.dtype, device=dev)
+                _native.check(lib.mpcx_gather_f64(values.data_ptr(), idx.data_ptr(), idx.numel(), sbuf.data_ptr(), st),
+                              "mpcx_gather_f64")
+            else:
+                sbuf = values.index_select(0, idx)
         rbuf = torch.empty(getattr(self, recv_idx).size, dtype=values.dtype, device=dev)
         if stage_cpu:
             sbuf = None if sbuf is None else sbuf.cpu()
@@ -219,7 +233,13 @@ class SlabExchange:
         for w in dist.batch_isend_irecv(ops) if ops else []:
             w.wait()
         if self.recv_from is not None:
-            values.index_add_(0, self._idx(recv_idx, dev), rbuf.to(dev))
+            idx = self._idx(recv_idx, dev)
+            if on_gpu:
+                rbuf = rbuf.to(dev)
+                _native.check(lib.mpcx_scatter_add_f64(values.data_ptr(), idx.data_ptr(), idx.numel(), rbuf.data_ptr(), st),
+                              "mpcx_scatter_add_f64")
+            else:
+                values.index_add_(0, idx, rbuf.to(dev))
 
     def reduce_matrix(self, A):
         """A.assemble() analogue: add the neighbour's partial sums into the owned rows."""

@@ -361,6 +361,13 @@ int mpcx_cg_step(int32_t n, const int32_t* rowptr, const int32_t* cols, const do
                  const double* dinv, double* x, double* r, double* z, double* p, double* Ap,
                  double* scal, int32_t k, void* stream);
 
+/* Interface exchange between GPUs (the `A.assemble()` / `ghostUpdate(ADD, REVERSE)` step of the
+ * reference, python/src/dolfinx_mpc/assemble_matrix.py:64, python/benchmarks/bench_periodic.py:108):
+ * pack out[i] = values[idx[i]] for the send buffer, values[idx[i]] += in[i] for the received partial
+ * sums.  All pointers DEVICE, 64-bit indices. */
+int mpcx_gather_f64(const double* values, const int64_t* idx, int64_t n, double* out, void* stream);
+int mpcx_scatter_add_f64(double* values, const int64_t* idx, int64_t n, const double* in, void* stream);
+
 /* misc */
 const char* mpcx_last_error(void);
 int mpcx_version(void);
