@@ -93,6 +93,10 @@ class MatrixArgs(C.Structure):
         ("mdofmap0", C.c_void_p),
         ("mdofmap1", C.c_void_p),
         ("lean", C.c_int32),
+        ("mpc_plan_off", C.c_void_p),
+        ("mpc_plan_pq", C.c_void_p),
+        ("mpc_plan_pos", C.c_void_p),
+        ("mpc_plan_coef", C.c_void_p),
         ("stream", C.c_void_p),
     ]
 
@@ -182,6 +186,10 @@ EXPORTS = [
     "mpcx_rowblock_plan_num_ents",
     "mpcx_rowblock_plan_copy",
     "mpcx_rowblock_plan_free",
+    "mpcx_mpc_plan_build",
+    "mpcx_mpc_plan_size",
+    "mpcx_mpc_plan_copy",
+    "mpcx_mpc_plan_free",
     "mpcx_compress_offsets",
     "mpcx_gather_f64",
     "mpcx_scatter_add_f64",
@@ -265,6 +273,14 @@ def lib() -> C.CDLL:
     L.mpcx_rowblock_plan_copy.restype = C.c_int
     L.mpcx_rowblock_plan_free.argtypes = [vp]
     L.mpcx_rowblock_plan_free.restype = None
+    L.mpcx_mpc_plan_build.argtypes = [i64, vp, i32, vp, vp, vp, i32, i32, vp, i32, i32] + [vp] * 12
+    L.mpcx_mpc_plan_build.restype = vp
+    L.mpcx_mpc_plan_size.argtypes = [vp]
+    L.mpcx_mpc_plan_size.restype = i64
+    L.mpcx_mpc_plan_copy.argtypes = [vp, vp, vp, vp, vp]
+    L.mpcx_mpc_plan_copy.restype = C.c_int
+    L.mpcx_mpc_plan_free.argtypes = [vp]
+    L.mpcx_mpc_plan_free.restype = None
     L.mpcx_compress_offsets.argtypes = [vp, i64, i32, i32, vp, vp]
     L.mpcx_compress_offsets.restype = i32
     L.mpcx_gather_f64.argtypes = [vp, vp, i64, vp, vp]

@@ -229,6 +229,41 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False):
     return A._plans[key]
 
 
+def _mpc_plan(A: MPCMatrix, form: Form, i: int, mpc0, mpc1, bc0_h, bc1_h, slave_ents_h):
+    """Scatter plan of the master contributions of integral i's slave entities (mpcx_mpc_plan_build:
+    the index logic of modify_mpc_cell evaluated once), as device tensors (off, pq, pos, coef); cached
+    on the matrix per (form, integral, constraints, Dirichlet markers)."""
+    key = ("mpc_plan", id(form), i, id(mpc0), id(mpc1), None if bc0_h is None else id(bc0_h),
+           None if bc1_h is None else id(bc1_h))
+    if key not in A._plans:
+        L = _native.lib()
+        p = _native._ptr
+        integ = form.integrals[i]
+        V0, V1 = form.function_spaces
+        ents = np.ascontiguousarray(integ.entities.astype(np.int32).reshape(-1))
+        c0, c1 = mpc0.coefficients()[0], mpc1.coefficients()[0]
+        h = L.mpcx_mpc_plan_build(
+            slave_ents_h.size, p(slave_ents_h), integ.estride, p(ents), p(ents), p(V0.dofmap.list), V0.element_ndofs,
+            V0.dofmap.bs, p(V1.dofmap.list), V1.element_ndofs, V1.dofmap.bs,
+            None if bc0_h is None else p(bc0_h), None if bc1_h is None else p(bc1_h),
+            p(mpc0.is_slave), p(mpc0.masters.offsets), p(mpc0.masters.array), p(c0),
+            p(mpc1.is_slave), p(mpc1.masters.offsets), p(mpc1.masters.array), p(c1), p(A.rowptr), p(A.cols))
+        if not h:
+            raise RuntimeError("mpcx_mpc_plan_build failed: " + L.mpcx_last_error().decode())
+        try:
+            n = L.mpcx_mpc_plan_size(h)
+            off = np.empty(slave_ents_h.size + 1, dtype=np.int64)
+            pq = np.empty(max(n, 1), dtype=np.int32)
+            pos = np.empty(max(n, 1), dtype=np.int32)
+            coef = np.empty(max(n, 1), dtype=np.float64)
+            L.mpcx_mpc_plan_copy(h, p(off), p(pq), p(pos), p(coef))
+        finally:
+            L.mpcx_mpc_plan_free(h)
+        dev = A.device
+        A._plans[key] = tuple(D._to_dev(t, dev) for t in (off, pq, pos, coef))
+    return A._plans[key]
+
+
 def _masked_dofmap(form: Form, V, bc_dev, mpc, which: int, rotate: bool = False):
     """dofmap with the Dirichlet/slave mask folded into bits 28.. (device, cached
     per (space, bcs, constraint)): replaces the marker gathers of
@@ -257,12 +292,12 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
     integ = form.integrals[i]
     md = D.mesh_device(form.mesh)
     s0, s1 = D.space_device(V0), D.space_device(V1)
-    _, bc0 = D.bc_markers(V0, bcs, form._device)
-    _, bc1 = D.bc_markers(V1, bcs, form._device)
+    bc0_h, bc0 = D.bc_markers(V0, bcs, form._device)
+    bc1_h, bc1 = D.bc_markers(V1, bcs, form._device)
     m0, k0 = mpc0._device()
     m1, k1 = mpc1._device()
     idv = D.integral_device(form, i)
-    _, slave_ents = _slave_entities(form, i, mpc0, mpc1)
+    slave_ents_h, slave_ents = _slave_entities(form, i, mpc0, mpc1)
     a = _native.MatrixArgs()
     a.nrows = A.shape[0]
     a.rowptr, a.cols, a.vals = A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), A.vals.data_ptr()
@@ -279,10 +314,14 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
     a.mpc0, a.mpc1 = m0, m1
     a.slave_entities = slave_ents.data_ptr()
     a.n_slave_entities = slave_ents.numel() if with_mpc_kernel else 0
+    mplan = None
+    if a.n_slave_entities > 0 and not os.environ.get("MPCX_NO_MPC_PLAN"):
+        mplan = _mpc_plan(A, form, i, mpc0, mpc1, bc0_h, bc1_h, slave_ents_h)
+        a.mpc_plan_off, a.mpc_plan_pq, a.mpc_plan_pos, a.mpc_plan_coef = (t.data_ptr() for t in mplan)
     a.algorithm = alg
     a.store_mode = store_mode
     a.stream = D.stream_ptr()
-    keep = [md, s0, s1, bc0, bc1, k0, k1, idv, slave_ents]
+    keep = [md, s0, s1, bc0, bc1, k0, k1, idv, slave_ents, mplan]
     if alg == 2:
         # lean path (include/mpcx.h, mpcx_matrix_args_t::lean): square P1-type form over all cells
         same = V1 is V0 and mpc1 is mpc0 and bc1 is bc0

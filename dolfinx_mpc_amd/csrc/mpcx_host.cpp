@@ -430,6 +430,128 @@ extern "C" int mpcx_rowblock_plan_copy(void* p, int32_t* block_row0, int64_t* bl
 extern "C" void mpcx_rowblock_plan_free(void* p) { delete static_cast<RowBlockPlan*>(p); }
 
 // ---------------------------------------------------------------------------
+// Scatter plan of the master contributions of slave entities: the index logic of modify_mpc_cell
+// (cpp/assemble_matrix.cpp:182-267) evaluated once on the host -- which entry (p, q) of the element
+// tensor goes, times which coefficient, to which position of the CSR values -- so that the device
+// kernel is a list of multiply-adds instead of chains of dependent CSR searches.
+namespace
+{
+struct MpcPlan
+{
+  std::vector<int64_t> off; // [n_slave_entities + 1]
+  std::vector<int32_t> pq;  // p * N1 + q
+  std::vector<int32_t> pos; // position in vals
+  std::vector<double> coef;
+};
+inline int host_csr_find(const int32_t* cols, int lo, int hi, int col)
+{
+  const int32_t* b = cols + lo;
+  const int32_t* e = cols + hi;
+  const int32_t* it = std::lower_bound(b, e, col);
+  return (it != e && *it == col) ? int(it - cols) : -1;
+}
+} // namespace
+
+extern "C" void* mpcx_mpc_plan_build(int64_t n_slave_entities, const int32_t* slave_entities, int32_t estride,
+                                     const int32_t* entities0, const int32_t* entities1, const int32_t* dofmap0,
+                                     int32_t nd0, int32_t bs0, const int32_t* dofmap1, int32_t nd1, int32_t bs1,
+                                     const int8_t* bc0, const int8_t* bc1, const int8_t* is_slave0,
+                                     const int32_t* m_off0, const int32_t* masters0, const double* coeffs0,
+                                     const int8_t* is_slave1, const int32_t* m_off1, const int32_t* masters1,
+                                     const double* coeffs1, const int32_t* rowptr, const int32_t* cols)
+{
+  auto* P = new MpcPlan;
+  P->off.assign(size_t(n_slave_entities) + 1, 0);
+  const int N0 = nd0 * bs0, N1 = nd1 * bs1;
+  std::vector<int32_t> rows(N0), colsd(N1);
+  std::vector<char> rbc(N0), cbc(N1), rsl(N0), csl(N1);
+  for (int64_t t = 0; t < n_slave_entities; ++t)
+  {
+    const int64_t e = slave_entities[t];
+    const int64_t cell0 = entities0 ? entities0[e * estride] : e;
+    const int64_t cell1 = entities1 ? entities1[e * estride] : e;
+    for (int i = 0; i < nd0; ++i)
+      for (int k = 0; k < bs0; ++k)
+      {
+        const int32_t r = dofmap0[cell0 * nd0 + i] * bs0 + k;
+        rows[i * bs0 + k] = r;
+        rbc[i * bs0 + k] = bc0 && bc0[r];
+        rsl[i * bs0 + k] = is_slave0[r];
+      }
+    for (int j = 0; j < nd1; ++j)
+      for (int k = 0; k < bs1; ++k)
+      {
+        const int32_t c = dofmap1[cell1 * nd1 + j] * bs1 + k;
+        colsd[j * bs1 + k] = c;
+        cbc[j * bs1 + k] = bc1 && bc1[c];
+        csl[j * bs1 + k] = is_slave1[c];
+      }
+    auto emit = [&](int p, int q, int pos, double c)
+    {
+      if (pos < 0 || rbc[p] || cbc[q]) // Dirichlet rows/cols of the element tensor are zero (:510-533)
+        return;
+      P->pq.push_back(p * N1 + q);
+      P->pos.push_back(pos);
+      P->coef.push_back(c);
+    };
+    // row masters (:214-246)
+    for (int p = 0; p < N0; ++p)
+    {
+      if (!rsl[p])
+        continue;
+      for (int mi = m_off0[rows[p]]; mi < m_off0[rows[p] + 1]; ++mi)
+      {
+        const int32_t m = masters0[mi];
+        const double ci = coeffs0[mi];
+        const int lo = rowptr[m], hi = rowptr[m + 1];
+        for (int q = 0; q < N1; ++q)
+        {
+          if (csl[q])
+          {
+            // master-master term from the un-stripped tensor (:239-245)
+            for (int mj = m_off1[colsd[q]]; mj < m_off1[colsd[q] + 1]; ++mj)
+              emit(p, q, host_csr_find(cols, lo, hi, masters1[mj]), ci * coeffs1[mj]);
+          }
+          else
+            emit(p, q, host_csr_find(cols, lo, hi, colsd[q]), ci); // stripped row (:226-236)
+        }
+      }
+    }
+    // column masters (:251-267)
+    for (int q = 0; q < N1; ++q)
+    {
+      if (!csl[q])
+        continue;
+      for (int mj = m_off1[colsd[q]]; mj < m_off1[colsd[q] + 1]; ++mj)
+      {
+        const int32_t m = masters1[mj];
+        const double cj = coeffs1[mj];
+        for (int p = 0; p < N0; ++p)
+        {
+          if (rsl[p])
+            continue;
+          emit(p, q, host_csr_find(cols, rowptr[rows[p]], rowptr[rows[p] + 1], m), cj);
+        }
+      }
+    }
+    P->off[t + 1] = int64_t(P->pq.size());
+  }
+  return P;
+}
+
+extern "C" int64_t mpcx_mpc_plan_size(void* plan) { return int64_t(static_cast<MpcPlan*>(plan)->pq.size()); }
+extern "C" int mpcx_mpc_plan_copy(void* plan, int64_t* off, int32_t* pq, int32_t* pos, double* coef)
+{
+  auto* P = static_cast<MpcPlan*>(plan);
+  std::memcpy(off, P->off.data(), P->off.size() * sizeof(int64_t));
+  std::memcpy(pq, P->pq.data(), P->pq.size() * sizeof(int32_t));
+  std::memcpy(pos, P->pos.data(), P->pos.size() * sizeof(int32_t));
+  std::memcpy(coef, P->coef.data(), P->coef.size() * sizeof(double));
+  return 0;
+}
+extern "C" void mpcx_mpc_plan_free(void* plan) { delete static_cast<MpcPlan*>(plan); }
+
+// ---------------------------------------------------------------------------
 // Dictionary compression of the scatter-offset table: distinct rows -> ids.
 extern "C" int32_t mpcx_compress_offsets(const uint8_t* rows, int64_t n, int32_t noff, int32_t max_patterns,
                                          uint16_t* pattern_ids, uint8_t* table)
