@@ -93,9 +93,11 @@ class MatrixArgs(C.Structure):
         ("mdofmap0", C.c_void_p),
         ("mdofmap1", C.c_void_p),
         ("lean", C.c_int32),
+        ("mpc_plan_targets", C.c_int64),
+        ("mpc_plan_tgt", C.c_void_p),
         ("mpc_plan_off", C.c_void_p),
+        ("mpc_plan_ent", C.c_void_p),
         ("mpc_plan_pq", C.c_void_p),
-        ("mpc_plan_pos", C.c_void_p),
         ("mpc_plan_coef", C.c_void_p),
         ("stream", C.c_void_p),
     ]
@@ -188,6 +190,7 @@ EXPORTS = [
     "mpcx_rowblock_plan_free",
     "mpcx_mpc_plan_build",
     "mpcx_mpc_plan_size",
+    "mpcx_mpc_plan_num_targets",
     "mpcx_mpc_plan_copy",
     "mpcx_mpc_plan_free",
     "mpcx_compress_offsets",
@@ -277,7 +280,9 @@ def lib() -> C.CDLL:
     L.mpcx_mpc_plan_build.restype = vp
     L.mpcx_mpc_plan_size.argtypes = [vp]
     L.mpcx_mpc_plan_size.restype = i64
-    L.mpcx_mpc_plan_copy.argtypes = [vp, vp, vp, vp, vp]
+    L.mpcx_mpc_plan_num_targets.argtypes = [vp]
+    L.mpcx_mpc_plan_num_targets.restype = i64
+    L.mpcx_mpc_plan_copy.argtypes = [vp, vp, vp, vp, vp, vp]
     L.mpcx_mpc_plan_copy.restype = C.c_int
     L.mpcx_mpc_plan_free.argtypes = [vp]
     L.mpcx_mpc_plan_free.restype = None

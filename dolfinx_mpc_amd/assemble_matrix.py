@@ -230,9 +230,10 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False):
 
 
 def _mpc_plan(A: MPCMatrix, form: Form, i: int, mpc0, mpc1, bc0_h, bc1_h, slave_ents_h):
-    """Scatter plan of the master contributions of integral i's slave entities (mpcx_mpc_plan_build:
-    the index logic of modify_mpc_cell evaluated once), as device tensors (off, pq, pos, coef); cached
-    on the matrix per (form, integral, constraints, Dirichlet markers)."""
+    """Plan of the master contributions of integral i's slave entities (mpcx_mpc_plan_build: the index
+    logic of modify_mpc_cell evaluated once, gathered by target position), as device tensors
+    (tgt, off, ent, pq, coef) + a has-targets flag; cached on the matrix per (form, integral,
+    constraints, Dirichlet markers)."""
     key = ("mpc_plan", id(form), i, id(mpc0), id(mpc1), None if bc0_h is None else id(bc0_h),
            None if bc1_h is None else id(bc1_h))
     if key not in A._plans:
@@ -251,16 +252,17 @@ def _mpc_plan(A: MPCMatrix, form: Form, i: int, mpc0, mpc1, bc0_h, bc1_h, slave_
         if not h:
             raise RuntimeError("mpcx_mpc_plan_build failed: " + L.mpcx_last_error().decode())
         try:
-            n = L.mpcx_mpc_plan_size(h)
-            off = np.empty(slave_ents_h.size + 1, dtype=np.int64)
-            pq = np.empty(max(n, 1), dtype=np.int32)
-            pos = np.empty(max(n, 1), dtype=np.int32)
-            coef = np.empty(max(n, 1), dtype=np.float64)
-            L.mpcx_mpc_plan_copy(h, p(off), p(pq), p(pos), p(coef))
+            n, nt = L.mpcx_mpc_plan_size(h), L.mpcx_mpc_plan_num_targets(h)
+            tgt = np.zeros(max(nt, 1), dtype=np.int32)
+            off = np.zeros(max(nt, 1) + 1, dtype=np.int64)
+            ent = np.zeros(max(n, 1), dtype=np.int32)
+            pq = np.zeros(max(n, 1), dtype=np.int32)
+            coef = np.zeros(max(n, 1), dtype=np.float64)
+            L.mpcx_mpc_plan_copy(h, p(tgt), p(off), p(ent), p(pq), p(coef))
         finally:
             L.mpcx_mpc_plan_free(h)
         dev = A.device
-        A._plans[key] = tuple(D._to_dev(t, dev) for t in (off, pq, pos, coef))
+        A._plans[key] = tuple(D._to_dev(t, dev) for t in (tgt, off, ent, pq, coef)) + (nt > 0,)
     return A._plans[key]
 
 
@@ -317,7 +319,9 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
     mplan = None
     if a.n_slave_entities > 0 and not os.environ.get("MPCX_NO_MPC_PLAN"):
         mplan = _mpc_plan(A, form, i, mpc0, mpc1, bc0_h, bc1_h, slave_ents_h)
-        a.mpc_plan_off, a.mpc_plan_pq, a.mpc_plan_pos, a.mpc_plan_coef = (t.data_ptr() for t in mplan)
+        a.mpc_plan_targets = mplan[0].numel() if mplan[5] else 0
+        (a.mpc_plan_tgt, a.mpc_plan_off, a.mpc_plan_ent, a.mpc_plan_pq,
+         a.mpc_plan_coef) = (t.data_ptr() for t in mplan[:5])
     a.algorithm = alg
     a.store_mode = store_mode
     a.stream = D.stream_ptr()

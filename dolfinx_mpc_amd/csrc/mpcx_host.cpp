@@ -438,10 +438,14 @@ namespace
 {
 struct MpcPlan
 {
-  std::vector<int64_t> off; // [n_slave_entities + 1]
-  std::vector<int32_t> pq;  // p * N1 + q
-  std::vector<int32_t> pos; // position in vals
+  // gathered by target: target k (position tgt_pos[k] of vals) sums coef * Ae_ent[pq] over its tuples
+  std::vector<int32_t> tgt_pos; // [n_targets] distinct positions, ascending
+  std::vector<int64_t> off;     // [n_targets + 1] into the tuple arrays
+  std::vector<int32_t> ent;     // entity (index into the integral's entity list) of every tuple
+  std::vector<int32_t> pq;      // p * N1 + q
   std::vector<double> coef;
+  // scratch while building
+  std::vector<int32_t> pos;
 };
 inline int host_csr_find(const int32_t* cols, int lo, int hi, int col)
 {
@@ -461,7 +465,6 @@ extern "C" void* mpcx_mpc_plan_build(int64_t n_slave_entities, const int32_t* sl
                                      const double* coeffs1, const int32_t* rowptr, const int32_t* cols)
 {
   auto* P = new MpcPlan;
-  P->off.assign(size_t(n_slave_entities) + 1, 0);
   const int N0 = nd0 * bs0, N1 = nd1 * bs1;
   std::vector<int32_t> rows(N0), colsd(N1);
   std::vector<char> rbc(N0), cbc(N1), rsl(N0), csl(N1);
@@ -490,6 +493,7 @@ extern "C" void* mpcx_mpc_plan_build(int64_t n_slave_entities, const int32_t* sl
     {
       if (pos < 0 || rbc[p] || cbc[q]) // Dirichlet rows/cols of the element tensor are zero (:510-533)
         return;
+      P->ent.push_back(int32_t(e));
       P->pq.push_back(p * N1 + q);
       P->pos.push_back(pos);
       P->coef.push_back(c);
@@ -534,18 +538,47 @@ extern "C" void* mpcx_mpc_plan_build(int64_t n_slave_entities, const int32_t* sl
         }
       }
     }
-    P->off[t + 1] = int64_t(P->pq.size());
   }
+  // group the tuples by target position (stable: entity order inside a target is kept)
+  const size_t n = P->pos.size();
+  std::vector<int64_t> order(n);
+  std::iota(order.begin(), order.end(), int64_t(0));
+  std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return P->pos[x] < P->pos[y]; });
+  std::vector<int32_t> ent(n), pq(n);
+  std::vector<double> coef(n);
+  P->off.push_back(0);
+  for (size_t k = 0; k < n; ++k)
+  {
+    const int64_t src = order[k];
+    ent[k] = P->ent[src];
+    pq[k] = P->pq[src];
+    coef[k] = P->coef[src];
+    if (k == 0 || P->pos[src] != P->tgt_pos.back())
+    {
+      if (k > 0)
+        P->off.push_back(int64_t(k));
+      P->tgt_pos.push_back(P->pos[src]);
+    }
+  }
+  if (n > 0)
+    P->off.push_back(int64_t(n));
+  P->ent.swap(ent);
+  P->pq.swap(pq);
+  P->coef.swap(coef);
+  P->pos.clear();
+  P->pos.shrink_to_fit();
   return P;
 }
 
 extern "C" int64_t mpcx_mpc_plan_size(void* plan) { return int64_t(static_cast<MpcPlan*>(plan)->pq.size()); }
-extern "C" int mpcx_mpc_plan_copy(void* plan, int64_t* off, int32_t* pq, int32_t* pos, double* coef)
+extern "C" int64_t mpcx_mpc_plan_num_targets(void* plan) { return int64_t(static_cast<MpcPlan*>(plan)->tgt_pos.size()); }
+extern "C" int mpcx_mpc_plan_copy(void* plan, int32_t* tgt_pos, int64_t* off, int32_t* ent, int32_t* pq, double* coef)
 {
   auto* P = static_cast<MpcPlan*>(plan);
+  std::memcpy(tgt_pos, P->tgt_pos.data(), P->tgt_pos.size() * sizeof(int32_t));
   std::memcpy(off, P->off.data(), P->off.size() * sizeof(int64_t));
+  std::memcpy(ent, P->ent.data(), P->ent.size() * sizeof(int32_t));
   std::memcpy(pq, P->pq.data(), P->pq.size() * sizeof(int32_t));
-  std::memcpy(pos, P->pos.data(), P->pos.size() * sizeof(int32_t));
   std::memcpy(coef, P->coef.data(), P->coef.size() * sizeof(double));
   return 0;
 }

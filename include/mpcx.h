@@ -154,12 +154,15 @@ typedef struct
    * rotate = 1; the kernel then reads only mdofmap0 + ent_offs per entity and takes the
    * geometry nodes from mdofmap0.  Checked; violating calls are rejected. */
   int32_t lean;
-  /* Optional scatter plan of the slave entities' master contributions (mpcx_mpc_plan_build), DEVICE:
-   * entity t of slave_entities adds coef[k] * Ae[pq[k] / N1][pq[k] % N1] to vals[pos[k]] for
-   * k in [off[t], off[t+1]).  NULL: the kernel searches the CSR rows itself. */
+  /* Optional plan of the slave entities' master contributions (mpcx_mpc_plan_build), DEVICE, gathered by
+   * target: position mpc_plan_tgt[t] of vals receives the sum over k in [off[t], off[t+1]) of
+   * coef[k] * Ae(entity ent[k])[pq[k] / N1][pq[k] % N1].  mpc_plan_off == NULL: the kernel walks the
+   * slave entities and searches the CSR rows itself (device atomics). */
+  int64_t mpc_plan_targets;
+  const int32_t* mpc_plan_tgt;
   const int64_t* mpc_plan_off;
+  const int32_t* mpc_plan_ent;
   const int32_t* mpc_plan_pq;
-  const int32_t* mpc_plan_pos;
   const double* mpc_plan_coef;
   void* stream;
 } mpcx_matrix_args_t;
@@ -338,10 +341,10 @@ int mpcx_rowblock_plan_copy(void* plan, int32_t* block_row0, int64_t* block_ent_
                             int32_t* block_ents);
 void mpcx_rowblock_plan_free(void* plan);
 
-/* HOST: scatter plan of the master contributions (the index logic of modify_mpc_cell,
- * cpp/assemble_matrix.cpp:182-267, evaluated once): for every slave entity the list of
- * (element-tensor entry p*N1+q, coefficient, position in the CSR values).  Dirichlet rows/cols of the
- * element tensor contribute nothing; entities0/1 may be NULL (= identity); bc0/bc1 may be NULL. */
+/* HOST: plan of the master contributions (the index logic of modify_mpc_cell,
+ * cpp/assemble_matrix.cpp:182-267, evaluated once), gathered by target position of the CSR values:
+ * tuples (entity, element-tensor entry p*N1+q, coefficient).  Dirichlet rows/cols of the element
+ * tensor contribute nothing; entities0/1 may be NULL (= identity); bc0/bc1 may be NULL. */
 void* mpcx_mpc_plan_build(int64_t n_slave_entities, const int32_t* slave_entities, int32_t estride,
                           const int32_t* entities0, const int32_t* entities1, const int32_t* dofmap0,
                           int32_t nd0, int32_t bs0, const int32_t* dofmap1, int32_t nd1, int32_t bs1,
@@ -349,8 +352,9 @@ void* mpcx_mpc_plan_build(int64_t n_slave_entities, const int32_t* slave_entitie
                           const int32_t* masters_offsets0, const int32_t* masters0, const double* coeffs0,
                           const int8_t* is_slave1, const int32_t* masters_offsets1, const int32_t* masters1,
                           const double* coeffs1, const int32_t* rowptr, const int32_t* cols);
-int64_t mpcx_mpc_plan_size(void* plan);
-int mpcx_mpc_plan_copy(void* plan, int64_t* off, int32_t* pq, int32_t* pos, double* coef);
+int64_t mpcx_mpc_plan_size(void* plan);        /* tuples */
+int64_t mpcx_mpc_plan_num_targets(void* plan); /* distinct positions */
+int mpcx_mpc_plan_copy(void* plan, int32_t* tgt_pos, int64_t* off, int32_t* ent, int32_t* pq, double* coef);
 void mpcx_mpc_plan_free(void* plan);
 
 /* HOST: dictionary-compress n rows of `noff` bytes (the scatter-offset table copied to the
