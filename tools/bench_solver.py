@@ -13,7 +13,6 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import bench  # noqa: E402
-import dolfinx_mpc_amd as dm  # noqa: E402
 from dolfinx_mpc_amd import _device as D  # noqa: E402
 from dolfinx_mpc_amd import _native  # noqa: E402
 from dolfinx_mpc_amd.la import Vector  # noqa: E402

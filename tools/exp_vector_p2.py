@@ -2,7 +2,6 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np
 import torch
 import dolfinx_mpc_amd as dm
 from dolfinx_mpc_amd import fem
