@@ -192,15 +192,22 @@ def main():
 
         exchange = SlabExchange(mesh, rowptr, cols, rank, world, device=torch.device("cuda", dev_index))
 
+    # the interface rows of the matrix travel while the vector kernel runs: post the transfer after the
+    # matrix assembly, finish it (wait + add) after the vector assembly
+    pending = []
+
     def step_matrix():
         dm.assemble_matrix(a, mpc, bcs=bcs, A=A, algorithm=args.alg)
         if exchange is not None:
-            exchange.reduce_matrix(A)
+            pending.append(exchange.reduce_matrix_begin(A))
 
     def step_vector():
         dm.assemble_vector(L, mpc, b=b)
         if exchange is not None:
-            exchange.reduce_vector(b)
+            pending.append(exchange.reduce_vector_begin(b))
+            for h in pending:
+                exchange.finish(h)
+            pending.clear()
 
     t = time.time()
     step_matrix()

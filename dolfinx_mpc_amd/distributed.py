@@ -199,26 +199,25 @@ class SlabExchange:
             self._tensors[key] = torch.from_numpy(np.ascontiguousarray(getattr(self, name))).to(torch.int64).to(dev)
         return self._tensors[key]
 
-    def _exchange(self, values, send_idx, recv_idx):
-        """values: 1-D fp64 tensor (CSR values or vector), modified in place."""
+    def _begin(self, values, send_idx, recv_idx):
+        """Pack the send buffer and post the neighbour send / receive; returns a handle for ``finish``.
+        Nothing waits here: work enqueued afterwards (the next assembly kernel) overlaps the transfer."""
         import torch
         import torch.distributed as dist
 
         dev = values.device
         stage_cpu = dist.get_backend() == "gloo" and dev.type == "cuda"
         on_gpu = dev.type == "cuda"
-        if on_gpu:
-            from . import _device as D
-            from . import _native
-
-            lib, st = _native.lib(), D.stream_ptr()
         sbuf = None
         if self.send_to is not None:
             idx = self._idx(send_idx, dev)
             if on_gpu:  # library kernels for the data path (64-bit indexing)
+                from . import _device as D
+                from . import _native
+
                 sbuf = torch.empty(idx.numel(), dtype=values.dtype, device=dev)
-                _native.check(lib.mpcx_gather_f64(values.data_ptr(), idx.data_ptr(), idx.numel(), sbuf.data_ptr(), st),
-                              "mpcx_gather_f64")
+                _native.check(_native.lib().mpcx_gather_f64(values.data_ptr(), idx.data_ptr(), idx.numel(),
+                                                            sbuf.data_ptr(), D.stream_ptr()), "mpcx_gather_f64")
             else:
                 sbuf = values.index_select(0, idx)
         rbuf = torch.empty(getattr(self, recv_idx).size, dtype=values.dtype, device=dev)
@@ -230,16 +229,38 @@ class SlabExchange:
             ops.append(dist.P2POp(dist.isend, sbuf, self.send_to))
         if self.recv_from is not None:
             ops.append(dist.P2POp(dist.irecv, rbuf, self.recv_from))
-        for w in dist.batch_isend_irecv(ops) if ops else []:
+        works = dist.batch_isend_irecv(ops) if ops else []
+        return (values, recv_idx, sbuf, rbuf, works)
+
+    def finish(self, handle):
+        """Wait for the transfer of ``handle`` and add the received partial sums into the owned rows."""
+        if handle is None:
+            return
+        values, recv_idx, _sbuf, rbuf, works = handle
+        for w in works:
             w.wait()
         if self.recv_from is not None:
+            dev = values.device
             idx = self._idx(recv_idx, dev)
-            if on_gpu:
+            if dev.type == "cuda":
+                from . import _device as D
+                from . import _native
+
                 rbuf = rbuf.to(dev)
-                _native.check(lib.mpcx_scatter_add_f64(values.data_ptr(), idx.data_ptr(), idx.numel(), rbuf.data_ptr(), st),
-                              "mpcx_scatter_add_f64")
+                _native.check(_native.lib().mpcx_scatter_add_f64(values.data_ptr(), idx.data_ptr(), idx.numel(),
+                                                                 rbuf.data_ptr(), D.stream_ptr()), "mpcx_scatter_add_f64")
             else:
                 values.index_add_(0, idx, rbuf.to(dev))
+
+    def _exchange(self, values, send_idx, recv_idx):
+        """values: 1-D fp64 tensor (CSR values or vector), modified in place."""
+        self.finish(self._begin(values, send_idx, recv_idx))
+
+    def reduce_matrix_begin(self, A):
+        return self._begin(A.vals if hasattr(A, "vals") else A, "send_pos", "recv_pos")
+
+    def reduce_vector_begin(self, b):
+        return self._begin(b.array if hasattr(b, "array") else b, "send_rows", "recv_rows")
 
     def reduce_matrix(self, A):
         """A.assemble() analogue: add the neighbour's partial sums into the owned rows."""
