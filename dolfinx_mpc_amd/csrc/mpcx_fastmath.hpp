@@ -141,7 +141,7 @@ MPCX_HD inline double fast_exp_nonpos(double y)
 {
   const double INV = 0x1.71547652b82fep+6;
   const double L_HI = 0x1.62e42fee00000p-7, L_LO = 0x1.a39ef35793c76p-39;
-  y = y < -708.0 ? -708.0 : y; // exp(-708) = 3.3e-308, still normal after the scaling below
+  y = std::fmax(y, -708.0); // one v_max_f64; exp(-708) = 3.3e-308, still normal after the scaling below
   const double n = std::rint(y * INV);
   double r = std::fma(-n, L_HI, y);
   r = std::fma(-n, L_LO, r);
