@@ -3,6 +3,8 @@ provider; the kernels only ever see raw pointers through the C ABI)."""
 
 from __future__ import annotations
 
+from collections import OrderedDict
+
 import numpy as np
 
 from . import _native
@@ -13,6 +15,26 @@ def _to_dev(a: np.ndarray, dev):
     import torch
 
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def cached(store: dict, kind: str, objs, extra, build, maxsize: int = 8):
+    """Small LRU cache inside ``store`` (the ``_device`` / ``_cache`` / ``_plans`` dict of the object
+    that owns the derived data), keyed by the IDENTITY of ``objs`` plus the hashable ``extra``.
+    Every entry keeps strong references to its key objects, so their ids cannot be handed to new
+    objects while the entry lives, and a hit is confirmed with ``is``.  (Keys made of bare ``id()``s
+    can silently match a new form / bc / constraint that inherited the id of a collected one.)"""
+    od = store.setdefault(("objcache", kind), OrderedDict())
+    objs = tuple(objs)
+    key = (tuple(id(o) for o in objs), extra)
+    hit = od.get(key)
+    if hit is not None and all(a is b for a, b in zip(hit[0], objs)):
+        od.move_to_end(key)
+        return hit[1]
+    val = build()
+    od[key] = (objs, val)
+    while len(od) > maxsize:
+        od.popitem(last=False)
+    return val
 
 
 def mesh_device(mesh):
@@ -42,16 +64,21 @@ def space_device(V: FunctionSpace):
 
 
 def integral_device(form: Form, i: int):
-    """entities / coefficients / constants / quadrature tables of integral i."""
+    """entities / quadrature tables of integral i (structural: uploaded once) and its packed
+    coefficients / constants, which are VALUES: refreshed whenever the coefficient's dof array was
+    handed out again or the constants differ from the uploaded copy (the reference packs both on every
+    call, cpp/assemble_matrix.cpp:583-589)."""
     dev = _native.require_gpu()
     key = (str(dev), i)
+    integ: Integral = form.integrals[i]
     if key not in form._device:
-        integ: Integral = form.integrals[i]
         k = integ.kernel
         d = {
             "entities": _to_dev(integ.entities.astype(np.int32).reshape(-1), dev),
-            "coeffs": None if integ.coeffs is None else _to_dev(integ.coeffs.astype(np.float64), dev),
-            "constants": None if integ.constants is None else _to_dev(integ.constants.astype(np.float64), dev),
+            "coeffs": None,
+            "coeff_version": ("never",),
+            "constants": None,
+            "constants_host": None,
             "qpts": _to_dev(k.qpts.astype(np.float64).reshape(-1), dev),
             "qwts": _to_dev(k.qwts.astype(np.float64), dev),
             "fqpts": _to_dev(k.fqpts.astype(np.float64).reshape(-1), dev),
@@ -67,7 +94,15 @@ def integral_device(form: Form, i: int):
             d["qpts"].data_ptr(), d["qwts"].data_ptr(), d["fqpts"].data_ptr(), d["fqwts"].data_ptr(),
         )
         form._device[key] = d
-    return form._device[key]
+    d = form._device[key]
+    if integ.coefficient is not None and d["coeff_version"] != integ.coeff_version:
+        d["coeffs"] = _to_dev(integ.coeffs.astype(np.float64, copy=False), dev)
+        d["coeff_version"] = integ.coeff_version
+    c = integ.constants
+    if c is not None and (d["constants_host"] is None or not np.array_equal(c, d["constants_host"])):
+        d["constants_host"] = c.copy()
+        d["constants"] = _to_dev(d["constants_host"], dev)
+    return d
 
 
 def bc_markers(V: FunctionSpace, bcs, cache: dict):
@@ -77,13 +112,47 @@ def bc_markers(V: FunctionSpace, bcs, cache: dict):
     if not mine:
         return None, None
     dev = _native.require_gpu()
-    key = ("bcm", str(dev), id(V), tuple(id(bc) for bc in mine))
-    if key not in cache:
+
+    def build():
         m = np.zeros(V.num_dofs, dtype=np.int8)
         for bc in mine:
             bc.mark_dofs(m)
-        cache[key] = (m, _to_dev(m, dev))
-    return cache[key]
+        return (m, _to_dev(m, dev))
+
+    return cached(cache, "bcm", [V] + mine, str(dev), build)
+
+
+def bc_values(V: FunctionSpace, bcs, cache: dict):
+    """(host markers, device markers, device values) over the unrolled dofs of V for lifting
+    (cpp/lifting.h:166-180).  The markers and dof lists are structural and cached per (space, bcs);
+    the VALUES are read from the live bc objects on every call -- a time-dependent boundary function
+    or a constant changed between solves must reach the kernel, as set_bc re-reads them too -- and
+    re-uploaded only when they differ from what the device holds."""
+    import torch
+
+    dev = _native.require_gpu()
+    bcs = list(bcs)
+
+    def build():
+        markers = np.zeros(V.num_dofs, dtype=np.int8)
+        for bc in bcs:
+            bc.dof_indices()  # settles the owned-first order of bc._dofs
+            bc.mark_dofs(markers)
+        return {"markers": markers, "d_markers": _to_dev(markers, dev),
+                "d_values": torch.zeros(V.num_dofs, dtype=torch.float64, device=dev),
+                "d_dofs": [_to_dev(bc._dofs.astype(np.int64), dev) for bc in bcs], "g": [None] * len(bcs)}
+
+    s = cached(cache, "lift", [V] + bcs, str(dev), build)
+    for k, bc in enumerate(bcs):
+        g = bc.values_at_dofs()
+        if s["g"][k] is None or not np.array_equal(g, s["g"][k]):
+            # later bcs override earlier ones on shared dofs: refresh this and every later bc in order
+            for k2 in range(k, len(bcs)):
+                g2 = bcs[k2].values_at_dofs()
+                s["g"][k2] = g2.copy()
+                s["d_values"][s["d_dofs"][k2]] = _to_dev(g2, dev)
+            break
+    return s["markers"], s["d_markers"], s["d_values"]
 
 
 def ptr(t):

@@ -25,8 +25,8 @@ ROWBLOCK_MAX_NNZ = int(os.environ.get("MPCX_ROWBLOCK_MAX_NNZ", 9216))
 ROWBLOCK_MAX_ROWS = int(os.environ.get("MPCX_ROWBLOCK_MAX_ROWS", 512))
 # the lean scalar P1 kernel needs 64 VGPRs only: half-size blocks (half tiles of an 8x8x8 numbering) put
 # four workgroups of 512 threads on a CU -- 1.75 ms against 1.82 ms at config 2 (sweep in DESIGN.md section 5)
-ROWBLOCK_LIGHT_MAX_NNZ = int(os.environ.get("MPCX_ROWBLOCK_MAX_NNZ", 4608))
-ROWBLOCK_LIGHT_MAX_ROWS = int(os.environ.get("MPCX_ROWBLOCK_MAX_ROWS", 256))
+ROWBLOCK_LIGHT_MAX_NNZ = int(os.environ.get("MPCX_ROWBLOCK_LIGHT_MAX_NNZ", 4608))
+ROWBLOCK_LIGHT_MAX_ROWS = int(os.environ.get("MPCX_ROWBLOCK_LIGHT_MAX_ROWS", 256))
 # scatter-offset rows are dictionary-compressed when at most this many are distinct (table stays cache resident)
 MAX_OFFSET_PATTERNS = 4096
 
@@ -151,22 +151,21 @@ def create_matrix(form: Form, mpc0: MultiPointConstraint, mpc1: Optional[MultiPo
 
 def _slave_entities(form: Form, i: int, mpc0, mpc1):
     """entity indices of integral i whose cell holds a slave of mpc0 or mpc1."""
-    key = ("slave_ents", id(form), i, id(mpc1))
-    if key not in mpc0._cache:
+    def build():
         cells = form.integrals[i].cells
         n0 = np.diff(mpc0.cell_to_slaves.offsets)[cells]
         n1 = np.diff(mpc1.cell_to_slaves.offsets)[cells]
         idx = np.flatnonzero((n0 > 0) | (n1 > 0)).astype(np.int32)
-        mpc0._cache[key] = (idx, D._to_dev(idx, _native.require_gpu()))
-    return mpc0._cache[key]
+        return (idx, D._to_dev(idx, _native.require_gpu()))
+
+    return D.cached(form._device, "slave_ents", (mpc0, mpc1), i, build)
 
 
 def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False):
     light = lean and V0.dofmap.bs == 1 and V0.element_ndofs <= 4
     max_rows_cap, max_nnz_cap = ((ROWBLOCK_LIGHT_MAX_ROWS, ROWBLOCK_LIGHT_MAX_NNZ) if light
                                  else (ROWBLOCK_MAX_ROWS, ROWBLOCK_MAX_NNZ))
-    key = (id(form), i, max_nnz_cap, max_rows_cap, lean)
-    if key not in A._plans:
+    def build():
         L = _native.lib()
         p = _native._ptr
         integ = form.integrals[i]
@@ -224,9 +223,11 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False):
         max_nnz = int(np.diff(A.rowptr[row0].astype(np.int64)).max())
         s = _native.RowBlockPlanT(nb, max_rows, max_nnz, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
                                   t[3].data_ptr(), D.ptr(pattern))
-        A._plans[key] = (s, t, {"num_blocks": nb, "num_ents": int(ents_b.size), "max_rows": max_rows,
-                                "max_nnz": max_nnz, "offset_patterns": npat})
-    return A._plans[key]
+        return (s, t, {"num_blocks": nb, "num_ents": int(ents_b.size), "max_rows": max_rows,
+                       "max_nnz": max_nnz, "offset_patterns": npat,
+                       "bytes": int(sum(x.numel() * x.element_size() for x in t if x is not None))})
+
+    return D.cached(A._plans, "rowblock", (form,), (i, max_nnz_cap, max_rows_cap, lean), build)
 
 
 def _mpc_plan(A: MPCMatrix, form: Form, i: int, mpc0, mpc1, bc0_h, bc1_h, slave_ents_h):
@@ -234,9 +235,7 @@ def _mpc_plan(A: MPCMatrix, form: Form, i: int, mpc0, mpc1, bc0_h, bc1_h, slave_
     logic of modify_mpc_cell evaluated once, gathered by target position), as device tensors
     (tgt, off, ent, pq, coef) + a has-targets flag; cached on the matrix per (form, integral,
     constraints, Dirichlet markers)."""
-    key = ("mpc_plan", id(form), i, id(mpc0), id(mpc1), None if bc0_h is None else id(bc0_h),
-           None if bc1_h is None else id(bc1_h))
-    if key not in A._plans:
+    def build():
         L = _native.lib()
         p = _native._ptr
         integ = form.integrals[i]
@@ -262,8 +261,10 @@ def _mpc_plan(A: MPCMatrix, form: Form, i: int, mpc0, mpc1, bc0_h, bc1_h, slave_
         finally:
             L.mpcx_mpc_plan_free(h)
         dev = A.device
-        A._plans[key] = tuple(D._to_dev(t, dev) for t in (tgt, off, ent, pq, coef)) + (nt > 0,)
-    return A._plans[key]
+        return tuple(D._to_dev(t, dev) for t in (tgt, off, ent, pq, coef)) + (nt > 0,)
+
+    # bc0_h / bc1_h are the marker arrays cached per (space, bcs): their identity stands for the bc set
+    return D.cached(A._plans, "mpc_plan", (form, mpc0, mpc1, bc0_h, bc1_h), i, build)
 
 
 def _masked_dofmap(form: Form, V, bc_dev, mpc, which: int, rotate: bool = False):
@@ -272,8 +273,7 @@ def _masked_dofmap(form: Form, V, bc_dev, mpc, which: int, rotate: bool = False)
     cpp/assemble_matrix.cpp:511-533 and the is_slave look-ups in the bulk kernel."""
     import torch
 
-    key = ("mdof", which, id(V), id(mpc), None if bc_dev is None else bc_dev.data_ptr(), rotate)
-    if key not in form._device:
+    def build():
         if V.num_dofs // V.dofmap.bs >= (1 << 28):
             raise RuntimeError("row-block algorithm: more than 2^28 dof blocks per GPU; shard the mesh")
         sd = D.space_device(V)
@@ -283,8 +283,10 @@ def _masked_dofmap(form: Form, V, bc_dev, mpc, which: int, rotate: bool = False)
                                             V.dofmap.bs, D.ptr(bc_dev), t["is_slave"].data_ptr(), int(rotate),
                                             out.data_ptr(), D.stream_ptr())
         _native.check(rc, "mpcx_mask_dofmap")
-        form._device[key] = out
-    return form._device[key]
+        return out
+
+    # bc_dev is the marker tensor cached per (space, bcs): its identity stands for the bc set
+    return D.cached(form._device, "mdof", (V, mpc, bc_dev), (which, rotate), build, maxsize=4)
 
 
 def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, store_mode: int = 0,
@@ -391,8 +393,9 @@ def assemble_matrix(
     for i, integ in enumerate(form.integrals):
         if integ.itype not in ("cell", "exterior_facet"):
             raise RuntimeError("Not implemented yet")  # cpp/assemble_matrix.cpp:658-659
-        if alg == 2:
-            # the first integral's row blocks overwrite every value: no memset pass
+        if alg == 2 and (zeroed or integ.num_entities > 0):
+            # the first non-empty integral's row blocks overwrite every value: no memset pass (an empty
+            # integral launches nothing, so it must not count as having cleared a reused matrix)
             store_mode = 0 if zeroed else 1
             zeroed = True
         else:
@@ -419,11 +422,11 @@ def assemble_matrix(
         for bc in bcs:
             if not V0.contains(bc.function_space):
                 continue
-            key = ("bcdofs", str(A.device), id(bc))
-            if key not in form._device:
+            def owned_dofs(bc=bc):
                 dofs_h, nowned = bc.dof_indices()  # owned dofs only, like dolfinx insert_diagonal
-                form._device[key] = D._to_dev(dofs_h[:nowned], A.device)
-            dofs = form._device[key]
+                return D._to_dev(dofs_h[:nowned], A.device)
+
+            dofs = D.cached(form._device, "bcdofs", (bc,), str(A.device), owned_dofs, maxsize=16)
             _native.check(
                 L.mpcx_add_diagonal(A.shape[0], A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), A.vals.data_ptr(),
                                     dofs.data_ptr(), dofs.numel(), float(diagval), stream),

@@ -120,9 +120,10 @@ def assemble_vector(form: Form, constraint: MultiPointConstraint, b: Optional[Ve
     return b
 
 
-def _lift_entities(form: Form, i: int, markers: np.ndarray, V1, cache: dict, key):
-    """compact list of entities with a bc-marked column dof (cpp/lifting.h:93-109)."""
-    if key not in cache:
+def _lift_entities(form: Form, i: int, markers: np.ndarray, V1):
+    """compact list of entities with a bc-marked column dof (cpp/lifting.h:93-109); cached per
+    marker array (itself cached per (space, bcs): its identity stands for the bc set)."""
+    def build():
         integ = form.integrals[i]
         dofs = V1.dofmap.list[integ.cells]  # (n, nd) blocked
         bs = V1.dofmap.bs
@@ -130,8 +131,9 @@ def _lift_entities(form: Form, i: int, markers: np.ndarray, V1, cache: dict, key
         for k in range(bs):
             hit |= markers[dofs * bs + k].any(axis=1)
         idx = np.flatnonzero(hit).astype(np.int32)
-        cache[key] = (idx, D._to_dev(idx, _native.require_gpu()))
-    return cache[key]
+        return (idx, D._to_dev(idx, _native.require_gpu()))
+
+    return D.cached(form._device, "lift_ents", (markers,), i, build)
 
 
 def apply_lifting(
@@ -180,16 +182,8 @@ def apply_lifting(
         if aj is None or len(bcs[j]) == 0:
             continue
         V0, V1 = aj.function_spaces
-        # bc markers / values over the column space, cpp/lifting.h:166-180
-        key = ("lift", str(dev), tuple(id(bc) for bc in bcs[j]))
-        if key not in aj._device:
-            markers = np.zeros(V1.num_dofs, dtype=np.int8)
-            values = np.zeros(V1.num_dofs, dtype=np.float64)
-            for bc in bcs[j]:
-                bc.mark_dofs(markers)
-                bc.set(values, None, 1.0)
-            aj._device[key] = (markers, D._to_dev(markers, dev), D._to_dev(values, dev))
-        markers, d_markers, d_values = aj._device[key]
+        # bc markers / values over the column space, cpp/lifting.h:166-180 (values read live)
+        markers, d_markers, d_values = D.bc_values(V1, bcs[j], aj._device)
         md = D.mesh_device(aj.mesh)
         s0, s1 = D.space_device(V0), D.space_device(V1)
         x0j = None
@@ -199,7 +193,7 @@ def apply_lifting(
             if integ.itype not in ("cell", "exterior_facet"):
                 raise RuntimeError("Interior facet integrals currently not supported")
             idv = D.integral_device(aj, i)
-            _, lift = _lift_entities(aj, i, markers, V1, aj._device, key + ("ents", i))
+            _, lift = _lift_entities(aj, i, markers, V1)
             a = _native.LiftingArgs()
             a.b, a.num_dofs = b.array.data_ptr(), b.size
             a.kernel = idv["kernel"]
@@ -226,10 +220,8 @@ def set_bc(b: Vector, bcs: Sequence[DirichletBC], x0: Optional[Vector] = None, s
 
     for bc in bcs:
         dofs = bc.dof_indices()[0]
-        vals = np.zeros(b.size, dtype=np.float64)
-        bc.set(vals, None, 1.0)
         idx = torch.from_numpy(dofs.astype(np.int64)).to(b.array.device)
-        g = torch.from_numpy(vals[dofs]).to(b.array.device)
+        g = torch.from_numpy(np.ascontiguousarray(bc.values_at_dofs())).to(b.array.device)
         if x0 is not None:
             g = g - x0.array[idx]
         b.array[idx] = scale * g

@@ -197,8 +197,33 @@ def functionspace(mesh: Mesh, element, shape: Optional[tuple] = None) -> Functio
 
 
 class _Vector:
+    """Host dof array of a ``Function``.  ``array`` hands out the writable numpy array and counts the
+    hand-outs in ``version``: consumers that keep a packed / device copy (coefficients, Dirichlet
+    values) compare versions and refresh after ANY access by the user, so that values updated between
+    two assemblies are never stale -- the reference packs coefficients and reads boundary values on
+    every call (cpp/assemble_matrix.cpp:587-589, cpp/lifting.h:166-180)."""
+
     def __init__(self, n: int):
-        self.array = np.zeros(n, dtype=np.float64)
+        self._data = np.zeros(n, dtype=np.float64)
+        self.version = 0
+
+    @property
+    def array(self) -> np.ndarray:
+        self.version += 1
+        return self._data
+
+    @array.setter
+    def array(self, value):
+        self.version += 1
+        self._data[:] = value
+
+
+class Constant:
+    """``dolfinx.fem.Constant`` stand-in: ``value`` may be changed between assemblies; the
+    assemblers pack it on every call (cpp/assemble_matrix.cpp:583-585)."""
+
+    def __init__(self, value):
+        self.value = np.atleast_1d(np.asarray(value, dtype=np.float64)).copy()
 
 
 class Function:
@@ -249,18 +274,21 @@ class DirichletBC:
     def mark_dofs(self, markers: np.ndarray):
         markers[self._dofs] = 1
 
-    def set(self, values: np.ndarray, x0=None, alpha: float = 1.0):
+    def values_at_dofs(self) -> np.ndarray:
+        """current boundary value at each of ``dof_indices()[0]`` (read from the live ``value``)"""
         v = self.value
         if isinstance(v, Function):
-            g = v.x.array[self._dofs]
-        else:
-            v = np.asarray(v, dtype=np.float64)
-            if v.ndim == 0:
-                g = np.full(self._dofs.size, float(v))
-            else:
-                bs = self.function_space.dofmap.bs
-                g = v.reshape(-1)[self._dofs % bs] if v.size == bs else v.reshape(-1)[self._dofs]
-        values[self._dofs] = alpha * g
+            return v.x._data[self._dofs]
+        if isinstance(v, Constant):
+            v = v.value
+        v = np.asarray(v, dtype=np.float64)
+        if v.ndim == 0 or v.size == 1:
+            return np.full(self._dofs.size, float(v.reshape(-1)[0]))
+        bs = self.function_space.dofmap.bs
+        return v.reshape(-1)[self._dofs % bs] if v.size == bs else v.reshape(-1)[self._dofs]
+
+    def set(self, values: np.ndarray, x0=None, alpha: float = 1.0):
+        values[self._dofs] = alpha * self.values_at_dofs()
 
 
 def dirichletbc(value, dofs, V: FunctionSpace, component: Optional[int] = None) -> DirichletBC:
@@ -292,13 +320,46 @@ class KernelSpec:
     bs1: int = 0
 
 
-@dataclass
 class Integral:
-    itype: str  # "cell" | "exterior_facet"
-    entities: np.ndarray  # cells int32[n] or (cell, local_facet) int32[n, 2]
-    kernel: KernelSpec
-    coeffs: Optional[np.ndarray] = None  # float64[n, cstride]
-    constants: Optional[np.ndarray] = None
+    """One integral of a form: kind, integration entities, element kernel, and the SOURCES of the
+    packed data the kernel reads -- ``coefficient`` (a ``Function`` or None) and ``constant``
+    (a ``Constant``, raw numbers, or None).  ``coeffs`` / ``constants`` pack them when read, like
+    dolfinx ``pack_coefficients`` / ``pack_constants`` do on every assembly call
+    (cpp/assemble_matrix.cpp:583-589); the coefficient pack is reused while the function's dof array
+    has not been handed out again (``_Vector.version``)."""
+
+    def __init__(self, itype: str, entities: np.ndarray, kernel: KernelSpec, coefficient=None, constant=None):
+        self.itype = itype  # "cell" | "exterior_facet"
+        self.entities = entities  # cells int32[n] or (cell, local_facet) int32[n, 2]
+        self.kernel = kernel
+        self.coefficient = coefficient
+        self.constant = constant
+        self._packed = (None, None)  # (version, array)
+
+    @property
+    def coeffs(self) -> Optional[np.ndarray]:
+        """float64[n, cstride] packed coefficient dofs of the entities' cells, or None"""
+        f = self.coefficient
+        if f is None:
+            return None
+        if isinstance(f, np.ndarray):  # already packed by the caller
+            return f
+        if self._packed[0] != f.x.version:
+            Vc = f.function_space
+            self._packed = (f.x.version, np.ascontiguousarray(f.x._data[Vc.dofmap.list[self.cells]]))
+        return self._packed[1]
+
+    @property
+    def coeff_version(self):
+        f = self.coefficient
+        return None if f is None or isinstance(f, np.ndarray) else f.x.version
+
+    @property
+    def constants(self) -> Optional[np.ndarray]:
+        c = self.constant
+        if c is None:
+            return None
+        return np.atleast_1d(np.asarray(c.value if isinstance(c, Constant) else c, dtype=np.float64))
 
     @property
     def estride(self) -> int:
@@ -330,12 +391,12 @@ class Form:
         return Form(self.function_spaces, self.integrals + other.integrals)
 
 
-def _pack_coefficient(coefficient: Optional[Function], cells: np.ndarray):
+def _coefficient_degree(coefficient: Optional[Function]) -> int:
     if coefficient is None:
-        return None, 0
+        return 0
     Vc = coefficient.function_space
     assert Vc.dofmap.bs == 1, "only scalar coefficients"
-    return np.ascontiguousarray(coefficient.x.array[Vc.dofmap.list[cells]]), Vc.degree
+    return Vc.degree
 
 
 def _cells_or_all(mesh: Mesh, cells) -> np.ndarray:
@@ -346,7 +407,10 @@ def _cells_or_all(mesh: Mesh, cells) -> np.ndarray:
 
 
 def _constants(c):
-    return None if c is None else np.atleast_1d(np.asarray(c, dtype=np.float64)).copy()
+    """a ``Constant`` is kept by reference (live value); raw numbers are frozen here"""
+    if c is None or isinstance(c, Constant):
+        return c
+    return np.atleast_1d(np.asarray(c, dtype=np.float64)).copy()
 
 
 def _cell_kernel(V: FunctionSpace, form: int, qdeg: int, fn_id: int = 0, coeff_degree: int = 0) -> KernelSpec:
@@ -365,16 +429,16 @@ def form_stiffness(V, constant=None, coefficient: Optional[Function] = None, cel
     """a(u, v) = c * w * inner(grad(u), grad(v)) dx  (bench_periodic.py:84;
     test_mpc_pipeline.py:45 with coefficient and constant)."""
     cells = _cells_or_all(V.mesh, cells)
-    w, cd = _pack_coefficient(coefficient, cells)
+    cd = _coefficient_degree(coefficient)
     k = _cell_kernel(V, FORM_STIFFNESS, 2 * (V.degree - 1) + cd, coeff_degree=cd)
-    return Form([V, V], [Integral("cell", cells, k, w, _constants(constant))])
+    return Form([V, V], [Integral("cell", cells, k, coefficient, _constants(constant))])
 
 
 def form_mass(V, constant=None, coefficient: Optional[Function] = None, cells=None) -> Form:
     cells = _cells_or_all(V.mesh, cells)
-    w, cd = _pack_coefficient(coefficient, cells)
+    cd = _coefficient_degree(coefficient)
     k = _cell_kernel(V, FORM_MASS, 2 * V.degree + cd, coeff_degree=cd)
-    return Form([V, V], [Integral("cell", cells, k, w, _constants(constant))])
+    return Form([V, V], [Integral("cell", cells, k, coefficient, _constants(constant))])
 
 
 def form_elasticity(V, mu: float, lmbda: float, cells=None) -> Form:
@@ -410,11 +474,11 @@ def form_source(V, fn_id: int = FN_ONE, constant=None, coefficient: Optional[Fun
     """L(v) = c * w * inner(f, v) dx with analytic f (bench_periodic.py:85-91).
     Non-polynomial f: estimated degree +2 per UFL's rule -> P1: 5."""
     cells = _cells_or_all(V.mesh, cells)
-    w, cd = _pack_coefficient(coefficient, cells)
+    cd = _coefficient_degree(coefficient)
     fdeg = _FN_DEGREE[fn_id]
     qdeg = V.degree + fdeg + cd if quadrature_degree is None else quadrature_degree
     k = _cell_kernel(V, FORM_SOURCE, qdeg, fn_id, cd)
-    return Form([V], [Integral("cell", cells, k, w, _constants(constant))])
+    return Form([V], [Integral("cell", cells, k, coefficient, _constants(constant))])
 
 
 def form_facet_mass(V, facets: np.ndarray, constant=None) -> Form:

@@ -164,7 +164,8 @@ class MultiPointConstraint:
         blocks = np.flatnonzero(np.asarray(indicator(x.T), dtype=bool))
         is_bc = np.zeros(V.num_dofs, dtype=np.int8)
         for bc in bcs:
-            bc.mark_dofs(is_bc)
+            if V.contains(bc.function_space):  # cpp/utils.h:1470-1476: only conditions living in V
+                bc.mark_dofs(is_bc)
         xm = np.asarray(relation(x[blocks].T)).T
         if blocks.size == 0:
             return
@@ -182,8 +183,10 @@ class MultiPointConstraint:
             )
         slaves = (blocks[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)
         masters = (mblk[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)
-        # slaves under a Dirichlet condition are dropped (cpp/utils.h:1459-1496)
-        keep = is_bc[slaves] == 0
+        # a slave BLOCK with any component under a Dirichlet condition is dropped as a whole
+        # (cpp/utils.h:1459-1496 marks blocks, cpp/PeriodicConstraint.h:563-567 filters with it)
+        blk_bc = is_bc.reshape(-1, bs)[blocks].any(axis=1)
+        keep = np.repeat(~blk_bc, bs)
         slaves, masters = slaves[keep], masters[keep]
         n = slaves.size
         self.add_constraint(V, slaves.astype(np.int32), masters.astype(np.int64), np.full(n, scale, dtype=np.float64),
@@ -311,25 +314,52 @@ class MultiPointConstraint:
         return self._dev
 
     # -- post-solve (python/src/dolfinx_mpc/multipointconstraint.py:586-617) ----
-    def backsubstitution(self, u) -> None:
-        """u[slave] = sum_k c_k u[master_k] on a device vector (``Vector`` or torch tensor)."""
+    def _on_device(self, u, kernel):
+        """run ``kernel(device fp64 tensor)`` on u: a device ``Vector`` / torch tensor in place, or a
+        ``fem.Function`` (the reference's call shape ``mpc.backsubstitution(uh)``,
+        python/src/dolfinx_mpc/multipointconstraint.py:586-617) through an upload and a copy back."""
         import torch
 
+        from .fem import Function
+
+        if isinstance(u, Function):
+            if u.function_space is not self.V:
+                raise ValueError("The input function has to be in the function space in the multi-point constraint")
+            dev = _native.require_gpu()
+            arr = torch.from_numpy(u.x._data).to(dev)
+            kernel(arr)
+            u.x.array[:] = arr.cpu().numpy()
+            return
         arr = u.array if hasattr(u, "array") else u
+        if not isinstance(arr, torch.Tensor) or arr.dtype != torch.float64 or not arr.is_cuda:
+            raise TypeError("backsubstitution / homogenize need a fem.Function, a la.Vector or a float64 device tensor")
+        kernel(arr)
+
+    def backsubstitution(self, u) -> None:
+        """u[slave] = sum_k c_k u[master_k] (cpp/MultiPointConstraint.h:129-145)."""
+        import torch
+
         s, t = self._device()
-        L = _native.lib()
-        rc = L.mpcx_backsubstitution(arr.data_ptr(), t["slaves"].data_ptr(), t["slaves"].numel(), C.byref(s),
-                                     torch.cuda.current_stream().cuda_stream)
-        _native.check(rc, "mpcx_backsubstitution")
+
+        def run(arr):
+            rc = _native.lib().mpcx_backsubstitution(arr.data_ptr(), t["slaves"].data_ptr(), t["slaves"].numel(),
+                                                     C.byref(s), torch.cuda.current_stream().cuda_stream)
+            _native.check(rc, "mpcx_backsubstitution")
+
+        self._on_device(u, run)
 
     def homogenize(self, u) -> None:
+        """u[slave] = 0 (cpp/MultiPointConstraint.h:147-152)."""
         import torch
 
-        arr = u.array if hasattr(u, "array") else u
         _, t = self._device()
-        rc = _native.lib().mpcx_homogenize(arr.data_ptr(), t["slaves"].data_ptr(), t["slaves"].numel(),
-                                           torch.cuda.current_stream().cuda_stream)
-        _native.check(rc, "mpcx_homogenize")
+
+        def run(arr):
+            rc = _native.lib().mpcx_homogenize(arr.data_ptr(), t["slaves"].data_ptr(), t["slaves"].numel(),
+                                               torch.cuda.current_stream().cuda_stream)
+            _native.check(rc, "mpcx_homogenize")
+
+        self._on_device(u, run)
 
     def _already_finalized(self):
         if self.finalized:

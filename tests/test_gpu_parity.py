@@ -191,3 +191,179 @@ def test_backsubstitution_homogenize(oracle):
     assert np.allclose(v.numpy(), ref, rtol=0, atol=1e-14)
     mpc.homogenize(v)
     assert np.all(v.numpy()[mpc.slaves] == 0.0)
+
+
+# ---------------------------------------------------------------------------------------------
+# kernel variants that the default configuration never reaches
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("env", ["MPCX_NO_MPC_PLAN", "MPCX_NO_LEAN"])
+@pytest.mark.parametrize("alg", ["atomic", "rowblock"])
+@pytest.mark.parametrize("make", CASES, ids=[f"case{i}" for i in range(len(CASES))])
+def test_small_cases_kernel_variants(oracle, make, alg, env, monkeypatch):
+    """MPCX_NO_MPC_PLAN=1: the master contributions of the slave entities come from ``matrix_mpc_kernel``
+    (one thread per slave entity, CSR searches, device atomics) -- the path a caller of the bare C ABI
+    gets when it passes ``mpc_plan_off == NULL`` -- instead of the host-built plan.
+    MPCX_NO_LEAN=1: the general row-block kernel instead of the lean P1 one."""
+    monkeypatch.setenv(env, "1")
+    case = make()
+    if case.a is None:
+        pytest.skip("no bilinear form")
+    ref = oracle_outputs(oracle, case)
+    out = product_outputs(case, algorithm=alg)
+    assert np.array_equal(out["A"].indptr, ref["A"].indptr) and np.array_equal(out["A"].indices, ref["A"].indices)
+    _close(out["A"].data, ref["A"].data, RTOL_A, f"{case.name} A [{env}]")
+
+
+def test_reproducibility_statement(oracle):
+    """What repeated assembly of the same system guarantees (determinism):
+    * pattern, plans and the master contributions (one thread per target position, fixed tuple order)
+      are deterministic;
+    * a row-block value is the sum of <= ~30 fp64 addends added with LDS atomics (ds_add_f64) in an
+      order that depends on wave scheduling, the atomic kernel's with device atomics likewise: fp64
+      addition is not associative, so two runs may differ in the last bits.  The spread is bounded by
+      n * eps * sum|addends|; asserted here as <= 64 ulp of the row's largest entry (measured: 0-2 ulp).
+    Bitwise equality run to run is therefore NOT promised by either algorithm (nor by the reference
+    under MPI, where PETSc adds off-rank contributions in arrival order)."""
+    import dolfinx_mpc_amd as dm
+
+    case = case_cube_periodic(10, 1, 0.0, reorder=(4, 4, 4))
+    mpc = product_mpc(case)
+    for alg in ("rowblock", "atomic"):
+        A = dm.assemble_matrix(case.a, mpc, bcs=case.bcs, algorithm=alg)
+        runs = []
+        for _ in range(5):
+            dm.assemble_matrix(case.a, mpc, bcs=case.bcs, A=A, algorithm=alg)
+            runs.append(A.to_scipy().data.copy())
+        spread = np.max(np.abs(np.array(runs) - runs[0]), axis=0)
+        scale = np.abs(runs[0]).max()
+        assert spread.max() <= 64 * np.finfo(np.float64).eps * scale, (alg, spread.max())
+    b_runs = [dm.assemble_vector(case.L, mpc).numpy().copy() for _ in range(3)]
+    assert np.max(np.abs(b_runs[1] - b_runs[0])) <= 64 * np.finfo(np.float64).eps * np.abs(b_runs[0]).max()
+
+
+# ---------------------------------------------------------------------------------------------
+# values are read live, structure is cached per object (not per id())
+# ---------------------------------------------------------------------------------------------
+def test_lifting_reads_live_boundary_values(oracle):
+    """A boundary Function updated between two apply_lifting calls (time-dependent condition,
+    repeated LinearProblem.solve) must reach the kernel: the reference reads bc values on every call
+    (cpp/lifting.h:166-180)."""
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import fem
+
+    case = case_cube_periodic(4, 1, 0.0)
+    V = case.V
+    g = fem.Function(V)
+    g.x.array[:] = 1.25
+    bc = fem.dirichletbc(g, case.bcs[0].dof_indices()[0], V)
+    mpc = product_mpc(case)
+    o_mpc = oracle_mpc(oracle, case)
+    for value in (1.25, -3.5, 0.75):
+        g.x.array[:] = value
+        b = dm.assemble_vector(case.L, mpc)
+        dm.apply_lifting(b, [case.a], [[bc]], mpc)
+        dm.set_bc(b, [bc])
+        ref = oracle.assemble_vector(case.L, o_mpc)
+        oracle.apply_lifting(ref, [case.a], [[bc]], o_mpc)
+        ref[bc.dof_indices()[0]] = value
+        _close(b.numpy(), ref, RTOL_B, f"b lifted with g = {value}")
+
+
+def test_coefficients_and_constants_are_packed_per_call(oracle):
+    """dolfinx packs coefficients and constants on every assembly call
+    (cpp/assemble_matrix.cpp:583-589): changing them between calls changes the result."""
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import fem
+    from problems import case_pipeline
+
+    case = case_pipeline((1, 1))
+    V = case.V
+    w = fem.Function(V)
+    c = fem.Constant(1.5)
+    a = fem.form_stiffness(V, constant=c, coefficient=w)
+    mpc = product_mpc(case)
+    o_mpc = oracle_mpc(oracle, case)
+    A = None
+    for k, cval in enumerate((1.5, 0.25, 4.0)):
+        w.interpolate(lambda x: 1.0 + k + np.sin(x[0] + k) * x[1])
+        c.value[:] = cval
+        A = dm.assemble_matrix(a, mpc, A=A)
+        ref = oracle.assemble_matrix(a, o_mpc)
+        _close(A.to_scipy().data, ref.data, RTOL_A, f"A with coefficient/constant set {k}")
+
+
+def test_new_objects_never_hit_stale_caches(oracle):
+    """Fresh DirichletBC / Form objects created in a loop (ids of collected objects get reused by
+    CPython) must each be assembled with their OWN markers, masked dofmaps and plans."""
+    import gc
+
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import fem
+
+    case = case_cube_periodic(5, 1, 0.0, reorder=(2, 2, 2))
+    V = case.V
+    mpc = product_mpc(case)
+    o_mpc = oracle_mpc(oracle, case)
+    A = dm.create_matrix(case.a, mpc)
+    walls = [lambda x: np.isclose(x[1], 0), lambda x: np.isclose(x[2], 1), lambda x: np.isclose(x[1], 1) | np.isclose(x[2], 0)]
+    for rep in range(6):
+        marker = walls[rep % 3]
+        # slaves may not carry a Dirichlet condition: keep the constraint's face x = 1 and its masters' x = 0 free
+        dofs = fem.locate_dofs_geometrical(V, lambda x: marker(x) & ~np.isclose(x[0], 1) & ~np.isclose(x[0], 0))
+        bc = fem.dirichletbc(0.5 + rep, dofs, V)
+        a = fem.form_stiffness(V)  # a new form object every time
+        for alg in ("rowblock", "atomic"):
+            dm.assemble_matrix(a, mpc, bcs=[bc], A=A, algorithm=alg)
+            ref = oracle.assemble_matrix(a, o_mpc, bcs=[bc], pattern=(A.rowptr, A.cols))
+            _close(A.to_scipy().data, ref.data, RTOL_A, f"A rep {rep} {alg}")
+        b = dm.assemble_vector(case.L, mpc)
+        dm.apply_lifting(b, [a], [[bc]], mpc)
+        ref_b = oracle.assemble_vector(case.L, o_mpc)
+        oracle.apply_lifting(ref_b, [a], [[bc]], o_mpc)
+        _close(b.numpy(), ref_b, RTOL_B, f"b rep {rep}")
+        del bc, a
+        gc.collect()
+
+
+def test_reassembly_with_empty_first_integral(oracle):
+    """A reused, non-zero matrix and a form whose FIRST integral is empty on this rank: the row-block
+    path must still clear the old values (it skips the memset only when the first non-empty integral
+    overwrites them)."""
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import fem
+
+    case = case_cube_periodic(4, 1, 0.0)
+    V = case.V
+    mpc = product_mpc(case)
+    A = dm.assemble_matrix(case.a, mpc, bcs=case.bcs, algorithm="rowblock")
+    A.vals.fill_(7.0)  # stale values everywhere
+    a2 = fem.form_stiffness(V, cells=np.zeros(0, dtype=np.int32)) + fem.form_stiffness(V, constant=2.0)
+    dm.assemble_matrix(a2, mpc, bcs=case.bcs, A=A, algorithm="rowblock")
+    ref = oracle.assemble_matrix(fem.form_stiffness(V, constant=2.0), oracle_mpc(oracle, case), bcs=case.bcs)
+    _close(A.to_scipy().data, ref.data, RTOL_A, "A after an empty first integral")
+    # only empty integrals: everything but the diagonal is cleared
+    A.vals.fill_(7.0)
+    dm.assemble_matrix(fem.form_stiffness(V, cells=np.zeros(0, dtype=np.int32)), mpc, bcs=case.bcs, A=A,
+                       algorithm="rowblock")
+    assert set(np.unique(A.to_scipy().data)) <= {0.0, 1.0}
+
+
+def test_backsubstitution_accepts_a_function(oracle):
+    """the reference's call shape: mpc.backsubstitution(uh) with a fem.Function
+    (python/src/dolfinx_mpc/multipointconstraint.py:586-604)."""
+    from dolfinx_mpc_amd import fem
+    from problems import case_cube_contact_like
+
+    case = case_cube_contact_like(3)
+    mpc = product_mpc(case)
+    u = fem.Function(case.V)
+    rng = np.random.default_rng(3)
+    u.x.array[:] = rng.standard_normal(case.V.num_dofs)
+    ref = u.x.array.copy()
+    oracle.backsubstitution(oracle_mpc(oracle, case), ref)
+    mpc.backsubstitution(u)
+    assert np.allclose(u.x.array, ref, rtol=0, atol=1e-14)
+    mpc.homogenize(u)
+    assert np.all(u.x.array[mpc.slaves] == 0.0)
+    with pytest.raises(TypeError):
+        mpc.backsubstitution(np.zeros(case.V.num_dofs))

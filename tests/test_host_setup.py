@@ -298,3 +298,95 @@ def test_compress_offsets_dictionary():
     ids = np.empty(500, dtype=np.uint16)
     table = np.empty(16 * 9, dtype=np.uint8)
     assert L.mpcx_compress_offsets(p(many), 500, 9, 16, p(ids), p(table)) == -1
+
+
+def test_object_cache_is_keyed_by_identity_not_id():
+    """_device.cached keeps its key objects alive and confirms hits with ``is``: an object created
+    after another one died can never inherit its entry (bare id() keys could)."""
+    from dolfinx_mpc_amd import _device as D
+
+    class K:
+        pass
+
+    store, built = {}, []
+
+    def make(tag):
+        def build():
+            built.append(tag)
+            return tag
+        return build
+
+    a, b = K(), K()
+    assert D.cached(store, "t", (a,), 0, make("a")) == "a"
+    assert D.cached(store, "t", (a,), 0, make("a2")) == "a"  # hit
+    assert D.cached(store, "t", (a,), 1, make("a1")) == "a1"  # other hashable part
+    assert D.cached(store, "t", (b,), 0, make("b")) == "b"
+    assert built == ["a", "a1", "b"]
+    # the cache holds `a` strongly: a new object cannot get a's id while the entry lives
+    ida = id(a)
+    del a
+    fresh = [K() for _ in range(1000)]
+    assert all(id(f) != ida for f in fresh)
+    # LRU bound
+    for k in range(20):
+        D.cached(store, "lru", (fresh[k],), 0, make(k), maxsize=4)
+    assert len(store[("objcache", "lru")]) == 4
+
+
+def test_coefficients_constants_and_bc_values_are_live():
+    """Integral.coeffs / .constants and DirichletBC.values_at_dofs read the CURRENT values of the
+    Function / Constant they were built from (the reference packs per assembly call,
+    cpp/assemble_matrix.cpp:583-589; reads bc values per call, cpp/lifting.h:166-180)."""
+    from dolfinx_mpc_amd import fem
+    from dolfinx_mpc_amd.mesh import create_unit_square
+
+    mesh = create_unit_square(3, 2)
+    V = fem.functionspace(mesh, ("Lagrange", 1))
+    w = fem.Function(V)
+    c = fem.Constant(2.0)
+    a = fem.form_stiffness(V, constant=c, coefficient=w)
+    integ = a.integrals[0]
+    assert np.all(integ.coeffs == 0.0) and integ.constants[0] == 2.0
+    first = integ.coeffs
+    assert integ.coeffs is first  # untouched function: the pack is reused
+    w.x.array[:] = np.arange(V.num_dofs)
+    c.value[0] = -1.0
+    assert np.array_equal(integ.coeffs, np.arange(V.num_dofs, dtype=float)[V.dofmap.list])
+    assert integ.constants[0] == -1.0
+    g = fem.Function(V)
+    bc = fem.dirichletbc(g, np.array([0, 3], dtype=np.int32), V)
+    assert np.all(bc.values_at_dofs() == 0.0)
+    g.x.array[:] = 4.0
+    assert np.all(bc.values_at_dofs() == 4.0)
+    kc = fem.Constant(1.0)
+    bck = fem.dirichletbc(kc, np.array([1], dtype=np.int32), V)
+    kc.value[0] = 9.0
+    assert bck.values_at_dofs()[0] == 9.0
+
+
+def test_periodic_builder_drops_whole_blocks_under_a_bc():
+    """cpp/utils.h:1459-1496 + cpp/PeriodicConstraint.h:563-567: a slave block with ANY component under a
+    Dirichlet condition is dropped entirely; conditions of other spaces are ignored."""
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import fem
+    from dolfinx_mpc_amd.mesh import create_unit_square
+
+    mesh = create_unit_square(3, 3)
+    V = fem.functionspace(mesh, ("Lagrange", 1, (2,)))
+    Q = fem.functionspace(mesh, ("Lagrange", 1))
+    x = V.tabulate_dof_coordinates()
+    top_right = np.flatnonzero(np.isclose(x[:, 0], 1) & np.isclose(x[:, 1], 1)).astype(np.int32)
+    bc_y = fem.dirichletbc(0.0, top_right, V, component=1)  # only the y-component of one slave block
+    bc_q = fem.dirichletbc(0.0, np.arange(Q.num_dofs, dtype=np.int32), Q)  # other space: ignored
+
+    def relation(x):
+        out = x.copy()
+        out[0] = 1 - x[0]
+        return out
+
+    mpc = dm.MultiPointConstraint(V)
+    mpc.create_periodic_constraint_geometrical(V, lambda x: np.isclose(x[0], 1), relation, [bc_y, bc_q])
+    mpc.finalize()
+    right = np.flatnonzero(np.isclose(x[:, 0], 1))
+    expect = np.sort(np.concatenate([b * 2 + np.arange(2) for b in right if b != top_right[0]]))
+    assert np.array_equal(mpc.slaves, expect)
