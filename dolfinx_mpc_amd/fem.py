@@ -302,6 +302,32 @@ def locate_dofs_geometrical(V: FunctionSpace, marker: Callable[[np.ndarray], np.
     return np.flatnonzero(np.asarray(marker(x.T), dtype=bool)).astype(np.int32)
 
 
+def locate_dofs_topological(V: FunctionSpace, entity_dim: int, entities: np.ndarray) -> np.ndarray:
+    """Blocked dofs in the closure of the given facets, (cell, local_facet) pairs
+    (python/benchmarks/bench_contact_3D.py:222 ``locate_dofs_topological(V, fdim, mt.find(5))``):
+    the facet's vertices and, for P2, the edges between them."""
+    from .mesh import TET_EDGES, TET_FACETS, TRI_EDGES, TRI_FACETS
+
+    mesh = V.mesh
+    assert entity_dim == mesh.tdim - 1, "facets only"
+    ents = np.asarray(entities, dtype=np.int64).reshape(-1, 2)
+    lf = TET_FACETS if mesh.tdim == 3 else TRI_FACETS
+    le = TET_EDGES if mesh.tdim == 3 else TRI_EDGES
+    nv = mesh.tdim + 1
+    out = []
+    for f in range(lf.shape[0]):
+        sel = ents[ents[:, 1] == f, 0]
+        if sel.size == 0:
+            continue
+        loc = list(lf[f])
+        if V.degree == 2:  # edges whose two end vertices lie on the facet
+            loc += [nv + e for e in range(le.shape[0]) if le[e][0] in lf[f] and le[e][1] in lf[f]]
+        out.append(V.dofmap.list[sel][:, loc].reshape(-1))
+    if not out:
+        return np.zeros(0, dtype=np.int32)
+    return np.unique(np.concatenate(out)).astype(np.int32)
+
+
 @dataclass
 class KernelSpec:
     """Description of one element kernel (stands in for an FFCx ``tabulate_tensor``)."""

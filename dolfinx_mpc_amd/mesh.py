@@ -196,3 +196,115 @@ def create_rectangle(p0, p1, n, cell_type: str = "triangle") -> Mesh:
 def create_unit_square(nx: int, ny: int, cell_type: str = "triangle") -> Mesh:
     """python/tests/test_matrix_assembly.py:30 ``create_unit_square(comm, 5, 3, ct)``."""
     return create_rectangle((0.0, 0.0), (1.0, 1.0), (nx, ny), cell_type)
+
+
+# ---------------------------------------------------------------------------------------------
+# facet tags and the two-body mesh of the contact benchmark
+# ---------------------------------------------------------------------------------------------
+class MeshTags:
+    """``dolfinx.mesh.MeshTags`` stand-in for FACETS: entities are (cell, local_facet) pairs -- the
+    stride-2 layout the reference's exterior-facet integrals use
+    (cpp/assemble_matrix.cpp:343-348) -- with one integer value each."""
+
+    def __init__(self, mesh: Mesh, dim: int, entities: np.ndarray, values: np.ndarray):
+        assert dim == mesh.tdim - 1, "facet tags only"
+        self.mesh = mesh
+        self.dim = dim
+        self.entities = np.ascontiguousarray(entities, dtype=np.int32).reshape(-1, 2)
+        self.values = np.ascontiguousarray(values, dtype=np.int32)
+        assert self.entities.shape[0] == self.values.size
+
+    def find(self, value: int) -> np.ndarray:
+        """(cell, local_facet) pairs tagged ``value`` (python/benchmarks/bench_contact_3D.py:222 ``mt.find(5)``)"""
+        return np.ascontiguousarray(self.entities[self.values == value])
+
+
+def facet_vertices(mesh: Mesh, facets: np.ndarray) -> np.ndarray:
+    """geometry nodes of the given (cell, local_facet) pairs, shape (n, tdim)"""
+    lf = TET_FACETS if mesh.tdim == 3 else TRI_FACETS
+    facets = np.asarray(facets).reshape(-1, 2)
+    return mesh.geometry.dofmap[facets[:, 0]][np.arange(facets.shape[0])[:, None], lf[facets[:, 1]]]
+
+
+def rotation_matrix(axis, angle: float) -> np.ndarray:
+    """rotation about ``axis`` by ``angle`` (Rodrigues; python/src/dolfinx_mpc/utils/mpc_utils.py:35-48)"""
+    n = np.asarray(axis, dtype=np.float64)
+    n = n / np.sqrt(n @ n)
+    K = np.array([[0, -n[2], n[1]], [n[2], 0, -n[0]], [-n[1], n[0], 0]])
+    return np.sin(angle) * K + np.cos(angle) * np.eye(3) + (1 - np.cos(angle)) * np.outer(n, n)
+
+
+def _facets_on_plane(cells: np.ndarray, cell_ids: np.ndarray, on_plane: np.ndarray) -> np.ndarray:
+    """(cell, local_facet) of the facets of ``cell_ids`` whose three vertices all satisfy ``on_plane``"""
+    hit = on_plane[cells[cell_ids]]  # (n, 4) vertex flags
+    out = []
+    for f in range(4):
+        sel = hit[:, TET_FACETS[f]].all(axis=1)
+        if sel.any():
+            out.append(np.stack([cell_ids[sel], np.full(int(sel.sum()), f, dtype=np.int64)], axis=1))
+    return np.concatenate(out, axis=0).astype(np.int32) if out else np.zeros((0, 2), dtype=np.int32)
+
+
+def merge_meshes(meshes) -> Mesh:
+    """Disjoint union: points and cells concatenated in the given order (what
+    python/benchmarks/bench_contact_3D.py:108-110 does with ``np.vstack``)."""
+    xs, cs, hints = [], [], []
+    off = 0
+    for m in meshes:
+        xs.append(m.geometry.x)
+        cs.append(m.geometry.dofmap.astype(np.int64) + off)
+        if m.node_tile_offsets is not None:
+            hints.append(m.node_tile_offsets.astype(np.int64) + off)
+        else:
+            hints.append(np.array([off], dtype=np.int64))
+        off += m.num_nodes
+    out = Mesh(np.concatenate(xs, axis=0), np.concatenate(cs, axis=0).astype(np.int32), meshes[0].cell_name)
+    if any(m.node_tile_offsets is not None for m in meshes):
+        out.node_tile_offsets = np.concatenate(hints).astype(np.int32)
+    return out
+
+
+# facet markers of the contact benchmark (python/benchmarks/bench_contact_3D.py:163-168)
+CONTACT_TOP, CONTACT_BOTTOM_INTERFACE, CONTACT_TOP_INTERFACE, CONTACT_BOTTOM = 3, 4, 9, 5
+
+
+def create_stacked_cubes(n_top: int, n_bottom: int | None = None, theta: float = 0.0, reorder=None):
+    """The two-body mesh of python/benchmarks/bench_contact_3D.py:62-195 (``mesh_3D_dolfin``): a unit cube
+    with ``n_top``^3 cubes on z in [1, 2] stacked on a unit cube with ``n_bottom``^3 (default 2 n_top) on
+    z in [0, 1]; points and cells of the top body first, then the bottom body; every cube split into 6
+    tets; the whole rotated about (1, 1, 0)/sqrt(2) by -theta.  The two bodies share no node: they touch
+    along the plane z = 1 (before rotation).
+
+    Returns (mesh, facet_tags, cell_tags) with the reference's markers: 3 top (z = 2), 4 bottom
+    interface (the bottom body's facets on z = 1), 9 top interface (the top body's), 5 bottom
+    (z = 0); cell_tags[c] = 2 for cells of the top body, 0 otherwise."""
+    n_bottom = 2 * n_top if n_bottom is None else n_bottom
+    top = create_box((0.0, 0.0, 1.0), (1.0, 1.0, 2.0), (n_top,) * 3, "tetrahedron", reorder)
+    bot = create_box((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), (n_bottom,) * 3, "tetrahedron", reorder)
+    mesh = merge_meshes([top, bot])
+    x = mesh.geometry.x
+    z = x[:, 2]
+    cells = mesh.geometry.dofmap
+    nct = top.num_cells
+    is_top_node = np.arange(mesh.num_nodes) < top.num_nodes
+    # candidate cells: those with a vertex on the plane (cheap: vertex flags, no global facet sort)
+    def tagged(on_plane, body_cells):
+        cand = body_cells[on_plane[cells[body_cells]].any(axis=1)]
+        return _facets_on_plane(cells, cand, on_plane)
+
+    top_cells = np.arange(nct, dtype=np.int64)
+    bot_cells = np.arange(nct, mesh.num_cells, dtype=np.int64)
+    f_top = tagged(np.isclose(z, 2.0), top_cells)
+    f_tif = tagged(np.isclose(z, 1.0) & is_top_node, top_cells)
+    f_bif = tagged(np.isclose(z, 1.0) & ~is_top_node, bot_cells)
+    f_bot = tagged(np.isclose(z, 0.0), bot_cells)
+    ents = np.concatenate([f_top, f_bif, f_tif, f_bot], axis=0)
+    vals = np.concatenate([np.full(f.shape[0], v, dtype=np.int32) for f, v in
+                           ((f_top, CONTACT_TOP), (f_bif, CONTACT_BOTTOM_INTERFACE), (f_tif, CONTACT_TOP_INTERFACE),
+                            (f_bot, CONTACT_BOTTOM))])
+    if theta != 0.0:
+        R = rotation_matrix([1 / np.sqrt(2), 1 / np.sqrt(2), 0], -theta)
+        mesh.geometry.x[:] = x @ R.T
+    cell_tags = np.zeros(mesh.num_cells, dtype=np.int32)
+    cell_tags[:nct] = 2
+    return mesh, MeshTags(mesh, 2, ents, vals), cell_tags

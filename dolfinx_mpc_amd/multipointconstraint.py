@@ -253,6 +253,118 @@ class MultiPointConstraint:
                             np.array(coeffs, dtype=np.float64), np.zeros(len(masters), dtype=np.int32),
                             np.array(offsets, dtype=np.int32))
 
+    def create_contact_inelastic_condition(self, meshtags, slave_marker: int, master_marker: int,
+                                           eps2: float = 1e-20, allow_missing_masters: bool = False,
+                                           num_threads: Optional[int] = 1):
+        """u_s = u_m between two sets of tagged facets whose surfaces coincide; the vertices need not
+        align (python/src/dolfinx_mpc/multipointconstraint.py:465-501, cpp/ContactConstraint.h:908-1174,
+        serial branch).  Every dof block in the closure of the slave facets is tied, per component, to
+        the dof blocks of the master-side cell it collides with, weighted by that cell's basis functions
+        at the slave point; weights with |c| <= 1e-6 are dropped (cpp/ContactConstraint.h:1033).
+
+        Output shape: slaves = block * bs + j for j < bs, masters = master block * bs + j, the same
+        weights for every component.  A slave point that touches no master cell raises RuntimeError
+        unless ``allow_missing_masters`` (then the block is skipped), as the reference does in serial
+        (cpp/ContactConstraint.h:1086-1094)."""
+        from scipy.spatial import cKDTree
+
+        from .fem import locate_dofs_topological
+        from .mesh import facet_vertices
+
+        self._already_finalized()
+        V = self.V
+        mesh = V.mesh
+        bs = V.dofmap.bs
+        tdim = mesh.tdim
+        fdim = tdim - 1
+        x = mesh.geometry.x
+        slave_blocks = locate_dofs_topological(V, fdim, meshtags.find(slave_marker))
+        if slave_blocks.size == 0:
+            return
+        mfac = meshtags.find(master_marker)
+        if mfac.shape[0] == 0:
+            if allow_missing_masters:
+                return
+            raise RuntimeError("No masters found on contact surface (when executed in serial). Please make sure "
+                               "that the surfaces are in contact, or increase the tolerance eps2.")
+        pts = V.tabulate_dof_coordinates()[slave_blocks]
+        # candidate master cells per slave point: the cells of the nearest master facets (by centroid)
+        mcells = mfac[:, 0].astype(np.int64)
+        cent = x[facet_vertices(mesh, mfac)].mean(axis=1)
+        k = int(min(16, mfac.shape[0]))
+        _, near = cKDTree(cent).query(pts, k=k)
+        near = near.reshape(pts.shape[0], k)
+        tol = max(np.sqrt(eps2), 1e-12)
+        found = np.full(pts.shape[0], -1, dtype=np.int64)
+        lam_found = np.zeros((pts.shape[0], tdim + 1))
+
+        def barycentric(cells, p):
+            """barycentric coordinates of points p[i] in cells[i] (affine simplices)"""
+            xv = x[mesh.geometry.dofmap[cells]]  # (n, tdim+1, 3)
+            J = np.transpose(xv[:, 1:, :] - xv[:, :1, :], (0, 2, 1))[:, :, :tdim]  # (n, 3, tdim)
+            rhs = (p - xv[:, 0, :])
+            if tdim == 2:
+                J, rhs = J[:, :2, :], rhs[:, :2]
+            mu = np.linalg.solve(J, rhs[:, :, None])[:, :, 0]
+            lam = np.concatenate([1.0 - mu.sum(axis=1, keepdims=True), mu], axis=1)
+            return lam, xv
+
+        for col in range(k):
+            todo = np.flatnonzero(found < 0)
+            if todo.size == 0:
+                break
+            cells = mcells[near[todo, col]]
+            lam, xv = barycentric(cells, pts[todo])
+            h = np.linalg.norm(xv[:, 1, :] - xv[:, 0, :], axis=1)
+            inside = lam.min(axis=1) >= -tol / np.maximum(h, 1e-300) - 1e-10
+            hit = todo[inside]
+            found[hit] = cells[inside]
+            lam_found[hit] = lam[inside]
+        missing = np.flatnonzero(found < 0)
+        if missing.size:  # points the nearest-centroid shortlist missed: try every master cell
+            ucells = np.unique(mcells)
+            for i in missing:
+                lam, xv = barycentric(ucells, np.repeat(pts[i][None, :], ucells.size, axis=0))
+                h = np.linalg.norm(xv[:, 1, :] - xv[:, 0, :], axis=1)
+                ok = np.flatnonzero(lam.min(axis=1) >= -tol / np.maximum(h, 1e-300) - 1e-10)
+                if ok.size:
+                    found[i], lam_found[i] = ucells[ok[0]], lam[ok[0]]
+        missing = np.flatnonzero(found < 0)
+        if missing.size and not allow_missing_masters:
+            raise RuntimeError("No masters found on contact surface (when executed in serial). Please make sure "
+                               "that the surfaces are in contact, or increase the tolerance eps2.")
+        keep = found >= 0
+        slave_blocks, found, lam_found = slave_blocks[keep], found[keep], lam_found[keep]
+        # basis functions of the master cell at the slave point (Lagrange P1 / P2 in barycentric form)
+        if V.degree == 1:
+            basis = lam_found
+        else:
+            from .mesh import TET_EDGES, TRI_EDGES
+
+            le = TET_EDGES if tdim == 3 else TRI_EDGES
+            basis = np.concatenate([lam_found * (2.0 * lam_found - 1.0),
+                                    4.0 * lam_found[:, le[:, 0]] * lam_found[:, le[:, 1]]], axis=1)
+        cell_blocks = V.dofmap.list[found]  # (n, nd)
+        nz = np.abs(basis) > 1e-6  # cpp/ContactConstraint.h:1033
+        cnt = nz.sum(axis=1)
+        mblk = cell_blocks[nz]  # row-major: per slave block, masters in cell-dof order
+        coef = basis[nz]
+        n = slave_blocks.size
+        # per component j: slave = block*bs + j, masters = master block*bs + j (cpp/ContactConstraint.h:1054-1066)
+        blk_off = np.concatenate([[0], np.cumsum(cnt)])
+        slaves = (slave_blocks[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)
+        rep = np.repeat(cnt, bs)
+        offsets = np.concatenate([[0], np.cumsum(rep)]).astype(np.int32)
+        # output entry -> (slave block, component, position inside the block's master list)
+        seg = np.repeat(np.arange(n * bs), rep)
+        within = np.arange(int(rep.sum())) - np.repeat(offsets[:-1].astype(np.int64), rep)
+        src = blk_off[seg // bs] + within
+        comp = seg % bs
+        masters = mblk[src].astype(np.int64) * bs + comp
+        coeffs = coef[src]
+        self.add_constraint(V, slaves.astype(np.int32), masters.astype(np.int64), coeffs.astype(np.float64),
+                            np.zeros(masters.size, dtype=np.int32), offsets)
+
     # -- accessors (python/src/dolfinx_mpc/multipointconstraint.py:503-584) ----
     @property
     def is_slave(self) -> np.ndarray:
