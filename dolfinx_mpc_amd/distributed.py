@@ -30,35 +30,56 @@ import numpy as np
 from .mesh import _KUHN, Mesh, _tile_permutation
 
 
-def create_slab_mesh(N: int, rank: int, world: int, reorder=None) -> Mesh:
-    """Local mesh of rank ``rank``: owned cubes + (r>0) one ghost cube layer below.
-    Nodes are numbered owned-first (tile order inside each group), cells
-    owned-first.  Sets ``mesh.num_owned_nodes``, ``mesh.node_global`` (global
-    node id, x fastest over the (N+1, N+1, N*world+1) grid), ``mesh.num_owned_cells``."""
-    kz0 = rank * N - (1 if rank > 0 else 0)  # first cube layer held
-    kz1 = (rank + 1) * N  # one past the last cube layer
-    nzc = kz1 - kz0
-    nx1, ny1, nz1 = N + 1, N + 1, nzc + 1
-    pz0 = kz0  # first node plane held
-    xs = np.linspace(0.0, 1.0, N + 1)
-    zs = (pz0 + np.arange(nz1)) / float(N)
-    Z, Y, X = np.meshgrid(zs, xs, xs, indexing="ij")
+def slab_layers(n_axis: int, rank: int, world: int):
+    """cube layers [l0, l1) of rank ``rank`` when ``n_axis`` layers are dealt out as evenly as possible"""
+    return (rank * n_axis) // world, ((rank + 1) * n_axis) // world
+
+
+def create_box_slab(p0, p1, n, rank: int, world: int, axis: int = 2, reorder=None, layers=None,
+                    global_offset: int = 0, ghost_layers: int = 1) -> Mesh:
+    """Rank ``rank``'s part of ONE global box of ``n = (nx, ny, nz)`` cubes (6 tets each) on [p0, p1],
+    cut into ``world`` slabs of cube layers along ``axis`` (strong scaling: the global problem is fixed).
+    The local mesh holds the owned cube layers ``[l0, l1)`` (``layers`` or an even split) plus, for
+    rank > 0, ``ghost_layers`` ghost layers below (never integrated; they supply the columns the lower
+    neighbour's contributions need: one layer for plain assembly, more when constraints carry
+    contributions further, see create_stacked_cubes_slab).  Node planes l0 .. l1-1 are owned (the last rank also owns plane n_axis); the
+    plane l1 above is held as ghost nodes whose partial sums go to rank + 1, the plane l0 - 1 below as
+    column-only ghosts.  Nodes and cells are numbered owned-first (tile order inside each group).
+
+    Sets ``num_owned_nodes``, ``num_owned_cells``, ``node_global`` (id in the global box, x fastest,
+    + ``global_offset``), ``node_send_up`` (bool: ghost node of the upper interface plane)."""
+    nx, ny, nz = (int(v) for v in n)
+    nax = (nx, ny, nz)[axis]
+    l0, l1 = slab_layers(nax, rank, world) if layers is None else layers
+    if l1 <= l0:
+        raise RuntimeError(f"create_box_slab: rank {rank} of {world} gets no cube layer of {nax}")
+    c0 = max(0, l0 - ghost_layers) if rank > 0 else l0  # first cube layer held
+    ncl = l1 - c0  # cube layers held
+    # local grid: `ncl` cube layers along `axis`, full extent in the other two directions
+    nloc = [nx, ny, nz]
+    nloc[axis] = ncl
+    lx, ly, lz = nloc
+    nx1, ny1, nz1 = lx + 1, ly + 1, lz + 1
+    ax = [np.linspace(p0[d], p1[d], (nx, ny, nz)[d] + 1) for d in range(3)]
+    ax[axis] = ax[axis][c0 : l1 + 1]
+    Z, Y, X = np.meshgrid(ax[2], ax[1], ax[0], indexing="ij")
     x = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
-    k, j, i = np.meshgrid(np.arange(nzc), np.arange(N), np.arange(N), indexing="ij")
+    k, j, i = np.meshgrid(np.arange(lz), np.arange(ly), np.arange(lx), indexing="ij")
     base = ((k * ny1 + j) * nx1 + i).ravel().astype(np.int64)
     corner = np.empty((base.size, 8), dtype=np.int64)
     for b in range(8):
         corner[:, b] = base + (b & 1) + ((b >> 1) & 1) * nx1 + ((b >> 2) & 1) * nx1 * ny1
     cells = corner[:, _KUHN]  # (ncubes, 6, 4) lexicographic local node ids
-    cube_kz = (kz0 + k).ravel()
-    node_plane = pz0 + np.repeat(np.arange(nz1), nx1 * ny1)
+    cube_layer = c0 + (i, j, k)[axis].ravel()
+    gk, gj, gi = np.meshgrid(np.arange(nz1), np.arange(ny1), np.arange(nx1), indexing="ij")
+    loc = [gi.ravel(), gj.ravel(), gk.ravel()]
+    node_plane = c0 + loc[axis]  # global plane index along the slab axis
     last = rank == world - 1
-    owned_node = (node_plane >= rank * N) & ((node_plane < (rank + 1) * N) | (last & (node_plane == (rank + 1) * N)))
-    owned_cube = cube_kz >= rank * N
-    # numbering: tile order (or lexicographic), owned first
+    owned_node = (node_plane >= l0) & ((node_plane < l1) | (last & (node_plane == l1)))
+    owned_cube = cube_layer >= l0
     if reorder is not None:
         tperm = _tile_permutation((nx1, ny1, nz1), reorder)  # old -> tile position
-        cperm = _tile_permutation((N, N, nzc), reorder)
+        cperm = _tile_permutation((lx, ly, lz), reorder)
     else:
         tperm = np.arange(x.shape[0])
         cperm = np.arange(base.size)
@@ -67,8 +88,9 @@ def create_slab_mesh(N: int, rank: int, world: int, reorder=None) -> Mesh:
     perm[order] = np.arange(order.size)  # old -> new
     corder = np.lexsort((cperm, ~owned_cube))
     cells = perm[cells[corder]].reshape(-1, 4)
-    gk, gj, gi = node_plane, np.tile(np.repeat(np.arange(ny1), nx1), nz1), np.tile(np.arange(nx1), ny1 * nz1)
-    node_global = ((gk.astype(np.int64) * ny1 + gj) * nx1 + gi)[order]
+    glob = [loc[0].astype(np.int64), loc[1].astype(np.int64), loc[2].astype(np.int64)]
+    glob[axis] = glob[axis] + c0
+    node_global = ((glob[2] * (ny + 1) + glob[1]) * (nx + 1) + glob[0])[order] + int(global_offset)
     mesh = Mesh(x[order], cells.astype(np.int32), "tetrahedron")
     if reorder is not None:
         from .mesh import _tile_ids, _tile_starts
@@ -80,8 +102,109 @@ def create_slab_mesh(N: int, rank: int, world: int, reorder=None) -> Mesh:
     mesh.num_owned_nodes = int(owned_node.sum())
     mesh.num_owned_cells = int(owned_cube.sum()) * 6
     mesh.node_global = node_global
+    mesh.node_send_up = ((node_plane == l1) & ~owned_node)[order]
+    mesh.node_plane = node_plane[order]
+    mesh.partition = dict(axis=axis, layers=(l0, l1), n=(nx, ny, nz), rank=rank, world=world)
+    return mesh
+
+
+def create_slab_mesh(N: int, rank: int, world: int, reorder=None) -> Mesh:
+    """Weak-scaling partition: rank ``rank``'s N^3 box of the (N, N, N*world) mesh on
+    [0,1]^2 x [0,world] (every rank gets the same amount of work whatever ``world`` is)."""
+    mesh = create_box_slab((0.0, 0.0, 0.0), (1.0, 1.0, float(world)), (N, N, N * world), rank, world, 2, reorder,
+                           layers=(rank * N, (rank + 1) * N))
     mesh.slab = (N, rank, world)
     return mesh
+
+
+def merge_slab_meshes(meshes) -> Mesh:
+    """Disjoint union of slab meshes of several bodies held by ONE rank (the two cubes of the contact
+    benchmark): nodes owned-first over all bodies, then the ghosts; cells likewise; the per-node
+    partition data (global id, send-up flag) follows."""
+    nn = [m.num_nodes for m in meshes]
+    no = [m.num_owned_nodes for m in meshes]
+    noff_owned = np.concatenate([[0], np.cumsum(no)])
+    ng = [a - b for a, b in zip(nn, no)]
+    goff = noff_owned[-1] + np.concatenate([[0], np.cumsum(ng)])
+    new_of = []  # per body: old local node -> new local node
+    for b, m in enumerate(meshes):
+        t = np.empty(nn[b], dtype=np.int64)
+        t[: no[b]] = noff_owned[b] + np.arange(no[b])
+        t[no[b] :] = goff[b] + np.arange(ng[b])
+        new_of.append(t)
+    ntot = int(sum(nn))
+    x = np.empty((ntot, 3))
+    node_global = np.empty(ntot, dtype=np.int64)
+    send_up = np.zeros(ntot, dtype=bool)
+    body = np.empty(ntot, dtype=np.int32)
+    for b, m in enumerate(meshes):
+        x[new_of[b]] = m.geometry.x
+        node_global[new_of[b]] = m.node_global
+        send_up[new_of[b]] = m.node_send_up
+        body[new_of[b]] = b
+    owned_cells = [new_of[b][m.geometry.dofmap[: m.num_owned_cells]] for b, m in enumerate(meshes)]
+    ghost_cells = [new_of[b][m.geometry.dofmap[m.num_owned_cells :]] for b, m in enumerate(meshes)]
+    cells = np.concatenate(owned_cells + ghost_cells, axis=0)
+    cell_body = np.concatenate([np.full(c.shape[0], b, dtype=np.int32) for b, c in enumerate(owned_cells)]
+                               + [np.full(c.shape[0], b, dtype=np.int32) for b, c in enumerate(ghost_cells)])
+    out = Mesh(x, cells.astype(np.int32), meshes[0].cell_name)
+    out.num_owned_nodes = int(noff_owned[-1])
+    out.num_owned_cells = int(sum(m.num_owned_cells for m in meshes))
+    out.node_global = node_global
+    out.node_send_up = send_up
+    out.node_body = body
+    out.cell_body = cell_body
+    if all(m.node_tile_offsets is not None for m in meshes):
+        hints = []
+        for b, m in enumerate(meshes):
+            h = m.node_tile_offsets.astype(np.int64)
+            hints.append(new_of[b][h])
+        out.node_tile_offsets = np.unique(np.concatenate(hints)).astype(np.int32)
+    out.partition = dict(meshes[0].partition, bodies=len(meshes))
+    return out
+
+
+def create_stacked_cubes_slab(n_top: int, rank: int, world: int, theta: float = 0.0, reorder=None, axis: int = 1):
+    """Rank ``rank``'s part of the two-body contact mesh (``mesh.create_stacked_cubes(n_top)``, bottom body
+    2 n_top cubes per side): BOTH bodies are cut along ``axis`` (default y, a direction inside the contact
+    plane), at the same physical positions, so that the two interface layers of a slab live on one GPU
+    and every slave finds its masters locally.
+    ``n_top`` must be divisible by ``world``.  Returns (mesh, facet_tags)."""
+    from .mesh import (CONTACT_BOTTOM, CONTACT_BOTTOM_INTERFACE, CONTACT_TOP, CONTACT_TOP_INTERFACE, MeshTags,
+                       _facets_on_plane, rotation_matrix)
+
+    if axis == 2:
+        raise RuntimeError("create_stacked_cubes_slab: cut along x or y (z is the contact normal)")
+    if n_top % world != 0:
+        raise RuntimeError("create_stacked_cubes_slab: n_top must be divisible by the number of ranks")
+    lt = (rank * n_top // world, (rank + 1) * n_top // world)
+    top = create_box_slab((0.0, 0.0, 1.0), (1.0, 1.0, 2.0), (n_top,) * 3, rank, world, axis, reorder, layers=lt)
+    # two fine ghost layers below: a master row on the slab's upper plane collects the contributions of the
+    # cells round its slaves (fine nodes one fine layer below the plane), which reach two fine layers down
+    bot = create_box_slab((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), (2 * n_top,) * 3, rank, world, axis, reorder,
+                          layers=(2 * lt[0], 2 * lt[1]), global_offset=(n_top + 1) ** 3, ghost_layers=2)
+    mesh = merge_slab_meshes([top, bot])
+    z = mesh.geometry.x[:, 2]
+    cells = mesh.geometry.dofmap.astype(np.int64)
+    is_top_node = mesh.node_body == 0
+
+    def tagged(on_plane, body):
+        ids = np.flatnonzero(mesh.cell_body == body)
+        cand = ids[on_plane[cells[ids]].any(axis=1)]
+        return _facets_on_plane(cells, cand, on_plane)
+
+    f_top = tagged(np.isclose(z, 2.0), 0)
+    f_tif = tagged(np.isclose(z, 1.0) & is_top_node, 0)
+    f_bif = tagged(np.isclose(z, 1.0) & ~is_top_node, 1)
+    f_bot = tagged(np.isclose(z, 0.0), 1)
+    ents = np.concatenate([f_top, f_bif, f_tif, f_bot], axis=0)
+    vals = np.concatenate([np.full(f.shape[0], v, dtype=np.int32) for f, v in
+                           ((f_top, CONTACT_TOP), (f_bif, CONTACT_BOTTOM_INTERFACE), (f_tif, CONTACT_TOP_INTERFACE),
+                            (f_bot, CONTACT_BOTTOM))])
+    if theta != 0.0:
+        R = rotation_matrix([1 / np.sqrt(2), 1 / np.sqrt(2), 0], -theta)
+        mesh.geometry.x[:] = mesh.geometry.x @ R.T
+    return mesh, MeshTags(mesh, 2, ents, vals)
 
 
 class SlabExchange:
@@ -100,20 +223,24 @@ class SlabExchange:
 
         self.rank, self.world = rank, world
         self.device = device
-        N = mesh.slab[0]
         if space is not None:
             bs = space.dofmap.bs
-            blk_global, blk_plane = space.dof_global, space.dof_plane
+        if space is not None and space.degree == 2:
+            # P2 on the weak-scaling slabs: edge dofs carry their own global ids / planes
+            N = mesh.slab[0]
+            blk_global = space.dof_global
+            blk_send = space.dof_plane == (rank + 1) * N
         else:
+            # dofs numbered like the mesh nodes (P1, scalar or blocked)
             blk_global = mesh.node_global
-            blk_plane = mesh.node_global // ((N + 1) * (N + 1))
+            blk_send = mesh.node_send_up
         # unrolled dofs: dof = block * bs + component
         g = (blk_global[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)
-        plane = np.repeat(blk_plane, bs)
+        send = np.repeat(blk_send, bs)
         self.send_to = rank + 1 if rank + 1 < world else None
         self.recv_from = rank - 1 if rank > 0 else None
-        # ---- what I send: every entry of my top-plane rows -------------------
-        top = np.flatnonzero(plane == (rank + 1) * N) if self.send_to is not None else np.zeros(0, dtype=np.int64)
+        # ---- what I send: every entry of my upper-interface (ghost) rows -------
+        top = np.flatnonzero(send) if self.send_to is not None else np.zeros(0, dtype=np.int64)
         top = top[np.argsort(g[top])]
         cnt = rowptr[top + 1] - rowptr[top]
         pos = (np.repeat(rowptr[top].astype(np.int64) - np.concatenate([[0], np.cumsum(cnt)[:-1]]), cnt)

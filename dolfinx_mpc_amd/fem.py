@@ -102,9 +102,8 @@ class FunctionSpace:
             nblocks = mesh.num_owned_nodes
             nghost = mesh.num_nodes - mesh.num_owned_nodes
             if mesh.node_global is not None:
-                N = mesh.slab[0]
                 self.dof_global = mesh.node_global
-                self.dof_plane = mesh.node_global // ((N + 1) * (N + 1))
+                self.dof_plane = getattr(mesh, "node_plane", None)
         elif mesh.num_owned_nodes == mesh.num_nodes:
             cell_edges, ev = mesh.edges()
             cell_dofs = np.concatenate([mesh.geometry.dofmap, cell_edges + mesh.num_nodes], axis=1)

@@ -209,3 +209,130 @@ def test_slab_partition_gpu_kernels_two_ranks(oracle, tmp_path):
     b = np.zeros(n)
     b[np.concatenate(brow)] = np.concatenate(bval)
     assert np.allclose(b, bref, rtol=0, atol=1e-12 * abs(bref).max())
+
+
+# ---------------------------------------------------------------------------------------------
+# strong-scaling partition of ONE box (create_box_slab) and the two-body contact mesh (config 4)
+# ---------------------------------------------------------------------------------------------
+def _strong_problem(mesh, kind):
+    from dolfinx_mpc_amd import fem
+    from problems import periodic_raw
+
+    if kind == "poisson":
+        V = fem.functionspace(mesh, ("Lagrange", 1))
+        dofs = fem.locate_dofs_geometrical(
+            V, lambda x: np.isclose(x[1], 0) | np.isclose(x[1], 1) | np.isclose(x[2], 0) | np.isclose(x[2], 1))
+        bc = fem.dirichletbc(0.3, dofs, V)
+        return V, [bc], periodic_raw(V, [bc]), fem.form_stiffness(V), fem.form_source(V, fem.FN_BENCH_PERIODIC)
+    raise ValueError(kind)
+
+
+def _strong_worker(rank, world, outdir, kind, n, axis, reorder):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+
+    from dolfinx_mpc_amd.distributed import SlabExchange, create_box_slab, create_stacked_cubes_slab
+    from oracle import pyoracle as po
+
+    dist.init_process_group("gloo", init_method=f"file://{outdir}/rendezvous", rank=rank, world_size=world)
+    if kind == "contact":
+        import dolfinx_mpc_amd as dm
+        from dolfinx_mpc_amd import fem
+        from dolfinx_mpc_amd.mesh import (CONTACT_BOTTOM, CONTACT_BOTTOM_INTERFACE, CONTACT_TOP,
+                                          CONTACT_TOP_INTERFACE)
+
+        mesh, ft = create_stacked_cubes_slab(n, rank, world, theta=0.3, reorder=reorder, axis=axis)
+        V = fem.functionspace(mesh, ("Lagrange", 1, (3,)))
+        u_top = fem.Function(V)
+        u_top.x.array[2::3] = -4.25e-1
+        bcs = [fem.dirichletbc(fem.Function(V), fem.locate_dofs_topological(V, 2, ft.find(CONTACT_BOTTOM)), V),
+               fem.dirichletbc(u_top, fem.locate_dofs_topological(V, 2, ft.find(CONTACT_TOP)), V)]
+        a = fem.form_elasticity(V, 500.0, 0.0)
+        L = fem.form_source(V, fem.FN_CONSTANT_VEC, constant=[1.0, 0.3, -0.2, -1.0])
+        # the product's builder on the LOCAL mesh (owned + ghost cells): every local slave finds its masters locally
+        pm = dm.MultiPointConstraint(V)
+        pm.create_contact_inelastic_condition(ft, CONTACT_BOTTOM_INTERFACE, CONTACT_TOP_INTERFACE)
+        raw = (pm._slaves, pm._masters, pm._coeffs, pm._owners, pm._offsets)
+    else:
+        mesh = create_box_slab((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), (n, n, n), rank, world, axis, reorder)
+        V, bcs, raw, a, L = _strong_problem(mesh, kind)
+    bs = V.dofmap.bs
+    mpc = po.OracleMPC.from_raw(V, *raw)
+    pattern = po.create_pattern(a, mpc, mpc)
+    A = po.assemble_matrix(a, mpc, bcs=bcs, pattern=pattern)
+    b = po.assemble_vector(L, mpc)
+    po.apply_lifting(b, [a], [bcs], mpc)
+    ex = SlabExchange(mesh, pattern[0], pattern[1], rank, world, bs=bs)
+    vals = torch.from_numpy(A.data.copy())
+    bt = torch.from_numpy(b.copy())
+    ex.reduce_matrix(vals)
+    ex.reduce_vector(bt)
+    A = scipy.sparse.csr_matrix((vals.numpy(), A.indices, A.indptr), shape=A.shape)
+    g = (mesh.node_global[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)
+    nown = V.dofmap.index_map.size_local * bs
+    Aown = A[:nown].tocoo()
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), row=g[Aown.row], col=g[Aown.col], val=Aown.data,
+             brow=g[:nown], bval=bt.numpy()[:nown], nslaves=mpc.num_local_slaves, ncells=mesh.num_owned_cells)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _gather(tmp_path, world, n):
+    rows, cols, vals, brow, bval, nsl, ncells = [], [], [], [], [], 0, 0
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        rows.append(d["row"]), cols.append(d["col"]), vals.append(d["val"])
+        brow.append(d["brow"]), bval.append(d["bval"])
+        nsl += int(d["nslaves"])
+        ncells += int(d["ncells"])
+    A = scipy.sparse.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsr()
+    assert np.array_equal(np.sort(np.concatenate(brow)), np.arange(n))  # every row owned exactly once
+    b = np.zeros(n)
+    b[np.concatenate(brow)] = np.concatenate(bval)
+    return A, b, nsl, ncells
+
+
+@pytest.mark.parametrize("world,n,axis,reorder", [(2, 4, 2, None), (3, 5, 2, (2, 2, 2)), (2, 5, 1, (2, 2, 2)), (4, 6, 2, None)])
+def test_strong_scaling_partition_matches_global_assembly(oracle, tmp_path, world, n, axis, reorder):
+    """ONE n^3 unit cube cut into `world` slabs of layers (uneven when world does not divide n): the
+    union of the ranks' owned rows after the exchange is the single-process matrix and vector."""
+    import torch.multiprocessing as mp
+
+    from dolfinx_mpc_amd.mesh import create_unit_cube
+
+    mp.spawn(_strong_worker, args=(world, str(tmp_path), "poisson", n, axis, reorder), nprocs=world, join=True)
+    gmesh = create_unit_cube(n, n, n)
+    V, bcs, raw, a, L = _strong_problem(gmesh, "poisson")
+    mpc = oracle.OracleMPC.from_raw(V, *raw)
+    Aref = oracle.assemble_matrix(a, mpc, bcs=bcs)
+    bref = oracle.assemble_vector(L, mpc)
+    oracle.apply_lifting(bref, [a], [bcs], mpc)
+    A, b, nsl, ncells = _gather(tmp_path, world, V.num_dofs)
+    assert ncells == gmesh.num_cells and nsl == mpc.num_local_slaves
+    assert abs(A - Aref).max() < 1e-12 * abs(Aref).max()
+    assert np.allclose(b, bref, rtol=0, atol=1e-13 * max(1.0, abs(bref).max()))
+
+
+@pytest.mark.parametrize("world,n_top,reorder", [(2, 2, None), (2, 4, (2, 2, 2))])
+def test_contact_two_body_partition_matches_global_assembly(oracle, tmp_path, world, n_top, reorder):
+    """BASELINE config 4 on `world` ranks: both bodies cut along y at the same positions, so the slave
+    and master layers of a slab are on one rank and the constraint needs no exchange of its own; the
+    interface rows (including master rows that collected slave contributions) travel in the usual
+    neighbour exchange.  Against a single-process assembly with the brute-force constraint."""
+    import torch.multiprocessing as mp
+
+    from problems import case_contact_two_body
+
+    mp.spawn(_strong_worker, args=(world, str(tmp_path), "contact", n_top, 1, reorder), nprocs=world, join=True)
+    case = case_contact_two_body(n_top, None, 0.3)
+    mpc = oracle.OracleMPC.from_raw(case.V, *case.raw)
+    a = __import__("dolfinx_mpc_amd").fem.form_elasticity(case.V, 500.0, 0.0)
+    Aref = oracle.assemble_matrix(a, mpc, bcs=case.bcs)
+    bref = oracle.assemble_vector(case.L, mpc)
+    oracle.apply_lifting(bref, [a], [case.bcs], mpc)
+    A, b, nsl, ncells = _gather(tmp_path, world, case.V.num_dofs)
+    assert ncells == case.mesh.num_cells and nsl == mpc.num_local_slaves
+    assert abs(A - Aref).max() < 1e-12 * abs(Aref).max()
+    assert np.allclose(b, bref, rtol=0, atol=1e-12 * max(1.0, abs(bref).max()))
