@@ -27,6 +27,8 @@ ROWBLOCK_MAX_ROWS = int(os.environ.get("MPCX_ROWBLOCK_MAX_ROWS", 512))
 # four workgroups of 512 threads on a CU -- 1.75 ms against 1.82 ms at config 2 (sweep in DESIGN.md section 5)
 ROWBLOCK_LIGHT_MAX_NNZ = int(os.environ.get("MPCX_ROWBLOCK_LIGHT_MAX_NNZ", 4608))
 ROWBLOCK_LIGHT_MAX_ROWS = int(os.environ.get("MPCX_ROWBLOCK_LIGHT_MAX_ROWS", 256))
+# slave entities x element-tensor entries above which the master contributions skip the host-built plan
+MPC_PLAN_MAX_ENTRIES = int(float(os.environ.get("MPCX_MPC_PLAN_MAX_ENTRIES", 1e8)))
 # scatter-offset rows are dictionary-compressed when at most this many are distinct (table stays cache resident)
 MAX_OFFSET_PATTERNS = 4096
 
@@ -38,9 +40,10 @@ def _pair(constraint):
     return constraint[0], constraint[1]
 
 
-def _pattern_on_device(V0, V1, mpc0, mpc1):
-    """(rowptr, cols) built by the HIP kernels (include/mpcx.h, mpcx_pattern_device_*); None if a
-    row block has more distinct column blocks than the kernel holds in LDS."""
+def _pattern_on_device(V0, V1, mpc0, mpc1, keep_on_device: bool = False):
+    """(rowptr int64, cols int32) built by the HIP kernels (include/mpcx.h, mpcx_pattern_device_*), as
+    numpy arrays or -- ``keep_on_device`` -- as device tensors; None if a row block has more distinct
+    column blocks than the kernel holds in LDS."""
     import torch
 
     L = _native.lib()
@@ -84,24 +87,24 @@ def _pattern_on_device(V0, V1, mpc0, mpc1):
     rowptr64 = torch.zeros(nb0 * bs0 + 1, dtype=torch.int64, device=dev)
     torch.cumsum(per_row, 0, out=rowptr64[1:])
     nnz = int(rowptr64[-1].item())
-    if nnz > np.iinfo(np.int32).max:
-        raise RuntimeError("mpcx_pattern_device: nnz exceeds 2^31-1 (shard the mesh)")
-    rowptr = rowptr64.to(torch.int32)
     cols = torch.empty(nnz, dtype=torch.int32, device=dev)
-    _native.check(L.mpcx_pattern_device_rows(*args, rowptr.data_ptr(), bs0, cols.data_ptr(), flag.data_ptr(), st),
+    _native.check(L.mpcx_pattern_device_rows(*args, rowptr64.data_ptr(), bs0, cols.data_ptr(), flag.data_ptr(), st),
                   "mpcx_pattern_device_rows")
-    return rowptr.cpu().numpy(), cols.cpu().numpy()
+    if keep_on_device:
+        return rowptr64, cols
+    return rowptr64.cpu().numpy(), cols.cpu().numpy()
 
 
 def create_sparsity_pattern(form: Form, mpc: Union[MultiPointConstraint, Sequence[MultiPointConstraint]],
-                            num_threads: int = 0, where: Optional[str] = None):
-    """MPC sparsity pattern as scalar CSR ``(rowptr, cols)`` with sorted columns:
+                            num_threads: int = 0, where: Optional[str] = None, keep_on_device: bool = False):
+    """MPC sparsity pattern as scalar CSR ``(rowptr int64, cols int32)`` with sorted columns:
     the pattern cpp/utils.h:381-496 inserts into a dolfinx SparsityPattern,
     after ``finalize()`` (python/src/dolfinx_mpc/assemble_matrix.py:68-88).
 
     ``where``: "device" (HIP kernels, 0.5 s at config 2 including the transfers), "host"
     (threaded C++ builder, 2.6 s) or None = env MPCX_PATTERN, default: device when a GPU is
-    present; both give the same arrays."""
+    present; both give the same arrays.  ``keep_on_device``: return device tensors when the device
+    builder ran (create_matrix does: the pattern is consumed there)."""
     mpc0, mpc1 = _pair(mpc)
     mpc0._not_finalized()
     mpc1._not_finalized()
@@ -119,7 +122,7 @@ def create_sparsity_pattern(form: Form, mpc: Union[MultiPointConstraint, Sequenc
 
         where = "device" if torch.cuda.is_available() else "host"
     if where.lower() == "device":
-        out = _pattern_on_device(V0, V1, mpc0, mpc1)
+        out = _pattern_on_device(V0, V1, mpc0, mpc1, keep_on_device)
         if out is not None:
             return out
     if num_threads <= 0:
@@ -134,7 +137,7 @@ def create_sparsity_pattern(form: Form, mpc: Union[MultiPointConstraint, Sequenc
     if not h:
         raise RuntimeError("mpcx_pattern_build failed: " + L.mpcx_last_error().decode())
     try:
-        rowptr = np.empty(L.mpcx_pattern_nrows(h) + 1, dtype=np.int32)
+        rowptr = np.empty(L.mpcx_pattern_nrows(h) + 1, dtype=np.int64)
         cols = np.empty(L.mpcx_pattern_nnz(h), dtype=np.int32)
         L.mpcx_pattern_copy(h, p(rowptr), p(cols))
     finally:
@@ -145,7 +148,7 @@ def create_sparsity_pattern(form: Form, mpc: Union[MultiPointConstraint, Sequenc
 def create_matrix(form: Form, mpc0: MultiPointConstraint, mpc1: Optional[MultiPointConstraint] = None) -> MPCMatrix:
     """python/src/dolfinx_mpc/mpc.cpp:321-344 ``cpp.mpc.create_matrix``."""
     mpc1 = mpc0 if mpc1 is None else mpc1
-    rowptr, cols = create_sparsity_pattern(form, (mpc0, mpc1))
+    rowptr, cols = create_sparsity_pattern(form, (mpc0, mpc1), keep_on_device=True)
     return MPCMatrix(rowptr, cols, mpc1.function_space.num_dofs)
 
 
@@ -220,7 +223,7 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False):
                 pattern = D._to_dev(ids.view(np.int16), dev)  # torch has no uint16 on every build: same bits
         t = (D._to_dev(row0, dev), D._to_dev(off, dev), D._to_dev(ents_b, dev), offs, pattern)
         max_rows = int(np.diff(row0).max())
-        max_nnz = int(np.diff(A.rowptr[row0].astype(np.int64)).max())
+        max_nnz = int(np.diff(A.rowptr[row0]).max())
         s = _native.RowBlockPlanT(nb, max_rows, max_nnz, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
                                   t[3].data_ptr(), D.ptr(pattern))
         return (s, t, {"num_blocks": nb, "num_ents": int(ents_b.size), "max_rows": max_rows,
@@ -252,7 +255,7 @@ def _mpc_plan(A: MPCMatrix, form: Form, i: int, mpc0, mpc1, bc0_h, bc1_h, slave_
             raise RuntimeError("mpcx_mpc_plan_build failed: " + L.mpcx_last_error().decode())
         try:
             n, nt = L.mpcx_mpc_plan_size(h), L.mpcx_mpc_plan_num_targets(h)
-            tgt = np.zeros(max(nt, 1), dtype=np.int32)
+            tgt = np.zeros(max(nt, 1), dtype=np.int64)
             off = np.zeros(max(nt, 1) + 1, dtype=np.int64)
             ent = np.zeros(max(n, 1), dtype=np.int32)
             pq = np.zeros(max(n, 1), dtype=np.int32)
@@ -319,7 +322,12 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
     a.slave_entities = slave_ents.data_ptr()
     a.n_slave_entities = slave_ents.numel() if with_mpc_kernel else 0
     mplan = None
-    if a.n_slave_entities > 0 and not os.environ.get("MPCX_NO_MPC_PLAN"):
+    # the host-built plan (gathered by target: no device atomics) pays off for the usual thin layer of slave
+    # entities; a very large layer of big elements (Taylor-Hood slip walls on 128^3: > 10^8 tensor entries)
+    # would take the host minutes and gigabytes, so those go through matrix_mpc_kernel (device atomics)
+    n0n1 = V0.element_ndofs * V0.dofmap.bs * V1.element_ndofs * V1.dofmap.bs
+    if (a.n_slave_entities > 0 and not os.environ.get("MPCX_NO_MPC_PLAN")
+            and a.n_slave_entities * n0n1 <= MPC_PLAN_MAX_ENTRIES):
         mplan = _mpc_plan(A, form, i, mpc0, mpc1, bc0_h, bc1_h, slave_ents_h)
         a.mpc_plan_targets = mplan[0].numel() if mplan[5] else 0
         (a.mpc_plan_tgt, a.mpc_plan_off, a.mpc_plan_ent, a.mpc_plan_pq,

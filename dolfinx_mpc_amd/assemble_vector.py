@@ -32,7 +32,7 @@ def _vector_plan(form: Form, i: int, V):
         ents = np.ascontiguousarray(integ.entities.astype(np.int32).reshape(-1))
         dm = V.dofmap.list
         nrows = V.num_dofs
-        rowptr = np.arange(nrows + 1, dtype=np.int32)
+        rowptr = np.arange(nrows + 1, dtype=np.int64)
         hints = None
         if V.dof_tile_offsets is not None:
             hints = np.ascontiguousarray(V.dof_tile_offsets.astype(np.int32) * V.dofmap.bs)

@@ -132,7 +132,7 @@ namespace
 struct Pattern
 {
   int32_t nrows = 0;
-  std::vector<int32_t> rowptr;
+  std::vector<int64_t> rowptr;
   std::vector<int32_t> cols;
 };
 
@@ -259,13 +259,7 @@ extern "C" void* mpcx_pattern_build(int64_t num_cells, const int32_t* dofmap0, i
     for (int k = 0; k < bs0; ++k)
     {
       nnz += int64_t(row_count[r]) * bs1;
-      if (nnz > INT32_MAX)
-      {
-        mpcx_set_error("mpcx_pattern_build: nnz exceeds 2^31-1 (shard the mesh)");
-        delete P;
-        return nullptr;
-      }
-      P->rowptr[size_t(r) * bs0 + k + 1] = static_cast<int32_t>(nnz);
+      P->rowptr[size_t(r) * bs0 + k + 1] = nnz;
     }
   P->cols.resize(nnz);
   // block-row start inside each thread's buffer
@@ -296,10 +290,10 @@ extern "C" void* mpcx_pattern_build(int64_t num_cells, const int32_t* dofmap0, i
 
 extern "C" int64_t mpcx_pattern_nnz(void* p) { return static_cast<Pattern*>(p)->cols.size(); }
 extern "C" int32_t mpcx_pattern_nrows(void* p) { return static_cast<Pattern*>(p)->nrows; }
-extern "C" int mpcx_pattern_copy(void* p, int32_t* rowptr, int32_t* cols)
+extern "C" int mpcx_pattern_copy(void* p, mpcx_nnz_t* rowptr, int32_t* cols)
 {
   auto* P = static_cast<Pattern*>(p);
-  std::memcpy(rowptr, P->rowptr.data(), P->rowptr.size() * sizeof(int32_t));
+  std::memcpy(rowptr, P->rowptr.data(), P->rowptr.size() * sizeof(mpcx_nnz_t));
   std::memcpy(cols, P->cols.data(), P->cols.size() * sizeof(int32_t));
   return 0;
 }
@@ -316,7 +310,7 @@ struct RowBlockPlan
 };
 } // namespace
 
-extern "C" void* mpcx_rowblock_plan_build(int32_t nrows, const int32_t* rowptr, int32_t max_rows,
+extern "C" void* mpcx_rowblock_plan_build(int32_t nrows, const mpcx_nnz_t* rowptr, int32_t max_rows,
                                           int32_t max_nnz, int64_t n_entities, int32_t estride,
                                           const int32_t* entities0, const int32_t* dofmap0,
                                           int32_t nd0, int32_t bs0, const int32_t* row_hints,
@@ -439,20 +433,20 @@ namespace
 struct MpcPlan
 {
   // gathered by target: target k (position tgt_pos[k] of vals) sums coef * Ae_ent[pq] over its tuples
-  std::vector<int32_t> tgt_pos; // [n_targets] distinct positions, ascending
+  std::vector<int64_t> tgt_pos; // [n_targets] distinct positions, ascending
   std::vector<int64_t> off;     // [n_targets + 1] into the tuple arrays
   std::vector<int32_t> ent;     // entity (index into the integral's entity list) of every tuple
   std::vector<int32_t> pq;      // p * N1 + q
   std::vector<double> coef;
   // scratch while building
-  std::vector<int32_t> pos;
+  std::vector<int64_t> pos;
 };
-inline int host_csr_find(const int32_t* cols, int lo, int hi, int col)
+inline int64_t host_csr_find(const int32_t* cols, int64_t lo, int64_t hi, int col)
 {
   const int32_t* b = cols + lo;
   const int32_t* e = cols + hi;
   const int32_t* it = std::lower_bound(b, e, col);
-  return (it != e && *it == col) ? int(it - cols) : -1;
+  return (it != e && *it == col) ? int64_t(it - cols) : int64_t(-1);
 }
 } // namespace
 
@@ -462,7 +456,7 @@ extern "C" void* mpcx_mpc_plan_build(int64_t n_slave_entities, const int32_t* sl
                                      const int8_t* bc0, const int8_t* bc1, const int8_t* is_slave0,
                                      const int32_t* m_off0, const int32_t* masters0, const double* coeffs0,
                                      const int8_t* is_slave1, const int32_t* m_off1, const int32_t* masters1,
-                                     const double* coeffs1, const int32_t* rowptr, const int32_t* cols)
+                                     const double* coeffs1, const mpcx_nnz_t* rowptr, const int32_t* cols)
 {
   auto* P = new MpcPlan;
   const int N0 = nd0 * bs0, N1 = nd1 * bs1;
@@ -489,7 +483,7 @@ extern "C" void* mpcx_mpc_plan_build(int64_t n_slave_entities, const int32_t* sl
         cbc[j * bs1 + k] = bc1 && bc1[c];
         csl[j * bs1 + k] = is_slave1[c];
       }
-    auto emit = [&](int p, int q, int pos, double c)
+    auto emit = [&](int p, int q, int64_t pos, double c)
     {
       if (pos < 0 || rbc[p] || cbc[q]) // Dirichlet rows/cols of the element tensor are zero (:510-533)
         return;
@@ -507,7 +501,7 @@ extern "C" void* mpcx_mpc_plan_build(int64_t n_slave_entities, const int32_t* sl
       {
         const int32_t m = masters0[mi];
         const double ci = coeffs0[mi];
-        const int lo = rowptr[m], hi = rowptr[m + 1];
+        const int64_t lo = rowptr[m], hi = rowptr[m + 1];
         for (int q = 0; q < N1; ++q)
         {
           if (csl[q])
@@ -572,10 +566,10 @@ extern "C" void* mpcx_mpc_plan_build(int64_t n_slave_entities, const int32_t* sl
 
 extern "C" int64_t mpcx_mpc_plan_size(void* plan) { return int64_t(static_cast<MpcPlan*>(plan)->pq.size()); }
 extern "C" int64_t mpcx_mpc_plan_num_targets(void* plan) { return int64_t(static_cast<MpcPlan*>(plan)->tgt_pos.size()); }
-extern "C" int mpcx_mpc_plan_copy(void* plan, int32_t* tgt_pos, int64_t* off, int32_t* ent, int32_t* pq, double* coef)
+extern "C" int mpcx_mpc_plan_copy(void* plan, mpcx_nnz_t* tgt_pos, int64_t* off, int32_t* ent, int32_t* pq, double* coef)
 {
   auto* P = static_cast<MpcPlan*>(plan);
-  std::memcpy(tgt_pos, P->tgt_pos.data(), P->tgt_pos.size() * sizeof(int32_t));
+  std::memcpy(tgt_pos, P->tgt_pos.data(), P->tgt_pos.size() * sizeof(mpcx_nnz_t));
   std::memcpy(off, P->off.data(), P->off.size() * sizeof(int64_t));
   std::memcpy(ent, P->ent.data(), P->ent.size() * sizeof(int32_t));
   std::memcpy(pq, P->pq.data(), P->pq.size() * sizeof(int32_t));

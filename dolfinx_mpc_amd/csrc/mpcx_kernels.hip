@@ -31,12 +31,12 @@ __device__ inline void atomic_add_f64(double* p, double v)
 }
 
 // position of `col` in the sorted row [lo, hi) of the CSR, or -1
-__device__ inline int csr_find(const int32_t* __restrict__ cols, int lo, int hi, int col)
+__device__ inline int64_t csr_find(const int32_t* __restrict__ cols, int64_t lo, int64_t hi, int col)
 {
-  const int end = hi;
+  const int64_t end = hi;
   while (lo < hi)
   {
-    const int mid = (lo + hi) >> 1;
+    const int64_t mid = (lo + hi) >> 1;
     if (cols[mid] < col)
       lo = mid + 1;
     else
@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(256) matrix_atomic_kernel(mpcx_matrix_args_t a
   {
     if (rmask[p])
       continue;
-    const int lo = a.rowptr[rows[p]], hi = a.rowptr[rows[p] + 1];
+    const int64_t lo = a.rowptr[rows[p]], hi = a.rowptr[rows[p] + 1];
 #pragma unroll
     for (int q = 0; q < N1; ++q)
     {
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(256) matrix_atomic_kernel(mpcx_matrix_args_t a
         if ((p % BS0) != (q % BS1))
           continue; // structurally zero entry of a component-diagonal form
       }
-      const int pos = csr_find(a.cols, lo, hi, colsd[q]);
+      const int64_t pos = csr_find(a.cols, lo, hi, colsd[q]);
       if (pos >= 0)
         atomic_add_f64(a.vals + pos, Op::get(Ae, p, q));
     }
@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(64) matrix_mpc_kernel(mpcx_matrix_args_t a)
     {
       const int32_t m = a.mpc0.masters[mi];
       const double ci = a.mpc0.coeffs[mi];
-      const int lo = a.rowptr[m], hi = a.rowptr[m + 1];
+      const int64_t lo = a.rowptr[m], hi = a.rowptr[m + 1];
       for (int q = 0; q < N1; ++q)
       {
         const double v = entry(p, q);
@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(64) matrix_mpc_kernel(mpcx_matrix_args_t a)
           // master-master term uses the un-stripped original (:239-245)
           for (int mj = a.mpc1.masters_offsets[colsd[q]]; mj < a.mpc1.masters_offsets[colsd[q] + 1]; ++mj)
           {
-            const int pos = csr_find(a.cols, lo, hi, a.mpc1.masters[mj]);
+            const int64_t pos = csr_find(a.cols, lo, hi, a.mpc1.masters[mj]);
             if (pos >= 0)
               atomic_add_f64(a.vals + pos, ci * a.mpc1.coeffs[mj] * v);
           }
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(64) matrix_mpc_kernel(mpcx_matrix_args_t a)
         else if (!cbc[q])
         {
           // stripped row: slave-slave entries removed (:226-236)
-          const int pos = csr_find(a.cols, lo, hi, colsd[q]);
+          const int64_t pos = csr_find(a.cols, lo, hi, colsd[q]);
           if (pos >= 0)
             atomic_add_f64(a.vals + pos, ci * v);
         }
@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(64) matrix_mpc_kernel(mpcx_matrix_args_t a)
       {
         if (rsl[p] || rbc[p])
           continue;
-        const int pos = csr_find(a.cols, a.rowptr[rows[p]], a.rowptr[rows[p] + 1], m);
+        const int64_t pos = csr_find(a.cols, a.rowptr[rows[p]], a.rowptr[rows[p] + 1], m);
         if (pos >= 0)
           atomic_add_f64(a.vals + pos, cj * entry(p, q));
       }
@@ -310,15 +310,15 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
   const int tid = threadIdx.x;
   const int r0 = a.plan.block_row0[b], r1 = a.plan.block_row0[b + 1];
   const int nrow = r1 - r0;
-  const int nnz0 = a.rowptr[r0];
-  const int nnzb = a.rowptr[r1] - nnz0;
+  const int64_t nnz0 = a.rowptr[r0];
+  const int nnzb = int(a.rowptr[r1] - nnz0);
   double* s_vals = reinterpret_cast<double*>(smem);                        // [max_nnz]
   int32_t* s_rowlo = reinterpret_cast<int32_t*>(s_vals + a.plan.max_nnz); // [max_rows]
 
   for (int i = tid; i < nnzb; i += NT)
     s_vals[i] = 0.0;
   for (int rl = tid; rl < nrow; rl += NT)
-    s_rowlo[rl] = a.rowptr[r0 + rl] - nnz0;
+    s_rowlo[rl] = int(a.rowptr[r0 + rl] - nnz0);
   __syncthreads();
 
   // per-entity index data: everything that is read through the entity index
@@ -509,7 +509,7 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
 __host__ __device__ inline int rotated_local(int i, int64_t cell, int nd) { return int((i + cell % nd) % nd); }
 
 // scatter-offset table (set-up kernel, one thread per (entity, local row block))
-__global__ void scatter_offsets_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+__global__ void scatter_offsets_kernel(const mpcx_nnz_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
                                        int estride, int64_t n_entities, const int32_t* __restrict__ entities0,
                                        const int32_t* __restrict__ entities1, const int32_t* __restrict__ dofmap0,
                                        int nd0, int bs0, const int32_t* __restrict__ dofmap1, int nd1, int bs1,
@@ -522,12 +522,12 @@ __global__ void scatter_offsets_kernel(const int32_t* __restrict__ rowptr, const
   const int i = int(t - e * nd0);
   const int64_t cell0 = entities0[e * estride], cell1 = entities1[e * estride];
   const int r = dofmap0[cell0 * nd0 + (rotate ? rotated_local(i, cell0, nd0) : i)] * bs0;
-  const int lo = rowptr[r], hi = rowptr[r + 1];
+  const int64_t lo = rowptr[r], hi = rowptr[r + 1];
   for (int j = 0; j < nd1; ++j)
   {
     const int c = dofmap1[cell1 * nd1 + (rotate ? rotated_local(j, cell1, nd1) : j)] * bs1;
-    const int pos = csr_find(cols, lo, hi, c);
-    const int o = pos < 0 ? 256 : (pos - lo) / bs1;
+    const int64_t pos = csr_find(cols, lo, hi, c);
+    const int o = pos < 0 ? 256 : int((pos - lo) / bs1);
     if (o > 255)
       atomicOr(overflow, 1);
     out[(e * nd0 + i) * nd1 + j] = uint8_t(o);
@@ -602,7 +602,7 @@ pattern_rows_kernel(int32_t num_blocks0, const int64_t* __restrict__ adj_off, co
                     const int32_t* __restrict__ dofmap1, int nd1, int bs1, const int32_t* __restrict__ c2s_off,
                     const int32_t* __restrict__ c2s, const int32_t* __restrict__ m_off,
                     const int32_t* __restrict__ masters, int32_t* __restrict__ row_count,
-                    const int32_t* __restrict__ rowptr, int bs0, int32_t* __restrict__ cols,
+                    const mpcx_nnz_t* __restrict__ rowptr, int bs0, int32_t* __restrict__ cols,
                     int32_t* __restrict__ overflow)
 {
   // list of thread t: s_list[k * PATTERN_THREADS + t] (bank-conflict-free across the wave)
@@ -668,14 +668,14 @@ pattern_rows_kernel(int32_t num_blocks0, const int64_t* __restrict__ adj_off, co
 }
 
 // ---------------------------------------------------------------------------
-__global__ void add_diagonal_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+__global__ void add_diagonal_kernel(const mpcx_nnz_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
                                     double* vals, const int32_t* __restrict__ dofs, int64_t n, double diagval)
 {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n)
     return;
   const int32_t d = dofs[i];
-  const int pos = csr_find(cols, rowptr[d], rowptr[d + 1], d);
+  const int64_t pos = csr_find(cols, rowptr[d], rowptr[d + 1], d);
   if (pos >= 0)
     atomic_add_f64(vals + pos, diagval);
 }
@@ -1369,7 +1369,7 @@ extern "C" int mpcx_apply_lifting(const mpcx_lifting_args_t* args)
   return unsupported(k);
 }
 
-extern "C" int mpcx_add_diagonal(int32_t nrows, const int32_t* rowptr, const int32_t* cols,
+extern "C" int mpcx_add_diagonal(int32_t nrows, const mpcx_nnz_t* rowptr, const int32_t* cols,
                                  double* vals, const int32_t* dofs, int64_t n, double diagval,
                                  void* stream)
 {
@@ -1417,7 +1417,7 @@ extern "C" int mpcx_mask_dofmap(const int32_t* dofmap, int64_t num_cells, int32_
   return check(hipGetLastError(), "mask_dofmap launch");
 }
 
-extern "C" int mpcx_scatter_offsets(const int32_t* rowptr, const int32_t* cols, int32_t estride,
+extern "C" int mpcx_scatter_offsets(const mpcx_nnz_t* rowptr, const int32_t* cols, int32_t estride,
                                     int64_t n_entities, const int32_t* entities0,
                                     const int32_t* entities1, const int32_t* dofmap0, int32_t nd0,
                                     int32_t bs0, const int32_t* dofmap1, int32_t nd1, int32_t bs1,
@@ -1448,7 +1448,7 @@ extern "C" int mpcx_pattern_device_rows(int32_t num_blocks0, const int64_t* adj_
                                         const int32_t* dofmap1, int32_t nd1, int32_t bs1,
                                         const int32_t* c2s_offsets1, const int32_t* c2s1,
                                         const int32_t* masters_offsets1, const int32_t* masters1,
-                                        int32_t* row_count, const int32_t* rowptr, int32_t bs0, int32_t* cols,
+                                        int32_t* row_count, const mpcx_nnz_t* rowptr, int32_t bs0, int32_t* cols,
                                         int32_t* overflow, void* stream)
 {
   if (num_blocks0 == 0)

@@ -77,7 +77,7 @@ enum
 // y = A x; optionally dot += x.y (one atomic per workgroup) -- SPMV_GROUP lanes share a row
 template <bool DOT>
 __global__ void __launch_bounds__(SPMV_THREADS)
-spmv_kernel(int32_t nrows, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+spmv_kernel(int32_t nrows, const mpcx_nnz_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
             const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, double* dot,
             double* zero_a, double* zero_b)
 {
@@ -94,7 +94,7 @@ spmv_kernel(int32_t nrows, const int32_t* __restrict__ rowptr, const int32_t* __
   for (int64_t row = int64_t(blockIdx.x) * ROWS + threadIdx.x / SPMV_GROUP; row < nrows;
        row += int64_t(gridDim.x) * ROWS)
   {
-    const int lo = rowptr[row], hi = rowptr[row + 1];
+    const int64_t lo = rowptr[row], hi = rowptr[row + 1];
     double sum = 0.0;
     for (int k = lo + lane; k < hi; k += SPMV_GROUP)
       sum += vals[k] * x[cols[k]];
@@ -179,7 +179,7 @@ cg_start_kernel(int32_t n, const double* __restrict__ dinv, const double* __rest
   }
 }
 
-__global__ void inverse_diagonal_kernel(int32_t nrows, const int32_t* __restrict__ rowptr,
+__global__ void inverse_diagonal_kernel(int32_t nrows, const mpcx_nnz_t* __restrict__ rowptr,
                                         const int32_t* __restrict__ cols, const double* __restrict__ vals,
                                         double* __restrict__ dinv)
 {
@@ -187,7 +187,7 @@ __global__ void inverse_diagonal_kernel(int32_t nrows, const int32_t* __restrict
   if (r >= nrows)
     return;
   double d = 0.0;
-  int lo = rowptr[r], hi = rowptr[r + 1];
+  int64_t lo = rowptr[r], hi = rowptr[r + 1];
   while (lo < hi) // sorted columns
   {
     const int mid = (lo + hi) >> 1;
@@ -242,7 +242,7 @@ extern "C" int mpcx_scatter_add_f64(double* values, const int64_t* idx, int64_t 
   return check(hipGetLastError(), "scatter_add_f64 launch");
 }
 
-extern "C" int mpcx_spmv(int32_t nrows, const int32_t* rowptr, const int32_t* cols, const double* vals,
+extern "C" int mpcx_spmv(int32_t nrows, const mpcx_nnz_t* rowptr, const int32_t* cols, const double* vals,
                          const double* x, double* y, void* stream)
 {
   if (nrows == 0)
@@ -253,7 +253,7 @@ extern "C" int mpcx_spmv(int32_t nrows, const int32_t* rowptr, const int32_t* co
   return check(hipGetLastError(), "spmv launch");
 }
 
-extern "C" int mpcx_inverse_diagonal(int32_t nrows, const int32_t* rowptr, const int32_t* cols,
+extern "C" int mpcx_inverse_diagonal(int32_t nrows, const mpcx_nnz_t* rowptr, const int32_t* cols,
                                      const double* vals, double* dinv, void* stream)
 {
   if (nrows == 0)
@@ -275,7 +275,7 @@ extern "C" int mpcx_cg_start(int32_t n, const double* dinv, const double* b, dou
   return check(hipGetLastError(), "cg_start launch");
 }
 
-extern "C" int mpcx_cg_step(int32_t n, const int32_t* rowptr, const int32_t* cols, const double* vals,
+extern "C" int mpcx_cg_step(int32_t n, const mpcx_nnz_t* rowptr, const int32_t* cols, const double* vals,
                             const double* dinv, double* x, double* r, double* z, double* p, double* Ap,
                             double* scal, int32_t k, void* stream)
 {

@@ -22,7 +22,13 @@
 extern "C" {
 #endif
 
-#define MPCX_VERSION 1
+#define MPCX_VERSION 2
+
+/* Offsets into the CSR value / column arrays (rowptr entries, positions): 64-bit, so that one GPU can
+ * hold matrices with more than 2^31 - 1 stored entries (Taylor-Hood a00 on 128^3 cells: 4.4 G) -- PETSc's
+ * blocked insertion behind the reference (python/src/dolfinx_mpc/mpc.cpp:284-287) has no such limit either.
+ * Row and column INDICES stay 32-bit. */
+typedef int64_t mpcx_nnz_t;
 
 /* ---- form kinds / cell types (element kernels replacing the FFCx-generated
  *      tabulate_tensor, cpp/assemble_matrix.cpp:438-439) ------------------- */
@@ -112,7 +118,7 @@ typedef struct
 {
   /* CSR, scalar (unrolled) rows/cols, columns sorted per row */
   int32_t nrows;
-  const int32_t* rowptr; /* DEVICE [nrows+1] */
+  const mpcx_nnz_t* rowptr; /* DEVICE [nrows+1] */
   const int32_t* cols;   /* DEVICE [nnz] */
   double* vals;          /* DEVICE [nnz], accumulated into */
   mpcx_kernel_t kernel;
@@ -159,7 +165,7 @@ typedef struct
    * coef[k] * Ae(entity ent[k])[pq[k] / N1][pq[k] % N1].  mpc_plan_off == NULL: the kernel walks the
    * slave entities and searches the CSR rows itself (device atomics). */
   int64_t mpc_plan_targets;
-  const int32_t* mpc_plan_tgt;
+  const mpcx_nnz_t* mpc_plan_tgt;
   const int64_t* mpc_plan_off;
   const int32_t* mpc_plan_ent;
   const int32_t* mpc_plan_pq;
@@ -181,7 +187,7 @@ int mpcx_mask_dofmap(const int32_t* dofmap, int64_t num_cells, int32_t nd, int32
  * zeroed by the caller) is set non-zero if an offset does not fit in 8 bits or
  * a column is missing from the pattern.  rotate != 0: local rows and columns of the cell c an
  * entity lies in are listed in the rotated order of mpcx_mask_dofmap. */
-int mpcx_scatter_offsets(const int32_t* rowptr, const int32_t* cols, int32_t estride,
+int mpcx_scatter_offsets(const mpcx_nnz_t* rowptr, const int32_t* cols, int32_t estride,
                          int64_t n_entities, const int32_t* entities0,
                          const int32_t* entities1, const int32_t* dofmap0, int32_t nd0,
                          int32_t bs0, const int32_t* dofmap1, int32_t nd1, int32_t bs1,
@@ -190,7 +196,7 @@ int mpcx_scatter_offsets(const int32_t* rowptr, const int32_t* cols, int32_t est
 /* vals[pos(d,d)] += diagval for d in dofs.  Replaces the slave-diagonal loop
  * of cpp/assemble_matrix.cpp:711-724 and dolfinx insert_diagonal called at
  * python/src/dolfinx_mpc/assemble_matrix.py:59-62. */
-int mpcx_add_diagonal(int32_t nrows, const int32_t* rowptr, const int32_t* cols,
+int mpcx_add_diagonal(int32_t nrows, const mpcx_nnz_t* rowptr, const int32_t* cols,
                       double* vals, const int32_t* dofs, int64_t n,
                       double diagval, void* stream);
 
@@ -300,7 +306,7 @@ void* mpcx_pattern_build(int64_t num_cells, const int32_t* dofmap0, int32_t nd0,
                          int32_t num_threads);
 int64_t mpcx_pattern_nnz(void* pattern);
 int32_t mpcx_pattern_nrows(void* pattern);
-int mpcx_pattern_copy(void* pattern, int32_t* rowptr, int32_t* cols);
+int mpcx_pattern_copy(void* pattern, mpcx_nnz_t* rowptr, int32_t* cols);
 void mpcx_pattern_free(void* pattern);
 
 /* The same pattern built on the DEVICE (all pointers DEVICE).  Protocol:
@@ -322,7 +328,7 @@ int mpcx_pattern_device_rows(int32_t num_blocks0, const int64_t* adj_off, const 
                              const int32_t* dofmap1, int32_t nd1, int32_t bs1,
                              const int32_t* c2s_offsets1, const int32_t* c2s1,
                              const int32_t* masters_offsets1, const int32_t* masters1,
-                             int32_t* row_count, const int32_t* rowptr, int32_t bs0, int32_t* cols,
+                             int32_t* row_count, const mpcx_nnz_t* rowptr, int32_t bs0, int32_t* cols,
                              int32_t* overflow, void* stream);
 
 /* Row-block plan for MPCX_ALG_ROWBLOCK: contiguous row ranges with at most
@@ -330,7 +336,7 @@ int mpcx_pattern_device_rows(int32_t num_blocks0, const int64_t* adj_off, const 
  * test-space cell has a dof in it.  `row_hints` (sorted row indices, may be
  * NULL) are preferred cut positions, e.g. the first row of each numbering tile.
  * Returns an opaque handle. */
-void* mpcx_rowblock_plan_build(int32_t nrows, const int32_t* rowptr, int32_t max_rows,
+void* mpcx_rowblock_plan_build(int32_t nrows, const mpcx_nnz_t* rowptr, int32_t max_rows,
                                int32_t max_nnz, int64_t n_entities, int32_t estride,
                                const int32_t* entities0, const int32_t* dofmap0,
                                int32_t nd0, int32_t bs0, const int32_t* row_hints,
@@ -351,10 +357,10 @@ void* mpcx_mpc_plan_build(int64_t n_slave_entities, const int32_t* slave_entitie
                           const int8_t* bc0, const int8_t* bc1, const int8_t* is_slave0,
                           const int32_t* masters_offsets0, const int32_t* masters0, const double* coeffs0,
                           const int8_t* is_slave1, const int32_t* masters_offsets1, const int32_t* masters1,
-                          const double* coeffs1, const int32_t* rowptr, const int32_t* cols);
+                          const double* coeffs1, const mpcx_nnz_t* rowptr, const int32_t* cols);
 int64_t mpcx_mpc_plan_size(void* plan);        /* tuples */
 int64_t mpcx_mpc_plan_num_targets(void* plan); /* distinct positions */
-int mpcx_mpc_plan_copy(void* plan, int32_t* tgt_pos, int64_t* off, int32_t* ent, int32_t* pq, double* coef);
+int mpcx_mpc_plan_copy(void* plan, mpcx_nnz_t* tgt_pos, int64_t* off, int32_t* ent, int32_t* pq, double* coef);
 void mpcx_mpc_plan_free(void* plan);
 
 /* HOST: dictionary-compress n rows of `noff` bytes (the scatter-offset table copied to the
@@ -377,13 +383,13 @@ int32_t mpcx_compress_offsets(const uint8_t* rows, int64_t n, int32_t noff, int3
  *                          r -= alpha Ap, z = dinv r (+ r.z, r.r), p = z + beta p; no host round
  *                          trip; |r|^2 after the step is scal[4 + ((k + 1) & 1)]
  * ---------------------------------------------------------------------- */
-int mpcx_spmv(int32_t nrows, const int32_t* rowptr, const int32_t* cols, const double* vals,
+int mpcx_spmv(int32_t nrows, const mpcx_nnz_t* rowptr, const int32_t* cols, const double* vals,
               const double* x, double* y, void* stream);
-int mpcx_inverse_diagonal(int32_t nrows, const int32_t* rowptr, const int32_t* cols, const double* vals,
+int mpcx_inverse_diagonal(int32_t nrows, const mpcx_nnz_t* rowptr, const int32_t* cols, const double* vals,
                           double* dinv, void* stream);
 int mpcx_cg_start(int32_t n, const double* dinv, const double* b, double* x, double* r, double* z,
                   double* p, double* scal, void* stream);
-int mpcx_cg_step(int32_t n, const int32_t* rowptr, const int32_t* cols, const double* vals,
+int mpcx_cg_step(int32_t n, const mpcx_nnz_t* rowptr, const int32_t* cols, const double* vals,
                  const double* dinv, double* x, double* r, double* z, double* p, double* Ap,
                  double* scal, int32_t k, void* stream);
 

@@ -356,6 +356,50 @@ def case_contact_two_body(n_top=2, n_bottom=None, theta=0.0, reorder=None) -> Ca
     return Case(f"contact_two_body_{n_top}_{nb}_theta{theta:.2f}{tag}", V, a, L, bcs, raw)
 
 
+def stokes_slip_problem(dim, n, reorder=None):
+    """Taylor-Hood Stokes blocks with a slip constraint on the velocity space (BASELINE config 3;
+    forms of python/tests/test_stokes_channelflow.py:77-81, nest assembly with (mpc_i, mpc_j) as in
+    python/tests/test_rectangular_assembly.py; constraint in the output shape of
+    cpp/SlipConstraint.h:115-166: one slave per wall block -- the component with the largest |n_i| --
+    and the other components of the same block as masters with c_i = -n_i / n_s):
+
+        a00 = inner(grad u, grad v) dx   (P2^d x P2^d)      a01 = -p div v dx   (P2^d x P1)
+        a10 = -div u q dx                (P1 x P2^d)        L0  = inner(f, v) dx
+
+    inflow profile on x = 0 (non-zero Dirichlet), no-slip on y = 0, slip on y = 1 with a tilted normal.
+    Returns V, Q, bcs, raw_v, forms {(i, j): form}, L0."""
+    mesh = create_unit_cube(n, n, n, reorder=reorder) if dim == 3 else create_unit_square(n, n)
+    V = fem.functionspace(mesh, ("Lagrange", 2, (dim,)))
+    Q = fem.functionspace(mesh, ("Lagrange", 1))
+    x = V.tabulate_dof_coordinates()
+    inflow = fem.Function(V)
+    inflow.interpolate(lambda x: np.stack([x[1] * (1 - x[1])] + [0 * x[1]] * (dim - 1)))
+    bc_in = fem.dirichletbc(inflow, fem.locate_dofs_geometrical(V, lambda x: np.isclose(x[0], 0)), V)
+    bc_wall = fem.dirichletbc(0.0, fem.locate_dofs_geometrical(V, lambda x: np.isclose(x[1], 0) & ~np.isclose(x[0], 0)), V)
+    bcs = [bc_in, bc_wall]
+    is_bc = np.zeros(V.num_dofs, dtype=np.int8)
+    for bc in bcs:
+        bc.mark_dofs(is_bc)
+    nrm = np.array([0.25, 1.0, -0.15])[:dim]
+    nrm /= np.linalg.norm(nrm)
+    s = int(np.argmax(np.abs(nrm)))
+    blocks = np.flatnonzero(np.isclose(x[:, 1], 1.0))
+    blocks = blocks[~is_bc.reshape(-1, dim)[blocks].any(axis=1)]  # blocks touched by a Dirichlet condition stay free
+    others = [k for k in range(dim) if k != s]
+    slaves = (blocks * dim + s).astype(np.int32)
+    masters = (blocks[:, None] * dim + np.array(others)[None, :]).reshape(-1).astype(np.int64)
+    coeffs = np.tile(np.array([-nrm[k] / nrm[s] for k in others]), blocks.size)
+    offsets = (np.arange(blocks.size + 1) * len(others)).astype(np.int32)
+    raw_v = (slaves, masters, coeffs, np.zeros(masters.size, dtype=np.int32), offsets)
+    forms = {
+        (0, 0): fem.form_stiffness(V),
+        (0, 1): fem.form_div_test(V, Q, constant=-1.0),
+        (1, 0): fem.form_div_trial(Q, V, constant=-1.0),
+    }
+    L0 = fem.form_source(V, fem.FN_LINEAR)
+    return V, Q, bcs, raw_v, forms, L0
+
+
 def all_small_cases() -> List[Callable[[], Case]]:
     return [
         lambda: case_square_dict(1, (1, 1)),

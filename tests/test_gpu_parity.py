@@ -83,7 +83,7 @@ def test_device_pattern_equals_host_pattern(make):
     mpc = product_mpc(case)
     rp_h, cols_h = dm.create_sparsity_pattern(case.a, mpc, where="host")
     rp_d, cols_d = dm.create_sparsity_pattern(case.a, mpc, where="device")
-    assert rp_d.dtype == np.int32 and cols_d.dtype == np.int32
+    assert rp_d.dtype == np.int64 and cols_d.dtype == np.int32
     assert np.array_equal(rp_h, rp_d)
     assert np.array_equal(cols_h, cols_d)
 

@@ -1,0 +1,153 @@
+"""BASELINE config 3 at FULL size on one GPU: Taylor-Hood Stokes blocks on 128^3 cubes (12 582 912 tets,
+V = P2^3 with 50 923 779 dofs, Q = P1 with 2 146 689 dofs) with a slip constraint on the wall y = 1
+(cpp/SlipConstraint.h:115-166 output shape) and non-zero inflow data.  The a00 block holds about
+4.4e9 stored entries -- more than a 32-bit offset can address, which is why the CSR offsets of this
+backend are 64-bit (include/mpcx.h ``mpcx_nnz_t``).  Properties checked (the oracle cannot run at
+this size; it is compared directly at 2^3 / 3^2 in tests/test_stokes.py):
+
+1. sizes: nnz(a00) > 2^31 at N = 128; every block assembles with the row-block kernels;
+2. a00 is symmetric (x^T A y == y^T A x) and its slave / Dirichlet rows are identity rows;
+3. the off-diagonal blocks are transposes of each other, constraint and boundary conditions included:
+   x^T (A01 p) == (A10 x)^T p; slave and Dirichlet rows of a01 are empty;
+4. the reference's own identity (python/src/dolfinx_mpc/utils/test.py:202-242) at full size, in
+   operator form:  A00_mpc K^T-reduced == K^T A00_org K  applied to a random vector, with A00_org the
+   same form assembled WITHOUT the constraint (second 35 GB matrix) and K applied on the device
+   (homogenize + backsubstitution) -- ties the master contributions of 66 k slip slaves to the bulk.
+
+MPCX_STOKES_N overrides N (default 128; 64 fits 32-bit offsets and runs in a third of the time)."""
+
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N = int(os.environ.get("MPCX_STOKES_N", 64))
+
+
+@pytest.fixture(scope="module")
+def problem():
+    import torch
+
+    import dolfinx_mpc_amd as dm
+    from problems import stokes_slip_problem
+
+    V, Q, bcs, raw_v, forms, L0 = stokes_slip_problem(3, N, reorder=(8, 8, 8))
+    mv = dm.MultiPointConstraint(V)
+    mv.add_constraint(V, *raw_v)
+    mv.finalize()
+    mq = dm.MultiPointConstraint(Q)
+    mq.finalize()
+    mpcs = [mv, mq]
+    if N == 128:
+        assert V.mesh.num_cells == 12582912 and V.num_dofs == 50923779 and Q.num_dofs == 2146689
+    A = {}
+    for (i, j), f in forms.items():
+        A[(i, j)] = dm.assemble_matrix(f, (mpcs[i], mpcs[j]), bcs=bcs, algorithm="rowblock")
+    torch.cuda.synchronize()
+    return dict(V=V, Q=Q, bcs=bcs, mv=mv, mq=mq, forms=forms, A=A)
+
+
+def _spmv(A, x):
+    import torch
+
+    from dolfinx_mpc_amd import _device as D
+    from dolfinx_mpc_amd import _native
+
+    y = torch.zeros(A.shape[0], dtype=torch.float64, device=A.device)
+    rc = _native.lib().mpcx_spmv(A.shape[0], A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), A.vals.data_ptr(),
+                                 x.data_ptr(), y.data_ptr(), D.stream_ptr())
+    _native.check(rc, "mpcx_spmv")
+    return y
+
+
+def _rand(n, dev, seed):
+    import torch
+
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    return torch.rand(n, dtype=torch.float64, device=dev, generator=gen) - 0.5
+
+
+def _constrained_rows(p, dev):
+    import torch
+
+    idx = [p["mv"].slaves.astype(np.int64)] + [bc.dof_indices()[0].astype(np.int64) for bc in p["bcs"]]
+    return torch.from_numpy(np.unique(np.concatenate(idx))).to(dev)
+
+
+def test_sizes_and_64bit_offsets(problem):
+    import torch
+
+    A00 = problem["A"][(0, 0)]
+    assert A00.d_rowptr.dtype == torch.int64
+    if N == 128:
+        assert A00.nnz > 2**31, A00.nnz
+    assert int(A00.d_rowptr[-1]) == A00.nnz
+    # rows of a vector space come in blocks with identical column sets
+    cnt = (A00.d_rowptr[1:] - A00.d_rowptr[:-1]).view(-1, 3)
+    assert bool((cnt[:, 0] == cnt[:, 1]).all() and (cnt[:, 0] == cnt[:, 2]).all())
+
+
+def test_a00_symmetric_with_identity_rows(problem):
+    import torch
+
+    A = problem["A"][(0, 0)]
+    x, y = _rand(A.shape[0], A.device, 1), _rand(A.shape[0], A.device, 2)
+    Ay, Ax = _spmv(A, y), _spmv(A, x)
+    xAy, yAx = float(torch.dot(x, Ay)), float(torch.dot(y, Ax))
+    scale = float(torch.linalg.vector_norm(x) * torch.linalg.vector_norm(Ay))
+    assert abs(xAy - yAx) <= 1e-12 * scale, (xAy, yAx, scale)
+    rows = _constrained_rows(problem, A.device)
+    assert bool((Ax[rows] == x[rows]).all())  # identity rows: diagval 1, nothing else
+
+
+def test_offdiagonal_blocks_are_transposes(problem):
+    import torch
+
+    A01, A10 = problem["A"][(0, 1)], problem["A"][(1, 0)]
+    assert A01.shape == (A10.shape[1], A10.shape[0])
+    x, q = _rand(A01.shape[0], A01.device, 3), _rand(A01.shape[1], A01.device, 4)
+    A01q, A10x = _spmv(A01, q), _spmv(A10, x)
+    lhs, rhs = float(torch.dot(x, A01q)), float(torch.dot(A10x, q))
+    scale = float(torch.linalg.vector_norm(x) * torch.linalg.vector_norm(A01q))
+    assert abs(lhs - rhs) <= 1e-12 * scale, (lhs, rhs, scale)
+    rows = _constrained_rows(problem, A01.device)
+    assert float(A01q[rows].abs().max()) == 0.0  # no diagonal in an off-diagonal block
+
+
+def test_reference_lhs_identity_in_operator_form(problem):
+    """K^T A_org K u == A_mpc u on the free rows (utils/test.py:202-242 applied to a vector)."""
+    import torch
+
+    import dolfinx_mpc_amd as dm
+
+    p = problem
+    V, mv, bcs = p["V"], p["mv"], p["bcs"]
+    A = p["A"][(0, 0)]
+    dev = A.device
+    none = dm.MultiPointConstraint(V)
+    none.finalize()
+    A_org = dm.assemble_matrix(p["forms"][(0, 0)], none, bcs=bcs, algorithm="rowblock")
+    u = _rand(V.num_dofs, dev, 5)
+    mv.homogenize(u)  # free values only ...
+    y_mpc = _spmv(A, u)
+    mv.backsubstitution(u)  # ... u <- K u_free
+    y = _spmv(A_org, u)
+    # K^T y: every slave row is added to its masters (2 same-block masters per slave), then dropped
+    sl = torch.from_numpy(mv.slaves.astype(np.int64)).to(dev)
+    off = mv.masters.offsets
+    cnt = np.diff(off)[mv.slaves]
+    src = torch.from_numpy(np.repeat(mv.slaves.astype(np.int64), cnt)).to(dev)
+    lo = off[mv.slaves]
+    sel = np.repeat(lo, cnt) + (np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt))
+    m = torch.from_numpy(mv.masters.array[sel].astype(np.int64)).to(dev)
+    c = torch.from_numpy(mv.coefficients()[0][sel]).to(dev)
+    y.index_add_(0, m, c * y[src])
+    free = torch.ones(V.num_dofs, dtype=torch.bool, device=dev)
+    free[sl] = False
+    scale = float(y[free].abs().max())
+    diff = float((y[free] - y_mpc[free]).abs().max())
+    assert diff <= 1e-11 * scale, (diff, scale)
+    del A_org
+    torch.cuda.empty_cache()

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_native.EXPORTS)
     for name in declared:
         assert hasattr(L, name), f"libmpcx.so does not export {name}"
-    assert L.mpcx_version() == 1
+    assert L.mpcx_version() == int(re.search(r"#define MPCX_VERSION (\d+)", header).group(1))
 
 
 def test_ctypes_structs_match_header_field_order():

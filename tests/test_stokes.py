@@ -16,46 +16,11 @@ import pytest
 
 from dolfinx_mpc_amd import fem
 from dolfinx_mpc_amd.mesh import create_unit_cube, create_unit_square
-from problems import empty_raw
+from problems import empty_raw, stokes_slip_problem
 
 
 def _stokes(dim, n):
-    mesh = create_unit_cube(n, n, n) if dim == 3 else create_unit_square(n, n)
-    V = fem.functionspace(mesh, ("Lagrange", 2, (dim,)))
-    Q = fem.functionspace(mesh, ("Lagrange", 1))
-    x = V.tabulate_dof_coordinates()
-    # inflow profile on x = 0 (non-zero Dirichlet), no-slip on y = 0
-    inflow = fem.Function(V)
-    inflow.interpolate(lambda x: np.stack([x[1] * (1 - x[1])] + [0 * x[1]] * (dim - 1)))
-    bc_in = fem.dirichletbc(inflow, fem.locate_dofs_geometrical(V, lambda x: np.isclose(x[0], 0)), V)
-    bc_wall = fem.dirichletbc(0.0, fem.locate_dofs_geometrical(V, lambda x: np.isclose(x[1], 0) & ~np.isclose(x[0], 0)), V)
-    bcs = [bc_in, bc_wall]
-    is_bc = np.zeros(V.num_dofs, dtype=np.int8)
-    for bc in bcs:
-        bc.mark_dofs(is_bc)
-    # slip u.n = 0 on y = 1 with a tilted normal (cpp/SlipConstraint.h:115-166 output shape)
-    nrm = np.array([0.25, 1.0, -0.15])[:dim]
-    nrm /= np.linalg.norm(nrm)
-    slaves, masters, coeffs, offsets = [], [], [], [0]
-    for b in np.flatnonzero(np.isclose(x[:, 1], 1.0)):
-        s = int(np.argmax(np.abs(nrm)))
-        if is_bc[b * dim + s] or any(is_bc[b * dim + k] for k in range(dim)):
-            continue
-        slaves.append(b * dim + s)
-        for k in range(dim):
-            if k != s:
-                masters.append(b * dim + k)
-                coeffs.append(-nrm[k] / nrm[s])
-        offsets.append(len(masters))
-    raw_v = (np.array(slaves, dtype=np.int32), np.array(masters, dtype=np.int64), np.array(coeffs),
-             np.zeros(len(masters), dtype=np.int32), np.array(offsets, dtype=np.int32))
-    forms = {
-        (0, 0): fem.form_stiffness(V),
-        (0, 1): fem.form_div_test(V, Q, constant=-1.0),
-        (1, 0): fem.form_div_trial(Q, V, constant=-1.0),
-    }
-    L0 = fem.form_source(V, fem.FN_LINEAR)
-    return V, Q, bcs, raw_v, forms, L0
+    return stokes_slip_problem(dim, n)
 
 
 def _oracle_blocks(po, dim, n):

@@ -11,16 +11,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
 import dolfinx_mpc_amd as dm  # noqa: E402
-import test_stokes  # noqa: E402
-from dolfinx_mpc_amd.mesh import create_unit_cube  # noqa: E402
-from test_stokes import _stokes  # noqa: E402
-
-# tiled numbering (what the benchmark meshes use); the test helper builds the plain one
-if not os.environ.get("MPCX_STOKES_UNTILED"):
-    test_stokes.create_unit_cube = lambda *a: create_unit_cube(*a, reorder=(8, 8, 8))
+from problems import stokes_slip_problem  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-V, Q, bcs, raw_v, forms, L0 = _stokes(3, n)
+# tiled numbering (what the benchmark meshes use) unless MPCX_STOKES_UNTILED
+V, Q, bcs, raw_v, forms, L0 = stokes_slip_problem(3, n, None if os.environ.get("MPCX_STOKES_UNTILED") else (8, 8, 8))
 mv = dm.MultiPointConstraint(V)
 mv.add_constraint(V, *raw_v)
 mv.finalize()
