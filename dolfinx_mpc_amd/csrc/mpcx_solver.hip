@@ -96,7 +96,7 @@ spmv_kernel(int32_t nrows, const mpcx_nnz_t* __restrict__ rowptr, const int32_t*
   {
     const int64_t lo = rowptr[row], hi = rowptr[row + 1];
     double sum = 0.0;
-    for (int k = lo + lane; k < hi; k += SPMV_GROUP)
+    for (int64_t k = lo + lane; k < hi; k += SPMV_GROUP)
       sum += vals[k] * x[cols[k]];
     sum = group_sum(sum);
     if (lane == 0)
@@ -190,7 +190,7 @@ __global__ void inverse_diagonal_kernel(int32_t nrows, const mpcx_nnz_t* __restr
   int64_t lo = rowptr[r], hi = rowptr[r + 1];
   while (lo < hi) // sorted columns
   {
-    const int mid = (lo + hi) >> 1;
+    const int64_t mid = (lo + hi) >> 1;
     if (cols[mid] < r)
       lo = mid + 1;
     else

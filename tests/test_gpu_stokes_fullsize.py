@@ -23,7 +23,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-N = int(os.environ.get("MPCX_STOKES_N", 64))
+N = int(os.environ.get("MPCX_STOKES_N", 128))
 
 
 @pytest.fixture(scope="module")
