@@ -1,20 +1,25 @@
 #!/usr/bin/env python
-"""bench.py -- headline benchmark of the constrained-assembly hot path.
+"""bench.py -- benchmark of the constrained-assembly hot path on MI355X.
 
-Workload (BASELINE.json configs[1]; python/benchmarks/bench_periodic.py:35-110):
-periodic-BC Poisson, P1 tets on the N^3 unit cube (N=256 by default:
-100 663 296 cells, 16 974 593 dofs, 65 025 slaves), fp64.
+    python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5] [--scaling strong|weak]
 
-One "step" = assemble_matrix (into the cached MPC-pattern CSR) + assemble_vector,
-inputs resident in HBM.  metric = Ndof / (t_matrix + t_vector).  apply_lifting is
-timed separately (as the reference's timers do).
+Default = BASELINE.json's metric: config 2, periodic-BC Poisson, P1 tets on the 256^3 unit cube
+(python/benchmarks/bench_periodic.py:35-110): 100 663 296 cells, 16 974 593 dofs, 65 025 slaves, fp64.
+One "step" = one pass of the hot path over the workload with every input resident in HBM:
 
-    python bench.py --gpus N --steps K --warmup W
+    config 2 / 5   assemble_matrix (into the cached MPC-pattern CSR) + assemble_vector   (P1 / P2 Poisson)
+    config 3       the three Taylor-Hood blocks a00, a01, a10 with (mpc_i, mpc_j) + assemble_vector (Stokes, slip)
+    config 4       assemble_matrix + assemble_vector (two-body contact elasticity, vector P1)
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling, every
-rank assembles its own N^3 box of a (N, N, N*world) mesh and exchanges the
-partial sums of the interface-plane rows with its z-neighbours over RCCL.
-Rank 0 prints ONE JSON line.
+metric = global dofs / step time.  apply_lifting is timed separately (the reference's timers do the same).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL):
+    --scaling strong (default): THE global mesh of the config is cut into N slabs of cube layers
+        (config 2/5 along z, config 4 along y through both bodies), value = global dofs / time;
+    --scaling weak: every rank assembles its own N^3 box of a (N, N, N*world) mesh (configs 2 / 5).
+After the local kernels the ranks exchange the partial sums of their interface-plane rows with their
+slab neighbours (the reference's `A.assemble()` / `ghostUpdate(ADD, REVERSE)`); the matrix rows travel
+while the vector kernel runs.  Rank 0 prints ONE JSON line.
 """
 
 from __future__ import annotations
@@ -23,6 +28,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,6 +37,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PEAK_HBM_GBS = 8000.0  # HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_FP64_TFLOPS = 78.6  # fp64 vector peak
 
 
 def log(*a):
@@ -38,89 +48,240 @@ def log(*a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def build_problem(N: int, reorder, rank=0, world=1):
-    """mesh, space, bc, constraint, forms of the periodic Poisson benchmark.
-    world > 1: rank's z-slab of the (N, N, N*world) mesh on [0,1]^2 x [0,world]."""
+# ---------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------
+class Workload:
+    """What a config assembles: ``blocks`` = [(label, form, (mpc_row, mpc_col), matrix)], ``vectors`` =
+    [(label, form, mpc, vector)], the Dirichlet conditions, and (N > 1) the interface exchanges."""
+
+    def __init__(self):
+        self.blocks, self.vectors, self.bcs = [], [], []
+        self.exchange = {}  # label -> SlabExchange
+        self.config, self.ndofs_total, self.lift = {}, 0, None
+
+
+def poisson_workload(args, rank, world, degree):
+    """configs 2 and 5: bench_periodic.py:35-110"""
     from dolfinx_mpc_amd import MultiPointConstraint, fem
-    from dolfinx_mpc_amd.distributed import create_slab_mesh
+    from dolfinx_mpc_amd.distributed import create_box_slab, create_slab_mesh
     from dolfinx_mpc_amd.mesh import create_box
 
-    t = time.time()
+    N = args.n
+    reorder = None if args.no_tile else tuple(args.tile)
+    zmax = 1.0
     if world == 1:
         mesh = create_box((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), (N, N, N), "tetrahedron", reorder)
+        n_glob = (N, N, N)
+    elif args.scaling == "strong":
+        mesh = create_box_slab((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), (N, N, N), rank, world, 2, reorder)
+        n_glob = (N, N, N)
     else:
         mesh = create_slab_mesh(N, rank, world, reorder)
-    zmax = float(world)
-    V = fem.functionspace(mesh, ("Lagrange", 1))
-    log(f"mesh: {mesh.num_cells} cells, {V.num_dofs} dofs ({time.time() - t:.1f}s)")
+        zmax = float(world)
+        n_glob = (N, N, N * world)
+    V = fem.functionspace(mesh, ("Lagrange", degree))
 
-    t = time.time()
-
-    def dirichletboundary(x):  # bench_periodic.py:49-55 (global walls y,z in {0,1})
+    def dirichletboundary(x):  # bench_periodic.py:49-55 (global walls y, z in {0, zmax})
         return np.isclose(x[1], 0) | np.isclose(x[1], 1) | np.isclose(x[2], 0) | np.isclose(x[2], zmax)
 
-    bdofs = fem.locate_dofs_geometrical(V, dirichletboundary)
-    bc = fem.dirichletbc(0.0, bdofs, V)
+    bc = fem.dirichletbc(0.0, fem.locate_dofs_geometrical(V, dirichletboundary), V)
     mpc = MultiPointConstraint(V)
 
     def periodic_relation(x):  # bench_periodic.py:63-68
-        out = np.zeros(x.shape)
+        out = x.copy()
         out[0] = 1 - x[0]
-        out[1] = x[1]
-        out[2] = x[2]
         return out
 
     mpc.create_periodic_constraint_geometrical(V, lambda x: np.isclose(x[0], 1), periodic_relation, [bc])
     mpc.finalize()
-    log(f"constraint: {mpc.slaves.size} slaves ({time.time() - t:.1f}s)")
-    a = fem.form_stiffness(V)
-    L = fem.form_source(V, fem.FN_BENCH_PERIODIC)
-    return mesh, V, bc, mpc, a, L
+    w = Workload()
+    w.mesh, w.V, w.bcs = mesh, V, [bc]
+    w.blocks = [("A", fem.form_stiffness(V), (mpc, mpc))]
+    w.vectors = [("b", fem.form_source(V, fem.FN_BENCH_PERIODIC), mpc)]
+    w.lift = ("b", "A")
+    d = degree
+    w.ndofs_total = int(np.prod([d * n + 1 for n in n_glob]))
+    w.config = {"workload": f"periodic-BC Poisson, P{degree} tets, {n_glob[0]}x{n_glob[1]}x{n_glob[2]} cubes on "
+                            f"[0,1]^2x[0,{zmax:g}], fp64 (BASELINE configs[{1 if degree == 1 else 4}])",
+                "slaves_per_gpu": int(mpc.slaves.size)}
+    w.cpu_sample = ("poisson", degree)
+    return w
 
 
-def measured_traffic(path: str, kernel_substr: str, N: int):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC
-    passes (FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 correction
-    2*FETCH_SIZE, see tools/collect_pmc.py); None if not collected for this N."""
-    try:
-        d = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    if d.get("_workload_n") != N:
-        return None
-    for name, c in d.items():
-        if isinstance(c, dict) and kernel_substr in name and "hbm_bytes_per_launch" in c:
-            return int(c["hbm_bytes_per_launch"])
-    return None
+def stokes_workload(args, rank, world):
+    """config 3: Taylor-Hood blocks with a slip constraint (tests/problems.py stokes_slip_problem)"""
+    import dolfinx_mpc_amd as dm
+    from problems import stokes_slip_problem
+
+    if world > 1:
+        raise SystemExit("config 3 is a single-GPU configuration (BASELINE configs[2])")
+    V, Q, bcs, raw_v, forms, L0 = stokes_slip_problem(3, args.n, None if args.no_tile else tuple(args.tile))
+    mv = dm.MultiPointConstraint(V)
+    mv.add_constraint(V, *raw_v)
+    mv.finalize()
+    mq = dm.MultiPointConstraint(Q)
+    mq.finalize()
+    mp = [mv, mq]
+    w = Workload()
+    w.mesh, w.V, w.bcs = V.mesh, V, bcs
+    w.blocks = [(f"a{i}{j}", f, (mp[i], mp[j])) for (i, j), f in forms.items()]
+    w.vectors = [("b0", L0, mv)]
+    w.lift = ("b0", "a00")
+    w.ndofs_total = V.num_dofs + Q.num_dofs
+    w.config = {"workload": f"Stokes Taylor-Hood P2^3/P1 on {args.n}^3 cubes, slip constraint on y = 1 "
+                            f"(cpp/SlipConstraint.h shape), nest assembly of a00, a01, a10 + b0, fp64 (BASELINE configs[2])",
+                "slaves_per_gpu": int(mv.slaves.size), "dofs_V": V.num_dofs, "dofs_Q": Q.num_dofs}
+    w.cpu_sample = ("stokes", 0)
+    return w
 
 
-def cpu_baseline(sample_n: int):
-    """The oracle (C restatement of the reference's serial loops) timed on one
-    host core on a bounded sample: the same workload at N = sample_n."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+def contact_workload(args, rank, world):
+    """config 4: bench_contact_3D.py:62-270 with the inelastic contact condition"""
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import fem
+    from dolfinx_mpc_amd.distributed import create_stacked_cubes_slab
+    from dolfinx_mpc_amd.mesh import (CONTACT_BOTTOM, CONTACT_BOTTOM_INTERFACE, CONTACT_TOP, CONTACT_TOP_INTERFACE,
+                                      create_stacked_cubes)
+
+    n0 = args.n
+    reorder = None if args.no_tile else tuple(args.tile)
+    if world == 1:
+        mesh, ft, _ = create_stacked_cubes(n0, None, 0.0, reorder)
+    else:
+        mesh, ft = create_stacked_cubes_slab(n0, rank, world, 0.0, reorder, axis=1)
+    V = fem.functionspace(mesh, ("Lagrange", 1, (3,)))
+    u_top = fem.Function(V)
+    u_top.x.array[2::3] = -4.25e-1
+    bcs = [fem.dirichletbc(fem.Function(V), fem.locate_dofs_topological(V, 2, ft.find(CONTACT_BOTTOM)), V),
+           fem.dirichletbc(u_top, fem.locate_dofs_topological(V, 2, ft.find(CONTACT_TOP)), V)]
+    E, nu = 1.0e3, 0.0
+    a = fem.form_elasticity(V, E / (2.0 * (1.0 + nu)), E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu)))
+    L = fem.form_source(V, fem.FN_CONSTANT_VEC, constant=[1.0, 0.0, 0.0, 0.0])  # bench_contact_3D.py:270: zero rhs
+    mpc = dm.MultiPointConstraint(V)
+    mpc.create_contact_inelastic_condition(ft, CONTACT_BOTTOM_INTERFACE, CONTACT_TOP_INTERFACE)
+    mpc.finalize()
+    w = Workload()
+    w.mesh, w.V, w.bcs = mesh, V, bcs
+    w.blocks = [("A", a, (mpc, mpc))]
+    w.vectors = [("b", L, mpc)]
+    w.lift = ("b", "A")
+    w.ndofs_total = 3 * ((n0 + 1) ** 3 + (2 * n0 + 1) ** 3)
+    w.config = {"workload": f"two-body inelastic contact (cpp/ContactConstraint.h:908-1174), vector P1 elasticity, "
+                            f"{n0}^3 over {2 * n0}^3 cubes, E=1e3, nu=0, fp64 (BASELINE configs[3])",
+                "slaves_per_gpu": int(mpc.slaves.size)}
+    w.cpu_sample = ("contact", 0)
+    return w
+
+
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle on the box's host cores, bounded sample of the same workload
+# ---------------------------------------------------------------------------------------------------
+def cpu_baseline(kind, degree, sample_n):
     from oracle import pyoracle as po
-    from problems import case_cube_periodic, oracle_mpc
+    from problems import case_contact_two_body, case_cube_periodic, oracle_mpc, stokes_slip_problem
 
-    case = case_cube_periodic(sample_n, 1, 0.0)
-    mpc = oracle_mpc(po, case)
-    pattern = po.create_pattern(case.a, mpc, mpc)
-    po.assemble_matrix(case.a, mpc, bcs=case.bcs, pattern=pattern, fast=True)  # warm
-    t0 = time.perf_counter()
-    po.assemble_matrix(case.a, mpc, bcs=case.bcs, pattern=pattern, fast=True)
-    t1 = time.perf_counter()
-    po.assemble_vector(case.L, mpc, fast=True)
-    t2 = time.perf_counter()
-    ndofs = case.V.num_dofs
-    return {
-        "value": ndofs / (t2 - t0),
-        "unit": "DoFs/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"same workload at N={sample_n} ({case.mesh.num_cells} cells, {ndofs} dofs): "
-                  f"matrix {t1 - t0:.2f}s + vector {t2 - t1:.2f}s, oracle/mpc_oracle.c -O3, 1 thread",
-        "t_matrix_s": t1 - t0,
-        "t_vector_s": t2 - t1,
-    }
+    t_parts = {}
+    if kind == "poisson":
+        case = case_cube_periodic(sample_n, degree, 0.0)
+        what = f"same workload at N={sample_n} ({case.mesh.num_cells} cells, {case.V.num_dofs} dofs)"
+    elif kind == "contact":
+        case = case_contact_two_body(sample_n)
+        what = f"same workload at {sample_n}^3 over {2 * sample_n}^3 cubes ({case.mesh.num_cells} cells, {case.V.num_dofs} dofs)"
+    if kind in ("poisson", "contact"):
+        from oracle.cpu_parallel import host_pattern
+
+        mpc = oracle_mpc(po, case)
+        pattern = host_pattern(case.a, case)  # set-up (not timed): the product's C++ host builder
+        t0 = time.perf_counter()
+        po.assemble_matrix(case.a, mpc, bcs=case.bcs, pattern=pattern, fast=True)
+        t1 = time.perf_counter()
+        po.assemble_vector(case.L, mpc, fast=True)
+        t2 = time.perf_counter()
+        ndofs = case.V.num_dofs
+        t_parts = {"t_matrix_s": t1 - t0, "t_vector_s": t2 - t1}
+    else:
+        V, Q, bcs, raw_v, forms, L0 = stokes_slip_problem(3, sample_n)
+        from problems import empty_raw
+
+        import dolfinx_mpc_amd as dm
+
+        mp = [po.OracleMPC.from_raw(V, *raw_v), po.OracleMPC.from_raw(Q, *empty_raw())]
+        pm = [dm.MultiPointConstraint(V), dm.MultiPointConstraint(Q)]
+        pm[0].add_constraint(V, *raw_v)
+        for m in pm:
+            m.finalize()
+        pats = {}
+        for k, f in forms.items():  # set-up (not timed)
+            rp, cl = dm.create_sparsity_pattern(f, (pm[k[0]], pm[k[1]]), where="host")
+            pats[k] = (rp.astype(np.int32), cl)
+        t0 = time.perf_counter()
+        for k, f in forms.items():
+            po.assemble_matrix(f, mp[k[0]], mp[k[1]], bcs=bcs, pattern=pats[k], fast=True)
+        t1 = time.perf_counter()
+        po.assemble_vector(L0, mp[0], fast=True)
+        t2 = time.perf_counter()
+        ndofs = V.num_dofs + Q.num_dofs
+        what = f"same workload at N={sample_n} ({V.mesh.num_cells} cells, {ndofs} dofs)"
+        t_parts = {"t_matrix_s": t1 - t0, "t_vector_s": t2 - t1}
+    return dict(value=ndofs / (t2 - t0), unit="DoFs/s", cores=1, kind="port",
+                sample=f"{what}: matrix {t1 - t0:.2f}s + vector {t2 - t1:.2f}s, oracle/mpc_oracle.c -O3, 1 thread",
+                **t_parts)
+
+
+# ---------------------------------------------------------------------------------------------------
+def hip_time(fn, reps):
+    """average duration (ms) of fn() measured with HIP events on the launch stream"""
+    import torch
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    fn()
+    for s, e in ev:
+        s.record()
+        fn()
+        e.record()
+    torch.cuda.synchronize()
+    return float(np.mean([s.elapsed_time(e) for s, e in ev]))
+
+
+def measure_traffic(argv_child, kernel_substr):
+    """HBM bytes per launch of the kernel whose name contains ``kernel_substr``, measured NOW with
+    rocprofv3 PMC passes of a short child run of this script (FETCH_SIZE and WRITE_SIZE need separate
+    passes; gfx950 correction 2 * FETCH_SIZE, MI355X_MICROARCH.md HBM section).  None if it cannot be
+    collected (no rocprofv3, counters unavailable, time-out)."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="mpcx_pmc_", dir="/tmp")
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "p_" + counter, "--", sys.executable,
+                   os.path.abspath(__file__)] + argv_child
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd="/tmp", timeout=420,
+                               env=dict(os.environ, TMPDIR="/tmp", MPCX_BENCH_CHILD="1"))
+            dbs = glob.glob(os.path.join(out, "**", f"p_{counter}*results.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+            cur = sqlite3.connect(dbs[0]).cursor()
+            rows = cur.execute(
+                "select k.name, count(distinct p.dispatch_id), sum(p.counter_value) from pmc_events p join kernels k "
+                "on k.dispatch_id = p.dispatch_id where p.counter_name = ? group by k.name", (counter,)).fetchall()
+            hit = [(n, s / c) for n, c, s in rows if kernel_substr in n]
+            if not hit:
+                return None, f"kernel {kernel_substr} not in the PMC pass"
+            vals[counter] = max(hit, key=lambda t: t[1])[1]
+    except (subprocess.TimeoutExpired, sqlite3.Error, OSError) as e:
+        return None, f"PMC collection failed: {e}"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0), \
+        {"FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"], "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024"}
 
 
 def main():
@@ -128,240 +289,242 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=int(os.environ.get("MPCX_BENCH_N", 256)))
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5])
+    ap.add_argument("--scaling", default=os.environ.get("MPCX_BENCH_SCALING", "strong"), choices=["strong", "weak"])
+    ap.add_argument("--n", type=int, default=0, help="mesh resolution (default: 256 / 128 / 56 / 246 for config 2 / 3 / 4 / 5)")
     ap.add_argument("--alg", default=os.environ.get("MPCX_MATRIX_ALG", "rowblock"))
     ap.add_argument("--tile", type=int, nargs=3, default=[8, 8, 8], help="node/cell tile of the numbering")
     ap.add_argument("--no-tile", action="store_true")
-    ap.add_argument("--cpu-sample-n", type=int, default=96)
+    ap.add_argument("--cpu-sample-n", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-allcores", type=int, default=0, metavar="P",
-                    help="additionally time the oracle on P forked workers (oracle/cpu_parallel.py); off by default")
-    ap.add_argument("--setup-only", action="store_true", help="host set-up only (no GPU), for timing the plan")
-    ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "pmc_latest.json"),
-                    help="rocprofv3 PMC summary (tools/collect_pmc.py) of the same workload: source of roofline.traffic")
+    ap.add_argument("--cpu-allcores", type=int, default=-1, metavar="P",
+                    help="threads of the all-core CPU leg (default: min(host cores, 64); 0 = skip)")
+    ap.add_argument("--cpu-allcores-n", type=int, default=0)
+    ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 PMC measurement of roofline.traffic")
     args = ap.parse_args()
+    if args.n == 0:
+        args.n = int(os.environ.get("MPCX_BENCH_N", {2: 256, 3: 128, 4: 56, 5: 246}[args.config]))
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    N = args.n
-    reorder = None if args.no_tile else tuple(args.tile)
-
-    import dolfinx_mpc_amd as dm
-    from dolfinx_mpc_amd import _native
-    am = sys.modules["dolfinx_mpc_amd.assemble_matrix"]  # the module (the package re-exports the function)
-
-    # one rank = one GPU: select it before anything touches the device (the sparsity pattern is
-    # built there when a GPU is present)
-    import torch
-
-    if torch.cuda.is_available():
-        torch.cuda.set_device(local_rank % torch.cuda.device_count())
-
-    t_setup = time.time()
-    mesh, V, bc, mpc, a, L = build_problem(N, reorder, rank, world)
-    t = time.time()
-    rowptr, cols = dm.create_sparsity_pattern(a, mpc, where="host" if args.setup_only else None)
-    log(f"pattern: nnz {cols.size} ({time.time() - t:.1f}s)")
-    if args.setup_only:
-        log(f"host set-up total {time.time() - t_setup:.1f}s")
-        return
+    child = bool(os.environ.get("MPCX_BENCH_CHILD"))  # short run under rocprofv3: kernels only
 
     import torch
     import torch.distributed as dist
 
-    # MPCX_DIST_BACKEND=gloo lets several ranks share one GPU (smoke test of the N>1 path
-    # on a 1-GPU box); the real runs use RCCL ("nccl"), one rank per GPU
-    backend = os.environ.get("MPCX_DIST_BACKEND", "nccl")
-    dev_index = local_rank % torch.cuda.device_count()
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import _native
+    from dolfinx_mpc_amd.la import create_vector
+    am = sys.modules["dolfinx_mpc_amd.assemble_matrix"]
+    av = sys.modules["dolfinx_mpc_amd.assemble_vector"]
+
+    # one rank = one GPU: select it before anything touches the device
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
+    backend = os.environ.get("MPCX_DIST_BACKEND", "nccl")  # gloo: several ranks on one GPU (smoke test of N > 1)
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
-    from dolfinx_mpc_amd.la import MPCMatrix, create_vector
 
-    A = MPCMatrix(rowptr, cols, V.num_dofs)
-    b = create_vector(V)
-    bcs = [bc]
-
-    exchange = None
+    # ---- set-up: mesh, space, constraint, forms (host), pattern (device), matrices -------------------
+    t_setup = time.time()
+    if args.config in (2, 5):
+        w = poisson_workload(args, rank, world, 1 if args.config == 2 else 2)
+    elif args.config == 3:
+        w = stokes_workload(args, rank, world)
+    else:
+        w = contact_workload(args, rank, world)
+    t_problem = time.time() - t_setup
+    log(f"problem: {w.mesh.num_owned_cells} cells, {w.V.num_dofs} dofs on rank 0 ({t_problem:.1f}s)")
+    t = time.time()
+    mats = {label: dm.create_matrix(f, m0, m1) for label, f, (m0, m1) in w.blocks}
+    vecs = {label: create_vector(m.function_space) for label, _f, m in w.vectors}
+    torch.cuda.synchronize()
+    t_pattern = time.time() - t
+    log("pattern: nnz " + ", ".join(f"{k} {A.nnz}" for k, A in mats.items()) + f" ({t_pattern:.1f}s)")
     if world > 1:
         from dolfinx_mpc_amd.distributed import SlabExchange
 
-        exchange = SlabExchange(mesh, rowptr, cols, rank, world, device=torch.device("cuda", dev_index))
-
-    # the interface rows of the matrix travel while the vector kernel runs: post the transfer after the
-    # matrix assembly, finish it (wait + add) after the vector assembly
+        A0 = mats[w.blocks[0][0]]
+        V = w.V
+        w.exchange = SlabExchange(w.mesh, A0.rowptr, A0.cols, rank, world, device=torch.device("cuda", dev_index),
+                                  bs=V.dofmap.bs, space=V if V.degree == 2 else None)
+    bcs = w.bcs
     pending = []
 
-    def step_matrix():
-        dm.assemble_matrix(a, mpc, bcs=bcs, A=A, algorithm=args.alg)
-        if exchange is not None:
-            pending.append(exchange.reduce_matrix_begin(A))
-
-    def step_vector():
-        dm.assemble_vector(L, mpc, b=b)
-        if exchange is not None:
-            pending.append(exchange.reduce_vector_begin(b))
-            for h in pending:
-                exchange.finish(h)
-            pending.clear()
+    def step():
+        for label, f, (m0, m1) in w.blocks:
+            dm.assemble_matrix(f, (m0, m1), bcs=bcs, A=mats[label], algorithm=args.alg)
+            if w.exchange:
+                pending.append(w.exchange.reduce_matrix_begin(mats[label]))
+        for label, f, m in w.vectors:
+            dm.assemble_vector(f, m, b=vecs[label])
+            if w.exchange:
+                pending.append(w.exchange.reduce_vector_begin(vecs[label]))
+        for h in pending:
+            w.exchange.finish(h)
+        pending.clear()
 
     t = time.time()
-    step_matrix()
-    step_vector()
+    step()
     torch.cuda.synchronize()
-    log(f"first step incl. plan build + uploads: {time.time() - t:.1f}s; host set-up total {time.time() - t_setup:.1f}s")
-
+    t_first = time.time() - t
+    t_setup = time.time() - t_setup
+    plan_bytes = sum(p[1][2]["bytes"] for A in mats.values() for k, od in A._plans.items() if k == ("objcache", "rowblock")
+                     for p in od.values())
+    log(f"first step incl. plan build + uploads: {t_first:.1f}s; set-up total {t_setup:.1f}s; row-block plans {plan_bytes / 1e9:.2f} GB")
+    if child:
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        return
     for _ in range(args.warmup):
-        step_matrix()
-        step_vector()
+        step()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- the timed region: exactly K steps --------------------------------
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    # ---- the timed region: exactly K steps ----------------------------------------------------------
     barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()
-        step_matrix()
-        ev[k][1].record()
-        step_vector()
-        ev[k][2].record()
+    for _ in range(args.steps):
+        step()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    t_mat = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-    t_vec = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
 
-    # ---- per-kernel timing of the dominant (bulk matrix) kernel, HIP events on
-    #      the launch stream ----------------------------------------------------
+    # ---- per-call and per-kernel timing (HIP events on the launch stream), outside the timed region ----
+    reps = max(min(args.steps, 10), 3)
+    timings = {}
+    for label, f, (m0, m1) in w.blocks:
+        timings[f"assemble_matrix[{label}]"] = hip_time(
+            lambda: dm.assemble_matrix(f, (m0, m1), bcs=bcs, A=mats[label], algorithm=args.alg), reps)
+    for label, f, m in w.vectors:
+        timings[f"assemble_vector[{label}]"] = hip_time(lambda: dm.assemble_vector(f, m, b=vecs[label]), reps)
     Lib = _native.lib()
     alg_id = am._ALG[args.alg]
-    margs, _keep = am.matrix_args(a, 0, A, mpc, mpc, bcs, alg_id, store_mode=1 if alg_id == 2 else 0,
-                                  with_mpc_kernel=False)
-    reps = max(args.steps, 5)
-    kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    for s, e in kev:
-        s.record()
-        _native.check(Lib.mpcx_assemble_matrix(C.byref(margs)), "mpcx_assemble_matrix")
-        e.record()
+    kernels = []
+    mesh, nv = w.mesh, 4
+    nc = mesh.num_owned_cells
+    for label, f, (m0, m1) in w.blocks:
+        A = mats[label]
+        margs, keep = am.matrix_args(f, 0, A, m0, m1, bcs, alg_id, store_mode=1 if alg_id == 2 else 0, with_mpc_kernel=False)
+        tk = hip_time(lambda: _native.check(Lib.mpcx_assemble_matrix(C.byref(margs)), "mpcx_assemble_matrix"), reps)
+        V0, V1 = f.function_spaces
+        nbytes = (4 * nv * nc + 4 * V0.element_ndofs * nc + (0 if V1 is V0 else 4 * V1.element_ndofs * nc)
+                  + 24 * mesh.num_nodes + 8 * A.nnz + V0.num_dofs + V1.num_dofs)
+        kernels.append({"kernel": f"matrix_{args.alg}_kernel[{label}]", "call": f"assemble_matrix[{label}]", "launch_ms": tk,
+                        "algorithmic_bytes": int(nbytes), "pmc_name": f"matrix_{args.alg}_kernel"})
+        del keep
+    for label, f, m in w.vectors:
+        vargs, keep = av.vector_args(f, 0, vecs[label], m, 0)
+        tk = hip_time(lambda: _native.check(Lib.mpcx_assemble_vector(C.byref(vargs)), "mpcx_assemble_vector"), reps)
+        V0 = f.function_spaces[0]
+        nbytes = 4 * nv * nc + 4 * V0.element_ndofs * nc + 24 * mesh.num_nodes + 9 * V0.num_dofs
+        k = {"kernel": ("vector_rowblock_kernel" if vargs.algorithm == 2 else "vector_kernel") + f"[{label}]",
+             "call": f"assemble_vector[{label}]", "launch_ms": tk, "algorithmic_bytes": int(nbytes),
+             "pmc_name": "vector_rowblock_kernel" if vargs.algorithm == 2 else "vector_kernel"}
+        if args.config == 2:
+            # fp64 arithmetic of the 14-point source loop: 82 flop per point in the ISA (35 fma/fmac, 9 mul, 3 add)
+            nq = int(f.integrals[0].kernel.qwts.size)
+            k["fp64_flops"] = 82.0 * nq * nc
+        kernels.append(k)
+        del keep
+    for k in kernels:
+        k["hbm_GBs"] = k["algorithmic_bytes"] / (k["launch_ms"] * 1e-3) / 1e9
+        k["hbm_frac"] = k["hbm_GBs"] / PEAK_HBM_GBS
+        if "fp64_flops" in k:
+            k["fp64_TFLOPs"] = k["fp64_flops"] / (k["launch_ms"] * 1e-3) / 1e12
+            k["fp64_frac"] = k["fp64_TFLOPs"] / PEAK_FP64_TFLOPS
+    t_lift = None
+    if w.lift:
+        bl, al = w.lift
+        fa = next(f for lab, f, _ in w.blocks if lab == al)
+        mp = next(m for lab, _f, m in w.vectors if lab == bl)
+        t_lift = hip_time(lambda: dm.apply_lifting(vecs[bl], [fa], [bcs], mp), 3)
+        timings["apply_lifting"] = t_lift
+    step()  # leave consistent A / b
     torch.cuda.synchronize()
-    t_bulk = float(np.mean([s.elapsed_time(e) for s, e in kev]))
-    # lifting, separately
-    lev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
-    for s, e in lev:
-        s.record()
-        dm.apply_lifting(b, [a], [bcs], mpc)
-        e.record()
-    torch.cuda.synchronize()
-    t_lift = float(np.mean([s.elapsed_time(e) for s, e in lev[1:]]))
-    # restore a consistent A/b
-    step_matrix()
-    step_vector()
-    torch.cuda.synchronize()
-
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
-    # achievable HBM bandwidth on this device: device-to-device copy of 2 GiB, read + write
+    # achievable HBM bandwidth on this device: device copy of 2 GiB, read + write
     probe = torch.empty(1 << 28, dtype=torch.float64, device="cuda")
     probe2 = torch.empty_like(probe)
-    probe2.copy_(probe)
-    pe = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    pe[0].record()
-    for _ in range(5):
-        probe2.copy_(probe)
-    pe[1].record()
-    torch.cuda.synchronize()
-    copy_gbs = 5 * 2 * probe.numel() * 8 / (pe[0].elapsed_time(pe[1]) * 1e-3) / 1e9
+    copy_ms = hip_time(lambda: probe2.copy_(probe), 5)
+    copy_gbs = 2 * probe.numel() * 8 / (copy_ms * 1e-3) / 1e9
     del probe, probe2
 
-    ndofs_rank = V.num_dofs
-    # global dof count of the (N, N, N*world) mesh: interface planes counted once
-    ndofs_total = (N + 1) ** 2 * (N * world + 1)
-    nc, nv, nd = mesh.num_owned_cells, 4, 4
-    alg_bytes = 4 * nv * nc + 4 * nd * nc + 24 * mesh.num_nodes + 8 * cols.size + 2 * V.num_dofs
-    peak = 8000.0  # GB/s, HBM3E spec (MI355X_MICROARCH.md)
-    achieved = alg_bytes / (t_bulk * 1e-3) / 1e9
+    dom = max(kernels, key=lambda k: k["launch_ms"])  # the time-dominant kernel of the step
     out = {
-        "metric": "assembled DoFs/sec (matrix+vector), periodic Poisson P1 256^3",
-        "value": ndofs_total * args.steps / elapsed,
+        "metric": "assembled DoFs/sec (matrix+vector), periodic Poisson P1 256^3" if args.config == 2 else
+                  f"assembled DoFs/sec (matrix+vector), BASELINE config {args.config}",
+        "value": w.ndofs_total * args.steps / elapsed,
         "unit": "DoFs/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling if world > 1 or args.config != 3 else "strong",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {
-            "workload": f"periodic-BC Poisson, P1 tets, {N}^3 unit cube per GPU, fp64 (BASELINE configs[1])",
-            "cells_per_gpu": int(nc),
-            "dofs_per_gpu": int(ndofs_rank),
-            "slaves_per_gpu": int(mpc.slaves.size),
-            "nnz_per_gpu": int(cols.size),
-            "matrix_algorithm": args.alg,
-            "numbering_tile": None if reorder is None else list(reorder),
-            "parallelism": f"z-slab x{world}" if world > 1 else "single GPU",
-        },
-        "timings_ms": {"assemble_matrix": t_mat, "assemble_vector": t_vec, "apply_lifting": t_lift,
-                       "matrix_bulk_kernel": t_bulk},
+        "config": dict(w.config, baseline_config=args.config, cells_per_gpu=int(nc), dofs_per_gpu=int(w.V.num_dofs),
+                       dofs_global=int(w.ndofs_total), nnz_per_gpu={k: int(A.nnz) for k, A in mats.items()},
+                       matrix_algorithm=args.alg, numbering_tile=None if args.no_tile else list(args.tile),
+                       parallelism=(f"{args.scaling}-scaling slabs x{world}" if world > 1 else "single GPU")),
+        "timings_ms": timings,
+        "one_shot": {"setup_s": t_setup, "problem_s": t_problem, "pattern_s": t_pattern, "first_call_s": t_first,
+                     "plan_bytes": int(plan_bytes),
+                     "note": "the reference assembles once (bench_periodic.py:97-103): time to the first matrix+vector "
+                             "= first_call_s after set-up; steady-state steps reuse pattern, plans and device mirrors"},
         "roofline": {
-            "kernel": f"matrix_{args.alg}_kernel<P1 tet stiffness>",
-            "bound": "hbm",
-            "achieved": achieved,
-            "peak": peak,
-            "unit": "GB/s",
-            "frac": achieved / peak,
-            "traffic": measured_traffic(args.pmc_json, f"matrix_{args.alg}_kernel", N),
-            "algorithmic_bytes": int(alg_bytes),
-            "launch_ms": t_bulk,
-            "copy_probe_GBs": copy_gbs,  # what a plain device copy reaches on this box
-            "frac_of_copy_probe": achieved / copy_gbs,
+            "kernel": dom["kernel"], "bound": "hbm", "achieved": dom["hbm_GBs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": dom["hbm_frac"], "traffic": None, "algorithmic_bytes": dom["algorithmic_bytes"],
+            "launch_ms": dom["launch_ms"], "copy_probe_GBs": copy_gbs, "frac_of_copy_probe": dom["hbm_GBs"] / copy_gbs,
+            "selection": "time-dominant kernel of the step; every kernel of the step is listed in roofline_kernels",
         },
+        "roofline_kernels": [{k2: v for k2, v in k.items() if k2 != "pmc_name"} for k in kernels],
     }
-    # second kernel of the step, both bounds: compulsory bytes B_b over the assemble_vector
-    # time, and the fp64 arithmetic of the 14-point source loop (82 flop per point in the ISA:
-    # 35 fma/fmac, 9 mul, 3 add) against the fp64 vector peak
-    nq = int(L.integrals[0].kernel.qwts.size)
-    vec_bytes = 4 * nv * nc + 4 * nd * nc + 24 * mesh.num_nodes + 9 * V.num_dofs
-    out["roofline_vector"] = {
-        "kernel": "vector_kernel<P1 tet source, f of bench_periodic.py>",
-        "hbm": {"achieved": vec_bytes / (t_vec * 1e-3) / 1e9, "peak": peak, "unit": "GB/s",
-                "frac": vec_bytes / (t_vec * 1e-3) / 1e9 / peak, "algorithmic_bytes": int(vec_bytes)},
-        "fp64_valu": {"achieved": 82.0 * nq * nc / (t_vec * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
-                      "frac": 82.0 * nq * nc / (t_vec * 1e-3) / 1e12 / 78.6, "quadrature_points": nq},
-        "launch_ms": t_vec,
-        "note": "longer than the matrix kernel; neither bound is reached: see DESIGN.md section 5",
-    }
-    if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
-        log("timing the CPU baseline (oracle, 1 core) ...")
-        out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n)
-        if args.cpu_allcores > 0:
-            # the way the reference is deployed: one serial loop per MPI rank over its cells (SURVEY 8d ii);
-            # fresh interpreter so that nothing forks with a live HIP runtime
-            import subprocess
+    if "fp64_frac" in dom:
+        out["roofline"]["fp64_valu"] = {"achieved": dom["fp64_TFLOPs"], "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": dom["fp64_frac"]}
+    if world == 1 and not args.no_traffic and not os.environ.get("MPCX_BENCH_NO_PMC"):
+        log("measuring HBM traffic of the dominant kernel (rocprofv3 --pmc, two short child runs) ...")
+        child_args = ["--config", str(args.config), "--n", str(args.n), "--alg", args.alg, "--steps", "1", "--warmup", "0",
+                      "--no-cpu-baseline", "--no-traffic"] + (["--no-tile"] if args.no_tile else ["--tile"] + [str(v) for v in args.tile])
+        traffic, info = measure_traffic(child_args, dom["pmc_name"])
+        out["roofline"]["traffic"] = traffic
+        out["roofline"]["traffic_source"] = info
+        if traffic:
+            out["roofline"]["traffic_over_algorithmic"] = traffic / dom["algorithmic_bytes"]
+    if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
+        kind, degree = w.cpu_sample
+        sample_n = args.cpu_sample_n or {("poisson", 1): 96, ("poisson", 2): 40, ("stokes", 0): 16, ("contact", 0): 16}[(kind, degree)]
+        log(f"timing the CPU baseline (oracle, 1 core, sample {sample_n}) ...")
+        out["cpu_baseline"] = cpu_baseline(kind, degree, sample_n)
+        P = args.cpu_allcores if args.cpu_allcores >= 0 else min(os.cpu_count() or 1, 64)
+        if kind == "poisson" and P > 1:
+            # the way the reference is deployed: one serial loop per MPI rank over its cells (SURVEY 8d ii)
+            n_all = args.cpu_allcores_n or (192 if degree == 1 else 80)
+            log(f"timing the CPU baseline on {P} cores (sample N={n_all}) ...")
+            try:
+                from oracle import cpu_parallel
 
-            r = subprocess.run([sys.executable, "-m", "oracle.cpu_parallel", str(args.cpu_sample_n), str(args.cpu_allcores)],
-                               cwd=ROOT, capture_output=True, text=True, timeout=900)
-            if r.returncode == 0:
-                out["cpu_baseline_allcores"] = json.loads(r.stdout.strip().splitlines()[-1])
-            else:
-                log("oracle.cpu_parallel failed: " + r.stderr[-300:])
+                out["cpu_baseline_allcores"] = cpu_parallel.main(n_all, P, degree)
+            except Exception as e:  # noqa: BLE001
+                log(f"all-core CPU leg failed: {e}")
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -193,6 +193,7 @@ EXPORTS = [
     "mpcx_mpc_plan_num_targets",
     "mpcx_mpc_plan_copy",
     "mpcx_mpc_plan_free",
+    "mpcx_mpc_plan_device",
     "mpcx_compress_offsets",
     "mpcx_gather_f64",
     "mpcx_scatter_add_f64",
@@ -286,6 +287,9 @@ def lib() -> C.CDLL:
     L.mpcx_mpc_plan_copy.restype = C.c_int
     L.mpcx_mpc_plan_free.argtypes = [vp]
     L.mpcx_mpc_plan_free.restype = None
+    L.mpcx_mpc_plan_device.argtypes = [i64, vp, i32, vp, vp, vp, i32, i32, vp, i32, i32, vp, vp, C.POINTER(MpcT),
+                                       C.POINTER(MpcT), vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.mpcx_mpc_plan_device.restype = C.c_int
     L.mpcx_compress_offsets.argtypes = [vp, i64, i32, i32, vp, vp]
     L.mpcx_compress_offsets.restype = i32
     L.mpcx_gather_f64.argtypes = [vp, vp, i64, vp, vp]

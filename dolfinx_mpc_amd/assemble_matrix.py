@@ -270,6 +270,69 @@ def _mpc_plan(A: MPCMatrix, form: Form, i: int, mpc0, mpc1, bc0_h, bc1_h, slave_
     return D.cached(A._plans, "mpc_plan", (form, mpc0, mpc1, bc0_h, bc1_h), i, build)
 
 
+# tuples above which the device plan is not built (its sort / gathers run through torch, whose indexing is not
+# trusted beyond 2^31 bytes on this stack): such layers go through matrix_mpc_kernel
+MPC_PLAN_MAX_TUPLES = int(float(os.environ.get("MPCX_MPC_PLAN_MAX_TUPLES", 2.5e8)))
+
+
+def _mpc_plan_device(A: MPCMatrix, form: Form, i: int, mpc0, mpc1, bc0_dev, bc1_dev, slave_ents_dev):
+    """The same plan built by the HIP kernel ``mpc_plan_device_kernel`` (include/mpcx.h mpcx_mpc_plan_device):
+    count -> scan -> fill, then a stable sort by target position and a run-length pass (torch: plumbing).
+    Nothing visits the host: 0.02 s instead of 0.5 s at config 2, 1 s instead of minutes for the slip walls of
+    config 3.  Returns the tuple (tgt, off, ent, pq, coef, has_targets) or None if there are too many tuples."""
+    import torch
+
+    def build():
+        L = _native.lib()
+        integ = form.integrals[i]
+        V0, V1 = form.function_spaces
+        s0, s1 = D.space_device(V0), D.space_device(V1)
+        idv = D.integral_device(form, i)
+        m0, _k0 = mpc0._device()
+        m1, _k1 = mpc1._device()
+        dev = A.device
+        n = slave_ents_dev.numel()
+        k = integ.kernel
+        diag = int(k.form in (0, 1, 4) and V0.dofmap.bs > 1)  # stiffness / mass / facet mass on blocked spaces
+        ents = idv["entities_ptr"]
+        st = D.stream_ptr()
+        counts = torch.empty(n, dtype=torch.int64, device=dev)
+
+        def call(offsets, pos, ent, pq, coef):
+            rc = L.mpcx_mpc_plan_device(n, slave_ents_dev.data_ptr(), integ.estride, ents, ents, s0["dofmap"].data_ptr(),
+                                        V0.element_ndofs, V0.dofmap.bs, s1["dofmap"].data_ptr(), V1.element_ndofs,
+                                        V1.dofmap.bs, D.ptr(bc0_dev), D.ptr(bc1_dev), C.byref(m0), C.byref(m1),
+                                        A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), diag, counts.data_ptr(),
+                                        D.ptr(offsets), D.ptr(pos), D.ptr(ent), D.ptr(pq), D.ptr(coef), st)
+            _native.check(rc, "mpcx_mpc_plan_device")
+
+        call(None, None, None, None, None)
+        total = int(counts.sum().item())
+        if total > MPC_PLAN_MAX_TUPLES:
+            return None
+        z64 = torch.zeros(1, dtype=torch.int64, device=dev)
+        if total == 0:
+            return (z64, torch.zeros(2, dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.int32, device=dev),
+                    torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.float64, device=dev), False)
+        offsets = torch.cumsum(counts, 0) - counts
+        pos = torch.empty(total, dtype=torch.int64, device=dev)
+        ent = torch.empty(total, dtype=torch.int32, device=dev)
+        pq = torch.empty(total, dtype=torch.int32, device=dev)
+        coef = torch.empty(total, dtype=torch.float64, device=dev)
+        call(offsets, pos, ent, pq, coef)
+        pos, order = torch.sort(pos, stable=True)
+        nneg = int((pos < 0).sum().item())  # tuples outside the pattern (none for a pattern built from the same constraint)
+        pos, order = pos[nneg:], order[nneg:]
+        if pos.numel() == 0:
+            return (z64, torch.zeros(2, dtype=torch.int64, device=dev), ent[:1], pq[:1], coef[:1], False)
+        tgt, cnt = torch.unique_consecutive(pos, return_counts=True)
+        off = torch.zeros(tgt.numel() + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(cnt, 0, out=off[1:])
+        return (tgt, off, ent[order].contiguous(), pq[order].contiguous(), coef[order].contiguous(), True)
+
+    return D.cached(A._plans, "mpc_plan_dev", (form, mpc0, mpc1, bc0_dev, bc1_dev), i, build)
+
+
 def _masked_dofmap(form: Form, V, bc_dev, mpc, which: int, rotate: bool = False):
     """dofmap with the Dirichlet/slave mask folded into bits 28.. (device, cached
     per (space, bcs, constraint)): replaces the marker gathers of
@@ -322,13 +385,18 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
     a.slave_entities = slave_ents.data_ptr()
     a.n_slave_entities = slave_ents.numel() if with_mpc_kernel else 0
     mplan = None
-    # the host-built plan (gathered by target: no device atomics) pays off for the usual thin layer of slave
-    # entities; a very large layer of big elements (Taylor-Hood slip walls on 128^3: > 10^8 tensor entries)
-    # would take the host minutes and gigabytes, so those go through matrix_mpc_kernel (device atomics)
+    # master contributions from a plan gathered by target position (no device atomics, no CSR searches in the
+    # timed path).  MPCX_MPC_PLAN = device (default: built by a HIP kernel) | host (mpcx_mpc_plan_build; only for
+    # thin layers: a large layer of big elements would take the host minutes) | none (matrix_mpc_kernel: what a
+    # caller of the bare C ABI gets with mpc_plan_off == NULL); MPCX_NO_MPC_PLAN=1 is the old spelling of none
+    mode = "none" if os.environ.get("MPCX_NO_MPC_PLAN") else os.environ.get("MPCX_MPC_PLAN", "device").lower()
     n0n1 = V0.element_ndofs * V0.dofmap.bs * V1.element_ndofs * V1.dofmap.bs
-    if (a.n_slave_entities > 0 and not os.environ.get("MPCX_NO_MPC_PLAN")
-            and a.n_slave_entities * n0n1 <= MPC_PLAN_MAX_ENTRIES):
+    if a.n_slave_entities > 0 and mode == "device" and max(V0.element_ndofs * V0.dofmap.bs,
+                                                           V1.element_ndofs * V1.dofmap.bs) <= 32:
+        mplan = _mpc_plan_device(A, form, i, mpc0, mpc1, bc0, bc1, slave_ents)
+    elif a.n_slave_entities > 0 and mode == "host" and a.n_slave_entities * n0n1 <= MPC_PLAN_MAX_ENTRIES:
         mplan = _mpc_plan(A, form, i, mpc0, mpc1, bc0_h, bc1_h, slave_ents_h)
+    if mplan is not None:
         a.mpc_plan_targets = mplan[0].numel() if mplan[5] else 0
         (a.mpc_plan_tgt, a.mpc_plan_off, a.mpc_plan_ent, a.mpc_plan_pq,
          a.mpc_plan_coef) = (t.data_ptr() for t in mplan[:5])

@@ -58,6 +58,47 @@ def _vector_plan(form: Form, i: int, V):
     return form._device[key]
 
 
+def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint, alg: int):
+    """Fill the C-ABI argument block of ``mpcx_assemble_vector`` for integral i; returns (args, keep-alive)."""
+    V = form.function_spaces[0]
+    integ = form.integrals[i]
+    md = D.mesh_device(form.mesh)
+    sd = D.space_device(V)
+    m, mkeep = constraint._device()
+    idv = D.integral_device(form, i)
+    a = _native.VectorArgs()
+    a.b, a.num_dofs = b.array.data_ptr(), b.size
+    a.kernel = idv["kernel"]
+    a.x, a.x_dofmap, a.nv = md["x"].data_ptr(), md["x_dofmap"].data_ptr(), form.mesh.geometry.dofmap.shape[1]
+    a.estride, a.n_entities = integ.estride, integ.num_entities
+    a.entities = a.entities0 = idv["entities_ptr"]
+    a.coeffs = D.ptr(idv["coeffs"])
+    a.cstride = 0 if integ.coeffs is None else integ.coeffs.shape[1]
+    a.constants = D.ptr(idv["constants"])
+    a.dofmap, a.nd, a.bs = sd["dofmap"].data_ptr(), V.element_ndofs, V.dofmap.bs
+    a.mpc = m
+    a.algorithm = 1
+    keep = [md, sd, mkeep, idv]
+    # auto: row blocks for cheap integrands (few quadrature points), the hash kernel otherwise
+    nq = integ.kernel.qwts.size if integ.itype == "cell" else integ.kernel.fqwts.size
+    # (P2 with a tile-wise numbering, 96^3: hash kernel 0.71 ms whatever the rule, row blocks 0.46 ms at
+    # 4 points, 0.85 ms at 14)
+    nq_max = 8 if (V.degree == 2 and V.dof_tile_offsets is not None) else 4
+    if (alg == 2 or (alg == 0 and nq <= nq_max)) and integ.num_entities > 0:
+        from .assemble_matrix import _masked_dofmap, _slave_entities
+
+        plan, pk = _vector_plan(form, i, V)
+        md0 = _masked_dofmap(form, V, None, constraint, 0)  # slave flag only: bcs do not touch b here
+        _, slave_ents = _slave_entities(form, i, constraint, constraint)
+        a.algorithm = 2
+        a.plan = plan
+        a.mdofmap = md0.data_ptr()
+        a.slave_entities, a.n_slave_entities = slave_ents.data_ptr(), slave_ents.numel()
+        keep += [pk, md0, slave_ents]
+    a.stream = D.stream_ptr()
+    return a, keep
+
+
 def assemble_vector(form: Form, constraint: MultiPointConstraint, b: Optional[Vector] = None,
                     num_threads: Optional[int] = 1, algorithm: Optional[str] = None) -> Vector:
     """Assemble a linear form into ``b`` with the multi point constraint applied
@@ -73,48 +114,14 @@ def assemble_vector(form: Form, constraint: MultiPointConstraint, b: Optional[Ve
     constraint._not_finalized()
     _native.require_gpu()
     L = _native.lib()
-    V = form.function_spaces[0]
     if b is None:
         b = create_vector(constraint.function_space)
     b.set(0.0)
     alg = _ALG[(algorithm or os.environ.get("MPCX_VECTOR_ALG", "auto")).lower()]
-    md = D.mesh_device(form.mesh)
-    sd = D.space_device(V)
-    m, _keep = constraint._device()
     for i, integ in enumerate(form.integrals):
         if integ.itype not in ("cell", "exterior_facet"):
             raise RuntimeError("Interior facet integrals currently not supported")
-        idv = D.integral_device(form, i)
-        a = _native.VectorArgs()
-        a.b, a.num_dofs = b.array.data_ptr(), b.size
-        a.kernel = idv["kernel"]
-        a.x, a.x_dofmap, a.nv = md["x"].data_ptr(), md["x_dofmap"].data_ptr(), form.mesh.geometry.dofmap.shape[1]
-        a.estride, a.n_entities = integ.estride, integ.num_entities
-        a.entities = a.entities0 = idv["entities_ptr"]
-        a.coeffs = D.ptr(idv["coeffs"])
-        a.cstride = 0 if integ.coeffs is None else integ.coeffs.shape[1]
-        a.constants = D.ptr(idv["constants"])
-        a.dofmap, a.nd, a.bs = sd["dofmap"].data_ptr(), V.element_ndofs, V.dofmap.bs
-        a.mpc = m
-        a.algorithm = 1
-        keep = []
-        # auto: row blocks for cheap integrands (few quadrature points), the hash kernel otherwise
-        nq = integ.kernel.qwts.size if integ.itype == "cell" else integ.kernel.fqwts.size
-        # (P2 with a tile-wise numbering, 96^3: hash kernel 0.71 ms whatever the rule, row blocks 0.46 ms at
-        # 4 points, 0.85 ms at 14)
-        nq_max = 8 if (V.degree == 2 and V.dof_tile_offsets is not None) else 4
-        if (alg == 2 or (alg == 0 and nq <= nq_max)) and integ.num_entities > 0:
-            from .assemble_matrix import _masked_dofmap, _slave_entities
-
-            plan, pk = _vector_plan(form, i, V)
-            md0 = _masked_dofmap(form, V, None, constraint, 0)  # slave flag only: bcs do not touch b here
-            _, slave_ents = _slave_entities(form, i, constraint, constraint)
-            a.algorithm = 2
-            a.plan = plan
-            a.mdofmap = md0.data_ptr()
-            a.slave_entities, a.n_slave_entities = slave_ents.data_ptr(), slave_ents.numel()
-            keep = [pk, md0, slave_ents]
-        a.stream = D.stream_ptr()
+        a, keep = vector_args(form, i, b, constraint, alg)
         _native.check(L.mpcx_assemble_vector(C.byref(a)), "mpcx_assemble_vector")
         del keep
     return b

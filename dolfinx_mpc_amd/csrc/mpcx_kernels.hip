@@ -244,25 +244,156 @@ __global__ void __launch_bounds__(64) matrix_mpc_kernel(mpcx_matrix_args_t a)
 template <class Op>
 __global__ void __launch_bounds__(64) matrix_mpc_plan_kernel(mpcx_matrix_args_t a)
 {
-  constexpr int NV = Op::NV, N1 = Op::N1;
+  constexpr int NV = Op::NV, N1 = Op::N1, BS0 = Op::BS0, BS1 = Op::BS1;
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= a.mpc_plan_targets)
     return;
+  // entries straight from the compact per-cell context where the operator has one (Op::prepare /
+  // Op::entry): a tuple then costs a few dozen flops instead of a full element tensor in scratch memory
+  // (P1 elasticity, 144 entries: 35 ms -> 1 ms for the contact benchmark's master contributions)
+  bool lazy = false;
+  if constexpr (Op::LAZY)
+    lazy = Op::lazy_applies(a.kernel);
   double sum = 0.0;
+  int64_t last = -1;
+  typename Op::Lazy lz;
+  double Ae[Op::SIZE];
   for (int64_t k = a.mpc_plan_off[t]; k < a.mpc_plan_off[t + 1]; ++k)
   {
     const int64_t e = a.mpc_plan_ent[k];
-    const int64_t l = e * a.estride;
-    const int64_t cell = (a.entities ? a.entities[l] : e);
-    const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
-    double cd[NV * 3];
-    gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
-    double Ae[Op::SIZE];
-    Op::tabulate(Ae, a.coeffs ? a.coeffs + e * a.cstride : nullptr, a.constants, cd, lf, a.kernel);
+    if (e != last) // the tuples of a target are ordered by entity: geometry once per entity
+    {
+      last = e;
+      const int64_t l = e * a.estride;
+      const int64_t cell = (a.entities ? a.entities[l] : e);
+      const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
+      double cd[NV * 3];
+      gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
+      if (lazy)
+      {
+        if constexpr (Op::LAZY)
+          Op::prepare(lz, a.constants, cd);
+      }
+      else
+        Op::tabulate(Ae, a.coeffs ? a.coeffs + e * a.cstride : nullptr, a.constants, cd, lf, a.kernel);
+    }
     const int pq = a.mpc_plan_pq[k];
-    sum += a.mpc_plan_coef[k] * Op::get(Ae, pq / N1, pq % N1);
+    const int p = pq / N1, q = pq % N1;
+    double v = 0.0;
+    if (lazy)
+    {
+      if constexpr (Op::LAZY)
+        v = Op::entry(lz, p / BS0, p % BS0, q / BS1, q % BS1);
+    }
+    else
+      v = Op::get(Ae, p, q);
+    sum += a.mpc_plan_coef[k] * v;
   }
   a.vals[a.mpc_plan_tgt[t]] += sum;
+}
+
+// ---------------------------------------------------------------------------
+// The plan itself on the device (host version: mpcx_mpc_plan_build).  One thread per
+// slave entity walks the index logic of modify_mpc_cell (cpp/assemble_matrix.cpp:182-267) twice: a
+// counting pass, then -- after the caller's scan -- a pass that writes the tuples
+// (position in vals, entity, tensor entry p*N1+q, coefficient).  The caller sorts them by position
+// (stable, so a target's tuples stay ordered by entity).  Entries of Dirichlet rows / columns are zero
+// (:510-533) and emit nothing; neither do the structural zeros of component-diagonal forms (diag != 0).
+// ---------------------------------------------------------------------------
+constexpr int MPC_PLAN_MAXN = 32; // unrolled dofs per element side (P2 vector tets: 30)
+
+template <bool FILL>
+__global__ void __launch_bounds__(64)
+mpc_plan_device_kernel(int64_t n_slave_entities, const int32_t* __restrict__ slave_entities, int estride,
+                       const int32_t* __restrict__ entities0, const int32_t* __restrict__ entities1,
+                       const int32_t* __restrict__ dofmap0, int nd0, int bs0, const int32_t* __restrict__ dofmap1,
+                       int nd1, int bs1, const int8_t* __restrict__ bc0, const int8_t* __restrict__ bc1, mpcx_mpc_t mpc0,
+                       mpcx_mpc_t mpc1, const mpcx_nnz_t* __restrict__ rowptr, const int32_t* __restrict__ cols, int diag,
+                       int64_t* __restrict__ counts, const int64_t* __restrict__ offsets, int64_t* __restrict__ out_pos,
+                       int32_t* __restrict__ out_ent, int32_t* __restrict__ out_pq, double* __restrict__ out_coef)
+{
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n_slave_entities)
+    return;
+  const int64_t e = slave_entities[t];
+  const int64_t cell0 = entities0 ? entities0[e * estride] : e;
+  const int64_t cell1 = entities1 ? entities1[e * estride] : e;
+  const int N0 = nd0 * bs0, N1 = nd1 * bs1;
+  int32_t rows[MPC_PLAN_MAXN], colsd[MPC_PLAN_MAXN];
+  uint32_t rbc = 0, cbc = 0, rsl = 0, csl = 0; // one bit per unrolled local dof
+  for (int i = 0; i < nd0; ++i)
+    for (int k = 0; k < bs0; ++k)
+    {
+      const int32_t r = dofmap0[cell0 * nd0 + i] * bs0 + k;
+      rows[i * bs0 + k] = r;
+      rbc |= uint32_t(bc0 && bc0[r]) << (i * bs0 + k);
+      rsl |= uint32_t(mpc0.is_slave[r] != 0) << (i * bs0 + k);
+    }
+  for (int j = 0; j < nd1; ++j)
+    for (int k = 0; k < bs1; ++k)
+    {
+      const int32_t c = dofmap1[cell1 * nd1 + j] * bs1 + k;
+      colsd[j * bs1 + k] = c;
+      cbc |= uint32_t(bc1 && bc1[c]) << (j * bs1 + k);
+      csl |= uint32_t(mpc1.is_slave[c] != 0) << (j * bs1 + k);
+    }
+  int64_t n = 0;
+  const int64_t base = FILL ? offsets[t] : 0;
+  auto emit = [&](int p, int q, int64_t lo, int64_t hi, int32_t col, double c)
+  {
+    if (((rbc >> p) & 1) || ((cbc >> q) & 1) || (diag && (p % bs0) != (q % bs1)))
+      return;
+    if constexpr (FILL)
+    {
+      out_pos[base + n] = csr_find(cols, lo, hi, col); // -1 (outside the pattern) is dropped by the caller
+      out_ent[base + n] = int32_t(e);
+      out_pq[base + n] = p * N1 + q;
+      out_coef[base + n] = c;
+    }
+    ++n;
+  };
+  // row masters (:214-246)
+  for (int p = 0; p < N0; ++p)
+  {
+    if (!((rsl >> p) & 1))
+      continue;
+    for (int mi = mpc0.masters_offsets[rows[p]]; mi < mpc0.masters_offsets[rows[p] + 1]; ++mi)
+    {
+      const int32_t m = mpc0.masters[mi];
+      const double ci = mpc0.coeffs[mi];
+      const int64_t lo = rowptr[m], hi = rowptr[m + 1];
+      for (int q = 0; q < N1; ++q)
+      {
+        if ((csl >> q) & 1)
+        {
+          // master-master term from the un-stripped tensor (:239-245)
+          for (int mj = mpc1.masters_offsets[colsd[q]]; mj < mpc1.masters_offsets[colsd[q] + 1]; ++mj)
+            emit(p, q, lo, hi, mpc1.masters[mj], ci * mpc1.coeffs[mj]);
+        }
+        else
+          emit(p, q, lo, hi, colsd[q], ci); // stripped row (:226-236)
+      }
+    }
+  }
+  // column masters (:251-267)
+  for (int q = 0; q < N1; ++q)
+  {
+    if (!((csl >> q) & 1))
+      continue;
+    for (int mj = mpc1.masters_offsets[colsd[q]]; mj < mpc1.masters_offsets[colsd[q] + 1]; ++mj)
+    {
+      const int32_t m = mpc1.masters[mj];
+      const double cj = mpc1.coeffs[mj];
+      for (int p = 0; p < N0; ++p)
+      {
+        if ((rsl >> p) & 1)
+          continue;
+        emit(p, q, rowptr[rows[p]], rowptr[rows[p] + 1], m, cj);
+      }
+    }
+  }
+  if constexpr (!FILL)
+    counts[t] = n;
 }
 
 // ---------------------------------------------------------------------------
@@ -1464,6 +1595,34 @@ extern "C" int mpcx_pattern_device_rows(int32_t num_blocks0, const int64_t* adj_
                        dofmap1, nd1, bs1, c2s_offsets1, c2s1, masters_offsets1, masters1, row_count, rowptr, bs0,
                        cols, overflow);
   return check(hipGetLastError(), "pattern_rows launch");
+}
+
+extern "C" int mpcx_mpc_plan_device(int64_t n_slave_entities, const int32_t* slave_entities, int32_t estride,
+                                    const int32_t* entities0, const int32_t* entities1, const int32_t* dofmap0,
+                                    int32_t nd0, int32_t bs0, const int32_t* dofmap1, int32_t nd1, int32_t bs1,
+                                    const int8_t* bc0, const int8_t* bc1, const mpcx_mpc_t* mpc0, const mpcx_mpc_t* mpc1,
+                                    const mpcx_nnz_t* rowptr, const int32_t* cols, int32_t diag, int64_t* counts,
+                                    const int64_t* offsets, int64_t* pos, int32_t* ent, int32_t* pq, double* coef,
+                                    void* stream)
+{
+  if (n_slave_entities == 0)
+    return 0;
+  if (nd0 * bs0 > MPC_PLAN_MAXN || nd1 * bs1 > MPC_PLAN_MAXN)
+  {
+    mpcx_set_error("mpcx_mpc_plan_device: more than 32 unrolled dofs per element side");
+    return -7;
+  }
+  const dim3 grid(grid_for(n_slave_entities, 64));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!offsets)
+    hipLaunchKernelGGL(mpc_plan_device_kernel<false>, grid, dim3(64), 0, st, n_slave_entities, slave_entities, estride,
+                       entities0, entities1, dofmap0, nd0, bs0, dofmap1, nd1, bs1, bc0, bc1, *mpc0, *mpc1, rowptr, cols,
+                       diag, counts, offsets, pos, ent, pq, coef);
+  else
+    hipLaunchKernelGGL(mpc_plan_device_kernel<true>, grid, dim3(64), 0, st, n_slave_entities, slave_entities, estride,
+                       entities0, entities1, dofmap0, nd0, bs0, dofmap1, nd1, bs1, bc0, bc1, *mpc0, *mpc1, rowptr, cols,
+                       diag, counts, offsets, pos, ent, pq, coef);
+  return check(hipGetLastError(), "mpc_plan_device launch");
 }
 
 extern "C" int mpcx_device_count(void)

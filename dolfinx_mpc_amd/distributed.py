@@ -226,10 +226,9 @@ class SlabExchange:
         if space is not None:
             bs = space.dofmap.bs
         if space is not None and space.degree == 2:
-            # P2 on the weak-scaling slabs: edge dofs carry their own global ids / planes
-            N = mesh.slab[0]
+            # P2 on z-slabs: edge dofs carry their own global ids / planes
             blk_global = space.dof_global
-            blk_send = space.dof_plane == (rank + 1) * N
+            blk_send = space.dof_send_up
         else:
             # dofs numbered like the mesh nodes (P1, scalar or blocked)
             blk_global = mesh.node_global

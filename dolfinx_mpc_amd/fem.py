@@ -65,13 +65,16 @@ def _lagrange_ndofs(cell_name: str, degree: int) -> int:
     return {("tetrahedron", 1): 4, ("tetrahedron", 2): 10, ("triangle", 1): 3, ("triangle", 2): 6}[(cell_name, degree)]
 
 
-def kuhn_edge_global_ids(ga: np.ndarray, gb: np.ndarray, n1: int, num_global_nodes: int) -> np.ndarray:
+def kuhn_edge_global_ids(ga: np.ndarray, gb: np.ndarray, n1, num_global_nodes: int) -> np.ndarray:
     """Global id of the edges (ga, gb) of the structured Kuhn mesh whose global node id is
-    (k*n1 + j)*n1 + i: every edge runs from its lower node in one of 7 directions
-    (1,0,0) (0,1,0) (0,0,1) (1,1,0) (0,1,1) (1,0,1) (1,1,1), so id = Gn + 7*lower + direction."""
+    (k*ny1 + j)*nx1 + i (``n1`` = nx1 = ny1, or the pair (nx1, ny1)): every edge runs from its lower
+    node in one of 7 directions (1,0,0) (0,1,0) (0,0,1) (1,1,0) (0,1,1) (1,0,1) (1,1,1), so
+    id = Gn + 7*lower + direction."""
     g0, g1 = np.minimum(ga, gb).astype(np.int64), np.maximum(ga, gb).astype(np.int64)
     d = g1 - g0
-    code = {1: 0, n1: 1, n1 * n1: 2, n1 + 1: 3, n1 * n1 + n1: 4, n1 * n1 + 1: 5, n1 * n1 + n1 + 1: 6}
+    nx1, ny1 = (n1, n1) if np.isscalar(n1) else n1
+    sx, sy, sz = 1, nx1, nx1 * ny1
+    code = {sx: 0, sy: 1, sz: 2, sy + sx: 3, sz + sy: 4, sz + sx: 5, sz + sy + sx: 6}
     ud = np.unique(d)
     direction = np.array([code[int(v)] for v in ud])[np.searchsorted(ud, d)]
     return num_global_nodes + 7 * g0 + direction
@@ -133,17 +136,20 @@ class FunctionSpace:
         its two node planes (the only rank whose cells touch a vertical edge; the same rule as
         for nodes when the edge lies in a plane).  Numbering: owned nodes, owned edges, ghost
         nodes, ghost edges.  Global edge id = Gn + 7 * (lower global node) + direction."""
-        N, rank, world = mesh.slab
-        n1 = N + 1
+        part = mesh.partition
+        if part["axis"] != 2 or part.get("bodies", 1) != 1:
+            raise NotImplementedError("P2 on partitioned meshes: single box cut along z only")
+        (nx, ny, nz), (l0, l1) = part["n"], part["layers"]
+        rank, world = part["rank"], part["world"]
         cell_edges, ev = mesh.edges()
         g = mesh.node_global
-        plane = g // (n1 * n1)
-        edge_global = kuhn_edge_global_ids(g[ev[:, 0]], g[ev[:, 1]], n1, n1 * n1 * (N * world + 1))
+        plane = g // ((nx + 1) * (ny + 1))
+        edge_global = kuhn_edge_global_ids(g[ev[:, 0]], g[ev[:, 1]], (nx + 1, ny + 1), (nx + 1) * (ny + 1) * (nz + 1))
         edge_plane = np.minimum(plane[ev[:, 0]], plane[ev[:, 1]])
         last = rank == world - 1
 
         def owned(p):
-            return (p >= rank * N) & ((p < (rank + 1) * N) | (last & (p == (rank + 1) * N)))
+            return (p >= l0) & ((p < l1) | (last & (p == l1)))
 
         eo = owned(edge_plane)
         n_on, n_nodes = mesh.num_owned_nodes, mesh.num_nodes
@@ -163,6 +169,8 @@ class FunctionSpace:
         self._dof_coords = np.empty((ntot, 3))
         self._dof_coords[node_new] = x
         self._dof_coords[edge_new] = 0.5 * (x[ev[:, 0]] + x[ev[:, 1]])
+        # dofs of the upper interface plane (ghosts whose partial sums go to rank + 1)
+        self.dof_send_up = (self.dof_plane == l1) & (np.arange(ntot) >= n_on + n_oe) if not last else np.zeros(ntot, bool)
         return cell_dofs, n_on + n_oe, ntot - n_on - n_oe
 
     @property

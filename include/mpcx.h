@@ -363,6 +363,21 @@ int64_t mpcx_mpc_plan_num_targets(void* plan); /* distinct positions */
 int mpcx_mpc_plan_copy(void* plan, mpcx_nnz_t* tgt_pos, int64_t* off, int32_t* ent, int32_t* pq, double* coef);
 void mpcx_mpc_plan_free(void* plan);
 
+/* The same plan built on the DEVICE (all pointers DEVICE), two calls:
+ *   1. offsets == NULL: counts[t] = number of tuples slave entity t emits;
+ *   2. the caller scans counts into offsets (exclusive, int64 [n_slave_entities]), allocates pos / ent / pq /
+ *      coef with the total and calls again: tuple k of entity t goes to offsets[t] + k.
+ * pos = position in vals (-1: outside the pattern, to be dropped).  The caller then sorts the tuples by
+ * pos (stable) and forms tgt / off -- see dolfinx_mpc_amd/assemble_matrix.py.  diag != 0: component-diagonal
+ * form on blocked spaces (entries with different components are structural zeros and emit nothing).
+ * At most 32 unrolled dofs per element side. */
+int mpcx_mpc_plan_device(int64_t n_slave_entities, const int32_t* slave_entities, int32_t estride,
+                         const int32_t* entities0, const int32_t* entities1, const int32_t* dofmap0, int32_t nd0,
+                         int32_t bs0, const int32_t* dofmap1, int32_t nd1, int32_t bs1, const int8_t* bc0,
+                         const int8_t* bc1, const mpcx_mpc_t* mpc0, const mpcx_mpc_t* mpc1, const mpcx_nnz_t* rowptr,
+                         const int32_t* cols, int32_t diag, int64_t* counts, const int64_t* offsets, mpcx_nnz_t* pos,
+                         int32_t* ent, int32_t* pq, double* coef, void* stream);
+
 /* HOST: dictionary-compress n rows of `noff` bytes (the scatter-offset table copied to the
  * host).  pattern_ids[n] (uint16) and table[max_patterns*noff] are caller-allocated.
  * Returns the number of distinct rows, or -1 if there are more than max_patterns (<= 65536). */

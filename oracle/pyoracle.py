@@ -271,7 +271,7 @@ def create_pattern(form, mpc0: OracleMPC, mpc1: OracleMPC):
 
 
 def assemble_matrix(form, mpc0: OracleMPC, mpc1: OracleMPC = None, bcs=(), diagval=1.0, pattern=None, fast=False,
-                    same_space=None, out_vals=None):
+                    same_space=None, out_vals=None, raw_vals=None):
     """Restates python/src/dolfinx_mpc/assemble_matrix.py:43-65 +
     cpp/assemble_matrix.cpp:662-726 on the oracle; returns scipy CSR."""
     L = lib()
@@ -282,9 +282,14 @@ def assemble_matrix(form, mpc0: OracleMPC, mpc1: OracleMPC = None, bcs=(), diagv
     cols = np.ascontiguousarray(cols, dtype=np.int32)
     # out_vals: caller-owned value array (zeroed here); the values are then returned as that array
     # instead of a scipy matrix (oracle/cpu_parallel.py: workers write into shared memory)
-    vals = np.zeros(cols.size, dtype=np.float64) if out_vals is None else out_vals
-    vals[:] = 0.0
-    csr = _Csr(rowptr.size - 1, _p(rowptr), _p(cols), _p(vals), 0)
+    # raw_vals: (address of the value with position 0, already zeroed) -- oracle/cpu_parallel.py hands a
+    # worker a compact private array covering only the rows its cells touch; no diagonals are added then
+    if raw_vals is not None:
+        csr = _Csr(rowptr.size - 1, _p(rowptr), _p(cols), C.c_void_p(raw_vals), 0)
+    else:
+        vals = np.zeros(cols.size, dtype=np.float64) if out_vals is None else out_vals
+        vals[:] = 0.0
+        csr = _Csr(rowptr.size - 1, _p(rowptr), _p(cols), _p(vals), 0)
     bc0 = bc1 = None
     for bc in bcs:
         if V0.contains(bc.function_space):
@@ -307,6 +312,10 @@ def assemble_matrix(form, mpc0: OracleMPC, mpc1: OracleMPC = None, bcs=(), diagv
             0 if w is None else w.shape[1], _p(cst), C.byref(mpc0._s), C.byref(mpc1._s))
         if rc != 0:
             raise RuntimeError(f"oracle_assemble_matrix rc={rc} missing={csr.missing}")
+    if raw_vals is not None:
+        if csr.missing:
+            raise RuntimeError(f"oracle: {csr.missing} insertions outside the pattern")
+        return None
     if same_space is None:
         same_space = V0 is V1
     if mpc0.V is mpc1.V:
@@ -324,13 +333,17 @@ def assemble_matrix(form, mpc0: OracleMPC, mpc1: OracleMPC = None, bcs=(), diagv
     return scipy.sparse.csr_matrix((vals, cols, rowptr), shape=(rowptr.size - 1, V1.num_dofs))
 
 
-def assemble_vector(form, mpc: OracleMPC, b=None, fast=False):
-    """python/src/dolfinx_mpc/assemble_vector.py:79-104: zero then accumulate."""
+def assemble_vector(form, mpc: OracleMPC, b=None, fast=False, raw_b=None):
+    """python/src/dolfinx_mpc/assemble_vector.py:79-104: zero then accumulate.
+    raw_b: address of entry 0 of an already zeroed array (compact private arrays of oracle/cpu_parallel.py)."""
     L = lib()
     V = form.function_spaces[0]
-    if b is None:
-        b = np.zeros(V.num_dofs, dtype=np.float64)
-    b[:] = 0.0
+    if raw_b is not None:
+        b = C.c_void_p(raw_b)
+    else:
+        if b is None:
+            b = np.zeros(V.num_dofs, dtype=np.float64)
+        b[:] = 0.0
     x = form.mesh.geometry.x
     xd = form.mesh.geometry.dofmap
     for integ in form.integrals:
@@ -338,7 +351,7 @@ def assemble_vector(form, mpc: OracleMPC, b=None, fast=False):
         e = _ents(integ)
         w = None if integ.coeffs is None else np.ascontiguousarray(integ.coeffs, dtype=np.float64)
         cst = None if integ.constants is None else np.ascontiguousarray(integ.constants, dtype=np.float64)
-        rc = L.oracle_assemble_vector(_p(b), _which(integ.kernel, fast), C.byref(d), integ.estride, _p(e), _p(e),
+        rc = L.oracle_assemble_vector(b if raw_b is not None else _p(b), _which(integ.kernel, fast), C.byref(d), integ.estride, _p(e), _p(e),
                                       integ.num_entities, _p(x), _p(xd), xd.shape[1], _p(V.dofmap.list),
                                       V.element_ndofs, V.dofmap.bs, _p(w), 0 if w is None else w.shape[1], _p(cst),
                                       C.byref(mpc._s))

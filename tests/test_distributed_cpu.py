@@ -224,6 +224,12 @@ def _strong_problem(mesh, kind):
             V, lambda x: np.isclose(x[1], 0) | np.isclose(x[1], 1) | np.isclose(x[2], 0) | np.isclose(x[2], 1))
         bc = fem.dirichletbc(0.3, dofs, V)
         return V, [bc], periodic_raw(V, [bc]), fem.form_stiffness(V), fem.form_source(V, fem.FN_BENCH_PERIODIC)
+    if kind == "p2":  # BASELINE config 5's space on a strong-scaling partition
+        V = fem.functionspace(mesh, ("Lagrange", 2))
+        dofs = fem.locate_dofs_geometrical(
+            V, lambda x: np.isclose(x[1], 0) | np.isclose(x[1], 1) | np.isclose(x[2], 0) | np.isclose(x[2], 1))
+        bc = fem.dirichletbc(-0.4, dofs, V)
+        return V, [bc], periodic_raw(V, [bc]), fem.form_stiffness(V), fem.form_source(V, fem.FN_POLY3)
     raise ValueError(kind)
 
 
@@ -264,13 +270,14 @@ def _strong_worker(rank, world, outdir, kind, n, axis, reorder):
     A = po.assemble_matrix(a, mpc, bcs=bcs, pattern=pattern)
     b = po.assemble_vector(L, mpc)
     po.apply_lifting(b, [a], [bcs], mpc)
-    ex = SlabExchange(mesh, pattern[0], pattern[1], rank, world, bs=bs)
+    ex = SlabExchange(mesh, pattern[0], pattern[1], rank, world, bs=bs, space=V if V.degree == 2 else None)
     vals = torch.from_numpy(A.data.copy())
     bt = torch.from_numpy(b.copy())
     ex.reduce_matrix(vals)
     ex.reduce_vector(bt)
     A = scipy.sparse.csr_matrix((vals.numpy(), A.indices, A.indptr), shape=A.shape)
-    g = (mesh.node_global[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)
+    blk_global = V.dof_global if V.degree == 2 else mesh.node_global
+    g = (blk_global[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)
     nown = V.dofmap.index_map.size_local * bs
     Aown = A[:nown].tocoo()
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), row=g[Aown.row], col=g[Aown.col], val=Aown.data,
@@ -312,6 +319,45 @@ def test_strong_scaling_partition_matches_global_assembly(oracle, tmp_path, worl
     A, b, nsl, ncells = _gather(tmp_path, world, V.num_dofs)
     assert ncells == gmesh.num_cells and nsl == mpc.num_local_slaves
     assert abs(A - Aref).max() < 1e-12 * abs(Aref).max()
+    assert np.allclose(b, bref, rtol=0, atol=1e-13 * max(1.0, abs(bref).max()))
+
+
+@pytest.mark.parametrize("world,n", [(2, 3), (3, 4)])
+def test_strong_scaling_partition_p2(oracle, tmp_path, world, n):
+    """P2 (config 5's space) on an uneven strong-scaling z-partition against the single-process assembly."""
+    import torch.multiprocessing as mp
+
+    from dolfinx_mpc_amd.fem import kuhn_edge_global_ids
+    from dolfinx_mpc_amd.mesh import create_unit_cube
+
+    mp.spawn(_strong_worker, args=(world, str(tmp_path), "p2", n, 2, None), nprocs=world, join=True)
+    gmesh = create_unit_cube(n, n, n)
+    V, bcs, raw, a, L = _strong_problem(gmesh, "p2")
+    mpc = oracle.OracleMPC.from_raw(V, *raw)
+    Aref = oracle.assemble_matrix(a, mpc, bcs=bcs)
+    bref = oracle.assemble_vector(L, mpc)
+    oracle.apply_lifting(bref, [a], [bcs], mpc)
+    _, ev = gmesh.edges()
+    gkey = np.concatenate([np.arange(gmesh.num_nodes, dtype=np.int64),
+                           kuhn_edge_global_ids(ev[:, 0], ev[:, 1], n + 1, gmesh.num_nodes)])
+    order = np.argsort(gkey)
+
+    def to_ref(q):
+        p = np.searchsorted(gkey[order], q)
+        assert np.array_equal(gkey[order][p], q)
+        return order[p]
+
+    nd = V.num_dofs
+    rows, cols, vals, brow, bval = [], [], [], [], []
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        rows.append(to_ref(d["row"])), cols.append(to_ref(d["col"])), vals.append(d["val"])
+        brow.append(to_ref(d["brow"])), bval.append(d["bval"])
+    A = scipy.sparse.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nd, nd)).tocsr()
+    assert np.array_equal(np.sort(np.concatenate(brow)), np.arange(nd))
+    assert abs(A - Aref).max() < 1e-12 * abs(Aref).max()
+    b = np.zeros(nd)
+    b[np.concatenate(brow)] = np.concatenate(bval)
     assert np.allclose(b, bref, rtol=0, atol=1e-13 * max(1.0, abs(bref).max()))
 
 

@@ -196,15 +196,16 @@ def test_backsubstitution_homogenize(oracle):
 # ---------------------------------------------------------------------------------------------
 # kernel variants that the default configuration never reaches
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("env", ["MPCX_NO_MPC_PLAN", "MPCX_NO_LEAN"])
+@pytest.mark.parametrize("env", ["MPCX_NO_MPC_PLAN=1", "MPCX_NO_LEAN=1", "MPCX_MPC_PLAN=host"])
 @pytest.mark.parametrize("alg", ["atomic", "rowblock"])
 @pytest.mark.parametrize("make", CASES, ids=[f"case{i}" for i in range(len(CASES))])
 def test_small_cases_kernel_variants(oracle, make, alg, env, monkeypatch):
     """MPCX_NO_MPC_PLAN=1: the master contributions of the slave entities come from ``matrix_mpc_kernel``
     (one thread per slave entity, CSR searches, device atomics) -- the path a caller of the bare C ABI
     gets when it passes ``mpc_plan_off == NULL`` -- instead of the host-built plan.
-    MPCX_NO_LEAN=1: the general row-block kernel instead of the lean P1 one."""
-    monkeypatch.setenv(env, "1")
+    MPCX_NO_LEAN=1: the general row-block kernel instead of the lean P1 one.
+    MPCX_MPC_PLAN=host: the plan from the host builder mpcx_mpc_plan_build instead of the device kernel."""
+    monkeypatch.setenv(*env.split("="))
     case = make()
     if case.a is None:
         pytest.skip("no bilinear form")

@@ -6,7 +6,7 @@ MI355X_MICROARCH.md "rocprofv3 PMC slots"), and write
     <out>/pmc_summary.json   per kernel: avg counter value per dispatch (+ derived HBM bytes)
     <out>/pmc_summary.txt    human-readable table
 
-Run on the GPU box:   python tools/collect_pmc.py gpurun_out/pmc_rNN [N]
+Run on the GPU box:   python tools/collect_pmc.py gpurun_out/pmc_rNN [N] [config]
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE
 reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section);
 WRITE_SIZE matched the known byte count of our coalesced stores 1:1 (2.04 GB of
@@ -33,12 +33,14 @@ GROUPS = [
 def main():
     out = os.path.abspath(sys.argv[1])
     N = sys.argv[2] if len(sys.argv) > 2 else "256"
+    global CONFIG
+    CONFIG = sys.argv[3] if len(sys.argv) > 3 else "2"
     os.makedirs(out, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     for g in GROUPS:
         name = g.split()[0]
         cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + g.split() + ["-d", out, "-o", "p_" + name, "--",
-                                                                      sys.executable, os.path.join(ROOT, "tools", "profile_kernels.py"), N, "2"]
+                                                                      sys.executable, os.path.join(ROOT, "tools", "profile_kernels.py"), N, CONFIG]
         with open(os.path.join(out, f"log_{name}.txt"), "w") as fh:
             try:
                 subprocess.run(cmd, stdout=fh, stderr=subprocess.STDOUT, env=env, cwd="/tmp", timeout=240)
