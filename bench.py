@@ -421,17 +421,18 @@ def main():
         V0, V1 = f.function_spaces
         nbytes = (4 * nv * nc + 4 * V0.element_ndofs * nc + (0 if V1 is V0 else 4 * V1.element_ndofs * nc)
                   + 24 * mesh.num_nodes + 8 * A.nnz + V0.num_dofs + V1.num_dofs)
-        kernels.append({"kernel": f"matrix_{args.alg}_kernel[{label}]", "call": f"assemble_matrix[{label}]", "launch_ms": tk,
-                        "algorithmic_bytes": int(nbytes), "pmc_name": f"matrix_{args.alg}_kernel"})
+        kname = "matrix_cube_kernel" if margs.algorithm == 3 else f"matrix_{args.alg}_kernel"
+        kernels.append({"kernel": f"{kname}[{label}]", "call": f"assemble_matrix[{label}]", "launch_ms": tk,
+                        "algorithmic_bytes": int(nbytes), "pmc_name": kname})
         del keep
     for label, f, m in w.vectors:
         vargs, keep = av.vector_args(f, 0, vecs[label], m, 0)
         tk = hip_time(lambda: _native.check(Lib.mpcx_assemble_vector(C.byref(vargs)), "mpcx_assemble_vector"), reps)
         V0 = f.function_spaces[0]
         nbytes = 4 * nv * nc + 4 * V0.element_ndofs * nc + 24 * mesh.num_nodes + 9 * V0.num_dofs
-        k = {"kernel": ("vector_rowblock_kernel" if vargs.algorithm == 2 else "vector_kernel") + f"[{label}]",
-             "call": f"assemble_vector[{label}]", "launch_ms": tk, "algorithmic_bytes": int(nbytes),
-             "pmc_name": "vector_rowblock_kernel" if vargs.algorithm == 2 else "vector_kernel"}
+        kname = {2: "vector_rowblock_kernel", 3: "vector_cube_kernel"}.get(vargs.algorithm, "vector_kernel")
+        k = {"kernel": f"{kname}[{label}]", "call": f"assemble_vector[{label}]", "launch_ms": tk,
+             "algorithmic_bytes": int(nbytes), "pmc_name": kname}
         if args.config == 2:
             # fp64 arithmetic of the 14-point source loop: 82 flop per point in the ISA (35 fma/fmac, 9 mul, 3 add)
             nq = int(f.integrals[0].kernel.qwts.size)

@@ -93,6 +93,7 @@ class MatrixArgs(C.Structure):
         ("mdofmap0", C.c_void_p),
         ("mdofmap1", C.c_void_p),
         ("lean", C.c_int32),
+        ("cube_recs", C.c_void_p),
         ("mpc_plan_targets", C.c_int64),
         ("mpc_plan_tgt", C.c_void_p),
         ("mpc_plan_off", C.c_void_p),
@@ -127,6 +128,8 @@ class VectorArgs(C.Structure):
         ("mdofmap", C.c_void_p),
         ("slave_entities", C.c_void_p),
         ("n_slave_entities", C.c_int64),
+        ("cube_verts", C.c_void_p),
+        ("n_cubes", C.c_int64),
         ("stream", C.c_void_p),
     ]
 
@@ -169,6 +172,7 @@ EXPORTS = [
     "mpcx_assemble_matrix",
     "mpcx_mask_dofmap",
     "mpcx_scatter_offsets",
+    "mpcx_cube_records",
     "mpcx_add_diagonal",
     "mpcx_assemble_vector",
     "mpcx_apply_lifting",
@@ -267,6 +271,8 @@ def lib() -> C.CDLL:
     L.mpcx_mask_dofmap.restype = C.c_int
     L.mpcx_scatter_offsets.argtypes = [vp, vp, i32, i64, vp, vp, vp, i32, i32, vp, i32, i32, i32, vp, vp, vp]
     L.mpcx_scatter_offsets.restype = C.c_int
+    L.mpcx_cube_records.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.mpcx_cube_records.restype = C.c_int
     L.mpcx_rowblock_plan_build.argtypes = [i32, vp, i32, i32, i64, i32, vp, vp, i32, i32, vp, i32, i32]
     L.mpcx_rowblock_plan_build.restype = vp
     L.mpcx_rowblock_plan_num_blocks.argtypes = [vp]

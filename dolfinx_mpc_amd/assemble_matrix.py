@@ -17,6 +17,9 @@ from .la import MPCMatrix
 from .multipointconstraint import MultiPointConstraint
 
 _ALG = {"auto": 0, "atomic": 1, "rowblock": 2}
+# cluster kernel (MPCX_ALG_CUBE): row blocks of the cluster path (LDS: max_nnz * 8 B + max_rows * 4 B)
+CUBE_MAX_NNZ = int(os.environ.get("MPCX_CUBE_MAX_NNZ", 9216))
+CUBE_MAX_ROWS = int(os.environ.get("MPCX_CUBE_MAX_ROWS", 512))
 
 # LDS budget of one row block: max_nnz * (8 B value + 4 B column) + row offsets
 # (measured on MI355X, tools/sweep_rowblock.py: 512 rows x 9216 nnz = 76 KB of LDS
@@ -233,6 +236,86 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False):
     return D.cached(A._plans, "rowblock", (form,), (i, max_nnz_cap, max_rows_cap, lean), build)
 
 
+def _cube_eligible(form: Form, i: int, V0) -> bool:
+    """scalar P1 stiffness on tetrahedra without coefficient, over cells 0..n-1 (MPCX_ALG_CUBE)"""
+    integ = form.integrals[i]
+    k = integ.kernel
+    return (k.form == 0 and k.celltype == 2 and k.degree == 1 and k.bs == 1 and (k.degree1 or 1) == 1
+            and (k.bs1 or 1) == 1 and k.coeff_degree == 0 and integ.coefficient is None and integ.itype == "cell"
+            and not os.environ.get("MPCX_NO_CUBE"))
+
+
+def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc):
+    """Row blocks over the mesh's cell clusters + one 96-byte record per (block, cluster) slot
+    (mpcx_cube_records); cached per (form, constraint, Dirichlet markers).  Returns
+    (plan struct, records tensor, keep-alive, info, leftover cells) or None when the mesh has no clusters."""
+    import torch
+
+    from .clusters import mesh_clusters
+
+    integ = form.integrals[i]
+    verts, left = mesh_clusters(form.mesh, integ.num_entities)
+    if verts.shape[0] == 0 or verts.shape[0] * 6 < 0.5 * integ.num_entities:
+        return None
+
+    def build():
+        L = _native.lib()
+        p = _native._ptr
+        dev = A.device
+        nc = verts.shape[0]
+        ents = np.arange(nc, dtype=np.int32)
+        hints = None
+        if V0.dof_tile_offsets is not None:
+            hints = np.ascontiguousarray(V0.dof_tile_offsets.astype(np.int32))
+        h = L.mpcx_rowblock_plan_build(A.shape[0], p(A.rowptr), CUBE_MAX_ROWS, CUBE_MAX_NNZ, nc, 1, p(ents), p(verts), 8, 1,
+                                       None if hints is None else p(hints), 0 if hints is None else hints.size, 1)
+        if not h:
+            raise RuntimeError("mpcx_rowblock_plan_build failed: " + L.mpcx_last_error().decode())
+        try:
+            nb = L.mpcx_rowblock_plan_num_blocks(h)
+            row0 = np.empty(nb + 1, dtype=np.int32)
+            off = np.empty(nb + 1, dtype=np.int64)
+            ents_b = np.empty(L.mpcx_rowblock_plan_num_ents(h), dtype=np.int32)
+            L.mpcx_rowblock_plan_copy(h, p(row0), p(off), p(ents_b))
+        finally:
+            L.mpcx_rowblock_plan_free(h)
+        d_verts = D._to_dev(verts, dev)
+        d_ents = D._to_dev(ents_b, dev)
+        recs = torch.empty(ents_b.size * 96, dtype=torch.uint8, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        _, t = mpc._device()
+        rc = L.mpcx_cube_records(ents_b.size, d_ents.data_ptr(), d_verts.data_ptr(), D.ptr(bc_dev), t["is_slave"].data_ptr(),
+                                 A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), recs.data_ptr(), flag.data_ptr(), D.stream_ptr())
+        _native.check(rc, "mpcx_cube_records")
+        if int(flag.item()) != 0:
+            raise RuntimeError("cluster algorithm: a scatter offset does not fit 8 bits (or a column is missing)")
+        keep = (D._to_dev(row0, dev), D._to_dev(off, dev), recs)
+        max_rows = int(np.diff(row0).max())
+        max_nnz = int(np.diff(A.rowptr[row0]).max())
+        plan = _native.RowBlockPlanT(nb, max_rows, max_nnz, keep[0].data_ptr(), keep[1].data_ptr(), None, None, None)
+        info = {"num_blocks": nb, "num_ents": int(ents_b.size), "max_rows": max_rows, "max_nnz": max_nnz,
+                "clusters": int(nc), "bytes": int(sum(x.numel() * x.element_size() for x in keep))}
+        return (plan, keep, info)
+
+    try:
+        plan, keep, info = D.cached(A._plans, "cubes", (form, mpc, bc_dev), (i, CUBE_MAX_ROWS, CUBE_MAX_NNZ), build)
+    except RuntimeError:
+        return None
+    return plan, keep, info, left
+
+
+def _leftover_form(form: Form, i: int, left: np.ndarray) -> Form:
+    """integral i restricted to the cells outside any cluster (per-cell kernels)"""
+    from .fem import Integral
+
+    def build():
+        integ = form.integrals[i]
+        return Form(form.function_spaces, [Integral("cell", np.ascontiguousarray(left, dtype=np.int32), integ.kernel,
+                                                    None, integ.constant)])
+
+    return D.cached(form._device, "leftover", (), (i, left.size), build)
+
+
 def _mpc_plan(A: MPCMatrix, form: Form, i: int, mpc0, mpc1, bc0_h, bc1_h, slave_ents_h):
     """Plan of the master contributions of integral i's slave entities (mpcx_mpc_plan_build: the index
     logic of modify_mpc_cell evaluated once, gathered by target position), as device tensors
@@ -356,7 +439,7 @@ def _masked_dofmap(form: Form, V, bc_dev, mpc, which: int, rotate: bool = False)
 
 
 def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, store_mode: int = 0,
-                with_mpc_kernel: bool = True):
+                with_mpc_kernel: bool = True, allow_cubes: bool = True):
     """Fill the C-ABI argument block of ``mpcx_assemble_matrix`` for integral i."""
     V0, V1 = form.function_spaces
     integ = form.integrals[i]
@@ -404,11 +487,22 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
     a.store_mode = store_mode
     a.stream = D.stream_ptr()
     keep = [md, s0, s1, bc0, bc1, k0, k1, idv, slave_ents, mplan]
+    a.leftover = None  # (python attribute) cells the cluster kernel does not cover
     if alg == 2:
         # lean path (include/mpcx.h, mpcx_matrix_args_t::lean): square P1-type form over all cells
         same = V1 is V0 and mpc1 is mpc0 and bc1 is bc0
         lean = (same and s0["dofmap"] is md["x_dofmap"] and idv["entities_ptr"] is None and integ.estride == 1
                 and integ.coeffs is None and not os.environ.get("MPCX_NO_LEAN"))
+        if lean and allow_cubes and _cube_eligible(form, i, V0):
+            cp = _cube_plan(A, form, i, V0, bc0, mpc0)
+            if cp is not None:
+                plan, ck, _info, left = cp
+                a.algorithm = 3
+                a.plan = plan
+                a.cube_recs = ck[2].data_ptr()
+                a.leftover = left if left.size else None
+                keep += [ck]
+                return a, keep
         plan, pk, _info = _rowblock_plan(A, form, i, V0, lean)
         a.plan = plan
         a.lean = int(lean)
@@ -481,6 +575,12 @@ def assemble_matrix(
                 zeroed = True
         a, _keep = matrix_args(form, i, A, mpc0, mpc1, bcs, alg, store_mode)
         _native.check(L.mpcx_assemble_matrix(C.byref(a)), "mpcx_assemble_matrix")
+        if a.leftover is not None:
+            # cells outside any cluster: per-cell row-block kernel, ADDed; their master contributions were part
+            # of the call above (its plan covers every slave entity of the integral)
+            fl = _leftover_form(form, i, a.leftover)
+            al, _kl = matrix_args(fl, 0, A, mpc0, mpc1, bcs, alg, 0, with_mpc_kernel=False, allow_cubes=False)
+            _native.check(L.mpcx_assemble_matrix(C.byref(al)), "mpcx_assemble_matrix")
     if not zeroed:
         A.zeroEntries()
 

@@ -58,7 +58,7 @@ def _vector_plan(form: Form, i: int, V):
     return form._device[key]
 
 
-def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint, alg: int):
+def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint, alg: int, allow_cubes: bool = True):
     """Fill the C-ABI argument block of ``mpcx_assemble_vector`` for integral i; returns (args, keep-alive)."""
     V = form.function_spaces[0]
     integ = form.integrals[i]
@@ -79,6 +79,24 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
     a.mpc = m
     a.algorithm = 1
     keep = [md, sd, mkeep, idv]
+    a.leftover = None  # (python attribute) cells the cluster kernel does not cover
+    k = integ.kernel
+    if (alg in (0, 1) and allow_cubes and not os.environ.get("MPCX_NO_CUBE") and k.form == 2 and k.celltype == 2
+            and k.degree == 1 and k.bs == 1 and k.coeff_degree == 0 and integ.coefficient is None and integ.itype == "cell"
+            and idv["entities_ptr"] is None and sd["dofmap"] is md["x_dofmap"]):
+        # scalar P1 source over all cells: one thread per cell cluster (MPCX_ALG_CUBE, csrc/mpcx_cubes.hip)
+        from .clusters import mesh_clusters
+
+        verts, left = mesh_clusters(form.mesh, integ.num_entities)
+        if verts.shape[0] * 6 >= 0.5 * integ.num_entities:
+            d_verts = D.cached(form.mesh._device, "cube_verts_dev", (), (str(b.array.device), integ.num_entities),
+                               lambda: D._to_dev(verts, b.array.device))
+            a.algorithm = 3
+            a.cube_verts, a.n_cubes = d_verts.data_ptr(), verts.shape[0]
+            a.leftover = left if left.size else None
+            a.stream = D.stream_ptr()
+            keep += [d_verts]
+            return a, keep
     # auto: row blocks for cheap integrands (few quadrature points), the hash kernel otherwise
     nq = integ.kernel.qwts.size if integ.itype == "cell" else integ.kernel.fqwts.size
     # (P2 with a tile-wise numbering, 96^3: hash kernel 0.71 ms whatever the rule, row blocks 0.46 ms at
@@ -123,6 +141,11 @@ def assemble_vector(form: Form, constraint: MultiPointConstraint, b: Optional[Ve
             raise RuntimeError("Interior facet integrals currently not supported")
         a, keep = vector_args(form, i, b, constraint, alg)
         _native.check(L.mpcx_assemble_vector(C.byref(a)), "mpcx_assemble_vector")
+        if a.leftover is not None:  # cells outside any cluster: per-cell kernel
+            from .assemble_matrix import _leftover_form
+
+            al, kl = vector_args(_leftover_form(form, i, a.leftover), 0, b, constraint, alg, allow_cubes=False)
+            _native.check(L.mpcx_assemble_vector(C.byref(al)), "mpcx_assemble_vector")
         del keep
     return b
 

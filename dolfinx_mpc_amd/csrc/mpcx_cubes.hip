@@ -1,0 +1,461 @@
+// Cell clusters ("Kuhn fans") for P1 tetrahedral meshes on gfx950.
+//
+// Six tets that share one edge v0-v7 and together have eight vertices -- what every structured
+// box generator (ours, DOLFINx create_box) emits per hexahedral cube -- couple only 8 + 2*19 = 46
+// matrix entries, while the six element tensors scattered one by one cost 6*16 = 96 scatter-adds.
+// One thread takes the whole cluster: 8 vertex ids and 24 coordinates are loaded once, the six
+// element tensors are summed in registers (27 distinct values, the matrix is symmetric) and 46
+// ds_add_f64 go to the LDS copy of the row block -- half the LDS atomics and a third of the index
+// bytes of the per-cell kernel (cpp/assemble_matrix.cpp:488-547 is the loop being replaced; the
+// per-cell semantics -- Dirichlet / slave rows and columns masked, values ADDed -- are unchanged).
+// The clusters are found topologically at set-up (dolfinx_mpc_amd/clusters.py: six consecutive cells
+// with the fan's vertex pattern); cells outside any cluster keep going through the per-cell kernels.
+// The geometry of every tet is computed from its own coordinates: nothing assumes a cube.
+#include "mpcx.h"
+#include "mpcx_elements.hpp"
+#include "mpcx_internal.h"
+
+#include <hip/hip_runtime.h>
+#include <string>
+
+namespace mpcx
+{
+namespace
+{
+constexpr int MASK_SHIFT = 28;
+constexpr int DOF_MASK = (1 << MASK_SHIFT) - 1;
+
+// local vertices of the six tets of a fan (cube corner b: bit0 = x, bit1 = y, bit2 = z)
+__host__ __device__ constexpr int fan_vertex(int t, int i)
+{
+  constexpr int T[6][4] = {{0, 1, 3, 7}, {0, 1, 7, 5}, {0, 5, 7, 4}, {0, 3, 2, 7}, {0, 6, 4, 7}, {0, 2, 6, 7}};
+  return T[t][i];
+}
+// the fan walked round its shared edge: consecutive tets share a face
+__host__ __device__ constexpr int fan_order(int step)
+{
+  constexpr int O[6] = {0, 1, 2, 4, 5, 3};
+  return O[step];
+}
+// do local vertices a and b share a tet? (a == b counts)
+__host__ __device__ constexpr bool fan_coupled(int a, int b)
+{
+  for (int t = 0; t < 6; ++t)
+  {
+    bool ha = false, hb = false;
+    for (int i = 0; i < 4; ++i)
+    {
+      ha |= fan_vertex(t, i) == a;
+      hb |= fan_vertex(t, i) == b;
+    }
+    if (ha && hb)
+      return true;
+  }
+  return false;
+}
+
+// last step (in fan_order) whose tet holds both a and b; -1 if they share none
+__host__ __device__ constexpr int fan_last_step(int a, int b)
+{
+  int last = -1;
+  for (int s = 0; s < 6; ++s)
+  {
+    const int t = fan_order(s);
+    bool ha = false, hb = false;
+    for (int i = 0; i < 4; ++i)
+    {
+      ha |= fan_vertex(t, i) == a;
+      hb |= fan_vertex(t, i) == b;
+    }
+    if (ha && hb)
+      last = s;
+  }
+  return last;
+}
+
+struct __align__(16) CubeRec
+{
+  int32_t v[8];   // vertex (= dof) ids with the Dirichlet / slave mask in bit 28
+  uint8_t off[64]; // off[a*8+b]: position of column v[b] inside CSR row v[a] (coupled pairs only)
+};
+static_assert(sizeof(CubeRec) == 96, "record layout");
+
+inline int check(hipError_t err, const char* what)
+{
+  if (err != hipSuccess)
+  {
+    mpcx_set_error(std::string(what) + ": " + hipGetErrorString(err));
+    return -100;
+  }
+  return 0;
+}
+inline unsigned grid_for(int64_t n, int block) { return static_cast<unsigned>((n + block - 1) / block); }
+
+__device__ inline int64_t find_col(const int32_t* __restrict__ cols, int64_t lo, int64_t hi, int col)
+{
+  const int64_t end = hi;
+  while (lo < hi)
+  {
+    const int64_t mid = (lo + hi) >> 1;
+    if (cols[mid] < col)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return (lo < end && cols[lo] == col) ? lo : -1;
+}
+
+// set-up: one record per (row block, cluster touching it) slot k
+__global__ void cube_records_kernel(int64_t n_slots, const int32_t* __restrict__ block_ents,
+                                    const int32_t* __restrict__ cube_verts, const int8_t* __restrict__ bc,
+                                    const int8_t* __restrict__ is_slave, const mpcx_nnz_t* __restrict__ rowptr,
+                                    const int32_t* __restrict__ cols, CubeRec* __restrict__ recs, int32_t* overflow)
+{
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n_slots * 8)
+    return;
+  const int64_t k = t >> 3;
+  const int a = int(t & 7);
+  const int32_t* v = cube_verts + int64_t(block_ents[k]) * 8;
+  const int32_t r = v[a];
+  CubeRec& R = recs[k];
+  R.v[a] = r | (((bc && bc[r]) || is_slave[r]) ? (1 << MASK_SHIFT) : 0);
+  const int64_t lo = rowptr[r], hi = rowptr[r + 1];
+  for (int b = 0; b < 8; ++b)
+  {
+    int o = 255;
+    if (fan_coupled(a, b))
+    {
+      const int64_t pos = find_col(cols, lo, hi, v[b]);
+      o = pos < 0 ? 256 : int(pos - lo);
+      if (o > 255)
+        atomicOr(overflow, 1);
+    }
+    R.off[a * 8 + b] = uint8_t(o);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// matrix: P1 scalar stiffness, one thread per (row block, cluster) slot
+// ---------------------------------------------------------------------------
+constexpr int CUBE_MAX_THREADS = 512;
+
+__global__ void __launch_bounds__(CUBE_MAX_THREADS) matrix_cube_kernel(mpcx_matrix_args_t a)
+{
+  const int NT = blockDim.x;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int nb = a.plan.num_blocks;
+  const int per = (nb + 7) >> 3;
+  const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3); // contiguous runs of row blocks per XCD
+  if (b >= nb)
+    return;
+  const int tid = threadIdx.x;
+  const int r0 = a.plan.block_row0[b], r1 = a.plan.block_row0[b + 1];
+  const int nrow = r1 - r0;
+  const int64_t nnz0 = a.rowptr[r0];
+  const int nnzb = int(a.rowptr[r1] - nnz0);
+  double* s_vals = reinterpret_cast<double*>(smem);
+  int32_t* s_rowlo = reinterpret_cast<int32_t*>(s_vals + a.plan.max_nnz);
+  for (int i = tid; i < nnzb; i += NT)
+    s_vals[i] = 0.0;
+  for (int rl = tid; rl < nrow; rl += NT)
+    s_rowlo[rl] = int(a.rowptr[r0 + rl] - nnz0);
+  __syncthreads();
+
+  const double c0 = a.constants ? a.constants[0] : 1.0;
+  const CubeRec* __restrict__ recs = static_cast<const CubeRec*>(a.cube_recs);
+  const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  auto load = [&](int64_t t, uint4 (&w)[6])
+  {
+    const uint4* p = reinterpret_cast<const uint4*>(recs + t);
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      w[i] = p[i];
+  };
+  auto gather = [&](const uint4 (&w)[6], double (&X)[8][3])
+  {
+    const int32_t v[8] = {int32_t(w[0].x), int32_t(w[0].y), int32_t(w[0].z), int32_t(w[0].w),
+                          int32_t(w[1].x), int32_t(w[1].y), int32_t(w[1].z), int32_t(w[1].w)};
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+    {
+      const int64_t n = v[i] & DOF_MASK;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        X[i][k] = a.x[3 * n + k];
+    }
+  };
+  // Software pipeline, two slots deep: while slot t is computed, the 24 coordinates of slot t + NT and the
+  // record of slot t + 2 NT are in flight (the kernel runs two waves per SIMD, so the latency of the
+  // dependent chain record -> coordinates has to be covered inside the wave; 256 VGPRs are available)
+  uint4 cur[6], nxt[6];
+  double X[8][3], Xn[8][3];
+  int64_t t = e0 + tid;
+  if (t < e1)
+  {
+    load(t, cur);
+    if (t + NT < e1)
+      load(t + NT, nxt);
+    gather(cur, X);
+  }
+  for (; t < e1; t += NT)
+  {
+    const int32_t v[8] = {int32_t(cur[0].x), int32_t(cur[0].y), int32_t(cur[0].z), int32_t(cur[0].w),
+                          int32_t(cur[1].x), int32_t(cur[1].y), int32_t(cur[1].z), int32_t(cur[1].w)};
+    const uint32_t ow[16] = {cur[2].x, cur[2].y, cur[2].z, cur[2].w, cur[3].x, cur[3].y, cur[3].z, cur[3].w,
+                             cur[4].x, cur[4].y, cur[4].z, cur[4].w, cur[5].x, cur[5].y, cur[5].z, cur[5].w};
+    const bool has_next = t + NT < e1;
+    if (has_next)
+      gather(nxt, Xn);
+    // LDS address of every row of this block that takes contributions (-1: outside the block or masked)
+    int base[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+    {
+      const int r = v[i] & DOF_MASK;
+      const bool mine = r >= r0 && r < r1 && !(v[i] >> MASK_SHIFT);
+      base[i] = mine ? s_rowlo[mine ? r - r0 : 0] : -1;
+    }
+    // The six element tensors are summed per vertex pair (upper triangle, static indices -> registers) walking
+    // round the shared edge, and a pair is scattered as soon as its last tet is done, so that only the pairs
+    // of the current face stay live (27 accumulators otherwise).
+    double A[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = i; j < 8; ++j)
+        A[i][j] = 0.0;
+#pragma unroll
+    for (int step = 0; step < 6; ++step)
+    {
+      const int tet = fan_order(step);
+      double cd[12];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          cd[3 * i + k] = X[fan_vertex(tet, i)][k];
+      double G[4][3], det;
+      cofactor_gradients<3>(cd, G, det); // det * grad(lambda_i)
+      const double s = c0 / (6.0 * fabs(det));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = i; j < 4; ++j)
+        {
+          const int gi = fan_vertex(tet, i), gj = fan_vertex(tet, j);
+          const double e = s * (G[i][0] * G[j][0] + G[i][1] * G[j][1] + G[i][2] * G[j][2]);
+          A[gi < gj ? gi : gj][gi < gj ? gj : gi] += e;
+        }
+      // pairs whose last tet this was: rows of this block, unmasked columns
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = i; j < 8; ++j)
+        {
+          if (fan_last_step(i, j) != step)
+            continue;
+          const double val = A[i][j];
+          if (base[i] >= 0 && !(v[j] >> MASK_SHIFT))
+          {
+            const int off = int((ow[(i * 8 + j) >> 2] >> (8 * ((i * 8 + j) & 3))) & 0xff);
+            __hip_atomic_fetch_add(s_vals + base[i] + off, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          if (i != j && base[j] >= 0 && !(v[i] >> MASK_SHIFT))
+          {
+            const int off = int((ow[(j * 8 + i) >> 2] >> (8 * ((j * 8 + i) & 3))) & 0xff);
+            __hip_atomic_fetch_add(s_vals + base[j] + off, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+    }
+    if (has_next)
+    {
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        cur[i] = nxt[i];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          X[i][k] = Xn[i][k];
+      if (t + 2 * NT < e1)
+        load(t + 2 * NT, nxt);
+    }
+  }
+  __syncthreads();
+  if (a.store_mode)
+    for (int i = tid; i < nnzb; i += NT)
+      a.vals[nnz0 + i] = s_vals[i];
+  else
+    for (int i = tid; i < nnzb; i += NT)
+      a.vals[nnz0 + i] += s_vals[i];
+}
+
+// ---------------------------------------------------------------------------
+// vector: P1 source term, one thread per cluster; contributions merged per destination dof in an
+// LDS hash table, one device atomic per distinct dof of the workgroup (8 inserts per 6 cells instead
+// of 24, and a third of the device atomics: the workgroup's clusters share most of their vertices)
+// ---------------------------------------------------------------------------
+constexpr int VCUBE_THREADS = 256;
+constexpr int VCUBE_LOG2H = 11;
+constexpr int VCUBE_H = 1 << VCUBE_LOG2H;
+constexpr int VCUBE_PROBES = 64;
+
+template <int FN>
+__global__ void __launch_bounds__(VCUBE_THREADS) vector_cube_kernel(mpcx_vector_args_t a)
+{
+  using Op = ElementOp<3, 1, 1, 1, 1, MPCX_FORM_SOURCE, FN>;
+  __shared__ int32_t s_key[VCUBE_H];
+  __shared__ double s_val[VCUBE_H];
+  for (int i = threadIdx.x; i < VCUBE_H; i += VCUBE_THREADS)
+  {
+    s_key[i] = -1;
+    s_val[i] = 0.0;
+  }
+  fastmath_init_lds(); // ends in a barrier
+  const int64_t c = int64_t(blockIdx.x) * VCUBE_THREADS + threadIdx.x;
+  if (c < a.n_cubes)
+  {
+    int32_t v[8];
+    {
+      const uint4* p = reinterpret_cast<const uint4*>(a.cube_verts + c * 8);
+      const uint4 w0 = p[0], w1 = p[1];
+      v[0] = w0.x, v[1] = w0.y, v[2] = w0.z, v[3] = w0.w, v[4] = w1.x, v[5] = w1.y, v[6] = w1.z, v[7] = w1.w;
+    }
+    double X[8][3];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        X[i][k] = a.x[3 * int64_t(v[i]) + k];
+    double be8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      be8[i] = 0.0;
+#pragma unroll
+    for (int tet = 0; tet < 6; ++tet)
+    {
+      double cd[12];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          cd[3 * i + k] = X[fan_vertex(tet, i)][k];
+      double be[4];
+      Op::tabulate(be, nullptr, a.constants, cd, 0, a.kernel);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        be8[fan_vertex(tet, i)] += be[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+    {
+      const int32_t d = v[i];
+      double val = be8[i];
+      if (a.mpc.is_slave[d])
+      {
+        const int m0 = a.mpc.masters_offsets[d], m1 = a.mpc.masters_offsets[d + 1];
+        for (int mi = m0; mi < m1; ++mi)
+          __hip_atomic_fetch_add(a.b + a.mpc.masters[mi], a.mpc.coeffs[mi] * val, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+        if (m1 > m0)
+          val = 0.0; // be[slave] is cleared once it has been moved (cpp/assemble_vector.h:65)
+      }
+      if (val != 0.0)
+      {
+        unsigned h = (unsigned(d) * 2654435761u) >> (32 - VCUBE_LOG2H);
+        int probe = 0;
+#pragma nounroll
+        for (; probe < VCUBE_PROBES; ++probe)
+        {
+          const int32_t old = atomicCAS(&s_key[h], -1, d);
+          if (old == -1 || old == d)
+          {
+            __hip_atomic_fetch_add(&s_val[h], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            break;
+          }
+          h = (h + 1) & (VCUBE_H - 1);
+        }
+        if (probe == VCUBE_PROBES)
+          __hip_atomic_fetch_add(a.b + d, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < VCUBE_H; i += VCUBE_THREADS)
+  {
+    const int32_t d = s_key[i];
+    if (d >= 0)
+      __hip_atomic_fetch_add(a.b + d, s_val[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+} // namespace
+
+int launch_matrix_cubes(const mpcx_matrix_args_t& a)
+{
+  const mpcx_kernel_t& k = a.kernel;
+  if (k.form != MPCX_FORM_STIFFNESS || k.celltype != MPCX_CELL_TETRAHEDRON || k.degree != 1 || k.bs != 1
+      || k.degree1 != 1 || k.bs1 != 1 || k.coeff_degree != 0 || a.coeffs || a.estride != 1 || a.nv != 4)
+  {
+    mpcx_set_error("mpcx_assemble_matrix: the cluster algorithm covers the scalar P1 stiffness form on tetrahedra "
+                   "without coefficients");
+    return -10;
+  }
+  if (!a.cube_recs || a.plan.num_blocks <= 0)
+  {
+    mpcx_set_error("mpcx_assemble_matrix: the cluster algorithm needs records (mpcx_cube_records) and a row-block plan");
+    return -3;
+  }
+  const size_t lds = size_t(a.plan.max_nnz) * 8 + size_t(a.plan.max_rows) * 4;
+  if (lds > 160 * 1024)
+  {
+    mpcx_set_error("mpcx_assemble_matrix: row-block plan exceeds 160 KiB of LDS");
+    return -4;
+  }
+  if (int rc = check(hipFuncSetAttribute(reinterpret_cast<const void*>(matrix_cube_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)),
+                     "hipFuncSetAttribute"))
+    return rc;
+  const char* e = std::getenv("MPCX_CUBE_THREADS");
+  int threads = e ? std::atoi(e) : 256;
+  if (threads < 64 || threads > CUBE_MAX_THREADS || threads % 64)
+    threads = 256;
+  const unsigned grid = 8u * unsigned((a.plan.num_blocks + 7) / 8);
+  hipLaunchKernelGGL(matrix_cube_kernel, dim3(grid), dim3(threads), lds, static_cast<hipStream_t>(a.stream), a);
+  return check(hipGetLastError(), "matrix cluster kernel launch");
+}
+
+int launch_vector_cubes(const mpcx_vector_args_t& a)
+{
+  const mpcx_kernel_t& k = a.kernel;
+  if (k.form != MPCX_FORM_SOURCE || k.celltype != MPCX_CELL_TETRAHEDRON || k.degree != 1 || k.bs != 1
+      || k.coeff_degree != 0 || a.coeffs || a.nv != 4 || !a.cube_verts)
+  {
+    mpcx_set_error("mpcx_assemble_vector: the cluster algorithm covers the scalar P1 source form on tetrahedra "
+                   "without coefficients");
+    return -10;
+  }
+  if (a.n_cubes == 0)
+    return 0;
+  const dim3 grid(grid_for(a.n_cubes, VCUBE_THREADS));
+  hipStream_t st = static_cast<hipStream_t>(a.stream);
+  if (k.fn_id == 1)
+    hipLaunchKernelGGL(vector_cube_kernel<1>, grid, dim3(VCUBE_THREADS), 0, st, a);
+  else
+    hipLaunchKernelGGL(vector_cube_kernel<-1>, grid, dim3(VCUBE_THREADS), 0, st, a);
+  return check(hipGetLastError(), "vector cluster kernel launch");
+}
+
+} // namespace mpcx
+
+extern "C" int mpcx_cube_records(int64_t n_slots, const int32_t* block_ents, const int32_t* cube_verts,
+                                 const int8_t* bc, const int8_t* is_slave, const mpcx_nnz_t* rowptr,
+                                 const int32_t* cols, void* recs, int32_t* overflow, void* stream)
+{
+  if (n_slots == 0)
+    return 0;
+  hipLaunchKernelGGL(mpcx::cube_records_kernel, dim3(mpcx::grid_for(n_slots * 8, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), n_slots, block_ents, cube_verts, bc, is_slave, rowptr, cols,
+                     static_cast<mpcx::CubeRec*>(recs), overflow);
+  return mpcx::check(hipGetLastError(), "cube_records launch");
+}

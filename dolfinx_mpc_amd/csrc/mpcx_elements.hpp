@@ -572,6 +572,9 @@ struct ElementOp
           org[1] -= 0.5;
           org[2] -= 0.1;
         }
+        [[maybe_unused]] FmConsts FK;
+        if constexpr (FN_ == 1 && TDIM == 3)
+          FK = g_fm_consts; // uniform loads: the polynomial coefficients live in scalar registers
         double S[BS0], SX[BS0][TDIM];
 #pragma unroll
         for (int b = 0; b < BS0; ++b)
@@ -610,8 +613,8 @@ struct ElementOp
               // of its Gaussian: x - 0.9, y - 0.5, z - 0.1 come straight out of the affine map (x was
               // formed from the shifted origin above), 5 y = 5 (y - 0.5) + 2.5 is one fma
               const double t = fma(5.0, x[1], 2.5);
-              f = wq * ((x[0] + 0.9) * fast_sinpi(t)
-                        + fast_exp_nonpos(-(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]) * (1.0 / 0.02)));
+              f = wq * ((x[0] + 0.9) * fast_sinpi_k(t, FK)
+                        + fast_exp_nonpos_k(-(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]) * (1.0 / 0.02), FK));
             }
             else
               f = wq * eval_fn(FN_ >= 0 ? FN_ : k.fn_id, x, b, c);

@@ -3,3 +3,11 @@
 #include <string>
 
 void mpcx_set_error(const std::string& msg);
+
+#include "mpcx.h"
+namespace mpcx
+{
+// cluster ("Kuhn fan") kernels, mpcx_cubes.hip
+int launch_matrix_cubes(const mpcx_matrix_args_t& a);
+int launch_vector_cubes(const mpcx_vector_args_t& a);
+} // namespace mpcx

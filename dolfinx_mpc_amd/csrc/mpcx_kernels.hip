@@ -1185,7 +1185,12 @@ int launch_matrix(const mpcx_matrix_args_t& a)
   int alg = a.algorithm;
   if (alg == MPCX_ALG_AUTO)
     alg = a.plan.num_blocks > 0 ? MPCX_ALG_ROWBLOCK : MPCX_ALG_ATOMIC;
-  if (a.n_entities > 0)
+  if (alg == MPCX_ALG_CUBE)
+  {
+    if (int rc = launch_matrix_cubes(a))
+      return rc;
+  }
+  else if (a.n_entities > 0)
   {
     if (alg == MPCX_ALG_ROWBLOCK)
     {
@@ -1448,6 +1453,8 @@ extern "C" int mpcx_assemble_vector(const mpcx_vector_args_t* args)
 {
   const mpcx_vector_args_t& a = *args;
   const mpcx_kernel_t& k = a.kernel;
+  if (a.algorithm == MPCX_ALG_CUBE)
+    return launch_vector_cubes(a);
   switch (k.form)
   {
   case MPCX_FORM_SOURCE:

@@ -48,7 +48,13 @@ enum { MPCX_CELL_TRIANGLE = 1, MPCX_CELL_TETRAHEDRON = 2 };
 enum {
   MPCX_ALG_AUTO = 0,
   MPCX_ALG_ATOMIC = 1,  /* thread-per-entity, CSR binary search, device atomics */
-  MPCX_ALG_ROWBLOCK = 2 /* LDS-privatised row blocks, each value written once */
+  MPCX_ALG_ROWBLOCK = 2, /* LDS-privatised row blocks, each value written once */
+  /* row blocks fed by CELL CLUSTERS (six P1 tets round a shared edge, eight vertices: what a structured box
+   * generator emits per cube) instead of single cells: one thread sums the six element tensors in registers
+   * and scatters 46 entries instead of 96; vectors: 8 contributions instead of 24.  Scalar P1 stiffness /
+   * source forms on tetrahedra only; cells outside any cluster go through a second call with one of the
+   * per-cell algorithms.  See mpcx_cube_records. */
+  MPCX_ALG_CUBE = 3
 };
 
 /* Built-in element kernel: (form, cell, degree, block size) + quadrature table.
@@ -164,6 +170,10 @@ typedef struct
    * target: position mpc_plan_tgt[t] of vals receives the sum over k in [off[t], off[t+1]) of
    * coef[k] * Ae(entity ent[k])[pq[k] / N1][pq[k] % N1].  mpc_plan_off == NULL: the kernel walks the
    * slave entities and searches the CSR rows itself (device atomics). */
+  /* MPCX_ALG_CUBE: one 96-byte record per (row block, cluster) slot, built by mpcx_cube_records; plan carries
+   * num_blocks / max_rows / max_nnz / block_row0 / block_ent_off (slots per block), nothing else; n_entities is
+   * ignored (the slots say what is assembled) */
+  const void* cube_recs;
   int64_t mpc_plan_targets;
   const mpcx_nnz_t* mpc_plan_tgt;
   const int64_t* mpc_plan_off;
@@ -192,6 +202,15 @@ int mpcx_scatter_offsets(const mpcx_nnz_t* rowptr, const int32_t* cols, int32_t 
                          const int32_t* entities1, const int32_t* dofmap0, int32_t nd0,
                          int32_t bs0, const int32_t* dofmap1, int32_t nd1, int32_t bs1,
                          int32_t rotate, uint8_t* ent_offs, int32_t* overflow, void* stream);
+
+/* Set-up for MPCX_ALG_CUBE (all pointers DEVICE): recs[k] (96 bytes: 8 x int32 vertex id with the Dirichlet /
+ * slave mask in bit 28, then 64 x uint8 offsets [a][b] of column v[b] inside CSR row v[a] for the 46 coupled
+ * vertex pairs) for every slot k of the row-block plan built over the clusters (mpcx_rowblock_plan_build with
+ * dofmap0 = cube_verts, nd0 = 8): block_ents[k] is the cluster of slot k.  *overflow is set if an offset does
+ * not fit 8 bits or a column is missing. */
+int mpcx_cube_records(int64_t n_slots, const int32_t* block_ents, const int32_t* cube_verts, const int8_t* bc,
+                      const int8_t* is_slave, const mpcx_nnz_t* rowptr, const int32_t* cols, void* recs,
+                      int32_t* overflow, void* stream);
 
 /* vals[pos(d,d)] += diagval for d in dofs.  Replaces the slave-diagonal loop
  * of cpp/assemble_matrix.cpp:711-724 and dolfinx insert_diagonal called at
@@ -229,6 +248,11 @@ typedef struct
   const int32_t* mdofmap;        /* DEVICE [num_cells][nd]: slave flag in bit 28+k (mpcx_mask_dofmap, bc = NULL) */
   const int32_t* slave_entities; /* DEVICE entity indices whose cell holds a slave */
   int64_t n_slave_entities;
+  /* MPCX_ALG_CUBE: vertex (= dof) ids of the clusters, DEVICE [n_cubes][8], local vertex b of a cluster has
+   * bit0 = x, bit1 = y, bit2 = z of the cube corner; its six tets are (0,1,3,7) (0,1,7,5) (0,5,7,4) (0,3,2,7)
+   * (0,6,4,7) (0,2,6,7).  entities / n_entities are ignored. */
+  const int32_t* cube_verts;
+  int64_t n_cubes;
   void* stream;
 } mpcx_vector_args_t;
 

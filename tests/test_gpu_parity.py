@@ -196,7 +196,7 @@ def test_backsubstitution_homogenize(oracle):
 # ---------------------------------------------------------------------------------------------
 # kernel variants that the default configuration never reaches
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("env", ["MPCX_NO_MPC_PLAN=1", "MPCX_NO_LEAN=1", "MPCX_MPC_PLAN=host"])
+@pytest.mark.parametrize("env", ["MPCX_NO_MPC_PLAN=1", "MPCX_NO_LEAN=1", "MPCX_MPC_PLAN=host", "MPCX_NO_CUBE=1"])
 @pytest.mark.parametrize("alg", ["atomic", "rowblock"])
 @pytest.mark.parametrize("make", CASES, ids=[f"case{i}" for i in range(len(CASES))])
 def test_small_cases_kernel_variants(oracle, make, alg, env, monkeypatch):
@@ -204,7 +204,8 @@ def test_small_cases_kernel_variants(oracle, make, alg, env, monkeypatch):
     (one thread per slave entity, CSR searches, device atomics) -- the path a caller of the bare C ABI
     gets when it passes ``mpc_plan_off == NULL`` -- instead of the host-built plan.
     MPCX_NO_LEAN=1: the general row-block kernel instead of the lean P1 one.
-    MPCX_MPC_PLAN=host: the plan from the host builder mpcx_mpc_plan_build instead of the device kernel."""
+    MPCX_MPC_PLAN=host: the plan from the host builder mpcx_mpc_plan_build instead of the device kernel.
+    MPCX_NO_CUBE=1: the per-cell lean kernels where the default takes the cell-cluster kernels (MPCX_ALG_CUBE)."""
     monkeypatch.setenv(*env.split("="))
     case = make()
     if case.a is None:
@@ -368,3 +369,39 @@ def test_backsubstitution_accepts_a_function(oracle):
     assert np.all(u.x.array[mpc.slaves] == 0.0)
     with pytest.raises(TypeError):
         mpc.backsubstitution(np.zeros(case.V.num_dofs))
+
+
+@pytest.mark.parametrize("reorder", [None, (2, 2, 2)])
+def test_cluster_kernels_with_leftover_cells(oracle, reorder):
+    """MPCX_ALG_CUBE on a mesh where some groups of six cells are NOT Kuhn fans (two cells swapped, one
+    cell's vertices rotated): those cells go through the per-cell kernels, the rest through the cluster
+    kernels; matrix, vector and lifting must still match the oracle on the same (scrambled) mesh."""
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import fem
+    from dolfinx_mpc_amd.clusters import kuhn_fans
+    from dolfinx_mpc_amd.mesh import Mesh, create_unit_cube
+    from problems import Case, _walls_yz, periodic_raw
+
+    base = create_unit_cube(6, 6, 6, reorder=reorder)
+    cells = base.geometry.dofmap.copy()
+    rng = np.random.default_rng(5)
+    groups = rng.choice(cells.shape[0] // 6, size=40, replace=False)
+    for g in groups[:20]:
+        cells[[6 * g + 1, 6 * g + 4]] = cells[[6 * g + 4, 6 * g + 1]]  # order of the cells inside the group
+    for g in groups[20:]:
+        cells[6 * g + 2] = cells[6 * g + 2][[1, 2, 0, 3]]  # an even permutation of one cell's vertices
+    mesh = Mesh(base.geometry.x, cells, "tetrahedron")
+    mesh.node_tile_offsets = base.node_tile_offsets
+    verts, left = kuhn_fans(cells, cells.shape[0])
+    assert left.size == 6 * 40 and verts.shape[0] == cells.shape[0] // 6 - 40
+    V = fem.functionspace(mesh, ("Lagrange", 1))
+    bc = fem.dirichletbc(0.4, fem.locate_dofs_geometrical(V, _walls_yz), V)
+    case = Case("cluster_leftover", V, fem.form_stiffness(V, constant=1.7), fem.form_source(V, fem.FN_BENCH_PERIODIC), [bc],
+                periodic_raw(V, [bc]))
+    ref = oracle_outputs(oracle, case)
+    out = product_outputs(case, algorithm="rowblock")
+    assert np.array_equal(out["A"].indptr, ref["A"].indptr) and np.array_equal(out["A"].indices, ref["A"].indices)
+    _close(out["A"].data, ref["A"].data, RTOL_A, "A (clusters + leftover cells)")
+    out_v = product_outputs(case, algorithm=None)  # vector: "auto" takes the cluster kernel for this form
+    _close(out_v["b"], ref["b"], RTOL_B, "b (clusters + leftover cells)")
+    _close(out_v["b_lifted"], ref["b_lifted"], RTOL_B, "b_lifted")
