@@ -242,6 +242,32 @@ __global__ void __launch_bounds__(64) matrix_mpc_kernel(mpcx_matrix_args_t a)
 // (re-tabulating the tuple's entity) and adds the sum with one plain read-modify-write -- no device
 // atomics (4.7 M of them at config 2 took 0.2 ms) and no CSR searches.
 template <class Op>
+__global__ void __launch_bounds__(64) matrix_mpc_plan_small_kernel(mpcx_matrix_args_t a)
+{
+  // small element tensors (P1 scalar: 16 entries): every tuple simply tabulates its entity; the tuples of a
+  // thread are independent, so their load chains overlap
+  constexpr int NV = Op::NV, N1 = Op::N1;
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= a.mpc_plan_targets)
+    return;
+  double sum = 0.0;
+  for (int64_t k = a.mpc_plan_off[t]; k < a.mpc_plan_off[t + 1]; ++k)
+  {
+    const int64_t e = a.mpc_plan_ent[k];
+    const int64_t l = e * a.estride;
+    const int64_t cell = (a.entities ? a.entities[l] : e);
+    const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
+    double cd[NV * 3];
+    gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
+    double Ae[Op::SIZE];
+    Op::tabulate(Ae, a.coeffs ? a.coeffs + e * a.cstride : nullptr, a.constants, cd, lf, a.kernel);
+    const int pq = a.mpc_plan_pq[k];
+    sum += a.mpc_plan_coef[k] * Op::get(Ae, pq / N1, pq % N1);
+  }
+  a.vals[a.mpc_plan_tgt[t]] += sum;
+}
+
+template <class Op>
 __global__ void __launch_bounds__(64) matrix_mpc_plan_kernel(mpcx_matrix_args_t a)
 {
   constexpr int NV = Op::NV, N1 = Op::N1, BS0 = Op::BS0, BS1 = Op::BS1;
@@ -1287,7 +1313,13 @@ int launch_matrix(const mpcx_matrix_args_t& a)
     if (a.mpc_plan_off)
     {
       if (a.mpc_plan_targets > 0)
-        hipLaunchKernelGGL(matrix_mpc_plan_kernel<Op>, dim3(grid_for(a.mpc_plan_targets, 64)), dim3(64), 0, stream, a);
+      {
+        static const bool force_big = std::getenv("MPCX_PLAN_KERNEL_BIG") != nullptr;
+        if (Op::SIZE <= 36 && !force_big)
+          hipLaunchKernelGGL(matrix_mpc_plan_small_kernel<Op>, dim3(grid_for(a.mpc_plan_targets, 64)), dim3(64), 0, stream, a);
+        else
+          hipLaunchKernelGGL(matrix_mpc_plan_kernel<Op>, dim3(grid_for(a.mpc_plan_targets, 64)), dim3(64), 0, stream, a);
+      }
     }
     else
       hipLaunchKernelGGL(matrix_mpc_kernel<Op>, dim3(grid_for(a.n_slave_entities, 64)), dim3(64), 0, stream, a);
