@@ -373,8 +373,8 @@ def main():
     torch.cuda.synchronize()
     t_first = time.time() - t
     t_setup = time.time() - t_setup
-    plan_bytes = sum(p[1][2]["bytes"] for A in mats.values() for k, od in A._plans.items() if k == ("objcache", "rowblock")
-                     for p in od.values())
+    plan_bytes = sum(p[1][2]["bytes"] for A in mats.values() for k, od in A._plans.items()
+                     if k in (("objcache", "rowblock"), ("objcache", "cubes")) for p in od.values())
     log(f"first step incl. plan build + uploads: {t_first:.1f}s; set-up total {t_setup:.1f}s; row-block plans {plan_bytes / 1e9:.2f} GB")
     if child:
         for _ in range(2):

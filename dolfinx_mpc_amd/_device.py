@@ -17,6 +17,26 @@ def _to_dev(a: np.ndarray, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
+def _timed_build(kind, build):
+    """MPCX_TIMING=1: print what every one-off builder (plans, masks, device mirrors) costs"""
+    import os
+    import sys
+    import time
+
+    if not os.environ.get("MPCX_TIMING"):
+        return build()
+    import torch
+
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    val = build()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    print(f"[mpcx timing] {kind}: {time.perf_counter() - t0:.3f}s", file=sys.stderr, flush=True)
+    return val
+
+
 def cached(store: dict, kind: str, objs, extra, build, maxsize: int = 8):
     """Small LRU cache inside ``store`` (the ``_device`` / ``_cache`` / ``_plans`` dict of the object
     that owns the derived data), keyed by the IDENTITY of ``objs`` plus the hashable ``extra``.
@@ -30,7 +50,7 @@ def cached(store: dict, kind: str, objs, extra, build, maxsize: int = 8):
     if hit is not None and all(a is b for a, b in zip(hit[0], objs)):
         od.move_to_end(key)
         return hit[1]
-    val = build()
+    val = _timed_build(kind, build)
     od[key] = (objs, val)
     while len(od) > maxsize:
         od.popitem(last=False)
@@ -73,8 +93,12 @@ def integral_device(form: Form, i: int):
     integ: Integral = form.integrals[i]
     if key not in form._device:
         k = integ.kernel
+        # cell integral over cells 0..n-1 in order: the kernels skip the indirection (and nothing is uploaded)
+        n = integ.entities.shape[0]
+        ident = integ.itype == "cell" and n > 0 and int(integ.entities[0]) == 0 and int(integ.entities[-1]) == n - 1 and \
+            bool(np.array_equal(integ.entities, np.arange(n, dtype=integ.entities.dtype)))
         d = {
-            "entities": _to_dev(integ.entities.astype(np.int32).reshape(-1), dev),
+            "entities": None if ident else _to_dev(integ.entities.astype(np.int32).reshape(-1), dev),
             "coeffs": None,
             "coeff_version": ("never",),
             "constants": None,
@@ -84,9 +108,6 @@ def integral_device(form: Form, i: int):
             "fqpts": _to_dev(k.fqpts.astype(np.float64).reshape(-1), dev),
             "fqwts": _to_dev(k.fqwts.astype(np.float64), dev),
         }
-        # cell integral over cells 0..n-1 in order: the kernels skip the indirection
-        ident = integ.itype == "cell" and integ.entities.size > 0 and int(integ.entities[0]) == 0 and \
-            int(integ.entities[-1]) == integ.entities.size - 1 and bool(np.all(np.diff(integ.entities) == 1))
         d["entities_ptr"] = None if ident else d["entities"].data_ptr()
         d["kernel"] = _native.KernelT(
             k.form, k.celltype, k.degree, k.bs, k.degree1 or k.degree, k.bs1 or k.bs, k.fn_id, k.coeff_degree,

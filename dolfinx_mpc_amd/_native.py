@@ -173,6 +173,8 @@ EXPORTS = [
     "mpcx_mask_dofmap",
     "mpcx_scatter_offsets",
     "mpcx_cube_records",
+    "mpcx_cube_detect",
+    "mpcx_rowblock_pairs_device",
     "mpcx_add_diagonal",
     "mpcx_assemble_vector",
     "mpcx_apply_lifting",
@@ -273,6 +275,10 @@ def lib() -> C.CDLL:
     L.mpcx_scatter_offsets.restype = C.c_int
     L.mpcx_cube_records.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.mpcx_cube_records.restype = C.c_int
+    L.mpcx_cube_detect.argtypes = [vp, i64, vp, vp, vp]
+    L.mpcx_cube_detect.restype = C.c_int
+    L.mpcx_rowblock_pairs_device.argtypes = [i64, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+    L.mpcx_rowblock_pairs_device.restype = C.c_int
     L.mpcx_rowblock_plan_build.argtypes = [i32, vp, i32, i32, i64, i32, vp, vp, i32, i32, vp, i32, i32]
     L.mpcx_rowblock_plan_build.restype = vp
     L.mpcx_rowblock_plan_num_blocks.argtypes = [vp]

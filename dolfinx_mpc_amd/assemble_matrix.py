@@ -158,13 +158,69 @@ def create_matrix(form: Form, mpc0: MultiPointConstraint, mpc1: Optional[MultiPo
 def _slave_entities(form: Form, i: int, mpc0, mpc1):
     """entity indices of integral i whose cell holds a slave of mpc0 or mpc1."""
     def build():
-        cells = form.integrals[i].cells
-        n0 = np.diff(mpc0.cell_to_slaves.offsets)[cells]
-        n1 = np.diff(mpc1.cell_to_slaves.offsets)[cells]
-        idx = np.flatnonzero((n0 > 0) | (n1 > 0)).astype(np.int32)
+        integ = form.integrals[i]
+        cells = integ.cells
+        # cells 0..n-1 in order (the usual domain): no gather through the entity list
+        ident = D.integral_device(form, i)["entities_ptr"] is None
+        has = np.diff(mpc0.cell_to_slaves.offsets) > 0
+        if mpc1 is not mpc0:
+            has = has | (np.diff(mpc1.cell_to_slaves.offsets) > 0)
+        has = has[: integ.num_entities] if ident else has[cells]
+        idx = np.flatnonzero(has).astype(np.int32)
         return (idx, D._to_dev(idx, _native.require_gpu()))
 
     return D.cached(form._device, "slave_ents", (mpc0, mpc1), i, build)
+
+
+def _block_ranges(nrows: int, rowptr: np.ndarray, max_rows: int, max_nnz: int, bs: int, hints) -> np.ndarray:
+    """contiguous row ranges of a row-block plan (host: one greedy pass over rowptr), block_row0 [nb + 1]"""
+    L = _native.lib()
+    p = _native._ptr
+    h = L.mpcx_rowblock_plan_build(nrows, p(rowptr), max_rows, max_nnz, 0, 1, None, None, 1, bs,
+                                   None if hints is None else p(hints), 0 if hints is None else hints.size, 1)
+    if not h:
+        raise RuntimeError("mpcx_rowblock_plan_build failed: " + L.mpcx_last_error().decode())
+    try:
+        nb = L.mpcx_rowblock_plan_num_blocks(h)
+        row0 = np.empty(nb + 1, dtype=np.int32)
+        off = np.empty(nb + 1, dtype=np.int64)
+        L.mpcx_rowblock_plan_copy(h, p(row0), p(off), None)
+    finally:
+        L.mpcx_rowblock_plan_free(h)
+    return row0
+
+
+def _block_lists_device(row0: np.ndarray, n_entities: int, estride: int, entities_ptr, dofmap_dev, nd: int, bs: int, dev):
+    """entities touching every row block, built on the device (mpcx_rowblock_pairs_device: count -> scan -> fill
+    in entity order, then a stable sort by block: torch, plumbing).  Returns (block_row0, block_ent_off, block_ents)
+    device tensors; the lists are ordered by entity inside each block, like the host builder's."""
+    import torch
+
+    L = _native.lib()
+    st = D.stream_ptr()
+    nb = row0.size - 1
+    d_row0 = D._to_dev(row0, dev)
+    counts = torch.empty(max(n_entities, 1), dtype=torch.int32, device=dev)
+    args = (n_entities, estride, entities_ptr, dofmap_dev.data_ptr(), nd, bs, nb, d_row0.data_ptr(), counts.data_ptr())
+    _native.check(L.mpcx_rowblock_pairs_device(*args, None, None, None, st), "mpcx_rowblock_pairs_device")
+    c64 = counts[:n_entities].to(torch.int64)
+    offsets = torch.cumsum(c64, 0) - c64
+    total = int(c64.sum().item()) if n_entities else 0
+    pair_block = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+    pair_ent = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+    if total:
+        _native.check(L.mpcx_rowblock_pairs_device(*args, offsets.data_ptr(), pair_block.data_ptr(), pair_ent.data_ptr(), st),
+                      "mpcx_rowblock_pairs_device")
+    pair_block, pair_ent = pair_block[:total], pair_ent[:total]
+    per_block = torch.bincount(pair_block, minlength=nb) if total else torch.zeros(nb, dtype=torch.int64, device=dev)
+    off = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(per_block, 0, out=off[1:])
+    if total:
+        _, order = torch.sort(pair_block, stable=True)
+        ents = pair_ent[order].contiguous()
+    else:
+        ents = pair_ent
+    return d_row0, off, ents
 
 
 def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False):
@@ -175,26 +231,33 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False):
         L = _native.lib()
         p = _native._ptr
         integ = form.integrals[i]
-        ents = np.ascontiguousarray(integ.entities.astype(np.int32).reshape(-1))
         dm = V0.dofmap.list
         # numbering hint: first row of every tile of a tiled P1 numbering
         hints = None
         if V0.dof_tile_offsets is not None:
             hints = np.ascontiguousarray(V0.dof_tile_offsets.astype(np.int32) * V0.dofmap.bs)
-        h = L.mpcx_rowblock_plan_build(A.shape[0], p(A.rowptr), max_rows_cap, max_nnz_cap,
-                                       integ.num_entities, integ.estride, p(ents), p(dm), dm.shape[1], V0.dofmap.bs,
-                                       None if hints is None else p(hints), 0 if hints is None else hints.size, 1)
-        if not h:
-            raise RuntimeError("mpcx_rowblock_plan_build failed: " + L.mpcx_last_error().decode())
-        try:
-            nb = L.mpcx_rowblock_plan_num_blocks(h)
-            row0 = np.empty(nb + 1, dtype=np.int32)
-            off = np.empty(nb + 1, dtype=np.int64)
-            ents_b = np.empty(L.mpcx_rowblock_plan_num_ents(h), dtype=np.int32)
-            L.mpcx_rowblock_plan_copy(h, p(row0), p(off), p(ents_b))
-        finally:
-            L.mpcx_rowblock_plan_free(h)
         dev = A.device
+        if os.environ.get("MPCX_PLAN_LISTS", "device") == "host":
+            ents = np.ascontiguousarray(integ.entities.astype(np.int32).reshape(-1))
+            h = L.mpcx_rowblock_plan_build(A.shape[0], p(A.rowptr), max_rows_cap, max_nnz_cap,
+                                           integ.num_entities, integ.estride, p(ents), p(dm), dm.shape[1], V0.dofmap.bs,
+                                           None if hints is None else p(hints), 0 if hints is None else hints.size, 1)
+            if not h:
+                raise RuntimeError("mpcx_rowblock_plan_build failed: " + L.mpcx_last_error().decode())
+            try:
+                nb = L.mpcx_rowblock_plan_num_blocks(h)
+                row0 = np.empty(nb + 1, dtype=np.int32)
+                off = np.empty(nb + 1, dtype=np.int64)
+                ents_b = np.empty(L.mpcx_rowblock_plan_num_ents(h), dtype=np.int32)
+                L.mpcx_rowblock_plan_copy(h, p(row0), p(off), p(ents_b))
+            finally:
+                L.mpcx_rowblock_plan_free(h)
+            lists = (D._to_dev(row0, dev), D._to_dev(off, dev), D._to_dev(ents_b, dev))
+        else:
+            row0 = _block_ranges(A.shape[0], A.rowptr, max_rows_cap, max_nnz_cap, V0.dofmap.bs, hints)
+            nb = row0.size - 1
+            lists = _block_lists_device(row0, integ.num_entities, integ.estride, D.integral_device(form, i)["entities_ptr"],
+                                        D.space_device(V0)["dofmap"], V0.element_ndofs, V0.dofmap.bs, dev)
         # 8-bit scatter offsets of every (entity, local row, local col), built on the device
         import torch
 
@@ -204,7 +267,7 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False):
         offs = torch.empty(integ.num_entities * V0.element_ndofs * V1.element_ndofs, dtype=torch.uint8, device=dev)
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         rc = L.mpcx_scatter_offsets(A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), integ.estride, integ.num_entities,
-                                    idv["entities"].data_ptr(), idv["entities"].data_ptr(), s0["dofmap"].data_ptr(),
+                                    idv["entities_ptr"], idv["entities_ptr"], s0["dofmap"].data_ptr(),
                                     V0.element_ndofs, V0.dofmap.bs, s1["dofmap"].data_ptr(), V1.element_ndofs,
                                     V1.dofmap.bs, int(lean), offs.data_ptr(), flag.data_ptr(), D.stream_ptr())
         _native.check(rc, "mpcx_scatter_offsets")
@@ -224,12 +287,12 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False):
             if npat > 0:
                 offs = D._to_dev(table[: npat * noff].copy(), dev)
                 pattern = D._to_dev(ids.view(np.int16), dev)  # torch has no uint16 on every build: same bits
-        t = (D._to_dev(row0, dev), D._to_dev(off, dev), D._to_dev(ents_b, dev), offs, pattern)
+        t = lists + (offs, pattern)
         max_rows = int(np.diff(row0).max())
         max_nnz = int(np.diff(A.rowptr[row0]).max())
         s = _native.RowBlockPlanT(nb, max_rows, max_nnz, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
                                   t[3].data_ptr(), D.ptr(pattern))
-        return (s, t, {"num_blocks": nb, "num_ents": int(ents_b.size), "max_rows": max_rows,
+        return (s, t, {"num_blocks": nb, "num_ents": int(t[2].numel()), "max_rows": max_rows,
                        "max_nnz": max_nnz, "offset_patterns": npat,
                        "bytes": int(sum(x.numel() * x.element_size() for x in t if x is not None))})
 
@@ -251,49 +314,37 @@ def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc):
     (plan struct, records tensor, keep-alive, info, leftover cells) or None when the mesh has no clusters."""
     import torch
 
-    from .clusters import mesh_clusters
+    from .clusters import mesh_clusters_device
 
     integ = form.integrals[i]
-    verts, left = mesh_clusters(form.mesh, integ.num_entities)
-    if verts.shape[0] == 0 or verts.shape[0] * 6 < 0.5 * integ.num_entities:
+    d_verts, left = mesh_clusters_device(form.mesh, integ.num_entities)
+    if d_verts.shape[0] == 0 or d_verts.shape[0] * 6 < 0.5 * integ.num_entities:
         return None
 
     def build():
         L = _native.lib()
-        p = _native._ptr
         dev = A.device
-        nc = verts.shape[0]
-        ents = np.arange(nc, dtype=np.int32)
+        nc = d_verts.shape[0]
         hints = None
         if V0.dof_tile_offsets is not None:
             hints = np.ascontiguousarray(V0.dof_tile_offsets.astype(np.int32))
-        h = L.mpcx_rowblock_plan_build(A.shape[0], p(A.rowptr), CUBE_MAX_ROWS, CUBE_MAX_NNZ, nc, 1, p(ents), p(verts), 8, 1,
-                                       None if hints is None else p(hints), 0 if hints is None else hints.size, 1)
-        if not h:
-            raise RuntimeError("mpcx_rowblock_plan_build failed: " + L.mpcx_last_error().decode())
-        try:
-            nb = L.mpcx_rowblock_plan_num_blocks(h)
-            row0 = np.empty(nb + 1, dtype=np.int32)
-            off = np.empty(nb + 1, dtype=np.int64)
-            ents_b = np.empty(L.mpcx_rowblock_plan_num_ents(h), dtype=np.int32)
-            L.mpcx_rowblock_plan_copy(h, p(row0), p(off), p(ents_b))
-        finally:
-            L.mpcx_rowblock_plan_free(h)
-        d_verts = D._to_dev(verts, dev)
-        d_ents = D._to_dev(ents_b, dev)
-        recs = torch.empty(ents_b.size * 96, dtype=torch.uint8, device=dev)
+        row0 = _block_ranges(A.shape[0], A.rowptr, CUBE_MAX_ROWS, CUBE_MAX_NNZ, 1, hints)
+        nb = row0.size - 1
+        d_row0, d_off, d_ents = _block_lists_device(row0, nc, 1, None, d_verts, 8, 1, dev)
+        nslots = d_ents.numel()
+        recs = torch.empty(nslots * 96, dtype=torch.uint8, device=dev)
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         _, t = mpc._device()
-        rc = L.mpcx_cube_records(ents_b.size, d_ents.data_ptr(), d_verts.data_ptr(), D.ptr(bc_dev), t["is_slave"].data_ptr(),
+        rc = L.mpcx_cube_records(nslots, d_ents.data_ptr(), d_verts.data_ptr(), D.ptr(bc_dev), t["is_slave"].data_ptr(),
                                  A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), recs.data_ptr(), flag.data_ptr(), D.stream_ptr())
         _native.check(rc, "mpcx_cube_records")
         if int(flag.item()) != 0:
             raise RuntimeError("cluster algorithm: a scatter offset does not fit 8 bits (or a column is missing)")
-        keep = (D._to_dev(row0, dev), D._to_dev(off, dev), recs)
+        keep = (d_row0, d_off, recs)
         max_rows = int(np.diff(row0).max())
         max_nnz = int(np.diff(A.rowptr[row0]).max())
         plan = _native.RowBlockPlanT(nb, max_rows, max_nnz, keep[0].data_ptr(), keep[1].data_ptr(), None, None, None)
-        info = {"num_blocks": nb, "num_ents": int(ents_b.size), "max_rows": max_rows, "max_nnz": max_nnz,
+        info = {"num_blocks": nb, "num_ents": int(nslots), "max_rows": max_rows, "max_nnz": max_nnz,
                 "clusters": int(nc), "bytes": int(sum(x.numel() * x.element_size() for x in keep))}
         return (plan, keep, info)
 

@@ -26,31 +26,19 @@ def _vector_plan(form: Form, i: int, V):
     one-entry-per-row pattern), cached per integral."""
     key = ("vplan", i, VECTOR_BLOCK_ROWS)
     if key not in form._device:
-        L = _native.lib()
-        p = _native._ptr
+        from .assemble_matrix import _block_lists_device, _block_ranges
+
         integ = form.integrals[i]
-        ents = np.ascontiguousarray(integ.entities.astype(np.int32).reshape(-1))
-        dm = V.dofmap.list
         nrows = V.num_dofs
         rowptr = np.arange(nrows + 1, dtype=np.int64)
         hints = None
         if V.dof_tile_offsets is not None:
             hints = np.ascontiguousarray(V.dof_tile_offsets.astype(np.int32) * V.dofmap.bs)
-        h = L.mpcx_rowblock_plan_build(nrows, p(rowptr), VECTOR_BLOCK_ROWS, VECTOR_BLOCK_ROWS, integ.num_entities,
-                                       integ.estride, p(ents), p(dm), dm.shape[1], V.dofmap.bs,
-                                       None if hints is None else p(hints), 0 if hints is None else hints.size, 1)
-        if not h:
-            raise RuntimeError("mpcx_rowblock_plan_build failed: " + L.mpcx_last_error().decode())
-        try:
-            nb = L.mpcx_rowblock_plan_num_blocks(h)
-            row0 = np.empty(nb + 1, dtype=np.int32)
-            off = np.empty(nb + 1, dtype=np.int64)
-            ents_b = np.empty(L.mpcx_rowblock_plan_num_ents(h), dtype=np.int32)
-            L.mpcx_rowblock_plan_copy(h, p(row0), p(off), p(ents_b))
-        finally:
-            L.mpcx_rowblock_plan_free(h)
+        row0 = _block_ranges(nrows, rowptr, VECTOR_BLOCK_ROWS, VECTOR_BLOCK_ROWS, V.dofmap.bs, hints)
+        nb = row0.size - 1
         dev = _native.require_gpu()
-        t = (D._to_dev(row0, dev), D._to_dev(off, dev), D._to_dev(ents_b, dev))
+        t = _block_lists_device(row0, integ.num_entities, integ.estride, D.integral_device(form, i)["entities_ptr"],
+                                D.space_device(V)["dofmap"], V.element_ndofs, V.dofmap.bs, dev)
         max_rows = int(np.diff(row0).max()) if nb > 0 else 0
         plan = _native.RowBlockPlanT(nb, max_rows, max_rows, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
                                      None, None)
@@ -85,14 +73,12 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
             and k.degree == 1 and k.bs == 1 and k.coeff_degree == 0 and integ.coefficient is None and integ.itype == "cell"
             and idv["entities_ptr"] is None and sd["dofmap"] is md["x_dofmap"]):
         # scalar P1 source over all cells: one thread per cell cluster (MPCX_ALG_CUBE, csrc/mpcx_cubes.hip)
-        from .clusters import mesh_clusters
+        from .clusters import mesh_clusters_device
 
-        verts, left = mesh_clusters(form.mesh, integ.num_entities)
-        if verts.shape[0] * 6 >= 0.5 * integ.num_entities:
-            d_verts = D.cached(form.mesh._device, "cube_verts_dev", (), (str(b.array.device), integ.num_entities),
-                               lambda: D._to_dev(verts, b.array.device))
+        d_verts, left = mesh_clusters_device(form.mesh, integ.num_entities)
+        if d_verts.shape[0] * 6 >= 0.5 * integ.num_entities:
             a.algorithm = 3
-            a.cube_verts, a.n_cubes = d_verts.data_ptr(), verts.shape[0]
+            a.cube_verts, a.n_cubes = d_verts.data_ptr(), d_verts.shape[0]
             a.leftover = left if left.size else None
             a.stream = D.stream_ptr()
             keep += [d_verts]

@@ -45,3 +45,30 @@ def mesh_clusters(mesh, ncells: int):
     if key not in mesh._device:
         mesh._device[key] = kuhn_fans(mesh.geometry.dofmap, int(ncells))
     return mesh._device[key]
+
+
+def mesh_clusters_device(mesh, ncells: int):
+    """(cube_verts device tensor (n, 8) int32, leftover cells (host int32, possibly empty)) -- detection by the HIP
+    kernel ``cube_detect_kernel`` on the device-resident geometry dofmap; only when some group is not a fan does
+    the (slower) host path run to compact the clusters and list the leftovers.  Cached per (mesh, ncells)."""
+    import torch
+
+    from . import _device as D
+    from . import _native
+
+    def build():
+        dm = D.mesh_device(mesh)["x_dofmap"]
+        dev = dm.device
+        ng = int(ncells) // 6
+        if dm.shape[1] != 4 or ng == 0:
+            return torch.zeros((0, 8), dtype=torch.int32, device=dev), np.arange(ncells, dtype=np.int32)
+        verts = torch.empty((ng, 8), dtype=torch.int32, device=dev)
+        ok = torch.empty(ng, dtype=torch.int8, device=dev)
+        _native.check(_native.lib().mpcx_cube_detect(dm.data_ptr(), ng, verts.data_ptr(), ok.data_ptr(), D.stream_ptr()),
+                      "mpcx_cube_detect")
+        if int(ok.sum(dtype=torch.int64).item()) == ng and ncells % 6 == 0:
+            return verts, np.zeros(0, dtype=np.int32)
+        v, left = kuhn_fans(mesh.geometry.dofmap, int(ncells))
+        return D._to_dev(v, dev), left
+
+    return D.cached(mesh._device, "kuhn_fans_dev", (), int(ncells), build)

@@ -105,6 +105,88 @@ __device__ inline int64_t find_col(const int32_t* __restrict__ cols, int64_t lo,
   return (lo < end && cols[lo] == col) ? lo : -1;
 }
 
+// set-up: does the group of six consecutive cells g form a fan?  verts[g] = its eight vertices, ok[g] = 1 / 0
+__global__ void cube_detect_kernel(const int32_t* __restrict__ cells, int64_t n_groups, int32_t* __restrict__ verts,
+                                   int8_t* __restrict__ ok)
+{
+  const int64_t g = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= n_groups)
+    return;
+  int32_t c[6][4];
+  const uint4* p = reinterpret_cast<const uint4*>(cells + g * 24);
+#pragma unroll
+  for (int t = 0; t < 6; ++t)
+  {
+    const uint4 w = p[t];
+    c[t][0] = w.x, c[t][1] = w.y, c[t][2] = w.z, c[t][3] = w.w;
+  }
+  // vertex b of the fan read from the first tet that introduces it; every other occurrence must agree
+  int32_t v[8];
+  v[0] = c[0][0], v[1] = c[0][1], v[3] = c[0][2], v[7] = c[0][3];
+  v[5] = c[1][3], v[4] = c[2][3], v[2] = c[3][2], v[6] = c[4][1];
+  bool good = true;
+#pragma unroll
+  for (int t = 0; t < 6; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      good &= c[t][i] == v[fan_vertex(t, i)];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = a + 1; b < 8; ++b)
+      good &= v[a] != v[b];
+  uint4* q = reinterpret_cast<uint4*>(verts + g * 8);
+  q[0] = make_uint4(v[0], v[1], v[2], v[3]);
+  q[1] = make_uint4(v[4], v[5], v[6], v[7]);
+  ok[g] = good ? 1 : 0;
+}
+
+// set-up: (row block, entity) pairs of the row-block plan, in entity order (the caller sorts them by block):
+// entity e belongs to every block that holds one of its nd dofs.  counts / offsets protocol as mpcx_mpc_plan_device.
+template <bool FILL>
+__global__ void rowblock_pairs_kernel(int64_t n_entities, int estride, const int32_t* __restrict__ entities0,
+                                      const int32_t* __restrict__ dofmap0, int nd0, int bs0, int num_blocks,
+                                      const int32_t* __restrict__ block_row0, int32_t* __restrict__ counts,
+                                      const int64_t* __restrict__ offsets, int32_t* __restrict__ pair_block,
+                                      int32_t* __restrict__ pair_ent)
+{
+  const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= n_entities)
+    return;
+  const int64_t cell = entities0 ? entities0[e * estride] : e;
+  int32_t seen[32];
+  int ns = 0;
+  for (int i = 0; i < nd0 && i < 32; ++i)
+  {
+    const int32_t row = dofmap0[cell * nd0 + i] * bs0;
+    int lo = 0, hi = num_blocks; // last block with block_row0[b] <= row
+    while (hi - lo > 1)
+    {
+      const int mid = (lo + hi) >> 1;
+      if (block_row0[mid] <= row)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    bool dup = false;
+    for (int k = 0; k < ns; ++k)
+      dup |= seen[k] == lo;
+    if (!dup)
+      seen[ns++] = lo;
+  }
+  if constexpr (!FILL)
+    counts[e] = ns;
+  else
+  {
+    const int64_t base = offsets[e];
+    for (int k = 0; k < ns; ++k)
+    {
+      pair_block[base + k] = seen[k];
+      pair_ent[base + k] = int32_t(e);
+    }
+  }
+}
+
 // set-up: one record per (row block, cluster touching it) slot k
 __global__ void cube_records_kernel(int64_t n_slots, const int32_t* __restrict__ block_ents,
                                     const int32_t* __restrict__ cube_verts, const int8_t* __restrict__ bc,
@@ -447,6 +529,38 @@ int launch_vector_cubes(const mpcx_vector_args_t& a)
 }
 
 } // namespace mpcx
+
+extern "C" int mpcx_cube_detect(const int32_t* cells, int64_t n_groups, int32_t* verts, int8_t* ok, void* stream)
+{
+  if (n_groups == 0)
+    return 0;
+  hipLaunchKernelGGL(mpcx::cube_detect_kernel, dim3(mpcx::grid_for(n_groups, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), cells, n_groups, verts, ok);
+  return mpcx::check(hipGetLastError(), "cube_detect launch");
+}
+
+extern "C" int mpcx_rowblock_pairs_device(int64_t n_entities, int32_t estride, const int32_t* entities0,
+                                          const int32_t* dofmap0, int32_t nd0, int32_t bs0, int32_t num_blocks,
+                                          const int32_t* block_row0, int32_t* counts, const int64_t* offsets,
+                                          int32_t* pair_block, int32_t* pair_ent, void* stream)
+{
+  if (n_entities == 0)
+    return 0;
+  if (nd0 > 32)
+  {
+    mpcx_set_error("mpcx_rowblock_pairs_device: more than 32 dofs per entity");
+    return -7;
+  }
+  const dim3 grid(mpcx::grid_for(n_entities, 256));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!offsets)
+    hipLaunchKernelGGL(mpcx::rowblock_pairs_kernel<false>, grid, dim3(256), 0, st, n_entities, estride, entities0, dofmap0,
+                       nd0, bs0, num_blocks, block_row0, counts, offsets, pair_block, pair_ent);
+  else
+    hipLaunchKernelGGL(mpcx::rowblock_pairs_kernel<true>, grid, dim3(256), 0, st, n_entities, estride, entities0, dofmap0,
+                       nd0, bs0, num_blocks, block_row0, counts, offsets, pair_block, pair_ent);
+  return mpcx::check(hipGetLastError(), "rowblock_pairs launch");
+}
 
 extern "C" int mpcx_cube_records(int64_t n_slots, const int32_t* block_ents, const int32_t* cube_verts,
                                  const int8_t* bc, const int8_t* is_slave, const mpcx_nnz_t* rowptr,

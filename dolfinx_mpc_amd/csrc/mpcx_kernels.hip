@@ -677,7 +677,7 @@ __global__ void scatter_offsets_kernel(const mpcx_nnz_t* __restrict__ rowptr, co
     return;
   const int64_t e = t / nd0;
   const int i = int(t - e * nd0);
-  const int64_t cell0 = entities0[e * estride], cell1 = entities1[e * estride];
+  const int64_t cell0 = entities0 ? entities0[e * estride] : e, cell1 = entities1 ? entities1[e * estride] : e;
   const int r = dofmap0[cell0 * nd0 + (rotate ? rotated_local(i, cell0, nd0) : i)] * bs0;
   const int64_t lo = rowptr[r], hi = rowptr[r + 1];
   for (int j = 0; j < nd1; ++j)

@@ -196,7 +196,8 @@ int mpcx_mask_dofmap(const int32_t* dofmap, int64_t num_cells, int32_t nd, int32
  * mpcx_rowblock_plan_t::ent_offs.  All pointers DEVICE.  *overflow (DEVICE int32,
  * zeroed by the caller) is set non-zero if an offset does not fit in 8 bits or
  * a column is missing from the pattern.  rotate != 0: local rows and columns of the cell c an
- * entity lies in are listed in the rotated order of mpcx_mask_dofmap. */
+ * entity lies in are listed in the rotated order of mpcx_mask_dofmap.  entities0 / entities1 == NULL:
+ * entity e is cell e. */
 int mpcx_scatter_offsets(const mpcx_nnz_t* rowptr, const int32_t* cols, int32_t estride,
                          int64_t n_entities, const int32_t* entities0,
                          const int32_t* entities1, const int32_t* dofmap0, int32_t nd0,
@@ -211,6 +212,18 @@ int mpcx_scatter_offsets(const mpcx_nnz_t* rowptr, const int32_t* cols, int32_t 
 int mpcx_cube_records(int64_t n_slots, const int32_t* block_ents, const int32_t* cube_verts, const int8_t* bc,
                       const int8_t* is_slave, const mpcx_nnz_t* rowptr, const int32_t* cols, void* recs,
                       int32_t* overflow, void* stream);
+
+/* Set-up for MPCX_ALG_CUBE (DEVICE): for every group g of six consecutive cells (x_dofmap rows 6g .. 6g+5)
+ * verts[g][0..7] = the eight vertices read off the fan pattern, ok[g] = 1 if the six cells really form it. */
+int mpcx_cube_detect(const int32_t* cells, int64_t n_groups, int32_t* verts, int8_t* ok, void* stream);
+
+/* The entity lists of a row-block plan on the DEVICE (host version: second half of mpcx_rowblock_plan_build):
+ * (block, entity) pairs in entity order; two calls like mpcx_mpc_plan_device (offsets == NULL: counts[e] =
+ * number of distinct blocks entity e touches; then with the exclusive scan of counts: the pairs).  The caller
+ * sorts the pairs by block (stable) to get block_ents / block_ent_off.  block_row0 [num_blocks + 1] DEVICE. */
+int mpcx_rowblock_pairs_device(int64_t n_entities, int32_t estride, const int32_t* entities0, const int32_t* dofmap0,
+                               int32_t nd0, int32_t bs0, int32_t num_blocks, const int32_t* block_row0, int32_t* counts,
+                               const int64_t* offsets, int32_t* pair_block, int32_t* pair_ent, void* stream);
 
 /* vals[pos(d,d)] += diagval for d in dofs.  Replaces the slave-diagonal loop
  * of cpp/assemble_matrix.cpp:711-724 and dolfinx insert_diagonal called at
@@ -360,6 +373,8 @@ int mpcx_pattern_device_rows(int32_t num_blocks0, const int64_t* adj_off, const 
  * test-space cell has a dof in it.  `row_hints` (sorted row indices, may be
  * NULL) are preferred cut positions, e.g. the first row of each numbering tile.
  * Returns an opaque handle. */
+/* n_entities == 0: only the row ranges are computed (the entity lists then come from
+ * mpcx_rowblock_pairs_device). */
 void* mpcx_rowblock_plan_build(int32_t nrows, const mpcx_nnz_t* rowptr, int32_t max_rows,
                                int32_t max_nnz, int64_t n_entities, int32_t estride,
                                const int32_t* entities0, const int32_t* dofmap0,

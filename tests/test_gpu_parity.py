@@ -196,7 +196,7 @@ def test_backsubstitution_homogenize(oracle):
 # ---------------------------------------------------------------------------------------------
 # kernel variants that the default configuration never reaches
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("env", ["MPCX_NO_MPC_PLAN=1", "MPCX_NO_LEAN=1", "MPCX_MPC_PLAN=host", "MPCX_NO_CUBE=1"])
+@pytest.mark.parametrize("env", ["MPCX_NO_MPC_PLAN=1", "MPCX_NO_LEAN=1", "MPCX_MPC_PLAN=host", "MPCX_NO_CUBE=1", "MPCX_PLAN_LISTS=host"])
 @pytest.mark.parametrize("alg", ["atomic", "rowblock"])
 @pytest.mark.parametrize("make", CASES, ids=[f"case{i}" for i in range(len(CASES))])
 def test_small_cases_kernel_variants(oracle, make, alg, env, monkeypatch):
