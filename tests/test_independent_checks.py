@@ -1,0 +1,161 @@
+"""Ground truth that does not pass through our own element / mesh helpers: analytic integrals of
+polynomials over the unit cube and its faces, evaluated here with tensor Gauss-Legendre rules in plain
+numpy, against what the assembled objects give for the same polynomials.
+
+The oracle and the product share ``dolfinx_mpc_amd.fem`` / ``mesh`` / ``quadrature`` (tests/problems.py), so a
+wrong P2 edge ordering, local facet convention, dof-coordinate table or quadrature rule would be invisible to
+every oracle-vs-product comparison.  These identities catch each of them:
+
+* P_k reproduces polynomials of degree <= k, so with u_i = u(x_i) at the space's own dof coordinates
+      u^T A v = int grad(u).grad(v),    u^T M v = int u v,    u^T b = int f u,    u^T b_facet = int_Gamma f u ds
+  hold exactly (quadrature degrees are sufficient) -- they fail if the dofs' coordinates, the local basis
+  ordering (vertices, then edges (2,3)(1,3)(1,2)(0,3)(0,2)(0,1)) or the facet numbering (facet i opposite
+  vertex i) disagree with each other;
+* mesh: positive cell volumes adding up to 1, every interior facet shared by exactly two cells, the edge count
+  of the 6-tet split, exterior facets on the boundary only.
+The same checks run on the GPU product in tests/test_gpu_independent.py."""
+
+import itertools
+
+import numpy as np
+import pytest
+
+from dolfinx_mpc_amd import fem
+from dolfinx_mpc_amd.mesh import create_unit_cube, create_unit_square
+
+
+def gauss_cube(f, n=6, dim=3):
+    """int_[0,1]^dim f by a tensor Gauss-Legendre rule with n points per direction (exact to degree 2n-1)"""
+    x, w = np.polynomial.legendre.leggauss(n)
+    x, w = 0.5 * (x + 1.0), 0.5 * w
+    pts = np.array(list(itertools.product(x, repeat=dim))).T
+    wts = np.prod(np.array(list(itertools.product(w, repeat=dim))), axis=1)
+    if dim == 2:
+        pts = np.vstack([pts, np.zeros(pts.shape[1])])
+    return float(np.sum(wts * f(pts)))
+
+
+def u_fun(deg):
+    if deg == 1:
+        return (lambda x: 0.3 + x[0] - 2.0 * x[1] + 0.5 * x[2],
+                lambda x: np.stack([np.ones_like(x[0]), -2.0 * np.ones_like(x[0]), 0.5 * np.ones_like(x[0])]))
+    return (lambda x: 0.3 + x[0] - 2.0 * x[1] + 0.5 * x[2] + x[0] * x[1] - 0.7 * x[2] ** 2 + 0.4 * x[1] * x[2] + 1.1 * x[0] ** 2,
+            lambda x: np.stack([1.0 + x[1] + 2.2 * x[0], -2.0 + x[0] + 0.4 * x[2], 0.5 - 1.4 * x[2] + 0.4 * x[1]]))
+
+
+def v_fun(deg):
+    if deg == 1:
+        return (lambda x: -1.0 + 0.25 * x[0] + x[1] + 2.0 * x[2],
+                lambda x: np.stack([0.25 * np.ones_like(x[0]), np.ones_like(x[0]), 2.0 * np.ones_like(x[0])]))
+    return (lambda x: -1.0 + 0.25 * x[0] + x[1] + 2.0 * x[2] - x[0] * x[2] + 0.9 * x[1] ** 2,
+            lambda x: np.stack([0.25 - x[2], 1.0 + 1.8 * x[1], 2.0 - x[0]]))
+
+
+def poly3(x):  # fem.FN_POLY3 (csrc/mpcx_elements.hpp eval_fn case 3), component 0
+    return 1.0 + 2.0 * x[0] + 3.0 * x[1] ** 2 - x[2] ** 3 + x[0] * x[1] * x[2]
+
+
+@pytest.mark.parametrize("degree", [1, 2])
+@pytest.mark.parametrize("reorder", [None, (2, 2, 2)])
+def test_bilinear_and_linear_forms_reproduce_analytic_integrals(oracle, degree, reorder):
+    mesh = create_unit_cube(3, 3, 3, reorder=reorder)
+    V = fem.functionspace(mesh, ("Lagrange", degree))
+    X = V.tabulate_dof_coordinates().T
+    (u, gu), (v, gv) = u_fun(degree), v_fun(degree)
+    U, W = u(X), v(X)
+    none = oracle.OracleMPC.empty(V)
+    A = oracle.assemble_matrix(fem.form_stiffness(V), none)
+    M = oracle.assemble_matrix(fem.form_mass(V), none)
+    b = oracle.assemble_vector(fem.form_source(V, fem.FN_POLY3), none)
+    assert U @ (A @ W) == pytest.approx(gauss_cube(lambda x: np.sum(gu(x) * gv(x), axis=0)), rel=1e-12)
+    assert U @ (M @ W) == pytest.approx(gauss_cube(lambda x: u(x) * v(x)), rel=1e-12)
+    assert U @ b == pytest.approx(gauss_cube(lambda x: poly3(x) * u(x)), rel=1e-12)
+    # exterior facets: the face x = 1 (local facet numbering: facet i is opposite vertex i)
+    right = mesh.locate_exterior_facets(lambda x: np.isclose(x[0], 1.0))
+    assert right.shape[0] == 2 * 3 * 3
+    Mf = oracle.assemble_matrix(fem.form_facet_mass(V, right), none)
+    bf = oracle.assemble_vector(fem.form_facet_source(V, right, fem.FN_LINEAR), none)
+    on_face = lambda g: (lambda s: g(np.stack([np.ones_like(s[0]), s[0], s[1]])))  # (y, z) -> (1, y, z)
+    assert U @ (Mf @ W) == pytest.approx(gauss_cube(on_face(lambda x: u(x) * v(x)), dim=2), rel=1e-12)
+    lin = lambda x: 1.0 + x[0] - 2.0 * x[1] + 0.5 * x[2]  # fem.FN_LINEAR, component 0
+    assert U @ bf == pytest.approx(gauss_cube(on_face(lambda x: lin(x) * u(x)), dim=2), rel=1e-12)
+
+
+@pytest.mark.parametrize("degree", [1, 2])
+def test_vector_valued_forms_reproduce_analytic_integrals(oracle, degree):
+    """blocked spaces (dof = block * bs + component) and the Taylor-Hood coupling blocks"""
+    mesh = create_unit_cube(2, 2, 2)
+    V = fem.functionspace(mesh, ("Lagrange", degree, (3,)))
+    Q = fem.functionspace(mesh, ("Lagrange", 1))
+    X = V.tabulate_dof_coordinates().T
+    (u, gu), (v, gv) = u_fun(degree), v_fun(degree)
+    # vector fields (u, 2v, u - v) and (v, -u, 0.5 u)
+    Uv = np.stack([u(X), 2 * v(X), u(X) - v(X)], axis=1).reshape(-1)
+    Wv = np.stack([v(X), -u(X), 0.5 * u(X)], axis=1).reshape(-1)
+    none = oracle.OracleMPC.empty(V)
+    A = oracle.assemble_matrix(fem.form_stiffness(V), none)
+    exact = gauss_cube(lambda x: np.sum(gu(x) * gv(x), axis=0) - 2 * np.sum(gv(x) * gu(x), axis=0)
+                       + 0.5 * np.sum((gu(x) - gv(x)) * gu(x), axis=0))
+    assert Uv @ (A @ Wv) == pytest.approx(exact, rel=1e-12)
+    if degree == 1:
+        # linear elasticity: int 2 mu eps(U):eps(W) + lambda div U div W
+        mu, lam = 1.3, 0.7
+        E = oracle.assemble_matrix(fem.form_elasticity(V, mu, lam), none)
+
+        def integrand(x):
+            GU = np.stack([gu(x), 2 * gv(x), gu(x) - gv(x)])  # GU[i][j] = d_j U_i
+            GW = np.stack([gv(x), -gu(x), 0.5 * gu(x)])
+            eU, eW = 0.5 * (GU + GU.transpose(1, 0, 2)), 0.5 * (GW + GW.transpose(1, 0, 2))
+            return 2 * mu * np.sum(eU * eW, axis=(0, 1)) + lam * np.trace(GU) * np.trace(GW)
+
+        assert Uv @ (E @ Wv) == pytest.approx(gauss_cube(integrand), rel=1e-12)
+    if degree == 2:
+        # Taylor-Hood: q^T A10 U = -int div(U) q, and A01 = A10^T
+        mq = oracle.OracleMPC.empty(Q)
+        A10 = oracle.assemble_matrix(fem.form_div_trial(Q, V, constant=-1.0), mq, none)
+        A01 = oracle.assemble_matrix(fem.form_div_test(V, Q, constant=-1.0), none, mq)
+        q = lambda x: 0.2 + x[0] - x[1] + 3.0 * x[2]
+        Qh = q(Q.tabulate_dof_coordinates().T)
+        divU = lambda x: gu(x)[0] + 2 * gv(x)[1] + gu(x)[2] - gv(x)[2]
+        assert Qh @ (A10 @ Uv) == pytest.approx(-gauss_cube(lambda x: divU(x) * q(x)), rel=1e-12)
+        assert abs(A10 - A01.T).max() < 1e-14
+
+
+def test_triangle_spaces(oracle):
+    mesh = create_unit_square(4, 3)
+    for degree in (1, 2):
+        V = fem.functionspace(mesh, ("Lagrange", degree))
+        X = V.tabulate_dof_coordinates().T
+        (u, gu), (v, gv) = u_fun(degree), v_fun(degree)
+        U, W = u(X), v(X)
+        A = oracle.assemble_matrix(fem.form_stiffness(V), oracle.OracleMPC.empty(V))
+        plane = lambda g: (lambda s: g(np.stack([s[0], s[1], np.zeros_like(s[0])])))
+        exact = gauss_cube(plane(lambda x: gu(x)[0] * gv(x)[0] + gu(x)[1] * gv(x)[1]), dim=2)
+        assert U @ (A @ W) == pytest.approx(exact, rel=1e-12)
+
+
+@pytest.mark.parametrize("N,reorder", [(2, None), (3, (2, 2, 2)), (4, None)])
+def test_mesh_is_a_conforming_positive_partition(N, reorder):
+    mesh = create_unit_cube(N, N, N, reorder=reorder)
+    x, cells = mesh.geometry.x, mesh.geometry.dofmap.astype(np.int64)
+    e = x[cells[:, 1:]] - x[cells[:, :1]]
+    vol = np.abs(np.linalg.det(e)) / 6.0
+    assert vol.min() > 0 and vol.sum() == pytest.approx(1.0, rel=1e-13)
+    # facets by brute force: sorted vertex triples
+    faces = {}
+    for c, vs in enumerate(cells):
+        for tri in itertools.combinations(vs.tolist(), 3):
+            faces.setdefault(tuple(sorted(tri)), []).append(c)
+    counts = np.array([len(v) for v in faces.values()])
+    assert set(counts.tolist()) <= {1, 2}
+    boundary = [k for k, v in faces.items() if len(v) == 1]
+    assert len(boundary) == 6 * 2 * N * N
+    for tri in boundary:  # on one of the six faces of the cube
+        p = x[list(tri)]
+        assert any(np.allclose(p[:, d], 0.0) or np.allclose(p[:, d], 1.0) for d in range(3))
+    edges = {tuple(sorted(p)) for vs in cells for p in itertools.combinations(vs.tolist(), 2)}
+    assert len(edges) == 3 * N * (N + 1) ** 2 + 3 * N * N * (N + 1) + N ** 3
+    # the product's own exterior facet list agrees, with (cell, local facet) = facet opposite local vertex
+    ext = mesh.exterior_facets()
+    mine = {tuple(sorted(np.delete(cells[c], f).tolist())) for c, f in ext}
+    assert mine == set(boundary)
