@@ -83,6 +83,28 @@ def space_device(V: FunctionSpace):
     return V._device[key]
 
 
+_ufcx_handles = {}
+
+
+def ufcx_compile(k, form: Form):
+    """handle of the hipRTC-compiled kernels for an imported UFCx function (include/mpcx.h mpcx_ufcx_compile),
+    one per (source, name, element shapes); compilation needs no device"""
+    V0 = form.function_spaces[0]
+    V1 = form.function_spaces[1] if form.rank == 2 else None
+    nv = form.mesh.geometry.dofmap.shape[1]
+    key = (k.ufcx_source, k.ufcx_name, form.rank, V0.element_ndofs, V0.dofmap.bs,
+           0 if V1 is None else V1.element_ndofs, 0 if V1 is None else V1.dofmap.bs, nv)
+    if key not in _ufcx_handles:
+        d = _native.UfcxDescT(k.ufcx_source.encode(), k.ufcx_name.encode(), form.rank, V0.element_ndofs, V0.dofmap.bs,
+                              0 if V1 is None else V1.element_ndofs, 0 if V1 is None else V1.dofmap.bs, nv)
+        L = _native.lib()
+        h = L.mpcx_ufcx_compile(d)
+        if not h:
+            raise RuntimeError("mpcx_ufcx_compile failed: " + L.mpcx_last_error().decode())
+        _ufcx_handles[key] = h
+    return _ufcx_handles[key]
+
+
 def integral_device(form: Form, i: int):
     """entities / quadrature tables of integral i (structural: uploaded once) and its packed
     coefficients / constants, which are VALUES: refreshed whenever the coefficient's dof array was
@@ -113,6 +135,7 @@ def integral_device(form: Form, i: int):
             k.form, k.celltype, k.degree, k.bs, k.degree1 or k.degree, k.bs1 or k.bs, k.fn_id, k.coeff_degree,
             int(k.qwts.size), int(k.fqwts.size),
             d["qpts"].data_ptr(), d["qwts"].data_ptr(), d["fqpts"].data_ptr(), d["fqwts"].data_ptr(),
+            ufcx_compile(k, form) if k.form == 100 else None,
         )
         form._device[key] = d
     d = form._device[key]

@@ -32,6 +32,20 @@ class KernelT(C.Structure):
         ("qwts", C.c_void_p),
         ("fqpts", C.c_void_p),
         ("fqwts", C.c_void_p),
+        ("ufcx", C.c_void_p),
+    ]
+
+
+class UfcxDescT(C.Structure):
+    _fields_ = [
+        ("source", C.c_char_p),
+        ("function_name", C.c_char_p),
+        ("rank", C.c_int32),
+        ("nd0", C.c_int32),
+        ("bs0", C.c_int32),
+        ("nd1", C.c_int32),
+        ("bs1", C.c_int32),
+        ("nv", C.c_int32),
     ]
 
 
@@ -201,6 +215,9 @@ EXPORTS = [
     "mpcx_mpc_plan_free",
     "mpcx_mpc_plan_device",
     "mpcx_compress_offsets",
+    "mpcx_ufcx_compile",
+    "mpcx_ufcx_code_size",
+    "mpcx_ufcx_free",
     "mpcx_gather_f64",
     "mpcx_scatter_add_f64",
     "mpcx_spmv",
@@ -302,6 +319,12 @@ def lib() -> C.CDLL:
     L.mpcx_mpc_plan_device.argtypes = [i64, vp, i32, vp, vp, vp, i32, i32, vp, i32, i32, vp, vp, C.POINTER(MpcT),
                                        C.POINTER(MpcT), vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
     L.mpcx_mpc_plan_device.restype = C.c_int
+    L.mpcx_ufcx_compile.argtypes = [C.POINTER(UfcxDescT)]
+    L.mpcx_ufcx_compile.restype = vp
+    L.mpcx_ufcx_code_size.argtypes = [vp]
+    L.mpcx_ufcx_code_size.restype = i64
+    L.mpcx_ufcx_free.argtypes = [vp]
+    L.mpcx_ufcx_free.restype = None
     L.mpcx_compress_offsets.argtypes = [vp, i64, i32, i32, vp, vp]
     L.mpcx_compress_offsets.restype = i32
     L.mpcx_gather_f64.argtypes = [vp, vp, i64, vp, vp]

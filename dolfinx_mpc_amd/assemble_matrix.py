@@ -524,6 +524,8 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
     # thin layers: a large layer of big elements would take the host minutes) | none (matrix_mpc_kernel: what a
     # caller of the bare C ABI gets with mpc_plan_off == NULL); MPCX_NO_MPC_PLAN=1 is the old spelling of none
     mode = "none" if os.environ.get("MPCX_NO_MPC_PLAN") else os.environ.get("MPCX_MPC_PLAN", "device").lower()
+    if integ.kernel.form == 100:
+        mode = "none"  # imported UFCx kernels bring their own master-contribution kernel
     n0n1 = V0.element_ndofs * V0.dofmap.bs * V1.element_ndofs * V1.dofmap.bs
     if a.n_slave_entities > 0 and mode == "device" and max(V0.element_ndofs * V0.dofmap.bs,
                                                            V1.element_ndofs * V1.dofmap.bs) <= 32:
@@ -598,6 +600,8 @@ def assemble_matrix(
     if A is None:
         A = create_matrix(form, mpc0, mpc1)
     alg = _ALG[(algorithm or os.environ.get("MPCX_MATRIX_ALG", "auto")).lower()]
+    if any(integ.kernel.form == 100 for integ in form.integrals):
+        alg = 1  # imported UFCx kernels: generic per-entity kernels with device atomics
     if alg == 0:
         # "auto": LDS row blocks (each value written once) when a plan can be built for every
         # integral, device atomics otherwise (rows with more than 255 column blocks, tiny LDS...)

@@ -1453,6 +1453,8 @@ extern "C" int mpcx_assemble_matrix(const mpcx_matrix_args_t* args)
 {
   const mpcx_matrix_args_t& a = *args;
   const mpcx_kernel_t& k = a.kernel;
+  if (k.form == MPCX_FORM_UFCX)
+    return launch_matrix_ufcx(a);
   switch (k.form)
   {
   case MPCX_FORM_STIFFNESS:
@@ -1485,6 +1487,8 @@ extern "C" int mpcx_assemble_vector(const mpcx_vector_args_t* args)
 {
   const mpcx_vector_args_t& a = *args;
   const mpcx_kernel_t& k = a.kernel;
+  if (k.form == MPCX_FORM_UFCX)
+    return launch_vector_ufcx(a);
   if (a.algorithm == MPCX_ALG_CUBE)
     return launch_vector_cubes(a);
   switch (k.form)
@@ -1511,6 +1515,8 @@ extern "C" int mpcx_apply_lifting(const mpcx_lifting_args_t* args)
 {
   const mpcx_lifting_args_t& a = *args;
   const mpcx_kernel_t& k = a.kernel;
+  if (k.form == MPCX_FORM_UFCX)
+    return launch_lifting_ufcx(a);
   switch (k.form)
   {
   case MPCX_FORM_STIFFNESS:

@@ -26,6 +26,7 @@ FORM_FACET_MASS = 4
 FORM_FACET_SOURCE = 5
 FORM_DIV_TEST = 6  # c * p div(v): vector test space, scalar trial space
 FORM_DIV_TRIAL = 7  # c * div(u) q: scalar test space, vector trial space
+FORM_UFCX = 100  # an imported UFCx tabulate_tensor (C source), include/mpcx.h mpcx_ufcx_compile
 
 CELL_TRIANGLE = 1
 CELL_TETRAHEDRON = 2
@@ -351,6 +352,8 @@ class KernelSpec:
     fqwts: np.ndarray = field(default_factory=lambda: np.zeros(0))
     degree1: int = 0  # trial space (0 = same as test space)
     bs1: int = 0
+    ufcx_source: str = ""  # FORM_UFCX: C source of the tabulate_tensor function and its name
+    ufcx_name: str = ""
 
 
 class Integral:
@@ -512,6 +515,29 @@ def form_source(V, fn_id: int = FN_ONE, constant=None, coefficient: Optional[Fun
     qdeg = V.degree + fdeg + cd if quadrature_degree is None else quadrature_degree
     k = _cell_kernel(V, FORM_SOURCE, qdeg, fn_id, cd)
     return Form([V], [Integral("cell", cells, k, coefficient, _constants(constant))])
+
+
+def form_ufcx(spaces: Sequence[FunctionSpace], source: str, function_name: str, itype: str = "cell", entities=None,
+              coefficient: Optional[Function] = None, constant=None) -> Form:
+    """A form whose element kernel is an imported UFCx ``tabulate_tensor`` given as C SOURCE (what FFCx
+    writes to disk; the reference calls the compiled function through a pointer,
+    cpp/assemble_matrix.cpp:438-439).  ``spaces`` = [V] (linear form) or [V0, V1] (bilinear form: rows V0,
+    columns V1); the function must write the row-major [nd0*bs0][nd1*bs1] tensor of ONE entity with the
+    blocked dof index i*bs + k, accumulate into A (handed over zeroed) and read the local facet of an
+    exterior-facet integral from ``entity_local_index[0]``.  ``entities``: cells (default all owned cells) or
+    (cell, local_facet) pairs for ``itype="exterior_facet"``.  The kernel runs on the device (hipRTC) through
+    the generic per-entity kernels (device atomics)."""
+    spaces = list(spaces)
+    V0 = spaces[0]
+    V1 = spaces[1] if len(spaces) > 1 else None
+    if itype == "cell":
+        ents = _cells_or_all(V0.mesh, entities)
+    else:
+        ents = np.ascontiguousarray(entities, dtype=np.int32).reshape(-1, 2)
+    k = KernelSpec(FORM_UFCX, _CELL_ID[V0.mesh.cell_name], V0.degree, V0.dofmap.bs, ufcx_source=source, ufcx_name=function_name)
+    if V1 is not None:
+        k.degree1, k.bs1 = V1.degree, V1.dofmap.bs
+    return Form(spaces, [Integral(itype, ents, k, coefficient, _constants(constant))])
 
 
 def form_facet_mass(V, facets: np.ndarray, constant=None) -> Form:

@@ -40,7 +40,9 @@ enum {
   MPCX_FORM_FACET_MASS = 4,
   MPCX_FORM_FACET_SOURCE = 5,
   MPCX_FORM_DIV_TEST = 6,  /* a(p, v) = c * p div(v) dx: vector test space, scalar trial space */
-  MPCX_FORM_DIV_TRIAL = 7  /* a(u, q) = c * div(u) q dx: scalar test space, vector trial space */
+  MPCX_FORM_DIV_TRIAL = 7, /* a(u, q) = c * div(u) q dx: scalar test space, vector trial space */
+  /* an imported UFCx tabulate_tensor (mpcx_ufcx_compile): mpcx_kernel_t::ufcx holds the handle */
+  MPCX_FORM_UFCX = 100
 };
 enum { MPCX_CELL_TRIANGLE = 1, MPCX_CELL_TETRAHEDRON = 2 };
 
@@ -75,7 +77,32 @@ typedef struct
   const double* qwts;  /* DEVICE [nq] */
   const double* fqpts; /* DEVICE [nqf][tdim-1] */
   const double* fqwts; /* DEVICE [nqf] */
+  const void* ufcx;    /* form == MPCX_FORM_UFCX: handle from mpcx_ufcx_compile; NULL otherwise */
 } mpcx_kernel_t;
+
+/* ------------------------------------------------------------------------
+ * UFCx import.  The reference's element seam is a host function pointer with the UFCx signature
+ *   void tabulate_tensor(double* A, const double* w, const double* c, const double* coordinate_dofs,
+ *                        const int* entity_local_index, const uint8_t* quadrature_permutation, void* custom_data)
+ * (cpp/assemble_matrix.cpp:291-292, 438-439; python/src/dolfinx_mpc/numba/assemble_matrix.py:282-290).  Here the
+ * seam is the C SOURCE of such a function (what FFCx writes to disk): mpcx_ufcx_compile turns it into a
+ * gfx950 __device__ function with hipRTC and links it with generic per-entity assembly kernels for the given
+ * element shape.  The handle goes into mpcx_kernel_t::ufcx with form = MPCX_FORM_UFCX; mpcx_assemble_matrix
+ * (MPCX_ALG_ATOMIC), mpcx_assemble_vector and mpcx_apply_lifting then call it.  A is handed over zeroed and is
+ * accumulated into, row-major [nd0*bs0][nd1*bs1] with blocked dof index i*bs + k, like the reference does.
+ * Compilation needs no device; NULL + mpcx_last_error() on failure (the compiler log is in the message). */
+typedef struct
+{
+  const char* source;        /* HOST, NUL-terminated C source defining the function (and whatever it needs) */
+  const char* function_name; /* HOST */
+  int32_t rank;              /* 2: bilinear form (matrix, lifting), 1: linear form (vector) */
+  int32_t nd0; int32_t bs0;  /* test space: dofs per cell, block size */
+  int32_t nd1; int32_t bs1;  /* trial space (rank 2) */
+  int32_t nv;                /* geometry nodes per cell */
+} mpcx_ufcx_desc_t;
+void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* desc);
+int64_t mpcx_ufcx_code_size(void* handle); /* bytes of the gfx950 code object */
+void mpcx_ufcx_free(void* handle);
 
 /* Finalized constraint as the kernels read it: the accessors of
  * cpp/MultiPointConstraint.h:155-199 (is_slave, masters, coefficients) as

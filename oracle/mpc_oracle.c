@@ -470,10 +470,17 @@ void oracle_tabulate_source_p1_tet(double* A, const double* w, const double* c,
   }
 }
 
+/* an element kernel handed in by the caller (UFCx signature, the reference's own seam:
+ * cpp/assemble_matrix.cpp:438-439): which == 100 */
+static oracle_tabulate_fn g_user_kernel = 0;
+void oracle_set_user_kernel(oracle_tabulate_fn fn) { g_user_kernel = fn; }
+
 static oracle_tabulate_fn pick_kernel(int which)
 {
   switch (which)
   {
+  case 100:
+    return g_user_kernel;
   case 1:
     return oracle_tabulate_laplace_p1_tet;
   case 2:

@@ -37,6 +37,9 @@ typedef void (*oracle_tabulate_fn)(double* A, const double* w, const double* c,
                                    const uint8_t* quadrature_permutation,
                                    void* custom_data);
 
+/* which == 100 in the entry points below: call this function (a UFCx tabulate_tensor compiled by the caller) */
+void oracle_set_user_kernel(oracle_tabulate_fn fn);
+
 /* form kinds */
 enum {
   ORACLE_FORM_STIFFNESS = 0, /* a = c0 * w * grad(u).grad(v) dx (per component if bs>1) */

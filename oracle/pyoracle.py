@@ -248,8 +248,34 @@ def _desc(k):
     return d, keep
 
 
+_user_libs = {}
+
+
+def _load_user_kernel(k):
+    """UFCx import (fem.FORM_UFCX): the kernel's C source compiled with gcc -- the same text the product
+    compiles with hipRTC -- and registered as the oracle's kernel 100."""
+    import hashlib
+    import tempfile
+
+    key = hashlib.sha256((k.ufcx_source + k.ufcx_name).encode()).hexdigest()[:20]
+    if key not in _user_libs:
+        d = os.path.join(tempfile.gettempdir(), "mpcx_oracle_ufcx")
+        os.makedirs(d, exist_ok=True)
+        src, so = os.path.join(d, key + ".c"), os.path.join(d, key + ".so")
+        if not os.path.exists(so):
+            with open(src, "w") as fh:
+                fh.write("#include <stdint.h>\n#include <math.h>\n" + k.ufcx_source)
+            subprocess.run(["gcc", "-O2", "-std=c99", "-fPIC", "-shared", "-o", so, src, "-lm"], check=True)
+        _user_libs[key] = C.CDLL(so)
+    fn = getattr(_user_libs[key], k.ufcx_name)
+    lib().oracle_set_user_kernel(C.cast(fn, C.c_void_p))
+    return 100
+
+
 def _which(k, fast: bool):
-    """0 generic; FFCx-like fast paths only for the benchmark kernels."""
+    """0 generic; FFCx-like fast paths only for the benchmark kernels; 100 an imported UFCx kernel."""
+    if k.form == 100:
+        return _load_user_kernel(k)
     if not fast or k.coeff_degree != 0 or k.bs != 1 or k.degree != 1 or k.celltype != 2:
         return 0
     if k.form == 0:
