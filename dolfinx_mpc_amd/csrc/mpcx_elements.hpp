@@ -360,7 +360,7 @@ struct ElementOp
   //                   G_kl = |T| grad(l_k).grad(l_l) of the barycentric coordinates; with
   //                   int l_a = |T|/4, int l_a l_b = |T| (1 + d_ab)/20 every entry is a fixed
   //                   combination of at most four G_kl
-  static constexpr bool LAZY_ELASTICITY = (FORM == MPCX_FORM_ELASTICITY && DEG0_ == 1);
+  static constexpr bool LAZY_ELASTICITY = (FORM == MPCX_FORM_ELASTICITY && (DEG0_ == 1 || DEG0_ == 2));
   static constexpr bool LAZY_P2_STIFFNESS = (FORM == MPCX_FORM_STIFFNESS && DEG0_ == 2 && DEG1_ == 2);
   //   Taylor-Hood coupling blocks (P2^d x P1): int psi_j d_a(phi_i) from the gradients and the
   //                   same barycentric integrals
@@ -441,7 +441,49 @@ struct ElementOp
   }
   __device__ static inline double entry(const Lazy& L, int i, int a, int j, int b)
   {
-    if constexpr (LAZY_ELASTICITY)
+    if constexpr (LAZY_ELASTICITY && DEG0_ == 2)
+    {
+      // dense P2^d elasticity (the `2 mu eps(u):eps(v)` block of python/demos/demo_stokes.py): with
+      // grad(phi) = sum_k (d phi / d l_k) grad(l_k) every entry is  sum_{k,l} c_kl(i, j) H(k, l),
+      //   H(k, l) = |T| (mu g_k^b g_l^a + lambda g_k^a g_l^b + delta_ab mu g_k.g_l),
+      //   c_kl(i, j) = int (d phi_i / d l_k)(d phi_j / d l_l) / |T|   -- the same barycentric integrals as the
+      // P2 stiffness entries above, but H is not symmetric in (k, l): k belongs to the test function i
+      using LG = Lagrange<TDIM, 2>;
+      constexpr double m1 = 1.0 / (TDIM + 1), m2 = 1.0 / ((TDIM + 1) * (TDIM + 2));
+      auto d = [](int x, int y) { return x == y ? 2.0 : 1.0; };
+      auto H = [&](int k, int l)
+      {
+        double h = L.smu * L.g[k][b] * L.g[l][a] + L.sla * L.g[k][a] * L.g[l][b];
+        if (a == b)
+        {
+          double dot = 0.0;
+#pragma unroll
+          for (int x = 0; x < TDIM; ++x)
+            dot += L.g[k][x] * L.g[l][x];
+          h += L.smu * dot;
+        }
+        return h;
+      };
+      if (i < NV && j < NV) // (4 l_i - 1)(4 l_j - 1)
+        return (16.0 * d(i, j) * m2 - 8.0 * m1 + 1.0) * H(i, j);
+      if (i < NV) // test: vertex i; trial: edge (p, q) -> 4 (l_q grad l_p + l_p grad l_q)
+      {
+        int p, q;
+        LG::edge(j - NV, p, q);
+        return 4.0 * ((4.0 * d(i, q) * m2 - m1) * H(i, p) + (4.0 * d(i, p) * m2 - m1) * H(i, q));
+      }
+      if (j < NV) // test: edge (p, q); trial: vertex j
+      {
+        int p, q;
+        LG::edge(i - NV, p, q);
+        return 4.0 * ((4.0 * d(j, q) * m2 - m1) * H(p, j) + (4.0 * d(j, p) * m2 - m1) * H(q, j));
+      }
+      int p, q, r, t; // edges (p, q) and (r, t)
+      LG::edge(i - NV, p, q);
+      LG::edge(j - NV, r, t);
+      return 16.0 * m2 * (d(q, t) * H(p, r) + d(q, r) * H(p, t) + d(p, t) * H(q, r) + d(p, r) * H(q, t));
+    }
+    else if constexpr (LAZY_ELASTICITY)
     {
       // A[(i,a),(j,b)] = |T| (mu g_i^b g_j^a + lambda g_i^a g_j^b + delta_ab mu g_i.g_j)
       double v = L.smu * L.g[i][b] * L.g[j][a] + L.sla * L.g[i][a] * L.g[j][b];

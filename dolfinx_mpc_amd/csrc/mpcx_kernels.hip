@@ -1470,6 +1470,7 @@ extern "C" int mpcx_assemble_matrix(const mpcx_matrix_args_t* args)
     break;
   case MPCX_FORM_ELASTICITY:
     MPCX_FOR_VECTOR_SPACES(launch_matrix, MPCX_FORM_ELASTICITY)
+    MPCX_FOR_P2_VECTOR_SPACES(launch_matrix, MPCX_FORM_ELASTICITY)
     break;
   case MPCX_FORM_DIV_TEST:
     MPCX_FOR_DIV_TEST(launch_matrix)
@@ -1532,6 +1533,7 @@ extern "C" int mpcx_apply_lifting(const mpcx_lifting_args_t* args)
     break;
   case MPCX_FORM_ELASTICITY:
     MPCX_FOR_VECTOR_SPACES(launch_lifting, MPCX_FORM_ELASTICITY)
+    MPCX_FOR_P2_VECTOR_SPACES(launch_lifting, MPCX_FORM_ELASTICITY)
     break;
   case MPCX_FORM_DIV_TEST:
     MPCX_FOR_DIV_TEST(launch_lifting)

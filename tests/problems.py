@@ -400,6 +400,13 @@ def stokes_slip_problem(dim, n, reorder=None):
     return V, Q, bcs, raw_v, forms, L0
 
 
+def case_p2_vector_elasticity_slip(n=2) -> Case:
+    """dense P2^3 forms: the `2 mu eps(u):eps(v)` velocity block of python/demos/demo_stokes.py (30 x 30 local tensor,
+    every component coupled) with the slip constraint and boundary data of stokes_slip_problem"""
+    V, Q, bcs, raw_v, forms, L0 = stokes_slip_problem(3, n)
+    return Case(f"p2_vector_elasticity_slip_n{n}", V, fem.form_elasticity(V, 1.0, 0.0), L0, bcs, raw_v)
+
+
 def all_small_cases() -> List[Callable[[], Case]]:
     return [
         lambda: case_square_dict(1, (1, 1)),
@@ -428,6 +435,7 @@ def all_small_cases() -> List[Callable[[], Case]]:
         lambda: case_contact_two_body(2),  # config 4's shape: nested interface grids
         lambda: case_contact_two_body(2, 3, np.pi / 3),  # non-matching grids, rotated: 3 masters per slave
         lambda: case_contact_two_body(4, 6, 0.0, reorder=(2, 2, 2)),  # tiled numbering (row-block hints per body)
+        lambda: case_p2_vector_elasticity_slip(2),  # dense P2^3 block of the Stokes demo
     ]
 
 

@@ -62,9 +62,9 @@ def test_product_vector_valued_forms(degree):
     exact = gauss_cube(lambda x: np.sum(gu(x) * gv(x), axis=0) - 2 * np.sum(gv(x) * gu(x), axis=0)
                        + 0.5 * np.sum((gu(x) - gv(x)) * gu(x), axis=0))
     assert Uv @ (A @ Wv) == pytest.approx(exact, rel=1e-12)
-    if degree == 1:
+    for alg in ("rowblock", "atomic"):
         mu, lam = 1.3, 0.7
-        E = dm.assemble_matrix(fem.form_elasticity(V, mu, lam), none).to_scipy()
+        E = dm.assemble_matrix(fem.form_elasticity(V, mu, lam), none, algorithm=alg).to_scipy()
 
         def integrand(x):
             GU = np.stack([gu(x), 2 * gv(x), gu(x) - gv(x)])
@@ -73,7 +73,7 @@ def test_product_vector_valued_forms(degree):
             return 2 * mu * np.sum(eU * eW, axis=(0, 1)) + lam * np.trace(GU) * np.trace(GW)
 
         assert Uv @ (E @ Wv) == pytest.approx(gauss_cube(integrand), rel=1e-12)
-    else:
+    if degree == 2:
         mq = _none(Q)
         A10 = dm.assemble_matrix(fem.form_div_trial(Q, V, constant=-1.0), (mq, none)).to_scipy()
         q = lambda x: 0.2 + x[0] - x[1] + 3.0 * x[2]
