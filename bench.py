@@ -291,7 +291,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5])
     ap.add_argument("--scaling", default=os.environ.get("MPCX_BENCH_SCALING", "strong"), choices=["strong", "weak"])
-    ap.add_argument("--n", type=int, default=0, help="mesh resolution (default: 256 / 128 / 56 / 246 for config 2 / 3 / 4 / 5)")
+    ap.add_argument("--size", dest="n", type=int, default=0, help="mesh resolution (default: 256 / 128 / 56 / 246 for config 2 / 3 / 4 / 5)")
     ap.add_argument("--alg", default=os.environ.get("MPCX_MATRIX_ALG", "rowblock"))
     ap.add_argument("--tile", type=int, nargs=3, default=[8, 8, 8], help="node/cell tile of the numbering")
     ap.add_argument("--no-tile", action="store_true")
@@ -503,7 +503,7 @@ def main():
                                         "frac": dom["fp64_frac"]}
     if world == 1 and not args.no_traffic and not os.environ.get("MPCX_BENCH_NO_PMC"):
         log("measuring HBM traffic of the dominant kernel (rocprofv3 --pmc, two short child runs) ...")
-        child_args = ["--config", str(args.config), "--n", str(args.n), "--alg", args.alg, "--steps", "1", "--warmup", "0",
+        child_args = ["--config", str(args.config), "--size", str(args.n), "--alg", args.alg, "--steps", "1", "--warmup", "0",
                       "--no-cpu-baseline", "--no-traffic"] + (["--no-tile"] if args.no_tile else ["--tile"] + [str(v) for v in args.tile])
         traffic, info = measure_traffic(child_args, dom["pmc_name"])
         out["roofline"]["traffic"] = traffic

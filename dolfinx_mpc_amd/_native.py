@@ -114,6 +114,7 @@ class MatrixArgs(C.Structure):
         ("mpc_plan_ent", C.c_void_p),
         ("mpc_plan_pq", C.c_void_p),
         ("mpc_plan_coef", C.c_void_p),
+        ("mpc_plan_group", C.c_int32),
         ("stream", C.c_void_p),
     ]
 

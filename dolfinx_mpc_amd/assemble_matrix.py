@@ -536,6 +536,8 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
         a.mpc_plan_targets = mplan[0].numel() if mplan[5] else 0
         (a.mpc_plan_tgt, a.mpc_plan_off, a.mpc_plan_ent, a.mpc_plan_pq,
          a.mpc_plan_coef) = (t.data_ptr() for t in mplan[:5])
+        mean = mplan[2].numel() / max(mplan[0].numel(), 1)  # tuples per target position
+        a.mpc_plan_group = 16 if mean > 10 else (4 if mean > 2.5 else 1)
     a.algorithm = alg
     a.store_mode = store_mode
     a.stream = D.stream_ptr()

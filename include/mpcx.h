@@ -207,6 +207,7 @@ typedef struct
   const int32_t* mpc_plan_ent;
   const int32_t* mpc_plan_pq;
   const double* mpc_plan_coef;
+  int32_t mpc_plan_group; /* lanes per target position: >= 16, >= 4 or one (pick ~ the average tuples per target) */
   void* stream;
 } mpcx_matrix_args_t;
 

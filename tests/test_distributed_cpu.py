@@ -382,3 +382,66 @@ def test_contact_two_body_partition_matches_global_assembly(oracle, tmp_path, wo
     assert ncells == case.mesh.num_cells and nsl == mpc.num_local_slaves
     assert abs(A - Aref).max() < 1e-12 * abs(Aref).max()
     assert np.allclose(b, bref, rtol=0, atol=1e-12 * max(1.0, abs(bref).max()))
+
+
+def _rccl_worker(rank, world, outdir, n):
+    """strong-scaling Poisson on `world` GPUs, HIP kernels, exchange over RCCL (backend "nccl")"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd.distributed import SlabExchange, create_box_slab
+
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", init_method=f"file://{outdir}/rendezvous", rank=rank, world_size=world,
+                            device_id=torch.device("cuda", rank))
+    mesh = create_box_slab((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), (n, n, n), rank, world, 2, (4, 4, 4))
+    V, bcs, raw, a, L = _strong_problem(mesh, "poisson")
+    mpc = dm.MultiPointConstraint(V)
+    mpc.add_constraint(V, *raw)
+    mpc.finalize()
+    A = dm.assemble_matrix(a, mpc, bcs=bcs)
+    b = dm.assemble_vector(L, mpc)
+    dm.apply_lifting(b, [a], [bcs], mpc)
+    ex = SlabExchange(mesh, A.rowptr, A.cols, rank, world, device=torch.device("cuda", rank))
+    h1 = ex.reduce_matrix_begin(A)
+    h2 = ex.reduce_vector_begin(b)
+    ex.finish(h1)
+    ex.finish(h2)
+    torch.cuda.synchronize()
+    S = A.to_scipy()
+    g = mesh.node_global
+    nown = mesh.num_owned_nodes
+    Aown = S[:nown].tocoo()
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), row=g[Aown.row], col=g[Aown.col], val=Aown.data,
+             brow=g[:nown], bval=b.numpy()[:nown], nslaves=mpc.num_local_slaves, ncells=mesh.num_owned_cells)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_strong_scaling_partition_over_rccl(oracle, tmp_path):
+    """the exchange on backend "nccl" (RCCL over xGMI), one rank per GPU: needs at least two visible devices,
+    skipped on the single-GPU boxes (the gloo tests above cover the logic; this covers the transport)"""
+    import torch
+    import torch.multiprocessing as mp
+
+    from dolfinx_mpc_amd.mesh import create_unit_cube
+
+    world = min(torch.cuda.device_count(), 4)
+    if world < 2:
+        pytest.skip("needs >= 2 GPUs")
+    n = 12
+    mp.spawn(_rccl_worker, args=(world, str(tmp_path), n), nprocs=world, join=True)
+    gmesh = create_unit_cube(n, n, n)
+    V, bcs, raw, a, L = _strong_problem(gmesh, "poisson")
+    mpc = oracle.OracleMPC.from_raw(V, *raw)
+    Aref = oracle.assemble_matrix(a, mpc, bcs=bcs)
+    bref = oracle.assemble_vector(L, mpc)
+    oracle.apply_lifting(bref, [a], [bcs], mpc)
+    A, b, nsl, ncells = _gather(tmp_path, world, V.num_dofs)
+    assert ncells == gmesh.num_cells and nsl == mpc.num_local_slaves
+    assert abs(A - Aref).max() < 1e-12 * abs(Aref).max()
+    assert np.allclose(b, bref, rtol=0, atol=1e-12 * max(1.0, abs(bref).max()))

@@ -9,5 +9,5 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N = sys.argv[1] if len(sys.argv) > 1 else "256"
 config = sys.argv[2] if len(sys.argv) > 2 else "2"
-sys.exit(subprocess.call([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--n", N, "--steps", "1",
+sys.exit(subprocess.call([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--size", N, "--steps", "1",
                           "--warmup", "0", "--no-cpu-baseline", "--no-traffic"], env=dict(os.environ, MPCX_BENCH_CHILD="1")))
