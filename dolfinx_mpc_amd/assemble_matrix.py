@@ -604,40 +604,52 @@ def assemble_matrix(
     alg = _ALG[(algorithm or os.environ.get("MPCX_MATRIX_ALG", "auto")).lower()]
     if any(integ.kernel.form == 100 for integ in form.integrals):
         alg = 1  # imported UFCx kernels: generic per-entity kernels with device atomics
-    if alg == 0:
-        # "auto": LDS row blocks (each value written once) when a plan can be built for every
-        # integral, device atomics otherwise (rows with more than 255 column blocks, tiny LDS...)
-        alg = 2
-        try:
-            for i in range(len(form.integrals)):
-                _rowblock_plan(A, form, i, form.function_spaces[0])
-        except RuntimeError:
-            alg = 1
+    auto = alg == 0
+    if auto:
+        alg = 2  # LDS row blocks (clusters where they apply); device atomics if a plan cannot be built
 
     V0, V1 = form.function_spaces
     stream = D.stream_ptr()
-    zeroed = False
-    for i, integ in enumerate(form.integrals):
+    for integ in form.integrals:
         if integ.itype not in ("cell", "exterior_facet"):
             raise RuntimeError("Not implemented yet")  # cpp/assemble_matrix.cpp:658-659
-        if alg == 2 and (zeroed or integ.num_entities > 0):
-            # the first non-empty integral's row blocks overwrite every value: no memset pass (an empty
-            # integral launches nothing, so it must not count as having cleared a reused matrix)
-            store_mode = 0 if zeroed else 1
-            zeroed = True
-        else:
-            store_mode = 0
-            if not zeroed:
-                A.zeroEntries()  # python/src/dolfinx_mpc/assemble_matrix.py:51
+
+    def prepare(alg):
+        """argument blocks of every integral (plans are built / fetched here, nothing is launched)"""
+        calls, zeroed = [], False
+        for i, integ in enumerate(form.integrals):
+            if alg == 2 and (zeroed or integ.num_entities > 0):
+                # the first non-empty integral's row blocks overwrite every value: no memset pass (an empty
+                # integral launches nothing, so it must not count as having cleared a reused matrix)
+                store_mode = 0 if zeroed else 1
                 zeroed = True
-        a, _keep = matrix_args(form, i, A, mpc0, mpc1, bcs, alg, store_mode)
+                memset = False
+            else:
+                store_mode = 0
+                memset = not zeroed  # python/src/dolfinx_mpc/assemble_matrix.py:51
+                zeroed = True
+            a, keep = matrix_args(form, i, A, mpc0, mpc1, bcs, alg, store_mode)
+            calls.append((memset, a, keep))
+            if a.leftover is not None:
+                # cells outside any cluster: per-cell row-block kernel, ADDed; their master contributions are part
+                # of the call above (its plan covers every slave entity of the integral)
+                fl = _leftover_form(form, i, a.leftover)
+                al, kl = matrix_args(fl, 0, A, mpc0, mpc1, bcs, alg, 0, with_mpc_kernel=False, allow_cubes=False)
+                calls.append((False, al, kl))
+        return calls, zeroed
+
+    try:
+        calls, zeroed = prepare(alg)
+    except RuntimeError:
+        if not auto:
+            raise
+        # rows with more than 255 column blocks before an entity's column, tiny LDS ...: thread-per-entity atomics
+        alg = 1
+        calls, zeroed = prepare(alg)
+    for memset, a, _keep in calls:
+        if memset:
+            A.zeroEntries()
         _native.check(L.mpcx_assemble_matrix(C.byref(a)), "mpcx_assemble_matrix")
-        if a.leftover is not None:
-            # cells outside any cluster: per-cell row-block kernel, ADDed; their master contributions were part
-            # of the call above (its plan covers every slave entity of the integral)
-            fl = _leftover_form(form, i, a.leftover)
-            al, _kl = matrix_args(fl, 0, A, mpc0, mpc1, bcs, alg, 0, with_mpc_kernel=False, allow_cubes=False)
-            _native.check(L.mpcx_assemble_matrix(C.byref(al)), "mpcx_assemble_matrix")
     if not zeroed:
         A.zeroEntries()
 

@@ -1,20 +1,19 @@
 #!/bin/bash
-# Round-end evidence on the GPU box (run through gpurun): GPU tests, bench line, rocprofv3 kernel
-# trace of the same bench command, PMC passes (tools/collect_pmc.py).  Outputs under gpurun_out/;
-# copy the summaries into profiles/.
-set -x
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-if [ "$1" != "trace-only" ]; then
-  timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > gpurun_out/final_tests.txt
-  timeout 400 python bench.py 2>gpurun_out/final_bench.log | tail -1 > gpurun_out/final_bench.json
-fi
-cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/final_trace
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/final_trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/final_trace.log 2>&1
-DB=$(find /tmp/final_trace -name '*.db' | head -1)
-python $GRAFT_REPO_ROOT/tools/rocprof_summary.py $DB > $GRAFT_REPO_ROOT/gpurun_out/final_kernel_trace.txt 2>&1
-if [ "$1" != "trace-only" ]; then
-  timeout 1500 python $GRAFT_REPO_ROOT/tools/collect_pmc.py $GRAFT_REPO_ROOT/gpurun_out/pmc_final 256 > $GRAFT_REPO_ROOT/gpurun_out/final_pmc.log 2>&1
-  rm -f $GRAFT_REPO_ROOT/gpurun_out/pmc_final/*.db
-fi
+# Round evidence on the GPU box: driver-style bench lines for every config, the rocprofv3 kernel trace of the
+# default bench command, PMC counters of the config-2 kernels.  Outputs under gpurun_out/r02_final/.
+set -u
+OUT=gpurun_out/r02_final
+mkdir -p $OUT
+for c in 2 3 4 5; do
+  timeout 1200 python bench.py --config $c --steps 20 --warmup 3 > $OUT/bench_c$c.json 2> $OUT/bench_c$c.log
+  echo "config $c rc $?"
+done
+export TMPDIR=/tmp
+( cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/trace -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-traffic --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/bench_under_rocprof.json 2> /dev/null )
+python tools/rocprof_summary.py $(ls $OUT/trace/*results.db $OUT/trace/*/*results.db 2>/dev/null | head -1) > $OUT/kernel_trace.txt
+rm -rf $OUT/trace
+for c in 2 4; do
+  python tools/collect_pmc.py $OUT/pmc_c$c $( [ $c = 2 ] && echo 256 || echo 56 ) $c > /dev/null 2>&1
+  rm -f $OUT/pmc_c$c/*.db $OUT/pmc_c$c/*/*.db
+done
+ls -la $OUT
