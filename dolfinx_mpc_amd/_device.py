@@ -115,6 +115,12 @@ def integral_device(form: Form, i: int):
     integ: Integral = form.integrals[i]
     if key not in form._device:
         k = integ.kernel
+        # basis of a P2 source form at the rule's points (mpcx_kernel_t::qphi)
+        qphi = None
+        if k.form == 2 and k.degree == 2 and k.qwts.size > 0:
+            from .quadrature import lagrange_basis
+
+            qphi = _to_dev(lagrange_basis(form.mesh.cell_name, 2, k.qpts).reshape(-1), dev)
         # cell integral over cells 0..n-1 in order: the kernels skip the indirection (and nothing is uploaded)
         n = integ.entities.shape[0]
         ident = integ.itype == "cell" and n > 0 and int(integ.entities[0]) == 0 and int(integ.entities[-1]) == n - 1 and \
@@ -129,13 +135,14 @@ def integral_device(form: Form, i: int):
             "qwts": _to_dev(k.qwts.astype(np.float64), dev),
             "fqpts": _to_dev(k.fqpts.astype(np.float64).reshape(-1), dev),
             "fqwts": _to_dev(k.fqwts.astype(np.float64), dev),
+            "qphi": qphi,
         }
         d["entities_ptr"] = None if ident else d["entities"].data_ptr()
         d["kernel"] = _native.KernelT(
             k.form, k.celltype, k.degree, k.bs, k.degree1 or k.degree, k.bs1 or k.bs, k.fn_id, k.coeff_degree,
             int(k.qwts.size), int(k.fqwts.size),
             d["qpts"].data_ptr(), d["qwts"].data_ptr(), d["fqpts"].data_ptr(), d["fqwts"].data_ptr(),
-            ufcx_compile(k, form) if k.form == 100 else None,
+            ufcx_compile(k, form) if k.form == 100 else None, None if qphi is None else qphi.data_ptr(),
         )
         form._device[key] = d
     d = form._device[key]

@@ -33,6 +33,7 @@ class KernelT(C.Structure):
         ("fqpts", C.c_void_p),
         ("fqwts", C.c_void_p),
         ("ufcx", C.c_void_p),
+        ("qphi", C.c_void_p),
     ]
 
 

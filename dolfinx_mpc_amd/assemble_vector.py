@@ -21,10 +21,16 @@ _ALG = {"auto": 0, "atomic": 1, "rowblock": 2}
 VECTOR_BLOCK_ROWS = int(os.environ.get("MPCX_VECTOR_BLOCK_ROWS", 512))
 
 
-def _vector_plan(form: Form, i: int, V):
+# P2 with a tile-wise numbering and a many-point rule: large row blocks keep the halo (entities evaluated by more
+# than one block) small -- 24-point source on 160^3: hash kernel 3.30 ms, row blocks of 512 rows 3.65, 2048 2.50,
+# 4096 2.36, 8192 2.34, 12288 2.73
+VECTOR_BLOCK_ROWS_P2 = int(os.environ.get("MPCX_VECTOR_BLOCK_ROWS_P2", 4096))
+
+
+def _vector_plan(form: Form, i: int, V, rows: int = VECTOR_BLOCK_ROWS):
     """Row blocks of b and the entities touching each (mpcx_rowblock_plan_build on a
     one-entry-per-row pattern), cached per integral."""
-    key = ("vplan", i, VECTOR_BLOCK_ROWS)
+    key = ("vplan", i, rows)
     if key not in form._device:
         from .assemble_matrix import _block_lists_device, _block_ranges
 
@@ -34,7 +40,7 @@ def _vector_plan(form: Form, i: int, V):
         hints = None
         if V.dof_tile_offsets is not None:
             hints = np.ascontiguousarray(V.dof_tile_offsets.astype(np.int32) * V.dofmap.bs)
-        row0 = _block_ranges(nrows, rowptr, VECTOR_BLOCK_ROWS, VECTOR_BLOCK_ROWS, V.dofmap.bs, hints)
+        row0 = _block_ranges(nrows, rowptr, rows, rows, V.dofmap.bs, hints)
         nb = row0.size - 1
         dev = _native.require_gpu()
         t = _block_lists_device(row0, integ.num_entities, integ.estride, D.integral_device(form, i)["entities_ptr"],
@@ -88,10 +94,13 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
     # (P2 with a tile-wise numbering, 96^3: hash kernel 0.71 ms whatever the rule, row blocks 0.46 ms at
     # 4 points, 0.85 ms at 14)
     nq_max = 8 if (V.degree == 2 and V.dof_tile_offsets is not None) else 4
-    if (alg == 2 or (alg == 0 and nq <= nq_max)) and integ.num_entities > 0:
+    # scalar P2 source with the basis table (mpcx_kernel_t::qphi) on a tiled numbering: large row blocks win for any rule
+    p2_fast = (V.degree == 2 and V.dofmap.bs == 1 and V.dof_tile_offsets is not None and k.form == 2 and k.coeff_degree == 0
+               and integ.itype == "cell")
+    if (alg == 2 or (alg == 0 and (nq <= nq_max or p2_fast))) and integ.num_entities > 0:
         from .assemble_matrix import _masked_dofmap, _slave_entities
 
-        plan, pk = _vector_plan(form, i, V)
+        plan, pk = _vector_plan(form, i, V, VECTOR_BLOCK_ROWS_P2 if (p2_fast and nq > nq_max) else VECTOR_BLOCK_ROWS)
         md0 = _masked_dofmap(form, V, None, constraint, 0)  # slave flag only: bcs do not touch b here
         _, slave_ents = _slave_entities(form, i, constraint, constraint)
         a.algorithm = 2

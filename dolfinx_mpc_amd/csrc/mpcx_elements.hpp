@@ -595,9 +595,9 @@ struct ElementOp
     // coordinate) and moment sums S = sum f w, S_d = sum f w X_d, from which the four basis
     // integrals follow (l_0 = 1 - sum X_d): ~7 fp64 instructions less per quadrature point
     // than the generic loop below
-    if constexpr (FORM == MPCX_FORM_SOURCE && DEG0_ == 1)
+    if constexpr (FORM == MPCX_FORM_SOURCE && (DEG0_ == 1 || DEG0_ == 2))
     {
-      if (k.coeff_degree == 0)
+      if (k.coeff_degree == 0 && (DEG0_ == 1 || k.qphi != nullptr))
       {
         double J[3][TDIM];
 #pragma unroll
@@ -660,23 +660,37 @@ struct ElementOp
             }
             else
               f = wq * eval_fn(FN_ >= 0 ? FN_ : k.fn_id, x, b, c);
-            S[b] += f;
+            if constexpr (DEG0_ == 1)
+            {
+              S[b] += f;
 #pragma unroll
-            for (int d = 0; d < TDIM; ++d)
-              SX[b][d] = fma(f, X[d], SX[b][d]);
+              for (int d = 0; d < TDIM; ++d)
+                SX[b][d] = fma(f, X[d], SX[b][d]);
+            }
+            else
+            {
+              // P2: the basis values at the point are kernel data (kernel.qphi: wave-uniform scalar loads, so
+              // every product below is one fma with an SGPR operand)
+#pragma unroll
+              for (int i = 0; i < ND0; ++i)
+                A[i * BS0 + b] = fma(f, k.qphi[q * ND0 + i], A[i * BS0 + b]);
+            }
           }
         }
-#pragma unroll
-        for (int b = 0; b < BS0; ++b)
+        if constexpr (DEG0_ == 1)
         {
-          double s0 = S[b];
 #pragma unroll
-          for (int d = 0; d < TDIM; ++d)
+          for (int b = 0; b < BS0; ++b)
           {
-            s0 -= SX[b][d];
-            A[(d + 1) * BS0 + b] = SX[b][d];
+            double s0 = S[b];
+#pragma unroll
+            for (int d = 0; d < TDIM; ++d)
+            {
+              s0 -= SX[b][d];
+              A[(d + 1) * BS0 + b] = SX[b][d];
+            }
+            A[b] = s0;
           }
-          A[b] = s0;
         }
         return;
       }

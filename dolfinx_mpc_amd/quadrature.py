@@ -114,3 +114,14 @@ def make_quadrature(cell_name: str, degree: int):
 
 def facet_cell_name(cell_name: str) -> str:
     return {"tetrahedron": "triangle", "triangle": "interval"}[cell_name]
+
+
+def lagrange_basis(cell: str, degree: int, pts: np.ndarray) -> np.ndarray:
+    """values (npts, nd) of the scalar Lagrange P1/P2 basis at reference points, in the dof order of the element
+    kernels: vertices, then (P2) edges -- tets (2,3)(1,3)(1,2)(0,3)(0,2)(0,1), triangles (1,2)(0,2)(0,1)"""
+    pts = np.asarray(pts, dtype=np.float64).reshape(-1, 3 if cell == "tetrahedron" else 2)
+    lam = np.concatenate([1.0 - pts.sum(axis=1, keepdims=True), pts], axis=1)
+    if degree == 1:
+        return lam
+    edges = [(2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1)] if cell == "tetrahedron" else [(1, 2), (0, 2), (0, 1)]
+    return np.concatenate([lam * (2.0 * lam - 1.0)] + [4.0 * lam[:, [a]] * lam[:, [b]] for a, b in edges], axis=1)

@@ -78,6 +78,8 @@ typedef struct
   const double* fqpts; /* DEVICE [nqf][tdim-1] */
   const double* fqwts; /* DEVICE [nqf] */
   const void* ufcx;    /* form == MPCX_FORM_UFCX: handle from mpcx_ufcx_compile; NULL otherwise */
+  const double* qphi;  /* DEVICE [nq][nd] values of the test space's scalar basis at the cell rule's points, or NULL:
+                        * lets the P2 source kernel take its basis from scalar loads instead of re-evaluating it */
 } mpcx_kernel_t;
 
 /* ------------------------------------------------------------------------
