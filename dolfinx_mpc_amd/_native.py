@@ -292,7 +292,7 @@ def lib() -> C.CDLL:
     L.mpcx_mask_dofmap.restype = C.c_int
     L.mpcx_scatter_offsets.argtypes = [vp, vp, i32, i64, vp, vp, vp, i32, i32, vp, i32, i32, i32, vp, vp, vp]
     L.mpcx_scatter_offsets.restype = C.c_int
-    L.mpcx_cube_records.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.mpcx_cube_records.argtypes = [i64, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
     L.mpcx_cube_records.restype = C.c_int
     L.mpcx_cube_detect.argtypes = [vp, i64, vp, vp, vp]
     L.mpcx_cube_detect.restype = C.c_int

@@ -303,8 +303,9 @@ def _cube_eligible(form: Form, i: int, V0) -> bool:
     """scalar P1 stiffness on tetrahedra without coefficient, over cells 0..n-1 (MPCX_ALG_CUBE)"""
     integ = form.integrals[i]
     k = integ.kernel
-    return (k.form == 0 and k.celltype == 2 and k.degree == 1 and k.bs == 1 and (k.degree1 or 1) == 1
-            and (k.bs1 or 1) == 1 and k.coeff_degree == 0 and integ.coefficient is None and integ.itype == "cell"
+    shape_ok = k.form == 0 and k.bs == 1
+    return (shape_ok and k.celltype == 2 and k.degree == 1 and (k.degree1 or 1) == 1 and (k.bs1 or k.bs) == k.bs
+            and k.coeff_degree == 0 and integ.coefficient is None and integ.itype == "cell"
             and not os.environ.get("MPCX_NO_CUBE"))
 
 
@@ -328,14 +329,17 @@ def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc):
         hints = None
         if V0.dof_tile_offsets is not None:
             hints = np.ascontiguousarray(V0.dof_tile_offsets.astype(np.int32))
-        row0 = _block_ranges(A.shape[0], A.rowptr, CUBE_MAX_ROWS, CUBE_MAX_NNZ, 1, hints)
+        bs = V0.dofmap.bs
+        if hints is not None:
+            hints = np.ascontiguousarray(hints * bs)
+        row0 = _block_ranges(A.shape[0], A.rowptr, CUBE_MAX_ROWS, CUBE_MAX_NNZ, bs, hints)
         nb = row0.size - 1
-        d_row0, d_off, d_ents = _block_lists_device(row0, nc, 1, None, d_verts, 8, 1, dev)
+        d_row0, d_off, d_ents = _block_lists_device(row0, nc, 1, None, d_verts, 8, bs, dev)
         nslots = d_ents.numel()
         recs = torch.empty(nslots * 96, dtype=torch.uint8, device=dev)
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         _, t = mpc._device()
-        rc = L.mpcx_cube_records(nslots, d_ents.data_ptr(), d_verts.data_ptr(), D.ptr(bc_dev), t["is_slave"].data_ptr(),
+        rc = L.mpcx_cube_records(nslots, d_ents.data_ptr(), d_verts.data_ptr(), bs, D.ptr(bc_dev), t["is_slave"].data_ptr(),
                                  A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), recs.data_ptr(), flag.data_ptr(), D.stream_ptr())
         _native.check(rc, "mpcx_cube_records")
         if int(flag.item()) != 0:

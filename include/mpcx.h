@@ -235,11 +235,11 @@ int mpcx_scatter_offsets(const mpcx_nnz_t* rowptr, const int32_t* cols, int32_t 
                          int32_t rotate, uint8_t* ent_offs, int32_t* overflow, void* stream);
 
 /* Set-up for MPCX_ALG_CUBE (all pointers DEVICE): recs[k] (96 bytes: 8 x int32 vertex id with the Dirichlet /
- * slave mask in bit 28, then 64 x uint8 offsets [a][b] of column v[b] inside CSR row v[a] for the 46 coupled
- * vertex pairs) for every slot k of the row-block plan built over the clusters (mpcx_rowblock_plan_build with
+ * slave mask of component c in bit 28 + c, then 64 x uint8 offsets [a][b] of column block v[b] inside the CSR rows
+ * of block v[a], counted in blocks, for the 46 coupled vertex pairs; bs = block size of the space, 1..3) for every slot k of the row-block plan built over the clusters (mpcx_rowblock_plan_build with
  * dofmap0 = cube_verts, nd0 = 8): block_ents[k] is the cluster of slot k.  *overflow is set if an offset does
  * not fit 8 bits or a column is missing. */
-int mpcx_cube_records(int64_t n_slots, const int32_t* block_ents, const int32_t* cube_verts, const int8_t* bc,
+int mpcx_cube_records(int64_t n_slots, const int32_t* block_ents, const int32_t* cube_verts, int32_t bs, const int8_t* bc,
                       const int8_t* is_slave, const mpcx_nnz_t* rowptr, const int32_t* cols, void* recs,
                       int32_t* overflow, void* stream);
 
