@@ -24,7 +24,7 @@ VECTOR_BLOCK_ROWS = int(os.environ.get("MPCX_VECTOR_BLOCK_ROWS", 512))
 # P2 with a tile-wise numbering and a many-point rule: large row blocks keep the halo (entities evaluated by more
 # than one block) small -- 24-point source on 160^3: hash kernel 3.30 ms, row blocks of 512 rows 3.65, 2048 2.50,
 # 4096 2.36, 8192 2.34, 12288 2.73
-VECTOR_BLOCK_ROWS_P2 = int(os.environ.get("MPCX_VECTOR_BLOCK_ROWS_P2", 4096))
+VECTOR_BLOCK_ROWS_P2 = int(os.environ.get("MPCX_VECTOR_BLOCK_ROWS_P2", 8192))
 
 
 def _vector_plan(form: Form, i: int, V, rows: int = VECTOR_BLOCK_ROWS):
@@ -95,7 +95,7 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
     # 4 points, 0.85 ms at 14)
     nq_max = 8 if (V.degree == 2 and V.dof_tile_offsets is not None) else 4
     # scalar P2 source with the basis table (mpcx_kernel_t::qphi) on a tiled numbering: large row blocks win for any rule
-    p2_fast = (V.degree == 2 and V.dofmap.bs == 1 and V.dof_tile_offsets is not None and k.form == 2 and k.coeff_degree == 0
+    p2_fast = (V.degree == 2 and V.dof_tile_offsets is not None and k.form == 2 and k.coeff_degree == 0
                and integ.itype == "cell")
     if (alg == 2 or (alg == 0 and (nq <= nq_max or p2_fast))) and integ.num_entities > 0:
         from .assemble_matrix import _masked_dofmap, _slave_entities
