@@ -227,6 +227,11 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False):
     light = lean and V0.dofmap.bs == 1 and V0.element_ndofs <= 4
     max_rows_cap, max_nnz_cap = ((ROWBLOCK_LIGHT_MAX_ROWS, ROWBLOCK_LIGHT_MAX_NNZ) if light
                                  else (ROWBLOCK_MAX_ROWS, ROWBLOCK_MAX_NNZ))
+    kf = form.integrals[i].kernel
+    if kf.form in (0, 1, 4) and V0.dofmap.bs > 1 and not os.environ.get("MPCX_NO_DIAG_COMPACT"):
+        # component-diagonal forms on blocked spaces: the kernel keeps one LDS value per column block, so a
+        # workgroup owns bs times more rows (include/mpcx.h, matrix_rowblock_kernel)
+        max_rows_cap, max_nnz_cap = max_rows_cap * V0.dofmap.bs, max_nnz_cap * V0.dofmap.bs
     def build():
         L = _native.lib()
         p = _native._ptr

@@ -474,13 +474,18 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
   const int nrow = r1 - r0;
   const int64_t nnz0 = a.rowptr[r0];
   const int nnzb = int(a.rowptr[r1] - nnz0);
-  double* s_vals = reinterpret_cast<double*>(smem);                        // [max_nnz]
-  int32_t* s_rowlo = reinterpret_cast<int32_t*>(s_vals + a.plan.max_nnz); // [max_rows]
+  // Component-diagonal forms on blocked spaces (S (x) I: vector stiffness / mass, Stokes a00) only ever touch the
+  // (k, k) entry of a BS x BS block: LDS keeps ONE value per column block of every scalar row (CW = BS1 times fewer
+  // entries, so a workgroup owns BS1 times more rows and the halo shrinks) and the structural zeros are produced
+  // when the block is written out.
+  constexpr int CW = Op::DIAG ? BS1 : 1;
+  double* s_vals = reinterpret_cast<double*>(smem);                             // [max_nnz / CW]
+  int32_t* s_rowlo = reinterpret_cast<int32_t*>(s_vals + a.plan.max_nnz / CW); // [max_rows]
 
-  for (int i = tid; i < nnzb; i += NT)
+  for (int i = tid; i < nnzb / CW; i += NT)
     s_vals[i] = 0.0;
   for (int rl = tid; rl < nrow; rl += NT)
-    s_rowlo[rl] = int(a.rowptr[r0 + rl] - nnz0);
+    s_rowlo[rl] = int(a.rowptr[r0 + rl] - nnz0) / CW;
   __syncthreads();
 
   // per-entity index data: everything that is read through the entity index
@@ -592,7 +597,7 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
 #pragma unroll
         for (int j = 0; j < ND1; ++j)
         {
-          const int off = int((E.ow[(i * ND1 + j) >> 2] >> (8 * ((i * ND1 + j) & 3))) & 0xff) * BS1;
+          const int off = int((E.ow[(i * ND1 + j) >> 2] >> (8 * ((i * ND1 + j) & 3))) & 0xff) * (BS1 / CW);
 #pragma unroll
           for (int q = 0; q < BS1; ++q)
           {
@@ -608,7 +613,8 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
               v = Op::entry(lz, i, k, j, q);
             else
               v = Op::get(Ae, i * BS0 + k, j * BS1 + q);
-            __hip_atomic_fetch_add(s_vals + base + off + q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(s_vals + base + off + (Op::DIAG ? 0 : q), v, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
           }
         }
       }
@@ -656,7 +662,28 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
   }
   __syncthreads();
   // one coalesced write of the finished block
-  if (a.store_mode)
+  if constexpr (Op::DIAG)
+  {
+    // expand: scalar row r = (node, k) holds (k, k) of every column block; a wave takes whole rows
+    const int wave = tid >> 6, lane = tid & 63, nwaves = NT >> 6;
+    for (int rl = wave; rl < nrow; rl += nwaves)
+    {
+      const int k = (r0 + rl) % BS0;
+      const int64_t p0 = a.rowptr[r0 + rl];
+      const int len = int(a.rowptr[r0 + rl + 1] - p0);
+      const double* src = s_vals + s_rowlo[rl];
+      for (int e = lane; e < len; e += 64)
+      {
+        const int q = e % BS1;
+        const double v = (q == k) ? src[e / BS1] : 0.0;
+        if (a.store_mode)
+          a.vals[p0 + e] = v;
+        else if (q == k)
+          a.vals[p0 + e] += v;
+      }
+    }
+  }
+  else if (a.store_mode)
     for (int i = tid; i < nnzb; i += NT)
       a.vals[nnz0 + i] = s_vals[i];
   else
@@ -1240,7 +1267,8 @@ int launch_matrix(const mpcx_matrix_args_t& a)
         mpcx_set_error("mpcx_assemble_matrix: row-block plan lacks the scatter-offset table (mpcx_scatter_offsets)");
         return -5;
       }
-      const size_t lds = size_t(a.plan.max_nnz) * 8 + size_t(a.plan.max_rows) * 4;
+      // component-diagonal forms keep one value per column block (see the kernel): BS1 times less LDS per row
+      const size_t lds = size_t(a.plan.max_nnz / (Op::DIAG ? Op::BS1 : 1)) * 8 + size_t(a.plan.max_rows) * 4;
       if (lds > 160 * 1024)
       {
         mpcx_set_error("mpcx_assemble_matrix: row-block plan exceeds 160 KiB of LDS");
