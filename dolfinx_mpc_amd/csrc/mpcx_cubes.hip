@@ -246,12 +246,6 @@ __global__ void __launch_bounds__(CUBE_MAX_THREADS) matrix_cube_kernel(mpcx_matr
   const int nnzb = int(a.rowptr[r1] - nnz0);
   double* s_vals = reinterpret_cast<double*>(smem);
   int32_t* s_rowlo = reinterpret_cast<int32_t*>(s_vals + a.plan.max_nnz);
-  for (int i = tid; i < nnzb; i += NT)
-    s_vals[i] = 0.0;
-  for (int rl = tid; rl < nrow; rl += NT)
-    s_rowlo[rl] = int(a.rowptr[r0 + rl] - nnz0);
-  __syncthreads();
-
   const double c0 = a.constants ? a.constants[0] : 1.0;
   const CubeRec* __restrict__ recs = static_cast<const CubeRec*>(a.cube_recs);
   const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
@@ -281,6 +275,7 @@ __global__ void __launch_bounds__(CUBE_MAX_THREADS) matrix_cube_kernel(mpcx_matr
   uint4 cur[6], nxt[6];
   double X[8][3], Xn[8][3];
   int64_t t = e0 + tid;
+  // the first records and coordinates travel while the block's LDS copy is cleared
   if (t < e1)
   {
     load(t, cur);
@@ -288,6 +283,11 @@ __global__ void __launch_bounds__(CUBE_MAX_THREADS) matrix_cube_kernel(mpcx_matr
       load(t + NT, nxt);
     gather(cur, X);
   }
+  for (int i = tid; i < nnzb; i += NT)
+    s_vals[i] = 0.0;
+  for (int rl = tid; rl < nrow; rl += NT)
+    s_rowlo[rl] = int(a.rowptr[r0 + rl] - nnz0);
+  __syncthreads();
   for (; t < e1; t += NT)
   {
     const int32_t v[8] = {int32_t(cur[0].x), int32_t(cur[0].y), int32_t(cur[0].z), int32_t(cur[0].w),
