@@ -390,3 +390,57 @@ def test_periodic_builder_drops_whole_blocks_under_a_bc():
     right = np.flatnonzero(np.isclose(x[:, 0], 1))
     expect = np.sort(np.concatenate([b * 2 + np.arange(2) for b in right if b != top_right[0]]))
     assert np.array_equal(mpc.slaves, expect)
+
+
+def test_cell_cluster_detection():
+    """clusters.kuhn_fans: six consecutive cells with the fan's vertex pattern; anything else is a leftover"""
+    from dolfinx_mpc_amd.clusters import kuhn_fans
+    from dolfinx_mpc_amd.distributed import create_box_slab
+    from dolfinx_mpc_amd.mesh import create_unit_cube
+
+    for mesh in (create_unit_cube(3, 4, 2), create_unit_cube(5, 5, 5, reorder=(2, 2, 2)),
+                 create_box_slab((0, 0, 0), (1, 1, 1), (4, 4, 5), 1, 2, 2, (2, 2, 2))):
+        verts, left = kuhn_fans(mesh.geometry.dofmap, mesh.num_owned_cells)
+        assert left.size == 0 and verts.shape == (mesh.num_owned_cells // 6, 8)
+        # the eight vertices of a fan are the corners of one cube: their coordinates span a box of volume h^3
+        x = mesh.geometry.x[verts]
+        ext = x.max(axis=1) - x.min(axis=1)
+        assert np.allclose(ext.prod(axis=1), ext[0].prod())
+        # cell t of fan g uses exactly the vertices of the pattern
+        pattern = np.array([[0, 1, 3, 7], [0, 1, 7, 5], [0, 5, 7, 4], [0, 3, 2, 7], [0, 6, 4, 7], [0, 2, 6, 7]])
+        cells = mesh.geometry.dofmap[: mesh.num_owned_cells].reshape(-1, 6, 4)
+        assert np.array_equal(np.take_along_axis(verts[:, None, :].repeat(6, 1), pattern[None].repeat(verts.shape[0], 0), 2), cells)
+    mesh = create_unit_cube(3, 3, 3)
+    cells = mesh.geometry.dofmap.copy()
+    cells[[7, 8]] = cells[[8, 7]]  # wrong order inside group 1
+    cells[13] = cells[13][[1, 0, 3, 2]]  # permuted vertices inside group 2
+    verts, left = kuhn_fans(cells, 100)  # 16 full groups + 4 trailing cells
+    assert verts.shape[0] == 14 and sorted(left.tolist()) == list(range(6, 18)) + [96, 97, 98, 99]
+
+
+def test_lagrange_basis_tables():
+    from dolfinx_mpc_amd.quadrature import lagrange_basis, make_quadrature
+
+    for cell, nd in (("tetrahedron", {1: 4, 2: 10}), ("triangle", {1: 3, 2: 6})):
+        q, w = make_quadrature(cell, 4)
+        for deg, n in nd.items():
+            phi = lagrange_basis(cell, deg, q)
+            assert phi.shape == (q.shape[0], n)
+            assert np.allclose(phi.sum(axis=1), 1.0)  # partition of unity
+        # P2 vertex functions integrate to -|T|/20 (tet) / 0 (triangle), edge functions to |T|/5 / |T|/3
+        phi = lagrange_basis(cell, 2, q)
+        vol = w.sum()
+        nv = 4 if cell == "tetrahedron" else 3
+        assert np.allclose(w @ phi[:, :nv], -vol / 20 if cell == "tetrahedron" else 0.0, atol=1e-15)
+        assert np.allclose(w @ phi[:, nv:], vol / 5 if cell == "tetrahedron" else vol / 3)
+
+
+def test_allcore_cpu_baseline_adds_up():
+    """oracle/cpu_parallel.py (bench.py's all-core leg): the slabs' private matrices, reduced by the owners, equal the
+    single-thread assembly (asserted inside for small N)"""
+    from oracle import cpu_parallel
+
+    r = cpu_parallel.main(10, 3, 1)
+    assert r["cores"] == 3 and r["value"] > 0
+    r = cpu_parallel.main(6, 2, 2)
+    assert r["cores"] == 2 and "P2" in r["sample"]
