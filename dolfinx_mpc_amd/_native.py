@@ -296,7 +296,7 @@ def lib() -> C.CDLL:
     L.mpcx_cube_records.restype = C.c_int
     L.mpcx_cube_detect.argtypes = [vp, i64, vp, vp, vp]
     L.mpcx_cube_detect.restype = C.c_int
-    L.mpcx_rowblock_pairs_device.argtypes = [i64, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+    L.mpcx_rowblock_pairs_device.argtypes = [i64, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]
     L.mpcx_rowblock_pairs_device.restype = C.c_int
     L.mpcx_rowblock_plan_build.argtypes = [i32, vp, i32, i32, i64, i32, vp, vp, i32, i32, vp, i32, i32]
     L.mpcx_rowblock_plan_build.restype = vp

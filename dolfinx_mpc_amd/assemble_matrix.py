@@ -190,10 +190,12 @@ def _block_ranges(nrows: int, rowptr: np.ndarray, max_rows: int, max_nnz: int, b
     return row0
 
 
-def _block_lists_device(row0: np.ndarray, n_entities: int, estride: int, entities_ptr, dofmap_dev, nd: int, bs: int, dev):
+def _block_lists_device(row0: np.ndarray, n_entities: int, estride: int, entities_ptr, dofmap_dev, nd: int, bs: int, dev,
+                        group_rows: bool = False, rotate: bool = False):
     """entities touching every row block, built on the device (mpcx_rowblock_pairs_device: count -> scan -> fill
     in entity order, then a stable sort by block: torch, plumbing).  Returns (block_row0, block_ent_off, block_ents)
-    device tensors; the lists are ordered by entity inside each block, like the host builder's."""
+    device tensors; the lists are ordered by entity inside each block, like the host builder's, or (group_rows) by
+    the set of local rows the entity has inside the block, then by entity."""
     import torch
 
     L = _native.lib()
@@ -202,21 +204,29 @@ def _block_lists_device(row0: np.ndarray, n_entities: int, estride: int, entitie
     d_row0 = D._to_dev(row0, dev)
     counts = torch.empty(max(n_entities, 1), dtype=torch.int32, device=dev)
     args = (n_entities, estride, entities_ptr, dofmap_dev.data_ptr(), nd, bs, nb, d_row0.data_ptr(), counts.data_ptr())
-    _native.check(L.mpcx_rowblock_pairs_device(*args, None, None, None, st), "mpcx_rowblock_pairs_device")
+    _native.check(L.mpcx_rowblock_pairs_device(*args, None, None, None, None, 0, st), "mpcx_rowblock_pairs_device")
     c64 = counts[:n_entities].to(torch.int64)
     offsets = torch.cumsum(c64, 0) - c64
     total = int(c64.sum().item()) if n_entities else 0
     pair_block = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
     pair_ent = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+    pair_rows = torch.empty(max(total, 1), dtype=torch.int32, device=dev) if group_rows else None
     if total:
-        _native.check(L.mpcx_rowblock_pairs_device(*args, offsets.data_ptr(), pair_block.data_ptr(), pair_ent.data_ptr(), st),
-                      "mpcx_rowblock_pairs_device")
+        _native.check(L.mpcx_rowblock_pairs_device(*args, offsets.data_ptr(), pair_block.data_ptr(), pair_ent.data_ptr(),
+                                                   D.ptr(pair_rows), int(rotate), st), "mpcx_rowblock_pairs_device")
     pair_block, pair_ent = pair_block[:total], pair_ent[:total]
     per_block = torch.bincount(pair_block, minlength=nb) if total else torch.zeros(nb, dtype=torch.int64, device=dev)
     off = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
     torch.cumsum(per_block, 0, out=off[1:])
     if total:
-        _, order = torch.sort(pair_block, stable=True)
+        if group_rows:
+            # entities that keep the same local rows next to each other: a wave then skips the rows of dofs outside
+            # the block as a whole instead of issuing their scatter-adds with most lanes masked off
+            key = (pair_block.to(torch.int64) << nd) | (pair_rows[:total].to(torch.int64) & ((1 << nd) - 1))
+            _, order = torch.sort(key, stable=True)
+            del key
+        else:
+            _, order = torch.sort(pair_block, stable=True)
         ents = pair_ent[order].contiguous()
     else:
         ents = pair_ent
@@ -228,7 +238,12 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False):
     max_rows_cap, max_nnz_cap = ((ROWBLOCK_LIGHT_MAX_ROWS, ROWBLOCK_LIGHT_MAX_NNZ) if light
                                  else (ROWBLOCK_MAX_ROWS, ROWBLOCK_MAX_NNZ))
     kf = form.integrals[i].kernel
+    # entities of a block ordered by which of their local rows lie inside it (measured: P1 elasticity 1.82 -> 1.49 ms,
+    # Taylor-Hood coupling blocks 2.0 -> 1.8, P2 stiffness +1.5 %; the light P1 kernel loses its coordinate locality,
+    # 2.07 -> 2.81 ms, and the compact component-diagonal layout 2.5 %: both keep entity order)
+    group_rows = not light and not os.environ.get("MPCX_NO_GROUP_ROWS")
     if kf.form in (0, 1, 4) and V0.dofmap.bs > 1 and not os.environ.get("MPCX_NO_DIAG_COMPACT"):
+        group_rows = False
         # component-diagonal forms on blocked spaces: the kernel keeps one LDS value per column block, so a
         # workgroup owns bs times more rows (include/mpcx.h, matrix_rowblock_kernel)
         max_rows_cap, max_nnz_cap = max_rows_cap * V0.dofmap.bs, max_nnz_cap * V0.dofmap.bs
@@ -262,7 +277,8 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False):
             row0 = _block_ranges(A.shape[0], A.rowptr, max_rows_cap, max_nnz_cap, V0.dofmap.bs, hints)
             nb = row0.size - 1
             lists = _block_lists_device(row0, integ.num_entities, integ.estride, D.integral_device(form, i)["entities_ptr"],
-                                        D.space_device(V0)["dofmap"], V0.element_ndofs, V0.dofmap.bs, dev)
+                                        D.space_device(V0)["dofmap"], V0.element_ndofs, V0.dofmap.bs, dev,
+                                        group_rows=group_rows, rotate=lean)
         # 8-bit scatter offsets of every (entity, local row, local col), built on the device
         import torch
 
@@ -301,7 +317,7 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False):
                        "max_nnz": max_nnz, "offset_patterns": npat,
                        "bytes": int(sum(x.numel() * x.element_size() for x in t if x is not None))})
 
-    return D.cached(A._plans, "rowblock", (form,), (i, max_nnz_cap, max_rows_cap, lean), build)
+    return D.cached(A._plans, "rowblock", (form,), (i, max_nnz_cap, max_rows_cap, lean, group_rows), build)
 
 
 def _cube_eligible(form: Form, i: int, V0) -> bool:

@@ -148,13 +148,14 @@ __global__ void rowblock_pairs_kernel(int64_t n_entities, int estride, const int
                                       const int32_t* __restrict__ dofmap0, int nd0, int bs0, int num_blocks,
                                       const int32_t* __restrict__ block_row0, int32_t* __restrict__ counts,
                                       const int64_t* __restrict__ offsets, int32_t* __restrict__ pair_block,
-                                      int32_t* __restrict__ pair_ent)
+                                      int32_t* __restrict__ pair_ent, int32_t* __restrict__ pair_rows, int rotate)
 {
   const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (e >= n_entities)
     return;
   const int64_t cell = entities0 ? entities0[e * estride] : e;
   int32_t seen[32];
+  uint32_t rows[32]; // bit i: local dof i has its rows in block seen[k]
   int ns = 0;
   for (int i = 0; i < nd0 && i < 32; ++i)
   {
@@ -168,11 +169,20 @@ __global__ void rowblock_pairs_kernel(int64_t n_entities, int estride, const int
       else
         hi = mid;
     }
+    // position of local dof i in the order the kernel lists it (lean path: rotated_local, mpcx_kernels.hip)
+    const uint32_t bit = 1u << (rotate ? int((i + nd0 - cell % nd0) % nd0) : i);
     bool dup = false;
     for (int k = 0; k < ns; ++k)
-      dup |= seen[k] == lo;
+      if (seen[k] == lo)
+      {
+        dup = true;
+        rows[k] |= bit;
+      }
     if (!dup)
+    {
+      rows[ns] = bit;
       seen[ns++] = lo;
+    }
   }
   if constexpr (!FILL)
     counts[e] = ns;
@@ -183,6 +193,8 @@ __global__ void rowblock_pairs_kernel(int64_t n_entities, int estride, const int
     {
       pair_block[base + k] = seen[k];
       pair_ent[base + k] = int32_t(e);
+      if (pair_rows)
+        pair_rows[base + k] = int32_t(rows[k]);
     }
   }
 }
@@ -555,7 +567,8 @@ extern "C" int mpcx_cube_detect(const int32_t* cells, int64_t n_groups, int32_t*
 extern "C" int mpcx_rowblock_pairs_device(int64_t n_entities, int32_t estride, const int32_t* entities0,
                                           const int32_t* dofmap0, int32_t nd0, int32_t bs0, int32_t num_blocks,
                                           const int32_t* block_row0, int32_t* counts, const int64_t* offsets,
-                                          int32_t* pair_block, int32_t* pair_ent, void* stream)
+                                          int32_t* pair_block, int32_t* pair_ent, int32_t* pair_rows, int32_t rotate,
+                                          void* stream)
 {
   if (n_entities == 0)
     return 0;
@@ -568,10 +581,10 @@ extern "C" int mpcx_rowblock_pairs_device(int64_t n_entities, int32_t estride, c
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (!offsets)
     hipLaunchKernelGGL(mpcx::rowblock_pairs_kernel<false>, grid, dim3(256), 0, st, n_entities, estride, entities0, dofmap0,
-                       nd0, bs0, num_blocks, block_row0, counts, offsets, pair_block, pair_ent);
+                       nd0, bs0, num_blocks, block_row0, counts, offsets, pair_block, pair_ent, pair_rows, rotate);
   else
     hipLaunchKernelGGL(mpcx::rowblock_pairs_kernel<true>, grid, dim3(256), 0, st, n_entities, estride, entities0, dofmap0,
-                       nd0, bs0, num_blocks, block_row0, counts, offsets, pair_block, pair_ent);
+                       nd0, bs0, num_blocks, block_row0, counts, offsets, pair_block, pair_ent, pair_rows, rotate);
   return mpcx::check(hipGetLastError(), "rowblock_pairs launch");
 }
 

@@ -267,46 +267,48 @@ __global__ void __launch_bounds__(64) matrix_mpc_plan_small_kernel(mpcx_matrix_a
   a.vals[a.mpc_plan_tgt[t]] += sum;
 }
 
-template <class Op, int G> // G lanes share one target position
+template <class Op, int G, bool USE_LAZY> // G lanes share one target position
 __global__ void __launch_bounds__(64) matrix_mpc_plan_kernel(mpcx_matrix_args_t a)
 {
   // Larger element tensors (vector P1: 144 entries, P2: 100-900): a group of G lanes takes one target position
   // and strides over its tuples (17 on average, up to ~150 for the contact benchmark: one thread per target left
   // the longest list on the critical path; 3-4 for slip walls, where G = 4: the caller passes G = the average list
   // length rounded to 1 / 4 / 16), each lane evaluating its entry straight from the compact per-cell
-  // context where the operator has one (Op::prepare / Op::entry: a few dozen flops instead of a full element
-  // tensor in scratch memory); the partial sums are combined with a shuffle reduction.
+  // context where the operator has one (USE_LAZY, Op::prepare / Op::entry: a few dozen flops instead of a full
+  // element tensor in scratch memory); the partial sums are combined with a shuffle reduction.
+  // The entry index is a run-time value here, so the context is indexed dynamically: it lives in LDS (one slot
+  // per lane).  Left in a local array it went to scratch memory -- 104 bytes written to HBM per tuple, 4.8 GB
+  // per launch on the contact benchmark, which made this kernel HBM-bound on its own spills -- and sharing a
+  // kernel with the full-tensor branch cost the lazy one the registers of both (369 VGPRs, one wave per SIMD).
   constexpr int NV = Op::NV, N1 = Op::N1, BS0 = Op::BS0, BS1 = Op::BS1;
   const int lane = threadIdx.x & (G - 1);
   const int64_t t = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
   if (t >= a.mpc_plan_targets)
     return; // the whole group leaves together
-  bool lazy = false;
-  if constexpr (Op::LAZY)
-    lazy = Op::lazy_applies(a.kernel);
+  [[maybe_unused]] __shared__ typename Op::Lazy s_lz[USE_LAZY ? 64 : 1];
   double sum = 0.0;
   for (int64_t k = a.mpc_plan_off[t] + lane; k < a.mpc_plan_off[t + 1]; k += G)
   {
     const int64_t e = a.mpc_plan_ent[k];
     const int64_t l = e * a.estride;
     const int64_t cell = (a.entities ? a.entities[l] : e);
-    const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
     double cd[NV * 3];
     gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
     const int pq = a.mpc_plan_pq[k];
     const int p = pq / N1, q = pq % N1;
     double v = 0.0;
-    if (lazy)
+    if constexpr (USE_LAZY)
     {
-      if constexpr (Op::LAZY)
       {
         typename Op::Lazy lz;
         Op::prepare(lz, a.constants, cd);
-        v = Op::entry(lz, p / BS0, p % BS0, q / BS1, q % BS1);
+        s_lz[threadIdx.x] = lz;
       }
+      v = Op::entry(s_lz[threadIdx.x], p / BS0, p % BS0, q / BS1, q % BS1);
     }
     else
     {
+      const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
       double Ae[Op::SIZE];
       Op::tabulate(Ae, a.coeffs ? a.coeffs + e * a.cstride : nullptr, a.constants, cd, lf, a.kernel);
       v = Op::get(Ae, p, q);
@@ -1350,12 +1352,24 @@ int launch_matrix(const mpcx_matrix_args_t& a)
         static const bool force_big = std::getenv("MPCX_PLAN_KERNEL_BIG") != nullptr;
         if (Op::SIZE <= 36 && !force_big)
           hipLaunchKernelGGL(matrix_mpc_plan_small_kernel<Op>, dim3(grid_for(a.mpc_plan_targets, 64)), dim3(64), 0, stream, a);
-        else if (a.mpc_plan_group >= 16)
-          hipLaunchKernelGGL((matrix_mpc_plan_kernel<Op, 16>), dim3(grid_for(a.mpc_plan_targets * 16, 64)), dim3(64), 0, stream, a);
-        else if (a.mpc_plan_group >= 4)
-          hipLaunchKernelGGL((matrix_mpc_plan_kernel<Op, 4>), dim3(grid_for(a.mpc_plan_targets * 4, 64)), dim3(64), 0, stream, a);
         else
-          hipLaunchKernelGGL((matrix_mpc_plan_kernel<Op, 1>), dim3(grid_for(a.mpc_plan_targets, 64)), dim3(64), 0, stream, a);
+        {
+          bool lazy = false;
+          if constexpr (Op::LAZY)
+            lazy = Op::lazy_applies(a.kernel);
+          const int g = a.mpc_plan_group >= 16 ? 16 : (a.mpc_plan_group >= 4 ? 4 : 1);
+          const dim3 grid(grid_for(a.mpc_plan_targets * g, 64));
+          auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(64), 0, stream, a); };
+          if constexpr (Op::LAZY)
+          {
+            if (lazy)
+              g == 16 ? go(matrix_mpc_plan_kernel<Op, 16, true>)
+                      : (g == 4 ? go(matrix_mpc_plan_kernel<Op, 4, true>) : go(matrix_mpc_plan_kernel<Op, 1, true>));
+          }
+          if (!lazy)
+            g == 16 ? go(matrix_mpc_plan_kernel<Op, 16, false>)
+                    : (g == 4 ? go(matrix_mpc_plan_kernel<Op, 4, false>) : go(matrix_mpc_plan_kernel<Op, 1, false>));
+        }
       }
     }
     else

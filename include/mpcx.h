@@ -250,10 +250,14 @@ int mpcx_cube_detect(const int32_t* cells, int64_t n_groups, int32_t* verts, int
 /* The entity lists of a row-block plan on the DEVICE (host version: second half of mpcx_rowblock_plan_build):
  * (block, entity) pairs in entity order; two calls like mpcx_mpc_plan_device (offsets == NULL: counts[e] =
  * number of distinct blocks entity e touches; then with the exclusive scan of counts: the pairs).  The caller
- * sorts the pairs by block (stable) to get block_ents / block_ent_off.  block_row0 [num_blocks + 1] DEVICE. */
+ * sorts the pairs by block (stable) to get block_ents / block_ent_off.  block_row0 [num_blocks + 1] DEVICE.
+ * pair_rows (optional): bit i set = local dof i of the entity has its rows inside the pair's block; entities of a
+ * block ordered by this word make the lanes of a wave skip the same local rows together (rotate != 0: bits in
+ * the rotated local order of the lean path, mpcx_mask_dofmap). */
 int mpcx_rowblock_pairs_device(int64_t n_entities, int32_t estride, const int32_t* entities0, const int32_t* dofmap0,
                                int32_t nd0, int32_t bs0, int32_t num_blocks, const int32_t* block_row0, int32_t* counts,
-                               const int64_t* offsets, int32_t* pair_block, int32_t* pair_ent, void* stream);
+                               const int64_t* offsets, int32_t* pair_block, int32_t* pair_ent, int32_t* pair_rows,
+                               int32_t rotate, void* stream);
 
 /* vals[pos(d,d)] += diagval for d in dofs.  Replaces the slave-diagonal loop
  * of cpp/assemble_matrix.cpp:711-724 and dolfinx insert_diagonal called at
