@@ -64,6 +64,7 @@ class RowBlockPlanT(C.Structure):
         ("num_blocks", C.c_int32),
         ("max_rows", C.c_int32),
         ("max_nnz", C.c_int32),
+        ("row_pairs", C.c_int32),
         ("block_row0", C.c_void_p),
         ("block_ent_off", C.c_void_p),
         ("block_ents", C.c_void_p),

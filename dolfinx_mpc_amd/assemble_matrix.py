@@ -233,7 +233,52 @@ def _block_lists_device(row0: np.ndarray, n_entities: int, estride: int, entitie
     return d_row0, off, ents
 
 
-def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False):
+def _block_pairs_device(row0: np.ndarray, n_entities: int, estride: int, entities_dev, dofmap_dev, nd: int, bs: int, dev):
+    """(entity, local row dof) pairs of every row block for the row-pair kernel (include/mpcx.h,
+    mpcx_rowblock_plan_t::row_pairs), built on the device with torch (plumbing: gather, searchsorted, two sorts).
+    Pair (e, i) belongs to the block that holds the rows of dof i of entity e, so every pair appears exactly once.
+    Inside a block the pairs are ordered by local row i (a wave runs one unrolled row body), then round-robin over
+    the row dofs (rank of the pair among the pairs of its dof, then dof), so neighbouring lanes add into different
+    CSR rows.  Returns (block_row0, block_pair_off, pair ids = e * nd + i as int32)."""
+    import torch
+
+    nb = row0.size - 1
+    d_row0 = D._to_dev(row0, dev)
+    if n_entities * nd >= 2 ** 31:
+        raise RuntimeError("row-pair plan: entity * nd + i does not fit 32 bits")
+    if entities_dev is None:
+        dof = dofmap_dev[:n_entities].reshape(-1)
+    else:
+        dof = dofmap_dev[entities_dev.view(n_entities, estride)[:, 0].long()].reshape(-1)
+    M = dof.numel()
+    if M == 0:
+        return (d_row0, torch.zeros(nb + 1, dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.int32, device=dev))
+    blk = torch.searchsorted(d_row0[1:].contiguous(), (dof * bs).contiguous(), right=True).to(torch.int64)
+    loc = dof.to(torch.int64) - (d_row0.to(torch.int64)[blk] // bs)  # dof inside its block: < 2^16 rows
+    li = torch.arange(M, device=dev, dtype=torch.int64) % nd
+    key = (blk << 40) | (li << 36) | loc
+    del li
+    key, order = torch.sort(key, stable=True)
+    _, counts = torch.unique_consecutive(key, return_counts=True)
+    starts = torch.cumsum(counts, 0) - counts
+    rank = torch.arange(M, device=dev, dtype=torch.int64) - torch.repeat_interleave(starts, counts)
+    del starts, counts
+    if int(rank.max().item()) >= 2 ** 12 or int(loc.max().item()) >= 2 ** 24:
+        raise RuntimeError("row-pair plan: more than 4096 entities round one dof")
+    del loc
+    key = (key & ~((1 << 36) - 1)) | (rank << 24) | (key & ((1 << 24) - 1))
+    del rank
+    _, order2 = torch.sort(key)
+    del key
+    ids = order[order2].to(torch.int32).contiguous()
+    del order, order2
+    per_block = torch.bincount(blk, minlength=nb)
+    off = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(per_block, 0, out=off[1:])
+    return d_row0, off, ids
+
+
+def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False, pairs: bool = False):
     light = lean and V0.dofmap.bs == 1 and V0.element_ndofs <= 4
     max_rows_cap, max_nnz_cap = ((ROWBLOCK_LIGHT_MAX_ROWS, ROWBLOCK_LIGHT_MAX_NNZ) if light
                                  else (ROWBLOCK_MAX_ROWS, ROWBLOCK_MAX_NNZ))
@@ -257,7 +302,12 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False):
         if V0.dof_tile_offsets is not None:
             hints = np.ascontiguousarray(V0.dof_tile_offsets.astype(np.int32) * V0.dofmap.bs)
         dev = A.device
-        if os.environ.get("MPCX_PLAN_LISTS", "device") == "host":
+        if pairs:
+            row0 = _block_ranges(A.shape[0], A.rowptr, max_rows_cap, max_nnz_cap, V0.dofmap.bs, hints)
+            nb = row0.size - 1
+            lists = _block_pairs_device(row0, integ.num_entities, integ.estride, D.integral_device(form, i)["entities"],
+                                        D.space_device(V0)["dofmap"], V0.element_ndofs, V0.dofmap.bs, dev)
+        elif os.environ.get("MPCX_PLAN_LISTS", "device") == "host":
             ents = np.ascontiguousarray(integ.entities.astype(np.int32).reshape(-1))
             h = L.mpcx_rowblock_plan_build(A.shape[0], p(A.rowptr), max_rows_cap, max_nnz_cap,
                                            integ.num_entities, integ.estride, p(ents), p(dm), dm.shape[1], V0.dofmap.bs,
@@ -311,13 +361,42 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False):
         t = lists + (offs, pattern)
         max_rows = int(np.diff(row0).max())
         max_nnz = int(np.diff(A.rowptr[row0]).max())
-        s = _native.RowBlockPlanT(nb, max_rows, max_nnz, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
+        s = _native.RowBlockPlanT(nb, max_rows, max_nnz, int(pairs), t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
                                   t[3].data_ptr(), D.ptr(pattern))
         return (s, t, {"num_blocks": nb, "num_ents": int(t[2].numel()), "max_rows": max_rows,
                        "max_nnz": max_nnz, "offset_patterns": npat,
                        "bytes": int(sum(x.numel() * x.element_size() for x in t if x is not None))})
 
-    return D.cached(A._plans, "rowblock", (form,), (i, max_nnz_cap, max_rows_cap, lean, group_rows), build)
+    return D.cached(A._plans, "rowblock", (form,), (i, max_nnz_cap, max_rows_cap, lean, group_rows, pairs), build)
+
+
+def _rowpair_eligible(form: Form, i: int, V0, V1) -> bool:
+    """Row-pair kernel (include/mpcx.h, mpcx_rowblock_plan_t::row_pairs): operators with a compact per-entity context
+    (csrc/mpcx_elements.hpp, ElementOp::LAZY / lazy_applies): cell integrals of stiffness without coefficient,
+    elasticity and the Taylor-Hood coupling blocks.  Chosen for vector-valued P1 only: there a 74 KB row block
+    holds ~70 nodes, two thirds of the lanes of a thread-per-cell block are masked off and the context is cheap
+    (contact elasticity 1.45 -> 0.96 ms).  P2 pays the context ten times per cell (P2 stiffness 246^3:
+    14.3 -> 22.6 ms; Taylor-Hood a00 unchanged, a01 1.9 -> 2.7 ms) and keeps thread-per-cell blocks;
+    MPCX_ROWPAIR=all forces it wherever the operator allows."""
+    mode = os.environ.get("MPCX_ROWPAIR", "auto")
+    if os.environ.get("MPCX_NO_ROWPAIR") or mode == "none":
+        return False
+    integ = form.integrals[i]
+    kf = integ.kernel
+    if integ.itype != "cell" or integ.coeffs is not None:
+        return False
+    d0, d1 = V0.degree, V1.degree
+    if mode != "all" and not (d0 == 1 and d1 == 1 and V0.dofmap.bs > 1):
+        return False
+    if kf.form == 0:
+        return kf.coeff_degree == 0 and d0 == d1 and d0 in (1, 2)
+    if kf.form == 3:
+        return d0 == d1 and d0 in (1, 2)
+    if kf.form == 6:
+        return kf.coeff_degree == 0 and d0 == 2 and d1 == 1
+    if kf.form == 7:
+        return kf.coeff_degree == 0 and d0 == 1 and d1 == 2
+    return False
 
 
 def _cube_eligible(form: Form, i: int, V0) -> bool:
@@ -368,7 +447,7 @@ def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc):
         keep = (d_row0, d_off, recs)
         max_rows = int(np.diff(row0).max())
         max_nnz = int(np.diff(A.rowptr[row0]).max())
-        plan = _native.RowBlockPlanT(nb, max_rows, max_nnz, keep[0].data_ptr(), keep[1].data_ptr(), None, None, None)
+        plan = _native.RowBlockPlanT(nb, max_rows, max_nnz, 0, keep[0].data_ptr(), keep[1].data_ptr(), None, None, None)
         info = {"num_blocks": nb, "num_ents": int(nslots), "max_rows": max_rows, "max_nnz": max_nnz,
                 "clusters": int(nc), "bytes": int(sum(x.numel() * x.element_size() for x in keep))}
         return (plan, keep, info)
@@ -583,7 +662,10 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
                 a.leftover = left if left.size else None
                 keep += [ck]
                 return a, keep
-        plan, pk, _info = _rowblock_plan(A, form, i, V0, lean)
+        pairs = _rowpair_eligible(form, i, V0, V1) and not (lean and V0.dofmap.bs == 1 and V0.element_ndofs <= 4)
+        if pairs:
+            lean = False  # the row-pair kernel reads the plain (unrotated) masked dofmaps
+        plan, pk, _info = _rowblock_plan(A, form, i, V0, lean, pairs)
         a.plan = plan
         a.lean = int(lean)
         md0 = _masked_dofmap(form, V0, bc0, mpc0, 0, lean)

@@ -46,7 +46,7 @@ def _vector_plan(form: Form, i: int, V, rows: int = VECTOR_BLOCK_ROWS):
         t = _block_lists_device(row0, integ.num_entities, integ.estride, D.integral_device(form, i)["entities_ptr"],
                                 D.space_device(V)["dofmap"], V.element_ndofs, V.dofmap.bs, dev)
         max_rows = int(np.diff(row0).max()) if nb > 0 else 0
-        plan = _native.RowBlockPlanT(nb, max_rows, max_rows, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
+        plan = _native.RowBlockPlanT(nb, max_rows, max_rows, 0, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
                                      None, None)
         form._device[key] = (plan, t)
     return form._device[key]

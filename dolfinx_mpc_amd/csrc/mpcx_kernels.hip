@@ -482,11 +482,11 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
   // when the block is written out.
   constexpr int CW = Op::DIAG ? BS1 : 1;
   double* s_vals = reinterpret_cast<double*>(smem);                             // [max_nnz / CW]
-  int32_t* s_rowlo = reinterpret_cast<int32_t*>(s_vals + a.plan.max_nnz / CW); // [max_rows]
+  int32_t* s_rowlo = reinterpret_cast<int32_t*>(s_vals + a.plan.max_nnz / CW); // [max_rows + 1]
 
   for (int i = tid; i < nnzb / CW; i += NT)
     s_vals[i] = 0.0;
-  for (int rl = tid; rl < nrow; rl += NT)
+  for (int rl = tid; rl <= nrow; rl += NT)
     s_rowlo[rl] = int(a.rowptr[r0 + rl] - nnz0) / CW;
   __syncthreads();
 
@@ -666,14 +666,135 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
   // one coalesced write of the finished block
   if constexpr (Op::DIAG)
   {
-    // expand: scalar row r = (node, k) holds (k, k) of every column block; a wave takes whole rows
+    // expand: scalar row r = (node, k) holds (k, k) of every column block; a wave takes whole rows (their bounds
+    // from the LDS copy: a dependent global load per row left the waves waiting on rowptr)
     const int wave = tid >> 6, lane = tid & 63, nwaves = NT >> 6;
     for (int rl = wave; rl < nrow; rl += nwaves)
     {
       const int k = (r0 + rl) % BS0;
-      const int64_t p0 = a.rowptr[r0 + rl];
-      const int len = int(a.rowptr[r0 + rl + 1] - p0);
-      const double* src = s_vals + s_rowlo[rl];
+      const int lo = s_rowlo[rl];
+      const int64_t p0 = nnz0 + int64_t(lo) * CW;
+      const int len = (s_rowlo[rl + 1] - lo) * CW;
+      const double* src = s_vals + lo;
+      for (int e = lane; e < len; e += 64)
+      {
+        const int q = e % BS1;
+        const double v = (q == k) ? src[e / BS1] : 0.0;
+        if (a.store_mode)
+          a.vals[p0 + e] = v;
+        else if (q == k)
+          a.vals[p0 + e] += v;
+      }
+    }
+  }
+  else if (a.store_mode)
+    for (int i = tid; i < nnzb; i += NT)
+      a.vals[nnz0 + i] = s_vals[i];
+  else
+    for (int i = tid; i < nnzb; i += NT)
+      a.vals[nnz0 + i] += s_vals[i];
+}
+
+// Row-pair variant of the row-block kernel (plan.row_pairs != 0): the unit of work is one (entity, local row dof)
+// pair whose rows lie inside the block, not one entity.  A thread-per-entity block evaluates every entity that
+// touches it and masks the rows outside, so with small blocks -- vector-valued and P2 spaces, where 74 KB of LDS
+// hold 70-110 nodes -- most lanes of most scatter instructions are idle (the halo factor R = 2.7-3 is paid in LDS
+// issue slots).  Here every lane owns rows it keeps: the entity context is recomputed per pair (cheaper than R
+// masked passes once R > ~1.5) and the pairs of a block are ordered by (local row, round-robin over row dofs), so
+// a wave runs ONE unrolled row body and its lanes add into different CSR rows (no same-address serialisation).
+// Operators with a compact context only (Op::prepare / Op::entry).
+template <class Op>
+__global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowpair_kernel(mpcx_matrix_args_t a)
+{
+  constexpr int ND0 = Op::ND0, ND1 = Op::ND1, BS0 = Op::BS0, BS1 = Op::BS1, NV = Op::NV;
+  const int NT = blockDim.x;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int nb = a.plan.num_blocks;
+  const int per = (nb + 7) >> 3;
+  const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (b >= nb)
+    return;
+  const int tid = threadIdx.x;
+  const int r0 = a.plan.block_row0[b], r1 = a.plan.block_row0[b + 1];
+  const int nrow = r1 - r0;
+  const int64_t nnz0 = a.rowptr[r0];
+  const int nnzb = int(a.rowptr[r1] - nnz0);
+  constexpr int CW = Op::DIAG ? BS1 : 1; // compact layout of component-diagonal forms, see matrix_rowblock_kernel
+  double* s_vals = reinterpret_cast<double*>(smem);
+  int32_t* s_rowlo = reinterpret_cast<int32_t*>(s_vals + a.plan.max_nnz / CW);
+  for (int i = tid; i < nnzb / CW; i += NT)
+    s_vals[i] = 0.0;
+  for (int rl = tid; rl <= nrow; rl += NT)
+    s_rowlo[rl] = int(a.rowptr[r0 + rl] - nnz0) / CW;
+  __syncthreads();
+
+  const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  const uint32_t* __restrict__ pairs = reinterpret_cast<const uint32_t*>(a.plan.block_ents);
+  for (int64_t t = e0 + tid; t < e1; t += NT)
+  {
+    const uint32_t id = pairs[t];
+    const int64_t e = id / uint32_t(ND0);
+    const int i = int(id - uint32_t(e) * uint32_t(ND0));
+    const int64_t l = e * a.estride;
+    const int64_t cell = (a.entities ? a.entities[l] : e);
+    const int64_t cell0 = (a.entities0 ? a.entities0[l] : e);
+    const int64_t cell1 = (a.entities1 ? a.entities1[l] : e);
+    const int32_t w0 = a.mdofmap0[cell0 * ND0 + i];
+    int32_t m1[ND1];
+#pragma unroll
+    for (int j = 0; j < ND1; ++j)
+      m1[j] = a.mdofmap1[cell1 * ND1 + j];
+    uint32_t off[ND1];
+    const uint8_t* po = a.plan.ent_offs + e * (ND0 * ND1) + i * ND1;
+#pragma unroll
+    for (int j = 0; j < ND1; ++j)
+      off[j] = po[j];
+    double cd[NV * 3];
+    gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
+    typename Op::Lazy lz;
+    Op::prepare(lz, a.constants, cd);
+#pragma unroll
+    for (int I = 0; I < ND0; ++I)
+    {
+      if (i != I)
+        continue;
+#pragma unroll
+      for (int k = 0; k < BS0; ++k)
+      {
+        if ((w0 >> (MPCX_MASK_SHIFT + k)) & 1)
+          continue;
+        const int base = s_rowlo[(w0 & MPCX_DOF_MASK) * BS0 + k - r0];
+#pragma unroll
+        for (int j = 0; j < ND1; ++j)
+        {
+#pragma unroll
+          for (int q = 0; q < BS1; ++q)
+          {
+            if constexpr (Op::DIAG)
+            {
+              if (k != q)
+                continue;
+            }
+            if ((m1[j] >> (MPCX_MASK_SHIFT + q)) & 1)
+              continue;
+            __hip_atomic_fetch_add(s_vals + base + int(off[j]) * (BS1 / CW) + (Op::DIAG ? 0 : q),
+                                   Op::entry(lz, I, k, j, q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if constexpr (Op::DIAG)
+  {
+    const int wave = tid >> 6, lane = tid & 63, nwaves = NT >> 6;
+    for (int rl = wave; rl < nrow; rl += nwaves)
+    {
+      const int k = (r0 + rl) % BS0;
+      const int lo = s_rowlo[rl];
+      const int64_t p0 = nnz0 + int64_t(lo) * CW;
+      const int len = (s_rowlo[rl + 1] - lo) * CW;
+      const double* src = s_vals + lo;
       for (int e = lane; e < len; e += 64)
       {
         const int q = e % BS1;
@@ -1270,7 +1391,7 @@ int launch_matrix(const mpcx_matrix_args_t& a)
         return -5;
       }
       // component-diagonal forms keep one value per column block (see the kernel): BS1 times less LDS per row
-      const size_t lds = size_t(a.plan.max_nnz / (Op::DIAG ? Op::BS1 : 1)) * 8 + size_t(a.plan.max_rows) * 4;
+      const size_t lds = size_t(a.plan.max_nnz / (Op::DIAG ? Op::BS1 : 1)) * 8 + size_t(a.plan.max_rows + 1) * 4;
       if (lds > 160 * 1024)
       {
         mpcx_set_error("mpcx_assemble_matrix: row-block plan exceeds 160 KiB of LDS");
@@ -1301,12 +1422,33 @@ int launch_matrix(const mpcx_matrix_args_t& a)
           // the pipelined small-element loop on full-size blocks: P1 stiffness 1.96 -> 1.81 ms (P2 and elasticity
           // lose with 768); the host picks half-size blocks for that kernel, four 512-thread workgroups per CU
           threads = (attr.numRegs <= 64 && Op::ND0 * Op::ND1 <= 16 && a.plan.max_rows > 256) ? 768 : 512;
+          if (a.plan.row_pairs && attr.numRegs <= 64)
+            threads = 1024; // light threads, many more of them than entities: contact elasticity 1.02 -> 0.96 ms
         }
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, stream, a);
         return 0;
       };
       constexpr bool CAN_LEAN = Op::SQUARE && !Op::FACET && Op::NV == Op::ND0;
       const bool lean = a.lean != 0;
+      if (a.plan.row_pairs)
+      {
+        bool ok = false;
+        if constexpr (Op::LAZY)
+          ok = Op::lazy_applies(a.kernel) && !a.plan.ent_pattern && !a.coeffs;
+        if (!ok)
+        {
+          mpcx_set_error("mpcx_assemble_matrix: a row-pair plan needs an operator with a compact context "
+                         "(stiffness without coefficient, elasticity, Taylor-Hood blocks) and a direct offset table");
+          return -8;
+        }
+        if constexpr (Op::LAZY)
+        {
+          if (int rc = launch(matrix_rowpair_kernel<Op>))
+            return rc;
+        }
+      }
+      else
+      {
       if (lean)
       {
         bool ok = false;
@@ -1335,6 +1477,7 @@ int launch_matrix(const mpcx_matrix_args_t& a)
         rc = launch(matrix_rowblock_kernel<Op, false, false>);
       if (rc)
         return rc;
+      }
     }
     else
     {

@@ -124,6 +124,10 @@ typedef struct
   int32_t num_blocks;
   int32_t max_rows;             /* max rows per block */
   int32_t max_nnz;              /* max nnz per block  */
+  /* 0: block_ents lists the entities touching the block (thread per entity, rows outside the block masked).
+   * 1: block_ents lists (entity, local row dof) pairs as entity * nd0 + i, only those whose rows lie in the
+   *    block (thread per pair; operators with a compact context only: matrix_rowpair_kernel) */
+  int32_t row_pairs;
   const int32_t* block_row0;    /* DEVICE [num_blocks + 1] first row of block */
   const int64_t* block_ent_off; /* DEVICE [num_blocks + 1] into block_ents */
   const int32_t* block_ents;    /* DEVICE entity indices touching the block */

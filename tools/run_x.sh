@@ -1,0 +1,12 @@
+run() { echo "== $*"; env "$@" python bench.py --config $C --no-traffic --no-cpu-baseline --steps 10 --warmup 3 2>&1 | python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print(d['value'], d['ms_per_step'], [(k['kernel'][:40], round(k['launch_ms'],3), round(k['hbm_frac'],3)) for k in d.get('roofline_kernels',[])][:6], d['one_shot']['first_call_s'], d['one_shot']['plan_bytes'])
+    elif 'Error' in l or 'error' in l: print(l.rstrip())
+"; }
+C=4 run MPCX_ROWBLOCK_MAX_NNZ=4608 MPCX_ROWBLOCK_MAX_ROWS=256
+C=4 run MPCX_ROWBLOCK_MAX_NNZ=6144 MPCX_ROWBLOCK_MAX_ROWS=384
+C=4 run MPCX_ROWBLOCK_MAX_NNZ=13824 MPCX_ROWBLOCK_MAX_ROWS=768
+C=3 run MPCX_ROWPAIR=all MPCX_ROWBLOCK_MAX_NNZ=4608 MPCX_ROWBLOCK_MAX_ROWS=256
+C=3 run MPCX_ROWBLOCK_MAX_NNZ=4608 MPCX_ROWBLOCK_MAX_ROWS=256
