@@ -110,6 +110,7 @@ class MatrixArgs(C.Structure):
         ("mdofmap1", C.c_void_p),
         ("lean", C.c_int32),
         ("cube_recs", C.c_void_p),
+        ("slot_mask", C.c_void_p),
         ("mpc_plan_targets", C.c_int64),
         ("mpc_plan_tgt", C.c_void_p),
         ("mpc_plan_off", C.c_void_p),
@@ -192,6 +193,7 @@ EXPORTS = [
     "mpcx_cube_records",
     "mpcx_cube_detect",
     "mpcx_rowblock_pairs_device",
+    "mpcx_diag_slot_mask",
     "mpcx_add_diagonal",
     "mpcx_assemble_vector",
     "mpcx_apply_lifting",
@@ -299,6 +301,8 @@ def lib() -> C.CDLL:
     L.mpcx_cube_detect.restype = C.c_int
     L.mpcx_rowblock_pairs_device.argtypes = [i64, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]
     L.mpcx_rowblock_pairs_device.restype = C.c_int
+    L.mpcx_diag_slot_mask.argtypes = [i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.mpcx_diag_slot_mask.restype = C.c_int
     L.mpcx_rowblock_plan_build.argtypes = [i32, vp, i32, i32, i64, i32, vp, vp, i32, i32, vp, i32, i32]
     L.mpcx_rowblock_plan_build.restype = vp
     L.mpcx_rowblock_plan_num_blocks.argtypes = [vp]

@@ -278,7 +278,35 @@ def _block_pairs_device(row0: np.ndarray, n_entities: int, estride: int, entitie
     return d_row0, off, ids
 
 
-def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False, pairs: bool = False):
+def _diag_blocked(form: Form, i: int, V0, V1) -> bool:
+    """component-diagonal operator on a blocked space (S (x) I: stiffness, mass, facet mass)"""
+    return form.integrals[i].kernel.form in (0, 1, 4) and V0.dofmap.bs > 1 and V1.dofmap.bs == V0.dofmap.bs
+
+
+def _slot_mask(A: MPCMatrix, form: Form, V0, V1, bc0, bc1, mpc0, mpc1):
+    """mpcx_matrix_args_t::slot_mask of the node-block kernel: one byte per bs x bs block of A, bit k = the (k, k)
+    entry lies in a Dirichlet / slave row or column.  None if A is not made of whole blocks."""
+    import torch
+
+    def build():
+        bs = V0.dofmap.bs
+        L = _native.lib()
+        if A.shape[0] % bs or A.nnz % (bs * bs):
+            return None
+        out = torch.zeros(max(A.nnz // (bs * bs), 1), dtype=torch.uint8, device=A.device)
+        bad = torch.zeros(1, dtype=torch.int32, device=A.device)
+        _, k0 = mpc0._device()
+        _, k1 = mpc1._device()
+        rc = L.mpcx_diag_slot_mask(A.shape[0] // bs, A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), bs, D.ptr(bc0),
+                                   k0["is_slave"].data_ptr(), D.ptr(bc1), k1["is_slave"].data_ptr(), out.data_ptr(),
+                                   bad.data_ptr(), D.stream_ptr())
+        _native.check(rc, "mpcx_diag_slot_mask")
+        return None if int(bad.item()) else out
+
+    return D.cached(A._plans, "slot_mask", (V0, V1, mpc0, mpc1, bc0, bc1), 0, build, maxsize=4)
+
+
+def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False, pairs: bool = False, nodeblock: bool = False):
     light = lean and V0.dofmap.bs == 1 and V0.element_ndofs <= 4
     max_rows_cap, max_nnz_cap = ((ROWBLOCK_LIGHT_MAX_ROWS, ROWBLOCK_LIGHT_MAX_NNZ) if light
                                  else (ROWBLOCK_MAX_ROWS, ROWBLOCK_MAX_NNZ))
@@ -287,7 +315,11 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False, pai
     # Taylor-Hood coupling blocks 2.0 -> 1.8, P2 stiffness +1.5 %; the light P1 kernel loses its coordinate locality,
     # 2.07 -> 2.81 ms, and the compact component-diagonal layout 2.5 %: both keep entity order)
     group_rows = not light and not os.environ.get("MPCX_NO_GROUP_ROWS")
-    if kf.form in (0, 1, 4) and V0.dofmap.bs > 1 and not os.environ.get("MPCX_NO_DIAG_COMPACT"):
+    if nodeblock:
+        # component-diagonal forms, node-block kernel: one LDS value per bs x bs block (matrix_nodeblock_kernel)
+        group_rows = True
+        max_rows_cap, max_nnz_cap = max_rows_cap * V0.dofmap.bs, max_nnz_cap * V0.dofmap.bs ** 2
+    elif kf.form in (0, 1, 4) and V0.dofmap.bs > 1 and not os.environ.get("MPCX_NO_DIAG_COMPACT"):
         group_rows = False
         # component-diagonal forms on blocked spaces: the kernel keeps one LDS value per column block, so a
         # workgroup owns bs times more rows (include/mpcx.h, matrix_rowblock_kernel)
@@ -367,7 +399,7 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False, pai
                        "max_nnz": max_nnz, "offset_patterns": npat,
                        "bytes": int(sum(x.numel() * x.element_size() for x in t if x is not None))})
 
-    return D.cached(A._plans, "rowblock", (form,), (i, max_nnz_cap, max_rows_cap, lean, group_rows, pairs), build)
+    return D.cached(A._plans, "rowblock", (form,), (i, max_nnz_cap, max_rows_cap, lean, group_rows, pairs, nodeblock), build)
 
 
 def _rowpair_eligible(form: Form, i: int, V0, V1) -> bool:
@@ -665,7 +697,15 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
         pairs = _rowpair_eligible(form, i, V0, V1) and not (lean and V0.dofmap.bs == 1 and V0.element_ndofs <= 4)
         if pairs:
             lean = False  # the row-pair kernel reads the plain (unrotated) masked dofmaps
-        plan, pk, _info = _rowblock_plan(A, form, i, V0, lean, pairs)
+        smask = None
+        if (not pairs and not (lean and V0.dofmap.bs == 1) and _diag_blocked(form, i, V0, V1)
+                and not os.environ.get("MPCX_NO_NODEBLOCK") and not os.environ.get("MPCX_OFFSET_DICT")):
+            smask = _slot_mask(A, form, V0, V1, bc0, bc1, mpc0, mpc1)
+        if smask is not None:
+            lean = False
+            a.slot_mask = smask.data_ptr()
+            keep += [smask]
+        plan, pk, _info = _rowblock_plan(A, form, i, V0, lean, pairs, smask is not None)
         a.plan = plan
         a.lean = int(lean)
         md0 = _masked_dofmap(form, V0, bc0, mpc0, 0, lean)

@@ -695,6 +695,170 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
       a.vals[nnz0 + i] += s_vals[i];
 }
 
+// Node-block variant for component-diagonal forms on blocked spaces (S (x) I: vector stiffness / mass, the
+// Taylor-Hood velocity block), used when the caller passes slot_mask.  The bs component rows of a node hold the
+// same scalar value in their (k, k) entries unless a Dirichlet / slave mask zeroes one of them, so LDS keeps ONE
+// value per (row node, column node) slot: ND0 * ND1 scatter-adds per entity instead of bs times that, a workgroup
+// owns bs^2 times more nodes for the same LDS than with the scalar layout (bs times more than with the compact
+// per-row layout above) and the halo shrinks accordingly.  The bs x bs blocks, their structural zeros and the
+// masked entries are produced when the block is written out: slot_mask[slot] bit k = "entry (k, k) of this
+// block is zero" (mpcx_diag_slot_mask).  The masked dofmaps are read for their dof ids only.
+template <class Op, bool USE_LAZY>
+__global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_nodeblock_kernel(mpcx_matrix_args_t a)
+{
+  constexpr int ND0 = Op::ND0, ND1 = Op::ND1, BS = Op::BS0, NV = Op::NV;
+  constexpr int NOFF = ND0 * ND1;
+  static_assert(Op::DIAG && Op::BS0 == Op::BS1, "component-diagonal operator expected");
+  const int NT = blockDim.x;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int nb = a.plan.num_blocks;
+  const int per = (nb + 7) >> 3;
+  const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (b >= nb)
+    return;
+  const int tid = threadIdx.x;
+  const int r0 = a.plan.block_row0[b], r1 = a.plan.block_row0[b + 1];
+  const int n0 = r0 / BS, nn = (r1 - r0) / BS; // node rows of the block
+  const int64_t nnz0 = a.rowptr[r0];
+  const int slots = int((a.rowptr[r1] - nnz0) / (BS * BS));
+  double* s_vals = reinterpret_cast<double*>(smem);                                     // [max_nnz / BS^2]
+  int32_t* s_rowlo = reinterpret_cast<int32_t*>(s_vals + a.plan.max_nnz / (BS * BS)); // [max_rows / BS + 1]
+  for (int i = tid; i < slots; i += NT)
+    s_vals[i] = 0.0;
+  for (int nl = tid; nl <= nn; nl += NT)
+    s_rowlo[nl] = int((a.rowptr[int64_t(n0 + nl) * BS] - nnz0) / (BS * BS));
+  // most blocks hold no Dirichlet / slave dof at all: they write their values out without looking at the masks
+  // (a global load inside the store loop put its latency on every row)
+  const int64_t gslot0 = nnz0 / (BS * BS);
+  int any = 0;
+  for (int i = tid; i < slots; i += NT)
+    any |= a.slot_mask[gslot0 + i];
+  const bool masked_block = __syncthreads_or(any) != 0;
+
+  const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  const int32_t* __restrict__ ents = a.plan.block_ents;
+  for (int64_t t = e0 + tid; t < e1; t += NT)
+  {
+    const int64_t e = ents[t];
+    const int64_t l = e * a.estride;
+    const int64_t cell = (a.entities ? a.entities[l] : e);
+    const int64_t cell0 = (a.entities0 ? a.entities0[l] : e);
+    const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
+    int32_t m0[ND0];
+#pragma unroll
+    for (int i = 0; i < ND0; ++i)
+      m0[i] = a.mdofmap0[cell0 * ND0 + i] & MPCX_DOF_MASK;
+    uint32_t ow[(NOFF + 3) / 4];
+    const uint8_t* po = a.plan.ent_offs + e * NOFF;
+    if constexpr (NOFF % 4 == 0)
+    {
+#pragma unroll
+      for (int w = 0; w < NOFF / 4; ++w)
+        ow[w] = reinterpret_cast<const uint32_t*>(po)[w];
+    }
+    else
+    {
+#pragma unroll
+      for (int w = 0; w < (NOFF + 3) / 4; ++w)
+      {
+        uint32_t u = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (4 * w + q < NOFF)
+            u |= uint32_t(po[4 * w + q]) << (8 * q);
+        ow[w] = u;
+      }
+    }
+    double cd[NV * 3];
+    gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
+    double Ae[USE_LAZY ? 1 : Op::SIZE];
+    typename Op::Lazy lz;
+    if constexpr (USE_LAZY)
+      Op::prepare(lz, a.constants, cd);
+    else
+      Op::tabulate(Ae, a.coeffs ? a.coeffs + e * a.cstride : nullptr, a.constants, cd, lf, a.kernel);
+#pragma unroll
+    for (int i = 0; i < ND0; ++i)
+    {
+      const int nl = m0[i] - n0;
+      if (nl < 0 || nl >= nn)
+        continue;
+      const int base = s_rowlo[nl];
+#pragma unroll
+      for (int j = 0; j < ND1; ++j)
+      {
+        const int off = int((ow[(i * ND1 + j) >> 2] >> (8 * ((i * ND1 + j) & 3))) & 0xff);
+        double v;
+        if constexpr (USE_LAZY)
+          v = Op::entry(lz, i, 0, j, 0);
+        else
+          v = Ae[i * ND1 + j];
+        __hip_atomic_fetch_add(s_vals + base + off, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+  __syncthreads();
+  // expand: a wave takes whole scalar rows (node nl, component k); row k of a node starts k * L * BS entries after
+  // row 0 (L = column blocks of the node's rows).  (A wave per node -- BS * BS * L contiguous entries, 98 % of the
+  // lanes busy instead of 66 % -- measured slower: 12.6 against 10.9 ms on the Taylor-Hood velocity block.)
+  const int wave = tid >> 6, lane = tid & 63, nwaves = NT >> 6;
+  for (int rl = wave; rl < nn * BS; rl += nwaves)
+  {
+    const int nl = rl / BS, k = rl - nl * BS;
+    const int lo = s_rowlo[nl];
+    const int len = (s_rowlo[nl + 1] - lo) * BS;
+    const int64_t p0 = nnz0 + int64_t(lo) * (BS * BS) + int64_t(k) * len;
+    for (int e = lane; e < len; e += 64)
+    {
+      const int sl = e / BS, q = e - sl * BS;
+      const bool keep = q == k && !(masked_block && ((a.slot_mask[gslot0 + lo + sl] >> k) & 1));
+      const double v = keep ? s_vals[lo + sl] : 0.0;
+      if (a.store_mode)
+        a.vals[p0 + e] = v;
+      else if (keep)
+        a.vals[p0 + e] += v;
+    }
+  }
+}
+
+// set-up for the node-block kernel: one thread per node row
+__global__ void diag_slot_mask_kernel(int32_t n_nodes, const mpcx_nnz_t* __restrict__ rowptr,
+                                      const int32_t* __restrict__ cols, int bs, const int8_t* __restrict__ bc0,
+                                      const int8_t* __restrict__ slave0, const int8_t* __restrict__ bc1,
+                                      const int8_t* __restrict__ slave1, uint8_t* __restrict__ out, int32_t* bad)
+{
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_nodes)
+    return;
+  const int64_t p = rowptr[int64_t(n) * bs];
+  const int64_t len = rowptr[int64_t(n) * bs + 1] - p;
+  bool ok = len % bs == 0 && p % (int64_t(bs) * bs) == 0;
+  for (int k = 1; k < bs; ++k)
+    ok &= rowptr[int64_t(n) * bs + k + 1] - rowptr[int64_t(n) * bs + k] == len;
+  if (!ok)
+  {
+    *bad = 1;
+    return;
+  }
+  unsigned rm = 0;
+  for (int k = 0; k < bs; ++k)
+    rm |= unsigned((bc0 && bc0[int64_t(n) * bs + k]) || (slave0 && slave0[int64_t(n) * bs + k])) << k;
+  const int64_t slot0 = p / (int64_t(bs) * bs);
+  for (int64_t sl = 0; sl < len / bs; ++sl)
+  {
+    const int32_t c = cols[p + sl * bs]; // first column of the block
+    if (c % bs != 0)
+    {
+      *bad = 1;
+      return;
+    }
+    unsigned m = rm;
+    for (int k = 0; k < bs; ++k)
+      m |= unsigned((bc1 && bc1[c + k]) || (slave1 && slave1[c + k])) << k;
+    out[slot0 + sl] = uint8_t(m);
+  }
+}
+
 // Row-pair variant of the row-block kernel (plan.row_pairs != 0): the unit of work is one (entity, local row dof)
 // pair whose rows lie inside the block, not one entity.  A thread-per-entity block evaluates every entity that
 // touches it and masks the rows outside, so with small blocks -- vector-valued and P2 spaces, where 74 KB of LDS
@@ -1391,7 +1555,8 @@ int launch_matrix(const mpcx_matrix_args_t& a)
         return -5;
       }
       // component-diagonal forms keep one value per column block (see the kernel): BS1 times less LDS per row
-      const size_t lds = size_t(a.plan.max_nnz / (Op::DIAG ? Op::BS1 : 1)) * 8 + size_t(a.plan.max_rows + 1) * 4;
+      const size_t lds = a.slot_mask ? size_t(a.plan.max_nnz / (Op::BS0 * Op::BS1)) * 8 + size_t(a.plan.max_rows / Op::BS0 + 1) * 4
+                                     : size_t(a.plan.max_nnz / (Op::DIAG ? Op::BS1 : 1)) * 8 + size_t(a.plan.max_rows + 1) * 4;
       if (lds > 160 * 1024)
       {
         mpcx_set_error("mpcx_assemble_matrix: row-block plan exceeds 160 KiB of LDS");
@@ -1422,7 +1587,7 @@ int launch_matrix(const mpcx_matrix_args_t& a)
           // the pipelined small-element loop on full-size blocks: P1 stiffness 1.96 -> 1.81 ms (P2 and elasticity
           // lose with 768); the host picks half-size blocks for that kernel, four 512-thread workgroups per CU
           threads = (attr.numRegs <= 64 && Op::ND0 * Op::ND1 <= 16 && a.plan.max_rows > 256) ? 768 : 512;
-          if (a.plan.row_pairs && attr.numRegs <= 64)
+          if ((a.plan.row_pairs && attr.numRegs <= 64) || a.slot_mask)
             threads = 1024; // light threads, many more of them than entities: contact elasticity 1.02 -> 0.96 ms
         }
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, stream, a);
@@ -1430,7 +1595,34 @@ int launch_matrix(const mpcx_matrix_args_t& a)
       };
       constexpr bool CAN_LEAN = Op::SQUARE && !Op::FACET && Op::NV == Op::ND0;
       const bool lean = a.lean != 0;
-      if (a.plan.row_pairs)
+      if (a.slot_mask)
+      {
+        if constexpr (Op::DIAG && Op::BS0 == Op::BS1)
+        {
+          if (a.plan.row_pairs || a.plan.ent_pattern || a.entities0 != a.entities || a.entities1 != a.entities)
+          {
+            mpcx_set_error("mpcx_assemble_matrix: slot_mask (node-block kernel) needs a plain entity plan and a "
+                           "direct offset table");
+            return -8;
+          }
+          bool lazy = false;
+          if constexpr (Op::LAZY)
+            lazy = Op::lazy_applies(a.kernel);
+          int rc = 0;
+          if constexpr (Op::LAZY)
+            rc = lazy ? launch(matrix_nodeblock_kernel<Op, true>) : launch(matrix_nodeblock_kernel<Op, false>);
+          else
+            rc = launch(matrix_nodeblock_kernel<Op, false>);
+          if (rc)
+            return rc;
+        }
+        else
+        {
+          mpcx_set_error("mpcx_assemble_matrix: slot_mask given for an operator that is not component-diagonal");
+          return -8;
+        }
+      }
+      else if (a.plan.row_pairs)
       {
         bool ok = false;
         if constexpr (Op::LAZY)
@@ -1770,6 +1962,17 @@ extern "C" int mpcx_homogenize(double* u, const int32_t* slaves, int64_t num_sla
   hipLaunchKernelGGL(homogenize_kernel, dim3(grid_for(num_slaves, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), u, slaves, num_slaves);
   return check(hipGetLastError(), "homogenize launch");
+}
+
+extern "C" int mpcx_diag_slot_mask(int32_t n_nodes, const mpcx_nnz_t* rowptr, const int32_t* cols, int32_t bs,
+                                   const int8_t* bc0, const int8_t* slave0, const int8_t* bc1, const int8_t* slave1,
+                                   uint8_t* out, int32_t* bad, void* stream)
+{
+  if (n_nodes <= 0)
+    return 0;
+  hipLaunchKernelGGL(mpcx::diag_slot_mask_kernel, dim3(mpcx::grid_for(n_nodes, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), n_nodes, rowptr, cols, bs, bc0, slave0, bc1, slave1, out, bad);
+  return mpcx::check(hipGetLastError(), "diag_slot_mask launch");
 }
 
 extern "C" int mpcx_mask_dofmap(const int32_t* dofmap, int64_t num_cells, int32_t nd, int32_t bs,

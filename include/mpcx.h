@@ -207,6 +207,12 @@ typedef struct
    * num_blocks / max_rows / max_nnz / block_row0 / block_ent_off (slots per block), nothing else; n_entities is
    * ignored (the slots say what is assembled) */
   const void* cube_recs;
+  /* rowblock, component-diagonal forms on blocked spaces (bs0 == bs1 = bs > 1), optional: DEVICE [nnz / bs^2], one
+   * byte per bs x bs block of the CSR (block s of node row n = entries rowptr[n*bs] / bs^2 + s), bit k set = entry
+   * (k, k) of the block is a Dirichlet / slave row or column and stays zero (mpcx_diag_slot_mask).  Given, the
+   * kernel keeps one LDS value per block (matrix_nodeblock_kernel); plan.max_rows / max_nnz still count scalar
+   * rows / entries (LDS: max_nnz / bs^2 * 8 + (max_rows / bs + 1) * 4 bytes). */
+  const uint8_t* slot_mask;
   int64_t mpc_plan_targets;
   const mpcx_nnz_t* mpc_plan_tgt;
   const int64_t* mpc_plan_off;
@@ -218,6 +224,12 @@ typedef struct
 } mpcx_matrix_args_t;
 
 int mpcx_assemble_matrix(const mpcx_matrix_args_t* args);
+
+/* Set-up for mpcx_matrix_args_t::slot_mask (all pointers DEVICE; bc / slave markers may be NULL): out [nnz / bs^2].
+ * *bad is set if the CSR does not consist of whole bs x bs blocks (the bs rows of a node with the same block columns). */
+int mpcx_diag_slot_mask(int32_t n_nodes, const mpcx_nnz_t* rowptr, const int32_t* cols, int32_t bs, const int8_t* bc0,
+                        const int8_t* slave0, const int8_t* bc1, const int8_t* slave1, uint8_t* out, int32_t* bad,
+                        void* stream);
 
 /* Set-up for MPCX_ALG_ROWBLOCK: out[c][i] = d | (masked(d, k) << (28 + k)) with d = dofmap[c][i],
  * masked = Dirichlet-marked (bc may be NULL) or slave.  All pointers DEVICE, dof blocks must be

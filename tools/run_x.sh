@@ -5,8 +5,6 @@ for l in sys.stdin:
         d=json.loads(l); print(d['value'], d['ms_per_step'], [(k['kernel'][:40], round(k['launch_ms'],3), round(k['hbm_frac'],3)) for k in d.get('roofline_kernels',[])][:6], d['one_shot']['first_call_s'], d['one_shot']['plan_bytes'])
     elif 'Error' in l or 'error' in l: print(l.rstrip())
 "; }
-C=4 run MPCX_ROWBLOCK_MAX_NNZ=4608 MPCX_ROWBLOCK_MAX_ROWS=256
-C=4 run MPCX_ROWBLOCK_MAX_NNZ=6144 MPCX_ROWBLOCK_MAX_ROWS=384
-C=4 run MPCX_ROWBLOCK_MAX_NNZ=13824 MPCX_ROWBLOCK_MAX_ROWS=768
-C=3 run MPCX_ROWPAIR=all MPCX_ROWBLOCK_MAX_NNZ=4608 MPCX_ROWBLOCK_MAX_ROWS=256
+C=3 run MPCX_X=1
 C=3 run MPCX_ROWBLOCK_MAX_NNZ=4608 MPCX_ROWBLOCK_MAX_ROWS=256
+C=3 run MPCX_ROWBLOCK_MAX_NNZ=6144 MPCX_ROWBLOCK_MAX_ROWS=384
