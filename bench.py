@@ -421,7 +421,15 @@ def main():
         V0, V1 = f.function_spaces
         nbytes = (4 * nv * nc + 4 * V0.element_ndofs * nc + (0 if V1 is V0 else 4 * V1.element_ndofs * nc)
                   + 24 * mesh.num_nodes + 8 * A.nnz + V0.num_dofs + V1.num_dofs)
-        kname = "matrix_cube_kernel" if margs.algorithm == 3 else f"matrix_{args.alg}_kernel"
+        # the kernel mpcx_assemble_matrix launches for these arguments (csrc/mpcx_kernels.hip, launch_matrix)
+        if margs.algorithm == 3:
+            kname = "matrix_cube_kernel"
+        elif margs.algorithm == 2 and margs.slot_mask:
+            kname = "matrix_nodeblock_kernel"
+        elif margs.algorithm == 2 and margs.plan.row_pairs:
+            kname = "matrix_rowpair_kernel"
+        else:
+            kname = {2: "matrix_rowblock_kernel", 1: "matrix_atomic_kernel"}.get(margs.algorithm, f"matrix_{args.alg}_kernel")
         kernels.append({"kernel": f"{kname}[{label}]", "call": f"assemble_matrix[{label}]", "launch_ms": tk,
                         "algorithmic_bytes": int(nbytes), "pmc_name": kname})
         del keep

@@ -197,7 +197,7 @@ def test_backsubstitution_homogenize(oracle):
 # kernel variants that the default configuration never reaches
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("env", ["MPCX_NO_MPC_PLAN=1", "MPCX_NO_LEAN=1", "MPCX_MPC_PLAN=host", "MPCX_NO_CUBE=1", "MPCX_PLAN_LISTS=host",
-                                 "MPCX_ROWPAIR=all", "MPCX_ROWPAIR=none", "MPCX_NO_GROUP_ROWS=1"])
+                                 "MPCX_ROWPAIR=all", "MPCX_ROWPAIR=none", "MPCX_NO_GROUP_ROWS=1", "MPCX_NO_NODEBLOCK=1"])
 @pytest.mark.parametrize("alg", ["atomic", "rowblock"])
 @pytest.mark.parametrize("make", CASES, ids=[f"case{i}" for i in range(len(CASES))])
 def test_small_cases_kernel_variants(oracle, make, alg, env, monkeypatch):
@@ -208,7 +208,9 @@ def test_small_cases_kernel_variants(oracle, make, alg, env, monkeypatch):
     MPCX_MPC_PLAN=host: the plan from the host builder mpcx_mpc_plan_build instead of the device kernel.
     MPCX_NO_CUBE=1: the per-cell lean kernels where the default takes the cell-cluster kernels (MPCX_ALG_CUBE).
     MPCX_ROWPAIR=all / none: the (entity, local row) row-pair kernel wherever the operator has a compact context
-    (default: vector-valued P1 only) / nowhere.  MPCX_NO_GROUP_ROWS=1: block entity lists in plain entity order."""
+    (default: vector-valued P1 only) / nowhere.  MPCX_NO_GROUP_ROWS=1: block entity lists in plain entity order.
+    MPCX_NO_NODEBLOCK=1: component-diagonal forms on blocked spaces through the per-row compact layout of
+    matrix_rowblock_kernel instead of matrix_nodeblock_kernel."""
     monkeypatch.setenv(*env.split("="))
     case = make()
     if case.a is None:

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round evidence on the GPU box: driver-style bench lines for every config, the rocprofv3 kernel trace of the
-# default bench command, PMC counters of the config-2 kernels.  Outputs under gpurun_out/r02_final/.
+# default bench command, PMC counters of every config's kernels.  Outputs under gpurun_out/r02_final/.
 set -u
 OUT=gpurun_out/r02_final
 mkdir -p $OUT
@@ -12,8 +12,9 @@ export TMPDIR=/tmp
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/trace -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-traffic --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/bench_under_rocprof.json 2> /dev/null )
 python tools/rocprof_summary.py $(ls $OUT/trace/*results.db $OUT/trace/*/*results.db 2>/dev/null | head -1) > $OUT/kernel_trace.txt
 rm -rf $OUT/trace
-for c in 2 4; do
-  python tools/collect_pmc.py $OUT/pmc_c$c $( [ $c = 2 ] && echo 256 || echo 56 ) $c > /dev/null 2>&1
+for c in 2 3 4 5; do
+  case $c in 2) n=256;; 3) n=128;; 4) n=56;; 5) n=246;; esac
+  python tools/collect_pmc.py $OUT/pmc_c$c $n $c > /dev/null 2>&1
   rm -f $OUT/pmc_c$c/*.db $OUT/pmc_c$c/*/*.db
 done
 ls -la $OUT
