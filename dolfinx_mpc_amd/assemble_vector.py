@@ -100,7 +100,9 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
     if (alg == 2 or (alg == 0 and (nq <= nq_max or p2_fast))) and integ.num_entities > 0:
         from .assemble_matrix import _masked_dofmap, _slave_entities
 
-        plan, pk = _vector_plan(form, i, V, VECTOR_BLOCK_ROWS_P2 if (p2_fast and nq > nq_max) else VECTOR_BLOCK_ROWS)
+        # blocked spaces: the same number of NODES per block (vector P1, contact benchmark: 0.43 -> 0.29 ms)
+        rows = VECTOR_BLOCK_ROWS if "MPCX_VECTOR_BLOCK_ROWS" in os.environ else VECTOR_BLOCK_ROWS * V.dofmap.bs
+        plan, pk = _vector_plan(form, i, V, VECTOR_BLOCK_ROWS_P2 if (p2_fast and nq > nq_max) else rows)
         md0 = _masked_dofmap(form, V, None, constraint, 0)  # slave flag only: bcs do not touch b here
         _, slave_ents = _slave_entities(form, i, constraint, constraint)
         a.algorithm = 2
