@@ -331,6 +331,7 @@ struct ElementOp
 {
   static constexpr int TDIM = TDIM_;
   static constexpr int FORM = FORM_;
+  static constexpr int DEG0 = DEG0_, FN = FN_;
   using L0 = Lagrange<TDIM, DEG0_>;
   using L1 = Lagrange<TDIM, DEG1_>;
   static constexpr int NV = TDIM + 1;
@@ -556,7 +557,9 @@ struct ElementOp
   }
 
   __device__ static inline void tabulate(double (&A)[SIZE], const double* w, const double* c,
-                                         const double (&cd)[NV * 3], int lf, const mpcx_kernel_t& k)
+                                         const double (&cd)[NV * 3], int lf, const mpcx_kernel_t& k,
+                                         int comp0 = 0) // comp0: first component (source forms evaluated one
+                                                        // component at a time by the scalar operator)
   {
 #pragma unroll
     for (int i = 0; i < SIZE; ++i)
@@ -659,7 +662,7 @@ struct ElementOp
                         + fast_exp_nonpos_k(-(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]) * (1.0 / 0.02), FK));
             }
             else
-              f = wq * eval_fn(FN_ >= 0 ? FN_ : k.fn_id, x, b, c);
+              f = wq * eval_fn(FN_ >= 0 ? FN_ : k.fn_id, x, b + comp0, c);
             if constexpr (DEG0_ == 1)
             {
               S[b] += f;
@@ -725,7 +728,7 @@ struct ElementOp
 #pragma unroll
         for (int b = 0; b < BS0; ++b)
         {
-          const double f = s * eval_fn(FN_ >= 0 ? FN_ : k.fn_id, x, b, c);
+          const double f = s * eval_fn(FN_ >= 0 ? FN_ : k.fn_id, x, b + comp0, c);
 #pragma unroll
           for (int i = 0; i < ND0; ++i)
             A[i * BS0 + b] += f * phi[i];

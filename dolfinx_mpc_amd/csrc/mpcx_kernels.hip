@@ -1274,7 +1274,7 @@ vector_kernel(mpcx_vector_args_t a)
 // ---------------------------------------------------------------------------
 // (launch bound 1024 = 128 VGPRs: the spill-free build -- 512, 139-175 VGPRs, 2-3 waves per SIMD -- measured slower:
 // P2 source 7.7 -> 8.0 ms, vector P1 0.43 -> 0.57 ms)
-template <class Op>
+template <class Op, bool SPLIT = false>
 __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) vector_rowblock_kernel(mpcx_vector_args_t a)
 {
   constexpr int N = Op::N0, ND = Op::ND0, BS = Op::BS0, NV = Op::NV;
@@ -1356,19 +1356,47 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) vector_rowblock_kernel(m
       load_ent(i1, nxt);
     if (t + 2 * NT < e1)
       i1 = ents[t + 2 * NT];
-    double be[N];
-    Op::tabulate(be, a.coeffs ? a.coeffs + int64_t(cur.e) * a.cstride : nullptr, a.constants, cd, cur.lf, a.kernel);
-#pragma unroll
-    for (int i = 0; i < ND; ++i)
+    // vector-valued P2 source without coefficient: one component at a time through the scalar operator (ND
+    // accumulators instead of ND * BS: at 128 VGPRs the 30 of P2^3 spilled 204 bytes per thread, 8.5 GB of scratch
+    // traffic per launch on the Taylor-Hood benchmark)
+    // (SPLIT: chosen by the launcher when there is no coefficient)
+    if constexpr (SPLIT)
     {
-#pragma unroll
-      for (int k = 0; k < BS; ++k)
       {
-        const int r = (cur.m[i] & MPCX_DOF_MASK) * BS + k;
-        if ((cur.m[i] >> (MPCX_MASK_SHIFT + k)) & 1)
-          continue;
-        if (r >= r0 && r < r1)
-          __hip_atomic_fetch_add(s_b + (r - r0), be[i * BS + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        using SOp = ElementOp<Op::TDIM, Op::DEG0, 1, Op::DEG0, 1, MPCX_FORM_SOURCE, Op::FN>;
+#pragma unroll 1
+        for (int k = 0; k < BS; ++k)
+        {
+          double bk[ND];
+          SOp::tabulate(bk, nullptr, a.constants, cd, cur.lf, a.kernel, k);
+#pragma unroll
+          for (int i = 0; i < ND; ++i)
+          {
+            const int r = (cur.m[i] & MPCX_DOF_MASK) * BS + k;
+            if ((cur.m[i] >> (MPCX_MASK_SHIFT + k)) & 1)
+              continue;
+            if (r >= r0 && r < r1)
+              __hip_atomic_fetch_add(s_b + (r - r0), bk[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+    }
+    else
+    {
+      double be[N];
+      Op::tabulate(be, a.coeffs ? a.coeffs + int64_t(cur.e) * a.cstride : nullptr, a.constants, cd, cur.lf, a.kernel);
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+      {
+#pragma unroll
+        for (int k = 0; k < BS; ++k)
+        {
+          const int r = (cur.m[i] & MPCX_DOF_MASK) * BS + k;
+          if ((cur.m[i] >> (MPCX_MASK_SHIFT + k)) & 1)
+            continue;
+          if (r >= r0 && r < r1)
+            __hip_atomic_fetch_add(s_b + (r - r0), be[i * BS + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
       }
     }
     cur = nxt;
@@ -1745,11 +1773,29 @@ int launch_vector(const mpcx_vector_args_t& a)
       return -4;
     }
     const unsigned grid = 8u * unsigned((a.plan.num_blocks + 7) / 8);
-    if (int rc = check(hipFuncSetAttribute(reinterpret_cast<const void*>(vector_rowblock_kernel<Op>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)),
-                       "hipFuncSetAttribute"))
-      return rc;
-    hipLaunchKernelGGL(vector_rowblock_kernel<Op>, dim3(grid), dim3(512), lds, stream, a);
+    constexpr bool BY_COMPONENT = Op::BS0 > 1 && Op::ND0 >= 6 && Op::FORM == MPCX_FORM_SOURCE;
+    bool split = false;
+    if constexpr (BY_COMPONENT)
+      split = a.coeffs == nullptr;
+    auto launch = [&](auto kernel) -> int
+    {
+      if (int rc = check(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)),
+                         "hipFuncSetAttribute"))
+        return rc;
+      hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, stream, a);
+      return 0;
+    };
+    int lrc = 0;
+    if constexpr (BY_COMPONENT)
+    {
+      if (split)
+        lrc = launch(vector_rowblock_kernel<Op, true>);
+    }
+    if (!split)
+      lrc = launch(vector_rowblock_kernel<Op, false>);
+    if (lrc)
+      return lrc;
     if (int rc = check(hipGetLastError(), "vector row-block kernel launch"))
       return rc;
     if (a.n_slave_entities > 0)
