@@ -219,6 +219,52 @@ class MeshTags:
         return np.ascontiguousarray(self.entities[self.values == value])
 
 
+def renumber(mesh: Mesh, node_new_of_old: np.ndarray, cell_old_of_new: np.ndarray, tags: "MeshTags | None" = None):
+    """The same mesh with nodes renumbered (``node_new_of_old``) and cells reordered (``cell_old_of_new``); local
+    vertex order inside every cell is kept, so (cell, local_facet) pairs only change their cell index.  Returns the
+    new mesh (and the re-indexed facet tags if ``tags`` is given)."""
+    perm = np.asarray(node_new_of_old, dtype=np.int64)
+    order = np.asarray(cell_old_of_new, dtype=np.int64)
+    x = np.empty_like(mesh.geometry.x)
+    x[perm] = mesh.geometry.x
+    cells = perm[mesh.geometry.dofmap.astype(np.int64)][order]
+    out = Mesh(x, cells.astype(np.int32), mesh.cell_name)
+    if tags is None:
+        return out
+    cell_new_of_old = np.empty(order.size, dtype=np.int64)
+    cell_new_of_old[order] = np.arange(order.size)
+    ents = tags.entities.astype(np.int64).copy()
+    ents[:, 0] = cell_new_of_old[ents[:, 0]]
+    return out, MeshTags(out, tags.dim, ents, tags.values.copy())
+
+
+def reorder_spatial(mesh: Mesh, tags: "MeshTags | None" = None, tile_nodes: int = 512):
+    """Renumber an arbitrarily numbered mesh for locality: nodes along a Z-order (Morton) curve through their
+    coordinates, cells by their lowest node.  The row-block kernels keep contiguous CSR row ranges in LDS and
+    evaluate every cell that touches a range, so they need numberings in which contiguous ranges are compact in
+    space -- the generators' tile-wise numbering is, a mesh read from a file may not be (DOLFINx reorders dofs for
+    locality too; the numbering is not part of the reference's contract).  ``node_tile_offsets`` of the result
+    marks every ``tile_nodes``-th node: along a Morton curve any aligned run is a compact brick."""
+    x = mesh.geometry.x
+    lo, hi = x.min(axis=0), x.max(axis=0)
+    span = np.where(hi > lo, hi - lo, 1.0)
+    bits = 21
+    q = np.minimum(((x - lo) / span * (1 << bits)).astype(np.int64), (1 << bits) - 1)
+    code = np.zeros(x.shape[0], dtype=np.int64)
+    for b in range(bits):
+        for d in range(3):
+            code |= ((q[:, d] >> b) & 1) << (3 * b + d)
+    order = np.argsort(code, kind="stable")  # new -> old
+    perm = np.empty_like(order)
+    perm[order] = np.arange(order.size)
+    cell_key = perm[mesh.geometry.dofmap.astype(np.int64)].min(axis=1)
+    cell_order = np.argsort(cell_key, kind="stable")
+    res = renumber(mesh, perm, cell_order, tags)
+    out = res[0] if tags is not None else res
+    out.node_tile_offsets = np.arange(0, out.num_nodes, tile_nodes, dtype=np.int32)
+    return res
+
+
 def facet_vertices(mesh: Mesh, facets: np.ndarray) -> np.ndarray:
     """geometry nodes of the given (cell, local_facet) pairs, shape (n, tdim)"""
     lf = TET_FACETS if mesh.tdim == 3 else TRI_FACETS

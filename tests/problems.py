@@ -191,21 +191,35 @@ def case_facet_mass() -> Case:
     return Case("facet_mass", V, a, L, [], dict_constraint_raw(V, s_m_c))
 
 
-def case_cube_periodic(N=4, degree=1, bc_value=0.0, reorder=None) -> Case:
+def renumbered(mesh, numbering: str, seed: int = 0):
+    """``shuffled``: nodes and cells in random order (a mesh as a file may deliver it); ``spatial``: the shuffled
+    mesh put back in order by dolfinx_mpc_amd.mesh.reorder_spatial"""
+    from dolfinx_mpc_amd.mesh import renumber, reorder_spatial
+
+    rng = np.random.default_rng(seed)
+    mesh = renumber(mesh, rng.permutation(mesh.num_nodes), rng.permutation(mesh.num_cells))
+    return reorder_spatial(mesh, tile_nodes=64) if numbering == "spatial" else mesh
+
+
+def case_cube_periodic(N=4, degree=1, bc_value=0.0, reorder=None, numbering=None) -> Case:
     """python/benchmarks/bench_periodic.py:35-110 (BASELINE configs 1/2 at small N)"""
     mesh = create_unit_cube(N, N, N, reorder=reorder)
+    if numbering is not None:
+        mesh = renumbered(mesh, numbering)
     V = fem.functionspace(mesh, ("Lagrange", degree))
     dofs = fem.locate_dofs_geometrical(V, _walls_yz)
     bc = fem.dirichletbc(bc_value, dofs, V)
-    tag = "" if reorder is None else "_tiled"
+    tag = ("" if reorder is None else "_tiled") + ("" if numbering is None else "_" + numbering)
     return Case(f"cube_periodic_p{degree}_n{N}_bc{bc_value:g}{tag}", V, fem.form_stiffness(V),
                 fem.form_source(V, fem.FN_BENCH_PERIODIC), [bc], periodic_raw(V, [bc]))
 
 
-def case_cube_elasticity_slip(N=3) -> Case:
+def case_cube_elasticity_slip(N=3, numbering=None) -> Case:
     """vector P1 tets, slip constraint u.n = 0 on x=1 with a tilted normal
     (cpp/SlipConstraint.h:115-166 output shape: 1 slave + bs-1 same-block masters)"""
     mesh = create_unit_cube(N, N, N)
+    if numbering is not None:
+        mesh = renumbered(mesh, numbering)
     V = fem.functionspace(mesh, ("Lagrange", 1, (3,)))
     x = V.tabulate_dof_coordinates()
     dofs = fem.locate_dofs_geometrical(V, lambda x: np.isclose(x[0], 0))
@@ -226,7 +240,7 @@ def case_cube_elasticity_slip(N=3) -> Case:
            np.zeros(len(masters), dtype=np.int32), np.array(offsets, dtype=np.int32))
     a = fem.form_elasticity(V, 1.0e3 / 2, 0.0)  # bench_contact_3D.py:257-269: E=1e3, nu=0
     L = fem.form_source(V, fem.FN_LINEAR)
-    return Case(f"cube_elasticity_slip_n{N}", V, a, L, [bc], raw)
+    return Case(f"cube_elasticity_slip_n{N}" + ("" if numbering is None else "_" + numbering), V, a, L, [bc], raw)
 
 
 def case_cube_contact_like(N=3) -> Case:

@@ -1,0 +1,55 @@
+"""The HIP path on arbitrarily numbered meshes.  The kernels make no assumption about
+the numbering -- a shuffled mesh only costs speed (every row block is touched by cells from everywhere) -- and
+``reorder_spatial`` gives the locality back that the generators' tile-wise numbering has."""
+import numpy as np
+import pytest
+
+from problems import case_cube_elasticity_slip, case_cube_periodic, oracle_outputs, product_mpc, product_outputs
+
+pytestmark = pytest.mark.gpu
+
+MAKERS = [lambda nb: case_cube_periodic(4, 1, 0.0, numbering=nb), lambda nb: case_cube_periodic(3, 2, 0.0, numbering=nb),
+          lambda nb: case_cube_elasticity_slip(3, numbering=nb)]
+
+
+@pytest.mark.parametrize("alg", ["atomic", "rowblock"])
+@pytest.mark.parametrize("numbering", ["shuffled", "spatial"])
+@pytest.mark.parametrize("make", MAKERS, ids=["p1", "p2", "elasticity"])
+def test_renumbered_meshes_match_oracle(oracle, make, numbering, alg):
+    case = make(numbering)
+    ref = oracle_outputs(oracle, case)
+    out = product_outputs(case, algorithm=alg)
+    assert np.array_equal(out["A"].indptr, ref["A"].indptr) and np.array_equal(out["A"].indices, ref["A"].indices)
+    scale = max(1.0, abs(ref["A"].data).max())
+    assert abs(out["A"].data - ref["A"].data).max() <= 1e-12 * scale
+    for k in ("b", "b_lifted"):
+        if k in ref:
+            assert abs(out[k] - ref[k]).max() <= 1e-12 * max(1.0, abs(ref[k]).max())
+
+
+@pytest.mark.parametrize("degree", [1, 2])
+def test_reorder_spatial_shrinks_the_row_block_plan(degree):
+    """entities evaluated per row block (the halo the row-block kernels pay for): a shuffled 16^3 mesh makes nearly
+    every cell touch nd different blocks; after reorder_spatial the plan is within 2x of the generator's own
+    tile-wise numbering"""
+    import dolfinx_mpc_amd as dm
+
+    def plan_entities(case):
+        mpc = product_mpc(case)
+        A = dm.assemble_matrix(case.a, mpc, bcs=case.bcs, algorithm="rowblock")
+        info = [p[1][2] for k, od in A._plans.items() if k == ("objcache", "rowblock") for p in od.values()]
+        assert info, "row-block plan expected"
+        return info[0]["num_ents"], case.V.mesh.num_cells
+
+    n = 16 if degree == 1 else 10
+    import os
+
+    os.environ["MPCX_NO_CUBE"] = "1"  # compare the per-cell plans (the cluster path needs the generator's cell order)
+    try:
+        shuffled, nc = plan_entities(case_cube_periodic(n, degree, 0.0, numbering="shuffled"))
+        spatial, _ = plan_entities(case_cube_periodic(n, degree, 0.0, numbering="spatial"))
+        tiled, _ = plan_entities(case_cube_periodic(n, degree, 0.0, reorder=(8, 8, 8)))
+    finally:
+        del os.environ["MPCX_NO_CUBE"]
+    assert spatial < 0.75 * shuffled, (shuffled, spatial, tiled, nc)
+    assert spatial <= 2.0 * tiled, (shuffled, spatial, tiled, nc)
