@@ -524,14 +524,14 @@ def main():
         log(f"timing the CPU baseline (oracle, 1 core, sample {sample_n}) ...")
         out["cpu_baseline"] = cpu_baseline(kind, degree, sample_n)
         P = args.cpu_allcores if args.cpu_allcores >= 0 else min(os.cpu_count() or 1, 64)
-        if kind == "poisson" and P > 1:
+        if kind in ("poisson", "contact") and P > 1:
             # the way the reference is deployed: one serial loop per MPI rank over its cells (SURVEY 8d ii)
-            n_all = args.cpu_allcores_n or (192 if degree == 1 else 80)
+            n_all = args.cpu_allcores_n or (40 if kind == "contact" else (192 if degree == 1 else 80))
             log(f"timing the CPU baseline on {P} cores (sample N={n_all}) ...")
             try:
                 from oracle import cpu_parallel
 
-                out["cpu_baseline_allcores"] = cpu_parallel.main(n_all, P, degree)
+                out["cpu_baseline_allcores"] = cpu_parallel.main(n_all, P, max(degree, 1), kind)
             except Exception as e:  # noqa: BLE001
                 log(f"all-core CPU leg failed: {e}")
     print(json.dumps(out), flush=True)

@@ -41,9 +41,11 @@ def assemble_allcores(V, a_of_cells, L_of_cells, mpc, bcs, pattern, P: int, chec
     # rows touched by slab r: its cells' dofs and the masters of the slaves among them
     lo, hi = np.empty(P, dtype=np.int64), np.empty(P, dtype=np.int64)
     moff, mast = mpc.masters_offsets, mpc.masters
+    lo_cells = np.empty(P, dtype=np.int64)
     for r in range(P):
         d = dm[bounds[r]:bounds[r + 1]]
         lo[r], hi[r] = int(d.min()) * bs, (int(d.max()) + 1) * bs
+        lo_cells[r] = lo[r]
         rows = np.unique(d) * bs
         sl = (rows[:, None] + np.arange(bs)[None, :]).reshape(-1)
         sl = sl[mpc.is_slave[sl] != 0]
@@ -51,7 +53,8 @@ def assemble_allcores(V, a_of_cells, L_of_cells, mpc, bcs, pattern, P: int, chec
             m = np.concatenate([mast[moff[s]:moff[s + 1]] for s in sl])
             if m.size:
                 lo[r], hi[r] = min(lo[r], int(m.min())), max(hi[r], int(m.max()) + 1)
-    own = np.concatenate([[0], lo[1:], [rowptr.size - 1]]).astype(np.int64)  # ownership boundaries
+    # ownership boundaries follow the cells' own rows (master rows elsewhere only widen the private range)
+    own = np.concatenate([[0], lo_cells[1:], [rowptr.size - 1]]).astype(np.int64)
     if np.any(np.diff(own) < 0):
         raise RuntimeError("cell slabs do not touch increasing row ranges: numbering not slab-ordered")
     nnz, n = int(rowptr[-1]), rowptr.size - 1
@@ -124,18 +127,31 @@ def host_pattern(form, case, cases=None):
     return rp.astype(np.int32), cols
 
 
-def main(N: int, P: int, degree: int = 1):
+def main(N: int, P: int, degree: int = 1, kind: str = "poisson"):
     from dolfinx_mpc_amd import fem
     from oracle import pyoracle as po
-    from problems import case_cube_periodic, oracle_mpc
+    from problems import case_contact_two_body, case_cube_periodic, oracle_mpc
 
-    case = case_cube_periodic(N, degree, 0.0)
+    if kind == "contact":
+        # two-body contact elasticity (config 4): N^3 cubes over (2N)^3; the slab that holds the slave cells also
+        # holds their masters' rows in the other body (a wider private matrix, like the ghost rows of an MPI rank)
+        case = case_contact_two_body(N)
+        degree = 1
+    else:
+        case = case_cube_periodic(N, degree, 0.0)
     V = case.V
     mpc = oracle_mpc(po, case)
     pattern = host_pattern(case.a, case)
     fn = case.L.integrals[0].kernel.fn_id
-    wall, tm, A, b = assemble_allcores(V, lambda c: fem.form_stiffness(V, cells=c),
-                                       lambda c: fem.form_source(V, fn, cells=c), mpc, case.bcs, pattern, P)
+    if kind == "contact":
+        mu, lam = (float(v) for v in case.a.integrals[0].constants[:2])
+        cL = np.array(case.L.integrals[0].constants, dtype=np.float64)
+        a_of = lambda c: fem.form_elasticity(V, mu, lam, cells=c)  # noqa: E731
+        L_of = lambda c: fem.form_source(V, fn, constant=cL, cells=c)  # noqa: E731
+    else:
+        a_of = lambda c: fem.form_stiffness(V, cells=c)  # noqa: E731
+        L_of = lambda c: fem.form_source(V, fn, cells=c)  # noqa: E731
+    wall, tm, A, b = assemble_allcores(V, a_of, L_of, mpc, case.bcs, pattern, P)
     if N <= 32:  # sanity: the slabs add up to the single-thread result (diagonals aside)
         ref_b = po.assemble_vector(case.L, mpc, fast=True)
         assert np.allclose(b, ref_b, rtol=1e-12, atol=1e-14 * abs(ref_b).max())
@@ -144,7 +160,7 @@ def main(N: int, P: int, degree: int = 1):
     ndofs, ncells = V.num_dofs, case.mesh.num_cells
     return {
         "value": ndofs / wall, "unit": "DoFs/s", "cores": P, "kind": "port",
-        "sample": f"same workload at N={N} (P{degree}, {ncells} cells, {ndofs} dofs) on {P} threads of the oracle's C loops "
+        "sample": f"same workload at N={N} ({kind}, P{degree}, {ncells} cells, {ndofs} dofs) on {P} threads of the oracle's C loops "
                   f"(cell slabs, private local matrices, interface rows added by the owners): slowest matrix "
                   f"{tm[:, 0].max():.2f}s, vector {tm[:, 1].max():.2f}s, reduction {tm[:, 2].max():.2f}s, wall {wall:.2f}s",
         "t_wall_s": wall,
@@ -154,4 +170,4 @@ def main(N: int, P: int, degree: int = 1):
 if __name__ == "__main__":
     print(json.dumps(main(int(sys.argv[1]) if len(sys.argv) > 1 else 96,
                           int(sys.argv[2]) if len(sys.argv) > 2 else (os.cpu_count() or 1),
-                          int(sys.argv[3]) if len(sys.argv) > 3 else 1)))
+                          int(sys.argv[3]) if len(sys.argv) > 3 else 1, sys.argv[4] if len(sys.argv) > 4 else "poisson")))
