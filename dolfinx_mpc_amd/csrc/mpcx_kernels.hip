@@ -1310,9 +1310,12 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) vector_rowblock_kernel(m
     const int64_t cell0 = (a.entities0 ? a.entities0[l] : e);
     E.e = int32_t(e);
     E.lf = a.estride == 2 ? a.entities[l + 1] : 0;
+    if constexpr (ND < 10) // (P2: the dof row is read after the quadrature loop, see below)
+    {
 #pragma unroll
-    for (int i = 0; i < ND; ++i)
-      E.m[i] = a.mdofmap[cell0 * ND + i];
+      for (int i = 0; i < ND; ++i)
+        E.m[i] = a.mdofmap[cell0 * ND + i];
+    }
     if (alias)
     {
       if constexpr (NV == ND)
@@ -1333,15 +1336,23 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) vector_rowblock_kernel(m
   const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
   const int32_t* __restrict__ ents = a.plan.block_ents;
   int64_t t = e0 + tid;
-  // same software pipeline as the matrix kernel: index data one entity ahead, entity index two
+  // same software pipeline as the matrix kernel: index data one entity ahead, entity index two -- for small
+  // elements.  P2 keeps one entity in flight only: the second set of index registers (14 VGPRs) is what made the
+  // 24-point source kernel spill inside its quadrature loop
+  constexpr bool PIPE = ND < 10;
   Ent cur;
   int32_t i1 = 0;
-  if (t < e1)
-    load_ent(ents[t], cur);
-  if (t + NT < e1)
-    i1 = ents[t + NT];
+  if constexpr (PIPE)
+  {
+    if (t < e1)
+      load_ent(ents[t], cur);
+    if (t + NT < e1)
+      i1 = ents[t + NT];
+  }
   for (; t < e1; t += NT)
   {
+    if constexpr (!PIPE)
+      load_ent(ents[t], cur);
     double cd[NV * 3];
 #pragma unroll
     for (int i = 0; i < NV; ++i)
@@ -1352,10 +1363,25 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) vector_rowblock_kernel(m
         cd[3 * i + k] = a.x[3 * v + k];
     }
     Ent nxt = cur;
-    if (t + NT < e1)
-      load_ent(i1, nxt);
-    if (t + 2 * NT < e1)
-      i1 = ents[t + 2 * NT];
+    if constexpr (PIPE)
+    {
+      if (t + NT < e1)
+        load_ent(i1, nxt);
+      if (t + 2 * NT < e1)
+        i1 = ents[t + 2 * NT];
+    }
+    // P2: the masked dof row is read AFTER the quadrature loop (ten registers less across it)
+    auto load_row = [&]()
+    {
+      if constexpr (!PIPE)
+      {
+        const int64_t l = int64_t(cur.e) * a.estride;
+        const int64_t cell0 = (a.entities0 ? a.entities0[l] : cur.e);
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+          cur.m[i] = a.mdofmap[cell0 * ND + i];
+      }
+    };
     // vector-valued P2 source without coefficient: one component at a time through the scalar operator (ND
     // accumulators instead of ND * BS: at 128 VGPRs the 30 of P2^3 spilled 204 bytes per thread, 8.5 GB of scratch
     // traffic per launch on the Taylor-Hood benchmark)
@@ -1369,6 +1395,7 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) vector_rowblock_kernel(m
         {
           double bk[ND];
           SOp::tabulate(bk, nullptr, a.constants, cd, cur.lf, a.kernel, k);
+          load_row();
 #pragma unroll
           for (int i = 0; i < ND; ++i)
           {
@@ -1385,6 +1412,7 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) vector_rowblock_kernel(m
     {
       double be[N];
       Op::tabulate(be, a.coeffs ? a.coeffs + int64_t(cur.e) * a.cstride : nullptr, a.constants, cd, cur.lf, a.kernel);
+      load_row();
 #pragma unroll
       for (int i = 0; i < ND; ++i)
       {
@@ -1399,7 +1427,8 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) vector_rowblock_kernel(m
         }
       }
     }
-    cur = nxt;
+    if constexpr (PIPE)
+      cur = nxt;
   }
   __syncthreads();
   for (int i = tid; i < r1 - r0; i += NT)
