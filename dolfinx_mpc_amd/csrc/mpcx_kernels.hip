@@ -1339,7 +1339,7 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) vector_rowblock_kernel(m
   // same software pipeline as the matrix kernel: index data one entity ahead, entity index two -- for small
   // elements.  P2 keeps one entity in flight only: the second set of index registers (14 VGPRs) is what made the
   // 24-point source kernel spill inside its quadrature loop
-  constexpr bool PIPE = ND < 10;
+  constexpr bool PIPE = ND < 10 && N <= 8;
   Ent cur;
   int32_t i1 = 0;
   if constexpr (PIPE)
@@ -1373,7 +1373,7 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) vector_rowblock_kernel(m
     // P2: the masked dof row is read AFTER the quadrature loop (ten registers less across it)
     auto load_row = [&]()
     {
-      if constexpr (!PIPE)
+      if constexpr (ND >= 10)
       {
         const int64_t l = int64_t(cur.e) * a.estride;
         const int64_t cell0 = (a.entities0 ? a.entities0[l] : cur.e);
