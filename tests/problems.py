@@ -338,7 +338,7 @@ def contact_raw_bruteforce(V, slave_facets, master_facets):
             np.zeros(len(masters), dtype=np.int32), np.array(offsets, dtype=np.int32))
 
 
-def contact_problem(n_top, n_bottom=None, theta=0.0, reorder=None, body_force=(0.0, 0.0, 0.0)):
+def contact_problem(n_top, n_bottom=None, theta=0.0, reorder=None, body_force=(0.0, 0.0, 0.0), numbering=None):
     """mesh, space, boundary conditions and forms of python/benchmarks/bench_contact_3D.py:199-270 with the
     inelastic (no-slip) contact condition: vector P1, bottom face clamped, top face displaced by
     (0, 0, -0.425), E = 1e3, nu = 0, right-hand side = a constant body force (the benchmark's is zero)."""
@@ -346,6 +346,14 @@ def contact_problem(n_top, n_bottom=None, theta=0.0, reorder=None, body_force=(0
                                       create_stacked_cubes)
 
     mesh, ft, _ct = create_stacked_cubes(n_top, n_bottom, theta, reorder)
+    if numbering is not None:
+        # a mesh as a file may deliver it (random order), optionally put back in order: the facet tags travel along
+        from dolfinx_mpc_amd.mesh import renumber, reorder_spatial
+
+        rng = np.random.default_rng(5)
+        mesh, ft = renumber(mesh, rng.permutation(mesh.num_nodes), rng.permutation(mesh.num_cells), ft)
+        if numbering == "spatial":
+            mesh, ft = reorder_spatial(mesh, ft, tile_nodes=64)
     V = fem.functionspace(mesh, ("Lagrange", 1, (3,)))
     u_bc = fem.Function(V)
     bc_bottom = fem.dirichletbc(u_bc, fem.locate_dofs_topological(V, 2, ft.find(CONTACT_BOTTOM)), V)
@@ -358,15 +366,16 @@ def contact_problem(n_top, n_bottom=None, theta=0.0, reorder=None, body_force=(0
     return mesh, ft, V, [bc_bottom, bc_top], a, L, (CONTACT_BOTTOM_INTERFACE, CONTACT_TOP_INTERFACE)
 
 
-def case_contact_two_body(n_top=2, n_bottom=None, theta=0.0, reorder=None) -> Case:
+def case_contact_two_body(n_top=2, n_bottom=None, theta=0.0, reorder=None, numbering=None) -> Case:
     """BASELINE config 4 at small size: two stacked cubes, inelastic contact, vector P1 elasticity
     (python/benchmarks/bench_contact_3D.py:62-270 with --no-slip; cpp/ContactConstraint.h:908-1174).
     n_bottom = 2 n_top: slave nodes fall on master nodes / edge midpoints (1-2 masters);
     other ratios: general barycentric weights (up to 3 masters per slave and component)."""
-    mesh, ft, V, bcs, a, L, (sm, mm) = contact_problem(n_top, n_bottom, theta, reorder, body_force=(0.3, -0.2, -1.0))
+    mesh, ft, V, bcs, a, L, (sm, mm) = contact_problem(n_top, n_bottom, theta, reorder, body_force=(0.3, -0.2, -1.0),
+                                                      numbering=numbering)
     raw = contact_raw_bruteforce(V, ft.find(sm), ft.find(mm))
     nb = 2 * n_top if n_bottom is None else n_bottom
-    tag = "" if reorder is None else "_tiled"
+    tag = ("" if reorder is None else "_tiled") + ("" if numbering is None else "_" + numbering)
     return Case(f"contact_two_body_{n_top}_{nb}_theta{theta:.2f}{tag}", V, a, L, bcs, raw)
 
 

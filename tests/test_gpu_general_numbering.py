@@ -4,17 +4,18 @@ the numbering -- a shuffled mesh only costs speed (every row block is touched by
 import numpy as np
 import pytest
 
-from problems import case_cube_elasticity_slip, case_cube_periodic, oracle_outputs, product_mpc, product_outputs
+from problems import (case_contact_two_body, case_cube_elasticity_slip, case_cube_periodic, oracle_outputs, product_mpc,
+                      product_outputs)
 
 pytestmark = pytest.mark.gpu
 
 MAKERS = [lambda nb: case_cube_periodic(4, 1, 0.0, numbering=nb), lambda nb: case_cube_periodic(3, 2, 0.0, numbering=nb),
-          lambda nb: case_cube_elasticity_slip(3, numbering=nb)]
+          lambda nb: case_cube_elasticity_slip(3, numbering=nb), lambda nb: case_contact_two_body(2, 3, 0.4, numbering=nb)]
 
 
 @pytest.mark.parametrize("alg", ["atomic", "rowblock"])
 @pytest.mark.parametrize("numbering", ["shuffled", "spatial"])
-@pytest.mark.parametrize("make", MAKERS, ids=["p1", "p2", "elasticity"])
+@pytest.mark.parametrize("make", MAKERS, ids=["p1", "p2", "elasticity", "contact"])
 def test_renumbered_meshes_match_oracle(oracle, make, numbering, alg):
     case = make(numbering)
     ref = oracle_outputs(oracle, case)

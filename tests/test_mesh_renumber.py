@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from dolfinx_mpc_amd.mesh import create_stacked_cubes, create_unit_cube, facet_vertices, renumber, reorder_spatial
-from problems import case_cube_elasticity_slip, case_cube_periodic, oracle_outputs
+from problems import case_contact_two_body, case_cube_elasticity_slip, case_cube_periodic, oracle_outputs
 
 
 def _volume(mesh):
@@ -58,15 +58,29 @@ def test_reorder_spatial_restores_locality():
 
 @pytest.mark.parametrize("make", [lambda nb: case_cube_periodic(3, 1, 0.0, numbering=nb),
                                   lambda nb: case_cube_periodic(2, 2, 0.0, numbering=nb),
-                                  lambda nb: case_cube_elasticity_slip(2, numbering=nb)], ids=["p1", "p2", "elasticity"])
+                                  lambda nb: case_cube_elasticity_slip(2, numbering=nb),
+                                  lambda nb: case_contact_two_body(2, 3, 0.4, numbering=nb)],
+                         ids=["p1", "p2", "elasticity", "contact"])
 def test_oracle_is_equivariant_under_renumbering(oracle, make):
     """the reference assembles the same operator whatever the numbering: with P matching dofs by coordinate,
     A' = P A P^T, b' = P b (the slaves are picked geometrically in these cases, so the constraint moves along)"""
     base, other = make(None), make("shuffled")
     ra, rb = oracle_outputs(oracle, base), oracle_outputs(oracle, other)
-    xa, xb = base.V.tabulate_dof_coordinates(), other.V.tabulate_dof_coordinates()
-    ka = np.lexsort(np.round(xa, 9).T)
-    kb = np.lexsort(np.round(xb, 9).T)
+    def keys(case):
+        # dof coordinates + the centroid of the cells round the dof: two bodies in contact have distinct nodes at the
+        # same coordinates, told apart by the side their cells lie on
+        x = case.V.tabulate_dof_coordinates()
+        dm = case.V.dofmap.list
+        cc = x[dm].mean(axis=1)
+        acc, cnt = np.zeros_like(x), np.zeros(x.shape[0])
+        for i in range(dm.shape[1]):
+            np.add.at(acc, dm[:, i], cc)
+            np.add.at(cnt, dm[:, i], 1.0)
+        return np.round(np.concatenate([x, acc / cnt[:, None]], axis=1), 9)
+
+    xa, xb = keys(base), keys(other)
+    ka = np.lexsort(xa.T)
+    kb = np.lexsort(xb.T)
     assert np.allclose(xa[ka], xb[kb])
     bs = base.V.dofmap.bs
     pa = (ka[:, None] * bs + np.arange(bs)).reshape(-1)  # unrolled dofs in coordinate order
