@@ -439,6 +439,8 @@ def main():
         V0 = f.function_spaces[0]
         nbytes = 4 * nv * nc + 4 * V0.element_ndofs * nc + 24 * mesh.num_nodes + 9 * V0.num_dofs
         kname = {2: "vector_rowblock_kernel", 3: "vector_cube_kernel"}.get(vargs.algorithm, "vector_kernel")
+        if vargs.algorithm == 2 and vargs.own_lmap:
+            kname = "vector_ownblock_kernel"  # + vector_spill_reduce_kernel, timed together
         k = {"kernel": f"{kname}[{label}]", "call": f"assemble_vector[{label}]", "launch_ms": tk,
              "algorithmic_bytes": int(nbytes), "pmc_name": kname}
         if args.config == 2:

@@ -148,6 +148,13 @@ class VectorArgs(C.Structure):
         ("n_slave_entities", C.c_int64),
         ("cube_verts", C.c_void_p),
         ("n_cubes", C.c_int64),
+        ("own_lmap", C.c_void_p),
+        ("own_hoff", C.c_void_p),
+        ("own_spill", C.c_void_p),
+        ("own_src", C.c_void_p),
+        ("own_rows", C.c_void_p),
+        ("own_seg", C.c_void_p),
+        ("n_own_rows", C.c_int64),
         ("stream", C.c_void_p),
     ]
 

@@ -52,6 +52,72 @@ def _vector_plan(form: Form, i: int, V, rows: int = VECTOR_BLOCK_ROWS):
     return form._device[key]
 
 
+VECTOR_LDS_ROWS = 96 * 1024 // 8  # rows of b one workgroup can hold (own + halo)
+VECTOR_OWNER_ROWS = int(os.environ.get("MPCX_VECTOR_OWNER_ROWS", 8192))  # own rows per block (3072: 8.0 ms, 4096-8192: 5.6-5.7 ms at config 5)
+
+
+def _vector_owner_plan(form: Form, i: int, V, md0, rows: int):
+    """Owner-computes plan of the row-block vector kernel (include/mpcx.h, mpcx_vector_args_t::own_*), built on the
+    device with torch (plumbing: gathers, searchsorted, sorts).  Every entity belongs to the block that holds the rows
+    of its local dof 0; the dofs of other blocks its entities touch are the block's halo, appended to its LDS copy.
+    ``md0``: the slave-masked dofmap (its flag bits move into the position table).  Returns None when a block with
+    its halo does not fit the LDS budget."""
+    key = ("voplan", i, rows, id(md0))
+    if key in form._device:
+        return form._device[key][0]
+    import torch
+
+    from .assemble_matrix import _block_ranges
+
+    integ = form.integrals[i]
+    n, nd, bs = integ.num_entities, V.element_ndofs, V.dofmap.bs
+    nrows = V.num_dofs
+    ndof_blocks = nrows // bs
+    hints = None
+    if V.dof_tile_offsets is not None:
+        hints = np.ascontiguousarray(V.dof_tile_offsets.astype(np.int32) * bs)
+    row0 = _block_ranges(nrows, np.arange(nrows + 1, dtype=np.int64), rows, rows, bs, hints)
+    nb = row0.size - 1
+    dev = _native.require_gpu()
+    d_row0 = D._to_dev(row0, dev)
+    ents = D.integral_device(form, i)["entities"]
+    cells = None if ents is None else ents.view(n, integ.estride)[:, 0].long()
+    mrow = md0.view(-1, nd)[:n] if cells is None else md0.view(-1, nd)[cells]  # masked dofmap rows of the entities
+    dof = (mrow & ((1 << 28) - 1)).to(torch.int64)
+    flags = (mrow >> 28) << 28
+    blk = torch.searchsorted(d_row0[1:].contiguous(), (dof * bs).contiguous(), right=True)  # (n, nd)
+    owner = blk[:, 0].contiguous()
+    order = torch.argsort(owner, stable=True)
+    off = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(torch.bincount(owner, minlength=nb), 0, out=off[1:])
+    foreign = blk != owner[:, None]
+    del blk
+    first = (d_row0[:-1].to(torch.int64) // bs)  # first dof of every block
+    nown = (d_row0[1:] - d_row0[:-1]).to(torch.int64) // bs
+    fe, fi = torch.nonzero(foreign, as_tuple=True)
+    ukey, inv = torch.unique(owner[fe] * ndof_blocks + dof[fe, fi], return_inverse=True)  # (block, halo dof), sorted
+    hblk, hdof = ukey // ndof_blocks, ukey % ndof_blocks
+    hoff = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(torch.bincount(hblk, minlength=nb), 0, out=hoff[1:])
+    max_rows = int(((nown + (hoff[1:] - hoff[:-1])) * bs).max().item()) if nb > 0 else 0
+    if max_rows > VECTOR_LDS_ROWS:
+        form._device[key] = (None,)
+        return None
+    lmap = dof - first[owner][:, None]
+    lmap[fe, fi] = nown[owner[fe]] + (inv - hoff[hblk[inv]])
+    lmap = (lmap.to(torch.int32) | flags.to(torch.int32)).contiguous()
+    sdof, sorder = torch.sort(hdof, stable=True)
+    urows, counts = torch.unique_consecutive(sdof, return_counts=True)
+    seg = torch.zeros(urows.numel() + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, out=seg[1:])
+    spill = torch.zeros(max(ukey.numel(), 1) * bs, dtype=torch.float64, device=dev)
+    t = (d_row0, off, order.to(torch.int32).contiguous(), lmap, hoff, spill, sorder.to(torch.int32).contiguous(),
+         urows.to(torch.int32).contiguous(), seg)
+    plan = _native.RowBlockPlanT(nb, max_rows, max_rows, 0, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), None, None)
+    form._device[key] = ((plan, t, int(urows.numel())), md0)  # md0 kept alive: its id is part of the key
+    return form._device[key][0]
+
+
 def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint, alg: int, allow_cubes: bool = True):
     """Fill the C-ABI argument block of ``mpcx_assemble_vector`` for integral i; returns (args, keep-alive)."""
     V = form.function_spaces[0]
@@ -102,8 +168,24 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
 
         # blocked spaces: the same number of NODES per block (vector P1, contact benchmark: 0.43 -> 0.29 ms)
         rows = VECTOR_BLOCK_ROWS if "MPCX_VECTOR_BLOCK_ROWS" in os.environ else VECTOR_BLOCK_ROWS * V.dofmap.bs
-        plan, pk = _vector_plan(form, i, V, VECTOR_BLOCK_ROWS_P2 if (p2_fast and nq > nq_max) else rows)
+        nrows_blk = VECTOR_BLOCK_ROWS_P2 if (p2_fast and nq > nq_max) else rows
         md0 = _masked_dofmap(form, V, None, constraint, 0)  # slave flag only: bcs do not touch b here
+        own = None
+        owner_mode = os.environ.get("MPCX_VECTOR_OWNER", "auto")
+        if owner_mode == "1" or (owner_mode == "auto" and nq > 4):
+            # owner-computes lists (no entity evaluated once per block it touches) where the quadrature is what
+            # costs (P2 source 246^3, 24 points: 6.6 -> 5.7 ms; Stokes b0 1.68 -> 1.46; a one-point rule loses:
+            # contact b 0.28 -> 0.31 ms); the halo rows share the LDS budget, so the own part of a block is smaller
+            for cap in (VECTOR_OWNER_ROWS, VECTOR_OWNER_ROWS * 3 // 4, VECTOR_OWNER_ROWS // 2):
+                own = _vector_owner_plan(form, i, V, md0, min(nrows_blk, cap))
+                if own is not None:
+                    break
+        if own is not None:
+            plan, pk, n_own = own
+            a.own_lmap, a.own_hoff, a.own_spill = pk[3].data_ptr(), pk[4].data_ptr(), pk[5].data_ptr()
+            a.own_src, a.own_rows, a.own_seg, a.n_own_rows = pk[6].data_ptr(), pk[7].data_ptr(), pk[8].data_ptr(), n_own
+        else:
+            plan, pk = _vector_plan(form, i, V, nrows_blk)
         _, slave_ents = _slave_entities(form, i, constraint, constraint)
         a.algorithm = 2
         a.plan = plan

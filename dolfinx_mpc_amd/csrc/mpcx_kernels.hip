@@ -1437,6 +1437,98 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) vector_rowblock_kernel(m
 
 // Slave rows of the entities that have any (modify_mpc_vec, cpp/assemble_vector.h:35-69):
 // b[master] += coeff * be[slave]; a slave without masters keeps its own row.
+// Owner-computes variant of the row-block vector kernel (mpcx_vector_args_t::own_lmap): every entity is evaluated
+// ONCE, by the block of its local dof 0.  The LDS copy of the block holds its own dofs followed by the dofs of
+// other blocks its entities touch, and the scatter position of every (entity, local dof) comes from a table that
+// takes the place of the masked dofmap -- no range tests, no stores from the quadrature loop's neighbourhood (the
+// kernel sits at its register bound).  At the end the own part is added to b and the halo part is written out
+// contiguously; vector_spill_reduce_kernel adds it to the rows it belongs to.
+template <class Op, bool SPLIT = false>
+__global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) vector_ownblock_kernel(mpcx_vector_args_t a)
+{
+  constexpr int N = Op::N0, ND = Op::ND0, BS = Op::BS0, NV = Op::NV;
+  constexpr int LMASK = (1 << MPCX_MASK_SHIFT) - 1;
+  const int NT = blockDim.x;
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* s_b = reinterpret_cast<double*>(smem); // [max_rows]: own rows, then halo rows
+  const int nb = a.plan.num_blocks;
+  const int per = (nb + 7) >> 3;
+  const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int tid = threadIdx.x;
+  const int r0 = b < nb ? a.plan.block_row0[b] : 0, r1 = b < nb ? a.plan.block_row0[b + 1] : 0;
+  const int64_t h0 = b < nb ? a.own_hoff[b] : 0, h1 = b < nb ? a.own_hoff[b + 1] : 0;
+  const int nown = r1 - r0, nhalo = int(h1 - h0) * BS;
+  for (int i = tid; i < nown + nhalo; i += NT)
+    s_b[i] = 0.0;
+  fastmath_init_lds(); // ends in a barrier
+  if (b >= nb)
+    return;
+  const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  const int32_t* __restrict__ ents = a.plan.block_ents;
+  for (int64_t t = e0 + tid; t < e1; t += NT)
+  {
+    const int64_t e = ents[t];
+    const int64_t l = e * a.estride;
+    const int64_t cell = (a.entities ? a.entities[l] : e);
+    const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
+    double cd[NV * 3];
+    gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
+    if constexpr (SPLIT)
+    {
+      using SOp = ElementOp<Op::TDIM, Op::DEG0, 1, Op::DEG0, 1, MPCX_FORM_SOURCE, Op::FN>;
+#pragma unroll 1
+      for (int k = 0; k < BS; ++k)
+      {
+        double bk[ND];
+        SOp::tabulate(bk, nullptr, a.constants, cd, lf, a.kernel, k);
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+        {
+          const int32_t w = a.own_lmap[e * ND + i]; // (read after the quadrature loop)
+          if (!((w >> (MPCX_MASK_SHIFT + k)) & 1))
+            __hip_atomic_fetch_add(s_b + (w & LMASK) * BS + k, bk[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
+    else
+    {
+      double be[N];
+      Op::tabulate(be, a.coeffs ? a.coeffs + e * a.cstride : nullptr, a.constants, cd, lf, a.kernel);
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+      {
+        const int32_t w = a.own_lmap[e * ND + i];
+#pragma unroll
+        for (int k = 0; k < BS; ++k)
+          if (!((w >> (MPCX_MASK_SHIFT + k)) & 1))
+            __hip_atomic_fetch_add(s_b + (w & LMASK) * BS + k, be[i * BS + k], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < nown; i += NT)
+    a.b[r0 + i] += s_b[i];
+  for (int i = tid; i < nhalo; i += NT)
+    a.own_spill[h0 * BS + i] = s_b[nown + i];
+}
+
+// second half of the owner-computes vector path: one thread per (distinct target dof, component)
+__global__ void vector_spill_reduce_kernel(int64_t n_rows, const int32_t* __restrict__ rows,
+                                           const int64_t* __restrict__ seg, const int32_t* __restrict__ src,
+                                           const double* __restrict__ spill, int bs, double* __restrict__ b)
+{
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n_rows * bs)
+    return;
+  const int64_t u = t / bs;
+  const int k = int(t - u * bs);
+  double sum = 0.0;
+  for (int64_t s = seg[u]; s < seg[u + 1]; ++s)
+    sum += spill[int64_t(src[s]) * bs + k];
+  b[int64_t(rows[u]) * bs + k] += sum;
+}
+
 template <class Op>
 __global__ void __launch_bounds__(64) vector_mpc_kernel(mpcx_vector_args_t a)
 {
@@ -1790,7 +1882,7 @@ int launch_vector(const mpcx_vector_args_t& a)
     alg = a.plan.num_blocks > 0 ? MPCX_ALG_ROWBLOCK : MPCX_ALG_ATOMIC;
   if (alg == MPCX_ALG_ROWBLOCK)
   {
-    if (a.plan.num_blocks <= 0 || !a.mdofmap)
+    if (a.plan.num_blocks <= 0 || (!a.mdofmap && !a.own_lmap))
     {
       mpcx_set_error("mpcx_assemble_vector: row-block algorithm needs a plan and the slave-masked dofmap");
       return -3;
@@ -1816,15 +1908,24 @@ int launch_vector(const mpcx_vector_args_t& a)
       return 0;
     };
     int lrc = 0;
+    const bool owner = a.own_lmap != nullptr;
+    if (owner && (!a.own_hoff || !a.own_spill || !a.own_seg || (a.n_own_rows > 0 && (!a.own_rows || !a.own_src))))
+    {
+      mpcx_set_error("mpcx_assemble_vector: incomplete owner-computes plan");
+      return -5;
+    }
     if constexpr (BY_COMPONENT)
     {
       if (split)
-        lrc = launch(vector_rowblock_kernel<Op, true>);
+        lrc = owner ? launch(vector_ownblock_kernel<Op, true>) : launch(vector_rowblock_kernel<Op, true>);
     }
     if (!split)
-      lrc = launch(vector_rowblock_kernel<Op, false>);
+      lrc = owner ? launch(vector_ownblock_kernel<Op, false>) : launch(vector_rowblock_kernel<Op, false>);
     if (lrc)
       return lrc;
+    if (owner && a.n_own_rows > 0)
+      hipLaunchKernelGGL(vector_spill_reduce_kernel, dim3(grid_for(a.n_own_rows * Op::BS0, 256)), dim3(256), 0, stream,
+                         a.n_own_rows, a.own_rows, a.own_seg, a.own_src, a.own_spill, int(Op::BS0), a.b);
     if (int rc = check(hipGetLastError(), "vector row-block kernel launch"))
       return rc;
     if (a.n_slave_entities > 0)

@@ -316,6 +316,20 @@ typedef struct
    * (0,6,4,7) (0,2,6,7).  entities / n_entities are ignored. */
   const int32_t* cube_verts;
   int64_t n_cubes;
+  /* MPCX_ALG_ROWBLOCK, owner-computes variant (own_lmap != NULL): plan.block_ents lists every entity ONCE, in the
+   * block that holds the rows of its local dof 0.  The LDS copy of a block holds its own dofs followed by the dofs of
+   * other blocks its entities touch (its halo): own_lmap[e][i] = LDS position (in dofs) of local dof i of entity e,
+   * slave flags of component k in bit 28 + k as in mdofmap; plan.max_rows counts own + halo rows.  The own part is
+   * added to b, the halo part is written to own_spill[(own_hoff[b] + j) * bs + k] (contiguous, no per-thread stores),
+   * and a second kernel adds the entries own_spill[own_src[s] * bs + k], s in [own_seg[u], own_seg[u + 1]), to the
+   * rows of dof own_rows[u].  No entity is evaluated twice, nothing is added atomically outside LDS. */
+  const int32_t* own_lmap;  /* DEVICE [n_entities][nd] */
+  const int64_t* own_hoff;  /* DEVICE [num_blocks + 1] halo dofs of the blocks */
+  double* own_spill;        /* DEVICE [halo dofs * bs] */
+  const int32_t* own_src;   /* DEVICE [halo dofs] halo slots ordered by target dof */
+  const int32_t* own_rows;  /* DEVICE [n_own_rows] distinct target dofs (blocked), ascending */
+  const int64_t* own_seg;   /* DEVICE [n_own_rows + 1] */
+  int64_t n_own_rows;
   void* stream;
 } mpcx_vector_args_t;
 

@@ -221,6 +221,24 @@ def test_small_cases_kernel_variants(oracle, make, alg, env, monkeypatch):
     _close(out["A"].data, ref["A"].data, RTOL_A, f"{case.name} A [{env}]")
 
 
+@pytest.mark.parametrize("env", ["MPCX_VECTOR_OWNER=1", "MPCX_VECTOR_OWNER=0"])
+@pytest.mark.parametrize("make", CASES, ids=[f"case{i}" for i in range(len(CASES))])
+def test_small_cases_vector_kernel_variants(oracle, make, env, monkeypatch):
+    """the row-block vector kernels for every case (MPCX_VECTOR_ALG=rowblock), with the owner-computes lists
+    (vector_ownblock_kernel + vector_spill_reduce_kernel: every entity evaluated once, halo rows through LDS and a
+    spill array) forced on / off -- the default takes them for rules of more than four points only"""
+    monkeypatch.setenv("MPCX_VECTOR_ALG", "rowblock")
+    monkeypatch.setenv(*env.split("="))
+    case = make()
+    if case.L is None:
+        pytest.skip("no linear form")
+    ref = oracle_outputs(oracle, case)
+    out = product_outputs(case, algorithm="rowblock")
+    for k in ("b", "b_lifted"):
+        if k in ref:
+            _close(out[k], ref[k], RTOL_B, f"{case.name} {k} [{env}]")
+
+
 def test_reproducibility_statement(oracle):
     """What repeated assembly of the same system guarantees (determinism):
     * pattern, plans and the master contributions (one thread per target position, fixed tuple order)
