@@ -96,10 +96,14 @@ def _worker(rank, world, port, N, reorder, outdir, kind="poisson"):
 def test_slab_partition_matches_global_assembly(oracle, tmp_path, world, N, reorder, kind):
     import torch.multiprocessing as mp
 
-    from dolfinx_mpc_amd.mesh import create_box
-
     port = _free_port()
     mp.spawn(_worker, args=(world, port, N, reorder, str(tmp_path), kind), nprocs=world, join=True)
+    _check_against_global_assembly(oracle, tmp_path, world, N, kind)
+
+
+def _check_against_global_assembly(oracle, tmp_path, world, N, kind):
+    """the ranks' owned rows (rank{r}.npz, global dof ids) against the oracle on the unpartitioned mesh"""
+    from dolfinx_mpc_amd.mesh import create_box
 
     gmesh = create_box((0, 0, 0), (1, 1, float(world)), (N, N, N * world))
     V, bc, raw, a, L = _problem(gmesh, world, N, kind)
@@ -144,7 +148,7 @@ def test_slab_partition_matches_global_assembly(oracle, tmp_path, world, N, reor
     assert np.allclose(b, bref, rtol=0, atol=1e-13 * abs(bref).max())
 
 
-def _gpu_worker(rank, world, port, N, reorder, outdir):
+def _gpu_worker(rank, world, port, N, reorder, outdir, kind="poisson"):
     """Same as _worker but the local assembly runs through the HIP kernels (both
     ranks share cuda:0; transport is gloo with host staging because RCCL refuses
     two ranks on one device)."""
@@ -162,20 +166,22 @@ def _gpu_worker(rank, world, port, N, reorder, outdir):
     # file rendezvous inside the test's tmp dir: no port to race for
     dist.init_process_group("gloo", init_method=f"file://{outdir}/rendezvous", rank=rank, world_size=world)
     mesh = create_slab_mesh(N, rank, world, reorder)
-    V, bc, raw, a, L = _problem(mesh, world, N)
+    V, bc, raw, a, L = _problem(mesh, world, N, kind)
+    bs = V.dofmap.bs
     mpc = dm.MultiPointConstraint(V)
     mpc.add_constraint(V, *raw)
     mpc.finalize()
     A = dm.assemble_matrix(a, mpc, bcs=[bc], algorithm="rowblock")
     b = dm.assemble_vector(L, mpc)
     dm.apply_lifting(b, [a], [[bc]], mpc)
-    ex = SlabExchange(mesh, A.rowptr, A.cols, rank, world, device=torch.device("cuda", 0))
+    ex = SlabExchange(mesh, A.rowptr, A.cols, rank, world, device=torch.device("cuda", 0), bs=bs,
+                      space=V if V.degree == 2 else None)
     ex.reduce_matrix(A)
     ex.reduce_vector(b)
     torch.cuda.synchronize()
     S = A.to_scipy()
-    g = mesh.node_global
-    nown = mesh.num_owned_nodes
+    g = (V.dof_global[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)  # global unrolled dof ids
+    nown = V.dofmap.index_map.size_local * bs
     Aown = S[:nown].tocoo()
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), row=g[Aown.row], col=g[Aown.col], val=Aown.data,
              brow=g[:nown], bval=b.numpy()[:nown], nslaves=mpc.num_local_slaves)
@@ -184,31 +190,16 @@ def _gpu_worker(rank, world, port, N, reorder, outdir):
 
 
 @pytest.mark.gpu
-def test_slab_partition_gpu_kernels_two_ranks(oracle, tmp_path):
+@pytest.mark.parametrize("kind,N", [("poisson", 6), ("p2", 4), ("elasticity", 4)])
+def test_slab_partition_gpu_kernels_two_ranks(oracle, tmp_path, kind, N):
+    """the HIP kernels on two ranks (cluster / row-pair / row-block matrix kernels, cluster and owner-computes
+    vector kernels on slab meshes with ghost cells) + the interface exchange against the unpartitioned oracle"""
     import torch.multiprocessing as mp
 
-    from dolfinx_mpc_amd.mesh import create_box
-
-    world, N, reorder = 2, 6, (4, 4, 4)
+    world, reorder = 2, (4, 4, 4)
     port = _free_port()
-    mp.spawn(_gpu_worker, args=(world, port, N, reorder, str(tmp_path)), nprocs=world, join=True)
-    gmesh = create_box((0, 0, 0), (1, 1, float(world)), (N, N, N * world))
-    V, bc, raw, a, L = _problem(gmesh, world, N)
-    mpc = oracle.OracleMPC.from_raw(V, *raw)
-    Aref = oracle.assemble_matrix(a, mpc, bcs=[bc])
-    bref = oracle.assemble_vector(L, mpc)
-    oracle.apply_lifting(bref, [a], [[bc]], mpc)
-    n = V.num_dofs
-    rows, cols, vals, brow, bval = [], [], [], [], []
-    for r in range(world):
-        d = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
-        rows.append(d["row"]), cols.append(d["col"]), vals.append(d["val"])
-        brow.append(d["brow"]), bval.append(d["bval"])
-    A = scipy.sparse.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsr()
-    assert abs(A - Aref).max() < 1e-12 * abs(Aref).max()
-    b = np.zeros(n)
-    b[np.concatenate(brow)] = np.concatenate(bval)
-    assert np.allclose(b, bref, rtol=0, atol=1e-12 * abs(bref).max())
+    mp.spawn(_gpu_worker, args=(world, port, N, reorder, str(tmp_path), kind), nprocs=world, join=True)
+    _check_against_global_assembly(oracle, tmp_path, world, N, kind)
 
 
 # ---------------------------------------------------------------------------------------------
