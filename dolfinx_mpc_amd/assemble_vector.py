@@ -77,9 +77,11 @@ def _vector_owner_plan(form: Form, i: int, V, md0, rows: int):
     of its local dof 0; the dofs of other blocks its entities touch are the block's halo, appended to its LDS copy.
     ``md0``: the slave-masked dofmap (its flag bits move into the position table).  Returns None when a block with
     its halo does not fit the LDS budget."""
-    key = ("voplan", i, rows, id(md0))
-    if key in form._device:
-        return form._device[key][0]
+    return D.cached(form._device, "voplan", (md0,), (i, rows), lambda: _build_vector_owner_plan(form, i, V, md0, rows),
+                    maxsize=2)
+
+
+def _build_vector_owner_plan(form: Form, i: int, V, md0, rows: int):
     import torch
 
     from .assemble_matrix import _block_ranges
@@ -116,7 +118,6 @@ def _vector_owner_plan(form: Form, i: int, V, md0, rows: int):
     torch.cumsum(torch.bincount(hblk, minlength=nb), 0, out=hoff[1:])
     max_rows = int(((nown + (hoff[1:] - hoff[:-1])) * bs).max().item()) if nb > 0 else 0
     if max_rows > VECTOR_LDS_ROWS:
-        form._device[key] = (None,)
         return None
     lmap = dof - first[owner][:, None]
     lmap[fe, fi] = nown[owner[fe]] + (inv - hoff[hblk[inv]])
@@ -129,8 +130,7 @@ def _vector_owner_plan(form: Form, i: int, V, md0, rows: int):
     t = (d_row0, off, order.to(torch.int32).contiguous(), lmap, hoff, spill, sorder.to(torch.int32).contiguous(),
          urows.to(torch.int32).contiguous(), seg)
     plan = _native.RowBlockPlanT(nb, max_rows, max_rows, 0, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), None, None)
-    form._device[key] = ((plan, t, int(urows.numel())), md0)  # md0 kept alive: its id is part of the key
-    return form._device[key][0]
+    return (plan, t, int(urows.numel()))
 
 
 def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint, alg: int, allow_cubes: bool = True):
