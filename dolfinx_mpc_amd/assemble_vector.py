@@ -78,7 +78,7 @@ def _vector_owner_plan(form: Form, i: int, V, md0, rows: int):
     ``md0``: the slave-masked dofmap (its flag bits move into the position table).  Returns None when a block with
     its halo does not fit the LDS budget."""
     return D.cached(form._device, "voplan", (md0,), (i, rows), lambda: _build_vector_owner_plan(form, i, V, md0, rows),
-                    maxsize=2)
+                    maxsize=4)
 
 
 def _build_vector_owner_plan(form: Form, i: int, V, md0, rows: int):
