@@ -178,15 +178,20 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
     # scalar P2 source with the basis table (mpcx_kernel_t::qphi) on a tiled numbering: large row blocks win for any rule
     p2_fast = (V.degree == 2 and V.dof_tile_offsets is not None and k.form == 2 and k.coeff_degree == 0
                and integ.itype == "cell")
-    if (alg == 2 or (alg == 0 and (nq <= nq_max or p2_fast))) and integ.num_entities > 0:
+    owner_mode = os.environ.get("MPCX_VECTOR_OWNER", "auto")
+    # many-point rules on a tiled numbering: row blocks with owner-computes lists beat the hash kernel too (P1, 14
+    # points, 256^3 without clusters: 3.77 -> 3.26 ms); without a tiled numbering the halo would not fit LDS
+    own_any = (owner_mode == "auto" and nq > 4 and V.dof_tile_offsets is not None and integ.itype == "cell")
+    if (alg == 2 or (alg == 0 and (nq <= nq_max or p2_fast or own_any))) and integ.num_entities > 0:
         from .assemble_matrix import _masked_dofmap, _slave_entities
 
         # blocked spaces: the same number of NODES per block (vector P1, contact benchmark: 0.43 -> 0.29 ms)
         rows = VECTOR_BLOCK_ROWS if "MPCX_VECTOR_BLOCK_ROWS" in os.environ else VECTOR_BLOCK_ROWS * V.dofmap.bs
         nrows_blk = VECTOR_BLOCK_ROWS_P2 if (p2_fast and nq > nq_max) else rows
+        if own_any and not p2_fast and nq > nq_max:
+            nrows_blk = max(nrows_blk, 2048 * V.dofmap.bs)
         md0 = _masked_dofmap(form, V, None, constraint, 0)  # slave flag only: bcs do not touch b here
         own = None
-        owner_mode = os.environ.get("MPCX_VECTOR_OWNER", "auto")
         if owner_mode == "1" or (owner_mode == "auto" and nq > 4):
             # owner-computes lists (no entity evaluated once per block it touches) where the quadrature is what
             # costs (P2 source 246^3, 24 points: 6.6 -> 5.7 ms; Stokes b0 1.68 -> 1.46; a one-point rule loses:
@@ -199,6 +204,9 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
             plan, pk, n_own = own
             a.own_lmap, a.own_hoff, a.own_spill = pk[3].data_ptr(), pk[4].data_ptr(), pk[5].data_ptr()
             a.own_src, a.own_rows, a.own_seg, a.n_own_rows = pk[6].data_ptr(), pk[7].data_ptr(), pk[8].data_ptr(), n_own
+        elif alg == 0 and nq > nq_max and not p2_fast:
+            a.stream = D.stream_ptr()
+            return a, keep  # no owner plan within the LDS budget: the hash kernel (a.algorithm == 1)
         else:
             plan, pk = _vector_plan(form, i, V, nrows_blk)
         _, slave_ents = _slave_entities(form, i, constraint, constraint)
