@@ -64,8 +64,15 @@ def mesh_device(mesh):
         mesh._device[key] = {
             "x": _to_dev(mesh.geometry.x, dev),
             "x_dofmap": _to_dev(mesh.geometry.dofmap, dev),
+            "x_version": mesh.geometry.version,
         }
-    return mesh._device[key]
+    d = mesh._device[key]
+    if d["x_version"] != mesh.geometry.version:
+        # the mesh was moved (mesh.geometry.x = ...): same tensor, new values, so that argument blocks and plans
+        # that hold its address stay valid (the reference re-reads x on every call, cpp/assemble_matrix.cpp:495-501)
+        d["x"].copy_(_to_dev(mesh.geometry.x, dev))
+        d["x_version"] = mesh.geometry.version
+    return d
 
 
 def space_device(V: FunctionSpace):
@@ -128,7 +135,7 @@ def integral_device(form: Form, i: int):
         d = {
             "entities": None if ident else _to_dev(integ.entities.astype(np.int32).reshape(-1), dev),
             "coeffs": None,
-            "coeff_version": ("never",),
+            "coeff_host": None,  # per coefficient: (copy of the dof values the device pack was made from, device dofs)
             "constants": None,
             "constants_host": None,
             "qpts": _to_dev(k.qpts.astype(np.float64).reshape(-1), dev),
@@ -146,14 +153,53 @@ def integral_device(form: Form, i: int):
         )
         form._device[key] = d
     d = form._device[key]
-    if integ.coefficient is not None and d["coeff_version"] != integ.coeff_version:
-        d["coeffs"] = _to_dev(integ.coeffs.astype(np.float64, copy=False), dev)
-        d["coeff_version"] = integ.coeff_version
+    if integ.coefficient is not None:
+        _refresh_coefficients(form, integ, d, dev)
     c = integ.constants
     if c is not None and (d["constants_host"] is None or not np.array_equal(c, d["constants_host"])):
         d["constants_host"] = c.copy()
         d["constants"] = _to_dev(d["constants_host"], dev)
     return d
+
+
+def _refresh_coefficients(form: Form, integ: Integral, d: dict, dev):
+    """Packed coefficients of one integral on the device, float64 [n_entities][cstride] in the layout of dolfinx
+    ``pack_coefficients``.  The reference packs on every call (cpp/assemble_matrix.cpp:587-589); here the CURRENT
+    dof values of every coefficient are compared with the copy the device pack was made from (a caller may keep
+    ``f.x.array`` and write through it at any time, so nothing short of looking at the values is reliable) and
+    only a changed coefficient is uploaded again; the gather through the dofmap runs on the device (torch:
+    plumbing)."""
+    import torch
+
+    if isinstance(integ.coefficient, np.ndarray):  # packed by the caller
+        if d["coeff_host"] is None or not np.array_equal(integ.coefficient, d["coeff_host"]):
+            d["coeff_host"] = integ.coefficient.copy()
+            d["coeffs"] = _to_dev(integ.coefficient.astype(np.float64, copy=False), dev)
+        return
+    fs = integ.coefficient_functions
+    if d["coeff_host"] is None:
+        d["coeff_host"] = [[None, None] for _ in fs]
+    dirty = False
+    for slot, f in zip(d["coeff_host"], fs):
+        cur = f.x._data
+        if slot[0] is None or not np.array_equal(cur, slot[0]):
+            slot[0] = cur.copy()
+            slot[1] = _to_dev(slot[0], dev)
+            dirty = True
+    if not dirty and d["coeffs"] is not None:
+        return
+    n = integ.num_entities
+    cells = None if d["entities"] is None else d["entities"].view(n, integ.estride)[:, 0].long()
+    parts = []
+    for slot, f in zip(d["coeff_host"], fs):
+        Vc = f.function_space
+        dm = space_device(Vc)["dofmap"].view(-1, Vc.element_ndofs)
+        dofs = (dm[:n] if cells is None else dm[cells]).long()
+        bs = Vc.dofmap.bs
+        if bs > 1:
+            dofs = (dofs[:, :, None] * bs + torch.arange(bs, device=dev)[None, None, :]).reshape(n, -1)
+        parts.append(slot[1][dofs])
+    d["coeffs"] = (parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)).contiguous()
 
 
 def bc_markers(V: FunctionSpace, bcs, cache: dict):

@@ -363,6 +363,12 @@ def lib() -> C.CDLL:
     return L
 
 
+class PlanNotRepresentable(RuntimeError):
+    """A row-block / cluster plan cannot express this problem (a scatter offset beyond 8 bits, a block beyond the
+    LDS budget, ...): the caller may fall back to the thread-per-entity algorithm.  Device faults, launch errors
+    and out-of-memory conditions are NOT of this type and propagate."""
+
+
 def check(rc: int, what: str):
     """Native return codes -> RuntimeError, like nanobind turns the reference's
     std::runtime_error into RuntimeError (SURVEY.md section 8b)."""

@@ -245,7 +245,7 @@ def _block_pairs_device(row0: np.ndarray, n_entities: int, estride: int, entitie
     nb = row0.size - 1
     d_row0 = D._to_dev(row0, dev)
     if n_entities * nd >= 2 ** 31:
-        raise RuntimeError("row-pair plan: entity * nd + i does not fit 32 bits")
+        raise _native.PlanNotRepresentable("row-pair plan: entity * nd + i does not fit 32 bits")
     if entities_dev is None:
         dof = dofmap_dev[:n_entities].reshape(-1)
     else:
@@ -264,7 +264,7 @@ def _block_pairs_device(row0: np.ndarray, n_entities: int, estride: int, entitie
     rank = torch.arange(M, device=dev, dtype=torch.int64) - torch.repeat_interleave(starts, counts)
     del starts, counts
     if int(rank.max().item()) >= 2 ** 12 or int(loc.max().item()) >= 2 ** 24:
-        raise RuntimeError("row-pair plan: more than 4096 entities round one dof")
+        raise _native.PlanNotRepresentable("row-pair plan: more than 4096 entities round one dof")
     del loc
     key = (key & ~((1 << 36) - 1)) | (rank << 24) | (key & ((1 << 24) - 1))
     del rank
@@ -375,8 +375,9 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False, pai
                                     V1.dofmap.bs, int(lean), offs.data_ptr(), flag.data_ptr(), D.stream_ptr())
         _native.check(rc, "mpcx_scatter_offsets")
         if int(flag.item()) != 0:
-            raise RuntimeError("row-block algorithm: a CSR row holds more than 255 column blocks before one of the "
-                               "entity's columns (or a column is missing from the pattern); use algorithm='atomic'")
+            raise _native.PlanNotRepresentable(
+                "row-block algorithm: a CSR row holds more than 255 column blocks before one of the "
+                "entity's columns (or a column is missing from the pattern); use algorithm='atomic'")
         # dictionary compression: structured / tiled meshes have few distinct offset rows, so the
         # kernel reads a 2-byte id per entity plus a cache-resident table instead of nd0*nd1 bytes
         noff = V0.element_ndofs * V1.element_ndofs
@@ -415,7 +416,7 @@ def _rowpair_eligible(form: Form, i: int, V0, V1) -> bool:
         return False
     integ = form.integrals[i]
     kf = integ.kernel
-    if integ.itype != "cell" or integ.coeffs is not None:
+    if integ.itype != "cell" or integ.coefficient is not None:
         return False
     d0, d1 = V0.degree, V1.degree
     if mode != "all" and not (d0 == 1 and d1 == 1 and V0.dofmap.bs > 1):
@@ -475,7 +476,7 @@ def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc):
                                  A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), recs.data_ptr(), flag.data_ptr(), D.stream_ptr())
         _native.check(rc, "mpcx_cube_records")
         if int(flag.item()) != 0:
-            raise RuntimeError("cluster algorithm: a scatter offset does not fit 8 bits (or a column is missing)")
+            raise _native.PlanNotRepresentable("cluster algorithm: a scatter offset does not fit 8 bits (or a column is missing)")
         keep = (d_row0, d_off, recs)
         max_rows = int(np.diff(row0).max())
         max_nnz = int(np.diff(A.rowptr[row0]).max())
@@ -486,7 +487,7 @@ def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc):
 
     try:
         plan, keep, info = D.cached(A._plans, "cubes", (form, mpc, bc_dev), (i, CUBE_MAX_ROWS, CUBE_MAX_NNZ), build)
-    except RuntimeError:
+    except _native.PlanNotRepresentable:
         return None
     return plan, keep, info, left
 
@@ -500,7 +501,7 @@ def _leftover_form(form: Form, i: int, left: np.ndarray) -> Form:
         return Form(form.function_spaces, [Integral("cell", np.ascontiguousarray(left, dtype=np.int32), integ.kernel,
                                                     None, integ.constant)])
 
-    return D.cached(form._device, "leftover", (), (i, left.size), build)
+    return D.cached(form._device, "leftover", (left,), i, build)
 
 
 def _mpc_plan(A: MPCMatrix, form: Form, i: int, mpc0, mpc1, bc0_h, bc1_h, slave_ents_h):
@@ -611,7 +612,7 @@ def _masked_dofmap(form: Form, V, bc_dev, mpc, which: int, rotate: bool = False)
 
     def build():
         if V.num_dofs // V.dofmap.bs >= (1 << 28):
-            raise RuntimeError("row-block algorithm: more than 2^28 dof blocks per GPU; shard the mesh")
+            raise _native.PlanNotRepresentable("row-block algorithm: more than 2^28 dof blocks per GPU; shard the mesh")
         sd = D.space_device(V)
         _, t = mpc._device()
         out = torch.empty_like(sd["dofmap"])
@@ -646,7 +647,7 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
     a.estride, a.n_entities = integ.estride, integ.num_entities
     a.entities = a.entities0 = a.entities1 = idv["entities_ptr"]
     a.coeffs = D.ptr(idv["coeffs"])
-    a.cstride = 0 if integ.coeffs is None else integ.coeffs.shape[1]
+    a.cstride = integ.cstride
     a.constants = D.ptr(idv["constants"])
     a.dofmap0, a.nd0, a.bs0 = s0["dofmap"].data_ptr(), V0.element_ndofs, V0.dofmap.bs
     a.dofmap1, a.nd1, a.bs1 = s1["dofmap"].data_ptr(), V1.element_ndofs, V1.dofmap.bs
@@ -683,7 +684,7 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
         # lean path (include/mpcx.h, mpcx_matrix_args_t::lean): square P1-type form over all cells
         same = V1 is V0 and mpc1 is mpc0 and bc1 is bc0
         lean = (same and s0["dofmap"] is md["x_dofmap"] and idv["entities_ptr"] is None and integ.estride == 1
-                and integ.coeffs is None and not os.environ.get("MPCX_NO_LEAN"))
+                and integ.coefficient is None and not os.environ.get("MPCX_NO_LEAN"))
         if lean and allow_cubes and _cube_eligible(form, i, V0):
             cp = _cube_plan(A, form, i, V0, bc0, mpc0)
             if cp is not None:
@@ -787,7 +788,7 @@ def assemble_matrix(
 
     try:
         calls, zeroed = prepare(alg)
-    except RuntimeError:
+    except _native.PlanNotRepresentable:
         if not auto:
             raise
         # rows with more than 255 column blocks before an entity's column, tiny LDS ...: thread-per-entity atomics

@@ -148,7 +148,7 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
     a.estride, a.n_entities = integ.estride, integ.num_entities
     a.entities = a.entities0 = idv["entities_ptr"]
     a.coeffs = D.ptr(idv["coeffs"])
-    a.cstride = 0 if integ.coeffs is None else integ.coeffs.shape[1]
+    a.cstride = integ.cstride
     a.constants = D.ptr(idv["constants"])
     a.dofmap, a.nd, a.bs = sd["dofmap"].data_ptr(), V.element_ndofs, V.dofmap.bs
     a.mpc = m
@@ -156,7 +156,7 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
     keep = [md, sd, mkeep, idv]
     a.leftover = None  # (python attribute) cells the cluster kernel does not cover
     k = integ.kernel
-    if (alg in (0, 1) and allow_cubes and not os.environ.get("MPCX_NO_CUBE") and k.form == 2 and k.celltype == 2
+    if (alg == 0 and allow_cubes and not os.environ.get("MPCX_NO_CUBE") and k.form == 2 and k.celltype == 2
             and k.degree == 1 and k.bs == 1 and k.coeff_degree == 0 and integ.coefficient is None and integ.itype == "cell"
             and idv["entities_ptr"] is None and sd["dofmap"] is md["x_dofmap"]):
         # scalar P1 source over all cells: one thread per cell cluster (MPCX_ALG_CUBE, csrc/mpcx_cubes.hip)
@@ -343,7 +343,7 @@ def apply_lifting(
             a.estride, a.n_entities = integ.estride, integ.num_entities
             a.entities = a.entities0 = a.entities1 = idv["entities_ptr"]
             a.coeffs = D.ptr(idv["coeffs"])
-            a.cstride = 0 if integ.coeffs is None else integ.coeffs.shape[1]
+            a.cstride = integ.cstride
             a.constants = D.ptr(idv["constants"])
             a.dofmap0, a.nd0, a.bs0 = s0["dofmap"].data_ptr(), V0.element_ndofs, V0.dofmap.bs
             a.dofmap1, a.nd1, a.bs1 = s1["dofmap"].data_ptr(), V1.element_ndofs, V1.dofmap.bs

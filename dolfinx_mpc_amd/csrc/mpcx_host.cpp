@@ -418,7 +418,8 @@ extern "C" int mpcx_rowblock_plan_copy(void* p, int32_t* block_row0, int64_t* bl
   auto* P = static_cast<RowBlockPlan*>(p);
   std::memcpy(block_row0, P->block_row0.data(), P->block_row0.size() * sizeof(int32_t));
   std::memcpy(block_ent_off, P->block_ent_off.data(), P->block_ent_off.size() * sizeof(int64_t));
-  std::memcpy(block_ents, P->block_ents.data(), P->block_ents.size() * sizeof(int32_t));
+  if (block_ents && !P->block_ents.empty())
+    std::memcpy(block_ents, P->block_ents.data(), P->block_ents.size() * sizeof(int32_t));
   return 0;
 }
 extern "C" void mpcx_rowblock_plan_free(void* p) { delete static_cast<RowBlockPlan*>(p); }

@@ -203,7 +203,7 @@ def create_stacked_cubes_slab(n_top: int, rank: int, world: int, theta: float = 
                             (f_bot, CONTACT_BOTTOM))])
     if theta != 0.0:
         R = rotation_matrix([1 / np.sqrt(2), 1 / np.sqrt(2), 0], -theta)
-        mesh.geometry.x[:] = mesh.geometry.x @ R.T
+        mesh.geometry.x = mesh.geometry.x @ R.T
     return mesh, MeshTags(mesh, 2, ents, vals)
 
 

@@ -185,6 +185,25 @@ class FunctionSpace:
         return (m.size_local + m.num_ghosts) * self.dofmap.index_map_bs
 
     def tabulate_dof_coordinates(self) -> np.ndarray:
+        gv = self.mesh.geometry.version
+        if self._dof_coords is not None and getattr(self, "_dof_coords_version", 0) != gv:
+            # the mesh was moved: recompute from the dofmap (P1: the nodes; P2: nodes and edge midpoints)
+            x = self.mesh.geometry.x
+            if self.degree == 1 and self.dofmap.list.shape == self.mesh.geometry.dofmap.shape \
+                    and np.array_equal(self.dofmap.list, self.mesh.geometry.dofmap):
+                self._dof_coords = x
+            else:
+                from .mesh import TET_EDGES, TRI_EDGES
+
+                le = TET_EDGES if self.mesh.tdim == 3 else TRI_EDGES
+                nv = self.mesh.tdim + 1
+                xc = x[self.mesh.geometry.dofmap]  # (nc, nv, 3)
+                out = np.empty((self.dofmap.list.max() + 1, 3))
+                out[self.dofmap.list[:, :nv]] = xc
+                if self.degree == 2:
+                    out[self.dofmap.list[:, nv:]] = 0.5 * (xc[:, le[:, 0]] + xc[:, le[:, 1]])
+                self._dof_coords = out
+            self._dof_coords_version = gv
         if self._dof_coords is None:
             x = self.mesh.geometry.x
             if self.degree == 1:
@@ -192,6 +211,7 @@ class FunctionSpace:
             else:
                 _, ev = self.mesh.edges()
                 self._dof_coords = np.concatenate([x, 0.5 * (x[ev[:, 0]] + x[ev[:, 1]])], axis=0)
+            self._dof_coords_version = gv
         return self._dof_coords
 
     def contains(self, other: "FunctionSpace") -> bool:
@@ -205,24 +225,21 @@ def functionspace(mesh: Mesh, element, shape: Optional[tuple] = None) -> Functio
 
 
 class _Vector:
-    """Host dof array of a ``Function``.  ``array`` hands out the writable numpy array and counts the
-    hand-outs in ``version``: consumers that keep a packed / device copy (coefficients, Dirichlet
-    values) compare versions and refresh after ANY access by the user, so that values updated between
-    two assemblies are never stale -- the reference packs coefficients and reads boundary values on
-    every call (cpp/assemble_matrix.cpp:587-589, cpp/lifting.h:166-180)."""
+    """Host dof array of a ``Function``.  ``array`` hands out the writable numpy array, and a caller may keep
+    that view and write through it at any time, so nothing here tries to track changes: consumers that
+    keep a packed / device copy (coefficients, Dirichlet values) COMPARE the current values with the copy
+    they uploaded on every assembly call and refresh when they differ -- the reference packs coefficients
+    and reads boundary values on every call (cpp/assemble_matrix.cpp:587-589, cpp/lifting.h:166-180)."""
 
     def __init__(self, n: int):
         self._data = np.zeros(n, dtype=np.float64)
-        self.version = 0
 
     @property
     def array(self) -> np.ndarray:
-        self.version += 1
         return self._data
 
     @array.setter
     def array(self, value):
-        self.version += 1
         self._data[:] = value
 
 
@@ -358,11 +375,11 @@ class KernelSpec:
 
 class Integral:
     """One integral of a form: kind, integration entities, element kernel, and the SOURCES of the
-    packed data the kernel reads -- ``coefficient`` (a ``Function`` or None) and ``constant``
-    (a ``Constant``, raw numbers, or None).  ``coeffs`` / ``constants`` pack them when read, like
-    dolfinx ``pack_coefficients`` / ``pack_constants`` do on every assembly call
-    (cpp/assemble_matrix.cpp:583-589); the coefficient pack is reused while the function's dof array
-    has not been handed out again (``_Vector.version``)."""
+    packed data the kernel reads -- ``coefficient`` (a ``Function``, a list of Functions, an already
+    packed array, or None) and ``constant`` (a ``Constant``, raw numbers, or None).  ``coeffs`` /
+    ``constants`` pack them when read, like dolfinx ``pack_coefficients`` / ``pack_constants`` do on every
+    assembly call (cpp/assemble_matrix.cpp:583-589): for every entity the cell dofs of every coefficient
+    in turn, unrolled ``dof * bs + k`` for blocked coefficient spaces."""
 
     def __init__(self, itype: str, entities: np.ndarray, kernel: KernelSpec, coefficient=None, constant=None):
         self.itype = itype  # "cell" | "exterior_facet"
@@ -370,25 +387,44 @@ class Integral:
         self.kernel = kernel
         self.coefficient = coefficient
         self.constant = constant
-        self._packed = (None, None)  # (version, array)
+
+    @property
+    def coefficient_functions(self) -> list:
+        """the ``Function`` objects behind the packed coefficients (empty for none / a pre-packed array)"""
+        f = self.coefficient
+        if f is None or isinstance(f, np.ndarray):
+            return []
+        return list(f) if isinstance(f, (list, tuple)) else [f]
+
+    @property
+    def cstride(self) -> int:
+        """packed coefficient values per entity (``coeffs.shape[1]``), without packing"""
+        f = self.coefficient
+        if f is None:
+            return 0
+        if isinstance(f, np.ndarray):
+            return int(f.shape[1])
+        return int(sum(g.function_space.element_ndofs * g.function_space.dofmap.bs for g in self.coefficient_functions))
 
     @property
     def coeffs(self) -> Optional[np.ndarray]:
-        """float64[n, cstride] packed coefficient dofs of the entities' cells, or None"""
+        """float64[n, cstride] packed coefficient dofs of the entities' cells, or None; packed from the
+        CURRENT dof values on every read"""
         f = self.coefficient
         if f is None:
             return None
         if isinstance(f, np.ndarray):  # already packed by the caller
             return f
-        if self._packed[0] != f.x.version:
-            Vc = f.function_space
-            self._packed = (f.x.version, np.ascontiguousarray(f.x._data[Vc.dofmap.list[self.cells]]))
-        return self._packed[1]
-
-    @property
-    def coeff_version(self):
-        f = self.coefficient
-        return None if f is None or isinstance(f, np.ndarray) else f.x.version
+        cells = self.cells
+        parts = []
+        for g in self.coefficient_functions:
+            Vc = g.function_space
+            bs = Vc.dofmap.bs
+            dofs = Vc.dofmap.list[cells].astype(np.int64)
+            if bs > 1:
+                dofs = (dofs[:, :, None] * bs + np.arange(bs)[None, None, :]).reshape(dofs.shape[0], -1)
+            parts.append(g.x._data[dofs])
+        return np.ascontiguousarray(parts[0] if len(parts) == 1 else np.concatenate(parts, axis=1))
 
     @property
     def constants(self) -> Optional[np.ndarray]:
@@ -518,15 +554,18 @@ def form_source(V, fn_id: int = FN_ONE, constant=None, coefficient: Optional[Fun
 
 
 def form_ufcx(spaces: Sequence[FunctionSpace], source: str, function_name: str, itype: str = "cell", entities=None,
-              coefficient: Optional[Function] = None, constant=None) -> Form:
+              coefficient=None, constant=None) -> Form:
     """A form whose element kernel is an imported UFCx ``tabulate_tensor`` given as C SOURCE (what FFCx
     writes to disk; the reference calls the compiled function through a pointer,
     cpp/assemble_matrix.cpp:438-439).  ``spaces`` = [V] (linear form) or [V0, V1] (bilinear form: rows V0,
     columns V1); the function must write the row-major [nd0*bs0][nd1*bs1] tensor of ONE entity with the
     blocked dof index i*bs + k, accumulate into A (handed over zeroed) and read the local facet of an
     exterior-facet integral from ``entity_local_index[0]``.  ``entities``: cells (default all owned cells) or
-    (cell, local_facet) pairs for ``itype="exterior_facet"``.  The kernel runs on the device (hipRTC) through
-    the generic per-entity kernels (device atomics)."""
+    (cell, local_facet) pairs for ``itype="exterior_facet"``.  ``coefficient``: a ``Function`` or a list of them
+    in the order the form declares its coefficients; ``w`` then holds, per entity, the cell dofs of each in turn,
+    unrolled ``dof * bs + k`` for blocked spaces (dolfinx ``pack_coefficients``).  The kernel is compiled for
+    gfx950 with hipRTC and runs inside the LDS row-block kernels (or the per-entity kernels with device atomics
+    when ``algorithm="atomic"``)."""
     spaces = list(spaces)
     V0 = spaces[0]
     V1 = spaces[1] if len(spaces) > 1 else None

@@ -10,8 +10,6 @@ per node (cpp/assemble_matrix.cpp:473, 499).
 
 from __future__ import annotations
 
-from dataclasses import dataclass
-
 import numpy as np
 
 # local facets: facet i is opposite vertex i (Basix/UFC convention)
@@ -28,10 +26,38 @@ _KUHN = np.array(
 )
 
 
-@dataclass
 class Geometry:
-    x: np.ndarray  # (num_nodes, 3) float64
-    dofmap: np.ndarray  # (num_cells, nv) int32
+    """``x`` (num_nodes, 3) float64 and ``dofmap`` (num_cells, nv) int32.
+
+    The reference gathers the coordinates from ``mesh.geometry.x`` on every assembly call
+    (cpp/assemble_matrix.cpp:495-501), so a moved mesh is picked up automatically.  Here the kernels read
+    a device mirror, and comparing 400 MB of host coordinates per call would cost more than the assembly:
+    ``x`` is therefore handed out READ-ONLY (an in-place write raises instead of silently assembling on
+    stale coordinates) and a moved mesh is stated explicitly, ``mesh.geometry.x = new_x`` (or
+    ``set_x``), which bumps ``version``; the device mirror is refreshed when the version differs."""
+
+    def __init__(self, x: np.ndarray, dofmap: np.ndarray):
+        self._x = np.array(x, dtype=np.float64, order="C", copy=True)
+        self._x.flags.writeable = False
+        self.dofmap = dofmap
+        self.version = 0
+
+    @property
+    def x(self) -> np.ndarray:
+        return self._x
+
+    @x.setter
+    def x(self, value):
+        self.set_x(value)
+
+    def set_x(self, value):
+        value = np.asarray(value, dtype=np.float64)
+        if value.shape != self._x.shape:
+            raise ValueError(f"geometry.x has shape {self._x.shape}, got {value.shape}")
+        new = np.array(value, dtype=np.float64, order="C", copy=True)
+        new.flags.writeable = False
+        self._x = new
+        self.version += 1
 
 
 class Mesh:
@@ -350,7 +376,7 @@ def create_stacked_cubes(n_top: int, n_bottom: int | None = None, theta: float =
                             (f_bot, CONTACT_BOTTOM))])
     if theta != 0.0:
         R = rotation_matrix([1 / np.sqrt(2), 1 / np.sqrt(2), 0], -theta)
-        mesh.geometry.x[:] = x @ R.T
+        mesh.geometry.x = x @ R.T
     cell_tags = np.zeros(mesh.num_cells, dtype=np.int32)
     cell_tags[:nct] = 2
     return mesh, MeshTags(mesh, 2, ents, vals), cell_tags

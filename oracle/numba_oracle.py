@@ -34,7 +34,10 @@ def _element_tensor(form, integ, e, rank):
     cell = int(ent if integ.itype == "cell" else ent[0])
     lf = 0 if integ.itype == "cell" else int(ent[1])
     cd = mesh.geometry.x[mesh.geometry.dofmap[cell]]
-    w = None if integ.coeffs is None else integ.coeffs[e]
+    # (Integral.coeffs packs from the live dof values on every read: pack once per assembly call, like
+    # pack_coefficients in numba/assemble_matrix.py)
+    packed = getattr(integ, "_oracle_pack", None)
+    w = None if packed is None else packed[e]
     return cell, np.array(po.tabulate_one(integ.kernel, cd, w=w, c=integ.constants, local_facet=lf), dtype=np.float64)
 
 
@@ -109,6 +112,8 @@ def assemble_matrix(form, mpc: po.OracleMPC, bcs=(), diagval=1.0):
     for integ in form.integrals:
         active = np.flatnonzero(np.isin(integ.cells, slave_cells))
         for e in active:
+            if e == 0:
+                integ._oracle_pack = integ.coeffs
             cell, A_local = _element_tensor(form, integ, e, 2)
             local_blocks = V.dofmap.list[cell]
             for j in range(nd):  # :294-298
@@ -146,6 +151,8 @@ def assemble_vector(form, mpc: po.OracleMPC):
     slave_cells = np.flatnonzero(np.diff(mpc.c2s_offsets) > 0)
     for integ in form.integrals:
         for e in np.flatnonzero(np.isin(integ.cells, slave_cells)):
+            if e == 0:
+                integ._oracle_pack = integ.coeffs
             cell, b_local = _element_tensor(form, integ, e, 1)
             b_copy = b_local.copy()
             cell_slaves = mpc.c2s[mpc.c2s_offsets[cell] : mpc.c2s_offsets[cell + 1]]

@@ -317,6 +317,55 @@ def test_coefficients_and_constants_are_packed_per_call(oracle):
         _close(A.to_scipy().data, ref.data, RTOL_A, f"A with coefficient/constant set {k}")
 
 
+def test_coefficient_written_through_a_kept_view_is_seen(oracle):
+    """``w = f.x.array; w[:] = 1; assemble; w[:] = 2; assemble`` -- the second assembly must see the
+    new values (the reference packs coefficients on every call, cpp/assemble_matrix.cpp:587-589)."""
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import fem
+    from problems import case_pipeline
+
+    case = case_pipeline((1, 1))
+    V = case.V
+    f = fem.Function(V)
+    a = fem.form_stiffness(V, coefficient=f)
+    L = fem.form_source(V, fem.FN_SIN2D, coefficient=f)
+    mpc = product_mpc(case)
+    o_mpc = oracle_mpc(oracle, case)
+    view = f.x.array
+    A, b = None, None
+    for val in (1.0, 2.0, -0.5):
+        view[:] = val + 0.1 * np.arange(V.num_dofs)
+        A = dm.assemble_matrix(a, mpc, A=A)
+        b = dm.assemble_vector(L, mpc, b=b)
+        _close(A.to_scipy().data, oracle.assemble_matrix(a, o_mpc).data, RTOL_A, f"A, coefficient {val}")
+        _close(b.numpy(), oracle.assemble_vector(L, o_mpc), RTOL_B, f"b, coefficient {val}")
+
+
+@pytest.mark.parametrize("degree", [1, 2])
+def test_moved_mesh_is_assembled_on_the_new_coordinates(oracle, degree):
+    """cpp/assemble_matrix.cpp:495-501 gathers x on every call: after ``mesh.geometry.x = new`` the cached
+    plans stay valid (topology unchanged) and the values follow the new geometry"""
+    import dolfinx_mpc_amd as dm
+
+    case = case_cube_periodic(4, degree, 0.0, reorder=(2, 2, 2))
+    mpc = product_mpc(case)
+    o_mpc = oracle_mpc(oracle, case)
+    A = dm.assemble_matrix(case.a, mpc, bcs=case.bcs)
+    b = dm.assemble_vector(case.L, mpc)
+    x = case.mesh.geometry.x
+    # an affine stretch plus a smooth interior wiggle that keeps the periodic faces matched
+    new = x * np.array([1.0, 1.5, 0.75])
+    new[:, 1] += 0.03 * np.sin(np.pi * x[:, 1]) * np.sin(np.pi * x[:, 2])
+    case.mesh.geometry.x = new
+    A = dm.assemble_matrix(case.a, mpc, bcs=case.bcs, A=A)
+    b = dm.assemble_vector(case.L, mpc, b=b)
+    ref_A = oracle.assemble_matrix(case.a, o_mpc, bcs=case.bcs)
+    ref_b = oracle.assemble_vector(case.L, o_mpc)
+    _close(A.to_scipy().data, ref_A.data, RTOL_A, "A on the moved mesh")
+    _close(b.numpy(), ref_b, RTOL_B, "b on the moved mesh")
+    assert abs(ref_A.data).max() > 0
+
+
 def test_new_objects_never_hit_stale_caches(oracle):
     """Fresh DirichletBC / Form objects created in a loop (ids of collected objects get reused by
     CPython) must each be assembled with their OWN markers, masked dofmaps and plans."""

@@ -347,11 +347,12 @@ def test_coefficients_constants_and_bc_values_are_live():
     a = fem.form_stiffness(V, constant=c, coefficient=w)
     integ = a.integrals[0]
     assert np.all(integ.coeffs == 0.0) and integ.constants[0] == 2.0
-    first = integ.coeffs
-    assert integ.coeffs is first  # untouched function: the pack is reused
-    w.x.array[:] = np.arange(V.num_dofs)
+    view = w.x.array  # a caller may keep the view and write through it between two assemblies
+    view[:] = np.arange(V.num_dofs)
     c.value[0] = -1.0
     assert np.array_equal(integ.coeffs, np.arange(V.num_dofs, dtype=float)[V.dofmap.list])
+    view[:] = 7.0
+    assert np.all(integ.coeffs == 7.0)
     assert integ.constants[0] == -1.0
     g = fem.Function(V)
     bc = fem.dirichletbc(g, np.array([0, 3], dtype=np.int32), V)
@@ -444,3 +445,46 @@ def test_allcore_cpu_baseline_adds_up():
     assert r["cores"] == 3 and r["value"] > 0
     r = cpu_parallel.main(6, 2, 2)
     assert r["cores"] == 2 and "P2" in r["sample"]
+
+
+def test_blocked_and_multiple_coefficients_are_packed_like_dolfinx():
+    """dolfinx pack_coefficients: per entity the cell dofs of every coefficient in turn, unrolled dof * bs + k for
+    blocked spaces (cpp/assemble_matrix.cpp:587-589 hands that array to the kernel)."""
+    from dolfinx_mpc_amd import fem
+    from dolfinx_mpc_amd.mesh import create_unit_square
+
+    mesh = create_unit_square(2, 2)
+    V = fem.functionspace(mesh, ("Lagrange", 1))
+    W = fem.functionspace(mesh, ("Lagrange", 2, (2,)))
+    f, g = fem.Function(V), fem.Function(W)
+    f.x.array[:] = 100.0 + np.arange(V.num_dofs)
+    g.x.array[:] = np.arange(W.num_dofs)
+    cells = np.array([3, 0, 5], dtype=np.int32)
+    form = fem.form_ufcx([V], "void k(void){}", "k", entities=cells, coefficient=[g, f])
+    integ = form.integrals[0]
+    assert integ.cstride == 6 * 2 + 3
+    w = integ.coeffs
+    assert w.shape == (3, 15)
+    for e, c in enumerate(cells):
+        exp_g = (W.dofmap.list[c][:, None] * 2 + np.arange(2)[None, :]).reshape(-1)
+        assert np.array_equal(w[e, :12], exp_g.astype(float))
+        assert np.array_equal(w[e, 12:], 100.0 + V.dofmap.list[c])
+
+
+def test_geometry_is_read_only_and_moves_through_the_setter():
+    """cpp/assemble_matrix.cpp:495-501 re-reads x on every call; here a moved mesh is stated with
+    ``mesh.geometry.x = new`` (version counter -> device refresh) and an in-place write fails loudly"""
+    from dolfinx_mpc_amd import fem
+    from dolfinx_mpc_amd.mesh import create_unit_cube
+
+    mesh = create_unit_cube(2, 2, 2)
+    with pytest.raises(ValueError):
+        mesh.geometry.x[:, 0] += 1.0
+    V2 = fem.functionspace(mesh, ("Lagrange", 2))
+    before = V2.tabulate_dof_coordinates().copy()
+    v0 = mesh.geometry.version
+    mesh.geometry.x = mesh.geometry.x * np.array([2.0, 1.0, 0.5])
+    assert mesh.geometry.version == v0 + 1
+    assert np.allclose(V2.tabulate_dof_coordinates(), before * np.array([2.0, 1.0, 0.5]))
+    with pytest.raises(ValueError):
+        mesh.geometry.x = np.zeros((3, 3))
