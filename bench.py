@@ -13,13 +13,16 @@ One "step" = one pass of the hot path over the workload with every input residen
 
 metric = global dofs / step time.  apply_lifting is timed separately (the reference's timers do the same).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL):
+N > 1: one rank per GPU over RCCL.  Either the caller launches the ranks (torch.distributed.run sets WORLD_SIZE) or
+`python bench.py --gpus N` launches them itself (re-exec through torch.distributed.run on 127.0.0.1); with fewer
+than N visible devices the ranks share GPUs over gloo (a smoke test of the N > 1 path, flagged in the JSON line):
     --scaling strong (default): THE global mesh of the config is cut into N slabs of cube layers
         (config 2/5 along z, config 4 along y through both bodies), value = global dofs / time;
     --scaling weak: every rank assembles its own N^3 box of a (N, N, N*world) mesh (configs 2 / 5).
-After the local kernels the ranks exchange the partial sums of their interface-plane rows with their
-slab neighbours (the reference's `A.assemble()` / `ghostUpdate(ADD, REVERSE)`); the matrix rows travel
-while the vector kernel runs.  Rank 0 prints ONE JSON line.
+The step is a reference-style driver: `assemble_matrix` ends in `A.assemble()` (assemble_matrix.py:64) and the
+vector is followed by `b.ghostUpdate(ADD, REVERSE)` (bench_periodic.py:108); on a partitioned mesh those calls
+exchange the partial sums of the interface-plane rows with the slab neighbours (the matrix rows travel while the
+vector kernel runs).  Rank 0 prints ONE JSON line.
 """
 
 from __future__ import annotations
@@ -53,11 +56,10 @@ def log(*a):
 # ---------------------------------------------------------------------------------------------------
 class Workload:
     """What a config assembles: ``blocks`` = [(label, form, (mpc_row, mpc_col), matrix)], ``vectors`` =
-    [(label, form, mpc, vector)], the Dirichlet conditions, and (N > 1) the interface exchanges."""
+    [(label, form, mpc, vector)] and the Dirichlet conditions."""
 
     def __init__(self):
         self.blocks, self.vectors, self.bcs = [], [], []
-        self.exchange = {}  # label -> SlabExchange
         self.config, self.ndofs_total, self.lift = {}, 0, None
 
 
@@ -229,6 +231,52 @@ def cpu_baseline(kind, degree, sample_n):
                 **t_parts)
 
 
+def cpu_baseline_workload(w, mats, threads: int = 1):
+    """The oracle on THE workload of this run (not a smaller sample): same mesh, forms and Dirichlet conditions; the
+    finalized constraint arrays and the sparsity pattern are handed over from the product's set-up (both are
+    checked against the oracle's own builders in tests/), so that nothing but the two assembly loops is timed.
+    threads > 1: oracle/cpu_parallel.py (one serial loop per cell slab, like one MPI rank each)."""
+    from oracle import cpu_parallel
+    from oracle import pyoracle as po
+
+    (_, a, (m0, _m1)), (_, L, _m) = w.blocks[0], w.vectors[0]
+    V = w.V
+    A = mats[w.blocks[0][0]]
+    o_mpc = po.OracleMPC.from_arrays(V, m0.is_slave, m0.slaves, m0.num_local_slaves, m0.masters.offsets, m0.masters.array,
+                                     m0.coefficients()[0], m0.cell_to_slaves.offsets, m0.cell_to_slaves.array)
+    if A.nnz >= 2 ** 31:
+        raise RuntimeError("the oracle's CSR offsets are 32-bit")
+    pattern = (A.rowptr.astype(np.int32), A.cols)
+    ncells, ndofs = w.mesh.num_cells, V.num_dofs
+    what = f"the full workload ({ncells} cells, {ndofs} dofs)"
+    if threads <= 1:
+        t0 = time.perf_counter()
+        po.assemble_matrix(a, o_mpc, bcs=w.bcs, pattern=pattern, fast=True)
+        t1 = time.perf_counter()
+        po.assemble_vector(L, o_mpc, fast=True)
+        t2 = time.perf_counter()
+        return dict(value=ndofs / (t2 - t0), unit="DoFs/s", cores=1, kind="port", full_workload=True,
+                    sample=f"{what}: matrix {t1 - t0:.2f}s + vector {t2 - t1:.2f}s, oracle/mpc_oracle.c -O3, 1 thread",
+                    t_matrix_s=t1 - t0, t_vector_s=t2 - t1)
+    from dolfinx_mpc_amd import fem
+
+    k = a.integrals[0].kernel
+    fn = L.integrals[0].kernel.fn_id
+    if k.form == fem.FORM_ELASTICITY:
+        mu, lam = (float(v) for v in a.integrals[0].constants[:2])
+        cL = np.array(L.integrals[0].constants, dtype=np.float64)
+        a_of = lambda c: fem.form_elasticity(V, mu, lam, cells=c)  # noqa: E731
+        L_of = lambda c: fem.form_source(V, fn, constant=cL, cells=c)  # noqa: E731
+    else:
+        a_of = lambda c: fem.form_stiffness(V, cells=c)  # noqa: E731
+        L_of = lambda c: fem.form_source(V, fn, cells=c)  # noqa: E731
+    wall, tm, _A, _b = cpu_parallel.assemble_allcores(V, a_of, L_of, o_mpc, w.bcs, pattern, threads)
+    return dict(value=ndofs / wall, unit="DoFs/s", cores=threads, kind="port", full_workload=True,
+                sample=f"{what} on {threads} threads of the oracle's C loops (cell slabs, private local matrices, interface "
+                       f"rows added by the owners): slowest matrix {tm[:, 0].max():.2f}s, vector {tm[:, 1].max():.2f}s, "
+                       f"reduction {tm[:, 2].max():.2f}s, wall {wall:.2f}s", t_wall_s=wall)
+
+
 # ---------------------------------------------------------------------------------------------------
 def hip_time(fn, reps):
     """average duration (ms) of fn() measured with HIP events on the launch stream"""
@@ -284,6 +332,31 @@ def measure_traffic(argv_child, kernel_substr):
         {"FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"], "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024"}
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script through
+    torch.distributed.run (rendezvous on 127.0.0.1, a free port), one per GPU over RCCL.  With fewer than N
+    visible devices the ranks share GPUs and talk over gloo (RCCL refuses two ranks on one device): the N > 1
+    code path on whatever hardware is there, flagged as such in the JSON line."""
+    import socket
+
+    import torch
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    ndev = torch.cuda.device_count()
+    if ndev < n and "MPCX_DIST_BACKEND" not in env:
+        env["MPCX_DIST_BACKEND"] = "gloo"
+        log(f"{ndev} device(s) for {n} ranks: ranks share GPUs, transport gloo (not a scaling measurement)")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -295,7 +368,8 @@ def main():
     ap.add_argument("--alg", default=os.environ.get("MPCX_MATRIX_ALG", "rowblock"))
     ap.add_argument("--tile", type=int, nargs=3, default=[8, 8, 8], help="node/cell tile of the numbering")
     ap.add_argument("--no-tile", action="store_true")
-    ap.add_argument("--cpu-sample-n", type=int, default=0)
+    ap.add_argument("--cpu-sample-n", type=int, default=0,
+                    help="time the CPU baseline on a smaller sample of this resolution instead of the full workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-allcores", type=int, default=-1, metavar="P",
                     help="threads of the all-core CPU leg (default: min(host cores, 64); 0 = skip)")
@@ -305,8 +379,12 @@ def main():
     if args.n == 0:
         args.n = int(os.environ.get("MPCX_BENCH_N", {2: 256, 3: 128, 4: 56, 5: 246}[args.config]))
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        log(f"--gpus {args.gpus} but the launcher started {world} rank(s): running on {world}")
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     child = bool(os.environ.get("MPCX_BENCH_CHILD"))  # short run under rocprofv3: kernels only
 
@@ -345,28 +423,24 @@ def main():
     torch.cuda.synchronize()
     t_pattern = time.time() - t
     log("pattern: nnz " + ", ".join(f"{k} {A.nnz}" for k, A in mats.items()) + f" ({t_pattern:.1f}s)")
-    if world > 1:
-        from dolfinx_mpc_amd.distributed import SlabExchange
-
-        A0 = mats[w.blocks[0][0]]
-        V = w.V
-        w.exchange = SlabExchange(w.mesh, A0.rowptr, A0.cols, rank, world, device=torch.device("cuda", dev_index),
-                                  bs=V.dofmap.bs, space=V if V.degree == 2 else None)
     bcs = w.bcs
-    pending = []
+    from dolfinx_mpc_amd.la import InsertMode, ScatterMode
 
     def step():
+        """the reference's driver (bench_periodic.py:97-108), nothing else: on a partitioned mesh create_matrix /
+        create_vector attached the interface exchange, so A.assemble() (inside assemble_matrix) and b.ghostUpdate
+        do the reduction"""
         for label, f, (m0, m1) in w.blocks:
             dm.assemble_matrix(f, (m0, m1), bcs=bcs, A=mats[label], algorithm=args.alg)
-            if w.exchange:
-                pending.append(w.exchange.reduce_matrix_begin(mats[label]))
         for label, f, m in w.vectors:
             dm.assemble_vector(f, m, b=vecs[label])
-            if w.exchange:
-                pending.append(w.exchange.reduce_vector_begin(vecs[label]))
-        for h in pending:
-            w.exchange.finish(h)
-        pending.clear()
+            vecs[label].ghostUpdate(addv=InsertMode.ADD, mode=ScatterMode.REVERSE)
+        if world > 1:
+            # a solver would read the values next; that read completes the posted exchanges (inside the timed region)
+            for A in mats.values():
+                A.assemblyEnd()
+            for v in vecs.values():
+                _ = v.array
 
     t = time.time()
     step()
@@ -396,10 +470,17 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    cells_per_rank, rccl_ranks = [int(w.mesh.num_owned_cells)], 1
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        cdev = "cuda" if backend == "nccl" else "cpu"
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        cc = torch.zeros(world, dtype=torch.int64, device=cdev)
+        cc[rank] = int(w.mesh.num_owned_cells)
+        dist.all_reduce(cc, op=dist.ReduceOp.SUM)  # doubles as the proof that `world` ranks are in the group
+        cells_per_rank = [int(v) for v in cc.cpu().tolist()]
+        rccl_ranks = dist.get_world_size()
 
     # ---- per-call and per-kernel timing (HIP events on the launch stream), outside the timed region ----
     reps = max(min(args.steps, 10), 3)
@@ -491,7 +572,10 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": dict(w.config, baseline_config=args.config, cells_per_gpu=int(nc), dofs_per_gpu=int(w.V.num_dofs),
+        "rccl_ranks": rccl_ranks,
+        "transport": ("rccl" if backend == "nccl" else backend + " (ranks share GPUs: smoke test, not a scaling number)") if world > 1 else None,
+        "config": dict(w.config, baseline_config=args.config, cells_per_gpu=cells_per_rank if world > 1 else int(nc),
+                       dofs_per_gpu=int(w.V.num_dofs),
                        dofs_global=int(w.ndofs_total), nnz_per_gpu={k: int(A.nnz) for k, A in mats.items()},
                        matrix_algorithm=args.alg, numbering_tile=None if args.no_tile else list(args.tile),
                        parallelism=(f"{args.scaling}-scaling slabs x{world}" if world > 1 else "single GPU")),
@@ -522,18 +606,37 @@ def main():
             out["roofline"]["traffic_over_algorithmic"] = traffic / dom["algorithmic_bytes"]
     if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
         kind, degree = w.cpu_sample
-        sample_n = args.cpu_sample_n or {("poisson", 1): 96, ("poisson", 2): 40, ("stokes", 0): 16, ("contact", 0): 16}[(kind, degree)]
-        log(f"timing the CPU baseline (oracle, 1 core, sample {sample_n}) ...")
-        out["cpu_baseline"] = cpu_baseline(kind, degree, sample_n)
+        # the stated workload itself where one core finishes it in about half a minute (configs 2 and 4: P1) and the
+        # host has the memory; a smaller sample of the same problem otherwise (P2 / Taylor-Hood: minutes on one core)
+        try:
+            import psutil
+
+            ram_ok = psutil.virtual_memory().available > 10 * (mats[w.blocks[0][0]].nnz * 12 + nc * 40)
+        except Exception:  # noqa: BLE001
+            ram_ok = False
+        full = (kind, degree) in (("poisson", 1), ("contact", 0)) and ram_ok and not args.cpu_sample_n
         P = args.cpu_allcores if args.cpu_allcores >= 0 else min(os.cpu_count() or 1, 64)
-        if kind in ("poisson", "contact") and P > 1:
+        if full:
+            for key, threads in (("cpu_baseline", 1), ("cpu_baseline_allcores", P)):
+                if threads < 1 or (key == "cpu_baseline_allcores" and threads == 1):
+                    continue
+                log(f"timing the CPU baseline (oracle) on the full workload, {threads} thread(s) ...")
+                try:
+                    out[key] = cpu_baseline_workload(w, mats, threads)
+                except Exception as e:  # noqa: BLE001
+                    log(f"full-workload CPU leg ({threads} threads) failed: {e}")
+        if "cpu_baseline" not in out:
+            sample_n = args.cpu_sample_n or {("poisson", 1): 96, ("poisson", 2): 40, ("stokes", 0): 16, ("contact", 0): 16}[(kind, degree)]
+            log(f"timing the CPU baseline (oracle, 1 core, sample {sample_n}) ...")
+            out["cpu_baseline"] = dict(cpu_baseline(kind, degree, sample_n), full_workload=False)
+        if "cpu_baseline_allcores" not in out and kind in ("poisson", "contact") and P > 1:
             # the way the reference is deployed: one serial loop per MPI rank over its cells (SURVEY 8d ii)
             n_all = args.cpu_allcores_n or (40 if kind == "contact" else (192 if degree == 1 else 80))
             log(f"timing the CPU baseline on {P} cores (sample N={n_all}) ...")
             try:
                 from oracle import cpu_parallel
 
-                out["cpu_baseline_allcores"] = cpu_parallel.main(n_all, P, max(degree, 1), kind)
+                out["cpu_baseline_allcores"] = dict(cpu_parallel.main(n_all, P, max(degree, 1), kind), full_workload=False)
             except Exception as e:  # noqa: BLE001
                 log(f"all-core CPU leg failed: {e}")
     print(json.dumps(out), flush=True)

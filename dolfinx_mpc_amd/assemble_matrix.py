@@ -152,7 +152,23 @@ def create_matrix(form: Form, mpc0: MultiPointConstraint, mpc1: Optional[MultiPo
     """python/src/dolfinx_mpc/mpc.cpp:321-344 ``cpp.mpc.create_matrix``."""
     mpc1 = mpc0 if mpc1 is None else mpc1
     rowptr, cols = create_sparsity_pattern(form, (mpc0, mpc1), keep_on_device=True)
-    return MPCMatrix(rowptr, cols, mpc1.function_space.num_dofs)
+    A = MPCMatrix(rowptr, cols, mpc1.function_space.num_dofs)
+    # partitioned mesh: A.assemble() ships the interface rows to their owner (assemble_matrix.py:64)
+    from .distributed import exchange_for
+
+    V0, V1 = mpc0.function_space, mpc1.function_space
+    part = getattr(V0.mesh, "partition", None)
+    if part is not None and part.get("world", 1) > 1:
+        if V0 is V1:
+            ex = exchange_for(V0, A)
+            if ex is not None:
+                A.attach_exchange(ex)
+        else:
+            import torch.distributed as dist
+
+            if dist.is_available() and dist.is_initialized():
+                raise NotImplementedError("partitioned meshes: square blocks (test space == trial space) only")
+    return A
 
 
 def _slave_entities(form: Form, i: int, mpc0, mpc1):

@@ -214,12 +214,18 @@ class SlabExchange:
     index tensors built once; positions are matched through global (row, col)
     keys exchanged at set-up."""
 
-    def __init__(self, mesh: Mesh, rowptr: np.ndarray, cols: np.ndarray, rank: int, world: int, device=None,
+    def __init__(self, mesh: Mesh, rowptr, cols, rank: int, world: int, device=None,
                  bs: int = 1, space=None):
         """``space``: the (row == column) function space; default = P1 on ``mesh`` with block size ``bs``.
-        P2 spaces carry their own global ids / planes (FunctionSpace._p2_on_slab)."""
+        P2 spaces carry their own global ids / planes (FunctionSpace._p2_on_slab).
+        ``rowptr`` / ``cols`` None: vectors only (``reduce_vector`` / ``forward_vector``)."""
         import torch
         import torch.distributed as dist
+
+        vector_only = rowptr is None
+        if vector_only:
+            rowptr, cols = np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32)
+        self.vector_only = vector_only
 
         self.rank, self.world = rank, world
         self.device = device
@@ -241,12 +247,12 @@ class SlabExchange:
         # ---- what I send: every entry of my upper-interface (ghost) rows -------
         top = np.flatnonzero(send) if self.send_to is not None else np.zeros(0, dtype=np.int64)
         top = top[np.argsort(g[top])]
-        cnt = rowptr[top + 1] - rowptr[top]
+        cnt = np.zeros(top.size, dtype=np.int64) if vector_only else rowptr[top + 1] - rowptr[top]
         pos = (np.repeat(rowptr[top].astype(np.int64) - np.concatenate([[0], np.cumsum(cnt)[:-1]]), cnt)
-               + np.arange(int(cnt.sum()))) if top.size else np.zeros(0, dtype=np.int64)
+               + np.arange(int(cnt.sum()))) if (top.size and not vector_only) else np.zeros(0, dtype=np.int64)
         # entries ordered by (global row, global col)
-        k_row = np.repeat(g[top], cnt).astype(np.int64) if top.size else np.zeros(0, dtype=np.int64)
-        k_col = g[cols[pos]].astype(np.int64) if top.size else np.zeros(0, dtype=np.int64)
+        k_row = np.repeat(g[top], cnt).astype(np.int64) if pos.size else np.zeros(0, dtype=np.int64)
+        k_col = g[cols[pos]].astype(np.int64) if pos.size else np.zeros(0, dtype=np.int64)
         o = np.lexsort((k_col, k_row))
         self.send_pos = pos[o]
         send_keys = np.concatenate([k_row[o], k_col[o]])  # [rows..., cols...]
@@ -297,9 +303,9 @@ class SlabExchange:
 
             lrow, lcol = to_local(grow), to_local(gcol)
             # vectorised binary search per entry inside its row
-            lo = rowptr[lrow].astype(np.int64)
-            hi = rowptr[lrow + 1].astype(np.int64)
-            while True:
+            lo = rowptr[lrow].astype(np.int64) if lrow.size else np.zeros(0, dtype=np.int64)
+            hi = rowptr[lrow + 1].astype(np.int64) if lrow.size else np.zeros(0, dtype=np.int64)
+            while lrow.size:
                 active = lo < hi
                 if not active.any():
                     break
@@ -308,7 +314,7 @@ class SlabExchange:
                 less[active] = cols[mid[active]] < lcol[active]
                 lo = np.where(active & less, mid + 1, lo)
                 hi = np.where(active & ~less, mid, hi)
-            if (cols[np.minimum(lo, cols.size - 1)] != lcol).any():
+            if lrow.size and (cols[np.minimum(lo, cols.size - 1)] != lcol).any():
                 raise RuntimeError("SlabExchange: received an entry outside the local sparsity pattern")
             self.recv_pos = lo
             self.recv_rows = to_local(r_recv.cpu().numpy())
@@ -383,7 +389,31 @@ class SlabExchange:
         self.finish(self._begin(values, send_idx, recv_idx))
 
     def reduce_matrix_begin(self, A):
+        if self.vector_only:
+            raise RuntimeError("SlabExchange: built without a sparsity pattern (vectors only)")
         return self._begin(A.vals if hasattr(A, "vals") else A, "send_pos", "recv_pos")
+
+    def forward_vector(self, b):
+        """``ghostUpdate(INSERT, FORWARD)`` / ``scatter_forward``: the owners' values of the interface rows are copied
+        to the ghost rows of the rank below (the reverse direction of ``reduce_vector``, same index lists)."""
+        import torch
+        import torch.distributed as dist
+
+        arr = b.array if hasattr(b, "array") else b
+        dev = arr.device
+        stage_cpu = dist.get_backend() == "gloo" and dev.type == "cuda"
+        ops, sbuf, rbuf = [], None, None
+        if self.recv_from is not None:  # I own rows my lower neighbour holds as ghosts
+            sbuf = arr.index_select(0, self._idx("recv_rows", dev))
+            sbuf = sbuf.cpu() if stage_cpu else sbuf
+            ops.append(dist.P2POp(dist.isend, sbuf, self.recv_from))
+        if self.send_to is not None:
+            rbuf = torch.empty(self.send_rows.size, dtype=arr.dtype, device="cpu" if stage_cpu else dev)
+            ops.append(dist.P2POp(dist.irecv, rbuf, self.send_to))
+        for w in dist.batch_isend_irecv(ops) if ops else []:
+            w.wait()
+        if rbuf is not None:
+            arr.index_copy_(0, self._idx("send_rows", dev), rbuf.to(dev))
 
     def reduce_vector_begin(self, b):
         return self._begin(b.array if hasattr(b, "array") else b, "send_rows", "recv_rows")
@@ -397,3 +427,29 @@ class SlabExchange:
         """b.ghostUpdate(ADD_VALUES, REVERSE) analogue."""
         arr = b.array if hasattr(b, "array") else b
         self._exchange(arr, "send_rows", "recv_rows")
+
+
+def exchange_for(space, A=None):
+    """The interface exchange of ``space`` on a partitioned mesh (``mesh.partition`` with world > 1) when a process
+    group is initialised, else None.  Without ``A``: vectors only, cached on the space; with the (square) matrix
+    ``A`` over ``space``: its value positions too, cached on the matrix.  This is what ``create_vector`` /
+    ``create_matrix`` attach, so that ``b.ghostUpdate`` / ``A.assemble()`` do the reduction
+    (bench_periodic.py:108, python/src/dolfinx_mpc/assemble_matrix.py:64)."""
+    import torch
+    import torch.distributed as dist
+
+    mesh = space.mesh
+    part = getattr(mesh, "partition", None)
+    if part is None or part.get("world", 1) <= 1 or not (dist.is_available() and dist.is_initialized()):
+        return None
+    dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+    kw = dict(device=dev, bs=space.dofmap.bs, space=space if space.degree == 2 else None)
+    if A is None:
+        key = ("vec_exchange", str(dev))
+        if key not in space._device:
+            space._device[key] = SlabExchange(mesh, None, None, part["rank"], part["world"], **kw)
+        return space._device[key]
+    key = ("mat_exchange", id(space))
+    if key not in A._plans:
+        A._plans[key] = (space, SlabExchange(mesh, A.rowptr, A.cols, part["rank"], part["world"], **kw))
+    return A._plans[key][1]

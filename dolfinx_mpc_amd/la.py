@@ -1,13 +1,47 @@
 """Device-resident linear algebra containers (stand-ins for the PETSc ``Mat`` /
-``Vec`` the reference assembles into, python/src/dolfinx_mpc/mpc.cpp:273-297)."""
+``Vec`` the reference assembles into, python/src/dolfinx_mpc/mpc.cpp:273-297).
+
+Partitioned meshes (dolfinx_mpc_amd.distributed): the objects carry the interface exchange of their
+space, so that the reference's own calls do the reduction -- ``A.assemble()``
+(python/src/dolfinx_mpc/assemble_matrix.py:64) and ``b.ghostUpdate(addv=ADD, mode=REVERSE)``
+(python/benchmarks/bench_periodic.py:108) -- and a reference-style driver runs unchanged on N GPUs."""
 
 from __future__ import annotations
 
 import contextlib
+import enum
 
 import numpy as np
 
 from . import _native
+
+
+class InsertMode(enum.IntEnum):
+    """petsc4py.PETSc.InsertMode values used by the reference's drivers"""
+    INSERT = 1
+    ADD = 2
+    INSERT_VALUES = 1
+    ADD_VALUES = 2
+
+
+class ScatterMode(enum.IntEnum):
+    """petsc4py.PETSc.ScatterMode"""
+    FORWARD = 0
+    REVERSE = 1
+
+
+class _Pending:
+    """An interface exchange that has been posted but not yet added into the owner's rows.  The packed send
+    buffer travels while later kernels run (the matrix rows during the vector assembly); whoever reads the
+    values next completes it first."""
+
+    __slots__ = ("exchange", "handle")
+
+    def __init__(self, exchange, handle):
+        self.exchange, self.handle = exchange, handle
+
+    def finish(self):
+        self.exchange.finish(self.handle)
 
 
 class Vector:
@@ -17,7 +51,17 @@ class Vector:
         import torch
 
         self.device = device if device is not None else _native.require_gpu()
-        self.array = torch.zeros(n, dtype=torch.float64, device=self.device)
+        self._array = torch.zeros(n, dtype=torch.float64, device=self.device)
+        self._exchange = None  # distributed.SlabExchange of the space (partitioned meshes)
+        self._pending = None
+
+    @property
+    def array(self):
+        """the device tensor; a posted ghost update is completed first"""
+        if self._pending is not None:
+            p, self._pending = self._pending, None
+            p.finish()
+        return self._array
 
     def set(self, value: float):
         self.array.fill_(value)
@@ -25,22 +69,43 @@ class Vector:
     def numpy(self) -> np.ndarray:
         return self.array.detach().cpu().numpy()
 
-    # PETSc-flavoured no-ops so reference-style drivers read the same
+    # PETSc-flavoured calls so reference-style drivers read the same
     @contextlib.contextmanager
     def localForm(self):
         yield self
 
-    def ghostUpdate(self, addv=None, mode=None):
-        """single process: nothing to exchange (bench_periodic.py:108)"""
+    def attach_exchange(self, exchange):
+        self._exchange = exchange
+
+    def ghostUpdate(self, addv=InsertMode.ADD, mode=ScatterMode.REVERSE):
+        """``b.ghostUpdate(addv=ADD, mode=REVERSE)`` (bench_periodic.py:108): the partial sums of the ghost
+        (interface-plane) rows are sent to their owner and added there; ``(INSERT, FORWARD)``: the owners'
+        values are copied back to the ghosts.  Single process / unpartitioned mesh: nothing to exchange."""
+        if self._exchange is None:
+            return None
+        reverse = int(mode) == int(ScatterMode.REVERSE) if mode is not None else True
+        arr = self.array  # completes anything posted earlier
+        if reverse:
+            self._pending = _Pending(self._exchange, self._exchange.reduce_vector_begin(arr))
+        else:
+            self._exchange.forward_vector(arr)
         return None
 
     @property
     def size(self) -> int:
-        return self.array.numel()
+        return self._array.numel()
 
 
 def create_vector(V) -> Vector:
-    return Vector(V.num_dofs)
+    """a vector over the dofs of ``V``; on a partitioned mesh with an initialised process group it carries the
+    space's interface exchange (distributed.exchange_for)"""
+    b = Vector(V.num_dofs)
+    from .distributed import exchange_for
+
+    ex = exchange_for(V)
+    if ex is not None:
+        b.attach_exchange(ex)
+    return b
 
 
 class MPCMatrix:
@@ -67,8 +132,18 @@ class MPCMatrix:
             self._cols = np.ascontiguousarray(cols, dtype=np.int32)
             self.d_cols = torch.from_numpy(self._cols).to(self.device)
         self.shape = (self.d_rowptr.numel() - 1, ncols)
-        self.vals = torch.zeros(self.d_cols.numel(), dtype=torch.float64, device=self.device)
+        self._vals = torch.zeros(self.d_cols.numel(), dtype=torch.float64, device=self.device)
         self._plans = {}
+        self._exchange = None
+        self._pending = None
+
+    @property
+    def vals(self):
+        """the CSR values (device tensor); a posted ``assemble()`` exchange is completed first"""
+        if self._pending is not None:
+            p, self._pending = self._pending, None
+            p.finish()
+        return self._vals
 
     @property
     def rowptr(self) -> np.ndarray:
@@ -91,8 +166,25 @@ class MPCMatrix:
     def zeroEntries(self):
         self.vals.zero_()
 
+    def attach_exchange(self, exchange):
+        self._exchange = exchange
+
+    def assemblyBegin(self):
+        """post the exchange of the interface rows' partial sums (PETSc MatAssemblyBegin); nothing waits here"""
+        if self._exchange is not None:
+            vals = self.vals  # completes anything posted earlier
+            self._pending = _Pending(self._exchange, self._exchange.reduce_matrix_begin(vals))
+
+    def assemblyEnd(self):
+        """wait for the posted exchange and add the received sums into the owned rows (PETSc MatAssemblyEnd)"""
+        _ = self.vals
+
     def assemble(self):
-        """single process: no off-rank rows to ship (assemble_matrix.py:64)"""
+        """``A.assemble()`` (python/src/dolfinx_mpc/assemble_matrix.py:64): rows another rank owns are shipped to
+        it and added there.  The transfer is posted here and completed when the values are next read
+        (``A.vals``, ``to_scipy``, a solver, the next assembly), so that it overlaps whatever is enqueued in
+        between; single process / unpartitioned mesh: nothing to ship."""
+        self.assemblyBegin()
         return None
 
     def to_scipy(self):

@@ -80,12 +80,31 @@ def _worker(rank, world, port, N, reorder, outdir, kind="poisson"):
     bt = torch.from_numpy(b.copy())
     ex.reduce_matrix(vals)
     ex.reduce_vector(bt)
+    # the same reduction behind the reference's own calls (python/src/dolfinx_mpc/assemble_matrix.py:64 A.assemble(),
+    # bench_periodic.py:108 b.ghostUpdate(ADD, REVERSE)) on the la containers, then the forward scatter
+    from dolfinx_mpc_amd.distributed import exchange_for
+    from dolfinx_mpc_amd.la import InsertMode, MPCMatrix, ScatterMode, Vector
+
+    cpu = torch.device("cpu")
+    Am = MPCMatrix(pattern[0], pattern[1], V.num_dofs, device=cpu)
+    Am._vals.copy_(torch.from_numpy(A.data))
+    Am.attach_exchange(exchange_for(V, Am))
+    Am.assemble()
+    bv = Vector(V.num_dofs, device=cpu)
+    bv._array.copy_(torch.from_numpy(b))
+    bv.attach_exchange(exchange_for(V))
+    bv.ghostUpdate(addv=InsertMode.ADD, mode=ScatterMode.REVERSE)
+    assert torch.equal(Am.vals, vals) and torch.equal(bv.array, bt)
+    bv.ghostUpdate(addv=InsertMode.INSERT, mode=ScatterMode.FORWARD)
     A = scipy.sparse.csr_matrix((vals.numpy(), A.indices, A.indptr), shape=A.shape)
     g = (V.dof_global[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)  # global unrolled dof ids
     nown = V.dofmap.index_map.size_local * bs
     Aown = A[:nown].tocoo()
+    blk_send = V.dof_send_up if V.degree == 2 else mesh.node_send_up
+    ghost = np.flatnonzero(np.repeat(blk_send, bs))
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), row=g[Aown.row], col=g[Aown.col], val=Aown.data,
-             brow=g[:nown], bval=bt.numpy()[:nown], nslaves=mpc.num_local_slaves)
+             brow=g[:nown], bval=bt.numpy()[:nown], nslaves=mpc.num_local_slaves,
+             ghost_g=g[ghost], ghost_val=bv.array.numpy()[ghost])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -146,6 +165,11 @@ def _check_against_global_assembly(oracle, tmp_path, world, N, kind):
     b = np.zeros(n)
     b[np.concatenate(brow)] = np.concatenate(bval)
     assert np.allclose(b, bref, rtol=0, atol=1e-13 * abs(bref).max())
+    # forward scatter: every ghost row of the upper interface planes holds its owner's value
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        if "ghost_g" in d and d["ghost_g"].size:
+            assert np.array_equal(d["ghost_val"], b[to_ref(d["ghost_g"])])
 
 
 def _gpu_worker(rank, world, port, N, reorder, outdir, kind="poisson"):
@@ -171,13 +195,14 @@ def _gpu_worker(rank, world, port, N, reorder, outdir, kind="poisson"):
     mpc = dm.MultiPointConstraint(V)
     mpc.add_constraint(V, *raw)
     mpc.finalize()
+    # a reference-style driver, unchanged: A.assemble() inside assemble_matrix (assemble_matrix.py:64) and
+    # b.ghostUpdate (bench_periodic.py:108) do the interface reduction through the attached exchange
+    from dolfinx_mpc_amd.la import InsertMode, ScatterMode
+
     A = dm.assemble_matrix(a, mpc, bcs=[bc], algorithm="rowblock")
     b = dm.assemble_vector(L, mpc)
     dm.apply_lifting(b, [a], [[bc]], mpc)
-    ex = SlabExchange(mesh, A.rowptr, A.cols, rank, world, device=torch.device("cuda", 0), bs=bs,
-                      space=V if V.degree == 2 else None)
-    ex.reduce_matrix(A)
-    ex.reduce_vector(b)
+    b.ghostUpdate(addv=InsertMode.ADD, mode=ScatterMode.REVERSE)
     torch.cuda.synchronize()
     S = A.to_scipy()
     g = (V.dof_global[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)  # global unrolled dof ids
@@ -393,14 +418,12 @@ def _rccl_worker(rank, world, outdir, n):
     mpc = dm.MultiPointConstraint(V)
     mpc.add_constraint(V, *raw)
     mpc.finalize()
-    A = dm.assemble_matrix(a, mpc, bcs=bcs)
-    b = dm.assemble_vector(L, mpc)
+    from dolfinx_mpc_amd.la import InsertMode, ScatterMode
+
+    A = dm.assemble_matrix(a, mpc, bcs=bcs)  # A.assemble() posts the RCCL send/recv of the interface rows
+    b = dm.assemble_vector(L, mpc)  # ... which travel while this runs
     dm.apply_lifting(b, [a], [bcs], mpc)
-    ex = SlabExchange(mesh, A.rowptr, A.cols, rank, world, device=torch.device("cuda", rank))
-    h1 = ex.reduce_matrix_begin(A)
-    h2 = ex.reduce_vector_begin(b)
-    ex.finish(h1)
-    ex.finish(h2)
+    b.ghostUpdate(addv=InsertMode.ADD, mode=ScatterMode.REVERSE)
     torch.cuda.synchronize()
     S = A.to_scipy()
     g = mesh.node_global
