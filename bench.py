@@ -99,14 +99,46 @@ def poisson_workload(args, rank, world, degree):
     mpc.finalize()
     w = Workload()
     w.mesh, w.V, w.bcs = mesh, V, [bc]
-    w.blocks = [("A", fem.form_stiffness(V), (mpc, mpc))]
-    w.vectors = [("b", fem.form_source(V, fem.FN_BENCH_PERIODIC), mpc)]
+    ufcx = getattr(args, "ufcx", None)
+    if ufcx and degree != 1:
+        raise SystemExit("--ufcx: config 2 (P1)")
+    if ufcx == "files":
+        # the reference's real seam: element kernels as UFCx C text (cpp/assemble_matrix.cpp:438-439), compiled for
+        # gfx950 with hipRTC and run inside the LDS row-block kernels.  tests/ufcx/laplace_p1_tet.c (closed form) and
+        # source_p1_tet.c (14-point table, P1 coefficient, constant, quadratic f)
+        src = lambda n: open(os.path.join(ROOT, "tests", "ufcx", n + ".c")).read()  # noqa: E731
+        wh = fem.Function(V)
+        wh.interpolate(lambda x: 1.0 + 0.5 * x[0] + x[2])
+        w.a_of = lambda c=None: fem.form_ufcx([V, V], src("laplace_p1_tet"), "tabulate_tensor_laplace_p1_tet", entities=c)
+        w.L_of = lambda c=None: fem.form_ufcx([V], src("source_p1_tet"), "tabulate_tensor_source_p1_tet", entities=c,
+                                              coefficient=wh, constant=fem.Constant(0.7))
+    elif ufcx == "generated":
+        # the benchmark's own forms (bench_periodic.py:84-91) the way FFCx would emit them: baked tables, a loop over
+        # the rule, libm sin / exp in the right-hand side (tools/ffcx_like.py)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from ffcx_like import BENCH_PERIODIC_F, generate
+
+        from dolfinx_mpc_amd.quadrature import make_quadrature
+
+        sa, na = generate("stiffness", "tetrahedron", 1, 1, make_quadrature("tetrahedron", 0))
+        sl, nl = generate("source", "tetrahedron", 1, 1, make_quadrature("tetrahedron", 5), fexpr=BENCH_PERIODIC_F)
+        w.a_of = lambda c=None: fem.form_ufcx([V, V], sa, na, entities=c)
+        w.L_of = lambda c=None: fem.form_ufcx([V], sl, nl, entities=c)
+    else:
+        w.a_of = lambda c=None: fem.form_stiffness(V, cells=c)
+        w.L_of = lambda c=None: fem.form_source(V, fem.FN_BENCH_PERIODIC, cells=c)
+    w.blocks = [("A", w.a_of(), (mpc, mpc))]
+    w.vectors = [("b", w.L_of(), mpc)]
     w.lift = ("b", "A")
     d = degree
     w.ndofs_total = int(np.prod([d * n + 1 for n in n_glob]))
     w.config = {"workload": f"periodic-BC Poisson, P{degree} tets, {n_glob[0]}x{n_glob[1]}x{n_glob[2]} cubes on "
                             f"[0,1]^2x[0,{zmax:g}], fp64 (BASELINE configs[{1 if degree == 1 else 4}])",
                 "slaves_per_gpu": int(mpc.slaves.size)}
+    if ufcx:
+        w.config["element_kernels"] = ("imported UFCx C text compiled with hipRTC: " + (
+            "tests/ufcx/laplace_p1_tet.c + source_p1_tet.c (P1 coefficient, constant, 14-point rule)" if ufcx == "files" else
+            "tools/ffcx_like.py output for the benchmark's forms (1-point stiffness, 14-point source with libm sin/exp)"))
     w.cpu_sample = ("poisson", degree)
     return w
 
@@ -167,6 +199,9 @@ def contact_workload(args, rank, world):
     w.mesh, w.V, w.bcs = mesh, V, bcs
     w.blocks = [("A", a, (mpc, mpc))]
     w.vectors = [("b", L, mpc)]
+    mu_, lam_ = E / (2.0 * (1.0 + nu)), E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu))
+    w.a_of = lambda c=None: fem.form_elasticity(V, mu_, lam_, cells=c)
+    w.L_of = lambda c=None: fem.form_source(V, fem.FN_CONSTANT_VEC, constant=[1.0, 0.0, 0.0, 0.0], cells=c)
     w.lift = ("b", "A")
     w.ndofs_total = 3 * ((n0 + 1) ** 3 + (2 * n0 + 1) ** 3)
     w.config = {"workload": f"two-body inelastic contact (cpp/ContactConstraint.h:908-1174), vector P1 elasticity, "
@@ -258,19 +293,7 @@ def cpu_baseline_workload(w, mats, threads: int = 1):
         return dict(value=ndofs / (t2 - t0), unit="DoFs/s", cores=1, kind="port", full_workload=True,
                     sample=f"{what}: matrix {t1 - t0:.2f}s + vector {t2 - t1:.2f}s, oracle/mpc_oracle.c -O3, 1 thread",
                     t_matrix_s=t1 - t0, t_vector_s=t2 - t1)
-    from dolfinx_mpc_amd import fem
-
-    k = a.integrals[0].kernel
-    fn = L.integrals[0].kernel.fn_id
-    if k.form == fem.FORM_ELASTICITY:
-        mu, lam = (float(v) for v in a.integrals[0].constants[:2])
-        cL = np.array(L.integrals[0].constants, dtype=np.float64)
-        a_of = lambda c: fem.form_elasticity(V, mu, lam, cells=c)  # noqa: E731
-        L_of = lambda c: fem.form_source(V, fn, constant=cL, cells=c)  # noqa: E731
-    else:
-        a_of = lambda c: fem.form_stiffness(V, cells=c)  # noqa: E731
-        L_of = lambda c: fem.form_source(V, fn, cells=c)  # noqa: E731
-    wall, tm, _A, _b = cpu_parallel.assemble_allcores(V, a_of, L_of, o_mpc, w.bcs, pattern, threads)
+    wall, tm, _A, _b = cpu_parallel.assemble_allcores(V, w.a_of, w.L_of, o_mpc, w.bcs, pattern, threads)
     return dict(value=ndofs / wall, unit="DoFs/s", cores=threads, kind="port", full_workload=True,
                 sample=f"{what} on {threads} threads of the oracle's C loops (cell slabs, private local matrices, interface "
                        f"rows added by the owners): slowest matrix {tm[:, 0].max():.2f}s, vector {tm[:, 1].max():.2f}s, "
@@ -375,6 +398,10 @@ def main():
                     help="threads of the all-core CPU leg (default: min(host cores, 64); 0 = skip)")
     ap.add_argument("--cpu-allcores-n", type=int, default=0)
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 PMC measurement of roofline.traffic")
+    ap.add_argument("--ufcx", choices=["files", "generated"], default=None,
+                    help="config 2 with IMPORTED element kernels (UFCx C text -> hipRTC -> LDS row-block kernels): "
+                         "'files' = tests/ufcx/laplace_p1_tet.c + source_p1_tet.c, 'generated' = the benchmark's own forms "
+                         "as tools/ffcx_like.py writes them")
     args = ap.parse_args()
     if args.n == 0:
         args.n = int(os.environ.get("MPCX_BENCH_N", {2: 256, 3: 128, 4: 56, 5: 246}[args.config]))
@@ -503,7 +530,9 @@ def main():
         nbytes = (4 * nv * nc + 4 * V0.element_ndofs * nc + (0 if V1 is V0 else 4 * V1.element_ndofs * nc)
                   + 24 * mesh.num_nodes + 8 * A.nnz + V0.num_dofs + V1.num_dofs)
         # the kernel mpcx_assemble_matrix launches for these arguments (csrc/mpcx_kernels.hip, launch_matrix)
-        if margs.algorithm == 3:
+        if f.integrals[0].kernel.form == 100:
+            kname = "ufcx_matrix_rowblock_kernel" if margs.algorithm == 2 else "ufcx_matrix_kernel"
+        elif margs.algorithm == 3:
             kname = "matrix_cube_kernel"
         elif margs.algorithm == 2 and margs.slot_mask:
             kname = "matrix_nodeblock_kernel"
@@ -518,13 +547,16 @@ def main():
         vargs, keep = av.vector_args(f, 0, vecs[label], m, 0)
         tk = hip_time(lambda: _native.check(Lib.mpcx_assemble_vector(C.byref(vargs)), "mpcx_assemble_vector"), reps)
         V0 = f.function_spaces[0]
-        nbytes = 4 * nv * nc + 4 * V0.element_ndofs * nc + 24 * mesh.num_nodes + 9 * V0.num_dofs
+        nbytes = (4 * nv * nc + 4 * V0.element_ndofs * nc + 24 * mesh.num_nodes + 9 * V0.num_dofs
+                  + 8 * f.integrals[0].cstride * nc)  # + the packed coefficients (cpp/assemble_vector.cpp reads them per cell)
         kname = {2: "vector_rowblock_kernel", 3: "vector_cube_kernel"}.get(vargs.algorithm, "vector_kernel")
         if vargs.algorithm == 2 and vargs.own_lmap:
             kname = "vector_ownblock_kernel"  # + vector_spill_reduce_kernel, timed together
+        if f.integrals[0].kernel.form == 100:
+            kname = "ufcx_vector_rowblock_kernel" if vargs.algorithm == 2 else "ufcx_vector_kernel"
         k = {"kernel": f"{kname}[{label}]", "call": f"assemble_vector[{label}]", "launch_ms": tk,
              "algorithmic_bytes": int(nbytes), "pmc_name": kname}
-        if args.config == 2:
+        if args.config == 2 and not args.ufcx:
             # fp64 arithmetic of the 14-point source loop: 82 flop per point in the ISA (35 fma/fmac, 9 mul, 3 add)
             nq = int(f.integrals[0].kernel.qwts.size)
             k["fp64_flops"] = 82.0 * nq * nc
@@ -559,7 +591,8 @@ def main():
 
     dom = max(kernels, key=lambda k: k["launch_ms"])  # the time-dominant kernel of the step
     out = {
-        "metric": "assembled DoFs/sec (matrix+vector), periodic Poisson P1 256^3" if args.config == 2 else
+        "metric": ("assembled DoFs/sec (matrix+vector), periodic Poisson P1 256^3"
+                   + (" [imported UFCx element kernels]" if args.ufcx else "")) if args.config == 2 else
                   f"assembled DoFs/sec (matrix+vector), BASELINE config {args.config}",
         "value": w.ndofs_total * args.steps / elapsed,
         "unit": "DoFs/s",
@@ -598,7 +631,7 @@ def main():
     if world == 1 and not args.no_traffic and not os.environ.get("MPCX_BENCH_NO_PMC"):
         log("measuring HBM traffic of the dominant kernel (rocprofv3 --pmc, two short child runs) ...")
         child_args = ["--config", str(args.config), "--size", str(args.n), "--alg", args.alg, "--steps", "1", "--warmup", "0",
-                      "--no-cpu-baseline", "--no-traffic"] + (["--no-tile"] if args.no_tile else ["--tile"] + [str(v) for v in args.tile])
+                      "--no-cpu-baseline", "--no-traffic"] + (["--ufcx", args.ufcx] if args.ufcx else []) + (["--no-tile"] if args.no_tile else ["--tile"] + [str(v) for v in args.tile])
         traffic, info = measure_traffic(child_args, dom["pmc_name"])
         out["roofline"]["traffic"] = traffic
         out["roofline"]["traffic_source"] = info

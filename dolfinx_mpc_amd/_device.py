@@ -12,9 +12,17 @@ from .fem import Form, FunctionSpace, Integral
 
 
 def _to_dev(a: np.ndarray, dev):
+    import warnings
+
     import torch
 
-    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    a = np.ascontiguousarray(a)
+    if a.flags.writeable:
+        return torch.from_numpy(a).to(dev)
+    with warnings.catch_warnings():  # read-only host arrays (mesh.geometry.x): the host tensor is only the source of the copy
+        warnings.simplefilter("ignore", UserWarning)
+        t = torch.from_numpy(a)
+    return t.to(dev) if torch.device(dev).type != "cpu" else t.clone()
 
 
 def _timed_build(kind, build):

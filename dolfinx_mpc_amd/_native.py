@@ -229,6 +229,7 @@ EXPORTS = [
     "mpcx_compress_offsets",
     "mpcx_ufcx_compile",
     "mpcx_ufcx_code_size",
+    "mpcx_ufcx_code",
     "mpcx_ufcx_free",
     "mpcx_gather_f64",
     "mpcx_scatter_add_f64",
@@ -337,6 +338,8 @@ def lib() -> C.CDLL:
     L.mpcx_ufcx_compile.restype = vp
     L.mpcx_ufcx_code_size.argtypes = [vp]
     L.mpcx_ufcx_code_size.restype = i64
+    L.mpcx_ufcx_code.argtypes = [vp, vp]
+    L.mpcx_ufcx_code.restype = C.c_int
     L.mpcx_ufcx_free.argtypes = [vp]
     L.mpcx_ufcx_free.restype = None
     L.mpcx_compress_offsets.argtypes = [vp, i64, i32, i32, vp, vp]

@@ -677,8 +677,6 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
     # thin layers: a large layer of big elements would take the host minutes) | none (matrix_mpc_kernel: what a
     # caller of the bare C ABI gets with mpc_plan_off == NULL); MPCX_NO_MPC_PLAN=1 is the old spelling of none
     mode = "none" if os.environ.get("MPCX_NO_MPC_PLAN") else os.environ.get("MPCX_MPC_PLAN", "device").lower()
-    if integ.kernel.form == 100:
-        mode = "none"  # imported UFCx kernels bring their own master-contribution kernel
     n0n1 = V0.element_ndofs * V0.dofmap.bs * V1.element_ndofs * V1.dofmap.bs
     if a.n_slave_entities > 0 and mode == "device" and max(V0.element_ndofs * V0.dofmap.bs,
                                                            V1.element_ndofs * V1.dofmap.bs) <= 32:
@@ -699,8 +697,9 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
     if alg == 2:
         # lean path (include/mpcx.h, mpcx_matrix_args_t::lean): square P1-type form over all cells
         same = V1 is V0 and mpc1 is mpc0 and bc1 is bc0
+        ufcx = integ.kernel.form == 100  # imported kernel: the general (unrotated) row-block path
         lean = (same and s0["dofmap"] is md["x_dofmap"] and idv["entities_ptr"] is None and integ.estride == 1
-                and integ.coefficient is None and not os.environ.get("MPCX_NO_LEAN"))
+                and integ.coefficient is None and not ufcx and not os.environ.get("MPCX_NO_LEAN"))
         if lean and allow_cubes and _cube_eligible(form, i, V0):
             cp = _cube_plan(A, form, i, V0, bc0, mpc0)
             if cp is not None:
@@ -766,8 +765,6 @@ def assemble_matrix(
     if A is None:
         A = create_matrix(form, mpc0, mpc1)
     alg = _ALG[(algorithm or os.environ.get("MPCX_MATRIX_ALG", "auto")).lower()]
-    if any(integ.kernel.form == 100 for integ in form.integrals):
-        alg = 1  # imported UFCx kernels: generic per-entity kernels with device atomics
     auto = alg == 0
     if auto:
         alg = 2  # LDS row blocks (clusters where they apply); device atomics if a plan cannot be built

@@ -182,6 +182,12 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
     # many-point rules on a tiled numbering: row blocks with owner-computes lists beat the hash kernel too (P1, 14
     # points, 256^3 without clusters: 3.77 -> 3.26 ms); without a tiled numbering the halo would not fit LDS
     own_any = (owner_mode == "auto" and nq > 4 and V.dof_tile_offsets is not None and integ.itype == "cell")
+    ufcx = k.form == 100
+    if ufcx:
+        # an imported kernel: its cost is unknown, so every entity is evaluated once (owner-computes row blocks:
+        # no device atomics) whenever a block with its halo fits LDS; halo-recomputing row blocks otherwise
+        nq = 1 << 20
+        own_any = owner_mode != "0"
     if (alg == 2 or (alg == 0 and (nq <= nq_max or p2_fast or own_any))) and integ.num_entities > 0:
         from .assemble_matrix import _masked_dofmap, _slave_entities
 
@@ -204,7 +210,7 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
             plan, pk, n_own = own
             a.own_lmap, a.own_hoff, a.own_spill = pk[3].data_ptr(), pk[4].data_ptr(), pk[5].data_ptr()
             a.own_src, a.own_rows, a.own_seg, a.n_own_rows = pk[6].data_ptr(), pk[7].data_ptr(), pk[8].data_ptr(), n_own
-        elif alg == 0 and nq > nq_max and not p2_fast:
+        elif alg == 0 and nq > nq_max and not p2_fast and not ufcx:
             a.stream = D.stream_ptr()
             return a, keep  # no owner plan within the LDS budget: the hash kernel (a.algorithm == 1)
         else:

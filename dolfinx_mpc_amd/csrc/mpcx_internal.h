@@ -14,4 +14,6 @@ int launch_vector_cubes(const mpcx_vector_args_t& a);
 int launch_matrix_ufcx(const mpcx_matrix_args_t& a);
 int launch_vector_ufcx(const mpcx_vector_args_t& a);
 int launch_lifting_ufcx(const mpcx_lifting_args_t& a);
+// second half of the owner-computes vector path (mpcx_kernels.hip), shared with the imported kernels
+int launch_vector_spill_reduce(const mpcx_vector_args_t& a, int bs);
 } // namespace mpcx

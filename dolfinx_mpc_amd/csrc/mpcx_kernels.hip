@@ -1866,6 +1866,13 @@ int launch_matrix(const mpcx_matrix_args_t& a)
   return 0;
 }
 
+int launch_vector_spill_reduce(const mpcx_vector_args_t& a, int bs)
+{
+  hipLaunchKernelGGL(vector_spill_reduce_kernel, dim3(grid_for(a.n_own_rows * bs, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(a.stream), a.n_own_rows, a.own_rows, a.own_seg, a.own_src, a.own_spill, bs, a.b);
+  return check(hipGetLastError(), "vector spill-reduce kernel launch");
+}
+
 template <class Op>
 int launch_vector(const mpcx_vector_args_t& a)
 {
@@ -1924,8 +1931,8 @@ int launch_vector(const mpcx_vector_args_t& a)
     if (lrc)
       return lrc;
     if (owner && a.n_own_rows > 0)
-      hipLaunchKernelGGL(vector_spill_reduce_kernel, dim3(grid_for(a.n_own_rows * Op::BS0, 256)), dim3(256), 0, stream,
-                         a.n_own_rows, a.own_rows, a.own_seg, a.own_src, a.own_spill, int(Op::BS0), a.b);
+      if (int rc = launch_vector_spill_reduce(a, Op::BS0))
+        return rc;
     if (int rc = check(hipGetLastError(), "vector row-block kernel launch"))
       return rc;
     if (a.n_slave_entities > 0)

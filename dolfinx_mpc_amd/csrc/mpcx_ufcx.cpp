@@ -12,6 +12,7 @@
 #include "mpcx.h"
 #include "mpcx_internal.h"
 
+#include <cstring>
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <mutex>
@@ -260,6 +261,273 @@ extern "C" __global__ void __launch_bounds__(64) ufcx_vector_kernel(mpcx_vector_
 #endif
 )MPCXK";
 
+
+const char* const ROWBLOCK_KERNELS_TEXT = R"MPCXR(
+// ---------------------------------------------------------------------------------------------------------
+// The imported tabulate_tensor inside the LDS row-block kernels (the fast path of the built-in operators,
+// csrc/mpcx_kernels.hip matrix_rowblock_kernel / vector_rowblock_kernel / vector_ownblock_kernel): the
+// per-entity loop of cpp/assemble_matrix.cpp:488-547 with the element tensor in registers (small elements:
+// every index is a compile-time constant after unrolling) or private memory (large ones), the Dirichlet /
+// slave masks folded into the dofmaps, the CSR positions from the plan's 8-bit scatter offsets, ds_add_f64
+// into the workgroup's copy of its row block and one coalesced write of the finished block.
+// ---------------------------------------------------------------------------------------------------------
+#define MASK_SHIFT 28
+#define DOF_MASK ((1 << MASK_SHIFT) - 1)
+#define NOFF (ND0 * ND1)
+#if UFCX_SMALL
+#define UFCX_UNROLL _Pragma("unroll")
+#else
+#define UFCX_UNROLL _Pragma("nounroll")
+#endif
+
+#if UFCX_RANK == 2
+extern "C" __global__ void __launch_bounds__(UFCX_RB_THREADS) ufcx_matrix_rowblock_kernel(mpcx_matrix_args_t a)
+{
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int NT = blockDim.x;
+  const int nb = a.plan.num_blocks;
+  const int per = (nb + 7) >> 3;
+  const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3); // contiguous runs of row blocks per XCD
+  if (b >= nb)
+    return;
+  const int tid = threadIdx.x;
+  const int r0 = a.plan.block_row0[b], r1 = a.plan.block_row0[b + 1];
+  const int nrow = r1 - r0;
+  const long long nnz0 = a.rowptr[r0];
+  const int nnzb = (int)(a.rowptr[r1] - nnz0);
+  double* s_vals = (double*)smem;                       // [max_nnz]
+  int* s_rowlo = (int*)(s_vals + a.plan.max_nnz);       // [max_rows + 1]
+  for (int i = tid; i < nnzb; i += NT)
+    s_vals[i] = 0.0;
+  for (int rl = tid; rl <= nrow; rl += NT)
+    s_rowlo[rl] = (int)(a.rowptr[r0 + rl] - nnz0);
+  __syncthreads();
+  const bool same_maps = (ND0 == ND1) && (a.mdofmap1 == a.mdofmap0) && (a.entities1 == a.entities0);
+  const bool geom_is_dofmap = (NV == ND0) && (a.x_dofmap == a.dofmap0) && (a.entities0 == a.entities);
+  const long long e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  const int* __restrict__ ents = a.plan.block_ents;
+  for (long long t = e0 + tid; t < e1; t += NT)
+  {
+    const long long e = ents[t];
+    const long long l = e * a.estride;
+    const long long cell = a.entities ? a.entities[l] : e;
+    const long long cell0 = a.entities0 ? a.entities0[l] : e;
+    const long long cell1 = a.entities1 ? a.entities1[l] : e;
+    const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
+    int m0[ND0], m1[ND1];
+#pragma unroll
+    for (int i = 0; i < ND0; ++i)
+      m0[i] = a.mdofmap0[cell0 * ND0 + i];
+#pragma unroll
+    for (int j = 0; j < ND1; ++j)
+      m1[j] = same_maps ? m0[j < ND0 ? j : 0] : a.mdofmap1[cell1 * ND1 + j];
+    // scatter offsets of this entity: NOFF bytes, contiguous
+    unsigned ow[(NOFF + 3) / 4];
+    const unsigned char* po = a.plan.ent_offs + e * NOFF;
+#if NOFF % 16 == 0
+#pragma unroll
+    for (int w = 0; w < NOFF / 16; ++w)
+    {
+      const uint4 v = ((const uint4*)po)[w];
+      ow[4 * w] = v.x, ow[4 * w + 1] = v.y, ow[4 * w + 2] = v.z, ow[4 * w + 3] = v.w;
+    }
+#elif NOFF % 4 == 0
+#pragma unroll
+    for (int w = 0; w < NOFF / 4; ++w)
+      ow[w] = ((const unsigned*)po)[w];
+#else
+#pragma unroll
+    for (int w = 0; w < (NOFF + 3) / 4; ++w)
+    {
+      unsigned u = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (4 * w + q < NOFF)
+          u |= (unsigned)po[4 * w + q] << (8 * q);
+      ow[w] = u;
+    }
+#endif
+    double cd[NV * 3];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+    {
+      const long long v = geom_is_dofmap ? (long long)(m0[i < ND0 ? i : 0] & DOF_MASK) : (long long)a.x_dofmap[cell * NV + i];
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        cd[3 * i + k] = a.x[3 * v + k];
+    }
+    double Ae[N0 * N1];
+    UFCX_UNROLL
+    for (int i = 0; i < N0 * N1; ++i)
+      Ae[i] = 0.0;
+    {
+      const unsigned char perm = 0;
+      UFCX_FN(Ae, a.coeffs ? a.coeffs + e * a.cstride : (const double*)0, a.constants, cd, &lf, &perm, (void*)0);
+    }
+    UFCX_UNROLL
+    for (int i = 0; i < ND0; ++i)
+    {
+      UFCX_UNROLL
+      for (int k = 0; k < BS0; ++k)
+      {
+        const int r = (m0[i] & DOF_MASK) * BS0 + k;
+        if (r < r0 || r >= r1 || ((m0[i] >> (MASK_SHIFT + k)) & 1))
+          continue;
+        const int base = s_rowlo[r - r0];
+        UFCX_UNROLL
+        for (int j = 0; j < ND1; ++j)
+        {
+          const int off = (int)((ow[(i * ND1 + j) >> 2] >> (8 * ((i * ND1 + j) & 3))) & 0xff) * BS1;
+          UFCX_UNROLL
+          for (int q = 0; q < BS1; ++q)
+          {
+            if ((m1[j] >> (MASK_SHIFT + q)) & 1)
+              continue;
+            const double v = Ae[(i * BS0 + k) * N1 + j * BS1 + q];
+            if (v != 0.0) // structural zeros of blocked forms cost no LDS atomic
+              __hip_atomic_fetch_add(s_vals + base + off + q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (a.store_mode)
+    for (int i = tid; i < nnzb; i += NT)
+      a.vals[nnz0 + i] = s_vals[i];
+  else
+    for (int i = tid; i < nnzb; i += NT)
+      a.vals[nnz0 + i] += s_vals[i];
+}
+
+// Master contributions from the plan gathered by target position (mpcx_mpc_plan_device): G lanes share one
+// target and stride over its tuples; a lane tabulates an entity once for its consecutive tuples (the plan
+// lists a target's tuples by entity).  No device atomics, no CSR searches.
+extern "C" __global__ void __launch_bounds__(64) ufcx_matrix_mpc_plan_kernel(mpcx_matrix_args_t a)
+{
+  const int G = a.mpc_plan_group >= 16 ? 16 : (a.mpc_plan_group >= 4 ? 4 : 1);
+  const int lane = threadIdx.x & (G - 1);
+  const long long t = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  if (t >= a.mpc_plan_targets)
+    return; // the whole group leaves together
+  double sum = 0.0;
+  double Ae[N0 * N1];
+  long long last = -1;
+  for (long long k = a.mpc_plan_off[t] + lane; k < a.mpc_plan_off[t + 1]; k += G)
+  {
+    const long long e = a.mpc_plan_ent[k];
+    if (e != last)
+    {
+      const long long l = e * a.estride;
+      const long long cell = a.entities ? a.entities[l] : e;
+      const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
+      double cd[NV * 3];
+      gather(a.x, a.x_dofmap, cell, cd);
+      tabulate(Ae, N0 * N1, a.coeffs, a.cstride, a.constants, cd, e, lf);
+      last = e;
+    }
+    sum += a.mpc_plan_coef[k] * Ae[a.mpc_plan_pq[k]];
+  }
+  for (int m = G >> 1; m > 0; m >>= 1)
+    sum += __shfl_xor(sum, m, G);
+  if (lane == 0)
+    a.vals[a.mpc_plan_tgt[t]] += sum;
+}
+#else
+// rank 1: row blocks of b in LDS.  own_lmap == NULL: every block evaluates the entities touching it and keeps its
+// own rows (vector_rowblock_kernel); own_lmap != NULL: owner-computes (vector_ownblock_kernel): every entity once,
+// the LDS copy holds the block's rows followed by its halo, the halo part is written out for
+// vector_spill_reduce_kernel.  Rows of slave dofs are skipped (flag in the masked dofmap / position table) and
+// handled by ufcx_vector_mpc_kernel.
+extern "C" __global__ void __launch_bounds__(UFCX_RB_THREADS) ufcx_vector_rowblock_kernel(mpcx_vector_args_t a)
+{
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* s_b = (double*)smem;
+  const int NT = blockDim.x;
+  const int nb = a.plan.num_blocks;
+  const int per = (nb + 7) >> 3;
+  const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (b >= nb)
+    return;
+  const int tid = threadIdx.x;
+  const int r0 = a.plan.block_row0[b], r1 = a.plan.block_row0[b + 1];
+  const bool owner = a.own_lmap != (const int*)0;
+  const long long h0 = owner ? a.own_hoff[b] : 0, h1 = owner ? a.own_hoff[b + 1] : 0;
+  const int nown = r1 - r0, nhalo = (int)(h1 - h0) * BS0;
+  for (int i = tid; i < nown + nhalo; i += NT)
+    s_b[i] = 0.0;
+  __syncthreads();
+  const long long e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  const int* __restrict__ ents = a.plan.block_ents;
+  for (long long t = e0 + tid; t < e1; t += NT)
+  {
+    const long long e = ents[t];
+    const long long l = e * a.estride;
+    const long long cell = a.entities ? a.entities[l] : e;
+    const long long cell0 = a.entities0 ? a.entities0[l] : e;
+    const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
+    double cd[NV * 3];
+    gather(a.x, a.x_dofmap, cell, cd);
+    double be[N0];
+    tabulate(be, N0, a.coeffs, a.cstride, a.constants, cd, e, lf);
+    UFCX_UNROLL
+    for (int i = 0; i < ND0; ++i)
+    {
+      // owner-computes: LDS position from the table (read after the element kernel); else the masked dof
+      const int w = owner ? a.own_lmap[e * ND0 + i] : a.mdofmap[cell0 * ND0 + i];
+      UFCX_UNROLL
+      for (int k = 0; k < BS0; ++k)
+      {
+        if ((w >> (MASK_SHIFT + k)) & 1)
+          continue;
+        int pos = (w & DOF_MASK) * BS0 + k;
+        if (!owner)
+        {
+          if (pos < r0 || pos >= r1)
+            continue;
+          pos -= r0;
+        }
+        __hip_atomic_fetch_add(s_b + pos, be[i * BS0 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < nown; i += NT)
+    a.b[r0 + i] += s_b[i];
+  for (int i = tid; i < nhalo; i += NT)
+    a.own_spill[h0 * BS0 + i] = s_b[nown + i];
+}
+
+// slave rows of the entities that have any (modify_mpc_vec, cpp/assemble_vector.h:35-69)
+extern "C" __global__ void __launch_bounds__(64) ufcx_vector_mpc_kernel(mpcx_vector_args_t a)
+{
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.n_slave_entities)
+    return;
+  const long long e = a.slave_entities[t];
+  const long long l = e * a.estride;
+  const long long cell = a.entities ? a.entities[l] : e;
+  const long long cell0 = a.entities0 ? a.entities0[l] : e;
+  const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
+  double cd[NV * 3];
+  gather(a.x, a.x_dofmap, cell, cd);
+  double be[N0];
+  tabulate(be, N0, a.coeffs, a.cstride, a.constants, cd, e, lf);
+  for (int p = 0; p < N0; ++p)
+  {
+    const int d = a.dofmap[cell0 * ND0 + p / BS0] * BS0 + p % BS0;
+    if (!a.mpc.is_slave[d])
+      continue;
+    const int m0 = a.mpc.masters_offsets[d], m1 = a.mpc.masters_offsets[d + 1];
+    for (int mi = m0; mi < m1; ++mi)
+      atomic_add_f64(a.b + a.mpc.masters[mi], a.mpc.coeffs[mi] * be[p]);
+    if (m1 == m0)
+      atomic_add_f64(a.b + d, be[p]);
+  }
+}
+#endif
+)MPCXR";
+
 struct Rtc
 {
   void* lib = nullptr;
@@ -303,6 +571,8 @@ struct UfcxKernel
   std::vector<char> code; // gfx950 code object
   hipModule_t module = nullptr;
   hipFunction_t matrix = nullptr, matrix_mpc = nullptr, lifting = nullptr, vector = nullptr;
+  hipFunction_t matrix_rowblock = nullptr, matrix_mpc_plan = nullptr, vector_rowblock = nullptr, vector_mpc = nullptr;
+  int rb_threads = 256; // threads per workgroup of the row-block kernels (their launch bound)
 };
 
 int hip_check(hipError_t err, const char* what)
@@ -322,15 +592,25 @@ int ensure_loaded(UfcxKernel* k)
     return 0;
   if (int rc = hip_check(hipModuleLoadData(&k->module, k->code.data()), "hipModuleLoadData"))
     return rc;
+  auto get = [&](hipFunction_t* f, const char* name)
+  { return hip_check(hipModuleGetFunction(f, k->module, name), "hipModuleGetFunction"); };
   if (k->desc.rank == 2)
   {
-    if (int rc = hip_check(hipModuleGetFunction(&k->matrix, k->module, "ufcx_matrix_kernel"), "hipModuleGetFunction"))
+    if (int rc = get(&k->matrix, "ufcx_matrix_kernel"))
       return rc;
-    if (int rc = hip_check(hipModuleGetFunction(&k->matrix_mpc, k->module, "ufcx_matrix_mpc_kernel"), "hipModuleGetFunction"))
+    if (int rc = get(&k->matrix_mpc, "ufcx_matrix_mpc_kernel"))
       return rc;
-    return hip_check(hipModuleGetFunction(&k->lifting, k->module, "ufcx_lifting_kernel"), "hipModuleGetFunction");
+    if (int rc = get(&k->matrix_rowblock, "ufcx_matrix_rowblock_kernel"))
+      return rc;
+    if (int rc = get(&k->matrix_mpc_plan, "ufcx_matrix_mpc_plan_kernel"))
+      return rc;
+    return get(&k->lifting, "ufcx_lifting_kernel");
   }
-  return hip_check(hipModuleGetFunction(&k->vector, k->module, "ufcx_vector_kernel"), "hipModuleGetFunction");
+  if (int rc = get(&k->vector_rowblock, "ufcx_vector_rowblock_kernel"))
+    return rc;
+  if (int rc = get(&k->vector_mpc, "ufcx_vector_mpc_kernel"))
+    return rc;
+  return get(&k->vector, "ufcx_vector_kernel");
 }
 
 template <class Args>
@@ -343,6 +623,20 @@ int launch(hipFunction_t f, int64_t n, const Args& a, void* stream)
   const unsigned grid = static_cast<unsigned>((n + 63) / 64);
   return hip_check(hipModuleLaunchKernel(f, grid, 1, 1, 64, 1, 1, 0, static_cast<hipStream_t>(stream), params, nullptr),
                    "hipModuleLaunchKernel");
+}
+
+// one workgroup per row block (grid rounded up to a multiple of 8: the kernels map blockIdx to XCD-contiguous runs)
+template <class Args>
+int launch_blocks(hipFunction_t f, int num_blocks, int threads, size_t lds, const Args& a, void* stream)
+{
+  if (num_blocks <= 0)
+    return 0;
+  Args copy = a;
+  void* params[] = {&copy};
+  const unsigned grid = 8u * unsigned((num_blocks + 7) / 8);
+  return hip_check(hipModuleLaunchKernel(f, grid, 1, 1, unsigned(threads), 1, 1, unsigned(lds), static_cast<hipStream_t>(stream),
+                                         params, nullptr),
+                   "hipModuleLaunchKernel (row blocks)");
 }
 } // namespace
 
@@ -371,18 +665,48 @@ extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
                     "typedef int int32_t;\ntypedef unsigned int uint32_t;\ntypedef long long int64_t;\n"
                     "typedef unsigned long long uint64_t;\n#define restrict __restrict__\n";
   src += hdr;
+  // the user's text: #include lines are dropped (hipRTC supplies the fixed-width types above and the math functions
+  // as built-ins; FFCx output includes <math.h>, <stdint.h>, <ufcx.h> ...), every function it defines becomes a
+  // __host__ __device__ function that is always inlined into the kernels (element tensor in registers)
+  std::string user(d->source);
+  for (size_t p = 0; (p = user.find("#include", p)) != std::string::npos;)
+  {
+    size_t b = user.rfind('\n', p);
+    b = b == std::string::npos ? 0 : b + 1;
+    bool only_space = true;
+    for (size_t q = b; q < p; ++q)
+      only_space = only_space && (user[q] == ' ' || user[q] == '\t');
+    if (only_space)
+    {
+      size_t e = user.find('\n', p);
+      e = e == std::string::npos ? user.size() : e;
+      user.replace(b, e - b, "");
+      p = b;
+    }
+    else
+      p += 8;
+  }
   src += "\n#pragma clang force_cuda_host_device begin\n";
-  src += d->source;
-  src += "\n#pragma clang force_cuda_host_device end\n";
+  src += "#pragma clang attribute push(__attribute__((always_inline)), apply_to = function)\n";
+  src += user;
+  src += "\n#pragma clang attribute pop\n";
+  src += "#pragma clang force_cuda_host_device end\n";
   src += KERNELS_TEXT;
+  src += ROWBLOCK_KERNELS_TEXT;
   void* prog = nullptr;
   if (r.create(&prog, src.c_str(), "mpcx_ufcx.hip", 0, nullptr, nullptr) != 0)
   {
     mpcx_set_error("mpcx_ufcx_compile: hiprtcCreateProgram failed");
     return nullptr;
   }
+  // element tensors up to 36 entries (P1 scalar, P1 x P1 on triangles / tets, bs <= ...): 512 threads, 128 VGPRs;
+  // up to 144 entries: fully unrolled at 256 threads (256 VGPRs); larger ones stay rolled in private memory
+  const int size = d->rank == 2 ? d->nd0 * d->bs0 * d->nd1 * d->bs1 : d->nd0 * d->bs0;
+  const int rb_threads = (d->rank == 1 || size <= 36) ? 512 : 256;
+  const int small = size <= 144 ? 1 : 0;
   std::vector<std::string> opts
       = {"--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-DUFCX_FN=" + std::string(d->function_name),
+         "-DUFCX_RB_THREADS=" + std::to_string(rb_threads), "-DUFCX_SMALL=" + std::to_string(small),
          "-DUFCX_RANK=" + std::to_string(d->rank), "-DND0=" + std::to_string(d->nd0), "-DBS0=" + std::to_string(d->bs0),
          "-DND1=" + std::to_string(d->rank == 2 ? d->nd1 : 1), "-DBS1=" + std::to_string(d->rank == 2 ? d->bs1 : 1),
          "-DNV=" + std::to_string(d->nv)};
@@ -402,6 +726,7 @@ extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
     return nullptr;
   }
   auto* k = new UfcxKernel;
+  k->rb_threads = rb_threads;
   k->desc = *d;
   k->desc.source = nullptr;
   k->desc.function_name = nullptr;
@@ -414,6 +739,15 @@ extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
 }
 
 extern "C" int64_t mpcx_ufcx_code_size(void* handle) { return handle ? int64_t(static_cast<UfcxKernel*>(handle)->code.size()) : 0; }
+
+extern "C" int mpcx_ufcx_code(void* handle, void* out)
+{
+  auto* k = static_cast<UfcxKernel*>(handle);
+  if (!k || !out)
+    return -1;
+  std::memcpy(out, k->code.data(), k->code.size());
+  return 0;
+}
 
 extern "C" void mpcx_ufcx_free(void* handle)
 {
@@ -436,15 +770,43 @@ int launch_matrix_ufcx(const mpcx_matrix_args_t& a)
     mpcx_set_error("mpcx_assemble_matrix: the imported kernel was compiled for other element shapes (or is not bilinear)");
     return -12;
   }
-  if (a.algorithm == MPCX_ALG_ROWBLOCK || a.algorithm == MPCX_ALG_CUBE)
+  if (a.algorithm == MPCX_ALG_CUBE)
   {
-    mpcx_set_error("mpcx_assemble_matrix: imported (UFCx) kernels are assembled with MPCX_ALG_ATOMIC");
+    mpcx_set_error("mpcx_assemble_matrix: imported (UFCx) kernels are assembled with MPCX_ALG_ROWBLOCK or MPCX_ALG_ATOMIC");
     return -3;
   }
   if (int rc = ensure_loaded(k))
     return rc;
-  if (int rc = launch(k->matrix, a.n_entities, a, a.stream))
+  int alg = a.algorithm;
+  if (alg == MPCX_ALG_AUTO)
+    alg = a.plan.num_blocks > 0 ? MPCX_ALG_ROWBLOCK : MPCX_ALG_ATOMIC;
+  if (alg == MPCX_ALG_ROWBLOCK && a.n_entities > 0)
+  {
+    if (a.plan.num_blocks <= 0 || !a.mdofmap0 || !a.mdofmap1 || !a.plan.ent_offs || a.plan.row_pairs || a.plan.ent_pattern
+        || a.lean || a.slot_mask)
+    {
+      mpcx_set_error("mpcx_assemble_matrix (UFCx, row blocks): needs a plain entity plan with its scatter-offset table "
+                     "(mpcx_scatter_offsets, rotate = 0) and the masked dofmaps (mpcx_mask_dofmap, rotate = 0)");
+      return -5;
+    }
+    const size_t lds = size_t(a.plan.max_nnz) * 8 + size_t(a.plan.max_rows + 1) * 4;
+    if (lds > 160 * 1024)
+    {
+      mpcx_set_error("mpcx_assemble_matrix: row-block plan exceeds 160 KiB of LDS");
+      return -4;
+    }
+    if (int rc = launch_blocks(k->matrix_rowblock, a.plan.num_blocks, k->rb_threads, lds, a, a.stream))
+      return rc;
+  }
+  else if (int rc = launch(k->matrix, a.n_entities, a, a.stream))
     return rc;
+  if (a.n_slave_entities > 0 && a.mpc_plan_off)
+  {
+    if (a.mpc_plan_targets <= 0)
+      return 0;
+    const int g = a.mpc_plan_group >= 16 ? 16 : (a.mpc_plan_group >= 4 ? 4 : 1);
+    return launch(k->matrix_mpc_plan, a.mpc_plan_targets * g, a, a.stream);
+  }
   return launch(k->matrix_mpc, a.n_slave_entities, a, a.stream);
 }
 int launch_vector_ufcx(const mpcx_vector_args_t& a)
@@ -457,6 +819,35 @@ int launch_vector_ufcx(const mpcx_vector_args_t& a)
   }
   if (int rc = ensure_loaded(k))
     return rc;
+  int alg = a.algorithm;
+  if (alg == MPCX_ALG_AUTO)
+    alg = a.plan.num_blocks > 0 ? MPCX_ALG_ROWBLOCK : MPCX_ALG_ATOMIC;
+  if (alg == MPCX_ALG_ROWBLOCK && a.n_entities > 0)
+  {
+    const bool owner = a.own_lmap != nullptr;
+    if (a.plan.num_blocks <= 0 || (!a.mdofmap && !owner))
+    {
+      mpcx_set_error("mpcx_assemble_vector (UFCx, row blocks): needs a plan and the slave-masked dofmap");
+      return -3;
+    }
+    if (owner && (!a.own_hoff || !a.own_spill || !a.own_seg || (a.n_own_rows > 0 && (!a.own_rows || !a.own_src))))
+    {
+      mpcx_set_error("mpcx_assemble_vector: incomplete owner-computes plan");
+      return -5;
+    }
+    const size_t lds = size_t(a.plan.max_rows) * 8;
+    if (lds > 96 * 1024)
+    {
+      mpcx_set_error("mpcx_assemble_vector: row-block plan exceeds the LDS budget");
+      return -4;
+    }
+    if (int rc = launch_blocks(k->vector_rowblock, a.plan.num_blocks, k->rb_threads, lds, a, a.stream))
+      return rc;
+    if (owner && a.n_own_rows > 0)
+      if (int rc = launch_vector_spill_reduce(a, k->desc.bs0))
+        return rc;
+    return launch(k->vector_mpc, a.n_slave_entities, a, a.stream);
+  }
   return launch(k->vector, a.n_entities, a, a.stream);
 }
 int launch_lifting_ufcx(const mpcx_lifting_args_t& a)

@@ -89,9 +89,14 @@ typedef struct
  * (cpp/assemble_matrix.cpp:291-292, 438-439; python/src/dolfinx_mpc/numba/assemble_matrix.py:282-290).  Here the
  * seam is the C SOURCE of such a function (what FFCx writes to disk): mpcx_ufcx_compile turns it into a
  * gfx950 __device__ function with hipRTC and links it with generic per-entity assembly kernels for the given
- * element shape.  The handle goes into mpcx_kernel_t::ufcx with form = MPCX_FORM_UFCX; mpcx_assemble_matrix
- * (MPCX_ALG_ATOMIC), mpcx_assemble_vector and mpcx_apply_lifting then call it.  A is handed over zeroed and is
- * accumulated into, row-major [nd0*bs0][nd1*bs1] with blocked dof index i*bs + k, like the reference does.
+ * element shape.  The handle goes into mpcx_kernel_t::ufcx with form = MPCX_FORM_UFCX; mpcx_assemble_matrix,
+ * mpcx_assemble_vector and mpcx_apply_lifting then call it -- inside the LDS row-block kernels (MPCX_ALG_ROWBLOCK:
+ * the same plan, masked dofmaps and scatter-offset table as for the built-in operators with lean = 0; vectors:
+ * row blocks or the owner-computes variant; master contributions from the mpc_plan_* arrays when given) or in
+ * thread-per-entity kernels with device atomics (MPCX_ALG_ATOMIC, no plan needed).  A is handed over zeroed and is
+ * accumulated into, row-major [nd0*bs0][nd1*bs1] with blocked dof index i*bs + k, like the reference does; w holds
+ * the packed coefficients of the entity (dolfinx pack_coefficients layout), c the packed constants.  #include lines
+ * of the source are dropped (fixed-width integer types and the math functions are built in).
  * Compilation needs no device; NULL + mpcx_last_error() on failure (the compiler log is in the message). */
 typedef struct
 {
@@ -104,6 +109,7 @@ typedef struct
 } mpcx_ufcx_desc_t;
 void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* desc);
 int64_t mpcx_ufcx_code_size(void* handle); /* bytes of the gfx950 code object */
+int mpcx_ufcx_code(void* handle, void* out); /* HOST out[mpcx_ufcx_code_size]: the code object (inspection, caching) */
 void mpcx_ufcx_free(void* handle);
 
 /* Finalized constraint as the kernels read it: the accessors of

@@ -100,11 +100,12 @@ def test_hiprtc_compiles_the_imported_kernels_without_a_device():
 
 # ------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
+@pytest.mark.parametrize("alg", ["atomic", "rowblock"])
 @pytest.mark.parametrize("reorder", [None, (2, 2, 2)])
-def test_gpu_imported_laplace_and_source_match_oracle(oracle, reorder):
+def test_gpu_imported_laplace_and_source_match_oracle(oracle, reorder, alg):
     case, _ = _laplace_case(5, reorder)
     ref = oracle_outputs(oracle, case)
-    out = product_outputs(case)
+    out = product_outputs(case, algorithm=alg)
     assert np.array_equal(out["A"].indptr, ref["A"].indptr) and np.array_equal(out["A"].indices, ref["A"].indices)
     assert abs(out["A"].data - ref["A"].data).max() <= 1e-12 * max(1.0, abs(ref["A"]).max())
     for k in ("b", "b_lifted"):
@@ -112,7 +113,8 @@ def test_gpu_imported_laplace_and_source_match_oracle(oracle, reorder):
 
 
 @pytest.mark.gpu
-def test_gpu_imported_slip_facet_block_matches_oracle(oracle):
+@pytest.mark.parametrize("alg", ["atomic", "rowblock"])
+def test_gpu_imported_slip_facet_block_matches_oracle(oracle, alg):
     """rectangular block (P2^3 x P1) on exterior facets with the slip constraint on the rows and Dirichlet rows"""
     import dolfinx_mpc_amd as dm
     from problems import empty_raw
@@ -125,7 +127,7 @@ def test_gpu_imported_slip_facet_block_matches_oracle(oracle):
     pv.finalize()
     pq = dm.MultiPointConstraint(Q)
     pq.finalize()
-    A = dm.assemble_matrix(a01f, (pv, pq), bcs=bcs).to_scipy()
+    A = dm.assemble_matrix(a01f, (pv, pq), bcs=bcs, algorithm=alg).to_scipy()
     assert np.array_equal(A.indptr, ref.indptr) and np.array_equal(A.indices, ref.indices)
     assert abs(A.data - ref.data).max() <= 1e-12 * max(1.0, abs(ref).max())
     assert abs(ref).max() > 0.01
