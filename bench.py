@@ -73,7 +73,20 @@ def poisson_workload(args, rank, world, degree):
     reorder = None if args.no_tile else tuple(args.tile)
     zmax = 1.0
     if world == 1:
-        mesh = create_box((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), (N, N, N), "tetrahedron", reorder)
+        numbering = getattr(args, "numbering", "tiled")
+        if numbering == "tiled":
+            mesh = create_box((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), (N, N, N), "tetrahedron", reorder)
+        else:
+            # a mesh as a file may deliver it: nodes renumbered at random, cells shuffled (the cluster kernels must
+            # not depend on the generator's cell order); "spatial": put back in order by
+            # mesh.reorder_spatial, the remedy the row-block plan builder recommends
+            from dolfinx_mpc_amd.mesh import renumber, reorder_spatial
+
+            rng = np.random.default_rng(0)
+            mesh = create_box((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), (N, N, N), "tetrahedron", None)
+            mesh = renumber(mesh, rng.permutation(mesh.num_nodes), rng.permutation(mesh.num_cells))
+            if numbering == "spatial":
+                mesh = reorder_spatial(mesh)
         n_glob = (N, N, N)
     elif args.scaling == "strong":
         mesh = create_box_slab((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), (N, N, N), rank, world, 2, reorder)
@@ -398,6 +411,9 @@ def main():
                     help="threads of the all-core CPU leg (default: min(host cores, 64); 0 = skip)")
     ap.add_argument("--cpu-allcores-n", type=int, default=0)
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 PMC measurement of roofline.traffic")
+    ap.add_argument("--numbering", choices=["tiled", "shuffled", "spatial"], default="tiled",
+                    help="configs 2 / 5 on one GPU: 'tiled' = the generator's tile-wise numbering (default), 'shuffled' = nodes "
+                         "and cells in random order, 'spatial' = the shuffled mesh after mesh.reorder_spatial")
     ap.add_argument("--ufcx", choices=["files", "generated"], default=None,
                     help="config 2 with IMPORTED element kernels (UFCx C text -> hipRTC -> LDS row-block kernels): "
                          "'files' = tests/ufcx/laplace_p1_tet.c + source_p1_tet.c, 'generated' = the benchmark's own forms "
@@ -575,6 +591,40 @@ def main():
         mp = next(m for lab, _f, m in w.vectors if lab == bl)
         t_lift = hip_time(lambda: dm.apply_lifting(vecs[bl], [fa], [bcs], mp), 3)
         timings["apply_lifting"] = t_lift
+    # ---- the generic path: the same step with the cell-cluster kernels switched off (per-cell LDS row blocks for the
+    # matrix, owner-computes row blocks for the vector) -- what a mesh without clean six-tet fans runs
+    generic = None
+    if args.config == 2 and not args.ufcx and world == 1 and not child and not os.environ.get("MPCX_NO_CUBE"):
+        os.environ["MPCX_NO_CUBE"] = "1"
+        try:
+            step()
+            torch.cuda.synchronize()
+            t0g = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            tg = (time.perf_counter() - t0g) / args.steps
+            label, f, (m0, m1) = w.blocks[0]
+            A = mats[label]
+            gm, keepm = am.matrix_args(f, 0, A, m0, m1, bcs, alg_id, store_mode=1 if alg_id == 2 else 0, with_mpc_kernel=False)
+            tkm = hip_time(lambda: _native.check(Lib.mpcx_assemble_matrix(C.byref(gm)), "mpcx_assemble_matrix"), reps)
+            lv, fv, mv = w.vectors[0]
+            gv, keepv = av.vector_args(fv, 0, vecs[lv], mv, 0)
+            tkv = hip_time(lambda: _native.check(Lib.mpcx_assemble_vector(C.byref(gv)), "mpcx_assemble_vector"), reps)
+            bm = next(k for k in kernels if k["call"].startswith("assemble_matrix"))["algorithmic_bytes"]
+            bv = next(k for k in kernels if k["call"].startswith("assemble_vector"))["algorithmic_bytes"]
+            generic = {"ms_per_step": 1e3 * tg, "value": w.ndofs_total / tg, "unit": "DoFs/s",
+                       "note": "MPCX_NO_CUBE=1: per-cell kernels only (meshes whose cells do not form six-tet fans)",
+                       "kernels": [
+                           {"kernel": "matrix_rowblock_kernel[A]" if gm.algorithm == 2 else "matrix_atomic_kernel[A]", "launch_ms": tkm,
+                            "algorithmic_bytes": int(bm), "hbm_frac": bm / (tkm * 1e-3) / 1e9 / PEAK_HBM_GBS},
+                           {"kernel": ("vector_ownblock_kernel[b]" if gv.own_lmap else "vector_rowblock_kernel[b]") if gv.algorithm == 2
+                            else "vector_kernel[b]", "launch_ms": tkv, "algorithmic_bytes": int(bv),
+                            "hbm_frac": bv / (tkv * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                            "fp64_frac": 82.0 * int(fv.integrals[0].kernel.qwts.size) * nc / (tkv * 1e-3) / 1e12 / PEAK_FP64_TFLOPS}]}
+            del keepm, keepv
+        finally:
+            del os.environ["MPCX_NO_CUBE"]
     step()  # leave consistent A / b
     torch.cuda.synchronize()
     if rank != 0:
@@ -611,6 +661,7 @@ def main():
                        dofs_per_gpu=int(w.V.num_dofs),
                        dofs_global=int(w.ndofs_total), nnz_per_gpu={k: int(A.nnz) for k, A in mats.items()},
                        matrix_algorithm=args.alg, numbering_tile=None if args.no_tile else list(args.tile),
+                       numbering=args.numbering,
                        parallelism=(f"{args.scaling}-scaling slabs x{world}" if world > 1 else "single GPU")),
         "timings_ms": timings,
         "one_shot": {"setup_s": t_setup, "problem_s": t_problem, "pattern_s": t_pattern, "first_call_s": t_first,
@@ -625,13 +676,15 @@ def main():
         },
         "roofline_kernels": [{k2: v for k2, v in k.items() if k2 != "pmc_name"} for k in kernels],
     }
+    if generic is not None:
+        out["roofline_generic"] = generic
     if "fp64_frac" in dom:
         out["roofline"]["fp64_valu"] = {"achieved": dom["fp64_TFLOPs"], "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                                         "frac": dom["fp64_frac"]}
     if world == 1 and not args.no_traffic and not os.environ.get("MPCX_BENCH_NO_PMC"):
         log("measuring HBM traffic of the dominant kernel (rocprofv3 --pmc, two short child runs) ...")
         child_args = ["--config", str(args.config), "--size", str(args.n), "--alg", args.alg, "--steps", "1", "--warmup", "0",
-                      "--no-cpu-baseline", "--no-traffic"] + (["--ufcx", args.ufcx] if args.ufcx else []) + (["--no-tile"] if args.no_tile else ["--tile"] + [str(v) for v in args.tile])
+                      "--no-cpu-baseline", "--no-traffic", "--numbering", args.numbering] + (["--ufcx", args.ufcx] if args.ufcx else []) + (["--no-tile"] if args.no_tile else ["--tile"] + [str(v) for v in args.tile])
         traffic, info = measure_traffic(child_args, dom["pmc_name"])
         out["roofline"]["traffic"] = traffic
         out["roofline"]["traffic_source"] = info

@@ -199,6 +199,8 @@ EXPORTS = [
     "mpcx_scatter_offsets",
     "mpcx_cube_records",
     "mpcx_cube_detect",
+    "mpcx_cluster_keys",
+    "mpcx_cluster_build",
     "mpcx_rowblock_pairs_device",
     "mpcx_diag_slot_mask",
     "mpcx_add_diagonal",
@@ -307,6 +309,10 @@ def lib() -> C.CDLL:
     L.mpcx_cube_records.restype = C.c_int
     L.mpcx_cube_detect.argtypes = [vp, i64, vp, vp, vp]
     L.mpcx_cube_detect.restype = C.c_int
+    L.mpcx_cluster_keys.argtypes = [vp, vp, i64, vp, vp]
+    L.mpcx_cluster_keys.restype = C.c_int
+    L.mpcx_cluster_build.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp]
+    L.mpcx_cluster_build.restype = C.c_int
     L.mpcx_rowblock_pairs_device.argtypes = [i64, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]
     L.mpcx_rowblock_pairs_device.restype = C.c_int
     L.mpcx_diag_slot_mask.argtypes = [i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]

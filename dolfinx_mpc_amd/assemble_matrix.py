@@ -36,6 +36,19 @@ MPC_PLAN_MAX_ENTRIES = int(float(os.environ.get("MPCX_MPC_PLAN_MAX_ENTRIES", 1e8
 MAX_OFFSET_PATTERNS = 4096
 
 
+def _warn_no_locality(kind: str, slots: int, entities: int, limit: float = 4.0):
+    """Row blocks are contiguous CSR row ranges held in LDS; every entity is listed under each block it touches.  On
+    a numbering without locality (a mesh as a file may deliver it) nearly every entity touches as many blocks as it
+    has dofs: correct, but 5-13 x slower.  Say so once, with the remedy."""
+    if entities > 4096 and slots > limit * entities:
+        import warnings
+
+        warnings.warn(f"dolfinx_mpc_amd: the {kind} plan lists {slots / entities:.1f} row blocks per entity -- the dof numbering "
+                      "has no spatial locality, the row-block kernels will run several times slower than they can.  "
+                      "Renumber the mesh once with dolfinx_mpc_amd.mesh.reorder_spatial(mesh) (nodes along a Z-order "
+                      "curve, cells by lowest node) before creating function spaces.", RuntimeWarning, stacklevel=3)
+
+
 def _pair(constraint):
     if isinstance(constraint, MultiPointConstraint):
         return constraint, constraint
@@ -408,6 +421,8 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False, pai
                 offs = D._to_dev(table[: npat * noff].copy(), dev)
                 pattern = D._to_dev(ids.view(np.int16), dev)  # torch has no uint16 on every build: same bits
         t = lists + (offs, pattern)
+        if not pairs:
+            _warn_no_locality("row-block", int(t[2].numel()), integ.num_entities)
         max_rows = int(np.diff(row0).max())
         max_nnz = int(np.diff(A.rowptr[row0]).max())
         s = _native.RowBlockPlanT(nb, max_rows, max_nnz, int(pairs), t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
@@ -485,6 +500,7 @@ def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc):
         nb = row0.size - 1
         d_row0, d_off, d_ents = _block_lists_device(row0, nc, 1, None, d_verts, 8, bs, dev)
         nslots = d_ents.numel()
+        _warn_no_locality("cluster", int(nslots), nc, limit=5.0)
         recs = torch.empty(nslots * 96, dtype=torch.uint8, device=dev)
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         _, t = mpc._device()

@@ -1,13 +1,19 @@
 """Cell clusters for the P1 cluster kernels (include/mpcx.h MPCX_ALG_CUBE, csrc/mpcx_cubes.hip).
 
-A cluster ("Kuhn fan") is a run of six consecutive tetrahedra that share one edge and have eight
-vertices in the pattern every structured box generator emits per cube:
+A cluster ("fan") is a set of six tetrahedra round one shared edge whose other vertices form a closed ring
+of six -- what a box generator (ours, DOLFINx create_box) emits per cube.  In the local numbering of the
+cluster kernels the shared edge is (0, 7) and the ring 1-3-2-6-4-5:
 
-    (0,1,3,7) (0,1,7,5) (0,5,7,4) (0,3,2,7) (0,6,4,7) (0,2,6,7)      local vertex b: bit0 = x, bit1 = y, bit2 = z
+    (0,1,3,7) (0,1,7,5) (0,5,7,4) (0,3,2,7) (0,6,4,7) (0,2,6,7)
 
-Detection is purely topological (vertex ids of consecutive cells); the kernels compute every tet's
-geometry from its own coordinates.  Cells that are not part of such a run are returned as leftovers
-and keep going through the per-cell kernels."""
+Detection (``fans_from_topology`` / the HIP kernels behind ``mesh_clusters_device``) does not depend on the
+order of the cells nor on the local vertex order inside a cell -- DOLFINx reorders both: every tet names its
+longest edge, tets are sorted by that key, runs of six whose other vertices close into a ring are fans.  The
+kernels compute every tet's geometry from its own coordinates.  Cells that are in no fan are returned as
+leftovers and go through the per-cell kernels.
+
+``kuhn_fans`` is the older detector for meshes that keep the generator's cell order (six consecutive cells
+with the pattern's local vertex order); kept as an independent check of the general one."""
 
 from __future__ import annotations
 
@@ -39,6 +45,76 @@ def kuhn_fans(cells: np.ndarray, ncells: int):
     return np.ascontiguousarray(verts[ok], dtype=np.int32), left
 
 
+_RING_LOCAL = (1, 3, 2, 6, 4, 5)  # local ids of the ring vertices in walking order
+
+
+def long_edge_keys(x: np.ndarray, cells: np.ndarray) -> np.ndarray:
+    """(vmin << 32) | vmax of every tet's longest edge (ties: the smaller pair) -- numpy restatement of
+    ``tet_long_edge_kernel``"""
+    c = np.asarray(cells, dtype=np.int64)
+    best = np.full(c.shape[0], -1.0)
+    key = np.full(c.shape[0], -1, dtype=np.int64)
+    for a in range(4):
+        for b in range(a + 1, 4):
+            d = x[c[:, a]] - x[c[:, b]]
+            ln = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+            k2 = (np.minimum(c[:, a], c[:, b]) << 32) | np.maximum(c[:, a], c[:, b])
+            take = (ln > best) | ((ln == best) & (k2 < key))
+            best = np.where(take, ln, best)
+            key = np.where(take, k2, key)
+    return key
+
+
+def fans_from_topology(x: np.ndarray, cells: np.ndarray, ncells: int):
+    """Fans among cells [0, ncells) of any order / local vertex order (host restatement of the device detection,
+    plain loops over the candidate runs: tests and small meshes).  Returns (cube_verts (n, 8) int32, leftover
+    cell ids int32, ascending)."""
+    cells = np.asarray(cells[:ncells], dtype=np.int64)
+    keys = long_edge_keys(np.asarray(x), cells)
+    order = np.argsort(keys, kind="stable")
+    ks = keys[order]
+    starts = np.flatnonzero(np.concatenate([[True], ks[1:] != ks[:-1]]))
+    lens = np.diff(np.concatenate([starts, [ks.size]]))
+    in_fan = np.zeros(ncells, dtype=bool)
+    verts = []
+    for p in starts[lens == 6]:
+        v0, v7 = int(ks[p] >> 32), int(ks[p] & 0xFFFFFFFF)
+        edges = []
+        for c in order[p:p + 6]:
+            o = [int(u) for u in cells[c] if u != v0 and u != v7]
+            if len(o) != 2 or o[0] == o[1]:
+                break
+            edges.append(o)
+        if len(edges) != 6:
+            continue
+        ring, used, good = [edges[0][0], edges[0][1]], {0}, True
+        for k in range(2, 7):
+            cur = ring[-1] if k < 7 else None
+            nxt = None
+            for t in range(1, 6):
+                if t not in used and cur in edges[t]:
+                    nxt = edges[t][0] if edges[t][1] == cur else edges[t][1]
+                    used.add(t)
+                    break
+            if nxt is None:
+                good = False
+                break
+            if k < 6:
+                ring.append(nxt)
+            elif nxt != ring[0]:
+                good = False
+        if not good or len(set(ring)) != 6 or v0 in ring or v7 in ring:
+            continue
+        v = [0] * 8
+        v[0], v[7] = v0, v7
+        for loc, r in zip(_RING_LOCAL, ring):
+            v[loc] = r
+        verts.append(v)
+        in_fan[order[p:p + 6]] = True
+    verts = np.array(verts, dtype=np.int32).reshape(-1, 8)
+    return np.ascontiguousarray(verts), np.flatnonzero(~in_fan).astype(np.int32)
+
+
 def mesh_clusters(mesh, ncells: int):
     """cached per (mesh, ncells): (cube_verts, leftover cells)"""
     key = ("kuhn_fans", int(ncells))
@@ -48,27 +124,51 @@ def mesh_clusters(mesh, ncells: int):
 
 
 def mesh_clusters_device(mesh, ncells: int):
-    """(cube_verts device tensor (n, 8) int32, leftover cells (host int32, possibly empty)) -- detection by the HIP
-    kernel ``cube_detect_kernel`` on the device-resident geometry dofmap; only when some group is not a fan does
-    the (slower) host path run to compact the clusters and list the leftovers.  Cached per (mesh, ncells)."""
+    """(cube_verts device tensor (n, 8) int32, leftover cells (host int32, ascending, possibly empty)) of cells
+    [0, ncells): detected on the device from topology + edge lengths, whatever the order of the cells and of their
+    local vertices (``tet_long_edge_kernel`` -> sort by key (torch: plumbing) -> ``fan_build_kernel`` -> compaction).
+    MPCX_CLUSTER_DETECT=consecutive selects the older detector (six consecutive cells in the generator's pattern).
+    Cached per (mesh, ncells, geometry version): the longest edge is a property of the coordinates."""
+    import os
+
     import torch
 
     from . import _device as D
     from . import _native
 
     def build():
-        dm = D.mesh_device(mesh)["x_dofmap"]
+        md = D.mesh_device(mesh)
+        dm = md["x_dofmap"]
         dev = dm.device
-        ng = int(ncells) // 6
-        if dm.shape[1] != 4 or ng == 0:
-            return torch.zeros((0, 8), dtype=torch.int32, device=dev), np.arange(ncells, dtype=np.int32)
-        verts = torch.empty((ng, 8), dtype=torch.int32, device=dev)
-        ok = torch.empty(ng, dtype=torch.int8, device=dev)
-        _native.check(_native.lib().mpcx_cube_detect(dm.data_ptr(), ng, verts.data_ptr(), ok.data_ptr(), D.stream_ptr()),
-                      "mpcx_cube_detect")
-        if int(ok.sum(dtype=torch.int64).item()) == ng and ncells % 6 == 0:
+        n = int(ncells)
+        if dm.shape[1] != 4 or n < 6:
+            return torch.zeros((0, 8), dtype=torch.int32, device=dev), np.arange(n, dtype=np.int32)
+        L = _native.lib()
+        st = D.stream_ptr()
+        if os.environ.get("MPCX_CLUSTER_DETECT", "topology") == "consecutive":
+            ng = n // 6
+            verts = torch.empty((ng, 8), dtype=torch.int32, device=dev)
+            ok = torch.empty(ng, dtype=torch.int8, device=dev)
+            _native.check(L.mpcx_cube_detect(dm.data_ptr(), ng, verts.data_ptr(), ok.data_ptr(), st), "mpcx_cube_detect")
+            if int(ok.sum(dtype=torch.int64).item()) == ng and n % 6 == 0:
+                return verts, np.zeros(0, dtype=np.int32)
+            v, left = kuhn_fans(mesh.geometry.dofmap, n)
+            return D._to_dev(v, dev), left
+        keys = torch.empty(n, dtype=torch.int64, device=dev)
+        _native.check(L.mpcx_cluster_keys(md["x"].data_ptr(), dm.data_ptr(), n, keys.data_ptr(), st), "mpcx_cluster_keys")
+        keys, order = torch.sort(keys, stable=True)
+        order = order.to(torch.int32)
+        verts = torch.empty((n, 8), dtype=torch.int32, device=dev)
+        ok = torch.empty(n, dtype=torch.int8, device=dev)
+        in_fan = torch.zeros(n, dtype=torch.int8, device=dev)
+        _native.check(L.mpcx_cluster_build(n, keys.data_ptr(), order.data_ptr(), dm.data_ptr(), verts.data_ptr(), ok.data_ptr(),
+                                           in_fan.data_ptr(), st), "mpcx_cluster_build")
+        del keys, order
+        sel = torch.nonzero(ok).reshape(-1)
+        verts = verts[sel].contiguous()
+        if verts.shape[0] * 6 == n:
             return verts, np.zeros(0, dtype=np.int32)
-        v, left = kuhn_fans(mesh.geometry.dofmap, int(ncells))
-        return D._to_dev(v, dev), left
+        left = torch.nonzero(in_fan == 0).reshape(-1).to(torch.int32).cpu().numpy()
+        return verts, left
 
-    return D.cached(mesh._device, "kuhn_fans_dev", (), int(ncells), build)
+    return D.cached(mesh._device, "fans_dev", (), (int(ncells), mesh.geometry.version), build, maxsize=2)

@@ -141,6 +141,123 @@ __global__ void cube_detect_kernel(const int32_t* __restrict__ cells, int64_t n_
   ok[g] = good ? 1 : 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Cluster detection from topology and geometry, independent of the order of the cells and of the local vertex order
+// inside a cell (DOLFINx reorders both).  A fan is six tets round one shared edge whose other vertices form a closed
+// ring of six.  Which edge: every tet names its LONGEST edge (ties: the smaller (vmin, vmax) pair) -- in a cube cut
+// into six tets that is the body diagonal, for any box shape.  Tets are then sorted by that key (by the caller); a run
+// of exactly six equal keys whose twelve other vertices close into one ring of six distinct vertices is a fan, and its
+// eight vertices are written in the local numbering the cluster kernels use (shared edge = local 0 and 7, the ring
+// 1-3-2-6-4-5, see fan_vertex).  Orientation does not matter: the kernels take |det| of every tet.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void tet_long_edge_kernel(const double* __restrict__ x, const int32_t* __restrict__ cells, int64_t n_cells,
+                                     int64_t* __restrict__ keys)
+{
+  const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (c >= n_cells)
+    return;
+  const uint4 w = reinterpret_cast<const uint4*>(cells)[c];
+  const int32_t v[4] = {int32_t(w.x), int32_t(w.y), int32_t(w.z), int32_t(w.w)};
+  double X[4][3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      X[i][k] = x[3 * int64_t(v[i]) + k];
+  double best = -1.0;
+  int64_t key = -1;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = a + 1; b < 4; ++b)
+    {
+      const double dx = X[a][0] - X[b][0], dy = X[a][1] - X[b][1], dz = X[a][2] - X[b][2];
+      // (no fma contraction: the same edge must get the same length in every tet that holds it, whichever of its
+      // two vertices comes first -- (a - b)^2 = (b - a)^2 exactly, product by product)
+      const double len = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+      const int32_t lo = v[a] < v[b] ? v[a] : v[b], hi = v[a] < v[b] ? v[b] : v[a];
+      const int64_t k2 = (int64_t(lo) << 32) | int64_t(uint32_t(hi));
+      if (len > best || (len == best && k2 < key))
+      {
+        best = len;
+        key = k2;
+      }
+    }
+  keys[c] = key;
+}
+
+// one thread per position of the key-sorted cell list; a run start with exactly six members is examined
+__global__ void fan_build_kernel(int64_t n, const int64_t* __restrict__ keys, const int32_t* __restrict__ order,
+                                 const int32_t* __restrict__ cells, int32_t* __restrict__ verts, int8_t* __restrict__ ok,
+                                 int8_t* __restrict__ cell_in_fan)
+{
+  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= n)
+    return;
+  ok[p] = 0;
+  const int64_t key = keys[p];
+  if ((p > 0 && keys[p - 1] == key) || p + 5 >= n || keys[p + 5] != key || (p + 6 < n && keys[p + 6] == key))
+    return;
+  const int32_t v0 = int32_t(key >> 32), v7 = int32_t(key & 0xffffffff);
+  int32_t ea[6], eb[6]; // the two other vertices of every tet: an edge of the ring graph
+  for (int t = 0; t < 6; ++t)
+  {
+    const int32_t* c = cells + int64_t(order[p + t]) * 4;
+    int32_t o[2];
+    int no = 0, hit = 0;
+    for (int i = 0; i < 4; ++i)
+    {
+      const int32_t u = c[i];
+      if (u == v0 || u == v7)
+        ++hit;
+      else if (no < 2)
+        o[no++] = u;
+    }
+    if (hit != 2 || no != 2 || o[0] == o[1])
+      return;
+    ea[t] = o[0], eb[t] = o[1];
+  }
+  // walk the ring: start with tet 0's pair, then always the unused tet that holds the current end
+  int32_t ring[6];
+  ring[0] = ea[0], ring[1] = eb[0];
+  unsigned used = 1u;
+  for (int k = 2; k < 7; ++k)
+  {
+    const int32_t cur = ring[k - 1];
+    int found = -1;
+    int32_t nxt = -1;
+    for (int t = 1; t < 6; ++t)
+      if (!((used >> t) & 1) && (ea[t] == cur || eb[t] == cur))
+      {
+        found = t;
+        nxt = ea[t] == cur ? eb[t] : ea[t];
+        break;
+      }
+    if (found < 0)
+      return;
+    used |= 1u << found;
+    if (k < 6)
+      ring[k] = nxt;
+    else if (nxt != ring[0])
+      return; // the sixth tet must close the ring
+  }
+  for (int a = 0; a < 6; ++a)
+  {
+    if (ring[a] == v0 || ring[a] == v7)
+      return;
+    for (int b = a + 1; b < 6; ++b)
+      if (ring[a] == ring[b])
+        return;
+  }
+  // local numbering of the cluster kernels: ring 1-3-2-6-4-5 (tets (0,1,3,7) (0,3,2,7) (0,2,6,7) (0,6,4,7) (0,5,7,4) (0,1,7,5))
+  int32_t* q = verts + p * 8;
+  q[0] = v0, q[7] = v7;
+  q[1] = ring[0], q[3] = ring[1], q[2] = ring[2], q[6] = ring[3], q[4] = ring[4], q[5] = ring[5];
+  ok[p] = 1;
+  for (int t = 0; t < 6; ++t)
+    cell_in_fan[order[p + t]] = 1;
+}
+
 // set-up: (row block, entity) pairs of the row-block plan, in entity order (the caller sorts them by block):
 // entity e belongs to every block that holds one of its nd dofs.  counts / offsets protocol as mpcx_mpc_plan_device.
 template <bool FILL>
@@ -562,6 +679,25 @@ extern "C" int mpcx_cube_detect(const int32_t* cells, int64_t n_groups, int32_t*
   hipLaunchKernelGGL(mpcx::cube_detect_kernel, dim3(mpcx::grid_for(n_groups, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), cells, n_groups, verts, ok);
   return mpcx::check(hipGetLastError(), "cube_detect launch");
+}
+
+extern "C" int mpcx_cluster_keys(const double* x, const int32_t* cells, int64_t n_cells, int64_t* keys, void* stream)
+{
+  if (n_cells == 0)
+    return 0;
+  hipLaunchKernelGGL(mpcx::tet_long_edge_kernel, dim3(mpcx::grid_for(n_cells, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, cells, n_cells, keys);
+  return mpcx::check(hipGetLastError(), "cluster_keys launch");
+}
+
+extern "C" int mpcx_cluster_build(int64_t n, const int64_t* sorted_keys, const int32_t* order, const int32_t* cells,
+                                  int32_t* verts, int8_t* ok, int8_t* cell_in_fan, void* stream)
+{
+  if (n == 0)
+    return 0;
+  hipLaunchKernelGGL(mpcx::fan_build_kernel, dim3(mpcx::grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n,
+                     sorted_keys, order, cells, verts, ok, cell_in_fan);
+  return mpcx::check(hipGetLastError(), "cluster_build launch");
 }
 
 extern "C" int mpcx_rowblock_pairs_device(int64_t n_entities, int32_t estride, const int32_t* entities0,

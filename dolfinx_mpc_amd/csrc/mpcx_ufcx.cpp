@@ -306,35 +306,45 @@ extern "C" __global__ void __launch_bounds__(UFCX_RB_THREADS) ufcx_matrix_rowblo
   const bool geom_is_dofmap = (NV == ND0) && (a.x_dofmap == a.dofmap0) && (a.entities0 == a.entities);
   const long long e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
   const int* __restrict__ ents = a.plan.block_ents;
-  for (long long t = e0 + tid; t < e1; t += NT)
+  // per-entity index data: everything that is read through the entity index
+  struct Ent
   {
-    const long long e = ents[t];
+    long long e;
+    int lf;
+    int xd[NV];
+    int m0[ND0], m1[ND1];
+    unsigned ow[(NOFF + 3) / 4]; // scatter offsets, 4 per word
+  };
+  auto load_ent = [&](long long e, Ent& E)
+  {
+    E.e = e;
     const long long l = e * a.estride;
     const long long cell = a.entities ? a.entities[l] : e;
     const long long cell0 = a.entities0 ? a.entities0[l] : e;
     const long long cell1 = a.entities1 ? a.entities1[l] : e;
-    const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
-    int m0[ND0], m1[ND1];
+    E.lf = a.estride == 2 ? a.entities[l + 1] : 0;
 #pragma unroll
     for (int i = 0; i < ND0; ++i)
-      m0[i] = a.mdofmap0[cell0 * ND0 + i];
+      E.m0[i] = a.mdofmap0[cell0 * ND0 + i];
 #pragma unroll
     for (int j = 0; j < ND1; ++j)
-      m1[j] = same_maps ? m0[j < ND0 ? j : 0] : a.mdofmap1[cell1 * ND1 + j];
+      E.m1[j] = same_maps ? E.m0[j < ND0 ? j : 0] : a.mdofmap1[cell1 * ND1 + j];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      E.xd[i] = geom_is_dofmap ? (E.m0[i < ND0 ? i : 0] & DOF_MASK) : a.x_dofmap[cell * NV + i];
     // scatter offsets of this entity: NOFF bytes, contiguous
-    unsigned ow[(NOFF + 3) / 4];
     const unsigned char* po = a.plan.ent_offs + e * NOFF;
 #if NOFF % 16 == 0
 #pragma unroll
     for (int w = 0; w < NOFF / 16; ++w)
     {
       const uint4 v = ((const uint4*)po)[w];
-      ow[4 * w] = v.x, ow[4 * w + 1] = v.y, ow[4 * w + 2] = v.z, ow[4 * w + 3] = v.w;
+      E.ow[4 * w] = v.x, E.ow[4 * w + 1] = v.y, E.ow[4 * w + 2] = v.z, E.ow[4 * w + 3] = v.w;
     }
 #elif NOFF % 4 == 0
 #pragma unroll
     for (int w = 0; w < NOFF / 4; ++w)
-      ow[w] = ((const unsigned*)po)[w];
+      E.ow[w] = ((const unsigned*)po)[w];
 #else
 #pragma unroll
     for (int w = 0; w < (NOFF + 3) / 4; ++w)
@@ -344,18 +354,52 @@ extern "C" __global__ void __launch_bounds__(UFCX_RB_THREADS) ufcx_matrix_rowblo
       for (int q = 0; q < 4; ++q)
         if (4 * w + q < NOFF)
           u |= (unsigned)po[4 * w + q] << (8 * q);
-      ow[w] = u;
+      E.ow[w] = u;
     }
+#endif
+  };
+  // small elements: software pipeline -- while one entity is computed, the index data of the next one and the
+  // entity index of the one after it are in flight, so an iteration only waits for its own coordinate gather
+#if NOFF <= 16
+#define UFCX_PIPE 1
+#else
+#define UFCX_PIPE 0
+#endif
+  long long t = e0 + tid;
+  Ent cur;
+  int i1 = 0;
+#if UFCX_PIPE
+  if (t < e1)
+    load_ent(ents[t], cur);
+  if (t + NT < e1)
+    i1 = ents[t + NT];
+#endif
+  for (; t < e1; t += NT)
+  {
+#if !UFCX_PIPE
+    load_ent(ents[t], cur);
 #endif
     double cd[NV * 3];
 #pragma unroll
     for (int i = 0; i < NV; ++i)
     {
-      const long long v = geom_is_dofmap ? (long long)(m0[i < ND0 ? i : 0] & DOF_MASK) : (long long)a.x_dofmap[cell * NV + i];
+      const long long v = cur.xd[i];
 #pragma unroll
       for (int k = 0; k < 3; ++k)
         cd[3 * i + k] = a.x[3 * v + k];
     }
+#if UFCX_PIPE
+    Ent nxt = cur;
+    if (t + NT < e1)
+      load_ent(i1, nxt);
+    if (t + 2 * NT < e1)
+      i1 = ents[t + 2 * NT];
+#endif
+    const long long e = cur.e;
+    const int lf = cur.lf;
+    const int (&m0)[ND0] = cur.m0;
+    const int (&m1)[ND1] = cur.m1;
+    const unsigned (&ow)[(NOFF + 3) / 4] = cur.ow;
     double Ae[N0 * N1];
     UFCX_UNROLL
     for (int i = 0; i < N0 * N1; ++i)
@@ -390,6 +434,9 @@ extern "C" __global__ void __launch_bounds__(UFCX_RB_THREADS) ufcx_matrix_rowblo
         }
       }
     }
+#if UFCX_PIPE
+    cur = nxt;
+#endif
   }
   __syncthreads();
   if (a.store_mode)

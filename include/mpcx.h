@@ -269,6 +269,18 @@ int mpcx_cube_records(int64_t n_slots, const int32_t* block_ents, const int32_t*
  * verts[g][0..7] = the eight vertices read off the fan pattern, ok[g] = 1 if the six cells really form it. */
 int mpcx_cube_detect(const int32_t* cells, int64_t n_groups, int32_t* verts, int8_t* ok, void* stream);
 
+/* Set-up for MPCX_ALG_CUBE on ANY cell order and local vertex order (all pointers DEVICE), three steps:
+ *   1. mpcx_cluster_keys: keys[c] = (vmin << 32) | vmax of the LONGEST edge of tet c (ties: the smaller pair) -- the
+ *      body diagonal for a cube cut into six tets;
+ *   2. the caller sorts the cell indices by key (order[], sorted_keys[]);
+ *   3. mpcx_cluster_build: a run of exactly six equal keys whose other vertices close into one ring of six distinct
+ *      vertices is a cluster: ok[p] = 1 at the run's first position p, verts[p][0..7] = its vertices in the local
+ *      numbering of mpcx_vector_args_t::cube_verts, cell_in_fan[c] = 1 for its six cells (zeroed by the caller).
+ * The caller compacts verts by ok; cells with cell_in_fan == 0 go through the per-cell kernels. */
+int mpcx_cluster_keys(const double* x, const int32_t* cells, int64_t n_cells, int64_t* keys, void* stream);
+int mpcx_cluster_build(int64_t n, const int64_t* sorted_keys, const int32_t* order, const int32_t* cells, int32_t* verts,
+                       int8_t* ok, int8_t* cell_in_fan, void* stream);
+
 /* The entity lists of a row-block plan on the DEVICE (host version: second half of mpcx_rowblock_plan_build):
  * (block, entity) pairs in entity order; two calls like mpcx_mpc_plan_device (offsets == NULL: counts[e] =
  * number of distinct blocks entity e touches; then with the exclusive scan of counts: the pairs).  The caller

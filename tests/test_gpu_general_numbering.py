@@ -28,6 +28,43 @@ def test_renumbered_meshes_match_oracle(oracle, make, numbering, alg):
             assert abs(out[k] - ref[k]).max() <= 1e-12 * max(1.0, abs(ref[k]).max())
 
 
+@pytest.mark.parametrize("numbering", ["shuffled", "spatial"])
+def test_cluster_kernels_run_on_renumbered_meshes(oracle, numbering):
+    """the headline kernels (cell clusters) off the generator's own cell order: nodes renumbered,
+    cells shuffled, local vertices of every cell permuted -- all cells end up in clusters, the cluster plan is the
+    one that runs, and matrix / vector / lifting match the oracle on the same mesh"""
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import fem
+    from dolfinx_mpc_amd.clusters import mesh_clusters_device
+    from dolfinx_mpc_amd.mesh import Mesh
+    from problems import Case, _walls_yz, periodic_raw
+
+    base = case_cube_periodic(6, 1, 0.0, numbering=numbering).mesh
+    rng = np.random.default_rng(11)
+    cells = base.geometry.dofmap.copy()
+    for c in range(cells.shape[0]):
+        cells[c] = cells[c][rng.permutation(4)]
+    mesh = Mesh(base.geometry.x, cells, "tetrahedron")
+    mesh.node_tile_offsets = base.node_tile_offsets
+    V = fem.functionspace(mesh, ("Lagrange", 1))
+    bc = fem.dirichletbc(0.3, fem.locate_dofs_geometrical(V, _walls_yz), V)
+    case = Case("clusters_" + numbering, V, fem.form_stiffness(V), fem.form_source(V, fem.FN_BENCH_PERIODIC), [bc],
+                periodic_raw(V, [bc]))
+    d_verts, left = mesh_clusters_device(mesh, mesh.num_cells)
+    assert left.size == 0 and d_verts.shape[0] * 6 == mesh.num_cells
+    ref = oracle_outputs(oracle, case)
+    mpc = product_mpc(case)
+    A = dm.assemble_matrix(case.a, mpc, bcs=case.bcs)
+    assert ("objcache", "cubes") in A._plans
+    S = A.to_scipy()
+    assert np.array_equal(S.indptr, ref["A"].indptr) and np.array_equal(S.indices, ref["A"].indices)
+    assert abs(S.data - ref["A"].data).max() <= 1e-12 * max(1.0, abs(ref["A"].data).max())
+    b = dm.assemble_vector(case.L, mpc)
+    assert abs(b.numpy() - ref["b"]).max() <= 1e-12 * max(1.0, abs(ref["b"]).max())
+    dm.apply_lifting(b, [case.a], [case.bcs], mpc)
+    assert abs(b.numpy() - ref["b_lifted"]).max() <= 1e-12 * max(1.0, abs(ref["b_lifted"]).max())
+
+
 @pytest.mark.parametrize("degree", [1, 2])
 def test_reorder_spatial_shrinks_the_row_block_plan(degree):
     """entities evaluated per row block (the halo the row-block kernels pay for): a shuffled 16^3 mesh makes nearly
@@ -45,7 +82,7 @@ def test_reorder_spatial_shrinks_the_row_block_plan(degree):
     n = 16 if degree == 1 else 10
     import os
 
-    os.environ["MPCX_NO_CUBE"] = "1"  # compare the per-cell plans (the cluster path needs the generator's cell order)
+    os.environ["MPCX_NO_CUBE"] = "1"  # this test compares the per-cell plans
     try:
         shuffled, nc = plan_entities(case_cube_periodic(n, degree, 0.0, numbering="shuffled"))
         spatial, _ = plan_entities(case_cube_periodic(n, degree, 0.0, numbering="spatial"))

@@ -444,13 +444,17 @@ def test_backsubstitution_accepts_a_function(oracle):
 
 
 @pytest.mark.parametrize("reorder", [None, (2, 2, 2)])
-def test_cluster_kernels_with_leftover_cells(oracle, reorder):
-    """MPCX_ALG_CUBE on a mesh where some groups of six cells are NOT Kuhn fans (two cells swapped, one
-    cell's vertices rotated): those cells go through the per-cell kernels, the rest through the cluster
-    kernels; matrix, vector and lifting must still match the oracle on the same (scrambled) mesh."""
+@pytest.mark.parametrize("scramble", [False, True])
+def test_cluster_kernels_with_leftover_cells(oracle, reorder, scramble):
+    """MPCX_ALG_CUBE on a mesh where some cubes are NOT clean fans (a few cells appear twice, so seven or eight
+    tets sit round their long edge): those cells go through the per-cell kernels, the rest through the cluster
+    kernels; matrix, vector and lifting must still match the oracle on the same mesh.  ``scramble``: cells
+    shuffled and the local vertices of every cell permuted -- the detection must not depend on either."""
+    import torch
+
     import dolfinx_mpc_amd as dm
     from dolfinx_mpc_amd import fem
-    from dolfinx_mpc_amd.clusters import kuhn_fans
+    from dolfinx_mpc_amd.clusters import fans_from_topology, mesh_clusters_device
     from dolfinx_mpc_amd.mesh import Mesh, create_unit_cube
     from problems import Case, _walls_yz, periodic_raw
 
@@ -458,22 +462,31 @@ def test_cluster_kernels_with_leftover_cells(oracle, reorder):
     cells = base.geometry.dofmap.copy()
     rng = np.random.default_rng(5)
     groups = rng.choice(cells.shape[0] // 6, size=40, replace=False)
-    for g in groups[:20]:
-        cells[[6 * g + 1, 6 * g + 4]] = cells[[6 * g + 4, 6 * g + 1]]  # order of the cells inside the group
-    for g in groups[20:]:
-        cells[6 * g + 2] = cells[6 * g + 2][[1, 2, 0, 3]]  # an even permutation of one cell's vertices
+    extra = np.concatenate([cells[6 * groups[:20] + 1], cells[6 * groups[20:] + 4], cells[6 * groups[20:30] + 2]], axis=0)
+    cells = np.concatenate([cells, extra], axis=0)  # 40 cubes with 7 or 8 tets round their diagonal
+    if scramble:
+        cells = cells[rng.permutation(cells.shape[0])]
+        for c in range(cells.shape[0]):
+            cells[c] = cells[c][rng.permutation(4)]
     mesh = Mesh(base.geometry.x, cells, "tetrahedron")
     mesh.node_tile_offsets = base.node_tile_offsets
-    verts, left = kuhn_fans(cells, cells.shape[0])
-    assert left.size == 6 * 40 and verts.shape[0] == cells.shape[0] // 6 - 40
+    verts, left = fans_from_topology(mesh.geometry.x, cells, cells.shape[0])
+    assert left.size == 6 * 40 + 50 and verts.shape[0] == base.num_cells // 6 - 40
+    d_verts, d_left = mesh_clusters_device(mesh, cells.shape[0])  # the HIP detection finds the same fans
+    assert np.array_equal(np.sort(d_left), left)
+    assert {tuple(sorted(r)) for r in d_verts.cpu().numpy().tolist()} == {tuple(sorted(r)) for r in verts.tolist()}
     V = fem.functionspace(mesh, ("Lagrange", 1))
     bc = fem.dirichletbc(0.4, fem.locate_dofs_geometrical(V, _walls_yz), V)
     case = Case("cluster_leftover", V, fem.form_stiffness(V, constant=1.7), fem.form_source(V, fem.FN_BENCH_PERIODIC), [bc],
                 periodic_raw(V, [bc]))
     ref = oracle_outputs(oracle, case)
-    out = product_outputs(case, algorithm="rowblock")
-    assert np.array_equal(out["A"].indptr, ref["A"].indptr) and np.array_equal(out["A"].indices, ref["A"].indices)
-    _close(out["A"].data, ref["A"].data, RTOL_A, "A (clusters + leftover cells)")
+    mpc = product_mpc(case)
+    A = dm.assemble_matrix(case.a, mpc, bcs=case.bcs, algorithm="rowblock")
+    assert ("objcache", "cubes") in A._plans, "the cluster kernel was expected to run"
+    S = A.to_scipy()
+    assert np.array_equal(S.indptr, ref["A"].indptr) and np.array_equal(S.indices, ref["A"].indices)
+    _close(S.data, ref["A"].data, RTOL_A, "A (clusters + leftover cells)")
     out_v = product_outputs(case, algorithm=None)  # vector: "auto" takes the cluster kernel for this form
     _close(out_v["b"], ref["b"], RTOL_B, "b (clusters + leftover cells)")
     _close(out_v["b_lifted"], ref["b_lifted"], RTOL_B, "b_lifted")
+    torch.cuda.synchronize()

@@ -419,6 +419,45 @@ def test_cell_cluster_detection():
     assert verts.shape[0] == 14 and sorted(left.tolist()) == list(range(6, 18)) + [96, 97, 98, 99]
 
 
+def test_cluster_detection_from_topology_ignores_cell_and_vertex_order():
+    """clusters.fans_from_topology (host restatement of the device detection): the same fans as the generator-order
+    detector on the generator's meshes, and still all of them after the nodes were renumbered, the cells shuffled
+    and the local vertices of every cell permuted (DOLFINx does all three); extra cells round an edge (duplicates)
+    turn that fan into leftovers"""
+    from dolfinx_mpc_amd.clusters import fans_from_topology, kuhn_fans
+    from dolfinx_mpc_amd.mesh import Mesh, create_box, create_unit_cube
+    from problems import renumbered
+
+    pattern = np.array([[0, 1, 3, 7], [0, 1, 7, 5], [0, 5, 7, 4], [0, 3, 2, 7], [0, 6, 4, 7], [0, 2, 6, 7]])
+    rng = np.random.default_rng(3)
+    for mesh in (create_unit_cube(3, 4, 2), create_unit_cube(5, 5, 5, reorder=(2, 2, 2)),
+                 create_box((0.0, 0.0, 0.0), (2.0, 1.0, 0.3), (4, 3, 5))):
+        ref, _ = kuhn_fans(mesh.geometry.dofmap, mesh.num_cells)
+        want = {tuple(sorted(r)) for r in ref.tolist()}
+        sh = renumbered(mesh, "shuffled")
+        cells = sh.geometry.dofmap.copy()
+        for c in range(cells.shape[0]):
+            cells[c] = cells[c][rng.permutation(4)]
+        for m in (mesh, Mesh(sh.geometry.x, cells, "tetrahedron")):
+            verts, left = fans_from_topology(m.geometry.x, m.geometry.dofmap, m.num_cells)
+            assert left.size == 0 and verts.shape == (m.num_cells // 6, 8)
+            # every fan's six tets (pattern over its eight vertices) are cells of the mesh, each cell exactly once
+            tets = np.sort(np.take_along_axis(verts[:, None, :].repeat(6, 1), pattern[None].repeat(verts.shape[0], 0), 2), axis=2)
+            have = np.sort(np.sort(m.geometry.dofmap, axis=1).view([("", np.int32)] * 4).ravel())
+            assert np.array_equal(np.sort(tets.reshape(-1, 4).astype(np.int32).view([("", np.int32)] * 4).ravel()), have)
+            # eight corners of one cube of the grid
+            ext = np.ptp(m.geometry.x[verts], axis=1)
+            assert np.allclose(ext.prod(axis=1), ext[0].prod())
+        if mesh.node_tile_offsets is None and mesh.num_cells == 6 * 24:
+            assert want == {tuple(sorted(int(v) for v in r)) for r in fans_from_topology(mesh.geometry.x, mesh.geometry.dofmap, mesh.num_cells)[0]}
+    mesh = create_unit_cube(3, 3, 3)
+    extra = mesh.geometry.dofmap[[7, 40, 41]]  # duplicates of three cells out of two different cubes
+    cells = np.concatenate([mesh.geometry.dofmap, extra], axis=0)
+    verts, left = fans_from_topology(mesh.geometry.x, cells, cells.shape[0])
+    assert verts.shape[0] == 27 - 2 and left.size == 6 * 2 + 3
+    assert set(left.tolist()) == set(range(6, 12)) | set(range(36, 42)) | {162, 163, 164}
+
+
 def test_lagrange_basis_tables():
     from dolfinx_mpc_amd.quadrature import lagrange_basis, make_quadrature
 
