@@ -82,12 +82,23 @@ def _vector_owner_plan(form: Form, i: int, V, md0, rows: int):
 
 
 def _build_vector_owner_plan(form: Form, i: int, V, md0, rows: int):
+    integ = form.integrals[i]
+    n, nd = integ.num_entities, V.element_ndofs
+    ents = D.integral_device(form, i)["entities"]
+    cells = None if ents is None else ents.view(n, integ.estride)[:, 0].long()
+    mrow = md0.view(-1, nd)[:n] if cells is None else md0.view(-1, nd)[cells]  # masked dofmap rows of the entities
+    return _owner_plan_from_rows(mrow, V, rows)
+
+
+def _owner_plan_from_rows(mrow, V, rows: int):
+    """owner-computes plan for ``n`` work items whose masked dof rows are ``mrow`` (n, nd) (dof | flags << 28): the
+    entities of an integral, or the cell clusters of the mesh with their eight vertices"""
     import torch
 
     from .assemble_matrix import _block_ranges
 
-    integ = form.integrals[i]
-    n, nd, bs = integ.num_entities, V.element_ndofs, V.dofmap.bs
+    n, nd = mrow.shape
+    bs = V.dofmap.bs
     nrows = V.num_dofs
     ndof_blocks = nrows // bs
     hints = None
@@ -97,9 +108,6 @@ def _build_vector_owner_plan(form: Form, i: int, V, md0, rows: int):
     nb = row0.size - 1
     dev = _native.require_gpu()
     d_row0 = D._to_dev(row0, dev)
-    ents = D.integral_device(form, i)["entities"]
-    cells = None if ents is None else ents.view(n, integ.estride)[:, 0].long()
-    mrow = md0.view(-1, nd)[:n] if cells is None else md0.view(-1, nd)[cells]  # masked dofmap rows of the entities
     dof = (mrow & ((1 << 28) - 1)).to(torch.int64)
     flags = (mrow >> 28) << 28
     blk = torch.searchsorted(d_row0[1:].contiguous(), (dof * bs).contiguous(), right=True)  # (n, nd)
@@ -131,6 +139,32 @@ def _build_vector_owner_plan(form: Form, i: int, V, md0, rows: int):
          urows.to(torch.int32).contiguous(), seg)
     plan = _native.RowBlockPlanT(nb, max_rows, max_rows, 0, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), None, None)
     return (plan, t, int(urows.numel()))
+
+
+# own rows per block of the owner-computes cluster vector kernel (4096 rows + halo: two 256-thread workgroups per CU)
+VCUBE_OWNER_ROWS = int(os.environ.get("MPCX_VCUBE_ROWS", 4096))
+
+
+def _vector_cube_owner_plan(mesh, V, d_verts, constraint, left: np.ndarray, slave_ents_h: np.ndarray):
+    """owner-computes plan over the mesh's cell clusters (work item = cluster, its eight vertices = its dofs; slave
+    flag folded into the vertex ids) + the slave CELLS the cluster call is responsible for (all but the leftover
+    ones, which the per-cell call handles); cached per (clusters, constraint)"""
+    import torch
+
+    def build():
+        _, t = constraint._device()
+        flag = t["is_slave"][d_verts.long()].to(torch.int32) << 28
+        mrow = (d_verts | flag).contiguous()
+        for rows in (VCUBE_OWNER_ROWS, VCUBE_OWNER_ROWS // 2, VCUBE_OWNER_ROWS // 4):
+            own = _owner_plan_from_rows(mrow, V, _even_rows(V, rows))
+            if own is not None:
+                break
+        if own is None:
+            return None
+        sl = slave_ents_h if left.size == 0 else np.setdiff1d(slave_ents_h, left)
+        return own + (D._to_dev(np.ascontiguousarray(sl, dtype=np.int32), d_verts.device),)
+
+    return D.cached(mesh._device, "vcube_own", (d_verts, constraint, left), VCUBE_OWNER_ROWS, build, maxsize=2)
 
 
 def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint, alg: int, allow_cubes: bool = True):
@@ -169,6 +203,20 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
             a.leftover = left if left.size else None
             a.stream = D.stream_ptr()
             keep += [d_verts]
+            if os.environ.get("MPCX_VCUBE_OWNER", "1") != "0":
+                # owner-computes row blocks over the clusters: no hash table, no device atomics, deterministic
+                # (MPCX_VCUBE_OWNER=0: the LDS-hash kernel, one device atomic per distinct dof of a workgroup)
+                from .assemble_matrix import _slave_entities
+
+                slave_h, _ = _slave_entities(form, i, constraint, constraint)
+                own = _vector_cube_owner_plan(form.mesh, V, d_verts, constraint, left, slave_h)
+                if own is not None:
+                    plan, pk, n_own, d_slaves = own
+                    a.plan = plan
+                    a.own_lmap, a.own_hoff, a.own_spill = pk[3].data_ptr(), pk[4].data_ptr(), pk[5].data_ptr()
+                    a.own_src, a.own_rows, a.own_seg, a.n_own_rows = pk[6].data_ptr(), pk[7].data_ptr(), pk[8].data_ptr(), n_own
+                    a.slave_entities, a.n_slave_entities = d_slaves.data_ptr(), d_slaves.numel()
+                    keep += [pk, d_slaves]
             return a, keep
     # auto: row blocks for cheap integrands (few quadrature points), the hash kernel otherwise
     nq = integ.kernel.qwts.size if integ.itype == "cell" else integ.kernel.fqwts.size

@@ -613,6 +613,88 @@ __global__ void __launch_bounds__(VCUBE_THREADS) vector_cube_kernel(mpcx_vector_
       __hip_atomic_fetch_add(a.b + d, s_val[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
+
+// Owner-computes variant (mpcx_vector_args_t::own_lmap != NULL with MPCX_ALG_CUBE): every cluster is evaluated by the
+// row block that holds its local vertex 0; the LDS copy of the block holds its own rows followed by its halo (vertices
+// of its clusters that other blocks own), the position of every (cluster, local vertex) comes from own_lmap (slave
+// flag in bit 28: skipped here, vector_mpc_kernel moves those rows to their masters).  No hash table, no device
+// atomics: b receives every row once from its owner plus the halo sums through vector_spill_reduce_kernel, in a
+// fixed order -- the result is bitwise reproducible up to the order of the LDS adds inside a block.
+constexpr int VCUBE_OWN_THREADS = 256;
+
+template <int FN>
+__global__ void __launch_bounds__(VCUBE_OWN_THREADS) vector_cube_own_kernel(mpcx_vector_args_t a)
+{
+  using Op = ElementOp<3, 1, 1, 1, 1, MPCX_FORM_SOURCE, FN>;
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* s_b = reinterpret_cast<double*>(smem);
+  const int NT = blockDim.x;
+  const int nb = a.plan.num_blocks;
+  const int per = (nb + 7) >> 3;
+  const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int tid = threadIdx.x;
+  const int r0 = b < nb ? a.plan.block_row0[b] : 0, r1 = b < nb ? a.plan.block_row0[b + 1] : 0;
+  const int64_t h0 = b < nb ? a.own_hoff[b] : 0, h1 = b < nb ? a.own_hoff[b + 1] : 0;
+  const int nown = r1 - r0, nhalo = int(h1 - h0);
+  for (int i = tid; i < nown + nhalo; i += NT)
+    s_b[i] = 0.0;
+  fastmath_init_lds(); // ends in a barrier
+  if (b >= nb)
+    return;
+  const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  const int32_t* __restrict__ ents = a.plan.block_ents;
+  for (int64_t t = e0 + tid; t < e1; t += NT)
+  {
+    const int64_t c = ents[t];
+    int32_t v[8];
+    {
+      const uint4* p = reinterpret_cast<const uint4*>(a.cube_verts + c * 8);
+      const uint4 w0 = p[0], w1 = p[1];
+      v[0] = w0.x, v[1] = w0.y, v[2] = w0.z, v[3] = w0.w, v[4] = w1.x, v[5] = w1.y, v[6] = w1.z, v[7] = w1.w;
+    }
+    double X[8][3];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        X[i][k] = a.x[3 * int64_t(v[i]) + k];
+    double be8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      be8[i] = 0.0;
+#pragma unroll
+    for (int tet = 0; tet < 6; ++tet)
+    {
+      double cd[12];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          cd[3 * i + k] = X[fan_vertex(tet, i)][k];
+      double be[4];
+      Op::tabulate(be, nullptr, a.constants, cd, 0, a.kernel);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        be8[fan_vertex(tet, i)] += be[i];
+    }
+    // LDS positions of the eight vertices (read after the quadrature: eight registers less across it)
+    int32_t w[8];
+    {
+      const uint4* p = reinterpret_cast<const uint4*>(a.own_lmap + c * 8);
+      const uint4 w0 = p[0], w1 = p[1];
+      w[0] = w0.x, w[1] = w0.y, w[2] = w0.z, w[3] = w0.w, w[4] = w1.x, w[5] = w1.y, w[6] = w1.z, w[7] = w1.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (!(w[i] >> MASK_SHIFT))
+        __hip_atomic_fetch_add(s_b + (w[i] & DOF_MASK), be8[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __syncthreads();
+  for (int i = tid; i < nown; i += NT)
+    a.b[r0 + i] += s_b[i];
+  for (int i = tid; i < nhalo; i += NT)
+    a.own_spill[h0 + i] = s_b[nown + i];
+}
 } // namespace
 
 int launch_matrix_cubes(const mpcx_matrix_args_t& a)
@@ -661,8 +743,38 @@ int launch_vector_cubes(const mpcx_vector_args_t& a)
   }
   if (a.n_cubes == 0)
     return 0;
-  const dim3 grid(grid_for(a.n_cubes, VCUBE_THREADS));
   hipStream_t st = static_cast<hipStream_t>(a.stream);
+  if (a.own_lmap)
+  {
+    if (a.plan.num_blocks <= 0 || !a.own_hoff || !a.own_spill || !a.own_seg || (a.n_own_rows > 0 && (!a.own_rows || !a.own_src)))
+    {
+      mpcx_set_error("mpcx_assemble_vector: incomplete owner-computes plan for the cluster algorithm");
+      return -5;
+    }
+    const size_t lds = size_t(a.plan.max_rows) * 8;
+    if (lds > 96 * 1024)
+    {
+      mpcx_set_error("mpcx_assemble_vector: cluster owner plan exceeds the LDS budget");
+      return -4;
+    }
+    const unsigned g = 8u * unsigned((a.plan.num_blocks + 7) / 8);
+    auto go = [&](auto kernel) -> int
+    {
+      if (int rc = check(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             int(lds)),
+                         "hipFuncSetAttribute"))
+        return rc;
+      hipLaunchKernelGGL(kernel, dim3(g), dim3(VCUBE_OWN_THREADS), lds, st, a);
+      return check(hipGetLastError(), "vector cluster owner kernel launch");
+    };
+    if (int rc = k.fn_id == 1 ? go(vector_cube_own_kernel<1>) : go(vector_cube_own_kernel<-1>))
+      return rc;
+    if (a.n_own_rows > 0)
+      if (int rc = launch_vector_spill_reduce(a, 1))
+        return rc;
+    return launch_vector_slave_rows(a); // rows of slave dofs: to their masters (cpp/assemble_vector.h:35-69)
+  }
+  const dim3 grid(grid_for(a.n_cubes, VCUBE_THREADS));
   if (k.fn_id == 1)
     hipLaunchKernelGGL(vector_cube_kernel<1>, grid, dim3(VCUBE_THREADS), 0, st, a);
   else

@@ -16,4 +16,6 @@ int launch_vector_ufcx(const mpcx_vector_args_t& a);
 int launch_lifting_ufcx(const mpcx_lifting_args_t& a);
 // second half of the owner-computes vector path (mpcx_kernels.hip), shared with the imported kernels
 int launch_vector_spill_reduce(const mpcx_vector_args_t& a, int bs);
+// slave rows of a.slave_entities through the built-in operator of a.kernel (vector_mpc_kernel, mpcx_kernels.hip)
+int launch_vector_slave_rows(const mpcx_vector_args_t& a);
 } // namespace mpcx

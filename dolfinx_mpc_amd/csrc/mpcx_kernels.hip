@@ -1948,6 +1948,24 @@ int launch_vector(const mpcx_vector_args_t& a)
 }
 
 template <class Op>
+int launch_slave_rows(const mpcx_vector_args_t& a)
+{
+  if (a.n_slave_entities <= 0)
+    return 0;
+  hipLaunchKernelGGL(vector_mpc_kernel<Op>, dim3(grid_for(a.n_slave_entities, 64)), dim3(64), 0,
+                     static_cast<hipStream_t>(a.stream), a);
+  return check(hipGetLastError(), "vector mpc kernel launch");
+}
+
+// the cluster algorithm covers scalar P1 sources on tetrahedra only
+int launch_vector_slave_rows(const mpcx_vector_args_t& a)
+{
+  if (a.kernel.fn_id == 1)
+    return launch_slave_rows<ElementOp<3, 1, 1, 1, 1, MPCX_FORM_SOURCE, 1>>(a);
+  return launch_slave_rows<ElementOp<3, 1, 1, 1, 1, MPCX_FORM_SOURCE>>(a);
+}
+
+template <class Op>
 int launch_lifting(const mpcx_lifting_args_t& a)
 {
   if (a.nd0 != Op::ND0 || a.nd1 != Op::ND1 || a.bs0 != Op::BS0 || a.bs1 != Op::BS1 || a.nv != Op::NV)

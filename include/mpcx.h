@@ -331,7 +331,10 @@ typedef struct
   int64_t n_slave_entities;
   /* MPCX_ALG_CUBE: vertex (= dof) ids of the clusters, DEVICE [n_cubes][8], local vertex b of a cluster has
    * bit0 = x, bit1 = y, bit2 = z of the cube corner; its six tets are (0,1,3,7) (0,1,7,5) (0,5,7,4) (0,3,2,7)
-   * (0,6,4,7) (0,2,6,7).  entities / n_entities are ignored. */
+   * (0,6,4,7) (0,2,6,7).  entities / n_entities are ignored.  With own_lmap != NULL (owner-computes, see below:
+   * plan.block_ents = the clusters a block owns, own_lmap [n_cubes][8], bs = 1) there is no hash table and no device
+   * atomic; slave rows are then skipped (flag in own_lmap) and sent to their masters from slave_entities (CELL
+   * indices of the clusters' cells that hold a slave). */
   const int32_t* cube_verts;
   int64_t n_cubes;
   /* MPCX_ALG_ROWBLOCK, owner-computes variant (own_lmap != NULL): plan.block_ents lists every entity ONCE, in the

@@ -239,6 +239,34 @@ def test_small_cases_vector_kernel_variants(oracle, make, env, monkeypatch):
             _close(out[k], ref[k], RTOL_B, f"{case.name} {k} [{env}]")
 
 
+@pytest.mark.parametrize("env", ["MPCX_VCUBE_OWNER=0", "MPCX_VCUBE_OWNER=1", "MPCX_VCUBE_ROWS=256", "MPCX_CLUSTER_DETECT=consecutive"])
+@pytest.mark.parametrize("n,reorder,bc", [(4, None, 0.0), (6, (2, 2, 2), 2.3), (9, (4, 4, 4), 0.0)])
+def test_cluster_vector_kernel_variants(oracle, n, reorder, bc, env, monkeypatch):
+    """the P1 source through the cell-cluster kernels (algorithm "auto"): owner-computes row blocks over the clusters
+    (default: no hash table, no device atomics) with large and small blocks, the LDS-hash kernel
+    (MPCX_VCUBE_OWNER=0), and the generator-order cluster detector; periodic slaves and lifting included"""
+    monkeypatch.setenv(*env.split("="))
+    case = case_cube_periodic(n, 1, bc, reorder=reorder)
+    ref = oracle_outputs(oracle, case)
+    out = product_outputs(case, algorithm=None)
+    for k in ("b", "b_lifted"):
+        _close(out[k], ref[k], RTOL_B, f"{case.name} {k} [{env}]")
+    _close(out["A"].data, ref["A"].data, RTOL_A, f"{case.name} A [{env}]")
+
+
+def test_cluster_vector_is_reproducible_without_device_atomics(oracle):
+    """owner-computes cluster vector: every row of b gets its value from ONE workgroup (LDS adds) plus the halo sums
+    gathered in a fixed order -- repeated assemblies agree to the last bits up to the order of the adds inside a
+    block (<= 4 ulp of the largest entry; the hash kernel's device atomics are only bounded by the addend count)"""
+    import dolfinx_mpc_amd as dm
+
+    case = case_cube_periodic(12, 1, 0.0, reorder=(4, 4, 4))
+    mpc = product_mpc(case)
+    runs = [dm.assemble_vector(case.L, mpc).numpy().copy() for _ in range(5)]
+    spread = np.max(np.abs(np.array(runs) - runs[0]))
+    assert spread <= 4 * np.finfo(float).eps * np.abs(runs[0]).max()
+
+
 def test_reproducibility_statement(oracle):
     """What repeated assembly of the same system guarantees (determinism):
     * pattern, plans and the master contributions (one thread per target position, fixed tuple order)
