@@ -141,8 +141,8 @@ def _owner_plan_from_rows(mrow, V, rows: int):
     return (plan, t, int(urows.numel()))
 
 
-# own rows per block of the owner-computes cluster vector kernel (4096 rows + halo: two 256-thread workgroups per CU)
-VCUBE_OWNER_ROWS = int(os.environ.get("MPCX_VCUBE_ROWS", 4096))
+# own rows per block of the owner-computes cluster vector kernel (config 2, kernel ms: 1024 rows 2.73, 2048 2.75, 4096 2.81, 8192 4.40)
+VCUBE_OWNER_ROWS = int(os.environ.get("MPCX_VCUBE_ROWS", 2048))
 
 
 def _vector_cube_owner_plan(mesh, V, d_verts, constraint, left: np.ndarray, slave_ents_h: np.ndarray):

@@ -15,6 +15,7 @@
 #include "mpcx_elements.hpp"
 #include "mpcx_internal.h"
 
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <string>
 
@@ -712,12 +713,21 @@ int launch_matrix_cubes(const mpcx_matrix_args_t& a)
     mpcx_set_error("mpcx_assemble_matrix: the cluster algorithm needs records (mpcx_cube_records) and a row-block plan");
     return -3;
   }
-  const size_t lds = size_t(a.plan.max_nnz) * 8 + size_t(a.plan.max_rows) * 4;
+  size_t lds = size_t(a.plan.max_nnz) * 8 + size_t(a.plan.max_rows) * 4;
   if (lds > 160 * 1024)
   {
     mpcx_set_error("mpcx_assemble_matrix: row-block plan exceeds 160 KiB of LDS");
     return -4;
   }
+  // occupancy shaping (experiments / co-scheduling with the vector kernel on a second stream): a workgroup asks for at
+  // least this much LDS, e.g. 90000 -> one workgroup per CU
+  static const size_t lds_floor = []
+  {
+    const char* e = std::getenv("MPCX_CUBE_LDS_FLOOR");
+    return e ? size_t(std::atol(e)) : size_t(0);
+  }();
+  if (lds_floor > lds && lds_floor <= 160 * 1024)
+    lds = lds_floor;
   if (int rc = check(hipFuncSetAttribute(reinterpret_cast<const void*>(matrix_cube_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)),
                      "hipFuncSetAttribute"))
@@ -751,12 +761,19 @@ int launch_vector_cubes(const mpcx_vector_args_t& a)
       mpcx_set_error("mpcx_assemble_vector: incomplete owner-computes plan for the cluster algorithm");
       return -5;
     }
-    const size_t lds = size_t(a.plan.max_rows) * 8;
+    size_t lds = size_t(a.plan.max_rows) * 8;
     if (lds > 96 * 1024)
     {
       mpcx_set_error("mpcx_assemble_vector: cluster owner plan exceeds the LDS budget");
       return -4;
     }
+    static const size_t lds_floor = []
+    {
+      const char* e = std::getenv("MPCX_VCUBE_LDS_FLOOR");
+      return e ? size_t(std::atol(e)) : size_t(0);
+    }();
+    if (lds_floor > lds && lds_floor <= 160 * 1024)
+      lds = lds_floor;
     const unsigned g = 8u * unsigned((a.plan.num_blocks + 7) / 8);
     auto go = [&](auto kernel) -> int
     {
