@@ -210,6 +210,14 @@ EXPORTS = [
     "mpcx_homogenize",
     "mpcx_mpc_finalize",
     "mpcx_cell_to_slaves",
+    "mpcx_mpc_finalize_device",
+    "mpcx_cell_to_slaves_device",
+    "mpcx_scan_exclusive_i32_i64",
+    "mpcx_scan_exclusive_i32",
+    "mpcx_sort_pairs_i64_i32",
+    "mpcx_sort_pairs_i64_i64",
+    "mpcx_run_heads",
+    "mpcx_run_fill",
     "mpcx_pattern_build",
     "mpcx_pattern_nnz",
     "mpcx_pattern_nrows",
@@ -287,6 +295,23 @@ def lib() -> C.CDLL:
     L.mpcx_mpc_finalize.restype = C.c_int
     L.mpcx_cell_to_slaves.argtypes = [i64, i32, i32, vp, vp, vp, vp]
     L.mpcx_cell_to_slaves.restype = i64
+    szp = C.POINTER(C.c_size_t)
+    L.mpcx_mpc_finalize_device.argtypes = [i32, i32, i32] + [vp] * 14 + [vp, szp, vp]
+    L.mpcx_mpc_finalize_device.restype = C.c_int
+    L.mpcx_cell_to_slaves_device.argtypes = [i64, i32, i32, vp, vp, vp, vp, vp, vp]
+    L.mpcx_cell_to_slaves_device.restype = C.c_int
+    L.mpcx_scan_exclusive_i32_i64.argtypes = [vp, i64, vp, vp, szp, vp]
+    L.mpcx_scan_exclusive_i32_i64.restype = C.c_int
+    L.mpcx_scan_exclusive_i32.argtypes = [vp, i64, vp, vp, szp, vp]
+    L.mpcx_scan_exclusive_i32.restype = C.c_int
+    L.mpcx_sort_pairs_i64_i32.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, szp, vp]
+    L.mpcx_sort_pairs_i64_i32.restype = C.c_int
+    L.mpcx_sort_pairs_i64_i64.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, szp, vp]
+    L.mpcx_sort_pairs_i64_i64.restype = C.c_int
+    L.mpcx_run_heads.argtypes = [vp, i64, vp, vp]
+    L.mpcx_run_heads.restype = C.c_int
+    L.mpcx_run_fill.argtypes = [vp, vp, vp, i64, vp, vp, vp]
+    L.mpcx_run_fill.restype = C.c_int
     L.mpcx_pattern_build.argtypes = [i64, vp, i32, i32, i32, vp, i32, i32, i32] + [vp] * 8 + [i32]
     L.mpcx_pattern_build.restype = vp
     L.mpcx_pattern_nnz.argtypes = [vp]

@@ -72,11 +72,8 @@ def _pattern_on_device(V0, V1, mpc0, mpc1, keep_on_device: bool = False):
     nb0 = V0.num_dofs // bs0
 
     def dev_mpc(m):
-        key = ("pattern_dev", str(dev))
-        if key not in m._cache:
-            m._cache[key] = tuple(D._to_dev(a, dev) for a in (m.cell_to_slaves.offsets, m.cell_to_slaves.array,
-                                                               m.masters.offsets, m.masters.array))
-        return m._cache[key]
+        t = m.device_tensors()  # resident since finalize() when it ran on the device
+        return (t["c2s_off"], t["c2s"], t["moff"], t["masters"])
 
     c0, c1 = dev_mpc(mpc0), dev_mpc(mpc1)
     counter = torch.zeros(nb0, dtype=torch.int32, device=dev)
@@ -187,16 +184,21 @@ def create_matrix(form: Form, mpc0: MultiPointConstraint, mpc1: Optional[MultiPo
 def _slave_entities(form: Form, i: int, mpc0, mpc1):
     """entity indices of integral i whose cell holds a slave of mpc0 or mpc1."""
     def build():
+        import torch
+
         integ = form.integrals[i]
-        cells = integ.cells
-        # cells 0..n-1 in order (the usual domain): no gather through the entity list
-        ident = D.integral_device(form, i)["entities_ptr"] is None
-        has = np.diff(mpc0.cell_to_slaves.offsets) > 0
+        idv = D.integral_device(form, i)
+        off0 = mpc0.device_tensors()["c2s_off"]
+        has = (off0[1:] - off0[:-1]) > 0  # per cell, on the device (100 M cells at config 2: no host pass, no download)
         if mpc1 is not mpc0:
-            has = has | (np.diff(mpc1.cell_to_slaves.offsets) > 0)
-        has = has[: integ.num_entities] if ident else has[cells]
-        idx = np.flatnonzero(has).astype(np.int32)
-        return (idx, D._to_dev(idx, _native.require_gpu()))
+            off1 = mpc1.device_tensors()["c2s_off"]
+            has = has | ((off1[1:] - off1[:-1]) > 0)
+        if idv["entities"] is None:  # cells 0..n-1 in order (the usual domain): no gather through the entity list
+            has = has[: integ.num_entities]
+        else:
+            has = has[idv["entities"].view(integ.num_entities, integ.estride)[:, 0].long()]
+        idx = torch.nonzero(has).reshape(-1).to(torch.int32).contiguous()
+        return (idx.cpu().numpy(), idx)
 
     return D.cached(form._device, "slave_ents", (mpc0, mpc1), i, build)
 

@@ -156,8 +156,10 @@ def mesh_clusters_device(mesh, ncells: int):
             return D._to_dev(v, dev), left
         keys = torch.empty(n, dtype=torch.int64, device=dev)
         _native.check(L.mpcx_cluster_keys(md["x"].data_ptr(), dm.data_ptr(), n, keys.data_ptr(), st), "mpcx_cluster_keys")
-        keys, order = torch.sort(keys, stable=True)
-        order = order.to(torch.int32)
+        from . import _prims
+
+        # stable radix sort on the key bits in use (rocPRIM behind the C ABI): vmin in the high word, vmax in the low one
+        keys, order = _prims.sort_pairs(keys, torch.arange(n, dtype=torch.int32, device=dev), 32 + int(mesh.num_nodes).bit_length())
         verts = torch.empty((n, 8), dtype=torch.int32, device=dev)
         ok = torch.empty(n, dtype=torch.int8, device=dev)
         in_fan = torch.zeros(n, dtype=torch.int8, device=dev)

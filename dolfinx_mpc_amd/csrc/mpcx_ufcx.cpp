@@ -705,12 +705,12 @@ extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
   // (FFCx emits C99: `restrict`, plain functions -- force_cuda_host_device makes them callable from kernels),
   // then the assembly kernels
   std::string hdr(MPCX_H_TEXT);
-  const std::string inc = "#include <stdint.h>";
-  if (auto p = hdr.find(inc); p != std::string::npos)
-    hdr.replace(p, inc.size(), "");
+  for (const std::string inc : {"#include <stdint.h>", "#include <stddef.h>"})
+    if (auto p = hdr.find(inc); p != std::string::npos)
+      hdr.replace(p, inc.size(), "");
   std::string src = "typedef signed char int8_t;\ntypedef unsigned char uint8_t;\ntypedef unsigned short uint16_t;\n"
                     "typedef int int32_t;\ntypedef unsigned int uint32_t;\ntypedef long long int64_t;\n"
-                    "typedef unsigned long long uint64_t;\n#define restrict __restrict__\n";
+                    "typedef unsigned long long uint64_t;\ntypedef __SIZE_TYPE__ size_t;\n#define restrict __restrict__\n";
   src += hdr;
   // the user's text: #include lines are dropped (hipRTC supplies the fixed-width types above and the math functions
   // as built-ins; FFCx output includes <math.h>, <stdint.h>, <ufcx.h> ...), every function it defines becomes a

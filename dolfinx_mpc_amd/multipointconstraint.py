@@ -90,22 +90,47 @@ class MultiPointConstraint:
         self._already_finalized()
         self.add_constraint(V, mpc_data.slaves, mpc_data.masters, mpc_data.coeffs, mpc_data.owners, mpc_data.offsets)
 
-    def finalize(self) -> None:
-        """Finalize the constraint (python/src/dolfinx_mpc/multipointconstraint.py:169-223)."""
+    def finalize(self, where: Optional[str] = None) -> None:
+        """Finalize the constraint (python/src/dolfinx_mpc/multipointconstraint.py:169-223): is_slave, the sorted
+        slave list, the slave -> masters / coefficients / owners adjacency over all local dofs
+        (cpp/MultiPointConstraint.h:36-126) and cell -> slaves (cpp/mpc_helpers.h:19-94).
+
+        ``where``: "device" (HIP kernels: mark -> scan -> fill; the arrays stay in HBM where the assembly kernels
+        read them and are downloaded only when a host accessor is used), "host" (the C++ routines) or None = env
+        MPCX_FINALIZE, default: device when a GPU is present.  Both give the same arrays."""
+        import os
+
         self._already_finalized()
-        L = _native.lib()
         V = self.V
         nd = V.num_dofs
         imap = V.dofmap.index_map
         nowned = imap.size_local * V.dofmap.index_map_bs
         ns = self._slaves.size
         nm = self._masters.size
-        slaves = np.ascontiguousarray(self._slaves, dtype=np.int32)
-        masters = np.ascontiguousarray(self._masters, dtype=np.int64)
-        coeffs = np.ascontiguousarray(self._coeffs, dtype=np.float64)
-        owners = np.ascontiguousarray(self._owners, dtype=np.int32)
-        offsets = np.ascontiguousarray(self._offsets, dtype=np.int32)
-        assert offsets.size == ns + 1 and offsets[-1] == nm and coeffs.size == nm and owners.size == nm
+        raw = dict(slaves=np.ascontiguousarray(self._slaves, dtype=np.int32),
+                   masters=np.ascontiguousarray(self._masters, dtype=np.int64),
+                   coeffs=np.ascontiguousarray(self._coeffs, dtype=np.float64),
+                   owners=np.ascontiguousarray(self._owners, dtype=np.int32),
+                   offsets=np.ascontiguousarray(self._offsets, dtype=np.int32))
+        assert raw["offsets"].size == ns + 1 and raw["offsets"][-1] == nm and raw["coeffs"].size == nm and raw["owners"].size == nm
+        if where is None:
+            where = os.environ.get("MPCX_FINALIZE")
+        if where is None:
+            import torch
+
+            where = "device" if torch.cuda.is_available() else "host"
+        self._host = {}  # host copies of the finalized arrays (filled by the host routine, or lazily from the device)
+        self._devt = None  # device tensors (filled by the device routine, or lazily from the host)
+        if not (where.lower() == "device" and self._finalize_device(nd, nowned, ns, nm, raw)):
+            self._finalize_host(nd, nowned, ns, nm, raw)
+        # single process: the extended function space is V itself
+        # (cpp/mpc_helpers.h:165-168)
+        self.finalized = True
+        del (self._slaves, self._masters, self._coeffs, self._owners, self._offsets)
+
+    def _finalize_host(self, nd, nowned, ns, nm, raw):
+        L = _native.lib()
+        V = self.V
         is_slave = np.zeros(nd, dtype=np.int8)
         sorted_slaves = np.zeros(ns, dtype=np.int32)
         nloc = C.c_int32(0)
@@ -114,18 +139,14 @@ class MultiPointConstraint:
         cout = np.zeros(nm, dtype=np.float64)
         oout = np.zeros(nm, dtype=np.int32)
         p = _native._ptr
-        rc = L.mpcx_mpc_finalize(nd, nowned, ns, p(slaves), p(masters), p(coeffs), p(owners), p(offsets),
-                                 p(is_slave), p(sorted_slaves), C.cast(C.byref(nloc), C.c_void_p), p(moff),
+        rc = L.mpcx_mpc_finalize(nd, nowned, ns, p(raw["slaves"]), p(raw["masters"]), p(raw["coeffs"]), p(raw["owners"]),
+                                 p(raw["offsets"]), p(is_slave), p(sorted_slaves), C.cast(C.byref(nloc), C.c_void_p), p(moff),
                                  p(mloc), p(cout), p(oout))
         _native.check(rc, "mpcx_mpc_finalize")
         # duplicates in the user's slave list collapse in the marker
         nuniq = int(is_slave.sum())
-        self._is_slave = is_slave
-        self._sorted_slaves = sorted_slaves[:nuniq].copy()
         self._num_local_slaves = int(nloc.value)
-        self._master_map = AdjacencyList(mloc, moff)
-        self._coeff_map = AdjacencyList(cout, moff)
-        self._owner_map = AdjacencyList(oout, moff)
+        self._num_slaves = nuniq
         # cell -> slaves (owned cells)
         dm = V.dofmap.list
         nc = dm.shape[0]
@@ -135,11 +156,87 @@ class MultiPointConstraint:
             _native.check(int(total), "mpcx_cell_to_slaves")
         c2s = np.zeros(int(total), dtype=np.int32)
         total = L.mpcx_cell_to_slaves(nc, dm.shape[1], V.dofmap.bs, p(dm), p(is_slave), p(c2s_off), p(c2s))
-        self._cell_to_slaves = AdjacencyList(c2s, c2s_off)
-        # single process: the extended function space is V itself
-        # (cpp/mpc_helpers.h:165-168)
-        self.finalized = True
-        del (self._slaves, self._masters, self._coeffs, self._owners, self._offsets)
+        self._host = dict(is_slave=is_slave, slaves=sorted_slaves[:nuniq].copy(), moff=moff, masters=mloc, coeffs=cout,
+                          owners=oout, c2s_off=c2s_off, c2s=c2s)
+
+    def _finalize_device(self, nd, nowned, ns, nm, raw) -> bool:
+        """the same on the device (include/mpcx.h mpcx_mpc_finalize_device / mpcx_cell_to_slaves_device); False if
+        the slave list holds a dof twice (the host routine's sequential semantics apply then)"""
+        import torch
+
+        from . import _device as D
+        from . import _prims
+
+        L = _native.lib()
+        V = self.V
+        dev = _native.require_gpu()
+        st = D.stream_ptr()
+        d = {k: D._to_dev(v, dev) for k, v in raw.items()}
+        t = dict(is_slave=torch.empty(nd, dtype=torch.int8, device=dev),
+                 slaves=torch.empty(max(ns, 1), dtype=torch.int32, device=dev),
+                 moff=torch.empty(nd + 1, dtype=torch.int32, device=dev),
+                 masters=torch.empty(max(nm, 1), dtype=torch.int32, device=dev),
+                 coeffs=torch.empty(max(nm, 1), dtype=torch.float64, device=dev),
+                 owners=torch.empty(max(nm, 1), dtype=torch.int32, device=dev))
+        nloc = torch.zeros(1, dtype=torch.int32, device=dev)
+        work = torch.empty(2 * nd + 2, dtype=torch.int32, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        args = (nd, nowned, ns, d["slaves"].data_ptr(), d["masters"].data_ptr(), d["coeffs"].data_ptr(), d["owners"].data_ptr(),
+                d["offsets"].data_ptr(), t["is_slave"].data_ptr(), t["slaves"].data_ptr(), nloc.data_ptr(), t["moff"].data_ptr(),
+                t["masters"].data_ptr(), t["coeffs"].data_ptr(), t["owners"].data_ptr(), work.data_ptr(), flag.data_ptr())
+        temp, nb = _prims._workspace(lambda tp, n_: L.mpcx_mpc_finalize_device(*args, tp, n_, st), dev)
+        _native.check(L.mpcx_mpc_finalize_device(*args, temp.data_ptr(), C.byref(nb), st), "mpcx_mpc_finalize_device")
+        f = int(flag.item())
+        if f & 1:
+            raise RuntimeError("mpcx_mpc_finalize failed (-1): mpcx_mpc_finalize: slave index out of range")
+        if f & 2:
+            raise RuntimeError("mpcx_mpc_finalize failed (-2): mpcx_mpc_finalize: master index out of range (single-process "
+                               "backend: global master index must equal a local dof)")
+        if f & 4:
+            return False
+        nuniq = int(work[2 * nd].item())  # total of the slave-marker scan
+        self._num_slaves = nuniq
+        self._num_local_slaves = int(nloc.item())
+        t["slaves"] = t["slaves"][:nuniq].contiguous() if nuniq else torch.zeros(0, dtype=torch.int32, device=dev)
+        del work, temp
+        # cell -> slaves over the device-resident dofmap (the one the assembly kernels read)
+        dm = D.space_device(V)["dofmap"]
+        nc, ndc = V.dofmap.list.shape
+        if ndc * V.dofmap.bs > 256:
+            raise RuntimeError("mpcx_cell_to_slaves: element too large")
+        counts = torch.empty(max(nc, 1), dtype=torch.int32, device=dev)
+        _native.check(L.mpcx_cell_to_slaves_device(nc, ndc, V.dofmap.bs, dm.data_ptr(), t["is_slave"].data_ptr(),
+                                                   counts.data_ptr(), None, None, st), "mpcx_cell_to_slaves_device")
+        c2s_off = _prims.scan_i32(counts[:nc])
+        total = int(c2s_off[-1].item())
+        c2s = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+        if total:
+            _native.check(L.mpcx_cell_to_slaves_device(nc, ndc, V.dofmap.bs, dm.data_ptr(), t["is_slave"].data_ptr(),
+                                                       counts.data_ptr(), c2s_off.data_ptr(), c2s.data_ptr(), st),
+                          "mpcx_cell_to_slaves_device")
+        t["c2s_off"], t["c2s"] = c2s_off, c2s[:total]
+        t["masters"], t["coeffs"], t["owners"] = t["masters"][:nm], t["coeffs"][:nm], t["owners"][:nm]
+        self._devt = t
+        return True
+
+    def _h(self, name: str) -> np.ndarray:
+        """host copy of a finalized array (downloaded from the device on first use)"""
+        self._not_finalized()
+        if name not in self._host:
+            self._host[name] = self._devt[name].cpu().numpy()
+        return self._host[name]
+
+    def device_tensors(self) -> dict:
+        """the finalized arrays as device tensors: is_slave int8 [ndofs], slaves int32 (sorted), moff int32 [ndofs + 1],
+        masters int32, coeffs float64, owners int32, c2s_off int32 [ncells + 1], c2s int32 (uploaded on first use when
+        the host routine finalized)"""
+        self._not_finalized()
+        if self._devt is None:
+            from . import _device as D
+
+            dev = _native.require_gpu()
+            self._devt = {k: D._to_dev(v, dev) for k, v in self._host.items()}
+        return self._devt
 
     # -- convenience builders (structured / matching meshes only) --------------
     def create_periodic_constraint_geometrical(
@@ -368,27 +465,28 @@ class MultiPointConstraint:
     # -- accessors (python/src/dolfinx_mpc/multipointconstraint.py:503-584) ----
     @property
     def is_slave(self) -> np.ndarray:
-        self._not_finalized()
-        return self._is_slave
+        return self._h("is_slave")
 
     @property
     def slaves(self) -> np.ndarray:
+        return self._h("slaves")
+
+    @property
+    def num_slaves(self) -> int:
+        """number of distinct slave dofs (``slaves.size`` without a download)"""
         self._not_finalized()
-        return self._sorted_slaves
+        return self._num_slaves
 
     @property
     def masters(self) -> AdjacencyList:
-        self._not_finalized()
-        return self._master_map
+        return AdjacencyList(self._h("masters"), self._h("moff"))
 
     def coefficients(self):
-        self._not_finalized()
-        return self._coeff_map.array, self._coeff_map.offsets
+        return self._h("coeffs"), self._h("moff")
 
     @property
     def owners(self) -> AdjacencyList:
-        self._not_finalized()
-        return self._owner_map
+        return AdjacencyList(self._h("owners"), self._h("moff"))
 
     @property
     def num_local_slaves(self) -> int:
@@ -397,8 +495,7 @@ class MultiPointConstraint:
 
     @property
     def cell_to_slaves(self) -> AdjacencyList:
-        self._not_finalized()
-        return self._cell_to_slaves
+        return AdjacencyList(self._h("c2s"), self._h("c2s_off"))
 
     @property
     def function_space(self) -> FunctionSpace:
@@ -410,16 +507,7 @@ class MultiPointConstraint:
         """(MpcT struct, keep-alive tensors, slaves tensor) on the current HIP device."""
         self._not_finalized()
         if self._dev is None:
-            import torch
-
-            dev = _native.require_gpu()
-            t = {
-                "is_slave": torch.from_numpy(self._is_slave).to(dev),
-                "moff": torch.from_numpy(self._master_map.offsets).to(dev),
-                "masters": torch.from_numpy(self._master_map.array).to(dev),
-                "coeffs": torch.from_numpy(self._coeff_map.array).to(dev),
-                "slaves": torch.from_numpy(self._sorted_slaves).to(dev),
-            }
+            t = self.device_tensors()
             s = _native.MpcT(t["is_slave"].data_ptr(), t["moff"].data_ptr(), t["masters"].data_ptr(),
                              t["coeffs"].data_ptr())
             self._dev = (s, t)

@@ -16,6 +16,7 @@
 #ifndef MPCX_H
 #define MPCX_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -406,6 +407,37 @@ int mpcx_mpc_finalize(int32_t num_dofs, int32_t num_owned_dofs, int32_t num_slav
                       int32_t* sorted_slaves, int32_t* num_local_slaves,
                       int32_t* masters_offsets, int32_t* masters_out,
                       double* coeffs_out, int32_t* owners_out);
+
+/* The same two set-up steps on the DEVICE (all pointers DEVICE unless said otherwise).
+ * mpcx_mpc_finalize_device: outputs as mpcx_mpc_finalize; sorted_slaves must hold num_slaves entries, the number of
+ * distinct slaves is masters-independent and comes back through the compaction (read num_local_slaves / count
+ * is_slave); work: int32 [2 * num_dofs + 1]; *flag (zeroed by the caller): bit 0 slave index out of range, bit 1
+ * master index out of range, bit 2 a dof listed twice as a slave (use the host routine).  temp / temp_bytes: rocPRIM
+ * workspace, size query with temp == NULL (HOST pointer temp_bytes).
+ * mpcx_cell_to_slaves_device: two calls -- c2s == NULL: counts[c] = slaves of cell c; the caller scans counts into
+ * c2s_offsets (mpcx_scan_exclusive_i32) and calls again with c2s: each cell's slaves ascending by dof. */
+int mpcx_mpc_finalize_device(int32_t num_dofs, int32_t num_owned_dofs, int32_t num_slaves, const int32_t* slaves,
+                             const int64_t* masters, const double* coeffs, const int32_t* owners, const int32_t* offsets,
+                             int8_t* is_slave, int32_t* sorted_slaves, int32_t* num_local_slaves, int32_t* masters_offsets,
+                             int32_t* masters_out, double* coeffs_out, int32_t* owners_out, int32_t* work, int32_t* flag,
+                             void* temp, size_t* temp_bytes, void* stream);
+int mpcx_cell_to_slaves_device(int64_t num_cells, int32_t nd, int32_t bs, const int32_t* dofmap, const int8_t* is_slave,
+                               int32_t* counts, const int32_t* c2s_offsets, int32_t* c2s, void* stream);
+
+/* Device primitives of the set-up path (rocPRIM behind the C ABI, so that a caller without torch can build plans):
+ * exclusive scans (out has n + 1 entries, the last one is the total), stable LSD radix sort of (key, value) pairs on
+ * key bits [begin_bit, end_bit), run boundaries of a sorted key array (heads[i] = 1 at the first element of a run;
+ * with the exclusive scan of heads: run_keys[r], run_start[r], run_start[num_runs] = n).  Workspace: called with
+ * temp == NULL they only write the bytes they need to *temp_bytes (HOST pointer). */
+int mpcx_scan_exclusive_i32_i64(const int32_t* in, int64_t n, int64_t* out, void* temp, size_t* temp_bytes, void* stream);
+int mpcx_scan_exclusive_i32(const int32_t* in, int64_t n, int32_t* out, void* temp, size_t* temp_bytes, void* stream);
+int mpcx_sort_pairs_i64_i32(const int64_t* keys_in, int64_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n,
+                            int32_t begin_bit, int32_t end_bit, void* temp, size_t* temp_bytes, void* stream);
+int mpcx_sort_pairs_i64_i64(const int64_t* keys_in, int64_t* keys_out, const int64_t* vals_in, int64_t* vals_out, int64_t n,
+                            int32_t begin_bit, int32_t end_bit, void* temp, size_t* temp_bytes, void* stream);
+int mpcx_run_heads(const int64_t* sorted_keys, int64_t n, int32_t* heads, void* stream);
+int mpcx_run_fill(const int64_t* sorted_keys, const int32_t* heads, const int64_t* heads_scan, int64_t n, int64_t* run_keys,
+                  int64_t* run_start, void* stream);
 
 /* create_cell_to_dofs_map, cpp/mpc_helpers.h:19-94.  Call with c2s == NULL to
  * fill c2s_offsets[num_cells+1] and get the total; then again with c2s

@@ -267,6 +267,51 @@ def test_cluster_vector_is_reproducible_without_device_atomics(oracle):
     assert spread <= 4 * np.finfo(float).eps * np.abs(runs[0]).max()
 
 
+@pytest.mark.parametrize("make", CASES, ids=[f"case{i}" for i in range(len(CASES))])
+def test_finalize_on_device_equals_host_finalize(make):
+    """MultiPointConstraint.finalize on the device (mpcx_mpc_finalize_device: mark -> scan -> fill;
+    mpcx_cell_to_slaves_device) against the host routines (cpp/MultiPointConstraint.h:36-126,
+    cpp/mpc_helpers.h:19-94 restated in mpcx_host.cpp): every array bit for bit"""
+    import dolfinx_mpc_amd as dm
+
+    case = make()
+    out = {}
+    for where in ("host", "device"):
+        m = dm.MultiPointConstraint(case.V)
+        m.add_constraint(case.V, *case.raw)
+        m.finalize(where=where)
+        out[where] = m
+    h, d = out["host"], out["device"]
+    assert d._devt is not None and not d._host, "the device path must not have touched the host arrays yet"
+    assert h.num_local_slaves == d.num_local_slaves and h.num_slaves == d.num_slaves
+    for name in ("is_slave", "slaves"):
+        assert np.array_equal(getattr(h, name), getattr(d, name)), name
+    for name in ("masters", "owners", "cell_to_slaves"):
+        assert np.array_equal(getattr(h, name).offsets, getattr(d, name).offsets), name
+        assert np.array_equal(getattr(h, name).array, getattr(d, name).array), name
+    assert np.array_equal(h.coefficients()[0], d.coefficients()[0])
+
+
+def test_finalize_on_device_errors_and_duplicates():
+    """out-of-range indices raise like the host routine; a dof listed twice as a slave takes the host routine
+    (its sequential semantics cannot be reproduced in parallel)"""
+    import dolfinx_mpc_amd as dm
+
+    case = case_cube_periodic(3, 1, 0.0)
+    V = case.V
+    z = np.zeros(1, dtype=np.int32)
+    for slaves, masters, msg in (([V.num_dofs + 3], [0], "slave index out of range"), ([2], [V.num_dofs + 5], "master index out of range")):
+        m = dm.MultiPointConstraint(V)
+        m.add_constraint(V, np.array(slaves, dtype=np.int32), np.array(masters, dtype=np.int64), np.ones(1), z, np.array([0, 1], dtype=np.int32))
+        with pytest.raises(RuntimeError, match=msg):
+            m.finalize(where="device")
+    m = dm.MultiPointConstraint(V)
+    m.add_constraint(V, np.array([5, 5], dtype=np.int32), np.array([1, 2], dtype=np.int64), np.array([0.5, 0.25]),
+                     np.zeros(2, dtype=np.int32), np.array([0, 1, 2], dtype=np.int32))
+    m.finalize(where="device")
+    assert m._devt is None and m.num_slaves == 1  # fell back to the host routine
+
+
 def test_reproducibility_statement(oracle):
     """What repeated assembly of the same system guarantees (determinism):
     * pattern, plans and the master contributions (one thread per target position, fixed tuple order)
