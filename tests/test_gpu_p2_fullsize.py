@@ -86,3 +86,51 @@ def test_vector_entries_add_up_to_the_integral(problem):
         total += float((f * W[None, :]).sum(dim=1).mul(det).sum())
     got = float(b.array.sum())
     assert abs(got - total) <= 1e-11 * max(1.0, abs(total)), (got, total)
+
+
+def test_p2_matrix_properties_at_size(problem):
+    """BASELINE config 5's MATRIX at a size where the plans matter: matrix_rowblock_kernel<P2> against
+    the thread-per-entity atomic kernel on the same pattern, symmetry (x.Ay == y.Ax), identity rows for Dirichlet and
+    slave dofs, and zero row sums of the stiffness matrix away from the constrained dofs -- properties that do not
+    need an oracle run at this size"""
+    import torch
+
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import fem
+    from dolfinx_mpc_amd.la import MPCMatrix, Vector
+    from dolfinx_mpc_amd.problem import spmv
+
+    p = problem
+    V, mpc = p["V"], p["mpc"]
+    walls = fem.locate_dofs_geometrical(
+        V, lambda x: np.isclose(x[1], 0) | np.isclose(x[1], 1) | np.isclose(x[2], 0) | np.isclose(x[2], 1))
+    bc = fem.dirichletbc(0.0, walls, V)
+    a = fem.form_stiffness(V)
+    A = dm.assemble_matrix(a, mpc, bcs=[bc], algorithm="rowblock")
+    assert ("objcache", "rowblock") in A._plans, "the LDS row-block kernel was expected"
+    B = MPCMatrix(A.d_rowptr, A.d_cols, A.shape[1])  # same pattern, second value array
+    dm.assemble_matrix(a, mpc, bcs=[bc], A=B, algorithm="atomic")
+    amax = float(A.vals.abs().max())
+    assert amax > 0
+    assert float((A.vals - B.vals).abs().max()) <= 1e-12 * amax
+    del B
+    n = A.shape[0]
+    g = torch.Generator(device=A.device).manual_seed(7)
+    x, y = Vector(n), Vector(n)
+    x.array.copy_(torch.rand(n, generator=g, device=A.device, dtype=torch.float64) - 0.5)
+    y.array.copy_(torch.rand(n, generator=g, device=A.device, dtype=torch.float64) - 0.5)
+    Ax, Ay = spmv(A, x), spmv(A, y)
+    s1, s2 = float(torch.dot(x.array, Ay.array)), float(torch.dot(y.array, Ax.array))
+    assert abs(s1 - s2) <= 1e-11 * float(torch.linalg.vector_norm(x.array) * torch.linalg.vector_norm(Ay.array))
+    # Dirichlet and slave rows are identity rows (diagval = 1): (A x)[r] == x[r]
+    rows = torch.from_numpy(np.concatenate([bc.dof_indices()[0], mpc.slaves]).astype(np.int64)).to(A.device)
+    assert torch.equal(Ax.array[rows], x.array[rows])
+    # stiffness: constants lie in the kernel -- rows whose neighbours are all free sum to zero
+    one = Vector(n)
+    one.array.fill_(1.0)
+    r = spmv(A, one).array
+    X = torch.from_numpy(V.tabulate_dof_coordinates()).to(A.device)
+    h = 2.0 / N
+    inner = ((X[:, 0] > h) & (X[:, 0] < 1 - h) & (X[:, 1] > h) & (X[:, 1] < 1 - h) & (X[:, 2] > h) & (X[:, 2] < 1 - h))
+    assert int(inner.sum()) > 0.5 * n
+    assert float(r[inner].abs().max()) <= 1e-11 * amax
