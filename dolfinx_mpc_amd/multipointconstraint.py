@@ -48,6 +48,116 @@ class MPCData:
         self.offsets = np.asarray(offsets, dtype=np.int32)
 
 
+def _barycentric(mesh, cells, p):
+    """barycentric coordinates of points p[i] in cells[i] (affine simplices) and the cells' vertex coordinates"""
+    x = mesh.geometry.x
+    tdim = mesh.tdim
+    xv = x[mesh.geometry.dofmap[cells]]  # (n, tdim+1, 3)
+    J = np.transpose(xv[:, 1:, :] - xv[:, :1, :], (0, 2, 1))[:, :, :tdim]  # (n, 3, tdim)
+    rhs = p - xv[:, 0, :]
+    if tdim == 2:
+        J, rhs = J[:, :2, :], rhs[:, :2]
+    mu = np.linalg.solve(J, rhs[:, :, None])[:, :, 0]
+    lam = np.concatenate([1.0 - mu.sum(axis=1, keepdims=True), mu], axis=1)
+    return lam, xv
+
+
+def locate_points(V: FunctionSpace, pts: np.ndarray, cells: Optional[np.ndarray] = None, tol: float = 1e-10, k: int = 16):
+    """For every point the index of a cell (of ``cells``, default all owned cells) that contains it, or -1, and the
+    values of V's scalar basis functions of that cell at the point, (n, nd) in cell-dof order -- what the reference
+    gets from its bounding-box-tree collision search + ``evaluate_basis_functions`` (cpp/ContactConstraint.h:466-475,
+    cpp/PeriodicConstraint.h:139-150).  Candidates: the cells with the nearest centroids, then every cell for points
+    the shortlist missed.  Affine simplices; Lagrange P1 / P2 in barycentric form."""
+    from scipy.spatial import cKDTree
+
+    mesh = V.mesh
+    tdim = mesh.tdim
+    pts = np.asarray(pts, dtype=np.float64).reshape(-1, 3)
+    cand = np.arange(mesh.num_owned_cells, dtype=np.int64) if cells is None else np.unique(np.asarray(cells, dtype=np.int64))
+    found = np.full(pts.shape[0], -1, dtype=np.int64)
+    lam_found = np.zeros((pts.shape[0], tdim + 1))
+    if cand.size and pts.shape[0]:
+        cent = mesh.geometry.x[mesh.geometry.dofmap[cand]].mean(axis=1)
+        kk = int(min(k, cand.size))
+        _, near = cKDTree(cent).query(pts, k=kk)
+        near = near.reshape(pts.shape[0], kk)
+
+        def inside(lam, xv):
+            h = np.linalg.norm(xv[:, 1, :] - xv[:, 0, :], axis=1)
+            return lam.min(axis=1) >= -tol / np.maximum(h, 1e-300) - 1e-10
+
+        for col in range(kk):
+            todo = np.flatnonzero(found < 0)
+            if todo.size == 0:
+                break
+            cc = cand[near[todo, col]]
+            lam, xv = _barycentric(mesh, cc, pts[todo])
+            ok = inside(lam, xv)
+            found[todo[ok]] = cc[ok]
+            lam_found[todo[ok]] = lam[ok]
+        for i in np.flatnonzero(found < 0):  # points the nearest-centroid shortlist missed: try every candidate cell
+            lam, xv = _barycentric(mesh, cand, np.repeat(pts[i][None, :], cand.size, axis=0))
+            ok = np.flatnonzero(inside(lam, xv))
+            if ok.size:
+                found[i], lam_found[i] = cand[ok[0]], lam[ok[0]]
+    if V.degree == 1:
+        basis = lam_found
+    else:
+        from .mesh import TET_EDGES, TRI_EDGES
+
+        le = TET_EDGES if tdim == 3 else TRI_EDGES
+        basis = np.concatenate([lam_found * (2.0 * lam_found - 1.0), 4.0 * lam_found[:, le[:, 0]] * lam_found[:, le[:, 1]]], axis=1)
+    basis[found < 0] = 0.0
+    return found, basis
+
+
+def create_normal_approximation(V: FunctionSpace, meshtags, value: int):
+    """python/src/dolfinx_mpc/utils/mpc_utils.py:422-438 / cpp/utils.h:201-267: a Function in the (vector) space V
+    whose blocks in the closure of the facets tagged ``value`` hold the sum of the adjacent tagged facets' unit normals
+    (each aligned with the first one), divided by its squared length -- the reference divides by ``abs(acc)`` with
+    ``acc`` the sum of squares (cpp/utils.h:254-261); only the direction matters to the slip constraints."""
+    from .fem import Function
+    from .mesh import TET_EDGES, TET_FACETS, TRI_EDGES, TRI_FACETS
+
+    mesh = V.mesh
+    tdim = mesh.tdim
+    bs = V.dofmap.bs
+    nh = Function(V)
+    facets = meshtags.find(value)
+    if facets.shape[0] == 0:
+        return nh
+    lf = TET_FACETS if tdim == 3 else TRI_FACETS
+    le = TET_EDGES if tdim == 3 else TRI_EDGES
+    x = mesh.geometry.x
+    cells, loc = facets[:, 0].astype(np.int64), facets[:, 1].astype(np.int64)
+    fv = mesh.geometry.dofmap[cells][np.arange(cells.size)[:, None], lf[loc]]  # (nf, tdim) vertices of the facets
+    if tdim == 3:
+        nrm = np.cross(x[fv[:, 1]] - x[fv[:, 0]], x[fv[:, 2]] - x[fv[:, 0]])
+    else:
+        t = x[fv[:, 1]] - x[fv[:, 0]]
+        nrm = np.stack([t[:, 1], -t[:, 0], np.zeros(t.shape[0])], axis=1)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    acc = {}
+    nv = tdim + 1
+    for f in range(facets.shape[0]):
+        ldofs = list(lf[loc[f]])
+        if V.degree == 2:
+            ldofs += [nv + e for e in range(le.shape[0]) if le[e][0] in lf[loc[f]] and le[e][1] in lf[loc[f]]]
+        for b in V.dofmap.list[cells[f]][ldofs]:
+            b = int(b)
+            if b not in acc:
+                acc[b] = (nrm[f].copy(), nrm[f].copy())  # (first normal, running sum)
+            else:
+                n0, tot = acc[b]
+                d = float(n0 @ nrm[f])
+                tot += (d / abs(d) if d != 0.0 else 1.0) * nrm[f]
+    arr = nh.x.array
+    for b, (_, tot) in acc.items():
+        a2 = float(tot[:bs] @ tot[:bs])
+        arr[b * bs:(b + 1) * bs] = tot[:bs] / a2 if a2 > 1e-10 else tot[:bs]
+    return nh
+
+
 class MultiPointConstraint:
     """Hold data for multi point constraint relationships.
 
@@ -239,6 +349,67 @@ class MultiPointConstraint:
         return self._devt
 
     # -- convenience builders (structured / matching meshes only) --------------
+    def _periodic(self, V: FunctionSpace, blocks: np.ndarray, relation, bcs, scale: float, tol: float):
+        """u(x_i) = scale * u(relation(x_i)) for the dof blocks ``blocks`` (cpp/PeriodicConstraint.h:30-222, serial
+        branch): a slave block with any component under a Dirichlet condition is dropped as a whole
+        (cpp/utils.h:1459-1496 marks blocks, cpp/PeriodicConstraint.h:563-567 filters with it); the mapped point is
+        located in a cell and the slave is tied to that cell's dofs with the values of their basis functions there,
+        |scale * phi_j| > tol kept (:170-196).  Mapped points that coincide with a dof (matching meshes: one
+        basis function is 1, the others vanish) get that dof with coefficient ``scale`` exactly; points in no cell
+        are skipped (in serial the reference finds no collision for them either)."""
+        from scipy.spatial import cKDTree
+
+        if V is not self.V:
+            raise RuntimeError("The input space has to be a sub space (or the full space) of the MPC")
+        blocks = np.unique(np.asarray(blocks, dtype=np.int64))
+        if blocks.size == 0:
+            return
+        x = V.tabulate_dof_coordinates()
+        bs = V.dofmap.bs
+        is_bc = np.zeros(V.num_dofs, dtype=np.int8)
+        for bc in bcs or []:
+            if V.contains(bc.function_space):  # cpp/utils.h:1470-1476: only conditions living in V
+                bc.mark_dofs(is_bc)
+        blocks = blocks[~is_bc.reshape(-1, bs)[blocks].any(axis=1)]
+        if blocks.size == 0:
+            return
+        xm = np.ascontiguousarray(np.asarray(relation(x[blocks].T)).T, dtype=np.float64)
+        # dofs AT the mapped points (matching meshes): exact coefficient, no basis evaluation
+        lo, hi = xm.min(axis=0) - 1e-8, xm.max(axis=0) + 1e-8
+        cand = np.flatnonzero(np.all((x >= lo) & (x <= hi), axis=1))
+        mblk = np.full(blocks.size, -1, dtype=np.int64)
+        if cand.size:
+            dist, loc = cKDTree(x[cand]).query(xm)
+            hit = dist <= 1e-8
+            mblk[hit] = cand[loc[hit]]
+        # (a) matching dofs, vectorised: one master per slave component
+        hb, hm = blocks[mblk >= 0], mblk[mblk >= 0]
+        slaves = [(hb[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)]
+        masters = [(hm[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)]
+        coeffs = [np.full(hb.size * bs, scale, dtype=np.float64)]
+        counts = [np.ones(hb.size * bs, dtype=np.int64)]
+        # (b) the others: cell of the mapped point, basis values there
+        rest = np.flatnonzero(mblk < 0)
+        if rest.size:
+            cells, basis = locate_points(V, xm[rest], tol=max(float(tol), 1e-12))
+            for r, c, phi in zip(rest, cells, basis):
+                if c < 0:
+                    continue  # no collision: skipped
+                val = scale * phi
+                keep = np.abs(val) > tol
+                mb = V.dofmap.list[c][keep].astype(np.int64)
+                for k in range(bs):
+                    slaves.append(np.array([blocks[r] * bs + k]))
+                    masters.append(mb * bs + k)
+                    coeffs.append(val[keep])
+                    counts.append(np.array([mb.size]))
+        slaves, masters, coeffs = np.concatenate(slaves), np.concatenate(masters), np.concatenate(coeffs)
+        if slaves.size == 0:
+            return
+        offsets = np.concatenate([[0], np.cumsum(np.concatenate(counts))]).astype(np.int32)
+        self.add_constraint(V, slaves.astype(np.int32), masters.astype(np.int64), coeffs.astype(np.float64),
+                            np.zeros(masters.size, dtype=np.int32), offsets)
+
     def create_periodic_constraint_geometrical(
         self,
         V: FunctionSpace,
@@ -246,48 +417,82 @@ class MultiPointConstraint:
         relation: Callable[[np.ndarray], np.ndarray],
         bcs: Sequence[DirichletBC],
         scale: float = 1.0,
-        tol: float = 1e-8,
+        tol: float = 500 * np.finfo(np.float64).eps,
+        num_threads: Optional[int] = 1,
     ):
-        """u(x_i) = scale * u(relation(x_i)) for dofs with indicator(x_i)
-        (python/src/dolfinx_mpc/multipointconstraint.py:282-340).  The general
-        builder (cpp/PeriodicConstraint.h) does point location and basis
-        evaluation; this backend only handles meshes whose mapped slave nodes
-        coincide with master nodes (one master, coefficient ``scale``)."""
-        from scipy.spatial import cKDTree
-
-        assert V is self.V
+        """u(x_i) = scale * u(relation(x_i)) for all dofs with indicator(x_i)
+        (python/src/dolfinx_mpc/multipointconstraint.py:282-323, cpp/PeriodicConstraint.h:30-222 + :560-600)."""
+        if isinstance(scale, np.generic):
+            scale = scale.item()
         x = V.tabulate_dof_coordinates()
-        bs = V.dofmap.bs
         blocks = np.flatnonzero(np.asarray(indicator(x.T), dtype=bool))
+        self._periodic(V, blocks, relation, bcs, float(scale), float(tol))
+
+    def create_periodic_constraint_topological(
+        self,
+        V: FunctionSpace,
+        meshtag,
+        tag: int,
+        relation: Callable[[np.ndarray], np.ndarray],
+        bcs: Sequence[DirichletBC],
+        scale: float = 1.0,
+        tol: float = 500 * np.finfo(np.float64).eps,
+        num_threads: Optional[int] = 1,
+    ):
+        """periodic condition for all closure dofs of the entities of ``meshtag`` with value ``tag``
+        (python/src/dolfinx_mpc/multipointconstraint.py:225-281, cpp/PeriodicConstraint.h:480-530:
+        locate_dofs_topological, then the same construction as the geometrical variant)."""
+        from .fem import locate_dofs_topological
+
+        if isinstance(scale, np.generic):
+            scale = scale.item()
+        blocks = locate_dofs_topological(V, meshtag.dim, meshtag.find(tag))
+        self._periodic(V, blocks, relation, bcs, float(scale), float(tol))
+
+    def create_slip_constraint(self, space: FunctionSpace, facet_marker, v, bcs: Sequence[DirichletBC] = ()):
+        """u . v = 0 on the dofs in the closure of the facets ``facet_marker = (meshtags, marker)``, ``v`` a Function
+        in ``space`` holding the direction, usually the facet normal (python/src/dolfinx_mpc/multipointconstraint.py:
+        325-399, cpp/SlipConstraint.h:16-175): dof blocks touched by a Dirichlet condition are left out as a whole
+        (:95-101), slave = the component with the largest |v_i| of the block, masters = the other components of the
+        same block, c_i = -v_i / v_s (every one of them, no tolerance filter).
+
+        Older call shape kept: ``create_slip_constraint(V, blocks, normals, bcs)`` with explicit dof blocks and an
+        (n, bs) array of directions."""
+        from .fem import Function, locate_dofs_topological
+
+        if space is not self.V:
+            raise ValueError("Input space has to be a sub space of the MPC space")
+        V = self.V
+        bs = V.dofmap.bs
         is_bc = np.zeros(V.num_dofs, dtype=np.int8)
-        for bc in bcs:
-            if V.contains(bc.function_space):  # cpp/utils.h:1470-1476: only conditions living in V
+        for bc in bcs or []:
+            if V.contains(bc.function_space):
                 bc.mark_dofs(is_bc)
-        xm = np.asarray(relation(x[blocks].T)).T
-        if blocks.size == 0:
+        if isinstance(facet_marker, tuple) and len(facet_marker) == 2 and hasattr(facet_marker[0], "find"):
+            if not isinstance(v, Function) or v.function_space.dofmap.bs != bs:
+                raise ValueError("v has to be a Function in the (blocked) space of the constraint")
+            meshtags, marker = facet_marker
+            blocks = np.unique(locate_dofs_topological(V, meshtags.dim, meshtags.find(marker))).astype(np.int64)
+            blocks = blocks[~is_bc.reshape(-1, bs)[blocks].any(axis=1)]  # cpp/SlipConstraint.h:95-101 (blocks, cpp/utils.h:1459-1496)
+            normals = v.x._data.reshape(-1, bs)[blocks]
+        else:
+            blocks = np.asarray(facet_marker, dtype=np.int64)
+            normals = np.asarray(v, dtype=np.float64).reshape(blocks.size, -1)[:, :bs]
+            keep = ~is_bc.reshape(-1, bs)[blocks].any(axis=1)
+            blocks, normals = blocks[keep], normals[keep]
+        n = blocks.size
+        if n == 0:
             return
-        # only dofs inside the bounding box of the mapped points can be masters
-        lo, hi = xm.min(axis=0) - tol, xm.max(axis=0) + tol
-        cand = np.flatnonzero(np.all((x >= lo) & (x <= hi), axis=1))
-        if cand.size == 0:
-            raise NotImplementedError("no dof at the mapped slave coordinates (non-matching meshes are out of scope)")
-        dist, loc = cKDTree(x[cand]).query(xm)
-        mblk = cand[loc]
-        if blocks.size and dist.max() > tol:
-            raise NotImplementedError(
-                "periodic constraint on non-matching nodes needs basis evaluation at the mapped "
-                "point (cpp/PeriodicConstraint.h:170-222): out of scope of this backend"
-            )
-        slaves = (blocks[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)
-        masters = (mblk[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)
-        # a slave BLOCK with any component under a Dirichlet condition is dropped as a whole
-        # (cpp/utils.h:1459-1496 marks blocks, cpp/PeriodicConstraint.h:563-567 filters with it)
-        blk_bc = is_bc.reshape(-1, bs)[blocks].any(axis=1)
-        keep = np.repeat(~blk_bc, bs)
-        slaves, masters = slaves[keep], masters[keep]
-        n = slaves.size
-        self.add_constraint(V, slaves.astype(np.int32), masters.astype(np.int64), np.full(n, scale, dtype=np.float64),
-                            np.zeros(n, dtype=np.int32), np.arange(n + 1, dtype=np.int32))
+        sidx = np.argmax(np.abs(normals), axis=1)  # first maximum, like std::ranges::max_element
+        comp = np.arange(bs)[None, :].repeat(n, 0)
+        others = comp[comp != sidx[:, None]].reshape(n, bs - 1)
+        ns = normals[np.arange(n), sidx]
+        slaves = blocks * bs + sidx
+        masters = (blocks[:, None] * bs + others).reshape(-1)
+        coeffs = (-normals[np.arange(n)[:, None], others] / ns[:, None]).reshape(-1)
+        offsets = np.arange(n + 1, dtype=np.int32) * (bs - 1)
+        self.add_constraint(V, slaves.astype(np.int32), masters.astype(np.int64), coeffs.astype(np.float64),
+                            np.zeros(masters.size, dtype=np.int32), offsets)
 
     def create_general_constraint(self, slave_master_dict: Dict[bytes, Dict[bytes, float]],
                                   subspace_slave: Optional[int] = None, subspace_master: Optional[int] = None):
@@ -324,45 +529,11 @@ class MultiPointConstraint:
                             np.array(coeffs, dtype=np.float64), np.zeros(len(masters), dtype=np.int32),
                             np.array(offsets, dtype=np.int32))
 
-    def create_slip_constraint(self, V: FunctionSpace, blocks: np.ndarray, normals: np.ndarray,
-                               bcs: Sequence[DirichletBC] = ()):
-        """u.n = 0 on the given dof blocks (cpp/SlipConstraint.h:115-166): slave =
-        component with the largest |n_i|, masters = the other components of the
-        same block, c_i = -n_i / n_s (no tolerance filter on zero coefficients)."""
-        assert V is self.V
-        bs = V.dofmap.bs
-        is_bc = np.zeros(V.num_dofs, dtype=np.int8)
-        for bc in bcs:
-            bc.mark_dofs(is_bc)
-        slaves, masters, coeffs, offsets = [], [], [], [0]
-        for blk, n in zip(np.asarray(blocks), np.asarray(normals)):
-            s = int(np.argmax(np.abs(n[:bs])))
-            sd = blk * bs + s
-            if is_bc[sd]:
-                continue
-            slaves.append(sd)
-            for k in range(bs):
-                if k != s:
-                    masters.append(blk * bs + k)
-                    coeffs.append(-n[k] / n[s])
-            offsets.append(len(masters))
-        self.add_constraint(V, np.array(slaves, dtype=np.int32), np.array(masters, dtype=np.int64),
-                            np.array(coeffs, dtype=np.float64), np.zeros(len(masters), dtype=np.int32),
-                            np.array(offsets, dtype=np.int32))
-
-    def create_contact_inelastic_condition(self, meshtags, slave_marker: int, master_marker: int,
-                                           eps2: float = 1e-20, allow_missing_masters: bool = False,
-                                           num_threads: Optional[int] = 1):
-        """u_s = u_m between two sets of tagged facets whose surfaces coincide; the vertices need not
-        align (python/src/dolfinx_mpc/multipointconstraint.py:465-501, cpp/ContactConstraint.h:908-1174,
-        serial branch).  Every dof block in the closure of the slave facets is tied, per component, to
-        the dof blocks of the master-side cell it collides with, weighted by that cell's basis functions
-        at the slave point; weights with |c| <= 1e-6 are dropped (cpp/ContactConstraint.h:1033).
-
-        Output shape: slaves = block * bs + j for j < bs, masters = master block * bs + j, the same
-        weights for every component.  A slave point that touches no master cell raises RuntimeError
-        unless ``allow_missing_masters`` (then the block is skipped), as the reference does in serial
-        (cpp/ContactConstraint.h:1086-1094)."""
+    def _contact_collisions(self, meshtags, slave_marker: int, master_marker: int, eps2: float, allow_missing_masters: bool):
+        """collision search shared by the contact builders (cpp/ContactConstraint.h:454-475 / :1010-1030, serial
+        branch): the dof blocks in the closure of the slave facets, for each the master-side cell that contains its
+        point, and the values of that cell's basis functions there.  Returns (slave_blocks, cells, basis (n, nd)) of
+        the blocks that collided, or None when there is nothing to tie."""
         from scipy.spatial import cKDTree
 
         from .fem import locate_dofs_topological
@@ -377,11 +548,11 @@ class MultiPointConstraint:
         x = mesh.geometry.x
         slave_blocks = locate_dofs_topological(V, fdim, meshtags.find(slave_marker))
         if slave_blocks.size == 0:
-            return
+            return None
         mfac = meshtags.find(master_marker)
         if mfac.shape[0] == 0:
             if allow_missing_masters:
-                return
+                return None
             raise RuntimeError("No masters found on contact surface (when executed in serial). Please make sure "
                                "that the surfaces are in contact, or increase the tolerance eps2.")
         pts = V.tabulate_dof_coordinates()[slave_blocks]
@@ -441,6 +612,27 @@ class MultiPointConstraint:
             le = TET_EDGES if tdim == 3 else TRI_EDGES
             basis = np.concatenate([lam_found * (2.0 * lam_found - 1.0),
                                     4.0 * lam_found[:, le[:, 0]] * lam_found[:, le[:, 1]]], axis=1)
+        return slave_blocks, found, basis
+
+    def create_contact_inelastic_condition(self, meshtags, slave_marker: int, master_marker: int,
+                                           eps2: float = 1e-20, allow_missing_masters: bool = False,
+                                           num_threads: Optional[int] = 1):
+        """u_s = u_m between two sets of tagged facets whose surfaces coincide; the vertices need not
+        align (python/src/dolfinx_mpc/multipointconstraint.py:465-501, cpp/ContactConstraint.h:908-1174,
+        serial branch).  Every dof block in the closure of the slave facets is tied, per component, to
+        the dof blocks of the master-side cell it collides with, weighted by that cell's basis functions
+        at the slave point; weights with |c| <= 1e-6 are dropped (cpp/ContactConstraint.h:1033).
+
+        Output shape: slaves = block * bs + j for j < bs, masters = master block * bs + j, the same
+        weights for every component.  A slave point that touches no master cell raises RuntimeError
+        unless ``allow_missing_masters`` (then the block is skipped), as the reference does in serial
+        (cpp/ContactConstraint.h:1086-1094)."""
+        hit = self._contact_collisions(meshtags, slave_marker, master_marker, eps2, allow_missing_masters)
+        if hit is None:
+            return
+        slave_blocks, found, basis = hit
+        V = self.V
+        bs = V.dofmap.bs
         cell_blocks = V.dofmap.list[found]  # (n, nd)
         nz = np.abs(basis) > 1e-6  # cpp/ContactConstraint.h:1033
         cnt = nz.sum(axis=1)
@@ -461,6 +653,61 @@ class MultiPointConstraint:
         coeffs = coef[src]
         self.add_constraint(V, slaves.astype(np.int32), masters.astype(np.int64), coeffs.astype(np.float64),
                             np.zeros(masters.size, dtype=np.int32), offsets)
+
+    def create_contact_slip_condition(self, meshtags, slave_marker: int, master_marker: int, normal, eps2: float = 1e-20,
+                                      num_threads: Optional[int] = 1):
+        """u_s . n_s = u_m . n_s between two sets of tagged facets whose surfaces coincide (vertices need not align):
+        python/src/dolfinx_mpc/multipointconstraint.py:435-463, cpp/ContactConstraint.h:359-503 (serial branch).
+        For every dof block b in the closure of the slave facets, with n = the values of ``normal`` in that block:
+        slave = the component s with the largest |n_j|; masters (a) the other components j of the same block with
+        |n_j| > 1e-6, c = -n_j / n_s (compute_block_contributions, :217-280), then (b) every component k of every dof
+        block m of the master-side cell the block's point lies in with |n_k / n_s * phi_m(x_b)| > 1e-6, c = that value
+        (compute_master_contributions, :59-160).  A slave point that touches no master cell raises RuntimeError
+        (:500-508).  No Dirichlet filtering (the reference has none here)."""
+        from .fem import Function
+
+        if isinstance(eps2, np.generic):
+            eps2 = eps2.item()
+        V = self.V
+        bs = V.dofmap.bs
+        if bs != V.mesh.tdim:
+            raise RuntimeError("create_contact_slip_condition needs a vector space with block size = geometric dimension")
+        if not isinstance(normal, Function) or normal.function_space.dofmap.bs != bs:
+            raise ValueError("normal has to be a Function in the space of the constraint")
+        hit = self._contact_collisions(meshtags, slave_marker, master_marker, eps2, False)
+        if hit is None:
+            return
+        slave_blocks, found, basis = hit
+        nrm = normal.x._data.reshape(-1, bs)[slave_blocks]  # (n, bs); not normalised (cpp/ContactConstraint.h:424-431)
+        n = slave_blocks.size
+        sidx = np.argmax(np.abs(nrm), axis=1)
+        ns = nrm[np.arange(n), sidx]
+        # (a) same block
+        comp = np.arange(bs)[None, :].repeat(n, 0)
+        in_a = (comp != sidx[:, None]) & (np.abs(nrm) > 1e-6)
+        cnt_a = in_a.sum(axis=1)
+        m_a = (slave_blocks[:, None] * bs + comp)[in_a]
+        c_a = (-nrm / ns[:, None])[in_a]
+        # (b) other side: val[i, j, k] = n_k / n_s * phi_j
+        val = basis[:, :, None] * (nrm / ns[:, None])[:, None, :]  # (n, nd, bs): cell dof j outer, component k inner
+        in_b = np.abs(val) > 1e-6
+        cnt_b = in_b.reshape(n, -1).sum(axis=1)
+        cell_dofs = V.dofmap.list[found].astype(np.int64)  # (n, nd)
+        m_b = (cell_dofs[:, :, None] * bs + np.arange(bs)[None, None, :])[in_b]
+        c_b = val[in_b]
+        # concatenate per slave: (a) then (b) (impl::concatenate, :283-340)
+        cnt = cnt_a + cnt_b
+        offsets = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+        masters = np.empty(int(cnt.sum()), dtype=np.int64)
+        coeffs = np.empty(int(cnt.sum()), dtype=np.float64)
+        oa = np.concatenate([[0], np.cumsum(cnt_a)])
+        ob = np.concatenate([[0], np.cumsum(cnt_b)])
+        pos_a = np.repeat(offsets[:-1].astype(np.int64), cnt_a) + (np.arange(int(cnt_a.sum())) - np.repeat(oa[:-1], cnt_a))
+        pos_b = np.repeat(offsets[:-1].astype(np.int64) + cnt_a, cnt_b) + (np.arange(int(cnt_b.sum())) - np.repeat(ob[:-1], cnt_b))
+        masters[pos_a], coeffs[pos_a] = m_a, c_a
+        masters[pos_b], coeffs[pos_b] = m_b, c_b
+        slaves = slave_blocks * bs + sidx
+        self.add_constraint(V, slaves.astype(np.int32), masters, coeffs, np.zeros(masters.size, dtype=np.int32), offsets)
 
     # -- accessors (python/src/dolfinx_mpc/multipointconstraint.py:503-584) ----
     @property

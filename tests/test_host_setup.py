@@ -214,10 +214,7 @@ def test_convenience_builders_match_raw_arrays(oracle):
     mpc.finalize()
     om = oracle_mpc(oracle, case)
     assert np.array_equal(mpc.slaves, om.slaves) and np.array_equal(mpc.masters.array, om.masters)
-    with pytest.raises(NotImplementedError):
-        m2 = dm.MultiPointConstraint(case.V)
-        m2.create_periodic_constraint_geometrical(case.V, lambda x: np.isclose(x[0], 1),
-                                                  lambda x: x * np.array([[0.0], [0.937], [1.0]]), case.bcs)
+    # (non-matching mapped points: tests/test_builders.py)
     # slip
     case = case_cube_elasticity_slip(3)
     x = case.V.tabulate_dof_coordinates()
