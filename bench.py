@@ -577,17 +577,12 @@ def main():
         V0, V1 = f.function_spaces
         nbytes = (4 * nv * nc + 4 * V0.element_ndofs * nc + (0 if V1 is V0 else 4 * V1.element_ndofs * nc)
                   + 24 * mesh.num_nodes + 8 * A.nnz + V0.num_dofs + V1.num_dofs)
-        # the kernel mpcx_assemble_matrix launches for these arguments (csrc/mpcx_kernels.hip, launch_matrix)
-        if f.integrals[0].kernel.form == 100:
-            kname = "ufcx_matrix_rowblock_kernel" if margs.algorithm == 2 else "ufcx_matrix_kernel"
-        elif margs.algorithm == 3:
-            kname = "matrix_cube_kernel"
-        elif margs.algorithm == 2 and margs.slot_mask:
-            kname = "matrix_nodeblock_kernel"
-        elif margs.algorithm == 2 and margs.plan.row_pairs:
-            kname = "matrix_rowpair_kernel"
-        else:
-            kname = {2: "matrix_rowblock_kernel", 1: "matrix_atomic_kernel"}.get(margs.algorithm, f"matrix_{args.alg}_kernel")
+        # the kernel mpcx_assemble_matrix launches for these arguments: the dispatch table's entry (dolfinx_mpc_amd/dispatch.py)
+        from dolfinx_mpc_amd import dispatch
+
+        ufcx_form = f.integrals[0].kernel.form == 100
+        entry = getattr(margs, "kernel_name", None) or ("ufcx_atomic" if ufcx_form else "atomic")
+        kname = dispatch.FUNCTION[("matrix", entry)]
         kernels.append({"kernel": f"{kname}[{label}]", "call": f"assemble_matrix[{label}]", "launch_ms": tk,
                         "algorithmic_bytes": int(nbytes), "pmc_name": kname,
                         "fp64_flops": algorithmic_flops(f.integrals[0], V0, V1) * f.integrals[0].num_entities})
@@ -598,13 +593,10 @@ def main():
         V0 = f.function_spaces[0]
         nbytes = (4 * nv * nc + 4 * V0.element_ndofs * nc + 24 * mesh.num_nodes + 9 * V0.num_dofs
                   + 8 * f.integrals[0].cstride * nc)  # + the packed coefficients (cpp/assemble_vector.cpp reads them per cell)
-        kname = {2: "vector_rowblock_kernel", 3: "vector_cube_kernel"}.get(vargs.algorithm, "vector_kernel")
-        if vargs.algorithm == 2 and vargs.own_lmap:
-            kname = "vector_ownblock_kernel"  # + vector_spill_reduce_kernel, timed together
-        if vargs.algorithm == 3 and vargs.own_lmap:
-            kname = "vector_cube_own_kernel"  # + vector_spill_reduce_kernel + vector_mpc_kernel, timed together
-        if f.integrals[0].kernel.form == 100:
-            kname = "ufcx_vector_rowblock_kernel" if vargs.algorithm == 2 else "ufcx_vector_kernel"
+        entry = getattr(vargs, "kernel_name", "atomic")
+        if entry == "atomic" and f.integrals[0].kernel.form == 100:
+            entry = "ufcx_atomic"
+        kname = dispatch.FUNCTION[("vector", entry)]  # (owner-computes entries: + spill-reduce and slave-row kernels, timed together)
         k = {"kernel": f"{kname}[{label}]", "call": f"assemble_vector[{label}]", "launch_ms": tk,
              "algorithmic_bytes": int(nbytes), "pmc_name": kname}
         k["fp64_flops"] = algorithmic_flops(f.integrals[0], V0) * f.integrals[0].num_entities
@@ -652,10 +644,10 @@ def main():
             generic = {"ms_per_step": 1e3 * tg, "value": w.ndofs_total / tg, "unit": "DoFs/s",
                        "note": "MPCX_NO_CUBE=1: per-cell kernels only (meshes whose cells do not form six-tet fans)",
                        "kernels": [
-                           {"kernel": "matrix_rowblock_kernel[A]" if gm.algorithm == 2 else "matrix_atomic_kernel[A]", "launch_ms": tkm,
+                           {"kernel": dispatch.FUNCTION[("matrix", getattr(gm, "kernel_name", None) or "atomic")] + "[A]", "launch_ms": tkm,
                             "algorithmic_bytes": int(bm), "hbm_frac": bm / (tkm * 1e-3) / 1e9 / PEAK_HBM_GBS},
-                           {"kernel": ("vector_ownblock_kernel[b]" if gv.own_lmap else "vector_rowblock_kernel[b]") if gv.algorithm == 2
-                            else "vector_kernel[b]", "launch_ms": tkv, "algorithmic_bytes": int(bv),
+                           {"kernel": dispatch.FUNCTION[("vector", getattr(gv, "kernel_name", "atomic"))] + "[b]", "launch_ms": tkv,
+                            "algorithmic_bytes": int(bv),
                             "hbm_frac": bv / (tkv * 1e-3) / 1e9 / PEAK_HBM_GBS,
                             "fp64_frac": algorithmic_flops(fv.integrals[0], w.V) * nc / (tkv * 1e-3) / 1e12 / PEAK_FP64_TFLOPS}]}
             del keepm, keepv

@@ -713,39 +713,52 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
     keep = [md, s0, s1, bc0, bc1, k0, k1, idv, slave_ents, mplan]
     a.leftover = None  # (python attribute) cells the cluster kernel does not cover
     if alg == 2:
-        # lean path (include/mpcx.h, mpcx_matrix_args_t::lean): square P1-type form over all cells
+        from . import dispatch
+
         same = V1 is V0 and mpc1 is mpc0 and bc1 is bc0
-        ufcx = integ.kernel.form == 100  # imported kernel: the general (unrotated) row-block path
-        lean = (same and s0["dofmap"] is md["x_dofmap"] and idv["entities_ptr"] is None and integ.estride == 1
-                and integ.coefficient is None and not ufcx and not os.environ.get("MPCX_NO_LEAN"))
-        if lean and allow_cubes and _cube_eligible(form, i, V0):
-            cp = _cube_plan(A, form, i, V0, bc0, mpc0)
-            if cp is not None:
+        kf = integ.kernel
+        ctx = dispatch.Ctx(form=kf.form, tet=kf.celltype == 2, d0=V0.degree, bs0=V0.dofmap.bs, d1=V1.degree, bs1=V1.dofmap.bs,
+                           nd0=V0.element_ndofs, nd1=V1.element_ndofs,
+                           nq=int(kf.qwts.size if integ.itype == "cell" else kf.fqwts.size), cell_integral=integ.itype == "cell",
+                           has_coefficient=integ.coefficient is not None, coeff_degree=kf.coeff_degree,
+                           all_cells=idv["entities_ptr"] is None and integ.estride == 1,
+                           p1_geometry=s0["dofmap"] is md["x_dofmap"], same=same, tiled=V0.dof_tile_offsets is not None)
+        a.kernel_name = None  # (python attribute) the table entry that was taken
+        for name in dispatch.candidates(dispatch.MATRIX, ctx, "matrix"):
+            lean = pairs = False
+            smask = None
+            if name == "cube":
+                # cell clusters (MPCX_ALG_CUBE); None when the mesh has no clean six-tet fans or an offset overflows
+                cp = _cube_plan(A, form, i, V0, bc0, mpc0) if allow_cubes else None
+                if cp is None:
+                    continue
                 plan, ck, _info, left = cp
                 a.algorithm = 3
                 a.plan = plan
                 a.cube_recs = ck[2].data_ptr()
                 a.leftover = left if left.size else None
+                a.kernel_name = name
                 keep += [ck]
                 return a, keep
-        pairs = _rowpair_eligible(form, i, V0, V1) and not (lean and V0.dofmap.bs == 1 and V0.element_ndofs <= 4)
-        if pairs:
-            lean = False  # the row-pair kernel reads the plain (unrotated) masked dofmaps
-        smask = None
-        if (not pairs and not (lean and V0.dofmap.bs == 1) and _diag_blocked(form, i, V0, V1)
-                and not os.environ.get("MPCX_NO_NODEBLOCK") and not os.environ.get("MPCX_OFFSET_DICT")):
-            smask = _slot_mask(A, form, V0, V1, bc0, bc1, mpc0, mpc1)
-        if smask is not None:
-            lean = False
-            a.slot_mask = smask.data_ptr()
-            keep += [smask]
-        plan, pk, _info = _rowblock_plan(A, form, i, V0, lean, pairs, smask is not None)
-        a.plan = plan
-        a.lean = int(lean)
-        md0 = _masked_dofmap(form, V0, bc0, mpc0, 0, lean)
-        md1 = md0 if same else _masked_dofmap(form, V1, bc1, mpc1, 1)
-        a.mdofmap0, a.mdofmap1 = md0.data_ptr(), md1.data_ptr()
-        keep += [pk, md0, md1]
+            if name == "rowpair":
+                pairs = True  # (reads the plain, unrotated masked dofmaps)
+            elif name == "nodeblock":
+                smask = _slot_mask(A, form, V0, V1, bc0, bc1, mpc0, mpc1)
+                if smask is None:  # the pattern is not made of whole bs x bs blocks
+                    continue
+                a.slot_mask = smask.data_ptr()
+                keep += [smask]
+            elif name == "rowblock_lean":
+                lean = True
+            plan, pk, _info = _rowblock_plan(A, form, i, V0, lean, pairs, smask is not None)
+            a.plan = plan
+            a.lean = int(lean)
+            md0 = _masked_dofmap(form, V0, bc0, mpc0, 0, lean)
+            md1 = md0 if same else _masked_dofmap(form, V1, bc1, mpc1, 1)
+            a.mdofmap0, a.mdofmap1 = md0.data_ptr(), md1.data_ptr()
+            a.kernel_name = name
+            keep += [pk, md0, md1]
+            break
     return a, keep
 
 

@@ -190,85 +190,84 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
     keep = [md, sd, mkeep, idv]
     a.leftover = None  # (python attribute) cells the cluster kernel does not cover
     k = integ.kernel
-    if (alg == 0 and allow_cubes and not os.environ.get("MPCX_NO_CUBE") and k.form == 2 and k.celltype == 2
-            and k.degree == 1 and k.bs == 1 and k.coeff_degree == 0 and integ.coefficient is None and integ.itype == "cell"
-            and idv["entities_ptr"] is None and sd["dofmap"] is md["x_dofmap"]):
-        # scalar P1 source over all cells: one thread per cell cluster (MPCX_ALG_CUBE, csrc/mpcx_cubes.hip)
-        from .clusters import mesh_clusters_device
+    a.stream = D.stream_ptr()
+    a.kernel_name = "atomic"  # (python attribute) the table entry that was taken
+    if alg == 1 or integ.num_entities == 0:
+        return a, keep  # thread-per-entity kernels: LDS hash + device atomics (built-in), plain atomics (imported)
+    from . import dispatch
+    from .assemble_matrix import _masked_dofmap, _slave_entities
 
-        d_verts, left = mesh_clusters_device(form.mesh, integ.num_entities)
-        if d_verts.shape[0] * 6 >= 0.5 * integ.num_entities:
+    nq = int(k.qwts.size if integ.itype == "cell" else k.fqwts.size)
+    tiled = V.dof_tile_offsets is not None
+    ctx = dispatch.Ctx(form=k.form, tet=k.celltype == 2, d0=V.degree, bs0=V.dofmap.bs, d1=V.degree, bs1=V.dofmap.bs,
+                       nd0=V.element_ndofs, nd1=V.element_ndofs, nq=nq, cell_integral=integ.itype == "cell",
+                       has_coefficient=integ.coefficient is not None, coeff_degree=k.coeff_degree,
+                       all_cells=idv["entities_ptr"] is None, p1_geometry=sd["dofmap"] is md["x_dofmap"], same=True, tiled=tiled)
+    # row-block shapes (rows of b one workgroup holds): blocked spaces get the same number of NODES per block (vector P1,
+    # contact benchmark: 0.43 -> 0.29 ms); scalar P2 sources with the basis table on a tiled numbering and many-point
+    # rules take large blocks (the halo is paid in arithmetic)
+    nq_max = 8 if (V.degree == 2 and tiled) else 4
+    p2_fast = V.degree == 2 and tiled and k.form == 2 and k.coeff_degree == 0 and integ.itype == "cell"
+    ufcx = k.form == 100
+    heavy = ufcx or nq > nq_max  # an imported kernel's cost is unknown: treated as expensive
+    rows = VECTOR_BLOCK_ROWS if "MPCX_VECTOR_BLOCK_ROWS" in os.environ else VECTOR_BLOCK_ROWS * V.dofmap.bs
+    nrows_blk = VECTOR_BLOCK_ROWS_P2 if (p2_fast and heavy) else rows
+    if heavy and not p2_fast and (tiled or ufcx):
+        nrows_blk = max(nrows_blk, 2048 * V.dofmap.bs)
+    for name in dispatch.candidates(dispatch.VECTOR, ctx, "vector", plan_only=(alg == 2)):
+        if name in ("cube_own", "cube_hash"):
+            # scalar P1 source over all cells: one thread per cell cluster (MPCX_ALG_CUBE, csrc/mpcx_cubes.hip); "auto" only
+            if alg != 0 or not allow_cubes:
+                continue
+            from .clusters import mesh_clusters_device
+
+            d_verts, left = mesh_clusters_device(form.mesh, integ.num_entities)
+            if d_verts.shape[0] * 6 < 0.5 * integ.num_entities:
+                continue
+            if name == "cube_own":
+                # owner-computes row blocks over the clusters: no hash table, no device atomics, deterministic
+                slave_h, _ = _slave_entities(form, i, constraint, constraint)
+                own = _vector_cube_owner_plan(form.mesh, V, d_verts, constraint, left, slave_h)
+                if own is None:
+                    continue
+                plan, pk, n_own, d_slaves = own
+                a.plan = plan
+                a.own_lmap, a.own_hoff, a.own_spill = pk[3].data_ptr(), pk[4].data_ptr(), pk[5].data_ptr()
+                a.own_src, a.own_rows, a.own_seg, a.n_own_rows = pk[6].data_ptr(), pk[7].data_ptr(), pk[8].data_ptr(), n_own
+                a.slave_entities, a.n_slave_entities = d_slaves.data_ptr(), d_slaves.numel()
+                keep += [pk, d_slaves]
             a.algorithm = 3
             a.cube_verts, a.n_cubes = d_verts.data_ptr(), d_verts.shape[0]
             a.leftover = left if left.size else None
-            a.stream = D.stream_ptr()
+            a.kernel_name = name
             keep += [d_verts]
-            if os.environ.get("MPCX_VCUBE_OWNER", "1") != "0":
-                # owner-computes row blocks over the clusters: no hash table, no device atomics, deterministic
-                # (MPCX_VCUBE_OWNER=0: the LDS-hash kernel, one device atomic per distinct dof of a workgroup)
-                from .assemble_matrix import _slave_entities
-
-                slave_h, _ = _slave_entities(form, i, constraint, constraint)
-                own = _vector_cube_owner_plan(form.mesh, V, d_verts, constraint, left, slave_h)
-                if own is not None:
-                    plan, pk, n_own, d_slaves = own
-                    a.plan = plan
-                    a.own_lmap, a.own_hoff, a.own_spill = pk[3].data_ptr(), pk[4].data_ptr(), pk[5].data_ptr()
-                    a.own_src, a.own_rows, a.own_seg, a.n_own_rows = pk[6].data_ptr(), pk[7].data_ptr(), pk[8].data_ptr(), n_own
-                    a.slave_entities, a.n_slave_entities = d_slaves.data_ptr(), d_slaves.numel()
-                    keep += [pk, d_slaves]
             return a, keep
-    # auto: row blocks for cheap integrands (few quadrature points), the hash kernel otherwise
-    nq = integ.kernel.qwts.size if integ.itype == "cell" else integ.kernel.fqwts.size
-    # (P2 with a tile-wise numbering, 96^3: hash kernel 0.71 ms whatever the rule, row blocks 0.46 ms at
-    # 4 points, 0.85 ms at 14)
-    nq_max = 8 if (V.degree == 2 and V.dof_tile_offsets is not None) else 4
-    # scalar P2 source with the basis table (mpcx_kernel_t::qphi) on a tiled numbering: large row blocks win for any rule
-    p2_fast = (V.degree == 2 and V.dof_tile_offsets is not None and k.form == 2 and k.coeff_degree == 0
-               and integ.itype == "cell")
-    owner_mode = os.environ.get("MPCX_VECTOR_OWNER", "auto")
-    # many-point rules on a tiled numbering: row blocks with owner-computes lists beat the hash kernel too (P1, 14
-    # points, 256^3 without clusters: 3.77 -> 3.26 ms); without a tiled numbering the halo would not fit LDS
-    own_any = (owner_mode == "auto" and nq > 4 and V.dof_tile_offsets is not None and integ.itype == "cell")
-    ufcx = k.form == 100
-    if ufcx:
-        # an imported kernel: its cost is unknown, so every entity is evaluated once (owner-computes row blocks:
-        # no device atomics) whenever a block with its halo fits LDS; halo-recomputing row blocks otherwise
-        nq = 1 << 20
-        own_any = owner_mode != "0"
-    if (alg == 2 or (alg == 0 and (nq <= nq_max or p2_fast or own_any))) and integ.num_entities > 0:
-        from .assemble_matrix import _masked_dofmap, _slave_entities
-
-        # blocked spaces: the same number of NODES per block (vector P1, contact benchmark: 0.43 -> 0.29 ms)
-        rows = VECTOR_BLOCK_ROWS if "MPCX_VECTOR_BLOCK_ROWS" in os.environ else VECTOR_BLOCK_ROWS * V.dofmap.bs
-        nrows_blk = VECTOR_BLOCK_ROWS_P2 if (p2_fast and nq > nq_max) else rows
-        if own_any and not p2_fast and nq > nq_max:
-            nrows_blk = max(nrows_blk, 2048 * V.dofmap.bs)
+        if name == "hash":
+            a.kernel_name = name
+            return a, keep
         md0 = _masked_dofmap(form, V, None, constraint, 0)  # slave flag only: bcs do not touch b here
-        own = None
-        if owner_mode == "1" or (owner_mode == "auto" and nq > 4):
-            # owner-computes lists (no entity evaluated once per block it touches) where the quadrature is what
-            # costs (P2 source 246^3, 24 points: 6.6 -> 5.7 ms; Stokes b0 1.68 -> 1.46; a one-point rule loses:
-            # contact b 0.28 -> 0.31 ms); the halo rows share the LDS budget, so the own part of a block is smaller
+        if name in ("ownblock", "ufcx_ownblock"):
+            # owner-computes lists; the halo rows share the LDS budget, so the own part of a block is smaller
+            own = None
             for cap in (VECTOR_OWNER_ROWS, VECTOR_OWNER_ROWS * 3 // 4, VECTOR_OWNER_ROWS // 2):
                 own = _vector_owner_plan(form, i, V, md0, _even_rows(V, min(nrows_blk, cap)))
                 if own is not None:
                     break
-        if own is not None:
+            if own is None:
+                continue
             plan, pk, n_own = own
             a.own_lmap, a.own_hoff, a.own_spill = pk[3].data_ptr(), pk[4].data_ptr(), pk[5].data_ptr()
             a.own_src, a.own_rows, a.own_seg, a.n_own_rows = pk[6].data_ptr(), pk[7].data_ptr(), pk[8].data_ptr(), n_own
-        elif alg == 0 and nq > nq_max and not p2_fast and not ufcx:
-            a.stream = D.stream_ptr()
-            return a, keep  # no owner plan within the LDS budget: the hash kernel (a.algorithm == 1)
-        else:
+        else:  # "rowblock" / "ufcx_rowblock": halo entities evaluated by every block they touch
             plan, pk = _vector_plan(form, i, V, nrows_blk)
         _, slave_ents = _slave_entities(form, i, constraint, constraint)
         a.algorithm = 2
         a.plan = plan
         a.mdofmap = md0.data_ptr()
         a.slave_entities, a.n_slave_entities = slave_ents.data_ptr(), slave_ents.numel()
+        a.kernel_name = name
         keep += [pk, md0, slave_ents]
+        break
     a.stream = D.stream_ptr()
     return a, keep
 

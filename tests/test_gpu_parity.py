@@ -312,6 +312,79 @@ def test_finalize_on_device_errors_and_duplicates():
     assert m._devt is None and m.num_slaves == 1  # fell back to the host routine
 
 
+def _table_names(which):
+    from dolfinx_mpc_amd import dispatch
+
+    return [k.name for k in (dispatch.MATRIX if which == "matrix" else dispatch.VECTOR)]
+
+
+@pytest.mark.parametrize("name", _table_names("matrix"))
+@pytest.mark.parametrize("make", CASES, ids=[f"case{i}" for i in range(len(CASES))])
+def test_dispatch_table_matrix_entries(oracle, make, name, monkeypatch):
+    """every entry of the matrix dispatch table (dolfinx_mpc_amd/dispatch.py) forced wherever it applies
+    (MPCX_FORCE_KERNEL=matrix=<name>; ignored where it does not), on every case"""
+    monkeypatch.setenv("MPCX_FORCE_KERNEL", f"matrix={name}")
+    case = make()
+    if case.a is None:
+        pytest.skip("no bilinear form")
+    ref = oracle_outputs(oracle, case)
+    out = product_outputs(case, algorithm="rowblock")
+    assert np.array_equal(out["A"].indptr, ref["A"].indptr) and np.array_equal(out["A"].indices, ref["A"].indices)
+    _close(out["A"].data, ref["A"].data, RTOL_A, f"{case.name} A [matrix={name}]")
+
+
+@pytest.mark.parametrize("name", _table_names("vector"))
+@pytest.mark.parametrize("make", CASES, ids=[f"case{i}" for i in range(len(CASES))])
+def test_dispatch_table_vector_entries(oracle, make, name, monkeypatch):
+    monkeypatch.setenv("MPCX_FORCE_KERNEL", f"vector={name}")
+    case = make()
+    if case.L is None:
+        pytest.skip("no linear form")
+    ref = oracle_outputs(oracle, case)
+    out = product_outputs(case, algorithm=None)
+    for k in ("b", "b_lifted"):
+        if k in ref:
+            _close(out[k], ref[k], RTOL_B, f"{case.name} {k} [vector={name}]")
+
+
+def test_forced_kernels_are_the_ones_that_run(monkeypatch):
+    """MPCX_FORCE_KERNEL really selects the table entry where it applies, and the defaults are the measured ones"""
+    import importlib
+
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd.la import create_vector
+    from problems import case_contact_two_body
+
+    am = importlib.import_module("dolfinx_mpc_amd.assemble_matrix")
+    av = importlib.import_module("dolfinx_mpc_amd.assemble_vector")
+
+    def taken(case, which, force=None):
+        if force:
+            monkeypatch.setenv("MPCX_FORCE_KERNEL", f"{which}={force}")
+        else:
+            monkeypatch.delenv("MPCX_FORCE_KERNEL", raising=False)
+        mpc = product_mpc(case)
+        if which == "matrix":
+            A = dm.create_matrix(case.a, mpc)
+            args, keep = am.matrix_args(case.a, 0, A, mpc, mpc, case.bcs, 2)
+        else:
+            args, keep = av.vector_args(case.L, 0, create_vector(case.V), mpc, 0)
+        return args.kernel_name
+
+    p1 = case_cube_periodic(6, 1, 0.0, reorder=(2, 2, 2))
+    assert taken(p1, "matrix") == "cube" and taken(p1, "vector") == "cube_own"
+    for name in ("rowblock_lean", "rowblock", "rowpair"):
+        assert taken(p1, "matrix", name) == (name if name != "rowpair" else "cube")  # rowpair does not apply to scalar P1
+    for name in ("cube_hash", "ownblock", "rowblock", "hash"):
+        assert taken(p1, "vector", name) == name
+    p2 = case_cube_periodic(4, 2, 0.0, reorder=(2, 2, 2))
+    assert taken(p2, "matrix") == "rowblock" and taken(p2, "matrix", "rowpair") == "rowpair"
+    assert taken(p2, "vector") == "ownblock"
+    el = case_contact_two_body(4, 6, 0.0, reorder=(2, 2, 2))
+    assert taken(el, "matrix") == "rowpair" and taken(el, "matrix", "rowblock") == "rowblock"
+    assert taken(el, "vector") == "rowblock"
+
+
 def test_reproducibility_statement(oracle):
     """What repeated assembly of the same system guarantees (determinism):
     * pattern, plans and the master contributions (one thread per target position, fixed tuple order)
