@@ -350,11 +350,15 @@ def hip_time(fn, reps):
     """average duration (ms) of fn() measured with HIP events on the launch stream"""
     import torch
 
+    from dolfinx_mpc_amd.la import wait_assembly  # (assemble_* run on the library's side streams: join them)
+
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     fn()
     for s, e in ev:
+        wait_assembly()
         s.record()
         fn()
+        wait_assembly()
         e.record()
     torch.cuda.synchronize()
     return float(np.mean([s.elapsed_time(e) for s, e in ev]))

@@ -45,6 +45,15 @@ def _timed_build(kind, build):
     return val
 
 
+def _settle():
+    """a freshly built cached object may be shared with calls running on another stream (la.side_stream): finish its
+    construction before anybody can see it (cache misses are set-up, not the timed path)"""
+    import torch
+
+    if torch.cuda.is_available():
+        torch.cuda.current_stream().synchronize()
+
+
 def cached(store: dict, kind: str, objs, extra, build, maxsize: int = 8):
     """Small LRU cache inside ``store`` (the ``_device`` / ``_cache`` / ``_plans`` dict of the object
     that owns the derived data), keyed by the IDENTITY of ``objs`` plus the hashable ``extra``.
@@ -59,6 +68,7 @@ def cached(store: dict, kind: str, objs, extra, build, maxsize: int = 8):
         od.move_to_end(key)
         return hit[1]
     val = _timed_build(kind, build)
+    _settle()
     od[key] = (objs, val)
     while len(od) > maxsize:
         od.popitem(last=False)
@@ -74,10 +84,15 @@ def mesh_device(mesh):
             "x_dofmap": _to_dev(mesh.geometry.dofmap, dev),
             "x_version": mesh.geometry.version,
         }
+        _settle()
     d = mesh._device[key]
     if d["x_version"] != mesh.geometry.version:
         # the mesh was moved (mesh.geometry.x = ...): same tensor, new values, so that argument blocks and plans
-        # that hold its address stay valid (the reference re-reads x on every call, cpp/assemble_matrix.cpp:495-501)
+        # that hold its address stay valid (the reference re-reads x on every call, cpp/assemble_matrix.cpp:495-501);
+        # assemblies still running on the side streams read the old coordinates first
+        from .la import wait_assembly
+
+        wait_assembly()
         d["x"].copy_(_to_dev(mesh.geometry.x, dev))
         d["x_version"] = mesh.geometry.version
     return d
@@ -95,6 +110,7 @@ def space_device(V: FunctionSpace):
             V._device[key] = {"dofmap": mesh_device(V.mesh)["x_dofmap"]}
         else:
             V._device[key] = {"dofmap": _to_dev(dm, dev)}
+        _settle()
     return V._device[key]
 
 

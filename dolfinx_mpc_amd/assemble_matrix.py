@@ -727,7 +727,7 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
         for name in dispatch.candidates(dispatch.MATRIX, ctx, "matrix"):
             lean = pairs = False
             smask = None
-            if name == "cube":
+            if name in ("cube", "cube_el"):
                 # cell clusters (MPCX_ALG_CUBE); None when the mesh has no clean six-tet fans or an offset overflows
                 cp = _cube_plan(A, form, i, V0, bc0, mpc0) if allow_cubes else None
                 if cp is None:
@@ -792,19 +792,31 @@ def assemble_matrix(
     if form.rank != 2:
         raise RuntimeError("assemble_matrix needs a bilinear form")
     _native.require_gpu()
-    L = _native.lib()
     if A is None:
         A = create_matrix(form, mpc0, mpc1)
     alg = _ALG[(algorithm or os.environ.get("MPCX_MATRIX_ALG", "auto")).lower()]
+    for integ in form.integrals:
+        if integ.itype not in ("cell", "exterior_facet"):
+            raise RuntimeError("Not implemented yet")  # cpp/assemble_matrix.cpp:658-659
+    D.mesh_device(form.mesh)  # a moved mesh is refreshed on the caller's stream, before any side stream reads it
+    from .la import side_stream
+
+    with side_stream("matrix", A):  # the library's matrix stream (la.side_stream); completion is awaited by A.vals
+        _assemble_matrix_on_stream(form, mpc0, mpc1, bcs, diagval, A, alg)
+    return A
+
+
+def _assemble_matrix_on_stream(form: Form, mpc0, mpc1, bcs, diagval, A: MPCMatrix, alg: int):
+    """the body of ``assemble_matrix``: everything is enqueued on the CURRENT torch stream"""
+    import torch  # noqa: F401
+
+    L = _native.lib()
     auto = alg == 0
     if auto:
         alg = 2  # LDS row blocks (clusters where they apply); device atomics if a plan cannot be built
 
     V0, V1 = form.function_spaces
     stream = D.stream_ptr()
-    for integ in form.integrals:
-        if integ.itype not in ("cell", "exterior_facet"):
-            raise RuntimeError("Not implemented yet")  # cpp/assemble_matrix.cpp:658-659
 
     def prepare(alg):
         """argument blocks of every integral (plans are built / fetched here, nothing is launched)"""
@@ -870,7 +882,6 @@ def assemble_matrix(
                 "mpcx_add_diagonal",
             )
     A.assemble()
-    return A
 
 
 def create_matrix_nest(a: Sequence[Sequence[Optional[Form]]], constraints: Sequence[MultiPointConstraint]):

@@ -289,19 +289,24 @@ def assemble_vector(form: Form, constraint: MultiPointConstraint, b: Optional[Ve
     L = _native.lib()
     if b is None:
         b = create_vector(constraint.function_space)
-    b.set(0.0)
     alg = _ALG[(algorithm or os.environ.get("MPCX_VECTOR_ALG", "auto")).lower()]
-    for i, integ in enumerate(form.integrals):
+    for integ in form.integrals:
         if integ.itype not in ("cell", "exterior_facet"):
             raise RuntimeError("Interior facet integrals currently not supported")
-        a, keep = vector_args(form, i, b, constraint, alg)
-        _native.check(L.mpcx_assemble_vector(C.byref(a)), "mpcx_assemble_vector")
-        if a.leftover is not None:  # cells outside any cluster: per-cell kernel
-            from .assemble_matrix import _leftover_form
+    D.mesh_device(form.mesh)  # a moved mesh is refreshed on the caller's stream, before any side stream reads it
+    from .la import side_stream
 
-            al, kl = vector_args(_leftover_form(form, i, a.leftover), 0, b, constraint, alg, allow_cubes=False)
-            _native.check(L.mpcx_assemble_vector(C.byref(al)), "mpcx_assemble_vector")
-        del keep
+    with side_stream("vector", b):  # the library's vector stream (la.side_stream); completion is awaited by b.array
+        b.set(0.0)
+        for i, integ in enumerate(form.integrals):
+            a, keep = vector_args(form, i, b, constraint, alg)
+            _native.check(L.mpcx_assemble_vector(C.byref(a)), "mpcx_assemble_vector")
+            if a.leftover is not None:  # cells outside any cluster: per-cell kernel
+                from .assemble_matrix import _leftover_form
+
+                al, kl = vector_args(_leftover_form(form, i, a.leftover), 0, b, constraint, alg, allow_cubes=False)
+                _native.check(L.mpcx_assemble_vector(C.byref(al)), "mpcx_assemble_vector")
+            del keep
     return b
 
 

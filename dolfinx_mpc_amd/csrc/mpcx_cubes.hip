@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <string>
+#include <type_traits>
 
 namespace mpcx
 {
@@ -511,10 +512,162 @@ __global__ void __launch_bounds__(CUBE_MAX_THREADS) matrix_cube_kernel(mpcx_matr
       a.vals[nnz0 + i] += s_vals[i];
 }
 
-// (A cluster kernel for P1 vector elasticity -- 27 vertex-pair blocks of 3 x 3, 414 scatter-adds instead of 864, the
-// gradients of the six tets held in registers -- was built and measured on the contact benchmark: 2.4 ms against
-// 1.83 ms for the per-cell row-block kernel.  A vector row block holds only ~68 nodes (45 entries x 3 rows x 8 B per
-// node), so a block sees ~125 cluster slots of 256 VGPRs + scratch each: one wave per SIMD and no pipelining.  Removed.)
+// ---------------------------------------------------------------------------
+// matrix: P1 vector elasticity (bs = 3) over cell clusters, one thread per (row block, cluster, ROW COMPONENT).
+// The six element tensors of a cluster hold 6 * 144 = 864 entries but only 46 coupled vertex pairs * 9 = 414
+// distinct matrix entries.  A thread that took all of them (round 2's attempt) needs the gradients of six tets and
+// 46 3x3 accumulators at once: 256 VGPRs + scratch, 2.4 ms against 1.83 for the per-cell kernel.  Split by row
+// component a, a thread owns the 46 * 3 entries A[(i,a),(j,b)] of its component: it walks the fan tet by tet, keeps
+// only the pairs of the current faces live (scattered as soon as their last tet is done, like matrix_cube_kernel)
+// and recomputes the four gradients of a tet -- 3 x redundant across the components, cheap -- for
+//     A[(i,a),(j,b)] += |T| (mu g_i^b g_j^a + lambda g_i^a g_j^b + delta_ab mu g_i.g_j).
+// Same records as the scalar kernel (mpcx_cube_records with bs = 3: mask of component c in bit 28 + c of the vertex id,
+// offsets counted in column blocks), rows of the block in LDS, 138 ds_add_f64 per thread = 414 per cluster.
+// ---------------------------------------------------------------------------
+constexpr int CUBE_EL_THREADS = 384; // multiple of 3 * 64: a wave never splits a slot's three components unevenly
+
+__global__ void __launch_bounds__(CUBE_EL_THREADS) matrix_cube_elasticity_kernel(mpcx_matrix_args_t a)
+{
+  constexpr int BS = 3;
+  const int NT = blockDim.x;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int nb = a.plan.num_blocks;
+  const int per = (nb + 7) >> 3;
+  const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (b >= nb)
+    return;
+  const int tid = threadIdx.x;
+  const int r0 = a.plan.block_row0[b], r1 = a.plan.block_row0[b + 1];
+  const int nrow = r1 - r0;
+  const int64_t nnz0 = a.rowptr[r0];
+  const int nnzb = int(a.rowptr[r1] - nnz0);
+  double* s_vals = reinterpret_cast<double*>(smem);
+  int32_t* s_rowlo = reinterpret_cast<int32_t*>(s_vals + a.plan.max_nnz);
+  const double mu = a.constants[0], lmbda = a.constants[1];
+  const CubeRec* __restrict__ recs = static_cast<const CubeRec*>(a.cube_recs);
+  const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  for (int i = tid; i < nnzb; i += NT)
+    s_vals[i] = 0.0;
+  for (int rl = tid; rl < nrow; rl += NT)
+    s_rowlo[rl] = int(a.rowptr[r0 + rl] - nnz0);
+  __syncthreads();
+  // wave k of the workgroup takes row component k mod 3 (a compile-time constant inside its body: no selects, fewer
+  // registers); the lanes of the waves of one component stride over the block's slots
+  const int wave = tid >> 6, nwaves = NT >> 6;
+  const int ca_rt = wave % BS;
+  const int lane_in_group = (wave / BS) * 64 + (tid & 63);
+  const int group_size = (nwaves / BS) * 64;
+  auto body = [&](auto CA)
+  {
+    constexpr int ca = decltype(CA)::value;
+    for (int64_t t = e0 + lane_in_group; t < e1; t += group_size)
+    {
+      const uint4* p = reinterpret_cast<const uint4*>(recs + t);
+      const uint4 q0 = p[0], q1 = p[1];
+      const int32_t v[8] = {int32_t(q0.x), int32_t(q0.y), int32_t(q0.z), int32_t(q0.w),
+                            int32_t(q1.x), int32_t(q1.y), int32_t(q1.z), int32_t(q1.w)};
+      // the shared edge's two vertices stay in registers; ring vertices are gathered tet by tet (a ring vertex is
+      // used by two consecutive tets: the second read hits L1) -- 24 registers less across the accumulators
+      double X0[3], X7[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+      {
+        X0[k] = a.x[3 * int64_t(v[0] & DOF_MASK) + k];
+        X7[k] = a.x[3 * int64_t(v[7] & DOF_MASK) + k];
+      }
+      const uint4 q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5];
+      const uint32_t ow[16] = {q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
+      // LDS address of row (v_i, ca) if it lies in this block and is not masked, else -1
+      int base[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+      {
+        const int r = (v[i] & DOF_MASK) * BS + ca;
+        const bool mine = r >= r0 && r < r1 && !((v[i] >> (MASK_SHIFT + ca)) & 1);
+        base[i] = mine ? s_rowlo[mine ? r - r0 : 0] : -1;
+      }
+      double A[8][8][3]; // A[i][j][cb]: entry (row (v_i, ca), column (v_j, cb)); static indices -> registers
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int cb = 0; cb < 3; ++cb)
+            A[i][j][cb] = 0.0;
+#pragma unroll
+      for (int step = 0; step < 6; ++step)
+      {
+        const int tet = fan_order(step);
+        double cd[12];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+          const int lv = fan_vertex(tet, i);
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            cd[3 * i + k] = lv == 0 ? X0[k] : (lv == 7 ? X7[k] : a.x[3 * int64_t(v[lv] & DOF_MASK) + k]);
+        }
+        double G[4][3], det;
+        cofactor_gradients<3>(cd, G, det); // det * grad(lambda_i)
+        // |T| g_i^x g_j^y = G_i^x G_j^y / (6 |det|)
+        const double sc = 1.0 / (6.0 * fabs(det));
+        const double smu = sc * mu, sla = sc * lmbda;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+          {
+            const int gi = fan_vertex(tet, i), gj = fan_vertex(tet, j);
+            const double dot = G[i][0] * G[j][0] + G[i][1] * G[j][1] + G[i][2] * G[j][2];
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb)
+            {
+              double e = smu * G[i][cb] * G[j][ca] + sla * G[i][ca] * G[j][cb];
+              if (cb == ca)
+                e += smu * dot;
+              A[gi][gj][cb] += e;
+            }
+          }
+        // ordered pairs whose last tet this was
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+          {
+            // local vertex 3 is the ring vertex shared by the FIRST and the LAST tet of the walk: its pairs would stay
+            // live across all six steps (15 accumulators); they are flushed after the first tet and start again
+            const bool wrap_flush = step == 0 && (i == 3 || j == 3) && fan_coupled(i, j);
+            if (fan_last_step(i, j) != step && !wrap_flush)
+              continue;
+            if (base[i] >= 0)
+            {
+              const int off = int((ow[(i * 8 + j) >> 2] >> (8 * ((i * 8 + j) & 3))) & 0xff) * BS;
+#pragma unroll
+              for (int cb = 0; cb < 3; ++cb)
+                if (!((v[j] >> (MASK_SHIFT + cb)) & 1))
+                  __hip_atomic_fetch_add(s_vals + base[i] + off + cb, A[i][j][cb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb)
+              A[i][j][cb] = 0.0;
+          }
+      }
+    }
+  };
+  if (ca_rt == 0)
+    body(std::integral_constant<int, 0>{});
+  else if (ca_rt == 1)
+    body(std::integral_constant<int, 1>{});
+  else
+    body(std::integral_constant<int, 2>{});
+  __syncthreads();
+  if (a.store_mode)
+    for (int i = tid; i < nnzb; i += NT)
+      a.vals[nnz0 + i] = s_vals[i];
+  else
+    for (int i = tid; i < nnzb; i += NT)
+      a.vals[nnz0 + i] += s_vals[i];
+}
 
 // ---------------------------------------------------------------------------
 // vector: P1 source term, one thread per cluster; contributions merged per destination dof in an
@@ -698,14 +851,44 @@ __global__ void __launch_bounds__(VCUBE_OWN_THREADS) vector_cube_own_kernel(mpcx
 }
 } // namespace
 
+static int launch_matrix_cubes_elasticity(const mpcx_matrix_args_t& a)
+{
+  if (!a.cube_recs || a.plan.num_blocks <= 0 || !a.constants)
+  {
+    mpcx_set_error("mpcx_assemble_matrix: the elasticity cluster algorithm needs records (mpcx_cube_records, bs = 3), a "
+                   "row-block plan and the constants (mu, lambda)");
+    return -3;
+  }
+  const size_t lds = size_t(a.plan.max_nnz) * 8 + size_t(a.plan.max_rows) * 4;
+  if (lds > 160 * 1024)
+  {
+    mpcx_set_error("mpcx_assemble_matrix: row-block plan exceeds 160 KiB of LDS");
+    return -4;
+  }
+  if (int rc = check(hipFuncSetAttribute(reinterpret_cast<const void*>(matrix_cube_elasticity_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)),
+                     "hipFuncSetAttribute"))
+    return rc;
+  const char* e = std::getenv("MPCX_CUBE_EL_THREADS");
+  int threads = e ? std::atoi(e) : 384;
+  if (threads < 192 || threads > CUBE_EL_THREADS || threads % 192)
+    threads = 384;
+  const unsigned grid = 8u * unsigned((a.plan.num_blocks + 7) / 8);
+  hipLaunchKernelGGL(matrix_cube_elasticity_kernel, dim3(grid), dim3(threads), lds, static_cast<hipStream_t>(a.stream), a);
+  return check(hipGetLastError(), "elasticity cluster kernel launch");
+}
+
 int launch_matrix_cubes(const mpcx_matrix_args_t& a)
 {
   const mpcx_kernel_t& k = a.kernel;
+  if (k.form == MPCX_FORM_ELASTICITY && k.celltype == MPCX_CELL_TETRAHEDRON && k.degree == 1 && k.bs == 3 && k.degree1 == 1
+      && k.bs1 == 3 && !a.coeffs && a.estride == 1 && a.nv == 4)
+    return launch_matrix_cubes_elasticity(a);
   if (k.form != MPCX_FORM_STIFFNESS || k.celltype != MPCX_CELL_TETRAHEDRON || k.degree != 1 || k.bs != 1
       || k.degree1 != 1 || k.bs1 != 1 || k.coeff_degree != 0 || a.coeffs || a.estride != 1 || a.nv != 4)
   {
-    mpcx_set_error("mpcx_assemble_matrix: the cluster algorithm covers the scalar P1 stiffness form on tetrahedra "
-                   "without coefficients");
+    mpcx_set_error("mpcx_assemble_matrix: the cluster algorithm covers the scalar P1 stiffness form and P1 vector "
+                   "elasticity on tetrahedra, without coefficients");
     return -10;
   }
   if (!a.cube_recs || a.plan.num_blocks <= 0)

@@ -77,6 +77,11 @@ MATRIX: List[Kernel] = [
            lambda c: (_lean_ok(c) and c.form == FORM_STIFFNESS and c.tet and c.d0 == 1 and c.bs0 == 1 and c.coeff_degree == 0),
            lambda c: True,
            "matrix_cube_kernel: six-tet clusters, 46 scatter-adds per 6 cells; config 2: 1.27 ms vs 1.75 ms (rowblock_lean)"),
+    Kernel("cube_el",
+           lambda c: (_lean_ok(c) and c.form == FORM_ELASTICITY and c.tet and c.d0 == 1 and c.bs0 == 3),
+           lambda c: True,
+           "matrix_cube_elasticity_kernel: clusters, one thread per (slot, row component): 414 scatter-adds per cluster instead "
+           "of 864 from six element tensors; contact elasticity (config 4): see DESIGN.md section 5 (round 3)"),
     Kernel("ufcx_rowblock", lambda c: c.form == FORM_UFCX, lambda c: True,
            "imported tabulate_tensor inside the LDS row-block kernel (hipRTC); config 2 with tests/ufcx/laplace_p1_tet.c: 2.32 ms "
            "vs 1.75 ms built-in, vs ~50 ms thread-per-entity atomics"),
@@ -130,7 +135,7 @@ VECTOR: List[Kernel] = [
 
 # table entry -> the __global__ function it launches (profiles, bench.py's per-kernel roofline lines)
 FUNCTION = {
-    ("matrix", "cube"): "matrix_cube_kernel", ("matrix", "ufcx_rowblock"): "ufcx_matrix_rowblock_kernel",
+    ("matrix", "cube"): "matrix_cube_kernel", ("matrix", "cube_el"): "matrix_cube_elasticity_kernel", ("matrix", "ufcx_rowblock"): "ufcx_matrix_rowblock_kernel",
     ("matrix", "rowpair"): "matrix_rowpair_kernel", ("matrix", "nodeblock"): "matrix_nodeblock_kernel",
     ("matrix", "rowblock_lean"): "matrix_rowblock_kernel", ("matrix", "rowblock"): "matrix_rowblock_kernel",
     ("matrix", "atomic"): "matrix_atomic_kernel", ("matrix", "ufcx_atomic"): "ufcx_matrix_kernel",
@@ -156,9 +161,9 @@ def _legacy_matrix(c: Ctx):
     ex, prefer = set(), None
     env = os.environ
     if env.get("MPCX_NO_CUBE"):
-        ex.add("cube")
+        ex |= {"cube", "cube_el"}
     if env.get("MPCX_NO_LEAN"):
-        ex |= {"cube", "rowblock_lean"}
+        ex |= {"cube", "cube_el", "rowblock_lean"}
     mode = env.get("MPCX_ROWPAIR", "auto")
     if env.get("MPCX_NO_ROWPAIR") or mode == "none":
         ex.add("rowpair")

@@ -346,6 +346,7 @@ class MultiPointConstraint:
 
             dev = _native.require_gpu()
             self._devt = {k: D._to_dev(v, dev) for k, v in self._host.items()}
+            D._settle()
         return self._devt
 
     # -- convenience builders (structured / matching meshes only) --------------

@@ -312,6 +312,51 @@ def test_finalize_on_device_errors_and_duplicates():
     assert m._devt is None and m.num_slaves == 1  # fell back to the host routine
 
 
+@pytest.mark.parametrize("async_streams", ["1", "0"])
+def test_side_streams_keep_results_ordered(oracle, monkeypatch, async_streams):
+    """assemble_matrix / assemble_vector run on the library's two side streams (la.side_stream) so that back-to-back
+    calls overlap; whoever reads A / b next waits for them.  A driver loop that alternates two geometries and two
+    coefficient values, lifts into b on the caller's stream and reads everything back each time must see exactly the
+    values of a serial run (big enough that a missing wait would show)."""
+    import torch
+
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import fem
+
+    monkeypatch.setenv("MPCX_ASYNC_STREAMS", async_streams)
+    case = case_cube_periodic(40, 1, 0.7, reorder=(8, 8, 8))
+    V = case.V
+    mpc = product_mpc(case)
+    w = fem.Function(V)
+    L = fem.form_source(V, fem.FN_BENCH_PERIODIC, coefficient=w)  # per-cell path with a coefficient pack
+    x0 = case.mesh.geometry.x.copy()
+    x1 = x0 * np.array([1.0, 1.3, 0.8])
+    A = b = b2 = None
+    seen = {}
+    for it in range(8):
+        k = it % 2
+        case.mesh.geometry.x = x1 if k else x0
+        w.x.array[:] = 1.0 + k
+        A = dm.assemble_matrix(case.a, mpc, bcs=case.bcs, A=A)
+        b = dm.assemble_vector(case.L, mpc, b=b)
+        b2 = dm.assemble_vector(L, mpc, b=b2)
+        dm.apply_lifting(b, [case.a], [case.bcs], mpc)
+        got = (A.vals.clone(), b.array.clone(), b2.array.clone())
+        torch.cuda.synchronize()
+        if k not in seen:
+            seen[k] = got
+        else:
+            for u, v, name in zip(got, seen[k], ("A", "b lifted", "b with coefficient")):
+                scale = float(v.abs().max())
+                assert float((u - v).abs().max()) <= 1e-13 * scale, (it, name)
+    # and the values themselves against the oracle for the last geometry / coefficient
+    o_mpc = oracle_mpc(oracle, case)
+    ref = oracle.assemble_matrix(case.a, o_mpc, bcs=case.bcs, fast=True)
+    _close(A.to_scipy().data, ref.data, RTOL_A, "A after the loop")
+    _close(b2.numpy(), oracle.assemble_vector(L, o_mpc), RTOL_B, "b with coefficient after the loop")
+    assert float((seen[0][0] - seen[1][0]).abs().max()) > 0  # the two geometries really differ
+
+
 def _table_names(which):
     from dolfinx_mpc_amd import dispatch
 
@@ -381,7 +426,8 @@ def test_forced_kernels_are_the_ones_that_run(monkeypatch):
     assert taken(p2, "matrix") == "rowblock" and taken(p2, "matrix", "rowpair") == "rowpair"
     assert taken(p2, "vector") == "ownblock"
     el = case_contact_two_body(4, 6, 0.0, reorder=(2, 2, 2))
-    assert taken(el, "matrix") == "rowpair" and taken(el, "matrix", "rowblock") == "rowblock"
+    assert taken(el, "matrix") == "cube_el" and taken(el, "matrix", "rowblock") == "rowblock"
+    assert taken(el, "matrix", "rowpair") == "rowpair"
     assert taken(el, "vector") == "rowblock"
 
 

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round evidence on the GPU box: driver-style bench lines for every config, the rocprofv3 kernel trace of the
-# default bench command, PMC counters of every config's kernels.  Outputs under gpurun_out/r02_final/.
+# default bench command, PMC counters of every config's kernels.  Outputs under gpurun_out/r03_final/.
 set -u
-OUT=gpurun_out/r02_final
+OUT=gpurun_out/r03_final
 mkdir -p $OUT
 for c in 2 3 4 5; do
   timeout 1200 python bench.py --config $c --steps 20 --warmup 3 > $OUT/bench_c$c.json 2> $OUT/bench_c$c.log
