@@ -118,6 +118,8 @@ class MatrixArgs(C.Structure):
         ("mpc_plan_pq", C.c_void_p),
         ("mpc_plan_coef", C.c_void_p),
         ("mpc_plan_group", C.c_int32),
+        ("block_vals", C.c_void_p),
+        ("mpc_plan_out", C.c_void_p),
         ("stream", C.c_void_p),
     ]
 
@@ -244,6 +246,10 @@ EXPORTS = [
     "mpcx_gather_f64",
     "mpcx_scatter_add_f64",
     "mpcx_spmv",
+    "mpcx_block_expand",
+    "mpcx_spmv_blockscalar",
+    "mpcx_csr_positions",
+    "mpcx_spmv_coo_add",
     "mpcx_inverse_diagonal",
     "mpcx_cg_start",
     "mpcx_cg_step",
@@ -381,6 +387,14 @@ def lib() -> C.CDLL:
     L.mpcx_scatter_add_f64.restype = C.c_int
     L.mpcx_spmv.argtypes = [i32, vp, vp, vp, vp, vp, vp]
     L.mpcx_spmv.restype = C.c_int
+    L.mpcx_block_expand.argtypes = [i32, vp, i32, vp, vp, vp, vp]
+    L.mpcx_block_expand.restype = C.c_int
+    L.mpcx_spmv_blockscalar.argtypes = [i32, vp, vp, i32, vp, vp, vp, vp, vp]
+    L.mpcx_spmv_blockscalar.restype = C.c_int
+    L.mpcx_csr_positions.argtypes = [vp, vp, vp, vp, i64, vp, vp]
+    L.mpcx_csr_positions.restype = C.c_int
+    L.mpcx_spmv_coo_add.argtypes = [i64, vp, vp, vp, vp, vp, vp]
+    L.mpcx_spmv_coo_add.restype = C.c_int
     L.mpcx_inverse_diagonal.argtypes = [i32, vp, vp, vp, vp, vp]
     L.mpcx_inverse_diagonal.restype = C.c_int
     L.mpcx_cg_start.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp]

@@ -661,8 +661,9 @@ def _masked_dofmap(form: Form, V, bc_dev, mpc, which: int, rotate: bool = False)
 
 
 def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, store_mode: int = 0,
-                with_mpc_kernel: bool = True, allow_cubes: bool = True):
-    """Fill the C-ABI argument block of ``mpcx_assemble_matrix`` for integral i."""
+                with_mpc_kernel: bool = True, allow_cubes: bool = True, allow_block_scalar: bool = False):
+    """Fill the C-ABI argument block of ``mpcx_assemble_matrix`` for integral i.  ``allow_block_scalar``: the
+    node-block kernel may leave its result in block-scalar storage (one value per bs x bs block, la.MPCMatrix)."""
     V0, V1 = form.function_spaces
     integ = form.integrals[i]
     md = D.mesh_device(form.mesh)
@@ -675,7 +676,7 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
     slave_ents_h, slave_ents = _slave_entities(form, i, mpc0, mpc1)
     a = _native.MatrixArgs()
     a.nrows = A.shape[0]
-    a.rowptr, a.cols, a.vals = A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), A.vals.data_ptr()
+    a.rowptr, a.cols = A.d_rowptr.data_ptr(), A.d_cols.data_ptr()  # (a.vals: at the end, unless block-scalar)
     a.kernel = idv["kernel"]
     a.x, a.x_dofmap, a.nv = md["x"].data_ptr(), md["x_dofmap"].data_ptr(), form.mesh.geometry.dofmap.shape[1]
     a.estride, a.n_entities = integ.estride, integ.num_entities
@@ -712,6 +713,7 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
     a.stream = D.stream_ptr()
     keep = [md, s0, s1, bc0, bc1, k0, k1, idv, slave_ents, mplan]
     a.leftover = None  # (python attribute) cells the cluster kernel does not cover
+    a.block_scalar = False  # (python attribute) the result goes to A._compact, not to A.vals
     if alg == 2:
         from . import dispatch
 
@@ -738,6 +740,7 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
                 a.cube_recs = ck[2].data_ptr()
                 a.leftover = left if left.size else None
                 a.kernel_name = name
+                a.vals = A.vals.data_ptr()
                 keep += [ck]
                 return a, keep
             if name == "rowpair":
@@ -748,6 +751,25 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
                     continue
                 a.slot_mask = smask.data_ptr()
                 keep += [smask]
+                if (allow_block_scalar and os.environ.get("MPCX_BLOCK_SCALAR", "1") != "0"
+                        and (a.n_slave_entities == 0 or mplan is not None)):
+                    # block-scalar storage: 8 B per bs x bs block instead of 8 bs^2; couplings and diagonals in an overlay
+                    import torch
+
+                    bs = V0.dofmap.bs
+                    c = A._compact
+                    if c is None or c["bs"] != bs or c["mask"] is not smask:
+                        c = dict(bs=bs, svals=torch.empty(A.nnz // (bs * bs), dtype=torch.float64, device=A.device), mask=smask,
+                                 ov_pos=None, ov_val=None, ov_plan=None, diag_pos=None, diagval=0.0, diag_key=None, ov_rc=None)
+                        A._compact = c
+                    if mplan is not None and mplan[5] and c["ov_plan"] is not mplan:
+                        c["ov_pos"], c["ov_plan"], c["ov_rc"] = mplan[0], mplan, None
+                        c["ov_val"] = torch.zeros(mplan[0].numel(), dtype=torch.float64, device=A.device)
+                    elif mplan is None or not mplan[5]:
+                        c["ov_pos"] = c["ov_val"] = c["ov_plan"] = c["ov_rc"] = None
+                    a.block_vals = c["svals"].data_ptr()
+                    a.mpc_plan_out = D.ptr(c["ov_val"])
+                    a.block_scalar = True
             elif name == "rowblock_lean":
                 lean = True
             plan, pk, _info = _rowblock_plan(A, form, i, V0, lean, pairs, smask is not None)
@@ -759,6 +781,9 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
             a.kernel_name = name
             keep += [pk, md0, md1]
             break
+    if not a.block_scalar:
+        A._compact_stale = False  # every value is (re)written below: nothing to expand first
+        a.vals = A.vals.data_ptr()
     return a, keep
 
 
@@ -832,7 +857,9 @@ def _assemble_matrix_on_stream(form: Form, mpc0, mpc1, bcs, diagval, A: MPCMatri
                 store_mode = 0
                 memset = not zeroed  # python/src/dolfinx_mpc/assemble_matrix.py:51
                 zeroed = True
-            a, keep = matrix_args(form, i, A, mpc0, mpc1, bcs, alg, store_mode)
+            a, keep = matrix_args(form, i, A, mpc0, mpc1, bcs, alg, store_mode,
+                                  allow_block_scalar=(len(form.integrals) == 1 and integ.num_entities > 0
+                                                      and A._exchange is None and alg == 2))
             calls.append((memset, a, keep))
             if a.leftover is not None:
                 # cells outside any cluster: per-cell row-block kernel, ADDed; their master contributions are part
@@ -850,12 +877,20 @@ def _assemble_matrix_on_stream(form: Form, mpc0, mpc1, bcs, diagval, A: MPCMatri
         # rows with more than 255 column blocks before an entity's column, tiny LDS ...: thread-per-entity atomics
         alg = 1
         calls, zeroed = prepare(alg)
+    block_scalar = len(calls) == 1 and calls[0][1].block_scalar
     for memset, a, _keep in calls:
         if memset:
             A.zeroEntries()
+        if a.block_scalar and A._compact["ov_val"] is not None:
+            A._compact["ov_val"].zero_()
         _native.check(L.mpcx_assemble_matrix(C.byref(a)), "mpcx_assemble_matrix")
     if not zeroed:
         A.zeroEntries()
+    if block_scalar:
+        _block_scalar_diagonals(A, form, mpc0, mpc1, bcs, diagval)
+        A._compact_stale = True
+        A.assemble()
+        return
 
     # slave diagonal, cpp/assemble_matrix.cpp:711-724 (only when mpc0.V == mpc1.V)
     if mpc0.function_space is mpc1.function_space:
@@ -882,6 +917,37 @@ def _assemble_matrix_on_stream(form: Form, mpc0, mpc1, bcs, diagval, A: MPCMatri
                 "mpcx_add_diagonal",
             )
     A.assemble()
+
+
+def _block_scalar_diagonals(A: MPCMatrix, form: Form, mpc0, mpc1, bcs, diagval):
+    """slave diagonal (cpp/assemble_matrix.cpp:711-724) and Dirichlet diagonal (insert_diagonal,
+    python/src/dolfinx_mpc/assemble_matrix.py:59-62) of a matrix kept in block-scalar storage: their positions in the
+    CSR, found once per (constraint, bcs), go to the overlay"""
+    import torch
+
+    c = A._compact
+    V0 = form.function_spaces[0]
+    key = (mpc0, mpc1, tuple(bcs))
+    if c["diag_key"] is None or len(c["diag_key"]) != 3 or c["diag_key"][0] is not mpc0 or c["diag_key"][1] is not mpc1 \
+            or len(c["diag_key"][2]) != len(bcs) or any(x is not y for x, y in zip(c["diag_key"][2], bcs)):
+        dofs = []
+        if mpc0.function_space is mpc1.function_space:
+            dofs.append(mpc0.device_tensors()["slaves"][: mpc0.num_local_slaves].to(torch.int32))
+        if form.function_spaces[0] is form.function_spaces[1]:
+            for bc in bcs:
+                if V0.contains(bc.function_space):
+                    d, nowned = bc.dof_indices()
+                    dofs.append(D._to_dev(np.ascontiguousarray(d[:nowned], dtype=np.int32), A.device))
+        if dofs:
+            d = torch.cat(dofs).contiguous()  # (a dof listed twice gets the diagonal twice, like the full path)
+            pos = torch.empty(d.numel(), dtype=torch.int64, device=A.device)
+            _native.check(_native.lib().mpcx_csr_positions(A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), d.data_ptr(), d.data_ptr(),
+                                                           d.numel(), pos.data_ptr(), D.stream_ptr()), "mpcx_csr_positions")
+            c["diag_pos"], c["diag_dofs"] = pos[pos >= 0].contiguous(), d[pos >= 0].contiguous()
+        else:
+            c["diag_pos"] = c["diag_dofs"] = None
+        c["diag_key"] = key
+    c["diagval"] = float(diagval)
 
 
 def create_matrix_nest(a: Sequence[Sequence[Optional[Form]]], constraints: Sequence[MultiPointConstraint]):

@@ -264,7 +264,10 @@ __global__ void __launch_bounds__(64) matrix_mpc_plan_small_kernel(mpcx_matrix_a
     const int pq = a.mpc_plan_pq[k];
     sum += a.mpc_plan_coef[k] * Op::get(Ae, pq / N1, pq % N1);
   }
-  a.vals[a.mpc_plan_tgt[t]] += sum;
+  if (a.mpc_plan_out)
+    a.mpc_plan_out[t] += sum; // block-scalar storage: the couplings live in an overlay, one entry per target
+  else
+    a.vals[a.mpc_plan_tgt[t]] += sum;
 }
 
 template <class Op, int G, bool USE_LAZY> // G lanes share one target position
@@ -322,7 +325,12 @@ __global__ void __launch_bounds__(64) matrix_mpc_plan_kernel(mpcx_matrix_args_t 
       sum += __shfl_xor(sum, m, G);
   }
   if (lane == 0)
-    a.vals[a.mpc_plan_tgt[t]] += sum;
+  {
+    if (a.mpc_plan_out)
+      a.mpc_plan_out[t] += sum;
+    else
+      a.vals[a.mpc_plan_tgt[t]] += sum;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -731,8 +739,9 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_nodeblock_kernel(
   // (a global load inside the store loop put its latency on every row)
   const int64_t gslot0 = nnz0 / (BS * BS);
   int any = 0;
-  for (int i = tid; i < slots; i += NT)
-    any |= a.slot_mask[gslot0 + i];
+  if (!a.block_vals) // (block-scalar storage leaves the masks to the consumers)
+    for (int i = tid; i < slots; i += NT)
+      any |= a.slot_mask[gslot0 + i];
   const bool masked_block = __syncthreads_or(any) != 0;
 
   const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
@@ -798,6 +807,18 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_nodeblock_kernel(
     }
   }
   __syncthreads();
+  if (a.block_vals)
+  {
+    // block-scalar storage: the block's values as they are, one per bs x bs block; masks and structural zeros are
+    // applied by the consumers (mpcx_block_expand, mpcx_spmv_blockscalar)
+    if (a.store_mode)
+      for (int i = tid; i < slots; i += NT)
+        a.block_vals[gslot0 + i] = s_vals[i];
+    else
+      for (int i = tid; i < slots; i += NT)
+        a.block_vals[gslot0 + i] += s_vals[i];
+    return;
+  }
   // expand: a wave takes whole scalar rows (node nl, component k); row k of a node starts k * L * BS entries after
   // row 0 (L = column blocks of the node's rows).  (A wave per node -- BS * BS * L contiguous entries, 98 % of the
   // lanes busy instead of 66 % -- measured slower: 12.6 against 10.9 ms on the Taylor-Hood velocity block.)
@@ -1828,6 +1849,12 @@ int launch_matrix(const mpcx_matrix_args_t& a)
     }
     if (int rc = check(hipGetLastError(), "matrix kernel launch"))
       return rc;
+  }
+  if (a.block_vals && (!a.slot_mask || alg != MPCX_ALG_ROWBLOCK || (a.n_slave_entities > 0 && (!a.mpc_plan_off || !a.mpc_plan_out))))
+  {
+    mpcx_set_error("mpcx_assemble_matrix: block_vals needs the node-block kernel (slot_mask, MPCX_ALG_ROWBLOCK) and, with slave "
+                   "entities, a master-contribution plan with mpc_plan_out");
+    return -8;
   }
   if (a.n_slave_entities > 0)
   {

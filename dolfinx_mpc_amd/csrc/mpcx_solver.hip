@@ -253,6 +253,128 @@ extern "C" int mpcx_spmv(int32_t nrows, const mpcx_nnz_t* rowptr, const int32_t*
   return check(hipGetLastError(), "spmv launch");
 }
 
+namespace
+{
+// one wave per scalar row (node n, component k): entry (k, q) of block sl
+__global__ void block_expand_kernel(int32_t n_nodes, const mpcx_nnz_t* __restrict__ rowptr, int bs,
+                                    const double* __restrict__ block_vals, const uint8_t* __restrict__ slot_mask,
+                                    double* __restrict__ vals)
+{
+  const int64_t row = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (row >= int64_t(n_nodes) * bs)
+    return;
+  const int64_t n = row / bs;
+  const int k = int(row - n * bs);
+  const int64_t p0 = rowptr[row];
+  const int len = int(rowptr[row + 1] - p0);
+  const int64_t slot0 = rowptr[n * bs] / (int64_t(bs) * bs);
+  for (int e = lane; e < len; e += 64)
+  {
+    const int sl = e / bs, q = e - sl * bs;
+    const bool keep = q == k && !((slot_mask[slot0 + sl] >> k) & 1);
+    vals[p0 + e] = keep ? block_vals[slot0 + sl] : 0.0;
+  }
+}
+
+// y(n, k) = sum over the blocks of node row n: (bit k of the mask clear) s * x(col block, k); a group of 8 lanes per row
+__global__ void spmv_blockscalar_kernel(int32_t n_nodes, const mpcx_nnz_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                        int bs, const double* __restrict__ block_vals, const uint8_t* __restrict__ slot_mask,
+                                        const double* __restrict__ x, double* __restrict__ y)
+{
+  constexpr int G = 8;
+  const int64_t row = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+  const int lane = threadIdx.x & (G - 1);
+  if (row >= int64_t(n_nodes) * bs)
+    return;
+  const int64_t n = row / bs;
+  const int k = int(row - n * bs);
+  const int64_t p0 = rowptr[n * bs]; // first row of the node: its entries list the column blocks
+  const int nblk = int(rowptr[n * bs + 1] - p0) / bs;
+  const int64_t slot0 = p0 / (int64_t(bs) * bs);
+  double sum = 0.0;
+  for (int sl = lane; sl < nblk; sl += G)
+    if (!((slot_mask[slot0 + sl] >> k) & 1))
+      sum += block_vals[slot0 + sl] * x[cols[p0 + int64_t(sl) * bs] + k];
+#pragma unroll
+  for (int m = G / 2; m > 0; m >>= 1)
+    sum += __shfl_xor(sum, m, G);
+  if (lane == 0)
+    y[row] = sum;
+}
+
+__global__ void csr_positions_kernel(const mpcx_nnz_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                     const int32_t* __restrict__ rows, const int32_t* __restrict__ colsq, int64_t n,
+                                     int64_t* __restrict__ pos)
+{
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  int64_t lo = rowptr[rows[i]], hi = rowptr[rows[i] + 1];
+  const int64_t end = hi;
+  const int32_t c = colsq[i];
+  while (lo < hi)
+  {
+    const int64_t mid = (lo + hi) >> 1;
+    if (cols[mid] < c)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  pos[i] = (lo < end && cols[lo] == c) ? lo : -1;
+}
+
+__global__ void spmv_coo_add_kernel(int64_t n, const int32_t* __restrict__ rows, const int32_t* __restrict__ colsq,
+                                    const double* __restrict__ v, const double* __restrict__ x, double* __restrict__ y)
+{
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n)
+    __hip_atomic_fetch_add(y + rows[i], v[i] * x[colsq[i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+} // namespace
+
+extern "C" int mpcx_block_expand(int32_t n_nodes, const mpcx_nnz_t* rowptr, int32_t bs, const double* block_vals,
+                                 const uint8_t* slot_mask, double* vals, void* stream)
+{
+  if (n_nodes == 0)
+    return 0;
+  const int64_t threads = int64_t(n_nodes) * bs * 64;
+  hipLaunchKernelGGL(block_expand_kernel, dim3(grid_for(threads, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n_nodes,
+                     rowptr, int(bs), block_vals, slot_mask, vals);
+  return check(hipGetLastError(), "block_expand launch");
+}
+
+extern "C" int mpcx_spmv_blockscalar(int32_t n_nodes, const mpcx_nnz_t* rowptr, const int32_t* cols, int32_t bs,
+                                     const double* block_vals, const uint8_t* slot_mask, const double* x, double* y, void* stream)
+{
+  if (n_nodes == 0)
+    return 0;
+  const int64_t threads = int64_t(n_nodes) * bs * 8;
+  hipLaunchKernelGGL(spmv_blockscalar_kernel, dim3(grid_for(threads, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     n_nodes, rowptr, cols, int(bs), block_vals, slot_mask, x, y);
+  return check(hipGetLastError(), "spmv_blockscalar launch");
+}
+
+extern "C" int mpcx_csr_positions(const mpcx_nnz_t* rowptr, const int32_t* cols, const int32_t* rows, const int32_t* colsq,
+                                  int64_t n, int64_t* pos, void* stream)
+{
+  if (n == 0)
+    return 0;
+  hipLaunchKernelGGL(csr_positions_kernel, dim3(grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), rowptr, cols,
+                     rows, colsq, n, pos);
+  return check(hipGetLastError(), "csr_positions launch");
+}
+
+extern "C" int mpcx_spmv_coo_add(int64_t n, const int32_t* rows, const int32_t* colsq, const double* v, const double* x,
+                                 double* y, void* stream)
+{
+  if (n == 0)
+    return 0;
+  hipLaunchKernelGGL(spmv_coo_add_kernel, dim3(grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n, rows, colsq,
+                     v, x, y);
+  return check(hipGetLastError(), "spmv_coo_add launch");
+}
+
 extern "C" int mpcx_inverse_diagonal(int32_t nrows, const mpcx_nnz_t* rowptr, const int32_t* cols,
                                      const double* vals, double* dinv, void* stream)
 {

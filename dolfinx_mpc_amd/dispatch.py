@@ -79,9 +79,10 @@ MATRIX: List[Kernel] = [
            "matrix_cube_kernel: six-tet clusters, 46 scatter-adds per 6 cells; config 2: 1.27 ms vs 1.75 ms (rowblock_lean)"),
     Kernel("cube_el",
            lambda c: (_lean_ok(c) and c.form == FORM_ELASTICITY and c.tet and c.d0 == 1 and c.bs0 == 3),
-           lambda c: True,
+           lambda c: False,
            "matrix_cube_elasticity_kernel: clusters, one thread per (slot, row component): 414 scatter-adds per cluster instead "
-           "of 864 from six element tensors; contact elasticity (config 4): see DESIGN.md section 5 (round 3)"),
+           "of 864 from six element tensors -- measured and NOT the default: contact elasticity (config 4) 1.81 ms vs 0.97 ms "
+           "(rowpair); 256 VGPRs + 24 B scratch, and a 74 KB vector row block holds only ~125 slots x 3 threads"),
     Kernel("ufcx_rowblock", lambda c: c.form == FORM_UFCX, lambda c: True,
            "imported tabulate_tensor inside the LDS row-block kernel (hipRTC); config 2 with tests/ufcx/laplace_p1_tet.c: 2.32 ms "
            "vs 1.75 ms built-in, vs ~50 ms thread-per-entity atomics"),

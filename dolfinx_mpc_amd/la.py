@@ -194,8 +194,12 @@ class MPCMatrix:
             self._cols = np.ascontiguousarray(cols, dtype=np.int32)
             self.d_cols = torch.from_numpy(self._cols).to(self.device)
         self.shape = (self.d_rowptr.numel() - 1, ncols)
-        self._vals = torch.zeros(self.d_cols.numel(), dtype=torch.float64, device=self.device)
+        self._vals = None  # scalar CSR values, allocated on first use (a block-scalar matrix may never need them)
         self._plans = {}
+        # block-scalar storage (component-diagonal forms on blocked spaces, include/mpcx.h mpcx_matrix_args_t::block_vals):
+        # dict(bs, svals [nnz / bs^2], mask uint8 [nnz / bs^2], ov_pos int64, ov_val, diag_pos int64, diagval) or None
+        self._compact = None
+        self._compact_stale = False  # the scalar values do not reflect the block-scalar ones yet
         self._exchange = None
         self._pending = None
         self._ready = None  # event recorded at the end of an assembly on a side stream
@@ -211,10 +215,44 @@ class MPCMatrix:
         """the CSR values (device tensor); the current stream first waits for an assembly still running on a side
         stream, and a posted ``assemble()`` exchange is completed"""
         self._wait_ready()
+        if self._vals is None:
+            import torch
+
+            self._vals = torch.zeros(self.d_cols.numel(), dtype=torch.float64, device=self.device)
+        if self._compact_stale:
+            self._expand_compact()
         if self._pending is not None:
             p, self._pending = self._pending, None
             p.finish()
         return self._vals
+
+    def _expand_compact(self):
+        """scalar CSR values from the block-scalar ones: (k, k) entries of every block unless masked, zeros elsewhere,
+        then the overlay (master contributions at their target positions, slave / Dirichlet diagonals)"""
+        import torch
+
+        from . import _device as D
+
+        c = self._compact
+        L = _native.lib()
+        st = D.stream_ptr()
+        bs = c["bs"]
+        _native.check(L.mpcx_block_expand(self.shape[0] // bs, self.d_rowptr.data_ptr(), bs, c["svals"].data_ptr(),
+                                          c["mask"].data_ptr(), self._vals.data_ptr(), st), "mpcx_block_expand")
+        if c["ov_pos"] is not None and c["ov_pos"].numel():
+            _native.check(L.mpcx_scatter_add_f64(self._vals.data_ptr(), c["ov_pos"].data_ptr(), c["ov_pos"].numel(),
+                                                 c["ov_val"].data_ptr(), st), "mpcx_scatter_add_f64")
+        if c["diag_pos"] is not None and c["diag_pos"].numel():
+            dv = torch.full((c["diag_pos"].numel(),), float(c["diagval"]), dtype=torch.float64, device=self.device)
+            _native.check(L.mpcx_scatter_add_f64(self._vals.data_ptr(), c["diag_pos"].data_ptr(), c["diag_pos"].numel(),
+                                                 dv.data_ptr(), st), "mpcx_scatter_add_f64")
+        self._compact_stale = False
+
+    @property
+    def is_block_scalar(self) -> bool:
+        """the last assembly left the values in block-scalar storage (one value per bs x bs block + overlay); ``vals`` /
+        ``to_scipy`` expand them on demand, ``problem.spmv`` multiplies straight from this layout"""
+        return self._compact is not None and self._compact_stale
 
     @property
     def rowptr(self) -> np.ndarray:
@@ -235,6 +273,7 @@ class MPCMatrix:
         return self.d_cols.numel()
 
     def zeroEntries(self):
+        self._compact_stale = False
         self.vals.zero_()
 
     def attach_exchange(self, exchange):

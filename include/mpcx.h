@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MPCX_VERSION 2
+#define MPCX_VERSION 3
 
 /* Offsets into the CSR value / column arrays (rowptr entries, positions): 64-bit, so that one GPU can
  * hold matrices with more than 2^31 - 1 stored entries (Taylor-Hood a00 on 128^3 cells: 4.4 G) -- PETSc's
@@ -227,6 +227,16 @@ typedef struct
   const int32_t* mpc_plan_pq;
   const double* mpc_plan_coef;
   int32_t mpc_plan_group; /* lanes per target position: >= 16, >= 4 or one (pick ~ the average tuples per target) */
+  /* Block-scalar value storage for component-diagonal forms on blocked spaces (S (x) I: vector stiffness / mass, the
+   * Taylor-Hood velocity block), optional, with slot_mask: DEVICE [nnz / bs^2], ONE value per bs x bs block -- the
+   * matrix is S (x) I except where slot_mask zeroes a diagonal entry and where constraints add couplings.  Given, the
+   * node-block kernel writes (store_mode) / adds its block values here and never touches vals: 8 bytes per block instead
+   * of 8 bs^2 (Taylor-Hood a00 on 128^3: 3.9 GB instead of 35 GB written per assembly).  The master contributions then go
+   * to mpc_plan_out[t] (+=, one entry per plan target, zeroed by the caller) instead of vals[mpc_plan_tgt[t]], so a plan
+   * is required when there are slave entities.  Consumers: mpcx_block_expand (the scalar CSR values, on demand) and
+   * mpcx_spmv_blockscalar (y = A x straight from this layout). */
+  double* block_vals;
+  double* mpc_plan_out;
   void* stream;
 } mpcx_matrix_args_t;
 
@@ -563,6 +573,21 @@ int mpcx_cg_start(int32_t n, const double* dinv, const double* b, double* x, dou
 int mpcx_cg_step(int32_t n, const mpcx_nnz_t* rowptr, const int32_t* cols, const double* vals,
                  const double* dinv, double* x, double* r, double* z, double* p, double* Ap,
                  double* scal, int32_t k, void* stream);
+
+/* Block-scalar storage (mpcx_matrix_args_t::block_vals), all pointers DEVICE; rowptr / cols are the scalar CSR pattern
+ * (whole bs x bs blocks, as mpcx_diag_slot_mask requires), n_nodes = nrows / bs:
+ *   mpcx_block_expand:      vals[entry (k, q) of block s] = (k == q and bit k of slot_mask[s] clear) ? block_vals[s] : 0
+ *   mpcx_spmv_blockscalar:  y = (S (x) I, masked) x, the same matrix without materialising it
+ *   mpcx_csr_positions:     pos[i] = position of (rows[i], colsq[i]) in the CSR, -1 if absent (overlay set-up)
+ *   mpcx_spmv_coo_add:      y[rows[i]] += v[i] * x[colsq[i]]  (the overlay: master contributions, diagonals) */
+int mpcx_block_expand(int32_t n_nodes, const mpcx_nnz_t* rowptr, int32_t bs, const double* block_vals,
+                      const uint8_t* slot_mask, double* vals, void* stream);
+int mpcx_spmv_blockscalar(int32_t n_nodes, const mpcx_nnz_t* rowptr, const int32_t* cols, int32_t bs,
+                          const double* block_vals, const uint8_t* slot_mask, const double* x, double* y, void* stream);
+int mpcx_csr_positions(const mpcx_nnz_t* rowptr, const int32_t* cols, const int32_t* rows, const int32_t* colsq, int64_t n,
+                       int64_t* pos, void* stream);
+int mpcx_spmv_coo_add(int64_t n, const int32_t* rows, const int32_t* colsq, const double* v, const double* x, double* y,
+                      void* stream);
 
 /* Interface exchange between GPUs (the `A.assemble()` / `ghostUpdate(ADD, REVERSE)` step of the
  * reference, python/src/dolfinx_mpc/assemble_matrix.py:64, python/benchmarks/bench_periodic.py:108):

@@ -87,7 +87,7 @@ def _worker(rank, world, port, N, reorder, outdir, kind="poisson"):
 
     cpu = torch.device("cpu")
     Am = MPCMatrix(pattern[0], pattern[1], V.num_dofs, device=cpu)
-    Am._vals.copy_(torch.from_numpy(A.data))
+    Am.vals.copy_(torch.from_numpy(A.data))
     Am.attach_exchange(exchange_for(V, Am))
     Am.assemble()
     bv = Vector(V.num_dofs, device=cpu)

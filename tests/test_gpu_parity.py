@@ -426,8 +426,8 @@ def test_forced_kernels_are_the_ones_that_run(monkeypatch):
     assert taken(p2, "matrix") == "rowblock" and taken(p2, "matrix", "rowpair") == "rowpair"
     assert taken(p2, "vector") == "ownblock"
     el = case_contact_two_body(4, 6, 0.0, reorder=(2, 2, 2))
-    assert taken(el, "matrix") == "cube_el" and taken(el, "matrix", "rowblock") == "rowblock"
-    assert taken(el, "matrix", "rowpair") == "rowpair"
+    assert taken(el, "matrix") == "rowpair" and taken(el, "matrix", "rowblock") == "rowblock"
+    assert taken(el, "matrix", "cube_el") == "cube_el"
     assert taken(el, "vector") == "rowblock"
 
 

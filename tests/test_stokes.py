@@ -117,3 +117,50 @@ def test_gpu_stokes_blocks_match_oracle(oracle, dim, n, alg):
         assert abs(out[key].data - ref[key].data).max() <= 1e-12 * scale, key
     for key in ("b0", "b1"):
         assert abs(out[key] - ref[key]).max() <= 1e-12 * max(1.0, abs(ref[key]).max()), key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,n", [(2, 4), (3, 3)])
+def test_gpu_block_scalar_storage_of_the_velocity_block(oracle, dim, n, monkeypatch):
+    """a00 = inner(grad u, grad v) on P2^d is S (x) I except for masked entries and constraint couplings: the node-block
+    kernel leaves ONE value per d x d block + an overlay (include/mpcx.h mpcx_matrix_args_t::block_vals).  The
+    expanded values, the block-scalar SpMV and the scalar-CSR path (MPCX_BLOCK_SCALAR=0) must all be the same matrix
+    as the oracle's, with a diagonal value other than 1 and across repeated assemblies into one matrix."""
+    import torch
+
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd.la import Vector
+    from dolfinx_mpc_amd.problem import spmv
+    from problems import stokes_slip_problem
+
+    V, Q, bcs, raw_v, forms, L0 = stokes_slip_problem(dim, n)
+    mv = dm.MultiPointConstraint(V)
+    mv.add_constraint(V, *raw_v)
+    mv.finalize()
+    om = oracle.OracleMPC.from_raw(V, *raw_v)
+    a00 = forms[(0, 0)]
+    A = None
+    for diagval in (1.0, 2.5):
+        ref = oracle.assemble_matrix(a00, om, bcs=bcs, diagval=diagval)
+        A = dm.assemble_matrix(a00, mv, bcs=bcs, diagval=diagval, A=A)
+        assert A.is_block_scalar, "block-scalar storage expected for a component-diagonal form on a blocked space"
+        x = Vector(V.num_dofs)
+        x.array.copy_(torch.from_numpy(np.random.default_rng(3).standard_normal(V.num_dofs)))
+        y = spmv(A, x).numpy()  # straight from the block-scalar layout (A still unexpanded)
+        assert A.is_block_scalar
+        S = A.to_scipy()  # expands
+        assert not A.is_block_scalar
+        assert np.array_equal(S.indptr, ref.indptr) and np.array_equal(S.indices, ref.indices)
+        assert abs(S.data - ref.data).max() <= 1e-12 * max(1.0, abs(ref).max())
+        yref = ref @ x.numpy()
+        assert abs(y - yref).max() <= 1e-12 * max(1.0, abs(yref).max())
+    monkeypatch.setenv("MPCX_BLOCK_SCALAR", "0")
+    B = dm.assemble_matrix(a00, mv, bcs=bcs, diagval=2.5)
+    assert not B.is_block_scalar and B._compact is None
+    assert abs(B.to_scipy().data - S.data).max() <= 1e-13 * abs(S.data).max()
+    # a matrix that was block-scalar can be assembled into through the scalar path and back
+    dm.assemble_matrix(a00, mv, bcs=bcs, diagval=2.5, A=A)
+    assert abs(A.to_scipy().data - S.data).max() <= 1e-13 * abs(S.data).max()
+    monkeypatch.delenv("MPCX_BLOCK_SCALAR")
+    dm.assemble_matrix(a00, mv, bcs=bcs, diagval=2.5, A=A)
+    assert A.is_block_scalar and abs(A.to_scipy().data - S.data).max() <= 1e-13 * abs(S.data).max()
