@@ -578,7 +578,12 @@ def main():
         A = mats[label]
         margs, keep = am.matrix_args(f, 0, A, m0, m1, bcs, alg_id, store_mode=1 if alg_id == 2 else 0, with_mpc_kernel=False,
                                      allow_block_scalar=A._compact is not None)
-        tk = hip_time(lambda: _native.check(Lib.mpcx_assemble_matrix(C.byref(margs)), "mpcx_assemble_matrix"), reps)
+        def launch_matrix(margs=margs):  # (cluster path: one launch per record format, narrow and wide row blocks)
+            _native.check(Lib.mpcx_assemble_matrix(C.byref(margs)), "mpcx_assemble_matrix")
+            if getattr(margs, "second", None) is not None:
+                _native.check(Lib.mpcx_assemble_matrix(C.byref(margs.second)), "mpcx_assemble_matrix")
+
+        tk = hip_time(launch_matrix, reps)
         V0, V1 = f.function_spaces
         # values: 8 B per stored entry; block-scalar storage (component-diagonal forms, one value per bs x bs block): 8 B per
         # block -- the matrix IS S (x) I there, the b^2 - 1 structural zeros of a block are not part of the algorithm

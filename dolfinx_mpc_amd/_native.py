@@ -110,6 +110,8 @@ class MatrixArgs(C.Structure):
         ("mdofmap1", C.c_void_p),
         ("lean", C.c_int32),
         ("cube_recs", C.c_void_p),
+        ("cube_rec_bytes", C.c_int32),
+        ("cube_block_ids", C.c_void_p),
         ("slot_mask", C.c_void_p),
         ("mpc_plan_targets", C.c_int64),
         ("mpc_plan_tgt", C.c_void_p),
@@ -201,6 +203,8 @@ EXPORTS = [
     "mpcx_scatter_offsets",
     "mpcx_cube_records",
     "mpcx_cube_detect",
+    "mpcx_cube_slot_width",
+    "mpcx_cube_pack_narrow",
     "mpcx_cluster_keys",
     "mpcx_cluster_build",
     "mpcx_rowblock_pairs_device",
@@ -340,6 +344,10 @@ def lib() -> C.CDLL:
     L.mpcx_cube_records.restype = C.c_int
     L.mpcx_cube_detect.argtypes = [vp, i64, vp, vp, vp]
     L.mpcx_cube_detect.restype = C.c_int
+    L.mpcx_cube_slot_width.argtypes = [i64, vp, vp, vp]
+    L.mpcx_cube_slot_width.restype = C.c_int
+    L.mpcx_cube_pack_narrow.argtypes = [i64, vp, vp, vp, vp]
+    L.mpcx_cube_pack_narrow.restype = C.c_int
     L.mpcx_cluster_keys.argtypes = [vp, vp, i64, vp, vp]
     L.mpcx_cluster_keys.restype = C.c_int
     L.mpcx_cluster_build.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp]

@@ -511,13 +511,49 @@ def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc):
         _native.check(rc, "mpcx_cube_records")
         if int(flag.item()) != 0:
             raise _native.PlanNotRepresentable("cluster algorithm: a scatter offset does not fit 8 bits (or a column is missing)")
-        keep = (d_row0, d_off, recs)
         max_rows = int(np.diff(row0).max())
         max_nnz = int(np.diff(A.rowptr[row0]).max())
-        plan = _native.RowBlockPlanT(nb, max_rows, max_nnz, 0, keep[0].data_ptr(), keep[1].data_ptr(), None, None, None)
-        info = {"num_blocks": nb, "num_ents": int(nslots), "max_rows": max_rows, "max_nnz": max_nnz,
-                "clusters": int(nc), "bytes": int(sum(x.numel() * x.element_size() for x in keep))}
-        return (plan, keep, info)
+        parts = None
+        if bs == 1 and os.environ.get("MPCX_CUBE_NARROW", "1") != "0" and nslots > 0:
+            # narrow records (64 B, 4-bit offsets) for the row blocks all of whose slots allow it, the 96-byte format
+            # for the rest (blocks that hold fat rows: master rows of a constraint); launched separately
+            wide = torch.empty(nslots, dtype=torch.uint8, device=dev)
+            _native.check(L.mpcx_cube_slot_width(nslots, recs.data_ptr(), wide.data_ptr(), D.stream_ptr()), "mpcx_cube_slot_width")
+            cs = torch.zeros(nslots + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(wide.to(torch.int64), 0, out=cs[1:])
+            per_block = cs[d_off[1:]] - cs[d_off[:-1]]
+            del wide, cs
+            sel_n = torch.nonzero(per_block == 0).reshape(-1)
+            sel_w = torch.nonzero(per_block > 0).reshape(-1)
+            if sel_n.numel() > 0:
+                parts = []
+                for sel, nbytes in ((sel_n, 64), (sel_w, 96)):
+                    if sel.numel() == 0:
+                        continue
+                    cnt = d_off[sel + 1] - d_off[sel]
+                    off_c = torch.zeros(sel.numel() + 1, dtype=torch.int64, device=dev)
+                    torch.cumsum(cnt, 0, out=off_c[1:])
+                    tot = int(off_c[-1].item())
+                    src = torch.repeat_interleave(d_off[sel] - off_c[:-1], cnt) + torch.arange(tot, dtype=torch.int64, device=dev)
+                    if nbytes == 64:
+                        out = torch.empty(tot * 64, dtype=torch.uint8, device=dev)
+                        _native.check(L.mpcx_cube_pack_narrow(tot, src.data_ptr(), recs.data_ptr(), out.data_ptr(), D.stream_ptr()),
+                                      "mpcx_cube_pack_narrow")
+                    else:
+                        out = recs.view(nslots, 96)[src].contiguous().view(-1)
+                    ids = sel.to(torch.int32).contiguous()
+                    parts.append((_native.RowBlockPlanT(int(sel.numel()), max_rows, max_nnz, 0, d_row0.data_ptr(), off_c.data_ptr(),
+                                                        None, None, None), out, nbytes, ids, off_c))
+                del recs
+        if parts is None:
+            parts = [(_native.RowBlockPlanT(nb, max_rows, max_nnz, 0, d_row0.data_ptr(), d_off.data_ptr(), None, None, None),
+                      recs, 96, None, d_off)]
+        keep = (d_row0, parts)
+        info = {"num_blocks": nb, "num_ents": int(nslots), "max_rows": max_rows, "max_nnz": max_nnz, "clusters": int(nc),
+                "narrow_blocks": int(parts[0][0].num_blocks) if parts[0][2] == 64 else 0,
+                "bytes": int(d_row0.numel() * 4 + sum(p[1].numel() + p[4].numel() * 8 + (0 if p[3] is None else p[3].numel() * 4)
+                                                      for p in parts))}
+        return (parts, keep, info)
 
     try:
         plan, keep, info = D.cached(A._plans, "cubes", (form, mpc, bc_dev), (i, CUBE_MAX_ROWS, CUBE_MAX_NNZ), build)
@@ -734,13 +770,20 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
                 cp = _cube_plan(A, form, i, V0, bc0, mpc0) if allow_cubes else None
                 if cp is None:
                     continue
-                plan, ck, _info, left = cp
+                parts, ck, _info, left = cp
                 a.algorithm = 3
-                a.plan = plan
-                a.cube_recs = ck[2].data_ptr()
                 a.leftover = left if left.size else None
                 a.kernel_name = name
                 a.vals = A.vals.data_ptr()
+                a.second = None  # (python attribute) the launch over the blocks of the other record format
+                for n_part, (plan, recs, nbytes, ids, _off) in enumerate(parts):
+                    t = a if n_part == 0 else _native.MatrixArgs.from_buffer_copy(a)
+                    t.plan = plan
+                    t.cube_recs, t.cube_rec_bytes, t.cube_block_ids = recs.data_ptr(), nbytes, D.ptr(ids)
+                    if n_part == 1:
+                        t.n_slave_entities = 0  # the master contributions ride on the first launch
+                        t.leftover, t.kernel_name, t.block_scalar = None, name, False
+                        a.second = t
                 keep += [ck]
                 return a, keep
             if name == "rowpair":
@@ -861,6 +904,8 @@ def _assemble_matrix_on_stream(form: Form, mpc0, mpc1, bcs, diagval, A: MPCMatri
                                   allow_block_scalar=(len(form.integrals) == 1 and integ.num_entities > 0
                                                       and A._exchange is None and alg == 2))
             calls.append((memset, a, keep))
+            if getattr(a, "second", None) is not None:  # cluster path: the row blocks of the other record format
+                calls.append((False, a.second, keep))
             if a.leftover is not None:
                 # cells outside any cluster: per-cell row-block kernel, ADDed; their master contributions are part
                 # of the call above (its plan covers every slave entity of the integral)

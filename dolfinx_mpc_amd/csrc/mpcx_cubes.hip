@@ -82,6 +82,33 @@ struct __align__(16) CubeRec
 };
 static_assert(sizeof(CubeRec) == 96, "record layout");
 
+// position of the coupled pair (a, b) among the 46 coupled pairs in row-major order, -1 if a and b share no tet
+__host__ __device__ constexpr int fan_pair_index(int a, int b)
+{
+  if (!fan_coupled(a, b))
+    return -1;
+  int n = 0;
+  for (int i = 0; i < 8; ++i)
+    for (int j = 0; j < 8; ++j)
+    {
+      if (i == a && j == b)
+        return n;
+      if (fan_coupled(i, j))
+        ++n;
+    }
+  return -1;
+}
+// Narrow record: rows of at most 16 entries before any of the cluster's columns (every interior row of a Kuhn mesh has
+// 15 entries) need 4 bits per offset: 8 ids + 46 nibbles = 55 bytes -> 64-byte records, four 16-byte loads per slot
+// instead of six and a third less plan memory.  Row blocks that hold a fat row (master rows of a constraint) keep the
+// 96-byte format; the two kinds are launched separately.
+struct __align__(16) CubeRecNarrow
+{
+  int32_t v[8];
+  uint8_t nib[32]; // nibble p = fan_pair_index(a, b): byte p / 2, low half for even p
+};
+static_assert(sizeof(CubeRecNarrow) == 64, "record layout");
+
 inline int check(hipError_t err, const char* what)
 {
   if (err != hipSuccess)
@@ -356,11 +383,49 @@ __global__ void cube_records_kernel(int64_t n_slots, const int32_t* __restrict__
   }
 }
 
+// set-up: does slot k fit the narrow format (every coupled offset < 16)?
+__global__ void cube_slot_width_kernel(int64_t n_slots, const CubeRec* __restrict__ recs, uint8_t* __restrict__ wide)
+{
+  const int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (k >= n_slots)
+    return;
+  const CubeRec& R = recs[k];
+  int mx = 0;
+  for (int a = 0; a < 8; ++a)
+    for (int b = 0; b < 8; ++b)
+      if (fan_coupled(a, b))
+        mx = max(mx, int(R.off[a * 8 + b]));
+  wide[k] = mx > 15 ? 1 : 0;
+}
+// set-up: narrow record j from wide record src[j]
+__global__ void cube_pack_narrow_kernel(int64_t n_out, const int64_t* __restrict__ src, const CubeRec* __restrict__ recs,
+                                        CubeRecNarrow* __restrict__ out)
+{
+  const int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j >= n_out)
+    return;
+  const CubeRec& R = recs[src[j]];
+  CubeRecNarrow N;
+  for (int i = 0; i < 8; ++i)
+    N.v[i] = R.v[i];
+  for (int i = 0; i < 32; ++i)
+    N.nib[i] = 0;
+  for (int a = 0; a < 8; ++a)
+    for (int b = 0; b < 8; ++b)
+    {
+      const int p = fan_pair_index(a, b);
+      if (p >= 0)
+        N.nib[p >> 1] |= uint8_t((R.off[a * 8 + b] & 0xf) << (4 * (p & 1)));
+    }
+  out[j] = N;
+}
+
 // ---------------------------------------------------------------------------
 // matrix: P1 scalar stiffness, one thread per (row block, cluster) slot
 // ---------------------------------------------------------------------------
 constexpr int CUBE_MAX_THREADS = 512;
 
+template <bool NARROW>
 __global__ void __launch_bounds__(CUBE_MAX_THREADS) matrix_cube_kernel(mpcx_matrix_args_t a)
 {
   const int NT = blockDim.x;
@@ -371,23 +436,43 @@ __global__ void __launch_bounds__(CUBE_MAX_THREADS) matrix_cube_kernel(mpcx_matr
   if (b >= nb)
     return;
   const int tid = threadIdx.x;
-  const int r0 = a.plan.block_row0[b], r1 = a.plan.block_row0[b + 1];
+  // (a launch covers the blocks of one record format: cube_block_ids lists them, NULL = all blocks in order)
+  const int bb = a.cube_block_ids ? a.cube_block_ids[b] : b;
+  const int r0 = a.plan.block_row0[bb], r1 = a.plan.block_row0[bb + 1];
   const int nrow = r1 - r0;
   const int64_t nnz0 = a.rowptr[r0];
   const int nnzb = int(a.rowptr[r1] - nnz0);
   double* s_vals = reinterpret_cast<double*>(smem);
   int32_t* s_rowlo = reinterpret_cast<int32_t*>(s_vals + a.plan.max_nnz);
   const double c0 = a.constants ? a.constants[0] : 1.0;
-  const CubeRec* __restrict__ recs = static_cast<const CubeRec*>(a.cube_recs);
+  constexpr int NW = NARROW ? 4 : 6; // 16-byte words per record
+  const uint4* __restrict__ recs = static_cast<const uint4*>(a.cube_recs);
   const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
-  auto load = [&](int64_t t, uint4 (&w)[6])
+  auto load = [&](int64_t t, uint4 (&w)[NW])
   {
-    const uint4* p = reinterpret_cast<const uint4*>(recs + t);
+    const uint4* p = recs + t * NW;
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < NW; ++i)
       w[i] = p[i];
   };
-  auto gather = [&](const uint4 (&w)[6], double (&X)[8][3])
+  // offset of column v[j] inside row v[i] (static i, j): a byte of the wide record, a nibble of the narrow one
+  auto offset_of = [&](const uint4 (&w)[NW], int i, int j) -> int
+  {
+    uint32_t ow[4 * (NW - 2)];
+#pragma unroll
+    for (int q = 0; q < NW - 2; ++q)
+    {
+      ow[4 * q] = w[2 + q].x, ow[4 * q + 1] = w[2 + q].y, ow[4 * q + 2] = w[2 + q].z, ow[4 * q + 3] = w[2 + q].w;
+    }
+    if constexpr (NARROW)
+    {
+      const int p = fan_pair_index(i, j);
+      return int((ow[p >> 3] >> (4 * (p & 7))) & 0xf);
+    }
+    else
+      return int((ow[(i * 8 + j) >> 2] >> (8 * ((i * 8 + j) & 3))) & 0xff);
+  };
+  auto gather = [&](const uint4 (&w)[NW], double (&X)[8][3])
   {
     const int32_t v[8] = {int32_t(w[0].x), int32_t(w[0].y), int32_t(w[0].z), int32_t(w[0].w),
                           int32_t(w[1].x), int32_t(w[1].y), int32_t(w[1].z), int32_t(w[1].w)};
@@ -403,7 +488,7 @@ __global__ void __launch_bounds__(CUBE_MAX_THREADS) matrix_cube_kernel(mpcx_matr
   // Software pipeline, two slots deep: while slot t is computed, the 24 coordinates of slot t + NT and the
   // record of slot t + 2 NT are in flight (the kernel runs two waves per SIMD, so the latency of the
   // dependent chain record -> coordinates has to be covered inside the wave; 256 VGPRs are available)
-  uint4 cur[6], nxt[6];
+  uint4 cur[NW], nxt[NW];
   double X[8][3], Xn[8][3];
   int64_t t = e0 + tid;
   // the first records and coordinates travel while the block's LDS copy is cleared
@@ -423,8 +508,6 @@ __global__ void __launch_bounds__(CUBE_MAX_THREADS) matrix_cube_kernel(mpcx_matr
   {
     const int32_t v[8] = {int32_t(cur[0].x), int32_t(cur[0].y), int32_t(cur[0].z), int32_t(cur[0].w),
                           int32_t(cur[1].x), int32_t(cur[1].y), int32_t(cur[1].z), int32_t(cur[1].w)};
-    const uint32_t ow[16] = {cur[2].x, cur[2].y, cur[2].z, cur[2].w, cur[3].x, cur[3].y, cur[3].z, cur[3].w,
-                             cur[4].x, cur[4].y, cur[4].z, cur[4].w, cur[5].x, cur[5].y, cur[5].z, cur[5].w};
     const bool has_next = t + NT < e1;
     if (has_next)
       gather(nxt, Xn);
@@ -479,12 +562,12 @@ __global__ void __launch_bounds__(CUBE_MAX_THREADS) matrix_cube_kernel(mpcx_matr
           const double val = A[i][j];
           if (base[i] >= 0 && !(v[j] >> MASK_SHIFT))
           {
-            const int off = int((ow[(i * 8 + j) >> 2] >> (8 * ((i * 8 + j) & 3))) & 0xff);
+            const int off = offset_of(cur, i, j);
             __hip_atomic_fetch_add(s_vals + base[i] + off, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
           if (i != j && base[j] >= 0 && !(v[i] >> MASK_SHIFT))
           {
-            const int off = int((ow[(j * 8 + i) >> 2] >> (8 * ((j * 8 + i) & 3))) & 0xff);
+            const int off = offset_of(cur, j, i);
             __hip_atomic_fetch_add(s_vals + base[j] + off, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
         }
@@ -492,7 +575,7 @@ __global__ void __launch_bounds__(CUBE_MAX_THREADS) matrix_cube_kernel(mpcx_matr
     if (has_next)
     {
 #pragma unroll
-      for (int i = 0; i < 6; ++i)
+      for (int i = 0; i < NW; ++i)
         cur[i] = nxt[i];
 #pragma unroll
       for (int i = 0; i < 8; ++i)
@@ -537,7 +620,8 @@ __global__ void __launch_bounds__(CUBE_EL_THREADS) matrix_cube_elasticity_kernel
   if (b >= nb)
     return;
   const int tid = threadIdx.x;
-  const int r0 = a.plan.block_row0[b], r1 = a.plan.block_row0[b + 1];
+  const int bb = a.cube_block_ids ? a.cube_block_ids[b] : b;
+  const int r0 = a.plan.block_row0[bb], r1 = a.plan.block_row0[bb + 1];
   const int nrow = r1 - r0;
   const int64_t nnz0 = a.rowptr[r0];
   const int nnzb = int(a.rowptr[r1] - nnz0);
@@ -911,16 +995,25 @@ int launch_matrix_cubes(const mpcx_matrix_args_t& a)
   }();
   if (lds_floor > lds && lds_floor <= 160 * 1024)
     lds = lds_floor;
-  if (int rc = check(hipFuncSetAttribute(reinterpret_cast<const void*>(matrix_cube_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)),
-                     "hipFuncSetAttribute"))
+  const bool narrow = a.cube_rec_bytes == 64;
+  if (a.cube_rec_bytes != 0 && a.cube_rec_bytes != 64 && a.cube_rec_bytes != 96)
+  {
+    mpcx_set_error("mpcx_assemble_matrix: cube_rec_bytes must be 96 (or 0) or 64");
+    return -6;
+  }
+  const void* kern = narrow ? reinterpret_cast<const void*>(matrix_cube_kernel<true>)
+                            : reinterpret_cast<const void*>(matrix_cube_kernel<false>);
+  if (int rc = check(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)), "hipFuncSetAttribute"))
     return rc;
   const char* e = std::getenv("MPCX_CUBE_THREADS");
   int threads = e ? std::atoi(e) : 256;
   if (threads < 64 || threads > CUBE_MAX_THREADS || threads % 64)
     threads = 256;
   const unsigned grid = 8u * unsigned((a.plan.num_blocks + 7) / 8);
-  hipLaunchKernelGGL(matrix_cube_kernel, dim3(grid), dim3(threads), lds, static_cast<hipStream_t>(a.stream), a);
+  if (narrow)
+    hipLaunchKernelGGL(matrix_cube_kernel<true>, dim3(grid), dim3(threads), lds, static_cast<hipStream_t>(a.stream), a);
+  else
+    hipLaunchKernelGGL(matrix_cube_kernel<false>, dim3(grid), dim3(threads), lds, static_cast<hipStream_t>(a.stream), a);
   return check(hipGetLastError(), "matrix cluster kernel launch");
 }
 
@@ -991,6 +1084,25 @@ extern "C" int mpcx_cube_detect(const int32_t* cells, int64_t n_groups, int32_t*
   hipLaunchKernelGGL(mpcx::cube_detect_kernel, dim3(mpcx::grid_for(n_groups, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), cells, n_groups, verts, ok);
   return mpcx::check(hipGetLastError(), "cube_detect launch");
+}
+
+extern "C" int mpcx_cube_slot_width(int64_t n_slots, const void* recs, uint8_t* wide, void* stream)
+{
+  if (n_slots == 0)
+    return 0;
+  hipLaunchKernelGGL(mpcx::cube_slot_width_kernel, dim3(mpcx::grid_for(n_slots, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), n_slots, static_cast<const mpcx::CubeRec*>(recs), wide);
+  return mpcx::check(hipGetLastError(), "cube_slot_width launch");
+}
+
+extern "C" int mpcx_cube_pack_narrow(int64_t n_out, const int64_t* src, const void* recs, void* out, void* stream)
+{
+  if (n_out == 0)
+    return 0;
+  hipLaunchKernelGGL(mpcx::cube_pack_narrow_kernel, dim3(mpcx::grid_for(n_out, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), n_out, src, static_cast<const mpcx::CubeRec*>(recs),
+                     static_cast<mpcx::CubeRecNarrow*>(out));
+  return mpcx::check(hipGetLastError(), "cube_pack_narrow launch");
 }
 
 extern "C" int mpcx_cluster_keys(const double* x, const int32_t* cells, int64_t n_cells, int64_t* keys, void* stream)

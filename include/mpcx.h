@@ -214,6 +214,13 @@ typedef struct
    * num_blocks / max_rows / max_nnz / block_row0 / block_ent_off (slots per block), nothing else; n_entities is
    * ignored (the slots say what is assembled) */
   const void* cube_recs;
+  /* record format of THIS launch: 96 (or 0) = the records of mpcx_cube_records; 64 = narrow records (4-bit offsets,
+   * mpcx_cube_pack_narrow) for row blocks all of whose slots have offsets < 16.  cube_block_ids (DEVICE [plan.num_blocks],
+   * or NULL = blocks 0 .. num_blocks-1): the blocks this launch covers -- block j of the launch is row block
+   * cube_block_ids[j] of plan.block_row0, its slots are [plan.block_ent_off[j], plan.block_ent_off[j+1]) of cube_recs.
+   * The caller launches the narrow and the wide blocks separately (both with store_mode as for one launch). */
+  int32_t cube_rec_bytes;
+  const int32_t* cube_block_ids;
   /* rowblock, component-diagonal forms on blocked spaces (bs0 == bs1 = bs > 1), optional: DEVICE [nnz / bs^2], one
    * byte per bs x bs block of the CSR (block s of node row n = entries rowptr[n*bs] / bs^2 + s), bit k set = entry
    * (k, k) of the block is a Dirichlet / slave row or column and stays zero (mpcx_diag_slot_mask).  Given, the
@@ -275,6 +282,12 @@ int mpcx_scatter_offsets(const mpcx_nnz_t* rowptr, const int32_t* cols, int32_t 
 int mpcx_cube_records(int64_t n_slots, const int32_t* block_ents, const int32_t* cube_verts, int32_t bs, const int8_t* bc,
                       const int8_t* is_slave, const mpcx_nnz_t* rowptr, const int32_t* cols, void* recs,
                       int32_t* overflow, void* stream);
+
+/* Narrow records (all pointers DEVICE): mpcx_cube_slot_width: wide[k] = 1 if a coupled offset of record k exceeds 15;
+ * mpcx_cube_pack_narrow: out[j] (64 bytes: the 8 ids, then 46 nibbles in row-major order of the coupled pairs) from the
+ * 96-byte record src[j]. */
+int mpcx_cube_slot_width(int64_t n_slots, const void* recs, uint8_t* wide, void* stream);
+int mpcx_cube_pack_narrow(int64_t n_out, const int64_t* src, const void* recs, void* out, void* stream);
 
 /* Set-up for MPCX_ALG_CUBE (DEVICE): for every group g of six consecutive cells (x_dofmap rows 6g .. 6g+5)
  * verts[g][0..7] = the eight vertices read off the fan pattern, ok[g] = 1 if the six cells really form it. */

@@ -239,7 +239,8 @@ def test_small_cases_vector_kernel_variants(oracle, make, env, monkeypatch):
             _close(out[k], ref[k], RTOL_B, f"{case.name} {k} [{env}]")
 
 
-@pytest.mark.parametrize("env", ["MPCX_VCUBE_OWNER=0", "MPCX_VCUBE_OWNER=1", "MPCX_VCUBE_ROWS=256", "MPCX_CLUSTER_DETECT=consecutive"])
+@pytest.mark.parametrize("env", ["MPCX_VCUBE_OWNER=0", "MPCX_VCUBE_OWNER=1", "MPCX_VCUBE_ROWS=256", "MPCX_CLUSTER_DETECT=consecutive",
+                                 "MPCX_CUBE_NARROW=0", "MPCX_CUBE_MAX_ROWS=64"])
 @pytest.mark.parametrize("n,reorder,bc", [(4, None, 0.0), (6, (2, 2, 2), 2.3), (9, (4, 4, 4), 0.0)])
 def test_cluster_vector_kernel_variants(oracle, n, reorder, bc, env, monkeypatch):
     """the P1 source through the cell-cluster kernels (algorithm "auto"): owner-computes row blocks over the clusters
@@ -252,6 +253,22 @@ def test_cluster_vector_kernel_variants(oracle, n, reorder, bc, env, monkeypatch
     for k in ("b", "b_lifted"):
         _close(out[k], ref[k], RTOL_B, f"{case.name} {k} [{env}]")
     _close(out["A"].data, ref["A"].data, RTOL_A, f"{case.name} A [{env}]")
+
+
+def test_cluster_plan_uses_narrow_and_wide_records(oracle):
+    """the cluster plan keeps 64-byte records (4-bit offsets) for row blocks whose rows have at most 16 entries before
+    any cluster column and 96-byte records for the blocks with fat rows (the periodic master rows): both formats are
+    launched, and together they give the oracle's matrix"""
+    import dolfinx_mpc_amd as dm
+
+    case = case_cube_periodic(16, 1, 0.0, reorder=(4, 4, 4))
+    mpc = product_mpc(case)
+    A = dm.assemble_matrix(case.a, mpc, bcs=case.bcs)
+    (parts, _keep, info), = [v[1] for v in A._plans[("objcache", "cubes")].values()]
+    assert [p[2] for p in parts] == [64, 96], "narrow and wide row blocks expected"
+    assert 0 < info["narrow_blocks"] < info["num_blocks"]
+    ref = oracle.assemble_matrix(case.a, oracle_mpc(oracle, case), bcs=case.bcs, fast=True)
+    _close(A.to_scipy().data, ref.data, RTOL_A, "A (narrow + wide cluster records)")
 
 
 def test_cluster_vector_is_reproducible_without_device_atomics(oracle):
