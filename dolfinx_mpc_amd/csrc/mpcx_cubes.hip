@@ -975,7 +975,9 @@ int launch_matrix_cubes(const mpcx_matrix_args_t& a)
                    "elasticity on tetrahedra, without coefficients");
     return -10;
   }
-  if (!a.cube_recs || a.plan.num_blocks <= 0)
+  // (cube_recs may be NULL when none of this launch's row blocks has a slot -- ghost-row blocks of a slab mesh: the
+  // blocks are still written, as zeros)
+  if (a.plan.num_blocks <= 0 || !a.plan.block_row0 || !a.plan.block_ent_off)
   {
     mpcx_set_error("mpcx_assemble_matrix: the cluster algorithm needs records (mpcx_cube_records) and a row-block plan");
     return -3;
