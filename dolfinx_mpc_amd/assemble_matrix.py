@@ -781,7 +781,9 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
                     t.plan = plan
                     t.cube_recs, t.cube_rec_bytes, t.cube_block_ids = recs.data_ptr(), nbytes, D.ptr(ids)
                     if n_part == 1:
-                        t.n_slave_entities = 0  # the master contributions ride on the first launch
+                        # the master contributions ride on the LAST launch: the row blocks are written in store mode,
+                        # so they must all be in place before anything is added to them
+                        a.n_slave_entities = 0
                         t.leftover, t.kernel_name, t.block_scalar = None, name, False
                         a.second = t
                 keep += [ck]
