@@ -261,7 +261,7 @@ def test_cluster_plan_uses_narrow_and_wide_records(oracle):
     launched, and together they give the oracle's matrix"""
     import dolfinx_mpc_amd as dm
 
-    case = case_cube_periodic(16, 1, 0.0, reorder=(4, 4, 4))
+    case = case_cube_periodic(32, 1, 0.0, reorder=(8, 8, 8))  # 512-row blocks = tiles: only those at x = 0 hold master rows
     mpc = product_mpc(case)
     A = dm.assemble_matrix(case.a, mpc, bcs=case.bcs)
     (parts, _keep, info), = [v[1] for v in A._plans[("objcache", "cubes")].values()]
