@@ -220,6 +220,8 @@ EXPORTS = [
     "mpcx_cell_to_slaves_device",
     "mpcx_scan_exclusive_i32_i64",
     "mpcx_scan_exclusive_i32",
+    "mpcx_scan_exclusive_i64",
+    "mpcx_segment_offsets",
     "mpcx_sort_pairs_i64_i32",
     "mpcx_sort_pairs_i64_i64",
     "mpcx_run_heads",
@@ -314,6 +316,10 @@ def lib() -> C.CDLL:
     L.mpcx_scan_exclusive_i32_i64.restype = C.c_int
     L.mpcx_scan_exclusive_i32.argtypes = [vp, i64, vp, vp, szp, vp]
     L.mpcx_scan_exclusive_i32.restype = C.c_int
+    L.mpcx_scan_exclusive_i64.argtypes = [vp, i64, vp, vp, szp, vp]
+    L.mpcx_scan_exclusive_i64.restype = C.c_int
+    L.mpcx_segment_offsets.argtypes = [vp, i64, i32, i64, vp, vp]
+    L.mpcx_segment_offsets.restype = C.c_int
     L.mpcx_sort_pairs_i64_i32.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, szp, vp]
     L.mpcx_sort_pairs_i64_i32.restype = C.c_int
     L.mpcx_sort_pairs_i64_i64.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, szp, vp]

@@ -49,6 +49,30 @@ def scan_i32(counts):
     return out
 
 
+def scan_i64(counts):
+    """exclusive scan of an int64 tensor into int64 [n + 1]"""
+    import torch
+
+    L = _native.lib()
+    n = counts.numel()
+    out = torch.empty(n + 1, dtype=torch.int64, device=counts.device)
+    st = D.stream_ptr()
+    call = lambda t, nb: L.mpcx_scan_exclusive_i64(counts.data_ptr(), n, out.data_ptr(), t, nb, st)  # noqa: E731
+    temp, nb = _workspace(call, counts.device)
+    _native.check(call(temp.data_ptr(), C.byref(nb)), "mpcx_scan_exclusive_i64")
+    return out
+
+
+def segment_offsets(sorted_keys, shift: int, num_segments: int):
+    """int64 [num_segments + 1]: first position of every segment id (key >> shift) in a sorted key tensor"""
+    import torch
+
+    out = torch.empty(num_segments + 1, dtype=torch.int64, device=sorted_keys.device)
+    _native.check(_native.lib().mpcx_segment_offsets(sorted_keys.data_ptr(), sorted_keys.numel(), shift, num_segments,
+                                                     out.data_ptr(), D.stream_ptr()), "mpcx_segment_offsets")
+    return out
+
+
 def sort_pairs(keys, vals, end_bit: int = 64):
     """stable sort of (int64 key, int32 | int64 value) pairs by the key bits [0, end_bit); returns new tensors"""
     import torch

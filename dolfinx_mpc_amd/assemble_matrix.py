@@ -236,9 +236,13 @@ def _block_lists_device(row0: np.ndarray, n_entities: int, estride: int, entitie
     counts = torch.empty(max(n_entities, 1), dtype=torch.int32, device=dev)
     args = (n_entities, estride, entities_ptr, dofmap_dev.data_ptr(), nd, bs, nb, d_row0.data_ptr(), counts.data_ptr())
     _native.check(L.mpcx_rowblock_pairs_device(*args, None, None, None, None, 0, st), "mpcx_rowblock_pairs_device")
-    c64 = counts[:n_entities].to(torch.int64)
-    offsets = torch.cumsum(c64, 0) - c64
-    total = int(c64.sum().item()) if n_entities else 0
+    from . import _prims
+
+    # scans, the stable sort by block and the per-block offsets are rocPRIM behind the C ABI (mpcx_scan_exclusive_*,
+    # mpcx_sort_pairs_*, mpcx_segment_offsets); torch only allocates and forms the sort key
+    scan = _prims.scan_i32_i64(counts[:n_entities])
+    offsets = scan[:-1]
+    total = int(scan[-1].item()) if n_entities else 0
     pair_block = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
     pair_ent = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
     pair_rows = torch.empty(max(total, 1), dtype=torch.int32, device=dev) if group_rows else None
@@ -246,21 +250,21 @@ def _block_lists_device(row0: np.ndarray, n_entities: int, estride: int, entitie
         _native.check(L.mpcx_rowblock_pairs_device(*args, offsets.data_ptr(), pair_block.data_ptr(), pair_ent.data_ptr(),
                                                    D.ptr(pair_rows), int(rotate), st), "mpcx_rowblock_pairs_device")
     pair_block, pair_ent = pair_block[:total], pair_ent[:total]
-    per_block = torch.bincount(pair_block, minlength=nb) if total else torch.zeros(nb, dtype=torch.int64, device=dev)
-    off = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(per_block, 0, out=off[1:])
     if total:
         if group_rows:
             # entities that keep the same local rows next to each other: a wave then skips the rows of dofs outside
             # the block as a whole instead of issuing their scatter-adds with most lanes masked off
+            shift = nd
             key = (pair_block.to(torch.int64) << nd) | (pair_rows[:total].to(torch.int64) & ((1 << nd) - 1))
-            _, order = torch.sort(key, stable=True)
-            del key
         else:
-            _, order = torch.sort(pair_block, stable=True)
-        ents = pair_ent[order].contiguous()
+            shift = 0
+            key = pair_block.to(torch.int64)
+        key, ents = _prims.sort_pairs(key, pair_ent.contiguous(), shift + max(int(nb).bit_length(), 1))
+        off = _prims.segment_offsets(key, shift, nb)
+        del key
     else:
         ents = pair_ent
+        off = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
     return d_row0, off, ents
 
 
@@ -647,28 +651,30 @@ def _mpc_plan_device(A: MPCMatrix, form: Form, i: int, mpc0, mpc1, bc0_dev, bc1_
                                         D.ptr(offsets), D.ptr(pos), D.ptr(ent), D.ptr(pq), D.ptr(coef), st)
             _native.check(rc, "mpcx_mpc_plan_device")
 
+        from . import _prims
+
         call(None, None, None, None, None)
-        total = int(counts.sum().item())
+        scan = _prims.scan_i64(counts)  # (rocPRIM behind the C ABI, like the sort and the run-length step below)
+        total = int(scan[-1].item())
         if total > MPC_PLAN_MAX_TUPLES:
             return None
         z64 = torch.zeros(1, dtype=torch.int64, device=dev)
         if total == 0:
             return (z64, torch.zeros(2, dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.int32, device=dev),
                     torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.float64, device=dev), False)
-        offsets = torch.cumsum(counts, 0) - counts
+        offsets = scan[:-1]
         pos = torch.empty(total, dtype=torch.int64, device=dev)
         ent = torch.empty(total, dtype=torch.int32, device=dev)
         pq = torch.empty(total, dtype=torch.int32, device=dev)
         coef = torch.empty(total, dtype=torch.float64, device=dev)
         call(offsets, pos, ent, pq, coef)
-        pos, order = torch.sort(pos, stable=True)
+        # stable sort by target position (signed keys: the -1 of tuples outside the pattern come first)
+        pos, order = _prims.sort_pairs(pos, torch.arange(total, dtype=torch.int64, device=dev), 64)
         nneg = int((pos < 0).sum().item())  # tuples outside the pattern (none for a pattern built from the same constraint)
-        pos, order = pos[nneg:], order[nneg:]
+        pos, order = pos[nneg:].contiguous(), order[nneg:]
         if pos.numel() == 0:
             return (z64, torch.zeros(2, dtype=torch.int64, device=dev), ent[:1], pq[:1], coef[:1], False)
-        tgt, cnt = torch.unique_consecutive(pos, return_counts=True)
-        off = torch.zeros(tgt.numel() + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(cnt, 0, out=off[1:])
+        tgt, off = _prims.runs(pos)
         return (tgt, off, ent[order].contiguous(), pq[order].contiguous(), coef[order].contiguous(), True)
 
     return D.cached(A._plans, "mpc_plan_dev", (form, mpc0, mpc1, bc0_dev, bc1_dev), i, build)

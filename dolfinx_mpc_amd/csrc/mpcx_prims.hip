@@ -64,6 +64,30 @@ __global__ void run_fill_kernel(const int64_t* __restrict__ keys, const int32_t*
     run_start[excl[i] + heads[i]] = n;
 }
 
+// out[b] = first position whose (key >> shift) >= b, b = 0 .. num_segments (sorted keys): the offsets of the segments
+__global__ void segment_offsets_kernel(const int64_t* __restrict__ keys, int64_t n, int shift, int64_t num_segments,
+                                       int64_t* __restrict__ out)
+{
+  const int64_t b = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (b > num_segments)
+    return;
+  int64_t lo = 0, hi = n;
+  while (lo < hi)
+  {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((keys[mid] >> shift) < b)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  out[b] = lo;
+}
+__global__ void last_plus_kernel64(const int64_t* __restrict__ excl, const int64_t* __restrict__ in, int64_t n, int64_t* out_total)
+{
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    *out_total = n > 0 ? excl[n - 1] + in[n - 1] : 0;
+}
+
 // ---- MultiPointConstraint constructor -----------------------------------------------------------------------
 __global__ void mpc_mark_kernel(int32_t num_dofs, int32_t num_slaves, const int32_t* __restrict__ slaves,
                                 const int32_t* __restrict__ offsets, int8_t* __restrict__ is_slave,
@@ -215,6 +239,39 @@ extern "C" int mpcx_scan_exclusive_i32(const int32_t* in, int64_t n, int32_t* ou
       return rc;
   hipLaunchKernelGGL(last_plus_kernel32, dim3(1), dim3(1), 0, st, out, in, n, out + n);
   return check(hipGetLastError(), "scan total");
+}
+
+extern "C" int mpcx_scan_exclusive_i64(const int64_t* in, int64_t n, int64_t* out, void* temp, size_t* temp_bytes, void* stream)
+{
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  size_t need = 0;
+  if (int rc = check(rocprim::exclusive_scan(nullptr, need, in, out, int64_t(0), size_t(n > 0 ? n : 1), rocprim::plus<int64_t>(), st),
+                     "rocprim::exclusive_scan (size)"))
+    return rc;
+  if (!temp)
+  {
+    *temp_bytes = need;
+    return 0;
+  }
+  if (*temp_bytes < need)
+  {
+    mpcx_set_error("mpcx_scan_exclusive_i64: workspace too small");
+    return -3;
+  }
+  if (n > 0)
+    if (int rc = check(rocprim::exclusive_scan(temp, need, in, out, int64_t(0), size_t(n), rocprim::plus<int64_t>(), st),
+                       "rocprim::exclusive_scan"))
+      return rc;
+  hipLaunchKernelGGL(last_plus_kernel64, dim3(1), dim3(1), 0, st, out, in, n, out + n);
+  return check(hipGetLastError(), "scan total");
+}
+
+extern "C" int mpcx_segment_offsets(const int64_t* sorted_keys, int64_t n, int32_t shift, int64_t num_segments, int64_t* out,
+                                    void* stream)
+{
+  hipLaunchKernelGGL(segment_offsets_kernel, dim3(grid_for(num_segments + 1, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     sorted_keys, n, int(shift), num_segments, out);
+  return check(hipGetLastError(), "segment_offsets launch");
 }
 
 extern "C" int mpcx_sort_pairs_i64_i32(const int64_t* keys_in, int64_t* keys_out, const int32_t* vals_in, int32_t* vals_out,

@@ -454,6 +454,10 @@ int mpcx_cell_to_slaves_device(int64_t num_cells, int32_t nd, int32_t bs, const 
  * temp == NULL they only write the bytes they need to *temp_bytes (HOST pointer). */
 int mpcx_scan_exclusive_i32_i64(const int32_t* in, int64_t n, int64_t* out, void* temp, size_t* temp_bytes, void* stream);
 int mpcx_scan_exclusive_i32(const int32_t* in, int64_t n, int32_t* out, void* temp, size_t* temp_bytes, void* stream);
+int mpcx_scan_exclusive_i64(const int64_t* in, int64_t n, int64_t* out, void* temp, size_t* temp_bytes, void* stream);
+/* out[b] = first position of sorted_keys whose (key >> shift) >= b, for b = 0 .. num_segments (out has num_segments + 1
+ * entries): the segment offsets of a sorted (segment id << shift | ...) key array, empty segments included */
+int mpcx_segment_offsets(const int64_t* sorted_keys, int64_t n, int32_t shift, int64_t num_segments, int64_t* out, void* stream);
 int mpcx_sort_pairs_i64_i32(const int64_t* keys_in, int64_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n,
                             int32_t begin_bit, int32_t end_bit, void* temp, size_t* temp_bytes, void* stream);
 int mpcx_sort_pairs_i64_i64(const int64_t* keys_in, int64_t* keys_out, const int64_t* vals_in, int64_t* vals_out, int64_t n,
