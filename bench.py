@@ -72,10 +72,13 @@ def poisson_workload(args, rank, world, degree):
     N = args.n
     reorder = None if args.no_tile else tuple(args.tile)
     zmax = 1.0
+    cell = "hexahedron" if getattr(args, "cell", "tet") == "hex" else "tetrahedron"
+    if cell == "hexahedron" and (world > 1 or degree != 1):
+        raise SystemExit("--cell hex: config 2 (Q1) on one GPU")
     if world == 1:
         numbering = getattr(args, "numbering", "tiled")
         if numbering == "tiled":
-            mesh = create_box((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), (N, N, N), "tetrahedron", reorder)
+            mesh = create_box((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), (N, N, N), cell, reorder)
         else:
             # a mesh as a file may deliver it: nodes renumbered at random, cells shuffled (the cluster kernels must
             # not depend on the generator's cell order); "spatial": put back in order by
@@ -83,7 +86,7 @@ def poisson_workload(args, rank, world, degree):
             from dolfinx_mpc_amd.mesh import renumber, reorder_spatial
 
             rng = np.random.default_rng(0)
-            mesh = create_box((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), (N, N, N), "tetrahedron", None)
+            mesh = create_box((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), (N, N, N), cell, None)
             mesh = renumber(mesh, rng.permutation(mesh.num_nodes), rng.permutation(mesh.num_cells))
             if numbering == "spatial":
                 mesh = reorder_spatial(mesh)
@@ -113,8 +116,8 @@ def poisson_workload(args, rank, world, degree):
     w = Workload()
     w.mesh, w.V, w.bcs = mesh, V, [bc]
     ufcx = getattr(args, "ufcx", None)
-    if ufcx and degree != 1:
-        raise SystemExit("--ufcx: config 2 (P1)")
+    if ufcx and (degree != 1 or cell == "hexahedron"):
+        raise SystemExit("--ufcx: config 2 (P1 tets; hexahedra always run generated UFCx kernels)")
     if ufcx == "files":
         # the reference's real seam: element kernels as UFCx C text (cpp/assemble_matrix.cpp:438-439), compiled for
         # gfx950 with hipRTC and run inside the LDS row-block kernels.  tests/ufcx/laplace_p1_tet.c (closed form) and
@@ -128,8 +131,7 @@ def poisson_workload(args, rank, world, degree):
     elif ufcx == "generated":
         # the benchmark's own forms (bench_periodic.py:84-91) the way FFCx would emit them: baked tables, a loop over
         # the rule, libm sin / exp in the right-hand side (tools/ffcx_like.py)
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        from ffcx_like import BENCH_PERIODIC_F, generate
+        from dolfinx_mpc_amd.codegen import BENCH_PERIODIC_F, generate
 
         from dolfinx_mpc_amd.quadrature import make_quadrature
 
@@ -148,6 +150,11 @@ def poisson_workload(args, rank, world, degree):
     w.config = {"workload": f"periodic-BC Poisson, P{degree} tets, {n_glob[0]}x{n_glob[1]}x{n_glob[2]} cubes on "
                             f"[0,1]^2x[0,{zmax:g}], fp64 (BASELINE configs[{1 if degree == 1 else 4}])",
                 "slaves_per_gpu": int(mpc.slaves.size)}
+    if cell == "hexahedron":
+        w.config["workload"] = (f"periodic-BC Poisson, Q1 hexahedra (bench_periodic.py's default cell), {N}^3 cells, fp64 -- the "
+                                f"secondary variant of BASELINE configs[1] (SURVEY 8, config 2 note), NOT the headline config")
+        w.config["element_kernels"] = ("generated UFCx C text (dolfinx_mpc_amd/codegen.py generate_hex: trilinear geometry, 8-point "
+                                       "stiffness, 27-point source with libm sin/exp) compiled with hipRTC")
     if ufcx:
         w.config["element_kernels"] = ("imported UFCx C text compiled with hipRTC: " + (
             "tests/ufcx/laplace_p1_tet.c + source_p1_tet.c (P1 coefficient, constant, 14-point rule)" if ufcx == "files" else
@@ -450,6 +457,9 @@ def main():
     ap.add_argument("--numbering", choices=["tiled", "shuffled", "spatial"], default="tiled",
                     help="configs 2 / 5 on one GPU: 'tiled' = the generator's tile-wise numbering (default), 'shuffled' = nodes "
                          "and cells in random order, 'spatial' = the shuffled mesh after mesh.reorder_spatial")
+    ap.add_argument("--cell", choices=["tet", "hex"], default="tet",
+                    help="config 2 only: hex = Q1 hexahedra, the reference script's default cell (secondary variant; the headline "
+                         "metric is quoted on tets)")
     ap.add_argument("--ufcx", choices=["files", "generated"], default=None,
                     help="config 2 with IMPORTED element kernels (UFCx C text -> hipRTC -> LDS row-block kernels): "
                          "'files' = tests/ufcx/laplace_p1_tet.c + source_p1_tet.c, 'generated' = the benchmark's own forms "

@@ -30,7 +30,8 @@ FORM_UFCX = 100  # an imported UFCx tabulate_tensor (C source), include/mpcx.h m
 
 CELL_TRIANGLE = 1
 CELL_TETRAHEDRON = 2
-_CELL_ID = {"triangle": CELL_TRIANGLE, "tetrahedron": CELL_TETRAHEDRON}
+CELL_HEXAHEDRON = 3  # Q1 only, element kernels imported as UFCx C text (codegen.generate_hex)
+_CELL_ID = {"triangle": CELL_TRIANGLE, "tetrahedron": CELL_TETRAHEDRON, "hexahedron": CELL_HEXAHEDRON}
 
 # analytic right-hand sides (evaluated at physical quadrature points)
 FN_ONE = 0
@@ -63,7 +64,8 @@ class DofMap:
 
 
 def _lagrange_ndofs(cell_name: str, degree: int) -> int:
-    return {("tetrahedron", 1): 4, ("tetrahedron", 2): 10, ("triangle", 1): 3, ("triangle", 2): 6}[(cell_name, degree)]
+    return {("tetrahedron", 1): 4, ("tetrahedron", 2): 10, ("triangle", 1): 3, ("triangle", 2): 6,
+            ("hexahedron", 1): 8}[(cell_name, degree)]
 
 
 def kuhn_edge_global_ids(ga: np.ndarray, gb: np.ndarray, n1, num_global_nodes: int) -> np.ndarray:
@@ -82,7 +84,7 @@ def kuhn_edge_global_ids(ga: np.ndarray, gb: np.ndarray, n1, num_global_nodes: i
 
 
 class FunctionSpace:
-    """Lagrange P1/P2 space, optionally blocked (``shape=(bs,)``)."""
+    """Lagrange P1/P2 space on simplices, Q1 on hexahedra, optionally blocked (``shape=(bs,)``)."""
 
     def __init__(self, mesh: Mesh, element=("Lagrange", 1), shape: Optional[tuple] = None):
         family, degree = element[0], int(element[1])
@@ -90,6 +92,8 @@ class FunctionSpace:
             raise NotImplementedError(f"element family {family}")
         if degree not in (1, 2):
             raise NotImplementedError("only Lagrange degree 1 and 2")
+        if mesh.cell_name == "hexahedron" and degree != 1:
+            raise NotImplementedError("hexahedra: Q1 only")
         self.mesh = mesh
         self.degree = degree
         bs = 1 if not shape else int(shape[0])
@@ -193,10 +197,10 @@ class FunctionSpace:
                     and np.array_equal(self.dofmap.list, self.mesh.geometry.dofmap):
                 self._dof_coords = x
             else:
-                from .mesh import TET_EDGES, TRI_EDGES
+                from .mesh import local_edges
 
-                le = TET_EDGES if self.mesh.tdim == 3 else TRI_EDGES
-                nv = self.mesh.tdim + 1
+                le = local_edges(self.mesh.cell_name)
+                nv = self.mesh.geometry.dofmap.shape[1]
                 xc = x[self.mesh.geometry.dofmap]  # (nc, nv, 3)
                 out = np.empty((self.dofmap.list.max() + 1, 3))
                 out[self.dofmap.list[:, :nv]] = xc
@@ -331,14 +335,13 @@ def locate_dofs_topological(V: FunctionSpace, entity_dim: int, entities: np.ndar
     """Blocked dofs in the closure of the given facets, (cell, local_facet) pairs
     (python/benchmarks/bench_contact_3D.py:222 ``locate_dofs_topological(V, fdim, mt.find(5))``):
     the facet's vertices and, for P2, the edges between them."""
-    from .mesh import TET_EDGES, TET_FACETS, TRI_EDGES, TRI_FACETS
+    from .mesh import local_edges, local_facets
 
     mesh = V.mesh
     assert entity_dim == mesh.tdim - 1, "facets only"
     ents = np.asarray(entities, dtype=np.int64).reshape(-1, 2)
-    lf = TET_FACETS if mesh.tdim == 3 else TRI_FACETS
-    le = TET_EDGES if mesh.tdim == 3 else TRI_EDGES
-    nv = mesh.tdim + 1
+    lf, le = local_facets(mesh.cell_name), local_edges(mesh.cell_name)
+    nv = mesh.geometry.dofmap.shape[1]
     out = []
     for f in range(lf.shape[0]):
         sel = ents[ents[:, 1] == f, 0]
@@ -497,9 +500,37 @@ def _facet_kernel(V: FunctionSpace, form: int, qdeg: int, fn_id: int = 0) -> Ker
     return KernelSpec(form, _CELL_ID[name], V.degree, V.dofmap.bs, fn_id, 0, fqpts=q, fqwts=w)
 
 
+_FN_EXPR = {FN_ONE: "1.0", FN_LINEAR: "1.0 + x[0] + 2.0 * x[1] + 3.0 * x[2]"}
+
+
+def _hex_form(V, kind: str, constant=None, coefficient: Optional[Function] = None, cells=None, fn_id: int = FN_ONE,
+              quadrature_degree: Optional[int] = None) -> Form:
+    """Forms on hexahedra: the element kernel is generated as UFCx C text (codegen.generate_hex: Q1, trilinear
+    geometry, tensor Gauss rule) and imported like an FFCx kernel -- there is no built-in hexahedron kernel."""
+    from .codegen import BENCH_PERIODIC_F, gauss_hex, generate_hex
+
+    if coefficient is not None:
+        Vc = coefficient.function_space
+        assert Vc.mesh is V.mesh and Vc.degree == 1 and Vc.dofmap.bs == 1, "hexahedra: scalar Q1 coefficients"
+    if kind == "source":
+        fexpr = BENCH_PERIODIC_F if fn_id == FN_BENCH_PERIODIC else _FN_EXPR[fn_id]
+        qdeg = (1 + _FN_DEGREE[fn_id]) if quadrature_degree is None else quadrature_degree
+    else:
+        fexpr, qdeg = "1.0", (2 if quadrature_degree is None else quadrature_degree)
+    if coefficient is not None:
+        qdeg += 1
+    src, name = generate_hex(kind, V.dofmap.bs, gauss_hex(qdeg), use_constant=constant is not None and kind != "elasticity",
+                             fexpr=fexpr, coefficient=coefficient is not None)
+    name_q = f"{name}_f{fn_id}"
+    src = src.replace(name, name_q)
+    return form_ufcx([V] if kind == "source" else [V, V], src, name_q, "cell", cells, coefficient, constant)
+
+
 def form_stiffness(V, constant=None, coefficient: Optional[Function] = None, cells=None) -> Form:
     """a(u, v) = c * w * inner(grad(u), grad(v)) dx  (bench_periodic.py:84;
     test_mpc_pipeline.py:45 with coefficient and constant)."""
+    if V.mesh.cell_name == "hexahedron":
+        return _hex_form(V, "stiffness", constant, coefficient, cells)
     cells = _cells_or_all(V.mesh, cells)
     cd = _coefficient_degree(coefficient)
     k = _cell_kernel(V, FORM_STIFFNESS, 2 * (V.degree - 1) + cd, coeff_degree=cd)
@@ -507,6 +538,8 @@ def form_stiffness(V, constant=None, coefficient: Optional[Function] = None, cel
 
 
 def form_mass(V, constant=None, coefficient: Optional[Function] = None, cells=None) -> Form:
+    if V.mesh.cell_name == "hexahedron":
+        return _hex_form(V, "mass", constant, coefficient, cells)
     cells = _cells_or_all(V.mesh, cells)
     cd = _coefficient_degree(coefficient)
     k = _cell_kernel(V, FORM_MASS, 2 * V.degree + cd, coeff_degree=cd)
@@ -517,6 +550,8 @@ def form_elasticity(V, mu: float, lmbda: float, cells=None) -> Form:
     """a(u, v) = inner(sigma(u), grad(v)) dx, sigma = 2 mu eps(u) + lambda tr(eps(u)) I
     (python/benchmarks/bench_contact_3D.py:257-269)."""
     assert V.dofmap.bs == V.mesh.tdim
+    if V.mesh.cell_name == "hexahedron":
+        return _hex_form(V, "elasticity", np.array([mu, lmbda], dtype=np.float64), None, cells)
     cells = _cells_or_all(V.mesh, cells)
     k = _cell_kernel(V, FORM_ELASTICITY, 2 * (V.degree - 1))
     return Form([V, V], [Integral("cell", cells, k, None, np.array([mu, lmbda], dtype=np.float64))])
@@ -545,6 +580,8 @@ def form_source(V, fn_id: int = FN_ONE, constant=None, coefficient: Optional[Fun
                 quadrature_degree: Optional[int] = None) -> Form:
     """L(v) = c * w * inner(f, v) dx with analytic f (bench_periodic.py:85-91).
     Non-polynomial f: estimated degree +2 per UFL's rule -> P1: 5."""
+    if V.mesh.cell_name == "hexahedron":
+        return _hex_form(V, "source", constant, coefficient, cells, fn_id, quadrature_degree)
     cells = _cells_or_all(V.mesh, cells)
     cd = _coefficient_degree(coefficient)
     fdeg = _FN_DEGREE[fn_id]

@@ -26,6 +26,21 @@ _KUHN = np.array(
 )
 
 
+# hexahedron, DOLFINx (tensor-product) vertex order: vertex v has (x, y, z) bits (v & 1, v >> 1 & 1, v >> 2 & 1)
+HEX_FACETS = np.array([[0, 1, 2, 3], [0, 1, 4, 5], [0, 2, 4, 6], [1, 3, 5, 7], [2, 3, 6, 7], [4, 5, 6, 7]], dtype=np.int64)
+HEX_EDGES = np.array(
+    [[0, 1], [0, 2], [0, 4], [1, 3], [1, 5], [2, 3], [2, 6], [3, 7], [4, 5], [4, 6], [5, 7], [6, 7]], dtype=np.int64
+)
+
+
+def local_facets(cell_name: str) -> np.ndarray:
+    return {"tetrahedron": TET_FACETS, "triangle": TRI_FACETS, "hexahedron": HEX_FACETS}[cell_name]
+
+
+def local_edges(cell_name: str) -> np.ndarray:
+    return {"tetrahedron": TET_EDGES, "triangle": TRI_EDGES, "hexahedron": HEX_EDGES}[cell_name]
+
+
 class Geometry:
     """``x`` (num_nodes, 3) float64 and ``dofmap`` (num_cells, nv) int32.
 
@@ -61,13 +76,14 @@ class Geometry:
 
 
 class Mesh:
-    """Single-process mesh: affine simplices, one geometry dofmap."""
+    """Single-process mesh, one geometry dofmap: affine simplices, or trilinear hexahedra (Q1 spaces, element
+    kernels generated as UFCx C text -- dolfinx_mpc_amd/codegen.py)."""
 
     def __init__(self, x: np.ndarray, cells: np.ndarray, cell_name: str):
-        assert cell_name in ("triangle", "tetrahedron")
+        assert cell_name in ("triangle", "tetrahedron", "hexahedron")
         self.geometry = Geometry(np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(cells, dtype=np.int32))
         self.cell_name = cell_name
-        self.tdim = 3 if cell_name == "tetrahedron" else 2
+        self.tdim = 2 if cell_name == "triangle" else 3
         self._exterior_facets = None
         self._edges = None
         self._device = {}
@@ -92,14 +108,18 @@ class Mesh:
         the reference's exterior-facet domains (cpp/assemble_matrix.cpp:343-348)."""
         if self._exterior_facets is None:
             cells = self.geometry.dofmap.astype(np.int64)
-            lf = TET_FACETS if self.tdim == 3 else TRI_FACETS
+            lf = local_facets(self.cell_name)
             nc, nf = cells.shape[0], lf.shape[0]
-            fv = np.sort(cells[:, lf], axis=2).reshape(nc * nf, -1)  # (nc*nf, tdim)
+            fv = np.sort(cells[:, lf], axis=2).reshape(nc * nf, -1)  # (nc*nf, vertices per facet)
             nn = self.num_nodes
-            key = fv[:, 0]
-            for k in range(1, fv.shape[1]):
-                key = key * nn + fv[:, k]
-            _, inv, cnt = np.unique(key, return_inverse=True, return_counts=True)
+            if float(nn) ** fv.shape[1] < 2.0**62:
+                key = fv[:, 0]
+                for k in range(1, fv.shape[1]):
+                    key = key * nn + fv[:, k]
+                _, inv, cnt = np.unique(key, return_inverse=True, return_counts=True)
+            else:
+                _, inv, cnt = np.unique(fv, axis=0, return_inverse=True, return_counts=True)
+                inv = inv.reshape(-1)
             ext = np.flatnonzero(cnt[inv] == 1)
             out = np.empty((ext.size, 2), dtype=np.int32)
             out[:, 0] = ext // nf
@@ -108,7 +128,7 @@ class Mesh:
         return self._exterior_facets
 
     def facet_midpoints(self, facets: np.ndarray) -> np.ndarray:
-        lf = TET_FACETS if self.tdim == 3 else TRI_FACETS
+        lf = local_facets(self.cell_name)
         verts = self.geometry.dofmap[facets[:, 0]][np.arange(facets.shape[0])[:, None], lf[facets[:, 1]]]
         return self.geometry.x[verts].mean(axis=1)
 
@@ -122,7 +142,7 @@ class Mesh:
         """Global edge numbering: returns (cell_edges (nc, ne) int32, edge_vertices (nE, 2))."""
         if self._edges is None:
             cells = self.geometry.dofmap.astype(np.int64)
-            le = TET_EDGES if self.tdim == 3 else TRI_EDGES
+            le = local_edges(self.cell_name)
             ev = np.sort(cells[:, le], axis=2).reshape(-1, 2)
             key = ev[:, 0] * self.num_nodes + ev[:, 1]
             uniq, inv = np.unique(key, return_inverse=True)
@@ -162,14 +182,16 @@ def _tile_starts(tid_new: np.ndarray) -> np.ndarray:
 
 
 def create_box(p0, p1, n, cell_type: str = "tetrahedron", reorder: tuple | None = None) -> Mesh:
-    """Box mesh of ``n = (nx, ny, nz)`` cubes, each split into 6 tets.
+    """Box mesh of ``n = (nx, ny, nz)`` cubes, each split into 6 tets (``cell_type="tetrahedron"``) or kept as one
+    hexahedron (``"hexahedron"``, the default cell of python/benchmarks/bench_periodic.py:38,199-200).
 
     Node index ``(k*(ny+1) + j)*(nx+1) + i`` (x fastest); cells follow cube
     order (x fastest), 6 consecutive tets per cube.  ``reorder=(tx,ty,tz)``
     renumbers nodes and cells tile by tile (DOLFINx also reorders for locality;
     numbering is not part of the reference's contract).
     """
-    assert cell_type == "tetrahedron"
+    assert cell_type in ("tetrahedron", "hexahedron")
+    per_cube, nvc = (6, 4) if cell_type == "tetrahedron" else (1, 8)
     nx, ny, nz = n
     xs = np.linspace(p0[0], p1[0], nx + 1)
     ys = np.linspace(p0[1], p1[1], ny + 1)
@@ -181,7 +203,7 @@ def create_box(p0, p1, n, cell_type: str = "tetrahedron", reorder: tuple | None 
     corner = np.empty((base.size, 8), dtype=np.int64)
     for b in range(8):
         corner[:, b] = base + (b & 1) + ((b >> 1) & 1) * (nx + 1) + ((b >> 2) & 1) * (nx + 1) * (ny + 1)
-    cells = corner[:, _KUHN].reshape(-1, 4)
+    cells = corner[:, _KUHN].reshape(-1, 4) if cell_type == "tetrahedron" else corner
     if reorder is not None:
         perm = _tile_permutation((nx + 1, ny + 1, nz + 1), reorder)
         xn = np.empty_like(x)
@@ -191,10 +213,10 @@ def create_box(p0, p1, n, cell_type: str = "tetrahedron", reorder: tuple | None 
         # cells tile by tile as well (tile of the cube's lower corner)
         cperm = _tile_permutation((nx, ny, nz), reorder)  # old cube -> new cube
         order = np.argsort(cperm, kind="stable")  # new cube -> old cube
-        cells = cells.reshape(-1, 6, 4)[order].reshape(-1, 4)
+        cells = cells.reshape(-1, per_cube, nvc)[order].reshape(-1, nvc)
         tid_new = np.empty(perm.size, dtype=np.int64)
         tid_new[perm] = _tile_ids((nx + 1, ny + 1, nz + 1), reorder)
-    mesh = Mesh(x, cells.astype(np.int32), "tetrahedron")
+    mesh = Mesh(x, cells.astype(np.int32), cell_type)
     if reorder is not None:
         mesh.node_tile_offsets = _tile_starts(tid_new)
     return mesh

@@ -201,23 +201,41 @@ def renumbered(mesh, numbering: str, seed: int = 0):
     return reorder_spatial(mesh, tile_nodes=64) if numbering == "spatial" else mesh
 
 
-def case_cube_periodic(N=4, degree=1, bc_value=0.0, reorder=None, numbering=None) -> Case:
-    """python/benchmarks/bench_periodic.py:35-110 (BASELINE configs 1/2 at small N)"""
-    mesh = create_unit_cube(N, N, N, reorder=reorder)
+def warped(mesh, amplitude=0.15):
+    """the same mesh with interior nodes moved by a smooth field (faces of the unit cube stay put, so that the
+    geometric markers of the cases keep working): hexahedra become genuinely trilinear, tets stay affine"""
+    x = mesh.geometry.x.copy()
+    bump = np.sin(np.pi * x[:, 0]) * np.sin(np.pi * x[:, 1]) * np.sin(np.pi * x[:, 2])
+    x[:, 0] += amplitude * bump * np.sin(2.0 * x[:, 1] + 1.0) / 3.0
+    x[:, 1] += amplitude * bump * np.cos(3.0 * x[:, 2]) / 3.0
+    x[:, 2] += amplitude * bump * np.sin(1.0 + 2.0 * x[:, 0]) / 3.0
+    mesh.geometry.x = x
+    return mesh
+
+
+def case_cube_periodic(N=4, degree=1, bc_value=0.0, reorder=None, numbering=None, cell_type="tetrahedron", warp=False) -> Case:
+    """python/benchmarks/bench_periodic.py:35-110 (BASELINE configs 1/2 at small N); ``cell_type="hexahedron"`` is
+    the script's own default cell (:38, :199-200)"""
+    mesh = create_unit_cube(N, N, N, cell_type, reorder=reorder)
+    if warp:
+        mesh = warped(mesh)
     if numbering is not None:
         mesh = renumbered(mesh, numbering)
     V = fem.functionspace(mesh, ("Lagrange", degree))
     dofs = fem.locate_dofs_geometrical(V, _walls_yz)
     bc = fem.dirichletbc(bc_value, dofs, V)
     tag = ("" if reorder is None else "_tiled") + ("" if numbering is None else "_" + numbering)
+    tag += ("" if cell_type == "tetrahedron" else "_hex") + ("_warped" if warp else "")
     return Case(f"cube_periodic_p{degree}_n{N}_bc{bc_value:g}{tag}", V, fem.form_stiffness(V),
                 fem.form_source(V, fem.FN_BENCH_PERIODIC), [bc], periodic_raw(V, [bc]))
 
 
-def case_cube_elasticity_slip(N=3, numbering=None) -> Case:
-    """vector P1 tets, slip constraint u.n = 0 on x=1 with a tilted normal
+def case_cube_elasticity_slip(N=3, numbering=None, cell_type="tetrahedron", warp=False) -> Case:
+    """vector P1 tets (or Q1 hexahedra), slip constraint u.n = 0 on x=1 with a tilted normal
     (cpp/SlipConstraint.h:115-166 output shape: 1 slave + bs-1 same-block masters)"""
-    mesh = create_unit_cube(N, N, N)
+    mesh = create_unit_cube(N, N, N, cell_type)
+    if warp:
+        mesh = warped(mesh)
     if numbering is not None:
         mesh = renumbered(mesh, numbering)
     V = fem.functionspace(mesh, ("Lagrange", 1, (3,)))
@@ -240,7 +258,8 @@ def case_cube_elasticity_slip(N=3, numbering=None) -> Case:
            np.zeros(len(masters), dtype=np.int32), np.array(offsets, dtype=np.int32))
     a = fem.form_elasticity(V, 1.0e3 / 2, 0.0)  # bench_contact_3D.py:257-269: E=1e3, nu=0
     L = fem.form_source(V, fem.FN_LINEAR)
-    return Case(f"cube_elasticity_slip_n{N}" + ("" if numbering is None else "_" + numbering), V, a, L, [bc], raw)
+    tag = ("" if numbering is None else "_" + numbering) + ("" if cell_type == "tetrahedron" else "_hex") + ("_warped" if warp else "")
+    return Case(f"cube_elasticity_slip_n{N}{tag}", V, a, L, [bc], raw)
 
 
 def case_cube_contact_like(N=3) -> Case:

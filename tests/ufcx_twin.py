@@ -1,5 +1,5 @@
 """The small parity cases with their cell integrals re-expressed as IMPORTED UFCx kernels (C text written by
-tools/ffcx_like.py in the shape FFCx gives its output: baked tables + quadrature loop), so that the whole parity
+dolfinx_mpc_amd/codegen.py in the shape FFCx gives its output: baked tables + quadrature loop), so that the whole parity
 suite also runs through the reference's real seam -- a ``tabulate_tensor`` per integral
 (cpp/assemble_matrix.cpp:438-439) -- on every kernel variant.  The oracle side keeps the built-in operators: the
 comparison pins the generated kernels against them as well."""
@@ -10,11 +10,8 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
-
-from ffcx_like import BENCH_PERIODIC_F, generate  # noqa: E402
-
 from dolfinx_mpc_amd import fem  # noqa: E402
+from dolfinx_mpc_amd.codegen import BENCH_PERIODIC_F, generate  # noqa: E402
 
 PI = "3.14159265358979323846"
 FN_C = {
