@@ -155,7 +155,8 @@ def integral_device(form: Form, i: int):
         # cell integral over cells 0..n-1 in order: the kernels skip the indirection (and nothing is uploaded)
         n = integ.entities.shape[0]
         ident = integ.itype == "cell" and n > 0 and int(integ.entities[0]) == 0 and int(integ.entities[-1]) == n - 1 and \
-            bool(np.array_equal(integ.entities, np.arange(n, dtype=integ.entities.dtype)))
+            (integ.entities is getattr(form.mesh, "_all_cells", None)
+             or bool(np.array_equal(integ.entities, np.arange(n, dtype=integ.entities.dtype))))
         d = {
             "entities": None if ident else _to_dev(integ.entities.astype(np.int32).reshape(-1), dev),
             "coeffs": None,

@@ -226,6 +226,11 @@ EXPORTS = [
     "mpcx_sort_pairs_i64_i64",
     "mpcx_run_heads",
     "mpcx_run_fill",
+    "mpcx_block_ranges",
+    "mpcx_owner_plan_count",
+    "mpcx_owner_plan_keys",
+    "mpcx_owner_plan_halo",
+    "mpcx_low_word_iota",
     "mpcx_pattern_build",
     "mpcx_pattern_nnz",
     "mpcx_pattern_nrows",
@@ -328,6 +333,16 @@ def lib() -> C.CDLL:
     L.mpcx_run_heads.restype = C.c_int
     L.mpcx_run_fill.argtypes = [vp, vp, vp, i64, vp, vp, vp]
     L.mpcx_run_fill.restype = C.c_int
+    L.mpcx_block_ranges.argtypes = [i32, vp, i32, i32, i32, vp, i32, vp, i64]
+    L.mpcx_block_ranges.restype = i64
+    L.mpcx_owner_plan_count.argtypes = [i64, i32, vp, i32, i32, vp, vp, vp, vp, vp]
+    L.mpcx_owner_plan_count.restype = C.c_int
+    L.mpcx_owner_plan_keys.argtypes = [i64, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.mpcx_owner_plan_keys.restype = C.c_int
+    L.mpcx_owner_plan_halo.argtypes = [i64, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp]
+    L.mpcx_owner_plan_halo.restype = C.c_int
+    L.mpcx_low_word_iota.argtypes = [i64, vp, vp, vp, vp]
+    L.mpcx_low_word_iota.restype = C.c_int
     L.mpcx_pattern_build.argtypes = [i64, vp, i32, i32, i32, vp, i32, i32, i32] + [vp] * 8 + [i32]
     L.mpcx_pattern_build.restype = vp
     L.mpcx_pattern_nnz.argtypes = [vp]

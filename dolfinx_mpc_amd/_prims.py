@@ -91,15 +91,18 @@ def sort_pairs(keys, vals, end_bit: int = 64):
     return ko, vo
 
 
-def runs(sorted_keys, want_keys: bool = True):
-    """run-length structure of a sorted int64 tensor: (run_keys [nr] or None, run_start int64 [nr + 1])"""
+def runs(sorted_keys, want_keys: bool = True, want_marks: bool = False):
+    """run-length structure of a sorted int64 tensor: (run_keys [nr] or None, run_start int64 [nr + 1]); with
+    ``want_marks`` also (heads int32 [n], their exclusive scan int64 [n + 1]): element t lies in run
+    ``scan[t] + heads[t] - 1``"""
     import torch
 
     L = _native.lib()
     n = sorted_keys.numel()
     dev = sorted_keys.device
     if n == 0:
-        return (torch.empty(0, dtype=torch.int64, device=dev) if want_keys else None), torch.zeros(1, dtype=torch.int64, device=dev)
+        out = (torch.empty(0, dtype=torch.int64, device=dev) if want_keys else None), torch.zeros(1, dtype=torch.int64, device=dev)
+        return out + (torch.empty(0, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)) if want_marks else out
     st = D.stream_ptr()
     heads = torch.empty(n, dtype=torch.int32, device=dev)
     _native.check(L.mpcx_run_heads(sorted_keys.data_ptr(), n, heads.data_ptr(), st), "mpcx_run_heads")
@@ -109,4 +112,4 @@ def runs(sorted_keys, want_keys: bool = True):
     rs = torch.empty(nr + 1, dtype=torch.int64, device=dev)
     _native.check(L.mpcx_run_fill(sorted_keys.data_ptr(), heads.data_ptr(), excl.data_ptr(), n, D.ptr(rk), rs.data_ptr(), st),
                   "mpcx_run_fill")
-    return rk, rs
+    return (rk, rs, heads, excl) if want_marks else (rk, rs)

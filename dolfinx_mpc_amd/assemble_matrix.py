@@ -204,20 +204,18 @@ def _slave_entities(form: Form, i: int, mpc0, mpc1):
 
 
 def _block_ranges(nrows: int, rowptr: np.ndarray, max_rows: int, max_nnz: int, bs: int, hints) -> np.ndarray:
-    """contiguous row ranges of a row-block plan (host: one greedy pass over rowptr), block_row0 [nb + 1]"""
+    """contiguous row ranges of a row-block plan (host: one greedy pass over rowptr), block_row0 [nb + 1];
+    ``rowptr=None``: one entry per row (the vector plans)"""
     L = _native.lib()
     p = _native._ptr
-    h = L.mpcx_rowblock_plan_build(nrows, p(rowptr), max_rows, max_nnz, 0, 1, None, None, 1, bs,
-                                   None if hints is None else p(hints), 0 if hints is None else hints.size, 1)
-    if not h:
-        raise RuntimeError("mpcx_rowblock_plan_build failed: " + L.mpcx_last_error().decode())
-    try:
-        nb = L.mpcx_rowblock_plan_num_blocks(h)
-        row0 = np.empty(nb + 1, dtype=np.int32)
-        off = np.empty(nb + 1, dtype=np.int64)
-        L.mpcx_rowblock_plan_copy(h, p(row0), p(off), None)
-    finally:
-        L.mpcx_rowblock_plan_free(h)
+    hp, hn = (None, 0) if hints is None else (p(hints), hints.size)
+    rp = None if rowptr is None else p(rowptr)
+    nb = L.mpcx_block_ranges(nrows, rp, max_rows, max_nnz, bs, hp, hn, None, 0)
+    if nb < 0:
+        raise RuntimeError("mpcx_block_ranges failed: " + L.mpcx_last_error().decode())
+    row0 = np.empty(nb + 1, dtype=np.int32)
+    if L.mpcx_block_ranges(nrows, rp, max_rows, max_nnz, bs, hp, hn, p(row0), row0.size) != nb:
+        raise RuntimeError("mpcx_block_ranges failed: " + L.mpcx_last_error().decode())
     return row0
 
 

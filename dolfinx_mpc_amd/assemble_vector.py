@@ -92,7 +92,75 @@ def _build_vector_owner_plan(form: Form, i: int, V, md0, rows: int):
 
 def _owner_plan_from_rows(mrow, V, rows: int):
     """owner-computes plan for ``n`` work items whose masked dof rows are ``mrow`` (n, nd) (dof | flags << 28): the
-    entities of an integral, or the cell clusters of the mesh with their eight vertices"""
+    entities of an integral, or the cell clusters of the mesh with their eight vertices.  Built through the C ABI
+    (include/mpcx.h mpcx_owner_plan_*: three fused passes over the table; rocPRIM scans / sorts between them); torch
+    allocates.  ``MPCX_OWNER_PLAN=torch``: the same plan from torch gathers / searches (kept as the cross-check)."""
+    import torch
+
+    from . import _prims
+    from .assemble_matrix import _block_ranges
+
+    n, nd = mrow.shape
+    if os.environ.get("MPCX_OWNER_PLAN", "") == "torch" or n * nd >= 2 ** 31 or n == 0:
+        return _owner_plan_from_rows_torch(mrow, V, rows)
+    bs = V.dofmap.bs
+    nrows = V.num_dofs
+    hints = None
+    if V.dof_tile_offsets is not None:
+        hints = np.ascontiguousarray(V.dof_tile_offsets.astype(np.int32) * bs)
+    row0 = _block_ranges(nrows, None, rows, rows, bs, hints)
+    nb = row0.size - 1
+    dev = _native.require_gpu()
+    L = _native.lib()
+    st = D.stream_ptr()
+    d_row0 = D._to_dev(row0, dev)
+    mrow = mrow.contiguous()
+    i32, i64 = torch.int32, torch.int64
+    owner = torch.empty(n, dtype=i64, device=dev)
+    item = torch.empty(n, dtype=i32, device=dev)
+    fcount = torch.empty(n, dtype=i32, device=dev)
+    _native.check(L.mpcx_owner_plan_count(n, nd, mrow.data_ptr(), bs, nb, d_row0.data_ptr(), owner.data_ptr(), item.data_ptr(),
+                                          fcount.data_ptr(), st), "mpcx_owner_plan_count")
+    foff = _prims.scan_i32_i64(fcount)
+    nf = int(foff[-1].item())
+    del fcount
+    sorted_owner, order = _prims.sort_pairs(owner, item, max(int(nb).bit_length(), 1))
+    off = _prims.segment_offsets(sorted_owner, 0, nb)
+    del sorted_owner, item
+    keys = torch.empty(max(nf, 1), dtype=i64, device=dev)
+    src = torch.empty(max(nf, 1), dtype=i32, device=dev)
+    lmap = torch.empty((n, nd), dtype=i32, device=dev)
+    _native.check(L.mpcx_owner_plan_keys(n, nd, mrow.data_ptr(), bs, nb, d_row0.data_ptr(), owner.data_ptr(), foff.data_ptr(),
+                                         keys.data_ptr(), src.data_ptr(), lmap.data_ptr(), st), "mpcx_owner_plan_keys")
+    del owner, foff
+    keys, src = _prims.sort_pairs(keys[:nf], src[:nf], 32 + max(int(nb).bit_length(), 1))
+    ukey, _, heads, hscan = _prims.runs(keys, want_keys=True, want_marks=True)
+    nu = ukey.numel()
+    hoff = _prims.segment_offsets(ukey, 32, nb)
+    max_rows_d = torch.zeros(1, dtype=i32, device=dev)
+    _native.check(L.mpcx_owner_plan_halo(nf, D.ptr(keys), D.ptr(src), D.ptr(heads), D.ptr(hscan), hoff.data_ptr(), nb,
+                                         d_row0.data_ptr(), bs, mrow.data_ptr(), lmap.data_ptr(), max_rows_d.data_ptr(), st),
+                  "mpcx_owner_plan_halo")
+    max_rows = int(max_rows_d.item())
+    if max_rows > VECTOR_LDS_ROWS:
+        return None
+    del keys, src, heads, hscan
+    # spill order: the halo entries sorted by dof (stable); runs of one dof are reduced into its row of b
+    low = torch.empty(max(nu, 1), dtype=i64, device=dev)
+    iota = torch.empty(max(nu, 1), dtype=i32, device=dev)
+    _native.check(L.mpcx_low_word_iota(nu, D.ptr(ukey), low.data_ptr(), iota.data_ptr(), st), "mpcx_low_word_iota")
+    sdof, sorder = _prims.sort_pairs(low[:nu], iota[:nu], max(int(nrows // bs).bit_length(), 1))
+    urows64, seg = _prims.runs(sdof, want_keys=True)
+    urows = urows64.to(i32).contiguous()
+    spill = torch.zeros(max(nu, 1) * bs, dtype=torch.float64, device=dev)
+    t = (d_row0, off, order, lmap, hoff, spill, sorder, urows, seg)
+    plan = _native.RowBlockPlanT(nb, max_rows, max_rows, 0, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), None, None)
+    return (plan, t, int(urows.numel()))
+
+
+def _owner_plan_from_rows_torch(mrow, V, rows: int):
+    """the owner-computes plan from torch gathers / searchsorted / unique (cross-check of the C-ABI builder; also taken
+    when item * nd + i does not fit 32 bits)"""
     import torch
 
     from .assemble_matrix import _block_ranges
@@ -104,7 +172,7 @@ def _owner_plan_from_rows(mrow, V, rows: int):
     hints = None
     if V.dof_tile_offsets is not None:
         hints = np.ascontiguousarray(V.dof_tile_offsets.astype(np.int32) * bs)
-    row0 = _block_ranges(nrows, np.arange(nrows + 1, dtype=np.int64), rows, rows, bs, hints)
+    row0 = _block_ranges(nrows, None, rows, rows, bs, hints)
     nb = row0.size - 1
     dev = _native.require_gpu()
     d_row0 = D._to_dev(row0, dev)

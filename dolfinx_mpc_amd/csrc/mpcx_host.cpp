@@ -310,36 +310,38 @@ struct RowBlockPlan
 };
 } // namespace
 
-extern "C" void* mpcx_rowblock_plan_build(int32_t nrows, const mpcx_nnz_t* rowptr, int32_t max_rows,
-                                          int32_t max_nnz, int64_t n_entities, int32_t estride,
-                                          const int32_t* entities0, const int32_t* dofmap0,
-                                          int32_t nd0, int32_t bs0, const int32_t* row_hints,
-                                          int32_t n_hints, int32_t num_threads)
+namespace
 {
-  (void)num_threads;
-  auto* P = new RowBlockPlan;
-  // greedy contiguous partition, boundaries on dof-block (bs0) multiples; a
-  // block is cut at the last hinted row (tile start of the numbering) inside
-  // its capacity window so that blocks do not straddle tiles
-  P->block_row0.push_back(0);
+// greedy contiguous partition of the rows, boundaries on dof-block (bs0) multiples; a block is cut at the last hinted
+// row (tile start of the numbering) inside its capacity window so that blocks do not straddle tiles.
+// rowptr == NULL: one entry per row (the vector plans).  Returns false when a single dof block exceeds the capacity.
+bool greedy_block_ranges(int32_t nrows, const mpcx_nnz_t* rowptr, int32_t max_rows, int32_t max_nnz, int32_t bs0,
+                         const int32_t* row_hints, int32_t n_hints, std::vector<int32_t>& block_row0)
+{
+  block_row0.clear();
+  block_row0.push_back(0);
   int32_t r0 = 0;
   int32_t h = 0; // first hint > r0
   while (r0 < nrows)
   {
     int32_t r1 = r0;
-    while (r1 < nrows)
+    if (!rowptr)
     {
-      const int32_t rn = std::min(r1 + bs0, nrows);
-      if (rn - r0 > max_rows || rowptr[rn] - rowptr[r0] > max_nnz)
-        break;
-      r1 = rn;
+      const int32_t cap = std::min(max_rows, max_nnz);
+      r1 = std::min(nrows, r0 + (cap / bs0) * bs0);
+      if (nrows - r0 <= cap)
+        r1 = nrows;
     }
+    else
+      while (r1 < nrows)
+      {
+        const int32_t rn = std::min(r1 + bs0, nrows);
+        if (rn - r0 > max_rows || rowptr[rn] - rowptr[r0] > max_nnz)
+          break;
+        r1 = rn;
+      }
     if (r1 == r0)
-    {
-      mpcx_set_error("mpcx_rowblock_plan_build: a single dof block exceeds the block capacity");
-      delete P;
-      return nullptr;
-    }
+      return false;
     if (row_hints && r1 < nrows)
     {
       while (h < n_hints && row_hints[h] <= r0)
@@ -350,8 +352,45 @@ extern "C" void* mpcx_rowblock_plan_build(int32_t nrows, const mpcx_nnz_t* rowpt
       if (cut > r0 && cut % bs0 == 0)
         r1 = cut;
     }
-    P->block_row0.push_back(r1);
+    block_row0.push_back(r1);
     r0 = r1;
+  }
+  return true;
+}
+} // namespace
+
+extern "C" int64_t mpcx_block_ranges(int32_t nrows, const mpcx_nnz_t* rowptr, int32_t max_rows, int32_t max_nnz, int32_t bs,
+                                     const int32_t* row_hints, int32_t n_hints, int32_t* block_row0, int64_t capacity)
+{
+  if (nrows < 0 || max_rows <= 0 || max_nnz <= 0 || bs <= 0)
+  {
+    mpcx_set_error("mpcx_block_ranges: invalid arguments");
+    return -1;
+  }
+  std::vector<int32_t> r;
+  if (!greedy_block_ranges(nrows, rowptr, max_rows, max_nnz, bs, row_hints, n_hints, r))
+  {
+    mpcx_set_error("mpcx_block_ranges: a single dof block exceeds the block capacity");
+    return -1;
+  }
+  if (block_row0 && int64_t(r.size()) <= capacity)
+    std::memcpy(block_row0, r.data(), r.size() * sizeof(int32_t));
+  return int64_t(r.size()) - 1;
+}
+
+extern "C" void* mpcx_rowblock_plan_build(int32_t nrows, const mpcx_nnz_t* rowptr, int32_t max_rows,
+                                          int32_t max_nnz, int64_t n_entities, int32_t estride,
+                                          const int32_t* entities0, const int32_t* dofmap0,
+                                          int32_t nd0, int32_t bs0, const int32_t* row_hints,
+                                          int32_t n_hints, int32_t num_threads)
+{
+  (void)num_threads;
+  auto* P = new RowBlockPlan;
+  if (!greedy_block_ranges(nrows, rowptr, max_rows, max_nnz, bs0, row_hints, n_hints, P->block_row0))
+  {
+    mpcx_set_error("mpcx_rowblock_plan_build: a single dof block exceeds the block capacity");
+    delete P;
+    return nullptr;
   }
   const int32_t nb = static_cast<int32_t>(P->block_row0.size()) - 1;
   // dof block -> row block

@@ -1,0 +1,195 @@
+// Owner-computes plan of the row-block VECTOR kernels (include/mpcx.h, mpcx_vector_args_t::own_*) built on the device
+// through the C ABI: every work item (an entity of the integral, or a cell cluster with its eight vertices) belongs to
+// the row block that holds the rows of its local dof 0; the dofs of other blocks its items touch are the block's halo,
+// appended to its LDS copy.  Three fused passes over the (item, local dof) table replace a chain of full-size
+// gathers / searches / index puts; scans, sorts and run lengths in between are mpcx_prims.hip's (rocPRIM).
+//   mpcx_owner_plan_count   owner block of every item (as sort key) + its number of foreign dofs
+//   mpcx_owner_plan_keys    (block << 32 | dof, item * nd + i) of every foreign dof; local map of the own dofs
+//   mpcx_owner_plan_halo    local map of the foreign dofs from the sorted, run-numbered keys
+// The reference has no counterpart: its vector loop adds into the global array (cpp/assemble_vector.cpp:60-110).
+#include "mpcx.h"
+#include "mpcx_internal.h"
+
+#include <hip/hip_runtime.h>
+#include <string>
+
+namespace
+{
+inline int check(hipError_t err, const char* what)
+{
+  if (err != hipSuccess)
+  {
+    mpcx_set_error(std::string(what) + ": " + hipGetErrorString(err));
+    return -100;
+  }
+  return 0;
+}
+inline unsigned grid_for(int64_t n, int block) { return static_cast<unsigned>((n + block - 1) / block); }
+
+constexpr int32_t DOF_MASK = (1 << 28) - 1;
+
+// largest b in [0, nb) with row0[b] <= row
+__device__ inline int32_t find_block(const int32_t* __restrict__ row0, int32_t nb, int32_t row)
+{
+  int32_t lo = 0, hi = nb; // row0[lo] <= row < row0[hi]
+  while (hi - lo > 1)
+  {
+    const int32_t mid = (lo + hi) >> 1;
+    if (row0[mid] <= row)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+__global__ void owner_count_kernel(int64_t n, int nd, const int32_t* __restrict__ mrow, int bs, int32_t nb,
+                                   const int32_t* __restrict__ row0, int64_t* __restrict__ owner_key,
+                                   int32_t* __restrict__ item, int32_t* __restrict__ fcount)
+{
+  const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= n)
+    return;
+  const int32_t* d = mrow + e * nd;
+  const int32_t own = find_block(row0, nb, (d[0] & DOF_MASK) * bs);
+  int32_t c = 0;
+  for (int i = 1; i < nd; ++i)
+  {
+    const int32_t row = (d[i] & DOF_MASK) * bs;
+    c += (row < row0[own] || row >= row0[own + 1]) ? 1 : 0;
+  }
+  owner_key[e] = own;
+  item[e] = static_cast<int32_t>(e);
+  fcount[e] = c;
+}
+
+__global__ void owner_keys_kernel(int64_t n, int nd, const int32_t* __restrict__ mrow, int bs, int32_t nb,
+                                  const int32_t* __restrict__ row0, const int64_t* __restrict__ owner_key,
+                                  const int64_t* __restrict__ foff, int64_t* __restrict__ keys, int32_t* __restrict__ src,
+                                  int32_t* __restrict__ lmap)
+{
+  const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= n)
+    return;
+  const int32_t* d = mrow + e * nd;
+  const int32_t own = static_cast<int32_t>(owner_key[e]);
+  const int32_t r0 = row0[own], r1 = row0[own + 1];
+  int64_t at = foff[e];
+  for (int i = 0; i < nd; ++i)
+  {
+    const int32_t dof = d[i] & DOF_MASK;
+    const int32_t row = dof * bs;
+    if (row >= r0 && row < r1)
+      lmap[e * nd + i] = (dof - r0 / bs) | (d[i] & ~DOF_MASK);
+    else
+    {
+      keys[at] = (int64_t(own) << 32) | int64_t(dof);
+      src[at] = static_cast<int32_t>(e * nd + i);
+      ++at;
+    }
+  }
+}
+
+__global__ void owner_halo_kernel(int64_t nf, const int64_t* __restrict__ keys, const int32_t* __restrict__ src,
+                                  const int32_t* __restrict__ heads, const int64_t* __restrict__ heads_scan,
+                                  const int64_t* __restrict__ hoff, const int32_t* __restrict__ row0, int bs,
+                                  const int32_t* __restrict__ mrow, int32_t* __restrict__ lmap)
+{
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= nf)
+    return;
+  const int64_t uid = heads_scan[t] + heads[t] - 1; // index of this element's run among the distinct (block, dof) keys
+  const int32_t blk = static_cast<int32_t>(keys[t] >> 32);
+  const int32_t nown = (row0[blk + 1] - row0[blk]) / bs;
+  const int32_t s = src[t];
+  lmap[s] = static_cast<int32_t>(nown + (uid - hoff[blk])) | (mrow[s] & ~DOF_MASK);
+}
+
+// rows (own + halo) of the largest block, times bs
+__global__ void owner_max_rows_kernel(int32_t nb, const int32_t* __restrict__ row0, const int64_t* __restrict__ hoff, int bs,
+                                      int32_t* __restrict__ out)
+{
+  const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb)
+    return;
+  const int32_t rows = (row0[b + 1] - row0[b]) + static_cast<int32_t>(hoff[b + 1] - hoff[b]) * bs;
+  atomicMax(out, rows);
+}
+
+// low 32 bits of every key as an int64 sort key + iota payload (the spill order of the halo rows)
+__global__ void low_word_iota_kernel(int64_t n, const int64_t* __restrict__ keys, int64_t* __restrict__ low, int32_t* __restrict__ iota)
+{
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n)
+    return;
+  low[t] = keys[t] & 0xffffffffLL;
+  iota[t] = static_cast<int32_t>(t);
+}
+} // namespace
+
+extern "C" int mpcx_owner_plan_count(int64_t n, int32_t nd, const int32_t* mrow, int32_t bs, int32_t nb, const int32_t* row0,
+                                     int64_t* owner_key, int32_t* item, int32_t* fcount, void* stream)
+{
+  if (n < 0 || nd <= 0 || bs <= 0 || nb <= 0 || !mrow || !row0 || !owner_key || !item || !fcount)
+  {
+    mpcx_set_error("mpcx_owner_plan_count: invalid arguments");
+    return -1;
+  }
+  if (n == 0)
+    return 0;
+  owner_count_kernel<<<grid_for(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(n, nd, mrow, bs, nb, row0, owner_key, item,
+                                                                                       fcount);
+  return check(hipGetLastError(), "mpcx_owner_plan_count");
+}
+
+extern "C" int mpcx_owner_plan_keys(int64_t n, int32_t nd, const int32_t* mrow, int32_t bs, int32_t nb, const int32_t* row0,
+                                    const int64_t* owner_key, const int64_t* foff, int64_t* keys, int32_t* src, int32_t* lmap,
+                                    void* stream)
+{
+  if (n < 0 || nd <= 0 || bs <= 0 || nb <= 0 || !mrow || !row0 || !owner_key || !foff || !lmap)
+  {
+    mpcx_set_error("mpcx_owner_plan_keys: invalid arguments");
+    return -1;
+  }
+  if (n * nd >= (int64_t(1) << 31))
+  {
+    mpcx_set_error("mpcx_owner_plan_keys: item * nd + i does not fit 32 bits");
+    return -2;
+  }
+  if (n == 0)
+    return 0;
+  owner_keys_kernel<<<grid_for(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(n, nd, mrow, bs, nb, row0, owner_key, foff,
+                                                                                      keys, src, lmap);
+  return check(hipGetLastError(), "mpcx_owner_plan_keys");
+}
+
+extern "C" int mpcx_owner_plan_halo(int64_t nf, const int64_t* sorted_keys, const int32_t* sorted_src, const int32_t* heads,
+                                    const int64_t* heads_scan, const int64_t* hoff, int32_t nb, const int32_t* row0, int32_t bs,
+                                    const int32_t* mrow, int32_t* lmap, int32_t* max_rows, void* stream)
+{
+  if (nf < 0 || nb <= 0 || !hoff || !row0 || !max_rows || (nf > 0 && (!sorted_keys || !sorted_src || !heads || !heads_scan || !mrow || !lmap)))
+  {
+    mpcx_set_error("mpcx_owner_plan_halo: invalid arguments");
+    return -1;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (nf > 0)
+    owner_halo_kernel<<<grid_for(nf, 256), 256, 0, st>>>(nf, sorted_keys, sorted_src, heads, heads_scan, hoff, row0, bs, mrow, lmap);
+  if (int rc = check(hipMemsetAsync(max_rows, 0, sizeof(int32_t), st), "mpcx_owner_plan_halo"))
+    return rc;
+  owner_max_rows_kernel<<<grid_for(nb, 256), 256, 0, st>>>(nb, row0, hoff, bs, max_rows);
+  return check(hipGetLastError(), "mpcx_owner_plan_halo");
+}
+
+extern "C" int mpcx_low_word_iota(int64_t n, const int64_t* keys, int64_t* low, int32_t* iota, void* stream)
+{
+  if (n < 0 || (n > 0 && (!keys || !low || !iota)))
+  {
+    mpcx_set_error("mpcx_low_word_iota: invalid arguments");
+    return -1;
+  }
+  if (n == 0)
+    return 0;
+  low_word_iota_kernel<<<grid_for(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(n, keys, low, iota);
+  return check(hipGetLastError(), "mpcx_low_word_iota");
+}

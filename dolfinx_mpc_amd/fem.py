@@ -476,8 +476,16 @@ def _coefficient_degree(coefficient: Optional[Function]) -> int:
 
 def _cells_or_all(mesh: Mesh, cells) -> np.ndarray:
     if cells is None:
-        # owned cells only, like a DOLFINx Form's default cell domain
-        return np.arange(mesh.num_owned_cells, dtype=np.int32)
+        # owned cells only, like a DOLFINx Form's default cell domain: ONE read-only array 0..n-1 per mesh -- consumers
+        # recognise the object (``entities is mesh._all_cells``) and skip the entity indirection without comparing
+        # 100 M indices
+        n = mesh.num_owned_cells
+        cached = getattr(mesh, "_all_cells", None)
+        if cached is None or cached.shape[0] != n:
+            cached = np.arange(n, dtype=np.int32)
+            cached.flags.writeable = False
+            mesh._all_cells = cached
+        return cached
     return np.ascontiguousarray(cells, dtype=np.int32)
 
 

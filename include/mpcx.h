@@ -512,6 +512,37 @@ int mpcx_pattern_device_rows(int32_t num_blocks0, const int64_t* adj_off, const 
                              int32_t* row_count, const mpcx_nnz_t* rowptr, int32_t bs0, int32_t* cols,
                              int32_t* overflow, void* stream);
 
+/* Only the row ranges of a row-block plan (HOST): block_row0[0..nb] into the caller's array of `capacity` entries;
+ * returns nb (call with block_row0 == NULL to learn it), -1 on error.  rowptr == NULL: one entry per row (plans of
+ * the vector kernels: max_rows rows per block). */
+int64_t mpcx_block_ranges(int32_t nrows, const mpcx_nnz_t* rowptr, int32_t max_rows, int32_t max_nnz, int32_t bs,
+                          const int32_t* row_hints, int32_t n_hints, int32_t* block_row0, int64_t capacity);
+
+/* Owner-computes plan of the row-block vector kernels (mpcx_vector_args_t::own_*) on the DEVICE (csrc/mpcx_plans.hip).
+ * Work item e (an entity, or a cell cluster) has nd dofs mrow[e*nd + i] = dof | flags << 28 and belongs to the block that
+ * holds the rows of its dof 0; dofs of other blocks are the block's halo, numbered after its own dofs in ascending dof
+ * order.  Steps (scans / sorts / run lengths between them: mpcx_scan_exclusive_*, mpcx_sort_pairs_*, mpcx_run_heads):
+ *   1. mpcx_owner_plan_count: owner_key[e] = block (int64: the sort key of the item order), item[e] = e,
+ *      fcount[e] = number of its dofs outside the block;
+ *   2. foff = exclusive scan of fcount;  (owner_key, item) sorted by key -> item order, block offsets;
+ *   3. mpcx_owner_plan_keys: keys[foff[e] + k] = block << 32 | dof, src = e*nd + i of every foreign dof;
+ *      lmap[e*nd + i] = (dof - first dof of the block) | flags for the own ones;
+ *   4. (keys, src) sorted; heads / heads_scan = mpcx_run_heads + exclusive scan; the DISTINCT keys are the halo
+ *      entries, hoff = their offsets per block (mpcx_segment_offsets with shift 32);
+ *   5. mpcx_owner_plan_halo: lmap[src] = (own dofs of the block + rank of the key inside the block) | flags;
+ *      *max_rows = rows (own + halo) of the largest block;
+ *   6. spill order: mpcx_low_word_iota(distinct keys) -> (dof, index) sorted by dof; runs of equal dof are the rows
+ *      mpcx_vector_args_t::spill_* reduces. */
+int mpcx_owner_plan_count(int64_t n, int32_t nd, const int32_t* mrow, int32_t bs, int32_t nb, const int32_t* block_row0,
+                          int64_t* owner_key, int32_t* item, int32_t* fcount, void* stream);
+int mpcx_owner_plan_keys(int64_t n, int32_t nd, const int32_t* mrow, int32_t bs, int32_t nb, const int32_t* block_row0,
+                         const int64_t* owner_key, const int64_t* foff, int64_t* keys, int32_t* src, int32_t* lmap,
+                         void* stream);
+int mpcx_owner_plan_halo(int64_t nf, const int64_t* sorted_keys, const int32_t* sorted_src, const int32_t* heads,
+                         const int64_t* heads_scan, const int64_t* hoff, int32_t nb, const int32_t* block_row0, int32_t bs,
+                         const int32_t* mrow, int32_t* lmap, int32_t* max_rows, void* stream);
+int mpcx_low_word_iota(int64_t n, const int64_t* keys, int64_t* low, int32_t* iota, void* stream);
+
 /* Row-block plan for MPCX_ALG_ROWBLOCK: contiguous row ranges with at most
  * max_rows rows / max_nnz nonzeros, and for each block the entities whose
  * test-space cell has a dof in it.  `row_hints` (sorted row indices, may be

@@ -221,6 +221,40 @@ def test_small_cases_kernel_variants(oracle, make, alg, env, monkeypatch):
     _close(out["A"].data, ref["A"].data, RTOL_A, f"{case.name} A [{env}]")
 
 
+@pytest.mark.parametrize("rows", [64, 1000])
+@pytest.mark.parametrize("idx", [0, 8, 12, 15, 19, 22, 25])
+def test_owner_plan_through_the_c_abi_equals_the_torch_builder(idx, rows):
+    """the owner-computes vector plan from libmpcx (mpcx_owner_plan_*: fused passes + rocPRIM) is, array by array, the
+    plan the torch gathers / searches / unique build"""
+    import importlib
+
+    import torch
+
+    from dolfinx_mpc_amd import _device as D
+
+    av = importlib.import_module("dolfinx_mpc_amd.assemble_vector")
+    case = CASES[idx]()
+    if case.L is None:
+        pytest.skip("no linear form")
+    V = case.V
+    mpc = product_mpc(case)
+    sd = D.space_device(V)
+    nd = V.element_ndofs
+    flag = torch.zeros(sd["dofmap"].numel(), dtype=torch.int32, device=sd["dofmap"].device)
+    flag[::3] = 1 << 28  # any flag pattern: the builder carries the bits through
+    mrow = (sd["dofmap"].view(-1) | flag).view(-1, nd)[: case.L.integrals[0].num_entities].contiguous()
+    a = av._owner_plan_from_rows(mrow, V, rows * V.dofmap.bs)
+    b = av._owner_plan_from_rows_torch(mrow, V, rows * V.dofmap.bs)
+    assert (a is None) == (b is None)
+    if a is None:
+        return
+    assert a[2] == b[2] and a[0].num_blocks == b[0].num_blocks and a[0].max_rows == b[0].max_rows
+    names = ("row0", "off", "order", "lmap", "hoff", "spill", "sorder", "urows", "seg")
+    for name, x, y in zip(names, a[1], b[1]):
+        assert x.shape == y.shape and torch.equal(x.to(torch.int64), y.to(torch.int64)), f"{case.name}: {name}"
+    del mpc
+
+
 @pytest.mark.parametrize("env", ["MPCX_VECTOR_OWNER=1", "MPCX_VECTOR_OWNER=0"])
 @pytest.mark.parametrize("make", CASES, ids=[f"case{i}" for i in range(len(CASES))])
 def test_small_cases_vector_kernel_variants(oracle, make, env, monkeypatch):
@@ -240,7 +274,7 @@ def test_small_cases_vector_kernel_variants(oracle, make, env, monkeypatch):
 
 
 @pytest.mark.parametrize("env", ["MPCX_VCUBE_OWNER=0", "MPCX_VCUBE_OWNER=1", "MPCX_VCUBE_ROWS=256", "MPCX_CLUSTER_DETECT=consecutive",
-                                 "MPCX_CUBE_NARROW=0", "MPCX_CUBE_MAX_ROWS=64"])
+                                 "MPCX_CUBE_NARROW=0", "MPCX_CUBE_MAX_ROWS=64", "MPCX_OWNER_PLAN=torch"])
 @pytest.mark.parametrize("n,reorder,bc", [(4, None, 0.0), (6, (2, 2, 2), 2.3), (9, (4, 4, 4), 0.0)])
 def test_cluster_vector_kernel_variants(oracle, n, reorder, bc, env, monkeypatch):
     """the P1 source through the cell-cluster kernels (algorithm "auto"): owner-computes row blocks over the clusters
