@@ -122,6 +122,8 @@ class MatrixArgs(C.Structure):
         ("mpc_plan_group", C.c_int32),
         ("block_vals", C.c_void_p),
         ("mpc_plan_out", C.c_void_p),
+        ("slave_tensors", C.c_void_p),
+        ("mpc_plan_slot", C.c_void_p),
         ("stream", C.c_void_p),
     ]
 

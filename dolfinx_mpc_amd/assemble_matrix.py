@@ -618,6 +618,17 @@ def _mpc_plan(A: MPCMatrix, form: Form, i: int, mpc0, mpc1, bc0_h, bc1_h, slave_
 MPC_PLAN_MAX_TUPLES = int(float(os.environ.get("MPCX_MPC_PLAN_MAX_TUPLES", 2.5e8)))
 
 
+# scratch for the element tensors of the slave entities of an imported kernel (one per matrix; above this the tuples
+# re-tabulate their entity)
+SLAVE_TENSOR_BYTES = int(float(os.environ.get("MPCX_SLAVE_TENSOR_BYTES", 4e9)))
+
+
+def _empty_f64(n: int, dev):
+    import torch
+
+    return torch.empty(max(int(n), 1), dtype=torch.float64, device=dev)
+
+
 def _mpc_plan_device(A: MPCMatrix, form: Form, i: int, mpc0, mpc1, bc0_dev, bc1_dev, slave_ents_dev):
     """The same plan built by the HIP kernel ``mpc_plan_device_kernel`` (include/mpcx.h mpcx_mpc_plan_device):
     count -> scan -> fill, then a stable sort by target position and a run-length pass (torch: plumbing).
@@ -748,6 +759,20 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
          a.mpc_plan_coef) = (t.data_ptr() for t in mplan[:5])
         mean = mplan[2].numel() / max(mplan[0].numel(), 1)  # tuples per target position
         a.mpc_plan_group = 16 if mean > 10 else (4 if mean > 2.5 else 1)
+        if integ.kernel.form == 100 and a.mpc_plan_targets > 0 and os.environ.get("MPCX_SLAVE_TENSORS", "1") != "0" \
+                and a.n_slave_entities * n0n1 * 8 <= SLAVE_TENSOR_BYTES:
+            # imported kernel: every slave entity's tensor once per call into a scratch array, the plan's tuples read
+            # their entry from it (include/mpcx.h mpcx_matrix_args_t::slave_tensors)
+            def slots():
+                import torch
+
+                return torch.searchsorted(slave_ents.to(torch.int64), mplan[2].to(torch.int64)).to(torch.int32).contiguous()
+
+            slot = D.cached(A._plans, "mpc_plan_slot", (mplan[2], slave_ents), i, slots)
+            scratch = D.cached(A._plans, "slave_tensors", (), (a.n_slave_entities, n0n1),
+                               lambda: _empty_f64(a.n_slave_entities * n0n1, A.device), maxsize=2)
+            a.mpc_plan_slot, a.slave_tensors = slot.data_ptr(), scratch.data_ptr()
+            mplan = tuple(mplan) + (slot, scratch)
     a.algorithm = alg
     a.store_mode = store_mode
     a.stream = D.stream_ptr()

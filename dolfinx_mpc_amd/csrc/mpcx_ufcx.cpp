@@ -480,6 +480,42 @@ extern "C" __global__ void __launch_bounds__(64) ufcx_matrix_mpc_plan_kernel(mpc
   if (lane == 0)
     a.vals[a.mpc_plan_tgt[t]] += sum;
 }
+
+// The same with every slave entity tabulated once (slave_tensors + mpc_plan_slot, include/mpcx.h): a thread per slave
+// entity stores its tensor entry-major (coalesced), then G lanes per target sum coef * entry over the target's tuples.
+extern "C" __global__ void __launch_bounds__(64) ufcx_slave_tensors_kernel(mpcx_matrix_args_t a)
+{
+  const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= a.n_slave_entities)
+    return;
+  const long long e = a.slave_entities[s];
+  const long long l = e * a.estride;
+  const long long cell = a.entities ? a.entities[l] : e;
+  const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
+  double cd[NV * 3];
+  gather(a.x, a.x_dofmap, cell, cd);
+  double Ae[N0 * N1];
+  tabulate(Ae, N0 * N1, a.coeffs, a.cstride, a.constants, cd, e, lf);
+#pragma unroll
+  for (int i = 0; i < N0 * N1; ++i)
+    a.slave_tensors[(long long)i * a.n_slave_entities + s] = Ae[i];
+}
+
+extern "C" __global__ void __launch_bounds__(64) ufcx_matrix_mpc_gather_kernel(mpcx_matrix_args_t a)
+{
+  const int G = a.mpc_plan_group >= 16 ? 16 : (a.mpc_plan_group >= 4 ? 4 : 1);
+  const int lane = threadIdx.x & (G - 1);
+  const long long t = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  if (t >= a.mpc_plan_targets)
+    return;
+  double sum = 0.0;
+  for (long long k = a.mpc_plan_off[t] + lane; k < a.mpc_plan_off[t + 1]; k += G)
+    sum += a.mpc_plan_coef[k] * a.slave_tensors[(long long)a.mpc_plan_pq[k] * a.n_slave_entities + a.mpc_plan_slot[k]];
+  for (int m = G >> 1; m > 0; m >>= 1)
+    sum += __shfl_xor(sum, m, G);
+  if (lane == 0)
+    a.vals[a.mpc_plan_tgt[t]] += sum;
+}
 #else
 // rank 1: row blocks of b in LDS.  own_lmap == NULL: every block evaluates the entities touching it and keeps its
 // own rows (vector_rowblock_kernel); own_lmap != NULL: owner-computes (vector_ownblock_kernel): every entity once,
@@ -619,6 +655,7 @@ struct UfcxKernel
   hipModule_t module = nullptr;
   hipFunction_t matrix = nullptr, matrix_mpc = nullptr, lifting = nullptr, vector = nullptr;
   hipFunction_t matrix_rowblock = nullptr, matrix_mpc_plan = nullptr, vector_rowblock = nullptr, vector_mpc = nullptr;
+  hipFunction_t slave_tensors = nullptr, matrix_mpc_gather = nullptr;
   int rb_threads = 256; // threads per workgroup of the row-block kernels (their launch bound)
 };
 
@@ -650,6 +687,10 @@ int ensure_loaded(UfcxKernel* k)
     if (int rc = get(&k->matrix_rowblock, "ufcx_matrix_rowblock_kernel"))
       return rc;
     if (int rc = get(&k->matrix_mpc_plan, "ufcx_matrix_mpc_plan_kernel"))
+      return rc;
+    if (int rc = get(&k->slave_tensors, "ufcx_slave_tensors_kernel"))
+      return rc;
+    if (int rc = get(&k->matrix_mpc_gather, "ufcx_matrix_mpc_gather_kernel"))
       return rc;
     return get(&k->lifting, "ufcx_lifting_kernel");
   }
@@ -852,6 +893,12 @@ int launch_matrix_ufcx(const mpcx_matrix_args_t& a)
     if (a.mpc_plan_targets <= 0)
       return 0;
     const int g = a.mpc_plan_group >= 16 ? 16 : (a.mpc_plan_group >= 4 ? 4 : 1);
+    if (a.slave_tensors && a.mpc_plan_slot)
+    {
+      if (int rc = launch(k->slave_tensors, a.n_slave_entities, a, a.stream))
+        return rc;
+      return launch(k->matrix_mpc_gather, a.mpc_plan_targets * g, a, a.stream);
+    }
     return launch(k->matrix_mpc_plan, a.mpc_plan_targets * g, a, a.stream);
   }
   return launch(k->matrix_mpc, a.n_slave_entities, a, a.stream);

@@ -244,6 +244,13 @@ typedef struct
    * mpcx_spmv_blockscalar (y = A x straight from this layout). */
   double* block_vals;
   double* mpc_plan_out;
+  /* Imported (UFCx) element kernels with a master-contribution plan, optional: the element tensor of every slave entity
+   * is tabulated ONCE per call -- as the reference does (cpp/assemble_matrix.cpp:504-546: one tabulate_tensor per cell, then
+   * modify_mpc_cell) -- into slave_tensors (DEVICE scratch of the caller, [N0 * N1][n_slave_entities] doubles, entry-major),
+   * and the plan's tuples read their entry from it: mpc_plan_slot[k] = index of tuple k's entity in slave_entities
+   * (DEVICE [tuples]).  NULL: every tuple re-tabulates its entity (a black-box kernel has no cheaper way to one entry). */
+  double* slave_tensors;
+  const int32_t* mpc_plan_slot;
   void* stream;
 } mpcx_matrix_args_t;
 

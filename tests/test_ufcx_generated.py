@@ -66,7 +66,7 @@ def test_gpu_imported_kernels_match_builtin_oracle(oracle, make, alg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["MPCX_NO_MPC_PLAN", "MPCX_VECTOR_OWNER=0", "MPCX_PLAN_LISTS=host"])
+@pytest.mark.parametrize("variant", ["MPCX_NO_MPC_PLAN", "MPCX_VECTOR_OWNER=0", "MPCX_PLAN_LISTS=host", "MPCX_SLAVE_TENSORS=0"])
 @pytest.mark.parametrize("idx", [2, 8, 15, 19, 20, 23])
 def test_gpu_imported_kernels_plan_variants(oracle, monkeypatch, idx, variant):
     """the imported kernels on the other routes of the row-block path: master contributions without a plan (what a
