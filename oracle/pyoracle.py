@@ -263,9 +263,14 @@ def _load_user_kernel(k):
         os.makedirs(d, exist_ok=True)
         src, so = os.path.join(d, key + ".c"), os.path.join(d, key + ".so")
         if not os.path.exists(so):
+            # private names, then an atomic rename: several test workers may want the same kernel at once
+            tag = "%s.%d" % (key, os.getpid())
+            src, tmp = os.path.join(d, tag + ".c"), os.path.join(d, tag + ".so")
             with open(src, "w") as fh:
                 fh.write("#include <stdint.h>\n#include <math.h>\n" + k.ufcx_source)
-            subprocess.run(["gcc", "-O2", "-std=c99", "-fPIC", "-shared", "-o", so, src, "-lm"], check=True)
+            subprocess.run(["gcc", "-O2", "-std=c99", "-fPIC", "-shared", "-o", tmp, src, "-lm"], check=True)
+            os.replace(tmp, so)
+            os.remove(src)
         _user_libs[key] = C.CDLL(so)
     fn = getattr(_user_libs[key], k.ufcx_name)
     lib().oracle_set_user_kernel(C.cast(fn, C.c_void_p))
