@@ -153,8 +153,10 @@ def poisson_workload(args, rank, world, degree):
     if cell == "hexahedron":
         w.config["workload"] = (f"periodic-BC Poisson, Q1 hexahedra (bench_periodic.py's default cell), {N}^3 cells, fp64 -- the "
                                 f"secondary variant of BASELINE configs[1] (SURVEY 8, config 2 note), NOT the headline config")
-        w.config["element_kernels"] = ("generated UFCx C text (dolfinx_mpc_amd/codegen.py generate_hex: trilinear geometry, 8-point "
-                                       "stiffness, 27-point source with libm sin/exp) compiled with hipRTC")
+        w.config["element_kernels"] = ("built-in Q1 kernels over the cells (csrc/mpcx_cubes.hip matrix_hex_kernel / vector_hex_own_kernel: "
+                                       "trilinear geometry, 8-point stiffness with the closed form on parallelepipeds, 27-point source) + "
+                                       "generated UFCx C text (dolfinx_mpc_amd/codegen.py generate_hex, hipRTC) for the constrained cells and "
+                                       "lifting; MPCX_NO_CUBE=1: the generated kernels everywhere")
     if ufcx:
         w.config["element_kernels"] = ("imported UFCx C text compiled with hipRTC: " + (
             "tests/ufcx/laplace_p1_tet.c + source_p1_tet.c (P1 coefficient, constant, 14-point rule)" if ufcx == "files" else
@@ -331,7 +333,19 @@ def algorithmic_flops(integ, V0, V1=None) -> float:
                  component-diagonal forms, 6 bs^2 + 2 tdim for elasticity, 2 bs for the Taylor-Hood coupling blocks;
       imported kernels (UFCx): unknown -> 0."""
     k = integ.kernel
-    tdim = 3 if k.celltype == 2 else 2
+    if getattr(k, "builtin", None) is not None:
+        # hexahedra: the imported kernel's built-in twin says what is integrated (non-affine map: the geometry -- Jacobian,
+        # cofactors, determinant: ~100 flops -- is evaluated at every point)
+        kb = k.builtin
+        nq, nd = int(kb.qwts.size), 8
+        if kb.form == 2:
+            fcost = {0: 0.0, 1: 52.0}.get(kb.fn_id, 0.0)
+            return nq * (100.0 + 2.0 + fcost + 2.0 * nd)
+        # stiffness: on parallelepipeds the kernel takes the closed form of the integral (six metric entries, <= 6 fma per
+        # entry of the upper triangle, mirrored): that count, not the eight-point quadrature a form compiler would emit,
+        # so that the fp64 fraction does not credit arithmetic the kernel does not do
+        return 60.0 + 36 * 12.0
+    tdim = 3 if k.celltype in (2, 3) else 2
     nd0, bs0 = V0.element_ndofs, V0.dofmap.bs
     nd1, bs1 = (V1.element_ndofs, V1.dofmap.bs) if V1 is not None else (nd0, bs0)
     nq = max(int(k.qwts.size if integ.itype == "cell" else k.fqwts.size), 1)
@@ -582,7 +596,8 @@ def main():
     Lib = _native.lib()
     alg_id = am._ALG[args.alg]
     kernels = []
-    mesh, nv = w.mesh, 4
+    mesh = w.mesh
+    nv = int(mesh.geometry.dofmap.shape[1])
     nc = mesh.num_owned_cells
     for label, f, (m0, m1) in w.blocks:
         A = mats[label]
@@ -590,8 +605,10 @@ def main():
                                      allow_block_scalar=A._compact is not None)
         def launch_matrix(margs=margs):  # (cluster path: one launch per record format, narrow and wide row blocks)
             _native.check(Lib.mpcx_assemble_matrix(C.byref(margs)), "mpcx_assemble_matrix")
-            if getattr(margs, "second", None) is not None:
-                _native.check(Lib.mpcx_assemble_matrix(C.byref(margs.second)), "mpcx_assemble_matrix")
+            nxt = getattr(margs, "second", None)
+            while nxt is not None:
+                _native.check(Lib.mpcx_assemble_matrix(C.byref(nxt)), "mpcx_assemble_matrix")
+                nxt = getattr(nxt, "second", None)
 
         tk = hip_time(launch_matrix, reps)
         V0, V1 = f.function_spaces

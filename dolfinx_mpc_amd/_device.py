@@ -176,6 +176,14 @@ def integral_device(form: Form, i: int):
             d["qpts"].data_ptr(), d["qwts"].data_ptr(), d["fqpts"].data_ptr(), d["fqwts"].data_ptr(),
             ufcx_compile(k, form) if k.form == 100 else None, None if qphi is None else qphi.data_ptr(),
         )
+        kb = getattr(k, "builtin", None)
+        d["kernel_builtin"] = None
+        if kb is not None:
+            d["qpts_b"], d["qwts_b"] = _to_dev(kb.qpts.astype(np.float64).reshape(-1), dev), _to_dev(kb.qwts.astype(np.float64), dev)
+            d["kernel_builtin"] = _native.KernelT(
+                kb.form, kb.celltype, kb.degree, kb.bs, kb.degree1 or kb.degree, kb.bs1 or kb.bs, kb.fn_id, kb.coeff_degree,
+                int(kb.qwts.size), 0, d["qpts_b"].data_ptr(), d["qwts_b"].data_ptr(), d["fqpts"].data_ptr(), d["fqwts"].data_ptr(),
+                None, None)
         form._device[key] = d
     d = form._device[key]
     if integ.coefficient is not None:

@@ -111,6 +111,7 @@ class MatrixArgs(C.Structure):
         ("lean", C.c_int32),
         ("cube_recs", C.c_void_p),
         ("cube_rec_bytes", C.c_int32),
+        ("cube_flags", C.c_int32),
         ("cube_block_ids", C.c_void_p),
         ("slot_mask", C.c_void_p),
         ("mpc_plan_targets", C.c_int64),
@@ -204,6 +205,8 @@ EXPORTS = [
     "mpcx_mask_dofmap",
     "mpcx_scatter_offsets",
     "mpcx_cube_records",
+    "mpcx_hex_records",
+    "mpcx_hex_slot_shapes",
     "mpcx_cube_detect",
     "mpcx_cube_slot_width",
     "mpcx_cube_pack_narrow",
@@ -365,6 +368,10 @@ def lib() -> C.CDLL:
     L.mpcx_scatter_offsets.restype = C.c_int
     L.mpcx_cube_records.argtypes = [i64, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
     L.mpcx_cube_records.restype = C.c_int
+    L.mpcx_hex_records.argtypes = [i64, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.mpcx_hex_records.restype = C.c_int
+    L.mpcx_hex_slot_shapes.argtypes = [i64, vp, vp, vp, vp]
+    L.mpcx_hex_slot_shapes.restype = C.c_int
     L.mpcx_cube_detect.argtypes = [vp, i64, vp, vp, vp]
     L.mpcx_cube_detect.restype = C.c_int
     L.mpcx_cube_slot_width.argtypes = [i64, vp, vp, vp]

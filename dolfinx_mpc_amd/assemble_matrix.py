@@ -20,6 +20,9 @@ _ALG = {"auto": 0, "atomic": 1, "rowblock": 2}
 # cluster kernel (MPCX_ALG_CUBE): row blocks of the cluster path (LDS: max_nnz * 8 B + max_rows * 4 B)
 CUBE_MAX_NNZ = int(os.environ.get("MPCX_CUBE_MAX_NNZ", 9216))
 CUBE_MAX_ROWS = int(os.environ.get("MPCX_CUBE_MAX_ROWS", 512))
+# hexahedra (27 entries per Q1 row): 256 rows = 55 KB, two workgroups per CU; a tile of 512 nodes is cut in two
+HEX_MAX_ROWS = int(os.environ.get("MPCX_HEX_MAX_ROWS", 256))
+HEX_MAX_NNZ = int(os.environ.get("MPCX_HEX_MAX_NNZ", 9216))
 
 # LDS budget of one row block: max_nnz * (8 B value + 4 B column) + row offsets
 # (measured on MI355X, tools/sweep_rowblock.py: 512 rows x 9216 nnz = 76 KB of LDS
@@ -477,18 +480,25 @@ def _cube_eligible(form: Form, i: int, V0) -> bool:
             and not os.environ.get("MPCX_NO_CUBE"))
 
 
-def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc):
+def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc, hexa: bool = False):
     """Row blocks over the mesh's cell clusters + one 96-byte record per (block, cluster) slot
     (mpcx_cube_records); cached per (form, constraint, Dirichlet markers).  Returns
-    (plan struct, records tensor, keep-alive, info, leftover cells) or None when the mesh has no clusters."""
+    (plan struct, records tensor, keep-alive, info, leftover cells) or None when the mesh has no clusters.
+    ``hexa``: the clusters are the hexahedra themselves (their Q1 dofmap; every vertex pair coupled: mpcx_hex_records)."""
     import torch
 
     from .clusters import mesh_clusters_device
 
     integ = form.integrals[i]
-    d_verts, left = mesh_clusters_device(form.mesh, integ.num_entities)
-    if d_verts.shape[0] == 0 or d_verts.shape[0] * 6 < 0.5 * integ.num_entities:
-        return None
+    if hexa:
+        d_verts = D.space_device(V0)["dofmap"].view(-1, 8)[: integ.num_entities]
+        left = np.zeros(0, dtype=np.int32)
+        max_rows_cfg, max_nnz_cfg = HEX_MAX_ROWS, HEX_MAX_NNZ
+    else:
+        d_verts, left = mesh_clusters_device(form.mesh, integ.num_entities)
+        if d_verts.shape[0] == 0 or d_verts.shape[0] * 6 < 0.5 * integ.num_entities:
+            return None
+        max_rows_cfg, max_nnz_cfg = CUBE_MAX_ROWS, CUBE_MAX_NNZ
 
     def build():
         L = _native.lib()
@@ -500,7 +510,7 @@ def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc):
         bs = V0.dofmap.bs
         if hints is not None:
             hints = np.ascontiguousarray(hints * bs)
-        row0 = _block_ranges(A.shape[0], A.rowptr, CUBE_MAX_ROWS, CUBE_MAX_NNZ, bs, hints)
+        row0 = _block_ranges(A.shape[0], A.rowptr, max_rows_cfg, max_nnz_cfg, bs, hints)
         nb = row0.size - 1
         d_row0, d_off, d_ents = _block_lists_device(row0, nc, 1, None, d_verts, 8, bs, dev)
         nslots = d_ents.numel()
@@ -508,15 +518,16 @@ def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc):
         recs = torch.empty(nslots * 96, dtype=torch.uint8, device=dev)
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         _, t = mpc._device()
-        rc = L.mpcx_cube_records(nslots, d_ents.data_ptr(), d_verts.data_ptr(), bs, D.ptr(bc_dev), t["is_slave"].data_ptr(),
-                                 A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), recs.data_ptr(), flag.data_ptr(), D.stream_ptr())
-        _native.check(rc, "mpcx_cube_records")
+        records = L.mpcx_hex_records if hexa else L.mpcx_cube_records
+        rc = records(nslots, d_ents.data_ptr(), d_verts.data_ptr(), bs, D.ptr(bc_dev), t["is_slave"].data_ptr(),
+                     A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), recs.data_ptr(), flag.data_ptr(), D.stream_ptr())
+        _native.check(rc, "mpcx_hex_records" if hexa else "mpcx_cube_records")
         if int(flag.item()) != 0:
             raise _native.PlanNotRepresentable("cluster algorithm: a scatter offset does not fit 8 bits (or a column is missing)")
         max_rows = int(np.diff(row0).max())
         max_nnz = int(np.diff(A.rowptr[row0]).max())
         parts = None
-        if bs == 1 and os.environ.get("MPCX_CUBE_NARROW", "1") != "0" and nslots > 0:
+        if bs == 1 and not hexa and os.environ.get("MPCX_CUBE_NARROW", "1") != "0" and nslots > 0:
             # narrow records (64 B, 4-bit offsets) for the row blocks all of whose slots allow it, the 96-byte format
             # for the rest (blocks that hold fat rows: master rows of a constraint); launched separately
             wide = torch.empty(nslots, dtype=torch.uint8, device=dev)
@@ -547,10 +558,38 @@ def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc):
                     parts.append((_native.RowBlockPlanT(int(sel.numel()), max_rows, max_nnz, 0, d_row0.data_ptr(), off_c.data_ptr(),
                                                         None, None, None), out, nbytes, ids, off_c))
                 del recs
+        if hexa and nslots > 0 and os.environ.get("MPCX_HEX_SPLIT", "1") != "0":
+            # row blocks all of whose cells are parallelepipeds go to the closed-form-only kernel instance (flag 1), the
+            # others to the instance that looks at every cell; launched separately, like the two record formats above
+            general = torch.empty(nslots, dtype=torch.uint8, device=dev)
+            _native.check(L.mpcx_hex_slot_shapes(nslots, recs.data_ptr(), D.mesh_device(form.mesh)["x"].data_ptr(),
+                                                 general.data_ptr(), D.stream_ptr()), "mpcx_hex_slot_shapes")
+            cs = torch.zeros(nslots + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(general.to(torch.int64), 0, out=cs[1:])
+            per_block = cs[d_off[1:]] - cs[d_off[:-1]]
+            del general, cs
+            sel_a = torch.nonzero(per_block == 0).reshape(-1)
+            sel_g = torch.nonzero(per_block > 0).reshape(-1)
+            if sel_g.numel() == 0:
+                parts = [(_native.RowBlockPlanT(nb, max_rows, max_nnz, 0, d_row0.data_ptr(), d_off.data_ptr(), None, None, None),
+                          recs, 96, None, d_off, 1)]
+            elif sel_a.numel() > 0:
+                parts = []
+                for sel, flags in ((sel_a, 1), (sel_g, 0)):
+                    cnt = d_off[sel + 1] - d_off[sel]
+                    off_c = torch.zeros(sel.numel() + 1, dtype=torch.int64, device=dev)
+                    torch.cumsum(cnt, 0, out=off_c[1:])
+                    tot = int(off_c[-1].item())
+                    src = torch.repeat_interleave(d_off[sel] - off_c[:-1], cnt) + torch.arange(tot, dtype=torch.int64, device=dev)
+                    out = recs.view(nslots, 96)[src].contiguous().view(-1)
+                    ids = sel.to(torch.int32).contiguous()
+                    parts.append((_native.RowBlockPlanT(int(sel.numel()), max_rows, max_nnz, 0, d_row0.data_ptr(), off_c.data_ptr(),
+                                                        None, None, None), out, 96, ids, off_c, flags))
+                del recs
         if parts is None:
             parts = [(_native.RowBlockPlanT(nb, max_rows, max_nnz, 0, d_row0.data_ptr(), d_off.data_ptr(), None, None, None),
                       recs, 96, None, d_off)]
-        keep = (d_row0, parts)
+        keep = (d_row0, parts, d_verts)
         info = {"num_blocks": nb, "num_ents": int(nslots), "max_rows": max_rows, "max_nnz": max_nnz, "clusters": int(nc),
                 "narrow_blocks": int(parts[0][0].num_blocks) if parts[0][2] == 64 else 0,
                 "bytes": int(d_row0.numel() * 4 + sum(p[1].numel() + p[4].numel() * 8 + (0 if p[3] is None else p[3].numel() * 4)
@@ -558,7 +597,9 @@ def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc):
         return (parts, keep, info)
 
     try:
-        plan, keep, info = D.cached(A._plans, "cubes", (form, mpc, bc_dev), (i, CUBE_MAX_ROWS, CUBE_MAX_NNZ), build)
+        # (hexahedra: the split by cell shape depends on the coordinates -- a moved mesh gets a new plan)
+        plan, keep, info = D.cached(A._plans, "cubes", (form, mpc, bc_dev),
+                                    (i, max_rows_cfg, max_nnz_cfg, hexa, form.mesh.geometry.version if hexa else 0), build)
     except _native.PlanNotRepresentable:
         return None
     return plan, keep, info, left
@@ -789,11 +830,48 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
                            nq=int(kf.qwts.size if integ.itype == "cell" else kf.fqwts.size), cell_integral=integ.itype == "cell",
                            has_coefficient=integ.coefficient is not None, coeff_degree=kf.coeff_degree,
                            all_cells=idv["entities_ptr"] is None and integ.estride == 1,
-                           p1_geometry=s0["dofmap"] is md["x_dofmap"], same=same, tiled=V0.dof_tile_offsets is not None)
+                           p1_geometry=s0["dofmap"] is md["x_dofmap"], same=same, tiled=V0.dof_tile_offsets is not None,
+                           builtin_form=(kf.builtin.form if getattr(kf, "builtin", None) is not None else -1))
         a.kernel_name = None  # (python attribute) the table entry that was taken
         for name in dispatch.candidates(dispatch.MATRIX, ctx, "matrix"):
             lean = pairs = False
             smask = None
+            if name == "hex_cube":
+                # hexahedra: the bulk through the built-in Q1 kernel over (row block, cell) slots (MPCX_ALG_CUBE with the
+                # built-in twin of the imported kernel), then the master contributions of the slave cells through the
+                # imported kernel -- a second call without bulk entities
+                cp = _cube_plan(A, form, i, V0, bc0, mpc0, hexa=True) if allow_cubes else None
+                if cp is None:
+                    continue
+                parts, ck, _info, _left = cp
+                t = _native.MatrixArgs.from_buffer_copy(a)  # the imported kernel's call: master contributions only
+                t.algorithm, t.n_entities, t.store_mode = 2, 0, 0
+                t.vals = A.vals.data_ptr()
+                t.leftover, t.kernel_name, t.block_scalar, t.second = None, name, False, None
+                a.kernel = idv["kernel_builtin"]
+                a.algorithm = 3
+                a.n_slave_entities = 0
+                a.kernel_name = name
+                a.vals = A.vals.data_ptr()
+                # one launch per kind of row block (all cells parallelepipeds / not), then the master contributions: a chain
+                # of follow-up calls (python attribute ``second``)
+                chain = []
+                for n_part, part in enumerate(parts):
+                    plan, recs, nbytes, ids, _off = part[:5]
+                    u = a if n_part == 0 else _native.MatrixArgs.from_buffer_copy(a)
+                    u.plan = plan
+                    u.cube_recs, u.cube_rec_bytes, u.cube_block_ids = recs.data_ptr(), nbytes, D.ptr(ids)
+                    u.cube_flags = part[5] if len(part) > 5 else 0
+                    if n_part > 0:
+                        u.leftover, u.kernel_name, u.block_scalar = None, name, False
+                    chain.append(u)
+                if t.n_slave_entities > 0:
+                    chain.append(t)
+                for u, v in zip(chain, chain[1:] + [None]):
+                    u.second = v
+                A._compact_stale = False
+                keep += [ck]
+                return a, keep
             if name in ("cube", "cube_el"):
                 # cell clusters (MPCX_ALG_CUBE); None when the mesh has no clean six-tet fans or an offset overflows
                 cp = _cube_plan(A, form, i, V0, bc0, mpc0) if allow_cubes else None
@@ -935,8 +1013,10 @@ def _assemble_matrix_on_stream(form: Form, mpc0, mpc1, bcs, diagval, A: MPCMatri
                                   allow_block_scalar=(len(form.integrals) == 1 and integ.num_entities > 0
                                                       and A._exchange is None and alg == 2))
             calls.append((memset, a, keep))
-            if getattr(a, "second", None) is not None:  # cluster path: the row blocks of the other record format
-                calls.append((False, a.second, keep))
+            nxt = getattr(a, "second", None)  # cluster path: the row blocks of the other record format / cell shape, ...
+            while nxt is not None:
+                calls.append((False, nxt, keep))
+                nxt = getattr(nxt, "second", None)
             if a.leftover is not None:
                 # cells outside any cluster: per-cell row-block kernel, ADDed; their master contributions are part
                 # of the call above (its plan covers every slave entity of the integral)

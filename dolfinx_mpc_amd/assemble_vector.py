@@ -257,6 +257,7 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
     a.algorithm = 1
     keep = [md, sd, mkeep, idv]
     a.leftover = None  # (python attribute) cells the cluster kernel does not cover
+    a.second = None  # (python attribute) a follow-up call (hexahedra: slave rows through the imported kernel)
     k = integ.kernel
     a.stream = D.stream_ptr()
     a.kernel_name = "atomic"  # (python attribute) the table entry that was taken
@@ -270,7 +271,8 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
     ctx = dispatch.Ctx(form=k.form, tet=k.celltype == 2, d0=V.degree, bs0=V.dofmap.bs, d1=V.degree, bs1=V.dofmap.bs,
                        nd0=V.element_ndofs, nd1=V.element_ndofs, nq=nq, cell_integral=integ.itype == "cell",
                        has_coefficient=integ.coefficient is not None, coeff_degree=k.coeff_degree,
-                       all_cells=idv["entities_ptr"] is None, p1_geometry=sd["dofmap"] is md["x_dofmap"], same=True, tiled=tiled)
+                       all_cells=idv["entities_ptr"] is None, p1_geometry=sd["dofmap"] is md["x_dofmap"], same=True, tiled=tiled,
+                       builtin_form=(k.builtin.form if getattr(k, "builtin", None) is not None else -1))
     # row-block shapes (rows of b one workgroup holds): blocked spaces get the same number of NODES per block (vector P1,
     # contact benchmark: 0.43 -> 0.29 ms); scalar P2 sources with the basis table on a tiled numbering and many-point
     # rules take large blocks (the halo is paid in arithmetic)
@@ -283,6 +285,37 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
     if heavy and not p2_fast and (tiled or ufcx):
         nrows_blk = max(nrows_blk, 2048 * V.dofmap.bs)
     for name in dispatch.candidates(dispatch.VECTOR, ctx, "vector", plan_only=(alg == 2)):
+        if name == "hex_own":
+            # hexahedra: one thread per cell through the built-in Q1 source kernel (MPCX_ALG_CUBE with the built-in twin of
+            # the imported kernel, owner-computes row blocks over the cell dofmap), then the rows of slave dofs through
+            # the imported kernel over the slave cells -- a second call without bulk entities; "auto" only
+            if alg != 0 or not allow_cubes:
+                continue
+            d_verts = sd.get("cell_verts")  # (ONE view object per space: the plan cache is keyed by identity)
+            if d_verts is None or d_verts.shape[0] != integ.num_entities:
+                d_verts = sd["cell_verts"] = sd["dofmap"].view(-1, 8)[: integ.num_entities]
+            left = getattr(form.mesh, "_no_leftover", None)
+            if left is None:
+                left = form.mesh._no_leftover = np.zeros(0, dtype=np.int32)
+            slave_h, _ = _slave_entities(form, i, constraint, constraint)
+            own = _vector_cube_owner_plan(form.mesh, V, d_verts, constraint, left, slave_h)
+            if own is None:
+                continue
+            plan, pk, n_own, d_slaves = own
+            t = _native.VectorArgs.from_buffer_copy(a)  # the imported kernel's call: slave rows only
+            t.algorithm, t.n_entities = 2, 0
+            t.slave_entities, t.n_slave_entities = d_slaves.data_ptr(), d_slaves.numel()
+            t.leftover, t.kernel_name, t.second = None, name, None
+            a.kernel = idv["kernel_builtin"]
+            a.plan = plan
+            a.own_lmap, a.own_hoff, a.own_spill = pk[3].data_ptr(), pk[4].data_ptr(), pk[5].data_ptr()
+            a.own_src, a.own_rows, a.own_seg, a.n_own_rows = pk[6].data_ptr(), pk[7].data_ptr(), pk[8].data_ptr(), n_own
+            a.algorithm = 3
+            a.cube_verts, a.n_cubes = d_verts.data_ptr(), d_verts.shape[0]
+            a.kernel_name = name
+            a.second = t if d_slaves.numel() > 0 else None
+            keep += [pk, d_slaves, d_verts]
+            return a, keep
         if name in ("cube_own", "cube_hash"):
             # scalar P1 source over all cells: one thread per cell cluster (MPCX_ALG_CUBE, csrc/mpcx_cubes.hip); "auto" only
             if alg != 0 or not allow_cubes:
@@ -369,6 +402,8 @@ def assemble_vector(form: Form, constraint: MultiPointConstraint, b: Optional[Ve
         for i, integ in enumerate(form.integrals):
             a, keep = vector_args(form, i, b, constraint, alg)
             _native.check(L.mpcx_assemble_vector(C.byref(a)), "mpcx_assemble_vector")
+            if a.second is not None:
+                _native.check(L.mpcx_assemble_vector(C.byref(a.second)), "mpcx_assemble_vector")
             if a.leftover is not None:  # cells outside any cluster: per-cell kernel
                 from .assemble_matrix import _leftover_form
 

@@ -345,7 +345,8 @@ __global__ void rowblock_pairs_kernel(int64_t n_entities, int estride, const int
   }
 }
 
-// set-up: one record per (row block, cluster touching it) slot k
+// set-up: one record per (row block, cluster touching it) slot k (ALL: every vertex pair is coupled -- hexahedra)
+template <bool ALL>
 __global__ void cube_records_kernel(int64_t n_slots, const int32_t* __restrict__ block_ents,
                                     const int32_t* __restrict__ cube_verts, int bs, const int8_t* __restrict__ bc,
                                     const int8_t* __restrict__ is_slave, const mpcx_nnz_t* __restrict__ rowptr,
@@ -372,7 +373,7 @@ __global__ void cube_records_kernel(int64_t n_slots, const int32_t* __restrict__
   for (int b = 0; b < 8; ++b)
   {
     int o = 255;
-    if (fan_coupled(a, b))
+    if (ALL || fan_coupled(a, b))
     {
       const int64_t pos = find_col(cols, lo, hi, v[b] * bs);
       o = pos < 0 ? 256 : int((pos - lo) / bs);
@@ -933,6 +934,445 @@ __global__ void __launch_bounds__(VCUBE_OWN_THREADS) vector_cube_own_kernel(mpcx
   for (int i = tid; i < nhalo; i += NT)
     a.own_spill[h0 + i] = s_b[nown + i];
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Hexahedra (Q1, trilinear geometry) -- the default cell of python/benchmarks/bench_periodic.py:38,199-200.
+// A hexahedron is the cluster: eight vertices, all 64 vertex pairs coupled, so the row-block machinery of the
+// six-tet fans carries over (96-byte records = 8 vertex ids + 64 scatter offsets, owner-computes vector plan over
+// the cell dofmap).  Local vertex v sits at (v & 1, v >> 1 & 1, v >> 2 & 1) of the reference cube.  The map is
+//     x(X, Y, Z) = sum_m c[m] X^(m & 1) Y^(m >> 1 & 1) Z^(m >> 2 & 1),
+// its Jacobian columns j0, j1, j2 are bilinear in the other two variables, the cofactor columns are cross products:
+//     grad(phi_i) = (j1 x j2, j2 x j0, j0 x j1) dphi_i / det,   det = j0 . (j1 x j2).
+// ---------------------------------------------------------------------------------------------------------
+template <int N>
+struct Gauss01; // Gauss-Legendre rule on [0, 1]
+template <>
+struct Gauss01<1>
+{
+  static constexpr double P[1] = {0.5};
+  static constexpr double W[1] = {1.0};
+};
+template <>
+struct Gauss01<2>
+{
+  static constexpr double P[2] = {0.21132486540518711775, 0.78867513459481288225};
+  static constexpr double W[2] = {0.5, 0.5};
+};
+template <>
+struct Gauss01<3>
+{
+  static constexpr double P[3] = {0.11270166537925831148, 0.5, 0.88729833462074168852};
+  static constexpr double W[3] = {5.0 / 18.0, 8.0 / 18.0, 5.0 / 18.0};
+};
+
+// trilinear coefficients from the eight vertices; differences are paired so that a parallelepiped whose opposite
+// edges are the same floating-point differences (any axis-aligned box grid) gets exact zeros in c[3], c[5], c[6], c[7]
+__device__ inline void hex_coefficients(const double (&X)[8][3], double (&c)[8][3])
+{
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+  {
+    const double e10 = X[1][r] - X[0][r], e32 = X[3][r] - X[2][r], e54 = X[5][r] - X[4][r], e76 = X[7][r] - X[6][r];
+    const double e20 = X[2][r] - X[0][r], e64 = X[6][r] - X[4][r];
+    c[0][r] = X[0][r];
+    c[1][r] = e10;
+    c[2][r] = e20;
+    c[3][r] = e32 - e10;
+    c[4][r] = X[4][r] - X[0][r];
+    c[5][r] = e54 - e10;
+    c[6][r] = e64 - e20;
+    c[7][r] = (e76 - e54) - (e32 - e10);
+  }
+}
+// is the cell a parallelepiped (to rounding)?  The bilinear / trilinear coefficients against the edge vectors.
+__device__ inline bool hex_is_parallelepiped(const double (&c)[8][3])
+{
+  double dev = 0.0, len = 0.0;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+  {
+    dev = fmax(dev, fmax(fmax(fabs(c[3][r]), fabs(c[5][r])), fmax(fabs(c[6][r]), fabs(c[7][r]))));
+    len = fmax(len, fmax(fabs(c[1][r]), fmax(fabs(c[2][r]), fabs(c[4][r]))));
+  }
+  return dev <= 0x1p-46 * len;
+}
+__global__ void hex_slot_shapes_kernel(int64_t n_slots, const CubeRec* __restrict__ recs, const double* __restrict__ x,
+                                       uint8_t* __restrict__ general)
+{
+  const int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (k >= n_slots)
+    return;
+  double X[8][3], c[8][3];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+  {
+    const int64_t n = recs[k].v[i] & DOF_MASK;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      X[i][r] = x[3 * n + r];
+  }
+  hex_coefficients(X, c);
+  general[k] = hex_is_parallelepiped(c) ? 0 : 1;
+}
+__device__ inline void cross3(const double (&u)[3], const double (&v)[3], double (&w)[3])
+{
+  w[0] = u[1] * v[2] - u[2] * v[1];
+  w[1] = u[2] * v[0] - u[0] * v[2];
+  w[2] = u[0] * v[1] - u[1] * v[0];
+}
+// index of (i, j), i <= j, in the packed upper triangle of an 8 x 8 matrix
+__host__ __device__ constexpr int tri8(int i, int j) { return i * 8 - i * (i - 1) / 2 + (j - i); }
+
+// integrals over [0, 1] of products of the 1D hat functions l_0 = 1 - t, l_1 = t
+__host__ __device__ constexpr double hat_mass(int a, int b) { return a == b ? 1.0 / 3.0 : 1.0 / 6.0; }
+__host__ __device__ constexpr double hat_sign(int a) { return a ? 1.0 : -1.0; }
+// coefficient of M_de in the exact Q1 stiffness entry (i, j) of a parallelepiped:
+//   A_ij = sum_{d <= e} M_de K_de(i, j),  M = c (C^T C) / |det|
+__host__ __device__ constexpr double hex_affine_coef(int d, int e, int i, int j)
+{
+  const int bi[3] = {i & 1, (i >> 1) & 1, (i >> 2) & 1}, bj[3] = {j & 1, (j >> 1) & 1, (j >> 2) & 1};
+  if (d == e)
+  {
+    double v = hat_sign(bi[d]) * hat_sign(bj[d]);
+    for (int k = 0; k < 3; ++k)
+      if (k != d)
+        v *= hat_mass(bi[k], bj[k]);
+    return v;
+  }
+  // int d_d phi_i d_e phi_j + int d_e phi_i d_d phi_j: (s/2)(s/2) in the two differentiated directions
+  const int k = 3 - d - e;
+  return (hat_sign(bi[d]) * hat_sign(bj[e]) + hat_sign(bi[e]) * hat_sign(bj[d])) * 0.25 * hat_mass(bi[k], bj[k]);
+}
+
+constexpr int HEX_MAX_THREADS = 512;
+
+// matrix: scalar Q1 stiffness c * inner(grad u, grad v) dx, 2 x 2 x 2 Gauss points, one thread per (row block, cell)
+// slot.  The 36 entries of the upper triangle are accumulated over the points in registers and scattered once.
+// A wave all of whose cells are parallelepipeds (c[3] = c[5] = c[6] = c[7] = 0 up to 2^-46 of the longest edge
+// vector: every cell of a box mesh, sheared or not) takes the closed form of the same integral -- the rule is exact
+// there -- from the six entries of M = c C^T C / |det|: ~200 fp64 instructions instead of ~2 100.
+// AFFINE_PATH: 1 = both paths, chosen per wave; 2 = closed form only (row blocks all of whose cells the set-up found to be
+// parallelepipeds, mpcx_matrix_args_t::cube_flags bit 0: 104 registers instead of 252, four waves per SIMD cover the
+// record -> coordinates round trip: 1.38 ms instead of 1.75 at 256^3 cells); 0 = quadrature only (MPCX_HEX_NO_AFFINE, tests).
+template <int AFFINE_PATH>
+__global__ void __launch_bounds__(HEX_MAX_THREADS) matrix_hex_kernel(mpcx_matrix_args_t a)
+{
+  const int NT = blockDim.x;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int nb = a.plan.num_blocks;
+  const int per = (nb + 7) >> 3;
+  const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3); // contiguous runs of row blocks per XCD
+  if (b >= nb)
+    return;
+  const int tid = threadIdx.x;
+  const int bb = a.cube_block_ids ? a.cube_block_ids[b] : b;
+  const int r0 = a.plan.block_row0[bb], r1 = a.plan.block_row0[bb + 1];
+  const int nrow = r1 - r0;
+  const int64_t nnz0 = a.rowptr[r0];
+  const int nnzb = int(a.rowptr[r1] - nnz0);
+  double* s_vals = reinterpret_cast<double*>(smem);
+  int32_t* s_rowlo = reinterpret_cast<int32_t*>(s_vals + a.plan.max_nnz);
+  const double c0 = a.constants ? a.constants[0] : 1.0;
+  const uint4* __restrict__ recs = static_cast<const uint4*>(a.cube_recs);
+  const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  auto load = [&](int64_t t, uint4 (&w)[6])
+  {
+    const uint4* p = recs + t * 6;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      w[i] = p[i];
+  };
+  uint4 cur[6], nxt[6];
+  int64_t t = e0 + tid;
+  if (t < e1)
+    load(t, cur); // the first record travels while the block's LDS copy is cleared
+  for (int i = tid; i < nnzb; i += NT)
+    s_vals[i] = 0.0;
+  for (int rl = tid; rl < nrow; rl += NT)
+    s_rowlo[rl] = int(a.rowptr[r0 + rl] - nnz0);
+  __syncthreads();
+  for (; t < e1; t += NT)
+  {
+    const int32_t v[8] = {int32_t(cur[0].x), int32_t(cur[0].y), int32_t(cur[0].z), int32_t(cur[0].w),
+                          int32_t(cur[1].x), int32_t(cur[1].y), int32_t(cur[1].z), int32_t(cur[1].w)};
+    double c[8][3];
+    {
+      double X[8][3];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+      {
+        const int64_t n = v[i] & DOF_MASK;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          X[i][k] = a.x[3 * n + k];
+      }
+      hex_coefficients(X, c);
+    }
+    const bool has_next = t + NT < e1;
+    if (has_next)
+      load(t + NT, nxt); // in flight across the arithmetic below
+    double A[36];
+    bool affine = false;
+    if constexpr (AFFINE_PATH == 2)
+      affine = true;
+    else if constexpr (AFFINE_PATH == 1)
+      affine = __all(hex_is_parallelepiped(c));
+    if (affine)
+    {
+      double C0[3], C1[3], C2[3];
+      cross3(c[2], c[4], C0);
+      cross3(c[4], c[1], C1);
+      cross3(c[1], c[2], C2);
+      const double det = c[1][0] * C0[0] + c[1][1] * C0[1] + c[1][2] * C0[2];
+      const double s = c0 / fabs(det);
+      const double M[3][3] = {{s * (C0[0] * C0[0] + C0[1] * C0[1] + C0[2] * C0[2]), s * (C0[0] * C1[0] + C0[1] * C1[1] + C0[2] * C1[2]),
+                               s * (C0[0] * C2[0] + C0[1] * C2[1] + C0[2] * C2[2])},
+                              {0.0, s * (C1[0] * C1[0] + C1[1] * C1[1] + C1[2] * C1[2]), s * (C1[0] * C2[0] + C1[1] * C2[1] + C1[2] * C2[2])},
+                              {0.0, 0.0, s * (C2[0] * C2[0] + C2[1] * C2[1] + C2[2] * C2[2])}};
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = i; j < 8; ++j)
+        {
+          double acc = 0.0;
+#pragma unroll
+          for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int e = d; e < 3; ++e)
+            {
+              const double k = hex_affine_coef(d, e, i, j);
+              if (k != 0.0)
+                acc = fma(k, M[d][e], acc);
+            }
+          A[tri8(i, j)] = acc;
+        }
+    }
+    else if constexpr (AFFINE_PATH != 2)
+    {
+#pragma unroll
+      for (int q = 0; q < 36; ++q)
+        A[q] = 0.0;
+      using G2 = Gauss01<2>;
+      // (a rolled loop over the points: unrolled, the scheduler interleaves several points and the 36 accumulators +
+      // 24 coefficients + 24 gradient components no longer fit 256 registers)
+#pragma unroll 1
+      for (int q = 0; q < 8; ++q)
+          {
+            const int qx = q & 1, qy = (q >> 1) & 1, qz = q >> 2;
+            const double xi = qx ? G2::P[1] : G2::P[0], eta = qy ? G2::P[1] : G2::P[0], zeta = qz ? G2::P[1] : G2::P[0];
+            double j0[3], j1[3], j2[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+            {
+              j0[r] = fma(c[7][r], eta * zeta, fma(c[5][r], zeta, fma(c[3][r], eta, c[1][r])));
+              j1[r] = fma(c[7][r], xi * zeta, fma(c[6][r], zeta, fma(c[3][r], xi, c[2][r])));
+              j2[r] = fma(c[7][r], xi * eta, fma(c[6][r], eta, fma(c[5][r], xi, c[4][r])));
+            }
+            double C0[3], C1[3], C2[3];
+            cross3(j1, j2, C0);
+            cross3(j2, j0, C1);
+            cross3(j0, j1, C2);
+            const double det = j0[0] * C0[0] + j0[1] * C0[1] + j0[2] * C0[2];
+            const double s = 0.125 * c0 / fabs(det);
+            double G[8][3];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+            {
+              const double lx = (i & 1) ? xi : 1.0 - xi, ly = (i & 2) ? eta : 1.0 - eta, lz = (i & 4) ? zeta : 1.0 - zeta;
+              const double d0 = hat_sign(i & 1) * ly * lz, d1 = hat_sign(i & 2) * lx * lz, d2 = hat_sign(i & 4) * lx * ly;
+#pragma unroll
+              for (int r = 0; r < 3; ++r)
+                G[i][r] = fma(C2[r], d2, fma(C1[r], d1, C0[r] * d0));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+            {
+              const double h0 = s * G[i][0], h1 = s * G[i][1], h2 = s * G[i][2];
+#pragma unroll
+              for (int j = i; j < 8; ++j)
+                A[tri8(i, j)] = fma(h2, G[j][2], fma(h1, G[j][1], fma(h0, G[j][0], A[tri8(i, j)])));
+            }
+          }
+    }
+    // scatter: rows of this block that are not masked, unmasked columns
+    const uint32_t ow[16] = {cur[2].x, cur[2].y, cur[2].z, cur[2].w, cur[3].x, cur[3].y, cur[3].z, cur[3].w,
+                             cur[4].x, cur[4].y, cur[4].z, cur[4].w, cur[5].x, cur[5].y, cur[5].z, cur[5].w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+    {
+      const int r = v[i] & DOF_MASK;
+      const bool mine = r >= r0 && r < r1 && !(v[i] >> MASK_SHIFT);
+      if (!mine)
+        continue;
+      const int base = s_rowlo[r - r0];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+      {
+        if (v[j] >> MASK_SHIFT)
+          continue;
+        const int off = int((ow[(i * 8 + j) >> 2] >> (8 * ((i * 8 + j) & 3))) & 0xff);
+        __hip_atomic_fetch_add(s_vals + base + off, A[i <= j ? tri8(i, j) : tri8(j, i)], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    if (has_next)
+    {
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        cur[i] = nxt[i];
+    }
+  }
+  __syncthreads();
+  if (a.store_mode)
+    for (int i = tid; i < nnzb; i += NT)
+      a.vals[nnz0 + i] = s_vals[i];
+  else
+    for (int i = tid; i < nnzb; i += NT)
+      a.vals[nnz0 + i] += s_vals[i];
+}
+
+// vector: scalar Q1 source term c * f v dx over an NQ1^3 Gauss rule, one thread per hexahedron, owner-computes row
+// blocks (the plan of vector_cube_own_kernel with cube_verts = the cell dofmap).  The points are walked line by line
+// in X: the map and two Jacobian columns are linear along a line (three fma each per point), the basis sums are
+// sum-factorised (two fma per point, four per line, eight per plane).
+template <int FN, int NQ1>
+__global__ void __launch_bounds__(VCUBE_OWN_THREADS) vector_hex_own_kernel(mpcx_vector_args_t a)
+{
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* s_b = reinterpret_cast<double*>(smem);
+  const int NT = blockDim.x;
+  const int nb = a.plan.num_blocks;
+  const int per = (nb + 7) >> 3;
+  const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int tid = threadIdx.x;
+  const int r0 = b < nb ? a.plan.block_row0[b] : 0, r1 = b < nb ? a.plan.block_row0[b + 1] : 0;
+  const int64_t h0 = b < nb ? a.own_hoff[b] : 0, h1 = b < nb ? a.own_hoff[b + 1] : 0;
+  const int nown = r1 - r0, nhalo = int(h1 - h0);
+  for (int i = tid; i < nown + nhalo; i += NT)
+    s_b[i] = 0.0;
+  fastmath_init_lds(); // ends in a barrier
+  if (b >= nb)
+    return;
+  using GQ = Gauss01<NQ1>;
+  const double cst = a.constants ? a.constants[0] : 1.0;
+  [[maybe_unused]] FmConsts FK;
+  if constexpr (FN == 1)
+    FK = g_fm_consts; // uniform loads: the polynomial coefficients live in scalar registers
+  const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  const int32_t* __restrict__ ents = a.plan.block_ents;
+  for (int64_t t = e0 + tid; t < e1; t += NT)
+  {
+    const int64_t cell = ents[t];
+    double c[8][3];
+    {
+      int32_t v[8];
+      const uint4* p = reinterpret_cast<const uint4*>(a.cube_verts + cell * 8);
+      const uint4 w0 = p[0], w1 = p[1];
+      v[0] = w0.x, v[1] = w0.y, v[2] = w0.z, v[3] = w0.w, v[4] = w1.x, v[5] = w1.y, v[6] = w1.z, v[7] = w1.w;
+      double X[8][3];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          X[i][k] = a.x[3 * int64_t(v[i]) + k];
+      hex_coefficients(X, c);
+    }
+    if constexpr (FN == 1)
+    {
+      // coordinates relative to the centre of the benchmark function's Gaussian (see ElementOp::tabulate)
+      c[0][0] -= 0.9;
+      c[0][1] -= 0.5;
+      c[0][2] -= 0.1;
+    }
+    double be[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      be[i] = 0.0;
+#pragma unroll
+    for (int qz = 0; qz < NQ1; ++qz)
+    {
+      const double zeta = GQ::P[qz];
+      double B0[3], B1[3]; // j1 = B0 + B1 X
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+      {
+        B0[r] = fma(c[6][r], zeta, c[2][r]);
+        B1[r] = fma(c[7][r], zeta, c[3][r]);
+      }
+      double V[2][2] = {{0.0, 0.0}, {0.0, 0.0}}; // V[by][bx]: sums of this plane
+#pragma unroll
+      for (int qy = 0; qy < NQ1; ++qy)
+      {
+        const double eta = GQ::P[qy];
+        double A0[3], A1[3], D0[3], D1[3]; // x = A0 + A1 X (A1 = j0), j2 = D0 + D1 X
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+        {
+          A0[r] = fma(c[6][r], eta * zeta, fma(c[4][r], zeta, fma(c[2][r], eta, c[0][r])));
+          A1[r] = fma(c[7][r], eta * zeta, fma(c[5][r], zeta, fma(c[3][r], eta, c[1][r])));
+          D0[r] = fma(c[6][r], eta, c[4][r]);
+          D1[r] = fma(c[7][r], eta, c[5][r]);
+        }
+        double T0 = 0.0, T1 = 0.0;
+#pragma unroll
+        for (int qx = 0; qx < NQ1; ++qx)
+        {
+          const double xi = GQ::P[qx];
+          double x[3], j1[3], j2[3], cr[3];
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+          {
+            x[r] = fma(A1[r], xi, A0[r]);
+            j1[r] = fma(B1[r], xi, B0[r]);
+            j2[r] = fma(D1[r], xi, D0[r]);
+          }
+          cross3(j1, j2, cr);
+          const double det = A1[0] * cr[0] + A1[1] * cr[1] + A1[2] * cr[2];
+          double f;
+          if constexpr (FN == 1)
+          {
+            const double tt = fma(5.0, x[1], 2.5); // 5 y with y = x[1] + 0.5
+            f = (x[0] + 0.9) * fast_sinpi_k(tt, FK)
+                + fast_exp_nonpos_k(-(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]) * (1.0 / 0.02), FK);
+          }
+          else
+            f = eval_fn(FN >= 0 ? FN : a.kernel.fn_id, x, 0, a.constants);
+          const double F = f * ((GQ::W[qx] * GQ::W[qy] * GQ::W[qz]) * cst) * fabs(det);
+          T0 = fma(F, 1.0 - xi, T0);
+          T1 = fma(F, xi, T1);
+        }
+        V[0][0] = fma(T0, 1.0 - eta, V[0][0]);
+        V[0][1] = fma(T1, 1.0 - eta, V[0][1]);
+        V[1][0] = fma(T0, eta, V[1][0]);
+        V[1][1] = fma(T1, eta, V[1][1]);
+      }
+#pragma unroll
+      for (int by = 0; by < 2; ++by)
+#pragma unroll
+        for (int bx = 0; bx < 2; ++bx)
+        {
+          be[by * 2 + bx] = fma(V[by][bx], 1.0 - zeta, be[by * 2 + bx]);
+          be[4 + by * 2 + bx] = fma(V[by][bx], zeta, be[4 + by * 2 + bx]);
+        }
+    }
+    // LDS positions of the eight vertices (read after the quadrature: eight registers less across it)
+    int32_t w[8];
+    {
+      const uint4* p = reinterpret_cast<const uint4*>(a.own_lmap + cell * 8);
+      const uint4 w0 = p[0], w1 = p[1];
+      w[0] = w0.x, w[1] = w0.y, w[2] = w0.z, w[3] = w0.w, w[4] = w1.x, w[5] = w1.y, w[6] = w1.z, w[7] = w1.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (!(w[i] >> MASK_SHIFT))
+        __hip_atomic_fetch_add(s_b + (w[i] & DOF_MASK), be[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __syncthreads();
+  for (int i = tid; i < nown; i += NT)
+    a.b[r0 + i] += s_b[i];
+  for (int i = tid; i < nhalo; i += NT)
+    a.own_spill[h0 + i] = s_b[nown + i];
+}
 } // namespace
 
 static int launch_matrix_cubes_elasticity(const mpcx_matrix_args_t& a)
@@ -962,9 +1402,62 @@ static int launch_matrix_cubes_elasticity(const mpcx_matrix_args_t& a)
   return check(hipGetLastError(), "elasticity cluster kernel launch");
 }
 
+static int launch_matrix_hex(const mpcx_matrix_args_t& a)
+{
+  const mpcx_kernel_t& k = a.kernel;
+  if (k.form != MPCX_FORM_STIFFNESS || k.degree != 1 || k.bs != 1 || k.degree1 != 1 || k.bs1 != 1 || k.coeff_degree != 0
+      || a.coeffs || a.estride != 1 || a.nv != 8 || k.nq != 8)
+  {
+    mpcx_set_error("mpcx_assemble_matrix: on hexahedra the cluster algorithm covers the scalar Q1 stiffness form with the "
+                   "2 x 2 x 2 Gauss rule, without coefficients");
+    return -10;
+  }
+  if (a.plan.num_blocks <= 0 || !a.plan.block_row0 || !a.plan.block_ent_off)
+  {
+    mpcx_set_error("mpcx_assemble_matrix: the cluster algorithm needs records (mpcx_hex_records) and a row-block plan");
+    return -3;
+  }
+  if (a.cube_rec_bytes != 0 && a.cube_rec_bytes != 96)
+  {
+    mpcx_set_error("mpcx_assemble_matrix: hexahedra take 96-byte records");
+    return -6;
+  }
+  const size_t lds = size_t(a.plan.max_nnz) * 8 + size_t(a.plan.max_rows) * 4;
+  if (lds > 160 * 1024)
+  {
+    mpcx_set_error("mpcx_assemble_matrix: row-block plan exceeds 160 KiB of LDS");
+    return -4;
+  }
+  static const bool no_affine = std::getenv("MPCX_HEX_NO_AFFINE") != nullptr;
+  const bool only_affine = (a.cube_flags & 1) != 0 && !no_affine; // the caller vouches for the cells of this launch
+  const void* kern = no_affine ? reinterpret_cast<const void*>(matrix_hex_kernel<0>)
+                               : (only_affine ? reinterpret_cast<const void*>(matrix_hex_kernel<2>)
+                                              : reinterpret_cast<const void*>(matrix_hex_kernel<1>));
+  if (int rc = check(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)), "hipFuncSetAttribute"))
+    return rc;
+  // threads per workgroup: the closed-form instance is light (104 registers): 512 threads put every slot of a 256-row
+  // block (~400) in flight at once, 1.38 ms against 1.66 with 256 threads; the instance with the quadrature path (252
+  // registers) runs two waves per SIMD either way: 256 threads 1.75 ms, 512 2.28 ms
+  const int dflt = only_affine ? 512 : 256;
+  const char* e = std::getenv("MPCX_HEX_THREADS");
+  int threads = e ? std::atoi(e) : dflt;
+  if (threads < 64 || threads > HEX_MAX_THREADS || threads % 64)
+    threads = dflt;
+  const unsigned grid = 8u * unsigned((a.plan.num_blocks + 7) / 8);
+  if (no_affine)
+    hipLaunchKernelGGL(matrix_hex_kernel<0>, dim3(grid), dim3(threads), lds, static_cast<hipStream_t>(a.stream), a);
+  else if (only_affine)
+    hipLaunchKernelGGL(matrix_hex_kernel<2>, dim3(grid), dim3(threads), lds, static_cast<hipStream_t>(a.stream), a);
+  else
+    hipLaunchKernelGGL(matrix_hex_kernel<1>, dim3(grid), dim3(threads), lds, static_cast<hipStream_t>(a.stream), a);
+  return check(hipGetLastError(), "hexahedron matrix kernel launch");
+}
+
 int launch_matrix_cubes(const mpcx_matrix_args_t& a)
 {
   const mpcx_kernel_t& k = a.kernel;
+  if (k.celltype == MPCX_CELL_HEXAHEDRON)
+    return launch_matrix_hex(a);
   if (k.form == MPCX_FORM_ELASTICITY && k.celltype == MPCX_CELL_TETRAHEDRON && k.degree == 1 && k.bs == 3 && k.degree1 == 1
       && k.bs1 == 3 && !a.coeffs && a.estride == 1 && a.nv == 4)
     return launch_matrix_cubes_elasticity(a);
@@ -1019,9 +1512,60 @@ int launch_matrix_cubes(const mpcx_matrix_args_t& a)
   return check(hipGetLastError(), "matrix cluster kernel launch");
 }
 
+static int launch_vector_hex(const mpcx_vector_args_t& a)
+{
+  const mpcx_kernel_t& k = a.kernel;
+  if (k.form != MPCX_FORM_SOURCE || k.degree != 1 || k.bs != 1 || k.coeff_degree != 0 || a.coeffs || a.nv != 8 || !a.cube_verts
+      || (k.nq != 1 && k.nq != 8 && k.nq != 27) || (k.fn_id != 0 && k.fn_id != 1))
+  {
+    mpcx_set_error("mpcx_assemble_vector: on hexahedra the cluster algorithm covers the scalar Q1 source form (fn_id 0 or 1, "
+                   "tensor Gauss rule of 1, 8 or 27 points) without coefficients");
+    return -10;
+  }
+  if (a.n_cubes == 0)
+    return 0;
+  if (!a.own_lmap || a.plan.num_blocks <= 0 || !a.own_hoff || !a.own_spill || !a.own_seg
+      || (a.n_own_rows > 0 && (!a.own_rows || !a.own_src)))
+  {
+    mpcx_set_error("mpcx_assemble_vector: hexahedra need the owner-computes plan (own_lmap ...)");
+    return -5;
+  }
+  const size_t lds = size_t(a.plan.max_rows) * 8;
+  if (lds > 96 * 1024)
+  {
+    mpcx_set_error("mpcx_assemble_vector: cluster owner plan exceeds the LDS budget");
+    return -4;
+  }
+  const unsigned g = 8u * unsigned((a.plan.num_blocks + 7) / 8);
+  hipStream_t st = static_cast<hipStream_t>(a.stream);
+  auto go = [&](auto kernel) -> int
+  {
+    if (int rc = check(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           int(lds)),
+                       "hipFuncSetAttribute"))
+      return rc;
+    hipLaunchKernelGGL(kernel, dim3(g), dim3(VCUBE_OWN_THREADS), lds, st, a);
+    return check(hipGetLastError(), "hexahedron vector kernel launch");
+  };
+  int rc = 0;
+  if (k.fn_id == 1)
+    rc = k.nq == 27 ? go(vector_hex_own_kernel<1, 3>) : (k.nq == 8 ? go(vector_hex_own_kernel<1, 2>) : go(vector_hex_own_kernel<1, 1>));
+  else
+    rc = k.nq == 27 ? go(vector_hex_own_kernel<-1, 3>) : (k.nq == 8 ? go(vector_hex_own_kernel<-1, 2>) : go(vector_hex_own_kernel<-1, 1>));
+  if (rc)
+    return rc;
+  if (a.n_own_rows > 0)
+    return launch_vector_spill_reduce(a, 1);
+  // (rows of slave dofs are skipped here; the caller moves them to their masters with the per-cell kernel over the
+  // slave cells -- on hexahedra an imported kernel, mpcx_assemble_vector with n_entities = 0)
+  return 0;
+}
+
 int launch_vector_cubes(const mpcx_vector_args_t& a)
 {
   const mpcx_kernel_t& k = a.kernel;
+  if (k.celltype == MPCX_CELL_HEXAHEDRON)
+    return launch_vector_hex(a);
   if (k.form != MPCX_FORM_SOURCE || k.celltype != MPCX_CELL_TETRAHEDRON || k.degree != 1 || k.bs != 1
       || k.coeff_degree != 0 || a.coeffs || a.nv != 4 || !a.cube_verts)
   {
@@ -1086,6 +1630,15 @@ extern "C" int mpcx_cube_detect(const int32_t* cells, int64_t n_groups, int32_t*
   hipLaunchKernelGGL(mpcx::cube_detect_kernel, dim3(mpcx::grid_for(n_groups, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), cells, n_groups, verts, ok);
   return mpcx::check(hipGetLastError(), "cube_detect launch");
+}
+
+extern "C" int mpcx_hex_slot_shapes(int64_t n_slots, const void* recs, const double* x, uint8_t* general, void* stream)
+{
+  if (n_slots == 0)
+    return 0;
+  hipLaunchKernelGGL(mpcx::hex_slot_shapes_kernel, dim3(mpcx::grid_for(n_slots, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), n_slots, static_cast<const mpcx::CubeRec*>(recs), x, general);
+  return mpcx::check(hipGetLastError(), "hex_slot_shapes launch");
 }
 
 extern "C" int mpcx_cube_slot_width(int64_t n_slots, const void* recs, uint8_t* wide, void* stream)
@@ -1161,8 +1714,25 @@ extern "C" int mpcx_cube_records(int64_t n_slots, const int32_t* block_ents, con
     mpcx_set_error("mpcx_cube_records: block size must be 1..3");
     return -6;
   }
-  hipLaunchKernelGGL(mpcx::cube_records_kernel, dim3(mpcx::grid_for(n_slots * 8, 256)), dim3(256), 0,
+  hipLaunchKernelGGL(mpcx::cube_records_kernel<false>, dim3(mpcx::grid_for(n_slots * 8, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), n_slots, block_ents, cube_verts, bs, bc, is_slave, rowptr, cols,
                      static_cast<mpcx::CubeRec*>(recs), overflow);
   return mpcx::check(hipGetLastError(), "cube_records launch");
+}
+
+extern "C" int mpcx_hex_records(int64_t n_slots, const int32_t* block_ents, const int32_t* cell_verts, int32_t bs,
+                                const int8_t* bc, const int8_t* is_slave, const mpcx_nnz_t* rowptr, const int32_t* cols,
+                                void* recs, int32_t* overflow, void* stream)
+{
+  if (n_slots == 0)
+    return 0;
+  if (bs != 1)
+  {
+    mpcx_set_error("mpcx_hex_records: scalar spaces only");
+    return -6;
+  }
+  hipLaunchKernelGGL(mpcx::cube_records_kernel<true>, dim3(mpcx::grid_for(n_slots * 8, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), n_slots, block_ents, cell_verts, bs, bc, is_slave, rowptr, cols,
+                     static_cast<mpcx::CubeRec*>(recs), overflow);
+  return mpcx::check(hipGetLastError(), "hex_records launch");
 }

@@ -2071,6 +2071,17 @@ extern "C" int mpcx_assemble_matrix(const mpcx_matrix_args_t* args)
   const mpcx_kernel_t& k = a.kernel;
   if (k.form == MPCX_FORM_UFCX)
     return launch_matrix_ufcx(a);
+  if (k.celltype == MPCX_CELL_HEXAHEDRON)
+  {
+    // hexahedra exist as cluster kernels only (bulk of the cells; the caller assembles the master contributions with
+    // the imported kernel of the same integral)
+    if (a.algorithm != MPCX_ALG_CUBE || a.n_slave_entities != 0)
+    {
+      mpcx_set_error("mpcx_assemble_matrix: built-in hexahedron operators run with MPCX_ALG_CUBE and n_slave_entities = 0");
+      return -10;
+    }
+    return launch_matrix_cubes(a);
+  }
   switch (k.form)
   {
   case MPCX_FORM_STIFFNESS:

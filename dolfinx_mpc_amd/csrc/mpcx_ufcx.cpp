@@ -942,6 +942,10 @@ int launch_vector_ufcx(const mpcx_vector_args_t& a)
         return rc;
     return launch(k->vector_mpc, a.n_slave_entities, a, a.stream);
   }
+  if (alg == MPCX_ALG_ROWBLOCK)
+    // no bulk entities: only the slave rows of a.slave_entities go to their masters (the bulk was assembled by another
+    // call that skipped them, e.g. the built-in hexahedron kernel of MPCX_ALG_CUBE)
+    return launch(k->vector_mpc, a.n_slave_entities, a, a.stream);
   return launch(k->vector, a.n_entities, a, a.stream);
 }
 int launch_lifting_ufcx(const mpcx_lifting_args_t& a)

@@ -43,6 +43,7 @@ class Ctx:
     p1_geometry: bool  # the space's dofmap IS the geometry dofmap (P1 on an affine mesh: one device array)
     same: bool  # test space is trial space, one constraint, one Dirichlet set
     tiled: bool  # the numbering carries tile hints (generators, mesh.reorder_spatial)
+    builtin_form: int = -1  # an imported kernel the library also knows as a built-in operator (fem.KernelSpec.builtin): its form id
 
 
 @dataclass
@@ -83,6 +84,12 @@ MATRIX: List[Kernel] = [
            "matrix_cube_elasticity_kernel: clusters, one thread per (slot, row component): 414 scatter-adds per cluster instead "
            "of 864 from six element tensors -- measured and NOT the default: contact elasticity (config 4) 1.81 ms vs 0.97 ms "
            "(rowpair); 256 VGPRs + 24 B scratch, and a 74 KB vector row block holds only ~125 slots x 3 threads"),
+    Kernel("hex_cube",
+           lambda c: (c.form == FORM_UFCX and c.builtin_form == FORM_STIFFNESS and c.same and c.p1_geometry and c.all_cells
+                      and c.cell_integral and not c.has_coefficient),
+           lambda c: True,
+           "matrix_hex_kernel: Q1 stiffness on hexahedra, thread per (row block, cell) slot, 96-byte records, closed form on "
+           "parallelepipeds; 256^3 cells: see DESIGN (generated UFCx kernel in the row blocks: 5.2 ms)"),
     Kernel("ufcx_rowblock", lambda c: c.form == FORM_UFCX, lambda c: True,
            "imported tabulate_tensor inside the LDS row-block kernel (hipRTC); config 2 with tests/ufcx/laplace_p1_tet.c: 2.32 ms "
            "vs 1.75 ms built-in, vs ~50 ms thread-per-entity atomics"),
@@ -115,6 +122,12 @@ VECTOR: List[Kernel] = [
                       and c.cell_integral and c.all_cells and c.p1_geometry),
            lambda c: False,
            "vector_cube_kernel: thread per cluster, LDS hash + one device atomic per distinct dof of the workgroup (2.82 ms)"),
+    Kernel("hex_own",
+           lambda c: (c.form == FORM_UFCX and c.builtin_form == FORM_SOURCE and c.p1_geometry and c.all_cells and c.cell_integral
+                      and not c.has_coefficient),
+           lambda c: True,
+           "vector_hex_own_kernel: Q1 source on hexahedra, thread per cell, owner-computes row blocks, sum-factorised basis, "
+           "fast sin / exp; 256^3 cells, 27 points: see DESIGN (generated UFCx kernel with libm: 4.1 ms)"),
     Kernel("ufcx_ownblock", lambda c: c.form == FORM_UFCX, lambda c: True,
            "imported tabulate_tensor, every entity evaluated once (its cost is unknown); config 2 with source_p1_tet.c 2.35 ms"),
     Kernel("ufcx_rowblock", lambda c: c.form == FORM_UFCX, lambda c: False, "imported tabulate_tensor, halo entities re-evaluated"),
@@ -136,6 +149,7 @@ VECTOR: List[Kernel] = [
 
 # table entry -> the __global__ function it launches (profiles, bench.py's per-kernel roofline lines)
 FUNCTION = {
+    ("matrix", "hex_cube"): "matrix_hex_kernel", ("vector", "hex_own"): "vector_hex_own_kernel",
     ("matrix", "cube"): "matrix_cube_kernel", ("matrix", "cube_el"): "matrix_cube_elasticity_kernel", ("matrix", "ufcx_rowblock"): "ufcx_matrix_rowblock_kernel",
     ("matrix", "rowpair"): "matrix_rowpair_kernel", ("matrix", "nodeblock"): "matrix_nodeblock_kernel",
     ("matrix", "rowblock_lean"): "matrix_rowblock_kernel", ("matrix", "rowblock"): "matrix_rowblock_kernel",
@@ -162,7 +176,7 @@ def _legacy_matrix(c: Ctx):
     ex, prefer = set(), None
     env = os.environ
     if env.get("MPCX_NO_CUBE"):
-        ex |= {"cube", "cube_el"}
+        ex |= {"cube", "cube_el", "hex_cube"}
     if env.get("MPCX_NO_LEAN"):
         ex |= {"cube", "cube_el", "rowblock_lean"}
     mode = env.get("MPCX_ROWPAIR", "auto")
@@ -181,7 +195,7 @@ def _legacy_vector(c: Ctx):
     ex, prefer = set(), None
     env = os.environ
     if env.get("MPCX_NO_CUBE"):
-        ex |= {"cube_own", "cube_hash"}
+        ex |= {"cube_own", "cube_hash", "hex_own"}
     if env.get("MPCX_VCUBE_OWNER", "1") == "0":
         ex.add("cube_own")
         prefer = "cube_hash"

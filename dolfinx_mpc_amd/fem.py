@@ -374,6 +374,10 @@ class KernelSpec:
     bs1: int = 0
     ufcx_source: str = ""  # FORM_UFCX: C source of the tabulate_tensor function and its name
     ufcx_name: str = ""
+    # FORM_UFCX: the same integral as a built-in operator of the library, where it has one (hexahedra: the cluster
+    # kernels of MPCX_ALG_CUBE take the bulk of the cells; constrained cells, lifting and the plan-free algorithm
+    # keep running the imported kernel)
+    builtin: Optional["KernelSpec"] = None
 
 
 class Integral:
@@ -531,7 +535,16 @@ def _hex_form(V, kind: str, constant=None, coefficient: Optional[Function] = Non
                              fexpr=fexpr, coefficient=coefficient is not None)
     name_q = f"{name}_f{fn_id}"
     src = src.replace(name, name_q)
-    return form_ufcx([V] if kind == "source" else [V, V], src, name_q, "cell", cells, coefficient, constant)
+    form = form_ufcx([V] if kind == "source" else [V, V], src, name_q, "cell", cells, coefficient, constant)
+    # the integrals the library also knows as built-in hexahedron operators (csrc/mpcx_cubes.hip: matrix_hex_kernel,
+    # vector_hex_own_kernel): scalar stiffness with the 2 x 2 x 2 rule, scalar sources with f = 1 or the benchmark's f
+    if V.dofmap.bs == 1 and coefficient is None:
+        pts, wts = gauss_hex(qdeg)
+        if kind == "stiffness" and wts.size == 8:
+            form.integrals[0].kernel.builtin = KernelSpec(FORM_STIFFNESS, CELL_HEXAHEDRON, 1, 1, 0, 0, pts, wts)
+        elif kind == "source" and wts.size in (1, 8, 27) and fn_id in (FN_ONE, FN_BENCH_PERIODIC):
+            form.integrals[0].kernel.builtin = KernelSpec(FORM_SOURCE, CELL_HEXAHEDRON, 1, 1, fn_id, 0, pts, wts)
+    return form
 
 
 def form_stiffness(V, constant=None, coefficient: Optional[Function] = None, cells=None) -> Form:

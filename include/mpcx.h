@@ -45,7 +45,11 @@ enum {
   /* an imported UFCx tabulate_tensor (mpcx_ufcx_compile): mpcx_kernel_t::ufcx holds the handle */
   MPCX_FORM_UFCX = 100
 };
-enum { MPCX_CELL_TRIANGLE = 1, MPCX_CELL_TETRAHEDRON = 2 };
+/* MPCX_CELL_HEXAHEDRON (Q1, trilinear geometry, DOLFINx tensor-product vertex order: local vertex v sits at
+ * (v & 1, v >> 1 & 1, v >> 2 & 1) of the reference cube) is known to the MPCX_ALG_CUBE kernels only: scalar
+ * stiffness (nq = 8: 2 x 2 x 2 Gauss points) and source forms (nq = 1, 8 or 27), one thread per hexahedron.  Every other
+ * path of a hexahedral mesh runs an imported kernel (MPCX_FORM_UFCX). */
+enum { MPCX_CELL_TRIANGLE = 1, MPCX_CELL_TETRAHEDRON = 2, MPCX_CELL_HEXAHEDRON = 3 };
 
 /* algorithms for the matrix scatter */
 enum {
@@ -56,7 +60,9 @@ enum {
    * generator emits per cube) instead of single cells: one thread sums the six element tensors in registers
    * and scatters 46 entries instead of 96; vectors: 8 contributions instead of 24.  Scalar P1 stiffness /
    * source forms on tetrahedra only; cells outside any cluster go through a second call with one of the
-   * per-cell algorithms.  See mpcx_cube_records. */
+   * per-cell algorithms.  See mpcx_cube_records.
+   * On hexahedra (kernel.celltype = MPCX_CELL_HEXAHEDRON) the unit of work is the cell itself: eight vertices, all
+   * 64 pairs coupled (records of mpcx_hex_records, 96-byte format only; vectors: cube_verts = the cell dofmap). */
   MPCX_ALG_CUBE = 3
 };
 
@@ -220,6 +226,11 @@ typedef struct
    * cube_block_ids[j] of plan.block_row0, its slots are [plan.block_ent_off[j], plan.block_ent_off[j+1]) of cube_recs.
    * The caller launches the narrow and the wide blocks separately (both with store_mode as for one launch). */
   int32_t cube_rec_bytes;
+  /* hexahedra, bit 0: every cell of this launch's slots is a parallelepiped (mpcx_hex_slot_shapes says so for all of
+   * them): the closed form of the stiffness integral is taken without looking, by a kernel instance that does not
+   * carry the quadrature path (104 instead of 252 registers: twice the waves per SIMD).  The caller launches such row
+   * blocks separately from the rest (cube_block_ids), like the two record formats of the tetrahedral clusters. */
+  int32_t cube_flags;
   const int32_t* cube_block_ids;
   /* rowblock, component-diagonal forms on blocked spaces (bs0 == bs1 = bs > 1), optional: DEVICE [nnz / bs^2], one
    * byte per bs x bs block of the CSR (block s of node row n = entries rowptr[n*bs] / bs^2 + s), bit k set = entry
@@ -289,6 +300,18 @@ int mpcx_scatter_offsets(const mpcx_nnz_t* rowptr, const int32_t* cols, int32_t 
 int mpcx_cube_records(int64_t n_slots, const int32_t* block_ents, const int32_t* cube_verts, int32_t bs, const int8_t* bc,
                       const int8_t* is_slave, const mpcx_nnz_t* rowptr, const int32_t* cols, void* recs,
                       int32_t* overflow, void* stream);
+
+/* The same records for hexahedra (cube_verts = the Q1 cell dofmap [n_cells][8], every one of the 64 vertex pairs
+ * coupled): the reference's per-row column search behind MatSetValuesLocal (cpp/assemble_matrix.cpp:546), hoisted
+ * to set-up like mpcx_scatter_offsets does for the per-cell kernels. */
+int mpcx_hex_records(int64_t n_slots, const int32_t* block_ents, const int32_t* cell_verts, int32_t bs, const int8_t* bc,
+                     const int8_t* is_slave, const mpcx_nnz_t* rowptr, const int32_t* cols, void* recs,
+                     int32_t* overflow, void* stream);
+
+/* general[k] = 1 if the hexahedron of record k is NOT a parallelepiped: one of the bilinear / trilinear coefficients of
+ * its map exceeds 2^-46 of the largest edge-vector component -- the test matrix_hex_kernel applies per wave when
+ * mpcx_matrix_args_t::cube_flags does not vouch for the launch (all pointers DEVICE; x [num_nodes][3]). */
+int mpcx_hex_slot_shapes(int64_t n_slots, const void* recs, const double* x, uint8_t* general, void* stream);
 
 /* Narrow records (all pointers DEVICE): mpcx_cube_slot_width: wide[k] = 1 if a coupled offset of record k exceeds 15;
  * mpcx_cube_pack_narrow: out[j] (64 bytes: the 8 ids, then 46 nibbles in row-major order of the coupled pairs) from the

@@ -201,11 +201,13 @@ def renumbered(mesh, numbering: str, seed: int = 0):
     return reorder_spatial(mesh, tile_nodes=64) if numbering == "spatial" else mesh
 
 
-def warped(mesh, amplitude=0.15):
+def warped(mesh, amplitude=0.15, half=False):
     """the same mesh with interior nodes moved by a smooth field (faces of the unit cube stay put, so that the
     geometric markers of the cases keep working): hexahedra become genuinely trilinear, tets stay affine"""
     x = mesh.geometry.x.copy()
     bump = np.sin(np.pi * x[:, 0]) * np.sin(np.pi * x[:, 1]) * np.sin(np.pi * x[:, 2])
+    if half:  # only the part x < 0.3 moves: a mesh of parallelepipeds and genuinely trilinear cells
+        bump = bump * (x[:, 0] < 0.3)
     x[:, 0] += amplitude * bump * np.sin(2.0 * x[:, 1] + 1.0) / 3.0
     x[:, 1] += amplitude * bump * np.cos(3.0 * x[:, 2]) / 3.0
     x[:, 2] += amplitude * bump * np.sin(1.0 + 2.0 * x[:, 0]) / 3.0
@@ -218,7 +220,7 @@ def case_cube_periodic(N=4, degree=1, bc_value=0.0, reorder=None, numbering=None
     the script's own default cell (:38, :199-200)"""
     mesh = create_unit_cube(N, N, N, cell_type, reorder=reorder)
     if warp:
-        mesh = warped(mesh)
+        mesh = warped(mesh, half=(warp == "half"))
     if numbering is not None:
         mesh = renumbered(mesh, numbering)
     V = fem.functionspace(mesh, ("Lagrange", degree))

@@ -206,9 +206,19 @@ def test_oracle_constrained_operators_on_hexahedra(oracle, make):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("alg", ["rowblock", "atomic"])
+@pytest.mark.parametrize("alg", ["auto", "rowblock", "atomic", "generated", "no_affine"])
 @pytest.mark.parametrize("make", HEX_CASES, ids=[f"hex{i}" for i in range(len(HEX_CASES))])
-def test_gpu_hexahedra_match_oracle(oracle, make, alg):
+def test_gpu_hexahedra_match_oracle(oracle, make, alg, monkeypatch):
+    """auto: the built-in hexahedron kernels where they apply (scalar stiffness / source forms without coefficient: slots
+    of (row block, cell), thread per cell) + the generated kernels for the constrained cells and everything else;
+    rowblock: built-in matrix kernel, generated vector kernel; generated: the generated kernels everywhere
+    (MPCX_NO_CUBE); no_affine: the quadrature path of the built-in matrix kernel also on parallelepipeds"""
+    if alg == "generated":
+        monkeypatch.setenv("MPCX_NO_CUBE", "1")
+    if alg == "no_affine":
+        monkeypatch.setenv("MPCX_HEX_NO_AFFINE", "1")
+    if alg in ("generated", "no_affine"):
+        alg = "auto"
     case = make()
     ref = oracle_outputs(oracle, case)
     out = product_outputs(case, algorithm=alg)
@@ -219,7 +229,7 @@ def test_gpu_hexahedra_match_oracle(oracle, make, alg):
 
 
 @pytest.mark.gpu
-def test_gpu_hexahedra_default_route_is_the_row_block_kernel():
+def test_gpu_hexahedra_default_route():
     import importlib
 
     import dolfinx_mpc_amd as dm
@@ -233,8 +243,16 @@ def test_gpu_hexahedra_default_route_is_the_row_block_kernel():
     mpc = product_mpc(case)
     A = dm.create_matrix(case.a, mpc)
     args, keep = am.matrix_args(case.a, 0, A, mpc, mpc, case.bcs, 2)
-    assert args.kernel_name == "ufcx_rowblock"
+    assert args.kernel_name == "hex_cube" and args.second is not None  # built-in bulk + generated kernel on the slave cells
     args, keep = av.vector_args(case.L, 0, create_vector(case.V), mpc, 0)
+    assert args.kernel_name == "hex_own" and args.second is not None
+    # forms without a built-in twin (here: with a coefficient) run the generated kernel inside the row blocks
+    cc = _coefficient_case(False)
+    mpc = product_mpc(cc)
+    A = dm.create_matrix(cc.a, mpc)
+    args, keep = am.matrix_args(cc.a, 0, A, mpc, mpc, cc.bcs, 2)
+    assert args.kernel_name == "ufcx_rowblock"
+    args, keep = av.vector_args(cc.L, 0, create_vector(cc.V), mpc, 0)
     assert args.kernel_name == "ufcx_ownblock"
 
 
@@ -256,3 +274,49 @@ def test_gpu_hexahedra_at_size_properties():
     assert abs(A0 @ np.ones(case.V.num_dofs)).max() < 1e-12
     M = dm.assemble_matrix(fem.form_mass(case.V), free).to_scipy()
     assert abs(M.sum() - 1.0) < 1e-11
+    # vector: thread-per-cell built-in kernel (owner-computes) against the generated kernel with device atomics
+    b = dm.assemble_vector(case.L, mpc).numpy().copy()
+    b2 = dm.assemble_vector(case.L, mpc, algorithm="atomic").numpy().copy()
+    assert abs(b - b2).max() <= 1e-12 * max(1.0, abs(b2).max())
+    # (the determinant of a trilinear map is quadratic in every variable: two points per direction are exact)
+    one = dm.assemble_vector(fem.form_source(case.V, fem.FN_ONE, quadrature_degree=3), free).numpy()
+    assert abs(one.sum() - 1.0) < 1e-11
+
+
+@pytest.mark.gpu
+def test_gpu_hexahedra_blocks_split_by_cell_shape(oracle, monkeypatch):
+    """a mesh of parallelepipeds (x > 0.375) and genuinely trilinear cells, numbered in tiles of 4 x 4 x 4 nodes = one row block: the row blocks all of whose cells are
+    parallelepipeds go to the closed-form kernel instance, the others to the instance that looks at every cell;
+    moving the mesh afterwards rebuilds the split"""
+    import importlib
+
+    import dolfinx_mpc_amd as dm
+    from problems import product_mpc, warped
+
+    am = importlib.import_module("dolfinx_mpc_amd.assemble_matrix")
+    monkeypatch.setattr(am, "HEX_MAX_ROWS", 64)
+    monkeypatch.setattr(am, "HEX_MAX_NNZ", 64 * 27)
+    case = case_cube_periodic(8, cell_type="hexahedron", warp="half", reorder=(4, 4, 4))
+    ref = oracle_outputs(oracle, case)
+    mpc = product_mpc(case)
+    A = dm.create_matrix(case.a, mpc)
+    args, keep = am.matrix_args(case.a, 0, A, mpc, mpc, case.bcs, 2)
+    chain, u = [], args
+    while u is not None:
+        chain.append(u)
+        u = u.second
+    assert [int(u.cube_flags) for u in chain[:2]] == [1, 0] and chain[0].cube_block_ids and chain[1].cube_block_ids
+    assert int(chain[0].plan.num_blocks) > 0 and int(chain[1].plan.num_blocks) > 0
+    assert chain[-1].n_entities == 0 and chain[-1].n_slave_entities > 0  # the imported kernel on the slave cells
+    dm.assemble_matrix(case.a, mpc, bcs=case.bcs, diagval=case.diagval, A=A)
+    got = A.to_scipy()
+    assert abs(got.data - ref["A"].data).max() <= 1e-12 * max(1.0, abs(ref["A"]).max())
+    # move the mesh: every cell becomes trilinear; same matrix object, same form
+    warped(case.V.mesh)
+    ref2 = oracle_outputs(oracle, case)
+    assert abs(ref2["A"] - ref["A"]).max() > 1e-3
+    dm.assemble_matrix(case.a, mpc, bcs=case.bcs, diagval=case.diagval, A=A)
+    got2 = A.to_scipy()
+    assert abs(got2.data - ref2["A"].data).max() <= 1e-12 * max(1.0, abs(ref2["A"]).max())
+    b = dm.assemble_vector(case.L, mpc).numpy()
+    assert abs(b - ref2["b"]).max() <= 1e-12 * max(1.0, abs(ref2["b"]).max())
