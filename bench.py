@@ -623,6 +623,8 @@ def main():
         ufcx_form = f.integrals[0].kernel.form == 100
         entry = getattr(margs, "kernel_name", None) or ("ufcx_atomic" if ufcx_form else "atomic")
         kname = dispatch.FUNCTION[("matrix", entry)]
+        if entry == "cube" and int(margs.cube_flags) & 1:
+            kname = "matrix_cube_affine_kernel"  # every row block of the first launch holds parallelepiped clusters only
         kernels.append({"kernel": f"{kname}[{label}]", "call": f"assemble_matrix[{label}]", "launch_ms": tk,
                         "algorithmic_bytes": int(nbytes), "pmc_name": kname, "value_storage": "block-scalar" if margs.block_scalar else "csr",
                         "fp64_flops": algorithmic_flops(f.integrals[0], V0, V1) * f.integrals[0].num_entities})

@@ -526,80 +526,73 @@ def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc, hexa: bool = F
             raise _native.PlanNotRepresentable("cluster algorithm: a scatter offset does not fit 8 bits (or a column is missing)")
         max_rows = int(np.diff(row0).max())
         max_nnz = int(np.diff(A.rowptr[row0]).max())
-        parts = None
-        if bs == 1 and not hexa and os.environ.get("MPCX_CUBE_NARROW", "1") != "0" and nslots > 0:
-            # narrow records (64 B, 4-bit offsets) for the row blocks all of whose slots allow it, the 96-byte format
-            # for the rest (blocks that hold fat rows: master rows of a constraint); launched separately
+        # Row blocks are launched by KIND: record format (tetrahedral clusters: 64-byte records with 4-bit offsets for the
+        # row blocks all of whose slots allow it, 96 bytes for blocks that hold fat rows -- master rows of a constraint) and
+        # cell shape (row blocks all of whose clusters / hexahedra are parallelepipeds go to the kernel instance that
+        # carries only the closed form of the integral: flag bit 0).  One part, one launch per kind that occurs.
+        want_narrow = bs == 1 and not hexa and os.environ.get("MPCX_CUBE_NARROW", "1") != "0"
+        want_shape = bs == 1 and os.environ.get("MPCX_CUBE_SHAPES", os.environ.get("MPCX_HEX_SPLIT", "1")) != "0"
+        kind = torch.zeros(nb, dtype=torch.int64, device=dev)  # per block: bit 0 = a wide slot, bit 1 = a general cell
+
+        def any_per_block(slot_flag):
+            cs = torch.zeros(nslots + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(slot_flag.to(torch.int64), 0, out=cs[1:])
+            return (cs[d_off[1:]] - cs[d_off[:-1]]) > 0
+
+        if nslots > 0 and want_narrow:
             wide = torch.empty(nslots, dtype=torch.uint8, device=dev)
             _native.check(L.mpcx_cube_slot_width(nslots, recs.data_ptr(), wide.data_ptr(), D.stream_ptr()), "mpcx_cube_slot_width")
-            cs = torch.zeros(nslots + 1, dtype=torch.int64, device=dev)
-            torch.cumsum(wide.to(torch.int64), 0, out=cs[1:])
-            per_block = cs[d_off[1:]] - cs[d_off[:-1]]
-            del wide, cs
-            sel_n = torch.nonzero(per_block == 0).reshape(-1)
-            sel_w = torch.nonzero(per_block > 0).reshape(-1)
-            if sel_n.numel() > 0:
-                parts = []
-                for sel, nbytes in ((sel_n, 64), (sel_w, 96)):
-                    if sel.numel() == 0:
-                        continue
-                    cnt = d_off[sel + 1] - d_off[sel]
-                    off_c = torch.zeros(sel.numel() + 1, dtype=torch.int64, device=dev)
-                    torch.cumsum(cnt, 0, out=off_c[1:])
-                    tot = int(off_c[-1].item())
-                    src = torch.repeat_interleave(d_off[sel] - off_c[:-1], cnt) + torch.arange(tot, dtype=torch.int64, device=dev)
-                    if nbytes == 64:
-                        out = torch.empty(tot * 64, dtype=torch.uint8, device=dev)
-                        _native.check(L.mpcx_cube_pack_narrow(tot, src.data_ptr(), recs.data_ptr(), out.data_ptr(), D.stream_ptr()),
-                                      "mpcx_cube_pack_narrow")
-                    else:
-                        out = recs.view(nslots, 96)[src].contiguous().view(-1)
-                    ids = sel.to(torch.int32).contiguous()
-                    parts.append((_native.RowBlockPlanT(int(sel.numel()), max_rows, max_nnz, 0, d_row0.data_ptr(), off_c.data_ptr(),
-                                                        None, None, None), out, nbytes, ids, off_c))
-                del recs
-        if hexa and nslots > 0 and os.environ.get("MPCX_HEX_SPLIT", "1") != "0":
-            # row blocks all of whose cells are parallelepipeds go to the closed-form-only kernel instance (flag 1), the
-            # others to the instance that looks at every cell; launched separately, like the two record formats above
+            kind += any_per_block(wide).to(torch.int64)
+            del wide
+        else:
+            kind += 1
+        if nslots > 0 and want_shape:
             general = torch.empty(nslots, dtype=torch.uint8, device=dev)
             _native.check(L.mpcx_hex_slot_shapes(nslots, recs.data_ptr(), D.mesh_device(form.mesh)["x"].data_ptr(),
                                                  general.data_ptr(), D.stream_ptr()), "mpcx_hex_slot_shapes")
-            cs = torch.zeros(nslots + 1, dtype=torch.int64, device=dev)
-            torch.cumsum(general.to(torch.int64), 0, out=cs[1:])
-            per_block = cs[d_off[1:]] - cs[d_off[:-1]]
-            del general, cs
-            sel_a = torch.nonzero(per_block == 0).reshape(-1)
-            sel_g = torch.nonzero(per_block > 0).reshape(-1)
-            if sel_g.numel() == 0:
-                parts = [(_native.RowBlockPlanT(nb, max_rows, max_nnz, 0, d_row0.data_ptr(), d_off.data_ptr(), None, None, None),
-                          recs, 96, None, d_off, 1)]
-            elif sel_a.numel() > 0:
-                parts = []
-                for sel, flags in ((sel_a, 1), (sel_g, 0)):
-                    cnt = d_off[sel + 1] - d_off[sel]
-                    off_c = torch.zeros(sel.numel() + 1, dtype=torch.int64, device=dev)
-                    torch.cumsum(cnt, 0, out=off_c[1:])
-                    tot = int(off_c[-1].item())
-                    src = torch.repeat_interleave(d_off[sel] - off_c[:-1], cnt) + torch.arange(tot, dtype=torch.int64, device=dev)
-                    out = recs.view(nslots, 96)[src].contiguous().view(-1)
-                    ids = sel.to(torch.int32).contiguous()
-                    parts.append((_native.RowBlockPlanT(int(sel.numel()), max_rows, max_nnz, 0, d_row0.data_ptr(), off_c.data_ptr(),
-                                                        None, None, None), out, 96, ids, off_c, flags))
-                del recs
-        if parts is None:
-            parts = [(_native.RowBlockPlanT(nb, max_rows, max_nnz, 0, d_row0.data_ptr(), d_off.data_ptr(), None, None, None),
-                      recs, 96, None, d_off)]
+            kind += 2 * any_per_block(general).to(torch.int64)
+            del general
+        else:
+            kind += 2
+        kinds = [int(k) for k in torch.unique(kind).tolist()] if nb > 0 else [3]
+        parts = []
+        for kd in kinds:
+            nbytes, flags = (96 if kd & 1 else 64), (0 if kd & 2 else 1)
+            if len(kinds) == 1:
+                sel, ids, off_c, src = None, None, d_off, None
+                nblk = nb
+            else:
+                sel = torch.nonzero(kind == kd).reshape(-1)
+                cnt = d_off[sel + 1] - d_off[sel]
+                off_c = torch.zeros(sel.numel() + 1, dtype=torch.int64, device=dev)
+                torch.cumsum(cnt, 0, out=off_c[1:])
+                tot = int(off_c[-1].item())
+                src = torch.repeat_interleave(d_off[sel] - off_c[:-1], cnt) + torch.arange(tot, dtype=torch.int64, device=dev)
+                ids = sel.to(torch.int32).contiguous()
+                nblk = int(sel.numel())
+            if nbytes == 64:
+                if src is None:
+                    src = torch.arange(nslots, dtype=torch.int64, device=dev)
+                out = torch.empty(src.numel() * 64, dtype=torch.uint8, device=dev)
+                _native.check(L.mpcx_cube_pack_narrow(src.numel(), src.data_ptr(), recs.data_ptr(), out.data_ptr(), D.stream_ptr()),
+                              "mpcx_cube_pack_narrow")
+            else:
+                out = recs if src is None else recs.view(nslots, 96)[src].contiguous().view(-1)
+            parts.append((_native.RowBlockPlanT(nblk, max_rows, max_nnz, 0, d_row0.data_ptr(), off_c.data_ptr(), None, None, None),
+                          out, nbytes, ids, off_c, flags))
+        del recs
         keep = (d_row0, parts, d_verts)
         info = {"num_blocks": nb, "num_ents": int(nslots), "max_rows": max_rows, "max_nnz": max_nnz, "clusters": int(nc),
-                "narrow_blocks": int(parts[0][0].num_blocks) if parts[0][2] == 64 else 0,
+                "narrow_blocks": sum(int(p[0].num_blocks) for p in parts if p[2] == 64),
+                "closed_form_blocks": sum(int(p[0].num_blocks) for p in parts if p[5] == 1),
                 "bytes": int(d_row0.numel() * 4 + sum(p[1].numel() + p[4].numel() * 8 + (0 if p[3] is None else p[3].numel() * 4)
                                                       for p in parts))}
         return (parts, keep, info)
 
     try:
-        # (hexahedra: the split by cell shape depends on the coordinates -- a moved mesh gets a new plan)
+        # (the split by cell shape depends on the coordinates -- a moved mesh gets a new plan)
         plan, keep, info = D.cached(A._plans, "cubes", (form, mpc, bc_dev),
-                                    (i, max_rows_cfg, max_nnz_cfg, hexa, form.mesh.geometry.version if hexa else 0), build)
+                                    (i, max_rows_cfg, max_nnz_cfg, hexa, form.mesh.geometry.version), build)
     except _native.PlanNotRepresentable:
         return None
     return plan, keep, info, left
@@ -882,17 +875,23 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
                 a.leftover = left if left.size else None
                 a.kernel_name = name
                 a.vals = A.vals.data_ptr()
-                a.second = None  # (python attribute) the launch over the blocks of the other record format
-                for n_part, (plan, recs, nbytes, ids, _off) in enumerate(parts):
+                # one launch per kind of row block (record format, cell shape): a chain of follow-up calls (python attribute
+                # ``second``).  The master contributions ride on the LAST launch: the row blocks are written in store mode, so
+                # they must all be in place before anything is added to them
+                chain = []
+                n_slave = a.n_slave_entities
+                for n_part, part in enumerate(parts):
+                    plan, recs, nbytes, ids, _off = part[:5]
                     t = a if n_part == 0 else _native.MatrixArgs.from_buffer_copy(a)
                     t.plan = plan
                     t.cube_recs, t.cube_rec_bytes, t.cube_block_ids = recs.data_ptr(), nbytes, D.ptr(ids)
-                    if n_part == 1:
-                        # the master contributions ride on the LAST launch: the row blocks are written in store mode,
-                        # so they must all be in place before anything is added to them
-                        a.n_slave_entities = 0
+                    t.cube_flags = part[5] if (len(part) > 5 and name == "cube") else 0
+                    t.n_slave_entities = n_slave if n_part == len(parts) - 1 else 0
+                    if n_part > 0:
                         t.leftover, t.kernel_name, t.block_scalar = None, name, False
-                        a.second = t
+                    chain.append(t)
+                for u, v in zip(chain, chain[1:] + [None]):
+                    u.second = v
                 keep += [ck]
                 return a, keep
             if name == "rowpair":

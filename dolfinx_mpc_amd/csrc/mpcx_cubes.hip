@@ -1373,6 +1373,195 @@ __global__ void __launch_bounds__(VCUBE_OWN_THREADS) vector_hex_own_kernel(mpcx_
   for (int i = tid; i < nhalo; i += NT)
     a.own_spill[h0 + i] = s_b[nown + i];
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Tetrahedral clusters that are parallelepipeds (the six tets of a cube of a box mesh, sheared or not): with local
+// vertex b at corner (b & 1, b >> 1 & 1, b >> 2 & 1) of the reference cube and x = x0 + J X, the sum of the six element
+// tensors is a fixed linear combination of the six entries of M = c C^T C / |det J| (C = cofactor matrix of J):
+//     A_ij = sum_{d <= e} M_de K_de(i, j),   K_de(i, j) = sum over the tets holding i and j of
+//                                                        (g_i^d g_j^e + [d != e] g_i^e g_j^d) / 6,
+// g = the gradients of the barycentric coordinates on the reference Kuhn cube (entries 0, +-1).  Row blocks all of whose
+// clusters pass hex_is_parallelepiped at set-up (mpcx_hex_slot_shapes on the records; mpcx_matrix_args_t::cube_flags
+// bit 0) are launched with this kernel: ~100 registers instead of 236, four waves per SIMD instead of two cover the
+// record -> coordinates round trip that the general kernel hides with its software pipeline.
+// ---------------------------------------------------------------------------------------------------------
+struct FanAffineTable
+{
+  double k[6][8][8]; // [d <= e packed: 00 01 02 11 12 22][i][j]
+};
+__host__ __device__ constexpr int sym6(int d, int e) { return d == 0 ? e : (d == 1 ? 2 + e : 5); }
+constexpr FanAffineTable make_fan_affine_table()
+{
+  FanAffineTable T{};
+  for (int t = 0; t < 6; ++t)
+  {
+    // the tet's vertices along the path 0 -> 7 (one more bit per step); gradient of lambda of the vertex with k bits:
+    // k = 0: -e_a1, k = 1: e_a1 - e_a2, k = 2: e_a2 - e_a3, k = 3: e_a3 (a_k = the axis added at step k)
+    int path[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i)
+    {
+      const int v = fan_vertex(t, i);
+      const int bits = (v & 1) + ((v >> 1) & 1) + ((v >> 2) & 1);
+      path[bits] = v;
+    }
+    int axis[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k)
+    {
+      const int diff = path[k + 1] ^ path[k];
+      axis[k] = diff == 1 ? 0 : (diff == 2 ? 1 : 2);
+    }
+    double g[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    g[0][axis[0]] = -1.0;
+    g[1][axis[0]] = 1.0;
+    g[1][axis[1]] = -1.0;
+    g[2][axis[1]] = 1.0;
+    g[2][axis[2]] = -1.0;
+    g[3][axis[2]] = 1.0;
+    for (int p = 0; p < 4; ++p)
+      for (int q = 0; q < 4; ++q)
+        for (int d = 0; d < 3; ++d)
+          for (int e = d; e < 3; ++e)
+          {
+            double v = g[p][d] * g[q][e];
+            if (d != e)
+              v += g[p][e] * g[q][d];
+            T.k[sym6(d, e)][path[p]][path[q]] += v / 6.0;
+          }
+  }
+  return T;
+}
+static constexpr FanAffineTable FAN_AFFINE = make_fan_affine_table();
+
+template <bool NARROW>
+__global__ void __launch_bounds__(CUBE_MAX_THREADS) matrix_cube_affine_kernel(mpcx_matrix_args_t a)
+{
+  const int NT = blockDim.x;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int nb = a.plan.num_blocks;
+  const int per = (nb + 7) >> 3;
+  const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (b >= nb)
+    return;
+  const int tid = threadIdx.x;
+  const int bb = a.cube_block_ids ? a.cube_block_ids[b] : b;
+  const int r0 = a.plan.block_row0[bb], r1 = a.plan.block_row0[bb + 1];
+  const int nrow = r1 - r0;
+  const int64_t nnz0 = a.rowptr[r0];
+  const int nnzb = int(a.rowptr[r1] - nnz0);
+  double* s_vals = reinterpret_cast<double*>(smem);
+  int32_t* s_rowlo = reinterpret_cast<int32_t*>(s_vals + a.plan.max_nnz);
+  const double c0 = a.constants ? a.constants[0] : 1.0;
+  constexpr int NW = NARROW ? 4 : 6;
+  const uint4* __restrict__ recs = static_cast<const uint4*>(a.cube_recs);
+  const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  uint4 cur[NW];
+  int64_t t = e0 + tid;
+  if (t < e1)
+  {
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+      cur[i] = recs[t * NW + i];
+  }
+  for (int i = tid; i < nnzb; i += NT)
+    s_vals[i] = 0.0;
+  for (int rl = tid; rl < nrow; rl += NT)
+    s_rowlo[rl] = int(a.rowptr[r0 + rl] - nnz0);
+  __syncthreads();
+  for (; t < e1; t += NT)
+  {
+    const int32_t v[8] = {int32_t(cur[0].x), int32_t(cur[0].y), int32_t(cur[0].z), int32_t(cur[0].w),
+                          int32_t(cur[1].x), int32_t(cur[1].y), int32_t(cur[1].z), int32_t(cur[1].w)};
+    // a parallelepiped is spanned from vertex 0 by the vertices 1, 2, 4
+    double j0[3], j1[3], j2[3];
+    {
+      const int64_t n0 = v[0] & DOF_MASK, n1 = v[1] & DOF_MASK, n2 = v[2] & DOF_MASK, n4 = v[4] & DOF_MASK;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+      {
+        const double x0 = a.x[3 * n0 + r];
+        j0[r] = a.x[3 * n1 + r] - x0;
+        j1[r] = a.x[3 * n2 + r] - x0;
+        j2[r] = a.x[3 * n4 + r] - x0;
+      }
+    }
+    uint32_t ow[4 * (NW - 2)];
+#pragma unroll
+    for (int q = 0; q < NW - 2; ++q)
+    {
+      ow[4 * q] = cur[2 + q].x, ow[4 * q + 1] = cur[2 + q].y, ow[4 * q + 2] = cur[2 + q].z, ow[4 * q + 3] = cur[2 + q].w;
+    }
+    if (t + NT < e1)
+    {
+#pragma unroll
+      for (int i = 0; i < NW; ++i)
+        cur[i] = recs[(t + NT) * NW + i];
+    }
+    double C0[3], C1[3], C2[3];
+    cross3(j1, j2, C0);
+    cross3(j2, j0, C1);
+    cross3(j0, j1, C2);
+    const double det = j0[0] * C0[0] + j0[1] * C0[1] + j0[2] * C0[2];
+    const double s = c0 / fabs(det);
+    const double M[6] = {s * (C0[0] * C0[0] + C0[1] * C0[1] + C0[2] * C0[2]), s * (C0[0] * C1[0] + C0[1] * C1[1] + C0[2] * C1[2]),
+                         s * (C0[0] * C2[0] + C0[1] * C2[1] + C0[2] * C2[2]), s * (C1[0] * C1[0] + C1[1] * C1[1] + C1[2] * C1[2]),
+                         s * (C1[0] * C2[0] + C1[1] * C2[1] + C1[2] * C2[2]), s * (C2[0] * C2[0] + C2[1] * C2[1] + C2[2] * C2[2])};
+    int base[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+    {
+      const int r = v[i] & DOF_MASK;
+      const bool mine = r >= r0 && r < r1 && !(v[i] >> MASK_SHIFT);
+      base[i] = mine ? s_rowlo[mine ? r - r0 : 0] : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = i; j < 8; ++j)
+      {
+        if (!fan_coupled(i, j))
+          continue;
+        double val = 0.0;
+#pragma unroll
+        for (int m = 0; m < 6; ++m)
+        {
+          const double k = FAN_AFFINE.k[m][i][j];
+          if (k != 0.0)
+            val = fma(k, M[m], val);
+        }
+        if (base[i] >= 0 && !(v[j] >> MASK_SHIFT))
+        {
+          int off;
+          if constexpr (NARROW)
+          {
+            const int p = fan_pair_index(i, j);
+            off = int((ow[p >> 3] >> (4 * (p & 7))) & 0xf);
+          }
+          else
+            off = int((ow[(i * 8 + j) >> 2] >> (8 * ((i * 8 + j) & 3))) & 0xff);
+          __hip_atomic_fetch_add(s_vals + base[i] + off, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (i != j && base[j] >= 0 && !(v[i] >> MASK_SHIFT))
+        {
+          int off;
+          if constexpr (NARROW)
+          {
+            const int p = fan_pair_index(j, i);
+            off = int((ow[p >> 3] >> (4 * (p & 7))) & 0xf);
+          }
+          else
+            off = int((ow[(j * 8 + i) >> 2] >> (8 * ((j * 8 + i) & 3))) & 0xff);
+          __hip_atomic_fetch_add(s_vals + base[j] + off, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+  }
+  __syncthreads();
+  if (a.store_mode)
+    for (int i = tid; i < nnzb; i += NT)
+      a.vals[nnz0 + i] = s_vals[i];
+  else
+    for (int i = tid; i < nnzb; i += NT)
+      a.vals[nnz0 + i] += s_vals[i];
+}
 } // namespace
 
 static int launch_matrix_cubes_elasticity(const mpcx_matrix_args_t& a)
@@ -1496,16 +1685,24 @@ int launch_matrix_cubes(const mpcx_matrix_args_t& a)
     mpcx_set_error("mpcx_assemble_matrix: cube_rec_bytes must be 96 (or 0) or 64");
     return -6;
   }
-  const void* kern = narrow ? reinterpret_cast<const void*>(matrix_cube_kernel<true>)
-                            : reinterpret_cast<const void*>(matrix_cube_kernel<false>);
+  const bool affine = (a.cube_flags & 1) != 0; // the caller vouches: every cluster of this launch is a parallelepiped
+  const void* kern = affine ? (narrow ? reinterpret_cast<const void*>(matrix_cube_affine_kernel<true>)
+                                      : reinterpret_cast<const void*>(matrix_cube_affine_kernel<false>))
+                            : (narrow ? reinterpret_cast<const void*>(matrix_cube_kernel<true>)
+                                      : reinterpret_cast<const void*>(matrix_cube_kernel<false>));
   if (int rc = check(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)), "hipFuncSetAttribute"))
     return rc;
-  const char* e = std::getenv("MPCX_CUBE_THREADS");
-  int threads = e ? std::atoi(e) : 256;
+  const int dflt = affine ? 512 : 256;
+  const char* e = std::getenv(affine ? "MPCX_CUBE_AFFINE_THREADS" : "MPCX_CUBE_THREADS");
+  int threads = e ? std::atoi(e) : dflt;
   if (threads < 64 || threads > CUBE_MAX_THREADS || threads % 64)
-    threads = 256;
+    threads = dflt;
   const unsigned grid = 8u * unsigned((a.plan.num_blocks + 7) / 8);
-  if (narrow)
+  if (affine && narrow)
+    hipLaunchKernelGGL(matrix_cube_affine_kernel<true>, dim3(grid), dim3(threads), lds, static_cast<hipStream_t>(a.stream), a);
+  else if (affine)
+    hipLaunchKernelGGL(matrix_cube_affine_kernel<false>, dim3(grid), dim3(threads), lds, static_cast<hipStream_t>(a.stream), a);
+  else if (narrow)
     hipLaunchKernelGGL(matrix_cube_kernel<true>, dim3(grid), dim3(threads), lds, static_cast<hipStream_t>(a.stream), a);
   else
     hipLaunchKernelGGL(matrix_cube_kernel<false>, dim3(grid), dim3(threads), lds, static_cast<hipStream_t>(a.stream), a);

@@ -305,6 +305,37 @@ def test_cluster_plan_uses_narrow_and_wide_records(oracle):
     _close(A.to_scipy().data, ref.data, RTOL_A, "A (narrow + wide cluster records)")
 
 
+def test_cluster_blocks_split_by_cluster_shape(oracle, monkeypatch):
+    """clusters that are parallelepipeds (x > 0.375) and clusters of moved nodes: row blocks all of whose clusters are
+    parallelepipeds are launched with the closed-form kernel (cube_flags bit 0), the others with the kernel that takes
+    every tet's own geometry; both record formats occur as well; moving the mesh afterwards rebuilds the split"""
+    import importlib
+
+    import dolfinx_mpc_amd as dm
+    from problems import warped
+
+    am = importlib.import_module("dolfinx_mpc_amd.assemble_matrix")
+    monkeypatch.setattr(am, "CUBE_MAX_ROWS", 64)
+    monkeypatch.setattr(am, "CUBE_MAX_NNZ", 64 * 16)
+    # 13 nodes per direction in tiles of 4: the tile of nodes 4..7 holds distorted clusters and no fat row (narrow records),
+    # the tiles next to the periodic faces hold fat rows (wide records), with and without distorted clusters
+    case = case_cube_periodic(12, 1, 0.3, reorder=(4, 4, 4), warp="half")
+    ref = oracle_outputs(oracle, case)
+    mpc = product_mpc(case)
+    A = dm.assemble_matrix(case.a, mpc, bcs=case.bcs, diagval=case.diagval)
+    (parts, _keep, info), = [v[1] for v in A._plans[("objcache", "cubes")].values()]
+    assert {p[5] for p in parts} == {0, 1} and {p[2] for p in parts} == {64, 96}
+    assert 0 < info["closed_form_blocks"] < info["num_blocks"]
+    _close(A.to_scipy().data, ref["A"].data, RTOL_A, "A (closed-form + general cluster kernels)")
+    warped(case.V.mesh)  # now every cluster is distorted: same matrix object, same form
+    ref2 = oracle_outputs(oracle, case)
+    assert abs(ref2["A"] - ref["A"]).max() > 1e-3
+    dm.assemble_matrix(case.a, mpc, bcs=case.bcs, diagval=case.diagval, A=A)
+    _close(A.to_scipy().data, ref2["A"].data, RTOL_A, "A after the mesh moved")
+    b = dm.assemble_vector(case.L, mpc).numpy()
+    _close(b, ref2["b"], RTOL_B, "b after the mesh moved")
+
+
 def test_cluster_vector_is_reproducible_without_device_atomics(oracle):
     """owner-computes cluster vector: every row of b gets its value from ONE workgroup (LDS adds) plus the halo sums
     gathered in a fixed order -- repeated assemblies agree to the last bits up to the order of the adds inside a
