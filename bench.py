@@ -756,7 +756,7 @@ def main():
     if world == 1 and not args.no_traffic and not os.environ.get("MPCX_BENCH_NO_PMC"):
         log("measuring HBM traffic of the dominant kernel (rocprofv3 --pmc, two short child runs) ...")
         child_args = ["--config", str(args.config), "--size", str(args.n), "--alg", args.alg, "--steps", "1", "--warmup", "0",
-                      "--no-cpu-baseline", "--no-traffic", "--numbering", args.numbering] + (["--ufcx", args.ufcx] if args.ufcx else []) + (["--no-tile"] if args.no_tile else ["--tile"] + [str(v) for v in args.tile])
+                      "--no-cpu-baseline", "--no-traffic", "--numbering", args.numbering] + (["--ufcx", args.ufcx] if args.ufcx else []) + ["--cell", args.cell] + (["--no-tile"] if args.no_tile else ["--tile"] + [str(v) for v in args.tile])
         traffic, info = measure_traffic(child_args, dom["pmc_name"])
         out["roofline"]["traffic"] = traffic
         out["roofline"]["traffic_source"] = info
