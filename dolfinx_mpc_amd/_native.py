@@ -207,6 +207,7 @@ EXPORTS = [
     "mpcx_cube_records",
     "mpcx_hex_records",
     "mpcx_hex_slot_shapes",
+    "mpcx_cell_shapes",
     "mpcx_cube_detect",
     "mpcx_cube_slot_width",
     "mpcx_cube_pack_narrow",
@@ -372,6 +373,8 @@ def lib() -> C.CDLL:
     L.mpcx_hex_records.restype = C.c_int
     L.mpcx_hex_slot_shapes.argtypes = [i64, vp, vp, vp, vp]
     L.mpcx_hex_slot_shapes.restype = C.c_int
+    L.mpcx_cell_shapes.argtypes = [i64, vp, vp, vp, vp]
+    L.mpcx_cell_shapes.restype = C.c_int
     L.mpcx_cube_detect.argtypes = [vp, i64, vp, vp, vp]
     L.mpcx_cube_detect.restype = C.c_int
     L.mpcx_cube_slot_width.argtypes = [i64, vp, vp, vp]

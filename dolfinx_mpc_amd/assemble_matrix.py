@@ -480,7 +480,7 @@ def _cube_eligible(form: Form, i: int, V0) -> bool:
             and not os.environ.get("MPCX_NO_CUBE"))
 
 
-def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc, hexa: bool = False):
+def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc, hexa: bool = False, closed_form_only: bool = False):
     """Row blocks over the mesh's cell clusters + one 96-byte record per (block, cluster) slot
     (mpcx_cube_records); cached per (form, constraint, Dirichlet markers).  Returns
     (plan struct, records tensor, keep-alive, info, leftover cells) or None when the mesh has no clusters.
@@ -495,7 +495,9 @@ def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc, hexa: bool = F
         left = np.zeros(0, dtype=np.int32)
         max_rows_cfg, max_nnz_cfg = HEX_MAX_ROWS, HEX_MAX_NNZ
     else:
-        d_verts, left = mesh_clusters_device(form.mesh, integ.num_entities)
+        # closed_form_only (vector elasticity): the kernel knows parallelepiped clusters only; the cells of every other
+        # cluster are leftover cells like those outside any cluster
+        d_verts, left = mesh_clusters_device(form.mesh, integ.num_entities, parallelepipeds_only=closed_form_only)
         if d_verts.shape[0] == 0 or d_verts.shape[0] * 6 < 0.5 * integ.num_entities:
             return None
         max_rows_cfg, max_nnz_cfg = CUBE_MAX_ROWS, CUBE_MAX_NNZ
@@ -512,9 +514,16 @@ def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc, hexa: bool = F
             hints = np.ascontiguousarray(hints * bs)
         row0 = _block_ranges(A.shape[0], A.rowptr, max_rows_cfg, max_nnz_cfg, bs, hints)
         nb = row0.size - 1
-        d_row0, d_off, d_ents = _block_lists_device(row0, nc, 1, None, d_verts, 8, bs, dev)
+        if closed_form_only:
+            # vector elasticity: ONE record per cluster and a row-pair plan over the clusters -- the unit of work is a
+            # (cluster, local row vertex) pair whose rows lie in the block (pair id = cluster * 8 + vertex)
+            d_row0, d_off, d_pairs = _block_pairs_device(row0, nc, 1, None, d_verts, 8, bs, dev)
+            d_ents = torch.arange(nc, dtype=torch.int32, device=dev)
+        else:
+            d_row0, d_off, d_ents = _block_lists_device(row0, nc, 1, None, d_verts, 8, bs, dev)
         nslots = d_ents.numel()
-        _warn_no_locality("cluster", int(nslots), nc, limit=5.0)
+        if not closed_form_only:
+            _warn_no_locality("cluster", int(nslots), nc, limit=5.0)
         recs = torch.empty(nslots * 96, dtype=torch.uint8, device=dev)
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         _, t = mpc._device()
@@ -526,6 +535,14 @@ def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc, hexa: bool = F
             raise _native.PlanNotRepresentable("cluster algorithm: a scatter offset does not fit 8 bits (or a column is missing)")
         max_rows = int(np.diff(row0).max())
         max_nnz = int(np.diff(A.rowptr[row0]).max())
+        if closed_form_only:
+            plan = _native.RowBlockPlanT(nb, max_rows, max_nnz, 1, d_row0.data_ptr(), d_off.data_ptr(), d_pairs.data_ptr(), None, None)
+            parts = [(plan, recs, 96, None, d_off, 1)]
+            keep = (d_row0, parts, d_verts, d_pairs)
+            info = {"num_blocks": nb, "num_ents": int(d_pairs.numel()), "max_rows": max_rows, "max_nnz": max_nnz, "clusters": int(nc),
+                    "narrow_blocks": 0, "closed_form_blocks": nb,
+                    "bytes": int(d_row0.numel() * 4 + recs.numel() + d_off.numel() * 8 + d_pairs.numel() * 4)}
+            return (parts, keep, info)
         # Row blocks are launched by KIND: record format (tetrahedral clusters: 64-byte records with 4-bit offsets for the
         # row blocks all of whose slots allow it, 96 bytes for blocks that hold fat rows -- master rows of a constraint) and
         # cell shape (row blocks all of whose clusters / hexahedra are parallelepipeds go to the kernel instance that
@@ -592,7 +609,7 @@ def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc, hexa: bool = F
     try:
         # (the split by cell shape depends on the coordinates -- a moved mesh gets a new plan)
         plan, keep, info = D.cached(A._plans, "cubes", (form, mpc, bc_dev),
-                                    (i, max_rows_cfg, max_nnz_cfg, hexa, form.mesh.geometry.version), build)
+                                    (i, max_rows_cfg, max_nnz_cfg, hexa, closed_form_only, form.mesh.geometry.version), build)
     except _native.PlanNotRepresentable:
         return None
     return plan, keep, info, left
@@ -867,7 +884,7 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
                 return a, keep
             if name in ("cube", "cube_el"):
                 # cell clusters (MPCX_ALG_CUBE); None when the mesh has no clean six-tet fans or an offset overflows
-                cp = _cube_plan(A, form, i, V0, bc0, mpc0) if allow_cubes else None
+                cp = _cube_plan(A, form, i, V0, bc0, mpc0, closed_form_only=(name == "cube_el")) if allow_cubes else None
                 if cp is None:
                     continue
                 parts, ck, _info, left = cp
@@ -885,7 +902,7 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
                     t = a if n_part == 0 else _native.MatrixArgs.from_buffer_copy(a)
                     t.plan = plan
                     t.cube_recs, t.cube_rec_bytes, t.cube_block_ids = recs.data_ptr(), nbytes, D.ptr(ids)
-                    t.cube_flags = part[5] if (len(part) > 5 and name == "cube") else 0
+                    t.cube_flags = part[5] if len(part) > 5 else 0
                     t.n_slave_entities = n_slave if n_part == len(parts) - 1 else 0
                     if n_part > 0:
                         t.leftover, t.kernel_name, t.block_scalar = None, name, False

@@ -123,12 +123,14 @@ def mesh_clusters(mesh, ncells: int):
     return mesh._device[key]
 
 
-def mesh_clusters_device(mesh, ncells: int):
+def mesh_clusters_device(mesh, ncells: int, parallelepipeds_only: bool = False):
     """(cube_verts device tensor (n, 8) int32, leftover cells (host int32, ascending, possibly empty)) of cells
     [0, ncells): detected on the device from topology + edge lengths, whatever the order of the cells and of their
     local vertices (``tet_long_edge_kernel`` -> sort by key (torch: plumbing) -> ``fan_build_kernel`` -> compaction).
     MPCX_CLUSTER_DETECT=consecutive selects the older detector (six consecutive cells in the generator's pattern).
-    Cached per (mesh, ncells, geometry version): the longest edge is a property of the coordinates."""
+    Cached per (mesh, ncells, geometry version): the longest edge is a property of the coordinates.
+    ``parallelepipeds_only``: clusters whose eight vertices are not an affine image of the cube (mpcx_cell_shapes) are
+    dropped and their cells returned among the leftover ones -- for kernels that only know the closed form."""
     import os
 
     import torch
@@ -165,6 +167,16 @@ def mesh_clusters_device(mesh, ncells: int):
         in_fan = torch.zeros(n, dtype=torch.int8, device=dev)
         _native.check(L.mpcx_cluster_build(n, keys.data_ptr(), order.data_ptr(), dm.data_ptr(), verts.data_ptr(), ok.data_ptr(),
                                            in_fan.data_ptr(), st), "mpcx_cluster_build")
+        if parallelepipeds_only:
+            general = torch.empty(n, dtype=torch.uint8, device=dev)  # (positions that start no fan hold garbage vertices: masked by ok)
+            vsafe = torch.where(ok[:, None] != 0, verts, torch.zeros_like(verts))
+            _native.check(L.mpcx_cell_shapes(n, vsafe.data_ptr(), md["x"].data_ptr(), general.data_ptr(), st), "mpcx_cell_shapes")
+            bad = torch.nonzero((ok != 0) & (general != 0)).reshape(-1)
+            if bad.numel() > 0:
+                cells = order.long()[(bad[:, None] + torch.arange(6, device=dev)[None, :]).reshape(-1)]
+                in_fan[cells] = 0
+                ok[bad] = 0
+            del general, vsafe
         del keys, order
         sel = torch.nonzero(ok).reshape(-1)
         verts = verts[sel].contiguous()
@@ -173,4 +185,4 @@ def mesh_clusters_device(mesh, ncells: int):
         left = torch.nonzero(in_fan == 0).reshape(-1).to(torch.int32).cpu().numpy()
         return verts, left
 
-    return D.cached(mesh._device, "fans_dev", (), (int(ncells), mesh.geometry.version), build, maxsize=2)
+    return D.cached(mesh._device, "fans_dev", (), (int(ncells), mesh.geometry.version, bool(parallelepipeds_only)), build, maxsize=3)

@@ -597,164 +597,6 @@ __global__ void __launch_bounds__(CUBE_MAX_THREADS) matrix_cube_kernel(mpcx_matr
 }
 
 // ---------------------------------------------------------------------------
-// matrix: P1 vector elasticity (bs = 3) over cell clusters, one thread per (row block, cluster, ROW COMPONENT).
-// The six element tensors of a cluster hold 6 * 144 = 864 entries but only 46 coupled vertex pairs * 9 = 414
-// distinct matrix entries.  A thread that took all of them (round 2's attempt) needs the gradients of six tets and
-// 46 3x3 accumulators at once: 256 VGPRs + scratch, 2.4 ms against 1.83 for the per-cell kernel.  Split by row
-// component a, a thread owns the 46 * 3 entries A[(i,a),(j,b)] of its component: it walks the fan tet by tet, keeps
-// only the pairs of the current faces live (scattered as soon as their last tet is done, like matrix_cube_kernel)
-// and recomputes the four gradients of a tet -- 3 x redundant across the components, cheap -- for
-//     A[(i,a),(j,b)] += |T| (mu g_i^b g_j^a + lambda g_i^a g_j^b + delta_ab mu g_i.g_j).
-// Same records as the scalar kernel (mpcx_cube_records with bs = 3: mask of component c in bit 28 + c of the vertex id,
-// offsets counted in column blocks), rows of the block in LDS, 138 ds_add_f64 per thread = 414 per cluster.
-// ---------------------------------------------------------------------------
-constexpr int CUBE_EL_THREADS = 384; // multiple of 3 * 64: a wave never splits a slot's three components unevenly
-
-__global__ void __launch_bounds__(CUBE_EL_THREADS) matrix_cube_elasticity_kernel(mpcx_matrix_args_t a)
-{
-  constexpr int BS = 3;
-  const int NT = blockDim.x;
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int nb = a.plan.num_blocks;
-  const int per = (nb + 7) >> 3;
-  const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if (b >= nb)
-    return;
-  const int tid = threadIdx.x;
-  const int bb = a.cube_block_ids ? a.cube_block_ids[b] : b;
-  const int r0 = a.plan.block_row0[bb], r1 = a.plan.block_row0[bb + 1];
-  const int nrow = r1 - r0;
-  const int64_t nnz0 = a.rowptr[r0];
-  const int nnzb = int(a.rowptr[r1] - nnz0);
-  double* s_vals = reinterpret_cast<double*>(smem);
-  int32_t* s_rowlo = reinterpret_cast<int32_t*>(s_vals + a.plan.max_nnz);
-  const double mu = a.constants[0], lmbda = a.constants[1];
-  const CubeRec* __restrict__ recs = static_cast<const CubeRec*>(a.cube_recs);
-  const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
-  for (int i = tid; i < nnzb; i += NT)
-    s_vals[i] = 0.0;
-  for (int rl = tid; rl < nrow; rl += NT)
-    s_rowlo[rl] = int(a.rowptr[r0 + rl] - nnz0);
-  __syncthreads();
-  // wave k of the workgroup takes row component k mod 3 (a compile-time constant inside its body: no selects, fewer
-  // registers); the lanes of the waves of one component stride over the block's slots
-  const int wave = tid >> 6, nwaves = NT >> 6;
-  const int ca_rt = wave % BS;
-  const int lane_in_group = (wave / BS) * 64 + (tid & 63);
-  const int group_size = (nwaves / BS) * 64;
-  auto body = [&](auto CA)
-  {
-    constexpr int ca = decltype(CA)::value;
-    for (int64_t t = e0 + lane_in_group; t < e1; t += group_size)
-    {
-      const uint4* p = reinterpret_cast<const uint4*>(recs + t);
-      const uint4 q0 = p[0], q1 = p[1];
-      const int32_t v[8] = {int32_t(q0.x), int32_t(q0.y), int32_t(q0.z), int32_t(q0.w),
-                            int32_t(q1.x), int32_t(q1.y), int32_t(q1.z), int32_t(q1.w)};
-      // the shared edge's two vertices stay in registers; ring vertices are gathered tet by tet (a ring vertex is
-      // used by two consecutive tets: the second read hits L1) -- 24 registers less across the accumulators
-      double X0[3], X7[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k)
-      {
-        X0[k] = a.x[3 * int64_t(v[0] & DOF_MASK) + k];
-        X7[k] = a.x[3 * int64_t(v[7] & DOF_MASK) + k];
-      }
-      const uint4 q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5];
-      const uint32_t ow[16] = {q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
-      // LDS address of row (v_i, ca) if it lies in this block and is not masked, else -1
-      int base[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-      {
-        const int r = (v[i] & DOF_MASK) * BS + ca;
-        const bool mine = r >= r0 && r < r1 && !((v[i] >> (MASK_SHIFT + ca)) & 1);
-        base[i] = mine ? s_rowlo[mine ? r - r0 : 0] : -1;
-      }
-      double A[8][8][3]; // A[i][j][cb]: entry (row (v_i, ca), column (v_j, cb)); static indices -> registers
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-          for (int cb = 0; cb < 3; ++cb)
-            A[i][j][cb] = 0.0;
-#pragma unroll
-      for (int step = 0; step < 6; ++step)
-      {
-        const int tet = fan_order(step);
-        double cd[12];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-        {
-          const int lv = fan_vertex(tet, i);
-#pragma unroll
-          for (int k = 0; k < 3; ++k)
-            cd[3 * i + k] = lv == 0 ? X0[k] : (lv == 7 ? X7[k] : a.x[3 * int64_t(v[lv] & DOF_MASK) + k]);
-        }
-        double G[4][3], det;
-        cofactor_gradients<3>(cd, G, det); // det * grad(lambda_i)
-        // |T| g_i^x g_j^y = G_i^x G_j^y / (6 |det|)
-        const double sc = 1.0 / (6.0 * fabs(det));
-        const double smu = sc * mu, sla = sc * lmbda;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-          {
-            const int gi = fan_vertex(tet, i), gj = fan_vertex(tet, j);
-            const double dot = G[i][0] * G[j][0] + G[i][1] * G[j][1] + G[i][2] * G[j][2];
-#pragma unroll
-            for (int cb = 0; cb < 3; ++cb)
-            {
-              double e = smu * G[i][cb] * G[j][ca] + sla * G[i][ca] * G[j][cb];
-              if (cb == ca)
-                e += smu * dot;
-              A[gi][gj][cb] += e;
-            }
-          }
-        // ordered pairs whose last tet this was
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-          {
-            // local vertex 3 is the ring vertex shared by the FIRST and the LAST tet of the walk: its pairs would stay
-            // live across all six steps (15 accumulators); they are flushed after the first tet and start again
-            const bool wrap_flush = step == 0 && (i == 3 || j == 3) && fan_coupled(i, j);
-            if (fan_last_step(i, j) != step && !wrap_flush)
-              continue;
-            if (base[i] >= 0)
-            {
-              const int off = int((ow[(i * 8 + j) >> 2] >> (8 * ((i * 8 + j) & 3))) & 0xff) * BS;
-#pragma unroll
-              for (int cb = 0; cb < 3; ++cb)
-                if (!((v[j] >> (MASK_SHIFT + cb)) & 1))
-                  __hip_atomic_fetch_add(s_vals + base[i] + off + cb, A[i][j][cb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-#pragma unroll
-            for (int cb = 0; cb < 3; ++cb)
-              A[i][j][cb] = 0.0;
-          }
-      }
-    }
-  };
-  if (ca_rt == 0)
-    body(std::integral_constant<int, 0>{});
-  else if (ca_rt == 1)
-    body(std::integral_constant<int, 1>{});
-  else
-    body(std::integral_constant<int, 2>{});
-  __syncthreads();
-  if (a.store_mode)
-    for (int i = tid; i < nnzb; i += NT)
-      a.vals[nnz0 + i] = s_vals[i];
-  else
-    for (int i = tid; i < nnzb; i += NT)
-      a.vals[nnz0 + i] += s_vals[i];
-}
-
-// ---------------------------------------------------------------------------
 // vector: P1 source term, one thread per cluster; contributions merged per destination dof in an
 // LDS hash table, one device atomic per distinct dof of the workgroup (8 inserts per 6 cells instead
 // of 24, and a third of the device atomics: the workgroup's clusters share most of their vertices)
@@ -996,8 +838,8 @@ __device__ inline bool hex_is_parallelepiped(const double (&c)[8][3])
   }
   return dev <= 0x1p-46 * len;
 }
-__global__ void hex_slot_shapes_kernel(int64_t n_slots, const CubeRec* __restrict__ recs, const double* __restrict__ x,
-                                       uint8_t* __restrict__ general)
+__global__ void hex_slot_shapes_kernel(int64_t n_slots, const int32_t* __restrict__ verts, int stride,
+                                       const double* __restrict__ x, uint8_t* __restrict__ general)
 {
   const int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (k >= n_slots)
@@ -1006,7 +848,7 @@ __global__ void hex_slot_shapes_kernel(int64_t n_slots, const CubeRec* __restric
 #pragma unroll
   for (int i = 0; i < 8; ++i)
   {
-    const int64_t n = recs[k].v[i] & DOF_MASK;
+    const int64_t n = verts[k * stride + i] & DOF_MASK;
 #pragma unroll
     for (int r = 0; r < 3; ++r)
       X[i][r] = x[3 * n + r];
@@ -1562,15 +1404,217 @@ __global__ void __launch_bounds__(CUBE_MAX_THREADS) matrix_cube_affine_kernel(mp
     for (int i = tid; i < nnzb; i += NT)
       a.vals[nnz0 + i] += s_vals[i];
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// matrix: P1 vector elasticity (bs = 3) over parallelepiped clusters, closed form.  The six element tensors of a
+// cluster hold 6 * 144 = 864 entries but only 46 coupled vertex pairs * 9 = 414 distinct matrix entries.  Summing the
+// tensors tet by tet needs the gradients of every tet and 3 x 3 accumulators for all pairs of the current faces: 256
+// registers + scratch, slower than the per-cell row-pair kernel (rounds 2 and 3).  On a parallelepiped the sums
+//     Q_ij^{ab} = sum_t |T_t| g_i^a g_j^b = (C Kp(i, j) C^T)^{ab} / |det J|,   Kp_de(i, j) = sum_t ghat_i^d ghat_j^e / 6
+// (C = cofactor matrix of J, ghat = barycentric gradients on the reference Kuhn cube: a constant table) need nothing
+// per tet, and
+//     A[(i,a),(j,b)] = mu Q_ij^{ba} + lambda Q_ij^{ab} + delta_ab mu tr Q_ij,   A[(j,b),(i,a)] = the same value
+// is scattered pair by pair: nothing stays live.  Clusters that are not parallelepipeds never get here: the plan leaves
+// their cells to the per-cell kernel (cube_flags bit 0 is required).  Same records as the scalar kernel
+// (mpcx_cube_records with bs = 3: mask of component c in bit 28 + c of the vertex id, offsets counted in column blocks).
+// ---------------------------------------------------------------------------------------------------------
+struct FanCoupled
+{
+  bool c[8][8];
+};
+constexpr FanCoupled make_fan_coupled()
+{
+  FanCoupled F{};
+  for (int i = 0; i < 8; ++i)
+    for (int j = 0; j < 8; ++j)
+      F.c[i][j] = fan_coupled(i, j);
+  return F;
+}
+static constexpr FanCoupled FAN_COUPLED = make_fan_coupled(); // (a table: look-ups with constant indices always fold)
+struct FanAffineTable9
+{
+  double k[9][8][8]; // [d * 3 + e][i][j] = sum over the tets holding i and j of ghat_i^d ghat_j^e / 6
+};
+constexpr FanAffineTable9 make_fan_affine_table9()
+{
+  FanAffineTable9 T{};
+  for (int t = 0; t < 6; ++t)
+  {
+    int path[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i)
+    {
+      const int v = fan_vertex(t, i);
+      path[(v & 1) + ((v >> 1) & 1) + ((v >> 2) & 1)] = v;
+    }
+    int axis[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k)
+    {
+      const int diff = path[k + 1] ^ path[k];
+      axis[k] = diff == 1 ? 0 : (diff == 2 ? 1 : 2);
+    }
+    double g[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    g[0][axis[0]] = -1.0;
+    g[1][axis[0]] = 1.0;
+    g[1][axis[1]] = -1.0;
+    g[2][axis[1]] = 1.0;
+    g[2][axis[2]] = -1.0;
+    g[3][axis[2]] = 1.0;
+    for (int p = 0; p < 4; ++p)
+      for (int q = 0; q < 4; ++q)
+        for (int d = 0; d < 3; ++d)
+          for (int e = 0; e < 3; ++e)
+            T.k[d * 3 + e][path[p]][path[q]] += g[p][d] * g[q][e] / 6.0;
+  }
+  return T;
+}
+static constexpr FanAffineTable9 FAN_AFFINE9 = make_fan_affine_table9();
+constexpr int CUBE_EL_THREADS = 1024;
+
+// One thread per (cluster, local row vertex I) pair whose three rows lie in the row block (the row-pair plan of
+// matrix_rowpair_kernel over the clusters: plan.row_pairs = 1, pair id = cluster * 8 + I, pairs of a block ordered by I
+// so that a wave runs one unrolled row body, round-robin over the row nodes).  Every lane keeps what it computes: a
+// thread per (block, cluster) slot masks the rows outside the block, and with ~70 nodes per 74 KB block half the lanes of
+// every LDS instruction are idle -- 1.1 ms, no better than the per-cell row-pair kernel (1.0 ms) although it issues half
+// the scatter-adds.  Records: ONE per cluster (cube_recs[cluster]: mpcx_cube_records over slots = clusters).
+__global__ void __launch_bounds__(CUBE_EL_THREADS) matrix_cube_elasticity_rowpair_kernel(mpcx_matrix_args_t a)
+{
+  constexpr int BS = 3;
+  const int NT = blockDim.x;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int nb = a.plan.num_blocks;
+  const int per = (nb + 7) >> 3;
+  const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (b >= nb)
+    return;
+  const int tid = threadIdx.x;
+  const int r0 = a.plan.block_row0[b], r1 = a.plan.block_row0[b + 1];
+  const int nrow = r1 - r0;
+  const int64_t nnz0 = a.rowptr[r0];
+  const int nnzb = int(a.rowptr[r1] - nnz0);
+  double* s_vals = reinterpret_cast<double*>(smem);
+  int32_t* s_rowlo = reinterpret_cast<int32_t*>(s_vals + a.plan.max_nnz);
+  const double mu = a.constants[0], lmbda = a.constants[1];
+  const CubeRec* __restrict__ recs = static_cast<const CubeRec*>(a.cube_recs);
+  for (int i = tid; i < nnzb; i += NT)
+    s_vals[i] = 0.0;
+  for (int rl = tid; rl < nrow; rl += NT)
+    s_rowlo[rl] = int(a.rowptr[r0 + rl] - nnz0);
+  __syncthreads();
+  const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  const uint32_t* __restrict__ pairs = reinterpret_cast<const uint32_t*>(a.plan.block_ents);
+  for (int64_t t = e0 + tid; t < e1; t += NT)
+  {
+    const uint32_t id = pairs[t];
+    const int64_t e = id >> 3;
+    const int i = int(id & 7u);
+    const uint4* p = reinterpret_cast<const uint4*>(recs + e);
+    const uint4 q0 = p[0], q1 = p[1];
+    const int32_t v[8] = {int32_t(q0.x), int32_t(q0.y), int32_t(q0.z), int32_t(q0.w),
+                          int32_t(q1.x), int32_t(q1.y), int32_t(q1.z), int32_t(q1.w)};
+    const uint2 orow = reinterpret_cast<const uint2*>(recs + e)[4 + i]; // off[i * 8 .. i * 8 + 7]
+    double j0[3], j1[3], j2[3];
+    {
+      const int64_t n0 = v[0] & DOF_MASK, n1 = v[1] & DOF_MASK, n2 = v[2] & DOF_MASK, n4 = v[4] & DOF_MASK;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+      {
+        const double x0 = a.x[3 * n0 + r];
+        j0[r] = a.x[3 * n1 + r] - x0;
+        j1[r] = a.x[3 * n2 + r] - x0;
+        j2[r] = a.x[3 * n4 + r] - x0;
+      }
+    }
+    double C[3][3]; // C[d] = d-th cofactor column
+    cross3(j1, j2, C[0]);
+    cross3(j2, j0, C[1]);
+    cross3(j0, j1, C[2]);
+    const double det = j0[0] * C[0][0] + j0[1] * C[0][1] + j0[2] * C[0][2];
+    const double inv = 1.0 / fabs(det);
+    const double smu = mu * inv, sla = lmbda * inv;
+#pragma unroll
+    for (int I = 0; I < 8; ++I)
+    {
+      if (i != I)
+        continue;
+      const int mi = v[I] >> MASK_SHIFT;
+      const int ri = (v[I] & DOF_MASK) * BS - r0;
+      int base[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        base[c] = s_rowlo[ri + c];
+#pragma unroll
+      for (int J = 0; J < 8; ++J)
+      {
+        if (!FAN_COUPLED.c[I][J])
+          continue;
+        // T[e][r] = sum_d Kp_de(I, J) C[d][r], Q[r][s] = sum_e T[e][r] C[e][s]  (= |det| sum_t |T_t| g_I^r g_J^s)
+        double T[3][3];
+#pragma unroll
+        for (int e2 = 0; e2 < 3; ++e2)
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+          {
+            double acc = 0.0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+            {
+              const double k = FAN_AFFINE9.k[d * 3 + e2][I][J];
+              if (k != 0.0)
+                acc = fma(k, C[d][r], acc);
+            }
+            T[e2][r] = acc;
+          }
+        double Q[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            Q[r][c] = fma(T[2][r], C[2][c], fma(T[1][r], C[1][c], T[0][r] * C[0][c]));
+        const double tr = smu * (Q[0][0] + Q[1][1] + Q[2][2]);
+        const int off = int(((J < 4 ? orow.x : orow.y) >> (8 * (J & 3))) & 0xff) * BS;
+        const int mj = v[J] >> MASK_SHIFT;
+#pragma unroll
+        for (int ca = 0; ca < 3; ++ca)
+        {
+          if ((mi >> ca) & 1)
+            continue;
+#pragma unroll
+          for (int cb = 0; cb < 3; ++cb)
+          {
+            if ((mj >> cb) & 1)
+              continue;
+            const double val = fma(smu, Q[cb][ca], sla * Q[ca][cb]) + (ca == cb ? tr : 0.0);
+            __hip_atomic_fetch_add(s_vals + base[ca] + off + cb, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (a.store_mode)
+    for (int i = tid; i < nnzb; i += NT)
+      a.vals[nnz0 + i] = s_vals[i];
+  else
+    for (int i = tid; i < nnzb; i += NT)
+      a.vals[nnz0 + i] += s_vals[i];
+}
 } // namespace
 
 static int launch_matrix_cubes_elasticity(const mpcx_matrix_args_t& a)
 {
-  if (!a.cube_recs || a.plan.num_blocks <= 0 || !a.constants)
+  if (!a.cube_recs || a.plan.num_blocks <= 0 || !a.constants || !a.plan.row_pairs || !a.plan.block_ents)
   {
-    mpcx_set_error("mpcx_assemble_matrix: the elasticity cluster algorithm needs records (mpcx_cube_records, bs = 3), a "
-                   "row-block plan and the constants (mu, lambda)");
+    mpcx_set_error("mpcx_assemble_matrix: the elasticity cluster algorithm needs one record per cluster (mpcx_cube_records, "
+                   "bs = 3, slots = clusters), a row-pair plan over the clusters (pair id = cluster * 8 + local vertex) and "
+                   "the constants (mu, lambda)");
     return -3;
+  }
+  if (!(a.cube_flags & 1))
+  {
+    mpcx_set_error("mpcx_assemble_matrix: the elasticity cluster kernel is the closed form on parallelepiped clusters: "
+                   "cube_flags bit 0 must vouch for the clusters of the launch (mpcx_cell_shapes); other cells go "
+                   "through the per-cell algorithms");
+    return -6;
   }
   const size_t lds = size_t(a.plan.max_nnz) * 8 + size_t(a.plan.max_rows) * 4;
   if (lds > 160 * 1024)
@@ -1578,16 +1622,19 @@ static int launch_matrix_cubes_elasticity(const mpcx_matrix_args_t& a)
     mpcx_set_error("mpcx_assemble_matrix: row-block plan exceeds 160 KiB of LDS");
     return -4;
   }
-  if (int rc = check(hipFuncSetAttribute(reinterpret_cast<const void*>(matrix_cube_elasticity_kernel),
+  if (int rc = check(hipFuncSetAttribute(reinterpret_cast<const void*>(matrix_cube_elasticity_rowpair_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)),
                      "hipFuncSetAttribute"))
     return rc;
+  // 512 threads: two workgroups per CU by LDS (74 KB blocks) AND by registers (104 VGPRs: 4 waves per SIMD), so one block
+  // is written out while the other computes; contact elasticity (config 4): 1024 threads 1.22 ms, 768 1.23, 512 0.86,
+  // 256 1.07; half-size blocks with 256 threads 0.93
   const char* e = std::getenv("MPCX_CUBE_EL_THREADS");
-  int threads = e ? std::atoi(e) : 384;
-  if (threads < 192 || threads > CUBE_EL_THREADS || threads % 192)
-    threads = 384;
+  int threads = e ? std::atoi(e) : 512;
+  if (threads < 64 || threads > CUBE_EL_THREADS || threads % 64)
+    threads = 512;
   const unsigned grid = 8u * unsigned((a.plan.num_blocks + 7) / 8);
-  hipLaunchKernelGGL(matrix_cube_elasticity_kernel, dim3(grid), dim3(threads), lds, static_cast<hipStream_t>(a.stream), a);
+  hipLaunchKernelGGL(matrix_cube_elasticity_rowpair_kernel, dim3(grid), dim3(threads), lds, static_cast<hipStream_t>(a.stream), a);
   return check(hipGetLastError(), "elasticity cluster kernel launch");
 }
 
@@ -1834,8 +1881,17 @@ extern "C" int mpcx_hex_slot_shapes(int64_t n_slots, const void* recs, const dou
   if (n_slots == 0)
     return 0;
   hipLaunchKernelGGL(mpcx::hex_slot_shapes_kernel, dim3(mpcx::grid_for(n_slots, 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), n_slots, static_cast<const mpcx::CubeRec*>(recs), x, general);
+                     static_cast<hipStream_t>(stream), n_slots, static_cast<const int32_t*>(recs), 24, x, general);
   return mpcx::check(hipGetLastError(), "hex_slot_shapes launch");
+}
+
+extern "C" int mpcx_cell_shapes(int64_t n, const int32_t* verts, const double* x, uint8_t* general, void* stream)
+{
+  if (n == 0)
+    return 0;
+  hipLaunchKernelGGL(mpcx::hex_slot_shapes_kernel, dim3(mpcx::grid_for(n, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), n, verts, 8, x, general);
+  return mpcx::check(hipGetLastError(), "cell_shapes launch");
 }
 
 extern "C" int mpcx_cube_slot_width(int64_t n_slots, const void* recs, uint8_t* wide, void* stream)

@@ -80,10 +80,12 @@ MATRIX: List[Kernel] = [
            "matrix_cube_kernel: six-tet clusters, 46 scatter-adds per 6 cells; config 2: 1.27 ms vs 1.75 ms (rowblock_lean)"),
     Kernel("cube_el",
            lambda c: (_lean_ok(c) and c.form == FORM_ELASTICITY and c.tet and c.d0 == 1 and c.bs0 == 3),
-           lambda c: False,
-           "matrix_cube_elasticity_kernel: clusters, one thread per (slot, row component): 414 scatter-adds per cluster instead "
-           "of 864 from six element tensors -- measured and NOT the default: contact elasticity (config 4) 1.81 ms vs 0.97 ms "
-           "(rowpair); 256 VGPRs + 24 B scratch, and a 74 KB vector row block holds only ~125 slots x 3 threads"),
+           lambda c: True,
+           "matrix_cube_elasticity_rowpair_kernel: parallelepiped clusters in closed form, one thread per (cluster, local row "
+           "vertex) pair whose rows lie in the block, 414 scatter-adds per cluster instead of 864 from six element tensors; "
+           "cells of other clusters through rowpair; contact elasticity (config 4): 0.86 ms vs 1.02 ms (rowpair alone); a "
+           "thread per (block, cluster) slot -- closed form 1.12 ms, summing the six tensors tet by tet 1.81 ms -- loses: half "
+           "the lanes of every LDS instruction are masked"),
     Kernel("hex_cube",
            lambda c: (c.form == FORM_UFCX and c.builtin_form == FORM_STIFFNESS and c.same and c.p1_geometry and c.all_cells
                       and c.cell_integral and not c.has_coefficient),
@@ -150,7 +152,7 @@ VECTOR: List[Kernel] = [
 # table entry -> the __global__ function it launches (profiles, bench.py's per-kernel roofline lines)
 FUNCTION = {
     ("matrix", "hex_cube"): "matrix_hex_kernel", ("vector", "hex_own"): "vector_hex_own_kernel",
-    ("matrix", "cube"): "matrix_cube_kernel", ("matrix", "cube_el"): "matrix_cube_elasticity_kernel", ("matrix", "ufcx_rowblock"): "ufcx_matrix_rowblock_kernel",
+    ("matrix", "cube"): "matrix_cube_kernel", ("matrix", "cube_el"): "matrix_cube_elasticity_rowpair_kernel", ("matrix", "ufcx_rowblock"): "ufcx_matrix_rowblock_kernel",
     ("matrix", "rowpair"): "matrix_rowpair_kernel", ("matrix", "nodeblock"): "matrix_nodeblock_kernel",
     ("matrix", "rowblock_lean"): "matrix_rowblock_kernel", ("matrix", "rowblock"): "matrix_rowblock_kernel",
     ("matrix", "atomic"): "matrix_atomic_kernel", ("matrix", "ufcx_atomic"): "ufcx_matrix_kernel",

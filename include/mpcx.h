@@ -312,6 +312,8 @@ int mpcx_hex_records(int64_t n_slots, const int32_t* block_ents, const int32_t* 
  * its map exceeds 2^-46 of the largest edge-vector component -- the test matrix_hex_kernel applies per wave when
  * mpcx_matrix_args_t::cube_flags does not vouch for the launch (all pointers DEVICE; x [num_nodes][3]). */
 int mpcx_hex_slot_shapes(int64_t n_slots, const void* recs, const double* x, uint8_t* general, void* stream);
+/* the same test on a plain vertex array verts[n][8] (clusters of mpcx_cluster_build, hexahedron dofmaps) */
+int mpcx_cell_shapes(int64_t n, const int32_t* verts, const double* x, uint8_t* general, void* stream);
 
 /* Narrow records (all pointers DEVICE): mpcx_cube_slot_width: wide[k] = 1 if a coupled offset of record k exceeds 15;
  * mpcx_cube_pack_narrow: out[j] (64 bytes: the 8 ids, then 46 nibbles in row-major order of the coupled pairs) from the

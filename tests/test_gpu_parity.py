@@ -336,6 +336,26 @@ def test_cluster_blocks_split_by_cluster_shape(oracle, monkeypatch):
     _close(b, ref2["b"], RTOL_B, "b after the mesh moved")
 
 
+def test_elasticity_clusters_closed_form_and_leftover_cells(oracle):
+    """vector P1 elasticity on a mesh of parallelepiped clusters and distorted ones: the former go through the closed-form
+    cluster kernel, the cells of the latter through the per-cell kernel; together the oracle's matrix"""
+    import dolfinx_mpc_amd as dm
+    from problems import case_cube_elasticity_slip, warped
+
+    case = case_cube_elasticity_slip(6)
+    warped(case.V.mesh, half=True)
+    ref = oracle_outputs(oracle, case)
+    mpc = product_mpc(case)
+    A = dm.assemble_matrix(case.a, mpc, bcs=case.bcs, diagval=case.diagval)
+    (parts, _keep, info), = [v[1] for v in A._plans[("objcache", "cubes")].values()]
+    assert all(p[5] == 1 for p in parts) and 0 < info["clusters"] < 6 ** 3
+    _close(A.to_scipy().data, ref["A"].data, RTOL_A, "A (closed-form elasticity clusters + leftover cells)")
+    warped(case.V.mesh)  # every cluster distorted now: the per-cell kernel takes all cells
+    ref2 = oracle_outputs(oracle, case)
+    dm.assemble_matrix(case.a, mpc, bcs=case.bcs, diagval=case.diagval, A=A)
+    _close(A.to_scipy().data, ref2["A"].data, RTOL_A, "A after the mesh moved")
+
+
 def test_cluster_vector_is_reproducible_without_device_atomics(oracle):
     """owner-computes cluster vector: every row of b gets its value from ONE workgroup (LDS adds) plus the halo sums
     gathered in a fixed order -- repeated assemblies agree to the last bits up to the order of the adds inside a
@@ -508,8 +528,9 @@ def test_forced_kernels_are_the_ones_that_run(monkeypatch):
     assert taken(p2, "matrix") == "rowblock" and taken(p2, "matrix", "rowpair") == "rowpair"
     assert taken(p2, "vector") == "ownblock"
     el = case_contact_two_body(4, 6, 0.0, reorder=(2, 2, 2))
-    assert taken(el, "matrix") == "rowpair" and taken(el, "matrix", "rowblock") == "rowblock"
-    assert taken(el, "matrix", "cube_el") == "cube_el"
+    # vector P1 elasticity on box meshes: parallelepiped clusters in closed form (leftover cells: rowpair)
+    assert taken(el, "matrix") == "cube_el" and taken(el, "matrix", "rowblock") == "rowblock"
+    assert taken(el, "matrix", "rowpair") == "rowpair"
     assert taken(el, "vector") == "rowblock"
 
 
