@@ -1759,8 +1759,11 @@ int launch_matrix(const mpcx_matrix_args_t& a)
           // the pipelined small-element loop on full-size blocks: P1 stiffness 1.96 -> 1.81 ms (P2 and elasticity
           // lose with 768); the host picks half-size blocks for that kernel, four 512-thread workgroups per CU
           threads = (attr.numRegs <= 64 && Op::ND0 * Op::ND1 <= 16 && a.plan.max_rows > 256) ? 768 : 512;
-          if ((a.plan.row_pairs && attr.numRegs <= 64) || a.slot_mask)
-            threads = 1024; // light threads, many more of them than entities: contact elasticity 1.02 -> 0.96 ms
+          // light threads, many more of them than entities: contact elasticity 1.02 -> 0.96 ms.  Only kernels of at most 64
+          // registers: two 1024-thread workgroups per CU are 8 waves per SIMD, and with ONE resident workgroup nothing
+          // computes while a block is written out (Taylor-Hood a00, 84 registers: 1024 threads 2.98 ms, 512 2.16 ms)
+          if ((a.plan.row_pairs || a.slot_mask) && attr.numRegs <= 64)
+            threads = 1024;
         }
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, stream, a);
         return 0;
@@ -1938,7 +1941,16 @@ int launch_vector(const mpcx_vector_args_t& a)
                                              hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)),
                          "hipFuncSetAttribute"))
         return rc;
-      hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, stream, a);
+      // 512 threads (measured: 1024 threads for the large owner-computes blocks, one workgroup per CU by LDS, lose --
+      // P2 source 246^3 5.70 -> 6.26 ms, Stokes b0 1.47 -> 1.60 ms)
+      static const int env_threads = []
+      {
+        const char* e = std::getenv("MPCX_VECTOR_THREADS");
+        const int t = e ? std::atoi(e) : 0;
+        return (t >= 64 && t <= 1024 && t % 64 == 0) ? t : 0;
+      }();
+      const int threads = env_threads ? env_threads : 512;
+      hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, stream, a);
       return 0;
     };
     int lrc = 0;
