@@ -1274,8 +1274,9 @@ constexpr FanAffineTable make_fan_affine_table()
 }
 static constexpr FanAffineTable FAN_AFFINE = make_fan_affine_table();
 
+constexpr int CUBE_AFFINE_MAX_THREADS = 1024;
 template <bool NARROW>
-__global__ void __launch_bounds__(CUBE_MAX_THREADS) matrix_cube_affine_kernel(mpcx_matrix_args_t a)
+__global__ void __launch_bounds__(CUBE_AFFINE_MAX_THREADS) matrix_cube_affine_kernel(mpcx_matrix_args_t a)
 {
   const int NT = blockDim.x;
   extern __shared__ __align__(16) unsigned char smem[];
@@ -1742,7 +1743,7 @@ int launch_matrix_cubes(const mpcx_matrix_args_t& a)
   const int dflt = affine ? 512 : 256;
   const char* e = std::getenv(affine ? "MPCX_CUBE_AFFINE_THREADS" : "MPCX_CUBE_THREADS");
   int threads = e ? std::atoi(e) : dflt;
-  if (threads < 64 || threads > CUBE_MAX_THREADS || threads % 64)
+  if (threads < 64 || threads > (affine ? CUBE_AFFINE_MAX_THREADS : CUBE_MAX_THREADS) || threads % 64)
     threads = dflt;
   const unsigned grid = 8u * unsigned((a.plan.num_blocks + 7) / 8);
   if (affine && narrow)

@@ -35,12 +35,13 @@ def main():
     N = sys.argv[2] if len(sys.argv) > 2 else "256"
     global CONFIG
     CONFIG = sys.argv[3] if len(sys.argv) > 3 else "2"
+    extra = sys.argv[4:]  # further bench.py options, e.g. --cell hex
     os.makedirs(out, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     for g in GROUPS:
         name = g.split()[0]
         cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + g.split() + ["-d", out, "-o", "p_" + name, "--",
-                                                                      sys.executable, os.path.join(ROOT, "tools", "profile_kernels.py"), N, CONFIG]
+                                                                      sys.executable, os.path.join(ROOT, "tools", "profile_kernels.py"), N, CONFIG] + extra
         with open(os.path.join(out, f"log_{name}.txt"), "w") as fh:
             try:
                 subprocess.run(cmd, stdout=fh, stderr=subprocess.STDOUT, env=env, cwd="/tmp", timeout=240)
