@@ -208,11 +208,15 @@ EXPORTS = [
     "mpcx_hex_records",
     "mpcx_hex_slot_shapes",
     "mpcx_cell_shapes",
+    "mpcx_p2_cluster_dofs",
+    "mpcx_p2_cluster_records",
+    "mpcx_p2_cluster_tables",
     "mpcx_cube_detect",
     "mpcx_cube_slot_width",
     "mpcx_cube_pack_narrow",
     "mpcx_cluster_keys",
     "mpcx_cluster_build",
+    "mpcx_cluster_canonical",
     "mpcx_rowblock_pairs_device",
     "mpcx_diag_slot_mask",
     "mpcx_add_diagonal",
@@ -373,8 +377,16 @@ def lib() -> C.CDLL:
     L.mpcx_hex_records.restype = C.c_int
     L.mpcx_hex_slot_shapes.argtypes = [i64, vp, vp, vp, vp]
     L.mpcx_hex_slot_shapes.restype = C.c_int
+    L.mpcx_cluster_canonical.argtypes = [i64, vp, vp, vp, vp]
+    L.mpcx_cluster_canonical.restype = C.c_int
     L.mpcx_cell_shapes.argtypes = [i64, vp, vp, vp, vp]
     L.mpcx_cell_shapes.restype = C.c_int
+    L.mpcx_p2_cluster_dofs.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp]
+    L.mpcx_p2_cluster_dofs.restype = C.c_int
+    L.mpcx_p2_cluster_records.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.mpcx_p2_cluster_records.restype = C.c_int
+    L.mpcx_p2_cluster_tables.argtypes = [vp, vp, vp, vp]
+    L.mpcx_p2_cluster_tables.restype = C.c_int
     L.mpcx_cube_detect.argtypes = [vp, i64, vp, vp, vp]
     L.mpcx_cube_detect.restype = C.c_int
     L.mpcx_cube_slot_width.argtypes = [i64, vp, vp, vp]

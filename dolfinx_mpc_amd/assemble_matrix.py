@@ -292,7 +292,8 @@ def _block_pairs_device(row0: np.ndarray, n_entities: int, estride: int, entitie
     blk = torch.searchsorted(d_row0[1:].contiguous(), (dof * bs).contiguous(), right=True).to(torch.int64)
     loc = dof.to(torch.int64) - (d_row0.to(torch.int64)[blk] // bs)  # dof inside its block: < 2^16 rows
     li = torch.arange(M, device=dev, dtype=torch.int64) % nd
-    key = (blk << 40) | (li << 36) | loc
+    assert nd <= 32
+    key = (blk << 41) | (li << 36) | loc  # bits: loc 0-23, rank 24-35 (below), local index 36-40, block 41-
     del li
     key, order = torch.sort(key, stable=True)
     _, counts = torch.unique_consecutive(key, return_counts=True)
@@ -615,6 +616,73 @@ def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc, hexa: bool = F
     return plan, keep, info, left
 
 
+P2CUBE_REC = 640  # bytes per cluster record of the P2 cluster kernel (include/mpcx.h mpcx_p2_cluster_records)
+
+
+def _p2_cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc):
+    """Plan of the P2 cluster kernel (scalar P2 stiffness on parallelepiped clusters, closed form): the 27 dofs of every
+    cluster, one 528-byte record per cluster, and a row-pair plan over the clusters ((cluster, local dof) pairs by row
+    block).  Cells of other clusters and cells in no cluster are leftover cells (per-cell kernel).  Same return shape as
+    ``_cube_plan``; None when fewer than half of the cells sit in parallelepiped clusters."""
+    import torch
+
+    from .clusters import mesh_clusters_device
+
+    integ = form.integrals[i]
+    if os.environ.get("MPCX_CLUSTER_DETECT", "topology") == "consecutive":
+        return None
+    d_verts, left, fan_cells = mesh_clusters_device(form.mesh, integ.num_entities, parallelepipeds_only=True, with_cells=True)
+    if d_verts.shape[0] == 0 or d_verts.shape[0] * 6 < 0.5 * integ.num_entities:
+        return None
+
+    def build():
+        L = _native.lib()
+        dev = A.device
+        nc = d_verts.shape[0]
+        if nc * 27 >= 2 ** 31:
+            raise _native.PlanNotRepresentable("P2 cluster plan: cluster * 27 + dof does not fit 32 bits; shard the mesh")
+        md = D.mesh_device(form.mesh)
+        sd = D.space_device(V0)
+        st = D.stream_ptr()
+        dofs27 = torch.empty((nc, 27), dtype=torch.int32, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        _native.check(L.mpcx_p2_cluster_dofs(nc, d_verts.data_ptr(), fan_cells.data_ptr(), md["x_dofmap"].data_ptr(),
+                                             sd["dofmap"].data_ptr(), dofs27.data_ptr(), flag.data_ptr(), st), "mpcx_p2_cluster_dofs")
+        if int(flag.item()) != 0:
+            raise _native.PlanNotRepresentable("P2 cluster plan: a cluster dof was not found in the cells' dofmaps")
+        hints = None
+        if V0.dof_tile_offsets is not None:
+            hints = np.ascontiguousarray(V0.dof_tile_offsets.astype(np.int32))
+        row0 = _block_ranges(A.shape[0], A.rowptr, ROWBLOCK_MAX_ROWS, ROWBLOCK_MAX_NNZ, 1, hints)
+        nb = row0.size - 1
+        d_row0, d_off, d_pairs = _block_pairs_device(row0, nc, 1, None, dofs27, 27, 1, dev)
+        recs = torch.empty(nc * P2CUBE_REC, dtype=torch.uint8, device=dev)
+        _, t = mpc._device()
+        _native.check(L.mpcx_p2_cluster_records(nc, d_verts.data_ptr(), dofs27.data_ptr(), md["x"].data_ptr(), D.ptr(bc_dev),
+                                                t["is_slave"].data_ptr(),
+                                                A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), recs.data_ptr(), flag.data_ptr(), st),
+                      "mpcx_p2_cluster_records")
+        if int(flag.item()) != 0:
+            raise _native.PlanNotRepresentable("P2 cluster plan: a scatter offset does not fit 8 bits (or a column is missing)")
+        del dofs27
+        max_rows = int(np.diff(row0).max())
+        max_nnz = int(np.diff(A.rowptr[row0]).max())
+        plan = _native.RowBlockPlanT(nb, max_rows, max_nnz, 1, d_row0.data_ptr(), d_off.data_ptr(), d_pairs.data_ptr(), None, None)
+        parts = [(plan, recs, P2CUBE_REC, None, d_off, 1)]
+        keep = (d_row0, parts, d_verts, d_pairs)
+        info = {"num_blocks": nb, "num_ents": int(d_pairs.numel()), "max_rows": max_rows, "max_nnz": max_nnz, "clusters": int(nc),
+                "narrow_blocks": 0, "closed_form_blocks": nb,
+                "bytes": int(d_row0.numel() * 4 + recs.numel() + d_off.numel() * 8 + d_pairs.numel() * 4)}
+        return (parts, keep, info)
+
+    try:
+        plan, keep, info = D.cached(A._plans, "cubes", (form, mpc, bc_dev),
+                                    (i, ROWBLOCK_MAX_ROWS, ROWBLOCK_MAX_NNZ, "p2", form.mesh.geometry.version), build)
+    except _native.PlanNotRepresentable:
+        return None
+    return plan, keep, info, left
+
+
 def _leftover_form(form: Form, i: int, left: np.ndarray) -> Form:
     """integral i restricted to the cells outside any cluster (per-cell kernels)"""
     from .fem import Integral
@@ -882,9 +950,14 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
                 A._compact_stale = False
                 keep += [ck]
                 return a, keep
-            if name in ("cube", "cube_el"):
+            if name in ("cube", "cube_el", "p2_cube"):
                 # cell clusters (MPCX_ALG_CUBE); None when the mesh has no clean six-tet fans or an offset overflows
-                cp = _cube_plan(A, form, i, V0, bc0, mpc0, closed_form_only=(name == "cube_el")) if allow_cubes else None
+                if not allow_cubes:
+                    cp = None
+                elif name == "p2_cube":
+                    cp = _p2_cube_plan(A, form, i, V0, bc0, mpc0)
+                else:
+                    cp = _cube_plan(A, form, i, V0, bc0, mpc0, closed_form_only=(name == "cube_el"))
                 if cp is None:
                     continue
                 parts, ck, _info, left = cp

@@ -123,14 +123,15 @@ def mesh_clusters(mesh, ncells: int):
     return mesh._device[key]
 
 
-def mesh_clusters_device(mesh, ncells: int, parallelepipeds_only: bool = False):
+def mesh_clusters_device(mesh, ncells: int, parallelepipeds_only: bool = False, with_cells: bool = False):
     """(cube_verts device tensor (n, 8) int32, leftover cells (host int32, ascending, possibly empty)) of cells
     [0, ncells): detected on the device from topology + edge lengths, whatever the order of the cells and of their
     local vertices (``tet_long_edge_kernel`` -> sort by key (torch: plumbing) -> ``fan_build_kernel`` -> compaction).
     MPCX_CLUSTER_DETECT=consecutive selects the older detector (six consecutive cells in the generator's pattern).
     Cached per (mesh, ncells, geometry version): the longest edge is a property of the coordinates.
     ``parallelepipeds_only``: clusters whose eight vertices are not an affine image of the cube (mpcx_cell_shapes) are
-    dropped and their cells returned among the leftover ones -- for kernels that only know the closed form."""
+    dropped and their cells returned among the leftover ones -- for kernels that only know the closed form.
+    ``with_cells``: a third result, the six cells of every cluster (device tensor (n, 6) int32)."""
     import os
 
     import torch
@@ -167,6 +168,8 @@ def mesh_clusters_device(mesh, ncells: int, parallelepipeds_only: bool = False):
         in_fan = torch.zeros(n, dtype=torch.int8, device=dev)
         _native.check(L.mpcx_cluster_build(n, keys.data_ptr(), order.data_ptr(), dm.data_ptr(), verts.data_ptr(), ok.data_ptr(),
                                            in_fan.data_ptr(), st), "mpcx_cluster_build")
+        # corner numbering for the fans that are parallelepipeds (the ring walk starts at an arbitrary ring vertex)
+        _native.check(L.mpcx_cluster_canonical(n, verts.data_ptr(), ok.data_ptr(), md["x"].data_ptr(), st), "mpcx_cluster_canonical")
         if parallelepipeds_only:
             general = torch.empty(n, dtype=torch.uint8, device=dev)  # (positions that start no fan hold garbage vertices: masked by ok)
             vsafe = torch.where(ok[:, None] != 0, verts, torch.zeros_like(verts))
@@ -177,12 +180,16 @@ def mesh_clusters_device(mesh, ncells: int, parallelepipeds_only: bool = False):
                 in_fan[cells] = 0
                 ok[bad] = 0
             del general, vsafe
-        del keys, order
         sel = torch.nonzero(ok).reshape(-1)
+        fan_cells = None
+        if with_cells:
+            fan_cells = order[(sel[:, None] + torch.arange(6, device=dev)[None, :]).reshape(-1)].view(-1, 6).contiguous()
+        del keys, order
         verts = verts[sel].contiguous()
         if verts.shape[0] * 6 == n:
-            return verts, np.zeros(0, dtype=np.int32)
-        left = torch.nonzero(in_fan == 0).reshape(-1).to(torch.int32).cpu().numpy()
-        return verts, left
+            left = np.zeros(0, dtype=np.int32)
+        else:
+            left = torch.nonzero(in_fan == 0).reshape(-1).to(torch.int32).cpu().numpy()
+        return (verts, left, fan_cells) if with_cells else (verts, left)
 
-    return D.cached(mesh._device, "fans_dev", (), (int(ncells), mesh.geometry.version, bool(parallelepipeds_only)), build, maxsize=3)
+    return D.cached(mesh._device, "fans_dev", (), (int(ncells), mesh.geometry.version, bool(parallelepipeds_only), bool(with_cells)), build, maxsize=3)

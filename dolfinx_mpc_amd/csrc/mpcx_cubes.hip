@@ -856,6 +856,36 @@ __global__ void hex_slot_shapes_kernel(int64_t n_slots, const int32_t* __restric
   hex_coefficients(X, c);
   general[k] = hex_is_parallelepiped(c) ? 0 : 1;
 }
+// The ring of a fan found from topology starts at an arbitrary ring vertex; topologically all six are alike (each shares
+// tet edges with both ends of the shared edge), geometrically they alternate between cube-edge neighbours of vertex 0
+// (corners 1, 2, 4) and of vertex 7 (corners 3, 6, 5).  The closed-form kernels need the corner numbering: if the
+// fan is a parallelepiped only after the ring is turned by one position, it is renumbered here.
+__global__ void fan_canonical_kernel(int64_t n, int32_t* __restrict__ verts, const int8_t* __restrict__ ok,
+                                     const double* __restrict__ x)
+{
+  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= n || (ok && !ok[p]))
+    return;
+  int32_t v[8];
+  for (int i = 0; i < 8; ++i)
+    v[i] = verts[p * 8 + i];
+  auto is_par = [&](const int32_t (&w)[8]) -> bool
+  {
+    double X[8][3], c[8][3];
+    for (int i = 0; i < 8; ++i)
+      for (int r = 0; r < 3; ++r)
+        X[i][r] = x[3 * int64_t(w[i]) + r];
+    hex_coefficients(X, c);
+    return hex_is_parallelepiped(c);
+  };
+  if (is_par(v))
+    return;
+  // ring 1-3-2-6-4-5 turned by one: new 1 = old 3, new 3 = old 2, new 2 = old 6, new 6 = old 4, new 4 = old 5, new 5 = old 1
+  const int32_t w[8] = {v[0], v[3], v[6], v[2], v[5], v[1], v[4], v[7]};
+  if (is_par(w))
+    for (int i = 0; i < 8; ++i)
+      verts[p * 8 + i] = w[i];
+}
 __device__ inline void cross3(const double (&u)[3], const double (&v)[3], double (&w)[3])
 {
   w[0] = u[1] * v[2] - u[2] * v[1];
@@ -1599,6 +1629,390 @@ __global__ void __launch_bounds__(CUBE_EL_THREADS) matrix_cube_elasticity_rowpai
     for (int i = tid; i < nnzb; i += NT)
       a.vals[nnz0 + i] += s_vals[i];
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// P2 stiffness on parallelepiped clusters, closed form.  A cluster carries 27 dofs: the eight vertices (local 0..7 = the
+// cube corners) and the 19 edges between coupled vertices (local 8 + rank of the pair (a < b) among the coupled pairs in
+// row-major order).  Two local dofs couple when a tet holds both: 393 of the 729 ordered pairs -- six element tensors
+// scattered one by one cost 600 scatter-adds.  With M = c C^T C / |det J| (six entries, as for P1)
+//     A_IJ = sum_m M_m K_m(I, J),   K_m(I, J) = sum over the common tets of the reference integrals of
+//                                                d_d phi_I d_e phi_J (+ the transposed product for d != e),
+// phi = the P2 basis in barycentric coordinates: vertex a: (4 l_a - 1) g_a, edge (a, b): 4 (l_a g_b + l_b g_a), g = the
+// constant barycentric gradients on the reference Kuhn cube; int l_a l_b = V (1 + delta_ab) / 20, int l_a = V / 4, V = 1/6.
+// ---------------------------------------------------------------------------------------------------------
+struct P2FanTables
+{
+  int ea[19], eb[19];     // vertices of edge dof 8 + k
+  int edge_of[8][8];      // local dof of the edge (a, b), -1 if a and b share no tet
+  unsigned tets[27];      // bit t: tet t holds the dof
+  double k[6][27][27];    // K_m(I, J)
+  bool coupled[27][27];
+  int row_start[28];      // packed position of the first coupled column of row I (rows in order, columns ascending)
+  int rank[27][27];       // position of column J among the coupled columns of row I
+};
+constexpr P2FanTables make_p2_fan_tables()
+{
+  P2FanTables T{};
+  int ne = 0;
+  for (int a = 0; a < 8; ++a)
+    for (int b = 0; b < 8; ++b)
+      T.edge_of[a][b] = -1;
+  for (int a = 0; a < 8; ++a)
+    for (int b = a + 1; b < 8; ++b)
+      if (fan_coupled(a, b))
+      {
+        T.ea[ne] = a;
+        T.eb[ne] = b;
+        T.edge_of[a][b] = T.edge_of[b][a] = 8 + ne;
+        ++ne;
+      }
+  for (int I = 0; I < 27; ++I)
+    T.tets[I] = 0u;
+  for (int t = 0; t < 6; ++t)
+  {
+    // vertices along the path 0 -> 7, gradients of their barycentric coordinates (see make_fan_affine_table)
+    int path[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i)
+    {
+      const int v = fan_vertex(t, i);
+      path[(v & 1) + ((v >> 1) & 1) + ((v >> 2) & 1)] = v;
+    }
+    int axis[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k)
+    {
+      const int diff = path[k + 1] ^ path[k];
+      axis[k] = diff == 1 ? 0 : (diff == 2 ? 1 : 2);
+    }
+    double g[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    g[0][axis[0]] = -1.0;
+    g[1][axis[0]] = 1.0;
+    g[1][axis[1]] = -1.0;
+    g[2][axis[1]] = 1.0;
+    g[2][axis[2]] = -1.0;
+    g[3][axis[2]] = 1.0;
+    // the ten P2 functions of the tet: local dof, and gradient = sum_p (alpha_p + sum_q beta_pq l_q) g_p
+    //   vertex p: alpha_p = -1, beta_pp = 4;  edge (p, q): beta_pq = beta_qp = 4
+    int dof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double alpha[10][4] = {};
+    double beta[10][4][4] = {};
+    int n = 0;
+    for (int p = 0; p < 4; ++p, ++n)
+    {
+      dof[n] = path[p];
+      alpha[n][p] = -1.0;
+      beta[n][p][p] = 4.0;
+    }
+    for (int p = 0; p < 4; ++p)
+      for (int q = p + 1; q < 4; ++q, ++n)
+      {
+        dof[n] = T.edge_of[path[p]][path[q]];
+        beta[n][p][q] = 4.0; // l_q g_p
+        beta[n][q][p] = 4.0; // l_p g_q
+      }
+    for (int i = 0; i < 10; ++i)
+      T.tets[dof[i]] |= 1u << t;
+    const double V = 1.0 / 6.0;
+    for (int i = 0; i < 10; ++i)
+      for (int j = 0; j < 10; ++j)
+        for (int p = 0; p < 4; ++p)
+          for (int q = 0; q < 4; ++q)
+          {
+            // int (alpha_ip + sum_r beta_ipr l_r) (alpha_jq + sum_s beta_jqs l_s)
+            double w = alpha[i][p] * alpha[j][q] * V;
+            for (int r = 0; r < 4; ++r)
+            {
+              w += beta[i][p][r] * alpha[j][q] * V / 4.0 + alpha[i][p] * beta[j][q][r] * V / 4.0;
+              for (int s2 = 0; s2 < 4; ++s2)
+                w += beta[i][p][r] * beta[j][q][s2] * V * (r == s2 ? 2.0 : 1.0) / 20.0;
+            }
+            if (w == 0.0)
+              continue;
+            for (int d = 0; d < 3; ++d)
+              for (int e = d; e < 3; ++e)
+              {
+                double v = g[p][d] * g[q][e];
+                if (d != e)
+                  v += g[p][e] * g[q][d];
+                T.k[sym6(d, e)][dof[i]][dof[j]] += w * v;
+              }
+          }
+  }
+  int pos = 0;
+  for (int I = 0; I < 27; ++I)
+  {
+    T.row_start[I] = pos;
+    for (int J = 0; J < 27; ++J)
+    {
+      T.coupled[I][J] = (T.tets[I] & T.tets[J]) != 0u;
+      T.rank[I][J] = pos - T.row_start[I];
+      if (T.coupled[I][J])
+        ++pos;
+    }
+  }
+  T.row_start[27] = pos;
+  return T;
+}
+static constexpr P2FanTables P2FAN = make_p2_fan_tables();
+static_assert(P2FAN.row_start[27] == 393, "393 coupled pairs of P2 dofs per cluster");
+
+// One record per cluster (P2CUBE_REC bytes):
+//   [  0,  48)  double M[6]     C^T C / |det J| of the cluster's parallelepiped (00 01 02 11 12 22): the geometry, once per
+//                               cluster instead of once per (cluster, row) unit
+//   [ 48,  52)  uint32 mask     bit I: local dof I is a Dirichlet or slave dof (its row and column stay empty)
+//   [ 52, 160)  int32 dof[27]
+//   [160, 636)  uint8 off[..]   position of column dof J inside CSR row dof I; the coupled columns of row I in ascending
+//                               order, every row starting at a multiple of four bytes (P2PACK.rowoff4)
+constexpr int P2CUBE_REC = 640;
+constexpr int P2CUBE_OFFS = 160;
+
+// the tables the kernel reads through scalar loads: a wave works on ONE local row I at a time, so the coefficients of the
+// entries of that row are wave-uniform (27 unrolled row bodies with the constants folded in were 120 KB of code: 20.8 ms)
+struct P2Packed
+{
+  double k[393][6];       // K_m(I, J) of the packed entry (row-major over the coupled pairs)
+  unsigned char col[396]; // its column J
+  short rowq[28];         // first packed entry of row I
+  short rowoff4[28];      // byte offset of row I's offsets inside the record's offset area (multiples of 4)
+};
+constexpr P2Packed make_p2_packed()
+{
+  P2Packed P{};
+  int q = 0, o = 0;
+  for (int I = 0; I < 27; ++I)
+  {
+    P.rowq[I] = short(q);
+    P.rowoff4[I] = short(o);
+    int deg = 0;
+    for (int J = 0; J < 27; ++J)
+      if (P2FAN.coupled[I][J])
+      {
+        for (int m = 0; m < 6; ++m)
+          P.k[q][m] = P2FAN.k[m][I][J];
+        P.col[q] = (unsigned char)J;
+        ++q;
+        ++deg;
+      }
+    o += (deg + 3) & ~3;
+  }
+  P.rowq[27] = short(q);
+  P.rowoff4[27] = short(o);
+  return P;
+}
+static constexpr P2Packed P2PACK_HOST = make_p2_packed();
+static_assert(P2PACK_HOST.rowoff4[27] + P2CUBE_OFFS <= P2CUBE_REC, "record too small");
+__constant__ P2Packed g_p2pack = make_p2_packed();
+
+// set-up: the 27 dofs of every cluster from the P2 dofmaps of its six cells (any local vertex order inside a cell):
+// vertex dofs from the cells' vertex slots, edge dofs from their edge slots (local edge e joins the local vertices
+// TET_EDGE[e]: dolfinx_mpc_amd/mesh.py)
+__global__ void p2_cluster_dofs_kernel(int64_t n, const int32_t* __restrict__ verts, const int32_t* __restrict__ fan_cells,
+                                       const int32_t* __restrict__ x_dofmap, const int32_t* __restrict__ dofmap,
+                                       int32_t* __restrict__ dofs27, int32_t* bad)
+{
+  const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (c >= n)
+    return;
+  constexpr int TE[6][2] = {{2, 3}, {1, 3}, {1, 2}, {0, 3}, {0, 2}, {0, 1}};
+  int32_t v[8];
+  for (int i = 0; i < 8; ++i)
+    v[i] = verts[c * 8 + i];
+  int32_t out[27];
+  for (int i = 0; i < 27; ++i)
+    out[i] = -1;
+  for (int t = 0; t < 6; ++t)
+  {
+    const int64_t cell = fan_cells[c * 6 + t];
+    int corner[4];
+    for (int i = 0; i < 4; ++i)
+    {
+      const int32_t w = x_dofmap[cell * 4 + i];
+      int b = -1;
+      for (int q = 0; q < 8; ++q)
+        if (v[q] == w)
+          b = q;
+      corner[i] = b;
+      if (b >= 0)
+        out[b] = dofmap[cell * 10 + i];
+    }
+    for (int e = 0; e < 6; ++e)
+    {
+      const int a0 = corner[TE[e][0]], b0 = corner[TE[e][1]];
+      if (a0 < 0 || b0 < 0)
+        continue;
+      const int I = P2FAN.edge_of[a0][b0];
+      if (I >= 0)
+        out[I] = dofmap[cell * 10 + 4 + e];
+    }
+  }
+  bool ok = true;
+  for (int i = 0; i < 27; ++i)
+  {
+    ok &= out[i] >= 0;
+    dofs27[c * 27 + i] = out[i];
+  }
+  if (!ok)
+    atomicOr(bad, 1);
+}
+
+// set-up: the records; one thread per (cluster, local dof I)
+__global__ void p2_cluster_records_kernel(int64_t n, const int32_t* __restrict__ verts, const int32_t* __restrict__ dofs27,
+                                          const double* __restrict__ x, const int8_t* __restrict__ bc,
+                                          const int8_t* __restrict__ is_slave, const mpcx_nnz_t* __restrict__ rowptr,
+                                          const int32_t* __restrict__ cols, unsigned char* __restrict__ recs, int32_t* overflow)
+{
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n * 27)
+    return;
+  const int64_t c = t / 27;
+  const int I = int(t - c * 27);
+  unsigned char* rec = recs + c * P2CUBE_REC;
+  const int32_t* d = dofs27 + c * 27;
+  if (I == 0)
+  {
+    const int64_t n0 = verts[c * 8 + 0], n1 = verts[c * 8 + 1], n2 = verts[c * 8 + 2], n4 = verts[c * 8 + 4];
+    double j0[3], j1[3], j2[3];
+    for (int r = 0; r < 3; ++r)
+    {
+      const double x0 = x[3 * n0 + r];
+      j0[r] = x[3 * n1 + r] - x0;
+      j1[r] = x[3 * n2 + r] - x0;
+      j2[r] = x[3 * n4 + r] - x0;
+    }
+    double C0[3], C1[3], C2[3];
+    cross3(j1, j2, C0);
+    cross3(j2, j0, C1);
+    cross3(j0, j1, C2);
+    const double det = j0[0] * C0[0] + j0[1] * C0[1] + j0[2] * C0[2];
+    const double s = 1.0 / fabs(det);
+    double* M = reinterpret_cast<double*>(rec);
+    M[0] = s * (C0[0] * C0[0] + C0[1] * C0[1] + C0[2] * C0[2]);
+    M[1] = s * (C0[0] * C1[0] + C0[1] * C1[1] + C0[2] * C1[2]);
+    M[2] = s * (C0[0] * C2[0] + C0[1] * C2[1] + C0[2] * C2[2]);
+    M[3] = s * (C1[0] * C1[0] + C1[1] * C1[1] + C1[2] * C1[2]);
+    M[4] = s * (C1[0] * C2[0] + C1[1] * C2[1] + C1[2] * C2[2]);
+    M[5] = s * (C2[0] * C2[0] + C2[1] * C2[1] + C2[2] * C2[2]);
+    uint32_t m = 0;
+    for (int J = 0; J < 27; ++J)
+      if ((bc && bc[d[J]]) || is_slave[d[J]])
+        m |= 1u << J;
+    *reinterpret_cast<uint32_t*>(rec + 48) = m;
+    for (int q = P2CUBE_OFFS + P2PACK_HOST.rowoff4[27]; q < P2CUBE_REC; ++q)
+      rec[q] = 0;
+  }
+  reinterpret_cast<int32_t*>(rec + 52)[I] = d[I];
+  const int64_t lo = rowptr[d[I]], hi = rowptr[d[I] + 1];
+  unsigned char* orow = rec + P2CUBE_OFFS + P2PACK_HOST.rowoff4[I];
+  int p = 0;
+  for (int J = 0; J < 27; ++J)
+  {
+    if (!P2FAN.coupled[I][J])
+      continue;
+    const int64_t pos = find_col(cols, lo, hi, d[J]);
+    const int64_t o = pos < 0 ? 256 : pos - lo;
+    if (o > 255)
+      atomicOr(overflow, 1);
+    orow[p++] = uint8_t(o);
+  }
+  while (p & 3)
+    orow[p++] = 0;
+}
+
+// matrix: scalar P2 stiffness on parallelepiped clusters, closed form; one thread per (cluster, local dof I) pair whose
+// row lies in the row block (row-pair plan over the clusters: pair id = cluster * 27 + I, pairs of a block ordered by I so
+// that a wave works on few distinct rows).  Every lane keeps what it computes -- the per-cell kernel evaluates a cell in
+// every block it touches and keeps 3.8 of its 10 rows on average (3.5e8 LDS wave instructions at 246^3 for 1.4e8 full ones).
+// MEASURED AND NOT A DEFAULT: 22.2 ms at 246^3 against 14.1 ms for the per-cell kernel (see dolfinx_mpc_amd/dispatch.py).
+constexpr int P2CUBE_MAX_THREADS = 1024;
+
+__global__ void __launch_bounds__(P2CUBE_MAX_THREADS) matrix_p2_cube_kernel(mpcx_matrix_args_t a)
+{
+  const int NT = blockDim.x;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int nb = a.plan.num_blocks;
+  const int per = (nb + 7) >> 3;
+  const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (b >= nb)
+    return;
+  const int tid = threadIdx.x;
+  const int r0 = a.plan.block_row0[b], r1 = a.plan.block_row0[b + 1];
+  const int nrow = r1 - r0;
+  const int64_t nnz0 = a.rowptr[r0];
+  const int nnzb = int(a.rowptr[r1] - nnz0);
+  double* s_vals = reinterpret_cast<double*>(smem);
+  int32_t* s_rowlo = reinterpret_cast<int32_t*>(s_vals + a.plan.max_nnz);
+  const double c0 = a.constants ? a.constants[0] : 1.0;
+  const unsigned char* __restrict__ recs = static_cast<const unsigned char*>(a.cube_recs);
+  for (int i = tid; i < nnzb; i += NT)
+    s_vals[i] = 0.0;
+  for (int rl = tid; rl < nrow; rl += NT)
+    s_rowlo[rl] = int(a.rowptr[r0 + rl] - nnz0);
+  __syncthreads();
+  const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  const uint32_t* __restrict__ pairs = reinterpret_cast<const uint32_t*>(a.plan.block_ents);
+  const int64_t span = ((e1 - e0 + NT - 1) / NT) * NT; // every lane of a wave takes part in the wave-level votes below
+  for (int64_t t = e0 + tid; t < e0 + span; t += NT)
+  {
+    const bool live = t < e1;
+    const uint32_t id = live ? pairs[t] : 0u;
+    const uint32_t e = id / 27u;
+    const int i = int(id - e * 27u);
+    const unsigned char* rec = recs + int64_t(e) * P2CUBE_REC;
+    double M[6];
+    uint32_t mask = 0;
+    int base = 0;
+    bool todo = false;
+    if (live)
+    {
+      const double2* pm = reinterpret_cast<const double2*>(rec);
+      const double2 m0 = pm[0], m1 = pm[1], m2 = pm[2];
+      M[0] = c0 * m0.x, M[1] = c0 * m0.y, M[2] = c0 * m1.x, M[3] = c0 * m1.y, M[4] = c0 * m2.x, M[5] = c0 * m2.y;
+      mask = *reinterpret_cast<const uint32_t*>(rec + 48);
+      todo = !((mask >> i) & 1); // a Dirichlet / slave row stays empty (cpp/assemble_matrix.cpp:513-525, :165-178)
+      if (todo)
+        base = s_rowlo[reinterpret_cast<const int32_t*>(rec + 52)[i] - r0];
+    }
+    // the lanes of a wave hold at most a few distinct local rows (the plan orders the pairs of a block by row): one
+    // pass per distinct row, its coefficients through scalar loads
+    for (;;)
+    {
+      const unsigned long long pending = __ballot(todo);
+      if (pending == 0ull)
+        break;
+      const int lane0 = __ffsll((long long)pending) - 1;
+      const int I = __builtin_amdgcn_readlane(i, lane0);
+      const int q0 = g_p2pack.rowq[I], deg = g_p2pack.rowq[I + 1] - q0, o4 = g_p2pack.rowoff4[I];
+      if (todo && i == I)
+      {
+        for (int c = 0; 4 * c < deg; ++c)
+        {
+          const uint32_t ow = *reinterpret_cast<const uint32_t*>(rec + P2CUBE_OFFS + o4 + 4 * c);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+          {
+            const int q = 4 * c + u;
+            if (q >= deg)
+              break;
+            const double* kk = g_p2pack.k[q0 + q];
+            const int J = g_p2pack.col[q0 + q];
+            const double val = fma(kk[5], M[5], fma(kk[4], M[4], fma(kk[3], M[3], fma(kk[2], M[2], fma(kk[1], M[1], kk[0] * M[0])))));
+            if (!((mask >> J) & 1))
+              __hip_atomic_fetch_add(s_vals + base + int((ow >> (8 * u)) & 0xff), val, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+        todo = false;
+      }
+    }
+  }
+  __syncthreads();
+  if (a.store_mode)
+    for (int i = tid; i < nnzb; i += NT)
+      a.vals[nnz0 + i] = s_vals[i];
+  else
+    for (int i = tid; i < nnzb; i += NT)
+      a.vals[nnz0 + i] += s_vals[i];
+}
+
 } // namespace
 
 static int launch_matrix_cubes_elasticity(const mpcx_matrix_args_t& a)
@@ -1690,11 +2104,44 @@ static int launch_matrix_hex(const mpcx_matrix_args_t& a)
   return check(hipGetLastError(), "hexahedron matrix kernel launch");
 }
 
+static int launch_matrix_p2_cubes(const mpcx_matrix_args_t& a)
+{
+  const mpcx_kernel_t& k = a.kernel;
+  if (k.coeff_degree != 0 || a.coeffs || a.estride != 1 || a.nv != 4 || !(a.cube_flags & 1) || a.cube_rec_bytes != P2CUBE_REC
+      || !a.cube_recs || a.plan.num_blocks <= 0 || !a.plan.row_pairs || !a.plan.block_ents)
+  {
+    mpcx_set_error("mpcx_assemble_matrix: the P2 cluster kernel covers the scalar P2 stiffness form without coefficients on "
+                   "parallelepiped clusters (cube_flags bit 0), with one record per cluster (mpcx_p2_cluster_records, "
+                   "cube_rec_bytes = 640) and a row-pair plan over the clusters (pair id = cluster * 27 + local dof)");
+    return -10;
+  }
+  const size_t lds = size_t(a.plan.max_nnz) * 8 + size_t(a.plan.max_rows) * 4;
+  if (lds > 160 * 1024)
+  {
+    mpcx_set_error("mpcx_assemble_matrix: row-block plan exceeds 160 KiB of LDS");
+    return -4;
+  }
+  if (int rc = check(hipFuncSetAttribute(reinterpret_cast<const void*>(matrix_p2_cube_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)),
+                     "hipFuncSetAttribute"))
+    return rc;
+  const char* e = std::getenv("MPCX_P2CUBE_THREADS");
+  int threads = e ? std::atoi(e) : 1024; // (246^3: 256 threads 40.2 ms, 512 30.2, 1024 22.2 -- the per-cell kernel: 14.1)
+  if (threads < 64 || threads > P2CUBE_MAX_THREADS || threads % 64)
+    threads = 1024;
+  const unsigned grid = 8u * unsigned((a.plan.num_blocks + 7) / 8);
+  hipLaunchKernelGGL(matrix_p2_cube_kernel, dim3(grid), dim3(threads), lds, static_cast<hipStream_t>(a.stream), a);
+  return check(hipGetLastError(), "P2 cluster kernel launch");
+}
+
 int launch_matrix_cubes(const mpcx_matrix_args_t& a)
 {
   const mpcx_kernel_t& k = a.kernel;
   if (k.celltype == MPCX_CELL_HEXAHEDRON)
     return launch_matrix_hex(a);
+  if (k.form == MPCX_FORM_STIFFNESS && k.celltype == MPCX_CELL_TETRAHEDRON && k.degree == 2 && k.bs == 1 && k.degree1 == 2
+      && k.bs1 == 1)
+    return launch_matrix_p2_cubes(a);
   if (k.form == MPCX_FORM_ELASTICITY && k.celltype == MPCX_CELL_TETRAHEDRON && k.degree == 1 && k.bs == 3 && k.degree1 == 1
       && k.bs1 == 3 && !a.coeffs && a.estride == 1 && a.nv == 4)
     return launch_matrix_cubes_elasticity(a);
@@ -1989,4 +2436,55 @@ extern "C" int mpcx_hex_records(int64_t n_slots, const int32_t* block_ents, cons
                      static_cast<hipStream_t>(stream), n_slots, block_ents, cell_verts, bs, bc, is_slave, rowptr, cols,
                      static_cast<mpcx::CubeRec*>(recs), overflow);
   return mpcx::check(hipGetLastError(), "hex_records launch");
+}
+
+// the constant tables of the P2 cluster kernel (tests: compared with a numpy restatement and with the oracle's element tensors)
+extern "C" int mpcx_p2_cluster_tables(double* k, int32_t* coupled, int32_t* edge_vertices, int32_t* row_start)
+{
+  for (int m = 0; m < 6; ++m)
+    for (int I = 0; I < 27; ++I)
+      for (int J = 0; J < 27; ++J)
+        k[(m * 27 + I) * 27 + J] = mpcx::P2FAN.k[m][I][J];
+  for (int I = 0; I < 27; ++I)
+    for (int J = 0; J < 27; ++J)
+      coupled[I * 27 + J] = mpcx::P2FAN.coupled[I][J] ? 1 : 0;
+  for (int e = 0; e < 19; ++e)
+  {
+    edge_vertices[2 * e] = mpcx::P2FAN.ea[e];
+    edge_vertices[2 * e + 1] = mpcx::P2FAN.eb[e];
+  }
+  for (int I = 0; I <= 27; ++I)
+    row_start[I] = mpcx::P2FAN.row_start[I];
+  return 0;
+}
+
+extern "C" int mpcx_p2_cluster_dofs(int64_t n, const int32_t* verts, const int32_t* fan_cells, const int32_t* x_dofmap,
+                                    const int32_t* dofmap, int32_t* dofs27, int32_t* bad, void* stream)
+{
+  if (n == 0)
+    return 0;
+  hipLaunchKernelGGL(mpcx::p2_cluster_dofs_kernel, dim3(mpcx::grid_for(n, 128)), dim3(128), 0, static_cast<hipStream_t>(stream), n,
+                     verts, fan_cells, x_dofmap, dofmap, dofs27, bad);
+  return mpcx::check(hipGetLastError(), "p2_cluster_dofs launch");
+}
+
+extern "C" int mpcx_p2_cluster_records(int64_t n, const int32_t* verts, const int32_t* dofs27, const double* x, const int8_t* bc,
+                                       const int8_t* is_slave, const mpcx_nnz_t* rowptr, const int32_t* cols, void* recs,
+                                       int32_t* overflow, void* stream)
+{
+  if (n == 0)
+    return 0;
+  hipLaunchKernelGGL(mpcx::p2_cluster_records_kernel, dim3(mpcx::grid_for(n * 27, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), n, verts, dofs27, x, bc, is_slave, rowptr, cols,
+                     static_cast<unsigned char*>(recs), overflow);
+  return mpcx::check(hipGetLastError(), "p2_cluster_records launch");
+}
+
+extern "C" int mpcx_cluster_canonical(int64_t n, int32_t* verts, const int8_t* ok, const double* x, void* stream)
+{
+  if (n == 0)
+    return 0;
+  hipLaunchKernelGGL(mpcx::fan_canonical_kernel, dim3(mpcx::grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n,
+                     verts, ok, x);
+  return mpcx::check(hipGetLastError(), "cluster_canonical launch");
 }

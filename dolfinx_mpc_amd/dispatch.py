@@ -86,6 +86,16 @@ MATRIX: List[Kernel] = [
            "cells of other clusters through rowpair; contact elasticity (config 4): 0.86 ms vs 1.02 ms (rowpair alone); a "
            "thread per (block, cluster) slot -- closed form 1.12 ms, summing the six tensors tet by tet 1.81 ms -- loses: half "
            "the lanes of every LDS instruction are masked"),
+    Kernel("p2_cube",
+           lambda c: (c.form == FORM_STIFFNESS and c.tet and c.d0 == 2 and c.d1 == 2 and c.bs0 == 1 and c.bs1 == 1 and c.same
+                      and c.all_cells and c.cell_integral and not c.has_coefficient and c.coeff_degree == 0),
+           lambda c: False,
+           "matrix_p2_cube_kernel: scalar P2 stiffness on parallelepiped clusters in closed form, one thread per (cluster, local "
+           "dof) pair whose row lies in the block, 393 scatter-adds per cluster instead of 600, every lane keeps what it computes; "
+           "cells of other clusters through rowblock -- measured and NOT the default: P2 Poisson 246^3 (config 5) 22.2 ms (row "
+           "coefficients through scalar loads, geometry in the record, 1024 threads; 512: 30.2) and 20.8 ms (27 unrolled row "
+           "bodies with folded constants, geometry per unit: 120 KB of code) against 14.1 ms (rowblock): 402 M units of ~15 "
+           "entries each pay their record / coefficient fetches per unit"),
     Kernel("hex_cube",
            lambda c: (c.form == FORM_UFCX and c.builtin_form == FORM_STIFFNESS and c.same and c.p1_geometry and c.all_cells
                       and c.cell_integral and not c.has_coefficient),
@@ -151,7 +161,7 @@ VECTOR: List[Kernel] = [
 
 # table entry -> the __global__ function it launches (profiles, bench.py's per-kernel roofline lines)
 FUNCTION = {
-    ("matrix", "hex_cube"): "matrix_hex_kernel", ("vector", "hex_own"): "vector_hex_own_kernel",
+    ("matrix", "p2_cube"): "matrix_p2_cube_kernel", ("matrix", "hex_cube"): "matrix_hex_kernel", ("vector", "hex_own"): "vector_hex_own_kernel",
     ("matrix", "cube"): "matrix_cube_kernel", ("matrix", "cube_el"): "matrix_cube_elasticity_rowpair_kernel", ("matrix", "ufcx_rowblock"): "ufcx_matrix_rowblock_kernel",
     ("matrix", "rowpair"): "matrix_rowpair_kernel", ("matrix", "nodeblock"): "matrix_nodeblock_kernel",
     ("matrix", "rowblock_lean"): "matrix_rowblock_kernel", ("matrix", "rowblock"): "matrix_rowblock_kernel",
@@ -178,7 +188,7 @@ def _legacy_matrix(c: Ctx):
     ex, prefer = set(), None
     env = os.environ
     if env.get("MPCX_NO_CUBE"):
-        ex |= {"cube", "cube_el", "hex_cube"}
+        ex |= {"cube", "cube_el", "hex_cube", "p2_cube"}
     if env.get("MPCX_NO_LEAN"):
         ex |= {"cube", "cube_el", "rowblock_lean"}
     mode = env.get("MPCX_ROWPAIR", "auto")

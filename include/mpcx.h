@@ -315,6 +315,26 @@ int mpcx_hex_slot_shapes(int64_t n_slots, const void* recs, const double* x, uin
 /* the same test on a plain vertex array verts[n][8] (clusters of mpcx_cluster_build, hexahedron dofmaps) */
 int mpcx_cell_shapes(int64_t n, const int32_t* verts, const double* x, uint8_t* general, void* stream);
 
+/* Set-up of the P2 cluster kernel (MPCX_ALG_CUBE with a scalar P2 stiffness kernel; all pointers DEVICE).  A cluster of
+ * six P2 tets carries 27 dofs -- its eight vertices and the 19 edges between coupled vertices -- and 393 coupled dof pairs
+ * (six element tensors: 600 entries); on a parallelepiped cluster every entry is a fixed combination of six metric
+ * entries (csrc/mpcx_cubes.hip, P2FAN).  mpcx_p2_cluster_dofs: dofs27[c][0..7] = the vertex dofs (local vertex b of
+ * verts[c]), [8..26] = the edge dofs of the coupled vertex pairs (a < b) in row-major order, read from the P2 dofmaps
+ * (vertices then edges, local edge e joins the local vertices {2,3},{1,3},{1,2},{0,3},{0,2},{0,1}[e]) of the cluster's
+ * six cells fan_cells[c][0..5]; *bad is set if a dof is missing.  mpcx_p2_cluster_records: recs[c] (640 bytes: double M[6] = C^T C /
+ * |det J| of the parallelepiped spanned by the local vertices 0, 1, 2, 4 (C = cofactor matrix; entries 00 01 02 11 12 22);
+ * uint32 mask, bit I = dof I is a Dirichlet / slave dof; int32 dof[27]; from byte 160: uint8 position of column dof J in
+ * CSR row dof I, the coupled columns of every row in ascending order, rows padded to multiples of four bytes); *overflow
+ * is set if an offset does not fit 8 bits or a column is missing.  The records hold geometry: rebuild them when the mesh
+ * moves.  The kernel takes a row-pair plan over the clusters (plan.row_pairs = 1, pair id = cluster * 27 + local dof),
+ * cube_recs = recs, cube_rec_bytes = 640, cube_flags bit 0.  mpcx_p2_cluster_tables (HOST): the constant tables, for tests. */
+int mpcx_p2_cluster_dofs(int64_t n, const int32_t* verts, const int32_t* fan_cells, const int32_t* x_dofmap,
+                         const int32_t* dofmap, int32_t* dofs27, int32_t* bad, void* stream);
+int mpcx_p2_cluster_records(int64_t n, const int32_t* verts, const int32_t* dofs27, const double* x, const int8_t* bc,
+                            const int8_t* is_slave,
+                            const mpcx_nnz_t* rowptr, const int32_t* cols, void* recs, int32_t* overflow, void* stream);
+int mpcx_p2_cluster_tables(double* k, int32_t* coupled, int32_t* edge_vertices, int32_t* row_start);
+
 /* Narrow records (all pointers DEVICE): mpcx_cube_slot_width: wide[k] = 1 if a coupled offset of record k exceeds 15;
  * mpcx_cube_pack_narrow: out[j] (64 bytes: the 8 ids, then 46 nibbles in row-major order of the coupled pairs) from the
  * 96-byte record src[j]. */
@@ -336,6 +356,10 @@ int mpcx_cube_detect(const int32_t* cells, int64_t n_groups, int32_t* verts, int
 int mpcx_cluster_keys(const double* x, const int32_t* cells, int64_t n_cells, int64_t* keys, void* stream);
 int mpcx_cluster_build(int64_t n, const int64_t* sorted_keys, const int32_t* order, const int32_t* cells, int32_t* verts,
                        int8_t* ok, int8_t* cell_in_fan, void* stream);
+/*   4. mpcx_cluster_canonical (optional; ok may be NULL = every position): the ring walk of step 3 starts at an arbitrary
+ *      ring vertex; a fan that is a parallelepiped once its ring is turned by one position (local vertices 1, 2, 4 the
+ *      cube-edge neighbours of vertex 0) is renumbered so -- what the closed-form kernels assume (cube_flags bit 0).  */
+int mpcx_cluster_canonical(int64_t n, int32_t* verts, const int8_t* ok, const double* x, void* stream);
 
 /* The entity lists of a row-block plan on the DEVICE (host version: second half of mpcx_rowblock_plan_build):
  * (block, entity) pairs in entity order; two calls like mpcx_mpc_plan_device (offsets == NULL: counts[e] =

@@ -356,6 +356,33 @@ def test_elasticity_clusters_closed_form_and_leftover_cells(oracle):
     _close(A.to_scipy().data, ref2["A"].data, RTOL_A, "A after the mesh moved")
 
 
+def test_p2_clusters_closed_form_and_leftover_cells(oracle, monkeypatch):
+    """scalar P2 stiffness (table entry p2_cube, not a default: slower than the per-cell row blocks): parallelepiped
+    clusters through the closed-form cluster kernel (27 dofs, 393 coupled pairs per cluster), the cells of distorted
+    clusters through the per-cell kernel; periodic slaves, Dirichlet values, lifting; then the mesh moves and every
+    cluster is distorted"""
+    import dolfinx_mpc_amd as dm
+    from problems import warped
+
+    monkeypatch.setenv("MPCX_FORCE_KERNEL", "matrix=p2_cube")
+
+    for kwargs in (dict(reorder=(2, 2, 2)), dict(numbering="shuffled"), dict(warp="half", reorder=(3, 3, 3))):
+        case = case_cube_periodic(6, 2, 0.3, **kwargs)
+        ref = oracle_outputs(oracle, case)
+        mpc = product_mpc(case)
+        A = dm.assemble_matrix(case.a, mpc, bcs=case.bcs, diagval=case.diagval)
+        (parts, _keep, info), = [v[1] for v in A._plans[("objcache", "cubes")].values()]
+        assert parts[0][2] == 640 and parts[0][5] == 1
+        assert info["clusters"] == 6 ** 3 if "warp" not in kwargs else 0 < info["clusters"] < 6 ** 3
+        _close(A.to_scipy().data, ref["A"].data, RTOL_A, f"A (P2 cluster kernel, {kwargs})")
+        out = product_outputs(case)
+        _close(out["b_lifted"], ref["b_lifted"], RTOL_B, f"b_lifted ({kwargs})")
+    warped(case.V.mesh)
+    ref2 = oracle_outputs(oracle, case)
+    dm.assemble_matrix(case.a, mpc, bcs=case.bcs, diagval=case.diagval, A=A)
+    _close(A.to_scipy().data, ref2["A"].data, RTOL_A, "A after the mesh moved")
+
+
 def test_cluster_vector_is_reproducible_without_device_atomics(oracle):
     """owner-computes cluster vector: every row of b gets its value from ONE workgroup (LDS adds) plus the halo sums
     gathered in a fixed order -- repeated assemblies agree to the last bits up to the order of the adds inside a
@@ -525,7 +552,7 @@ def test_forced_kernels_are_the_ones_that_run(monkeypatch):
     for name in ("cube_hash", "ownblock", "rowblock", "hash"):
         assert taken(p1, "vector", name) == name
     p2 = case_cube_periodic(4, 2, 0.0, reorder=(2, 2, 2))
-    assert taken(p2, "matrix") == "rowblock" and taken(p2, "matrix", "rowpair") == "rowpair"
+    assert taken(p2, "matrix") == "rowblock" and taken(p2, "matrix", "rowpair") == "rowpair" and taken(p2, "matrix", "p2_cube") == "p2_cube"
     assert taken(p2, "vector") == "ownblock"
     el = case_contact_two_body(4, 6, 0.0, reorder=(2, 2, 2))
     # vector P1 elasticity on box meshes: parallelepiped clusters in closed form (leftover cells: rowpair)
