@@ -211,6 +211,7 @@ EXPORTS = [
     "mpcx_p2_cluster_dofs",
     "mpcx_p2_cluster_records",
     "mpcx_p2_cluster_tables",
+    "mpcx_p1_cluster_tables",
     "mpcx_cube_detect",
     "mpcx_cube_slot_width",
     "mpcx_cube_pack_narrow",
@@ -387,6 +388,8 @@ def lib() -> C.CDLL:
     L.mpcx_p2_cluster_records.restype = C.c_int
     L.mpcx_p2_cluster_tables.argtypes = [vp, vp, vp, vp]
     L.mpcx_p2_cluster_tables.restype = C.c_int
+    L.mpcx_p1_cluster_tables.argtypes = [vp, vp, vp]
+    L.mpcx_p1_cluster_tables.restype = C.c_int
     L.mpcx_cube_detect.argtypes = [vp, i64, vp, vp, vp]
     L.mpcx_cube_detect.restype = C.c_int
     L.mpcx_cube_slot_width.argtypes = [i64, vp, vp, vp]

@@ -2438,6 +2438,25 @@ extern "C" int mpcx_hex_records(int64_t n_slots, const int32_t* block_ents, cons
   return mpcx::check(hipGetLastError(), "hex_records launch");
 }
 
+// the constant tables of the P1 closed-form kernels (tests): k6 [6][8][8] = K_m(i, j) of matrix_cube_affine_kernel,
+// k9 [9][8][8] = Kp_de(i, j) of matrix_cube_elasticity_rowpair_kernel, hex6 [6][8][8] = the coefficients of M_de in the
+// Q1 stiffness entry (i, j) of a parallelepiped (matrix_hex_kernel; off-diagonal d < e: both orders together)
+extern "C" int mpcx_p1_cluster_tables(double* k6, double* k9, double* hex6)
+{
+  for (int i = 0; i < 8; ++i)
+    for (int j = 0; j < 8; ++j)
+    {
+      for (int m = 0; m < 6; ++m)
+        k6[(m * 8 + i) * 8 + j] = mpcx::FAN_AFFINE.k[m][i][j];
+      for (int m = 0; m < 9; ++m)
+        k9[(m * 8 + i) * 8 + j] = mpcx::FAN_AFFINE9.k[m][i][j];
+      for (int d = 0; d < 3; ++d)
+        for (int e = d; e < 3; ++e)
+          hex6[(mpcx::sym6(d, e) * 8 + i) * 8 + j] = mpcx::hex_affine_coef(d, e, i, j);
+    }
+  return 0;
+}
+
 // the constant tables of the P2 cluster kernel (tests: compared with a numpy restatement and with the oracle's element tensors)
 extern "C" int mpcx_p2_cluster_tables(double* k, int32_t* coupled, int32_t* edge_vertices, int32_t* row_start)
 {

@@ -334,6 +334,10 @@ int mpcx_p2_cluster_records(int64_t n, const int32_t* verts, const int32_t* dofs
                             const int8_t* is_slave,
                             const mpcx_nnz_t* rowptr, const int32_t* cols, void* recs, int32_t* overflow, void* stream);
 int mpcx_p2_cluster_tables(double* k, int32_t* coupled, int32_t* edge_vertices, int32_t* row_start);
+/* (HOST, tests) the tables of the P1 closed-form kernels: k6 [6][8][8] (scalar stiffness on a tetrahedral cluster), k9
+ * [9][8][8] (the sums of gradient products behind the elasticity kernel), hex6 [6][8][8] (Q1 stiffness on a hexahedron);
+ * first index: the metric entry 00 01 02 11 12 22 (k9: d * 3 + e) */
+int mpcx_p1_cluster_tables(double* k6, double* k9, double* hex6);
 
 /* Narrow records (all pointers DEVICE): mpcx_cube_slot_width: wide[k] = 1 if a coupled offset of record k exceeds 15;
  * mpcx_cube_pack_narrow: out[j] (64 bytes: the 8 ids, then 46 nibbles in row-major order of the coupled pairs) from the
