@@ -481,12 +481,20 @@ def check(rc: int, what: str):
         raise RuntimeError(f"{what} failed ({rc}): {msg}")
 
 
+_gpu_seen = False
+
+
 def require_gpu():
+    """the current HIP device; raises without one (there is no CPU fallback).  Called a dozen times per assembly call:
+    the availability probe runs once per process, the device index is read every time (a rank may switch devices)."""
+    global _gpu_seen
     import torch
 
-    if not torch.cuda.is_available():
-        raise RuntimeError(
-            "dolfinx_mpc_amd needs a HIP device (MI355X / gfx950): torch.cuda.is_available() is False "
-            "and there is no CPU fallback for the assembly path."
-        )
+    if not _gpu_seen:
+        if not torch.cuda.is_available():
+            raise RuntimeError(
+                "dolfinx_mpc_amd needs a HIP device (MI355X / gfx950): torch.cuda.is_available() is False "
+                "and there is no CPU fallback for the assembly path."
+            )
+        _gpu_seen = True
     return torch.device("cuda", torch.cuda.current_device())

@@ -24,7 +24,7 @@ FORM_STIFFNESS, FORM_MASS, FORM_SOURCE, FORM_ELASTICITY, FORM_FACET_MASS, FORM_F
 FORM_UFCX = 100
 
 
-@dataclass
+@dataclass(frozen=True)
 class Ctx:
     """the facts the tables look at (one integral of one form)"""
     form: int
@@ -219,10 +219,26 @@ def _legacy_vector(c: Ctx):
     return ex, prefer
 
 
+_ENV_KEYS = ("MPCX_FORCE_KERNEL", "MPCX_NO_CUBE", "MPCX_NO_LEAN", "MPCX_ROWPAIR", "MPCX_NO_ROWPAIR", "MPCX_NO_NODEBLOCK",
+             "MPCX_OFFSET_DICT", "MPCX_VCUBE_OWNER", "MPCX_VECTOR_OWNER")
+_memo: dict = {}
+
+
 def candidates(table: List[Kernel], c: Ctx, which: str, plan_only: bool = False) -> List[str]:
     """kernel names to try, in order: the forced / preferred one (if it applies), the defaults in table order, then
     every other applicable entry.  ``plan_only``: the caller asked for the row-block family explicitly
-    (algorithm="rowblock"): plan-free entries ("hash") are dropped unless nothing else applies."""
+    (algorithm="rowblock"): plan-free entries ("hash") are dropped unless nothing else applies.  Memoised per (facts,
+    switches): the answer is a pure function of both and is asked for on every assembly call."""
+    key = (c, which, plan_only, tuple(os.environ.get(k) for k in _ENV_KEYS))
+    hit = _memo.get(key)
+    if hit is None:
+        if len(_memo) > 4096:
+            _memo.clear()
+        hit = _memo[key] = tuple(_candidates(table, c, which, plan_only))
+    return list(hit)
+
+
+def _candidates(table: List[Kernel], c: Ctx, which: str, plan_only: bool) -> List[str]:
     ex, prefer = (_legacy_matrix if which == "matrix" else _legacy_vector)(c)
     usable = [k for k in table if k.name not in ex and k.applies(c)]
     names = [k.name for k in usable]

@@ -81,7 +81,8 @@ def side_stream(kind: str, obj):
         prio = int(os.environ.get("MPCX_%s_STREAM_PRIORITY" % kind.upper(), -1 if kind == "matrix" else 0))
         _side[key] = torch.cuda.Stream(device=obj.device, priority=prio)
     side = _side[key]
-    if side == cur or any(cur == st for st in _side.values()):  # nested call from inside another assembly
+    raw = cur.cuda_stream
+    if any(raw == st.cuda_stream for st in _side.values()):  # nested call from inside another assembly
         yield
         return
     obj._wait_ready()  # (results of an earlier assembly into the same object: keep the caller's stream ordered too)
@@ -89,6 +90,7 @@ def side_stream(kind: str, obj):
     with torch.cuda.stream(side):
         yield
         obj._ready = side.record_event()
+        obj._ready_raw = side.cuda_stream
 
 
 def wait_assembly():
@@ -129,10 +131,14 @@ class Vector:
         self._ready = None  # event recorded at the end of an assembly on a side stream
 
     def _wait_ready(self):
-        if self._ready is not None:
+        ev = self._ready
+        if ev is not None:
             import torch
 
-            torch.cuda.current_stream(self.device).wait_event(self._ready)
+            # (nothing to wait for on the stream that recorded the event: the accessors are read several times per call
+            # from inside the side stream itself)
+            if torch._C._cuda_getCurrentRawStream(self.device.index) != getattr(self, "_ready_raw", None):
+                torch.cuda.current_stream(self.device).wait_event(ev)
 
     @property
     def array(self):
@@ -224,10 +230,14 @@ class MPCMatrix:
         self._ready = None  # event recorded at the end of an assembly on a side stream
 
     def _wait_ready(self):
-        if self._ready is not None:
+        ev = self._ready
+        if ev is not None:
             import torch
 
-            torch.cuda.current_stream(self.device).wait_event(self._ready)
+            # (nothing to wait for on the stream that recorded the event: the accessors are read several times per call
+            # from inside the side stream itself)
+            if torch._C._cuda_getCurrentRawStream(self.device.index) != getattr(self, "_ready_raw", None):
+                torch.cuda.current_stream(self.device).wait_event(ev)
 
     @property
     def vals(self):
