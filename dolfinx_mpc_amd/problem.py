@@ -103,6 +103,33 @@ def cg(A: MPCMatrix, b: Vector, x: Optional[Vector] = None, rtol: float = 1e-10,
                "converged": bool(converged)}
 
 
+def multigrid_cg(A: MPCMatrix, b: Vector, V, x: Optional[Vector] = None, rtol: float = 1e-10, atol: float = 0.0,
+                 max_it: int = 500, **_unused):
+    """Solve A x = b by CG preconditioned with a smoothed-aggregation V-cycle built from A and the dof coordinates of
+    ``V`` (dolfinx_mpc_amd/amg.py).  Returns (x, info); info also carries the set-up time, the level sizes and the
+    operator complexity."""
+    import time
+
+    import torch
+
+    from .amg import SmoothedAggregation, pcg
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mg = SmoothedAggregation(A.d_rowptr, A.d_cols, A.vals, V.tabulate_dof_coordinates(), bs=V.dofmap.bs)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t0
+    A0 = mg.levels[0].A
+    xt, info = pcg(lambda v: A0 @ v, mg.vcycle, b.array, rtol=rtol, atol=atol, max_it=max_it)
+    torch.cuda.synchronize()
+    if x is None:
+        x = Vector(A.shape[0])
+    x.array.copy_(xt)
+    info.update(setup_s=t_setup, solve_s=time.perf_counter() - t0 - t_setup, levels=mg.sizes(),
+                operator_complexity=mg.operator_complexity(), pc_type="gamg")
+    return x, info
+
+
 class LinearProblem:
     """a(u, v) = L(v) with a multi point constraint
     (python/src/dolfinx_mpc/problem.py:353-600).
@@ -113,7 +140,9 @@ class LinearProblem:
         bcs: Dirichlet conditions
         u: solution function on ``mpc.function_space`` (created if None)
         solver_options: {"rtol", "atol", "max_it", "check_every"} for the CG solver
-            (the reference's ``petsc_options`` play this role)
+            (the reference's ``petsc_options`` play this role); ``"pc_type"``: ``"jacobi"`` (default: the fused CG
+            kernels of libmpcx) or ``"gamg"`` (smoothed-aggregation multigrid V-cycle, dolfinx_mpc_amd/amg.py -- the
+            preconditioner family of the reference's benchmark solve, bench_periodic.py:112-149)
     """
 
     def __init__(self, a: Form, L: Form, mpc: MultiPointConstraint, bcs: Optional[Sequence[DirichletBC]] = None,
@@ -152,11 +181,22 @@ class LinearProblem:
         set_bc(self._b, self.bcs)
         return self._A, self._b
 
+    def _solve_multigrid(self, **opts):
+        _, info = multigrid_cg(self._A, self._b, self._mpc.function_space, x=self._x, **opts)
+        return info
+
     def solve(self) -> Function:
         """Assemble, solve on the device, impose the constraint on the slaves
         (``homogenize`` + ``backsubstitution``, problem.py:589-598) and return ``u``."""
         self.assemble()
-        _, self.info = cg(self._A, self._b, x=self._x, **self.solver_options)
+        opts = dict(self.solver_options)
+        pc = str(opts.pop("pc_type", "jacobi")).lower()
+        if pc in ("gamg", "amg"):
+            self.info = self._solve_multigrid(**opts)
+        elif pc == "jacobi":
+            _, self.info = cg(self._A, self._b, x=self._x, **opts)
+        else:
+            raise NotImplementedError(f"LinearProblem: pc_type {pc!r} (jacobi, gamg)")
         if not self.info["converged"]:
             raise RuntimeError(f"LinearProblem: CG did not converge: {self.info}")
         self._mpc.homogenize(self._x)

@@ -43,14 +43,15 @@ def test_spmv_matches_scipy():
 
 @pytest.mark.parametrize("make", [lambda: case_cube_periodic(10, 1, 0.3), lambda: case_cube_periodic(5, 2, 0.0),
                                   lambda: case_cube_elasticity_slip(4)], ids=["p1-periodic", "p2-periodic", "elasticity-slip"])
-def test_linear_problem_matches_direct_solve(make):
+@pytest.mark.parametrize("pc", ["jacobi", "gamg"])
+def test_linear_problem_matches_direct_solve(make, pc):
     import scipy.sparse.linalg as spla
 
     from dolfinx_mpc_amd.problem import LinearProblem
 
     case = make()
     mpc = product_mpc(case)
-    prob = LinearProblem(case.a, case.L, mpc, case.bcs, solver_options={"rtol": 1e-13, "max_it": 20000})
+    prob = LinearProblem(case.a, case.L, mpc, case.bcs, solver_options={"rtol": 1e-13, "max_it": 20000, "pc_type": pc})
     u = prob.solve()
     assert prob.info["converged"] and prob.info["residual_norm"] <= 1e-13 * prob.info["b_norm"]
     A, b = prob.A.to_scipy(), prob.b.numpy()
@@ -67,3 +68,23 @@ def test_linear_problem_matches_direct_solve(make):
         bc.set(vals, None, 1.0)
         dofs = bc.dof_indices()[0]
         assert abs(got[dofs] - vals[dofs]).max() <= 1e-12
+
+
+@pytest.mark.parametrize("degree,N", [(1, 40), (2, 20)], ids=["p1-40", "p2-20"])
+def test_multigrid_iteration_counts(degree, N):
+    """the smoothed-aggregation V-cycle makes the CG iteration count (nearly) independent of the mesh width: periodic
+    Poisson at two resolutions, a dozen iterations where Jacobi-CG needs hundreds"""
+    from dolfinx_mpc_amd.problem import LinearProblem
+
+    its = {}
+    for n in (N // 2, N):
+        case = case_cube_periodic(n, degree, 0.0, reorder=(4, 4, 4))
+        mpc = product_mpc(case)
+        prob = LinearProblem(case.a, case.L, mpc, case.bcs, solver_options={"rtol": 1e-10, "pc_type": "gamg"})
+        prob.solve()
+        its[n] = prob.info["iterations"]
+        assert prob.info["converged"] and len(prob.info["levels"]) >= 2, prob.info
+    jac = LinearProblem(case.a, case.L, mpc, case.bcs, solver_options={"rtol": 1e-10, "check_every": 10})
+    jac.solve()
+    assert its[N] <= 40 and its[N] <= its[N // 2] + 8, its
+    assert jac.info["iterations"] >= 3 * its[N], (jac.info["iterations"], its)

@@ -20,8 +20,12 @@ from dolfinx_mpc_amd.problem import LinearProblem, cg, spmv  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 rtol = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-8
-mesh, V, bc, mpc, a, L = bench.build_problem(N, (8, 8, 8), 0, 1)
-prob = LinearProblem(a, L, mpc, [bc], solver_options={"rtol": rtol, "max_it": 20000, "check_every": 50})
+import argparse  # noqa: E402
+
+args = argparse.Namespace(n=N, no_tile=False, tile=[8, 8, 8], cell="tet", scaling="strong", ufcx=None, numbering="tiled")
+w = bench.poisson_workload(args, 0, 1, 1)
+V, a, L, mpc = w.V, w.blocks[0][1], w.vectors[0][1], w.vectors[0][2]
+prob = LinearProblem(a, L, mpc, w.bcs, solver_options={"rtol": rtol, "max_it": 20000, "check_every": 50})
 A, b = prob.assemble()
 torch.cuda.synchronize()
 n, nnz = A.shape[0], A.nnz
