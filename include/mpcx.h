@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-#define MPCX_VERSION 3
+/* 4: mpcx_matrix_args_t::cube_flags (in the padding after cube_rec_bytes), hexahedron and closed-form cluster entry points */
+#define MPCX_VERSION 4
 
 /* Offsets into the CSR value / column arrays (rowptr entries, positions): 64-bit, so that one GPU can
  * hold matrices with more than 2^31 - 1 stored entries (Taylor-Hood a00 on 128^3 cells: 4.4 G) -- PETSc's
