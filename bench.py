@@ -467,6 +467,7 @@ def main():
     ap.add_argument("--cpu-allcores", type=int, default=-1, metavar="P",
                     help="threads of the all-core CPU leg (default: min(host cores, 64); 0 = skip)")
     ap.add_argument("--cpu-allcores-n", type=int, default=0)
+    ap.add_argument("--solve", action="store_true", help="also solve the assembled system (configs 2 / 5): multigrid-CG and Jacobi-CG")
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 PMC measurement of roofline.traffic")
     ap.add_argument("--numbering", choices=["tiled", "shuffled", "spatial"], default="tiled",
                     help="configs 2 / 5 on one GPU: 'tiled' = the generator's tile-wise numbering (default), 'shuffled' = nodes "
@@ -753,6 +754,24 @@ def main():
     }
     if generic is not None:
         out["roofline_generic"] = generic
+    if args.solve and world == 1 and args.config in (2, 5):
+        # the caller of the path (bench_periodic.py:112-149 solves the assembled system with BoomerAMG / GAMG): opt-in,
+        # outside the metric
+        from dolfinx_mpc_amd.problem import cg, multigrid_cg
+
+        label, f, (m0, _m1) = w.blocks[0]
+        A, b = mats[label], vecs[w.vectors[0][0]]
+        dm.assemble_matrix(f, m0, bcs=bcs, A=A)
+        dm.assemble_vector(w.vectors[0][1], m0, b=b)
+        dm.apply_lifting(b, [f], [bcs], m0)
+        dm.set_bc(b, bcs)
+        _x, mg_info = multigrid_cg(A, b, w.V, rtol=1e-8)
+        torch.cuda.synchronize()
+        t0s = time.perf_counter()
+        _x, j_info = cg(A, b, rtol=1e-8, max_it=20000, check_every=50)
+        torch.cuda.synchronize()
+        j_info["solve_s"] = time.perf_counter() - t0s
+        out["solve"] = {"rtol": 1e-8, "gamg_cg": mg_info, "jacobi_cg": j_info}
     if world == 1 and not args.no_traffic and not os.environ.get("MPCX_BENCH_NO_PMC"):
         log("measuring HBM traffic of the dominant kernel (rocprofv3 --pmc, two short child runs) ...")
         child_args = ["--config", str(args.config), "--size", str(args.n), "--alg", args.alg, "--steps", "1", "--warmup", "0",
