@@ -212,6 +212,14 @@ EXPORTS = [
     "mpcx_p2_cluster_records",
     "mpcx_p2_cluster_tables",
     "mpcx_p1_cluster_tables",
+    "mpcx_cluster_plan_create",
+    "mpcx_cluster_plan_num_parts",
+    "mpcx_cluster_plan_num_clusters",
+    "mpcx_cluster_plan_num_slots",
+    "mpcx_cluster_plan_verts",
+    "mpcx_cluster_plan_leftover",
+    "mpcx_cluster_plan_part",
+    "mpcx_cluster_plan_destroy",
     "mpcx_cube_detect",
     "mpcx_cube_slot_width",
     "mpcx_cube_pack_narrow",
@@ -390,6 +398,17 @@ def lib() -> C.CDLL:
     L.mpcx_p2_cluster_tables.restype = C.c_int
     L.mpcx_p1_cluster_tables.argtypes = [vp, vp, vp]
     L.mpcx_p1_cluster_tables.restype = C.c_int
+    L.mpcx_cluster_plan_create.argtypes = [i64, vp, i64, vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp, C.POINTER(C.c_void_p)]
+    L.mpcx_cluster_plan_create.restype = C.c_int
+    for name, rt in (("num_parts", C.c_int32), ("num_clusters", C.c_int64), ("num_slots", C.c_int64), ("verts", C.c_void_p)):
+        f = getattr(L, "mpcx_cluster_plan_" + name)
+        f.argtypes, f.restype = [vp], rt
+    L.mpcx_cluster_plan_leftover.argtypes = [vp, C.POINTER(C.c_void_p)]
+    L.mpcx_cluster_plan_leftover.restype = C.c_int64
+    L.mpcx_cluster_plan_part.argtypes = [vp, i32, C.POINTER(MatrixArgs)]
+    L.mpcx_cluster_plan_part.restype = C.c_int
+    L.mpcx_cluster_plan_destroy.argtypes = [vp]
+    L.mpcx_cluster_plan_destroy.restype = None
     L.mpcx_cube_detect.argtypes = [vp, i64, vp, vp, vp]
     L.mpcx_cube_detect.restype = C.c_int
     L.mpcx_cube_slot_width.argtypes = [i64, vp, vp, vp]

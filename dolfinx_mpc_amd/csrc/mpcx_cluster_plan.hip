@@ -1,0 +1,402 @@
+// The whole set-up of MPCX_ALG_CUBE for a scalar P1 stiffness integral over all cells of a tetrahedral mesh behind ONE
+// C-ABI call (include/mpcx.h mpcx_cluster_plan_*): a caller that is not Python / torch -- the C++ binding a dolfinx_mpc
+// maintainer would write into python/src/dolfinx_mpc/mpc.cpp -- gets the fastest matrix path with device memory the
+// library allocates itself.  The steps are the ones dolfinx_mpc_amd/assemble_matrix.py::_cube_plan and clusters.py drive
+// through torch (and the two builds are compared array by array in tests/test_gpu_cluster_plan.py):
+//   clusters    mpcx_cluster_keys -> radix sort -> mpcx_cluster_build -> mpcx_cluster_canonical -> compaction
+//   row blocks  mpcx_block_ranges (host, from the caller's host copy of rowptr) -> (block, cluster) slots:
+//               mpcx_rowblock_pairs_device count -> scan -> fill -> stable sort by block -> segment offsets
+//   records     mpcx_cube_records; per slot: wide offsets? (mpcx_cube_slot_width) parallelepiped? (mpcx_hex_slot_shapes)
+//   parts       row blocks by kind (record format x cluster shape), records gathered / packed per kind
+#include "mpcx.h"
+#include "mpcx_internal.h"
+
+#include <algorithm>
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace
+{
+inline int hip_ok(hipError_t e, const char* what)
+{
+  if (e != hipSuccess)
+  {
+    mpcx_set_error(std::string("mpcx_cluster_plan: ") + what + ": " + hipGetErrorString(e));
+    return -100;
+  }
+  return 0;
+}
+
+struct Dev
+{
+  void* p = nullptr;
+  size_t bytes = 0;
+  Dev() = default;
+  Dev(const Dev&) = delete;
+  Dev& operator=(const Dev&) = delete;
+  Dev(Dev&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; }
+  Dev& operator=(Dev&& o) noexcept
+  {
+    if (this != &o)
+    {
+      release();
+      p = o.p, bytes = o.bytes, o.p = nullptr;
+    }
+    return *this;
+  }
+  ~Dev() { release(); }
+  void release()
+  {
+    if (p)
+      (void)hipFree(p);
+    p = nullptr;
+  }
+  int alloc(size_t n)
+  {
+    release();
+    bytes = std::max<size_t>(n, 16);
+    return hip_ok(hipMalloc(&p, bytes), "hipMalloc");
+  }
+  template <class T>
+  T* as() const
+  {
+    return static_cast<T*>(p);
+  }
+};
+
+inline unsigned grid_for(int64_t n, int block) { return static_cast<unsigned>((n + block - 1) / block); }
+
+__global__ void iota_i32(int64_t n, int32_t* out)
+{
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n)
+    out[i] = int32_t(i);
+}
+// flag[i] = (in[i] != 0) == want
+__global__ void flags_from_i8(int64_t n, const int8_t* in, int want, int32_t* flag)
+{
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n)
+    flag[i] = ((in[i] != 0) == (want != 0)) ? 1 : 0;
+}
+// compaction of rows of `width` int32: out[pos[i]] = in[i] where flag[i]
+__global__ void compact_rows(int64_t n, const int32_t* flag, const int64_t* pos, const int32_t* in, int width, int32_t* out)
+{
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n || !flag[i])
+    return;
+  for (int k = 0; k < width; ++k)
+    out[pos[i] * width + k] = in ? in[i * width + k] : int32_t(i);
+}
+__global__ void widen_i32_i64(int64_t n, const int32_t* in, int64_t* out)
+{
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n)
+    out[i] = in[i];
+}
+// kind[b]: bit 0 = a slot of block b has a wide offset, bit 1 = a slot holds a cluster that is no parallelepiped
+__global__ void block_kinds(int32_t nb, const int64_t* off, const uint8_t* wide, const uint8_t* general, int32_t* kind)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb)
+    return;
+  int k = 0;
+  for (int64_t s = off[b]; s < off[b + 1]; ++s)
+    k |= (wide[s] ? 1 : 0) | (general[s] ? 2 : 0);
+  kind[b] = k;
+}
+// slots of the selected blocks, in order: src[off_c[j] + q] = off[ids[j]] + q
+__global__ void part_sources(int32_t nsel, const int32_t* ids, const int64_t* off, const int64_t* off_c, int64_t* src)
+{
+  const int j = blockIdx.x;
+  if (j >= nsel)
+    return;
+  const int64_t s0 = off[ids[j]], n = off[ids[j] + 1] - s0, d0 = off_c[j];
+  for (int64_t q = threadIdx.x; q < n; q += blockDim.x)
+    src[d0 + q] = s0 + q;
+}
+__global__ void gather_records96(int64_t n, const int64_t* src, const uint4* recs, uint4* out)
+{
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n * 6)
+    return;
+  const int64_t k = t / 6;
+  const int w = int(t - k * 6);
+  out[k * 6 + w] = recs[src[k] * 6 + w];
+}
+
+// a primitive of mpcx_prims.hip with its temp-storage protocol
+template <class F>
+int with_temp(F call)
+{
+  size_t bytes = 0;
+  if (int rc = call(nullptr, &bytes))
+    return rc;
+  Dev tmp;
+  if (int rc = tmp.alloc(bytes))
+    return rc;
+  return call(tmp.p, &bytes);
+}
+
+int bit_length(int64_t v)
+{
+  int n = 0;
+  while (v > 0)
+    ++n, v >>= 1;
+  return std::max(n, 1);
+}
+} // namespace
+
+struct mpcx_cluster_plan
+{
+  struct Part
+  {
+    Dev recs, ids, off; // records of this part's slots, its row blocks (ids into block_row0), slot offsets per block
+    int32_t num_blocks = 0, rec_bytes = 96, flags = 0;
+    bool all_blocks = false;
+  };
+  Dev verts, left, row0;
+  int64_t n_clusters = 0, n_left = 0, n_slots = 0;
+  int32_t num_blocks = 0, max_rows = 0, max_nnz = 0;
+  std::vector<Part> parts;
+};
+
+extern "C" int mpcx_cluster_plan_create(int64_t n_cells, const int32_t* x_dofmap, int64_t n_nodes, const double* x, int32_t nrows,
+                                        const mpcx_nnz_t* rowptr, const mpcx_nnz_t* rowptr_host, const int32_t* cols, const int8_t* bc,
+                                        const int8_t* is_slave, int32_t max_rows, int32_t max_nnz, const int32_t* row_hints,
+                                        int32_t n_hints, void* stream, mpcx_cluster_plan_t** out)
+{
+  if (!out || !x_dofmap || !x || !rowptr || !rowptr_host || !cols || !is_slave || n_cells < 0 || nrows <= 0)
+  {
+    mpcx_set_error("mpcx_cluster_plan_create: invalid arguments");
+    return -1;
+  }
+  *out = nullptr;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  auto plan = std::make_unique<mpcx_cluster_plan>();
+  const int64_t n = n_cells;
+  // ---- clusters
+  Dev keys, keys_s, iota, order, verts_all, ok, in_fan, flag, pos;
+  if (keys.alloc(n * 8) || keys_s.alloc(n * 8) || iota.alloc(n * 4) || order.alloc(n * 4) || verts_all.alloc(n * 32) || ok.alloc(n)
+      || in_fan.alloc(n) || flag.alloc(n * 4) || pos.alloc((n + 1) * 8))
+    return -100;
+  if (n > 0)
+  {
+    if (int rc = mpcx_cluster_keys(x, x_dofmap, n, keys.as<int64_t>(), stream))
+      return rc;
+    hipLaunchKernelGGL(iota_i32, dim3(grid_for(n, 256)), dim3(256), 0, st, n, iota.as<int32_t>());
+    const int end_bit = 32 + bit_length(n_nodes);
+    if (int rc = with_temp([&](void* t, size_t* b) {
+          return mpcx_sort_pairs_i64_i32(keys.as<int64_t>(), keys_s.as<int64_t>(), iota.as<int32_t>(), order.as<int32_t>(), n, 0, end_bit,
+                                         t, b, stream);
+        }))
+      return rc;
+    if (int rc = hip_ok(hipMemsetAsync(in_fan.p, 0, n, st), "hipMemsetAsync"))
+      return rc;
+    if (int rc = mpcx_cluster_build(n, keys_s.as<int64_t>(), order.as<int32_t>(), x_dofmap, verts_all.as<int32_t>(), ok.as<int8_t>(),
+                                    in_fan.as<int8_t>(), stream))
+      return rc;
+    if (int rc = mpcx_cluster_canonical(n, verts_all.as<int32_t>(), ok.as<int8_t>(), x, stream))
+      return rc;
+  }
+  auto compact = [&](const int8_t* marks, int want, const int32_t* rows, int width, Dev& dst, int64_t& count) -> int
+  {
+    count = 0;
+    if (n == 0)
+      return dst.alloc(16);
+    hipLaunchKernelGGL(flags_from_i8, dim3(grid_for(n, 256)), dim3(256), 0, st, n, marks, want, flag.as<int32_t>());
+    if (int rc = with_temp([&](void* t, size_t* b)
+                           { return mpcx_scan_exclusive_i32_i64(flag.as<int32_t>(), n, pos.as<int64_t>(), t, b, stream); }))
+      return rc;
+    int64_t total = 0;
+    if (int rc = hip_ok(hipMemcpyAsync(&total, pos.as<int64_t>() + n, 8, hipMemcpyDeviceToHost, st), "hipMemcpyAsync"))
+      return rc;
+    if (int rc = hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+      return rc;
+    count = total;
+    if (int rc = dst.alloc(size_t(std::max<int64_t>(total, 1)) * width * 4))
+      return rc;
+    hipLaunchKernelGGL(compact_rows, dim3(grid_for(n, 256)), dim3(256), 0, st, n, flag.as<int32_t>(), pos.as<int64_t>(), rows, width,
+                       dst.as<int32_t>());
+    return hip_ok(hipGetLastError(), "compaction");
+  };
+  if (int rc = compact(ok.as<int8_t>(), 1, verts_all.as<int32_t>(), 8, plan->verts, plan->n_clusters))
+    return rc;
+  if (int rc = compact(in_fan.as<int8_t>(), 0, nullptr, 1, plan->left, plan->n_left))
+    return rc;
+  keys.release(), keys_s.release(), iota.release(), order.release(), verts_all.release(), ok.release(), in_fan.release();
+  const int64_t nc = plan->n_clusters;
+  // ---- row blocks
+  std::vector<int32_t> row0(size_t(nrows) + 2);
+  const int64_t nb = mpcx_block_ranges(nrows, rowptr_host, max_rows, max_nnz, 1, row_hints, n_hints, row0.data(), int64_t(row0.size()));
+  if (nb < 0)
+    return -4;
+  plan->num_blocks = int32_t(nb);
+  for (int64_t b = 0; b < nb; ++b)
+  {
+    plan->max_rows = std::max(plan->max_rows, row0[b + 1] - row0[b]);
+    plan->max_nnz = std::max<int32_t>(plan->max_nnz, int32_t(rowptr_host[row0[b + 1]] - rowptr_host[row0[b]]));
+  }
+  if (plan->row0.alloc((nb + 1) * 4)
+      || hip_ok(hipMemcpyAsync(plan->row0.p, row0.data(), (nb + 1) * 4, hipMemcpyHostToDevice, st), "hipMemcpyAsync"))
+    return -100;
+  // ---- (block, cluster) slots, ordered by block, by cluster inside a block
+  Dev counts, offs, pair_block, pair_ent, key64, key64_s, ents, off;
+  if (counts.alloc(std::max<int64_t>(nc, 1) * 4) || offs.alloc((nc + 1) * 8) || off.alloc((nb + 1) * 8))
+    return -100;
+  int64_t total = 0;
+  if (nc > 0)
+  {
+    if (int rc = mpcx_rowblock_pairs_device(nc, 1, nullptr, plan->verts.as<int32_t>(), 8, 1, int32_t(nb), plan->row0.as<int32_t>(),
+                                            counts.as<int32_t>(), nullptr, nullptr, nullptr, nullptr, 0, stream))
+      return rc;
+    if (int rc = with_temp([&](void* t, size_t* b)
+                           { return mpcx_scan_exclusive_i32_i64(counts.as<int32_t>(), nc, offs.as<int64_t>(), t, b, stream); }))
+      return rc;
+    if (hip_ok(hipMemcpyAsync(&total, offs.as<int64_t>() + nc, 8, hipMemcpyDeviceToHost, st), "hipMemcpyAsync")
+        || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+      return -100;
+  }
+  plan->n_slots = total;
+  const size_t ts = size_t(std::max<int64_t>(total, 1));
+  if (pair_block.alloc(ts * 4) || pair_ent.alloc(ts * 4) || key64.alloc(ts * 8) || key64_s.alloc(ts * 8) || ents.alloc(ts * 4))
+    return -100;
+  if (total > 0)
+  {
+    if (int rc = mpcx_rowblock_pairs_device(nc, 1, nullptr, plan->verts.as<int32_t>(), 8, 1, int32_t(nb), plan->row0.as<int32_t>(),
+                                            counts.as<int32_t>(), offs.as<int64_t>(), pair_block.as<int32_t>(), pair_ent.as<int32_t>(),
+                                            nullptr, 0, stream))
+      return rc;
+    hipLaunchKernelGGL(widen_i32_i64, dim3(grid_for(total, 256)), dim3(256), 0, st, total, pair_block.as<int32_t>(), key64.as<int64_t>());
+    if (int rc = with_temp([&](void* t, size_t* b) {
+          return mpcx_sort_pairs_i64_i32(key64.as<int64_t>(), key64_s.as<int64_t>(), pair_ent.as<int32_t>(), ents.as<int32_t>(), total, 0,
+                                         bit_length(nb), t, b, stream);
+        }))
+      return rc;
+    if (int rc = mpcx_segment_offsets(key64_s.as<int64_t>(), total, 0, nb, off.as<int64_t>(), stream))
+      return rc;
+  }
+  else if (int rc = hip_ok(hipMemsetAsync(off.p, 0, (nb + 1) * 8, st), "hipMemsetAsync"))
+    return rc;
+  counts.release(), offs.release(), pair_block.release(), pair_ent.release(), key64.release(), key64_s.release();
+  // ---- records, slot properties, block kinds
+  Dev recs, wide, general, kind, oflag;
+  if (recs.alloc(ts * 96) || wide.alloc(ts) || general.alloc(ts) || kind.alloc(std::max<int64_t>(nb, 1) * 4) || oflag.alloc(4))
+    return -100;
+  if (hip_ok(hipMemsetAsync(oflag.p, 0, 4, st), "hipMemsetAsync"))
+    return -100;
+  if (total > 0)
+  {
+    if (int rc = mpcx_cube_records(total, ents.as<int32_t>(), plan->verts.as<int32_t>(), 1, bc, is_slave, rowptr, cols, recs.p,
+                                   oflag.as<int32_t>(), stream))
+      return rc;
+    if (int rc = mpcx_cube_slot_width(total, recs.p, wide.as<uint8_t>(), stream))
+      return rc;
+    if (int rc = mpcx_hex_slot_shapes(total, recs.p, x, general.as<uint8_t>(), stream))
+      return rc;
+  }
+  hipLaunchKernelGGL(block_kinds, dim3(grid_for(nb, 128)), dim3(128), 0, st, int32_t(nb), off.as<int64_t>(), wide.as<uint8_t>(),
+                     general.as<uint8_t>(), kind.as<int32_t>());
+  std::vector<int32_t> h_kind(size_t(std::max<int64_t>(nb, 1)));
+  std::vector<int64_t> h_off(size_t(nb) + 1);
+  int32_t overflow = 0;
+  if (hip_ok(hipMemcpyAsync(h_kind.data(), kind.p, nb * 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync")
+      || hip_ok(hipMemcpyAsync(h_off.data(), off.p, (nb + 1) * 8, hipMemcpyDeviceToHost, st), "hipMemcpyAsync")
+      || hip_ok(hipMemcpyAsync(&overflow, oflag.p, 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync")
+      || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+    return -100;
+  if (overflow)
+  {
+    mpcx_set_error("mpcx_cluster_plan_create: a scatter offset does not fit 8 bits (or a column is missing from the pattern)");
+    return -21;
+  }
+  wide.release(), general.release(), kind.release();
+  // ---- one part per kind of row block that occurs (ascending kind: narrow + parallelepiped first)
+  for (int kd = 0; kd < 4; ++kd)
+  {
+    std::vector<int32_t> ids;
+    std::vector<int64_t> off_c(1, 0);
+    for (int64_t b = 0; b < nb; ++b)
+      if (h_kind[b] == kd)
+      {
+        ids.push_back(int32_t(b));
+        off_c.push_back(off_c.back() + (h_off[b + 1] - h_off[b]));
+      }
+    if (ids.empty())
+      continue;
+    mpcx_cluster_plan::Part part;
+    part.num_blocks = int32_t(ids.size());
+    part.rec_bytes = (kd & 1) ? 96 : 64;
+    part.flags = (kd & 2) ? 0 : 1;
+    const int64_t tot = off_c.back();
+    Dev src;
+    if (part.ids.alloc(ids.size() * 4) || part.off.alloc(off_c.size() * 8) || src.alloc(size_t(std::max<int64_t>(tot, 1)) * 8)
+        || part.recs.alloc(size_t(std::max<int64_t>(tot, 1)) * part.rec_bytes))
+      return -100;
+    if (hip_ok(hipMemcpyAsync(part.ids.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, st), "hipMemcpyAsync")
+        || hip_ok(hipMemcpyAsync(part.off.p, off_c.data(), off_c.size() * 8, hipMemcpyHostToDevice, st), "hipMemcpyAsync"))
+      return -100;
+    hipLaunchKernelGGL(part_sources, dim3(unsigned(ids.size())), dim3(256), 0, st, int32_t(ids.size()), part.ids.as<int32_t>(),
+                       off.as<int64_t>(), part.off.as<int64_t>(), src.as<int64_t>());
+    if (tot > 0)
+    {
+      if (part.rec_bytes == 64)
+      {
+        if (int rc = mpcx_cube_pack_narrow(tot, src.as<int64_t>(), recs.p, part.recs.p, stream))
+          return rc;
+      }
+      else
+        hipLaunchKernelGGL(gather_records96, dim3(grid_for(tot * 6, 256)), dim3(256), 0, st, tot, src.as<int64_t>(),
+                           static_cast<const uint4*>(recs.p), part.recs.as<uint4>());
+    }
+    // (the host vectors above must outlive the asynchronous copies)
+    if (hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+      return -100;
+    part.all_blocks = int64_t(ids.size()) == nb;
+    plan->parts.push_back(std::move(part));
+  }
+  if (int rc = hip_ok(hipGetLastError(), "kernel launch"))
+    return rc;
+  *out = plan.release();
+  return 0;
+}
+
+extern "C" int32_t mpcx_cluster_plan_num_parts(const mpcx_cluster_plan_t* p) { return p ? int32_t(p->parts.size()) : 0; }
+extern "C" int64_t mpcx_cluster_plan_num_clusters(const mpcx_cluster_plan_t* p) { return p ? p->n_clusters : 0; }
+extern "C" int64_t mpcx_cluster_plan_num_slots(const mpcx_cluster_plan_t* p) { return p ? p->n_slots : 0; }
+extern "C" const int32_t* mpcx_cluster_plan_verts(const mpcx_cluster_plan_t* p) { return p ? p->verts.as<int32_t>() : nullptr; }
+extern "C" int64_t mpcx_cluster_plan_leftover(const mpcx_cluster_plan_t* p, const int32_t** cells)
+{
+  if (!p)
+    return 0;
+  if (cells)
+    *cells = p->left.as<int32_t>();
+  return p->n_left;
+}
+
+extern "C" int mpcx_cluster_plan_part(const mpcx_cluster_plan_t* p, int32_t part, mpcx_matrix_args_t* a)
+{
+  if (!p || !a || part < 0 || part >= int32_t(p->parts.size()))
+  {
+    mpcx_set_error("mpcx_cluster_plan_part: no such part");
+    return -1;
+  }
+  const auto& q = p->parts[size_t(part)];
+  std::memset(&a->plan, 0, sizeof(a->plan));
+  a->plan.num_blocks = q.num_blocks;
+  a->plan.max_rows = p->max_rows;
+  a->plan.max_nnz = p->max_nnz;
+  a->plan.block_row0 = p->row0.as<int32_t>();
+  a->plan.block_ent_off = q.off.as<int64_t>();
+  a->cube_recs = q.recs.p;
+  a->cube_rec_bytes = q.rec_bytes;
+  a->cube_flags = q.flags;
+  a->cube_block_ids = q.all_blocks ? nullptr : q.ids.as<int32_t>();
+  a->algorithm = MPCX_ALG_CUBE;
+  return 0;
+}
+
+extern "C" void mpcx_cluster_plan_destroy(mpcx_cluster_plan_t* p) { delete p; }

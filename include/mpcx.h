@@ -340,6 +340,33 @@ int mpcx_p2_cluster_tables(double* k, int32_t* coupled, int32_t* edge_vertices, 
  * first index: the metric entry 00 01 02 11 12 22 (k9: d * 3 + e) */
 int mpcx_p1_cluster_tables(double* k6, double* k9, double* hex6);
 
+/* The whole set-up of MPCX_ALG_CUBE for a scalar P1 stiffness integral over ALL cells of a tetrahedral mesh in one call,
+ * with device memory the library allocates itself -- for callers without torch (a C++ binding inside
+ * python/src/dolfinx_mpc/mpc.cpp): cluster detection (mpcx_cluster_keys .. mpcx_cluster_canonical), row blocks
+ * (mpcx_block_ranges on rowptr_host, max_rows / max_nnz as for mpcx_rowblock_plan_*; row_hints: HOST, first row of every
+ * tile of a tiled numbering, or NULL), the (block, cluster) slots, their records, and the split of the row blocks by
+ * record format and cluster shape.  x_dofmap [n_cells][4], x [n_nodes][3], rowptr / cols, bc (or NULL), is_slave: DEVICE;
+ * rowptr_host: the same offsets on the HOST.  The records hold Dirichlet / slave masks and depend on the coordinates
+ * through the split: rebuild when the constraint, the boundary conditions or the mesh geometry change.
+ *   mpcx_cluster_plan_num_parts   launches needed (1 .. 4); for part p, mpcx_cluster_plan_part fills plan, cube_recs,
+ *                                 cube_rec_bytes, cube_flags, cube_block_ids and algorithm of *args (everything else --
+ *                                 CSR, kernel, geometry, mpc, store_mode, slave entities on the LAST part -- is the caller's)
+ *   mpcx_cluster_plan_leftover    cells in no cluster (DEVICE, ascending; owned by the plan): a per-cell call adds them
+ *   mpcx_cluster_plan_verts       DEVICE [num_clusters][8]: mpcx_vector_args_t::cube_verts of the vector kernels
+ * Returns 0, -21 if a scatter offset does not fit 8 bits (use MPCX_ALG_ROWBLOCK / MPCX_ALG_ATOMIC then). */
+typedef struct mpcx_cluster_plan mpcx_cluster_plan_t;
+int mpcx_cluster_plan_create(int64_t n_cells, const int32_t* x_dofmap, int64_t n_nodes, const double* x, int32_t nrows,
+                             const mpcx_nnz_t* rowptr, const mpcx_nnz_t* rowptr_host, const int32_t* cols, const int8_t* bc,
+                             const int8_t* is_slave, int32_t max_rows, int32_t max_nnz, const int32_t* row_hints, int32_t n_hints,
+                             void* stream, mpcx_cluster_plan_t** plan);
+int32_t mpcx_cluster_plan_num_parts(const mpcx_cluster_plan_t* plan);
+int64_t mpcx_cluster_plan_num_clusters(const mpcx_cluster_plan_t* plan);
+int64_t mpcx_cluster_plan_num_slots(const mpcx_cluster_plan_t* plan);
+const int32_t* mpcx_cluster_plan_verts(const mpcx_cluster_plan_t* plan);
+int64_t mpcx_cluster_plan_leftover(const mpcx_cluster_plan_t* plan, const int32_t** cells);
+int mpcx_cluster_plan_part(const mpcx_cluster_plan_t* plan, int32_t part, mpcx_matrix_args_t* args);
+void mpcx_cluster_plan_destroy(mpcx_cluster_plan_t* plan);
+
 /* Narrow records (all pointers DEVICE): mpcx_cube_slot_width: wide[k] = 1 if a coupled offset of record k exceeds 15;
  * mpcx_cube_pack_narrow: out[j] (64 bytes: the 8 ids, then 46 nibbles in row-major order of the coupled pairs) from the
  * 96-byte record src[j]. */

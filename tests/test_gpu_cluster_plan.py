@@ -1,0 +1,118 @@
+"""mpcx_cluster_plan_*: the cluster set-up of MPCX_ALG_CUBE behind one C-ABI call (device memory owned by the library, no
+torch in the build) against the plan dolfinx_mpc_amd/assemble_matrix.py builds through torch -- array by array -- and
+the matrix assembled from it against the oracle."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+from problems import case_cube_periodic, oracle_outputs, product_mpc
+
+pytestmark = pytest.mark.gpu
+
+
+def _c_plan(case, mpc, A, max_rows, max_nnz):
+    import torch
+
+    from dolfinx_mpc_amd import _device as D
+    from dolfinx_mpc_amd import _native
+
+    L = _native.lib()
+    V = case.V
+    md = D.mesh_device(V.mesh)
+    _, bc = D.bc_markers(V, case.bcs, case.a._device)
+    _, t = mpc._device()
+    hints = None if V.dof_tile_offsets is None else np.ascontiguousarray(V.dof_tile_offsets.astype(np.int32))
+    rowptr_h = np.ascontiguousarray(A.rowptr.astype(np.int64))
+    h = C.c_void_p()
+    rc = L.mpcx_cluster_plan_create(V.mesh.num_owned_cells, md["x_dofmap"].data_ptr(), V.mesh.num_nodes, md["x"].data_ptr(), A.shape[0],
+                                    A.d_rowptr.data_ptr(), rowptr_h.ctypes.data, A.d_cols.data_ptr(), D.ptr(bc), t["is_slave"].data_ptr(),
+                                    max_rows, max_nnz, None if hints is None else hints.ctypes.data, 0 if hints is None else hints.size,
+                                    D.stream_ptr(), C.byref(h))
+    _native.check(rc, "mpcx_cluster_plan_create")
+    torch.cuda.synchronize()
+    return h
+
+
+def _dev_array(ptr, count, dtype):
+    import torch
+
+    if count == 0:
+        return np.zeros(0, dtype=dtype)
+    nbytes = count * np.dtype(dtype).itemsize
+    out = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(out.data_ptr(), ptr, nbytes, 3) == 0  # device to device
+    return out.cpu().numpy().view(dtype)
+
+
+@pytest.mark.parametrize("kwargs", [dict(reorder=(4, 4, 4)), dict(reorder=(4, 4, 4), warp="half"), dict(numbering="shuffled")],
+                         ids=["tiled", "half-warped", "shuffled"])
+def test_cluster_plan_from_the_c_abi_equals_the_torch_built_plan(oracle, kwargs, monkeypatch):
+    import torch
+
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import _native
+
+    am = importlib.import_module("dolfinx_mpc_amd.assemble_matrix")
+    monkeypatch.setattr(am, "CUBE_MAX_ROWS", 64)
+    monkeypatch.setattr(am, "CUBE_MAX_NNZ", 64 * 16)
+    case = case_cube_periodic(12, 1, 0.3, **kwargs)
+    mpc = product_mpc(case)
+    A = dm.assemble_matrix(case.a, mpc, bcs=case.bcs, diagval=case.diagval)
+    (parts, keep, info), = [v[1] for v in A._plans[("objcache", "cubes")].values()]
+    L = _native.lib()
+    h = _c_plan(case, mpc, A, 64, 64 * 16)
+    try:
+        assert L.mpcx_cluster_plan_num_clusters(h) == info["clusters"]
+        assert L.mpcx_cluster_plan_num_parts(h) == len(parts)
+        verts = _dev_array(L.mpcx_cluster_plan_verts(h), info["clusters"] * 8, np.int32)
+        assert np.array_equal(verts, keep[2].cpu().numpy().reshape(-1))
+        vals2 = torch.zeros_like(A.vals)
+        base, base_keep = am.matrix_args(case.a, 0, A, mpc, mpc, case.bcs, 2, store_mode=1)
+        chain, u = [], base
+        while u is not None:
+            chain.append(u)
+            u = u.second
+        assert len(chain) == len(parts)
+        for p, (part, ref_args) in enumerate(zip(parts, chain)):
+            a = _native.MatrixArgs.from_buffer_copy(ref_args)
+            _native.check(L.mpcx_cluster_plan_part(h, p, C.byref(a)), "mpcx_cluster_plan_part")
+            plan_t, recs, nbytes, ids, off, flags = part
+            assert (a.cube_rec_bytes, a.cube_flags, a.plan.num_blocks) == (nbytes, flags, plan_t.num_blocks)
+            assert (a.plan.max_rows, a.plan.max_nnz) == (plan_t.max_rows, plan_t.max_nnz)
+            nslots = recs.numel() // nbytes
+            assert np.array_equal(_dev_array(a.cube_recs, nslots * nbytes, np.uint8), recs.cpu().numpy())
+            assert np.array_equal(_dev_array(a.plan.block_ent_off, plan_t.num_blocks + 1, np.int64), off.cpu().numpy())
+            if ids is not None:
+                assert np.array_equal(_dev_array(a.cube_block_ids, plan_t.num_blocks, np.int32), ids.cpu().numpy())
+            else:
+                assert not a.cube_block_ids
+            # ... and the launch from the C-built plan writes the same values
+            a.vals = vals2.data_ptr()
+            _native.check(L.mpcx_assemble_matrix(C.byref(a)), "mpcx_assemble_matrix")
+        cells = C.c_void_p()
+        nleft = L.mpcx_cluster_plan_leftover(h, C.byref(cells))
+        assert nleft == case.V.mesh.num_owned_cells - 6 * info["clusters"]
+        if nleft:  # cells in no cluster (distorted regions): the per-cell kernel adds them, as assemble_matrix does
+            assert np.array_equal(_dev_array(cells.value, nleft, np.int32), base.leftover)
+            fl = am._leftover_form(case.a, 0, base.leftover)
+            al, _kl = am.matrix_args(fl, 0, A, mpc, mpc, case.bcs, 2, 0, with_mpc_kernel=False, allow_cubes=False)
+            al.vals = vals2.data_ptr()
+            _native.check(L.mpcx_assemble_matrix(C.byref(al)), "mpcx_assemble_matrix")
+        else:
+            assert base.leftover is None
+        torch.cuda.synchronize()
+        ref = oracle_outputs(oracle, case)["A"]
+        # (bulk + master contributions of the last launch; the diagonals of slave / Dirichlet rows are added by the wrapper)
+        got = A.to_scipy().copy()
+        got.data = vals2.cpu().numpy()
+        diag_rows = np.flatnonzero(abs(ref.diagonal() - got.diagonal()) > 1e-13)
+        assert abs((ref - got)).max() <= 1.0 + 1e-12 and set(diag_rows) <= set(np.flatnonzero(ref.diagonal() == case.diagval))
+        off_diag = (ref - got).tolil()
+        off_diag.setdiag(0.0)
+        assert abs(off_diag.tocsr()).max() <= 1e-12 * max(1.0, abs(ref).max())
+    finally:
+        L.mpcx_cluster_plan_destroy(h)
