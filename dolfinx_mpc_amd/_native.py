@@ -220,6 +220,9 @@ EXPORTS = [
     "mpcx_cluster_plan_leftover",
     "mpcx_cluster_plan_part",
     "mpcx_cluster_plan_destroy",
+    "mpcx_owner_plan_create",
+    "mpcx_owner_plan_fill",
+    "mpcx_owner_plan_destroy",
     "mpcx_cube_detect",
     "mpcx_cube_slot_width",
     "mpcx_cube_pack_narrow",
@@ -409,6 +412,12 @@ def lib() -> C.CDLL:
     L.mpcx_cluster_plan_part.restype = C.c_int
     L.mpcx_cluster_plan_destroy.argtypes = [vp]
     L.mpcx_cluster_plan_destroy.restype = None
+    L.mpcx_owner_plan_create.argtypes = [i64, i32, vp, i32, i32, i32, vp, i32, i32, vp, C.POINTER(C.c_void_p)]
+    L.mpcx_owner_plan_create.restype = C.c_int
+    L.mpcx_owner_plan_fill.argtypes = [vp, C.POINTER(VectorArgs)]
+    L.mpcx_owner_plan_fill.restype = C.c_int
+    L.mpcx_owner_plan_destroy.argtypes = [vp]
+    L.mpcx_owner_plan_destroy.restype = None
     L.mpcx_cube_detect.argtypes = [vp, i64, vp, vp, vp]
     L.mpcx_cube_detect.restype = C.c_int
     L.mpcx_cube_slot_width.argtypes = [i64, vp, vp, vp]

@@ -400,3 +400,192 @@ extern "C" int mpcx_cluster_plan_part(const mpcx_cluster_plan_t* p, int32_t part
 }
 
 extern "C" void mpcx_cluster_plan_destroy(mpcx_cluster_plan_t* p) { delete p; }
+
+// ---------------------------------------------------------------------------------------------------------
+// Owner-computes plan of the row-block vector kernels (mpcx_vector_args_t::own_*; cluster kernels: work item = cluster,
+// its eight vertices; per-cell kernels: work item = entity) behind one call: the six steps listed at
+// mpcx_owner_plan_count in include/mpcx.h with the scans / sorts / run lengths between them, in library-owned memory.
+// dolfinx_mpc_amd/assemble_vector.py::_owner_plan_from_rows is the torch-driven twin (compared in the tests).
+// ---------------------------------------------------------------------------------------------------------
+struct mpcx_owner_plan
+{
+  Dev row0, off, order, lmap, hoff, spill, sorder, urows, seg;
+  int32_t num_blocks = 0, max_rows = 0, bs = 1;
+  int64_t n_own_rows = 0;
+};
+
+namespace
+{
+__global__ void narrow_i64_i32(int64_t n, const int64_t* in, int32_t* out)
+{
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n)
+    out[i] = int32_t(in[i]);
+}
+// run-length structure of a sorted key array: heads, their exclusive scan, (optionally) the distinct keys and run starts
+int run_structure(const int64_t* keys, int64_t n, Dev& heads, Dev& hscan, Dev* run_keys, Dev* run_start, int64_t& nr, void* stream)
+{
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  nr = 0;
+  if (heads.alloc(size_t(std::max<int64_t>(n, 1)) * 4) || hscan.alloc(size_t(n + 1) * 8))
+    return -100;
+  if (n == 0)
+  {
+    if (hip_ok(hipMemsetAsync(hscan.p, 0, 8, st), "hipMemsetAsync"))
+      return -100;
+    if (run_keys && run_keys->alloc(16))
+      return -100;
+    if (run_start && (run_start->alloc(16) || hip_ok(hipMemsetAsync(run_start->p, 0, 8, st), "hipMemsetAsync")))
+      return -100;
+    return 0;
+  }
+  if (int rc = mpcx_run_heads(keys, n, heads.as<int32_t>(), stream))
+    return rc;
+  if (int rc = with_temp([&](void* t, size_t* b) { return mpcx_scan_exclusive_i32_i64(heads.as<int32_t>(), n, hscan.as<int64_t>(), t, b, stream); }))
+    return rc;
+  if (hip_ok(hipMemcpyAsync(&nr, hscan.as<int64_t>() + n, 8, hipMemcpyDeviceToHost, st), "hipMemcpyAsync")
+      || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+    return -100;
+  Dev rk_local, rs_local;
+  Dev& rk = run_keys ? *run_keys : rk_local;
+  Dev& rs = run_start ? *run_start : rs_local;
+  if (rk.alloc(size_t(std::max<int64_t>(nr, 1)) * 8) || rs.alloc(size_t(nr + 1) * 8))
+    return -100;
+  return mpcx_run_fill(keys, heads.as<int32_t>(), hscan.as<int64_t>(), n, rk.as<int64_t>(), rs.as<int64_t>(), stream);
+}
+} // namespace
+
+extern "C" int mpcx_owner_plan_create(int64_t n, int32_t nd, const int32_t* mrow, int32_t bs, int32_t nrows, int32_t rows_per_block,
+                                      const int32_t* row_hints, int32_t n_hints, int32_t max_lds_rows, void* stream,
+                                      mpcx_owner_plan_t** out)
+{
+  if (!out || !mrow || n <= 0 || nd <= 0 || bs <= 0 || nrows <= 0 || rows_per_block <= 0 || n * nd >= (int64_t(1) << 31))
+  {
+    mpcx_set_error("mpcx_owner_plan_create: invalid arguments (n * nd must fit 32 bits)");
+    return -1;
+  }
+  *out = nullptr;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  auto plan = std::make_unique<mpcx_owner_plan>();
+  plan->bs = bs;
+  std::vector<int32_t> row0(size_t(nrows) + 2);
+  const int64_t nb = mpcx_block_ranges(nrows, nullptr, rows_per_block, rows_per_block, bs, row_hints, n_hints, row0.data(), int64_t(row0.size()));
+  if (nb < 0)
+    return -4;
+  plan->num_blocks = int32_t(nb);
+  if (plan->row0.alloc((nb + 1) * 4)
+      || hip_ok(hipMemcpyAsync(plan->row0.p, row0.data(), (nb + 1) * 4, hipMemcpyHostToDevice, st), "hipMemcpyAsync"))
+    return -100;
+  const int32_t* d_row0 = plan->row0.as<int32_t>();
+  // 1-2: owner of every item, item order by block, count of foreign dofs
+  Dev owner, item, fcount, foff, owner_s;
+  if (owner.alloc(n * 8) || item.alloc(n * 4) || fcount.alloc(n * 4) || foff.alloc((n + 1) * 8) || owner_s.alloc(n * 8)
+      || plan->order.alloc(n * 4) || plan->off.alloc((nb + 1) * 8) || plan->lmap.alloc(size_t(n) * nd * 4))
+    return -100;
+  if (int rc = mpcx_owner_plan_count(n, nd, mrow, bs, int32_t(nb), d_row0, owner.as<int64_t>(), item.as<int32_t>(), fcount.as<int32_t>(), stream))
+    return rc;
+  if (int rc = with_temp([&](void* t, size_t* b) { return mpcx_scan_exclusive_i32_i64(fcount.as<int32_t>(), n, foff.as<int64_t>(), t, b, stream); }))
+    return rc;
+  int64_t nf = 0;
+  if (hip_ok(hipMemcpyAsync(&nf, foff.as<int64_t>() + n, 8, hipMemcpyDeviceToHost, st), "hipMemcpyAsync")
+      || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+    return -100;
+  if (int rc = with_temp([&](void* t, size_t* b) {
+        return mpcx_sort_pairs_i64_i32(owner.as<int64_t>(), owner_s.as<int64_t>(), item.as<int32_t>(), plan->order.as<int32_t>(), n, 0,
+                                       bit_length(nb), t, b, stream);
+      }))
+    return rc;
+  if (int rc = mpcx_segment_offsets(owner_s.as<int64_t>(), n, 0, nb, plan->off.as<int64_t>(), stream))
+    return rc;
+  // 3-4: (block, foreign dof) keys, sorted; distinct keys = halo entries
+  Dev keys, src, keys_s, src_s, heads, hscan, ukey;
+  const size_t fs = size_t(std::max<int64_t>(nf, 1));
+  if (keys.alloc(fs * 8) || src.alloc(fs * 4) || keys_s.alloc(fs * 8) || src_s.alloc(fs * 4) || plan->hoff.alloc((nb + 1) * 8))
+    return -100;
+  if (int rc = mpcx_owner_plan_keys(n, nd, mrow, bs, int32_t(nb), d_row0, owner.as<int64_t>(), foff.as<int64_t>(), keys.as<int64_t>(),
+                                    src.as<int32_t>(), plan->lmap.as<int32_t>(), stream))
+    return rc;
+  int64_t nu = 0;
+  if (nf > 0)
+  {
+    if (int rc = with_temp([&](void* t, size_t* b) {
+          return mpcx_sort_pairs_i64_i32(keys.as<int64_t>(), keys_s.as<int64_t>(), src.as<int32_t>(), src_s.as<int32_t>(), nf, 0,
+                                         32 + bit_length(nb), t, b, stream);
+        }))
+      return rc;
+  }
+  if (int rc = run_structure(keys_s.as<int64_t>(), nf, heads, hscan, &ukey, nullptr, nu, stream))
+    return rc;
+  if (int rc = mpcx_segment_offsets(ukey.as<int64_t>(), nu, 32, nb, plan->hoff.as<int64_t>(), stream))
+    return rc;
+  // 5: LDS positions of the foreign dofs, rows of the largest block
+  Dev maxr;
+  if (maxr.alloc(4) || hip_ok(hipMemsetAsync(maxr.p, 0, 4, st), "hipMemsetAsync"))
+    return -100;
+  if (int rc = mpcx_owner_plan_halo(nf, keys_s.as<int64_t>(), src_s.as<int32_t>(), heads.as<int32_t>(), hscan.as<int64_t>(),
+                                    plan->hoff.as<int64_t>(), int32_t(nb), d_row0, bs, mrow, plan->lmap.as<int32_t>(), maxr.as<int32_t>(),
+                                    stream))
+    return rc;
+  if (hip_ok(hipMemcpyAsync(&plan->max_rows, maxr.p, 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync")
+      || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+    return -100;
+  if (max_lds_rows > 0 && plan->max_rows > max_lds_rows)
+  {
+    mpcx_set_error("mpcx_owner_plan_create: a block with its halo exceeds max_lds_rows; use fewer rows per block");
+    return -4;
+  }
+  // 6: spill order -- halo entries by target dof
+  Dev low, iota, sdof, so, uh, us, urows64;
+  const size_t us_n = size_t(std::max<int64_t>(nu, 1));
+  if (low.alloc(us_n * 8) || iota.alloc(us_n * 4) || sdof.alloc(us_n * 8) || plan->sorder.alloc(us_n * 4) || plan->spill.alloc(us_n * bs * 8))
+    return -100;
+  int64_t nrows_u = 0;
+  if (nu > 0)
+  {
+    if (int rc = mpcx_low_word_iota(nu, ukey.as<int64_t>(), low.as<int64_t>(), iota.as<int32_t>(), stream))
+      return rc;
+    if (int rc = with_temp([&](void* t, size_t* b) {
+          return mpcx_sort_pairs_i64_i32(low.as<int64_t>(), sdof.as<int64_t>(), iota.as<int32_t>(), plan->sorder.as<int32_t>(), nu, 0,
+                                         bit_length(nrows / bs), t, b, stream);
+        }))
+      return rc;
+  }
+  if (int rc = run_structure(sdof.as<int64_t>(), nu, uh, us, &urows64, &plan->seg, nrows_u, stream))
+    return rc;
+  plan->n_own_rows = nrows_u;
+  if (plan->urows.alloc(size_t(std::max<int64_t>(nrows_u, 1)) * 4))
+    return -100;
+  if (nrows_u > 0)
+    hipLaunchKernelGGL(narrow_i64_i32, dim3(grid_for(nrows_u, 256)), dim3(256), 0, st, nrows_u, urows64.as<int64_t>(), plan->urows.as<int32_t>());
+  if (hip_ok(hipMemsetAsync(plan->spill.p, 0, us_n * bs * 8, st), "hipMemsetAsync") || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize")
+      || hip_ok(hipGetLastError(), "kernel launch"))
+    return -100;
+  *out = plan.release();
+  return 0;
+}
+
+extern "C" int mpcx_owner_plan_fill(const mpcx_owner_plan_t* p, mpcx_vector_args_t* a)
+{
+  if (!p || !a)
+  {
+    mpcx_set_error("mpcx_owner_plan_fill: NULL argument");
+    return -1;
+  }
+  std::memset(&a->plan, 0, sizeof(a->plan));
+  a->plan.num_blocks = p->num_blocks;
+  a->plan.max_rows = p->max_rows;
+  a->plan.max_nnz = p->max_rows;
+  a->plan.block_row0 = p->row0.as<int32_t>();
+  a->plan.block_ent_off = p->off.as<int64_t>();
+  a->plan.block_ents = p->order.as<int32_t>();
+  a->own_lmap = p->lmap.as<int32_t>();
+  a->own_hoff = p->hoff.as<int64_t>();
+  a->own_spill = p->spill.as<double>();
+  a->own_src = p->sorder.as<int32_t>();
+  a->own_rows = p->urows.as<int32_t>();
+  a->own_seg = p->seg.as<int64_t>();
+  a->n_own_rows = p->n_own_rows;
+  return 0;
+}
+
+extern "C" void mpcx_owner_plan_destroy(mpcx_owner_plan_t* p) { delete p; }

@@ -630,6 +630,16 @@ int mpcx_owner_plan_halo(int64_t nf, const int64_t* sorted_keys, const int32_t* 
                          const int64_t* heads_scan, const int64_t* hoff, int32_t nb, const int32_t* block_row0, int32_t bs,
                          const int32_t* mrow, int32_t* lmap, int32_t* max_rows, void* stream);
 int mpcx_low_word_iota(int64_t n, const int64_t* keys, int64_t* low, int32_t* iota, void* stream);
+/* The six steps above and everything between them behind ONE call, in device memory the library allocates (for callers
+ * without torch).  mrow: DEVICE [n][nd], e.g. mpcx_mask_dofmap(cluster vertices or cell dofmap, ..., bc = NULL, is_slave)
+ * -- slave flags in the bits 28 + k; rows_per_block own rows per block (multiples of bs; row_hints: HOST, preferred cuts,
+ * or NULL); max_lds_rows > 0: fail with -4 if a block with its halo is larger (96 KiB / 8 = 12288 rows for the kernels here).
+ * mpcx_owner_plan_fill sets plan and the own_* fields of *args (MPCX_ALG_ROWBLOCK, or MPCX_ALG_CUBE with cube_verts). */
+typedef struct mpcx_owner_plan mpcx_owner_plan_t;
+int mpcx_owner_plan_create(int64_t n, int32_t nd, const int32_t* mrow, int32_t bs, int32_t nrows, int32_t rows_per_block,
+                           const int32_t* row_hints, int32_t n_hints, int32_t max_lds_rows, void* stream, mpcx_owner_plan_t** plan);
+int mpcx_owner_plan_fill(const mpcx_owner_plan_t* plan, mpcx_vector_args_t* args);
+void mpcx_owner_plan_destroy(mpcx_owner_plan_t* plan);
 
 /* Row-block plan for MPCX_ALG_ROWBLOCK: contiguous row ranges with at most
  * max_rows rows / max_nnz nonzeros, and for each block the entities whose

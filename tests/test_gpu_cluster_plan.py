@@ -116,3 +116,62 @@ def test_cluster_plan_from_the_c_abi_equals_the_torch_built_plan(oracle, kwargs,
         assert abs(off_diag.tocsr()).max() <= 1e-12 * max(1.0, abs(ref).max())
     finally:
         L.mpcx_cluster_plan_destroy(h)
+
+
+@pytest.mark.parametrize("kwargs", [dict(reorder=(4, 4, 4)), dict(numbering="shuffled")], ids=["tiled", "shuffled"])
+def test_owner_plan_from_the_c_abi_equals_the_torch_allocated_plan(oracle, kwargs):
+    """mpcx_owner_plan_create (the owner-computes plan of the cluster vector kernel in library-owned memory) against
+    assemble_vector._owner_plan_from_rows, array by array; the vector assembled from it against the oracle"""
+    import torch
+
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import _device as D
+    from dolfinx_mpc_amd import _native
+    from dolfinx_mpc_amd.la import create_vector
+
+    av = importlib.import_module("dolfinx_mpc_amd.assemble_vector")
+    case = case_cube_periodic(12, 1, 0.3, **kwargs)
+    mpc = product_mpc(case)
+    b = create_vector(case.V)
+    args, keep = av.vector_args(case.L, 0, b, mpc, 0)
+    assert args.kernel_name == "cube_own"
+    pk = [k for k in keep if isinstance(k, tuple) and len(k) == 9][0]  # the torch-allocated plan: (row0, off, order, lmap, hoff, spill, src, rows, seg)
+    V = case.V
+    L = _native.lib()
+    nc = int(args.n_cubes)
+    verts = torch.empty((nc, 8), dtype=torch.int32, device="cuda")
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(verts.data_ptr(), args.cube_verts, nc * 32, 3) == 0
+    _, t = mpc._device()
+    mrow = torch.empty_like(verts)
+    _native.check(L.mpcx_mask_dofmap(verts.data_ptr(), nc, 8, 1, None, t["is_slave"].data_ptr(), 0, mrow.data_ptr(), D.stream_ptr()),
+                  "mpcx_mask_dofmap")
+    rows = int(np.diff(pk[0].cpu().numpy()).max())  # own rows per block of the reference plan
+    hints = None if V.dof_tile_offsets is None else np.ascontiguousarray(V.dof_tile_offsets.astype(np.int32))
+    h = C.c_void_p()
+    rows_cfg = av._even_rows(V, av.VCUBE_OWNER_ROWS)
+    rc = L.mpcx_owner_plan_create(nc, 8, mrow.data_ptr(), 1, V.num_dofs, rows_cfg, None if hints is None else hints.ctypes.data,
+                                  0 if hints is None else hints.size, av.VECTOR_LDS_ROWS, D.stream_ptr(), C.byref(h))
+    _native.check(rc, "mpcx_owner_plan_create")
+    try:
+        a2 = _native.VectorArgs.from_buffer_copy(args)
+        _native.check(L.mpcx_owner_plan_fill(h, C.byref(a2)), "mpcx_owner_plan_fill")
+        nb = int(a2.plan.num_blocks)
+        assert nb == pk[0].numel() - 1 and rows <= rows_cfg and int(a2.n_own_rows) == int(args.n_own_rows)
+        assert int(a2.plan.max_rows) == int(args.plan.max_rows)
+        for name, ptr, ref in (("row0", a2.plan.block_row0, pk[0]), ("off", a2.plan.block_ent_off, pk[1]), ("order", a2.plan.block_ents, pk[2]),
+                               ("lmap", a2.own_lmap, pk[3].reshape(-1)), ("hoff", a2.own_hoff, pk[4]), ("src", a2.own_src, pk[6]),
+                               ("rows", a2.own_rows, pk[7]), ("seg", a2.own_seg, pk[8])):
+            refh = ref.cpu().numpy()
+            n = refh.size if name != "src" else int(pk[4][-1].item())
+            got = _dev_array(ptr, n, refh.dtype)
+            assert np.array_equal(got, refh[:n]), name
+        b2 = create_vector(V)
+        a2.b = b2.array.data_ptr()
+        _native.check(L.mpcx_assemble_vector(C.byref(a2)), "mpcx_assemble_vector")
+        torch.cuda.synchronize()
+        ref = dm.assemble_vector(case.L, mpc).numpy()
+        assert abs(b2.numpy() - ref).max() <= 1e-12 * max(1.0, abs(ref).max())
+    finally:
+        L.mpcx_owner_plan_destroy(h)
