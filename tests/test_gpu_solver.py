@@ -41,8 +41,15 @@ def test_spmv_matches_scipy():
     assert abs(y - ref).max() <= bound
 
 
+def _contact():
+    from problems import case_contact_two_body
+
+    return case_contact_two_body(4, 8, 0.0, reorder=(4, 4, 4))
+
+
 @pytest.mark.parametrize("make", [lambda: case_cube_periodic(10, 1, 0.3), lambda: case_cube_periodic(5, 2, 0.0),
-                                  lambda: case_cube_elasticity_slip(4)], ids=["p1-periodic", "p2-periodic", "elasticity-slip"])
+                                  lambda: case_cube_elasticity_slip(4), _contact],
+                         ids=["p1-periodic", "p2-periodic", "elasticity-slip", "contact"])
 @pytest.mark.parametrize("pc", ["jacobi", "gamg"])
 def test_linear_problem_matches_direct_solve(make, pc):
     import scipy.sparse.linalg as spla
