@@ -215,7 +215,12 @@ def _block_ranges(nrows: int, rowptr: np.ndarray, max_rows: int, max_nnz: int, b
     rp = None if rowptr is None else p(rowptr)
     nb = L.mpcx_block_ranges(nrows, rp, max_rows, max_nnz, bs, hp, hn, None, 0)
     if nb < 0:
-        raise RuntimeError("mpcx_block_ranges failed: " + L.mpcx_last_error().decode())
+        msg = L.mpcx_last_error().decode()
+        if "exceeds the block capacity" in msg:
+            # one row longer than a block's LDS (a master with thousands of slaves): 'auto' falls back to the
+            # thread-per-entity kernels with device atomics
+            raise _native.PlanNotRepresentable("row-block algorithm: " + msg)
+        raise RuntimeError("mpcx_block_ranges failed: " + msg)
     row0 = np.empty(nb + 1, dtype=np.int32)
     if L.mpcx_block_ranges(nrows, rp, max_rows, max_nnz, bs, hp, hn, p(row0), row0.size) != nb:
         raise RuntimeError("mpcx_block_ranges failed: " + L.mpcx_last_error().decode())
@@ -382,7 +387,10 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False, pai
                                            integ.num_entities, integ.estride, p(ents), p(dm), dm.shape[1], V0.dofmap.bs,
                                            None if hints is None else p(hints), 0 if hints is None else hints.size, 1)
             if not h:
-                raise RuntimeError("mpcx_rowblock_plan_build failed: " + L.mpcx_last_error().decode())
+                msg = L.mpcx_last_error().decode()
+                if "exceeds the block capacity" in msg:
+                    raise _native.PlanNotRepresentable("row-block algorithm: " + msg)
+                raise RuntimeError("mpcx_rowblock_plan_build failed: " + msg)
             try:
                 nb = L.mpcx_rowblock_plan_num_blocks(h)
                 row0 = np.empty(nb + 1, dtype=np.int32)
@@ -993,7 +1001,8 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
                 a.slot_mask = smask.data_ptr()
                 keep += [smask]
                 if (allow_block_scalar and os.environ.get("MPCX_BLOCK_SCALAR", "1") != "0"
-                        and (a.n_slave_entities == 0 or mplan is not None)):
+                        and (a.n_slave_entities == 0 or (mplan is not None and mplan[5]))):
+                    # (a plan without a target inside the pattern has no overlay to add into: scalar CSR values then)
                     # block-scalar storage: 8 B per bs x bs block instead of 8 bs^2; couplings and diagonals in an overlay
                     import torch
 

@@ -512,20 +512,39 @@ def _facet_kernel(V: FunctionSpace, form: int, qdeg: int, fn_id: int = 0) -> Ker
     return KernelSpec(form, _CELL_ID[name], V.degree, V.dofmap.bs, fn_id, 0, fqpts=q, fqwts=w)
 
 
-_FN_EXPR = {FN_ONE: "1.0", FN_LINEAR: "1.0 + x[0] + 2.0 * x[1] + 3.0 * x[2]"}
+def fn_c_expression(fn_id: int) -> str:
+    """C text of the analytic right-hand side ``fn_id`` in x[0..2], the component k and the constants c -- the same
+    functions as the built-in ``eval_fn`` (csrc/mpcx_elements.hpp), every cell type, one table (the generated
+    hexahedron kernels and the imported-kernel twins of the tests both read it)"""
+    from .codegen import BENCH_PERIODIC_F
+
+    pi = "3.14159265358979323846"
+    table = {
+        FN_ONE: "1.0",
+        FN_BENCH_PERIODIC: BENCH_PERIODIC_F,
+        FN_SIN2D: f"sin(2.0 * {pi} * x[0]) * sin({pi} * x[1]) + 0.3 * (k + 1)",
+        FN_POLY3: "1.0 + 2.0 * x[0] + 3.0 * x[1] * x[1] - x[2] * x[2] * x[2] + x[0] * x[1] * x[2] + 0.5 * k * x[0]",
+        FN_LINEAR: "(k + 1) * (1.0 + x[0] - 2.0 * x[1] + 0.5 * x[2])",
+        FN_CONSTANT_VEC: "c[1 + k]",
+    }
+    if fn_id not in table:
+        raise NotImplementedError(f"analytic source function {fn_id}")
+    return table[fn_id]
 
 
 def _hex_form(V, kind: str, constant=None, coefficient: Optional[Function] = None, cells=None, fn_id: int = FN_ONE,
               quadrature_degree: Optional[int] = None) -> Form:
     """Forms on hexahedra: the element kernel is generated as UFCx C text (codegen.generate_hex: Q1, trilinear
     geometry, tensor Gauss rule) and imported like an FFCx kernel -- there is no built-in hexahedron kernel."""
-    from .codegen import BENCH_PERIODIC_F, gauss_hex, generate_hex
+    from .codegen import gauss_hex, generate_hex
 
     if coefficient is not None:
         Vc = coefficient.function_space
         assert Vc.mesh is V.mesh and Vc.degree == 1 and Vc.dofmap.bs == 1, "hexahedra: scalar Q1 coefficients"
     if kind == "source":
-        fexpr = BENCH_PERIODIC_F if fn_id == FN_BENCH_PERIODIC else _FN_EXPR[fn_id]
+        if fn_id == FN_CONSTANT_VEC:
+            raise NotImplementedError("hexahedra: FN_CONSTANT_VEC sources (the generated kernel takes c[0] as the scale only)")
+        fexpr = fn_c_expression(fn_id)
         qdeg = (1 + _FN_DEGREE[fn_id]) if quadrature_degree is None else quadrature_degree
     else:
         fexpr, qdeg = "1.0", (2 if quadrature_degree is None else quadrature_degree)

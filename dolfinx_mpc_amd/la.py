@@ -164,13 +164,20 @@ class Vector:
     def attach_exchange(self, exchange):
         self._exchange = exchange
 
-    def ghostUpdate(self, addv=InsertMode.ADD, mode=ScatterMode.REVERSE):
+    def ghostUpdate(self, addv=None, mode=None):
         """``b.ghostUpdate(addv=ADD, mode=REVERSE)`` (bench_periodic.py:108): the partial sums of the ghost
-        (interface-plane) rows are sent to their owner and added there; ``(INSERT, FORWARD)``: the owners'
-        values are copied back to the ghosts.  Single process / unpartitioned mesh: nothing to exchange."""
+        (interface-plane) rows are sent to their owner and added there; ``(INSERT, FORWARD)`` -- petsc4py's
+        default when called without arguments: the owners' values are copied to the ghosts.  The other two
+        combinations are not what the path uses and raise.  Single process / unpartitioned mesh: nothing to
+        exchange."""
+        addv = InsertMode.INSERT if addv is None else addv
+        mode = ScatterMode.FORWARD if mode is None else mode
+        add = int(addv) == int(InsertMode.ADD)
+        reverse = int(mode) == int(ScatterMode.REVERSE)
+        if add != reverse:
+            raise NotImplementedError("ghostUpdate: (ADD, REVERSE) and (INSERT, FORWARD) are supported")
         if self._exchange is None:
             return None
-        reverse = int(mode) == int(ScatterMode.REVERSE) if mode is not None else True
         arr = self.array  # completes anything posted earlier
         if reverse:
             self._pending = _Pending(self._exchange, self._exchange.reduce_vector_begin(arr))

@@ -524,3 +524,47 @@ def test_geometry_is_read_only_and_moves_through_the_setter():
     assert np.allclose(V2.tabulate_dof_coordinates(), before * np.array([2.0, 1.0, 0.5]))
     with pytest.raises(ValueError):
         mesh.geometry.x = np.zeros((3, 3))
+
+
+def test_block_ranges_fat_row_is_plan_not_representable():
+    """a CSR row longer than a row block's capacity (a master with thousands of slaves) must surface as
+    PlanNotRepresentable so that algorithm='auto' falls back to the thread-per-entity kernels, not as a bare RuntimeError"""
+    import importlib
+
+    am = importlib.import_module("dolfinx_mpc_amd.assemble_matrix")
+    lens = np.full(64, 15, dtype=np.int64)
+    lens[17] = am.ROWBLOCK_MAX_NNZ + 5
+    rowptr = np.zeros(65, dtype=np.int64)
+    np.cumsum(lens, out=rowptr[1:])
+    with pytest.raises(_native.PlanNotRepresentable):
+        am._block_ranges(64, rowptr, am.ROWBLOCK_MAX_ROWS, am.ROWBLOCK_MAX_NNZ, 1, None)
+    lens[17] = 15
+    np.cumsum(lens, out=rowptr[1:])
+    row0 = am._block_ranges(64, rowptr, am.ROWBLOCK_MAX_ROWS, am.ROWBLOCK_MAX_NNZ, 1, None)
+    assert row0[0] == 0 and row0[-1] == 64
+
+
+def test_ghost_update_defaults_follow_petsc():
+    """b.ghostUpdate() without arguments is (INSERT, FORWARD) as in petsc4py; the mixed combinations raise"""
+    from dolfinx_mpc_amd import la
+
+    class Ex:
+        calls = []
+
+        def forward_vector(self, arr):
+            self.calls.append("forward")
+
+        def reduce_vector_begin(self, arr):
+            self.calls.append("reverse")
+            return None
+
+    b = la.Vector.__new__(la.Vector)
+    b._exchange, b._pending, b._ready = Ex(), None, None
+    b._array = np.zeros(3)
+    with pytest.raises(NotImplementedError):
+        b.ghostUpdate(addv=la.InsertMode.ADD, mode=la.ScatterMode.FORWARD)
+    with pytest.raises(NotImplementedError):
+        b.ghostUpdate(addv=la.InsertMode.INSERT, mode=la.ScatterMode.REVERSE)
+    b.ghostUpdate()
+    b.ghostUpdate(addv=la.InsertMode.ADD, mode=la.ScatterMode.REVERSE)
+    assert Ex.calls == ["forward", "reverse"]

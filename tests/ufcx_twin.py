@@ -11,17 +11,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from dolfinx_mpc_amd import fem  # noqa: E402
-from dolfinx_mpc_amd.codegen import BENCH_PERIODIC_F, generate  # noqa: E402
+from dolfinx_mpc_amd.codegen import generate  # noqa: E402
 
-PI = "3.14159265358979323846"
-FN_C = {
-    fem.FN_ONE: "1.0",
-    fem.FN_BENCH_PERIODIC: BENCH_PERIODIC_F,
-    fem.FN_SIN2D: f"sin(2.0 * {PI} * x[0]) * sin({PI} * x[1]) + 0.3 * (k + 1)",
-    fem.FN_POLY3: "1.0 + 2.0 * x[0] + 3.0 * x[1] * x[1] - x[2] * x[2] * x[2] + x[0] * x[1] * x[2] + 0.5 * k * x[0]",
-    fem.FN_LINEAR: "(k + 1) * (1.0 + x[0] - 2.0 * x[1] + 0.5 * x[2])",
-    fem.FN_CONSTANT_VEC: "c[1 + k]",
-}
+FN_C = {i: fem.fn_c_expression(i) for i in range(6)}  # one table for every generated kernel (fem.py)
 _KIND = {fem.FORM_STIFFNESS: "stiffness", fem.FORM_MASS: "mass", fem.FORM_SOURCE: "source", fem.FORM_ELASTICITY: "elasticity"}
 
 
