@@ -125,6 +125,8 @@ class MatrixArgs(C.Structure):
         ("mpc_plan_out", C.c_void_p),
         ("slave_tensors", C.c_void_p),
         ("mpc_plan_slot", C.c_void_p),
+        ("pair_recs", C.c_void_p),
+        ("pair_ctx", C.c_void_p),
         ("stream", C.c_void_p),
     ]
 
@@ -230,6 +232,10 @@ EXPORTS = [
     "mpcx_cluster_build",
     "mpcx_cluster_canonical",
     "mpcx_rowblock_pairs_device",
+    "mpcx_pair_words",
+    "mpcx_pair_records",
+    "mpcx_pair_context_size",
+    "mpcx_pair_context",
     "mpcx_diag_slot_mask",
     "mpcx_add_diagonal",
     "mpcx_assemble_vector",
@@ -430,6 +436,14 @@ def lib() -> C.CDLL:
     L.mpcx_cluster_build.restype = C.c_int
     L.mpcx_rowblock_pairs_device.argtypes = [i64, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]
     L.mpcx_rowblock_pairs_device.restype = C.c_int
+    L.mpcx_pair_words.argtypes = [i32]
+    L.mpcx_pair_words.restype = i32
+    L.mpcx_pair_records.argtypes = [i64, vp, i32, vp, vp, vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]
+    L.mpcx_pair_records.restype = C.c_int
+    L.mpcx_pair_context_size.argtypes = [C.POINTER(KernelT)]
+    L.mpcx_pair_context_size.restype = i32
+    L.mpcx_pair_context.argtypes = [C.POINTER(KernelT), i64, i32, vp, vp, vp, i32, vp, vp]
+    L.mpcx_pair_context.restype = C.c_int
     L.mpcx_diag_slot_mask.argtypes = [i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
     L.mpcx_diag_slot_mask.restype = C.c_int
     L.mpcx_rowblock_plan_build.argtypes = [i32, vp, i32, i32, i64, i32, vp, vp, i32, i32, vp, i32, i32]

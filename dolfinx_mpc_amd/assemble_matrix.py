@@ -450,6 +450,86 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False, pai
     return D.cached(A._plans, "rowblock", (form,), (i, max_nnz_cap, max_rows_cap, lean, group_rows, pairs, nodeblock), build)
 
 
+# row blocks of the pair-record kernel (csrc/mpcx_pairs.hip): LDS bytes = 8 * nnz (+ 4 * rows for blocked spaces)
+PAIRS_MAX_NNZ = int(os.environ.get("MPCX_PAIRS_MAX_NNZ", 4608))
+PAIRS_MAX_ROWS = int(os.environ.get("MPCX_PAIRS_MAX_ROWS", 512))
+
+
+def _pairs_plan(A: MPCMatrix, form: Form, i: int, V0, V1, bc0, bc1, mpc0, mpc1):
+    """Plan of ``matrix_pairs_kernel`` (include/mpcx.h: plan.row_pairs == 2, pair_recs): row blocks, the (entity, local
+    row) pairs of every block ordered by local row, ONE record per pair.  Cached per (form, constraints, Dirichlet
+    markers): the records carry the row / column masks.  Returns (plan struct, keep-alive, info)."""
+    import torch
+
+    def build():
+        L = _native.lib()
+        integ = form.integrals[i]
+        dev = A.device
+        bs0 = V0.dofmap.bs
+        hints = None
+        if V0.dof_tile_offsets is not None:
+            hints = np.ascontiguousarray(V0.dof_tile_offsets.astype(np.int32) * bs0)
+        row0 = _block_ranges(A.shape[0], A.rowptr, PAIRS_MAX_ROWS, PAIRS_MAX_NNZ, bs0, hints)
+        nb = row0.size - 1
+        idv = D.integral_device(form, i)
+        s0, s1 = D.space_device(V0), D.space_device(V1)
+        d_row0, d_off, d_ids = _block_pairs_device(row0, integ.num_entities, integ.estride, idv["entities"], s0["dofmap"],
+                                                   V0.element_ndofs, bs0, dev)
+        npairs = integ.num_entities * V0.element_ndofs
+        W = L.mpcx_pair_words(V1.element_ndofs)
+        recs = torch.empty(max(npairs, 1) * W, dtype=torch.int32, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        _, k0 = mpc0._device()
+        _, k1 = mpc1._device()
+        rc = L.mpcx_pair_records(npairs, d_ids.data_ptr(), integ.estride, idv["entities_ptr"], idv["entities_ptr"],
+                                 s0["dofmap"].data_ptr(), V0.element_ndofs, bs0, s1["dofmap"].data_ptr(), V1.element_ndofs,
+                                 V1.dofmap.bs, D.ptr(bc0), k0["is_slave"].data_ptr(), D.ptr(bc1), k1["is_slave"].data_ptr(),
+                                 A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), nb, d_row0.data_ptr(), recs.data_ptr(),
+                                 flag.data_ptr(), D.stream_ptr())
+        _native.check(rc, "mpcx_pair_records")
+        bad = int(flag.item())
+        if bad:
+            raise _native.PlanNotRepresentable(
+                "pair records: " + ", ".join(m for b, m in ((1, "a scatter offset beyond 8 bits or a column missing from the pattern"),
+                                                            (2, "a row slot beyond its field"),
+                                                            (4, "more than 2^27 entities (shard the mesh)")) if bad & b))
+        del d_ids
+        max_rows = int(np.diff(row0).max())
+        max_nnz = int(np.diff(A.rowptr[row0]).max())
+        plan = _native.RowBlockPlanT(nb, max_rows, max_nnz, 2, d_row0.data_ptr(), d_off.data_ptr(), None, None, None)
+        keep = (d_row0, d_off, recs)
+        return (plan, keep, {"num_blocks": nb, "num_ents": npairs, "max_rows": max_rows, "max_nnz": max_nnz,
+                             "bytes": int(recs.numel() * 4 + d_off.numel() * 8 + d_row0.numel() * 4)})
+
+    return D.cached(A._plans, "pairs", (form, mpc0, mpc1, bc0, bc1), (i, PAIRS_MAX_ROWS, PAIRS_MAX_NNZ), build)
+
+
+def _pair_context(form: Form, i: int):
+    """per-entity constant-free context of the pair-record kernel (mpcx_pair_context), cached per geometry version;
+    None with MPCX_PAIRS_CONTEXT=recompute (the kernel then computes it per pair from the coordinates)"""
+    import torch
+
+    if os.environ.get("MPCX_PAIRS_CONTEXT", "cached") == "recompute":
+        return None
+
+    def build():
+        L = _native.lib()
+        integ = form.integrals[i]
+        idv = D.integral_device(form, i)
+        md = D.mesh_device(form.mesh)
+        cn = L.mpcx_pair_context_size(C.byref(idv["kernel"]))
+        if cn <= 0:
+            raise _native.PlanNotRepresentable("pair records: the operator has no compact context")
+        ctx = torch.empty(max(integ.num_entities, 1) * cn, dtype=torch.float64, device=md["x"].device)
+        rc = L.mpcx_pair_context(C.byref(idv["kernel"]), integ.num_entities, integ.estride, idv["entities_ptr"],
+                                 md["x"].data_ptr(), md["x_dofmap"].data_ptr(), form.mesh.geometry.dofmap.shape[1],
+                                 ctx.data_ptr(), D.stream_ptr())
+        _native.check(rc, "mpcx_pair_context")
+        return ctx
+
+    return D.cached(form._device, "pair_ctx", (form.mesh,), (i, form.mesh.geometry.version), build, maxsize=4)
+
+
 def _rowpair_eligible(form: Form, i: int, V0, V1) -> bool:
     """Row-pair kernel (include/mpcx.h, mpcx_rowblock_plan_t::row_pairs): operators with a compact per-entity context
     (csrc/mpcx_elements.hpp, ElementOp::LAZY / lazy_applies): cell integrals of stiffness without coefficient,
@@ -992,6 +1072,20 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
                     u.second = v
                 keep += [ck]
                 return a, keep
+            if name == "pairs":
+                # pair records + cached contexts (csrc/mpcx_pairs.hip): nothing else is read per entity
+                try:
+                    plan, pk, _info = _pairs_plan(A, form, i, V0, V1, bc0, bc1, mpc0, mpc1)
+                    pctx = _pair_context(form, i)
+                except _native.PlanNotRepresentable:
+                    continue
+                md1 = _masked_dofmap(form, V1, bc1, mpc1, 1)  # column masks of the few entities that have any
+                a.plan = plan
+                a.pair_recs, a.pair_ctx = pk[2].data_ptr(), D.ptr(pctx)
+                a.mdofmap1 = md1.data_ptr()
+                a.kernel_name = name
+                keep += [pk, pctx, md1]
+                break
             if name == "rowpair":
                 pairs = True  # (reads the plain, unrotated masked dofmaps)
             elif name == "nodeblock":

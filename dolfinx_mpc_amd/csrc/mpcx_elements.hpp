@@ -440,6 +440,109 @@ struct ElementOp
       L.smu = L.sla = 0.0;
     }
   }
+  // Constant-free, compact form of the context: what matrix_pairs_kernel keeps per entity in HBM (cached per geometry
+  // version) instead of recomputing the context for every (entity, local row) pair.  Row 0 of the gradients / of G is
+  // minus the sum of the other rows (the barycentric coordinates sum to one), so only rows 1..TDIM travel:
+  //   P2 stiffness:          G_kl / c0 for 1 <= k <= l <= TDIM                      (6 doubles in 3D)
+  //   elasticity, div blocks: the inverse Jacobian (= gradients of l_1..l_TDIM) + |T|  (10 doubles)
+  //   P1 stiffness:          cofactor rows 1..TDIM + 1 / (d! |det|)                 (10 doubles)
+  static constexpr int CTXN = LAZY_P2_STIFFNESS ? TDIM * (TDIM + 1) / 2 : TDIM * TDIM + 1;
+  __device__ static inline void ctx_store(double (&out)[CTXN], const double (&cd)[NV * 3])
+  {
+    if constexpr (LAZY_ELASTICITY || LAZY_DIV)
+    {
+      double K[TDIM][TDIM], detJ;
+      affine_geometry<TDIM>(cd, K, detJ);
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d)
+#pragma unroll
+        for (int a = 0; a < TDIM; ++a)
+          out[d * TDIM + a] = K[d][a];
+      out[TDIM * TDIM] = fabs(detJ) * (TDIM == 3 ? 1.0 / 6.0 : 0.5);
+    }
+    else
+    {
+      double C[NV][TDIM], det;
+      cofactor_gradients<TDIM>(cd, C, det);
+      const double s = 1.0 / ((TDIM == 3 ? 6.0 : 2.0) * fabs(det));
+      if constexpr (LAZY_P1_STIFFNESS)
+      {
+#pragma unroll
+        for (int k = 0; k < TDIM; ++k)
+#pragma unroll
+          for (int d = 0; d < TDIM; ++d)
+            out[k * TDIM + d] = C[k + 1][d];
+        out[TDIM * TDIM] = s;
+      }
+      else
+      {
+        int n = 0;
+#pragma unroll
+        for (int k = 1; k < NV; ++k)
+#pragma unroll
+          for (int l = k; l < NV; ++l)
+          {
+            double dot = 0.0;
+#pragma unroll
+            for (int d = 0; d < TDIM; ++d)
+              dot += C[k][d] * C[l][d];
+            out[n++] = s * dot;
+          }
+      }
+    }
+  }
+  __device__ static inline void ctx_load(Lazy& L, const double* c, const double (&in)[CTXN])
+  {
+    if constexpr (LAZY_P2_STIFFNESS)
+    {
+      const double c0 = c ? c[0] : 1.0;
+      int n = 0;
+#pragma unroll
+      for (int k = 1; k < NV; ++k)
+#pragma unroll
+        for (int l = k; l < NV; ++l)
+          L.g[k][l] = L.g[l][k] = c0 * in[n++];
+      double s00 = 0.0;
+#pragma unroll
+      for (int l = 1; l < NV; ++l)
+      {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 1; k < NV; ++k)
+          s += L.g[k][l];
+        L.g[0][l] = L.g[l][0] = -s;
+        s00 += s;
+      }
+      L.g[0][0] = s00;
+      L.smu = L.sla = 0.0;
+    }
+    else
+    {
+#pragma unroll
+      for (int a = 0; a < TDIM; ++a)
+      {
+        double s = 0.0;
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d)
+        {
+          L.g[d + 1][a] = in[d * TDIM + a];
+          s += in[d * TDIM + a];
+        }
+        L.g[0][a] = -s;
+      }
+      const double w = in[TDIM * TDIM];
+      if constexpr (LAZY_ELASTICITY)
+      {
+        L.smu = w * c[0];
+        L.sla = w * c[1];
+      }
+      else
+      {
+        L.smu = w * (c ? c[0] : 1.0);
+        L.sla = 0.0;
+      }
+    }
+  }
   __device__ static inline double entry(const Lazy& L, int i, int a, int j, int b)
   {
     if constexpr (LAZY_ELASTICITY && DEG0_ == 2)

@@ -10,6 +10,8 @@ namespace mpcx
 // cluster ("Kuhn fan") kernels, mpcx_cubes.hip
 int launch_matrix_cubes(const mpcx_matrix_args_t& a);
 int launch_vector_cubes(const mpcx_vector_args_t& a);
+// pair records + cached entity contexts (plan.row_pairs == 2), mpcx_pairs.hip
+int launch_matrix_pairs(const mpcx_matrix_args_t& a);
 // imported UFCx kernels, mpcx_ufcx.cpp
 int launch_matrix_ufcx(const mpcx_matrix_args_t& a);
 int launch_vector_ufcx(const mpcx_vector_args_t& a);

@@ -1709,7 +1709,13 @@ int launch_matrix(const mpcx_matrix_args_t& a)
   }
   else if (a.n_entities > 0)
   {
-    if (alg == MPCX_ALG_ROWBLOCK)
+    if (alg == MPCX_ALG_ROWBLOCK && a.plan.row_pairs == 2)
+    {
+      // pair records + cached contexts (mpcx_pairs.hip)
+      if (int rc = launch_matrix_pairs(a))
+        return rc;
+    }
+    else if (alg == MPCX_ALG_ROWBLOCK)
     {
       if (a.plan.num_blocks <= 0)
       {

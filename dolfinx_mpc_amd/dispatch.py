@@ -105,6 +105,13 @@ MATRIX: List[Kernel] = [
     Kernel("ufcx_rowblock", lambda c: c.form == FORM_UFCX, lambda c: True,
            "imported tabulate_tensor inside the LDS row-block kernel (hipRTC); config 2 with tests/ufcx/laplace_p1_tet.c: 2.32 ms "
            "vs 1.75 ms built-in, vs ~50 ms thread-per-entity atomics"),
+    Kernel("pairs",
+           lambda c: (c.form != FORM_UFCX and _compact_context(c) and not (c.form == FORM_STIFFNESS and c.bs0 > 1)
+                      and c.nd0 <= 16 and c.nd1 * c.bs1 <= 32 and c.bs0 <= 3),
+           lambda c: c.d0 == 2 or c.d1 == 2,
+           "matrix_pairs_kernel: thread per (entity, local row) pair, one coalesced record per pair (entity, LDS slot of the row, "
+           "scatter offsets) and the entity's context cached in HBM per geometry version -- no masked lanes, no per-pair "
+           "geometry; round 4: P2 stiffness 246^3 and the Taylor-Hood coupling blocks, see DESIGN section 4"),
     Kernel("rowpair",
            lambda c: c.form != FORM_UFCX and _compact_context(c) and not (_lean_ok(c) and c.bs0 == 1 and c.nd0 <= 4),
            lambda c: c.d0 == 1 and c.d1 == 1 and c.bs0 > 1,
@@ -163,7 +170,7 @@ VECTOR: List[Kernel] = [
 FUNCTION = {
     ("matrix", "p2_cube"): "matrix_p2_cube_kernel", ("matrix", "hex_cube"): "matrix_hex_kernel", ("vector", "hex_own"): "vector_hex_own_kernel",
     ("matrix", "cube"): "matrix_cube_kernel", ("matrix", "cube_el"): "matrix_cube_elasticity_rowpair_kernel", ("matrix", "ufcx_rowblock"): "ufcx_matrix_rowblock_kernel",
-    ("matrix", "rowpair"): "matrix_rowpair_kernel", ("matrix", "nodeblock"): "matrix_nodeblock_kernel",
+    ("matrix", "pairs"): "matrix_pairs_kernel", ("matrix", "rowpair"): "matrix_rowpair_kernel", ("matrix", "nodeblock"): "matrix_nodeblock_kernel",
     ("matrix", "rowblock_lean"): "matrix_rowblock_kernel", ("matrix", "rowblock"): "matrix_rowblock_kernel",
     ("matrix", "atomic"): "matrix_atomic_kernel", ("matrix", "ufcx_atomic"): "ufcx_matrix_kernel",
     ("vector", "cube_own"): "vector_cube_own_kernel", ("vector", "cube_hash"): "vector_cube_kernel",

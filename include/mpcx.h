@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 /* 4: mpcx_matrix_args_t::cube_flags (in the padding after cube_rec_bytes), hexahedron and closed-form cluster entry points */
-#define MPCX_VERSION 4
+#define MPCX_VERSION 5
 
 /* Offsets into the CSR value / column arrays (rowptr entries, positions): 64-bit, so that one GPU can
  * hold matrices with more than 2^31 - 1 stored entries (Taylor-Hood a00 on 128^3 cells: 4.4 G) -- PETSc's
@@ -140,7 +140,10 @@ typedef struct
   int32_t max_nnz;              /* max nnz per block  */
   /* 0: block_ents lists the entities touching the block (thread per entity, rows outside the block masked).
    * 1: block_ents lists (entity, local row dof) pairs as entity * nd0 + i, only those whose rows lie in the
-   *    block (thread per pair; operators with a compact context only: matrix_rowpair_kernel) */
+   *    block (thread per pair; operators with a compact context only: matrix_rowpair_kernel)
+   * 2: pair RECORDS (mpcx_matrix_args_t::pair_recs, built by mpcx_pair_records from the pair list of mode 1): the
+   *    kernel reads one self-contained record per pair and nothing else per entity but its cached context
+   *    (matrix_pairs_kernel); block_ents / ent_offs are not read */
   int32_t row_pairs;
   const int32_t* block_row0;    /* DEVICE [num_blocks + 1] first row of block */
   const int64_t* block_ent_off; /* DEVICE [num_blocks + 1] into block_ents */
@@ -263,6 +266,20 @@ typedef struct
    * (DEVICE [tuples]).  NULL: every tuple re-tabulates its entity (a black-box kernel has no cheaper way to one entry). */
   double* slave_tensors;
   const int32_t* mpc_plan_slot;
+  /* plan.row_pairs == 2 (matrix_pairs_kernel; cell integrals of operators with a compact per-entity context: stiffness
+   * without coefficient on P1 / P2 scalar spaces, elasticity, the Taylor-Hood coupling blocks): pair_recs DEVICE
+   * [n_pairs][W] uint32, W = mpcx_pair_words(nd1), pair t of plan.block_ent_off, ordered inside a block by local row:
+   *   word 0       bits 0-26 entity index, bits 27-30 local row dof i, bit 31 = a column dof of the entity is masked
+   *                (Dirichlet / slave: the kernel then reads the masks from mdofmap1, which may be NULL otherwise)
+   *   bytes 4-5    uint16 row slot: bs0 == 1: index of the row's first value inside the block (rowptr[r] - rowptr[r0]),
+   *                0xFFFF = masked row, nothing to do; bs0 > 1: bits 0-12 the row's node inside the block
+   *                ((r - r0) / bs0), bit 13 + k = row of component k is masked
+   *   bytes 6..    uint8 [nd1]: position of column block dofs1[j] inside CSR row dofs0[i] * bs0, counted in blocks
+   * pair_ctx: DEVICE [n_entities][mpcx_pair_context_size] doubles, the constant-free context of every entity
+   * (mpcx_pair_context; geometry only: rebuild when the mesh moves), or NULL = the kernel computes the context of every
+   * pair from the coordinates (x, x_dofmap, entities). */
+  const uint32_t* pair_recs;
+  const double* pair_ctx;
   void* stream;
 } mpcx_matrix_args_t;
 
@@ -404,6 +421,25 @@ int mpcx_rowblock_pairs_device(int64_t n_entities, int32_t estride, const int32_
                                int32_t nd0, int32_t bs0, int32_t num_blocks, const int32_t* block_row0, int32_t* counts,
                                const int64_t* offsets, int32_t* pair_block, int32_t* pair_ent, int32_t* pair_rows,
                                int32_t rotate, void* stream);
+
+/* Set-up of matrix_pairs_kernel (plan.row_pairs == 2; all pointers DEVICE).  mpcx_pair_words: 32-bit words per record.
+ * mpcx_pair_records: one record (layout: mpcx_matrix_args_t::pair_recs) per pair id = entity * nd0 + i of pair_ids
+ * [n_pairs] -- the list mode 1 of the row-block plan uses, ordered by (block, local row, ...) -- from the dofmaps, the
+ * Dirichlet / slave markers (may be NULL) and the CSR pattern; this is the per-row column search behind the reference's
+ * MatSetValuesLocal (cpp/assemble_matrix.cpp:546) hoisted to set-up.  *overflow (zeroed by the caller) is set when a
+ * record cannot be written: an offset beyond 8 bits or a column missing from the pattern (1), a row slot beyond 16 / 13
+ * bits (2), an entity index beyond 27 bits or nd0 > 16 (4).
+ * mpcx_pair_context_size: doubles per entity of the cached context for this kernel descriptor (0: no such operator);
+ * mpcx_pair_context: ctx [n_entities][size] from the coordinates (entities == NULL: entity e is cell e). */
+int32_t mpcx_pair_words(int32_t nd1);
+int mpcx_pair_records(int64_t n_pairs, const uint32_t* pair_ids, int32_t estride, const int32_t* entities0,
+                      const int32_t* entities1, const int32_t* dofmap0, int32_t nd0, int32_t bs0, const int32_t* dofmap1,
+                      int32_t nd1, int32_t bs1, const int8_t* bc0, const int8_t* slave0, const int8_t* bc1,
+                      const int8_t* slave1, const mpcx_nnz_t* rowptr, const int32_t* cols, int32_t num_blocks,
+                      const int32_t* block_row0, uint32_t* recs, int32_t* overflow, void* stream);
+int32_t mpcx_pair_context_size(const mpcx_kernel_t* kernel);
+int mpcx_pair_context(const mpcx_kernel_t* kernel, int64_t n_entities, int32_t estride, const int32_t* entities,
+                      const double* x, const int32_t* x_dofmap, int32_t nv, double* ctx, void* stream);
 
 /* vals[pos(d,d)] += diagval for d in dofs.  Replaces the slave-diagonal loop
  * of cpp/assemble_matrix.cpp:711-724 and dolfinx insert_diagonal called at

@@ -1,0 +1,35 @@
+#!/bin/bash
+# matrix_pairs_kernel (round 4): block size / threads / context mode at config 5 (P2 Poisson 246^3), config 3, config 4
+OUT=gpurun_out/pairs_sweep; mkdir -p $OUT
+run() { cfg=$1; name=$2; shift 2
+  env "$@" timeout 900 python bench.py --config $cfg --steps 5 --warmup 2 --no-cpu-baseline --no-traffic > $OUT/c${cfg}_$name.json 2> $OUT/c${cfg}_$name.log
+  python tools/show_bench.py $OUT/c${cfg}_$name.json | grep -vE "roofline|timings|generic|one_shot" | tr '\n' ' '; echo " [c$cfg $name]"; }
+for cfg in "$@"; do
+case $cfg in
+5)
+run 5 base MPCX_FORCE_KERNEL=matrix=rowblock
+run 5 p4608 MPCX_FORCE_KERNEL=matrix=pairs
+run 5 p4608_rc MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_CONTEXT=recompute
+run 5 p9216 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=9216
+run 5 p9216_t1024 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=9216 MPCX_PAIRS_THREADS=1024
+run 5 p2304 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=2304
+run 5 p2304_t256 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=2304 MPCX_PAIRS_THREADS=256
+run 5 p4608_t512 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_THREADS=512
+run 5 p4608_t128 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_THREADS=128
+run 5 p6144 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=6144 MPCX_PAIRS_THREADS=384
+;;
+3)
+run 3 base MPCX_FORCE_KERNEL=matrix=rowblock
+run 3 p4608 MPCX_FORCE_KERNEL=matrix=pairs
+run 3 p9216 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=9216
+run 3 p2304 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=2304
+;;
+4)
+run 4 base
+run 4 rowpair MPCX_FORCE_KERNEL=matrix=rowpair
+run 4 p4608 MPCX_FORCE_KERNEL=matrix=pairs
+run 4 p9216 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=9216
+run 4 p2304 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=2304
+;;
+esac
+done
