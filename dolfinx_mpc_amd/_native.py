@@ -127,6 +127,7 @@ class MatrixArgs(C.Structure):
         ("mpc_plan_slot", C.c_void_p),
         ("pair_recs", C.c_void_p),
         ("pair_ctx", C.c_void_p),
+        ("pair_dict", C.c_void_p),
         ("stream", C.c_void_p),
     ]
 
@@ -234,6 +235,9 @@ EXPORTS = [
     "mpcx_rowblock_pairs_device",
     "mpcx_pair_words",
     "mpcx_pair_records",
+    "mpcx_pair_dict_stride",
+    "mpcx_pair_compress_workspace",
+    "mpcx_pair_compress",
     "mpcx_pair_context_size",
     "mpcx_pair_context",
     "mpcx_diag_slot_mask",
@@ -440,6 +444,12 @@ def lib() -> C.CDLL:
     L.mpcx_pair_words.restype = i32
     L.mpcx_pair_records.argtypes = [i64, vp, i32, vp, vp, vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]
     L.mpcx_pair_records.restype = C.c_int
+    L.mpcx_pair_dict_stride.argtypes = [i32]
+    L.mpcx_pair_dict_stride.restype = i32
+    L.mpcx_pair_compress_workspace.argtypes = [i32]
+    L.mpcx_pair_compress_workspace.restype = i64
+    L.mpcx_pair_compress.argtypes = [i64, vp, i32, vp, vp, C.POINTER(C.c_int32), vp, vp]
+    L.mpcx_pair_compress.restype = C.c_int
     L.mpcx_pair_context_size.argtypes = [C.POINTER(KernelT)]
     L.mpcx_pair_context_size.restype = i32
     L.mpcx_pair_context.argtypes = [C.POINTER(KernelT), i64, i32, vp, vp, vp, i32, vp, vp]

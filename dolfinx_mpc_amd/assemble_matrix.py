@@ -451,8 +451,19 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False, pai
 
 
 # row blocks of the pair-record kernel (csrc/mpcx_pairs.hip): LDS bytes = 8 * nnz (+ 4 * rows for blocked spaces)
-PAIRS_MAX_NNZ = int(os.environ.get("MPCX_PAIRS_MAX_NNZ", 4608))
-PAIRS_MAX_ROWS = int(os.environ.get("MPCX_PAIRS_MAX_ROWS", 512))
+# Measured (MI355X): scalar P2 stiffness 246^3: 2304 entries per block 10.0 ms, 4608 (37 KB, four workgroups of 512 threads per
+# CU) 9.5, 9216 10.2; Taylor-Hood a01 / a10 128^3: 4608 1.94 / 1.58 ms, 2304 1.89 / 1.38; contact elasticity: 4608 1.14,
+# 2304 0.94 -- the short pair lists of a block are a chain of dependent phases (zero, records, contexts, write-out), so
+# the CU wants many small resident blocks, but a block whose (local row) segments are shorter than a wave loses lanes
+def _pairs_caps(V0, V1):
+    """(max rows, max entries) of a row block; MPCX_PAIRS_MAX_NNZ / MPCX_PAIRS_MAX_ROWS override"""
+    rows = int(os.environ.get("MPCX_PAIRS_MAX_ROWS", 512))
+    nnz = int(os.environ.get("MPCX_PAIRS_MAX_NNZ", 0))
+    if nnz > 0:
+        return rows, nnz
+    PAIRS_MAX_ROWS = rows
+    scalar_p2 = V0.dofmap.bs == 1 and V1.dofmap.bs == 1 and V0.element_ndofs >= 6 and V1.element_ndofs >= 6
+    return PAIRS_MAX_ROWS, (4608 if scalar_p2 else 2304)
 
 
 def _pairs_plan(A: MPCMatrix, form: Form, i: int, V0, V1, bc0, bc1, mpc0, mpc1):
@@ -460,6 +471,8 @@ def _pairs_plan(A: MPCMatrix, form: Form, i: int, V0, V1, bc0, bc1, mpc0, mpc1):
     row) pairs of every block ordered by local row, ONE record per pair.  Cached per (form, constraints, Dirichlet
     markers): the records carry the row / column masks.  Returns (plan struct, keep-alive, info)."""
     import torch
+
+    caps = _pairs_caps(V0, V1)
 
     def build():
         L = _native.lib()
@@ -469,7 +482,7 @@ def _pairs_plan(A: MPCMatrix, form: Form, i: int, V0, V1, bc0, bc1, mpc0, mpc1):
         hints = None
         if V0.dof_tile_offsets is not None:
             hints = np.ascontiguousarray(V0.dof_tile_offsets.astype(np.int32) * bs0)
-        row0 = _block_ranges(A.shape[0], A.rowptr, PAIRS_MAX_ROWS, PAIRS_MAX_NNZ, bs0, hints)
+        row0 = _block_ranges(A.shape[0], A.rowptr, caps[0], caps[1], bs0, hints)
         nb = row0.size - 1
         idv = D.integral_device(form, i)
         s0, s1 = D.space_device(V0), D.space_device(V1)
@@ -494,14 +507,34 @@ def _pairs_plan(A: MPCMatrix, form: Form, i: int, V0, V1, bc0, bc1, mpc0, mpc1):
                                                             (2, "a row slot beyond its field"),
                                                             (4, "more than 2^27 entities (shard the mesh)")) if bad & b))
         del d_ids
+        # dictionary of offset patterns (opt-in, MPCX_PAIRS_DICT=1): a structured mesh has a few thousand whatever its size
+        # (P2 on a tiled Kuhn mesh: 1 500), so a record shrinks to two words -- half the plan memory, but the dependent
+        # table load costs more than the bytes it saves: P2 Poisson 246^3 9.5 -> 11.3 ms.  More than 65535 patterns
+        # (unstructured meshes): full records
+        table, npat = None, -1
+        if npairs > 0 and os.environ.get("MPCX_PAIRS_DICT", "0") == "1":
+            ws = torch.empty(L.mpcx_pair_compress_workspace(V1.element_ndofs), dtype=torch.uint8, device=dev)
+            recs2 = torch.empty(npairs * 2, dtype=torch.int32, device=dev)
+            ds = L.mpcx_pair_dict_stride(V1.element_ndofs)
+            table = torch.empty(65535 * ds, dtype=torch.int32, device=dev)
+            n = C.c_int32(0)
+            _native.check(L.mpcx_pair_compress(npairs, recs.data_ptr(), V1.element_ndofs, recs2.data_ptr(), table.data_ptr(),
+                                               C.byref(n), ws.data_ptr(), D.stream_ptr()), "mpcx_pair_compress")
+            npat = int(n.value)
+            if npat >= 0:
+                recs, table = recs2, table[: max(npat, 1) * ds].clone()
+            else:
+                table = None
+            del ws
         max_rows = int(np.diff(row0).max())
         max_nnz = int(np.diff(A.rowptr[row0]).max())
         plan = _native.RowBlockPlanT(nb, max_rows, max_nnz, 2, d_row0.data_ptr(), d_off.data_ptr(), None, None, None)
-        keep = (d_row0, d_off, recs)
+        keep = (d_row0, d_off, recs, table)
         return (plan, keep, {"num_blocks": nb, "num_ents": npairs, "max_rows": max_rows, "max_nnz": max_nnz,
+                             "offset_patterns": npat,
                              "bytes": int(recs.numel() * 4 + d_off.numel() * 8 + d_row0.numel() * 4)})
 
-    return D.cached(A._plans, "pairs", (form, mpc0, mpc1, bc0, bc1), (i, PAIRS_MAX_ROWS, PAIRS_MAX_NNZ), build)
+    return D.cached(A._plans, "pairs", (form, mpc0, mpc1, bc0, bc1), (i,) + caps + (os.environ.get("MPCX_PAIRS_DICT", "0"),), build)
 
 
 def _pair_context(form: Form, i: int):
@@ -1081,7 +1114,7 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
                     continue
                 md1 = _masked_dofmap(form, V1, bc1, mpc1, 1)  # column masks of the few entities that have any
                 a.plan = plan
-                a.pair_recs, a.pair_ctx = pk[2].data_ptr(), D.ptr(pctx)
+                a.pair_recs, a.pair_ctx, a.pair_dict = pk[2].data_ptr(), D.ptr(pctx), D.ptr(pk[3])
                 a.mdofmap1 = md1.data_ptr()
                 a.kernel_name = name
                 keep += [pk, pctx, md1]

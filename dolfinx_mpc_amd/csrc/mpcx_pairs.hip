@@ -19,6 +19,7 @@
 
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 
 #include "mpcx_elements.hpp"
 #include "mpcx_internal.h"
@@ -32,6 +33,8 @@ constexpr int PAIR_MASK_SHIFT = 28;
 constexpr uint32_t PAIR_ENTITY_MASK = (1u << 27) - 1;
 
 __host__ __device__ constexpr int pair_words(int nd1) { return 1 + (nd1 + 2 + 3) / 4; }
+// words per entry of the pattern dictionary: W - 1 rounded up to a power of two (one dwordx2 / dwordx4 load per entry)
+__host__ __device__ constexpr int pair_dict_stride(int nd1) { return pair_words(nd1) - 1 <= 2 ? 2 : 4; }
 
 inline int check(hipError_t err, const char* what)
 {
@@ -98,7 +101,15 @@ __device__ inline void load_ctx(const double* __restrict__ p, double (&c)[N])
   }
 }
 
-template <class Op, bool CACHED>
+// DICT: compact records (two words: word 0 as above, word 1 = row slot | pattern id << 16) + a table of the DISTINCT
+// offset patterns (words 1 .. W-1 of a full record with the slot bits cleared), mpcx_pair_compress.  A box mesh has a
+// few thousand distinct patterns whatever its size (P2 on a tiled Kuhn mesh: 1 500), so the table stays in L1 / L2 and
+// a P2 record shrinks from 16 to 8 bytes -- the kernel is HBM-bound, records are a third of its read traffic.
+// CACHED: the context of a pair is gathered from the per-entity array pair_ctx; otherwise computed from the coordinates.
+// (Measured and removed: staging the contexts of a block's entities through LDS once per block -- one gather per (block,
+// entity) visit instead of one per pair -- P2 Poisson 246^3 9.4 -> 13.8 ms: the extra dependent phase in front of every
+// block and the LDS it takes from the resident workgroups cost more than the gathers it saves.)
+template <class Op, bool CACHED, bool DICT>
 __global__ void __launch_bounds__(PAIRS_MAX_THREADS) matrix_pairs_kernel(mpcx_matrix_args_t a)
 {
   constexpr int ND0 = Op::ND0, ND1 = Op::ND1, BS0 = Op::BS0, BS1 = Op::BS1, NV = Op::NV;
@@ -132,6 +143,47 @@ __global__ void __launch_bounds__(PAIRS_MAX_THREADS) matrix_pairs_kernel(mpcx_ma
   const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
   const uint32_t* __restrict__ recs = a.pair_recs;
   const double* __restrict__ ctxs = a.pair_ctx;
+  const uint32_t* __restrict__ dict = a.pair_dict;
+  // the offset words of a compact record: the pattern its id selects (a dependent load that hits L1 / L2)
+  auto expand = [&](PairRec<W>& r)
+  {
+    if constexpr (DICT)
+    {
+      constexpr int DS = pair_dict_stride(ND1);
+      const uint32_t w1 = r.w[1];
+      const uint32_t* __restrict__ p = dict + size_t(w1 >> 16) * DS;
+      uint32_t e[DS];
+      if constexpr (DS == 2)
+      {
+        const uint2 v = *reinterpret_cast<const uint2*>(p);
+        e[0] = v.x;
+        e[1] = v.y;
+      }
+      else
+      {
+        const uint4 v = *reinterpret_cast<const uint4*>(p);
+        e[0] = v.x;
+        e[1] = v.y;
+        e[2] = v.z;
+        e[3] = v.w;
+      }
+      r.w[1] = (w1 & 0xffffu) | e[0];
+#pragma unroll
+      for (int k = 2; k < W; ++k)
+        r.w[k] = e[k - 1];
+    }
+  };
+  auto load = [&](int64_t t, PairRec<W>& r)
+  {
+    if constexpr (DICT)
+    {
+      const uint2 v = *reinterpret_cast<const uint2*>(recs + t * 2);
+      r.w[0] = v.x;
+      r.w[1] = v.y;
+    }
+    else
+      load_rec<W>(recs + t * W, r);
+  };
 
   auto fetch_ctx = [&](const PairRec<W>& r, double (&c)[CN])
   {
@@ -179,52 +231,69 @@ __global__ void __launch_bounds__(PAIRS_MAX_THREADS) matrix_pairs_kernel(mpcx_ma
     }
     typename Op::Lazy lz;
     Op::ctx_load(lz, a.constants, c);
-#pragma unroll
-    for (int I = 0; I < ND0; ++I)
+    // MASKED = std::false_type: no column of the entity is masked (all but the entities at Dirichlet / slave dofs):
+    // straight-line row bodies, no per-entry test (the tests cost five instructions per entry: 211 -> ~120 VALU
+    // instructions per P2 pair)
+    auto rows = [&](auto masked_t)
     {
-      if (i != I)
-        continue;
+      constexpr bool MASKED = decltype(masked_t)::value;
 #pragma unroll
-      for (int k = 0; k < BS0; ++k)
+      for (int I = 0; I < ND0; ++I)
       {
-        int base;
-        if constexpr (BS0 == 1)
-          base = int(slot);
-        else
-        {
-          if ((slot >> (13 + k)) & 1u)
-            continue;
-          base = s_rowlo[int(slot & 0x1fffu) * BS0 + k];
-        }
+        if (i != I)
+          continue;
 #pragma unroll
-        for (int j = 0; j < ND1; ++j)
+        for (int k = 0; k < BS0; ++k)
         {
-          const int off = int((r.w[(6 + j) >> 2] >> (8 * ((6 + j) & 3))) & 0xffu) * BS1;
-#pragma unroll
-          for (int q = 0; q < BS1; ++q)
+          int base;
+          if constexpr (BS0 == 1)
+            base = int(slot);
+          else
           {
-            if ((cm >> (j * BS1 + q)) & 1u)
+            if ((slot >> (13 + k)) & 1u)
               continue;
-            __hip_atomic_fetch_add(s_vals + base + off + q, Op::entry(lz, I, k, j, q), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+            base = s_rowlo[int(slot & 0x1fffu) * BS0 + k];
+          }
+          double* row = s_vals + base;
+#pragma unroll
+          for (int j = 0; j < ND1; ++j)
+          {
+            const int off = int((r.w[(6 + j) >> 2] >> (8 * ((6 + j) & 3))) & 0xffu) * BS1;
+#pragma unroll
+            for (int q = 0; q < BS1; ++q)
+            {
+              if constexpr (MASKED)
+              {
+                if ((cm >> (j * BS1 + q)) & 1u)
+                  continue;
+              }
+              __hip_atomic_fetch_add(row + off + q, Op::entry(lz, I, k, j, q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
           }
         }
       }
-    }
+    };
+    if (cm == 0)
+      rows(std::false_type{});
+    else
+      rows(std::true_type{});
   };
 
   int64_t t = e0 + tid;
   if constexpr (CACHED)
   {
-    // two-stage pipeline: record of t + 2 NT and context of t + NT in flight while pair t is computed
+    // two-stage pipeline: record of t + 2 NT and context (+ offset pattern) of t + NT in flight while pair t is computed
     PairRec<W> cur, nxt;
     double cc[CN];
     if (t < e1)
-      load_rec<W>(recs + t * W, cur);
+      load(t, cur);
     if (t + NT < e1)
-      load_rec<W>(recs + (t + NT) * W, nxt);
+      load(t + NT, nxt);
     if (t < e1)
+    {
       fetch_ctx(cur, cc);
+      expand(cur);
+    }
     for (; t < e1; t += NT)
     {
       PairRec<W> nn = nxt;
@@ -233,9 +302,12 @@ __global__ void __launch_bounds__(PAIRS_MAX_THREADS) matrix_pairs_kernel(mpcx_ma
       for (int k = 0; k < CN; ++k)
         cn[k] = cc[k];
       if (t + NT < e1)
+      {
         fetch_ctx(nxt, cn);
+        expand(nxt);
+      }
       if (t + 2 * NT < e1)
-        load_rec<W>(recs + (t + 2 * NT) * W, nn);
+        load(t + 2 * NT, nn);
       process(cur, cc);
       cur = nxt;
       nxt = nn;
@@ -248,14 +320,15 @@ __global__ void __launch_bounds__(PAIRS_MAX_THREADS) matrix_pairs_kernel(mpcx_ma
   {
     PairRec<W> cur;
     if (t < e1)
-      load_rec<W>(recs + t * W, cur);
+      load(t, cur);
     for (; t < e1; t += NT)
     {
       PairRec<W> nxt = cur;
       if (t + NT < e1)
-        load_rec<W>(recs + (t + NT) * W, nxt);
+        load(t + NT, nxt);
       double cc[CN];
       fetch_ctx(cur, cc);
+      expand(cur);
       process(cur, cc);
       cur = nxt;
     }
@@ -385,6 +458,145 @@ __global__ void __launch_bounds__(256)
     atomicOr(overflow, bad);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Dictionary of offset patterns (set-up).  A pattern = words 1 .. W-1 of a record with the slot bits cleared.
+//   pair_dict_insert_kernel : every pair inserts the 64-bit hash of its pattern into an open-addressing table
+//                             (PAIR_DICT_SLOTS slots, atomicCAS on the hash); the thread that claims a slot writes the
+//                             pattern next to it.  More than PAIR_DICT_MAX distinct hashes: *count passes the limit and
+//                             the caller keeps the full records.
+//   pair_dict_number_kernel : dense ids for the occupied slots (one workgroup), compact table.
+//   pair_dict_records_kernel: every pair looks its slot up, CHECKS its pattern against the table entry (two patterns
+//                             with one hash would otherwise share an entry: *mismatch is set and the caller keeps
+//                             the full records) and writes its compact record.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int PAIR_DICT_SLOTS = 1 << 17;
+constexpr int PAIR_DICT_MAX = 65535;
+
+__device__ inline uint64_t pair_pattern_hash(const uint32_t* __restrict__ rec, int W)
+{
+  uint64_t h = 0x9e3779b97f4a7c15ull;
+  for (int k = 1; k < W; ++k)
+  {
+    const uint64_t v = (k == 1) ? (rec[1] & 0xffff0000u) : rec[k];
+    h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+    h *= 0xff51afd7ed558ccdull;
+    h ^= h >> 33;
+  }
+  return h ? h : 1;
+}
+
+__global__ void __launch_bounds__(256)
+    pair_dict_insert_kernel(int64_t n_pairs, const uint32_t* __restrict__ recs, int W, unsigned long long* __restrict__ keys,
+                            uint32_t* __restrict__ raw, int32_t* __restrict__ count)
+{
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n_pairs)
+    return;
+  if (*reinterpret_cast<volatile int32_t*>(count) > PAIR_DICT_MAX)
+    return; // already too many: the caller gives up
+  const uint32_t* __restrict__ r = recs + t * W;
+  const uint64_t h = pair_pattern_hash(r, W);
+  uint32_t s = uint32_t(h >> 20) & (PAIR_DICT_SLOTS - 1);
+  for (int probe = 0; probe < PAIR_DICT_SLOTS; ++probe)
+  {
+    const unsigned long long cur = keys[s];
+    if (cur == h)
+      return;
+    if (cur == 0)
+    {
+      const unsigned long long old = atomicCAS(keys + s, 0ull, (unsigned long long)h);
+      if (old == 0)
+      {
+        raw[size_t(s) * (W - 1)] = r[1] & 0xffff0000u;
+        for (int k = 2; k < W; ++k)
+          raw[size_t(s) * (W - 1) + k - 1] = r[k];
+        atomicAdd(count, 1);
+        return;
+      }
+      if (old == h)
+        return;
+    }
+    s = (s + 1) & (PAIR_DICT_SLOTS - 1);
+  }
+}
+
+__global__ void __launch_bounds__(1024)
+    pair_dict_number_kernel(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ raw, int W, int DS,
+                            int32_t* __restrict__ ids, uint32_t* __restrict__ table)
+{
+  // one workgroup: exclusive scan of the occupancy flags in chunks of 1024 slots
+  __shared__ int32_t s_scan[1024];
+  __shared__ int32_t s_base;
+  const int tid = threadIdx.x;
+  if (tid == 0)
+    s_base = 0;
+  __syncthreads();
+  for (int c = 0; c < PAIR_DICT_SLOTS; c += 1024)
+  {
+    const int slot = c + tid;
+    const int f = keys[slot] != 0 ? 1 : 0;
+    s_scan[tid] = f;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1)
+    {
+      const int v = tid >= d ? s_scan[tid - d] : 0;
+      __syncthreads();
+      s_scan[tid] += v;
+      __syncthreads();
+    }
+    const int id = s_base + s_scan[tid] - f;
+    ids[slot] = f ? id : -1;
+    if (f && id < PAIR_DICT_MAX)
+      for (int k = 0; k < DS; ++k)
+        table[size_t(id) * DS + k] = k < W - 1 ? raw[size_t(slot) * (W - 1) + k] : 0u;
+    __syncthreads();
+    if (tid == 1023)
+      s_base += s_scan[1023];
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    pair_dict_records_kernel(int64_t n_pairs, const uint32_t* __restrict__ recs, int W, int DS, const unsigned long long* __restrict__ keys,
+                             const int32_t* __restrict__ ids, const uint32_t* __restrict__ table, uint32_t* __restrict__ out,
+                             int32_t* __restrict__ mismatch)
+{
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n_pairs)
+    return;
+  const uint32_t* __restrict__ r = recs + t * W;
+  const uint64_t h = pair_pattern_hash(r, W);
+  uint32_t s = uint32_t(h >> 20) & (PAIR_DICT_SLOTS - 1);
+  int id = -1;
+  for (int probe = 0; probe < PAIR_DICT_SLOTS; ++probe)
+  {
+    const unsigned long long cur = keys[s];
+    if (cur == h)
+    {
+      id = ids[s];
+      break;
+    }
+    if (cur == 0)
+      break;
+    s = (s + 1) & (PAIR_DICT_SLOTS - 1);
+  }
+  bool ok = id >= 0 && id < PAIR_DICT_MAX;
+  if (ok)
+  {
+    const uint32_t* __restrict__ p = table + size_t(id) * DS;
+    ok = p[0] == (r[1] & 0xffff0000u);
+    for (int k = 2; k < W; ++k)
+      ok = ok && p[k - 1] == r[k];
+  }
+  if (!ok)
+  {
+    *mismatch = 1;
+    id = 0;
+  }
+  out[2 * t] = r[0];
+  out[2 * t + 1] = (r[1] & 0xffffu) | (uint32_t(id) << 16);
+}
+
 // the operators with a compact context (ElementOp::LAZY) that are not component-diagonal
 #define MPCX_FOR_PAIR_OPS(X)                                                                                          \
   if (k.form == MPCX_FORM_STIFFNESS && k.bs == 1 && k.bs1 == 1 && k.degree == k.degree1 && k.coeff_degree == 0)       \
@@ -451,11 +663,20 @@ int launch_pairs(const mpcx_matrix_args_t& a)
     mpcx_set_error("mpcx_assemble_matrix: row-block plan exceeds 160 KiB of LDS");
     return -4;
   }
-  const void* kern = a.pair_ctx ? reinterpret_cast<const void*>(matrix_pairs_kernel<Op, true>)
-                                : reinterpret_cast<const void*>(matrix_pairs_kernel<Op, false>);
+  const bool cached = a.pair_ctx != nullptr;
+  const bool dictm = a.pair_dict != nullptr;
+  auto pick = [&](auto dict_t) -> const void*
+  {
+    constexpr bool D = decltype(dict_t)::value;
+    return cached ? reinterpret_cast<const void*>(matrix_pairs_kernel<Op, true, D>)
+                  : reinterpret_cast<const void*>(matrix_pairs_kernel<Op, false, D>);
+  };
+  const void* kern = dictm ? pick(std::true_type{}) : pick(std::false_type{});
   if (int rc = check(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)), "hipFuncSetAttribute"))
     return rc;
-  // workgroups per CU by LDS; threads so that the CU holds 16 waves (registers allow: <= 128) -- MPCX_PAIRS_THREADS overrides
+  // Threads per workgroup: the CU should hold as many waves as the registers allow (8 per SIMD up to 64 VGPRs), spread
+  // over the workgroups the LDS of the plan admits -- P2 Poisson 246^3, 37 KB blocks (four per CU): 128 threads 14.0 ms,
+  // 256 11.2, 512 9.5; 74 KB blocks: 512 11.2, 1024 10.2; 18 KB blocks with 256 threads 10.0.  MPCX_PAIRS_THREADS overrides.
   static const int env_threads = []
   {
     const char* e = std::getenv("MPCX_PAIRS_THREADS");
@@ -465,15 +686,19 @@ int launch_pairs(const mpcx_matrix_args_t& a)
   int threads = env_threads;
   if (threads == 0)
   {
-    const int wgs = int((160 * 1024) / (lds + 512));
-    threads = wgs >= 4 ? 256 : (wgs >= 2 ? 512 : 1024);
+    hipFuncAttributes attr;
+    if (int rc = check(hipFuncGetAttributes(&attr, kern), "hipFuncGetAttributes"))
+      return rc;
+    const int per_simd = attr.numRegs <= 64 ? 8 : (attr.numRegs <= 72 ? 7 : (attr.numRegs <= 80 ? 6 : (attr.numRegs <= 96 ? 5 : 4)));
+    const int wgs = int((160 * 1024) / (lds + 1024)) < 1 ? 1 : int((160 * 1024) / (lds + 1024));
+    threads = 64 * ((4 * per_simd) / (wgs > 16 ? 16 : wgs));
+    threads = threads < 128 ? 128 : (threads > PAIRS_MAX_THREADS ? PAIRS_MAX_THREADS : threads);
   }
   const unsigned grid = 8u * unsigned((a.plan.num_blocks + 7) / 8);
   hipStream_t stream = static_cast<hipStream_t>(a.stream);
-  if (a.pair_ctx)
-    hipLaunchKernelGGL((matrix_pairs_kernel<Op, true>), dim3(grid), dim3(threads), lds, stream, a);
-  else
-    hipLaunchKernelGGL((matrix_pairs_kernel<Op, false>), dim3(grid), dim3(threads), lds, stream, a);
+  void* kargs[] = {const_cast<mpcx_matrix_args_t*>(&a)};
+  if (int rc = check(hipLaunchKernel(kern, dim3(grid), dim3(threads), kargs, lds, stream), "pairs kernel launch"))
+    return rc;
   return check(hipGetLastError(), "pairs kernel launch");
 }
 } // namespace
@@ -497,6 +722,7 @@ int launch_matrix_pairs(const mpcx_matrix_args_t& a)
 using namespace mpcx;
 
 extern "C" int32_t mpcx_pair_words(int32_t nd1) { return pair_words(nd1); }
+extern "C" int32_t mpcx_pair_dict_stride(int32_t nd1) { return pair_dict_stride(nd1); }
 
 extern "C" int mpcx_pair_records(int64_t n_pairs, const uint32_t* pair_ids, int32_t estride, const int32_t* entities0,
                                  const int32_t* entities1, const int32_t* dofmap0, int32_t nd0, int32_t bs0,
@@ -548,4 +774,44 @@ extern "C" int mpcx_pair_context(const mpcx_kernel_t* kernel, int64_t n_entities
 #undef X
   mpcx_set_error("mpcx_pair_context: no compact context for this operator");
   return -10;
+}
+
+extern "C" int64_t mpcx_pair_compress_workspace(int32_t nd1)
+{
+  const int W = pair_words(nd1);
+  // keys [SLOTS] u64, raw [SLOTS][W-1] u32, ids [SLOTS] i32, counters [2] i32
+  return int64_t(PAIR_DICT_SLOTS) * 8 + int64_t(PAIR_DICT_SLOTS) * (W - 1) * 4 + int64_t(PAIR_DICT_SLOTS) * 4 + 16;
+}
+
+extern "C" int mpcx_pair_compress(int64_t n_pairs, const uint32_t* recs, int32_t nd1, uint32_t* recs2, uint32_t* table,
+                                  int32_t* num_patterns, void* workspace, void* stream_)
+{
+  const int W = pair_words(nd1);
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  unsigned char* ws = static_cast<unsigned char*>(workspace);
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(ws);
+  uint32_t* raw = reinterpret_cast<uint32_t*>(ws + size_t(PAIR_DICT_SLOTS) * 8);
+  int32_t* ids = reinterpret_cast<int32_t*>(ws + size_t(PAIR_DICT_SLOTS) * 8 + size_t(PAIR_DICT_SLOTS) * (W - 1) * 4);
+  int32_t* counters = ids + PAIR_DICT_SLOTS; // [0] distinct patterns, [1] mismatch
+  if (int rc = check(hipMemsetAsync(ws, 0, size_t(mpcx_pair_compress_workspace(nd1)), stream), "hipMemsetAsync"))
+    return rc;
+  if (n_pairs > 0)
+  {
+    hipLaunchKernelGGL(pair_dict_insert_kernel, dim3(grid_for(n_pairs, 256)), dim3(256), 0, stream, n_pairs, recs, W, keys, raw,
+                       counters);
+    hipLaunchKernelGGL(pair_dict_number_kernel, dim3(1), dim3(1024), 0, stream, keys, raw, W, pair_dict_stride(nd1), ids, table);
+    hipLaunchKernelGGL(pair_dict_records_kernel, dim3(grid_for(n_pairs, 256)), dim3(256), 0, stream, n_pairs, recs, W,
+                       pair_dict_stride(nd1), keys, ids,
+                       table, recs2, counters + 1);
+  }
+  if (int rc = check(hipGetLastError(), "pair dictionary kernels"))
+    return rc;
+  int32_t host[2] = {0, 0};
+  if (int rc = check(hipMemcpyAsync(host, counters, 8, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync"))
+    return rc;
+  if (int rc = check(hipStreamSynchronize(stream), "hipStreamSynchronize"))
+    return rc;
+  // more distinct patterns than 16-bit ids, or two patterns with one hash: no dictionary (the caller keeps the full records)
+  *num_patterns = (host[0] > PAIR_DICT_MAX || host[1] != 0) ? -1 : host[0];
+  return 0;
 }

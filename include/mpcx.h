@@ -280,6 +280,11 @@ typedef struct
    * pair from the coordinates (x, x_dofmap, entities). */
   const uint32_t* pair_recs;
   const double* pair_ctx;
+  /* Optional dictionary of offset patterns (mpcx_pair_compress): pair_dict DEVICE [num_patterns][S] uint32, S =
+   * mpcx_pair_dict_stride(nd1) (W - 1 rounded up to 2 or 4), entry = words 1 .. W-1 of the DISTINCT full records with the
+   * row-slot bits cleared, zero padded; pair_recs then holds COMPACT records, two words
+   * per pair: word 0 as above, word 1 = row slot | pattern id << 16.  NULL: full records. */
+  const uint32_t* pair_dict;
   void* stream;
 } mpcx_matrix_args_t;
 
@@ -437,6 +442,15 @@ int mpcx_pair_records(int64_t n_pairs, const uint32_t* pair_ids, int32_t estride
                       int32_t nd1, int32_t bs1, const int8_t* bc0, const int8_t* slave0, const int8_t* bc1,
                       const int8_t* slave1, const mpcx_nnz_t* rowptr, const int32_t* cols, int32_t num_blocks,
                       const int32_t* block_row0, uint32_t* recs, int32_t* overflow, void* stream);
+/* Dictionary compression of the records (all pointers DEVICE except num_patterns): recs2 [n_pairs][2] compact records,
+ * table [65535][mpcx_pair_dict_stride(nd1)] the distinct offset patterns, workspace of mpcx_pair_compress_workspace(nd1)
+ * bytes.  Blocking.
+ * *num_patterns (HOST) = number of distinct patterns, or -1 when there are more than 65535 (an unstructured mesh): keep
+ * the full records then.  Structured / tiled meshes have a few thousand patterns whatever their size. */
+int32_t mpcx_pair_dict_stride(int32_t nd1);
+int64_t mpcx_pair_compress_workspace(int32_t nd1);
+int mpcx_pair_compress(int64_t n_pairs, const uint32_t* recs, int32_t nd1, uint32_t* recs2, uint32_t* table,
+                       int32_t* num_patterns, void* workspace, void* stream);
 int32_t mpcx_pair_context_size(const mpcx_kernel_t* kernel);
 int mpcx_pair_context(const mpcx_kernel_t* kernel, int64_t n_entities, int32_t estride, const int32_t* entities,
                       const double* x, const int32_t* x_dofmap, int32_t nv, double* ctx, void* stream);

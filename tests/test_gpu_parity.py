@@ -197,7 +197,9 @@ def test_backsubstitution_homogenize(oracle):
 # kernel variants that the default configuration never reaches
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("env", ["MPCX_NO_MPC_PLAN=1", "MPCX_NO_LEAN=1", "MPCX_MPC_PLAN=host", "MPCX_NO_CUBE=1", "MPCX_PLAN_LISTS=host",
-                                 "MPCX_ROWPAIR=all", "MPCX_ROWPAIR=none", "MPCX_NO_GROUP_ROWS=1", "MPCX_NO_NODEBLOCK=1"])
+                                 "MPCX_ROWPAIR=all", "MPCX_ROWPAIR=none", "MPCX_NO_GROUP_ROWS=1", "MPCX_NO_NODEBLOCK=1",
+                                 "MPCX_FORCE_KERNEL=matrix=pairs+MPCX_PAIRS_DICT=1", "MPCX_FORCE_KERNEL=matrix=pairs+MPCX_PAIRS_CONTEXT=recompute",
+                                 "MPCX_FORCE_KERNEL=matrix=pairs+MPCX_PAIRS_MAX_NNZ=600"])
 @pytest.mark.parametrize("alg", ["atomic", "rowblock"])
 @pytest.mark.parametrize("make", CASES, ids=[f"case{i}" for i in range(len(CASES))])
 def test_small_cases_kernel_variants(oracle, make, alg, env, monkeypatch):
@@ -210,8 +212,11 @@ def test_small_cases_kernel_variants(oracle, make, alg, env, monkeypatch):
     MPCX_ROWPAIR=all / none: the (entity, local row) row-pair kernel wherever the operator has a compact context
     (default: vector-valued P1 only) / nowhere.  MPCX_NO_GROUP_ROWS=1: block entity lists in plain entity order.
     MPCX_NO_NODEBLOCK=1: component-diagonal forms on blocked spaces through the per-row compact layout of
-    matrix_rowblock_kernel instead of matrix_nodeblock_kernel."""
-    monkeypatch.setenv(*env.split("="))
+    matrix_rowblock_kernel instead of matrix_nodeblock_kernel.  matrix=pairs + MPCX_PAIRS_DICT=1 / MPCX_PAIRS_CONTEXT=recompute /
+    MPCX_PAIRS_MAX_NNZ=600: the pair-record kernel with dictionary-compressed records, with contexts computed per pair
+    instead of cached, and with tiny row blocks (many blocks, segments shorter than a wave)."""
+    for part in env.split("+"):
+        monkeypatch.setenv(*part.split("=", 1))
     case = make()
     if case.a is None:
         pytest.skip("no bilinear form")
@@ -552,7 +557,9 @@ def test_forced_kernels_are_the_ones_that_run(monkeypatch):
     for name in ("cube_hash", "ownblock", "rowblock", "hash"):
         assert taken(p1, "vector", name) == name
     p2 = case_cube_periodic(4, 2, 0.0, reorder=(2, 2, 2))
-    assert taken(p2, "matrix") == "rowblock" and taken(p2, "matrix", "rowpair") == "rowpair" and taken(p2, "matrix", "p2_cube") == "p2_cube"
+    # scalar P2 stiffness: pair records + cached contexts since round 4 (the thread-per-entity row blocks are its fall-back)
+    assert taken(p2, "matrix") == "pairs" and taken(p2, "matrix", "rowblock") == "rowblock"
+    assert taken(p2, "matrix", "rowpair") == "rowpair" and taken(p2, "matrix", "p2_cube") == "p2_cube"
     assert taken(p2, "vector") == "ownblock"
     el = case_contact_two_body(4, 6, 0.0, reorder=(2, 2, 2))
     # vector P1 elasticity on box meshes: parallelepiped clusters in closed form (leftover cells: rowpair)

@@ -70,6 +70,13 @@ def main():
             for k, v in sorted(d.items()):
                 fh.write(f"    {k:32s} {v:.6g}\n")
     print(open(os.path.join(out, "pmc_summary.txt")).read())
+    # the rocprofv3 databases are large (hundreds of MB at full size) and gpurun_out/ only travels back below 64 MiB:
+    # the summaries are what is kept
+    for f in glob.glob(os.path.join(out, "p_*")):
+        try:
+            os.remove(f)
+        except OSError:
+            pass
 
 
 if __name__ == "__main__":

@@ -7,29 +7,30 @@ run() { cfg=$1; name=$2; shift 2
 for cfg in "$@"; do
 case $cfg in
 5)
-run 5 base MPCX_FORCE_KERNEL=matrix=rowblock
 run 5 p4608 MPCX_FORCE_KERNEL=matrix=pairs
-run 5 p4608_rc MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_CONTEXT=recompute
-run 5 p9216 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=9216
-run 5 p9216_t1024 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=9216 MPCX_PAIRS_THREADS=1024
+run 5 p4608_nodict MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_DICT=0
+run 5 p4608_nostage_nodict MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_DICT=0 MPCX_PAIRS_STAGE=0
+run 5 p3584 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=3584
+run 5 p3584_nodict MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=3584 MPCX_PAIRS_DICT=0
 run 5 p2304 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=2304
-run 5 p2304_t256 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=2304 MPCX_PAIRS_THREADS=256
-run 5 p4608_t512 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_THREADS=512
-run 5 p4608_t128 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_THREADS=128
-run 5 p6144 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=6144 MPCX_PAIRS_THREADS=384
+run 5 p2304_nodict MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=2304 MPCX_PAIRS_DICT=0
+run 5 p6144 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=6144
+run 5 p9216 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=9216
+run 5 p4608_rc MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_CONTEXT=recompute
 ;;
 3)
-run 3 base MPCX_FORCE_KERNEL=matrix=rowblock
+run 3 base
 run 3 p4608 MPCX_FORCE_KERNEL=matrix=pairs
-run 3 p9216 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=9216
 run 3 p2304 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=2304
+run 3 p1152 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=1152
+run 3 p2304_nodict MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=2304 MPCX_PAIRS_DICT=0
 ;;
 4)
 run 4 base
-run 4 rowpair MPCX_FORCE_KERNEL=matrix=rowpair
 run 4 p4608 MPCX_FORCE_KERNEL=matrix=pairs
-run 4 p9216 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=9216
 run 4 p2304 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=2304
+run 4 p1152 MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=1152
+run 4 p2304_nodict MPCX_FORCE_KERNEL=matrix=pairs MPCX_PAIRS_MAX_NNZ=2304 MPCX_PAIRS_DICT=0
 ;;
 esac
 done
