@@ -375,6 +375,11 @@ def create_stacked_cubes(n_top: int, n_bottom: int | None = None, theta: float =
     n_bottom = 2 * n_top if n_bottom is None else n_bottom
     top = create_box((0.0, 0.0, 1.0), (1.0, 1.0, 2.0), (n_top,) * 3, "tetrahedron", reorder)
     bot = create_box((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), (n_bottom,) * 3, "tetrahedron", reorder)
+    return _stack_bodies(top, bot, theta)
+
+
+def _stack_bodies(top: Mesh, bot: Mesh, theta: float = 0.0):
+    """two tetrahedral bodies on z in [1, 2] and [0, 1] merged (top first) with the contact benchmark's facet markers"""
     mesh = merge_meshes([top, bot])
     x = mesh.geometry.x
     z = x[:, 2]
@@ -402,3 +407,53 @@ def create_stacked_cubes(n_top: int, n_bottom: int | None = None, theta: float =
     cell_tags = np.zeros(mesh.num_cells, dtype=np.int32)
     cell_tags[:nct] = 2
     return mesh, MeshTags(mesh, 2, ents, vals), cell_tags
+
+
+def _delaunay_points(n, p0, p1, rng, jitter: float) -> np.ndarray:
+    """lattice of (n_d + 1) points per direction on the box, every point moved by up to ``jitter`` lattice widths -- but
+    only inside the face / edge of the box it lies on (corners stay): the boundary of the box stays the boundary"""
+    n = np.asarray(n, dtype=np.int64)
+    dim = n.size
+    p0, p1 = np.asarray(p0, dtype=np.float64)[:dim], np.asarray(p1, dtype=np.float64)[:dim]
+    idx = np.stack(np.meshgrid(*[np.arange(k + 1) for k in n], indexing="ij"), axis=-1).reshape(-1, dim)
+    h = (p1 - p0) / n
+    pts = p0 + idx * h
+    move = (rng.random(pts.shape) * 2.0 - 1.0) * jitter * h
+    move[(idx == 0) | (idx == n)] = 0.0
+    return pts + move
+
+
+def create_delaunay_box(p0, p1, n, seed: int = 0, jitter: float = 0.4) -> Mesh:
+    """An IRREGULAR simplicial mesh of the box [p0, p1] (2D: triangles, 3D: tetrahedra): jittered lattice points
+    triangulated by ``scipy.spatial.Delaunay`` -- variable vertex valence, no six-tet fans, no numbering locality (the
+    points are shuffled): what a mesh generator such as gmsh hands the reference (python/tests/test_cube_contact.py:15-160).
+    Flat simplices among the coplanar points of the box faces are dropped (they have no volume; the mesh stays
+    conforming: such a simplex only touches the boundary).  The point sets of opposite faces do NOT match."""
+    from scipy.spatial import Delaunay
+
+    n = tuple(int(k) for k in n)
+    dim = len(n)
+    assert dim in (2, 3)
+    rng = np.random.default_rng(seed)
+    pts = _delaunay_points(n, p0, p1, rng, jitter)
+    pts = pts[rng.permutation(pts.shape[0])]
+    tri = Delaunay(pts)
+    cells = tri.simplices.astype(np.int64)
+    xv = pts[cells]
+    vol = np.abs(np.linalg.det(xv[:, 1:] - xv[:, :1])) / (6.0 if dim == 3 else 2.0)
+    box = float(np.prod(np.asarray(p1, dtype=np.float64)[:dim] - np.asarray(p0, dtype=np.float64)[:dim]))
+    keep = vol > 1e-12 * box / max(cells.shape[0], 1)
+    cells = cells[keep]
+    assert abs(vol[keep].sum() - box) <= 1e-10 * box, "Delaunay mesh does not fill the box"
+    cells = cells[rng.permutation(cells.shape[0])]
+    x = np.zeros((pts.shape[0], 3))
+    x[:, :dim] = pts
+    return Mesh(x, cells.astype(np.int32), "tetrahedron" if dim == 3 else "triangle")
+
+
+def create_stacked_delaunay(n_top: int, n_bottom: int, seed: int = 0, theta: float = 0.0):
+    """the two-body contact mesh (``create_stacked_cubes``) with irregular bodies: two Delaunay boxes whose interface
+    point sets do not match.  Returns (mesh, facet_tags, cell_tags) with the same markers."""
+    top = create_delaunay_box((0.0, 0.0, 1.0), (1.0, 1.0, 2.0), (n_top,) * 3, seed)
+    bot = create_delaunay_box((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), (n_bottom,) * 3, seed + 1)
+    return _stack_bodies(top, bot, theta)

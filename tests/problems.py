@@ -14,7 +14,7 @@ import numpy as np
 from scipy.spatial import cKDTree
 
 from dolfinx_mpc_amd import fem
-from dolfinx_mpc_amd.mesh import create_unit_cube, create_unit_square
+from dolfinx_mpc_amd.mesh import create_unit_cube, create_unit_square, rotation_matrix
 
 
 @dataclass
@@ -449,6 +449,114 @@ def case_p2_vector_elasticity_slip(n=2) -> Case:
     every component coupled) with the slip constraint and boundary data of stokes_slip_problem"""
     V, Q, bcs, raw_v, forms, L0 = stokes_slip_problem(3, n)
     return Case(f"p2_vector_elasticity_slip_n{n}", V, fem.form_elasticity(V, 1.0, 0.0), L0, bcs, raw_v)
+
+
+# --------------------------------------------------------------------------
+# Irregular meshes (VERDICT r3 P-2): Delaunay triangulations of jittered points -- variable valence, no cell
+# clusters, no numbering locality, point sets of opposite faces that do not match -- the kind of mesh gmsh hands the
+# reference (python/tests/test_cube_contact.py:15-160), with the constraints built by the library's own builders.
+# --------------------------------------------------------------------------
+def _built_raw(m):
+    return (m._slaves.copy(), m._masters.copy(), m._coeffs.copy(), m._owners.copy(), m._offsets.copy())
+
+
+def _facet_tags_by_marker(mesh, value, marker):
+    from dolfinx_mpc_amd.mesh import MeshTags
+
+    f = mesh.locate_exterior_facets(marker)
+    return MeshTags(mesh, mesh.tdim - 1, f, np.full(f.shape[0], value, dtype=np.int32))
+
+
+def case_delaunay_periodic(dim=3, degree=1, n=4, seed=0, scale=1.0, bc_value=0.0, spatial=False) -> Case:
+    """periodic Poisson with NON-MATCHING faces: every dof on x = 1 is tied to the dofs of the cell of the face x = 0 its
+    image lies in, weighted by their basis values there (python/src/dolfinx_mpc/multipointconstraint.py:225-300 ->
+    cpp/PeriodicConstraint.h): several masters per slave, masters shared between slaves, fat master rows"""
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd.mesh import create_delaunay_box, reorder_spatial
+
+    mesh = create_delaunay_box((0.0,) * dim, (1.0,) * dim, (n,) * dim, seed)
+    if spatial:
+        mesh = reorder_spatial(mesh, tile_nodes=32)
+    V = fem.functionspace(mesh, ("Lagrange", degree))
+
+    def walls(x):
+        w = np.isclose(x[1], 0) | np.isclose(x[1], 1)
+        return (w | np.isclose(x[2], 0) | np.isclose(x[2], 1)) if dim == 3 else w
+
+    bc = fem.dirichletbc(bc_value, fem.locate_dofs_geometrical(V, walls), V)
+
+    def relation(x):
+        out = x.copy()
+        out[0] = x[0] - 1.0
+        return out
+
+    m = dm.MultiPointConstraint(V)
+    m.create_periodic_constraint_geometrical(V, lambda x: np.isclose(x[0], 1.0), relation, [bc], scale)
+    raw = _built_raw(m)
+    assert raw[0].size > 0 and raw[1].size > raw[0].size  # non-matching: more than one master per slave
+    L = fem.form_source(V, fem.FN_BENCH_PERIODIC if dim == 3 else fem.FN_SIN2D)
+    tag = "_spatial" if spatial else ""
+    return Case(f"delaunay_periodic_{dim}d_p{degree}_n{n}{tag}", V, fem.form_stiffness(V), L, [bc], raw)
+
+
+def case_delaunay_elasticity_slip(dim=3, n=3, seed=3) -> Case:
+    """vector P1 elasticity on an irregular mesh with a slip wall built by create_slip_constraint from facet tags and the
+    approximated facet normal (cpp/SlipConstraint.h:16-175), clamped on x = 0"""
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd.mesh import create_delaunay_box
+    from dolfinx_mpc_amd.multipointconstraint import create_normal_approximation
+
+    mesh = create_delaunay_box((0.0,) * dim, (1.0,) * dim, (n,) * dim, seed)
+    # tilt the box so that the wall normal has every component
+    R = rotation_matrix([1.0, 2.0, -0.5], 0.4) if dim == 3 else np.array([[np.cos(0.3), -np.sin(0.3), 0], [np.sin(0.3), np.cos(0.3), 0], [0, 0, 1.0]])
+    mesh.geometry.x = mesh.geometry.x @ R.T
+    V = fem.functionspace(mesh, ("Lagrange", 1, (dim,)))
+    mt = _facet_tags_by_marker(mesh, 5, lambda x: np.isclose((R.T @ x)[0], 1.0))
+    xd = V.tabulate_dof_coordinates() @ R
+    val = np.array([0.0, 0.1, -0.05])[:dim]
+    bcs = [fem.dirichletbc(val, np.flatnonzero(np.isclose(xd[:, 0], 0.0)).astype(np.int32), V)]
+    m = dm.MultiPointConstraint(V)
+    m.create_slip_constraint(V, (mt, 5), create_normal_approximation(V, mt, 5), bcs)
+    raw = _built_raw(m)
+    assert raw[0].size > 0
+    return Case(f"delaunay_elasticity_slip_{dim}d_n{n}", V, fem.form_elasticity(V, 400.0, 250.0), fem.form_source(V, fem.FN_LINEAR),
+                bcs, raw)
+
+
+def case_delaunay_contact(n_top=2, n_bottom=3, seed=7, theta=0.0) -> Case:
+    """two irregular bodies with non-matching interface triangulations, inelastic contact built by
+    create_contact_inelastic_condition (cpp/ContactConstraint.h:908-1174): up to three masters per slave and component"""
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd.mesh import (CONTACT_BOTTOM, CONTACT_BOTTOM_INTERFACE, CONTACT_TOP, CONTACT_TOP_INTERFACE,
+                                      create_stacked_delaunay)
+
+    mesh, ft, _ct = create_stacked_delaunay(n_top, n_bottom, seed, theta)
+    V = fem.functionspace(mesh, ("Lagrange", 1, (3,)))
+    u0 = fem.Function(V)
+    bc_bottom = fem.dirichletbc(u0, fem.locate_dofs_topological(V, 2, ft.find(CONTACT_BOTTOM)), V)
+    u_top = fem.Function(V)
+    u_top.interpolate(lambda x: np.stack([np.zeros(x.shape[1]), np.zeros(x.shape[1]), np.full(x.shape[1], -0.2)]))
+    bc_top = fem.dirichletbc(u_top, fem.locate_dofs_topological(V, 2, ft.find(CONTACT_TOP)), V)
+    m = dm.MultiPointConstraint(V)
+    m.create_contact_inelastic_condition(ft, CONTACT_BOTTOM_INTERFACE, CONTACT_TOP_INTERFACE)
+    raw = _built_raw(m)
+    assert raw[0].size > 0
+    a = fem.form_elasticity(V, 500.0, 0.0)
+    L = fem.form_source(V, fem.FN_CONSTANT_VEC, constant=[1.0, 0.3, -0.2, -1.0])
+    return Case(f"delaunay_contact_{n_top}_{n_bottom}", V, a, L, [bc_bottom, bc_top], raw)
+
+
+def irregular_cases() -> List[Callable[[], Case]]:
+    return [
+        lambda: case_delaunay_periodic(3, 1, 4),
+        lambda: case_delaunay_periodic(3, 2, 3, seed=1, scale=0.7, bc_value=0.4),
+        lambda: case_delaunay_periodic(2, 1, 7, seed=2),
+        lambda: case_delaunay_periodic(2, 2, 5, seed=4, bc_value=1.5),
+        lambda: case_delaunay_periodic(3, 2, 4, seed=5, spatial=True),  # the same kind of mesh after reorder_spatial
+        lambda: case_delaunay_elasticity_slip(3, 3),
+        lambda: case_delaunay_elasticity_slip(2, 5),
+        lambda: case_delaunay_contact(2, 3),
+    ]
 
 
 def all_small_cases() -> List[Callable[[], Case]]:
