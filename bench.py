@@ -600,9 +600,23 @@ def main():
     mesh = w.mesh
     nv = int(mesh.geometry.dofmap.shape[1])
     nc = mesh.num_owned_cells
+    # a numbering without locality is assembled on the library's internal twin (dolfinx_mpc_amd/locality.py): the kernels
+    # timed below are the ones that run there, plus the pass that hands the values back in the caller's numbering
+    from dolfinx_mpc_amd import locality
+
+    tw = locality.twin_of(w.mesh) if alg_id != 1 else None
+    kbcs = bcs if tw is None else tw.bcs(bcs)
     for label, f, (m0, m1) in w.blocks:
         A = mats[label]
-        margs, keep = am.matrix_args(f, 0, A, m0, m1, bcs, alg_id, store_mode=1 if alg_id == 2 else 0, with_mpc_kernel=False,
+        if tw is not None:
+            A_caller = A
+            A, src, wide = tw.matrix(A_caller, f, m0, m1)
+            f, m0, m1 = tw.form(f), tw.mpc(m0), tw.mpc(m1)
+            tp = hip_time(lambda: _native.check(Lib.mpcx_permute_values(A_caller.nnz, src.data_ptr(), int(wide), A.vals.data_ptr(),
+                                                                        A_caller.vals.data_ptr(), None), "mpcx_permute_values"), reps)
+            kernels.append({"kernel": f"permute_values_kernel[{label}]", "call": f"assemble_matrix[{label}]", "launch_ms": tp,
+                            "algorithmic_bytes": int(20 * A_caller.nnz), "pmc_name": "permute_values_kernel"})
+        margs, keep = am.matrix_args(f, 0, A, m0, m1, kbcs, alg_id, store_mode=1 if alg_id == 2 else 0, with_mpc_kernel=False,
                                      allow_block_scalar=A._compact is not None)
         def launch_matrix(margs=margs):  # (cluster path: one launch per record format, narrow and wide row blocks)
             _native.check(Lib.mpcx_assemble_matrix(C.byref(margs)), "mpcx_assemble_matrix")
@@ -631,7 +645,10 @@ def main():
                         "fp64_flops": algorithmic_flops(f.integrals[0], V0, V1) * f.integrals[0].num_entities})
         del keep
     for label, f, m in w.vectors:
-        vargs, keep = av.vector_args(f, 0, vecs[label], m, 0)
+        bvec = vecs[label]
+        if tw is not None:
+            f, m, bvec = tw.form(f), tw.mpc(m), vecs[label]._twin[1]
+        vargs, keep = av.vector_args(f, 0, bvec, m, 0)
         tk = hip_time(lambda: _native.check(Lib.mpcx_assemble_vector(C.byref(vargs)), "mpcx_assemble_vector"), reps)
         V0 = f.function_spaces[0]
         nbytes = (4 * nv * nc + 4 * V0.element_ndofs * nc + 24 * mesh.num_nodes + 9 * V0.num_dofs

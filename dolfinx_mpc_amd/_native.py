@@ -233,6 +233,8 @@ EXPORTS = [
     "mpcx_cluster_build",
     "mpcx_cluster_canonical",
     "mpcx_rowblock_pairs_device",
+    "mpcx_csr_permutation",
+    "mpcx_permute_values",
     "mpcx_pair_words",
     "mpcx_pair_records",
     "mpcx_pair_dict_stride",
@@ -440,6 +442,10 @@ def lib() -> C.CDLL:
     L.mpcx_cluster_build.restype = C.c_int
     L.mpcx_rowblock_pairs_device.argtypes = [i64, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]
     L.mpcx_rowblock_pairs_device.restype = C.c_int
+    L.mpcx_csr_permutation.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
+    L.mpcx_csr_permutation.restype = C.c_int
+    L.mpcx_permute_values.argtypes = [i64, vp, i32, vp, vp, vp]
+    L.mpcx_permute_values.restype = C.c_int
     L.mpcx_pair_words.argtypes = [i32]
     L.mpcx_pair_words.restype = i32
     L.mpcx_pair_records.argtypes = [i64, vp, i32, vp, vp, vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]

@@ -1200,6 +1200,17 @@ def assemble_matrix(
     for integ in form.integrals:
         if integ.itype not in ("cell", "exterior_facet"):
             raise RuntimeError("Not implemented yet")  # cpp/assemble_matrix.cpp:658-659
+    if alg != 1:
+        # a numbering without locality: assemble on the spatially reordered twin, hand the values back in the caller's
+        # numbering (dolfinx_mpc_amd/locality.py)
+        from . import locality
+
+        tw = locality.twin_of(form.mesh)
+        if tw is not None:
+            try:
+                return locality.assemble_matrix(tw, form, mpc0, mpc1, bcs, diagval, A, alg)
+            except _native.PlanNotRepresentable:
+                pass
     D.mesh_device(form.mesh)  # a moved mesh is refreshed on the caller's stream, before any side stream reads it
     from .la import side_stream
 

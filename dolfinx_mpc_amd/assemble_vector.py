@@ -394,23 +394,38 @@ def assemble_vector(form: Form, constraint: MultiPointConstraint, b: Optional[Ve
     for integ in form.integrals:
         if integ.itype not in ("cell", "exterior_facet"):
             raise RuntimeError("Interior facet integrals currently not supported")
+    if alg != 1:
+        from . import locality  # a numbering without locality: the spatially reordered twin (locality.py)
+
+        tw = locality.twin_of(form.mesh)
+        if tw is not None:
+            try:
+                return locality.assemble_vector(tw, form, constraint, b, alg)
+            except _native.PlanNotRepresentable:
+                pass
     D.mesh_device(form.mesh)  # a moved mesh is refreshed on the caller's stream, before any side stream reads it
     from .la import side_stream
 
     with side_stream("vector", b):  # the library's vector stream (la.side_stream); completion is awaited by b.array
-        b.set(0.0)
-        for i, integ in enumerate(form.integrals):
-            a, keep = vector_args(form, i, b, constraint, alg)
-            _native.check(L.mpcx_assemble_vector(C.byref(a)), "mpcx_assemble_vector")
-            if a.second is not None:
-                _native.check(L.mpcx_assemble_vector(C.byref(a.second)), "mpcx_assemble_vector")
-            if a.leftover is not None:  # cells outside any cluster: per-cell kernel
-                from .assemble_matrix import _leftover_form
-
-                al, kl = vector_args(_leftover_form(form, i, a.leftover), 0, b, constraint, alg, allow_cubes=False)
-                _native.check(L.mpcx_assemble_vector(C.byref(al)), "mpcx_assemble_vector")
-            del keep
+        _assemble_vector_on_stream(form, constraint, b, alg)
     return b
+
+
+def _assemble_vector_on_stream(form: Form, constraint: MultiPointConstraint, b: Vector, alg: int):
+    """the body of ``assemble_vector``: zero, then every integral, enqueued on the CURRENT torch stream"""
+    L = _native.lib()
+    b.set(0.0)
+    for i, integ in enumerate(form.integrals):
+        a, keep = vector_args(form, i, b, constraint, alg)
+        _native.check(L.mpcx_assemble_vector(C.byref(a)), "mpcx_assemble_vector")
+        if a.second is not None:
+            _native.check(L.mpcx_assemble_vector(C.byref(a.second)), "mpcx_assemble_vector")
+        if a.leftover is not None:  # cells outside any cluster: per-cell kernel
+            from .assemble_matrix import _leftover_form
+
+            al, kl = vector_args(_leftover_form(form, i, a.leftover), 0, b, constraint, alg, allow_cubes=False)
+            _native.check(L.mpcx_assemble_vector(C.byref(al)), "mpcx_assemble_vector")
+        del keep
 
 
 def _lift_entities(form: Form, i: int, markers: np.ndarray, d_markers, V1):
@@ -479,6 +494,15 @@ def apply_lifting(
         return
     constraint._not_finalized()
     dev = _native.require_gpu()
+    first = next(f for f in form if f is not None)
+    from . import locality  # a numbering without locality: the spatially reordered twin (locality.py)
+
+    tw = locality.twin_of(first.mesh)
+    if tw is not None:
+        try:
+            return locality.apply_lifting(tw, b, form, bcs, constraint, x0, scale)
+        except _native.PlanNotRepresentable:
+            pass
     L = _native.lib()
     m, _keep = constraint._device()
     for j, aj in enumerate(form):

@@ -792,6 +792,17 @@ int mpcx_spmv_coo_add(int64_t n, const int32_t* rows, const int32_t* colsq, cons
 int mpcx_gather_f64(const double* values, const int64_t* idx, int64_t n, double* out, void* stream);
 int mpcx_scatter_add_f64(double* values, const int64_t* idx, int64_t n, const double* in, void* stream);
 
+/* Internal renumbering for locality (dolfinx_mpc_amd/locality.py: a mesh numbered without locality is assembled on a
+ * spatially reordered twin and the result is handed back in the caller's numbering; all pointers DEVICE).
+ * mpcx_csr_permutation: src[k] (uint32, or int64 when wide != 0: more than 2^32 - 1 entries) = position in the twin's
+ * CSR (rowptr2, cols2) of entry k of the caller's CSR (rowptr, cols): caller row r = twin row new_of_old0[r], caller
+ * column c = twin column new_of_old1[c]; *bad (zeroed by the caller) is set if an entry has no counterpart.
+ * mpcx_permute_values: dst[k] = vals2[src[k]], k < n. */
+int mpcx_csr_permutation(int32_t nrows, const mpcx_nnz_t* rowptr, const int32_t* cols, const int32_t* new_of_old0,
+                         const int32_t* new_of_old1, const mpcx_nnz_t* rowptr2, const int32_t* cols2, void* src, int32_t wide,
+                         int32_t* bad, void* stream);
+int mpcx_permute_values(int64_t n, const void* src, int32_t wide, const double* vals2, double* dst, void* stream);
+
 /* misc */
 const char* mpcx_last_error(void);
 int mpcx_version(void);
