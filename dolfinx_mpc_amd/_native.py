@@ -233,6 +233,7 @@ EXPORTS = [
     "mpcx_cluster_build",
     "mpcx_cluster_canonical",
     "mpcx_rowblock_pairs_device",
+    "mpcx_hbm_probe",
     "mpcx_csr_permutation",
     "mpcx_permute_values",
     "mpcx_pair_words",
@@ -442,6 +443,8 @@ def lib() -> C.CDLL:
     L.mpcx_cluster_build.restype = C.c_int
     L.mpcx_rowblock_pairs_device.argtypes = [i64, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]
     L.mpcx_rowblock_pairs_device.restype = C.c_int
+    L.mpcx_hbm_probe.argtypes = [vp, vp, i64, i32, vp]
+    L.mpcx_hbm_probe.restype = C.c_int
     L.mpcx_csr_permutation.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
     L.mpcx_csr_permutation.restype = C.c_int
     L.mpcx_permute_values.argtypes = [i64, vp, i32, vp, vp, vp]

@@ -224,6 +224,50 @@ inline unsigned stream_grid(int64_t n) // grid-stride kernels: enough workgroups
 }
 } // namespace
 
+// HBM bandwidth probes (bench.py's roofline denominators, tools/probes): 16 bytes per lane and access, grid-stride --
+// the access shape /opt/skills/guides/MI355X_MICROARCH.md quotes ~6.3 TB/s for; mode 0: copy dst = src (read + write),
+// 1: read only (sum kept in a register, one store per workgroup at the end), 2: write only.
+__global__ void __launch_bounds__(256) hbm_probe_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16, int mode)
+{
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+  int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (mode == 0)
+  {
+    for (; i < n16; i += stride)
+      dst[i] = src[i];
+  }
+  else if (mode == 1)
+  {
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (; i < n16; i += stride)
+    {
+      const uint4 v = src[i];
+      acc.x ^= v.x;
+      acc.y ^= v.y;
+      acc.z ^= v.z;
+      acc.w ^= v.w;
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) // (practically never: keeps the loads alive)
+      dst[blockIdx.x] = acc;
+  }
+  else
+  {
+    const uint4 v = make_uint4(1, 2, 3, 4);
+    for (; i < n16; i += stride)
+      dst[i] = v;
+  }
+}
+
+extern "C" int mpcx_hbm_probe(const void* src, void* dst, int64_t bytes, int32_t mode, void* stream)
+{
+  if (bytes < 16 || mode < 0 || mode > 2)
+    return 0;
+  // 8 workgroups per CU, contiguous 4 KB per workgroup and trip
+  hipLaunchKernelGGL(hbm_probe_kernel, dim3(256 * 8), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const uint4*>(src), static_cast<uint4*>(dst), bytes / 16, int(mode));
+  return check(hipGetLastError(), "hbm_probe launch");
+}
+
 extern "C" int mpcx_gather_f64(const double* values, const int64_t* idx, int64_t n, double* out, void* stream)
 {
   if (n == 0)

@@ -803,6 +803,10 @@ int mpcx_csr_permutation(int32_t nrows, const mpcx_nnz_t* rowptr, const int32_t*
                          int32_t* bad, void* stream);
 int mpcx_permute_values(int64_t n, const void* src, int32_t wide, const double* vals2, double* dst, void* stream);
 
+/* HBM bandwidth probe (the denominator bench.py prints next to the 8 TB/s specification): 16 bytes per lane and access,
+ * grid-stride over `bytes` of DEVICE memory; mode 0 copy dst = src, 1 read src only, 2 write dst only. */
+int mpcx_hbm_probe(const void* src, void* dst, int64_t bytes, int32_t mode, void* stream);
+
 /* misc */
 const char* mpcx_last_error(void);
 int mpcx_version(void);

@@ -15,27 +15,8 @@ from scipy.spatial import cKDTree
 
 from dolfinx_mpc_amd import fem
 from dolfinx_mpc_amd.mesh import create_unit_cube, create_unit_square, rotation_matrix
-
-
-@dataclass
-class Case:
-    name: str
-    V: fem.FunctionSpace
-    a: Optional[fem.Form]
-    L: Optional[fem.Form]
-    bcs: list
-    raw: tuple  # (slaves i32, masters i64, coeffs f64, owners i32, offsets i32)
-    x0: Optional[np.ndarray] = None
-    scale: float = 1.0
-    diagval: float = 1.0
-
-    @property
-    def mesh(self):
-        return self.V.mesh
-
-
-def l2b(li):
-    return np.array(li, dtype=np.float64).tobytes()
+from dolfinx_mpc_amd.workloads import (Case, _walls_yz, case_contact_two_body, case_cube_periodic, contact_problem,  # noqa: F401
+                                       contact_raw_bruteforce, empty_raw, l2b, periodic_raw, renumbered, stokes_slip_problem, warped)
 
 
 def dict_constraint_raw(V, s_m_c: Dict[bytes, Dict[bytes, float]], subspace_slave=None, subspace_master=None):
@@ -63,37 +44,6 @@ def dict_constraint_raw(V, s_m_c: Dict[bytes, Dict[bytes, float]], subspace_slav
             offsets.append(len(masters))
     return (np.array(slaves, dtype=np.int32), np.array(masters, dtype=np.int64), np.array(coeffs, dtype=np.float64),
             np.zeros(len(masters), dtype=np.int32), np.array(offsets, dtype=np.int32))
-
-
-def periodic_raw(V, bcs, scale=1.0):
-    """slave (1, y, z) <- scale * master (0, y, z), bc dofs removed
-    (python/benchmarks/bench_periodic.py:60-81)."""
-    x = V.tabulate_dof_coordinates()
-    bs = V.dofmap.bs
-    is_bc = np.zeros(V.num_dofs, dtype=np.int8)
-    for bc in bcs:
-        bc.mark_dofs(is_bc)
-    blocks = np.flatnonzero(np.isclose(x[:, 0], 1.0))
-    xm = x[blocks].copy()
-    xm[:, 0] = 1.0 - xm[:, 0]
-    d, mb = cKDTree(x).query(xm)
-    assert d.max() < 1e-10
-    slaves = (blocks[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)
-    masters = (mb[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)
-    keep = is_bc[slaves] == 0
-    slaves, masters = slaves[keep], masters[keep]
-    n = slaves.size
-    return (slaves.astype(np.int32), masters.astype(np.int64), np.full(n, scale), np.zeros(n, dtype=np.int32),
-            np.arange(n + 1, dtype=np.int32))
-
-
-def empty_raw():
-    z = np.zeros(0, dtype=np.int32)
-    return (z, np.zeros(0, dtype=np.int64), np.zeros(0), z, np.zeros(1, dtype=np.int32))
-
-
-def _walls_yz(x):
-    return np.isclose(x[1], 0) | np.isclose(x[1], 1) | np.isclose(x[2], 0) | np.isclose(x[2], 1)
 
 
 # --------------------------------------------------------------------------
@@ -191,47 +141,6 @@ def case_facet_mass() -> Case:
     return Case("facet_mass", V, a, L, [], dict_constraint_raw(V, s_m_c))
 
 
-def renumbered(mesh, numbering: str, seed: int = 0):
-    """``shuffled``: nodes and cells in random order (a mesh as a file may deliver it); ``spatial``: the shuffled
-    mesh put back in order by dolfinx_mpc_amd.mesh.reorder_spatial"""
-    from dolfinx_mpc_amd.mesh import renumber, reorder_spatial
-
-    rng = np.random.default_rng(seed)
-    mesh = renumber(mesh, rng.permutation(mesh.num_nodes), rng.permutation(mesh.num_cells))
-    return reorder_spatial(mesh, tile_nodes=64) if numbering == "spatial" else mesh
-
-
-def warped(mesh, amplitude=0.15, half=False):
-    """the same mesh with interior nodes moved by a smooth field (faces of the unit cube stay put, so that the
-    geometric markers of the cases keep working): hexahedra become genuinely trilinear, tets stay affine"""
-    x = mesh.geometry.x.copy()
-    bump = np.sin(np.pi * x[:, 0]) * np.sin(np.pi * x[:, 1]) * np.sin(np.pi * x[:, 2])
-    if half:  # only the part x < 0.3 moves: a mesh of parallelepipeds and genuinely trilinear cells
-        bump = bump * (x[:, 0] < 0.3)
-    x[:, 0] += amplitude * bump * np.sin(2.0 * x[:, 1] + 1.0) / 3.0
-    x[:, 1] += amplitude * bump * np.cos(3.0 * x[:, 2]) / 3.0
-    x[:, 2] += amplitude * bump * np.sin(1.0 + 2.0 * x[:, 0]) / 3.0
-    mesh.geometry.x = x
-    return mesh
-
-
-def case_cube_periodic(N=4, degree=1, bc_value=0.0, reorder=None, numbering=None, cell_type="tetrahedron", warp=False) -> Case:
-    """python/benchmarks/bench_periodic.py:35-110 (BASELINE configs 1/2 at small N); ``cell_type="hexahedron"`` is
-    the script's own default cell (:38, :199-200)"""
-    mesh = create_unit_cube(N, N, N, cell_type, reorder=reorder)
-    if warp:
-        mesh = warped(mesh, half=(warp == "half"))
-    if numbering is not None:
-        mesh = renumbered(mesh, numbering)
-    V = fem.functionspace(mesh, ("Lagrange", degree))
-    dofs = fem.locate_dofs_geometrical(V, _walls_yz)
-    bc = fem.dirichletbc(bc_value, dofs, V)
-    tag = ("" if reorder is None else "_tiled") + ("" if numbering is None else "_" + numbering)
-    tag += ("" if cell_type == "tetrahedron" else "_hex") + ("_warped" if warp else "")
-    return Case(f"cube_periodic_p{degree}_n{N}_bc{bc_value:g}{tag}", V, fem.form_stiffness(V),
-                fem.form_source(V, fem.FN_BENCH_PERIODIC), [bc], periodic_raw(V, [bc]))
-
-
 def case_cube_elasticity_slip(N=3, numbering=None, cell_type="tetrahedron", warp=False) -> Case:
     """vector P1 tets (or Q1 hexahedra), slip constraint u.n = 0 on x=1 with a tilted normal
     (cpp/SlipConstraint.h:115-166 output shape: 1 slave + bs-1 same-block masters)"""
@@ -318,130 +227,6 @@ def case_cube_single_master(N=12, master_point=(0.5, 0.5, 0.5)) -> Case:
     raw = (slaves, np.full(n, master, dtype=np.int64), np.linspace(0.2, 1.3, n), np.zeros(n, dtype=np.int32),
            np.arange(n + 1, dtype=np.int32))
     return Case(f"cube_single_master_n{N}", V, fem.form_stiffness(V), fem.form_source(V, fem.FN_POLY3), [bc], raw)
-
-
-def contact_raw_bruteforce(V, slave_facets, master_facets):
-    """Independent restatement (plain loops, no shared code with the product's builder) of the serial
-    branch of cpp/ContactConstraint.h:908-1174 for P1 spaces: every node of the slave facets is tied,
-    per component, to the nodes of the first master-side cell that contains it, weighted by that
-    cell's barycentric coordinates; |c| <= 1e-6 dropped (:1033)."""
-    from dolfinx_mpc_amd.mesh import TET_FACETS
-
-    mesh = V.mesh
-    assert V.degree == 1 and mesh.tdim == 3
-    x = mesh.geometry.x
-    cells = mesh.geometry.dofmap
-    bs = V.dofmap.bs
-    snodes = sorted({int(v) for c, f in slave_facets for v in cells[c][TET_FACETS[f]]})
-    mcells = sorted({int(c) for c, f in master_facets})
-    slaves, masters, coeffs, offsets = [], [], [], [0]
-    for s in snodes:
-        p = x[s]
-        hit = None
-        for c in mcells:
-            xv = x[cells[c]]
-            T = np.stack([xv[1] - xv[0], xv[2] - xv[0], xv[3] - xv[0]], axis=1)
-            mu = np.linalg.solve(T, p - xv[0])
-            lam = np.array([1.0 - mu.sum(), mu[0], mu[1], mu[2]])
-            if lam.min() >= -1e-9:
-                hit = (c, lam)
-                break
-        assert hit is not None, f"slave node {s} touches no master cell"
-        c, lam = hit
-        for j in range(bs):
-            slaves.append(s * bs + j)
-            for k in range(4):
-                if abs(lam[k]) > 1e-6:
-                    masters.append(int(cells[c][k]) * bs + j)
-                    coeffs.append(float(lam[k]))
-            offsets.append(len(masters))
-    return (np.array(slaves, dtype=np.int32), np.array(masters, dtype=np.int64), np.array(coeffs),
-            np.zeros(len(masters), dtype=np.int32), np.array(offsets, dtype=np.int32))
-
-
-def contact_problem(n_top, n_bottom=None, theta=0.0, reorder=None, body_force=(0.0, 0.0, 0.0), numbering=None):
-    """mesh, space, boundary conditions and forms of python/benchmarks/bench_contact_3D.py:199-270 with the
-    inelastic (no-slip) contact condition: vector P1, bottom face clamped, top face displaced by
-    (0, 0, -0.425), E = 1e3, nu = 0, right-hand side = a constant body force (the benchmark's is zero)."""
-    from dolfinx_mpc_amd.mesh import (CONTACT_BOTTOM, CONTACT_BOTTOM_INTERFACE, CONTACT_TOP, CONTACT_TOP_INTERFACE,
-                                      create_stacked_cubes)
-
-    mesh, ft, _ct = create_stacked_cubes(n_top, n_bottom, theta, reorder)
-    if numbering is not None:
-        # a mesh as a file may deliver it (random order), optionally put back in order: the facet tags travel along
-        from dolfinx_mpc_amd.mesh import renumber, reorder_spatial
-
-        rng = np.random.default_rng(5)
-        mesh, ft = renumber(mesh, rng.permutation(mesh.num_nodes), rng.permutation(mesh.num_cells), ft)
-        if numbering == "spatial":
-            mesh, ft = reorder_spatial(mesh, ft, tile_nodes=64)
-    V = fem.functionspace(mesh, ("Lagrange", 1, (3,)))
-    u_bc = fem.Function(V)
-    bc_bottom = fem.dirichletbc(u_bc, fem.locate_dofs_topological(V, 2, ft.find(CONTACT_BOTTOM)), V)
-    u_top = fem.Function(V)
-    u_top.interpolate(lambda x: np.stack([np.zeros(x.shape[1]), np.zeros(x.shape[1]), np.full(x.shape[1], -4.25e-1)]))
-    bc_top = fem.dirichletbc(u_top, fem.locate_dofs_topological(V, 2, ft.find(CONTACT_TOP)), V)
-    E, nu = 1.0e3, 0.0
-    a = fem.form_elasticity(V, E / (2.0 * (1.0 + nu)), E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu)))
-    L = fem.form_source(V, fem.FN_CONSTANT_VEC, constant=[1.0, *body_force])
-    return mesh, ft, V, [bc_bottom, bc_top], a, L, (CONTACT_BOTTOM_INTERFACE, CONTACT_TOP_INTERFACE)
-
-
-def case_contact_two_body(n_top=2, n_bottom=None, theta=0.0, reorder=None, numbering=None) -> Case:
-    """BASELINE config 4 at small size: two stacked cubes, inelastic contact, vector P1 elasticity
-    (python/benchmarks/bench_contact_3D.py:62-270 with --no-slip; cpp/ContactConstraint.h:908-1174).
-    n_bottom = 2 n_top: slave nodes fall on master nodes / edge midpoints (1-2 masters);
-    other ratios: general barycentric weights (up to 3 masters per slave and component)."""
-    mesh, ft, V, bcs, a, L, (sm, mm) = contact_problem(n_top, n_bottom, theta, reorder, body_force=(0.3, -0.2, -1.0),
-                                                      numbering=numbering)
-    raw = contact_raw_bruteforce(V, ft.find(sm), ft.find(mm))
-    nb = 2 * n_top if n_bottom is None else n_bottom
-    tag = ("" if reorder is None else "_tiled") + ("" if numbering is None else "_" + numbering)
-    return Case(f"contact_two_body_{n_top}_{nb}_theta{theta:.2f}{tag}", V, a, L, bcs, raw)
-
-
-def stokes_slip_problem(dim, n, reorder=None):
-    """Taylor-Hood Stokes blocks with a slip constraint on the velocity space (BASELINE config 3;
-    forms of python/tests/test_stokes_channelflow.py:77-81, nest assembly with (mpc_i, mpc_j) as in
-    python/tests/test_rectangular_assembly.py; constraint in the output shape of
-    cpp/SlipConstraint.h:115-166: one slave per wall block -- the component with the largest |n_i| --
-    and the other components of the same block as masters with c_i = -n_i / n_s):
-
-        a00 = inner(grad u, grad v) dx   (P2^d x P2^d)      a01 = -p div v dx   (P2^d x P1)
-        a10 = -div u q dx                (P1 x P2^d)        L0  = inner(f, v) dx
-
-    inflow profile on x = 0 (non-zero Dirichlet), no-slip on y = 0, slip on y = 1 with a tilted normal.
-    Returns V, Q, bcs, raw_v, forms {(i, j): form}, L0."""
-    mesh = create_unit_cube(n, n, n, reorder=reorder) if dim == 3 else create_unit_square(n, n)
-    V = fem.functionspace(mesh, ("Lagrange", 2, (dim,)))
-    Q = fem.functionspace(mesh, ("Lagrange", 1))
-    x = V.tabulate_dof_coordinates()
-    inflow = fem.Function(V)
-    inflow.interpolate(lambda x: np.stack([x[1] * (1 - x[1])] + [0 * x[1]] * (dim - 1)))
-    bc_in = fem.dirichletbc(inflow, fem.locate_dofs_geometrical(V, lambda x: np.isclose(x[0], 0)), V)
-    bc_wall = fem.dirichletbc(0.0, fem.locate_dofs_geometrical(V, lambda x: np.isclose(x[1], 0) & ~np.isclose(x[0], 0)), V)
-    bcs = [bc_in, bc_wall]
-    is_bc = np.zeros(V.num_dofs, dtype=np.int8)
-    for bc in bcs:
-        bc.mark_dofs(is_bc)
-    nrm = np.array([0.25, 1.0, -0.15])[:dim]
-    nrm /= np.linalg.norm(nrm)
-    s = int(np.argmax(np.abs(nrm)))
-    blocks = np.flatnonzero(np.isclose(x[:, 1], 1.0))
-    blocks = blocks[~is_bc.reshape(-1, dim)[blocks].any(axis=1)]  # blocks touched by a Dirichlet condition stay free
-    others = [k for k in range(dim) if k != s]
-    slaves = (blocks * dim + s).astype(np.int32)
-    masters = (blocks[:, None] * dim + np.array(others)[None, :]).reshape(-1).astype(np.int64)
-    coeffs = np.tile(np.array([-nrm[k] / nrm[s] for k in others]), blocks.size)
-    offsets = (np.arange(blocks.size + 1) * len(others)).astype(np.int32)
-    raw_v = (slaves, masters, coeffs, np.zeros(masters.size, dtype=np.int32), offsets)
-    forms = {
-        (0, 0): fem.form_stiffness(V),
-        (0, 1): fem.form_div_test(V, Q, constant=-1.0),
-        (1, 0): fem.form_div_trial(Q, V, constant=-1.0),
-    }
-    L0 = fem.form_source(V, fem.FN_LINEAR)
-    return V, Q, bcs, raw_v, forms, L0
 
 
 def case_p2_vector_elasticity_slip(n=2) -> Case:

@@ -2,7 +2,7 @@
 # matrix_pairs_kernel (round 4): block size / threads / context mode at config 5 (P2 Poisson 246^3), config 3, config 4
 OUT=gpurun_out/pairs_sweep; mkdir -p $OUT
 run() { cfg=$1; name=$2; shift 2
-  env "$@" timeout 900 python bench.py --config $cfg --steps 5 --warmup 2 --no-cpu-baseline --no-traffic > $OUT/c${cfg}_$name.json 2> $OUT/c${cfg}_$name.log
+  env "$@" timeout 900 python bench.py --config $cfg --steps 5 --warmup 2 --no-cpu-baseline --no-traffic --no-sub-records > $OUT/c${cfg}_$name.json 2> $OUT/c${cfg}_$name.log
   python tools/show_bench.py $OUT/c${cfg}_$name.json | grep -vE "roofline|timings|generic|one_shot" | tr '\n' ' '; echo " [c$cfg $name]"; }
 for cfg in "$@"; do
 case $cfg in
