@@ -753,19 +753,32 @@ def main():
         lv, _fv, mv = w.vectors[0]
         sa, na = generate("stiffness", "tetrahedron", 1, 1, make_quadrature("tetrahedron", 0))
         sl, nl = generate("source", "tetrahedron", 1, 1, make_quadrature("tetrahedron", 5), fexpr=BENCH_PERIODIC_F)
-        fa_u, fl_u = fem.form_ufcx([w.V, w.V], sa, na), fem.form_ufcx([w.V], sl, nl)
 
-        def step_ufcx():
-            dm.assemble_matrix(fa_u, (m0, m1), bcs=bcs, A=mats[label], algorithm=args.alg)
-            dm.assemble_vector(fl_u, mv, b=vecs[lv])
+        def ufcx_record(fa_u, fl_u, note):
+            def step_ufcx():
+                dm.assemble_matrix(fa_u, (m0, m1), bcs=bcs, A=mats[label], algorithm=args.alg)
+                dm.assemble_vector(fl_u, mv, b=vecs[lv])
 
-        tu = timed_steps(step_ufcx, args.steps)
-        tm_u = hip_time(lambda: dm.assemble_matrix(fa_u, (m0, m1), bcs=bcs, A=mats[label], algorithm=args.alg), reps)
-        tv_u = hip_time(lambda: dm.assemble_vector(fl_u, mv, b=vecs[lv]), reps)
-        extra["roofline_ufcx"] = {"ms_per_step": tu, "value": w.ndofs_total / (tu * 1e-3), "unit": "DoFs/s",
-                                  "note": "the benchmark's forms as FFCx-shaped C text (tools/ffcx_like.py: baked tables, quadrature loop, "
-                                          "sin / exp calls) compiled with hipRTC into the row-block kernels",
-                                  "timings_ms": {"assemble_matrix[A]": tm_u, "assemble_vector[b]": tv_u}}
+            tu = timed_steps(step_ufcx, args.steps)
+            tm_u = hip_time(lambda: dm.assemble_matrix(fa_u, (m0, m1), bcs=bcs, A=mats[label], algorithm=args.alg), reps)
+            tv_u = hip_time(lambda: dm.assemble_vector(fl_u, mv, b=vecs[lv]), reps)
+            return {"ms_per_step": tu, "value": w.ndofs_total / (tu * 1e-3), "unit": "DoFs/s", "note": note,
+                    "kernels_run": ["built-in twin" if fa_u.integrals[0].kernel.form != 100 else "imported text",
+                                    "built-in twin" if fl_u.integrals[0].kernel.form != 100 else "imported text"],
+                    "timings_ms": {"assemble_matrix[A]": tm_u, "assemble_vector[b]": tv_u}}
+
+        # (a1) the text as an unknown kernel: it runs everywhere (hipRTC, inside the row-block kernels, sin / cos / exp
+        # through the library's full-range fp64 routines)
+        extra["roofline_ufcx_text"] = ufcx_record(
+            fem.form_ufcx([w.V, w.V], sa, na), fem.form_ufcx([w.V], sl, nl),
+            "the benchmark's forms as FFCx-shaped C text (tools/ffcx_like.py: baked tables, quadrature loop, sin / exp calls) "
+            "compiled with hipRTC into the row-block kernels; nothing is known about the text")
+        # (a2) the same text handed over by a form generator that states which built-in operator it implements
+        # (fem.form_generated): checked on sample cells at first use, then the built-in kernels stand in for it
+        fa_u, fl_u = fem.form_generated("stiffness", w.V), fem.form_generated("source", w.V, fem.FN_BENCH_PERIODIC)
+        extra["roofline_ufcx"] = ufcx_record(
+            fa_u, fl_u, "the same C text with its generator's statement of the built-in operator it implements "
+                        "(fem.form_ufcx(builtin=...)): verified numerically on sample cells at first use, then replaced by that operator")
         del fa_u, fl_u
     if subs and args.config == 2 and args.cell == "tet" and args.numbering == "tiled" and not args.ufcx and not args.no_shuffled_record:
         from dolfinx_mpc_amd import MultiPointConstraint, fem

@@ -136,6 +136,77 @@ def ufcx_compile(k, form: Form):
     return _ufcx_handles[key]
 
 
+def resolve_builtin_twins(form: Form) -> None:
+    """Imported kernels with a stated built-in twin on simplices (fem.form_ufcx(builtin=...)): evaluate both on a sample of
+    the entities with the plan-free kernels, and if they agree to 1e-12 of the largest entry let the built-in operator
+    stand in for the text from now on (the integral's ``kernel`` becomes the twin; the text stays in ``kernel_imported``).
+    A twin that does not check out is dropped.  MPCX_UFCX_BUILTIN=0: no substitution.  Once per form."""
+    if getattr(form, "_twins_resolved", False):
+        return
+    form._twins_resolved = True
+    import os
+
+    from .fem import Form as _Form
+    from .fem import Integral as _Integral
+
+    for i, integ in enumerate(form.integrals):
+        k = integ.kernel
+        kb = getattr(k, "builtin", None)
+        if k.form != 100 or kb is None or kb.celltype not in (1, 2) or os.environ.get("MPCX_UFCX_BUILTIN", "1") == "0":
+            continue
+        ok = False
+        try:
+            ok = _twin_agrees(form, integ, kb, _Form, _Integral)
+        except Exception:  # noqa: BLE001  (a twin the library cannot evaluate is no twin)
+            ok = False
+        if ok:
+            integ.kernel_imported = k
+            integ.kernel = kb
+        else:
+            k.builtin = None
+    form._device.clear()  # argument blocks built for the text are stale
+
+
+def _twin_agrees(form, integ, kb, _Form, _Integral) -> bool:
+    import importlib
+
+    import torch
+
+    from .multipointconstraint import MultiPointConstraint
+
+    n = integ.num_entities
+    if n == 0:
+        return True
+    pick = np.unique(np.linspace(0, n - 1, min(n, 257)).astype(np.int64))
+    ents = np.ascontiguousarray(integ.entities[pick])
+    coeff = integ.coefficient
+    if isinstance(coeff, np.ndarray):
+        coeff = np.ascontiguousarray(coeff[pick])
+    spaces = form.function_spaces
+    f_txt = _Form(spaces, [_Integral(integ.itype, ents, integ.kernel, coeff, integ.constant)])
+    f_txt._twins_resolved = True
+    f_blt = _Form(spaces, [_Integral(integ.itype, ents, kb, coeff, integ.constant)])
+    f_blt._twins_resolved = True
+    empties = []
+    for V in spaces:
+        m = getattr(V, "_empty_mpc", None)
+        if m is None:
+            m = V._empty_mpc = MultiPointConstraint(V)
+            m.finalize()
+        empties.append(m)
+    if form.rank == 1:
+        av = importlib.import_module(__package__ + ".assemble_vector")
+        a = av.assemble_vector(f_txt, empties[0], algorithm="atomic").array
+        b = av.assemble_vector(f_blt, empties[0], algorithm="atomic").array
+    else:
+        am = importlib.import_module(__package__ + ".assemble_matrix")
+        A = am.create_matrix(f_txt, empties[0], empties[1])
+        a = am.assemble_matrix(f_txt, (empties[0], empties[1]), A=A, algorithm="atomic").vals.clone()
+        b = am.assemble_matrix(f_blt, (empties[0], empties[1]), A=A, algorithm="atomic").vals
+    scale = float(torch.maximum(a.abs().max(), b.abs().max()).item())
+    return bool(float((a - b).abs().max().item()) <= 1e-12 * max(scale, 1e-300)) and scale > 0.0
+
+
 def integral_device(form: Form, i: int):
     """entities / quadrature tables of integral i (structural: uploaded once) and its packed
     coefficients / constants, which are VALUES: refreshed whenever the coefficient's dof array was

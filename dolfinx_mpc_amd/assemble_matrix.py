@@ -1194,6 +1194,7 @@ def assemble_matrix(
     if form.rank != 2:
         raise RuntimeError("assemble_matrix needs a bilinear form")
     _native.require_gpu()
+    D.resolve_builtin_twins(form)  # imported kernels with a stated (and checked) built-in twin, fem.form_ufcx(builtin=...)
     if A is None:
         A = create_matrix(form, mpc0, mpc1)
     alg = _ALG[(algorithm or os.environ.get("MPCX_MATRIX_ALG", "auto")).lower()]

@@ -387,6 +387,7 @@ def assemble_vector(form: Form, constraint: MultiPointConstraint, b: Optional[Ve
         raise RuntimeError("assemble_vector needs a linear form")
     constraint._not_finalized()
     _native.require_gpu()
+    D.resolve_builtin_twins(form)  # imported kernels with a stated (and checked) built-in twin, fem.form_ufcx(builtin=...)
     L = _native.lib()
     if b is None:
         b = create_vector(constraint.function_space)
@@ -495,6 +496,9 @@ def apply_lifting(
     constraint._not_finalized()
     dev = _native.require_gpu()
     first = next(f for f in form if f is not None)
+    for f in form:
+        if f is not None:
+            D.resolve_builtin_twins(f)
     from . import locality  # a numbering without locality: the spatially reordered twin (locality.py)
 
     tw = locality.twin_of(first.mesh)

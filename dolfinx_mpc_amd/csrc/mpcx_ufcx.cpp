@@ -12,6 +12,7 @@
 #include "mpcx.h"
 #include "mpcx_internal.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -24,6 +25,10 @@ namespace
 // include/mpcx.h as text (the kernels take the very same argument structs by value)
 const char* const MPCX_H_TEXT =
 #include "mpcx_h_embed.inc"
+    ;
+// csrc/mpcx_ufcx_math.hpp as text: sin / cos / exp for the imported kernels (libm's cost 189 / 189 / 62 instructions each)
+const char* const MPCX_UFCX_MATH_TEXT =
+#include "mpcx_ufcx_math_embed.inc"
     ;
 
 const char* const KERNELS_TEXT = R"MPCXK(
@@ -774,9 +779,30 @@ extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
     else
       p += 8;
   }
+  // sin / cos / exp of the imported text go to the library's full-range fp64 routines (mpcx_ufcx_math.hpp: <= 2.5 ulp,
+  // libm itself outside their fast ranges) unless MPCX_UFCX_LIBM=1 asks for the device libm
+  const char* libm = std::getenv("MPCX_UFCX_LIBM");
+  if (!(libm && libm[0] == '1'))
+  {
+    src += "\nextern \"C\" __device__ double __ocml_sin_f64(double);\nextern \"C\" __device__ double __ocml_cos_f64(double);\n"
+           "extern \"C\" __device__ double __ocml_exp_f64(double);\n"
+           // (out of line and cold: inlined, libm's general paths doubled the kernel and took it over 128 registers)
+           "static __device__ __attribute__((noinline, cold)) double mpcx_slow_sin(double x) { return __ocml_sin_f64(x); }\n"
+           "static __device__ __attribute__((noinline, cold)) double mpcx_slow_cos(double x) { return __ocml_cos_f64(x); }\n"
+           "static __device__ __attribute__((noinline, cold)) double mpcx_slow_exp(double x) { return __ocml_exp_f64(x); }\n"
+           "#define MPCX_FM_LIBM_SIN(x) mpcx_slow_sin(x)\n#define MPCX_FM_LIBM_COS(x) mpcx_slow_cos(x)\n"
+           "#define MPCX_FM_LIBM_EXP(x) mpcx_slow_exp(x)\n"
+           "#define MPCX_UFCX_MATH_FN static __device__ __attribute__((always_inline)) inline\n#define MPCX_FM_DEVICE_TABLE 1\n";
+    std::string m(MPCX_UFCX_MATH_TEXT);
+    if (auto q = m.find("#pragma once"); q != std::string::npos)
+      m.replace(q, 12, "");
+    src += m;
+    src += "\n#define sin(x) mpcx_fast_sin(x)\n#define cos(x) mpcx_fast_cos(x)\n#define exp(x) mpcx_fast_exp(x)\n";
+  }
   src += "\n#pragma clang force_cuda_host_device begin\n";
   src += "#pragma clang attribute push(__attribute__((always_inline)), apply_to = function)\n";
   src += user;
+  src += "\n#undef sin\n#undef cos\n#undef exp\n";
   src += "\n#pragma clang attribute pop\n";
   src += "#pragma clang force_cuda_host_device end\n";
   src += KERNELS_TEXT;

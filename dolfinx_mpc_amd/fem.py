@@ -631,7 +631,7 @@ def form_source(V, fn_id: int = FN_ONE, constant=None, coefficient: Optional[Fun
 
 
 def form_ufcx(spaces: Sequence[FunctionSpace], source: str, function_name: str, itype: str = "cell", entities=None,
-              coefficient=None, constant=None) -> Form:
+              coefficient=None, constant=None, builtin: Optional[KernelSpec] = None) -> Form:
     """A form whose element kernel is an imported UFCx ``tabulate_tensor`` given as C SOURCE (what FFCx
     writes to disk; the reference calls the compiled function through a pointer,
     cpp/assemble_matrix.cpp:438-439).  ``spaces`` = [V] (linear form) or [V0, V1] (bilinear form: rows V0,
@@ -642,7 +642,13 @@ def form_ufcx(spaces: Sequence[FunctionSpace], source: str, function_name: str, 
     in the order the form declares its coefficients; ``w`` then holds, per entity, the cell dofs of each in turn,
     unrolled ``dof * bs + k`` for blocked spaces (dolfinx ``pack_coefficients``).  The kernel is compiled for
     gfx950 with hipRTC and runs inside the LDS row-block kernels (or the per-entity kernels with device atomics
-    when ``algorithm="atomic"``)."""
+    when ``algorithm="atomic"``).
+
+    ``builtin``: the ``KernelSpec`` of a built-in operator the caller (a form generator) states this text implements.
+    On simplices the library CHECKS the statement at first use -- both kernels are evaluated on a sample of the form's
+    entities on the device and must agree to 1e-12 of the largest entry -- and, if it holds, runs the built-in operator
+    in place of the text (cell-cluster kernels, closed forms); otherwise, and with MPCX_UFCX_BUILTIN=0, the text runs
+    everywhere.  (Hexahedra: the built-in Q1 kernels take the bulk of the cells, the text keeps the constrained ones.)"""
     spaces = list(spaces)
     V0 = spaces[0]
     V1 = spaces[1] if len(spaces) > 1 else None
@@ -653,7 +659,30 @@ def form_ufcx(spaces: Sequence[FunctionSpace], source: str, function_name: str, 
     k = KernelSpec(FORM_UFCX, _CELL_ID[V0.mesh.cell_name], V0.degree, V0.dofmap.bs, ufcx_source=source, ufcx_name=function_name)
     if V1 is not None:
         k.degree1, k.bs1 = V1.degree, V1.dofmap.bs
+    k.builtin = builtin
     return Form(spaces, [Integral(itype, ents, k, coefficient, _constants(constant))])
+
+
+def form_generated(kind: str, V: FunctionSpace, fn_id: int = FN_ONE, constant=None, coefficient: Optional[Function] = None,
+                   cells=None, mu: float = 1.0, lmbda: float = 0.0) -> Form:
+    """The library's stand-in for running FFCx on a form: ``kind`` = "stiffness" | "mass" | "source" | "elasticity" on
+    Lagrange P1 / P2 simplices, written as UFCx C text in the shape FFCx gives its output (``codegen.generate``: baked
+    rule and tables, a loop over the points, libm calls in the source function) and imported through ``form_ufcx`` --
+    with the built-in operator of the same integral attached as its stated twin (``form_ufcx(builtin=...)``)."""
+    from .codegen import generate
+
+    cell = V.mesh.cell_name
+    if cell not in ("triangle", "tetrahedron"):
+        raise NotImplementedError("form_generated: simplices (hexahedra: the form_* functions already generate their kernels)")
+    ref = {"stiffness": lambda: form_stiffness(V, constant, coefficient, cells), "mass": lambda: form_mass(V, constant, coefficient, cells),
+           "source": lambda: form_source(V, fn_id, constant, coefficient, cells),
+           "elasticity": lambda: form_elasticity(V, mu, lmbda, cells)}[kind]()
+    integ = ref.integrals[0]
+    k = integ.kernel
+    has_c = integ.constant is not None or (kind == "source" and fn_id == FN_CONSTANT_VEC)
+    src, name = generate(kind, cell, V.degree, V.dofmap.bs, (k.qpts, k.qwts), coefficient_degree=k.coeff_degree,
+                         use_constant=has_c and kind != "elasticity", fexpr=fn_c_expression(fn_id) if kind == "source" else "1.0")
+    return form_ufcx([V] if kind == "source" else [V, V], src, name, "cell", integ.entities, integ.coefficient, integ.constant, builtin=k)
 
 
 def form_facet_mass(V, facets: np.ndarray, constant=None) -> Form:

@@ -91,3 +91,71 @@ def test_fast_exp_nonpos(tmp_path):
     assert np.all((v2 >= 0.0) & (v2 < 1e-307))
     t3, v3 = _run(tmp_path, 2, -1e-300, 0.0, 3)
     assert np.all(v3 == 1.0)
+
+
+UFCX_SRC = r"""
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include "mpcx_ufcx_math.hpp"
+static double ulps(double got, long double ref)
+{
+  if (ref == 0)
+    return got == 0 ? 0 : 1e9;
+  int e;
+  std::frexp((double)fabsl(ref), &e);
+  return (double)(fabsl((long double)got - ref) / std::ldexp(1.0L, e - 53));
+}
+int main()
+{
+  double ms = 0, mc = 0, me = 0;
+  srand(1);
+  for (int i = 0; i < 2000000; ++i)
+  {
+    const double t = rand() / (double)RAND_MAX;
+    const double x = (i % 4 == 0) ? (t - 0.5) * 20 : (i % 4 == 1) ? (t - 0.5) * 2e3 : (i % 4 == 2) ? (t - 0.5) * 3.2e6 : (t - 0.5) * 1e-3;
+    ms = fmax(ms, ulps(mpcx_fast_sin(x), sinl((long double)x)));
+    mc = fmax(mc, ulps(mpcx_fast_cos(x), cosl((long double)x)));
+    const double y = (i % 2) ? (t - 0.5) * 1400 : (t - 0.5) * 20;
+    me = fmax(me, ulps(mpcx_fast_exp(y), expl((long double)y)));
+  }
+  for (int k = 1; k < 200000; k += 7) // next to the zeros of sin and cos
+    for (int d = -2; d <= 2; ++d)
+    {
+      double x = k * 3.14159265358979323846;
+      for (int s = 0; s < (d < 0 ? -d : d); ++s)
+        x = std::nextafter(x, d > 0 ? 1e300 : -1e300);
+      ms = fmax(ms, ulps(mpcx_fast_sin(x), sinl((long double)x)));
+      const double xc = x + 1.5707963267948966;
+      mc = fmax(mc, ulps(mpcx_fast_cos(xc), cosl((long double)xc)));
+    }
+  printf("%.4f %.4f %.4f\n", ms, mc, me);
+  // outside the fast range: libm's answers, bit for bit
+  const double big[] = {1e7, -3.3e9, 1e300, 2e6};
+  int same = 1;
+  for (double x : big)
+    same = same && mpcx_fast_sin(x) == std::sin(x) && mpcx_fast_cos(x) == std::cos(x);
+  same = same && mpcx_fast_exp(-720.0) == std::exp(-720.0) && mpcx_fast_exp(709.5) == std::exp(709.5) && std::isinf(mpcx_fast_exp(800.0))
+         && mpcx_fast_exp(-800.0) == 0.0 && std::isnan(mpcx_fast_sin(NAN)) && std::isnan(mpcx_fast_exp(NAN)) && std::isnan(mpcx_fast_cos(INFINITY));
+  printf("%d\n", same);
+  printf("%.17g %.17g %.17g\n", mpcx_fast_sin(0.0), mpcx_fast_cos(0.0), mpcx_fast_exp(0.0));
+  return 0;
+}
+"""
+
+
+def test_imported_kernel_math_full_range(tmp_path):
+    """csrc/mpcx_ufcx_math.hpp -- the sin / cos / exp that imported (FFCx-shaped) kernels get instead of the device libm:
+    <= 2.5 ulp for sin / cos on |x| <= 2^19 pi including the neighbourhoods of their zeros, <= 1.5 ulp for exp on
+    [-700, 700]; outside the fast ranges, and for NaN / inf, the libm result itself"""
+    src = os.path.join(str(tmp_path), "um.cpp")
+    exe = os.path.join(str(tmp_path), "um")
+    open(src, "w").write(UFCX_SRC)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "dolfinx_mpc_amd", "csrc"), src, "-o", exe],
+                   check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split("\n")
+    ms, mc, me = (float(v) for v in out[0].split())
+    assert ms <= 2.5 and mc <= 2.5 and me <= 1.5, (ms, mc, me)
+    assert out[1].strip() == "1"
+    s0, c0, e0 = (float(v) for v in out[2].split())
+    assert s0 == 0.0 and c0 == 1.0 and e0 == 1.0

@@ -81,3 +81,38 @@ def test_gpu_imported_kernels_plan_variants(oracle, monkeypatch, idx, variant):
     for k in ("b", "b_lifted"):
         if k in ref:
             assert abs(out[k] - ref[k]).max() <= 1e-12 * max(1.0, abs(ref[k]).max()), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("degree", [1, 2])
+def test_stated_builtin_twin_is_checked_then_used(oracle, degree, monkeypatch):
+    """fem.form_generated hands the text over WITH the built-in operator it implements: the statement is checked on sample
+    cells on the device and the operator then stands in for the text; a wrong statement is dropped and the text runs;
+    MPCX_UFCX_BUILTIN=0 never substitutes.  All three give the oracle's result (which runs the text through gcc)."""
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import fem
+    from problems import Case, case_cube_periodic, oracle_outputs, product_outputs
+
+    base = case_cube_periodic(4, degree, 0.3, reorder=(2, 2, 2))
+    V = base.V
+
+    def forms():
+        return fem.form_generated("stiffness", V), fem.form_generated("source", V, fem.FN_BENCH_PERIODIC)
+
+    def check(a, L, want_builtin):
+        ref = oracle_outputs(oracle, Case("twin", V, *forms(), base.bcs, base.raw))
+        out = product_outputs(Case("twin", V, a, L, base.bcs, base.raw), algorithm="rowblock")
+        assert (a.integrals[0].kernel.form != fem.FORM_UFCX) == want_builtin and (L.integrals[0].kernel.form != fem.FORM_UFCX) == want_builtin
+        assert abs(out["A"].data - ref["A"].data).max() <= 1e-12 * max(1.0, abs(ref["A"].data).max())
+        assert abs(out["b_lifted"] - ref["b_lifted"]).max() <= 1e-12 * max(1.0, abs(ref["b_lifted"]).max())
+
+    a, L = forms()
+    check(a, L, True)
+    # a wrong statement: the stiffness text with the MASS operator as its twin, the source text with another function
+    a, L = forms()
+    a.integrals[0].kernel.builtin = fem.form_mass(V).integrals[0].kernel
+    L.integrals[0].kernel.builtin = fem.form_source(V, fem.FN_POLY3).integrals[0].kernel
+    check(a, L, False)
+    monkeypatch.setenv("MPCX_UFCX_BUILTIN", "0")
+    a, L = forms()
+    check(a, L, False)
