@@ -11,6 +11,19 @@ from . import _native
 from .fem import Form, FunctionSpace, Integral
 
 
+def _update_dev(old, a: np.ndarray, dev):
+    """``a`` on the device, written INTO ``old`` when that is a device tensor of the same shape and dtype (argument blocks,
+    cached plans and captured HIP graphs hold its address), a new tensor otherwise"""
+    import torch
+
+    if old is not None and isinstance(old, torch.Tensor) and tuple(old.shape) == tuple(a.shape) and old.is_contiguous():
+        src = torch.from_numpy(np.ascontiguousarray(a))
+        if src.dtype == old.dtype:
+            old.copy_(src)
+            return old
+    return _to_dev(a, dev)
+
+
 def _to_dev(a: np.ndarray, dev):
     import warnings
 
@@ -262,7 +275,7 @@ def integral_device(form: Form, i: int):
     c = integ.constants
     if c is not None and (d["constants_host"] is None or not np.array_equal(c, d["constants_host"])):
         d["constants_host"] = c.copy()
-        d["constants"] = _to_dev(d["constants_host"], dev)
+        d["constants"] = _update_dev(d.get("constants"), d["constants_host"], dev)
     return d
 
 
@@ -305,7 +318,7 @@ def _refresh_coefficients(form: Form, integ: Integral, d: dict, dev):
     if isinstance(integ.coefficient, np.ndarray):  # packed by the caller
         if d["coeff_host"] is None or not same_values(integ.coefficient, d["coeff_host"]):
             d["coeff_host"] = integ.coefficient.copy()
-            d["coeffs"] = _to_dev(integ.coefficient.astype(np.float64, copy=False), dev)
+            d["coeffs"] = _update_dev(d["coeffs"], integ.coefficient.astype(np.float64, copy=False), dev)
         return
     fs = integ.coefficient_functions
     if d["coeff_host"] is None:
@@ -315,7 +328,7 @@ def _refresh_coefficients(form: Form, integ: Integral, d: dict, dev):
         cur = f.x._data
         if slot[0] is None or not same_values(cur, slot[0]):
             slot[0] = cur.copy()
-            slot[1] = _to_dev(slot[0], dev)
+            slot[1] = _update_dev(slot[1], slot[0], dev)
             dirty = True
     if not dirty and d["coeffs"] is not None:
         return
@@ -330,7 +343,11 @@ def _refresh_coefficients(form: Form, integ: Integral, d: dict, dev):
         if bs > 1:
             dofs = (dofs[:, :, None] * bs + torch.arange(bs, device=dev)[None, None, :]).reshape(n, -1)
         parts.append(slot[1][dofs])
-    d["coeffs"] = (parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)).contiguous()
+    new = (parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)).contiguous()
+    if d["coeffs"] is not None and d["coeffs"].shape == new.shape:
+        d["coeffs"].copy_(new)  # in place: argument blocks / captured graphs keep reading the same tensor
+    else:
+        d["coeffs"] = new
 
 
 def bc_markers(V: FunctionSpace, bcs, cache: dict):
