@@ -259,6 +259,7 @@ def integral_device(form: Form, i: int):
             int(k.qwts.size), int(k.fqwts.size),
             d["qpts"].data_ptr(), d["qwts"].data_ptr(), d["fqpts"].data_ptr(), d["fqwts"].data_ptr(),
             ufcx_compile(k, form) if k.form == 100 else None, None if qphi is None else qphi.data_ptr(),
+            _native.scalar_id(getattr(form, "dtype", np.float64)),
         )
         kb = getattr(k, "builtin", None)
         d["kernel_builtin"] = None
@@ -267,12 +268,14 @@ def integral_device(form: Form, i: int):
             d["kernel_builtin"] = _native.KernelT(
                 kb.form, kb.celltype, kb.degree, kb.bs, kb.degree1 or kb.degree, kb.bs1 or kb.bs, kb.fn_id, kb.coeff_degree,
                 int(kb.qwts.size), 0, d["qpts_b"].data_ptr(), d["qwts_b"].data_ptr(), d["fqpts"].data_ptr(), d["fqwts"].data_ptr(),
-                None, None)
+                None, None, 0)
         form._device[key] = d
     d = form._device[key]
     if integ.coefficient is not None:
         _refresh_coefficients(form, integ, d, dev)
     c = integ.constants
+    if c is not None:
+        c = c.astype(getattr(form, "dtype", np.float64), copy=False)  # (the form's scalar type: the kernels read T)
     if c is not None and (d["constants_host"] is None or not np.array_equal(c, d["constants_host"])):
         d["constants_host"] = c.copy()
         d["constants"] = _update_dev(d.get("constants"), d["constants_host"], dev)
@@ -315,10 +318,11 @@ def _refresh_coefficients(form: Form, integ: Integral, d: dict, dev):
     plumbing)."""
     import torch
 
+    T = np.dtype(getattr(form, "dtype", np.float64))  # the form's scalar type: the kernels read packed values of T
     if isinstance(integ.coefficient, np.ndarray):  # packed by the caller
         if d["coeff_host"] is None or not same_values(integ.coefficient, d["coeff_host"]):
             d["coeff_host"] = integ.coefficient.copy()
-            d["coeffs"] = _update_dev(d["coeffs"], integ.coefficient.astype(np.float64, copy=False), dev)
+            d["coeffs"] = _update_dev(d["coeffs"], integ.coefficient.astype(T, copy=False), dev)
         return
     fs = integ.coefficient_functions
     if d["coeff_host"] is None:
@@ -328,7 +332,7 @@ def _refresh_coefficients(form: Form, integ: Integral, d: dict, dev):
         cur = f.x._data
         if slot[0] is None or not same_values(cur, slot[0]):
             slot[0] = cur.copy()
-            slot[1] = _update_dev(slot[1], slot[0], dev)
+            slot[1] = _update_dev(slot[1], slot[0].astype(T, copy=False), dev)
             dirty = True
     if not dirty and d["coeffs"] is not None:
         return
@@ -367,7 +371,7 @@ def bc_markers(V: FunctionSpace, bcs, cache: dict):
     return cached(cache, "bcm", [V] + mine, str(dev), build)
 
 
-def bc_values(V: FunctionSpace, bcs, cache: dict):
+def bc_values(V: FunctionSpace, bcs, cache: dict, dtype=np.float64):
     """(host markers, device markers, device values) over the unrolled dofs of V for lifting
     (cpp/lifting.h:166-180).  The markers and dof lists are structural and cached per (space, bcs);
     the VALUES are read from the live bc objects on every call -- a time-dependent boundary function
@@ -384,10 +388,10 @@ def bc_values(V: FunctionSpace, bcs, cache: dict):
             bc.dof_indices()  # settles the owned-first order of bc._dofs
             bc.mark_dofs(markers)
         return {"markers": markers, "d_markers": _to_dev(markers, dev),
-                "d_values": torch.zeros(V.num_dofs, dtype=torch.float64, device=dev),
+                "d_values": torch.from_numpy(np.zeros(V.num_dofs, dtype=dtype)).to(dev),
                 "d_dofs": [_to_dev(bc._dofs.astype(np.int64), dev) for bc in bcs], "g": [None] * len(bcs)}
 
-    s = cached(cache, "lift", [V] + bcs, str(dev), build)
+    s = cached(cache, "lift", [V] + bcs, (str(dev), np.dtype(dtype).name), build)
     for k, bc in enumerate(bcs):
         g = bc.values_at_dofs()
         if s["g"][k] is None or not np.array_equal(g, s["g"][k]):
@@ -395,7 +399,7 @@ def bc_values(V: FunctionSpace, bcs, cache: dict):
             for k2 in range(k, len(bcs)):
                 g2 = bcs[k2].values_at_dofs()
                 s["g"][k2] = g2.copy()
-                s["d_values"][s["d_dofs"][k2]] = _to_dev(g2, dev)
+                s["d_values"][s["d_dofs"][k2]] = _to_dev(np.asarray(g2).astype(dtype, copy=False), dev)
             break
     return s["markers"], s["d_markers"], s["d_values"]
 

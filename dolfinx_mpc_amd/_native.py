@@ -34,7 +34,21 @@ class KernelT(C.Structure):
         ("fqwts", C.c_void_p),
         ("ufcx", C.c_void_p),
         ("qphi", C.c_void_p),
+        ("scalar_type", C.c_int32),
     ]
+
+
+# mpcx_kernel_t::scalar_type (include/mpcx.h MPCX_SCALAR_*): the reference's four instantiations
+SCALAR_TYPES = {"float64": 0, "float32": 1, "complex128": 2, "complex64": 3}
+
+
+def scalar_id(dtype) -> int:
+    import numpy as np
+
+    name = np.dtype(dtype).name
+    if name not in SCALAR_TYPES:
+        raise NotImplementedError(f"scalar type {name}: float32, float64, complex64, complex128 (python/src/dolfinx_mpc/multipointconstraint.py:55-64)")
+    return SCALAR_TYPES[name]
 
 
 class UfcxDescT(C.Structure):
@@ -234,6 +248,9 @@ EXPORTS = [
     "mpcx_cluster_canonical",
     "mpcx_rowblock_pairs_device",
     "mpcx_hbm_probe",
+    "mpcx_add_diagonal_scalar",
+    "mpcx_backsubstitution_scalar",
+    "mpcx_homogenize_scalar",
     "mpcx_csr_permutation",
     "mpcx_permute_values",
     "mpcx_pair_words",
@@ -443,6 +460,12 @@ def lib() -> C.CDLL:
     L.mpcx_cluster_build.restype = C.c_int
     L.mpcx_rowblock_pairs_device.argtypes = [i64, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]
     L.mpcx_rowblock_pairs_device.restype = C.c_int
+    L.mpcx_add_diagonal_scalar.argtypes = [i32, vp, vp, vp, vp, i64, dbl, dbl, vp]
+    L.mpcx_add_diagonal_scalar.restype = C.c_int
+    L.mpcx_backsubstitution_scalar.argtypes = [i32, vp, vp, i64, C.POINTER(MpcT), vp]
+    L.mpcx_backsubstitution_scalar.restype = C.c_int
+    L.mpcx_homogenize_scalar.argtypes = [i32, vp, vp, i64, vp]
+    L.mpcx_homogenize_scalar.restype = C.c_int
     L.mpcx_hbm_probe.argtypes = [vp, vp, i64, i32, vp]
     L.mpcx_hbm_probe.restype = C.c_int
     L.mpcx_csr_permutation.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]

@@ -165,7 +165,7 @@ def create_matrix(form: Form, mpc0: MultiPointConstraint, mpc1: Optional[MultiPo
     """python/src/dolfinx_mpc/mpc.cpp:321-344 ``cpp.mpc.create_matrix``."""
     mpc1 = mpc0 if mpc1 is None else mpc1
     rowptr, cols = create_sparsity_pattern(form, (mpc0, mpc1), keep_on_device=True)
-    A = MPCMatrix(rowptr, cols, mpc1.function_space.num_dofs)
+    A = MPCMatrix(rowptr, cols, mpc1.function_space.num_dofs, dtype=getattr(form, "dtype", None))
     # partitioned mesh: A.assemble() ships the interface rows to their owner (assemble_matrix.py:64)
     from .distributed import exchange_for
 
@@ -182,6 +182,12 @@ def create_matrix(form: Form, mpc0: MultiPointConstraint, mpc1: Optional[MultiPo
             if dist.is_available() and dist.is_initialized():
                 raise NotImplementedError("partitioned meshes: square blocks (test space == trial space) only")
     return A
+
+
+def _torch_dtype_of(dtype):
+    from .la import _torch_dtype
+
+    return _torch_dtype(dtype)
 
 
 def _slave_entities(form: Form, i: int, mpc0, mpc1):
@@ -987,6 +993,8 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
     # thin layers: a large layer of big elements would take the host minutes) | none (matrix_mpc_kernel: what a
     # caller of the bare C ABI gets with mpc_plan_off == NULL); MPCX_NO_MPC_PLAN=1 is the old spelling of none
     mode = "none" if os.environ.get("MPCX_NO_MPC_PLAN") else os.environ.get("MPCX_MPC_PLAN", "device").lower()
+    if _native.scalar_id(getattr(form, "dtype", np.float64)) != 0:
+        mode = "none"  # (the plan carries fp64 coefficients; the scalar-type kernels eliminate inside the entity loop)
     n0n1 = V0.element_ndofs * V0.dofmap.bs * V1.element_ndofs * V1.dofmap.bs
     if a.n_slave_entities > 0 and mode == "device" and max(V0.element_ndofs * V0.dofmap.bs,
                                                            V1.element_ndofs * V1.dofmap.bs) <= 32:
@@ -1198,10 +1206,22 @@ def assemble_matrix(
     if A is None:
         A = create_matrix(form, mpc0, mpc1)
     alg = _ALG[(algorithm or os.environ.get("MPCX_MATRIX_ALG", "auto")).lower()]
+    sid = _native.scalar_id(form.dtype)
+    if sid != 0:
+        # float32 / complex64 / complex128: the general per-entity kernels (csrc/mpcx_scalar.hip); the LDS row-block,
+        # cluster and pair kernels are fp64-real
+        if alg == 2:
+            raise NotImplementedError("algorithm='rowblock' is built for float64; float32 / complex forms take the per-entity kernels")
+        for m in (mpc0, mpc1):
+            if np.dtype(m.dtype) != form.dtype:
+                raise ValueError(f"form of scalar type {form.dtype} assembled with a constraint of {np.dtype(m.dtype)}")
+        if A.dtype != _torch_dtype_of(form.dtype):
+            raise ValueError("matrix and form of different scalar types")
+        alg = 1
     for integ in form.integrals:
         if integ.itype not in ("cell", "exterior_facet"):
             raise RuntimeError("Not implemented yet")  # cpp/assemble_matrix.cpp:658-659
-    if alg != 1:
+    if alg != 1 and sid == 0:
         # a numbering without locality: assemble on the spatially reordered twin, hand the values back in the caller's
         # numbering (dolfinx_mpc_amd/locality.py)
         from . import locality
@@ -1289,11 +1309,7 @@ def _assemble_matrix_on_stream(form: Form, mpc0, mpc1, bcs, diagval, A: MPCMatri
     if mpc0.function_space is mpc1.function_space:
         _, t = mpc0._device()
         ns = mpc0.num_local_slaves
-        _native.check(
-            L.mpcx_add_diagonal(A.shape[0], A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), A.vals.data_ptr(),
-                                t["slaves"].data_ptr(), ns, float(diagval), stream),
-            "mpcx_add_diagonal",
-        )
+        _add_diagonal(L, A, t["slaves"].data_ptr(), ns, diagval, stream, form)
     # Dirichlet diagonal: dolfinx insert_diagonal, python/src/dolfinx_mpc/assemble_matrix.py:59-62
     if form.function_spaces[0] is form.function_spaces[1]:
         for bc in bcs:
@@ -1304,12 +1320,20 @@ def _assemble_matrix_on_stream(form: Form, mpc0, mpc1, bcs, diagval, A: MPCMatri
                 return D._to_dev(dofs_h[:nowned], A.device)
 
             dofs = D.cached(form._device, "bcdofs", (bc,), str(A.device), owned_dofs, maxsize=16)
-            _native.check(
-                L.mpcx_add_diagonal(A.shape[0], A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), A.vals.data_ptr(),
-                                    dofs.data_ptr(), dofs.numel(), float(diagval), stream),
-                "mpcx_add_diagonal",
-            )
+            _add_diagonal(L, A, dofs.data_ptr(), dofs.numel(), diagval, stream, form)
     A.assemble()
+
+
+def _add_diagonal(L, A: MPCMatrix, dofs_ptr, n: int, diagval, stream, form: Form):
+    """A[d, d] += diagval for the listed dofs, in the matrix's scalar type"""
+    sid = _native.scalar_id(getattr(form, "dtype", np.float64))
+    if sid == 0:
+        _native.check(L.mpcx_add_diagonal(A.shape[0], A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), A.vals.data_ptr(), dofs_ptr, n,
+                                          float(diagval), stream), "mpcx_add_diagonal")
+    else:
+        dv = complex(diagval)
+        _native.check(L.mpcx_add_diagonal_scalar(sid, A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), A.vals.data_ptr(), dofs_ptr, n,
+                                                 dv.real, dv.imag, stream), "mpcx_add_diagonal_scalar")
 
 
 def _block_scalar_diagonals(A: MPCMatrix, form: Form, mpc0, mpc1, bcs, diagval):

@@ -389,13 +389,21 @@ def assemble_vector(form: Form, constraint: MultiPointConstraint, b: Optional[Ve
     _native.require_gpu()
     D.resolve_builtin_twins(form)  # imported kernels with a stated (and checked) built-in twin, fem.form_ufcx(builtin=...)
     L = _native.lib()
+    sid = _native.scalar_id(form.dtype)
     if b is None:
-        b = create_vector(constraint.function_space)
+        b = create_vector(constraint.function_space, dtype=form.dtype)
     alg = _ALG[(algorithm or os.environ.get("MPCX_VECTOR_ALG", "auto")).lower()]
+    if sid != 0:
+        # float32 / complex64 / complex128: the general per-entity kernel (csrc/mpcx_scalar.hip)
+        if alg == 2:
+            raise NotImplementedError("algorithm='rowblock' is built for float64; float32 / complex forms take the per-entity kernels")
+        if np.dtype(constraint.dtype) != form.dtype:
+            raise ValueError(f"form of scalar type {form.dtype} assembled with a constraint of {np.dtype(constraint.dtype)}")
+        alg = 1
     for integ in form.integrals:
         if integ.itype not in ("cell", "exterior_facet"):
             raise RuntimeError("Interior facet integrals currently not supported")
-    if alg != 1:
+    if alg != 1 and sid == 0:
         from . import locality  # a numbering without locality: the spatially reordered twin (locality.py)
 
         tw = locality.twin_of(form.mesh)
@@ -501,7 +509,7 @@ def apply_lifting(
             D.resolve_builtin_twins(f)
     from . import locality  # a numbering without locality: the spatially reordered twin (locality.py)
 
-    tw = locality.twin_of(first.mesh)
+    tw = locality.twin_of(first.mesh) if _native.scalar_id(first.dtype) == 0 else None
     if tw is not None:
         try:
             return locality.apply_lifting(tw, b, form, bcs, constraint, x0, scale)
@@ -514,7 +522,7 @@ def apply_lifting(
             continue
         V0, V1 = aj.function_spaces
         # bc markers / values over the column space, cpp/lifting.h:166-180 (values read live)
-        markers, d_markers, d_values = D.bc_values(V1, bcs[j], aj._device)
+        markers, d_markers, d_values = D.bc_values(V1, bcs[j], aj._device, aj.dtype)
         md = D.mesh_device(aj.mesh)
         s0, s1 = D.space_device(V0), D.space_device(V1)
         x0j = None

@@ -12,6 +12,10 @@ int launch_matrix_cubes(const mpcx_matrix_args_t& a);
 int launch_vector_cubes(const mpcx_vector_args_t& a);
 // pair records + cached entity contexts (plan.row_pairs == 2), mpcx_pairs.hip
 int launch_matrix_pairs(const mpcx_matrix_args_t& a);
+// scalar types other than fp64 real (mpcx_kernel_t::scalar_type != 0), mpcx_scalar.hip
+int launch_matrix_scalar(const mpcx_matrix_args_t& a);
+int launch_vector_scalar(const mpcx_vector_args_t& a);
+int launch_lifting_scalar(const mpcx_lifting_args_t& a);
 // imported UFCx kernels, mpcx_ufcx.cpp
 int launch_matrix_ufcx(const mpcx_matrix_args_t& a);
 int launch_vector_ufcx(const mpcx_vector_args_t& a);

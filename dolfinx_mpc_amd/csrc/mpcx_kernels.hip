@@ -2087,6 +2087,8 @@ extern "C" int mpcx_assemble_matrix(const mpcx_matrix_args_t* args)
 {
   const mpcx_matrix_args_t& a = *args;
   const mpcx_kernel_t& k = a.kernel;
+  if (k.scalar_type != MPCX_SCALAR_F64)
+    return launch_matrix_scalar(a);
   if (k.form == MPCX_FORM_UFCX)
     return launch_matrix_ufcx(a);
   if (k.celltype == MPCX_CELL_HEXAHEDRON)
@@ -2133,6 +2135,8 @@ extern "C" int mpcx_assemble_vector(const mpcx_vector_args_t* args)
 {
   const mpcx_vector_args_t& a = *args;
   const mpcx_kernel_t& k = a.kernel;
+  if (k.scalar_type != MPCX_SCALAR_F64)
+    return launch_vector_scalar(a);
   if (k.form == MPCX_FORM_UFCX)
     return launch_vector_ufcx(a);
   if (a.algorithm == MPCX_ALG_CUBE)
@@ -2161,6 +2165,8 @@ extern "C" int mpcx_apply_lifting(const mpcx_lifting_args_t* args)
 {
   const mpcx_lifting_args_t& a = *args;
   const mpcx_kernel_t& k = a.kernel;
+  if (k.scalar_type != MPCX_SCALAR_F64)
+    return launch_lifting_scalar(a);
   if (k.form == MPCX_FORM_UFCX)
     return launch_lifting_ufcx(a);
   switch (k.form)

@@ -235,8 +235,8 @@ class _Vector:
     they uploaded on every assembly call and refresh when they differ -- the reference packs coefficients
     and reads boundary values on every call (cpp/assemble_matrix.cpp:587-589, cpp/lifting.h:166-180)."""
 
-    def __init__(self, n: int):
-        self._data = np.zeros(n, dtype=np.float64)
+    def __init__(self, n: int, dtype=np.float64):
+        self._data = np.zeros(n, dtype=dtype)
 
     @property
     def array(self) -> np.ndarray:
@@ -252,20 +252,25 @@ class Constant:
     assemblers pack it on every call (cpp/assemble_matrix.cpp:583-585)."""
 
     def __init__(self, value):
-        self.value = np.atleast_1d(np.asarray(value, dtype=np.float64)).copy()
+        v = np.atleast_1d(np.asarray(value))
+        self.value = v.astype(np.complex128 if np.iscomplexobj(v) else np.float64).copy()
 
 
 class Function:
     """Nodal coefficient (packed per cell like dolfinx ``pack_coefficients``,
     cpp/assemble_matrix.cpp:587-589)."""
 
-    def __init__(self, V: FunctionSpace):
+    def __init__(self, V: FunctionSpace, dtype=np.float64):
         self.function_space = V
-        self.x = _Vector(V.num_dofs)
+        self.x = _Vector(V.num_dofs, dtype)
+
+    @property
+    def dtype(self):
+        return self.x._data.dtype
 
     def interpolate(self, f: Callable[[np.ndarray], np.ndarray]):
         V = self.function_space
-        vals = np.asarray(f(V.tabulate_dof_coordinates().T), dtype=np.float64)
+        vals = np.asarray(f(V.tabulate_dof_coordinates().T), dtype=self.x._data.dtype)
         bs = V.dofmap.bs
         if bs == 1:
             self.x.array[:] = vals.reshape(-1)
@@ -310,9 +315,10 @@ class DirichletBC:
             return v.x._data[self._dofs]
         if isinstance(v, Constant):
             v = v.value
-        v = np.asarray(v, dtype=np.float64)
+        v = np.asarray(v)
+        v = v.astype(np.complex128 if np.iscomplexobj(v) else np.float64, copy=False)
         if v.ndim == 0 or v.size == 1:
-            return np.full(self._dofs.size, float(v.reshape(-1)[0]))
+            return np.full(self._dofs.size, v.reshape(-1)[0])
         bs = self.function_space.dofmap.bs
         return v.reshape(-1)[self._dofs % bs] if v.size == bs else v.reshape(-1)[self._dofs]
 
@@ -438,7 +444,8 @@ class Integral:
         c = self.constant
         if c is None:
             return None
-        return np.atleast_1d(np.asarray(c.value if isinstance(c, Constant) else c, dtype=np.float64))
+        v = np.atleast_1d(np.asarray(c.value if isinstance(c, Constant) else c))
+        return v.astype(np.complex128 if np.iscomplexobj(v) else np.float64, copy=False)
 
     @property
     def estride(self) -> int:
@@ -456,18 +463,32 @@ class Integral:
 class Form:
     """Compiled-form stand-in: ``rank``, ``function_spaces``, integrals."""
 
-    def __init__(self, function_spaces: Sequence[FunctionSpace], integrals: Sequence[Integral]):
+    def __init__(self, function_spaces: Sequence[FunctionSpace], integrals: Sequence[Integral], dtype=np.float64):
         self.function_spaces = list(function_spaces)
         self.rank = len(self.function_spaces)
         self.integrals = list(integrals)
         self.mesh = self.function_spaces[0].mesh
         self._device = {}
+        # scalar type of the assembled tensor (``dolfinx.fem.form(a, dtype=...)``): float64 runs the tuned kernels,
+        # float32 / complex64 / complex128 the general ones (``set_dtype`` / the ``dtype`` argument of ``fem.form``)
+        self.dtype = np.dtype(dtype)
+
+    def set_dtype(self, dtype) -> "Form":
+        if np.dtype(dtype) != self.dtype:
+            self.dtype = np.dtype(dtype)
+            self._device.clear()
+        return self
 
     def __add__(self, other: "Form") -> "Form":
         assert self.rank == other.rank
         for a, b in zip(self.function_spaces, other.function_spaces):
             assert a is b
-        return Form(self.function_spaces, self.integrals + other.integrals)
+        return Form(self.function_spaces, self.integrals + other.integrals, np.result_type(self.dtype, other.dtype))
+
+
+def form(f: "Form", dtype=np.float64) -> "Form":
+    """``dolfinx.fem.form(a, dtype=...)``: the scalar type the form is assembled in"""
+    return f.set_dtype(dtype)
 
 
 def _coefficient_degree(coefficient: Optional[Function]) -> int:
@@ -497,7 +518,8 @@ def _constants(c):
     """a ``Constant`` is kept by reference (live value); raw numbers are frozen here"""
     if c is None or isinstance(c, Constant):
         return c
-    return np.atleast_1d(np.asarray(c, dtype=np.float64)).copy()
+    v = np.atleast_1d(np.asarray(c))
+    return v.astype(np.complex128 if np.iscomplexobj(v) else np.float64).copy()
 
 
 def _cell_kernel(V: FunctionSpace, form: int, qdeg: int, fn_id: int = 0, coeff_degree: int = 0) -> KernelSpec:

@@ -118,14 +118,26 @@ class _Pending:
         self.exchange.finish(self.handle)
 
 
-class Vector:
-    """fp64 vector over the local (owned + ghost) dofs, resident in HBM."""
+def _torch_dtype(dtype):
+    """numpy-style dtype (None = float64) as a torch dtype"""
+    import torch
 
-    def __init__(self, n: int, device=None):
+    if dtype is None:
+        return torch.float64
+    if isinstance(dtype, torch.dtype):
+        return dtype
+    return {"float64": torch.float64, "float32": torch.float32, "complex128": torch.complex128,
+            "complex64": torch.complex64}[np.dtype(dtype).name]
+
+
+class Vector:
+    """vector over the local (owned + ghost) dofs, resident in HBM (fp64 unless ``dtype`` says otherwise)."""
+
+    def __init__(self, n: int, device=None, dtype=None):
         import torch
 
         self.device = device if device is not None else _native.require_gpu()
-        self._array = torch.zeros(n, dtype=torch.float64, device=self.device)
+        self._array = torch.zeros(n, dtype=_torch_dtype(dtype), device=self.device)
         self._exchange = None  # distributed.SlabExchange of the space (partitioned meshes)
         self._pending = None
         self._ready = None  # event recorded at the end of an assembly on a side stream
@@ -190,10 +202,10 @@ class Vector:
         return self._array.numel()
 
 
-def create_vector(V) -> Vector:
+def create_vector(V, dtype=None) -> Vector:
     """a vector over the dofs of ``V``; on a partitioned mesh with an initialised process group it carries the
     space's interface exchange (distributed.exchange_for)"""
-    b = Vector(V.num_dofs)
+    b = Vector(V.num_dofs, dtype=dtype)
     from .distributed import exchange_for
 
     ex = exchange_for(V)
@@ -209,10 +221,11 @@ class MPCMatrix:
     arrays or as device tensors (the device pattern builder hands over tensors, so a 17 GB column
     array never visits the host unless somebody asks for ``A.cols``)."""
 
-    def __init__(self, rowptr, cols, ncols: int, device=None):
+    def __init__(self, rowptr, cols, ncols: int, device=None, dtype=None):
         import torch
 
         self.device = device if device is not None else _native.require_gpu()
+        self.dtype = _torch_dtype(dtype)  # scalar type of the values (fp64: the tuned kernels)
         if isinstance(rowptr, torch.Tensor):
             self.d_rowptr = rowptr.to(self.device, torch.int64)
             self._rowptr = None
@@ -254,7 +267,7 @@ class MPCMatrix:
         if self._vals is None:
             import torch
 
-            self._vals = torch.zeros(self.d_cols.numel(), dtype=torch.float64, device=self.device)
+            self._vals = torch.zeros(self.d_cols.numel(), dtype=self.dtype, device=self.device)
         if self._compact_stale:
             self._expand_compact()
         if self._pending is not None:

@@ -163,12 +163,14 @@ class MultiPointConstraint:
 
     Args:
         V: The function space
-        dtype: scalar type; only float64 is built into the HIP backend
+        dtype: scalar type of the coefficients: float64 (the tuned kernels), float32, complex64, complex128 (the general
+            per-entity kernels, csrc/mpcx_scalar.hip) -- the reference's four instantiations,
+            python/src/dolfinx_mpc/multipointconstraint.py:55-64
     """
 
     def __init__(self, V: FunctionSpace, dtype=np.float64):
-        if np.dtype(dtype) != np.float64:
-            raise NotImplementedError("the HIP backend is built for float64 only")
+        _native.scalar_id(dtype)  # (raises NotImplementedError for anything else)
+        dtype = np.dtype(dtype)
         self._slaves = np.array([], dtype=np.int32)
         self._masters = np.array([], dtype=np.int64)
         self._coeffs = np.array([], dtype=dtype)
@@ -217,9 +219,15 @@ class MultiPointConstraint:
         nowned = imap.size_local * V.dofmap.index_map_bs
         ns = self._slaves.size
         nm = self._masters.size
+        # the finalize routines move fp64 coefficients; any other scalar type rides along as its POSITION in the input
+        # (exactly representable) and is put in place afterwards
+        true_coeffs = None
+        if self._dtype != np.float64:
+            true_coeffs = np.ascontiguousarray(self._coeffs, dtype=self._dtype)
         raw = dict(slaves=np.ascontiguousarray(self._slaves, dtype=np.int32),
                    masters=np.ascontiguousarray(self._masters, dtype=np.int64),
-                   coeffs=np.ascontiguousarray(self._coeffs, dtype=np.float64),
+                   coeffs=(np.ascontiguousarray(self._coeffs, dtype=np.float64) if true_coeffs is None
+                           else np.arange(nm, dtype=np.float64)),
                    owners=np.ascontiguousarray(self._owners, dtype=np.int32),
                    offsets=np.ascontiguousarray(self._offsets, dtype=np.int32))
         assert raw["offsets"].size == ns + 1 and raw["offsets"][-1] == nm and raw["coeffs"].size == nm and raw["owners"].size == nm
@@ -233,6 +241,14 @@ class MultiPointConstraint:
         self._devt = None  # device tensors (filled by the device routine, or lazily from the host)
         if not (where.lower() == "device" and self._finalize_device(nd, nowned, ns, nm, raw)):
             self._finalize_host(nd, nowned, ns, nm, raw)
+        if true_coeffs is not None:
+            if self._devt is not None:
+                import torch
+
+                order = self._devt["coeffs"].to(torch.int64)
+                self._devt["coeffs"] = torch.from_numpy(true_coeffs).to(order.device)[order].contiguous()
+            else:
+                self._host["coeffs"] = np.ascontiguousarray(true_coeffs[self._host["coeffs"].astype(np.int64)])
         # single process: the extended function space is V itself
         # (cpp/mpc_helpers.h:165-168)
         self.finalized = True
@@ -737,6 +753,10 @@ class MultiPointConstraint:
         return AdjacencyList(self._h("owners"), self._h("moff"))
 
     @property
+    def dtype(self):
+        return self._dtype
+
+    @property
     def num_local_slaves(self) -> int:
         self._not_finalized()
         return self._num_local_slaves
@@ -774,13 +794,16 @@ class MultiPointConstraint:
             if u.function_space is not self.V:
                 raise ValueError("The input function has to be in the function space in the multi-point constraint")
             dev = _native.require_gpu()
-            arr = torch.from_numpy(u.x._data).to(dev)
+            arr = torch.from_numpy(u.x._data.astype(self._dtype, copy=False)).to(dev)
             kernel(arr)
             u.x.array[:] = arr.cpu().numpy()
             return
         arr = u.array if hasattr(u, "array") else u
-        if not isinstance(arr, torch.Tensor) or arr.dtype != torch.float64 or not arr.is_cuda:
-            raise TypeError("backsubstitution / homogenize need a fem.Function, a la.Vector or a float64 device tensor")
+        from .la import _torch_dtype
+
+        if not isinstance(arr, torch.Tensor) or arr.dtype != _torch_dtype(self._dtype) or not arr.is_cuda:
+            raise TypeError("backsubstitution / homogenize need a fem.Function, a la.Vector or a device tensor of the constraint's "
+                            "scalar type")
         kernel(arr)
 
     def backsubstitution(self, u) -> None:
@@ -789,9 +812,16 @@ class MultiPointConstraint:
 
         s, t = self._device()
 
+        sid = _native.scalar_id(self._dtype)
+
         def run(arr):
-            rc = _native.lib().mpcx_backsubstitution(arr.data_ptr(), t["slaves"].data_ptr(), t["slaves"].numel(),
-                                                     C.byref(s), torch.cuda.current_stream().cuda_stream)
+            if sid == 0:
+                rc = _native.lib().mpcx_backsubstitution(arr.data_ptr(), t["slaves"].data_ptr(), t["slaves"].numel(),
+                                                         C.byref(s), torch.cuda.current_stream().cuda_stream)
+            else:
+                assert _native.scalar_id(str(arr.dtype).replace("torch.", "")) == sid, "vector and constraint of different scalar types"
+                rc = _native.lib().mpcx_backsubstitution_scalar(sid, arr.data_ptr(), t["slaves"].data_ptr(), t["slaves"].numel(),
+                                                                C.byref(s), torch.cuda.current_stream().cuda_stream)
             _native.check(rc, "mpcx_backsubstitution")
 
         self._on_device(u, run)
@@ -803,8 +833,13 @@ class MultiPointConstraint:
         _, t = self._device()
 
         def run(arr):
-            rc = _native.lib().mpcx_homogenize(arr.data_ptr(), t["slaves"].data_ptr(), t["slaves"].numel(),
-                                               torch.cuda.current_stream().cuda_stream)
+            sid = _native.scalar_id(str(arr.dtype).replace("torch.", ""))
+            if sid == 0:
+                rc = _native.lib().mpcx_homogenize(arr.data_ptr(), t["slaves"].data_ptr(), t["slaves"].numel(),
+                                                   torch.cuda.current_stream().cuda_stream)
+            else:
+                rc = _native.lib().mpcx_homogenize_scalar(sid, arr.data_ptr(), t["slaves"].data_ptr(), t["slaves"].numel(),
+                                                          torch.cuda.current_stream().cuda_stream)
             _native.check(rc, "mpcx_homogenize")
 
         self._on_device(u, run)

@@ -88,6 +88,13 @@ typedef struct
   const void* ufcx;    /* form == MPCX_FORM_UFCX: handle from mpcx_ufcx_compile; NULL otherwise */
   const double* qphi;  /* DEVICE [nq][nd] values of the test space's scalar basis at the cell rule's points, or NULL:
                         * lets the P2 source kernel take its basis from scalar loads instead of re-evaluating it */
+  /* Scalar type T of the assembly (MPCX_SCALAR_*; 0 = fp64 real).  The reference instantiates the path for float32,
+   * float64, complex64, complex128 (cpp/assemble_matrix.cpp:729-812).  For T != fp64 the `double*` fields that carry
+   * VALUES -- vals / b, coeffs, constants, the constraints' coeffs, bc_values1, x0 -- point to arrays of T (complex:
+   * interleaved re, im), geometry and quadrature tables stay fp64, and the general per-entity kernels run
+   * (csrc/mpcx_scalar.hip: device atomics, no plan, row-side coefficients conjugated for complex T); built-in operators
+   * on simplices only. */
+  int32_t scalar_type;
 } mpcx_kernel_t;
 
 /* ------------------------------------------------------------------------
@@ -119,6 +126,11 @@ void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* desc);
 int64_t mpcx_ufcx_code_size(void* handle); /* bytes of the gfx950 code object */
 int mpcx_ufcx_code(void* handle, void* out); /* HOST out[mpcx_ufcx_code_size]: the code object (inspection, caching) */
 void mpcx_ufcx_free(void* handle);
+
+#define MPCX_SCALAR_F64 0
+#define MPCX_SCALAR_F32 1
+#define MPCX_SCALAR_C128 2
+#define MPCX_SCALAR_C64 3
 
 /* Finalized constraint as the kernels read it: the accessors of
  * cpp/MultiPointConstraint.h:155-199 (is_slave, masters, coefficients) as
@@ -802,6 +814,14 @@ int mpcx_csr_permutation(int32_t nrows, const mpcx_nnz_t* rowptr, const int32_t*
                          const int32_t* new_of_old1, const mpcx_nnz_t* rowptr2, const int32_t* cols2, void* src, int32_t wide,
                          int32_t* bad, void* stream);
 int mpcx_permute_values(int64_t n, const void* src, int32_t wide, const double* vals2, double* dst, void* stream);
+
+/* The small kernels of the path for any scalar type (mpcx_kernel_t::scalar_type; pointers DEVICE, values of that type):
+ * vals[pos(d, d)] += (re + i im) for d in dofs (cpp/assemble_matrix.cpp:711-724 and dolfinx insert_diagonal),
+ * u[s] = sum_j c_j u[m_j] (cpp/MultiPointConstraint.h:129-145, no conjugation), u[s] = 0 (:147-152). */
+int mpcx_add_diagonal_scalar(int32_t scalar_type, const mpcx_nnz_t* rowptr, const int32_t* cols, void* vals, const int32_t* dofs,
+                             int64_t n, double re, double im, void* stream);
+int mpcx_backsubstitution_scalar(int32_t scalar_type, void* u, const int32_t* slaves, int64_t n, const mpcx_mpc_t* mpc, void* stream);
+int mpcx_homogenize_scalar(int32_t scalar_type, void* u, const int32_t* slaves, int64_t n, void* stream);
 
 /* HBM bandwidth probe (the denominator bench.py prints next to the 8 TB/s specification): 16 bytes per lane and access,
  * grid-stride over `bytes` of DEVICE memory; mode 0 copy dst = src, 1 read src only, 2 write dst only. */
