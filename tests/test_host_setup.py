@@ -169,8 +169,15 @@ def test_add_constraint_concatenation_and_finalize_once():
     with pytest.raises(RuntimeError, match="already been finalized"):
         mpc.add_constraint(V, np.array([1], dtype=np.int32), np.array([0], dtype=np.int64), np.array([1.0]),
                            np.zeros(1, dtype=np.int32), np.array([0, 1], dtype=np.int32))
-    with pytest.raises(NotImplementedError):
-        dm.MultiPointConstraint(V, dtype=np.complex128)
+    with pytest.raises(NotImplementedError):  # (float32 / float64 / complex64 / complex128 are the reference's four types)
+        dm.MultiPointConstraint(V, dtype=np.int64)
+    # a complex constraint finalizes on the host with its coefficients in place
+    mc = dm.MultiPointConstraint(V, dtype=np.complex128)
+    mc.add_constraint(V, np.array([5, 3], dtype=np.int32), np.array([4, 6, 0], dtype=np.int64), np.array([2.0 + 1j, 3.0, -1j]),
+                      np.zeros(3, dtype=np.int32), np.array([0, 2, 3], dtype=np.int32))
+    mc.finalize(where="host")
+    cc, oo = mc.coefficients()
+    assert cc.dtype == np.complex128 and np.array_equal(cc[oo[5] : oo[6]], [2.0 + 1j, 3.0]) and np.array_equal(cc[oo[3] : oo[4]], [-1j])
 
 
 def test_finalize_rejects_bad_indices():
