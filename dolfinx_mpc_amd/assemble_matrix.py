@@ -42,14 +42,17 @@ MAX_OFFSET_PATTERNS = 4096
 def _warn_no_locality(kind: str, slots: int, entities: int, limit: float = 4.0):
     """Row blocks are contiguous CSR row ranges held in LDS; every entity is listed under each block it touches.  On
     a numbering without locality (a mesh as a file may deliver it) nearly every entity touches as many blocks as it
-    has dofs: correct, but 5-13 x slower.  Say so once, with the remedy."""
+    has dofs: correct, but 5-13 x slower.  Meshes of MPCX_AUTO_REORDER_MIN_CELLS cells and more never get
+    here: they are assembled on the internal, spatially reordered twin (locality.py).  For the small ones, and with
+    MPCX_AUTO_REORDER=0, say so once, with the remedy."""
     if entities > 4096 and slots > limit * entities:
         import warnings
 
         warnings.warn(f"dolfinx_mpc_amd: the {kind} plan lists {slots / entities:.1f} row blocks per entity -- the dof numbering "
                       "has no spatial locality, the row-block kernels will run several times slower than they can.  "
-                      "Renumber the mesh once with dolfinx_mpc_amd.mesh.reorder_spatial(mesh) (nodes along a Z-order "
-                      "curve, cells by lowest node) before creating function spaces.", RuntimeWarning, stacklevel=3)
+                      "Set MPCX_AUTO_REORDER=1 (the library then assembles on an internal, spatially reordered copy; automatic "
+                      "from MPCX_AUTO_REORDER_MIN_CELLS = 50 000 cells), or renumber the mesh once with "
+                      "dolfinx_mpc_amd.mesh.reorder_spatial(mesh) before creating function spaces.", RuntimeWarning, stacklevel=3)
 
 
 def _pair(constraint):

@@ -83,11 +83,13 @@ def test_reorder_spatial_shrinks_the_row_block_plan(degree):
     import os
 
     os.environ["MPCX_NO_CUBE"] = "1"  # this test compares the per-cell plans
+    os.environ["MPCX_FORCE_KERNEL"] = "matrix=rowblock"  # (P2: the entity lists of the per-cell row blocks, not the pair records)
     try:
         shuffled, nc = plan_entities(case_cube_periodic(n, degree, 0.0, numbering="shuffled"))
         spatial, _ = plan_entities(case_cube_periodic(n, degree, 0.0, numbering="spatial"))
         tiled, _ = plan_entities(case_cube_periodic(n, degree, 0.0, reorder=(8, 8, 8)))
     finally:
         del os.environ["MPCX_NO_CUBE"]
+        del os.environ["MPCX_FORCE_KERNEL"]
     assert spatial < 0.75 * shuffled, (shuffled, spatial, tiled, nc)
     assert spatial <= 2.0 * tiled, (shuffled, spatial, tiled, nc)
