@@ -361,6 +361,8 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False, pai
     light = lean and V0.dofmap.bs == 1 and V0.element_ndofs <= 4
     max_rows_cap, max_nnz_cap = ((ROWBLOCK_LIGHT_MAX_ROWS, ROWBLOCK_LIGHT_MAX_NNZ) if light
                                  else (ROWBLOCK_MAX_ROWS, ROWBLOCK_MAX_NNZ))
+    if np.dtype(getattr(form, "dtype", np.float64)).itemsize > 8:
+        max_nnz_cap //= 2  # complex128: 16 bytes per LDS value
     kf = form.integrals[i].kernel
     # entities of a block ordered by which of their local rows lie inside it (measured: P1 elasticity 1.82 -> 1.49 ms,
     # Taylor-Hood coupling blocks 2.0 -> 1.8, P2 stiffness +1.5 %; the light P1 kernel loses its coordinate locality,
@@ -370,7 +372,8 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False, pai
         # component-diagonal forms, node-block kernel: one LDS value per bs x bs block (matrix_nodeblock_kernel)
         group_rows = True
         max_rows_cap, max_nnz_cap = max_rows_cap * V0.dofmap.bs, max_nnz_cap * V0.dofmap.bs ** 2
-    elif kf.form in (0, 1, 4) and V0.dofmap.bs > 1 and not os.environ.get("MPCX_NO_DIAG_COMPACT"):
+    elif (kf.form in (0, 1, 4) and V0.dofmap.bs > 1 and not os.environ.get("MPCX_NO_DIAG_COMPACT")
+          and _native.scalar_id(getattr(form, "dtype", np.float64)) == 0):
         group_rows = False
         # component-diagonal forms on blocked spaces: the kernel keeps one LDS value per column block, so a
         # workgroup owns bs times more rows (include/mpcx.h, matrix_rowblock_kernel)
@@ -1043,7 +1046,12 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
                            p1_geometry=s0["dofmap"] is md["x_dofmap"], same=same, tiled=V0.dof_tile_offsets is not None,
                            builtin_form=(kf.builtin.form if getattr(kf, "builtin", None) is not None else -1))
         a.kernel_name = None  # (python attribute) the table entry that was taken
-        for name in dispatch.candidates(dispatch.MATRIX, ctx, "matrix"):
+        names = dispatch.candidates(dispatch.MATRIX, ctx, "matrix")
+        if _native.scalar_id(getattr(form, "dtype", np.float64)) != 0:
+            if kf.form == 100:
+                raise NotImplementedError("imported (UFCx) kernels are fp64-real")
+            names = ["rowblock"]  # the one formulation csrc/mpcx_scalar.hip restates over a scalar type
+        for name in names:
             lean = pairs = False
             smask = None
             if name == "hex_cube":
@@ -1211,16 +1219,14 @@ def assemble_matrix(
     alg = _ALG[(algorithm or os.environ.get("MPCX_MATRIX_ALG", "auto")).lower()]
     sid = _native.scalar_id(form.dtype)
     if sid != 0:
-        # float32 / complex64 / complex128: the general per-entity kernels (csrc/mpcx_scalar.hip); the LDS row-block,
-        # cluster and pair kernels are fp64-real
-        if alg == 2:
-            raise NotImplementedError("algorithm='rowblock' is built for float64; float32 / complex forms take the per-entity kernels")
+        # float32 / complex64 / complex128: the general kernels of csrc/mpcx_scalar.hip -- LDS row blocks over a plain
+        # entity plan ("rowblock", and "auto" when the plan can be built) or per-entity device atomics ("atomic"); the
+        # cluster, pair, node-block and lean kernels are fp64-real
         for m in (mpc0, mpc1):
             if np.dtype(m.dtype) != form.dtype:
                 raise ValueError(f"form of scalar type {form.dtype} assembled with a constraint of {np.dtype(m.dtype)}")
         if A.dtype != _torch_dtype_of(form.dtype):
             raise ValueError("matrix and form of different scalar types")
-        alg = 1
     for integ in form.integrals:
         if integ.itype not in ("cell", "exterior_facet"):
             raise RuntimeError("Not implemented yet")  # cpp/assemble_matrix.cpp:658-659

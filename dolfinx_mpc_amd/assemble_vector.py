@@ -284,7 +284,12 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
     nrows_blk = VECTOR_BLOCK_ROWS_P2 if (p2_fast and heavy) else rows
     if heavy and not p2_fast and (tiled or ufcx):
         nrows_blk = max(nrows_blk, 2048 * V.dofmap.bs)
-    for name in dispatch.candidates(dispatch.VECTOR, ctx, "vector", plan_only=(alg == 2)):
+    names = dispatch.candidates(dispatch.VECTOR, ctx, "vector", plan_only=(alg == 2))
+    if _native.scalar_id(getattr(form, "dtype", np.float64)) != 0:
+        if k.form == 100:
+            raise NotImplementedError("imported (UFCx) kernels are fp64-real")
+        names = ["rowblock"]  # the one row-block formulation csrc/mpcx_scalar.hip restates over a scalar type
+    for name in names:
         if name == "hex_own":
             # hexahedra: one thread per cell through the built-in Q1 source kernel (MPCX_ALG_CUBE with the built-in twin of
             # the imported kernel, owner-computes row blocks over the cell dofmap), then the rows of slave dofs through
@@ -395,11 +400,10 @@ def assemble_vector(form: Form, constraint: MultiPointConstraint, b: Optional[Ve
     alg = _ALG[(algorithm or os.environ.get("MPCX_VECTOR_ALG", "auto")).lower()]
     if sid != 0:
         # float32 / complex64 / complex128: the general per-entity kernel (csrc/mpcx_scalar.hip)
-        if alg == 2:
-            raise NotImplementedError("algorithm='rowblock' is built for float64; float32 / complex forms take the per-entity kernels")
         if np.dtype(constraint.dtype) != form.dtype:
             raise ValueError(f"form of scalar type {form.dtype} assembled with a constraint of {np.dtype(constraint.dtype)}")
-        alg = 1
+        if alg == 0:
+            alg = 2  # (LDS row blocks; the per-entity kernel with algorithm="atomic")
     for integ in form.integrals:
         if integ.itype not in ("cell", "exterior_facet"):
             raise RuntimeError("Interior facet integrals currently not supported")

@@ -221,16 +221,19 @@ __device__ inline W get_w(const W* A, int p, int q)
 // ---------------------------------------------------------------------------------------------------------------
 // matrix: cpp/assemble_matrix.cpp:488-547 + modify_mpc_cell (:99-268) per entity, device atomics
 // ---------------------------------------------------------------------------------------------------------------
-template <class Op, class S>
+// PART 0: the whole entity (plan-free algorithm); PART 1: only the master contributions, over a.slave_entities (after the
+// LDS row-block kernel below has written the entities' own blocks)
+template <class Op, class S, int PART>
 __global__ void __launch_bounds__(64) matrix_scalar_kernel(mpcx_matrix_args_t a, int32_t* __restrict__ fail)
 {
   using T = typename S::T;
   using W = typename S::W;
   constexpr int N0 = Op::N0, N1 = Op::N1, ND0 = Op::ND0, ND1 = Op::ND1, BS0 = Op::BS0, BS1 = Op::BS1, NV = Op::NV;
   fastmath_init_lds();
-  const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (e >= a.n_entities)
+  const int64_t t0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t0 >= (PART == 0 ? a.n_entities : a.n_slave_entities))
     return;
+  const int64_t e = PART == 0 ? t0 : int64_t(a.slave_entities[t0]);
   const int64_t l = e * a.estride;
   const int64_t cell = (a.entities ? a.entities[l] : e);
   const int64_t cell0 = (a.entities0 ? a.entities0[l] : e);
@@ -286,22 +289,23 @@ __global__ void __launch_bounds__(64) matrix_scalar_kernel(mpcx_matrix_args_t a,
       S::atomic_add(vals + pos, v);
   };
   // the entity's own block with slave rows / columns zeroed (:165-178, :546)
-  for (int p = 0; p < N0; ++p)
-  {
-    if (rbc[p] || rsl[p])
-      continue;
-    for (int q = 0; q < N1; ++q)
+  if constexpr (PART == 0)
+    for (int p = 0; p < N0; ++p)
     {
-      if (cbc[q] || csl[q])
+      if (rbc[p] || rsl[p])
         continue;
-      if constexpr (Op::DIAG)
+      for (int q = 0; q < N1; ++q)
       {
-        if ((p % BS0) != (q % BS1))
+        if (cbc[q] || csl[q])
           continue;
+        if constexpr (Op::DIAG)
+        {
+          if ((p % BS0) != (q % BS1))
+            continue;
+        }
+        add(rows[p], colsd[q], get_w<Op, W>(Ae, p, q));
       }
-      add(rows[p], colsd[q], get_w<Op, W>(Ae, p, q));
     }
-  }
   if (!any_slave)
     return;
   // row masters (:214-246): Hermitian transpose -- the row-side coefficient is conjugated for complex T
@@ -347,18 +351,182 @@ __global__ void __launch_bounds__(64) matrix_scalar_kernel(mpcx_matrix_args_t a,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// LDS row blocks for the other scalar types (MPCX_ALG_ROWBLOCK with a plain entity plan: plan.row_pairs == 0, masked
+// dofmaps, the 8-bit scatter-offset table): one workgroup per contiguous CSR row range held in LDS in the STORAGE type
+// (complex: two adds per entry), every entity touching the block evaluated, rows outside masked, one coalesced write --
+// the formulation of matrix_rowblock_kernel without its fp64-only shortcuts (lean path, lazy entries, register tensors).
+// ---------------------------------------------------------------------------------------------------------------
+template <class S>
+__device__ inline void lds_add(typename S::T* p, typename S::W v)
+{
+  if constexpr (S::COMPLEX)
+  {
+    auto* q = reinterpret_cast<decltype(p->x)*>(p);
+    __hip_atomic_fetch_add(q, decltype(p->x)(v.re), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(q + 1, decltype(p->x)(v.im), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  else
+    __hip_atomic_fetch_add(p, typename S::T(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+constexpr int SC_MASK_SHIFT = 28;
+constexpr int SC_DOF_MASK = (1 << SC_MASK_SHIFT) - 1;
+
+template <class Op, class S>
+__global__ void __launch_bounds__(256) matrix_rowblock_scalar_kernel(mpcx_matrix_args_t a, int32_t* __restrict__ fail)
+{
+  using T = typename S::T;
+  using W = typename S::W;
+  constexpr int ND0 = Op::ND0, ND1 = Op::ND1, BS0 = Op::BS0, BS1 = Op::BS1, NV = Op::NV;
+  extern __shared__ __align__(16) unsigned char smem[];
+  fastmath_init_lds();
+  const int nb = a.plan.num_blocks;
+  const int per = (nb + 7) >> 3;
+  const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (b >= nb)
+    return;
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int r0 = a.plan.block_row0[b], r1 = a.plan.block_row0[b + 1];
+  const int nrow = r1 - r0;
+  const int64_t nnz0 = a.rowptr[r0];
+  const int nnzb = int(a.rowptr[r1] - nnz0);
+  T* s_vals = reinterpret_cast<T*>(smem);
+  int32_t* s_rowlo = reinterpret_cast<int32_t*>(s_vals + a.plan.max_nnz);
+  for (int i = tid; i < nnzb; i += NT)
+    S::store(s_vals + i, S::zero());
+  for (int rl = tid; rl <= nrow; rl += NT)
+    s_rowlo[rl] = int(a.rowptr[r0 + rl] - nnz0);
+  __syncthreads();
+  T* vals = reinterpret_cast<T*>(a.vals);
+  const T* coeffs = reinterpret_cast<const T*>(a.coeffs);
+  const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  for (int64_t t = e0 + tid; t < e1; t += NT)
+  {
+    const int64_t e = a.plan.block_ents[t];
+    const int64_t l = e * a.estride;
+    const int64_t cell = (a.entities ? a.entities[l] : e);
+    const int64_t cell0 = (a.entities0 ? a.entities0[l] : e);
+    const int64_t cell1 = (a.entities1 ? a.entities1[l] : e);
+    const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
+    double cd[NV * 3];
+    gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
+    W Ae[Op::SIZE];
+    if (!tabulate_w<Op, S>(Ae, coeffs ? coeffs + e * a.cstride : nullptr, a.cstride, reinterpret_cast<const T*>(a.constants), cd, lf,
+                           a.kernel))
+    {
+      *fail = 1;
+      continue;
+    }
+    const uint8_t* __restrict__ po = a.plan.ent_offs + e * (ND0 * ND1);
+    for (int i = 0; i < ND0; ++i)
+    {
+      const int32_t m0 = a.mdofmap0[cell0 * ND0 + i];
+      for (int k = 0; k < BS0; ++k)
+      {
+        const int r = (m0 & SC_DOF_MASK) * BS0 + k;
+        if (r < r0 || r >= r1 || ((m0 >> (SC_MASK_SHIFT + k)) & 1))
+          continue;
+        T* row = s_vals + s_rowlo[r - r0];
+        for (int j = 0; j < ND1; ++j)
+        {
+          const int32_t m1 = a.mdofmap1[cell1 * ND1 + j];
+          const int off = int(po[i * ND1 + j]) * BS1;
+          for (int q = 0; q < BS1; ++q)
+          {
+            if ((m1 >> (SC_MASK_SHIFT + q)) & 1)
+              continue;
+            if constexpr (Op::DIAG)
+            {
+              if (k != q)
+                continue;
+            }
+            lds_add<S>(row + off + q, get_w<Op, W>(Ae, i * BS0 + k, j * BS1 + q));
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (a.store_mode)
+    for (int i = tid; i < nnzb; i += NT)
+      vals[nnz0 + i] = s_vals[i];
+  else
+    for (int i = tid; i < nnzb; i += NT)
+      S::store(vals + nnz0 + i, S::load(vals + nnz0 + i) + S::load(s_vals + i));
+}
+
+// vector row blocks: the rows of b a workgroup owns live in LDS; halo entities are evaluated by every block they touch;
+// slave rows are masked here and moved to their masters by vector_scalar_kernel<PART 1> over the slave entities
+template <class Op, class S>
+__global__ void __launch_bounds__(256) vector_rowblock_scalar_kernel(mpcx_vector_args_t a, int32_t* __restrict__ fail)
+{
+  using T = typename S::T;
+  using W = typename S::W;
+  constexpr int ND = Op::ND0, BS = Op::BS0, NV = Op::NV;
+  extern __shared__ __align__(16) unsigned char smem[];
+  fastmath_init_lds();
+  const int nb = a.plan.num_blocks;
+  const int per = (nb + 7) >> 3;
+  const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (b >= nb)
+    return;
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int r0 = a.plan.block_row0[b], r1 = a.plan.block_row0[b + 1];
+  T* s_b = reinterpret_cast<T*>(smem);
+  for (int i = tid; i < r1 - r0; i += NT)
+    S::store(s_b + i, S::zero());
+  __syncthreads();
+  T* bg = reinterpret_cast<T*>(a.b);
+  const T* coeffs = reinterpret_cast<const T*>(a.coeffs);
+  const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  for (int64_t t = e0 + tid; t < e1; t += NT)
+  {
+    const int64_t e = a.plan.block_ents[t];
+    const int64_t l = e * a.estride;
+    const int64_t cell = (a.entities ? a.entities[l] : e);
+    const int64_t cell0 = (a.entities0 ? a.entities0[l] : e);
+    const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
+    double cd[NV * 3];
+    gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
+    W be[Op::N0];
+    if (!tabulate_w<Op, S>(be, coeffs ? coeffs + e * a.cstride : nullptr, a.cstride, reinterpret_cast<const T*>(a.constants), cd, lf,
+                           a.kernel))
+    {
+      *fail = 1;
+      continue;
+    }
+    for (int i = 0; i < ND; ++i)
+    {
+      const int32_t m0 = a.mdofmap[cell0 * ND + i];
+      for (int k = 0; k < BS; ++k)
+      {
+        const int r = (m0 & SC_DOF_MASK) * BS + k;
+        if (r < r0 || r >= r1 || ((m0 >> (SC_MASK_SHIFT + k)) & 1))
+          continue;
+        lds_add<S>(s_b + (r - r0), be[i * BS + k]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < r1 - r0; i += NT)
+    S::store(bg + r0 + i, S::load(bg + r0 + i) + S::load(s_b + i));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // vector: cpp/assemble_vector.cpp:34-91 + modify_mpc_vec (cpp/assemble_vector.h:35-69)
 // ---------------------------------------------------------------------------------------------------------------
-template <class Op, class S>
+// PART 0: the whole entity; PART 1: only the slave rows (to their masters), over a.slave_entities
+template <class Op, class S, int PART>
 __global__ void __launch_bounds__(64) vector_scalar_kernel(mpcx_vector_args_t a, int32_t* __restrict__ fail)
 {
   using T = typename S::T;
   using W = typename S::W;
   constexpr int N = Op::N0, ND = Op::ND0, BS = Op::BS0, NV = Op::NV;
   fastmath_init_lds();
-  const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (e >= a.n_entities)
+  const int64_t t0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t0 >= (PART == 0 ? a.n_entities : a.n_slave_entities))
     return;
+  const int64_t e = PART == 0 ? t0 : int64_t(a.slave_entities[t0]);
   const int64_t l = e * a.estride;
   const int64_t cell = (a.entities ? a.entities[l] : e);
   const int64_t cell0 = (a.entities0 ? a.entities0[l] : e);
@@ -389,8 +557,11 @@ __global__ void __launch_bounds__(64) vector_scalar_kernel(mpcx_vector_args_t a,
           S::atomic_add(b + a.mpc.masters[mi], wconj(S::load(mc + mi)) * v);
         if (m1 > m0)
           continue; // be[slave] = 0 (inside the master loop of the reference: a slave without masters keeps its entry)
+        if constexpr (PART == 1)
+          S::atomic_add(b + d, v); // (masked in the row-block kernel)
       }
-      S::atomic_add(b + d, v);
+      if constexpr (PART == 0)
+        S::atomic_add(b + d, v);
     }
   }
 }
@@ -579,7 +750,18 @@ struct MatrixK
 {
   static void launch(dim3 grid, hipStream_t st, const mpcx_matrix_args_t& a, int32_t* flag)
   {
-    hipLaunchKernelGGL((matrix_scalar_kernel<Op, S>), grid, dim3(64), 0, st, a, flag);
+    if (a.algorithm == MPCX_ALG_ROWBLOCK && a.plan.num_blocks > 0)
+    {
+      const size_t lds = size_t(a.plan.max_nnz) * sizeof(typename S::T) + size_t(a.plan.max_rows + 1) * 4 + 512;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(matrix_rowblock_scalar_kernel<Op, S>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+      hipLaunchKernelGGL((matrix_rowblock_scalar_kernel<Op, S>), dim3(8u * unsigned((a.plan.num_blocks + 7) / 8)), dim3(256), lds, st,
+                         a, flag);
+      if (a.n_slave_entities > 0)
+        hipLaunchKernelGGL((matrix_scalar_kernel<Op, S, 1>), dim3(grid_for(a.n_slave_entities, 64)), dim3(64), 0, st, a, flag);
+    }
+    else
+      hipLaunchKernelGGL((matrix_scalar_kernel<Op, S, 0>), grid, dim3(64), 0, st, a, flag);
   }
 };
 template <class Op, class S>
@@ -587,7 +769,18 @@ struct VectorK
 {
   static void launch(dim3 grid, hipStream_t st, const mpcx_vector_args_t& a, int32_t* flag)
   {
-    hipLaunchKernelGGL((vector_scalar_kernel<Op, S>), grid, dim3(64), 0, st, a, flag);
+    if (a.algorithm == MPCX_ALG_ROWBLOCK && a.plan.num_blocks > 0)
+    {
+      const size_t lds = size_t(a.plan.max_rows) * sizeof(typename S::T) + 512;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vector_rowblock_scalar_kernel<Op, S>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+      hipLaunchKernelGGL((vector_rowblock_scalar_kernel<Op, S>), dim3(8u * unsigned((a.plan.num_blocks + 7) / 8)), dim3(256), lds, st,
+                         a, flag);
+      if (a.n_slave_entities > 0)
+        hipLaunchKernelGGL((vector_scalar_kernel<Op, S, 1>), dim3(grid_for(a.n_slave_entities, 64)), dim3(64), 0, st, a, flag);
+    }
+    else
+      hipLaunchKernelGGL((vector_scalar_kernel<Op, S, 0>), grid, dim3(64), 0, st, a, flag);
   }
 };
 template <class Op, class S>

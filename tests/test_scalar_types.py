@@ -5,7 +5,7 @@ CPU: (1) in float64 the T-generic restatement IS the C oracle on all 27 small ca
 language); (2) in complex128 it satisfies the reference's identity with the HERMITIAN transpose,
 A_mpc[free, free] == K^H A K and b_mpc[free] == K^H b (python/src/dolfinx_mpc/utils/test.py:202-265 with K complex):
 a transposed-but-not-conjugated row side fails it.
-GPU (-m gpu): all 27 cases in complex128, complex64 and float32 against the T-generic oracle.  Tolerances: complex128 as
+GPU (-m gpu): all 27 cases in complex128, complex64 and float32, both algorithms, against the T-generic oracle.  Tolerances: complex128 as
 fp64 (1e-12 of the largest entry); float32 / complex64: the tensor is computed in fp64 and every scatter-add rounds to
 fp32 -- <= ~30 addends per entry -- 2e-5 of the largest entry (fp32 epsilon 1.2e-7 x addends x safety)."""
 
@@ -86,12 +86,14 @@ TOL = {"complex128": 1e-12, "complex64": 2e-5, "float32": 2e-5}
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("alg", ["atomic", "rowblock"])
 @pytest.mark.parametrize("dtype", ["complex128", "complex64", "float32"])
 @pytest.mark.parametrize("make", CASES, ids=IDS)
-def test_gpu_scalar_types_match_the_generic_oracle(so, make, dtype):
+def test_gpu_scalar_types_match_the_generic_oracle(so, make, dtype, alg):
+    """both algorithms of csrc/mpcx_scalar.hip: per-entity device atomics and LDS row blocks"""
     case = retype(make(), np.dtype(dtype))
     ref = oracle_outputs_scalar(so, retype(make(), np.complex128 if dtype.startswith("complex") else np.float64))
-    out = product_outputs_scalar(case, algorithm=None)  # 'auto': the per-entity kernels of csrc/mpcx_scalar.hip
+    out = product_outputs_scalar(case, algorithm=alg)
     tol = TOL[dtype]
     if "A" in ref:
         assert out["A"].dtype == np.dtype(dtype)
@@ -127,7 +129,10 @@ def test_gpu_complex_backsubstitution_and_errors(so):
     real.finalize()
     with pytest.raises(ValueError):
         dm.assemble_matrix(case.a, real, bcs=case.bcs)
-    with pytest.raises(NotImplementedError):
-        dm.assemble_matrix(case.a, mpc, bcs=case.bcs, algorithm="rowblock")
+    gen = fem.form_generated("stiffness", case.V)
+    k = gen.integrals[0].kernel
+    fu = fem.form_ufcx([case.V, case.V], k.ufcx_source, k.ufcx_name).set_dtype(np.complex128)  # imported text: fp64-real only
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        dm.assemble_matrix(fu, mpc, bcs=case.bcs)
     with pytest.raises(NotImplementedError):
         dm.MultiPointConstraint(case.V, dtype=np.int32)
