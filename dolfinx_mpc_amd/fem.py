@@ -30,8 +30,10 @@ FORM_UFCX = 100  # an imported UFCx tabulate_tensor (C source), include/mpcx.h m
 
 CELL_TRIANGLE = 1
 CELL_TETRAHEDRON = 2
-CELL_HEXAHEDRON = 3  # Q1 only, element kernels imported as UFCx C text (codegen.generate_hex)
-_CELL_ID = {"triangle": CELL_TRIANGLE, "tetrahedron": CELL_TETRAHEDRON, "hexahedron": CELL_HEXAHEDRON}
+CELL_HEXAHEDRON = 3  # Q1 (built-in kernels + generated text), Q2 (generated text)
+CELL_QUADRILATERAL = 4  # Q1-Q3, element kernels imported as generated UFCx C text (codegen.generate_general)
+_CELL_ID = {"triangle": CELL_TRIANGLE, "tetrahedron": CELL_TETRAHEDRON, "hexahedron": CELL_HEXAHEDRON,
+            "quadrilateral": CELL_QUADRILATERAL}
 
 # analytic right-hand sides (evaluated at physical quadrature points)
 FN_ONE = 0
@@ -90,10 +92,15 @@ class FunctionSpace:
         family, degree = element[0], int(element[1])
         if family not in ("Lagrange", "CG", "P"):
             raise NotImplementedError(f"element family {family}")
-        if degree not in (1, 2):
-            raise NotImplementedError("only Lagrange degree 1 and 2")
-        if mesh.cell_name == "hexahedron" and degree != 1:
-            raise NotImplementedError("hexahedra: Q1 only")
+        # general Lagrange elements (elements.py): degree 3 on triangles, Q1-Q3 on quadrilaterals, Q2 on hexahedra -- the
+        # cell / degree sweep of python/tests/test_matrix_assembly.py:23-26; their forms run generated (imported) kernels
+        self.general = (mesh.cell_name == "quadrilateral" and degree in (1, 2, 3)) or (mesh.cell_name == "triangle" and degree == 3) \
+            or (mesh.cell_name == "hexahedron" and degree == 2)
+        if not self.general:
+            if degree not in (1, 2):
+                raise NotImplementedError("Lagrange degree 1 and 2 (degree 3: triangles and quadrilaterals)")
+            if mesh.cell_name == "hexahedron" and degree != 1:
+                raise NotImplementedError("hexahedra: Q1 and Q2")
         self.mesh = mesh
         self.degree = degree
         bs = 1 if not shape else int(shape[0])
@@ -104,7 +111,14 @@ class FunctionSpace:
         self.dof_global = None
         self.dof_plane = None
         self.dof_tile_offsets = None  # first dof block of every tile of a tiled numbering (hint for row blocks)
-        if degree == 1:
+        if self.general:
+            from . import elements
+
+            if mesh.num_owned_nodes != mesh.num_nodes:
+                raise NotImplementedError("general Lagrange elements on partitioned meshes")
+            cell_dofs, nblocks, self._dof_coords = elements.build_dofmap(mesh, degree)
+            self._dof_coords_version = mesh.geometry.version
+        elif degree == 1:
             cell_dofs = mesh.geometry.dofmap.copy()
             self.dof_tile_offsets = mesh.node_tile_offsets
             nblocks = mesh.num_owned_nodes
@@ -190,6 +204,11 @@ class FunctionSpace:
 
     def tabulate_dof_coordinates(self) -> np.ndarray:
         gv = self.mesh.geometry.version
+        if self.general and getattr(self, "_dof_coords_version", 0) != gv:
+            from . import elements
+
+            self._dof_coords = elements.build_dofmap(self.mesh, self.degree)[2]
+            self._dof_coords_version = gv
         if self._dof_coords is not None and getattr(self, "_dof_coords_version", 0) != gv:
             # the mesh was moved: recompute from the dofmap (P1: the nodes; P2: nodes and edge midpoints)
             x = self.mesh.geometry.x
@@ -346,6 +365,12 @@ def locate_dofs_topological(V: FunctionSpace, entity_dim: int, entities: np.ndar
     mesh = V.mesh
     assert entity_dim == mesh.tdim - 1, "facets only"
     ents = np.asarray(entities, dtype=np.int64).reshape(-1, 2)
+    if getattr(V, "general", False):
+        from . import elements
+
+        closure = elements.facet_closure_dofs(mesh.cell_name, V.degree)
+        out = [V.dofmap.list[ents[ents[:, 1] == f, 0]][:, loc].reshape(-1) for f, loc in enumerate(closure) if (ents[:, 1] == f).any()]
+        return np.unique(np.concatenate(out)).astype(np.int32) if out else np.zeros(0, dtype=np.int32)
     lf, le = local_facets(mesh.cell_name), local_edges(mesh.cell_name)
     nv = mesh.geometry.dofmap.shape[1]
     out = []
@@ -588,9 +613,44 @@ def _hex_form(V, kind: str, constant=None, coefficient: Optional[Function] = Non
     return form
 
 
+def _general_form(V, kind: str, constant=None, coefficient: Optional[Function] = None, cells=None, fn_id: int = FN_ONE,
+                  quadrature_degree: Optional[int] = None) -> Form:
+    """Forms on the general Lagrange elements (elements.py): the kernel is generated as UFCx C text
+    (codegen.generate_general: basis from baked tables, geometry of degree 1 evaluated at every point) and imported like
+    an FFCx kernel.  Rule: exact for the integrand on affine cells -- 2 (p - 1) for stiffness on simplices, 2 p on tensor
+    cells, 2 p for mass, p + deg(f) for sources (+ the coefficient's degree); Gauss per variable on tensor cells."""
+    from . import elements
+    from .codegen import gauss_tensor, generate_general
+
+    cell, p = V.mesh.cell_name, V.degree
+    cd = 0
+    if coefficient is not None:
+        Vc = coefficient.function_space
+        assert Vc.mesh is V.mesh and Vc.dofmap.bs == 1, "scalar coefficients on the same mesh"
+        cd = Vc.degree
+    simplex = elements.is_simplex(cell)
+    if kind == "source":
+        if fn_id == FN_CONSTANT_VEC:
+            raise NotImplementedError("general elements: FN_CONSTANT_VEC sources")
+        fexpr, base = fn_c_expression(fn_id), p + _FN_DEGREE[fn_id]
+    else:
+        # per-variable degree of the integrand on an affine cell: a derivative lowers the degree only in ITS variable on
+        # tensor cells (Q1 stiffness needs the 2 x 2 rule: one point leaves the hourglass modes in the kernel)
+        fexpr, base = "1.0", (2 * (p - 1) if (kind == "stiffness" and simplex) else 2 * p)
+    qdeg = base + cd if quadrature_degree is None else quadrature_degree
+    rule = make_quadrature(cell, qdeg) if simplex else gauss_tensor(elements.tdim(cell), qdeg)
+    src, name = generate_general(kind, cell, p, V.dofmap.bs, rule, use_constant=constant is not None, fexpr=fexpr,
+                                 coefficient_degree=cd)
+    name_q = f"{name}_f{fn_id}"
+    src = src.replace(name, name_q)
+    return form_ufcx([V] if kind == "source" else [V, V], src, name_q, "cell", cells, coefficient, constant)
+
+
 def form_stiffness(V, constant=None, coefficient: Optional[Function] = None, cells=None) -> Form:
     """a(u, v) = c * w * inner(grad(u), grad(v)) dx  (bench_periodic.py:84;
     test_mpc_pipeline.py:45 with coefficient and constant)."""
+    if getattr(V, "general", False):
+        return _general_form(V, "stiffness", constant, coefficient, cells)
     if V.mesh.cell_name == "hexahedron":
         return _hex_form(V, "stiffness", constant, coefficient, cells)
     cells = _cells_or_all(V.mesh, cells)
@@ -600,6 +660,8 @@ def form_stiffness(V, constant=None, coefficient: Optional[Function] = None, cel
 
 
 def form_mass(V, constant=None, coefficient: Optional[Function] = None, cells=None) -> Form:
+    if getattr(V, "general", False):
+        return _general_form(V, "mass", constant, coefficient, cells)
     if V.mesh.cell_name == "hexahedron":
         return _hex_form(V, "mass", constant, coefficient, cells)
     cells = _cells_or_all(V.mesh, cells)
@@ -642,6 +704,8 @@ def form_source(V, fn_id: int = FN_ONE, constant=None, coefficient: Optional[Fun
                 quadrature_degree: Optional[int] = None) -> Form:
     """L(v) = c * w * inner(f, v) dx with analytic f (bench_periodic.py:85-91).
     Non-polynomial f: estimated degree +2 per UFL's rule -> P1: 5."""
+    if getattr(V, "general", False):
+        return _general_form(V, "source", constant, coefficient, cells, fn_id, quadrature_degree)
     if V.mesh.cell_name == "hexahedron":
         return _hex_form(V, "source", constant, coefficient, cells, fn_id, quadrature_degree)
     cells = _cells_or_all(V.mesh, cells)

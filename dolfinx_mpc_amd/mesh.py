@@ -33,12 +33,16 @@ HEX_EDGES = np.array(
 )
 
 
+# quadrilateral, DOLFINx (tensor-product) vertex order: vertex v has (x, y) bits (v & 1, v >> 1 & 1); facets = edges
+QUAD_EDGES = np.array([[0, 1], [0, 2], [1, 3], [2, 3]], dtype=np.int64)
+
+
 def local_facets(cell_name: str) -> np.ndarray:
-    return {"tetrahedron": TET_FACETS, "triangle": TRI_FACETS, "hexahedron": HEX_FACETS}[cell_name]
+    return {"tetrahedron": TET_FACETS, "triangle": TRI_FACETS, "hexahedron": HEX_FACETS, "quadrilateral": QUAD_EDGES}[cell_name]
 
 
 def local_edges(cell_name: str) -> np.ndarray:
-    return {"tetrahedron": TET_EDGES, "triangle": TRI_EDGES, "hexahedron": HEX_EDGES}[cell_name]
+    return {"tetrahedron": TET_EDGES, "triangle": TRI_EDGES, "hexahedron": HEX_EDGES, "quadrilateral": QUAD_EDGES}[cell_name]
 
 
 class Geometry:
@@ -80,10 +84,10 @@ class Mesh:
     kernels generated as UFCx C text -- dolfinx_mpc_amd/codegen.py)."""
 
     def __init__(self, x: np.ndarray, cells: np.ndarray, cell_name: str):
-        assert cell_name in ("triangle", "tetrahedron", "hexahedron")
+        assert cell_name in ("triangle", "tetrahedron", "hexahedron", "quadrilateral")
         self.geometry = Geometry(np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(cells, dtype=np.int32))
         self.cell_name = cell_name
-        self.tdim = 2 if cell_name == "triangle" else 3
+        self.tdim = 2 if cell_name in ("triangle", "quadrilateral") else 3
         self._exterior_facets = None
         self._edges = None
         self._device = {}
@@ -228,7 +232,9 @@ def create_unit_cube(nx: int, ny: int, nz: int, cell_type: str = "tetrahedron", 
 
 
 def create_rectangle(p0, p1, n, cell_type: str = "triangle") -> Mesh:
-    assert cell_type == "triangle"
+    """rectangle of nx x ny squares: two triangles each, or one quadrilateral (DOLFINx tensor-product vertex order) --
+    python/tests/test_matrix_assembly.py:25-30 sweeps both cell types"""
+    assert cell_type in ("triangle", "quadrilateral")
     nx, ny = n
     xs = np.linspace(p0[0], p1[0], nx + 1)
     ys = np.linspace(p0[1], p1[1], ny + 1)
@@ -237,6 +243,8 @@ def create_rectangle(p0, p1, n, cell_type: str = "triangle") -> Mesh:
     j, i = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
     v0 = (j * (nx + 1) + i).ravel().astype(np.int64)
     v1, v2, v3 = v0 + 1, v0 + nx + 1, v0 + nx + 2
+    if cell_type == "quadrilateral":
+        return Mesh(x, np.stack([v0, v1, v2, v3], axis=1).astype(np.int32), "quadrilateral")
     cells = np.stack([np.stack([v0, v1, v3], axis=1), np.stack([v0, v3, v2], axis=1)], axis=1).reshape(-1, 3)
     return Mesh(x, cells.astype(np.int32), "triangle")
 

@@ -47,12 +47,14 @@ def dict_constraint_raw(V, s_m_c: Dict[bytes, Dict[bytes, float]], subspace_slav
 
 
 # --------------------------------------------------------------------------
-def case_square_dict(degree=1, master_point=(1, 1), n=(5, 3)) -> Case:
-    """python/tests/test_matrix_assembly.py:23-57 / test_vector_assembly.py:22-63"""
-    mesh = create_unit_square(*n)
+def case_square_dict(degree=1, master_point=(1, 1), n=(5, 3), cell_type="triangle") -> Case:
+    """python/tests/test_matrix_assembly.py:23-57 / test_vector_assembly.py:22-63 (the reference sweeps degree 1-3 on
+    triangles and quadrilaterals: degree 3 and the quadrilaterals run generated kernels, dolfinx_mpc_amd/elements.py)"""
+    mesh = create_unit_square(*n, cell_type)
     V = fem.functionspace(mesh, ("Lagrange", degree))
     s_m_c = {l2b([1, 0]): {l2b([0, 1]): 0.43, l2b([1, 1]): 0.11}, l2b([0, 0]): {l2b(list(master_point)): 0.69}}
-    return Case(f"square_dict_p{degree}_m{master_point[0]}{master_point[1]}_{n[0]}x{n[1]}", V, fem.form_stiffness(V),
+    tag = "" if cell_type == "triangle" else "_quad"
+    return Case(f"square_dict_p{degree}_m{master_point[0]}{master_point[1]}_{n[0]}x{n[1]}{tag}", V, fem.form_stiffness(V),
                 fem.form_source(V, fem.FN_SIN2D), [], dict_constraint_raw(V, s_m_c))
 
 
@@ -342,6 +344,28 @@ def irregular_cases() -> List[Callable[[], Case]]:
         lambda: case_delaunay_elasticity_slip(2, 5),
         lambda: case_delaunay_contact(2, 3),
     ]
+
+
+def element_sweep_cases() -> List[Callable[[], Case]]:
+    """the cell / degree sweep of python/tests/test_matrix_assembly.py:23-26, 61-64 and test_vector_assembly.py:22-24 beyond
+    what the built-in operators cover: degree 3 on triangles, degree 1-3 on quadrilaterals (both master choices, and the
+    slaves-sharing-a-cell mesh), plus Q2 on hexahedra (python/tests/test_stokes_channelflow.py:21-22 uses Q2 velocities)"""
+    out = []
+    for cell, degs in (("triangle", (3,)), ("quadrilateral", (1, 2, 3))):
+        for d in degs:
+            out.append(lambda cell=cell, d=d: case_square_dict(d, (1, 1), (5, 3), cell))
+            out.append(lambda cell=cell, d=d: case_square_dict(d, (0, 1), (1, 8), cell))
+    out.append(case_hex_q2_periodic)
+    return out
+
+
+def case_hex_q2_periodic(N=3) -> Case:
+    """periodic Poisson with Q2 on hexahedra (27 dofs per cell, generated kernels), Dirichlet walls, mass + stiffness"""
+    mesh = create_unit_cube(N, N, N, "hexahedron")
+    V = fem.functionspace(mesh, ("Lagrange", 2))
+    bc = fem.dirichletbc(0.2, fem.locate_dofs_geometrical(V, _walls_yz), V)
+    a = fem.form_stiffness(V) + fem.form_mass(V, constant=0.7)
+    return Case(f"hex_q2_periodic_n{N}", V, a, fem.form_source(V, fem.FN_POLY3), [bc], periodic_raw(V, [bc]))
 
 
 def all_small_cases() -> List[Callable[[], Case]]:
