@@ -125,8 +125,10 @@ def test_hex_mesh_topology():
     assert np.array_equal(dofs, fem.locate_dofs_geometrical(V, lambda x: np.isclose(x[2], 1.0)))
     ce, ev = mesh.edges()
     assert ce.shape == (60, 12) and ev.shape[0] == 3 * 5 * 6 + 4 * 4 * 6 + 5 * 4 * 5
+    V2 = fem.functionspace(mesh, ("Lagrange", 2))  # Q2: 27 dofs per cell (elements.py), generated kernels
+    assert V2.element_ndofs == 27 and V2.num_dofs == 7 * 9 * 11
     with pytest.raises(NotImplementedError):
-        fem.functionspace(mesh, ("Lagrange", 2))
+        fem.functionspace(mesh, ("Lagrange", 3))
 
 
 def test_tiled_hex_mesh_is_the_same_mesh():
