@@ -630,8 +630,6 @@ def _general_form(V, kind: str, constant=None, coefficient: Optional[Function] =
         cd = Vc.degree
     simplex = elements.is_simplex(cell)
     if kind == "source":
-        if fn_id == FN_CONSTANT_VEC:
-            raise NotImplementedError("general elements: FN_CONSTANT_VEC sources")
         fexpr, base = fn_c_expression(fn_id), p + _FN_DEGREE[fn_id]
     else:
         # per-variable degree of the integrand on an affine cell: a derivative lowers the degree only in ITS variable on
@@ -681,10 +679,32 @@ def form_elasticity(V, mu: float, lmbda: float, cells=None) -> Form:
     return Form([V, V], [Integral("cell", cells, k, None, np.array([mu, lmbda], dtype=np.float64))])
 
 
+def _general_div(V, Q, test: bool, constant, cells) -> Form:
+    """the Taylor-Hood coupling blocks on general elements (any pair of degrees on one cell type): generated kernels"""
+    from . import elements
+    from .codegen import gauss_tensor, generate_general
+
+    cell = V.mesh.cell_name
+    simplex = elements.is_simplex(cell)
+    qdeg = (V.degree - 1 + Q.degree) if simplex else (V.degree + Q.degree)
+    rule = make_quadrature(cell, qdeg) if simplex else gauss_tensor(elements.tdim(cell), qdeg)
+    if test:
+        src, name = generate_general("div_test", cell, V.degree, V.dofmap.bs, rule, use_constant=True, degree1=Q.degree)
+        return form_ufcx([V, Q], src, name, "cell", cells, None, constant)
+    src, name = generate_general("div_trial", cell, Q.degree, 1, rule, use_constant=True, degree1=V.degree)
+    return form_ufcx([Q, V], src, name, "cell", cells, None, constant)
+
+
+def _is_general_pair(V, Q) -> bool:
+    return getattr(V, "general", False) or getattr(Q, "general", False) or V.mesh.cell_name in ("hexahedron", "quadrilateral")
+
+
 def form_div_test(V, Q, constant=-1.0, cells=None) -> Form:
     """a(p, v) = c * p div(v) dx, rows = V (vector), cols = Q (scalar): the ``a01`` block
     of python/tests/test_stokes_channelflow.py:77-80 with c = -1."""
     assert V.mesh is Q.mesh and V.dofmap.bs == V.mesh.tdim and Q.dofmap.bs == 1
+    if _is_general_pair(V, Q):
+        return _general_div(V, Q, True, constant, cells)
     cells = _cells_or_all(V.mesh, cells)
     k = _cell_kernel(V, FORM_DIV_TEST, V.degree - 1 + Q.degree)
     k.degree1, k.bs1 = Q.degree, 1
@@ -694,6 +714,8 @@ def form_div_test(V, Q, constant=-1.0, cells=None) -> Form:
 def form_div_trial(Q, V, constant=-1.0, cells=None) -> Form:
     """a(u, q) = c * div(u) q dx, rows = Q (scalar), cols = V (vector): the ``a10`` block."""
     assert V.mesh is Q.mesh and V.dofmap.bs == V.mesh.tdim and Q.dofmap.bs == 1
+    if _is_general_pair(V, Q):
+        return _general_div(V, Q, False, constant, cells)
     cells = _cells_or_all(Q.mesh, cells)
     k = _cell_kernel(Q, FORM_DIV_TRIAL, V.degree - 1 + Q.degree)
     k.degree1, k.bs1 = V.degree, V.dofmap.bs

@@ -58,6 +58,34 @@ def _raw_periodic(V, indicator, relation, bcs):
     return captured["raw"]
 
 
+def _problem_general(cell, pv, pq, n):
+    """the same channel on the cell types / degree pairs of python/tests/test_stokes_channelflow.py:21-22 beyond P2/P1
+    tetrahedra: P3/P2 triangles, Q2/Q1 quadrilaterals and hexahedra (generated kernels, dolfinx_mpc_amd/elements.py)"""
+    from dolfinx_mpc_amd.mesh import create_unit_square
+
+    two = cell in ("triangle", "quadrilateral")
+    mesh = create_unit_square(n, n, cell) if two else create_unit_cube(n, n, n, cell)
+    d = 2 if two else 3
+    V = fem.functionspace(mesh, ("Lagrange", pv, (d,)))
+    Q = fem.functionspace(mesh, ("Lagrange", pq))
+    walls = fem.locate_dofs_geometrical(V, lambda x: np.isclose(x[1], 0) | np.isclose(x[1], 1))
+    bc = fem.dirichletbc(np.zeros(d), walls, V)
+
+    def periodic_boundary(x):
+        return np.isclose(x[0], 1) if two else (np.isclose(x[0], 1) | np.isclose(x[2], 1))
+
+    def periodic_map(x):
+        out = x.copy()
+        out[0][np.isclose(x[0], 1)] -= 1
+        if not two:
+            out[2][np.isclose(x[2], 1)] -= 1
+        return out
+
+    forms = {(0, 0): fem.form_stiffness(V), (0, 1): fem.form_div_test(V, Q, constant=-1.0), (1, 0): fem.form_div_trial(Q, V, constant=-1.0)}
+    L0 = fem.form_source(V, fem.FN_CONSTANT_VEC, constant=np.array([1.0, 1.0] + [0.0] * (d - 1)))
+    return V, Q, bc, periodic_boundary, periodic_map, forms, L0
+
+
 def _solve_and_check(V, Q, A00, A01, A10, b0, slaves_u, masters_u, slaves_p, masters_p):
     nu, npq = V.num_dofs, Q.num_dofs
     K = sp.bmat([[A00, A01], [A10, None]], format="csr")
@@ -73,7 +101,7 @@ def _solve_and_check(V, Q, A00, A01, A10, b0, slaves_u, masters_u, slaves_p, mas
     u[slaves_u] = u[masters_u]  # one master, coefficient 1
     p[slaves_p] = p[masters_p]
     x = V.tabulate_dof_coordinates()
-    exact = np.zeros((x.shape[0], 3))
+    exact = np.zeros((x.shape[0], V.dofmap.bs))
     exact[:, 0] = 0.5 * x[:, 1] * (1.0 - x[:, 1])
     err = np.linalg.norm(u - exact.reshape(-1))
     assert err < 1e-10, err
@@ -93,6 +121,54 @@ def test_oracle_poiseuille(oracle, n):
     po.apply_lifting(b0, [forms[(0, 0)]], [[bc]], mu)
     b0[bc.dof_indices()[0]] = 0.0  # set_bc with homogeneous values
     _solve_and_check(V, Q, A00, A01, A10, b0, raw_u[0], raw_u[1].astype(np.int64), raw_p[0], raw_p[1].astype(np.int64))
+
+
+GENERAL = [("triangle", 3, 2, 3), ("quadrilateral", 2, 1, 3), ("quadrilateral", 3, 2, 2), ("hexahedron", 2, 1, 2)]
+
+
+@pytest.mark.parametrize("cell,pv,pq,n", GENERAL)
+def test_oracle_poiseuille_general_elements(oracle, cell, pv, pq, n):
+    po = oracle
+    V, Q, bc, ind, rel, forms, L0 = _problem_general(cell, pv, pq, n)
+    raw_u, raw_p = _raw_periodic(V, ind, rel, [bc]), _raw_periodic(Q, ind, rel, [])
+    mu, mp = po.OracleMPC.from_raw(V, *raw_u), po.OracleMPC.from_raw(Q, *raw_p)
+    A00 = po.assemble_matrix(forms[(0, 0)], mu, mu, bcs=[bc])
+    A01 = po.assemble_matrix(forms[(0, 1)], mu, mp, bcs=[bc])
+    A10 = po.assemble_matrix(forms[(1, 0)], mp, mu, bcs=[bc])
+    assert abs(A01 - A10.T).max() < 1e-13  # a10 = a01^T
+    b0 = po.assemble_vector(L0, mu)
+    po.apply_lifting(b0, [forms[(0, 0)]], [[bc]], mu)
+    b0[bc.dof_indices()[0]] = 0.0
+    _solve_and_check(V, Q, A00, A01, A10, b0, raw_u[0], raw_u[1].astype(np.int64), raw_p[0], raw_p[1].astype(np.int64))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cell,pv,pq,n", GENERAL)
+def test_gpu_blocks_general_elements(oracle, cell, pv, pq, n):
+    """the Taylor-Hood blocks on the general elements through the HIP path (nest API) against the oracle"""
+    import dolfinx_mpc_amd as dm
+
+    po = oracle
+    V, Q, bc, ind, rel, forms, L0 = _problem_general(cell, pv, pq, n)
+    raw_u, raw_p = _raw_periodic(V, ind, rel, [bc]), _raw_periodic(Q, ind, rel, [])
+    mu_o, mp_o = po.OracleMPC.from_raw(V, *raw_u), po.OracleMPC.from_raw(Q, *raw_p)
+    mpcs = []
+    for W, raw in ((V, raw_u), (Q, raw_p)):
+        m = dm.MultiPointConstraint(W)
+        m.add_constraint(W, *raw)
+        m.finalize()
+        mpcs.append(m)
+    a = [[forms[(0, 0)], forms[(0, 1)]], [forms[(1, 0)], None]]
+    A = dm.create_matrix_nest(a, mpcs)
+    dm.assemble_matrix_nest(A, a, mpcs, bcs=[bc])
+    ref = {(0, 0): po.assemble_matrix(forms[(0, 0)], mu_o, mu_o, bcs=[bc]), (0, 1): po.assemble_matrix(forms[(0, 1)], mu_o, mp_o, bcs=[bc]),
+           (1, 0): po.assemble_matrix(forms[(1, 0)], mp_o, mu_o, bcs=[bc])}
+    for (i, j), R in ref.items():
+        S = A[i][j].to_scipy()
+        assert np.array_equal(S.indptr, R.indptr) and np.array_equal(S.indices, R.indices)
+        assert abs(S.data - R.data).max() <= 1e-12 * max(1.0, abs(R.data).max()), (i, j)
+    b = dm.assemble_vector(L0, mpcs[0])
+    assert abs(b.numpy() - po.assemble_vector(L0, mu_o)).max() < 1e-12
 
 
 @pytest.mark.gpu
