@@ -10,9 +10,14 @@ Set-up (once per matrix)
   * aggregates: the dofs (nodes of a blocked space) that fall into one cell of a grid of three mesh widths, from the
     dof coordinates -- the size the distance-two aggregates of GAMG have on a structured mesh; coarse levels reuse the
     centroids of their aggregates;
-  * tentative prolongator: one column per aggregate and component (near-null space = the constants / translations),
-    normalised; smoothed with one damped Jacobi step, ``P = (I - 4 / (3 rho) D^-1 A) P_tent``; Galerkin coarse
-    operator ``P^T A P`` (two sparse-sparse products);
+  * tentative prolongator from a near-null space ``B`` (n x k; default: the constants of every component, k = bs --
+    the translations; ``near_null`` = the rigid body modes of ``utils.rigid_motions_nullspace`` for elasticity, what
+    ``A.setNearNullSpace`` gives GAMG in python/benchmarks/bench_contact_3D.py:287,320): on every aggregate the rows of
+    ``B`` are orthonormalised (batched Cholesky-QR of the k x k Gram matrices, eigen-decomposition where an aggregate is
+    too small to carry all k modes -- those columns are dropped), ``P_tent = blockdiag(Q_a)``, and the triangular factors
+    are the near-null space of the coarse level (k dofs per aggregate), so that ``P_tent B_coarse = B`` exactly on every
+    level; smoothed with one damped Jacobi step, ``P = (I - 4 / (3 rho) D^-1 A) P_tent``; Galerkin coarse operator
+    ``P^T A P`` (two sparse-sparse products);
   * coarsest level (<= ``coarse_size`` rows): dense Cholesky.
 Cycle: V(1, 1) with a degree-3 Chebyshev smoother on [rho / 10, 1.1 rho] of ``D^-1 A`` (rho from a few power
 iterations), symmetric, so that the cycle is a valid CG preconditioner."""
@@ -87,11 +92,13 @@ class SmoothedAggregation:
     Args:
         rowptr, cols, vals: CSR arrays (device tensors; offsets may be int64, columns int32)
         coords: (n / bs, 3) coordinates of the dof blocks (device or host)
-        bs: block size of the space (components are aggregated together, one coarse dof per component)
+        bs: block size of the space (the dofs of a node are aggregated together)
+        near_null: (n, k) near-null space (numpy or tensor), e.g. the six rigid body modes; None: the constants of every
+            component
     """
 
     def __init__(self, rowptr, cols, vals, coords, bs: int = 1, coarse_size: int = 3000, max_levels: int = 12,
-                 cell_widths: float = 3.0):
+                 cell_widths: float = 3.0, near_null=None):
         import torch
 
         dev = vals.device
@@ -101,8 +108,16 @@ class SmoothedAggregation:
         A = _csr(rowptr.to(it), cols.to(it), vals, (n, n))
         X = torch.as_tensor(np.asarray(coords) if not torch.is_tensor(coords) else coords, dtype=torch.float64, device=dev)
         self.bs = bs
+        if near_null is None:
+            B = torch.eye(bs, dtype=torch.float64, device=dev).repeat(n // bs, 1)
+        else:
+            B = torch.as_tensor(np.asarray(near_null) if not torch.is_tensor(near_null) else near_null, dtype=torch.float64,
+                                device=dev).reshape(n, -1).clone()
+        self.near_null_dim = k = int(B.shape[1])
         self.levels: List[_Level] = []
-        h = float((torch.prod(X.max(0).values - X.min(0).values + 1e-300) / max(X.shape[0], 1)) ** (1.0 / 3.0))
+        ext = X.max(0).values - X.min(0).values
+        flat = ext <= 1e-12 * float(ext.max())  # a planar mesh: the mesh width comes from the directions it extends in
+        h = float((torch.prod(torch.where(flat, torch.ones_like(ext), ext)) / max(X.shape[0], 1)) ** (1.0 / max(int((~flat).sum()), 1)))
         while True:
             n = A.shape[0]
             crow, col, val = A.crow_indices(), A.col_indices(), A.values()
@@ -112,8 +127,10 @@ class SmoothedAggregation:
             diag.index_add_(0, rows[isd], val[isd])
             offd = torch.zeros(n, dtype=torch.float64, device=dev)
             offd.index_add_(0, rows[~isd], val[~isd].abs())
-            dinv = 1.0 / diag
+            # (a coarse dof whose mode an aggregate could not carry has an empty row: it stays at zero)
+            dinv = torch.where(diag != 0, 1.0 / torch.where(diag != 0, diag, torch.ones_like(diag)), torch.zeros_like(diag))
             active = offd > 1e-14 * diag.abs()  # identity rows (slaves, Dirichlet dofs) stay out of the hierarchy
+            B = B * active[:, None]
             Am = _Mat(A)
             lvl = _Level(Am, dinv, 1.1 * _power_rho(Am, dinv), active)
             self.levels.append(lvl)
@@ -133,7 +150,7 @@ class SmoothedAggregation:
                 nagg = uniq.numel() - 1
             else:
                 nagg = uniq.numel()
-            if nagg == 0 or nagg * bs >= 0.7 * n:
+            if nagg == 0 or nagg * k >= 0.7 * n:
                 break
             cnt = torch.zeros(nagg, dtype=torch.float64, device=dev)
             sel = agg >= 0
@@ -141,15 +158,37 @@ class SmoothedAggregation:
             Xc = torch.zeros((nagg, 3), dtype=torch.float64, device=dev)
             Xc.index_add_(0, agg[sel], X[sel])
             Xc /= cnt[:, None]
-            # ---- tentative prolongator (piecewise constant per component, normalised), then one Jacobi smoothing step
+            # ---- tentative prolongator: Q_a R_a = B restricted to aggregate a (see the module docstring)
             b_idx = torch.nonzero(sel).reshape(-1)
             comp = torch.arange(bs, device=dev)
             prow = (b_idx[:, None] * bs + comp[None, :]).reshape(-1)
-            pcol = (agg[b_idx][:, None] * bs + comp[None, :]).reshape(-1)
-            pval = (1.0 / torch.sqrt(cnt[agg[b_idx]]))[:, None].expand(-1, bs).reshape(-1)
             keep = active[prow]  # a masked component of an otherwise active block
-            prow, pcol, pval = prow[keep], pcol[keep], pval[keep]
-            nc = nagg * bs
+            prow = prow[keep]
+            pagg = agg[b_idx][:, None].expand(-1, bs).reshape(-1)[keep]
+            Br = B[prow]  # (m, k)
+            G = torch.zeros((nagg, k, k), dtype=torch.float64, device=dev)
+            G.index_add_(0, pagg, Br[:, :, None] * Br[:, None, :])
+            eye_k = torch.eye(k, dtype=torch.float64, device=dev)
+            Lc, info = torch.linalg.cholesky_ex(G)
+            dR = torch.diagonal(Lc, dim1=1, dim2=2)
+            bad = (info != 0) | ~torch.isfinite(dR).all(dim=1) | (dR.min(dim=1).values ** 2 <= 1e-10 * dR.max(dim=1).values ** 2)
+            R = Lc.transpose(1, 2).contiguous()  # G = R^T R
+            R[bad] = eye_k
+            W = torch.linalg.solve_triangular(R, eye_k.expand(nagg, k, k), upper=True)  # Q_a = B_a W_a
+            if bool(bad.any()):
+                lam, U = torch.linalg.eigh(G[bad])
+                good = lam > 1e-10 * lam[:, -1:].clamp(min=1e-300)
+                sq = torch.sqrt(lam.clamp(min=0.0))
+                W[bad] = U * torch.where(good, 1.0 / torch.where(good, sq, torch.ones_like(sq)), torch.zeros_like(sq))[:, None, :]
+                R[bad] = (U * torch.where(good, sq, torch.zeros_like(sq))[:, None, :]).transpose(1, 2)
+            Qr = torch.einsum("mk,mkc->mc", Br, W[pagg])
+            pcol = (pagg[:, None] * k + torch.arange(k, device=dev)[None, :])
+            prow = prow[:, None].expand(-1, k)
+            nzq = Qr != 0
+            prow, pcol, pval = prow[nzq], pcol[nzq], Qr[nzq]
+            B = R.reshape(nagg * k, k)  # the coarse near-null space
+            del Br, G, W, Qr, Lc
+            nc = nagg * k
             Pt = torch.sparse_coo_tensor(torch.stack([prow, pcol]), pval, (n, nc)).coalesce().to_sparse_csr()
             AP = A @ Pt
             omega = 4.0 / (3.0 * lvl.rho)
@@ -169,15 +208,16 @@ class SmoothedAggregation:
             del Pc, PTc, P, Pt, AP, APs
             X = Xc
             h = cell
+            bs = k  # coarse nodes carry one dof per near-null mode
         last = self.levels[-1]
         nL = last.n
         if nL <= 20000:
             D = A.to_dense()  # (A: the torch tensor of the last level)
             D = 0.5 * (D + D.T)
-            try:
-                last.chol = torch.linalg.cholesky(D)
-            except Exception:
-                last.chol = None
+            dd = torch.diagonal(D)
+            dd += (dd == 0).to(D.dtype)  # empty rows (dropped modes): identity
+            Lc, info = torch.linalg.cholesky_ex(D)
+            last.chol = Lc if int(info) == 0 else None  # not positive definite to rounding: smoother sweeps instead
 
     # ------------------------------------------------------------------------------------------------
     def _smooth(self, lvl: _Level, x, b, degree: int = 3):
@@ -221,30 +261,4 @@ class SmoothedAggregation:
         return [int(lv.n) for lv in self.levels]
 
 
-def pcg(A_mv, M_inv, b, x0=None, rtol: float = 1e-10, atol: float = 0.0, max_it: int = 500):
-    """preconditioned conjugate gradients on device tensors; ``A_mv(v)`` and ``M_inv(r)`` are callables"""
-    import torch
-
-    x = torch.zeros_like(b) if x0 is None else x0.clone()
-    r = b - A_mv(x) if x0 is not None else b.clone()
-    z = M_inv(r)
-    p = z.clone()
-    rz = torch.dot(r, z)
-    bb = float(torch.dot(b, b))
-    tol2 = max(rtol * rtol * bb, atol * atol)
-    k = 0
-    rr = float(torch.dot(r, r))
-    while rr > tol2 and k < max_it:
-        Ap = A_mv(p)
-        alpha = rz / torch.dot(p, Ap)
-        x = x + alpha * p
-        r = r - alpha * Ap
-        rr = float(torch.dot(r, r))
-        k += 1
-        if rr <= tol2:
-            break
-        z = M_inv(r)
-        rz_new = torch.dot(r, z)
-        p = z + (rz_new / rz) * p
-        rz = rz_new
-    return x, {"iterations": k, "residual_norm": float(np.sqrt(rr)), "b_norm": float(np.sqrt(bb)), "converged": bool(rr <= tol2)}
+from .krylov import pcg  # noqa: E402,F401  (the solver lives with MINRES in krylov.py)

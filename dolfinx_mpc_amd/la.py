@@ -202,6 +202,25 @@ class Vector:
         return self._array.numel()
 
 
+class NullSpace:
+    """a set of vectors spanning a (near) null space -- the role of ``PETSc.NullSpace`` in
+    ``A.setNearNullSpace(rigid_motions_nullspace(V))`` (python/benchmarks/bench_contact_3D.py:287,320).
+    ``vectors``: list of host arrays over the local dofs; ``basis()``: (n, dim) array."""
+
+    def __init__(self, vectors):
+        self.vectors = [np.ascontiguousarray(v, dtype=np.float64) for v in vectors]
+
+    @property
+    def dim(self) -> int:
+        return len(self.vectors)
+
+    def basis(self) -> np.ndarray:
+        return np.stack(self.vectors, axis=1)
+
+    def getVecs(self):
+        return self.vectors
+
+
 def create_vector(V, dtype=None) -> Vector:
     """a vector over the dofs of ``V``; on a partitioned mesh with an initialised process group it carries the
     space's interface exchange (distributed.exchange_for)"""
@@ -248,6 +267,14 @@ class MPCMatrix:
         self._exchange = None
         self._pending = None
         self._ready = None  # event recorded at the end of an assembly on a side stream
+        self.near_nullspace = None  # la.NullSpace, setNearNullSpace
+
+    def setNearNullSpace(self, nullspace):
+        """the near-null space the multigrid preconditioner builds its prolongators from (petsc4py ``Mat.setNearNullSpace``,
+        python/benchmarks/bench_contact_3D.py:320)"""
+        if nullspace is not None and nullspace.basis().shape[0] != self.shape[0]:
+            raise ValueError("setNearNullSpace: the vectors do not have the matrix' number of rows")
+        self.near_nullspace = nullspace
 
     def _wait_ready(self):
         ev = self._ready

@@ -88,6 +88,7 @@ class Mesh:
         self.geometry = Geometry(np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(cells, dtype=np.int32))
         self.cell_name = cell_name
         self.tdim = 2 if cell_name in ("triangle", "quadrilateral") else 3
+        self.geometry.dim = self.tdim  # (planar meshes live in the z = 0 plane of the 3-column coordinate array)
         self._exterior_facets = None
         self._edges = None
         self._device = {}

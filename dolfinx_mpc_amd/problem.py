@@ -2,8 +2,10 @@
 (python/src/dolfinx_mpc/problem.py:353-600): assemble the constrained system with the
 HIP assemblers and solve it without leaving the GPU -- Jacobi-preconditioned conjugate
 gradients on the assembled CSR matrix (include/mpcx.h: ``mpcx_spmv``, ``mpcx_cg_*``) in
-place of the reference's PETSc KSP.  Single (non-nest) forms, symmetric positive definite
-problems (Poisson, elasticity); SURVEY section 8f rank 3.
+place of the reference's PETSc KSP; symmetric positive definite problems (Poisson, elasticity) by CG with a Jacobi
+or smoothed-aggregation preconditioner, nest systems (Stokes: ``a = [[a00, a01], [a10, None]]``, one constraint per
+block row, python/src/dolfinx_mpc/problem.py:418-447) by MINRES with an additive field split
+(python/tests/test_stokes_channelflow.py:107-125).  SURVEY section 8f rank 3.
 """
 
 from __future__ import annotations
@@ -21,6 +23,13 @@ from .la import MPCMatrix, Vector, create_vector
 from .multipointconstraint import MultiPointConstraint
 
 
+class _View:
+    """a device tensor in the place of a ``Vector`` (sub-vectors of a nest system are views of one tensor)"""
+
+    def __init__(self, t):
+        self.array = t
+
+
 def spmv(A: MPCMatrix, x: Vector, y: Optional[Vector] = None) -> Vector:
     """y = A x on the device."""
     if y is None:
@@ -31,6 +40,46 @@ def spmv(A: MPCMatrix, x: Vector, y: Optional[Vector] = None) -> Vector:
                                  x.array.data_ptr(), y.array.data_ptr(), D.stream_ptr())
     _native.check(rc, "mpcx_spmv")
     return y
+
+
+class NestOperator:
+    """y = [sum_j A_ij x_j]_i on one concatenated device tensor; ``None`` blocks are zero (PETSc ``MatNest``)"""
+
+    def __init__(self, blocks: Sequence[Sequence[Optional[MPCMatrix]]]):
+        self.blocks = [list(r) for r in blocks]
+        nb = len(self.blocks)
+        rows = [next((b.shape[0] for b in r if b is not None), None) for r in self.blocks]
+        cols = [next((self.blocks[i][j].shape[1] for i in range(nb) if self.blocks[i][j] is not None), None) for j in range(nb)]
+        self.sizes = [r if r is not None else c for r, c in zip(rows, cols)]
+        if any(sz is None for sz in self.sizes) or any(c is not None and c != sz for c, sz in zip(cols, self.sizes)):
+            raise ValueError("NestOperator: block sizes do not match / an empty block row and column")
+        self.offsets = np.concatenate([[0], np.cumsum(self.sizes)]).astype(np.int64)
+        self.n = int(self.offsets[-1])
+
+    def split(self, t):
+        return [t[self.offsets[i]:self.offsets[i + 1]] for i in range(len(self.sizes))]
+
+    def __call__(self, x):
+        import torch
+
+        x = x.contiguous()
+        y = torch.zeros_like(x)
+        xs, ys = self.split(x), self.split(y)
+        tmp = None
+        for i, row in enumerate(self.blocks):
+            first = True
+            for j, blk in enumerate(row):
+                if blk is None:
+                    continue
+                if first:
+                    spmv(blk, _View(xs[j]), _View(ys[i]))
+                    first = False
+                else:
+                    if tmp is None or tmp.numel() < self.sizes[i]:
+                        tmp = torch.empty(max(self.sizes), dtype=x.dtype, device=x.device)
+                    spmv(blk, _View(xs[j]), _View(tmp[: self.sizes[i]]))
+                    ys[i].add_(tmp[: self.sizes[i]])
+        return y
 
 
 def _spmv_block_scalar(A: MPCMatrix, x: Vector, y: Vector) -> Vector:
@@ -116,7 +165,9 @@ def multigrid_cg(A: MPCMatrix, b: Vector, V, x: Optional[Vector] = None, rtol: f
 
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    mg = SmoothedAggregation(A.d_rowptr, A.d_cols, A.vals, V.tabulate_dof_coordinates(), bs=V.dofmap.bs)
+    ns = getattr(A, "near_nullspace", None)
+    mg = SmoothedAggregation(A.d_rowptr, A.d_cols, A.vals, V.tabulate_dof_coordinates(), bs=V.dofmap.bs,
+                             near_null=None if ns is None else ns.basis())
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t0
     A0 = mg.levels[0].A
@@ -126,8 +177,73 @@ def multigrid_cg(A: MPCMatrix, b: Vector, V, x: Optional[Vector] = None, rtol: f
         x = Vector(A.shape[0])
     x.array.copy_(xt)
     info.update(setup_s=t_setup, solve_s=time.perf_counter() - t0 - t_setup, levels=mg.sizes(),
-                operator_complexity=mg.operator_complexity(), pc_type="gamg")
+                operator_complexity=mg.operator_complexity(), pc_type="gamg", near_null_dim=mg.near_null_dim)
     return x, info
+
+
+def _inverse_diagonal(A: MPCMatrix):
+    """1 / diag(A) as a device tensor (empty diagonals -> 1: PETSc's Jacobi does the same for the pressure slaves)"""
+    import torch
+
+    n = A.shape[0]
+    dinv = torch.empty(n, dtype=torch.float64, device=A.device)
+    _native.check(_native.lib().mpcx_inverse_diagonal(n, A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), A.vals.data_ptr(),
+                                                      dinv.data_ptr(), D.stream_ptr()), "mpcx_inverse_diagonal")
+    return torch.where(torch.isfinite(dinv) & (dinv != 0), dinv, torch.ones_like(dinv))
+
+
+def fieldsplit_minres(A: Sequence[Sequence[Optional[MPCMatrix]]], b: Sequence[Vector], spaces, P=None, pc_types=None,
+                      rtol: float = 1e-10, atol: float = 0.0, max_it: int = 2000, check_every: int = 10, **_unused):
+    """Solve the symmetric nest system A x = b by MINRES with an additive field split
+    (python/tests/test_stokes_channelflow.py:107-125, python/demos/demo_stokes_nest.py:231-252): block i of the
+    preconditioner is built from ``P[i][i]`` if a preconditioner matrix is given, else from ``A[i][i]``, else it is the
+    identity; ``pc_types[i]``: ``"gamg"`` (one smoothed-aggregation V-cycle, dolfinx_mpc_amd/amg.py), ``"jacobi"`` or
+    ``"none"``; default: ``gamg`` for the first block, ``jacobi`` for the others (the reference's demo set-up).
+    Returns (list of solution tensors, info)."""
+    import time
+
+    import torch
+
+    from .amg import SmoothedAggregation
+    from .krylov import minres
+
+    op = NestOperator(A)
+    nb = len(op.sizes)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pcs, kinds = [], []
+    for i in range(nb):
+        M = None if P is None else P[i][i]
+        M = A[i][i] if M is None else M
+        kind = (pc_types[i] if pc_types is not None else ("gamg" if i == 0 else "jacobi")).lower()
+        if M is None or kind == "none":
+            pcs.append(lambda r: r.clone())
+            kinds.append("none")
+        elif kind in ("gamg", "amg"):
+            V = spaces[i]
+            ns = getattr(M, "near_nullspace", None)
+            mg = SmoothedAggregation(M.d_rowptr, M.d_cols, M.vals, V.tabulate_dof_coordinates(), bs=V.dofmap.bs,
+                                     near_null=None if ns is None else ns.basis())
+            pcs.append(mg.vcycle)
+            kinds.append("gamg" + str(mg.sizes()))
+        elif kind == "jacobi":
+            dinv = _inverse_diagonal(M)
+            pcs.append(lambda r, dinv=dinv: dinv * r)
+            kinds.append("jacobi")
+        else:
+            raise NotImplementedError(f"fieldsplit_minres: pc_type {kind!r} (gamg, jacobi, none)")
+
+    def M_inv(r):
+        return torch.cat([pc(ri.contiguous()) for pc, ri in zip(pcs, op.split(r))])
+
+    rhs = torch.cat([bi.array for bi in b])
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t0
+    x, info = minres(op, M_inv, rhs, rtol=rtol, atol=atol, max_it=max_it, check_every=check_every)
+    torch.cuda.synchronize()
+    info.update(setup_s=t_setup, solve_s=time.perf_counter() - t0 - t_setup, ksp_type="minres", pc_type="fieldsplit",
+                fieldsplit=kinds)
+    return op.split(x), info
 
 
 class LinearProblem:
@@ -135,23 +251,59 @@ class LinearProblem:
     (python/src/dolfinx_mpc/problem.py:353-600).
 
     Args:
-        a, L: bilinear and linear form
-        mpc: the (finalized) multi point constraint
+        a, L: bilinear and linear form; nest systems: ``a`` a list of lists of forms (``None`` = empty block), ``L`` a
+            list of forms (``None`` = zero), as in python/src/dolfinx_mpc/problem.py:418-447
+        mpc: the (finalized) multi point constraint; nest systems: one per block row
         bcs: Dirichlet conditions
-        u: solution function on ``mpc.function_space`` (created if None)
-        solver_options: {"rtol", "atol", "max_it", "check_every"} for the CG solver
+        u: solution function on ``mpc.function_space`` (created if None); nest systems: a list of functions
+        solver_options: {"rtol", "atol", "max_it", "check_every"} for the Krylov solver
             (the reference's ``petsc_options`` play this role); ``"pc_type"``: ``"jacobi"`` (default: the fused CG
             kernels of libmpcx) or ``"gamg"`` (smoothed-aggregation multigrid V-cycle, dolfinx_mpc_amd/amg.py -- the
-            preconditioner family of the reference's benchmark solve, bench_periodic.py:112-149)
+            preconditioner family of the reference's benchmark solve, bench_periodic.py:112-149; it uses
+            ``problem.A.near_nullspace`` if ``A.setNearNullSpace`` was called).  Nest systems: MINRES with an additive
+            field split (test_stokes_channelflow.py:107-125); ``"fieldsplit_pc_types"``: one of ``gamg`` / ``jacobi`` /
+            ``none`` per block (default ``gamg`` for the first, ``jacobi`` for the others)
+        P: nest systems: forms of a preconditioner matrix (``[[None, None], [None, mass]]``: blocks that are ``None`` fall
+            back to the system's own diagonal block), python/src/dolfinx_mpc/problem.py:470-480,
+            python/demos/demo_stokes_nest.py:226-228
     """
 
-    def __init__(self, a: Form, L: Form, mpc: MultiPointConstraint, bcs: Optional[Sequence[DirichletBC]] = None,
-                 u: Optional[Function] = None, solver_options: Optional[dict] = None):
-        if not isinstance(mpc, MultiPointConstraint):
-            raise NotImplementedError("LinearProblem: nest / blocked systems are not supported")
-        mpc._not_finalized()
+    def __init__(self, a, L, mpc, bcs: Optional[Sequence[DirichletBC]] = None, u=None, solver_options: Optional[dict] = None,
+                 P=None):
+        self._nest = isinstance(mpc, (list, tuple))
         self._a, self._L, self._mpc = a, L, mpc
         self.bcs = [] if bcs is None else list(bcs)
+        self.solver_options = dict(solver_options or {})
+        self.info: dict = {}
+        self._P_forms, self._P = P, None
+        if self._nest:
+            from .assemble_matrix import create_matrix_nest
+            from .assemble_vector import create_vector_nest
+
+            mpcs = list(mpc)
+            for m in mpcs:
+                if not isinstance(m, MultiPointConstraint):
+                    raise TypeError("LinearProblem: a sequence of MultiPointConstraint objects for a nest system")
+                m._not_finalized()
+            if len(a) != len(mpcs) or len(L) != len(mpcs) or any(len(r) != len(mpcs) for r in a):
+                raise ValueError("LinearProblem: a, L and the constraints do not have the same number of blocks")
+            if u is None:
+                u = [Function(m.function_space) for m in mpcs]
+            else:
+                u = list(u)
+                for ui, m in zip(u, mpcs):
+                    if ui.function_space is not m.function_space:
+                        raise ValueError("The input function has to be in the function space in the multi-point constraint")
+            self.u = u
+            self._A = create_matrix_nest(a, mpcs)
+            self._b = create_vector_nest(L, mpcs)
+            if P is not None:
+                self._P = create_matrix_nest(P, mpcs)
+            self._x = None
+            return
+        if not isinstance(mpc, MultiPointConstraint):
+            raise TypeError("LinearProblem: a MultiPointConstraint (or a sequence of them for a nest system)")
+        mpc._not_finalized()
         if u is None:
             u = Function(mpc.function_space)
         elif u.function_space is not mpc.function_space:
@@ -161,20 +313,35 @@ class LinearProblem:
         self._A = create_matrix(a, mpc)
         self._b = create_vector(mpc.function_space)
         self._x = Vector(mpc.function_space.num_dofs)
-        self.solver_options = dict(solver_options or {})
-        self.info: dict = {}
 
     @property
-    def A(self) -> MPCMatrix:
+    def A(self):
         return self._A
 
     @property
-    def b(self) -> Vector:
+    def b(self):
         return self._b
+
+    @property
+    def P_mat(self):
+        return self._P
 
     def assemble(self):
         """A, b with lifting and boundary values, as ``solve`` does before the linear solve
         (problem.py:537-585)."""
+        if self._nest:
+            from .assemble_matrix import assemble_matrix_nest
+            from .assemble_vector import assemble_vector_nest
+
+            mpcs = list(self._mpc)
+            assemble_matrix_nest(self._A, self._a, mpcs, bcs=self.bcs)
+            if self._P is not None:
+                assemble_matrix_nest(self._P, self._P_forms, mpcs, bcs=self.bcs)
+            assemble_vector_nest(self._b, self._L, mpcs)
+            apply_lifting(self._b, self._a, self.bcs, mpcs)
+            for bi, m in zip(self._b, mpcs):  # dolfinx bcs_by_block: the conditions that live in the block's space
+                set_bc(bi, [bc for bc in self.bcs if m.function_space.contains(bc.function_space)])
+            return self._A, self._b
         assemble_matrix(self._a, self._mpc, bcs=self.bcs, A=self._A)
         assemble_vector(self._L, self._mpc, b=self._b)
         apply_lifting(self._b, [self._a], [self.bcs], self._mpc)
@@ -185,10 +352,31 @@ class LinearProblem:
         _, info = multigrid_cg(self._A, self._b, self._mpc.function_space, x=self._x, **opts)
         return info
 
-    def solve(self) -> Function:
+    def _solve_nest(self):
+        opts = dict(self.solver_options)
+        ksp = str(opts.pop("ksp_type", "minres")).lower()
+        pc = str(opts.pop("pc_type", "fieldsplit")).lower()
+        if ksp != "minres" or pc != "fieldsplit":
+            raise NotImplementedError(f"LinearProblem (nest): ksp_type {ksp!r} / pc_type {pc!r} (minres with fieldsplit)")
+        mpcs = list(self._mpc)
+        xs, self.info = fieldsplit_minres(self._A, self._b, [m.function_space for m in mpcs], P=self._P,
+                                          pc_types=opts.pop("fieldsplit_pc_types", None), **opts)
+        if not self.info["converged"]:
+            raise RuntimeError(f"LinearProblem: MINRES did not converge: {self.info}")
+        for xi, ui, m in zip(xs, self.u, mpcs):
+            v = Vector(m.function_space.num_dofs)
+            v.array.copy_(xi)
+            m.homogenize(v)
+            m.backsubstitution(v)
+            ui.x.array[:] = v.numpy()
+        return self.u
+
+    def solve(self):
         """Assemble, solve on the device, impose the constraint on the slaves
-        (``homogenize`` + ``backsubstitution``, problem.py:589-598) and return ``u``."""
+        (``homogenize`` + ``backsubstitution``, problem.py:589-598) and return ``u`` (nest systems: the list)."""
         self.assemble()
+        if self._nest:
+            return self._solve_nest()
         opts = dict(self.solver_options)
         pc = str(opts.pop("pc_type", "jacobi")).lower()
         if pc in ("gamg", "amg"):

@@ -95,3 +95,114 @@ def test_multigrid_iteration_counts(degree, N):
     jac.solve()
     assert its[N] <= 40 and its[N] <= its[N // 2] + 8, its
     assert jac.info["iterations"] >= 3 * its[N], (jac.info["iterations"], its)
+
+
+def _poiseuille(n):
+    from dolfinx_mpc_amd import fem
+    from dolfinx_mpc_amd.mesh import create_unit_cube
+
+    import dolfinx_mpc_amd as dm
+
+    mesh = create_unit_cube(n, n, n)
+    V = fem.functionspace(mesh, ("Lagrange", 2, (3,)))
+    Q = fem.functionspace(mesh, ("Lagrange", 1))
+    walls = fem.locate_dofs_geometrical(V, lambda x: np.isclose(x[1], 0) | np.isclose(x[1], 1))
+    bc = fem.dirichletbc(np.zeros(3), walls, V)
+    ind = lambda x: np.isclose(x[0], 1) | np.isclose(x[2], 1)  # noqa: E731
+
+    def rel(x):
+        out = x.copy()
+        out[0][np.isclose(x[0], 1)] -= 1
+        out[2][np.isclose(x[2], 1)] -= 1
+        return out
+
+    mu = dm.MultiPointConstraint(V)
+    mu.create_periodic_constraint_geometrical(V, ind, rel, [bc])
+    mu.finalize()
+    mp = dm.MultiPointConstraint(Q)
+    mp.create_periodic_constraint_geometrical(Q, ind, rel, [])
+    mp.finalize()
+    a = [[fem.form_stiffness(V), fem.form_div_test(V, Q, constant=-1.0)], [fem.form_div_trial(Q, V, constant=-1.0), None]]
+    L = [fem.form_source(V, fem.FN_CONSTANT_VEC, constant=np.array([1.0, 1.0, 0.0, 0.0])), None]
+    return V, Q, bc, [mu, mp], a, L
+
+
+@pytest.mark.parametrize("n,with_P", [(3, False), (3, True), (6, True)], ids=["n3", "n3-massP", "n6-massP-amg"])
+def test_nest_linear_problem_poiseuille(n, with_P):
+    """the reference's nest solve (python/tests/test_stokes_channelflow.py:89-173: MINRES, additive field split) on
+    the channel whose exact solution P2 / P1 holds: u = (y (1 - y) / 2, 0, 0), p constant.  Solver rtol 1e-11; the
+    velocity is compared to 1e-8 (the system's conditioning times the residual)."""
+    from dolfinx_mpc_amd import fem
+    from dolfinx_mpc_amd.problem import LinearProblem
+
+    V, Q, bc, mpcs, a, L = _poiseuille(n)
+    P = [[None, None], [None, fem.form_mass(Q)]] if with_P else None  # demo_stokes_nest.py:226-228
+    prob = LinearProblem(a, L, mpcs, bcs=[bc], P=P, solver_options={"rtol": 1e-11, "max_it": 3000})
+    uh, ph = prob.solve()
+    info = prob.info
+    assert info["converged"] and info["ksp_type"] == "minres", info
+    if n == 6:
+        assert info["fieldsplit"][0].startswith("gamg[") and info["fieldsplit"][0].count(",") >= 1, info  # two levels
+    x = V.tabulate_dof_coordinates()
+    exact = np.zeros((x.shape[0], 3))
+    exact[:, 0] = 0.5 * x[:, 1] * (1.0 - x[:, 1])
+    assert abs(uh.x.array - exact.reshape(-1)).max() < 1e-8, (abs(uh.x.array - exact.reshape(-1)).max(), info)
+    assert np.ptp(ph.x.array) < 1e-7, (np.ptp(ph.x.array), info)
+    # the constraint holds on both fields
+    for f, m in zip((uh, ph), mpcs):
+        got = f.x.array
+        assert abs(got - _host_backsubstitute(m, got)).max() <= 1e-13
+    # wrong function space for u: the reference's ValueError (problem.py:437-441)
+    with pytest.raises(ValueError):
+        LinearProblem(a, L, mpcs, bcs=[bc], u=[fem.Function(Q), fem.Function(Q)])
+
+
+def test_nest_operator_matches_scipy():
+    import scipy.sparse as sp
+    import torch
+
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd.problem import NestOperator
+
+    V, Q, bc, mpcs, a, L = _poiseuille(3)
+    A = dm.create_matrix_nest(a, mpcs)
+    dm.assemble_matrix_nest(A, a, mpcs, bcs=[bc])
+    op = NestOperator(A)
+    K = sp.bmat([[A[0][0].to_scipy(), A[0][1].to_scipy()], [A[1][0].to_scipy(), None]], format="csr")
+    xh = np.random.default_rng(2).standard_normal(op.n)
+    y = op(torch.from_numpy(xh).to(A[0][0].device)).cpu().numpy()
+    ref = K @ xh
+    assert abs(y - ref).max() <= 1e-13 * (abs(K) @ abs(xh)).max()
+
+
+def test_rigid_body_near_null_space_helps_elasticity():
+    """``A.setNearNullSpace(rigid_motions_nullspace(V))`` (python/benchmarks/bench_contact_3D.py:287,320): with the
+    rotations in the prolongators the V-cycle needs fewer CG iterations than with the translations alone, and the answer
+    is the same"""
+    from dolfinx_mpc_amd import fem
+    from dolfinx_mpc_amd.mesh import create_box
+    from dolfinx_mpc_amd.problem import LinearProblem
+    from dolfinx_mpc_amd.utils import rigid_motions_nullspace
+
+    import dolfinx_mpc_amd as dm
+
+    # a slender cantilever (bending = the rotations matter), clamped at x = 0, body force downwards
+    mesh = create_box((0.0, 0.0, 0.0), (8.0, 1.0, 1.0), (64, 8, 8), reorder=(4, 4, 4))
+    V = fem.functionspace(mesh, ("Lagrange", 1, (3,)))
+    bc = fem.dirichletbc(np.zeros(3), fem.locate_dofs_geometrical(V, lambda x: np.isclose(x[0], 0)), V)
+    mpc = dm.MultiPointConstraint(V)
+    mpc.finalize()
+    a = fem.form_elasticity(V, 1.0, 1.25)
+    L = fem.form_source(V, fem.FN_CONSTANT_VEC, constant=np.array([1.0, 0.0, 0.0, -1.0]))
+    res = {}
+    for tag in ("translations", "rigid"):
+        prob = LinearProblem(a, L, mpc, [bc], solver_options={"rtol": 1e-9, "pc_type": "gamg", "max_it": 400})
+        if tag == "rigid":
+            prob.A.setNearNullSpace(rigid_motions_nullspace(V))
+        u = prob.solve()
+        assert prob.info["converged"] and len(prob.info["levels"]) >= 2, prob.info
+        res[tag] = (prob.info["iterations"], u.x.array.copy(), prob.info["near_null_dim"])
+    assert res["translations"][2] == 3 and res["rigid"][2] == 6
+    assert res["rigid"][0] < res["translations"][0], {k: v[0] for k, v in res.items()}
+    scale = abs(res["rigid"][1]).max()
+    assert abs(res["rigid"][1] - res["translations"][1]).max() <= 1e-6 * scale
