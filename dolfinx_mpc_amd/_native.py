@@ -142,6 +142,7 @@ class MatrixArgs(C.Structure):
         ("pair_recs", C.c_void_p),
         ("pair_ctx", C.c_void_p),
         ("pair_dict", C.c_void_p),
+        ("cube_rec_index", C.c_void_p),
         ("stream", C.c_void_p),
     ]
 

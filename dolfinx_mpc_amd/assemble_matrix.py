@@ -658,11 +658,19 @@ def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc, hexa: bool = F
         nslots = d_ents.numel()
         if not closed_form_only:
             _warn_no_locality("cluster", int(nslots), nc, limit=5.0)
-        recs = torch.empty(nslots * 96, dtype=torch.uint8, device=dev)
+        # One record per (row block, cluster) slot, streamed.  MPCX_CUBE_CLUSTER_RECORDS=1: ONE record per cluster (nothing in
+        # a record depends on the row block) and the slots carry the index of their cluster's record
+        # (mpcx_matrix_args_t::cube_rec_index) -- 6 % less traffic (the L2 does not catch all the re-reads of clusters that
+        # touch several blocks) but one more dependent load: 1.01 against 0.94 ms at 256^3 cubes, 1.53 against 1.35 ms on
+        # hexahedra (round 4), so not the default.
+        per_cluster = not closed_form_only and os.environ.get("MPCX_CUBE_CLUSTER_RECORDS", "0") == "1"
+        nrec = nc if (per_cluster or closed_form_only) else nslots
+        rec_ents = torch.arange(nc, dtype=torch.int32, device=dev) if per_cluster else d_ents
+        recs = torch.empty(nrec * 96, dtype=torch.uint8, device=dev)
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         _, t = mpc._device()
         records = L.mpcx_hex_records if hexa else L.mpcx_cube_records
-        rc = records(nslots, d_ents.data_ptr(), d_verts.data_ptr(), bs, D.ptr(bc_dev), t["is_slave"].data_ptr(),
+        rc = records(nrec, rec_ents.data_ptr(), d_verts.data_ptr(), bs, D.ptr(bc_dev), t["is_slave"].data_ptr(),
                      A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), recs.data_ptr(), flag.data_ptr(), D.stream_ptr())
         _native.check(rc, "mpcx_hex_records" if hexa else "mpcx_cube_records")
         if int(flag.item()) != 0:
@@ -684,22 +692,24 @@ def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc, hexa: bool = F
         want_narrow = bs == 1 and not hexa and os.environ.get("MPCX_CUBE_NARROW", "1") != "0"
         want_shape = bs == 1 and os.environ.get("MPCX_CUBE_SHAPES", os.environ.get("MPCX_HEX_SPLIT", "1")) != "0"
         kind = torch.zeros(nb, dtype=torch.int64, device=dev)  # per block: bit 0 = a wide slot, bit 1 = a general cell
+        slot_rec = d_ents.long() if per_cluster else None  # record of every slot
 
-        def any_per_block(slot_flag):
+        def any_per_block(rec_flag):
+            slot_flag = rec_flag[slot_rec] if per_cluster else rec_flag
             cs = torch.zeros(nslots + 1, dtype=torch.int64, device=dev)
             torch.cumsum(slot_flag.to(torch.int64), 0, out=cs[1:])
             return (cs[d_off[1:]] - cs[d_off[:-1]]) > 0
 
         if nslots > 0 and want_narrow:
-            wide = torch.empty(nslots, dtype=torch.uint8, device=dev)
-            _native.check(L.mpcx_cube_slot_width(nslots, recs.data_ptr(), wide.data_ptr(), D.stream_ptr()), "mpcx_cube_slot_width")
+            wide = torch.empty(nrec, dtype=torch.uint8, device=dev)
+            _native.check(L.mpcx_cube_slot_width(nrec, recs.data_ptr(), wide.data_ptr(), D.stream_ptr()), "mpcx_cube_slot_width")
             kind += any_per_block(wide).to(torch.int64)
             del wide
         else:
             kind += 1
         if nslots > 0 and want_shape:
-            general = torch.empty(nslots, dtype=torch.uint8, device=dev)
-            _native.check(L.mpcx_hex_slot_shapes(nslots, recs.data_ptr(), D.mesh_device(form.mesh)["x"].data_ptr(),
+            general = torch.empty(nrec, dtype=torch.uint8, device=dev)
+            _native.check(L.mpcx_hex_slot_shapes(nrec, recs.data_ptr(), D.mesh_device(form.mesh)["x"].data_ptr(),
                                                  general.data_ptr(), D.stream_ptr()), "mpcx_hex_slot_shapes")
             kind += 2 * any_per_block(general).to(torch.int64)
             del general
@@ -707,6 +717,7 @@ def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc, hexa: bool = F
             kind += 2
         kinds = [int(k) for k in torch.unique(kind).tolist()] if nb > 0 else [3]
         parts = []
+        narrow_all = None  # per-cluster narrow records, shared by the narrow launches
         for kd in kinds:
             nbytes, flags = (96 if kd & 1 else 64), (0 if kd & 2 else 1)
             if len(kinds) == 1:
@@ -721,7 +732,25 @@ def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc, hexa: bool = F
                 src = torch.repeat_interleave(d_off[sel] - off_c[:-1], cnt) + torch.arange(tot, dtype=torch.int64, device=dev)
                 ids = sel.to(torch.int32).contiguous()
                 nblk = int(sel.numel())
-            if nbytes == 64:
+            ridx = None
+            if per_cluster:
+                ridx = d_ents if src is None else d_ents[src].contiguous()  # cluster of every slot of this launch
+                if nbytes == 64:
+                    if narrow_all is None:
+                        allc = torch.arange(nc, dtype=torch.int64, device=dev)
+                        narrow_all = torch.empty(nc * 64, dtype=torch.uint8, device=dev)
+                        _native.check(L.mpcx_cube_pack_narrow(nc, allc.data_ptr(), recs.data_ptr(), narrow_all.data_ptr(), D.stream_ptr()),
+                                      "mpcx_cube_pack_narrow")
+                        del allc
+                    out = narrow_all
+                elif len(kinds) == 1 or not want_narrow:
+                    out = recs
+                else:
+                    # the wide launches of a mostly narrow mesh (row blocks with master rows) cover few slots: their records
+                    # are gathered per slot, so that the per-cluster wide records need not be kept
+                    out = recs.view(nc, 96)[ridx.long()].contiguous().view(-1)
+                    ridx = None
+            elif nbytes == 64:
                 if src is None:
                     src = torch.arange(nslots, dtype=torch.int64, device=dev)
                 out = torch.empty(src.numel() * 64, dtype=torch.uint8, device=dev)
@@ -730,14 +759,16 @@ def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc, hexa: bool = F
             else:
                 out = recs if src is None else recs.view(nslots, 96)[src].contiguous().view(-1)
             parts.append((_native.RowBlockPlanT(nblk, max_rows, max_nnz, 0, d_row0.data_ptr(), off_c.data_ptr(), None, None, None),
-                          out, nbytes, ids, off_c, flags))
+                          out, nbytes, ids, off_c, flags, ridx))
         del recs
         keep = (d_row0, parts, d_verts)
         info = {"num_blocks": nb, "num_ents": int(nslots), "max_rows": max_rows, "max_nnz": max_nnz, "clusters": int(nc),
                 "narrow_blocks": sum(int(p[0].num_blocks) for p in parts if p[2] == 64),
                 "closed_form_blocks": sum(int(p[0].num_blocks) for p in parts if p[5] == 1),
-                "bytes": int(d_row0.numel() * 4 + sum(p[1].numel() + p[4].numel() * 8 + (0 if p[3] is None else p[3].numel() * 4)
-                                                      for p in parts))}
+                "bytes": int(d_row0.numel() * 4 + sum(p[4].numel() * 8 + (0 if p[3] is None else p[3].numel() * 4)
+                                                      + (0 if p[6] is None else p[6].numel() * 4) for p in parts)
+                             + sum(t_.numel() for t_ in {id(p[1]): p[1] for p in parts}.values())),
+                "records": "per cluster" if per_cluster else "per slot"}
         return (parts, keep, info)
 
     try:
@@ -1080,6 +1111,7 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
                     u.plan = plan
                     u.cube_recs, u.cube_rec_bytes, u.cube_block_ids = recs.data_ptr(), nbytes, D.ptr(ids)
                     u.cube_flags = part[5] if len(part) > 5 else 0
+                    u.cube_rec_index = D.ptr(part[6]) if len(part) > 6 else None
                     if n_part > 0:
                         u.leftover, u.kernel_name, u.block_scalar = None, name, False
                     chain.append(u)
@@ -1116,6 +1148,7 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
                     t.plan = plan
                     t.cube_recs, t.cube_rec_bytes, t.cube_block_ids = recs.data_ptr(), nbytes, D.ptr(ids)
                     t.cube_flags = part[5] if len(part) > 5 else 0
+                    t.cube_rec_index = D.ptr(part[6]) if len(part) > 6 else None
                     t.n_slave_entities = n_slave if n_part == len(parts) - 1 else 0
                     if n_part > 0:
                         t.leftover, t.kernel_name, t.block_scalar = None, name, False

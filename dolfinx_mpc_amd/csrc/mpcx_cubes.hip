@@ -449,9 +449,10 @@ __global__ void __launch_bounds__(CUBE_MAX_THREADS) matrix_cube_kernel(mpcx_matr
   constexpr int NW = NARROW ? 4 : 6; // 16-byte words per record
   const uint4* __restrict__ recs = static_cast<const uint4*>(a.cube_recs);
   const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  const int32_t* __restrict__ ridx = a.cube_rec_index; // one record per cluster: slot -> record (include/mpcx.h)
   auto load = [&](int64_t t, uint4 (&w)[NW])
   {
-    const uint4* p = recs + t * NW;
+    const uint4* p = recs + (ridx ? int64_t(ridx[t]) : t) * NW;
 #pragma unroll
     for (int i = 0; i < NW; ++i)
       w[i] = p[i];
@@ -947,9 +948,10 @@ __global__ void __launch_bounds__(HEX_MAX_THREADS) matrix_hex_kernel(mpcx_matrix
   const double c0 = a.constants ? a.constants[0] : 1.0;
   const uint4* __restrict__ recs = static_cast<const uint4*>(a.cube_recs);
   const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  const int32_t* __restrict__ ridx = a.cube_rec_index; // one record per cell: slot -> record (include/mpcx.h)
   auto load = [&](int64_t t, uint4 (&w)[6])
   {
-    const uint4* p = recs + t * 6;
+    const uint4* p = recs + (ridx ? int64_t(ridx[t]) : t) * 6;
 #pragma unroll
     for (int i = 0; i < 6; ++i)
       w[i] = p[i];
@@ -1327,13 +1329,15 @@ __global__ void __launch_bounds__(CUBE_AFFINE_MAX_THREADS) matrix_cube_affine_ke
   constexpr int NW = NARROW ? 4 : 6;
   const uint4* __restrict__ recs = static_cast<const uint4*>(a.cube_recs);
   const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  const int32_t* __restrict__ ridx = a.cube_rec_index; // one record per cluster: slot -> record (include/mpcx.h)
   uint4 cur[NW];
   int64_t t = e0 + tid;
   if (t < e1)
   {
+    const int64_t ri = ridx ? int64_t(ridx[t]) : t;
 #pragma unroll
     for (int i = 0; i < NW; ++i)
-      cur[i] = recs[t * NW + i];
+      cur[i] = recs[ri * NW + i];
   }
   for (int i = tid; i < nnzb; i += NT)
     s_vals[i] = 0.0;
@@ -1365,9 +1369,10 @@ __global__ void __launch_bounds__(CUBE_AFFINE_MAX_THREADS) matrix_cube_affine_ke
     }
     if (t + NT < e1)
     {
+      const int64_t ri = ridx ? int64_t(ridx[t + NT]) : t + NT;
 #pragma unroll
       for (int i = 0; i < NW; ++i)
-        cur[i] = recs[(t + NT) * NW + i];
+        cur[i] = recs[ri * NW + i];
     }
     double C0[3], C1[3], C2[3];
     cross3(j1, j2, C0);

@@ -23,8 +23,9 @@
 extern "C" {
 #endif
 
-/* 4: mpcx_matrix_args_t::cube_flags (in the padding after cube_rec_bytes), hexahedron and closed-form cluster entry points */
-#define MPCX_VERSION 5
+/* 4: mpcx_matrix_args_t::cube_flags (in the padding after cube_rec_bytes), hexahedron and closed-form cluster entry points
+ * 5: pair records, scalar types;  6: mpcx_matrix_args_t::cube_rec_index (one cluster record per cluster, before ``stream``) */
+#define MPCX_VERSION 6
 
 /* Offsets into the CSR value / column arrays (rowptr entries, positions): 64-bit, so that one GPU can
  * hold matrices with more than 2^31 - 1 stored entries (Taylor-Hood a00 on 128^3 cells: 4.4 G) -- PETSc's
@@ -297,6 +298,14 @@ typedef struct
    * row-slot bits cleared, zero padded; pair_recs then holds COMPACT records, two words
    * per pair: word 0 as above, word 1 = row slot | pattern id << 16.  NULL: full records. */
   const uint32_t* pair_dict;
+  /* MPCX_ALG_CUBE, optional: DEVICE [slots of this launch] int32, cube_rec_index[t] = index into cube_recs of the record of
+   * slot t.  A record (vertex ids + mask bits, scatter offsets relative to the row starts) is a property of the CLUSTER,
+   * not of the (row block, cluster) slot: with an index the caller builds ONE record per cluster (mpcx_cube_records /
+   * mpcx_hex_records with block_ents = 0 .. n_clusters-1) and a cluster touching several row blocks is read through the
+   * L2 instead of being stored once per block.  Measured (round 4): 6 % less HBM traffic, but the extra dependent load costs
+   * more than it saves (1.01 against 0.94 ms at 256^3 cubes) -- the Python host leaves it NULL unless
+   * MPCX_CUBE_CLUSTER_RECORDS=1.  NULL: record t belongs to slot t. */
+  const int32_t* cube_rec_index;
   void* stream;
 } mpcx_matrix_args_t;
 
