@@ -103,7 +103,8 @@ class FunctionSpace:
                 raise NotImplementedError("hexahedra: Q1 and Q2")
         self.mesh = mesh
         self.degree = degree
-        bs = 1 if not shape else int(shape[0])
+        bs = 1 if not shape else int(np.prod(shape))  # vector (d,) and tensor (d, d) valued spaces: blocked dofs
+        self.value_shape = tuple(int(k) for k in shape) if shape else ()
         nghost = 0
         self._dof_coords = None
         # partitioned meshes (dolfinx_mpc_amd.distributed): global id and lowest node
@@ -791,6 +792,27 @@ def form_generated(kind: str, V: FunctionSpace, fn_id: int = FN_ONE, constant=No
     src, name = generate(kind, cell, V.degree, V.dofmap.bs, (k.qpts, k.qwts), coefficient_degree=k.coeff_degree,
                          use_constant=has_c and kind != "elasticity", fexpr=fn_c_expression(fn_id) if kind == "source" else "1.0")
     return form_ufcx([V] if kind == "source" else [V, V], src, name, "cell", integ.entities, integ.coefficient, integ.constant, builtin=k)
+
+
+def forms_nonlinear_poisson(V, u: Function, f_expr: str, quadrature_degree: Optional[int] = None):
+    """(F, J) of the quasi-linear Poisson problem of python/tests/test_nonlinear_assembly.py:76-81,
+    F = inner((1 + u^2) grad(u), grad(v)) dx - inner(f, v) dx and its Gateaux derivative J, as imported (generated)
+    kernels with ``u`` (a Function on ``V``) as coefficient -- what ``fem.form(F)`` / ``fem.form(ufl.derivative(F, u))``
+    give the reference through FFCx.  ``f_expr``: C expression of f in ``x[0..2]``.  Rule: degree 4 p (the integrand
+    u^2 grad(u).grad(v) has degree 4 p - 2 on affine cells)."""
+    from . import elements
+    from .codegen import gauss_tensor, generate_nonlinear_poisson
+
+    if u.function_space is not V or V.dofmap.bs != 1:
+        raise ValueError("forms_nonlinear_poisson: a scalar space and the unknown on the same space")
+    cell, p = V.mesh.cell_name, V.degree
+    qdeg = 4 * p if quadrature_degree is None else quadrature_degree
+    rule = make_quadrature(cell, qdeg) if elements.is_simplex(cell) else gauss_tensor(elements.tdim(cell), qdeg)
+    out = []
+    for which, spaces in (("F", [V]), ("J", [V, V])):
+        src, name = generate_nonlinear_poisson(which, cell, p, rule, f_expr)
+        out.append(form_ufcx(spaces, src, name, "cell", None, u, None))
+    return tuple(out)
 
 
 def form_facet_mass(V, facets: np.ndarray, constant=None) -> Form:

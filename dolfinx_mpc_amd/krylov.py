@@ -5,6 +5,7 @@ every scalar of the recurrences stays on the device as a 0-d tensor and the host
 
   * ``pcg``    -- preconditioned conjugate gradients (symmetric positive definite systems: Poisson, elasticity;
                   ``ksp_type cg`` of python/benchmarks/bench_periodic.py:112-149, bench_contact_3D.py:290-316)
+  * ``bicgstab`` -- right-preconditioned BiCGStab for nonsymmetric systems (the Jacobians of ``NonlinearProblem``)
   * ``minres`` -- preconditioned MINRES for symmetric indefinite systems with a symmetric positive definite
                   preconditioner: the Stokes nest system (``ksp.setType("minres")`` with an additive field split,
                   python/tests/test_stokes_channelflow.py:107-125, python/demos/demo_stokes_nest.py:231-252)
@@ -121,3 +122,46 @@ def minres(A_mv, M_inv, b, x0=None, rtol: float = 1e-10, atol: float = 0.0, max_
         info["converged"] = info["residual_norm"] <= tol
     info["iterations"] = k
     return x, info
+
+
+def bicgstab(A_mv, M_inv, b, x0=None, rtol: float = 1e-10, atol: float = 0.0, max_it: int = 2000, check_every: int = 5):
+    """Right-preconditioned BiCGStab (van der Vorst) for the nonsymmetric Jacobians of a Newton iteration
+    (python/src/dolfinx_mpc/problem.py:26-85: the SNES linear solves); same conventions as ``pcg``."""
+    import torch
+
+    x = torch.zeros_like(b) if x0 is None else x0.clone()
+    r = b - A_mv(x) if x0 is not None else b.clone()
+    rhat = r.clone()
+    bnorm = float(torch.linalg.vector_norm(b))
+    tol = max(rtol * bnorm, atol)
+    one = torch.ones((), dtype=b.dtype, device=b.device)
+
+    def safe(d):
+        return torch.where(d != 0, d, one)
+
+    rho_old, alpha, omega = one, one, one
+    v = torch.zeros_like(b)
+    p = torch.zeros_like(b)
+    rn = float(torch.linalg.vector_norm(r))
+    k = 0
+    while rn > tol and k < max_it:
+        for _ in range(min(check_every, max_it - k)):
+            rho = torch.dot(rhat, r)
+            beta = (rho / safe(rho_old)) * (alpha / safe(omega))
+            p = r + beta * (p - omega * v)
+            y = M_inv(p)
+            v = A_mv(y)
+            alpha = rho / safe(torch.dot(rhat, v))
+            s = r - alpha * v
+            z = M_inv(s)
+            t = A_mv(z)
+            omega = torch.dot(t, s) / safe(torch.dot(t, t))
+            x = x + alpha * y + omega * z
+            r = s - omega * t
+            rho_old = rho
+            k += 1
+        r = b - A_mv(x)  # the true residual replaces the recurrence's (which drifts) at every check
+        rn = float(torch.linalg.vector_norm(r))
+        if not np.isfinite(rn):
+            raise RuntimeError("bicgstab: the residual is not finite")
+    return x, {"iterations": k, "residual_norm": rn, "b_norm": bnorm, "converged": bool(rn <= tol)}

@@ -295,6 +295,17 @@ class MPCMatrix:
             import torch
 
             self._vals = torch.zeros(self.d_cols.numel(), dtype=self.dtype, device=self.device)
+            self._vals_streams = {torch._C._cuda_getCurrentRawStream(self.device.index)}  # the allocating stream
+        elif self._ready is not None:
+            # the values may have been allocated on a side stream (first assembly): tell the caching allocator about every
+            # other stream that reads them, so that the block is not handed out again while such a read is queued
+            import torch
+
+            raw = torch._C._cuda_getCurrentRawStream(self.device.index)
+            seen = getattr(self, "_vals_streams", None)
+            if seen is not None and raw not in seen:
+                self._vals.record_stream(torch.cuda.current_stream(self.device))
+                seen.add(raw)
         if self._compact_stale:
             self._expand_compact()
         if self._pending is not None:

@@ -391,3 +391,145 @@ class LinearProblem:
         self._mpc.backsubstitution(self._x)
         self.u.x.array[:] = self._x.numpy()
         return self.u
+
+
+class NonlinearProblem:
+    """F(u; v) = 0 with a multi point constraint by Newton's method -- the reference's ``NonlinearProblem``
+    (python/src/dolfinx_mpc/problem.py:155-352: PETSc SNES ``newtonls`` with its residual / Jacobian callbacks
+    ``assemble_residual_mpc`` :88-152 and ``assemble_jacobian_mpc`` :26-85), with the same call order round the hot path:
+
+        u <- x;  mpc.homogenize(u);  mpc.backsubstitution(u)              (the forms read u)
+        b  = assemble_vector(F, mpc);  apply_lifting(b, [J], [bcs], mpc, x0=[x], scale=-1);  set_bc(b, bcs, x0=x, scale=-1)
+        A  = assemble_matrix(J, mpc, bcs);   solve A dx = b;   x <- x - dx
+
+    Args:
+        F, J: residual (rank 1) and Jacobian (rank 2) forms whose coefficient is ``u`` (no symbolic differentiation here:
+            the caller -- a form compiler -- supplies J, e.g. ``fem.forms_nonlinear_poisson``)
+        u: the unknown, a ``fem.Function`` on ``mpc.function_space``; its values are the initial guess
+        mpc, bcs: constraint and Dirichlet conditions
+        solver_options: ``snes_rtol`` / ``snes_atol`` (residual norm), ``snes_stol`` (step), ``snes_max_it``; linear solves:
+            ``ksp_type`` ``"bicgstab"`` (device, Jacobi-preconditioned; default) or ``"preonly"`` with ``pc_type`` ``"lu"`` --
+            a sparse direct solve on the HOST (scipy SuperLU), the analogue of the reference tests' MUMPS LU
+            (python/tests/test_nonlinear_assembly.py:82-93) for small systems; ``ksp_rtol``, ``ksp_max_it``.
+    """
+
+    def __init__(self, F: Form, u: Function, mpc: MultiPointConstraint, bcs: Optional[Sequence[DirichletBC]] = None,
+                 J: Optional[Form] = None, solver_options: Optional[dict] = None):
+        if J is None:
+            raise ValueError("NonlinearProblem: the Jacobian form J is required (there is no symbolic differentiation here)")
+        if not isinstance(mpc, MultiPointConstraint):
+            raise NotImplementedError("NonlinearProblem: single (non-nest) systems")
+        mpc._not_finalized()
+        if u.function_space is not mpc.function_space:
+            raise ValueError("The input function has to be in the function space in the multi-point constraint")
+        self._F, self._J, self._u, self.mpc = F, J, u, mpc
+        self.bcs = [] if bcs is None else list(bcs)
+        self._A = create_matrix(J, mpc)
+        self._b = create_vector(mpc.function_space)
+        self._x = Vector(mpc.function_space.num_dofs)
+        self.solver_options = dict(solver_options or {})
+        self.info: dict = {}
+
+    @property
+    def A(self) -> MPCMatrix:
+        return self._A
+
+    @property
+    def b(self) -> Vector:
+        return self._b
+
+    @property
+    def x(self) -> Vector:
+        return self._x
+
+    def _assign_u(self):
+        """u <- x, then the constraint on the slaves (problem.py:101-113)"""
+        self._u.x.array[:] = self._x.numpy()
+        self.mpc.homogenize(self._u)
+        self.mpc.backsubstitution(self._u)
+
+    def assemble_residual(self) -> Vector:
+        """problem.py:88-152"""
+        self._assign_u()
+        assemble_vector(self._F, self.mpc, b=self._b)
+        apply_lifting(self._b, [self._J], [self.bcs], self.mpc, x0=[self._x], scale=-1.0)
+        set_bc(self._b, self.bcs, x0=self._x, scale=-1.0)
+        return self._b
+
+    def assemble_jacobian(self) -> MPCMatrix:
+        """problem.py:26-85 (u already holds the current iterate)"""
+        assemble_matrix(self._J, self.mpc, bcs=self.bcs, diagval=1.0, A=self._A)
+        return self._A
+
+    def _linear_solve(self, opts) -> "object":
+        import torch
+
+        from .krylov import bicgstab
+
+        ksp = str(opts.get("ksp_type", "bicgstab")).lower()
+        pc = str(opts.get("pc_type", "jacobi")).lower()
+        A, b = self._A, self._b
+        if ksp == "preonly" and pc == "lu":
+            import scipy.sparse.linalg as spla
+
+            dx = spla.splu(A.to_scipy().tocsc()).solve(b.numpy())
+            self.info["linear"] = {"ksp_type": "preonly", "pc_type": "lu (host, scipy SuperLU)"}
+            return torch.from_numpy(dx).to(b.array.device)
+        if ksp != "bicgstab" or pc != "jacobi":
+            raise NotImplementedError(f"NonlinearProblem: ksp_type {ksp!r} / pc_type {pc!r} (bicgstab + jacobi, preonly + lu)")
+        dinv = _inverse_diagonal(A)
+        Av = _View(None)
+
+        def mv(v):
+            y = torch.empty_like(v)
+            Av.array = v.contiguous()
+            spmv(A, Av, _View(y))
+            return y
+
+        dx, li = bicgstab(mv, lambda r: dinv * r, b.array, rtol=float(opts.get("ksp_rtol", 1e-12)),
+                          max_it=int(opts.get("ksp_max_it", 5000)))
+        if not li["converged"]:
+            raise RuntimeError(f"NonlinearProblem: the linear solve did not converge: {li}")
+        self.info.setdefault("linear_iterations", []).append(li["iterations"])
+        return dx
+
+    def solve(self):
+        """Newton iteration without line search (``snes_linesearch_type none``); returns (u, converged_reason,
+        iterations) with PETSc's reason codes: 2 = |F| < atol, 3 = |F| < rtol |F0|, 4 = |dx| < stol |x|, -5 = max_it."""
+        import torch
+
+        opts = self.solver_options
+        rtol, atol = float(opts.get("snes_rtol", 1e-8)), float(opts.get("snes_atol", 1e-50))
+        stol, max_it = float(opts.get("snes_stol", 1e-8)), int(opts.get("snes_max_it", 50))
+        self._x.array.copy_(torch.from_numpy(np.ascontiguousarray(self._u.x.array, dtype=np.float64)))
+        self.info = {"residual_norms": []}
+        reason, it = 0, 0
+        f0 = None
+        while True:
+            b = self.assemble_residual()
+            fn = float(torch.linalg.vector_norm(b.array))
+            self.info["residual_norms"].append(fn)
+            if not np.isfinite(fn):
+                reason = -4  # SNES_DIVERGED_FNORM_NAN
+                break
+            f0 = fn if f0 is None else f0
+            if fn < atol:
+                reason = 2
+                break
+            if it > 0 and fn <= rtol * f0:
+                reason = 3
+                break
+            if it >= max_it:
+                reason = -5
+                break
+            self.assemble_jacobian()
+            dx = self._linear_solve(opts)
+            self._x.array.sub_(dx)
+            it += 1
+            if float(torch.linalg.vector_norm(dx)) < stol * float(torch.linalg.vector_norm(self._x.array)):
+                reason = 4
+                self.assemble_residual()  # leaves u = the final iterate with the constraint imposed
+                break
+        self._assign_u()
+        self.info.update(iterations=it, converged_reason=reason)
+        return self._u, reason, it

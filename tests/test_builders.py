@@ -293,3 +293,39 @@ def test_gpu_assembly_with_built_constraints_matches_oracle(oracle, kind, alg):
     assert abs(out["A"].data - ref["A"].data).max() <= 1e-12 * max(1.0, abs(ref["A"]).max())
     for k in ("b", "b_lifted"):
         assert abs(out[k] - ref[k]).max() <= 1e-12 * max(1.0, abs(ref[k]).max()), k
+
+
+@pytest.mark.parametrize("tensor_order", [0, 1, 2])
+@pytest.mark.parametrize("poly_order", [1, 2, 3])
+def test_periodic_slaves_of_tensor_spaces(tensor_order, poly_order):
+    """the constraint of python/tests/test_nonlinear_assembly.py:117-150 (test_homogenize): scalar, vector and
+    TENSOR valued Lagrange P1-P3 spaces on an 8 x 8 square, x = 0 tied to x = 1 -- every component of every dof on the
+    slave line is a slave with one master of coefficient 1 in the same component"""
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import fem
+    from dolfinx_mpc_amd.mesh import create_unit_square
+
+    mesh = create_unit_square(8, 8)
+    shape = [(), (2,), (2, 2)][tensor_order]
+    V = fem.functionspace(mesh, ("Lagrange", poly_order, shape)) if shape else fem.functionspace(mesh, ("Lagrange", poly_order))
+    bs = int(np.prod(shape)) if shape else 1
+    assert V.dofmap.bs == bs
+
+    def rel(x):
+        out = np.zeros(x.shape)
+        out[0], out[1], out[2] = 1.0 - x[0], x[1], x[2]
+        return out
+
+    mpc = dm.MultiPointConstraint(V)
+    mpc.create_periodic_constraint_geometrical(V, lambda x: np.isclose(x[0], 0.0), rel, [])
+    mpc.finalize()
+    nline = 8 * poly_order + 1
+    assert mpc.slaves.size == nline * bs
+    xc = V.tabulate_dof_coordinates()
+    off, m = mpc.masters.offsets, mpc.masters.array
+    coef = mpc.coefficients()[0]
+    for s in mpc.slaves:
+        assert off[s + 1] - off[s] == 1 and abs(coef[off[s]] - 1.0) < 1e-13
+        mm = int(m[off[s]])
+        assert mm % bs == s % bs
+        assert np.allclose(xc[mm // bs], xc[s // bs] + [1.0, 0.0, 0.0])

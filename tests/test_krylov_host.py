@@ -105,3 +105,18 @@ def test_minres_matches_cg_on_spd():
     x, info = minres(_mv(A), lambda r: dinv * r, torch.from_numpy(b), rtol=1e-12, max_it=1000)
     assert info["converged"], info
     assert abs(x.numpy() - spla.spsolve(A.tocsc(), b)).max() < 1e-8
+
+
+def test_bicgstab_nonsymmetric():
+    import torch
+
+    from dolfinx_mpc_amd.krylov import bicgstab
+
+    n = 20
+    A = (_lap(n) + 0.4 * sp.kron(sp.eye(n), sp.diags([-1.0, 1.0], [-1, 1], shape=(n, n)))).tocsr()  # convection term
+    b = np.random.default_rng(7).standard_normal(A.shape[0])
+    dinv = torch.from_numpy(1.0 / A.diagonal())
+    x, info = bicgstab(_mv(A), lambda r: dinv * r, torch.from_numpy(b), rtol=1e-11, max_it=2000)
+    assert info["converged"], info
+    assert np.linalg.norm(A @ x.numpy() - b) <= 1.01e-11 * np.linalg.norm(b)
+    assert abs(x.numpy() - spla.spsolve(A.tocsc(), b)).max() < 1e-8
