@@ -295,7 +295,8 @@ class MPCMatrix:
             import torch
 
             self._vals = torch.zeros(self.d_cols.numel(), dtype=self.dtype, device=self.device)
-            self._vals_streams = {torch._C._cuda_getCurrentRawStream(self.device.index)}  # the allocating stream
+            if self.device.type == "cuda":
+                self._vals_streams = {torch._C._cuda_getCurrentRawStream(self.device.index)}  # the allocating stream
         elif self._ready is not None:
             # the values may have been allocated on a side stream (first assembly): tell the caching allocator about every
             # other stream that reads them, so that the block is not handed out again while such a read is queued
