@@ -241,6 +241,11 @@ class FunctionSpace:
     def contains(self, other: "FunctionSpace") -> bool:
         return other is self
 
+    def clone(self) -> "FunctionSpace":
+        """a distinct space object with the same mesh, element and dof numbering (dolfinx ``FunctionSpace.clone``,
+        python/tests/test_multispace_mpc.py:31): constraints and boundary conditions of the two do not mix"""
+        return FunctionSpace(self.mesh, ("Lagrange", self.degree), self.value_shape or None)
+
 
 def functionspace(mesh: Mesh, element, shape: Optional[tuple] = None) -> FunctionSpace:
     if len(element) == 3 and shape is None:

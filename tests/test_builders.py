@@ -329,3 +329,49 @@ def test_periodic_slaves_of_tensor_spaces(tensor_order, poly_order):
         mm = int(m[off[s]])
         assert mm % bs == s % bs
         assert np.allclose(xc[mm // bs], xc[s // bs] + [1.0, 0.0, 0.0])
+
+
+@pytest.mark.parametrize("cell_type,degrees", [("quadrilateral", (1, 2, 3)), ("hexahedron", (1, 2)), ("tetrahedron", (1, 2)),
+                                               ("triangle", (1, 2, 3))])
+@pytest.mark.parametrize("N", [3, 5, 8])
+def test_multiple_mpc_spaces_sparsity(cell_type, degrees, N):
+    """python/tests/test_multispace_mpc.py:12-77: the pattern of a rectangular block with constraints on two DISTINCT
+    (cloned) spaces has as many entries as with one constraint on both sides (degrees: those this package's elements
+    cover; the reference sweeps 1, 2, 4)"""
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import fem
+    from dolfinx_mpc_amd.mesh import create_unit_cube, create_unit_square
+
+    two = cell_type in ("quadrilateral", "triangle")
+    mesh = create_unit_square(N, N, cell_type) if two else create_unit_cube(N, N, N, cell_type)
+    gdim = 2 if two else 3
+    atol = 5000 * np.finfo(np.float64).eps
+
+    def periodic_boundary(x):
+        return np.isclose(x[0], 1, atol=atol) | np.isclose(x[2], 1, atol=atol)
+
+    def periodic_map(x):
+        out = x.copy()
+        out[0][np.isclose(x[0], 1, atol=atol)] -= 1
+        out[gdim - 1][np.isclose(x[2], 1, atol=atol)] -= 1
+        return out
+
+    for deg in degrees:
+        V = fem.functionspace(mesh, ("Lagrange", deg))
+        Q = V.clone()
+        assert Q is not V and Q.num_dofs == V.num_dofs and np.array_equal(Q.dofmap.list, V.dofmap.list)
+        mpc_u = dm.MultiPointConstraint(V)
+        mpc_u.create_periodic_constraint_geometrical(V, periodic_boundary, periodic_map, [], tol=atol)
+        mpc_u.finalize()
+        mpc_p = dm.MultiPointConstraint(Q)
+        mpc_p.create_periodic_constraint_geometrical(Q, periodic_boundary, periodic_map, [], tol=atol)
+        mpc_p.finalize()
+        assert mpc_u.slaves.size > 0
+        a01 = fem.Form([V, Q], fem.form_mass(V).integrals)  # inner(p, v) dx: rows V, columns Q (pattern only)
+        a10 = fem.Form([Q, V], fem.form_mass(V).integrals)
+        r0, c0 = dm.create_sparsity_pattern(a01, [mpc_u, mpc_p], where="host")
+        r1, c1 = dm.create_sparsity_pattern(a01, [mpc_u, mpc_u], where="host")
+        assert c0.size == c1.size and np.array_equal(r0, r1) and np.array_equal(c0, c1)
+        r0, c0 = dm.create_sparsity_pattern(a10, [mpc_p, mpc_u], where="host")
+        r1, c1 = dm.create_sparsity_pattern(a10, [mpc_u, mpc_u], where="host")
+        assert c0.size == c1.size and np.array_equal(r0, r1) and np.array_equal(c0, c1)
