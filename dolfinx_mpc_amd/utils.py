@@ -1,7 +1,8 @@
 """``dolfinx_mpc.utils`` names that belong to the constraint builders and the solve
 (python/src/dolfinx_mpc/utils/mpc_utils.py): ``create_normal_approximation`` (:422-438, the direction field the slip
 constraints take), ``rotation_matrix`` (:35-48), ``rigid_motions_nullspace`` (:163-213, the near-null space of the
-elasticity operators for the multigrid preconditioner)."""
+elasticity operators for the multigrid preconditioner), ``determine_closest_block`` / ``create_point_to_point_constraint``
+(:216-420, the constraint arrays that tie the dofs of two boundary points, python/demos/demo_elasticity_disconnect.py:176-190)."""
 
 import numpy as np
 
@@ -9,7 +10,8 @@ from .la import NullSpace
 from .mesh import rotation_matrix
 from .multipointconstraint import create_normal_approximation, locate_points
 
-__all__ = ["create_normal_approximation", "rotation_matrix", "locate_points", "rigid_motions_nullspace"]
+__all__ = ["create_normal_approximation", "rotation_matrix", "locate_points", "rigid_motions_nullspace",
+           "determine_closest_block", "create_point_to_point_constraint"]
 
 
 def rigid_motions_nullspace(V) -> NullSpace:
@@ -39,3 +41,60 @@ def rigid_motions_nullspace(V) -> NullSpace:
             vecs[i] -= (vecs[j] @ vecs[i]) * vecs[j]
         vecs[i] /= np.linalg.norm(vecs[i])
     return NullSpace(list(vecs))
+
+
+def determine_closest_block(V, point):
+    """(owning process, [dof block]) of the dof block closest to ``point`` among the dofs of the cells that touch the
+    boundary (python/src/dolfinx_mpc/utils/mpc_utils.py:216-297; single process: the owner is 0).  The reference first
+    finds the closest boundary CELL and then the closest block of that cell; here the closest block of all boundary cells is
+    taken, which is the same block whenever that block belongs to the closest cell (a point on or near the boundary)."""
+    mesh = V.mesh
+    cells = np.unique(mesh.exterior_facets()[:, 0])
+    if cells.size == 0:
+        return 0, []
+    blocks = np.unique(V.dofmap.list[cells].reshape(-1))
+    x = V.tabulate_dof_coordinates()[blocks]
+    p = np.zeros(3)
+    p[: np.size(point)] = np.asarray(point, dtype=np.float64).reshape(-1)
+    return 0, [int(blocks[int(np.argmin(np.linalg.norm(x - p[None, :], axis=1)))])]
+
+
+def create_point_to_point_constraint(V, slave_point, master_point, vector=None):
+    """(slaves, masters, coeffs, owners, offsets) for ``MultiPointConstraint.add_constraint`` tying the dof block closest to
+    ``slave_point`` to the block closest to ``master_point`` (python/src/dolfinx_mpc/utils/mpc_utils.py:300-420, single
+    process).  ``vector`` None: every component of the slave block equals the same component of the master block.
+    With a ``vector`` v (one entry per component): ONE slave, the component s of largest |v|, constrained so that
+    v . u_slave_block = v . u_master_block:  u_s = sum_{i != s} (-v_i / v_s) u_slave_block[i] + sum_i (v_i / v_s) u_master[i]
+    (components with v_i = 0 are left out)."""
+    _, sb = determine_closest_block(V, slave_point)
+    _, mb = determine_closest_block(V, master_point)
+    if not sb or not mb:
+        raise RuntimeError("create_point_to_point_constraint: the mesh has no boundary cells")
+    bs = V.dofmap.bs
+    sblock, mblock = sb[0], mb[0]
+    masters_all = np.arange(mblock * bs, mblock * bs + bs, dtype=np.int64)
+    if vector is None:
+        slaves = np.arange(sblock * bs, sblock * bs + bs, dtype=np.int32)
+        masters = masters_all
+        coeffs = np.ones(bs, dtype=np.float64)
+        offsets = np.arange(0, bs + 1, dtype=np.int32)
+    else:
+        v = np.asarray(vector, dtype=np.float64).reshape(-1)
+        assert v.size == bs, "one vector entry per component of the space"
+        zero = np.isclose(v, 0.0)
+        s = int(np.argmax(np.abs(v)))
+        assert not zero[s], "the vector must not vanish"
+        slaves = np.array([sblock * bs + s], dtype=np.int32)
+        m, c = [], []
+        for i in range(bs):  # the slave block's other components first (mpc_utils.py:332-336), then the master block
+            if i != s and not zero[i]:
+                m.append(sblock * bs + i)
+                c.append(-v[i] / v[s])
+        for i in range(bs):
+            if not zero[i]:
+                m.append(int(masters_all[i]))
+                c.append(v[i] / v[s])
+        masters, coeffs = np.asarray(m, dtype=np.int64), np.asarray(c, dtype=np.float64)
+        offsets = np.array([0, masters.size], dtype=np.int32)
+    owners = np.zeros(masters.size, dtype=np.int32)
+    return slaves, masters, coeffs, owners, offsets
