@@ -238,6 +238,11 @@ EXPORTS = [
     "mpcx_cluster_plan_leftover",
     "mpcx_cluster_plan_part",
     "mpcx_cluster_plan_destroy",
+    "mpcx_cell_plan_create",
+    "mpcx_cell_plan_fill",
+    "mpcx_cell_plan_num_slots",
+    "mpcx_cell_plan_num_blocks",
+    "mpcx_cell_plan_destroy",
     "mpcx_owner_plan_create",
     "mpcx_owner_plan_fill",
     "mpcx_owner_plan_destroy",
@@ -443,6 +448,17 @@ def lib() -> C.CDLL:
     L.mpcx_cluster_plan_part.restype = C.c_int
     L.mpcx_cluster_plan_destroy.argtypes = [vp]
     L.mpcx_cluster_plan_destroy.restype = None
+    L.mpcx_cell_plan_create.argtypes = [i32, vp, vp, vp, i64, i32, vp, i64, vp, i32, i32, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, i32, i32, vp,
+                                        C.POINTER(C.c_void_p)]
+    L.mpcx_cell_plan_create.restype = C.c_int
+    L.mpcx_cell_plan_fill.argtypes = [vp, vp]
+    L.mpcx_cell_plan_fill.restype = C.c_int
+    L.mpcx_cell_plan_num_slots.argtypes = [vp]
+    L.mpcx_cell_plan_num_slots.restype = C.c_int64
+    L.mpcx_cell_plan_num_blocks.argtypes = [vp]
+    L.mpcx_cell_plan_num_blocks.restype = C.c_int32
+    L.mpcx_cell_plan_destroy.argtypes = [vp]
+    L.mpcx_cell_plan_destroy.restype = None
     L.mpcx_owner_plan_create.argtypes = [i64, i32, vp, i32, i32, i32, vp, i32, i32, vp, C.POINTER(C.c_void_p)]
     L.mpcx_owner_plan_create.restype = C.c_int
     L.mpcx_owner_plan_fill.argtypes = [vp, C.POINTER(VectorArgs)]

@@ -589,3 +589,161 @@ extern "C" int mpcx_owner_plan_fill(const mpcx_owner_plan_t* p, mpcx_vector_args
 }
 
 extern "C" void mpcx_owner_plan_destroy(mpcx_owner_plan_t* p) { delete p; }
+
+// ---------------------------------------------------------------------------------------------------------
+// The per-cell row-block plan of MPCX_ALG_ROWBLOCK behind one call (include/mpcx.h mpcx_cell_plan_*): row ranges, the
+// entities of every block (ordered by the local rows they hold inside it), the 8-bit scatter-offset table and the two
+// masked dofmaps -- the steps dolfinx_mpc_amd/assemble_matrix.py::_rowblock_plan strings together through torch.
+// ---------------------------------------------------------------------------------------------------------
+namespace
+{
+// sort key of a (block, entity) pair: block in the high bits, then the word of local rows the entity holds in the block
+__global__ void group_keys(int64_t n, const int32_t* pair_block, const int32_t* pair_rows, int nd, int64_t* key)
+{
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n)
+    key[i] = (int64_t(pair_block[i]) << nd) | (pair_rows ? int64_t(uint32_t(pair_rows[i])) & ((int64_t(1) << nd) - 1) : 0);
+}
+} // namespace
+
+struct mpcx_cell_plan
+{
+  Dev row0, off, ents, offs, md0, md1;
+  int32_t num_blocks = 0, max_rows = 0, max_nnz = 0;
+  int64_t n_slots = 0;
+  bool same_mdofmap = false;
+};
+
+extern "C" int mpcx_cell_plan_create(int32_t nrows, const mpcx_nnz_t* rowptr, const mpcx_nnz_t* rowptr_host, const int32_t* cols,
+                                     int64_t n_entities, int32_t estride, const int32_t* entities, int64_t num_cells,
+                                     const int32_t* dofmap0, int32_t nd0, int32_t bs0, const int8_t* bc0, const int8_t* is_slave0,
+                                     const int32_t* dofmap1, int32_t nd1, int32_t bs1, const int8_t* bc1, const int8_t* is_slave1,
+                                     int32_t max_rows, int32_t max_nnz, const int32_t* row_hints, int32_t n_hints, int32_t group_rows,
+                                     void* stream, mpcx_cell_plan_t** out)
+{
+  if (!out || nrows <= 0 || !rowptr || !rowptr_host || !cols || n_entities < 0 || !dofmap0 || !dofmap1 || !is_slave0 || !is_slave1
+      || nd0 < 1 || nd1 < 1 || bs0 < 1 || bs1 < 1 || bs0 > 3 || bs1 > 3 || (estride != 1 && estride != 2) || (group_rows && nd0 > 30))
+  {
+    mpcx_set_error("mpcx_cell_plan_create: invalid arguments");
+    return -1;
+  }
+  *out = nullptr;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  auto plan = std::make_unique<mpcx_cell_plan>();
+  // ---- row ranges (host: one greedy pass over rowptr)
+  std::vector<int32_t> row0(size_t(nrows) + 2);
+  const int64_t nb = mpcx_block_ranges(nrows, rowptr_host, max_rows, max_nnz, bs0, row_hints, n_hints, row0.data(), int64_t(row0.size()));
+  if (nb < 0)
+    return -4; // (a single dof block beyond the block capacity: MPCX_ALG_ATOMIC is the way; the message is set)
+  plan->num_blocks = int32_t(nb);
+  for (int64_t b = 0; b < nb; ++b)
+  {
+    plan->max_rows = std::max(plan->max_rows, row0[b + 1] - row0[b]);
+    plan->max_nnz = std::max<int32_t>(plan->max_nnz, int32_t(rowptr_host[row0[b + 1]] - rowptr_host[row0[b]]));
+  }
+  if (plan->row0.alloc((nb + 1) * 4) || hip_ok(hipMemcpyAsync(plan->row0.p, row0.data(), (nb + 1) * 4, hipMemcpyHostToDevice, st), "hipMemcpyAsync"))
+    return -100;
+  // ---- (block, entity) slots: count -> scan -> fill -> stable sort by (block, rows held) -> offsets per block
+  Dev counts, offs, pair_block, pair_ent, pair_rows, key, key_s;
+  const size_t ne = size_t(std::max<int64_t>(n_entities, 1));
+  if (counts.alloc(ne * 4) || offs.alloc((ne + 1) * 8) || plan->off.alloc((nb + 1) * 8))
+    return -100;
+  int64_t total = 0;
+  if (n_entities > 0)
+  {
+    if (int rc = mpcx_rowblock_pairs_device(n_entities, estride, entities, dofmap0, nd0, bs0, int32_t(nb), plan->row0.as<int32_t>(),
+                                            counts.as<int32_t>(), nullptr, nullptr, nullptr, nullptr, 0, stream))
+      return rc;
+    if (int rc = with_temp([&](void* t, size_t* b) { return mpcx_scan_exclusive_i32_i64(counts.as<int32_t>(), n_entities, offs.as<int64_t>(), t, b, stream); }))
+      return rc;
+    if (hip_ok(hipMemcpyAsync(&total, offs.as<int64_t>() + n_entities, 8, hipMemcpyDeviceToHost, st), "hipMemcpyAsync")
+        || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+      return -100;
+  }
+  plan->n_slots = total;
+  const size_t ts = size_t(std::max<int64_t>(total, 1));
+  if (pair_block.alloc(ts * 4) || pair_ent.alloc(ts * 4) || key.alloc(ts * 8) || key_s.alloc(ts * 8) || plan->ents.alloc(ts * 4)
+      || (group_rows && pair_rows.alloc(ts * 4)))
+    return -100;
+  const int shift = group_rows ? nd0 : 0;
+  if (total > 0)
+  {
+    if (int rc = mpcx_rowblock_pairs_device(n_entities, estride, entities, dofmap0, nd0, bs0, int32_t(nb), plan->row0.as<int32_t>(),
+                                            counts.as<int32_t>(), offs.as<int64_t>(), pair_block.as<int32_t>(), pair_ent.as<int32_t>(),
+                                            group_rows ? pair_rows.as<int32_t>() : nullptr, 0, stream))
+      return rc;
+    hipLaunchKernelGGL(group_keys, dim3(grid_for(total, 256)), dim3(256), 0, st, total, pair_block.as<int32_t>(),
+                       group_rows ? pair_rows.as<int32_t>() : nullptr, shift, key.as<int64_t>());
+    if (int rc = with_temp([&](void* t, size_t* b) {
+          return mpcx_sort_pairs_i64_i32(key.as<int64_t>(), key_s.as<int64_t>(), pair_ent.as<int32_t>(), plan->ents.as<int32_t>(), total, 0,
+                                         shift + bit_length(nb), t, b, stream);
+        }))
+      return rc;
+    if (int rc = mpcx_segment_offsets(key_s.as<int64_t>(), total, shift, nb, plan->off.as<int64_t>(), stream))
+      return rc;
+  }
+  else if (int rc = hip_ok(hipMemsetAsync(plan->off.p, 0, (nb + 1) * 8, st), "hipMemsetAsync"))
+    return rc;
+  counts.release(), offs.release(), pair_block.release(), pair_ent.release(), pair_rows.release(), key.release(), key_s.release();
+  // ---- scatter offsets of every (entity, local row, local column)
+  Dev oflag;
+  if (plan->offs.alloc(ne * size_t(nd0) * size_t(nd1)) || oflag.alloc(4) || hip_ok(hipMemsetAsync(oflag.p, 0, 4, st), "hipMemsetAsync"))
+    return -100;
+  if (n_entities > 0)
+    if (int rc = mpcx_scatter_offsets(rowptr, cols, estride, n_entities, entities, entities, dofmap0, nd0, bs0, dofmap1, nd1, bs1, 0,
+                                      plan->offs.as<uint8_t>(), oflag.as<int32_t>(), stream))
+      return rc;
+  // ---- masked dofmaps (Dirichlet / slave flags in the bits 28 + k)
+  plan->same_mdofmap = dofmap0 == dofmap1 && nd0 == nd1 && bs0 == bs1 && bc0 == bc1 && is_slave0 == is_slave1;
+  if (plan->md0.alloc(size_t(std::max<int64_t>(num_cells, 1)) * nd0 * 4))
+    return -100;
+  if (int rc = mpcx_mask_dofmap(dofmap0, num_cells, nd0, bs0, bc0, is_slave0, 0, plan->md0.as<int32_t>(), stream))
+    return rc;
+  if (!plan->same_mdofmap)
+  {
+    if (plan->md1.alloc(size_t(std::max<int64_t>(num_cells, 1)) * nd1 * 4))
+      return -100;
+    if (int rc = mpcx_mask_dofmap(dofmap1, num_cells, nd1, bs1, bc1, is_slave1, 0, plan->md1.as<int32_t>(), stream))
+      return rc;
+  }
+  int32_t overflow = 0;
+  if (hip_ok(hipMemcpyAsync(&overflow, oflag.p, 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync") || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+    return -100;
+  if (overflow)
+  {
+    mpcx_set_error("mpcx_cell_plan_create: a CSR row holds more than 255 column blocks before one of an entity's columns (or a column "
+                   "is missing from the pattern); use MPCX_ALG_ATOMIC");
+    return -21;
+  }
+  if (int rc = hip_ok(hipGetLastError(), "kernel launch"))
+    return rc;
+  *out = plan.release();
+  return 0;
+}
+
+extern "C" int mpcx_cell_plan_fill(const mpcx_cell_plan_t* p, mpcx_matrix_args_t* a)
+{
+  if (!p || !a)
+  {
+    mpcx_set_error("mpcx_cell_plan_fill: null argument");
+    return -1;
+  }
+  std::memset(&a->plan, 0, sizeof(a->plan));
+  a->plan.num_blocks = p->num_blocks;
+  a->plan.max_rows = p->max_rows;
+  a->plan.max_nnz = p->max_nnz;
+  a->plan.row_pairs = 0;
+  a->plan.block_row0 = p->row0.as<int32_t>();
+  a->plan.block_ent_off = p->off.as<int64_t>();
+  a->plan.block_ents = p->ents.as<int32_t>();
+  a->plan.ent_offs = p->offs.as<uint8_t>();
+  a->plan.ent_pattern = nullptr;
+  a->mdofmap0 = p->md0.as<int32_t>();
+  a->mdofmap1 = p->same_mdofmap ? p->md0.as<int32_t>() : p->md1.as<int32_t>();
+  a->lean = 0;
+  a->algorithm = MPCX_ALG_ROWBLOCK;
+  return 0;
+}
+extern "C" int64_t mpcx_cell_plan_num_slots(const mpcx_cell_plan_t* p) { return p ? p->n_slots : 0; }
+extern "C" int32_t mpcx_cell_plan_num_blocks(const mpcx_cell_plan_t* p) { return p ? p->num_blocks : 0; }
+extern "C" void mpcx_cell_plan_destroy(mpcx_cell_plan_t* p) { delete p; }

@@ -5,7 +5,7 @@
 // kernel descriptors with their quadrature tables), runs the WHOLE constrained assembly through libmpcx.so with memory
 // from hipMalloc --
 //     mpcx_mpc_finalize -> mpcx_cell_to_slaves -> mpcx_pattern_build                       (host set-up)
-//     mpcx_cluster_plan_create -> mpcx_assemble_matrix per part (+ leftover cells) -> mpcx_add_diagonal
+//     mpcx_cluster_plan_create (+ mpcx_cell_plan_create for cells outside the clusters) -> mpcx_assemble_matrix -> mpcx_add_diagonal
 //     mpcx_mask_dofmap -> mpcx_owner_plan_create -> mpcx_assemble_vector (+ leftover cells)
 //     mpcx_apply_lifting, set_bc
 // -- and writes the CSR matrix and the vector.  tests/test_gpu_driver.py compares them with the Python host layer's
@@ -304,8 +304,22 @@ int main(int argc, char** argv)
     for (int32_t c : slave_cells)
       (is_left[size_t(c)] ? slave_cells_left : slave_cells_cluster).push_back(c);
     const int32_t* d_slave_cells_cluster = dev.upload(slave_cells_cluster);
-    const int32_t* d_slave_cells_left = dev.upload(slave_cells_left);
+    // cells the cluster kernels do not cover (all cells of a mesh without six-tet fans): the per-cell LDS row-block plan
+    mpcx_cell_plan_t* cellplan = nullptr;
+    const int64_t n_percell = n_clusters > 0 ? n_left : n_cells;
+    if (n_percell > 0)
+      mpcx_check(mpcx_cell_plan_create(ndofs, d_rowptr, rowptr.data(), d_cols, n_percell, 1, n_clusters > 0 ? d_left : nullptr, n_cells, d_cells, 4,
+                                       1, d_bc, mpc.is_slave, d_cells, 4, 1, d_bc, mpc.is_slave, max_rows, max_nnz, hints, n_hints, 1, stream,
+                                       &cellplan),
+                 "mpcx_cell_plan_create");
     mpcx_owner_plan_t* oplan = nullptr;
+    mpcx_owner_plan_t* oplan_cells = nullptr; // no clusters at all: owner-computes row blocks over the cells
+    if (n_clusters == 0)
+    {
+      int32_t* mrow = dev.alloc<int32_t>(size_t(n_cells) * 4);
+      mpcx_check(mpcx_mask_dofmap(d_cells, n_cells, 4, 1, nullptr, mpc.is_slave, 0, mrow, stream), "mpcx_mask_dofmap");
+      mpcx_check(mpcx_owner_plan_create(n_cells, 4, mrow, 1, ndofs, vrows, hints, n_hints, 12288, stream, &oplan_cells), "mpcx_owner_plan_create");
+    }
     if (n_clusters > 0)
     {
       int32_t* mrow = dev.alloc<int32_t>(size_t(n_clusters) * 8);
@@ -319,9 +333,10 @@ int main(int argc, char** argv)
     const int32_t *d_plan_ent = nullptr, *d_plan_pq = nullptr;
     const double* d_plan_coef = nullptr;
     int64_t plan_targets = 0, plan_tuples = 0;
-    if (!slave_cells_cluster.empty() && n_clusters > 0)
+    // (entity = cell for the calls that carry them: the last cluster launch, or the per-cell launch of a mesh without clusters)
+    if (!slave_cells.empty())
     {
-      void* mp = mpcx_mpc_plan_build(int64_t(slave_cells_cluster.size()), slave_cells_cluster.data(), 1, nullptr, nullptr, cells, 4, 1, cells, 4, 1,
+      void* mp = mpcx_mpc_plan_build(int64_t(slave_cells.size()), slave_cells.data(), 1, nullptr, nullptr, cells, 4, 1, cells, 4, 1,
                                      BCM.as<int8_t>(), BCM.as<int8_t>(), is_slave.data(), m_off.data(), m_idx.data(), m_coef.data(),
                                      is_slave.data(), m_off.data(), m_idx.data(), m_coef.data(), rowptr.data(), cols.data());
       if (!mp)
@@ -372,6 +387,19 @@ int main(int argc, char** argv)
       v.stream = s_vec;
       return v;
     };
+    // the master contributions of ALL slave cells ride on one call whose entities are the cells themselves (entities ==
+    // NULL): slave_entities are entity indices (cpp/assemble_matrix.cpp:504-546 does them inside the cell loop)
+    auto with_master_contributions = [&](mpcx_matrix_args_t& a)
+    {
+      a.slave_entities = d_slave_cells, a.n_slave_entities = int64_t(slave_cells.size());
+      if (plan_targets > 0)
+      {
+        a.mpc_plan_targets = plan_targets, a.mpc_plan_tgt = d_plan_tgt, a.mpc_plan_off = d_plan_off, a.mpc_plan_ent = d_plan_ent;
+        a.mpc_plan_pq = d_plan_pq, a.mpc_plan_coef = d_plan_coef;
+        const double mean = double(plan_tuples) / double(plan_targets);
+        a.mpc_plan_group = mean > 10 ? 16 : (mean > 2.5 ? 4 : 1);
+      }
+    };
     double t_steps = 0.0;
     // (one untimed pass first when several are asked for: code objects are loaded at the first launch of a kernel)
     for (int step = (steps > 1 ? -1 : 0); step < steps; ++step)
@@ -389,27 +417,18 @@ int main(int argc, char** argv)
         a.store_mode = 1;
         // the master contributions of the slave cells ride on the last launch (they add to rows the launches write)
         if (p == n_parts - 1)
-        {
-          a.slave_entities = d_slave_cells_cluster, a.n_slave_entities = int64_t(slave_cells_cluster.size());
-          if (plan_targets > 0)
-          {
-            a.mpc_plan_targets = plan_targets, a.mpc_plan_tgt = d_plan_tgt, a.mpc_plan_off = d_plan_off, a.mpc_plan_ent = d_plan_ent;
-            a.mpc_plan_pq = d_plan_pq, a.mpc_plan_coef = d_plan_coef;
-            const double mean = double(plan_tuples) / double(plan_targets);
-            a.mpc_plan_group = mean > 10 ? 16 : (mean > 2.5 ? 4 : 1);
-          }
-        }
+          with_master_contributions(a);
         mpcx_check(mpcx_assemble_matrix(&a), "mpcx_assemble_matrix (clusters)");
       }
       if (n_left > 0 || n_parts == 0)
       {
-        // cells in no cluster (or a mesh without clusters): thread-per-entity kernel with device atomics, no plan
+        // cells in no cluster (or a mesh without clusters): per-cell LDS row blocks, added to what the launches above wrote
         mpcx_matrix_args_t a = matrix_base();
-        a.algorithm = MPCX_ALG_ATOMIC;
+        mpcx_check(mpcx_cell_plan_fill(cellplan, &a), "mpcx_cell_plan_fill");
         if (n_parts > 0)
-          a.entities = a.entities0 = a.entities1 = d_left, a.n_entities = n_left;
-        a.slave_entities = n_parts > 0 ? d_slave_cells_left : d_slave_cells;
-        a.n_slave_entities = int64_t(n_parts > 0 ? slave_cells_left.size() : slave_cells.size());
+          a.entities = a.entities0 = a.entities1 = d_left, a.n_entities = n_left; // (their slave cells went with the cluster call)
+        else
+          with_master_contributions(a);
         mpcx_check(mpcx_assemble_matrix(&a), "mpcx_assemble_matrix (per cell)");
       }
       mpcx_check(mpcx_add_diagonal(ndofs, d_rowptr, d_cols, d_vals, d_slaves, n_local_slaves, 1.0, s_mat), "mpcx_add_diagonal (slaves)");
@@ -429,9 +448,17 @@ int main(int argc, char** argv)
       if (n_left > 0 || !oplan)
       {
         mpcx_vector_args_t v = vector_base();
-        v.algorithm = MPCX_ALG_ATOMIC;
-        if (oplan)
+        if (oplan_cells)
+        {
+          mpcx_check(mpcx_owner_plan_fill(oplan_cells, &v), "mpcx_owner_plan_fill");
+          v.algorithm = MPCX_ALG_ROWBLOCK;
+          v.slave_entities = d_slave_cells, v.n_slave_entities = int64_t(slave_cells.size());
+        }
+        else
+        {
+          v.algorithm = MPCX_ALG_ATOMIC; // the few cells outside the clusters: LDS hash + device atomics, no plan
           v.entities = v.entities0 = d_left, v.n_entities = n_left;
+        }
         mpcx_check(mpcx_assemble_vector(&v), "mpcx_assemble_vector (per cell)");
       }
       // apply_lifting (assemble_vector.py:25-76), scale 1, x0 empty
@@ -472,6 +499,10 @@ int main(int argc, char** argv)
                 t_plans, 1e3 * t_steps / steps);
     if (oplan)
       mpcx_owner_plan_destroy(oplan);
+    if (oplan_cells)
+      mpcx_owner_plan_destroy(oplan_cells);
+    if (cellplan)
+      mpcx_cell_plan_destroy(cellplan);
     mpcx_cluster_plan_destroy(cplan);
     return 0;
   }

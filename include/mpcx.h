@@ -712,6 +712,27 @@ int mpcx_owner_plan_create(int64_t n, int32_t nd, const int32_t* mrow, int32_t b
 int mpcx_owner_plan_fill(const mpcx_owner_plan_t* plan, mpcx_vector_args_t* args);
 void mpcx_owner_plan_destroy(mpcx_owner_plan_t* plan);
 
+/* The per-cell plan of MPCX_ALG_ROWBLOCK behind ONE call, in device memory the library allocates (for callers without
+ * torch; the counterpart of mpcx_cluster_plan_create for meshes / forms the cluster kernels do not cover): row ranges
+ * (mpcx_block_ranges over rowptr_host), the entities of every row block (mpcx_rowblock_pairs_device -> scan -> stable sort;
+ * group_rows != 0: entities of a block ordered by the set of their local rows inside it, nd0 <= 30), the scatter-offset table
+ * (mpcx_scatter_offsets) and the masked dofmaps (mpcx_mask_dofmap; bc0 / bc1 may be NULL).  entities: DEVICE [n_entities *
+ * estride] or NULL (entity e is cell e); num_cells: rows of the dofmaps.  mpcx_cell_plan_fill sets plan, mdofmap0, mdofmap1,
+ * lean = 0 and algorithm of *args; everything else (CSR, kernel, geometry, dofmaps, markers, constraints, slave entities and
+ * their optional mpc_plan_*) stays the caller's.  Returns 0; -4: a dof block beyond the block capacity, -21: an offset beyond
+ * 8 bits (both: use MPCX_ALG_ATOMIC). */
+typedef struct mpcx_cell_plan mpcx_cell_plan_t;
+int mpcx_cell_plan_create(int32_t nrows, const mpcx_nnz_t* rowptr, const mpcx_nnz_t* rowptr_host, const int32_t* cols,
+                          int64_t n_entities, int32_t estride, const int32_t* entities, int64_t num_cells,
+                          const int32_t* dofmap0, int32_t nd0, int32_t bs0, const int8_t* bc0, const int8_t* is_slave0,
+                          const int32_t* dofmap1, int32_t nd1, int32_t bs1, const int8_t* bc1, const int8_t* is_slave1,
+                          int32_t max_rows, int32_t max_nnz, const int32_t* row_hints, int32_t n_hints, int32_t group_rows,
+                          void* stream, mpcx_cell_plan_t** plan);
+int mpcx_cell_plan_fill(const mpcx_cell_plan_t* plan, mpcx_matrix_args_t* args);
+int64_t mpcx_cell_plan_num_slots(const mpcx_cell_plan_t* plan);
+int32_t mpcx_cell_plan_num_blocks(const mpcx_cell_plan_t* plan);
+void mpcx_cell_plan_destroy(mpcx_cell_plan_t* plan);
+
 /* Row-block plan for MPCX_ALG_ROWBLOCK: contiguous row ranges with at most
  * max_rows rows / max_nnz nonzeros, and for each block the entities whose
  * test-space cell has a dof in it.  `row_hints` (sorted row indices, may be

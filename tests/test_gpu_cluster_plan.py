@@ -80,7 +80,8 @@ def test_cluster_plan_from_the_c_abi_equals_the_torch_built_plan(oracle, kwargs,
         for p, (part, ref_args) in enumerate(zip(parts, chain)):
             a = _native.MatrixArgs.from_buffer_copy(ref_args)
             _native.check(L.mpcx_cluster_plan_part(h, p, C.byref(a)), "mpcx_cluster_plan_part")
-            plan_t, recs, nbytes, ids, off, flags = part
+            plan_t, recs, nbytes, ids, off, flags = part[:6]
+            assert part[6] is None  # (no slot -> record index: per-slot records, like the C builder's)
             assert (a.cube_rec_bytes, a.cube_flags, a.plan.num_blocks) == (nbytes, flags, plan_t.num_blocks)
             assert (a.plan.max_rows, a.plan.max_nnz) == (plan_t.max_rows, plan_t.max_nnz)
             nslots = recs.numel() // nbytes

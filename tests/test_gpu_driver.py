@@ -112,6 +112,102 @@ def test_driver_matches_oracle_and_python_layer(oracle, tmp_path, kwargs, expect
     assert abs(bp.numpy() - res["b"]).max() <= 1e-13 * max(1.0, abs(b_ref).max())
 
 
+@pytest.mark.gpu
+def test_driver_on_a_mesh_without_clusters(oracle, tmp_path):
+    """a Delaunay tetrahedral mesh with a non-matching periodic pair (multi-master slaves, fat rows, no six-tet fans): the
+    driver takes the per-cell LDS row-block plan (mpcx_cell_plan_create) and the owner-computes vector plan over the cells"""
+    from problems import case_delaunay_periodic
+
+    case = case_delaunay_periodic(3, 1, 6, seed=3, bc_value=0.4)
+    pin, pout = str(tmp_path / "problem.bin"), str(tmp_path / "result.bin")
+    problem_file(case, pin)
+    run = subprocess.run([DRIVER, pin, pout], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    res = read_bundle(pout)
+    # (a random mesh may hold a chance six-tet fan or two: those go to the cluster kernel, the rest are per-cell cells)
+    assert res["timings"][5] >= 0.9 * case.V.mesh.num_cells and 6 * res["timings"][4] + res["timings"][5] == case.V.mesh.num_cells
+    ref = oracle_outputs(oracle, case)
+    refA = ref["A"].tocsr()
+    refA.sort_indices()
+    assert np.array_equal(res["rowptr"], refA.indptr) and np.array_equal(res["cols"], refA.indices)
+    assert abs(res["vals"] - refA.data).max() <= 1e-12 * abs(refA.data).max()
+    b_ref = ref["b_lifted"].copy()
+    for bc in case.bcs:
+        bc.set(b_ref, None, 1.0)
+    assert abs(res["b"] - b_ref).max() <= 1e-12 * max(1.0, abs(b_ref).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("make", ["cube_p2", "delaunay_p1", "stokes_a01"])
+def test_cell_plan_from_the_c_abi_equals_the_torch_built_plan(make):
+    """mpcx_cell_plan_create (row ranges, entity lists grouped by local rows, scatter offsets, masked dofmaps in library-owned
+    memory) against assemble_matrix._rowblock_plan + _masked_dofmap, array by array"""
+    import ctypes as C
+    import importlib
+
+    import torch
+
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import _device as D
+    from dolfinx_mpc_amd import _native
+    from problems import case_delaunay_periodic, product_mpc
+    from test_gpu_cluster_plan import _dev_array
+
+    am = importlib.import_module("dolfinx_mpc_amd.assemble_matrix")
+    if make == "stokes_a01":
+        from dolfinx_mpc_amd.workloads import stokes_slip_problem
+
+        V, Q, bcs, raw_v, forms, _L0 = stokes_slip_problem(3, 3, None)
+        mv = dm.MultiPointConstraint(V)
+        mv.add_constraint(V, *raw_v)
+        mv.finalize()
+        mq = dm.MultiPointConstraint(Q)
+        mq.finalize()
+        form, mpc0, mpc1 = forms[(0, 1)], mv, mq
+    else:
+        case = case_cube_periodic(6, 2, 0.3, reorder=(2, 2, 2)) if make == "cube_p2" else case_delaunay_periodic(3, 1, 5, seed=7)
+        form, bcs = case.a, case.bcs
+        mpc0 = mpc1 = product_mpc(case)
+    V0, V1 = form.function_spaces
+    A = dm.create_matrix(form, mpc0, mpc1)
+    plan_t, t, info = am._rowblock_plan(A, form, 0, V0)
+    group_rows = 1  # (what _rowblock_plan takes for these forms)
+    _, bc0 = D.bc_markers(V0, bcs, form._device)
+    _, bc1 = D.bc_markers(V1, bcs, form._device)
+    md0 = am._masked_dofmap(form, V0, bc0, mpc0, 0)
+    md1 = am._masked_dofmap(form, V1, bc1, mpc1, 1)
+    s0, s1 = D.space_device(V0), D.space_device(V1)
+    _, k0 = mpc0._device()
+    _, k1 = mpc1._device()
+    L = _native.lib()
+    hints = None if V0.dof_tile_offsets is None else np.ascontiguousarray(V0.dof_tile_offsets.astype(np.int32) * V0.dofmap.bs)
+    rowptr_h = np.ascontiguousarray(A.rowptr.astype(np.int64))
+    nc = V0.dofmap.list.shape[0]
+    h = C.c_void_p()
+    rc = L.mpcx_cell_plan_create(A.shape[0], A.d_rowptr.data_ptr(), rowptr_h.ctypes.data, A.d_cols.data_ptr(), nc, 1, None, nc,
+                                 s0["dofmap"].data_ptr(), V0.element_ndofs, V0.dofmap.bs, D.ptr(bc0), k0["is_slave"].data_ptr(),
+                                 s1["dofmap"].data_ptr(), V1.element_ndofs, V1.dofmap.bs, D.ptr(bc1), k1["is_slave"].data_ptr(),
+                                 am.ROWBLOCK_MAX_ROWS, am.ROWBLOCK_MAX_NNZ, None if hints is None else hints.ctypes.data,
+                                 0 if hints is None else hints.size, group_rows, D.stream_ptr(), C.byref(h))
+    _native.check(rc, "mpcx_cell_plan_create")
+    torch.cuda.synchronize()
+    try:
+        a = _native.MatrixArgs()
+        _native.check(L.mpcx_cell_plan_fill(h, C.byref(a)), "mpcx_cell_plan_fill")
+        assert (a.plan.num_blocks, a.plan.max_rows, a.plan.max_nnz, a.plan.row_pairs) == (plan_t.num_blocks, plan_t.max_rows, plan_t.max_nnz, 0)
+        assert a.algorithm == 2 and a.lean == 0
+        nb, nslots = plan_t.num_blocks, int(t[2].numel())
+        assert L.mpcx_cell_plan_num_slots(h) == nslots and L.mpcx_cell_plan_num_blocks(h) == nb
+        assert np.array_equal(_dev_array(a.plan.block_row0, nb + 1, np.int32), t[0].cpu().numpy())
+        assert np.array_equal(_dev_array(a.plan.block_ent_off, nb + 1, np.int64), t[1].cpu().numpy())
+        assert np.array_equal(_dev_array(a.plan.block_ents, nslots, np.int32), t[2].cpu().numpy())
+        assert np.array_equal(_dev_array(a.plan.ent_offs, t[3].numel(), np.uint8), t[3].cpu().numpy())
+        assert np.array_equal(_dev_array(a.mdofmap0, md0.numel(), np.int32), md0.cpu().numpy().reshape(-1))
+        assert np.array_equal(_dev_array(a.mdofmap1, md1.numel(), np.int32), md1.cpu().numpy().reshape(-1))
+    finally:
+        L.mpcx_cell_plan_destroy(h)
+
+
 def test_driver_binary_links_only_the_library_and_hip():
     """built on CPU by build(); its dynamic dependencies are libmpcx.so, the HIP runtime and the C / C++ runtimes"""
     assert os.path.exists(DRIVER)
