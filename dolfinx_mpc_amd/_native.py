@@ -238,6 +238,7 @@ EXPORTS = [
     "mpcx_cluster_plan_leftover",
     "mpcx_cluster_plan_part",
     "mpcx_cluster_plan_destroy",
+    "mpcx_ufcx_big_tensor",
     "mpcx_cell_plan_create",
     "mpcx_cell_plan_fill",
     "mpcx_cell_plan_num_slots",
@@ -451,6 +452,8 @@ def lib() -> C.CDLL:
     L.mpcx_cell_plan_create.argtypes = [i32, vp, vp, vp, i64, i32, vp, i64, vp, i32, i32, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, i32, i32, vp,
                                         C.POINTER(C.c_void_p)]
     L.mpcx_cell_plan_create.restype = C.c_int
+    L.mpcx_ufcx_big_tensor.argtypes = [vp]
+    L.mpcx_ufcx_big_tensor.restype = C.c_int
     L.mpcx_cell_plan_fill.argtypes = [vp, vp]
     L.mpcx_cell_plan_fill.restype = C.c_int
     L.mpcx_cell_plan_num_slots.argtypes = [vp]

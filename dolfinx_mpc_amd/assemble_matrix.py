@@ -1032,6 +1032,13 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
     mode = "none" if os.environ.get("MPCX_NO_MPC_PLAN") else os.environ.get("MPCX_MPC_PLAN", "device").lower()
     if _native.scalar_id(getattr(form, "dtype", np.float64)) != 0:
         mode = "none"  # (the plan carries fp64 coefficients; the scalar-type kernels eliminate inside the entity loop)
+    if integ.kernel.form == 100 and _native.lib().mpcx_ufcx_big_tensor(idv["kernel"].ufcx):
+        # an imported kernel whose element tensor does not fit a thread's private memory (vector-valued Q3 hexahedra:
+        # 192 x 192): per-entity kernels with the tensor in a global scratch slab only (include/mpcx.h mpcx_ufcx_big_tensor)
+        if alg != 1:
+            raise _native.PlanNotRepresentable("imported kernel with an element tensor of more than 12288 entries: "
+                                               "algorithm='atomic' (or 'auto')")
+        mode = "none"
     n0n1 = V0.element_ndofs * V0.dofmap.bs * V1.element_ndofs * V1.dofmap.bs
     if a.n_slave_entities > 0 and mode == "device" and max(V0.element_ndofs * V0.dofmap.bs,
                                                            V1.element_ndofs * V1.dofmap.bs) <= 32:

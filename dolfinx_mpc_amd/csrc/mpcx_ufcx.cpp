@@ -17,6 +17,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <mutex>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -71,12 +72,39 @@ __device__ inline void tabulate(double* Ae, int n, const double* coeffs, int cst
   UFCX_FN(Ae, coeffs ? coeffs + e * cstride : (const double*)0, constants, cd, &lf, &perm, (void*)0);
 }
 
+// The element tensor of the per-entity kernels: N0 * N1 doubles of the thread's stack, or -- UFCX_BIG, tensors beyond
+// 96 KiB such as vector-valued Q3 hexahedra (192 x 192) -- a slab of a global scratch array the host allocates per kernel
+// (one slab per launched thread; the kernels then stride over their work items with a bounded grid).  Big tensors have
+// the per-entity kernels only: no LDS row blocks, no master-contribution plan.
+#if UFCX_BIG
+extern "C" __device__ double* ufcx_scratch_matrix;
+extern "C" __device__ double* ufcx_scratch_mpc;
+extern "C" __device__ double* ufcx_scratch_lifting;
+__device__ double* ufcx_scratch_matrix = 0;
+__device__ double* ufcx_scratch_mpc = 0;
+__device__ double* ufcx_scratch_lifting = 0;
+#define UFCX_ITEMS(t, n, scratch, body)                                                                                                \
+  {                                                                                                                                  \
+    const long long tid_ = (long long)blockIdx.x * blockDim.x + threadIdx.x, nt_ = (long long)gridDim.x * blockDim.x;                  \
+    double* Ae = scratch + (unsigned long long)tid_ * (unsigned long long)(N0 * N1);                                                   \
+    for (long long t = tid_; t < (n); t += nt_)                                                                                      \
+      body(a, t, Ae);                                                                                                                \
+  }
+#else
+#define UFCX_ITEMS(t, n, scratch, body)                                                                                                \
+  {                                                                                                                                  \
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;                                                              \
+    if (t < (n))                                                                                                                     \
+    {                                                                                                                                \
+      double Ae[N0 * N1];                                                                                                            \
+      body(a, t, Ae);                                                                                                                \
+    }                                                                                                                                \
+  }
+#endif
+
 #if UFCX_RANK == 2
-extern "C" __global__ void __launch_bounds__(64) ufcx_matrix_kernel(mpcx_matrix_args_t a)
+__device__ inline void matrix_item(const mpcx_matrix_args_t& a, long long e, double* Ae)
 {
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= a.n_entities)
-    return;
   const long long l = e * a.estride;
   const long long cell = a.entities ? a.entities[l] : e;
   const long long cell0 = a.entities0 ? a.entities0[l] : e;
@@ -84,7 +112,6 @@ extern "C" __global__ void __launch_bounds__(64) ufcx_matrix_kernel(mpcx_matrix_
   const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
   double cd[NV * 3];
   gather(a.x, a.x_dofmap, cell, cd);
-  double Ae[N0 * N1];
   tabulate(Ae, N0 * N1, a.coeffs, a.cstride, a.constants, cd, e, lf);
   // bulk part: Dirichlet and slave rows / columns masked (cpp/assemble_matrix.cpp:510-533, 165-178)
   for (int p = 0; p < N0; ++p)
@@ -104,13 +131,12 @@ extern "C" __global__ void __launch_bounds__(64) ufcx_matrix_kernel(mpcx_matrix_
     }
   }
 }
+extern "C" __global__ void __launch_bounds__(64) ufcx_matrix_kernel(mpcx_matrix_args_t a)
+UFCX_ITEMS(e, a.n_entities, ufcx_scratch_matrix, matrix_item)
 
 // master contributions of the slave entities: cpp/assemble_matrix.cpp:182-267
-extern "C" __global__ void __launch_bounds__(64) ufcx_matrix_mpc_kernel(mpcx_matrix_args_t a)
+__device__ inline void matrix_mpc_item(const mpcx_matrix_args_t& a, long long t, double* Ae)
 {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= a.n_slave_entities)
-    return;
   const long long e = a.slave_entities[t];
   const long long l = e * a.estride;
   const long long cell = a.entities ? a.entities[l] : e;
@@ -119,7 +145,6 @@ extern "C" __global__ void __launch_bounds__(64) ufcx_matrix_mpc_kernel(mpcx_mat
   const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
   double cd[NV * 3];
   gather(a.x, a.x_dofmap, cell, cd);
-  double Ae[N0 * N1];
   tabulate(Ae, N0 * N1, a.coeffs, a.cstride, a.constants, cd, e, lf);
   int rows[N0], colsd[N1];
   bool rbc[N0], cbc[N1], rsl[N0], csl[N1];
@@ -186,13 +211,12 @@ extern "C" __global__ void __launch_bounds__(64) ufcx_matrix_mpc_kernel(mpcx_mat
     }
   }
 }
+extern "C" __global__ void __launch_bounds__(64) ufcx_matrix_mpc_kernel(mpcx_matrix_args_t a)
+UFCX_ITEMS(t, a.n_slave_entities, ufcx_scratch_mpc, matrix_mpc_item)
 
 // cpp/lifting.h:77-133: raw element tensor, b -= scale * Ae[:, j] (g_j - x0_j), slaves moved to their masters
-extern "C" __global__ void __launch_bounds__(64) ufcx_lifting_kernel(mpcx_lifting_args_t a)
+__device__ inline void lifting_item(const mpcx_lifting_args_t& a, long long t, double* Ae)
 {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= a.n_lift_entities)
-    return;
   const long long e = a.lift_entities[t];
   const long long l = e * a.estride;
   const long long cell = a.entities ? a.entities[l] : e;
@@ -201,7 +225,6 @@ extern "C" __global__ void __launch_bounds__(64) ufcx_lifting_kernel(mpcx_liftin
   const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
   double cd[NV * 3];
   gather(a.x, a.x_dofmap, cell, cd);
-  double Ae[N0 * N1];
   tabulate(Ae, N0 * N1, a.coeffs, a.cstride, a.constants, cd, e, lf);
   double be[N0];
   for (int m = 0; m < N0; ++m)
@@ -232,6 +255,8 @@ extern "C" __global__ void __launch_bounds__(64) ufcx_lifting_kernel(mpcx_liftin
       atomic_add_f64(a.b + d, v);
   }
 }
+extern "C" __global__ void __launch_bounds__(64) ufcx_lifting_kernel(mpcx_lifting_args_t a)
+UFCX_ITEMS(t, a.n_lift_entities, ufcx_scratch_lifting, lifting_item)
 #else
 // cpp/assemble_vector.cpp:65-90 + modify_mpc_vec (cpp/assemble_vector.h:35-69)
 extern "C" __global__ void __launch_bounds__(64) ufcx_vector_kernel(mpcx_vector_args_t a)
@@ -286,6 +311,7 @@ const char* const ROWBLOCK_KERNELS_TEXT = R"MPCXR(
 #endif
 
 #if UFCX_RANK == 2
+#if !UFCX_BIG
 extern "C" __global__ void __launch_bounds__(UFCX_RB_THREADS) ufcx_matrix_rowblock_kernel(mpcx_matrix_args_t a)
 {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -521,6 +547,7 @@ extern "C" __global__ void __launch_bounds__(64) ufcx_matrix_mpc_gather_kernel(m
   if (lane == 0)
     a.vals[a.mpc_plan_tgt[t]] += sum;
 }
+#endif // !UFCX_BIG
 #else
 // rank 1: row blocks of b in LDS.  own_lmap == NULL: every block evaluates the entities touching it and keeps its
 // own rows (vector_rowblock_kernel); own_lmap != NULL: owner-computes (vector_ownblock_kernel): every entity once,
@@ -662,7 +689,14 @@ struct UfcxKernel
   hipFunction_t matrix_rowblock = nullptr, matrix_mpc_plan = nullptr, vector_rowblock = nullptr, vector_mpc = nullptr;
   hipFunction_t slave_tensors = nullptr, matrix_mpc_gather = nullptr;
   int rb_threads = 256; // threads per workgroup of the row-block kernels (their launch bound)
+  // element tensors beyond UFCX_BIG_ENTRIES doubles: per-entity kernels only, the tensor of a thread lives in a slab of a
+  // global scratch array (one per kernel, so that the matrix and the lifting call of a step may overlap on two streams)
+  bool big = false;
+  void* scratch[3] = {nullptr, nullptr, nullptr}; // matrix, master contributions, lifting
+  int64_t scratch_threads = 0;
 };
+// 12288 doubles = 96 KiB of the 128 KiB a thread's stack may hold next to the kernel's own arrays
+constexpr int UFCX_BIG_ENTRIES = 12288;
 
 int hip_check(hipError_t err, const char* what)
 {
@@ -683,6 +717,31 @@ int ensure_loaded(UfcxKernel* k)
     return rc;
   auto get = [&](hipFunction_t* f, const char* name)
   { return hip_check(hipModuleGetFunction(f, k->module, name), "hipModuleGetFunction"); };
+  if (k->desc.rank == 2 && k->big)
+  {
+    if (int rc = get(&k->matrix, "ufcx_matrix_kernel"))
+      return rc;
+    if (int rc = get(&k->matrix_mpc, "ufcx_matrix_mpc_kernel"))
+      return rc;
+    if (int rc = get(&k->lifting, "ufcx_lifting_kernel"))
+      return rc;
+    // slabs for as many threads as 256 MiB per kernel hold (at least one wave, at most 16 384 threads)
+    const size_t slab = size_t(k->desc.nd0) * k->desc.bs0 * k->desc.nd1 * k->desc.bs1 * 8;
+    k->scratch_threads = std::min<int64_t>(16384, std::max<int64_t>(64, int64_t((size_t(256) << 20) / slab) / 64 * 64));
+    const char* names[3] = {"ufcx_scratch_matrix", "ufcx_scratch_mpc", "ufcx_scratch_lifting"};
+    for (int i = 0; i < 3; ++i)
+    {
+      if (int rc = hip_check(hipMalloc(&k->scratch[i], slab * size_t(k->scratch_threads)), "hipMalloc (element tensor scratch)"))
+        return rc;
+      hipDeviceptr_t sym = nullptr;
+      size_t bytes = 0;
+      if (int rc = hip_check(hipModuleGetGlobal(&sym, &bytes, k->module, names[i]), "hipModuleGetGlobal"))
+        return rc;
+      if (int rc = hip_check(hipMemcpyHtoD(sym, &k->scratch[i], sizeof(void*)), "hipMemcpyHtoD"))
+        return rc;
+    }
+    return 0;
+  }
   if (k->desc.rank == 2)
   {
     if (int rc = get(&k->matrix, "ufcx_matrix_kernel"))
@@ -707,13 +766,15 @@ int ensure_loaded(UfcxKernel* k)
 }
 
 template <class Args>
-int launch(hipFunction_t f, int64_t n, const Args& a, void* stream)
+int launch(hipFunction_t f, int64_t n, const Args& a, void* stream, int64_t max_threads = 0)
 {
   if (n == 0)
     return 0;
   Args copy = a;
   void* params[] = {&copy};
-  const unsigned grid = static_cast<unsigned>((n + 63) / 64);
+  unsigned grid = static_cast<unsigned>((n + 63) / 64);
+  if (max_threads > 0) // big element tensors: the kernel strides over its items with as many threads as it has scratch slabs
+    grid = std::min<unsigned>(grid, unsigned(max_threads / 64));
   return hip_check(hipModuleLaunchKernel(f, grid, 1, 1, 64, 1, 1, 0, static_cast<hipStream_t>(stream), params, nullptr),
                    "hipModuleLaunchKernel");
 }
@@ -818,8 +879,9 @@ extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
   const int size = d->rank == 2 ? d->nd0 * d->bs0 * d->nd1 * d->bs1 : d->nd0 * d->bs0;
   const int rb_threads = (d->rank == 1 || size <= 36) ? 512 : 256;
   const int small = size <= 144 ? 1 : 0;
+  const int big = (d->rank == 2 && size > UFCX_BIG_ENTRIES) ? 1 : 0; // element tensor beyond the per-thread scratch limit
   std::vector<std::string> opts
-      = {"--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-DUFCX_FN=" + std::string(d->function_name),
+      = {"--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-DUFCX_FN=" + std::string(d->function_name), "-DUFCX_BIG=" + std::to_string(big),
          "-DUFCX_RB_THREADS=" + std::to_string(rb_threads), "-DUFCX_SMALL=" + std::to_string(small),
          "-DUFCX_RANK=" + std::to_string(d->rank), "-DND0=" + std::to_string(d->nd0), "-DBS0=" + std::to_string(d->bs0),
          "-DND1=" + std::to_string(d->rank == 2 ? d->nd1 : 1), "-DBS1=" + std::to_string(d->rank == 2 ? d->bs1 : 1),
@@ -841,6 +903,7 @@ extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
   }
   auto* k = new UfcxKernel;
   k->rb_threads = rb_threads;
+  k->big = big != 0;
   k->desc = *d;
   k->desc.source = nullptr;
   k->desc.function_name = nullptr;
@@ -852,6 +915,7 @@ extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
   return k;
 }
 
+extern "C" int mpcx_ufcx_big_tensor(void* handle) { return handle && static_cast<UfcxKernel*>(handle)->big ? 1 : 0; }
 extern "C" int64_t mpcx_ufcx_code_size(void* handle) { return handle ? int64_t(static_cast<UfcxKernel*>(handle)->code.size()) : 0; }
 
 extern "C" int mpcx_ufcx_code(void* handle, void* out)
@@ -868,6 +932,9 @@ extern "C" void mpcx_ufcx_free(void* handle)
   auto* k = static_cast<UfcxKernel*>(handle);
   if (!k)
     return;
+  for (void* p : k->scratch)
+    if (p)
+      (void)hipFree(p);
   if (k->module)
     (void)hipModuleUnload(k->module);
   delete k;
@@ -893,7 +960,19 @@ int launch_matrix_ufcx(const mpcx_matrix_args_t& a)
     return rc;
   int alg = a.algorithm;
   if (alg == MPCX_ALG_AUTO)
-    alg = a.plan.num_blocks > 0 ? MPCX_ALG_ROWBLOCK : MPCX_ALG_ATOMIC;
+    alg = (a.plan.num_blocks > 0 && !k->big) ? MPCX_ALG_ROWBLOCK : MPCX_ALG_ATOMIC;
+  if (k->big)
+  {
+    if (alg == MPCX_ALG_ROWBLOCK || a.mpc_plan_off)
+    {
+      mpcx_set_error("mpcx_assemble_matrix (UFCx): an element tensor of more than 12288 entries runs the per-entity kernels only "
+                     "(MPCX_ALG_ATOMIC, no master-contribution plan; mpcx_ufcx_big_tensor tells)");
+      return -4;
+    }
+    if (int rc = launch(k->matrix, a.n_entities, a, a.stream, k->scratch_threads))
+      return rc;
+    return launch(k->matrix_mpc, a.n_slave_entities, a, a.stream, k->scratch_threads);
+  }
   if (alg == MPCX_ALG_ROWBLOCK && a.n_entities > 0)
   {
     if (a.plan.num_blocks <= 0 || !a.mdofmap0 || !a.mdofmap1 || !a.plan.ent_offs || a.plan.row_pairs || a.plan.ent_pattern
@@ -985,6 +1064,6 @@ int launch_lifting_ufcx(const mpcx_lifting_args_t& a)
   }
   if (int rc = ensure_loaded(k))
     return rc;
-  return launch(k->lifting, a.n_lift_entities, a, a.stream);
+  return launch(k->lifting, a.n_lift_entities, a, a.stream, k->big ? k->scratch_threads : 0);
 }
 } // namespace mpcx

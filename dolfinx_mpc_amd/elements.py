@@ -1,7 +1,7 @@
 """General Lagrange elements of the host stand-in layer: degree 1-3 on triangles and quadrilaterals (what the
 reference's own assembly tests sweep -- python/tests/test_matrix_assembly.py:23-26, test_vector_assembly.py:22-24:
-``degree in range(1, 4)``, ``celltype in [triangle, quadrilateral]``), Q2 on hexahedra
-(python/tests/test_stokes_channelflow.py:21-22).  DOLFINx / Basix are absent here, so this module defines
+``degree in range(1, 4)``, ``celltype in [triangle, quadrilateral]``), P3 on tetrahedra and Q2 / Q3 on hexahedra
+(python/tests/test_stokes_channelflow.py:21-23: Taylor-Hood of order 2 and 3 on both cell types).  DOLFINx / Basix are absent here, so this module defines
 
   * the reference nodes and their association with sub-entities (vertices, edges, faces, interior), in the order of the
     element's local dofs: vertices, then the interior nodes of every local edge (``mesh.local_edges`` order, counted from
@@ -10,7 +10,10 @@ reference's own assembly tests sweep -- python/tests/test_matrix_assembly.py:23-
   * the nodal basis through the Vandermonde matrix of the monomials that span P_p (simplices) / Q_p (tensor cells);
   * the global dof numbering: a node on a shared edge is ONE dof, numbered along the edge from its lower to its higher
     global vertex, so the two cells of an edge agree whatever their local orientations (Lagrange elements need only this
-    permutation, no sign change -- what DOLFINx's dof transformations do for these elements).
+    permutation, no sign change -- what DOLFINx's dof transformations do for these elements); the (p - 1)^2 nodes of a
+    shared quadrilateral face are numbered in the frame its GLOBAL vertex numbers define (origin = the lowest vertex, first
+    direction = towards its lower face neighbour), so the two hexahedra of a face agree under any of the eight relative
+    orientations; a triangular face of a P3 tetrahedron carries one node.
 
 Imported (generated) kernels tabulate this basis (codegen.generate_general); the oracle compiles the same text."""
 
@@ -54,6 +57,15 @@ def reference_nodes(cell: str, degree: int):
             ent.append((1, e))
             pos.append(k - 1)
     d = V.shape[1]
+    if cell == "tetrahedron" and p >= 3:
+        if p > 3:
+            raise NotImplementedError("tetrahedra: degree 1-3 (several nodes on a shared triangular face need an orientation rule)")
+        from .mesh import TET_FACETS
+
+        for f, fv in enumerate(TET_FACETS):
+            pts.append(V[list(fv)].mean(axis=0))
+            ent.append((2, f))
+            pos.append(0)
     if cell == "hexahedron":
         for f, fv in enumerate(_HEX_FACES):
             n = 0
@@ -80,8 +92,6 @@ def reference_nodes(cell: str, degree: int):
                     ent.append((3, 0))
                     pos.append(n)
                     n += 1
-        if p >= 3:
-            raise NotImplementedError("tetrahedra: degree 1 and 2 (face nodes of degree 3 are not laid out)")
     elif cell == "quadrilateral":
         for j in range(1, p):
             for i in range(1, p):
@@ -130,17 +140,24 @@ def _monomials(ex: np.ndarray, pts: np.ndarray, deriv: int = -1) -> np.ndarray:
     return out
 
 
+def _centre(cell: str) -> np.ndarray:
+    """the monomials are taken about the centroid of the reference cell: the Vandermonde matrix of Q3 on a hexahedron has
+    condition 3e3 there instead of 2e6 about the origin (nodal basis exact to 1e-14 instead of 2e-12)"""
+    return _VERTS[cell].mean(axis=0)
+
+
 @lru_cache(maxsize=None)
 def _coefficients(cell: str, degree: int) -> np.ndarray:
     nodes = reference_nodes(cell, degree)[0]
-    Vm = _monomials(_exponents(cell, degree), nodes)
-    return np.linalg.inv(Vm)  # column j: monomial coefficients of basis function j
+    Vm = _monomials(_exponents(cell, degree), nodes - _centre(cell))
+    return np.linalg.inv(Vm)  # column j: (centred) monomial coefficients of basis function j
 
 
 def tabulate(cell: str, degree: int, pts) -> tuple[np.ndarray, np.ndarray]:
     """phi (npts, nd) and reference derivatives dphi (tdim, npts, nd) of the nodal basis at reference points"""
     pts = np.asarray(pts, dtype=np.float64).reshape(-1, tdim(cell))
     ex, Cm = _exponents(cell, degree), _coefficients(cell, degree)
+    pts = pts - _centre(cell)
     phi = _monomials(ex, pts) @ Cm
     dphi = np.stack([_monomials(ex, pts, d) @ Cm for d in range(tdim(cell))], axis=0)
     return phi, dphi
@@ -172,17 +189,39 @@ def build_dofmap(mesh, degree: int):
                 out[:, col] = off + g * ne_nodes + kk
         off += ev.shape[0] * ne_nodes
     col = nv + le.shape[0] * ne_nodes
+    if cell == "tetrahedron" and p == 3:
+        from .mesh import TET_FACETS
+
+        fv = np.sort(cells[:, TET_FACETS], axis=2).reshape(nc * 4, 3)
+        _, inv = np.unique(fv, axis=0, return_inverse=True)
+        inv = inv.reshape(nc, 4)
+        for f in range(4):
+            out[:, col + f] = off + inv[:, f]
+        off += int(inv.max()) + 1
+        col += 4
     if cell == "hexahedron" and p >= 2:
-        if p > 2:
-            raise NotImplementedError("hexahedra: degree 1 and 2 (the orientation of several nodes on a shared face is not laid out)")
         fv = np.sort(cells[:, _HEX_FACES], axis=2).reshape(nc * 6, 4)
         _, inv = np.unique(fv, axis=0, return_inverse=True)
         inv = inv.reshape(nc, 6)
         nfaces = int(inv.max()) + 1
+        m = p - 1  # nodes per direction inside a face
         for f in range(6):
-            out[:, col + f] = off + inv[:, f]
-        off += nfaces
-        col += 6
+            g = cells[:, _HEX_FACES[f]]  # global vertices of the face in local tensor order: (0,0) (1,0) (0,1) (1,1)
+            o = np.argmin(g, axis=1)  # the face's lowest global vertex: origin of the shared frame
+            io, jo = o & 1, o >> 1
+            rows = np.arange(nc)
+            first_is_i = g[rows, o ^ 1] < g[rows, o ^ 2]  # the frame's first direction: towards the lower neighbour
+            n = 0
+            for j in range(1, p):
+                for i in range(1, p):
+                    di = np.where(io == 1, p - i, i)  # distance from the origin along the local directions
+                    dj = np.where(jo == 1, p - j, j)
+                    sfirst = np.where(first_is_i, di, dj)
+                    ssecond = np.where(first_is_i, dj, di)
+                    out[:, col + f * m * m + n] = off + inv[:, f].astype(np.int64) * (m * m) + (ssecond - 1) * m + (sfirst - 1)
+                    n += 1
+        off += nfaces * m * m
+        col += 6 * m * m
     nint = nd - col
     for k in range(nint):
         out[:, col + k] = off + np.arange(nc) * nint + k

@@ -92,15 +92,15 @@ class FunctionSpace:
         family, degree = element[0], int(element[1])
         if family not in ("Lagrange", "CG", "P"):
             raise NotImplementedError(f"element family {family}")
-        # general Lagrange elements (elements.py): degree 3 on triangles, Q1-Q3 on quadrilaterals, Q2 on hexahedra -- the
+        # general Lagrange elements (elements.py): degree 3 on triangles / tetrahedra, Q1-Q3 on quadrilaterals, Q2 / Q3 on hexahedra -- the
         # cell / degree sweep of python/tests/test_matrix_assembly.py:23-26; their forms run generated (imported) kernels
-        self.general = (mesh.cell_name == "quadrilateral" and degree in (1, 2, 3)) or (mesh.cell_name == "triangle" and degree == 3) \
-            or (mesh.cell_name == "hexahedron" and degree == 2)
+        self.general = (mesh.cell_name == "quadrilateral" and degree in (1, 2, 3)) or (mesh.cell_name in ("triangle", "tetrahedron") and degree == 3) \
+            or (mesh.cell_name == "hexahedron" and degree in (2, 3))
         if not self.general:
             if degree not in (1, 2):
-                raise NotImplementedError("Lagrange degree 1 and 2 (degree 3: triangles and quadrilaterals)")
+                raise NotImplementedError("Lagrange degree 1-3")
             if mesh.cell_name == "hexahedron" and degree != 1:
-                raise NotImplementedError("hexahedra: Q1 and Q2")
+                raise NotImplementedError("hexahedra: Q1-Q3")
         self.mesh = mesh
         self.degree = degree
         bs = 1 if not shape else int(np.prod(shape))  # vector (d,) and tensor (d, d) valued spaces: blocked dofs

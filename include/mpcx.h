@@ -124,6 +124,12 @@ typedef struct
   int32_t nv;                /* geometry nodes per cell */
 } mpcx_ufcx_desc_t;
 void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* desc);
+/* 1 if the element tensor (nd0 * bs0 * nd1 * bs1 > 12288 entries, e.g. vector-valued Q3 hexahedra: 192 x 192) does not fit a
+ * thread's private memory: such a kernel has the per-entity variants only (MPCX_ALG_ATOMIC, mpc_plan_off == NULL); the tensor
+ * of a thread then lives in a slab of a scratch array the library allocates at first launch (256 MiB per kernel) and a
+ * bounded grid strides over the entities.  Launches of ONE handle must not overlap on several streams beyond one matrix, one
+ * master-contribution and one lifting launch. */
+int mpcx_ufcx_big_tensor(void* handle);
 int64_t mpcx_ufcx_code_size(void* handle); /* bytes of the gfx950 code object */
 int mpcx_ufcx_code(void* handle, void* out); /* HOST out[mpcx_ufcx_code_size]: the code object (inspection, caching) */
 void mpcx_ufcx_free(void* handle);

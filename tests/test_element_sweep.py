@@ -19,7 +19,7 @@ from problems import element_sweep_cases, oracle_mpc, oracle_outputs, product_ou
 CASES = element_sweep_cases()
 IDS = [f"el{i}" for i in range(len(CASES))]
 ELEMENTS = [("triangle", 1), ("triangle", 2), ("triangle", 3), ("quadrilateral", 1), ("quadrilateral", 2), ("quadrilateral", 3),
-            ("tetrahedron", 1), ("tetrahedron", 2), ("hexahedron", 1), ("hexahedron", 2)]
+            ("tetrahedron", 1), ("tetrahedron", 2), ("tetrahedron", 3), ("hexahedron", 1), ("hexahedron", 2), ("hexahedron", 3)]
 
 
 @pytest.mark.parametrize("cell,degree", ELEMENTS)
@@ -44,18 +44,49 @@ def test_nodal_basis_and_polynomial_reproduction(cell, degree):
         assert np.allclose(ph, lagrange_basis(cell, degree, x), atol=1e-12)
 
 
-@pytest.mark.parametrize("cell,degree", [("triangle", 3), ("quadrilateral", 2), ("quadrilateral", 3), ("hexahedron", 2)])
-def test_shared_dofs_agree_between_cells(cell, degree):
-    """a dof on a shared edge / face is ONE dof: the coordinates the two cells assign to it agree, whatever the cells'
-    local orientations (shuffled local vertex order on the simplices)"""
-    mesh = create_unit_square(4, 3, cell) if el.tdim(cell) == 2 else create_unit_cube(2, 3, 2, cell)
-    if cell == "triangle":  # scramble the local orientations: rotate the vertices of every second cell
-        c = mesh.geometry.dofmap.copy()
+def _hex_symmetry(perm, flips):
+    """local vertex order of a hexahedron after a symmetry of the reference cube: new vertex with bits (b0, b1, b2) is the
+    old vertex whose bit perm[k] is b_k ^ flips[k]"""
+    out = []
+    for v in range(8):
+        b = [(v >> k) & 1 for k in range(3)]
+        old = 0
+        for k in range(3):
+            old |= (b[k] ^ flips[k]) << perm[k]
+        out.append(old)
+    return out
+
+
+def _scrambled(mesh, cell):
+    """the same mesh with the local vertex order of its cells permuted cell by cell (all orientations a mesh file may hold)"""
+    from dolfinx_mpc_amd.mesh import Mesh
+
+    c = mesh.geometry.dofmap.copy()
+    if cell == "triangle":
         c[1::2] = c[1::2][:, [1, 2, 0]]
         c[::3] = c[::3][:, [0, 2, 1]]
-        from dolfinx_mpc_amd.mesh import Mesh
+    elif cell == "tetrahedron":
+        c[1::2] = c[1::2][:, [1, 2, 0, 3]]
+        c[::3] = c[::3][:, [0, 3, 2, 1]]
+        c[2::5] = c[2::5][:, [3, 0, 1, 2]]
+    elif cell == "hexahedron":
+        syms = [((1, 0, 2), (0, 0, 0)), ((2, 0, 1), (1, 0, 0)), ((0, 2, 1), (0, 1, 1)), ((1, 2, 0), (1, 1, 1)), ((0, 1, 2), (0, 0, 1)),
+                ((2, 1, 0), (0, 1, 0)), ((0, 1, 2), (1, 1, 0))]
+        for k, (perm, flips) in enumerate(syms):
+            c[k + 1::len(syms) + 1] = c[k + 1::len(syms) + 1][:, _hex_symmetry(perm, flips)]
+    else:
+        return mesh
+    return Mesh(mesh.geometry.x, c, cell)
 
-        mesh = Mesh(mesh.geometry.x, c, "triangle")
+
+@pytest.mark.parametrize("cell,degree", [("triangle", 3), ("quadrilateral", 2), ("quadrilateral", 3), ("hexahedron", 2), ("hexahedron", 3),
+                                         ("tetrahedron", 3)])
+def test_shared_dofs_agree_between_cells(cell, degree):
+    """a dof on a shared edge / face is ONE dof: the coordinates the two cells assign to it agree, whatever the cells'
+    local orientations (shuffled local vertex order on simplices AND hexahedra: all relative orientations of a shared
+    quadrilateral face occur)"""
+    mesh = create_unit_square(4, 3, cell) if el.tdim(cell) == 2 else create_unit_cube(2, 3, 2, cell)
+    mesh = _scrambled(mesh, cell)
     V = fem.functionspace(mesh, ("Lagrange", degree))
     x = V.tabulate_dof_coordinates()
     gphi, _ = el.tabulate(cell, 1, el.reference_nodes(cell, degree)[0])
@@ -72,12 +103,13 @@ def _unconstrained(V, a=None, L=None):
     return Case("plain", V, a, L, [], empty_raw())
 
 
-@pytest.mark.parametrize("cell,degree", [("triangle", 3), ("quadrilateral", 1), ("quadrilateral", 2), ("quadrilateral", 3), ("hexahedron", 2)])
+@pytest.mark.parametrize("cell,degree", [("triangle", 3), ("quadrilateral", 1), ("quadrilateral", 2), ("quadrilateral", 3), ("hexahedron", 2),
+                                         ("hexahedron", 3), ("tetrahedron", 3)])
 def test_analytic_integrals(oracle, cell, degree):
     """u^T A v = int grad u . grad v, u^T M v = int u v, u^T b = int f u for polynomials IN the space on the unit square /
     cube with u_i = u(x_i) at the space's own dof coordinates (also on a sheared mesh for the affine invariance)"""
     two = el.tdim(cell) == 2
-    mesh = create_unit_square(3, 2, cell) if two else create_unit_cube(2, 2, 1, cell)
+    mesh = create_unit_square(3, 2, cell) if two else _scrambled(create_unit_cube(2, 2, 1, cell), cell)
     V = fem.functionspace(mesh, ("Lagrange", degree))
     x = V.tabulate_dof_coordinates()
     A = oracle_outputs(oracle, _unconstrained(V, fem.form_stiffness(V)))["A"]

@@ -127,8 +127,10 @@ def test_hex_mesh_topology():
     assert ce.shape == (60, 12) and ev.shape[0] == 3 * 5 * 6 + 4 * 4 * 6 + 5 * 4 * 5
     V2 = fem.functionspace(mesh, ("Lagrange", 2))  # Q2: 27 dofs per cell (elements.py), generated kernels
     assert V2.element_ndofs == 27 and V2.num_dofs == 7 * 9 * 11
+    V3 = fem.functionspace(mesh, ("Lagrange", 3))  # Q3: 64 dofs per cell, four nodes per face in the face's global frame
+    assert V3.element_ndofs == 64 and V3.num_dofs == 10 * 13 * 16
     with pytest.raises(NotImplementedError):
-        fem.functionspace(mesh, ("Lagrange", 3))
+        fem.functionspace(mesh, ("Lagrange", 4))
 
 
 def test_tiled_hex_mesh_is_the_same_mesh():

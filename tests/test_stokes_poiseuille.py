@@ -123,7 +123,10 @@ def test_oracle_poiseuille(oracle, n):
     _solve_and_check(V, Q, A00, A01, A10, b0, raw_u[0], raw_u[1].astype(np.int64), raw_p[0], raw_p[1].astype(np.int64))
 
 
-GENERAL = [("triangle", 3, 2, 3), ("quadrilateral", 2, 1, 3), ("quadrilateral", 3, 2, 2), ("hexahedron", 2, 1, 2)]
+# (python/tests/test_stokes_channelflow.py:21-23 sweeps tetrahedra and hexahedra with order 2 and 3: P3/P2 tetrahedra and
+# Q3/Q2 hexahedra are the order-3 members; P2/P1 tetrahedra run the built-in operators above)
+GENERAL = [("triangle", 3, 2, 3), ("quadrilateral", 2, 1, 3), ("quadrilateral", 3, 2, 2), ("hexahedron", 2, 1, 2), ("tetrahedron", 3, 2, 2),
+           ("hexahedron", 3, 2, 2)]
 
 
 @pytest.mark.parametrize("cell,pv,pq,n", GENERAL)
