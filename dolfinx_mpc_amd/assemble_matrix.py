@@ -247,6 +247,9 @@ def _block_lists_device(row0: np.ndarray, n_entities: int, estride: int, entitie
     L = _native.lib()
     st = D.stream_ptr()
     nb = row0.size - 1
+    if nd > 32:
+        # (Q3 hexahedra: 64 nodes per cell) the list builder keeps an entity's blocks in a 32-entry register array
+        raise _native.PlanNotRepresentable("row-block plan: more than 32 dof blocks per entity; the per-entity kernels take it")
     d_row0 = D._to_dev(row0, dev)
     counts = torch.empty(max(n_entities, 1), dtype=torch.int32, device=dev)
     args = (n_entities, estride, entities_ptr, dofmap_dev.data_ptr(), nd, bs, nb, d_row0.data_ptr(), counts.data_ptr())

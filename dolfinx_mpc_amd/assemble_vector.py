@@ -429,7 +429,12 @@ def _assemble_vector_on_stream(form: Form, constraint: MultiPointConstraint, b: 
     L = _native.lib()
     b.set(0.0)
     for i, integ in enumerate(form.integrals):
-        a, keep = vector_args(form, i, b, constraint, alg)
+        try:
+            a, keep = vector_args(form, i, b, constraint, alg)
+        except _native.PlanNotRepresentable:
+            if alg != 0:
+                raise
+            a, keep = vector_args(form, i, b, constraint, 1)  # 'auto': no plan fits (e.g. 64 nodes per cell) -> per-entity kernel
         _native.check(L.mpcx_assemble_vector(C.byref(a)), "mpcx_assemble_vector")
         if a.second is not None:
             _native.check(L.mpcx_assemble_vector(C.byref(a.second)), "mpcx_assemble_vector")

@@ -356,7 +356,20 @@ def element_sweep_cases() -> List[Callable[[], Case]]:
             out.append(lambda cell=cell, d=d: case_square_dict(d, (1, 1), (5, 3), cell))
             out.append(lambda cell=cell, d=d: case_square_dict(d, (0, 1), (1, 8), cell))
     out.append(case_hex_q2_periodic)
+    # the order-3 members of python/tests/test_stokes_channelflow.py:21-23 in 3D: P3 tetrahedra, Q3 hexahedra
+    out.append(lambda: case_cube_p3_periodic("tetrahedron", 2))
+    out.append(lambda: case_cube_p3_periodic("hexahedron", 2))
     return out
+
+
+def case_cube_p3_periodic(cell, N=2) -> Case:
+    """periodic Poisson with degree 3 on tetrahedra (20 dofs per cell, one per face) / hexahedra (64 dofs per cell, four per
+    face: more dof blocks than a row-block plan lists per entity, so 'auto' takes the per-entity kernels)"""
+    mesh = create_unit_cube(N, N, N, cell)
+    V = fem.functionspace(mesh, ("Lagrange", 3))
+    bc = fem.dirichletbc(0.2, fem.locate_dofs_geometrical(V, _walls_yz), V)
+    a = fem.form_stiffness(V) + fem.form_mass(V, constant=0.7)
+    return Case(f"{cell[:3]}_p3_periodic_n{N}", V, a, fem.form_source(V, fem.FN_POLY3), [bc], periodic_raw(V, [bc]))
 
 
 def case_hex_q2_periodic(N=3) -> Case:
