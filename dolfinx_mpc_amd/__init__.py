@@ -3,8 +3,8 @@
 Drop-in for the hot path of dolfinx_mpc (``assemble_matrix``,
 ``assemble_vector``, ``apply_lifting`` and the ``MultiPointConstraint`` data
 they read; python/src/dolfinx_mpc/__init__.py:11-25 exports the same names).
-Everything else of dolfinx_mpc (constraint builders on unstructured meshes,
-solvers, I/O) is out of scope; see DESIGN.md.
+The callers either side of it -- constraint builders, ``LinearProblem`` / ``NonlinearProblem``, ``utils`` -- mirror the
+reference's names too; I/O and PETSc itself are out of scope, see DESIGN.md.
 """
 
 from .assemble_matrix import (
@@ -22,7 +22,8 @@ from .assemble_vector import (
     set_bc,
 )
 from .multipointconstraint import MPCData, MultiPointConstraint
-from .problem import LinearProblem
+from . import utils  # noqa: F401  (dolfinx_mpc.utils: constraint helpers, near-null space, the verification toolkit)
+from .problem import LinearProblem, NonlinearProblem
 
 __all__ = [
     "assemble_matrix",
@@ -38,4 +39,6 @@ __all__ = [
     "create_matrix",
     "set_bc",
     "LinearProblem",
+    "NonlinearProblem",
+    "utils",
 ]

@@ -98,3 +98,82 @@ def create_point_to_point_constraint(V, slave_point, master_point, vector=None):
         offsets = np.array([0, masters.size], dtype=np.int32)
     owners = np.zeros(masters.size, dtype=np.int32)
     return slaves, masters, coeffs, owners, offsets
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The verification toolkit of python/src/dolfinx_mpc/utils/test.py (the reference's demos and tests check their
+# constrained systems with it): host-side, scipy, single process.
+# ---------------------------------------------------------------------------------------------------------
+def log_info(message: str) -> None:
+    """``dolfinx_mpc.utils.log_info`` (mpc_utils.py:150-160): a line on the root process"""
+    import logging
+
+    logging.getLogger("dolfinx_mpc_amd").info(message)
+
+
+def gather_PETScMatrix(A, root: int = 0):
+    """the assembled matrix as a scipy CSR matrix (utils/test.py:152-175; here: ``MPCMatrix.to_scipy`` or a scipy matrix)"""
+    return A.to_scipy() if hasattr(A, "to_scipy") else A.tocsr()
+
+
+def gather_PETScVector(b, root: int = 0) -> np.ndarray:
+    """the assembled vector as a numpy array (utils/test.py:178-193)"""
+    if hasattr(b, "numpy"):
+        return b.numpy()
+    return np.asarray(b.x.array if hasattr(b, "x") else b)
+
+
+def gather_transformation_matrix(constraint, root: int = 0):
+    """K (num_dofs x (num_dofs - num_slaves)) with u = K u_reduced (utils/test.py:67-149): the row of a free dof holds a 1
+    in its reduced column, the row of a slave its coefficients in the reduced columns of its masters"""
+    import scipy.sparse
+
+    n = constraint.function_space.num_dofs
+    slaves = np.asarray(constraint.slaves[: constraint.num_local_slaves], dtype=np.int64)
+    is_slave = np.zeros(n, dtype=bool)
+    is_slave[slaves] = True
+    reduced = np.cumsum(~is_slave) - 1  # column of every free dof
+    off, masters = constraint.masters.offsets, np.asarray(constraint.masters.array, dtype=np.int64)
+    coeffs = constraint.coefficients()[0]
+    free = np.flatnonzero(~is_slave)
+    rows, cols, vals = [free], [reduced[free]], [np.ones(free.size, dtype=coeffs.dtype)]
+    for s in slaves:
+        lo, hi = off[s], off[s + 1]
+        if hi > lo:
+            rows.append(np.full(hi - lo, s, dtype=np.int64))
+            cols.append(reduced[masters[lo:hi]])
+            vals.append(coeffs[lo:hi])
+    return scipy.sparse.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
+                                   shape=(n, free.size)).tocsr()
+
+
+def compare_CSR(A, B, atol=1e-10) -> None:
+    """utils/test.py:196-199"""
+    assert abs(A - B).max() < atol
+
+
+def compare_mpc_lhs(A_org, A_mpc, mpc, root: int = 0, atol=5e3 * np.finfo(np.float64).resolution) -> None:
+    """``A_mpc`` without its slave rows / columns equals ``K^H A_org K`` (utils/test.py:202-242)"""
+    K = gather_transformation_matrix(mpc)
+    A0, A1 = gather_PETScMatrix(A_org), gather_PETScMatrix(A_mpc)
+    dt = np.complex128 if np.iscomplexobj(K.data) or np.iscomplexobj(A0.data) else np.float64
+    K, A0 = K.astype(dt), A0.astype(dt)
+    KTAK = K.conj().T @ A0 @ K
+    n = mpc.function_space.num_dofs
+    free = np.setdiff1d(np.arange(n), np.asarray(mpc.slaves[: mpc.num_local_slaves], dtype=np.int64))
+    compare_CSR(KTAK, A1.tocsr()[free, :][:, free], atol=atol)
+
+
+def compare_mpc_rhs(b_org, b, constraint, root: int = 0) -> None:
+    """``b`` is zero at the slaves and equals ``K^H b_org`` elsewhere (utils/test.py:245-265)"""
+    K = gather_transformation_matrix(constraint)
+    b0, b1 = gather_PETScVector(b_org), gather_PETScVector(b)
+    n = constraint.function_space.num_dofs
+    slaves = np.asarray(constraint.slaves[: constraint.num_local_slaves], dtype=np.int64)
+    free = np.setdiff1d(np.arange(n), slaves)
+    assert np.allclose(b1[slaves], 0)
+    assert np.allclose(b1[free], K.conj().T @ b0)
+
+
+__all__ += ["log_info", "gather_PETScMatrix", "gather_PETScVector", "gather_transformation_matrix", "compare_CSR", "compare_mpc_lhs",
+            "compare_mpc_rhs"]

@@ -415,3 +415,44 @@ def test_point_to_point_constraint(oracle):
     oracle.homogenize(om, u)
     oracle.backsubstitution(om, u)
     assert abs(v @ u[b0 * 3:b0 * 3 + 3] - v @ u[b1 * 3:b1 * 3 + 3]) < 1e-12 * abs(u).max()
+
+
+def test_verification_toolkit_agrees_with_the_oracle(oracle):
+    """``utils.gather_transformation_matrix`` / ``compare_mpc_lhs`` / ``compare_mpc_rhs`` (the reference's
+    utils/test.py:67-265, product side) against the oracle's own restatement on a constrained system with multi-master
+    slaves, and the docstring example of utils/test.py:72-86"""
+    import scipy.sparse as sp
+
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import utils
+    from problems import case_delaunay_periodic, oracle_mpc, oracle_outputs
+
+    case = case_delaunay_periodic(2, 1, 5, seed=2)
+
+    class _HostMPC:  # the finalized data without a GPU: what the toolkit reads
+        pass
+
+    om = oracle_mpc(oracle, case)
+    K_ref = oracle.gather_transformation_matrix(om)
+    h = _HostMPC()
+    h.function_space = case.V
+    h.slaves, h.num_local_slaves = om.slaves, om.num_local_slaves
+    h.masters = type("Adj", (), {"offsets": om.masters_offsets, "array": om.masters})()
+    h.coefficients = lambda: (om.coeffs, om.masters_offsets)
+    K = utils.gather_transformation_matrix(h)
+    assert K.shape == K_ref.shape and abs(K - K_ref).max() < 1e-15
+    out = oracle_outputs(oracle, case)
+    emp = oracle.OracleMPC.empty(case.V)
+    A_org = oracle.assemble_matrix(case.a, emp, bcs=case.bcs)
+    utils.compare_mpc_lhs(A_org, out["A"], h)
+    utils.compare_mpc_rhs(oracle.assemble_vector(case.L, emp), out["b"], h)
+    with pytest.raises(AssertionError):
+        utils.compare_mpc_lhs(A_org * 1.001, out["A"], h)
+    # utils/test.py:72-86: u_1 = alpha u_0 + beta u_2
+    ex = _HostMPC()
+    ex.function_space = type("V", (), {"num_dofs": 3})()
+    ex.slaves, ex.num_local_slaves = np.array([1]), 1
+    ex.masters = type("Adj", (), {"offsets": np.array([0, 0, 2, 2]), "array": np.array([0, 2])})()
+    ex.coefficients = lambda: (np.array([0.3, 0.7]), None)
+    assert np.allclose(utils.gather_transformation_matrix(ex).toarray(), [[1, 0], [0.3, 0.7], [0, 1]])
+    assert dm.utils is utils and hasattr(dm, "NonlinearProblem")
