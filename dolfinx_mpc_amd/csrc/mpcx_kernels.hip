@@ -2149,6 +2149,10 @@ extern "C" int mpcx_assemble_vector(const mpcx_vector_args_t* args)
       return launch_vector<ElementOp<3, 1, 1, 1, 1, MPCX_FORM_SOURCE, 1>>(a);
     if (is_space(k, MPCX_CELL_TETRAHEDRON, 2, 1) && k.fn_id == 1)
       return launch_vector<ElementOp<3, 2, 1, 2, 1, MPCX_FORM_SOURCE, 1>>(a);
+    // a constant body force on P2 vector spaces (the Taylor-Hood momentum right-hand side, config 3): with the function id
+    // known at compile time the map of the quadrature points to physical space drops out of the loop
+    if (is_space(k, MPCX_CELL_TETRAHEDRON, 2, 3) && k.fn_id == 5 && a.coeffs == nullptr)
+      return launch_vector<ElementOp<3, 2, 3, 2, 3, MPCX_FORM_SOURCE, 5>>(a);
     MPCX_FOR_SPACES(launch_vector, MPCX_FORM_SOURCE)
     MPCX_FOR_P2_VECTOR_SPACES(launch_vector, MPCX_FORM_SOURCE)
     break;
