@@ -169,7 +169,10 @@ class SmoothedAggregation:
             G = torch.zeros((nagg, k, k), dtype=torch.float64, device=dev)
             G.index_add_(0, pagg, Br[:, :, None] * Br[:, None, :])
             eye_k = torch.eye(k, dtype=torch.float64, device=dev)
-            Lc, info = torch.linalg.cholesky_ex(G)
+            if k == 1:  # (scalar problems: the factor of a 1 x 1 Gram matrix is a square root)
+                Lc, info = torch.sqrt(G.clamp(min=0.0)), torch.zeros(nagg, dtype=torch.int32, device=dev)
+            else:
+                Lc, info = torch.linalg.cholesky_ex(G)
             dR = torch.diagonal(Lc, dim1=1, dim2=2)
             bad = (info != 0) | ~torch.isfinite(dR).all(dim=1) | (dR.min(dim=1).values ** 2 <= 1e-10 * dR.max(dim=1).values ** 2)
             R = Lc.transpose(1, 2).contiguous()  # G = R^T R
