@@ -42,13 +42,13 @@ def _power_rho(A, dinv, iters: int = 12) -> float:
     n = A.shape[0]
     g = torch.Generator(device=dinv.device).manual_seed(11)
     v = torch.rand(n, generator=g, device=dinv.device, dtype=torch.float64) - 0.5
-    rho = 1.0
-    for _ in range(iters):
+    rho = torch.ones((), dtype=torch.float64, device=dinv.device)
+    for _ in range(iters):  # (no host round trip inside the iteration)
         v = v / torch.linalg.vector_norm(v)
         w = dinv * (A @ v)
-        rho = float(torch.dot(v, w))
+        rho = torch.dot(v, w)
         v = w
-    return abs(rho)
+    return abs(float(rho))
 
 
 class _Mat:
