@@ -18,6 +18,9 @@
 #include <hip/hip_runtime.h>
 #include <mutex>
 #include <algorithm>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <cstdio>
 #include <string>
 #include <vector>
 
@@ -765,6 +768,66 @@ int ensure_loaded(UfcxKernel* k)
   return get(&k->vector, "ufcx_vector_kernel");
 }
 
+// ---- code objects on disk (opt-in: MPCX_UFCX_CACHE = directory): a form's kernels are then compiled once per (source,
+// element shapes, options, library build), like the reference's FFCx / CFFI JIT cache (~/.cache/fenics).  Files are
+// written to a temporary name and renamed, so concurrent processes never read a partial file.
+std::string cache_dir()
+{
+  const char* e = std::getenv("MPCX_UFCX_CACHE");
+  return (e && *e && std::string(e) != "0") ? std::string(e) : std::string();
+}
+uint64_t fnv1a(const std::string& text, uint64_t h = 1469598103934665603ull)
+{
+  for (unsigned char c : text)
+    h = (h ^ c) * 1099511628211ull;
+  return h;
+}
+std::string cache_path(const std::string& src, const std::vector<std::string>& opts)
+{
+  const std::string dir = cache_dir();
+  if (dir.empty())
+    return {};
+  uint64_t h = fnv1a(src);
+  for (const auto& o : opts)
+    h = fnv1a(o, h);
+  h = fnv1a(std::string(__DATE__ " " __TIME__), h); // the library build (the embedded kernel text changes with it)
+  char name[32];
+  std::snprintf(name, sizeof(name), "%016llx.co", static_cast<unsigned long long>(h));
+  return dir + "/" + name;
+}
+bool read_file(const std::string& path, std::vector<char>& out)
+{
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f)
+    return false;
+  std::fseek(f, 0, SEEK_END);
+  const long n = std::ftell(f);
+  std::fseek(f, 0, SEEK_SET);
+  out.resize(n > 0 ? size_t(n) : 0);
+  const bool ok = n > 0 && std::fread(out.data(), 1, size_t(n), f) == size_t(n);
+  std::fclose(f);
+  return ok;
+}
+void write_file_atomically(const std::string& path, const std::vector<char>& data)
+{
+  const auto slash = path.rfind('/');
+  if (slash != std::string::npos)
+  {
+    std::string dir = path.substr(0, slash);
+    for (size_t i = 1; i <= dir.size(); ++i) // mkdir -p
+      if (i == dir.size() || dir[i] == '/')
+        (void)::mkdir(dir.substr(0, i).c_str(), 0755);
+  }
+  const std::string tmp = path + ".tmp" + std::to_string(static_cast<long long>(::getpid()));
+  FILE* f = std::fopen(tmp.c_str(), "wb");
+  if (!f)
+    return; // (a read-only home: no cache)
+  const bool ok = std::fwrite(data.data(), 1, data.size(), f) == data.size();
+  std::fclose(f);
+  if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0)
+    (void)std::remove(tmp.c_str());
+}
+
 template <class Args>
 int launch(hipFunction_t f, int64_t n, const Args& a, void* stream, int64_t max_threads = 0)
 {
@@ -796,12 +859,6 @@ int launch_blocks(hipFunction_t f, int num_blocks, int threads, size_t lds, cons
 
 extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
 {
-  Rtc& r = rtc();
-  if (!r.lib || !r.create || !r.compile || !r.code)
-  {
-    mpcx_set_error("mpcx_ufcx_compile: libhiprtc.so not found");
-    return nullptr;
-  }
   if (!d->source || !d->function_name || (d->rank != 1 && d->rank != 2) || d->nd0 <= 0 || d->bs0 <= 0 || d->nv <= 0
       || (d->rank == 2 && (d->nd1 <= 0 || d->bs1 <= 0)))
   {
@@ -868,12 +925,6 @@ extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
   src += "#pragma clang force_cuda_host_device end\n";
   src += KERNELS_TEXT;
   src += ROWBLOCK_KERNELS_TEXT;
-  void* prog = nullptr;
-  if (r.create(&prog, src.c_str(), "mpcx_ufcx.hip", 0, nullptr, nullptr) != 0)
-  {
-    mpcx_set_error("mpcx_ufcx_compile: hiprtcCreateProgram failed");
-    return nullptr;
-  }
   // element tensors up to 36 entries (P1 scalar, P1 x P1 on triangles / tets, bs <= ...): 512 threads, 128 VGPRs;
   // up to 144 entries: fully unrolled at 256 threads (256 VGPRs); larger ones stay rolled in private memory
   const int size = d->rank == 2 ? d->nd0 * d->bs0 * d->nd1 * d->bs1 : d->nd0 * d->bs0;
@@ -886,6 +937,39 @@ extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
          "-DUFCX_RANK=" + std::to_string(d->rank), "-DND0=" + std::to_string(d->nd0), "-DBS0=" + std::to_string(d->bs0),
          "-DND1=" + std::to_string(d->rank == 2 ? d->nd1 : 1), "-DBS1=" + std::to_string(d->rank == 2 ? d->bs1 : 1),
          "-DNV=" + std::to_string(d->nv)};
+  auto make_handle = [&]()
+  {
+    auto* k = new UfcxKernel;
+    k->rb_threads = rb_threads;
+    k->big = big != 0;
+    k->desc = *d;
+    k->desc.source = nullptr;
+    k->desc.function_name = nullptr;
+    return k;
+  };
+  const std::string cached = cache_path(src, opts);
+  if (!cached.empty())
+  {
+    std::vector<char> code;
+    if (read_file(cached, code))
+    {
+      auto* k = make_handle();
+      k->code = std::move(code);
+      return k;
+    }
+  }
+  Rtc& r = rtc(); // (loaded only when something has to be compiled)
+  if (!r.lib || !r.create || !r.compile || !r.code)
+  {
+    mpcx_set_error("mpcx_ufcx_compile: libhiprtc.so not found");
+    return nullptr;
+  }
+  void* prog = nullptr;
+  if (r.create(&prog, src.c_str(), "mpcx_ufcx.hip", 0, nullptr, nullptr) != 0)
+  {
+    mpcx_set_error("mpcx_ufcx_compile: hiprtcCreateProgram failed");
+    return nullptr;
+  }
   std::vector<const char*> copts;
   for (auto& o : opts)
     copts.push_back(o.c_str());
@@ -901,17 +985,14 @@ extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
     mpcx_set_error("mpcx_ufcx_compile: hipRTC compilation failed:\n" + log.substr(0, 4000));
     return nullptr;
   }
-  auto* k = new UfcxKernel;
-  k->rb_threads = rb_threads;
-  k->big = big != 0;
-  k->desc = *d;
-  k->desc.source = nullptr;
-  k->desc.function_name = nullptr;
+  auto* k = make_handle();
   size_t n = 0;
   r.code_size(prog, &n);
   k->code.resize(n);
   r.code(prog, k->code.data());
   r.destroy(&prog);
+  if (!cached.empty())
+    write_file_atomically(cached, k->code);
   return k;
 }
 

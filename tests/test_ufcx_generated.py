@@ -116,3 +116,35 @@ def test_stated_builtin_twin_is_checked_then_used(oracle, degree, monkeypatch):
     monkeypatch.setenv("MPCX_UFCX_BUILTIN", "0")
     a, L = forms()
     check(a, L, False)
+
+
+def test_code_object_cache(tmp_path, monkeypatch):
+    """MPCX_UFCX_CACHE: the second compilation of the same kernel is a file read (hipRTC cross-compiles on the CPU)"""
+    import time
+
+    from dolfinx_mpc_amd import _device as D
+    from dolfinx_mpc_amd import _native, fem
+    from dolfinx_mpc_amd.mesh import create_unit_square
+
+    monkeypatch.setenv("MPCX_UFCX_CACHE", str(tmp_path))
+    V = fem.functionspace(create_unit_square(2, 2, "quadrilateral"), ("Lagrange", 2))
+    form = fem.form_mass(V, constant=1.2345)
+    k = form.integrals[0].kernel
+    monkeypatch.setattr(D, "_ufcx_handles", {})
+    t0 = time.perf_counter()
+    h1 = D.ufcx_compile(k, form)
+    t_compile = time.perf_counter() - t0
+    files = list(tmp_path.glob("*.co"))
+    assert len(files) == 1 and files[0].stat().st_size == _native.lib().mpcx_ufcx_code_size(h1)
+    monkeypatch.setattr(D, "_ufcx_handles", {})
+    t0 = time.perf_counter()
+    h2 = D.ufcx_compile(k, form)
+    t_cached = time.perf_counter() - t0
+    L = _native.lib()
+    import ctypes as C
+
+    n = L.mpcx_ufcx_code_size(h2)
+    b1, b2 = C.create_string_buffer(n), C.create_string_buffer(n)
+    L.mpcx_ufcx_code(h1, b1)
+    L.mpcx_ufcx_code(h2, b2)
+    assert b1.raw == b2.raw and t_cached < 0.25 * t_compile, (t_compile, t_cached)
