@@ -213,6 +213,17 @@ def _owner_plan_from_rows_torch(mrow, V, rows: int):
 VCUBE_OWNER_ROWS = int(os.environ.get("MPCX_VCUBE_ROWS", 2048))
 
 
+def _vcube_owner_rows(V) -> int:
+    """own rows per block of the cluster vector kernel: MPCX_VCUBE_ROWS (default 2048), halved for small problems (the slab
+    one rank holds at 8 GPUs) until there are row blocks for several rounds over the 256 CUs -- 128^3 cubes: 2048 / 1024 /
+    512 rows 0.44 / 0.40 / 0.39 ms; 256^3 keeps 2048"""
+    top = VCUBE_OWNER_ROWS
+    if "MPCX_VCUBE_ROWS" not in os.environ:
+        while top > 512 and V.num_dofs // top < 4096:
+            top //= 2
+    return top
+
+
 def _vector_cube_owner_plan(mesh, V, d_verts, constraint, left: np.ndarray, slave_ents_h: np.ndarray):
     """owner-computes plan over the mesh's cell clusters (work item = cluster, its eight vertices = its dofs; slave
     flag folded into the vertex ids) + the slave CELLS the cluster call is responsible for (all but the leftover
@@ -223,7 +234,8 @@ def _vector_cube_owner_plan(mesh, V, d_verts, constraint, left: np.ndarray, slav
         _, t = constraint._device()
         flag = t["is_slave"][d_verts.long()].to(torch.int32) << 28
         mrow = (d_verts | flag).contiguous()
-        for rows in (VCUBE_OWNER_ROWS, VCUBE_OWNER_ROWS // 2, VCUBE_OWNER_ROWS // 4):
+        top = _vcube_owner_rows(V)
+        for rows in (top, top // 2, top // 4):
             own = _owner_plan_from_rows(mrow, V, _even_rows(V, rows))
             if own is not None:
                 break
