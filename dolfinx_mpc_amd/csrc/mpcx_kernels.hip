@@ -1550,40 +1550,78 @@ __global__ void vector_spill_reduce_kernel(int64_t n_rows, const int32_t* __rest
   b[int64_t(rows[u]) * bs + k] += sum;
 }
 
+// Rows of slave dofs go to their masters (cpp/assemble_vector.h:35-69).  The contributions of a workgroup's entities are
+// merged per target row in an LDS hash table first: neighbouring slave cells share their slaves (12 cells round a node of
+// a periodic face), and a device-scope fp64 atomic is served at the memory side (~0.1 us each when a step issues a
+// million of them: 128 us for the slave layer of config 2 without the table).
+constexpr int VECTOR_MPC_THREADS = 256;
+constexpr int VECTOR_MPC_LOG2H = 11;
+constexpr int VECTOR_MPC_H = 1 << VECTOR_MPC_LOG2H;
 template <class Op>
-__global__ void __launch_bounds__(64) vector_mpc_kernel(mpcx_vector_args_t a)
+__global__ void __launch_bounds__(VECTOR_MPC_THREADS) vector_mpc_kernel(mpcx_vector_args_t a)
 {
   constexpr int N = Op::N0, ND = Op::ND0, BS = Op::BS0, NV = Op::NV;
-  fastmath_init_lds();
-  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (t >= a.n_slave_entities)
-    return;
-  const int64_t e = a.slave_entities[t];
-  const int64_t l = e * a.estride;
-  const int64_t cell = (a.entities ? a.entities[l] : e);
-  const int64_t cell0 = (a.entities0 ? a.entities0[l] : e);
-  const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
-  double cd[NV * 3];
-  gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
-  double be[N];
-  Op::tabulate(be, a.coeffs ? a.coeffs + e * a.cstride : nullptr, a.constants, cd, lf, a.kernel);
-#pragma unroll
-  for (int i = 0; i < ND; ++i)
+  __shared__ int32_t s_key[VECTOR_MPC_H];
+  __shared__ double s_val[VECTOR_MPC_H];
+  for (int i = threadIdx.x; i < VECTOR_MPC_H; i += VECTOR_MPC_THREADS)
   {
-    const int32_t d0 = a.dofmap[cell0 * ND + i];
-#pragma unroll
-    for (int k = 0; k < BS; ++k)
+    s_key[i] = -1;
+    s_val[i] = 0.0;
+  }
+  fastmath_init_lds(); // ends in a barrier
+  auto add = [&](int32_t row, double v)
+  {
+    unsigned h = (unsigned(row) * 2654435761u) >> (32 - VECTOR_MPC_LOG2H);
+#pragma nounroll
+    for (int probe = 0; probe < 32; ++probe)
     {
-      const int32_t d = d0 * BS + k;
-      if (!a.mpc.is_slave[d])
-        continue;
-      const double v = be[i * BS + k];
-      const int m0 = a.mpc.masters_offsets[d], m1 = a.mpc.masters_offsets[d + 1];
-      for (int mi = m0; mi < m1; ++mi)
-        atomic_add_f64(a.b + a.mpc.masters[mi], a.mpc.coeffs[mi] * v);
-      if (m1 == m0)
-        atomic_add_f64(a.b + d, v);
+      const int32_t old = atomicCAS(&s_key[h], -1, row);
+      if (old == -1 || old == row)
+      {
+        __hip_atomic_fetch_add(&s_val[h], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+      }
+      h = (h + 1) & (VECTOR_MPC_H - 1);
     }
+    atomic_add_f64(a.b + row, v); // (a full neighbourhood of the table: straight to memory)
+  };
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t < a.n_slave_entities)
+  {
+    const int64_t e = a.slave_entities[t];
+    const int64_t l = e * a.estride;
+    const int64_t cell = (a.entities ? a.entities[l] : e);
+    const int64_t cell0 = (a.entities0 ? a.entities0[l] : e);
+    const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
+    double cd[NV * 3];
+    gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
+    double be[N];
+    Op::tabulate(be, a.coeffs ? a.coeffs + e * a.cstride : nullptr, a.constants, cd, lf, a.kernel);
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+    {
+      const int32_t d0 = a.dofmap[cell0 * ND + i];
+#pragma unroll
+      for (int k = 0; k < BS; ++k)
+      {
+        const int32_t d = d0 * BS + k;
+        if (!a.mpc.is_slave[d])
+          continue;
+        const double v = be[i * BS + k];
+        const int m0 = a.mpc.masters_offsets[d], m1 = a.mpc.masters_offsets[d + 1];
+        for (int mi = m0; mi < m1; ++mi)
+          add(a.mpc.masters[mi], a.mpc.coeffs[mi] * v);
+        if (m1 == m0)
+          add(d, v);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < VECTOR_MPC_H; i += VECTOR_MPC_THREADS)
+  {
+    const int32_t row = s_key[i];
+    if (row >= 0)
+      atomic_add_f64(a.b + row, s_val[i]);
   }
 }
 
@@ -1982,7 +2020,7 @@ int launch_vector(const mpcx_vector_args_t& a)
       return rc;
     if (a.n_slave_entities > 0)
     {
-      hipLaunchKernelGGL(vector_mpc_kernel<Op>, dim3(grid_for(a.n_slave_entities, 64)), dim3(64), 0, stream, a);
+      hipLaunchKernelGGL(vector_mpc_kernel<Op>, dim3(grid_for(a.n_slave_entities, VECTOR_MPC_THREADS)), dim3(VECTOR_MPC_THREADS), 0, stream, a);
       return check(hipGetLastError(), "vector mpc kernel launch");
     }
     return 0;
@@ -1997,7 +2035,7 @@ int launch_slave_rows(const mpcx_vector_args_t& a)
 {
   if (a.n_slave_entities <= 0)
     return 0;
-  hipLaunchKernelGGL(vector_mpc_kernel<Op>, dim3(grid_for(a.n_slave_entities, 64)), dim3(64), 0,
+  hipLaunchKernelGGL(vector_mpc_kernel<Op>, dim3(grid_for(a.n_slave_entities, VECTOR_MPC_THREADS)), dim3(VECTOR_MPC_THREADS), 0,
                      static_cast<hipStream_t>(a.stream), a);
   return check(hipGetLastError(), "vector mpc kernel launch");
 }
