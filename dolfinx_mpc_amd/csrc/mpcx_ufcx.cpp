@@ -617,31 +617,62 @@ extern "C" __global__ void __launch_bounds__(UFCX_RB_THREADS) ufcx_vector_rowblo
 }
 
 // slave rows of the entities that have any (modify_mpc_vec, cpp/assemble_vector.h:35-69)
+// (contributions merged per target row in an LDS hash table before the device atomics, as vector_mpc_kernel does)
+#define UFCX_VMPC_LOG2H 10
+#define UFCX_VMPC_H (1 << UFCX_VMPC_LOG2H)
 extern "C" __global__ void __launch_bounds__(64) ufcx_vector_mpc_kernel(mpcx_vector_args_t a)
 {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= a.n_slave_entities)
-    return;
-  const long long e = a.slave_entities[t];
-  const long long l = e * a.estride;
-  const long long cell = a.entities ? a.entities[l] : e;
-  const long long cell0 = a.entities0 ? a.entities0[l] : e;
-  const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
-  double cd[NV * 3];
-  gather(a.x, a.x_dofmap, cell, cd);
-  double be[N0];
-  tabulate(be, N0, a.coeffs, a.cstride, a.constants, cd, e, lf);
-  for (int p = 0; p < N0; ++p)
+  __shared__ int s_key[UFCX_VMPC_H];
+  __shared__ double s_val[UFCX_VMPC_H];
+  for (int i = threadIdx.x; i < UFCX_VMPC_H; i += 64)
   {
-    const int d = a.dofmap[cell0 * ND0 + p / BS0] * BS0 + p % BS0;
-    if (!a.mpc.is_slave[d])
-      continue;
-    const int m0 = a.mpc.masters_offsets[d], m1 = a.mpc.masters_offsets[d + 1];
-    for (int mi = m0; mi < m1; ++mi)
-      atomic_add_f64(a.b + a.mpc.masters[mi], a.mpc.coeffs[mi] * be[p]);
-    if (m1 == m0)
-      atomic_add_f64(a.b + d, be[p]);
+    s_key[i] = -1;
+    s_val[i] = 0.0;
   }
+  __syncthreads();
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < a.n_slave_entities)
+  {
+    const long long e = a.slave_entities[t];
+    const long long l = e * a.estride;
+    const long long cell = a.entities ? a.entities[l] : e;
+    const long long cell0 = a.entities0 ? a.entities0[l] : e;
+    const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
+    double cd[NV * 3];
+    gather(a.x, a.x_dofmap, cell, cd);
+    double be[N0];
+    tabulate(be, N0, a.coeffs, a.cstride, a.constants, cd, e, lf);
+    for (int p = 0; p < N0; ++p)
+    {
+      const int d = a.dofmap[cell0 * ND0 + p / BS0] * BS0 + p % BS0;
+      if (!a.mpc.is_slave[d])
+        continue;
+      const int m0 = a.mpc.masters_offsets[d], m1 = a.mpc.masters_offsets[d + 1];
+      for (int mi = m0 - (m1 == m0 ? 1 : 0); mi < m1; ++mi)
+      {
+        const int row = mi < m0 ? d : a.mpc.masters[mi];
+        const double v = mi < m0 ? be[p] : a.mpc.coeffs[mi] * be[p];
+        unsigned h = ((unsigned)row * 2654435761u) >> (32 - UFCX_VMPC_LOG2H);
+        int probe = 0;
+        for (; probe < 32; ++probe)
+        {
+          const int old = atomicCAS(&s_key[h], -1, row);
+          if (old == -1 || old == row)
+          {
+            __hip_atomic_fetch_add(&s_val[h], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            break;
+          }
+          h = (h + 1) & (UFCX_VMPC_H - 1);
+        }
+        if (probe == 32)
+          atomic_add_f64(a.b + row, v);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < UFCX_VMPC_H; i += 64)
+    if (s_key[i] >= 0)
+      atomic_add_f64(a.b + s_key[i], s_val[i]);
 }
 #endif
 )MPCXR";
