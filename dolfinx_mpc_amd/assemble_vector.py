@@ -211,6 +211,7 @@ def _owner_plan_from_rows_torch(mrow, V, rows: int):
 
 # own rows per block of the owner-computes cluster vector kernel (config 2, kernel ms: 1024 rows 2.73, 2048 2.75, 4096 2.81, 8192 4.40)
 VCUBE_OWNER_ROWS = int(os.environ.get("MPCX_VCUBE_ROWS", 2048))
+VCUBE_OWN_THREADS = 256  # threads per workgroup of vector_cube_own_kernel (csrc/mpcx_cubes.hip)
 
 
 def _vcube_owner_rows(V) -> int:
@@ -235,10 +236,29 @@ def _vector_cube_owner_plan(mesh, V, d_verts, constraint, left: np.ndarray, slav
         flag = t["is_slave"][d_verts.long()].to(torch.int32) << 28
         mrow = (d_verts | flag).contiguous()
         top = _vcube_owner_rows(V)
-        for rows in (top, top // 2, top // 4):
-            own = _owner_plan_from_rows(mrow, V, _even_rows(V, rows))
-            if own is not None:
-                break
+        own = None
+        if top < VCUBE_OWNER_ROWS:
+            # a small problem: the cap that needs the fewest 256-thread passes over the blocks' clusters (a slab with a
+            # ghost plane has tiles of 448 rows -- 273 clusters per 512-row block, two passes with 17 lanes in the second:
+            # 512 / 1024 / 2048 rows 0.65 / 0.65 / 0.53 ms on rank 1 of the 8-way cut of config 2, 0.46 / 0.50 / 0.51 on rank 0);
+            # ties go to the smaller blocks
+            best = None
+            for rows in (512, 1024, 2048):
+                cand = _owner_plan_from_rows(mrow, V, _even_rows(V, rows))
+                if cand is None:
+                    continue
+                per = cand[1][1][1:] - cand[1][1][:-1]  # clusters per block
+                passes = int(((per + (VCUBE_OWN_THREADS - 1)) // VCUBE_OWN_THREADS).sum().item())
+                if best is None or passes < best[0]:
+                    best = (passes, rows, cand)
+            if best is not None:
+                own, V._vcube_rows = best[2], best[1]
+        else:
+            for rows in (top, top // 2, top // 4):
+                own = _owner_plan_from_rows(mrow, V, _even_rows(V, rows))
+                if own is not None:
+                    V._vcube_rows = rows
+                    break
         if own is None:
             return None
         sl = slave_ents_h if left.size == 0 else np.setdiff1d(slave_ents_h, left)

@@ -151,7 +151,7 @@ def test_owner_plan_from_the_c_abi_equals_the_torch_allocated_plan(oracle, kwarg
     rows = int(np.diff(pk[0].cpu().numpy()).max())  # own rows per block of the reference plan
     hints = None if V.dof_tile_offsets is None else np.ascontiguousarray(V.dof_tile_offsets.astype(np.int32))
     h = C.c_void_p()
-    rows_cfg = av._even_rows(V, av._vcube_owner_rows(V))
+    rows_cfg = av._even_rows(V, V._vcube_rows)  # (the cap the plan builder chose for this problem size)
     rc = L.mpcx_owner_plan_create(nc, 8, mrow.data_ptr(), 1, V.num_dofs, rows_cfg, None if hints is None else hints.ctypes.data,
                                   0 if hints is None else hints.size, av.VECTOR_LDS_ROWS, D.stream_ptr(), C.byref(h))
     _native.check(rc, "mpcx_owner_plan_create")
