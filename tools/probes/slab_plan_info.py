@@ -26,3 +26,14 @@ for rank in (0, 1):
           "tile hints", None if V.dof_tile_offsets is None else len(V.dof_tile_offsets))
     top = np.argsort(per)[-5:]
     print("   heaviest blocks", [(int(t), int(per[t]), int(halo[t]), int(r0[t]), int(r0[t + 1] - r0[t])) for t in top])
+    # matrix cluster plan: parts by record format
+    lm, fm, (m0, m1) = w.blocks[0]
+    A = dm.create_matrix(fm, m0, m1)
+    dm.assemble_matrix(fm, (m0, m1), bcs=w.bcs, A=A)
+    for v in A._plans[("objcache", "cubes")].values():
+        parts, keep2, info = v[1]
+        print("   matrix plan", {k: info[k] for k in ("num_blocks", "num_ents", "max_rows", "max_nnz", "narrow_blocks", "closed_form_blocks")},
+              [(int(p[0].num_blocks), p[2], int(p[4][-1].item())) for p in parts])
+    nnz_row = np.diff(A.rowptr)
+    print("   rows", A.shape[0], "max nnz/row", int(nnz_row.max()), "rows with > 16 entries", int((nnz_row > 16).sum()),
+          "of which ghost rows", int((nnz_row[V.mesh.num_owned_nodes:] > 16).sum()), "ghost rows", V.num_dofs - V.mesh.num_owned_nodes)
