@@ -37,11 +37,12 @@ class ScatterMode(enum.IntEnum):
 # instead of 4.18, profiles/r03_overlap_probe.txt).  Ordering is kept with events: a side stream first waits for
 # everything the caller's stream holds at call time, and whoever reads the result next (``A.vals``, ``b.array``,
 # ``to_scipy`` ...) makes ITS stream wait for the event recorded at the end of the assembly -- the same deferral the
-# interface exchange uses.  Matrices take turns on MPCX_MATRIX_STREAMS (default 3) streams, one per object: the blocks
-# of a nest (a00, a01, a10 of python/src/dolfinx_mpc/assemble_matrix.py:140-146 are independent matrices) then run side
-# by side (Taylor-Hood 128^3: 9.00 -> 8.83 ms per step; the row-block kernels fill the LDS of every CU, so little of one
-# fits next to another -- launching the master-contribution kernel of a call on a stream of its own, next to its bulk
-# kernel, gained nothing and was removed).  MPCX_ASYNC_STREAMS=0 keeps everything on the caller's stream.
+# interface exchange uses.  Matrices take turns on MPCX_MATRIX_STREAMS streams, one per object.  Default 1 since round 4:
+# the blocks of a nest (a00, a01, a10 are independent matrices) gain nothing from running side by side (the row-block
+# kernels fill every CU: Taylor-Hood 128^3 7.58 / 7.54 / 7.51 ms per step with 3 / 2 / 1 streams), and a THIRD
+# high-priority stream turned out to share a hardware queue with the vector stream -- a matrix that landed on it lost
+# the matrix / vector overlap (slab of config 2: 0.78 instead of 0.53 ms per step; GPU_MAX_HW_QUEUES does not help).
+# MPCX_ASYNC_STREAMS=0 keeps everything on the caller's stream.
 # ---------------------------------------------------------------------------------------------------------
 _side = {}
 _next_slot = [0]
@@ -69,7 +70,7 @@ def side_stream(kind: str, obj):
         if slot is None:
             import os
 
-            slot = obj._side_slot = _next_slot[0] % max(int(os.environ.get("MPCX_MATRIX_STREAMS", 3)), 1)
+            slot = obj._side_slot = _next_slot[0] % max(int(os.environ.get("MPCX_MATRIX_STREAMS", 1)), 1)
             _next_slot[0] += 1
     key = (kind, obj.device.index, slot)
     if key not in _side:
