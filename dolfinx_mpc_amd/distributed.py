@@ -78,8 +78,14 @@ def create_box_slab(p0, p1, n, rank: int, world: int, axis: int = 2, reorder=Non
     owned_node = (node_plane >= l0) & ((node_plane < l1) | (last & (node_plane == l1)))
     owned_cube = cube_layer >= l0
     if reorder is not None:
-        tperm = _tile_permutation((nx1, ny1, nz1), reorder)  # old -> tile position
-        cperm = _tile_permutation((lx, ly, lz), reorder)
+        # the tiling starts at the first OWNED plane / cube layer: with the ghost layer below counted in, the owned nodes of a
+        # rank > 0 fell into tiles of 7 + 1 planes (448-row tiles, 273 clusters per row block: two 256-thread passes with 17
+        # lanes in the second)
+        shift = [0, 0, 0]
+        shift[axis] = l0 - c0
+        shift = tuple(shift)
+        tperm = _tile_permutation((nx1, ny1, nz1), reorder, shift)  # old -> tile position
+        cperm = _tile_permutation((lx, ly, lz), reorder, shift)
     else:
         tperm = np.arange(x.shape[0])
         cperm = np.arange(base.size)
@@ -96,7 +102,7 @@ def create_box_slab(p0, p1, n, rank: int, world: int, axis: int = 2, reorder=Non
         from .mesh import _tile_ids, _tile_starts
 
         # keep owned / ghost groups apart in the hint (ghost group gets its own tile ids)
-        tid = _tile_ids((nx1, ny1, nz1), reorder).astype(np.int64)
+        tid = _tile_ids((nx1, ny1, nz1), reorder, shift).astype(np.int64)
         tid = np.where(owned_node, tid, tid + tid.max() + 1)
         mesh.node_tile_offsets = _tile_starts(tid[order])
     mesh.num_owned_nodes = int(owned_node.sum())

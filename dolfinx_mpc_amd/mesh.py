@@ -156,14 +156,18 @@ class Mesh:
         return self._edges
 
 
-def _tile_permutation(n1: tuple, tile: tuple) -> np.ndarray:
+def _tile_permutation(n1: tuple, tile: tuple, shift: tuple = (0, 0, 0)) -> np.ndarray:
     """old node index -> new node index, numbering nodes tile by tile
-    (x fastest inside a tile, tiles x fastest)."""
+    (x fastest inside a tile, tiles x fastest).  ``shift``: grid index at which the tiling starts along every axis (the
+    first OWNED plane of a slab: the ghost planes below it form a thin tile layer of their own, so that the owned nodes
+    fall into whole tiles)."""
     nx1, ny1, nz1 = n1
     tx, ty, tz = tile
     k, j, i = np.meshgrid(np.arange(nz1), np.arange(ny1), np.arange(nx1), indexing="ij")
-    ntx, nty = -(-nx1 // tx), -(-ny1 // ty)
-    tid = ((k // tz) * nty + (j // ty)) * ntx + (i // tx)
+    i, j, k = i - shift[0], j - shift[1], k - shift[2]
+    o = [1 if sh > 0 else 0 for sh in shift]  # (the layer of the indices below the start)
+    ntx, nty = -(-(nx1 - shift[0]) // tx) + o[0], -(-(ny1 - shift[1]) // ty) + o[1]
+    tid = ((k // tz + o[2]) * nty + (j // ty + o[1])) * ntx + (i // tx + o[0])
     loc = ((k % tz) * ty + (j % ty)) * tx + (i % tx)
     key = tid.astype(np.int64) * (tx * ty * tz) + loc
     order = np.argsort(key.ravel(), kind="stable")  # new -> old
@@ -172,13 +176,15 @@ def _tile_permutation(n1: tuple, tile: tuple) -> np.ndarray:
     return perm  # old -> new
 
 
-def _tile_ids(n1: tuple, tile: tuple) -> np.ndarray:
-    """tile id of every node of the (nx1, ny1, nz1) grid, lexicographic node order"""
+def _tile_ids(n1: tuple, tile: tuple, shift: tuple = (0, 0, 0)) -> np.ndarray:
+    """tile id of every node of the (nx1, ny1, nz1) grid, lexicographic node order (``shift``: see _tile_permutation)"""
     nx1, ny1, nz1 = n1
     tx, ty, tz = tile
     k, j, i = np.meshgrid(np.arange(nz1), np.arange(ny1), np.arange(nx1), indexing="ij")
-    ntx, nty = -(-nx1 // tx), -(-ny1 // ty)
-    return (((k // tz) * nty + (j // ty)) * ntx + (i // tx)).ravel()
+    i, j, k = i - shift[0], j - shift[1], k - shift[2]
+    o = [1 if sh > 0 else 0 for sh in shift]
+    ntx, nty = -(-(nx1 - shift[0]) // tx) + o[0], -(-(ny1 - shift[1]) // ty) + o[1]
+    return (((k // tz + o[2]) * nty + (j // ty + o[1])) * ntx + (i // tx + o[0])).ravel()
 
 
 def _tile_starts(tid_new: np.ndarray) -> np.ndarray:
