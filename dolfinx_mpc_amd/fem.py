@@ -175,9 +175,26 @@ class FunctionSpace:
         n_on, n_nodes = mesh.num_owned_nodes, mesh.num_nodes
         n_oe = int(eo.sum())
         edge_new = np.empty(ev.shape[0], dtype=np.int64)
-        edge_new[eo] = n_on + np.arange(n_oe)
-        edge_new[~eo] = n_on + n_oe + (n_nodes - n_on) + np.arange(ev.shape[0] - n_oe)
         node_new = np.arange(n_nodes, dtype=np.int64)
+        if mesh.node_tile_offsets is not None:
+            # tiled numbering, as on an unpartitioned mesh: an owned edge dof is numbered next to its lowest OWNED end node,
+            # so that the owned dofs of a spatial tile form one contiguous range (without it the P2 kernels of a slab ran at
+            # half speed: 8.6 instead of 5.4 ms for the matrix of half of config 5)
+            lo, hi = np.minimum(ev[eo, 0], ev[eo, 1]).astype(np.int64), np.maximum(ev[eo, 0], ev[eo, 1]).astype(np.int64)
+            own_node = np.where(lo < n_on, lo, hi)  # (the end node in the owned planes; the lower index if both are)
+            assert (own_node < n_on).all()
+            owner = np.concatenate([np.arange(n_on, dtype=np.int64), own_node])
+            kind = np.concatenate([np.zeros(n_on, dtype=np.int8), np.ones(n_oe, dtype=np.int8)])
+            order = np.lexsort((kind, owner))  # old owned ids (nodes, then owned edges) in new order
+            pos = np.empty(order.size, dtype=np.int64)
+            pos[order] = np.arange(order.size)
+            node_new[:n_on] = pos[:n_on]
+            edge_new[eo] = pos[n_on:]
+            t_off = np.asarray(mesh.node_tile_offsets, dtype=np.int64)
+            self.dof_tile_offsets = np.where(t_off < n_on, node_new[np.minimum(t_off, n_on - 1)], t_off + n_oe)
+        else:
+            edge_new[eo] = n_on + np.arange(n_oe)
+        edge_new[~eo] = n_on + n_oe + (n_nodes - n_on) + np.arange(ev.shape[0] - n_oe)
         node_new[n_on:] += n_oe
         cell_dofs = np.concatenate([node_new[mesh.geometry.dofmap], edge_new[cell_edges]], axis=1)
         ntot = n_nodes + ev.shape[0]
