@@ -462,8 +462,7 @@ def launch_ranks(n: int) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # (defaults: long enough for the steady state -- the two library streams pipeline consecutive steps, so a run of 10 steps
-    # carries ~0.4 step of fill / drain: 3.53 ms per step against 3.39 with 50)
+    # (defaults: the first ~10 steps of a fresh process run slower -- 3.7 ms, then 3.45, then 3.39: tools/probes/warm_transient.py)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5])
