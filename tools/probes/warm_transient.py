@@ -17,11 +17,22 @@ def step():
     dm.assemble_matrix(f, (m0, m1), bcs=w.bcs, A=A)
     dm.assemble_vector(fv, mv, b=b)
 step(); torch.cuda.synchronize()
-out = []
+if os.environ.get("BUSY"):
+    # an unrelated load first: is the transient the device's (clocks) or the library's (first uses)?
+    z = torch.rand(8192, 8192, device="cuda")
+    for _ in range(int(os.environ["BUSY"])):
+        z = (z @ z).clamp_(0, 1)
+    torch.cuda.synchronize()
+out, host, mallocs = [], [], []
 for batch in range(10):
+    m0_ = torch.cuda.memory_stats().get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for _ in range(5):
         step()
+    th = time.perf_counter() - t0
     torch.cuda.synchronize()
     out.append(round((time.perf_counter() - t0) / 5 * 1e3, 3))
+    host.append(round(th / 5 * 1e3, 3))
+    mallocs.append(torch.cuda.memory_stats().get("num_device_alloc", 0) - m0_)
 print("ms per step, batches of 5:", out)
+print("host ms per step:", host, "device allocations per batch:", mallocs)
