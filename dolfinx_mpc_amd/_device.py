@@ -3,6 +3,8 @@ provider; the kernels only ever see raw pointers through the C ABI)."""
 
 from __future__ import annotations
 
+import os
+
 from collections import OrderedDict
 
 import numpy as np
@@ -128,6 +130,9 @@ def space_device(V: FunctionSpace):
 
 
 _ufcx_handles = {}
+# switches read by mpcx_ufcx_compile (csrc/mpcx_ufcx.cpp): part of the handle cache key
+_UFCX_COMPILE_ENV = ("MPCX_UFCX_FP", "MPCX_UFCX_LIBM", "MPCX_UFCX_CUBE_THREADS", "MPCX_UFCX_CUBE_PIPE", "MPCX_UFCX_CUBE_WAVES",
+                     "MPCX_UFCX_VCUBE_THREADS", "MPCX_UFCX_VCUBE_WAVES")
 
 
 def ufcx_compile(k, form: Form):
@@ -137,7 +142,8 @@ def ufcx_compile(k, form: Form):
     V1 = form.function_spaces[1] if form.rank == 2 else None
     nv = form.mesh.geometry.dofmap.shape[1]
     key = (k.ufcx_source, k.ufcx_name, form.rank, V0.element_ndofs, V0.dofmap.bs,
-           0 if V1 is None else V1.element_ndofs, 0 if V1 is None else V1.dofmap.bs, nv)
+           0 if V1 is None else V1.element_ndofs, 0 if V1 is None else V1.dofmap.bs, nv,
+           tuple(os.environ.get(e) for e in _UFCX_COMPILE_ENV))
     if key not in _ufcx_handles:
         d = _native.UfcxDescT(k.ufcx_source.encode(), k.ufcx_name.encode(), form.rank, V0.element_ndofs, V0.dofmap.bs,
                               0 if V1 is None else V1.element_ndofs, 0 if V1 is None else V1.dofmap.bs, nv)

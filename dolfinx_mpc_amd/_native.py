@@ -143,6 +143,7 @@ class MatrixArgs(C.Structure):
         ("pair_ctx", C.c_void_p),
         ("pair_dict", C.c_void_p),
         ("cube_rec_index", C.c_void_p),
+        ("cube_cells", C.c_void_p),
         ("stream", C.c_void_p),
     ]
 
@@ -180,6 +181,7 @@ class VectorArgs(C.Structure):
         ("own_rows", C.c_void_p),
         ("own_seg", C.c_void_p),
         ("n_own_rows", C.c_int64),
+        ("cube_cells", C.c_void_p),
         ("stream", C.c_void_p),
     ]
 
@@ -253,6 +255,7 @@ EXPORTS = [
     "mpcx_cluster_keys",
     "mpcx_cluster_build",
     "mpcx_cluster_canonical",
+    "mpcx_cluster_ordered",
     "mpcx_rowblock_pairs_device",
     "mpcx_hbm_probe",
     "mpcx_add_diagonal_scalar",
@@ -428,6 +431,8 @@ def lib() -> C.CDLL:
     L.mpcx_hex_slot_shapes.restype = C.c_int
     L.mpcx_cluster_canonical.argtypes = [i64, vp, vp, vp, vp]
     L.mpcx_cluster_canonical.restype = C.c_int
+    L.mpcx_cluster_ordered.argtypes = [i64, vp, vp, vp, vp, vp]
+    L.mpcx_cluster_ordered.restype = C.c_int
     L.mpcx_cell_shapes.argtypes = [i64, vp, vp, vp, vp]
     L.mpcx_cell_shapes.restype = C.c_int
     L.mpcx_p2_cluster_dofs.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp]

@@ -617,17 +617,27 @@ def _cube_eligible(form: Form, i: int, V0) -> bool:
             and not os.environ.get("MPCX_NO_CUBE"))
 
 
-def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc, hexa: bool = False, closed_form_only: bool = False):
+def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc, hexa: bool = False, closed_form_only: bool = False,
+               ordered: bool = False):
     """Row blocks over the mesh's cell clusters + one 96-byte record per (block, cluster) slot
     (mpcx_cube_records); cached per (form, constraint, Dirichlet markers).  Returns
     (plan struct, records tensor, keep-alive, info, leftover cells) or None when the mesh has no clusters.
-    ``hexa``: the clusters are the hexahedra themselves (their Q1 dofmap; every vertex pair coupled: mpcx_hex_records)."""
+    ``hexa``: the clusters are the hexahedra themselves (their Q1 dofmap; every vertex pair coupled: mpcx_hex_records).
+    ``ordered`` (imported kernels): only clusters whose cells the mesh lists in the cluster kernels' own vertex order
+    (clusters.mesh_clusters_ordered_device); every part then carries the cluster of each of its slots (block_ents) and the
+    keep-alive tuple ends with the clusters' cells (mpcx_matrix_args_t::cube_cells)."""
     import torch
 
-    from .clusters import mesh_clusters_device
+    from .clusters import mesh_clusters_device, mesh_clusters_ordered_device
 
     integ = form.integrals[i]
-    if hexa:
+    d_cells = None
+    if ordered:
+        d_verts, left, d_cells = mesh_clusters_ordered_device(form.mesh, integ.num_entities)
+        if d_verts.shape[0] == 0 or d_verts.shape[0] * 6 < 0.5 * integ.num_entities:
+            return None
+        max_rows_cfg, max_nnz_cfg = CUBE_MAX_ROWS, CUBE_MAX_NNZ
+    elif hexa:
         d_verts = D.space_device(V0)["dofmap"].view(-1, 8)[: integ.num_entities]
         left = np.zeros(0, dtype=np.int32)
         max_rows_cfg, max_nnz_cfg = HEX_MAX_ROWS, HEX_MAX_NNZ
@@ -693,7 +703,7 @@ def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc, hexa: bool = F
         # cell shape (row blocks all of whose clusters / hexahedra are parallelepipeds go to the kernel instance that
         # carries only the closed form of the integral: flag bit 0).  One part, one launch per kind that occurs.
         want_narrow = bs == 1 and not hexa and os.environ.get("MPCX_CUBE_NARROW", "1") != "0"
-        want_shape = bs == 1 and os.environ.get("MPCX_CUBE_SHAPES", os.environ.get("MPCX_HEX_SPLIT", "1")) != "0"
+        want_shape = bs == 1 and not ordered and os.environ.get("MPCX_CUBE_SHAPES", os.environ.get("MPCX_HEX_SPLIT", "1")) != "0"
         kind = torch.zeros(nb, dtype=torch.int64, device=dev)  # per block: bit 0 = a wide slot, bit 1 = a general cell
         slot_rec = d_ents.long() if per_cluster else None  # record of every slot
 
@@ -761,10 +771,14 @@ def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc, hexa: bool = F
                               "mpcx_cube_pack_narrow")
             else:
                 out = recs if src is None else recs.view(nslots, 96)[src].contiguous().view(-1)
-            parts.append((_native.RowBlockPlanT(nblk, max_rows, max_nnz, 0, d_row0.data_ptr(), off_c.data_ptr(), None, None, None),
-                          out, nbytes, ids, off_c, flags, ridx))
+            slot_cluster = None
+            if ordered:  # the cluster of every slot of this launch: forms with coefficients index cube_cells with it
+                slot_cluster = d_ents if src is None or src.numel() == nslots else d_ents[src].contiguous()
+            parts.append((_native.RowBlockPlanT(nblk, max_rows, max_nnz, 0, d_row0.data_ptr(), off_c.data_ptr(),
+                                                D.ptr(slot_cluster), None, None),
+                          out, nbytes, ids, off_c, flags, ridx, slot_cluster))
         del recs
-        keep = (d_row0, parts, d_verts)
+        keep = (d_row0, parts, d_verts, d_cells)
         info = {"num_blocks": nb, "num_ents": int(nslots), "max_rows": max_rows, "max_nnz": max_nnz, "clusters": int(nc),
                 "narrow_blocks": sum(int(p[0].num_blocks) for p in parts if p[2] == 64),
                 "closed_form_blocks": sum(int(p[0].num_blocks) for p in parts if p[5] == 1),
@@ -777,7 +791,7 @@ def _cube_plan(A: MPCMatrix, form: Form, i: int, V0, bc_dev, mpc, hexa: bool = F
     try:
         # (the split by cell shape depends on the coordinates -- a moved mesh gets a new plan)
         plan, keep, info = D.cached(A._plans, "cubes", (form, mpc, bc_dev),
-                                    (i, max_rows_cfg, max_nnz_cfg, hexa, closed_form_only, form.mesh.geometry.version), build)
+                                    (i, max_rows_cfg, max_nnz_cfg, hexa, closed_form_only, ordered, form.mesh.geometry.version), build)
     except _native.PlanNotRepresentable:
         return None
     return plan, keep, info, left
@@ -1132,17 +1146,19 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
                 A._compact_stale = False
                 keep += [ck]
                 return a, keep
-            if name in ("cube", "cube_el", "p2_cube"):
+            if name in ("cube", "cube_el", "p2_cube", "ufcx_cube"):
                 # cell clusters (MPCX_ALG_CUBE); None when the mesh has no clean six-tet fans or an offset overflows
                 if not allow_cubes:
                     cp = None
                 elif name == "p2_cube":
                     cp = _p2_cube_plan(A, form, i, V0, bc0, mpc0)
                 else:
-                    cp = _cube_plan(A, form, i, V0, bc0, mpc0, closed_form_only=(name == "cube_el"))
+                    cp = _cube_plan(A, form, i, V0, bc0, mpc0, closed_form_only=(name == "cube_el"), ordered=(name == "ufcx_cube"))
                 if cp is None:
                     continue
                 parts, ck, _info, left = cp
+                if name == "ufcx_cube" and integ.cstride > 0:
+                    a.cube_cells = ck[3].data_ptr()  # the cell of every cluster tet: index of its packed coefficients
                 a.algorithm = 3
                 a.leftover = left if left.size else None
                 a.kernel_name = name

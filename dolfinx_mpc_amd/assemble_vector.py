@@ -353,16 +353,23 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
             a.second = t if d_slaves.numel() > 0 else None
             keep += [pk, d_slaves, d_verts]
             return a, keep
-        if name in ("cube_own", "cube_hash"):
+        if name in ("cube_own", "cube_hash", "ufcx_cube_own"):
             # scalar P1 source over all cells: one thread per cell cluster (MPCX_ALG_CUBE, csrc/mpcx_cubes.hip); "auto" only
             if alg != 0 or not allow_cubes:
                 continue
-            from .clusters import mesh_clusters_device
+            from .clusters import mesh_clusters_device, mesh_clusters_ordered_device
 
-            d_verts, left = mesh_clusters_device(form.mesh, integ.num_entities)
+            if name == "ufcx_cube_own":
+                # imported kernel: only clusters whose cells the mesh lists in the cluster kernels' own vertex order
+                d_verts, left, d_cells = mesh_clusters_ordered_device(form.mesh, integ.num_entities)
+                if integ.cstride > 0:
+                    a.cube_cells = d_cells.data_ptr()
+                    keep += [d_cells]
+            else:
+                d_verts, left = mesh_clusters_device(form.mesh, integ.num_entities)
             if d_verts.shape[0] * 6 < 0.5 * integ.num_entities:
                 continue
-            if name == "cube_own":
+            if name in ("cube_own", "ufcx_cube_own"):
                 # owner-computes row blocks over the clusters: no hash table, no device atomics, deterministic
                 slave_h, _ = _slave_entities(form, i, constraint, constraint)
                 own = _vector_cube_owner_plan(form.mesh, V, d_verts, constraint, left, slave_h)

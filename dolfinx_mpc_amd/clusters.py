@@ -193,3 +193,37 @@ def mesh_clusters_device(mesh, ncells: int, parallelepipeds_only: bool = False, 
         return (verts, left, fan_cells) if with_cells else (verts, left)
 
     return D.cached(mesh._device, "fans_dev", (), (int(ncells), mesh.geometry.version, bool(parallelepipeds_only), bool(with_cells)), build, maxsize=3)
+
+
+def mesh_clusters_ordered_device(mesh, ncells: int):
+    """Clusters for IMPORTED element kernels: (cube_verts (n, 8), leftover cells (host int32, ascending), cluster cells
+    (n, 6) device int32).  An imported ``tabulate_tensor`` must see every cell with the vertex order the mesh lists
+    (a quadrature rule need not be symmetric), and the cluster kernels hand it tet t of a cluster as local vertices
+    (0,1,3,7) (0,1,7,5) (0,5,7,4) (0,3,2,7) (0,6,4,7) (0,2,6,7): a fan found from topology qualifies when some numbering of
+    its eight vertices makes its six cells read exactly so (``mpcx_cluster_ordered``; what a Kuhn box generator emits).
+    The others -- cells listed in another local order -- are returned among the leftover cells and keep the per-cell
+    kernels.  ``cluster cells[p][t]`` is the cell of table row t (the index of its packed coefficients)."""
+    import torch
+
+    from . import _device as D
+    from . import _native
+
+    def build():
+        verts, left, cells = mesh_clusters_device(mesh, ncells, with_cells=True)
+        n = int(verts.shape[0])
+        if n == 0:
+            return verts, left, torch.zeros((0, 6), dtype=torch.int32, device=verts.device)
+        md = D.mesh_device(mesh)
+        verts, cells = verts.clone(), cells.clone()
+        ok = torch.empty(n, dtype=torch.int8, device=verts.device)
+        _native.check(_native.lib().mpcx_cluster_ordered(n, verts.data_ptr(), cells.data_ptr(), md["x_dofmap"].data_ptr(),
+                                                         ok.data_ptr(), D.stream_ptr()), "mpcx_cluster_ordered")
+        nok = int(ok.sum(dtype=torch.int64).item())
+        if nok < n:
+            bad = cells[ok == 0].reshape(-1).cpu().numpy().astype(np.int32)
+            left = np.union1d(left, bad).astype(np.int32)
+            keep = torch.nonzero(ok).reshape(-1)
+            verts, cells = verts[keep].contiguous(), cells[keep].contiguous()
+        return verts, left, cells
+
+    return D.cached(mesh._device, "fans_ordered", (), (int(ncells), mesh.geometry.version), build, maxsize=2)

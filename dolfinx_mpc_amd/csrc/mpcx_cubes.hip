@@ -20,6 +20,8 @@
 #include <string>
 #include <type_traits>
 
+#include "mpcx_fan.hpp"
+
 namespace mpcx
 {
 namespace
@@ -27,87 +29,7 @@ namespace
 constexpr int MASK_SHIFT = 28;
 constexpr int DOF_MASK = (1 << MASK_SHIFT) - 1;
 
-// local vertices of the six tets of a fan (cube corner b: bit0 = x, bit1 = y, bit2 = z)
-__host__ __device__ constexpr int fan_vertex(int t, int i)
-{
-  constexpr int T[6][4] = {{0, 1, 3, 7}, {0, 1, 7, 5}, {0, 5, 7, 4}, {0, 3, 2, 7}, {0, 6, 4, 7}, {0, 2, 6, 7}};
-  return T[t][i];
-}
-// the fan walked round its shared edge: consecutive tets share a face
-__host__ __device__ constexpr int fan_order(int step)
-{
-  constexpr int O[6] = {0, 1, 2, 4, 5, 3};
-  return O[step];
-}
-// do local vertices a and b share a tet? (a == b counts)
-__host__ __device__ constexpr bool fan_coupled(int a, int b)
-{
-  for (int t = 0; t < 6; ++t)
-  {
-    bool ha = false, hb = false;
-    for (int i = 0; i < 4; ++i)
-    {
-      ha |= fan_vertex(t, i) == a;
-      hb |= fan_vertex(t, i) == b;
-    }
-    if (ha && hb)
-      return true;
-  }
-  return false;
-}
-
-// last step (in fan_order) whose tet holds both a and b; -1 if they share none
-__host__ __device__ constexpr int fan_last_step(int a, int b)
-{
-  int last = -1;
-  for (int s = 0; s < 6; ++s)
-  {
-    const int t = fan_order(s);
-    bool ha = false, hb = false;
-    for (int i = 0; i < 4; ++i)
-    {
-      ha |= fan_vertex(t, i) == a;
-      hb |= fan_vertex(t, i) == b;
-    }
-    if (ha && hb)
-      last = s;
-  }
-  return last;
-}
-
-struct __align__(16) CubeRec
-{
-  int32_t v[8];   // vertex (= dof) ids with the Dirichlet / slave mask in bit 28
-  uint8_t off[64]; // off[a*8+b]: position of column v[b] inside CSR row v[a] (coupled pairs only)
-};
-static_assert(sizeof(CubeRec) == 96, "record layout");
-
-// position of the coupled pair (a, b) among the 46 coupled pairs in row-major order, -1 if a and b share no tet
-__host__ __device__ constexpr int fan_pair_index(int a, int b)
-{
-  if (!fan_coupled(a, b))
-    return -1;
-  int n = 0;
-  for (int i = 0; i < 8; ++i)
-    for (int j = 0; j < 8; ++j)
-    {
-      if (i == a && j == b)
-        return n;
-      if (fan_coupled(i, j))
-        ++n;
-    }
-  return -1;
-}
-// Narrow record: rows of at most 16 entries before any of the cluster's columns (every interior row of a Kuhn mesh has
-// 15 entries) need 4 bits per offset: 8 ids + 46 nibbles = 55 bytes -> 64-byte records, four 16-byte loads per slot
-// instead of six and a third less plan memory.  Row blocks that hold a fat row (master rows of a constraint) keep the
-// 96-byte format; the two kinds are launched separately.
-struct __align__(16) CubeRecNarrow
-{
-  int32_t v[8];
-  uint8_t nib[32]; // nibble p = fan_pair_index(a, b): byte p / 2, low half for even p
-};
-static_assert(sizeof(CubeRecNarrow) == 64, "record layout");
+using namespace mpcx_fan; // fan_vertex, fan_order, fan_coupled, fan_last_step, fan_pair_index, CubeRec, CubeRecNarrow
 
 inline int check(hipError_t err, const char* what)
 {
@@ -886,6 +808,98 @@ __global__ void fan_canonical_kernel(int64_t n, int32_t* __restrict__ verts, con
   if (is_par(w))
     for (int i = 0; i < 8; ++i)
       verts[p * 8 + i] = w[i];
+}
+// Imported (UFCx) element kernels are called with a cell's vertices in the order the mesh lists them: a quadrature rule
+// need not be symmetric, so a permuted call is another approximation of the integral.  The cluster kernels built round an
+// imported function hand it the coordinates of tet t as local vertices fan_vertex(t, 0..3) of the cluster; that is the
+// mesh's own order exactly when the six cells read, in the cluster's numbering, as the rows of the table
+//     (0,1,3,7) (0,1,7,5) (0,5,7,4) (0,3,2,7) (0,6,4,7) (0,2,6,7)
+// (what a Kuhn box generator emits).  Given a fan found from topology (any numbering of its ring) and its six cells, this
+// kernel finds the one numbering under which they do -- vertex 0 is every cell's first vertex, the two cells with the other
+// shared vertex in third place are (0,1,7,5) and (0,5,7,4), the rest follows along the ring -- renumbers verts[p], orders
+// cells[p] by table row and sets ok[p]; fans whose cells are listed otherwise get ok[p] = 0 (their cells then go through the
+// per-cell kernels).
+__global__ void fan_ordered_kernel(int64_t n, int32_t* __restrict__ verts, int32_t* __restrict__ fan_cells,
+                                   const int32_t* __restrict__ x_dofmap, int8_t* __restrict__ ok)
+{
+  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= n)
+    return;
+  ok[p] = 0;
+  int32_t cell[6], c[6][4];
+  for (int t = 0; t < 6; ++t)
+  {
+    cell[t] = fan_cells[p * 6 + t];
+    for (int i = 0; i < 4; ++i)
+      c[t][i] = x_dofmap[int64_t(cell[t]) * 4 + i];
+  }
+  const int32_t v0 = c[0][0];
+  const int32_t a0 = verts[p * 8], a7 = verts[p * 8 + 7];
+  if (v0 != a0 && v0 != a7)
+    return;
+  const int32_t v7 = v0 == a0 ? a7 : a0;
+  // the two cells with v7 in third place
+  int third[2], n3 = 0;
+  for (int t = 0; t < 6; ++t)
+  {
+    if (c[t][0] != v0)
+      return;
+    if (c[t][2] == v7)
+    {
+      if (n3 < 2)
+        third[n3] = t;
+      ++n3;
+    }
+    else if (c[t][3] != v7)
+      return;
+  }
+  if (n3 != 2)
+    return;
+  int t1 = third[0], t2 = third[1]; // (0,1,7,5), (0,5,7,4): the first one's last vertex is the second one's second
+  if (c[t1][3] != c[t2][1])
+  {
+    const int s = t1;
+    t1 = t2, t2 = s;
+  }
+  if (c[t1][3] != c[t2][1])
+    return;
+  int32_t v[8];
+  v[0] = v0, v[7] = v7, v[1] = c[t1][1], v[5] = c[t1][3], v[4] = c[t2][3];
+  int row[6] = {-1, t1, t2, -1, -1, -1}; // cell of every table row
+  unsigned used = (1u << t1) | (1u << t2);
+  // (0,1,3,7) -> (0,3,2,7) -> (0,2,6,7) -> (0,6,4,7): each starts where the one before ended
+  const int chain_row[4] = {0, 3, 5, 4};
+  const int chain_new[4] = {3, 2, 6, 4};
+  int32_t cur = v[1];
+  for (int k = 0; k < 4; ++k)
+  {
+    int found = -1;
+    for (int t = 0; t < 6; ++t)
+      if (!((used >> t) & 1) && c[t][1] == cur && c[t][3] == v7)
+        found = t;
+    if (found < 0)
+      return;
+    used |= 1u << found;
+    row[chain_row[k]] = found;
+    if (k < 3)
+      v[chain_new[k]] = c[found][2];
+    else if (c[found][2] != v[4])
+      return;
+    cur = c[found][2];
+  }
+  for (int a = 0; a < 8; ++a)
+    for (int b = a + 1; b < 8; ++b)
+      if (v[a] == v[b])
+        return;
+  for (int t = 0; t < 6; ++t)
+    for (int i = 0; i < 4; ++i)
+      if (c[row[t]][i] != v[fan_vertex(t, i)])
+        return;
+  for (int i = 0; i < 8; ++i)
+    verts[p * 8 + i] = v[i];
+  for (int t = 0; t < 6; ++t)
+    fan_cells[p * 6 + t] = cell[row[t]];
+  ok[p] = 1;
 }
 __device__ inline void cross3(const double (&u)[3], const double (&v)[3], double (&w)[3])
 {
@@ -2511,4 +2525,13 @@ extern "C" int mpcx_cluster_canonical(int64_t n, int32_t* verts, const int8_t* o
   hipLaunchKernelGGL(mpcx::fan_canonical_kernel, dim3(mpcx::grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n,
                      verts, ok, x);
   return mpcx::check(hipGetLastError(), "cluster_canonical launch");
+}
+
+extern "C" int mpcx_cluster_ordered(int64_t n, int32_t* verts, int32_t* fan_cells, const int32_t* x_dofmap, int8_t* ok, void* stream)
+{
+  if (n == 0)
+    return 0;
+  hipLaunchKernelGGL(mpcx::fan_ordered_kernel, dim3(mpcx::grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n,
+                     verts, fan_cells, x_dofmap, ok);
+  return mpcx::check(hipGetLastError(), "cluster_ordered launch");
 }

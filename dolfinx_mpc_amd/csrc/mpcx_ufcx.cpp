@@ -35,6 +35,11 @@ const char* const MPCX_UFCX_MATH_TEXT =
 #include "mpcx_ufcx_math_embed.inc"
     ;
 
+// csrc/mpcx_fan.hpp as text: the six-tet cluster tables and record formats of the cluster kernels
+const char* const MPCX_FAN_TEXT =
+#include "mpcx_fan_embed.inc"
+    ;
+
 const char* const KERNELS_TEXT = R"MPCXK(
 #define N0 (ND0 * BS0)
 #define N1 (ND1 * BS1)
@@ -677,6 +682,307 @@ extern "C" __global__ void __launch_bounds__(64) ufcx_vector_mpc_kernel(mpcx_vec
 #endif
 )MPCXR";
 
+const char* const CUBE_KERNELS_TEXT = R"MPCXC(
+// ---------------------------------------------------------------------------------------------------------
+// The imported tabulate_tensor inside the CLUSTER kernels (csrc/mpcx_cubes.hip matrix_cube_kernel /
+// vector_cube_own_kernel; scalar P1 on tetrahedra): one thread takes the six tets round a shared edge, calls the
+// imported function once per tet with that tet's coordinates in the mesh's own vertex order (the caller vouches for
+// it: mpcx_cluster_ordered), sums the six tensors per vertex pair in registers and scatters 46 values per cluster
+// instead of 96 (vectors: 8 instead of 24).  Nothing is assumed about the function: no symmetry, no closed form;
+// coefficients are taken per cell through cube_cells.  The loop being replaced: cpp/assemble_matrix.cpp:488-547,
+// cpp/assemble_vector.cpp:65-90.
+// ---------------------------------------------------------------------------------------------------------
+#if UFCX_CUBE
+using namespace mpcx_fan;
+#if UFCX_RANK == 2
+template <bool NARROW>
+__device__ __attribute__((always_inline)) inline void ufcx_matrix_cube_body(const mpcx_matrix_args_t& a, unsigned char* smem)
+{
+  const int NT = blockDim.x;
+  const int nb = a.plan.num_blocks;
+  const int per = (nb + 7) >> 3;
+  const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3); // contiguous runs of row blocks per XCD
+  if (b >= nb)
+    return;
+  const int tid = threadIdx.x;
+  const int bb = a.cube_block_ids ? a.cube_block_ids[b] : b;
+  const int r0 = a.plan.block_row0[bb], r1 = a.plan.block_row0[bb + 1];
+  const int nrow = r1 - r0;
+  const long long nnz0 = a.rowptr[r0];
+  const int nnzb = (int)(a.rowptr[r1] - nnz0);
+  double* s_vals = (double*)smem;
+  int* s_rowlo = (int*)(s_vals + a.plan.max_nnz);
+  constexpr int NW = NARROW ? 4 : 6; // 16-byte words per record
+  const uint4* __restrict__ recs = (const uint4*)a.cube_recs;
+  const long long e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  const int* __restrict__ ridx = a.cube_rec_index;
+  const bool has_w = a.coeffs != (const double*)0; // (uniform: forms with coefficients read the cells of their cluster)
+  auto load = [&](long long t, uint4 (&w)[NW])
+  {
+    const uint4* p = recs + (ridx ? (long long)ridx[t] : t) * NW;
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+      w[i] = p[i];
+  };
+  auto offset_of = [&](const uint4 (&w)[NW], int i, int j) -> int
+  {
+    unsigned ow[4 * (NW - 2)];
+#pragma unroll
+    for (int q = 0; q < NW - 2; ++q)
+    {
+      ow[4 * q] = w[2 + q].x, ow[4 * q + 1] = w[2 + q].y, ow[4 * q + 2] = w[2 + q].z, ow[4 * q + 3] = w[2 + q].w;
+    }
+    if constexpr (NARROW)
+    {
+      const int p = fan_pair_index(i, j);
+      return (int)((ow[p >> 3] >> (4 * (p & 7))) & 0xf);
+    }
+    else
+      return (int)((ow[(i * 8 + j) >> 2] >> (8 * ((i * 8 + j) & 3))) & 0xff);
+  };
+  auto gather8 = [&](const uint4 (&w)[NW], double (&X)[8][3])
+  {
+    const int v[8] = {(int)w[0].x, (int)w[0].y, (int)w[0].z, (int)w[0].w, (int)w[1].x, (int)w[1].y, (int)w[1].z, (int)w[1].w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+    {
+      const long long n = v[i] & DOF_MASK;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        X[i][k] = a.x[3 * n + k];
+    }
+  };
+  // software pipeline as in matrix_cube_kernel: the coordinates of slot t + NT and the record of slot t + 2 NT travel
+  // while slot t is computed
+  uint4 cur[NW];
+  double X[8][3];
+#if UFCX_CUBE_PIPE
+  uint4 nxt[NW];
+  double Xn[8][3];
+#endif
+  long long t = e0 + tid;
+  if (t < e1)
+  {
+    load(t, cur);
+#if UFCX_CUBE_PIPE
+    if (t + NT < e1)
+      load(t + NT, nxt);
+    gather8(cur, X);
+#endif
+  }
+  for (int i = tid; i < nnzb; i += NT)
+    s_vals[i] = 0.0;
+  for (int rl = tid; rl < nrow; rl += NT)
+    s_rowlo[rl] = (int)(a.rowptr[r0 + rl] - nnz0);
+  __syncthreads();
+  for (; t < e1; t += NT)
+  {
+    const int v[8] = {(int)cur[0].x, (int)cur[0].y, (int)cur[0].z, (int)cur[0].w,
+                      (int)cur[1].x, (int)cur[1].y, (int)cur[1].z, (int)cur[1].w};
+    const bool has_next = t + NT < e1;
+#if UFCX_CUBE_PIPE
+    if (has_next)
+      gather8(nxt, Xn);
+#else
+    // no software pipeline (imported functions are heavy: the registers go to occupancy instead): the record of the next
+    // slot travels across the arithmetic, the coordinate round trip is covered by the other waves of the SIMD
+    gather8(cur, X);
+    uint4 nxt[NW];
+    if (has_next)
+      load(t + NT, nxt);
+#endif
+    int cells[6] = {0, 0, 0, 0, 0, 0};
+    if (has_w)
+    {
+      const int* pc = a.cube_cells + 6ll * a.plan.block_ents[t];
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+        cells[q] = pc[q];
+    }
+    int base[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+    {
+      const int r = v[i] & DOF_MASK;
+      const bool mine = r >= r0 && r < r1 && !(v[i] >> MASK_SHIFT);
+      base[i] = mine ? s_rowlo[mine ? r - r0 : 0] : -1;
+    }
+    // the six tensors summed per ORDERED vertex pair (static indices: registers); a pair is scattered as soon as its
+    // last tet is done
+    double A[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        A[i][j] = 0.0;
+#pragma unroll
+    for (int step = 0; step < 6; ++step)
+    {
+      const int tet = fan_order(step);
+      double cd[12];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          cd[3 * i + k] = X[fan_vertex(tet, i)][k];
+      double Ae[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        Ae[i] = 0.0;
+      {
+        const int lf = 0;
+        const unsigned char perm = 0;
+        UFCX_FN(Ae, has_w ? a.coeffs + (long long)cells[tet] * a.cstride : (const double*)0, a.constants, cd, &lf, &perm, (void*)0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          A[fan_vertex(tet, i)][fan_vertex(tet, j)] += Ae[4 * i + j];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+        {
+          if (fan_last_step(i, j) != step)
+            continue;
+          if (base[i] >= 0 && !(v[j] >> MASK_SHIFT))
+            __hip_atomic_fetch_add(s_vals + base[i] + offset_of(cur, i, j), A[i][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    if (has_next)
+    {
+#pragma unroll
+      for (int i = 0; i < NW; ++i)
+        cur[i] = nxt[i];
+#if UFCX_CUBE_PIPE
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          X[i][k] = Xn[i][k];
+      if (t + 2 * NT < e1)
+        load(t + 2 * NT, nxt);
+#endif
+    }
+  }
+  __syncthreads();
+  if (a.store_mode)
+    for (int i = tid; i < nnzb; i += NT)
+      a.vals[nnz0 + i] = s_vals[i];
+  else
+    for (int i = tid; i < nnzb; i += NT)
+      a.vals[nnz0 + i] += s_vals[i];
+}
+#if UFCX_CUBE_WAVES
+#define UFCX_CUBE_OCC __attribute__((amdgpu_waves_per_eu(UFCX_CUBE_WAVES)))
+#else
+#define UFCX_CUBE_OCC
+#endif
+extern "C" __global__ void __launch_bounds__(UFCX_CUBE_THREADS) UFCX_CUBE_OCC ufcx_matrix_cube_wide_kernel(mpcx_matrix_args_t a)
+{
+  extern __shared__ __align__(16) unsigned char smem[];
+  ufcx_matrix_cube_body<false>(a, smem);
+}
+extern "C" __global__ void __launch_bounds__(UFCX_CUBE_THREADS) UFCX_CUBE_OCC ufcx_matrix_cube_narrow_kernel(mpcx_matrix_args_t a)
+{
+  extern __shared__ __align__(16) unsigned char smem[];
+  ufcx_matrix_cube_body<true>(a, smem);
+}
+#else
+// owner-computes row blocks over the clusters (the plan of vector_cube_own_kernel: plan.block_ents = the clusters a
+// block owns, own_lmap = LDS position of every cluster vertex with the slave flag in bit 28)
+#if UFCX_VCUBE_WAVES
+#define UFCX_VCUBE_OCC __attribute__((amdgpu_waves_per_eu(UFCX_VCUBE_WAVES)))
+#else
+#define UFCX_VCUBE_OCC
+#endif
+extern "C" __global__ void __launch_bounds__(UFCX_VCUBE_THREADS) UFCX_VCUBE_OCC ufcx_vector_cube_own_kernel(mpcx_vector_args_t a)
+{
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* s_b = (double*)smem;
+  const int NT = blockDim.x;
+  const int nb = a.plan.num_blocks;
+  const int per = (nb + 7) >> 3;
+  const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (b >= nb)
+    return;
+  const int tid = threadIdx.x;
+  const int r0 = a.plan.block_row0[b], r1 = a.plan.block_row0[b + 1];
+  const long long h0 = a.own_hoff[b], h1 = a.own_hoff[b + 1];
+  const int nown = r1 - r0, nhalo = (int)(h1 - h0);
+  for (int i = tid; i < nown + nhalo; i += NT)
+    s_b[i] = 0.0;
+  __syncthreads();
+  const bool has_w = a.coeffs != (const double*)0;
+  const long long e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  const int* __restrict__ ents = a.plan.block_ents;
+  for (long long t = e0 + tid; t < e1; t += NT)
+  {
+    const long long c = ents[t];
+    int v[8];
+    {
+      const uint4* p = (const uint4*)(a.cube_verts + c * 8);
+      const uint4 w0 = p[0], w1 = p[1];
+      v[0] = w0.x, v[1] = w0.y, v[2] = w0.z, v[3] = w0.w, v[4] = w1.x, v[5] = w1.y, v[6] = w1.z, v[7] = w1.w;
+    }
+    int cells[6] = {0, 0, 0, 0, 0, 0};
+    if (has_w)
+    {
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+        cells[q] = a.cube_cells[6 * c + q];
+    }
+    double X[8][3];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        X[i][k] = a.x[3 * (long long)v[i] + k];
+    double be8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      be8[i] = 0.0;
+#pragma unroll
+    for (int tet = 0; tet < 6; ++tet)
+    {
+      double cd[12];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          cd[3 * i + k] = X[fan_vertex(tet, i)][k];
+      double be[4] = {0.0, 0.0, 0.0, 0.0};
+      {
+        const int lf = 0;
+        const unsigned char perm = 0;
+        UFCX_FN(be, has_w ? a.coeffs + (long long)cells[tet] * a.cstride : (const double*)0, a.constants, cd, &lf, &perm, (void*)0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        be8[fan_vertex(tet, i)] += be[i];
+    }
+    int w[8];
+    {
+      const uint4* p = (const uint4*)(a.own_lmap + c * 8);
+      const uint4 w0 = p[0], w1 = p[1];
+      w[0] = w0.x, w[1] = w0.y, w[2] = w0.z, w[3] = w0.w, w[4] = w1.x, w[5] = w1.y, w[6] = w1.z, w[7] = w1.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (!(w[i] >> MASK_SHIFT))
+        __hip_atomic_fetch_add(s_b + (w[i] & DOF_MASK), be8[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __syncthreads();
+  for (int i = tid; i < nown; i += NT)
+    a.b[r0 + i] += s_b[i];
+  for (int i = tid; i < nhalo; i += NT)
+    a.own_spill[h0 + i] = s_b[nown + i];
+}
+#endif
+#endif // UFCX_CUBE
+)MPCXC";
+
 struct Rtc
 {
   void* lib = nullptr;
@@ -722,6 +1028,10 @@ struct UfcxKernel
   hipFunction_t matrix = nullptr, matrix_mpc = nullptr, lifting = nullptr, vector = nullptr;
   hipFunction_t matrix_rowblock = nullptr, matrix_mpc_plan = nullptr, vector_rowblock = nullptr, vector_mpc = nullptr;
   hipFunction_t slave_tensors = nullptr, matrix_mpc_gather = nullptr;
+  // scalar P1 on tetrahedra: the cluster kernels (MPCX_ALG_CUBE)
+  bool cube = false;
+  hipFunction_t matrix_cube_wide = nullptr, matrix_cube_narrow = nullptr, vector_cube_own = nullptr;
+  int cube_threads = 256;
   int rb_threads = 256; // threads per workgroup of the row-block kernels (their launch bound)
   // element tensors beyond UFCX_BIG_ENTRIES doubles: per-entity kernels only, the tensor of a thread lives in a slab of a
   // global scratch array (one per kernel, so that the matrix and the lifting call of a step may overlap on two streams)
@@ -790,8 +1100,18 @@ int ensure_loaded(UfcxKernel* k)
       return rc;
     if (int rc = get(&k->matrix_mpc_gather, "ufcx_matrix_mpc_gather_kernel"))
       return rc;
+    if (k->cube)
+    {
+      if (int rc = get(&k->matrix_cube_wide, "ufcx_matrix_cube_wide_kernel"))
+        return rc;
+      if (int rc = get(&k->matrix_cube_narrow, "ufcx_matrix_cube_narrow_kernel"))
+        return rc;
+    }
     return get(&k->lifting, "ufcx_lifting_kernel");
   }
+  if (k->cube)
+    if (int rc = get(&k->vector_cube_own, "ufcx_vector_cube_own_kernel"))
+      return rc;
   if (int rc = get(&k->vector_rowblock, "ufcx_vector_rowblock_kernel"))
     return rc;
   if (int rc = get(&k->vector_mpc, "ufcx_vector_mpc_kernel"))
@@ -950,12 +1270,55 @@ extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
   }
   src += "\n#pragma clang force_cuda_host_device begin\n";
   src += "#pragma clang attribute push(__attribute__((always_inline)), apply_to = function)\n";
+  // Floating-point semantics of the imported text, MPCX_UFCX_FP (the counterpart of the cffi_extra_compile_args a dolfinx user
+  // hands FFCx's JIT; rounding of every operation stays IEEE in all modes but "fast"):
+  //   strict      nothing relaxed (cc -O2)
+  //   reciprocal  x / y may be evaluated as x * (1 / y): one reciprocal for the nine entries of an inverse Jacobian
+  //               K = adj(J) / detJ, a multiplication for ``/ 0.02`` -- <= 1 ulp more per division; an IEEE fp64 division is a
+  //               13-instruction sequence on gfx950 and FFCx text divides per cell and per point
+  //   finite      (default) reciprocal + the values are assumed finite and the sign of a zero not to matter
+  //               (-ffinite-math-only -fno-signed-zeros): products with the exact zeros and ones of baked tables fold away
+  //               (``K[d][a] * 0.0`` may not under strict semantics: it is NaN for an infinite K); no reassociation, the
+  //               result of every surviving operation is the strict one.  Config 2's imported stiffness kernel: 1204 -> 849
+  //               VALU instructions per cluster
+  //   fast        finite + reassociation (cc -Ofast)
+  const char* fpmode = std::getenv("MPCX_UFCX_FP");
+  const std::string fp = fpmode ? fpmode : "finite";
+  if (fp == "reciprocal" || fp == "finite")
+    src += "#pragma clang fp reciprocal(on)\n";
+  else if (fp == "fast") // + reassociation, and (compile options below) no NaN / infinity / signed-zero semantics: what -ffast-math
+    src += "#pragma clang fp reciprocal(on) reassociate(on)\n"; // gives an FFCx kernel built with cffi_extra_compile_args=["-Ofast"]
   src += user;
   src += "\n#undef sin\n#undef cos\n#undef exp\n";
   src += "\n#pragma clang attribute pop\n";
   src += "#pragma clang force_cuda_host_device end\n";
   src += KERNELS_TEXT;
   src += ROWBLOCK_KERNELS_TEXT;
+  // scalar P1 on tetrahedra (P1 x P1 for bilinear forms): the cluster kernels as well
+  const bool cube = d->nv == 4 && d->nd0 == 4 && d->bs0 == 1 && (d->rank == 1 || (d->nd1 == 4 && d->bs1 == 1));
+  if (cube)
+  {
+    std::string f(MPCX_FAN_TEXT);
+    if (auto q = f.find("#pragma once"); q != std::string::npos)
+      f.replace(q, 12, "");
+    src += f;
+    src += CUBE_KERNELS_TEXT;
+  }
+  // threads per workgroup / software pipeline / occupancy target of the cluster kernels (experiments: MPCX_UFCX_CUBE_THREADS,
+  // MPCX_UFCX_CUBE_PIPE, MPCX_UFCX_CUBE_WAVES for the matrix kernel, MPCX_UFCX_VCUBE_THREADS / _WAVES for the vector kernel)
+  auto env_int = [](const char* name, int dflt)
+  {
+    const char* e = std::getenv(name);
+    return e ? std::atoi(e) : dflt;
+  };
+  int cube_threads = env_int("MPCX_UFCX_CUBE_THREADS", 256);
+  if (cube_threads < 64 || cube_threads > 1024 || cube_threads % 64)
+    cube_threads = 256;
+  int vcube_threads = env_int("MPCX_UFCX_VCUBE_THREADS", 256);
+  if (vcube_threads < 64 || vcube_threads > 1024 || vcube_threads % 64)
+    vcube_threads = 256;
+  const int cube_pipe = env_int("MPCX_UFCX_CUBE_PIPE", 0);
+  const int cube_waves = env_int("MPCX_UFCX_CUBE_WAVES", 0), vcube_waves = env_int("MPCX_UFCX_VCUBE_WAVES", 0);
   // element tensors up to 36 entries (P1 scalar, P1 x P1 on triangles / tets, bs <= ...): 512 threads, 128 VGPRs;
   // up to 144 entries: fully unrolled at 256 threads (256 VGPRs); larger ones stay rolled in private memory
   const int size = d->rank == 2 ? d->nd0 * d->bs0 * d->nd1 * d->bs1 : d->nd0 * d->bs0;
@@ -967,11 +1330,21 @@ extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
          "-DUFCX_RB_THREADS=" + std::to_string(rb_threads), "-DUFCX_SMALL=" + std::to_string(small),
          "-DUFCX_RANK=" + std::to_string(d->rank), "-DND0=" + std::to_string(d->nd0), "-DBS0=" + std::to_string(d->bs0),
          "-DND1=" + std::to_string(d->rank == 2 ? d->nd1 : 1), "-DBS1=" + std::to_string(d->rank == 2 ? d->bs1 : 1),
-         "-DNV=" + std::to_string(d->nv)};
+         "-DNV=" + std::to_string(d->nv), "-DUFCX_CUBE=" + std::to_string(cube ? 1 : 0),
+         "-DUFCX_CUBE_THREADS=" + std::to_string(cube_threads), "-DUFCX_CUBE_PIPE=" + std::to_string(cube_pipe),
+         "-DUFCX_CUBE_WAVES=" + std::to_string(cube_waves), "-DUFCX_VCUBE_WAVES=" + std::to_string(vcube_waves),
+         "-DUFCX_VCUBE_THREADS=" + std::to_string(vcube_threads)};
+  if (fp == "fast" || fp == "finite")
+  {
+    opts.push_back("-fno-signed-zeros");
+    opts.push_back("-ffinite-math-only");
+  }
   auto make_handle = [&]()
   {
     auto* k = new UfcxKernel;
     k->rb_threads = rb_threads;
+    k->cube = cube && !big;
+    k->cube_threads = d->rank == 2 ? cube_threads : vcube_threads;
     k->big = big != 0;
     k->desc = *d;
     k->desc.source = nullptr;
@@ -1063,9 +1436,10 @@ int launch_matrix_ufcx(const mpcx_matrix_args_t& a)
     mpcx_set_error("mpcx_assemble_matrix: the imported kernel was compiled for other element shapes (or is not bilinear)");
     return -12;
   }
-  if (a.algorithm == MPCX_ALG_CUBE)
+  if (a.algorithm == MPCX_ALG_CUBE && !k->cube)
   {
-    mpcx_set_error("mpcx_assemble_matrix: imported (UFCx) kernels are assembled with MPCX_ALG_ROWBLOCK or MPCX_ALG_ATOMIC");
+    mpcx_set_error("mpcx_assemble_matrix: imported (UFCx) kernels take MPCX_ALG_CUBE for scalar P1 forms on tetrahedra only "
+                   "(nd0 = nd1 = nv = 4, bs = 1); MPCX_ALG_ROWBLOCK or MPCX_ALG_ATOMIC otherwise");
     return -3;
   }
   if (int rc = ensure_loaded(k))
@@ -1085,7 +1459,33 @@ int launch_matrix_ufcx(const mpcx_matrix_args_t& a)
       return rc;
     return launch(k->matrix_mpc, a.n_slave_entities, a, a.stream, k->scratch_threads);
   }
-  if (alg == MPCX_ALG_ROWBLOCK && a.n_entities > 0)
+  if (alg == MPCX_ALG_CUBE)
+  {
+    // the six tets of a cluster through the imported function, 46 scatter-adds per cluster (include/mpcx.h cube_cells)
+    if (a.estride != 1 || a.plan.num_blocks <= 0 || !a.plan.block_row0 || !a.plan.block_ent_off
+        || (a.cube_rec_bytes != 0 && a.cube_rec_bytes != 64 && a.cube_rec_bytes != 96))
+    {
+      mpcx_set_error("mpcx_assemble_matrix (UFCx, clusters): needs a row-block plan over the cluster slots and their records "
+                     "(mpcx_cube_records; cube_rec_bytes 96 or 64), cell integrals only");
+      return -3;
+    }
+    if (a.coeffs && (!a.cube_cells || !a.plan.block_ents))
+    {
+      mpcx_set_error("mpcx_assemble_matrix (UFCx, clusters): a form with coefficients needs cube_cells and plan.block_ents "
+                     "(the cluster of every slot)");
+      return -5;
+    }
+    const size_t lds = size_t(a.plan.max_nnz) * 8 + size_t(a.plan.max_rows) * 4;
+    if (lds > 160 * 1024)
+    {
+      mpcx_set_error("mpcx_assemble_matrix: row-block plan exceeds 160 KiB of LDS");
+      return -4;
+    }
+    if (int rc = launch_blocks(a.cube_rec_bytes == 64 ? k->matrix_cube_narrow : k->matrix_cube_wide, a.plan.num_blocks,
+                               k->cube_threads, lds, a, a.stream))
+      return rc;
+  }
+  else if (alg == MPCX_ALG_ROWBLOCK && a.n_entities > 0)
   {
     if (a.plan.num_blocks <= 0 || !a.mdofmap0 || !a.mdofmap1 || !a.plan.ent_offs || a.plan.row_pairs || a.plan.ent_pattern
         || a.lean || a.slot_mask)
@@ -1133,6 +1533,37 @@ int launch_vector_ufcx(const mpcx_vector_args_t& a)
   int alg = a.algorithm;
   if (alg == MPCX_ALG_AUTO)
     alg = a.plan.num_blocks > 0 ? MPCX_ALG_ROWBLOCK : MPCX_ALG_ATOMIC;
+  if (alg == MPCX_ALG_CUBE)
+  {
+    // one thread per cluster, owner-computes row blocks (the plan of vector_cube_own_kernel), six calls of the imported
+    // function per cluster; then the halo rows and the rows of slave dofs (ufcx_vector_mpc_kernel over slave_entities)
+    if (!k->cube)
+    {
+      mpcx_set_error("mpcx_assemble_vector: imported (UFCx) kernels take MPCX_ALG_CUBE for scalar P1 forms on tetrahedra only");
+      return -3;
+    }
+    if (a.n_cubes == 0)
+      return launch(k->vector_mpc, a.n_slave_entities, a, a.stream);
+    if (!a.cube_verts || !a.own_lmap || a.plan.num_blocks <= 0 || !a.plan.block_ents || !a.own_hoff || !a.own_spill || !a.own_seg
+        || (a.n_own_rows > 0 && (!a.own_rows || !a.own_src)) || (a.coeffs && !a.cube_cells))
+    {
+      mpcx_set_error("mpcx_assemble_vector (UFCx, clusters): needs cube_verts and the owner-computes plan over the clusters "
+                     "(own_lmap ...), and cube_cells for a form with coefficients");
+      return -5;
+    }
+    const size_t lds = size_t(a.plan.max_rows) * 8;
+    if (lds > 96 * 1024)
+    {
+      mpcx_set_error("mpcx_assemble_vector: cluster owner plan exceeds the LDS budget");
+      return -4;
+    }
+    if (int rc = launch_blocks(k->vector_cube_own, a.plan.num_blocks, k->cube_threads, lds, a, a.stream))
+      return rc;
+    if (a.n_own_rows > 0)
+      if (int rc = launch_vector_spill_reduce(a, 1))
+        return rc;
+    return launch(k->vector_mpc, a.n_slave_entities, a, a.stream);
+  }
   if (alg == MPCX_ALG_ROWBLOCK && a.n_entities > 0)
   {
     const bool owner = a.own_lmap != nullptr;

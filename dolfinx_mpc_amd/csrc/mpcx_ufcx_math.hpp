@@ -7,7 +7,9 @@
 //   mpcx_fast_sin / mpcx_fast_cos   |x| <= 2^19 pi: <= 2 ulp (Cody-Waite reduction to [-pi/2, pi/2] with a three-part
 //                                   pi/2, odd Taylor polynomial of degree 21); beyond: libm
 //   mpcx_fast_exp                   -708 <= x <= 709: <= 2 ulp (x = n ln2 + r, |r| <= ln2 / 2, Taylor degree 13, ldexp);
-//                                   beyond (underflow into the denormals, overflow), NaN: libm
+//                                   beyond (underflow into the denormals, overflow), NaN: libm.  (A 64-entry 2^(j/64) table
+//                                   with a degree-5 polynomial saves 7 of the 21 instructions but its per-lane table load
+//                                   stalls the in-order wave: config 2's imported right-hand side 3.45 -> 3.80 ms; not kept)
 // No includes, builtins only: the same text compiles under hipRTC (device) and g++ (host test).
 #pragma once
 // the libm functions the slow paths fall back to (hipRTC: the device library's entry points)
@@ -32,9 +34,9 @@
     /* 0..9: sin Taylor, -1/21! .. 1/3! (alternating) */                                                               \
     -1.9572941063391263e-20, 8.2206352466243295e-18, -2.8114572543455206e-15, 7.6471637318198164e-13,                  \
         -1.6059043836821613e-10, 2.5052108385441720e-08, -2.7557319223985893e-06, 1.9841269841269841e-04,              \
-        -8.3333333333333332e-03, 1.6666666666666666e-01, /* 10..12: pi/2 in three parts; 13: 1/pi; 14: 2^19 pi */      \
-        1.57079632673412561417e+00, 6.07710050630396597660e-11, 2.02226624879595063154e-21, 3.18309886183790671538e-01, \
-        1647099.0, /* 15: 1/ln2; 16, 17: ln2 in two parts; 18..29: exp Taylor 1/13! .. 1/2! */                          \
+        -8.3333333333333332e-03, 1.6666666666666666e-01, /* 10..12: pi in three parts; 13: 1/pi; 14: 2^19 pi */           \
+        2.0 * 1.57079632673412561417e+00, 2.0 * 6.07710050630396597660e-11, 2.0 * 2.02226624879595063154e-21,           \
+        3.18309886183790671538e-01, 1647099.0, /* 15: 1/ln2; 16, 17: ln2 in two parts; 18..29: exp Taylor 1/13! .. 1/2! */ \
         1.44269504088896338700e+00, 6.93147180369123816490e-01, 1.90821492927058770002e-10, 1.6059043836821613e-10,     \
         2.0876756987868099e-09, 2.5052108385441720e-08, 2.7557319223985888e-07, 2.7557319223985893e-06,                 \
         2.4801587301587302e-05, 1.9841269841269841e-04, 1.3888888888888889e-03, 8.3333333333333332e-03,                 \
@@ -73,7 +75,7 @@ MPCX_UFCX_MATH_FN double mpcx_fm_sin_poly(double r)
   return __builtin_fma(-(r * r2), p, r);
 }
 
-// x - m * pi/2, pi/2 in three parts of 33 + 33 + 53 bits (fdlibm's pio2_1, pio2_2, pio2_3): m * part is exact for |m| < 2^20
+// x - m * pi, pi in three parts of 33 + 33 + 53 bits (twice fdlibm's pio2_1, pio2_2, pio2_3): m * part is exact for |2 m| < 2^20
 MPCX_UFCX_MATH_FN double mpcx_fm_reduce(double x, double m)
 {
   double r = __builtin_fma(-m, MPCX_FM_K(10), x);
@@ -87,7 +89,7 @@ MPCX_UFCX_MATH_FN double mpcx_fast_sin(double x)
   if (!(__builtin_fabs(x) <= MPCX_FM_K(14))) // beyond 2^19 pi, inf, NaN
     return MPCX_FM_LIBM_SIN(x);
   const double n = __builtin_rint(x * MPCX_FM_K(13)); // x / pi
-  const double r = mpcx_fm_reduce(x, n + n);
+  const double r = mpcx_fm_reduce(x, n);
   return mpcx_fm_flip(mpcx_fm_sin_poly(r), (int)n);
 }
 
@@ -97,7 +99,7 @@ MPCX_UFCX_MATH_FN double mpcx_fast_cos(double x)
     return MPCX_FM_LIBM_COS(x);
   // x = (n + 1/2) pi + r:  cos(x) = (-1)^(n+1) sin(r)
   const double n = __builtin_rint(__builtin_fma(x, MPCX_FM_K(13), -0.5));
-  const double r = mpcx_fm_reduce(x, n + n + 1.0);
+  const double r = mpcx_fm_reduce(x, n + 0.5);
   return mpcx_fm_flip(mpcx_fm_sin_poly(r), (int)n + 1);
 }
 

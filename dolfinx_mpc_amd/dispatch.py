@@ -102,6 +102,13 @@ MATRIX: List[Kernel] = [
            lambda c: True,
            "matrix_hex_kernel: Q1 stiffness on hexahedra, thread per (row block, cell) slot, 96-byte records, closed form on "
            "parallelepipeds; 256^3 cells: see DESIGN (generated UFCx kernel in the row blocks: 5.2 ms)"),
+    Kernel("ufcx_cube",
+           lambda c: (c.form == FORM_UFCX and c.tet and c.d0 == 1 and c.bs0 == 1 and c.d1 == 1 and c.bs1 == 1 and c.same
+                      and c.p1_geometry and c.all_cells and c.cell_integral),
+           lambda c: True,
+           "ufcx_matrix_cube_kernel (hipRTC): the imported tabulate_tensor called six times per cluster, the tensors summed per "
+           "vertex pair in registers (no symmetry assumed), 46 scatter-adds per 6 cells; clusters whose cells the mesh lists in "
+           "another vertex order, and cells in no cluster, through ufcx_rowblock"),
     Kernel("ufcx_rowblock", lambda c: c.form == FORM_UFCX, lambda c: True,
            "imported tabulate_tensor inside the LDS row-block kernel (hipRTC); config 2 with tests/ufcx/laplace_p1_tet.c: 2.32 ms "
            "vs 1.75 ms built-in, vs ~50 ms thread-per-entity atomics"),
@@ -147,6 +154,12 @@ VECTOR: List[Kernel] = [
            lambda c: True,
            "vector_hex_own_kernel: Q1 source on hexahedra, thread per cell, owner-computes row blocks, sum-factorised basis, "
            "fast sin / exp; 256^3 cells, 27 points: see DESIGN (generated UFCx kernel with libm: 4.1 ms)"),
+    Kernel("ufcx_cube_own",
+           lambda c: (c.form == FORM_UFCX and c.tet and c.d0 == 1 and c.bs0 == 1 and c.p1_geometry and c.all_cells
+                      and c.cell_integral),
+           lambda c: True,
+           "ufcx_vector_cube_own_kernel (hipRTC): thread per cluster, six calls of the imported tabulate_tensor, owner-computes "
+           "row blocks (8 LDS adds per 6 cells), no device atomics"),
     Kernel("ufcx_ownblock", lambda c: c.form == FORM_UFCX, lambda c: True,
            "imported tabulate_tensor, every entity evaluated once (its cost is unknown); config 2 with source_p1_tet.c 2.35 ms"),
     Kernel("ufcx_rowblock", lambda c: c.form == FORM_UFCX, lambda c: False, "imported tabulate_tensor, halo entities re-evaluated"),
@@ -169,6 +182,7 @@ VECTOR: List[Kernel] = [
 # table entry -> the __global__ function it launches (profiles, bench.py's per-kernel roofline lines)
 FUNCTION = {
     ("matrix", "p2_cube"): "matrix_p2_cube_kernel", ("matrix", "hex_cube"): "matrix_hex_kernel", ("vector", "hex_own"): "vector_hex_own_kernel",
+    ("matrix", "ufcx_cube"): "ufcx_matrix_cube_narrow_kernel", ("vector", "ufcx_cube_own"): "ufcx_vector_cube_own_kernel",
     ("matrix", "cube"): "matrix_cube_kernel", ("matrix", "cube_el"): "matrix_cube_elasticity_rowpair_kernel", ("matrix", "ufcx_rowblock"): "ufcx_matrix_rowblock_kernel",
     ("matrix", "pairs"): "matrix_pairs_kernel", ("matrix", "rowpair"): "matrix_rowpair_kernel", ("matrix", "nodeblock"): "matrix_nodeblock_kernel",
     ("matrix", "rowblock_lean"): "matrix_rowblock_kernel", ("matrix", "rowblock"): "matrix_rowblock_kernel",
@@ -195,7 +209,7 @@ def _legacy_matrix(c: Ctx):
     ex, prefer = set(), None
     env = os.environ
     if env.get("MPCX_NO_CUBE"):
-        ex |= {"cube", "cube_el", "hex_cube", "p2_cube"}
+        ex |= {"cube", "cube_el", "hex_cube", "p2_cube", "ufcx_cube"}
     if env.get("MPCX_NO_LEAN"):
         ex |= {"cube", "cube_el", "rowblock_lean"}
     mode = env.get("MPCX_ROWPAIR", "auto")
@@ -214,7 +228,7 @@ def _legacy_vector(c: Ctx):
     ex, prefer = set(), None
     env = os.environ
     if env.get("MPCX_NO_CUBE"):
-        ex |= {"cube_own", "cube_hash", "hex_own"}
+        ex |= {"cube_own", "cube_hash", "hex_own", "ufcx_cube_own"}
     if env.get("MPCX_VCUBE_OWNER", "1") == "0":
         ex.add("cube_own")
         prefer = "cube_hash"

@@ -24,8 +24,9 @@ extern "C" {
 #endif
 
 /* 4: mpcx_matrix_args_t::cube_flags (in the padding after cube_rec_bytes), hexahedron and closed-form cluster entry points
- * 5: pair records, scalar types;  6: mpcx_matrix_args_t::cube_rec_index (one cluster record per cluster, before ``stream``) */
-#define MPCX_VERSION 6
+ * 5: pair records, scalar types;  6: mpcx_matrix_args_t::cube_rec_index (one cluster record per cluster, before ``stream``)
+ * 7: cube_cells, last field before ``stream`` of the matrix and the vector argument block: MPCX_ALG_CUBE with imported (UFCx) kernels */
+#define MPCX_VERSION 7
 
 /* Offsets into the CSR value / column arrays (rowptr entries, positions): 64-bit, so that one GPU can
  * hold matrices with more than 2^31 - 1 stored entries (Taylor-Hood a00 on 128^3 cells: 4.4 G) -- PETSc's
@@ -312,6 +313,15 @@ typedef struct
    * more than it saves (1.01 against 0.94 ms at 256^3 cubes) -- the Python host leaves it NULL unless
    * MPCX_CUBE_CLUSTER_RECORDS=1.  NULL: record t belongs to slot t. */
   const int32_t* cube_rec_index;
+  /* MPCX_ALG_CUBE with an imported kernel (kernel.form == MPCX_FORM_UFCX; scalar P1 on tetrahedra, nd0 = nd1 = nv = 4, bs = 1):
+   * the imported tabulate_tensor is called six times per cluster -- tet t with the coordinates of the cluster's local
+   * vertices (0,1,3,7) (0,1,7,5) (0,5,7,4) (0,3,2,7) (0,6,4,7) (0,2,6,7) -- and the six tensors are summed per vertex pair in
+   * registers (no symmetry assumed: 46 values, 46 scatter-adds).  The caller vouches that the mesh lists every cluster cell's
+   * vertices in exactly that order (mpcx_cluster_ordered says which clusters do), so the function sees each cell as the
+   * reference's loop would hand it over (cpp/assemble_matrix.cpp:495-506).  Forms with coefficients (coeffs != NULL)
+   * additionally need cube_cells, DEVICE [n_clusters][6]: the CELL of table row t (index into coeffs), and
+   * plan.block_ents = the cluster of every slot of this launch.  NULL otherwise. */
+  const int32_t* cube_cells;
   void* stream;
 } mpcx_matrix_args_t;
 
@@ -441,6 +451,12 @@ int mpcx_cluster_build(int64_t n, const int64_t* sorted_keys, const int32_t* ord
  *      ring vertex; a fan that is a parallelepiped once its ring is turned by one position (local vertices 1, 2, 4 the
  *      cube-edge neighbours of vertex 0) is renumbered so -- what the closed-form kernels assume (cube_flags bit 0).  */
 int mpcx_cluster_canonical(int64_t n, int32_t* verts, const int8_t* ok, const double* x, void* stream);
+/*   5. mpcx_cluster_ordered (imported kernels only): verts [n][8] and fan_cells [n][6] (the six cells of every fan, any order)
+ *      are renumbered / reordered IN PLACE so that cell fan_cells[p][t] lists its vertices as row t of the table
+ *      (0,1,3,7) (0,1,7,5) (0,5,7,4) (0,3,2,7) (0,6,4,7) (0,2,6,7) in the numbering verts[p]; ok[p] = 0 where no numbering
+ *      does that (cells listed in another local order: an imported tabulate_tensor must be called with the mesh's own vertex
+ *      order, so those fans stay with the per-cell kernels).  All pointers DEVICE. */
+int mpcx_cluster_ordered(int64_t n, int32_t* verts, int32_t* fan_cells, const int32_t* x_dofmap, int8_t* ok, void* stream);
 
 /* The entity lists of a row-block plan on the DEVICE (host version: second half of mpcx_rowblock_plan_build):
  * (block, entity) pairs in entity order; two calls like mpcx_mpc_plan_device (offsets == NULL: counts[e] =
@@ -540,6 +556,9 @@ typedef struct
   const int32_t* own_rows;  /* DEVICE [n_own_rows] distinct target dofs (blocked), ascending */
   const int64_t* own_seg;   /* DEVICE [n_own_rows + 1] */
   int64_t n_own_rows;
+  /* MPCX_ALG_CUBE with an imported kernel and coefficients: DEVICE [n_cubes][6], the cell of every cluster tet in the order
+   * (0,1,3,7) (0,1,7,5) (0,5,7,4) (0,3,2,7) (0,6,4,7) (0,2,6,7) (see mpcx_matrix_args_t::cube_cells); NULL otherwise */
+  const int32_t* cube_cells;
   void* stream;
 } mpcx_vector_args_t;
 

@@ -48,15 +48,17 @@ void tt(double* restrict A, const double* restrict w, const double* restrict c, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("alg", ["atomic", "rowblock"])
+@pytest.mark.parametrize("alg", ["atomic", "rowblock", "auto"])
 @pytest.mark.parametrize("make", CASES, ids=[f"case{i}" for i in range(len(CASES))])
 def test_gpu_imported_kernels_match_builtin_oracle(oracle, make, alg):
+    """"rowblock" takes the first applicable entry of the matrix table (scalar P1 on tetrahedra: the cluster kernel round the
+    imported function, ufcx_cube), "auto" also the vector table's (ufcx_cube_own)"""
     case = make()
     twin = twin_case(case)
     if num_imported(twin) == 0:
         pytest.skip("no cell integral the generator covers")
     ref = oracle_outputs(oracle, case)
-    out = product_outputs(twin, algorithm=alg)
+    out = product_outputs(twin, algorithm=None if alg == "auto" else alg)
     if "A" in ref:
         assert np.array_equal(out["A"].indptr, ref["A"].indptr) and np.array_equal(out["A"].indices, ref["A"].indices)
         assert abs(out["A"].data - ref["A"].data).max() <= 1e-12 * max(1.0, abs(ref["A"]).max()), case.name + " A"
