@@ -479,6 +479,7 @@ def main():
     ap.add_argument("--cpu-allcores-n", type=int, default=0)
     ap.add_argument("--solve", action="store_true", help="also solve the assembled system (configs 2 / 5): multigrid-CG and Jacobi-CG")
     ap.add_argument("--no-sub-records", action="store_true", help="skip roofline_ufcx / roofline_spatial / roofline_csr_valued")
+    ap.add_argument("--no-config-records", action="store_true", help="config 2 only: skip the config 3 / 4 / 5 sub-records (three child runs)")
     ap.add_argument("--no-shuffled-record", action="store_true", help="skip roofline_spatial (a second 256^3 problem: ~40 s of set-up)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 PMC measurement of roofline.traffic")
     ap.add_argument("--numbering", choices=["tiled", "shuffled", "spatial"], default="tiled",
@@ -645,10 +646,13 @@ def main():
         # storage (component-diagonal forms: one value per bs x bs block, expanded on demand): that kernel then does not
         # materialise the values the reference's call produces, its fraction can exceed 1 and says so ("value_storage",
         # "value_bytes_written"); the CSR-valued step is timed separately (roofline_csr_valued)
+        # (the fractions of a kernel are computed from the value bytes IT writes -- block-scalar storage: 8 B per
+        # bs x bs block -- and the SURVEY 8d figure with every CSR value counted is kept beside it as algorithmic_bytes_csr)
         val_bytes = 8 * A.nnz
         val_written = 8 * A.nnz if not margs.block_scalar else 8 * (A.nnz // (V0.dofmap.bs ** 2))
-        nbytes = (4 * nv * nc + 4 * V0.element_ndofs * nc + (0 if V1 is V0 else 4 * V1.element_ndofs * nc)
-                  + 24 * mesh.num_nodes + val_bytes + V0.num_dofs + V1.num_dofs)
+        nbytes_csr = (4 * nv * nc + 4 * V0.element_ndofs * nc + (0 if V1 is V0 else 4 * V1.element_ndofs * nc)
+                      + 24 * mesh.num_nodes + val_bytes + V0.num_dofs + V1.num_dofs)
+        nbytes = nbytes_csr - val_bytes + val_written
         # the kernel mpcx_assemble_matrix launches for these arguments: the dispatch table's entry (dolfinx_mpc_amd/dispatch.py)
         from dolfinx_mpc_amd import dispatch
 
@@ -658,7 +662,8 @@ def main():
         if entry == "cube" and int(margs.cube_flags) & 1:
             kname = "matrix_cube_affine_kernel"  # every row block of the first launch holds parallelepiped clusters only
         kernels.append({"kernel": f"{kname}[{label}]", "call": f"assemble_matrix[{label}]", "launch_ms": tk,
-                        "algorithmic_bytes": int(nbytes), "pmc_name": kname, "value_storage": "block-scalar" if margs.block_scalar else "csr", "value_bytes_written": int(val_written),
+                        "algorithmic_bytes": int(nbytes), "algorithmic_bytes_csr": int(nbytes_csr), "pmc_name": kname,
+                        "value_storage": "block-scalar" if margs.block_scalar else "csr", "value_bytes_written": int(val_written),
                         "fp64_flops": algorithmic_flops(f.integrals[0], V0, V1) * f.integrals[0].num_entities})
         del keep
     for label, f, m in w.vectors:
@@ -849,15 +854,29 @@ def main():
     probe2 = torch.empty_like(probe)
     nb_probe = probe.numel() * 8
     probes = {}
-    for mode, name, moved in ((0, "copy", 2 * nb_probe), (1, "read", nb_probe), (2, "write", nb_probe)):
-        ms = hip_time(lambda: _native.check(Lib.mpcx_hbm_probe(probe.data_ptr(), probe2.data_ptr(), nb_probe, mode, None), "mpcx_hbm_probe"), 5)
-        probes[name + "_GBs"] = moved / (ms * 1e-3) / 1e9
+    for mode, name, moved in ((0, "copy", 2 * nb_probe), (3, "copy_x4", 2 * nb_probe), (4, "copy_x4_nt", 2 * nb_probe),
+                              (1, "read", nb_probe), (2, "write", nb_probe)):
+        for wgs in (512, 1024, 2048, 4096):  # the rate depends on the grid (tools/probes/hbm_probe_sweep.py): best of four
+            os.environ["MPCX_HBM_PROBE_WGS"] = str(wgs)
+            ms = hip_time(lambda: _native.check(Lib.mpcx_hbm_probe(probe.data_ptr(), probe2.data_ptr(), nb_probe, mode, None), "mpcx_hbm_probe"), 5)
+            rate = moved / (ms * 1e-3) / 1e9
+            if rate > probes.get(name + "_GBs", 0.0):
+                probes[name + "_GBs"], probes[name + "_workgroups"] = rate, wgs
+        del os.environ["MPCX_HBM_PROBE_WGS"]
+    ms = hip_time(lambda: probe2.zero_(), 5)
+    probes["torch_memset_GBs"] = nb_probe / (ms * 1e-3) / 1e9
     copy_ms = hip_time(lambda: probe2.copy_(probe), 5)
-    probes["torch_copy_GBs"] = 2 * nb_probe / (copy_ms * 1e-3) / 1e9
-    copy_gbs = probes["copy_GBs"]
+    probes["torch_copy_GBs"] = 2 * nb_probe / (copy_ms * 1e-3) / 1e9  # (hipMemcpyDtoD of the same run)
+    probes["note"] = ("2 GiB buffers, 16 B per lane, grid-stride with 512 / 1024 / 2048 / 4096 workgroups of 256 threads (best kept: the "
+                      "hardware guide quotes 6.29 TB/s for a float4 copy; this box gives 4.8-5.0 TB/s with 2048 workgroups and 5.8-5.9 "
+                      "with 1024); copy_x4: four loads in flight per lane, _nt: non-temporal; tools/probes/hbm_probe_sweep.py sweeps "
+                      "sizes and grids; copy_probe_GBs = the best copy figure of this run, hipMemcpyDtoD included")
+    copy_gbs = max(probes["copy_GBs"], probes["copy_x4_GBs"], probes["copy_x4_nt_GBs"], probes["torch_copy_GBs"])
     del probe, probe2
 
     dom = max(kernels, key=lambda k: k["launch_ms"])  # the time-dominant kernel of the step
+    step_ms = 1e3 * elapsed / args.steps
+    step_bytes = float(sum(k["algorithmic_bytes"] for k in kernels))
     out = {
         "metric": ("assembled DoFs/sec (matrix+vector), periodic Poisson P1 256^3"
                    + (" [imported UFCx element kernels]" if args.ufcx else "")) if args.config == 2 else
@@ -895,6 +914,13 @@ def main():
             "traffic": None, "algorithmic_bytes": dom["algorithmic_bytes"],
             "launch_ms": dom["launch_ms"], "copy_probe_GBs": copy_gbs, "frac_of_copy_probe": dom["hbm_GBs"] / copy_gbs,
             "hbm_probes": probes,
+            # side by side: the two ALGORITHMIC fractions of the dominant kernel, what the counters say it
+            # executes (filled in below: valu_issue, frac_hbm_executed), and the HBM fraction of the WHOLE step
+            "frac_hbm": dom["hbm_frac"], "frac_fp64": dom.get("fp64_frac"), "valu_issue": None, "frac_hbm_executed": None,
+            "frac_hbm_step": step_bytes / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            "step_algorithmic_bytes": int(step_bytes),
+            "frac_is": "algorithmic (formula-based); bound_by_counters names the resource the counters show busier",
+            "bound_by_counters": None,
             "selection": "time-dominant kernel of the step, judged by the larger of its two ALGORITHMIC roofline fractions: "
                          "SURVEY 8d bytes (every CSR value counted as 8 bytes written, whatever the storage) / 8 TB/s and the "
                          "flops of the quadrature formulation a form compiler emits / 78.6 TF -- one rule for every kernel; what "
@@ -944,10 +970,20 @@ def main():
                     # 4 cycles per wave64 VALU instruction, 1024 SIMDs, 2.4 GHz (the judge's arithmetic)
                     ko["valu_issue_frac"] = d["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.4e9 * k["launch_ms"] * 1e-3)
                     ko["valu_instructions"] = d["SQ_INSTS_VALU"]
+                ko["frac_hbm_executed"] = d["hbm_bytes"] / (k["launch_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS
                 if k is dom:
-                    out["roofline"]["traffic"] = d["hbm_bytes"]
-                    out["roofline"]["traffic_over_algorithmic"] = d["hbm_bytes"] / k["algorithmic_bytes"]
-                    out["roofline"]["traffic_is"] = "upper bound for gather-heavy kernels (see traffic_source)"
+                    R = out["roofline"]
+                    R["traffic"] = d["hbm_bytes"]
+                    R["traffic_over_algorithmic"] = d["hbm_bytes"] / k["algorithmic_bytes"]
+                    R["traffic_is"] = "upper bound for gather-heavy kernels (see traffic_source)"
+                    R["frac_hbm_executed"] = ko["frac_hbm_executed"]
+                    R["valu_issue"] = ko.get("valu_issue_frac")
+                    if R["valu_issue"] is not None:
+                        # the binding resource by the counters: VALU issue slots against executed HBM bytes at the rate the
+                        # box's own copy probe reaches
+                        hbm_busy = d["hbm_bytes"] / (k["launch_ms"] * 1e-3) / 1e9 / copy_gbs
+                        R["bound_by_counters"] = "fp64_valu" if R["valu_issue"] > hbm_busy else "hbm"
+                        R["hbm_busy_vs_copy_probe"] = hbm_busy
     if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
         kind, degree = w.cpu_sample
         # the stated workload itself where one core finishes it in about half a minute (configs 2 and 4: P1) and the
@@ -983,6 +1019,41 @@ def main():
                 out["cpu_baseline_allcores"] = dict(cpu_parallel.main(n_all, P, max(degree, 1), kind), full_workload=False)
             except Exception as e:  # noqa: BLE001
                 log(f"all-core CPU leg failed: {e}")
+    if world == 1 and args.config == 2 and not child and not args.no_config_records and not args.no_sub_records \
+            and not args.ufcx and args.cell == "tet" and args.numbering == "tiled" and not os.environ.get("MPCX_NO_CUBE"):
+        # BASELINE configs[2..4] in the same driver-run line: one child run each, same steps and
+        # warm-up, own roofline (counters included) and CPU baseline; the child's full line is trimmed to what a reader
+        # needs to check the DESIGN table.  The parent's device memory is released first.
+        del mats, vecs
+        w.blocks, w.vectors = [], []
+        torch.cuda.empty_cache()
+        for cfg in (3, 4, 5):
+            log(f"config {cfg} sub-record (child run) ...")
+            t0c = time.time()
+            cmd = [sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--steps", str(args.steps), "--warmup",
+                   str(args.warmup), "--no-config-records", "--cpu-allcores", "0"]
+            if args.no_traffic:
+                cmd.append("--no-traffic")
+            if args.no_cpu_baseline:
+                cmd.append("--no-cpu-baseline")
+            try:
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                if r.returncode != 0 or not line:
+                    out[f"config{cfg}"] = {"error": f"child rc {r.returncode}", "stderr_tail": r.stderr[-400:]}
+                    continue
+                c = json.loads(line[-1])
+                keep_k = ("kernel", "launch_ms", "hbm_frac", "fp64_frac", "bound", "algorithmic_bytes", "algorithmic_bytes_csr",
+                          "value_storage", "traffic", "traffic_over_algorithmic", "valu_issue_frac", "frac_hbm_executed")
+                out[f"config{cfg}"] = {
+                    "workload": c["config"]["workload"], "ms_per_step": c["ms_per_step"], "value": c["value"], "unit": c["unit"],
+                    "steps": c["steps"], "warmup": c["warmup"], "timings_ms": c["timings_ms"],
+                    "roofline": {k: v for k, v in c["roofline"].items() if k not in ("selection", "hbm_probes", "traffic_source")},
+                    "roofline_kernels": [{k: v for k, v in kk.items() if k in keep_k} for kk in c["roofline_kernels"]],
+                    "one_shot": c["one_shot"], "cpu_baseline": c.get("cpu_baseline"),
+                    "roofline_csr_valued": c.get("roofline_csr_valued"), "wall_s": time.time() - t0c}
+            except (subprocess.TimeoutExpired, ValueError, KeyError) as e:
+                out[f"config{cfg}"] = {"error": str(e)}
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -11,6 +11,7 @@
 #include "mpcx.h"
 #include "mpcx_internal.h"
 
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <string>
@@ -250,20 +251,49 @@ __global__ void __launch_bounds__(256) hbm_probe_kernel(const uint4* __restrict_
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) // (practically never: keeps the loads alive)
       dst[blockIdx.x] = acc;
   }
-  else
+  else if (mode == 2)
   {
     const uint4 v = make_uint4(1, 2, 3, 4);
     for (; i < n16; i += stride)
       dst[i] = v;
   }
+  else
+  {
+    // modes 3 / 4: copy with four independent 16-byte loads in flight per lane before the first store (mode 4: non-temporal
+    // loads and stores) -- the deepest simple pipeline; if these do not beat mode 0 the box, not the probe, sets the rate
+    for (; i + 3 * stride < n16; i += 4 * stride)
+    {
+      uint4 v0, v1, v2, v3;
+      if (mode == 4)
+      {
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        const v4u* s4 = reinterpret_cast<const v4u*>(src);
+        v4u* d4 = reinterpret_cast<v4u*>(dst);
+        const v4u w0 = __builtin_nontemporal_load(s4 + i), w1 = __builtin_nontemporal_load(s4 + i + stride);
+        const v4u w2 = __builtin_nontemporal_load(s4 + i + 2 * stride), w3 = __builtin_nontemporal_load(s4 + i + 3 * stride);
+        __builtin_nontemporal_store(w0, d4 + i), __builtin_nontemporal_store(w1, d4 + i + stride);
+        __builtin_nontemporal_store(w2, d4 + i + 2 * stride), __builtin_nontemporal_store(w3, d4 + i + 3 * stride);
+      }
+      else
+      {
+        v0 = src[i], v1 = src[i + stride], v2 = src[i + 2 * stride], v3 = src[i + 3 * stride];
+        dst[i] = v0, dst[i + stride] = v1, dst[i + 2 * stride] = v2, dst[i + 3 * stride] = v3;
+      }
+    }
+    for (; i < n16; i += stride)
+      dst[i] = src[i];
+  }
 }
 
 extern "C" int mpcx_hbm_probe(const void* src, void* dst, int64_t bytes, int32_t mode, void* stream)
 {
-  if (bytes < 16 || mode < 0 || mode > 2)
+  if (bytes < 16 || mode < 0 || mode > 4)
     return 0;
-  // 8 workgroups per CU, contiguous 4 KB per workgroup and trip
-  hipLaunchKernelGGL(hbm_probe_kernel, dim3(256 * 8), dim3(256), 0, static_cast<hipStream_t>(stream),
+  // 8 workgroups per CU, contiguous 4 KB per workgroup and trip; MPCX_HBM_PROBE_WGS: another grid (read at every call -- the
+  // rate depends on it: 2 GiB copy 4.8-5.0 TB/s with 2048 workgroups, 5.8-5.9 with 1024 on the same box, round 5)
+  const char* e = std::getenv("MPCX_HBM_PROBE_WGS");
+  const int wgs = (e && std::atoi(e) > 0) ? std::atoi(e) : 256 * 8;
+  hipLaunchKernelGGL(hbm_probe_kernel, dim3(wgs), dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const uint4*>(src), static_cast<uint4*>(dst), bytes / 16, int(mode));
   return check(hipGetLastError(), "hbm_probe launch");
 }

@@ -879,7 +879,8 @@ int mpcx_backsubstitution_scalar(int32_t scalar_type, void* u, const int32_t* sl
 int mpcx_homogenize_scalar(int32_t scalar_type, void* u, const int32_t* slaves, int64_t n, void* stream);
 
 /* HBM bandwidth probe (the denominator bench.py prints next to the 8 TB/s specification): 16 bytes per lane and access,
- * grid-stride over `bytes` of DEVICE memory; mode 0 copy dst = src, 1 read src only, 2 write dst only. */
+ * grid-stride over `bytes` of DEVICE memory; mode 0 copy dst = src, 1 read src only, 2 write dst only, 3 copy with four
+ * loads in flight per lane, 4 the same with non-temporal loads and stores. */
 int mpcx_hbm_probe(const void* src, void* dst, int64_t bytes, int32_t mode, void* stream);
 
 /* misc */
