@@ -468,3 +468,77 @@ def product_outputs(case: Case, algorithm=None):
             dm.apply_lifting(b, [case.a], [case.bcs], mpc, x0=x0, scale=case.scale)
             out["b_lifted"] = b.numpy().copy()
     return out
+
+
+def device_rows(A, rows):
+    """{row: (cols, vals)} of a few rows of a device CSR (MPCMatrix)"""
+    rp = A.d_rowptr
+    out = {}
+    for r in rows:
+        lo, hi = int(rp[r].item()), int(rp[r + 1].item())
+        out[int(r)] = (A.d_cols[lo:hi].cpu().numpy(), A.vals[lo:hi].cpu().numpy())
+    return out
+
+
+def assert_sub_box_rows_match_oracle(po, mesh, ncells, V, A, N, corner, nb, wall_y0=False):
+    """Oracle comparison at sizes the oracle cannot assemble: the cells of the box of ``nb``^3 cubes at cube
+    index ``corner`` of a unit-cube mesh of N^3 cubes are re-meshed on their own, their scalar P2 stiffness matrix is
+    assembled by the ORACLE (cpp/assemble_matrix.cpp:417-548 restated; no constraint inside the box, homogeneous Dirichlet
+    condition on the wall y = 0 if the box touches it), and every row of a dof strictly inside the box -- its whole cell patch
+    lies in the box -- must equal the row of the big device matrix ``A`` (space ``V`` on ``mesh``) entry by entry; dofs are
+    matched by their position on the half-step grid.  Returns the number of rows compared."""
+    from dolfinx_mpc_amd import fem
+    from dolfinx_mpc_amd.mesh import Mesh
+    from dolfinx_mpc_amd.workloads import empty_raw
+
+    h = 1.0 / N
+    lo = np.array(corner, dtype=np.float64) * h
+    hi = lo + nb * h
+    xg = mesh.geometry.x
+    cells = mesh.geometry.dofmap[:ncells]
+    tol = 1e-9
+    node_in = np.all((xg >= lo - tol) & (xg <= hi + tol), axis=1)
+    sel = np.flatnonzero(node_in[cells].all(axis=1))
+    assert sel.size == 6 * nb ** 3
+    nodes = np.unique(cells[sel])
+    new = -np.ones(xg.shape[0], dtype=np.int64)
+    new[nodes] = np.arange(nodes.size)
+    sub = Mesh(xg[nodes].copy(), new[cells[sel]].astype(np.int32), "tetrahedron")
+    Vs = fem.functionspace(sub, ("Lagrange", V.degree))
+    bcs = []
+    if wall_y0:
+        bcs = [fem.dirichletbc(0.0, fem.locate_dofs_geometrical(Vs, lambda x: np.isclose(x[1], 0.0)), Vs)]
+    ref = oracle_outputs(po, Case("sub_box", Vs, fem.form_stiffness(Vs), None, bcs, empty_raw()))["A"].tocsr()
+    M = 2 * N + 1
+
+    def key(x):
+        g = np.rint(x * (2 * N)).astype(np.int64)
+        return (g[:, 2] * M + g[:, 1]) * M + g[:, 0]
+
+    Xs = Vs.tabulate_dof_coordinates()
+    Xb = V.tabulate_dof_coordinates()
+    inb = np.flatnonzero(np.all((Xb >= lo - tol) & (Xb <= hi + tol), axis=1))
+    big_of_key = dict(zip(key(Xb[inb]).tolist(), inb.tolist()))
+    big_of_sub = np.array([big_of_key[k] for k in key(Xs).tolist()], dtype=np.int64)
+    strictly = np.all((Xs > lo + 0.25 * h) & (Xs < hi - 0.25 * h), axis=1)
+    if wall_y0:  # the wall itself is a mesh boundary, not a cut: rows next to it (and on it) are complete
+        strictly = ((Xs[:, 0] > lo[0] + 0.25 * h) & (Xs[:, 0] < hi[0] - 0.25 * h) & (Xs[:, 2] > lo[2] + 0.25 * h)
+                    & (Xs[:, 2] < hi[2] - 0.25 * h) & (Xs[:, 1] < hi[1] - 0.25 * h))
+    rows_s = np.flatnonzero(strictly)
+    got = device_rows(A, big_of_sub[rows_s])
+    scale = abs(ref).max()
+    sub_of_big = {int(bg): s for s, bg in enumerate(big_of_sub)}
+    for s in rows_s:
+        cols_b, vals_b = got[int(big_of_sub[s])]
+        row_ref = ref.getrow(s)
+        want = dict(zip(row_ref.indices.tolist(), row_ref.data.tolist()))
+        seen = 0
+        for c, v in zip(cols_b.tolist(), vals_b.tolist()):
+            sc = sub_of_big.get(c)
+            if sc is None:
+                assert abs(v) <= 1e-12 * scale, "an entry towards a dof outside the box in a row whose patch lies inside"
+                continue
+            assert abs(v - want.get(sc, 0.0)) <= 1e-12 * scale, (s, sc, v, want.get(sc))
+            seen += sc in want
+        assert seen == len(want)
+    return int(rows_s.size)

@@ -134,3 +134,23 @@ def test_p2_matrix_properties_at_size(problem):
     inner = ((X[:, 0] > h) & (X[:, 0] < 1 - h) & (X[:, 1] > h) & (X[:, 1] < 1 - h) & (X[:, 2] > h) & (X[:, 2] < 1 - h))
     assert int(inner.sum()) > 0.5 * n
     assert float(r[inner].abs().max()) <= 1e-11 * amax
+
+
+@pytest.mark.parametrize("where", ["interior", "dirichlet_wall"])
+def test_sampled_sub_box_against_the_oracle(problem, oracle, where):
+    """not only the library's kernels against each other -- rows of the 120 M-dof matrix against the ORACLE on
+    a re-meshed 5^3-cube sub-box (tests/problems.py assert_sub_box_rows_match_oracle), in the interior and at a Dirichlet wall"""
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import fem
+    from problems import assert_sub_box_rows_match_oracle
+
+    p = problem
+    V, mpc = p["V"], p["mpc"]
+    walls = fem.locate_dofs_geometrical(
+        V, lambda x: np.isclose(x[1], 0) | np.isclose(x[1], 1) | np.isclose(x[2], 0) | np.isclose(x[2], 1))
+    bc = fem.dirichletbc(0.0, walls, V)
+    A = dm.assemble_matrix(fem.form_stiffness(V), mpc, bcs=[bc])
+    nb = 5
+    corner = (N // 3, 0 if where == "dirichlet_wall" else N // 2, N // 2 - 2)
+    n = assert_sub_box_rows_match_oracle(oracle, p["mesh"], p["mesh"].num_cells, V, A, N, corner, nb, wall_y0=(where == "dirichlet_wall"))
+    assert n > 300
