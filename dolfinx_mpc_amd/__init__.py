@@ -22,6 +22,7 @@ from .assemble_vector import (
     set_bc,
 )
 from .multipointconstraint import MPCData, MultiPointConstraint
+from . import common  # noqa: F401  (Timer, list_timings: the reference's "~MPC: ..." scopes, also roctx ranges)
 from . import utils  # noqa: F401  (dolfinx_mpc.utils: constraint helpers, near-null space, the verification toolkit)
 from .problem import LinearProblem, NonlinearProblem
 
@@ -41,4 +42,5 @@ __all__ = [
     "LinearProblem",
     "NonlinearProblem",
     "utils",
+    "common",
 ]

@@ -256,6 +256,8 @@ EXPORTS = [
     "mpcx_cluster_build",
     "mpcx_cluster_canonical",
     "mpcx_cluster_ordered",
+    "mpcx_renumber_mesh",
+    "mpcx_dof_permutation",
     "mpcx_rowblock_pairs_device",
     "mpcx_hbm_probe",
     "mpcx_add_diagonal_scalar",
@@ -433,6 +435,10 @@ def lib() -> C.CDLL:
     L.mpcx_cluster_canonical.restype = C.c_int
     L.mpcx_cluster_ordered.argtypes = [i64, vp, vp, vp, vp, vp]
     L.mpcx_cluster_ordered.restype = C.c_int
+    L.mpcx_renumber_mesh.argtypes = [vp, i64, vp, i64, C.c_int32, vp, vp, vp, vp, vp, vp]
+    L.mpcx_renumber_mesh.restype = C.c_int
+    L.mpcx_dof_permutation.argtypes = [vp, vp, vp, i64, C.c_int32, vp, vp]
+    L.mpcx_dof_permutation.restype = C.c_int
     L.mpcx_cell_shapes.argtypes = [i64, vp, vp, vp, vp]
     L.mpcx_cell_shapes.restype = C.c_int
     L.mpcx_p2_cluster_dofs.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp]

@@ -10,6 +10,7 @@ from typing import Optional, Sequence, Union
 
 import numpy as np
 
+from .common import timed
 from . import _device as D
 from . import _native
 from .fem import DirichletBC, Form
@@ -114,6 +115,7 @@ def _pattern_on_device(V0, V1, mpc0, mpc1, keep_on_device: bool = False):
     return rowptr64.cpu().numpy(), cols.cpu().numpy()
 
 
+@timed("~MPC: Create sparsity pattern")
 def create_sparsity_pattern(form: Form, mpc: Union[MultiPointConstraint, Sequence[MultiPointConstraint]],
                             num_threads: int = 0, where: Optional[str] = None, keep_on_device: bool = False):
     """MPC sparsity pattern as scalar CSR ``(rowptr int64, cols int32)`` with sorted columns:
@@ -164,6 +166,7 @@ def create_sparsity_pattern(form: Form, mpc: Union[MultiPointConstraint, Sequenc
     return rowptr, cols
 
 
+@timed("~MPC: Create Matrix")
 def create_matrix(form: Form, mpc0: MultiPointConstraint, mpc1: Optional[MultiPointConstraint] = None) -> MPCMatrix:
     """python/src/dolfinx_mpc/mpc.cpp:321-344 ``cpp.mpc.create_matrix``."""
     mpc1 = mpc0 if mpc1 is None else mpc1
@@ -1242,6 +1245,7 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
     return a, keep
 
 
+@timed("~MPC: Assemble matrix (C++)")
 def assemble_matrix(
     form: Form,
     constraint: Union[MultiPointConstraint, Sequence[MultiPointConstraint]],
@@ -1299,10 +1303,11 @@ def assemble_matrix(
             try:
                 return locality.assemble_matrix(tw, form, mpc0, mpc1, bcs, diagval, A, alg)
             except _native.PlanNotRepresentable:
-                pass
+                tw.remember_failure(A, form)  # (pattern or plan of the twin not representable: not retried on every call)
     D.mesh_device(form.mesh)  # a moved mesh is refreshed on the caller's stream, before any side stream reads it
     from .la import side_stream
 
+    A._twin_stale = False
     with side_stream("matrix", A):  # the library's matrix stream (la.side_stream); completion is awaited by A.vals
         _assemble_matrix_on_stream(form, mpc0, mpc1, bcs, diagval, A, alg)
     return A

@@ -9,6 +9,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
+from .common import timed
 from . import _device as D
 from . import _native
 from .fem import DirichletBC, Form
@@ -417,6 +418,7 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
     return a, keep
 
 
+@timed("~MPC: Assemble vector (C++)")
 def assemble_vector(form: Form, constraint: MultiPointConstraint, b: Optional[Vector] = None,
                     num_threads: Optional[int] = 1, algorithm: Optional[str] = None) -> Vector:
     """Assemble a linear form into ``b`` with the multi point constraint applied
@@ -511,6 +513,7 @@ def _lift_entities(form: Form, i: int, markers: np.ndarray, d_markers, V1):
     return D.cached(form._device, "lift_ents", (markers,), i, build)
 
 
+@timed("~MPC: Apply lifting (C++)")
 def apply_lifting(
     b: Vector,
     form: Sequence[Optional[Form]],

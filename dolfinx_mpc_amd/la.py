@@ -265,6 +265,7 @@ class MPCMatrix:
         # dict(bs, svals [nnz / bs^2], mask uint8 [nnz / bs^2], ov_pos int64, ov_val, diag_pos int64, diagval) or None
         self._compact = None
         self._compact_stale = False  # the scalar values do not reflect the block-scalar ones yet
+        self._twin_stale = False  # the values live in the reordered twin's matrix (locality.py, lazy hand-back) and are not copied yet
         self._exchange = None
         self._pending = None
         self._ready = None  # event recorded at the end of an assembly on a side stream
@@ -310,6 +311,10 @@ class MPCMatrix:
                 seen.add(raw)
         if self._compact_stale:
             self._expand_compact()
+        if self._twin_stale:
+            from . import locality
+
+            locality.hand_back(self)
         if self._pending is not None:
             p, self._pending = self._pending, None
             p.finish()
@@ -363,6 +368,7 @@ class MPCMatrix:
 
     def zeroEntries(self):
         self._compact_stale = False
+        self._twin_stale = False
         self.vals.zero_()
 
     def attach_exchange(self, exchange):

@@ -16,12 +16,19 @@ The reference's call sequence stays what it is (python/src/dolfinx_mpc/assemble_
 assemble_vector.py:25-104): the twin is consulted inside ``assemble_matrix`` / ``assemble_vector`` / ``apply_lifting``.
 
 Switch: ``MPCX_AUTO_REORDER`` = ``0`` off, ``1`` always (tests), unset: meshes of at least ``MPCX_AUTO_REORDER_MIN_CELLS``
-(default 50 000) cells without tile hints on one process."""
+(default 50 000) cells without tile hints on one process.
+
+Memory: the twin holds a second copy of the mesh, of every dofmap / constraint / Function it has been shown, and -- per
+matrix -- a second value array with its pattern plus 4 (8 beyond 2^32 entries) bytes per entry for the hand-back index
+(config 2: + 3 GB per matrix).  The copies of Forms, Functions, Dirichlet conditions and constraints live exactly as long
+as the caller's objects do (weak references: a time loop that rebuilds its forms every step does not accumulate twins),
+a matrix's twin as long as the matrix; a (matrix, form) pair the twin could not represent is remembered and not retried."""
 
 from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from typing import Optional
 
 import numpy as np
@@ -89,6 +96,69 @@ def _morton_orders(mesh: Mesh):
     return perm.cpu().numpy(), cell_order.cpu().numpy()
 
 
+def _gpu():
+    try:
+        import torch
+
+        return torch.cuda.is_available()
+    except Exception:  # pragma: no cover
+        return False
+
+
+def _renumber(mesh: Mesh, perm: np.ndarray, cell_order: np.ndarray):
+    """(the renumbered mesh, cell_new_of_old): ``mesh.renumber`` with the gathers on the device when there is one -- the
+    host's fancy indexing of 4 x 10^8 node ids took 12 of the 23 s a shuffled 256^3 mesh spent in the library before its
+    first assembly (tools/probes/twin_setup_profile.py)"""
+    if not _gpu():
+        inv = np.empty(cell_order.size, dtype=np.int64)
+        inv[cell_order] = np.arange(cell_order.size)
+        return renumber(mesh, perm, cell_order), inv
+    import torch
+
+    dev = _native.require_gpu()
+    nn, nc, nv = mesh.num_nodes, mesh.num_cells, mesh.geometry.dofmap.shape[1]
+    p = torch.from_numpy(np.ascontiguousarray(perm, dtype=np.int64)).to(dev)
+    o = torch.from_numpy(np.ascontiguousarray(cell_order, dtype=np.int64)).to(dev)
+    xt = torch.from_numpy(np.ascontiguousarray(mesh.geometry.x)).to(dev)
+    ct = torch.from_numpy(np.ascontiguousarray(mesh.geometry.dofmap)).to(dev)
+    x2, c2 = torch.empty_like(xt), torch.empty_like(ct)
+    inv = torch.empty_like(o)
+    # (the library's own gathers: torch's advanced indexing with 4 x 10^8 indices faulted on this stack)
+    _native.check(_native.lib().mpcx_renumber_mesh(xt.data_ptr(), nn, ct.data_ptr(), nc, nv, p.data_ptr(), o.data_ptr(), x2.data_ptr(),
+                                                   c2.data_ptr(), inv.data_ptr(), D.stream_ptr()), "mpcx_renumber_mesh")
+    out = Mesh(x2.cpu().numpy(), c2.cpu().numpy(), mesh.cell_name)
+    return out, inv.cpu().numpy()
+
+
+class _WeakIdCache:
+    """identity-keyed cache whose entries die with their key object (the twin used to keep every Form, Function,
+    DirichletBC and constraint it had seen alive, with their device buffers and plans).  Values must not refer to the key."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, obj):
+        hit = self._d.get(id(obj))
+        if hit is None:
+            return None
+        if hit[0]() is not obj:  # (the id was reused by a new object before the callback ran)
+            self._d.pop(id(obj), None)
+            return None
+        return hit[1]
+
+    def put(self, obj, value):
+        key, d = id(obj), self._d
+
+        def drop(_ref, key=key, d=d):
+            d.pop(key, None)
+
+        d[key] = (weakref.ref(obj, drop), value)
+        return value
+
+    def __len__(self):
+        return len(self._d)
+
+
 class Twin:
     """the reordered copy of one mesh and of everything built on it that an assembly call has been given"""
 
@@ -97,14 +167,13 @@ class Twin:
         perm, cell_order = _morton_orders(mesh)
         self.node_new_of_old = perm
         self.cell_old_of_new = cell_order
-        self.cell_new_of_old = np.empty(cell_order.size, dtype=np.int64)
-        self.cell_new_of_old[cell_order] = np.arange(cell_order.size)
-        self.mesh2 = renumber(mesh, perm, cell_order)
+        self.mesh2, self.cell_new_of_old = _renumber(mesh, perm, cell_order)
         self.mesh2._is_twin = True
         self.mesh2.node_tile_offsets = np.arange(0, self.mesh2.num_nodes, int(os.environ.get("MPCX_AUTO_REORDER_TILE", 512)),
                                                  dtype=np.int32)
         self.version = mesh.geometry.version
-        self._spaces, self._functions, self._bcs, self._forms, self._mpcs = {}, {}, {}, {}, {}
+        self._spaces, self._functions, self._bcs, self._forms, self._mpcs = (_WeakIdCache() for _ in range(5))
+        self._failed = _WeakIdCache()  # matrix -> ids of the forms whose twin pattern / plan could not be represented
 
     # -- geometry ------------------------------------------------------------------------------------------------
     def sync_geometry(self):
@@ -118,52 +187,66 @@ class Twin:
     # -- spaces --------------------------------------------------------------------------------------------------
     def space(self, V: FunctionSpace):
         """(twin space, unrolled dof permutation new_of_old as numpy int64, the same on the device)"""
-        hit = self._spaces.get(id(V))
+        hit = self._spaces.get(V)
         if hit is not None:
-            return hit[1:]
+            return hit
         bs = V.dofmap.bs
         V2 = FunctionSpace(self.mesh2, ("Lagrange", V.degree), (bs,) if bs > 1 else None)
         # local dof order inside a cell is kept by the renumbering (local vertex order is), so the dofmaps of a cell and
         # of its twin cell list the same dofs position by position
         nblocks = V.num_dofs // bs
-        new_of_old = np.full(nblocks, -1, dtype=np.int64)
-        new_of_old[V.dofmap.list.reshape(-1)] = V2.dofmap.list[self.cell_new_of_old].reshape(-1)
-        if (new_of_old < 0).any() or V2.num_dofs != V.num_dofs:
-            raise _native.PlanNotRepresentable("automatic reordering: the space has dofs no cell refers to")
-        pu = (new_of_old[:, None] * bs + np.arange(bs)[None, :]).reshape(-1) if bs > 1 else new_of_old
         d_pu = None
-        try:
+        if V.degree == 1 and not getattr(V, "general", False):
+            new_of_old = np.asarray(self.node_new_of_old, dtype=np.int64)  # P1: the dofs are the nodes
+            ok = V2.num_dofs == V.num_dofs
+        elif _gpu():
             import torch
 
-            if torch.cuda.is_available():
-                d_pu = torch.from_numpy(pu).to(_native.require_gpu())
-        except Exception:  # pragma: no cover
-            d_pu = None
-        self._spaces[id(V)] = (V, V2, pu, d_pu)
+            dev = _native.require_gpu()
+            t_new = torch.full((nblocks,), -1, dtype=torch.int64, device=dev)
+            old_dm = torch.from_numpy(np.ascontiguousarray(V.dofmap.list)).to(dev)
+            new_dm = torch.from_numpy(np.ascontiguousarray(V2.dofmap.list)).to(dev)
+            inv = torch.from_numpy(np.ascontiguousarray(self.cell_new_of_old, dtype=np.int64)).to(dev)
+            _native.check(_native.lib().mpcx_dof_permutation(old_dm.data_ptr(), new_dm.data_ptr(), inv.data_ptr(), old_dm.shape[0],
+                                                             old_dm.shape[1], t_new.data_ptr(), D.stream_ptr()), "mpcx_dof_permutation")
+            ok = V2.num_dofs == V.num_dofs and int(t_new.min().item()) >= 0
+            new_of_old = t_new.cpu().numpy()
+            del t_new, old_dm, new_dm, inv
+        else:
+            new_of_old = np.full(nblocks, -1, dtype=np.int64)
+            new_of_old[V.dofmap.list.reshape(-1)] = V2.dofmap.list[self.cell_new_of_old].reshape(-1)
+            ok = V2.num_dofs == V.num_dofs and not (new_of_old < 0).any()
+        if not ok:
+            raise _native.PlanNotRepresentable("automatic reordering: the space has dofs no cell refers to")
+        pu = (new_of_old[:, None] * bs + np.arange(bs)[None, :]).reshape(-1) if bs > 1 else new_of_old
+        if _gpu():
+            import torch
+
+            d_pu = torch.from_numpy(np.ascontiguousarray(pu)).to(_native.require_gpu())
+        self._spaces.put(V, (V2, pu, d_pu))
         return V2, pu, d_pu
 
     # -- values --------------------------------------------------------------------------------------------------
     def function(self, f: Function) -> Function:
         V2, pu, _ = self.space(f.function_space)
-        hit = self._functions.get(id(f))
+        hit = self._functions.get(f)
         if hit is None:
-            hit = self._functions[id(f)] = [f, Function(V2), None]
+            hit = self._functions.put(f, [Function(V2), None])
         cur = f.x._data
-        if hit[2] is None or not D.same_values(cur, hit[2]):
-            hit[2] = cur.copy()
-            hit[1].x._data[pu] = cur
-        return hit[1]
+        if hit[1] is None or not D.same_values(cur, hit[1]):
+            hit[1] = cur.copy()
+            hit[0].x._data[pu] = cur
+        return hit[0]
 
     def bc(self, bc: DirichletBC) -> DirichletBC:
         V2, pu, _ = self.space(bc.function_space)
-        hit = self._bcs.get(id(bc))
-        if hit is None:
+        b2 = self._bcs.get(bc)
+        if b2 is None:
             b2 = DirichletBC.__new__(DirichletBC)
             b2.function_space = V2
             b2._dofs = np.ascontiguousarray(pu[bc._dofs], dtype=np.int32)
             b2.value = bc.value
-            hit = self._bcs[id(bc)] = (bc, b2)
-        b2 = hit[1]
+            self._bcs.put(bc, b2)
         v = bc.value
         if isinstance(v, Function):
             b2.value = self.function(v)
@@ -184,7 +267,7 @@ class Twin:
 
     # -- forms ---------------------------------------------------------------------------------------------------
     def form(self, form: Form) -> Form:
-        hit = self._forms.get(id(form))
+        hit = self._forms.get(form)
         if hit is None:
             spaces2 = [self.space(V)[0] for V in form.function_spaces]
             integrals, sources = [], []
@@ -204,8 +287,8 @@ class Twin:
                     ents2 = np.stack([mapped[order], ents[order, 1].astype(np.int64)], axis=1).astype(ents.dtype)
                 integrals.append(Integral(integ.itype, np.ascontiguousarray(ents2), integ.kernel, None, integ.constant))
                 sources.append(order)
-            hit = self._forms[id(form)] = (form, Form(spaces2, integrals), sources, [None] * len(integrals))
-        _, form2, orders, packed = hit
+            hit = self._forms.put(form, (Form(spaces2, integrals), sources, [None] * len(integrals)))
+        form2, orders, packed = hit
         # coefficients are live: Functions through their twins, packed arrays re-ordered when their values changed
         for k, (integ, integ2) in enumerate(zip(form.integrals, form2.integrals)):
             c = integ.coefficient
@@ -226,9 +309,9 @@ class Twin:
     def mpc(self, mpc):
         from .multipointconstraint import MultiPointConstraint
 
-        hit = self._mpcs.get(id(mpc))
+        hit = self._mpcs.get(mpc)
         if hit is not None:
-            return hit[1]
+            return hit
         mpc._not_finalized()
         V2, pu, _ = self.space(mpc.function_space)
         slaves = np.asarray(mpc.slaves, dtype=np.int64)
@@ -245,7 +328,7 @@ class Twin:
         m2.add_constraint(V2, pu[slaves].astype(np.int32), pu[masters].astype(np.int64), np.asarray(coeffs)[idx],
                           np.zeros(masters.size, dtype=np.int32), offsets.astype(np.int32))
         m2.finalize()
-        self._mpcs[id(mpc)] = (mpc, m2)
+        self._mpcs.put(mpc, m2)
         return m2
 
     # -- matrices ------------------------------------------------------------------------------------------------
@@ -256,9 +339,30 @@ class Twin:
 
         from .assemble_matrix import create_matrix
 
+        failed = self._failed.get(A)
+        if failed is not None and id(form) in failed:
+            raise _native.PlanNotRepresentable("automatic reordering: not representable for this matrix and form (remembered)")
         hit = getattr(A, "_twin", None)
         if hit is not None and hit[0] is self:
             return hit[1:]
+        try:
+            return self._build_matrix(A, form, mpc0, mpc1)
+        except _native.PlanNotRepresentable:
+            self.remember_failure(A, form)
+            raise
+
+    def remember_failure(self, A, form: Form):
+        """the (matrix, form) pair is assembled in the caller's numbering from now on: the failed build is not repeated"""
+        failed = self._failed.get(A)
+        if failed is None:
+            failed = self._failed.put(A, set())
+        failed.add(id(form))
+
+    def _build_matrix(self, A, form: Form, mpc0, mpc1):
+        import torch
+
+        from .assemble_matrix import create_matrix
+
         form2 = self.form(form)
         A2 = create_matrix(form2, self.mpc(mpc0), self.mpc(mpc1))
         if A2.nnz != A.nnz or A2.shape != A.shape:
@@ -311,12 +415,30 @@ def assemble_matrix(tw: Twin, form: Form, mpc0, mpc1, bcs, diagval, A, alg: int)
     form2, m0, bcs2 = tw.form(form), tw.mpc(mpc0), tw.bcs(bcs)
     m1 = m0 if mpc1 is mpc0 else tw.mpc(mpc1)
     D.mesh_device(form2.mesh)
+    lazy = os.environ.get("MPCX_TWIN_HANDBACK", "eager") == "lazy"
     with side_stream("matrix", A):
         am._assemble_matrix_on_stream(form2, m0, m1, bcs2, diagval, A2, alg)
         A._compact_stale = False
-        _native.check(_native.lib().mpcx_permute_values(A.nnz, src.data_ptr(), int(wide), A2.vals.data_ptr(), A.vals.data_ptr(),
-                                                        D.stream_ptr()), "mpcx_permute_values")
+        if lazy:
+            # the values stay in the twin's matrix until somebody reads ``A.vals`` (to_scipy, a solver, an exchange): like
+            # block-scalar storage, the pass that writes them to the caller's CSR positions runs on demand, once per assembly
+            # (PETSc keeps its own internal ordering behind MatSetValuesLocal as well)
+            A._twin_stale = True
+        else:
+            A._twin_stale = False
+            _native.check(_native.lib().mpcx_permute_values(A.nnz, src.data_ptr(), int(wide), A2.vals.data_ptr(), A.vals.data_ptr(),
+                                                            D.stream_ptr()), "mpcx_permute_values")
     return A
+
+
+def hand_back(A):
+    """``A.vals`` of a matrix assembled with MPCX_TWIN_HANDBACK=lazy: the twin's values written to the caller's positions, on
+    the current stream (which has already been ordered after the assembly by ``A._wait_ready()``)"""
+    A._twin_stale = False
+    tw, A2, src, wide = A._twin
+    _ = A.vals  # (allocates on first use; the flag is already cleared)
+    _native.check(_native.lib().mpcx_permute_values(A.nnz, src.data_ptr(), int(wide), A2.vals.data_ptr(), A._vals.data_ptr(),
+                                                    D.stream_ptr()), "mpcx_permute_values")
 
 
 def assemble_vector(tw: Twin, form: Form, mpc, b, alg: int):

@@ -15,6 +15,7 @@ from typing import Callable, Dict, Optional, Sequence
 
 import numpy as np
 
+from .common import timed
 from . import _native
 from .fem import DirichletBC, FunctionSpace
 
@@ -111,6 +112,7 @@ def locate_points(V: FunctionSpace, pts: np.ndarray, cells: Optional[np.ndarray]
     return found, basis
 
 
+@timed("~MPC: Facet normal projection")
 def create_normal_approximation(V: FunctionSpace, meshtags, value: int):
     """python/src/dolfinx_mpc/utils/mpc_utils.py:422-438 / cpp/utils.h:201-267: a Function in the (vector) space V
     whose blocks in the closure of the facets tagged ``value`` hold the sum of the adjacent tagged facets' unit normals
@@ -466,6 +468,7 @@ class MultiPointConstraint:
         blocks = locate_dofs_topological(V, meshtag.dim, meshtag.find(tag))
         self._periodic(V, blocks, relation, bcs, float(scale), float(tol))
 
+    @timed("~MPC: Create slip constraint")
     def create_slip_constraint(self, space: FunctionSpace, facet_marker, v, bcs: Sequence[DirichletBC] = ()):
         """u . v = 0 on the dofs in the closure of the facets ``facet_marker = (meshtags, marker)``, ``v`` a Function
         in ``space`` holding the direction, usually the facet normal (python/src/dolfinx_mpc/multipointconstraint.py:
@@ -631,6 +634,7 @@ class MultiPointConstraint:
                                     4.0 * lam_found[:, le[:, 0]] * lam_found[:, le[:, 1]]], axis=1)
         return slave_blocks, found, basis
 
+    @timed("~MPC: Inelastic condition")
     def create_contact_inelastic_condition(self, meshtags, slave_marker: int, master_marker: int,
                                            eps2: float = 1e-20, allow_missing_masters: bool = False,
                                            num_threads: Optional[int] = 1):

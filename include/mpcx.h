@@ -869,6 +869,15 @@ int mpcx_csr_permutation(int32_t nrows, const mpcx_nnz_t* rowptr, const int32_t*
                          const int32_t* new_of_old1, const mpcx_nnz_t* rowptr2, const int32_t* cols2, void* src, int32_t wide,
                          int32_t* bad, void* stream);
 int mpcx_permute_values(int64_t n, const void* src, int32_t wide, const double* vals2, double* dst, void* stream);
+/* The twin itself (all pointers DEVICE): mpcx_renumber_mesh: x_out[node_new_of_old[n]] = x[n] (3 coordinates per node),
+ * cells_out[c][i] = node_new_of_old[cells[cell_old_of_new[c]][i]], cell_new_of_old[cell_old_of_new[c]] = c.
+ * mpcx_dof_permutation: new_of_old[dofmap_old[c][i]] = dofmap_new[cell_new_of_old[c]][i] for every cell c and local dof i
+ * (new_of_old preset by the caller, e.g. to -1: a dof no cell refers to keeps the preset). */
+int mpcx_renumber_mesh(const double* x, int64_t n_nodes, const int32_t* cells, int64_t n_cells, int32_t nv,
+                       const int64_t* node_new_of_old, const int64_t* cell_old_of_new, double* x_out, int32_t* cells_out,
+                       int64_t* cell_new_of_old, void* stream);
+int mpcx_dof_permutation(const int32_t* dofmap_old, const int32_t* dofmap_new, const int64_t* cell_new_of_old, int64_t n_cells,
+                         int32_t nd, int64_t* new_of_old, void* stream);
 
 /* The small kernels of the path for any scalar type (mpcx_kernel_t::scalar_type; pointers DEVICE, values of that type):
  * vals[pos(d, d)] += (re + i im) for d in dofs (cpp/assemble_matrix.cpp:711-724 and dolfinx insert_diagonal),

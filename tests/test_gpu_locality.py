@@ -97,3 +97,27 @@ def test_twin_is_skipped_for_tiled_meshes_and_when_switched_off(monkeypatch):
     assert not locality.wanted(plain)  # below MPCX_AUTO_REORDER_MIN_CELLS
     monkeypatch.setenv("MPCX_AUTO_REORDER_MIN_CELLS", "10")
     assert locality.wanted(plain)
+
+
+def test_lazy_hand_back_defers_the_permutation_until_the_values_are_read(oracle, monkeypatch):
+    """MPCX_TWIN_HANDBACK=lazy: assemble_matrix leaves the values in the twin's matrix; A.vals / to_scipy run the pass that
+    writes them to the caller's positions, once; a later eager assembly into the same matrix is not disturbed"""
+    import dolfinx_mpc_amd as dm
+    from problems import case_cube_periodic, oracle_outputs, product_mpc
+
+    monkeypatch.setenv("MPCX_AUTO_REORDER", "1")
+    case = case_cube_periodic(5, 1, 0.3, numbering="shuffled")
+    ref = oracle_outputs(oracle, case)["A"]
+    mpc = product_mpc(case)
+    monkeypatch.setenv("MPCX_TWIN_HANDBACK", "lazy")
+    A = dm.assemble_matrix(case.a, mpc, bcs=case.bcs)
+    assert A._twin_stale
+    S = A.to_scipy()
+    assert not A._twin_stale
+    assert abs(S.data - ref.data).max() <= 1e-12 * abs(ref.data).max()
+    dm.assemble_matrix(case.a, mpc, bcs=case.bcs, A=A)
+    assert A._twin_stale
+    monkeypatch.setenv("MPCX_TWIN_HANDBACK", "eager")
+    dm.assemble_matrix(case.a, mpc, bcs=case.bcs, A=A)
+    assert not A._twin_stale
+    assert abs(A.to_scipy().data - ref.data).max() <= 1e-12 * abs(ref.data).max()
