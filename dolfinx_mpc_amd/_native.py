@@ -330,6 +330,7 @@ EXPORTS = [
     "mpcx_cg_step",
     "mpcx_last_error",
     "mpcx_version",
+    "mpcx_preload",
     "mpcx_device_count",
 ]
 
@@ -576,6 +577,8 @@ def lib() -> C.CDLL:
     L.mpcx_last_error.restype = C.c_char_p
     L.mpcx_version.argtypes = []
     L.mpcx_version.restype = C.c_int
+    L.mpcx_preload.argtypes = [vp]
+    L.mpcx_preload.restype = C.c_int
     L.mpcx_device_count.argtypes = []
     L.mpcx_device_count.restype = C.c_int
     _lib = L
@@ -612,4 +615,30 @@ def require_gpu():
                 "and there is no CPU fallback for the assembly path."
             )
         _gpu_seen = True
+        _start_preload(torch.cuda.current_device())
     return torch.device("cuda", torch.cuda.current_device())
+
+
+_preload_thread = None
+
+
+def _start_preload(device_index: int):
+    """load the library's code objects in the background (include/mpcx.h mpcx_preload): the first launch from every
+    translation unit of libmpcx.so loads tens of MB of gfx950 code, which a cold box used to pay inside the first assembly
+    (VERDICT r4 U-3); started once, when the process first asks for its device; MPCX_PRELOAD=0 switches it off"""
+    global _preload_thread
+    if _preload_thread is not None or os.environ.get("MPCX_PRELOAD", "1") == "0":
+        return
+    import threading
+
+    def run():
+        try:
+            import torch
+
+            torch.cuda.set_device(device_index)  # (the current device is per thread)
+            lib().mpcx_preload(None)
+        except Exception:  # noqa: BLE001  (an optimisation only)
+            pass
+
+    _preload_thread = threading.Thread(target=run, name="mpcx-preload", daemon=True)
+    _preload_thread.start()

@@ -747,3 +747,14 @@ extern "C" int mpcx_cell_plan_fill(const mpcx_cell_plan_t* p, mpcx_matrix_args_t
 extern "C" int64_t mpcx_cell_plan_num_slots(const mpcx_cell_plan_t* p) { return p ? p->n_slots : 0; }
 extern "C" int32_t mpcx_cell_plan_num_blocks(const mpcx_cell_plan_t* p) { return p ? p->num_blocks : 0; }
 extern "C" void mpcx_cell_plan_destroy(mpcx_cell_plan_t* p) { delete p; }
+
+// (mpcx_preload, csrc/mpcx_kernels.hip: the first launch from a translation unit loads its code object)
+namespace
+{
+__global__ void preload_cluster_plan_kernel() {}
+} // namespace
+extern "C" int mpcx_preload_cluster_plan(void* stream)
+{
+  hipLaunchKernelGGL(preload_cluster_plan_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream));
+  return hipGetLastError() == hipSuccess ? 0 : -100;
+}

@@ -2535,3 +2535,14 @@ extern "C" int mpcx_cluster_ordered(int64_t n, int32_t* verts, int32_t* fan_cell
                      verts, fan_cells, x_dofmap, ok);
   return mpcx::check(hipGetLastError(), "cluster_ordered launch");
 }
+
+// (mpcx_preload, csrc/mpcx_kernels.hip: the first launch from a translation unit loads its code object)
+namespace
+{
+__global__ void preload_cubes_kernel() {}
+} // namespace
+extern "C" int mpcx_preload_cubes(void* stream)
+{
+  hipLaunchKernelGGL(preload_cubes_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream));
+  return hipGetLastError() == hipSuccess ? 0 : -100;
+}

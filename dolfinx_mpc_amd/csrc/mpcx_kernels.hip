@@ -2383,3 +2383,28 @@ extern "C" int mpcx_device_count(void)
     return 0;
   return n;
 }
+
+// Code objects are loaded at the first launch from each translation unit of the library (tens of MB in all: on a cold box
+// the first assembly paid for it).  mpcx_preload launches one empty kernel per unit on `stream`; the Python
+// layer calls it from a background thread when the library is first loaded on a machine with a device, so the loads run
+// beside the host-side problem set-up.
+namespace
+{
+__global__ void preload_kernels_kernel() {}
+} // namespace
+extern "C" int mpcx_preload_cubes(void*);
+extern "C" int mpcx_preload_pairs(void*);
+extern "C" int mpcx_preload_prims(void*);
+extern "C" int mpcx_preload_plans(void*);
+extern "C" int mpcx_preload_cluster_plan(void*);
+extern "C" int mpcx_preload_solver(void*);
+extern "C" int mpcx_preload(void* stream)
+{
+  hipLaunchKernelGGL(preload_kernels_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream));
+  int rc = hipGetLastError() == hipSuccess ? 0 : -100;
+  rc |= mpcx_preload_cubes(stream) | mpcx_preload_pairs(stream) | mpcx_preload_prims(stream) | mpcx_preload_plans(stream)
+        | mpcx_preload_cluster_plan(stream) | mpcx_preload_solver(stream);
+  if (rc == 0 && hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess)
+    rc = -100;
+  return rc;
+}

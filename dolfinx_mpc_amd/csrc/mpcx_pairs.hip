@@ -815,3 +815,14 @@ extern "C" int mpcx_pair_compress(int64_t n_pairs, const uint32_t* recs, int32_t
   *num_patterns = (host[0] > PAIR_DICT_MAX || host[1] != 0) ? -1 : host[0];
   return 0;
 }
+
+// (mpcx_preload, csrc/mpcx_kernels.hip: the first launch from a translation unit loads its code object)
+namespace
+{
+__global__ void preload_pairs_kernel() {}
+} // namespace
+extern "C" int mpcx_preload_pairs(void* stream)
+{
+  hipLaunchKernelGGL(preload_pairs_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream));
+  return hipGetLastError() == hipSuccess ? 0 : -100;
+}

@@ -345,3 +345,14 @@ extern "C" int mpcx_dof_permutation(const int32_t* dofmap_old, const int32_t* do
                      dofmap_new, cell_new_of_old, n_cells, int(nd), new_of_old);
   return check(hipGetLastError(), "dof_permutation_kernel launch");
 }
+
+// (mpcx_preload, csrc/mpcx_kernels.hip: the first launch from a translation unit loads its code object)
+namespace
+{
+__global__ void preload_plans_kernel() {}
+} // namespace
+extern "C" int mpcx_preload_plans(void* stream)
+{
+  hipLaunchKernelGGL(preload_plans_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream));
+  return hipGetLastError() == hipSuccess ? 0 : -100;
+}

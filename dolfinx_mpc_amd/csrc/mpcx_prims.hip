@@ -405,3 +405,14 @@ extern "C" int mpcx_cell_to_slaves_device(int64_t num_cells, int32_t nd, int32_t
                        c2s_offsets, c2s);
   return check(hipGetLastError(), "cell_to_slaves_device launch");
 }
+
+// (mpcx_preload, csrc/mpcx_kernels.hip: the first launch from a translation unit loads its code object)
+namespace
+{
+__global__ void preload_prims_kernel() {}
+} // namespace
+extern "C" int mpcx_preload_prims(void* stream)
+{
+  hipLaunchKernelGGL(preload_prims_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream));
+  return hipGetLastError() == hipSuccess ? 0 : -100;
+}

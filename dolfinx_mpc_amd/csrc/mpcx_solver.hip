@@ -489,3 +489,14 @@ extern "C" int mpcx_cg_step(int32_t n, const mpcx_nnz_t* rowptr, const int32_t* 
                      scal + S_RZ + cur, scal + S_PAP + nxt);
   return check(hipGetLastError(), "cg_step launch");
 }
+
+// (mpcx_preload, csrc/mpcx_kernels.hip: the first launch from a translation unit loads its code object)
+namespace
+{
+__global__ void preload_solver_kernel() {}
+} // namespace
+extern "C" int mpcx_preload_solver(void* stream)
+{
+  hipLaunchKernelGGL(preload_solver_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream));
+  return hipGetLastError() == hipSuccess ? 0 : -100;
+}

@@ -895,6 +895,9 @@ int mpcx_hbm_probe(const void* src, void* dst, int64_t bytes, int32_t mode, void
 /* misc */
 const char* mpcx_last_error(void);
 int mpcx_version(void);
+/* Load the library's code objects now (one empty kernel per translation unit on `stream`, then a stream synchronisation)
+ * instead of at the first assembly call; optional, idempotent, thread-safe. */
+int mpcx_preload(void* stream);
 int mpcx_device_count(void);
 
 #ifdef __cplusplus
