@@ -141,12 +141,14 @@ def ufcx_compile(k, form: Form):
     V0 = form.function_spaces[0]
     V1 = form.function_spaces[1] if form.rank == 2 else None
     nv = form.mesh.geometry.dofmap.shape[1]
+    tr = getattr(k, "ufcx_transforms", None) or (None, None)
     key = (k.ufcx_source, k.ufcx_name, form.rank, V0.element_ndofs, V0.dofmap.bs,
-           0 if V1 is None else V1.element_ndofs, 0 if V1 is None else V1.dofmap.bs, nv,
+           0 if V1 is None else V1.element_ndofs, 0 if V1 is None else V1.dofmap.bs, nv, tr,
            tuple(os.environ.get(e) for e in _UFCX_COMPILE_ENV))
     if key not in _ufcx_handles:
         d = _native.UfcxDescT(k.ufcx_source.encode(), k.ufcx_name.encode(), form.rank, V0.element_ndofs, V0.dofmap.bs,
-                              0 if V1 is None else V1.element_ndofs, 0 if V1 is None else V1.dofmap.bs, nv)
+                              0 if V1 is None else V1.element_ndofs, 0 if V1 is None else V1.dofmap.bs, nv,
+                              None if tr[0] is None else tr[0].encode(), None if tr[1] is None else tr[1].encode())
         L = _native.lib()
         h = L.mpcx_ufcx_compile(d)
         if not h:
@@ -419,3 +421,20 @@ def stream_ptr():
     import torch
 
     return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+
+
+def cell_info_ptr(V, kernel):
+    """device pointer of the cell permutation words of V's mesh when ``kernel`` (an imported one) carries dof transformations
+    (include/mpcx.h cell_info0 / cell_info1), else None; uploaded once per mesh"""
+    if getattr(kernel, "ufcx_transforms", None) is None:
+        return None
+    mesh = V.mesh
+    info = getattr(mesh, "cell_permutation_info", None)
+    if info is None:
+        raise ValueError("imported kernel with dof transformations: mesh.cell_permutation_info is not set")
+    dev = _native.require_gpu()
+    key = ("cell_info", str(dev))
+    hit = mesh._device.get(key)
+    if hit is None or hit[0] is not info:
+        hit = mesh._device[key] = (info, _to_dev(np.ascontiguousarray(info, dtype=np.uint32).view(np.int32), dev))
+    return hit[1].data_ptr()

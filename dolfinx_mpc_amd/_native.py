@@ -61,6 +61,8 @@ class UfcxDescT(C.Structure):
         ("nd1", C.c_int32),
         ("bs1", C.c_int32),
         ("nv", C.c_int32),
+        ("transform0_name", C.c_char_p),
+        ("transform1_name", C.c_char_p),
     ]
 
 
@@ -144,6 +146,8 @@ class MatrixArgs(C.Structure):
         ("pair_dict", C.c_void_p),
         ("cube_rec_index", C.c_void_p),
         ("cube_cells", C.c_void_p),
+        ("cell_info0", C.c_void_p),
+        ("cell_info1", C.c_void_p),
         ("stream", C.c_void_p),
     ]
 
@@ -182,6 +186,7 @@ class VectorArgs(C.Structure):
         ("own_seg", C.c_void_p),
         ("n_own_rows", C.c_int64),
         ("cube_cells", C.c_void_p),
+        ("cell_info0", C.c_void_p),
         ("stream", C.c_void_p),
     ]
 
@@ -215,6 +220,8 @@ class LiftingArgs(C.Structure):
         ("lift_entities", C.c_void_p),
         ("n_lift_entities", C.c_int64),
         ("mpc0", MpcT),
+        ("cell_info0", C.c_void_p),
+        ("cell_info1", C.c_void_p),
         ("stream", C.c_void_p),
     ]
 

@@ -1044,6 +1044,7 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
     a.mpc0, a.mpc1 = m0, m1
     a.slave_entities = slave_ents.data_ptr()
     a.n_slave_entities = slave_ents.numel() if with_mpc_kernel else 0
+    a.cell_info0, a.cell_info1 = D.cell_info_ptr(V0, integ.kernel), D.cell_info_ptr(V1, integ.kernel)
     mplan = None
     # master contributions from a plan gathered by target position (no device atomics, no CSR searches in the
     # timed path).  MPCX_MPC_PLAN = device (default: built by a HIP kernel) | host (mpcx_mpc_plan_build; only for

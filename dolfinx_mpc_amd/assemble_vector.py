@@ -287,6 +287,7 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
     a.constants = D.ptr(idv["constants"])
     a.dofmap, a.nd, a.bs = sd["dofmap"].data_ptr(), V.element_ndofs, V.dofmap.bs
     a.mpc = m
+    a.cell_info0 = D.cell_info_ptr(V, integ.kernel)
     a.algorithm = 1
     keep = [md, sd, mkeep, idv]
     a.leftover = None  # (python attribute) cells the cluster kernel does not cover
@@ -600,6 +601,7 @@ def apply_lifting(
             a.scale = float(scale)
             a.lift_entities, a.n_lift_entities = lift.data_ptr(), lift.numel()
             a.mpc0 = m
+            a.cell_info0, a.cell_info1 = D.cell_info_ptr(V0, integ.kernel), D.cell_info_ptr(V1, integ.kernel)
             a.stream = D.stream_ptr()
             _native.check(L.mpcx_apply_lifting(C.byref(a)), "mpcx_apply_lifting")
 

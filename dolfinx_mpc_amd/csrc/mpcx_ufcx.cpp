@@ -43,6 +43,18 @@ const char* const MPCX_FAN_TEXT =
 const char* const KERNELS_TEXT = R"MPCXK(
 #define N0 (ND0 * BS0)
 #define N1 (ND1 * BS1)
+// dof transformations of the imported element (include/mpcx.h mpcx_ufcx_desc_t::transform0_name / transform1_name): applied to
+// the element tensor right after the kernel call, like cpp/assemble_matrix.cpp:507-508 / cpp/assemble_vector.cpp:184
+#ifdef UFCX_T0
+#define UFCX_POST0(A, info, cell, n) UFCX_T0(A, info, (int)(cell), n)
+#else
+#define UFCX_POST0(A, info, cell, n)
+#endif
+#ifdef UFCX_T1
+#define UFCX_POST1(A, info, cell, n) UFCX_T1(A, info, (int)(cell), n)
+#else
+#define UFCX_POST1(A, info, cell, n)
+#endif
 
 __device__ inline void atomic_add_f64(double* p, double v)
 {
@@ -121,6 +133,8 @@ __device__ inline void matrix_item(const mpcx_matrix_args_t& a, long long e, dou
   double cd[NV * 3];
   gather(a.x, a.x_dofmap, cell, cd);
   tabulate(Ae, N0 * N1, a.coeffs, a.cstride, a.constants, cd, e, lf);
+  UFCX_POST0(Ae, a.cell_info0, cell0, N1);
+  UFCX_POST1(Ae, a.cell_info1, cell1, N0);
   // bulk part: Dirichlet and slave rows / columns masked (cpp/assemble_matrix.cpp:510-533, 165-178)
   for (int p = 0; p < N0; ++p)
   {
@@ -154,6 +168,8 @@ __device__ inline void matrix_mpc_item(const mpcx_matrix_args_t& a, long long t,
   double cd[NV * 3];
   gather(a.x, a.x_dofmap, cell, cd);
   tabulate(Ae, N0 * N1, a.coeffs, a.cstride, a.constants, cd, e, lf);
+  UFCX_POST0(Ae, a.cell_info0, cell0, N1);
+  UFCX_POST1(Ae, a.cell_info1, cell1, N0);
   int rows[N0], colsd[N1];
   bool rbc[N0], cbc[N1], rsl[N0], csl[N1];
   for (int p = 0; p < N0; ++p)
@@ -234,6 +250,8 @@ __device__ inline void lifting_item(const mpcx_lifting_args_t& a, long long t, d
   double cd[NV * 3];
   gather(a.x, a.x_dofmap, cell, cd);
   tabulate(Ae, N0 * N1, a.coeffs, a.cstride, a.constants, cd, e, lf);
+  UFCX_POST0(Ae, a.cell_info0, cell0, N1);
+  UFCX_POST1(Ae, a.cell_info1, cell1, N0);
   double be[N0];
   for (int m = 0; m < N0; ++m)
     be[m] = 0.0;
@@ -280,6 +298,7 @@ extern "C" __global__ void __launch_bounds__(64) ufcx_vector_kernel(mpcx_vector_
   gather(a.x, a.x_dofmap, cell, cd);
   double be[N0];
   tabulate(be, N0, a.coeffs, a.cstride, a.constants, cd, e, lf);
+  UFCX_POST0(be, a.cell_info0, cell0, 1);
   for (int p = 0; p < N0; ++p)
   {
     const int d = a.dofmap[cell0 * ND0 + p / BS0] * BS0 + p % BS0;
@@ -447,6 +466,13 @@ extern "C" __global__ void __launch_bounds__(UFCX_RB_THREADS) ufcx_matrix_rowblo
       const unsigned char perm = 0;
       UFCX_FN(Ae, a.coeffs ? a.coeffs + e * a.cstride : (const double*)0, a.constants, cd, &lf, &perm, (void*)0);
     }
+#if defined(UFCX_T0) || defined(UFCX_T1)
+    {
+      const long long lt = e * a.estride;
+      UFCX_POST0(Ae, a.cell_info0, a.entities0 ? a.entities0[lt] : e, N1);
+      UFCX_POST1(Ae, a.cell_info1, a.entities1 ? a.entities1[lt] : e, N0);
+    }
+#endif
     UFCX_UNROLL
     for (int i = 0; i < ND0; ++i)
     {
@@ -510,6 +536,8 @@ extern "C" __global__ void __launch_bounds__(64) ufcx_matrix_mpc_plan_kernel(mpc
       double cd[NV * 3];
       gather(a.x, a.x_dofmap, cell, cd);
       tabulate(Ae, N0 * N1, a.coeffs, a.cstride, a.constants, cd, e, lf);
+      UFCX_POST0(Ae, a.cell_info0, a.entities0 ? a.entities0[l] : e, N1);
+      UFCX_POST1(Ae, a.cell_info1, a.entities1 ? a.entities1[l] : e, N0);
       last = e;
     }
     sum += a.mpc_plan_coef[k] * Ae[a.mpc_plan_pq[k]];
@@ -535,6 +563,8 @@ extern "C" __global__ void __launch_bounds__(64) ufcx_slave_tensors_kernel(mpcx_
   gather(a.x, a.x_dofmap, cell, cd);
   double Ae[N0 * N1];
   tabulate(Ae, N0 * N1, a.coeffs, a.cstride, a.constants, cd, e, lf);
+  UFCX_POST0(Ae, a.cell_info0, a.entities0 ? a.entities0[l] : e, N1);
+  UFCX_POST1(Ae, a.cell_info1, a.entities1 ? a.entities1[l] : e, N0);
 #pragma unroll
   for (int i = 0; i < N0 * N1; ++i)
     a.slave_tensors[(long long)i * a.n_slave_entities + s] = Ae[i];
@@ -593,6 +623,7 @@ extern "C" __global__ void __launch_bounds__(UFCX_RB_THREADS) ufcx_vector_rowblo
     gather(a.x, a.x_dofmap, cell, cd);
     double be[N0];
     tabulate(be, N0, a.coeffs, a.cstride, a.constants, cd, e, lf);
+    UFCX_POST0(be, a.cell_info0, cell0, 1);
     UFCX_UNROLL
     for (int i = 0; i < ND0; ++i)
     {
@@ -647,6 +678,7 @@ extern "C" __global__ void __launch_bounds__(64) ufcx_vector_mpc_kernel(mpcx_vec
     gather(a.x, a.x_dofmap, cell, cd);
     double be[N0];
     tabulate(be, N0, a.coeffs, a.cstride, a.constants, cd, e, lf);
+    UFCX_POST0(be, a.cell_info0, cell0, 1);
     for (int p = 0; p < N0; ++p)
     {
       const int d = a.dofmap[cell0 * ND0 + p / BS0] * BS0 + p % BS0;
@@ -1028,6 +1060,7 @@ struct UfcxKernel
   hipFunction_t matrix = nullptr, matrix_mpc = nullptr, lifting = nullptr, vector = nullptr;
   hipFunction_t matrix_rowblock = nullptr, matrix_mpc_plan = nullptr, vector_rowblock = nullptr, vector_mpc = nullptr;
   hipFunction_t slave_tensors = nullptr, matrix_mpc_gather = nullptr;
+  bool t0 = false, t1 = false; // compiled with dof transformations: the calls need cell_info0 / cell_info1
   // scalar P1 on tetrahedra: the cluster kernels (MPCX_ALG_CUBE)
   bool cube = false;
   hipFunction_t matrix_cube_wide = nullptr, matrix_cube_narrow = nullptr, vector_cube_own = nullptr;
@@ -1295,7 +1328,9 @@ extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
   src += KERNELS_TEXT;
   src += ROWBLOCK_KERNELS_TEXT;
   // scalar P1 on tetrahedra (P1 x P1 for bilinear forms): the cluster kernels as well
-  const bool cube = d->nv == 4 && d->nd0 == 4 && d->bs0 == 1 && (d->rank == 1 || (d->nd1 == 4 && d->bs1 == 1));
+  const bool has_transform = (d->transform0_name && d->transform0_name[0]) || (d->transform1_name && d->transform1_name[0]);
+  // (an element with dof transformations is never P1: the cluster kernels do not carry the hook)
+  const bool cube = !has_transform && d->nv == 4 && d->nd0 == 4 && d->bs0 == 1 && (d->rank == 1 || (d->nd1 == 4 && d->bs1 == 1));
   if (cube)
   {
     std::string f(MPCX_FAN_TEXT);
@@ -1334,6 +1369,10 @@ extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
          "-DUFCX_CUBE_THREADS=" + std::to_string(cube_threads), "-DUFCX_CUBE_PIPE=" + std::to_string(cube_pipe),
          "-DUFCX_CUBE_WAVES=" + std::to_string(cube_waves), "-DUFCX_VCUBE_WAVES=" + std::to_string(vcube_waves),
          "-DUFCX_VCUBE_THREADS=" + std::to_string(vcube_threads)};
+  if (d->transform0_name && d->transform0_name[0])
+    opts.push_back("-DUFCX_T0=" + std::string(d->transform0_name));
+  if (d->rank == 2 && d->transform1_name && d->transform1_name[0])
+    opts.push_back("-DUFCX_T1=" + std::string(d->transform1_name));
   if (fp == "fast" || fp == "finite")
   {
     opts.push_back("-fno-signed-zeros");
@@ -1349,6 +1388,9 @@ extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
     k->desc = *d;
     k->desc.source = nullptr;
     k->desc.function_name = nullptr;
+    k->t0 = d->transform0_name && d->transform0_name[0];
+    k->t1 = d->rank == 2 && d->transform1_name && d->transform1_name[0];
+    k->desc.transform0_name = k->desc.transform1_name = nullptr;
     return k;
   };
   const std::string cached = cache_path(src, opts);
@@ -1435,6 +1477,11 @@ int launch_matrix_ufcx(const mpcx_matrix_args_t& a)
   {
     mpcx_set_error("mpcx_assemble_matrix: the imported kernel was compiled for other element shapes (or is not bilinear)");
     return -12;
+  }
+  if ((k->t0 && !a.cell_info0) || (k->t1 && !a.cell_info1))
+  {
+    mpcx_set_error("mpcx_assemble_matrix: the imported kernel was compiled with dof transformations: cell_info0 / cell_info1 needed");
+    return -5;
   }
   if (a.algorithm == MPCX_ALG_CUBE && !k->cube)
   {
@@ -1528,6 +1575,11 @@ int launch_vector_ufcx(const mpcx_vector_args_t& a)
     mpcx_set_error("mpcx_assemble_vector: the imported kernel was compiled for another element shape (or is not linear)");
     return -12;
   }
+  if (k->t0 && !a.cell_info0)
+  {
+    mpcx_set_error("mpcx_assemble_vector: the imported kernel was compiled with a dof transformation: cell_info0 needed");
+    return -5;
+  }
   if (int rc = ensure_loaded(k))
     return rc;
   int alg = a.algorithm;
@@ -1604,6 +1656,11 @@ int launch_lifting_ufcx(const mpcx_lifting_args_t& a)
   {
     mpcx_set_error("mpcx_apply_lifting: the imported kernel was compiled for other element shapes (or is not bilinear)");
     return -12;
+  }
+  if ((k->t0 && !a.cell_info0) || (k->t1 && !a.cell_info1))
+  {
+    mpcx_set_error("mpcx_apply_lifting: the imported kernel was compiled with dof transformations: cell_info0 / cell_info1 needed");
+    return -5;
   }
   if (int rc = ensure_loaded(k))
     return rc;

@@ -1,4 +1,5 @@
-"""General Lagrange elements of the host stand-in layer: degree 1-3 on triangles and quadrilaterals (what the
+"""General Lagrange elements of the host stand-in layer (degree 4 on all four cell types since round 5: the degree
+python/tests/test_multispace_mpc.py:12-16 sweeps): degree 1-3 on triangles and quadrilaterals (what the
 reference's own assembly tests sweep -- python/tests/test_matrix_assembly.py:23-26, test_vector_assembly.py:22-24:
 ``degree in range(1, 4)``, ``celltype in [triangle, quadrilateral]``), P3 on tetrahedra and Q2 / Q3 on hexahedra
 (python/tests/test_stokes_channelflow.py:21-23: Taylor-Hood of order 2 and 3 on both cell types).  DOLFINx / Basix are absent here, so this module defines
@@ -58,14 +59,24 @@ def reference_nodes(cell: str, degree: int):
             pos.append(k - 1)
     d = V.shape[1]
     if cell == "tetrahedron" and p >= 3:
-        if p > 3:
-            raise NotImplementedError("tetrahedra: degree 1-3 (several nodes on a shared triangular face need an orientation rule)")
+        if p > 4:
+            raise NotImplementedError("tetrahedra: degree 1-4")
         from .mesh import TET_FACETS
 
         for f, fv in enumerate(TET_FACETS):
-            pts.append(V[list(fv)].mean(axis=0))
-            ent.append((2, f))
-            pos.append(0)
+            if p == 3:
+                pts.append(V[list(fv)].mean(axis=0))
+                ent.append((2, f))
+                pos.append(0)
+            else:
+                # P4: three nodes inside a triangular face, node k the one nearest to the face's k-th vertex (barycentric
+                # weights 2/4, 1/4, 1/4); two tets sharing the face agree on them through the GLOBAL ids of the face's
+                # vertices (build_dofmap: position = rank of the node's vertex among the three)
+                P = V[list(fv)]
+                for k in range(3):
+                    pts.append((P.sum(axis=0) + P[k]) / 4.0)
+                    ent.append((2, f))
+                    pos.append(k)
     if cell == "hexahedron":
         for f, fv in enumerate(_HEX_FACES):
             n = 0
@@ -189,16 +200,23 @@ def build_dofmap(mesh, degree: int):
                 out[:, col] = off + g * ne_nodes + kk
         off += ev.shape[0] * ne_nodes
     col = nv + le.shape[0] * ne_nodes
-    if cell == "tetrahedron" and p == 3:
+    if cell == "tetrahedron" and p in (3, 4):
         from .mesh import TET_FACETS
 
         fv = np.sort(cells[:, TET_FACETS], axis=2).reshape(nc * 4, 3)
         _, inv = np.unique(fv, axis=0, return_inverse=True)
         inv = inv.reshape(nc, 4)
+        nf = 1 if p == 3 else 3  # nodes inside a triangular face
         for f in range(4):
-            out[:, col + f] = off + inv[:, f]
-        off += int(inv.max()) + 1
-        col += 4
+            if p == 3:
+                out[:, col + f] = off + inv[:, f]
+            else:
+                g = cells[:, TET_FACETS[f]]  # (nc, 3) global vertices of the face in local order
+                rank = np.argsort(np.argsort(g, axis=1), axis=1)  # rank of every local face vertex among the three
+                for k in range(3):  # local face node k sits next to local face vertex k
+                    out[:, col + f * 3 + k] = off + inv[:, f].astype(np.int64) * 3 + rank[:, k]
+        off += (int(inv.max()) + 1) * nf
+        col += 4 * nf
     if cell == "hexahedron" and p >= 2:
         fv = np.sort(cells[:, _HEX_FACES], axis=2).reshape(nc * 6, 4)
         _, inv = np.unique(fv, axis=0, return_inverse=True)

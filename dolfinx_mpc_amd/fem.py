@@ -94,13 +94,13 @@ class FunctionSpace:
             raise NotImplementedError(f"element family {family}")
         # general Lagrange elements (elements.py): degree 3 on triangles / tetrahedra, Q1-Q3 on quadrilaterals, Q2 / Q3 on hexahedra -- the
         # cell / degree sweep of python/tests/test_matrix_assembly.py:23-26; their forms run generated (imported) kernels
-        self.general = (mesh.cell_name == "quadrilateral" and degree in (1, 2, 3)) or (mesh.cell_name in ("triangle", "tetrahedron") and degree == 3) \
-            or (mesh.cell_name == "hexahedron" and degree in (2, 3))
+        self.general = (mesh.cell_name == "quadrilateral" and degree in (1, 2, 3, 4)) or (mesh.cell_name in ("triangle", "tetrahedron") and degree in (3, 4)) \
+            or (mesh.cell_name == "hexahedron" and degree in (2, 3, 4))
         if not self.general:
             if degree not in (1, 2):
-                raise NotImplementedError("Lagrange degree 1-3")
+                raise NotImplementedError("Lagrange degree 1-4")
             if mesh.cell_name == "hexahedron" and degree != 1:
-                raise NotImplementedError("hexahedra: Q1-Q3")
+                raise NotImplementedError("hexahedra: Q1-Q4")
         self.mesh = mesh
         self.degree = degree
         bs = 1 if not shape else int(np.prod(shape))  # vector (d,) and tensor (d, d) valued spaces: blocked dofs
@@ -432,6 +432,10 @@ class KernelSpec:
     # kernels of MPCX_ALG_CUBE take the bulk of the cells; constrained cells, lifting and the plan-free algorithm
     # keep running the imported kernel)
     builtin: Optional["KernelSpec"] = None
+    # FORM_UFCX: names of the element's dof transformations defined in ufcx_source, (test space, trial space transposed), or
+    # None (every Lagrange element) -- include/mpcx.h mpcx_ufcx_desc_t::transform0_name; cell_info comes from the mesh
+    # (Mesh.cell_permutation_info)
+    ufcx_transforms: Optional[tuple] = None
 
 
 class Integral:
@@ -762,7 +766,7 @@ def form_source(V, fn_id: int = FN_ONE, constant=None, coefficient: Optional[Fun
 
 
 def form_ufcx(spaces: Sequence[FunctionSpace], source: str, function_name: str, itype: str = "cell", entities=None,
-              coefficient=None, constant=None, builtin: Optional[KernelSpec] = None) -> Form:
+              coefficient=None, constant=None, builtin: Optional[KernelSpec] = None, dof_transformations=None) -> Form:
     """A form whose element kernel is an imported UFCx ``tabulate_tensor`` given as C SOURCE (what FFCx
     writes to disk; the reference calls the compiled function through a pointer,
     cpp/assemble_matrix.cpp:438-439).  ``spaces`` = [V] (linear form) or [V0, V1] (bilinear form: rows V0,
@@ -791,6 +795,16 @@ def form_ufcx(spaces: Sequence[FunctionSpace], source: str, function_name: str, 
     if V1 is not None:
         k.degree1, k.bs1 = V1.degree, V1.dofmap.bs
     k.builtin = builtin
+    if dof_transformations is not None:
+        # (name of the test space's transformation, name of the trial space's transposed one) -- functions of ``source`` with
+        # the shape ``void T(double* A, const uint32_t* cell_info, int32_t cell, int32_t n)`` that the reference applies right
+        # after the kernel call (cpp/assemble_matrix.cpp:507-508, cpp/assemble_vector.cpp:184); the cell permutation words
+        # are the meshes' ``cell_permutation_info`` (uint32 per cell)
+        t = tuple(dof_transformations) if not isinstance(dof_transformations, str) else (dof_transformations,)
+        k.ufcx_transforms = (t[0], t[1] if len(t) > 1 else None)
+        for V in spaces:
+            if getattr(V.mesh, "cell_permutation_info", None) is None:
+                raise ValueError("form_ufcx(dof_transformations=...): mesh.cell_permutation_info (uint32 per cell) is not set")
     return Form(spaces, [Integral(itype, ents, k, coefficient, _constants(constant))])
 
 

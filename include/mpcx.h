@@ -25,8 +25,10 @@ extern "C" {
 
 /* 4: mpcx_matrix_args_t::cube_flags (in the padding after cube_rec_bytes), hexahedron and closed-form cluster entry points
  * 5: pair records, scalar types;  6: mpcx_matrix_args_t::cube_rec_index (one cluster record per cluster, before ``stream``)
- * 7: cube_cells, last field before ``stream`` of the matrix and the vector argument block: MPCX_ALG_CUBE with imported (UFCx) kernels */
-#define MPCX_VERSION 7
+ * 7: cube_cells, last field before ``stream`` of the matrix and the vector argument block: MPCX_ALG_CUBE with imported (UFCx) kernels
+ * 8: dof transformations of imported kernels: transform0_name / transform1_name of the descriptor, cell_info0 / cell_info1 of
+ *    the three argument blocks (before ``stream``) */
+#define MPCX_VERSION 8
 
 /* Offsets into the CSR value / column arrays (rowptr entries, positions): 64-bit, so that one GPU can
  * hold matrices with more than 2^31 - 1 stored entries (Taylor-Hood a00 on 128^3 cells: 4.4 G) -- PETSc's
@@ -123,6 +125,16 @@ typedef struct
   int32_t nd0; int32_t bs0;  /* test space: dofs per cell, block size */
   int32_t nd1; int32_t bs1;  /* trial space (rank 2) */
   int32_t nv;                /* geometry nodes per cell */
+  /* Dof transformations, optional (NULL: none -- every Lagrange element): names of functions DEFINED IN ``source`` with the
+   * shape of the std::function the reference applies to the element tensor right after the kernel call
+   * (cpp/assemble_matrix.cpp:432-436, 507-508; cpp/assemble_vector.cpp:184; cpp/lifting.h),
+   *     void T(double* A, const uint32_t* cell_info, int32_t cell, int32_t n);
+   * transform0_name: the test space's transformation, A = [nd0 * bs0][n] row-major (n = nd1 * bs1; 1 for a linear form):
+   * acts on the ROWS of cell ``cell`` of the test space's mesh; transform1_name (bilinear forms): the trial space's transposed
+   * transformation, A = [n][nd1 * bs1] with n = nd0 * bs0: acts on the COLUMNS.  cell_info is the per-cell permutation word
+   * of the mesh (DOLFINx ``Topology::get_cell_permutation_info``), handed in through the argument blocks. */
+  const char* transform0_name;
+  const char* transform1_name;
 } mpcx_ufcx_desc_t;
 void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* desc);
 /* 1 if the element tensor (nd0 * bs0 * nd1 * bs1 > 12288 entries, e.g. vector-valued Q3 hexahedra: 192 x 192) does not fit a
@@ -322,6 +334,11 @@ typedef struct
    * additionally need cube_cells, DEVICE [n_clusters][6]: the CELL of table row t (index into coeffs), and
    * plan.block_ents = the cluster of every slot of this launch.  NULL otherwise. */
   const int32_t* cube_cells;
+  /* imported kernels compiled with dof transformations (mpcx_ufcx_desc_t::transform0_name / transform1_name): DEVICE
+   * [num_cells] uint32, the cell permutation words of the test / trial space's mesh (cpp/assemble_matrix.cpp:606-616);
+   * NULL otherwise */
+  const uint32_t* cell_info0;
+  const uint32_t* cell_info1;
   void* stream;
 } mpcx_matrix_args_t;
 
@@ -559,6 +576,7 @@ typedef struct
   /* MPCX_ALG_CUBE with an imported kernel and coefficients: DEVICE [n_cubes][6], the cell of every cluster tet in the order
    * (0,1,3,7) (0,1,7,5) (0,5,7,4) (0,3,2,7) (0,6,4,7) (0,2,6,7) (see mpcx_matrix_args_t::cube_cells); NULL otherwise */
   const int32_t* cube_cells;
+  const uint32_t* cell_info0; /* the same for the linear form's space, cpp/assemble_vector.cpp:184, or NULL */
   void* stream;
 } mpcx_vector_args_t;
 
@@ -587,6 +605,8 @@ typedef struct
   double scale;
   const int32_t* lift_entities; int64_t n_lift_entities; /* DEVICE */
   mpcx_mpc_t mpc0;
+  const uint32_t* cell_info0; /* as in mpcx_matrix_args_t, or NULL */
+  const uint32_t* cell_info1;
   void* stream;
 } mpcx_lifting_args_t;
 

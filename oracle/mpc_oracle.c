@@ -475,6 +475,18 @@ void oracle_tabulate_source_p1_tet(double* A, const double* w, const double* c,
 static oracle_tabulate_fn g_user_kernel = 0;
 void oracle_set_user_kernel(oracle_tabulate_fn fn) { g_user_kernel = fn; }
 
+/* dof transformations of an imported element, applied to the element tensor right after the kernel call
+ * (cpp/assemble_matrix.cpp:432-436, 507-508: apply_dof_transformation(_Ae, cell_info0, cell0, ndim1) and
+ * apply_dof_transformation_to_transpose(_Ae, cell_info1, cell1, ndim0); cpp/assemble_vector.cpp:184; cpp/lifting.h): the
+ * caller hands in the two functions and the cell permutation words, NULL = none (every Lagrange element) */
+typedef void (*oracle_transform_fn)(double*, const uint32_t*, int32_t, int32_t);
+static oracle_transform_fn g_t0 = 0, g_t1 = 0;
+static const uint32_t *g_info0 = 0, *g_info1 = 0;
+void oracle_set_dof_transformations(oracle_transform_fn t0, oracle_transform_fn t1, const uint32_t* info0, const uint32_t* info1)
+{
+  g_t0 = t0, g_t1 = t1, g_info0 = info0, g_info1 = info1;
+}
+
 static oracle_tabulate_fn pick_kernel(int which)
 {
   switch (which)
@@ -703,6 +715,10 @@ int oracle_assemble_matrix(oracle_csr* A, int which, const oracle_kernel_desc* d
     memset(Aeb, 0, sizeof(double) * ndim0 * ndim1);
     kernel(Aeb, coeffs ? coeffs + (size_t)index * cstride : NULL, constants, coordinate_dofs,
            estride == 2 ? &local_facet : NULL, NULL, (void*)desc);
+    if (which == 100 && g_t0) /* cpp/assemble_matrix.cpp:507 */
+      g_t0(Aeb, g_info0, cell0, ndim1);
+    if (which == 100 && g_t1) /* :508 */
+      g_t1(Aeb, g_info1, cell1, ndim0);
 
     const int32_t* dofs0 = dofmap0 + (size_t)cell0 * nd0;
     const int32_t* dofs1 = dofmap1 + (size_t)cell1 * nd1;
@@ -805,6 +821,8 @@ int oracle_assemble_vector(double* b, int which, const oracle_kernel_desc* desc,
     memset(be, 0, sizeof(double) * n);
     kernel(be, coeffs ? coeffs + (size_t)e * cstride : NULL, constants, coordinate_dofs,
            estride == 2 ? &local_facet : NULL, NULL, (void*)desc);
+    if (which == 100 && g_t0) /* cpp/assemble_vector.cpp:184 */
+      g_t0(be, g_info0, cell0, 1);
     const int32_t* dofs = dofmap + (size_t)cell0 * nd;
     const int ns = mpc->c2s_offsets[cell0 + 1] - mpc->c2s_offsets[cell0];
     if (ns > 0)
@@ -866,6 +884,10 @@ int oracle_apply_lifting(double* b, int which, const oracle_kernel_desc* desc,
     memset(Ae, 0, sizeof(double) * num_rows * num_cols);
     kernel(Ae, coeffs ? coeffs + (size_t)e * cstride : NULL, constants, coordinate_dofs,
            estride == 2 ? &local_facet : NULL, NULL, (void*)desc);
+    if (which == 100 && g_t0) /* cpp/lifting.h: the same two transformations as in the matrix loop */
+      g_t0(Ae, g_info0, cell0, num_cols);
+    if (which == 100 && g_t1)
+      g_t1(Ae, g_info1, cell1, num_rows);
     memset(be, 0, sizeof(double) * num_rows);
     for (int j = 0; j < nd1; ++j)
       for (int k = 0; k < bs1; ++k)

@@ -39,6 +39,8 @@ typedef void (*oracle_tabulate_fn)(double* A, const double* w, const double* c,
 
 /* which == 100 in the entry points below: call this function (a UFCx tabulate_tensor compiled by the caller) */
 void oracle_set_user_kernel(oracle_tabulate_fn fn);
+void oracle_set_dof_transformations(void (*t0)(double*, const uint32_t*, int32_t, int32_t), void (*t1)(double*, const uint32_t*, int32_t, int32_t),
+                                    const uint32_t* info0, const uint32_t* info1);
 
 /* form kinds */
 enum {

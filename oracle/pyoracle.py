@@ -274,7 +274,33 @@ def _load_user_kernel(k):
         _user_libs[key] = C.CDLL(so)
     fn = getattr(_user_libs[key], k.ufcx_name)
     lib().oracle_set_user_kernel(C.cast(fn, C.c_void_p))
+    # dof transformations of the element (cpp/assemble_matrix.cpp:507-508): functions of the same text + the cell permutation
+    # words of the meshes; reset for kernels without any
+    tr = getattr(k, "ufcx_transforms", None)
+    L = lib()
+    L.oracle_set_dof_transformations.argtypes = [C.c_void_p] * 4
+    if tr is None:
+        L.oracle_set_dof_transformations(None, None, None, None)
+    else:
+        t0 = None if tr[0] is None else C.cast(getattr(_user_libs[key], tr[0]), C.c_void_p)
+        t1 = None if tr[1] is None else C.cast(getattr(_user_libs[key], tr[1]), C.c_void_p)
+        info = _cell_info_of.get("current")
+        L.oracle_set_dof_transformations(t0, t1, None if info is None else info[0].ctypes.data, None if info is None else info[1].ctypes.data)
     return 100
+
+
+# the cell permutation words (uint32 per cell) of the test / trial space's mesh for the NEXT imported kernel with dof
+# transformations: set by assemble_matrix / assemble_vector / apply_lifting from the form's spaces
+_cell_info_of = {}
+
+
+def _set_cell_info(V0, V1=None):
+    i0 = getattr(V0.mesh, "cell_permutation_info", None)
+    i1 = getattr((V1 or V0).mesh, "cell_permutation_info", None)
+    if i0 is None:
+        _cell_info_of.pop("current", None)
+    else:
+        _cell_info_of["current"] = (np.ascontiguousarray(i0, dtype=np.uint32), np.ascontiguousarray(i1, dtype=np.uint32))
 
 
 def _which(k, fast: bool):
@@ -331,6 +357,7 @@ def assemble_matrix(form, mpc0: OracleMPC, mpc1: OracleMPC = None, bcs=(), diagv
             bc.mark_dofs(bc1)
     x = form.mesh.geometry.x
     xd = form.mesh.geometry.dofmap
+    _set_cell_info(V0, V1)
     for integ in form.integrals:
         d, keep = _desc(integ.kernel)
         e = _ents(integ)
@@ -377,6 +404,7 @@ def assemble_vector(form, mpc: OracleMPC, b=None, fast=False, raw_b=None):
         b[:] = 0.0
     x = form.mesh.geometry.x
     xd = form.mesh.geometry.dofmap
+    _set_cell_info(V)
     for integ in form.integrals:
         d, keep = _desc(integ.kernel)
         e = _ents(integ)
@@ -411,6 +439,7 @@ def apply_lifting(b, forms, bcs, mpc: OracleMPC, x0=None, scale=1.0, fast=False)
         x0j = np.ascontiguousarray(x0[j], dtype=np.float64) if len(x0) else None
         x = aj.mesh.geometry.x
         xd = aj.mesh.geometry.dofmap
+        _set_cell_info(V0, V1)
         for integ in aj.integrals:
             d, keep = _desc(integ.kernel)
             e = _ents(integ)

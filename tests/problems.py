@@ -359,17 +359,24 @@ def element_sweep_cases() -> List[Callable[[], Case]]:
     # the order-3 members of python/tests/test_stokes_channelflow.py:21-23 in 3D: P3 tetrahedra, Q3 hexahedra
     out.append(lambda: case_cube_p3_periodic("tetrahedron", 2))
     out.append(lambda: case_cube_p3_periodic("hexahedron", 2))
+    # degree 4 (python/tests/test_multispace_mpc.py:16 sweeps it): triangles / quadrilaterals with the dictionary constraint,
+    # P4 tetrahedra (35 dofs per cell, three per shared face), Q4 hexahedra (125 dofs per cell)
+    out.append(lambda: case_square_dict(4, (1, 1), (5, 3), "triangle"))
+    out.append(lambda: case_square_dict(4, (0, 1), (3, 4), "quadrilateral"))
+    out.append(lambda: case_cube_p3_periodic("tetrahedron", 2, degree=4))
+    out.append(lambda: case_cube_p3_periodic("hexahedron", 1, degree=4))
     return out
 
 
-def case_cube_p3_periodic(cell, N=2) -> Case:
-    """periodic Poisson with degree 3 on tetrahedra (20 dofs per cell, one per face) / hexahedra (64 dofs per cell, four per
-    face: more dof blocks than a row-block plan lists per entity, so 'auto' takes the per-entity kernels)"""
+def case_cube_p3_periodic(cell, N=2, degree=3) -> Case:
+    """periodic Poisson with degree 3 / 4 on tetrahedra (20 / 35 dofs per cell, one / three per face) / hexahedra (64 / 125 dofs
+    per cell, four / nine per face: more dof blocks than a row-block plan lists per entity, so 'auto' takes the per-entity
+    kernels)"""
     mesh = create_unit_cube(N, N, N, cell)
-    V = fem.functionspace(mesh, ("Lagrange", 3))
+    V = fem.functionspace(mesh, ("Lagrange", degree))
     bc = fem.dirichletbc(0.2, fem.locate_dofs_geometrical(V, _walls_yz), V)
     a = fem.form_stiffness(V) + fem.form_mass(V, constant=0.7)
-    return Case(f"{cell[:3]}_p3_periodic_n{N}", V, a, fem.form_source(V, fem.FN_POLY3), [bc], periodic_raw(V, [bc]))
+    return Case(f"{cell[:3]}_p{degree}_periodic_n{N}", V, a, fem.form_source(V, fem.FN_POLY3), [bc], periodic_raw(V, [bc]))
 
 
 def case_hex_q2_periodic(N=3) -> Case:

@@ -331,13 +331,13 @@ def test_periodic_slaves_of_tensor_spaces(tensor_order, poly_order):
         assert np.allclose(xc[mm // bs], xc[s // bs] + [1.0, 0.0, 0.0])
 
 
-@pytest.mark.parametrize("cell_type,degrees", [("quadrilateral", (1, 2, 3)), ("hexahedron", (1, 2)), ("tetrahedron", (1, 2)),
-                                               ("triangle", (1, 2, 3))])
+@pytest.mark.parametrize("cell_type,degrees", [("quadrilateral", (1, 2, 3, 4)), ("hexahedron", (1, 2, 4)), ("tetrahedron", (1, 2, 4)),
+                                               ("triangle", (1, 2, 3, 4))])
 @pytest.mark.parametrize("N", [3, 5, 8])
 def test_multiple_mpc_spaces_sparsity(cell_type, degrees, N):
     """python/tests/test_multispace_mpc.py:12-77: the pattern of a rectangular block with constraints on two DISTINCT
-    (cloned) spaces has as many entries as with one constraint on both sides (degrees: those this package's elements
-    cover; the reference sweeps 1, 2, 4)"""
+    (cloned) spaces has as many entries as with one constraint on both sides (the reference sweeps degrees 1, 2, 4 on all four
+    cell types; degree 4 is laid out since round 5, dolfinx_mpc_amd/elements.py)"""
     import dolfinx_mpc_amd as dm
     from dolfinx_mpc_amd import fem
     from dolfinx_mpc_amd.mesh import create_unit_cube, create_unit_square

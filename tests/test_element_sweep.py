@@ -19,7 +19,8 @@ from problems import element_sweep_cases, oracle_mpc, oracle_outputs, product_ou
 CASES = element_sweep_cases()
 IDS = [f"el{i}" for i in range(len(CASES))]
 ELEMENTS = [("triangle", 1), ("triangle", 2), ("triangle", 3), ("quadrilateral", 1), ("quadrilateral", 2), ("quadrilateral", 3),
-            ("tetrahedron", 1), ("tetrahedron", 2), ("tetrahedron", 3), ("hexahedron", 1), ("hexahedron", 2), ("hexahedron", 3)]
+            ("tetrahedron", 1), ("tetrahedron", 2), ("tetrahedron", 3), ("hexahedron", 1), ("hexahedron", 2), ("hexahedron", 3),
+            ("triangle", 4), ("quadrilateral", 4), ("tetrahedron", 4), ("hexahedron", 4)]
 
 
 @pytest.mark.parametrize("cell,degree", ELEMENTS)
