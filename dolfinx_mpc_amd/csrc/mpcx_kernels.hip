@@ -1464,8 +1464,8 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) vector_rowblock_kernel(m
 // takes the place of the masked dofmap -- no range tests, no stores from the quadrature loop's neighbourhood (the
 // kernel sits at its register bound).  At the end the own part is added to b and the halo part is written out
 // contiguously; vector_spill_reduce_kernel adds it to the rows it belongs to.
-template <class Op, bool SPLIT = false>
-__global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) vector_ownblock_kernel(mpcx_vector_args_t a)
+template <class Op, bool SPLIT = false, int MAXT = ROWBLOCK_MAX_THREADS>
+__global__ void __launch_bounds__(MAXT) vector_ownblock_kernel(mpcx_vector_args_t a)
 {
   constexpr int N = Op::N0, ND = Op::ND0, BS = Op::BS0, NV = Op::NV;
   constexpr int LMASK = (1 << MPCX_MASK_SHIFT) - 1;
@@ -2006,6 +2006,9 @@ int launch_vector(const mpcx_vector_args_t& a)
     }
     if constexpr (BY_COMPONENT)
     {
+      // (round 5, measured and not kept: all components in ONE pass over the points -- a third of the geometry / point work,
+      // 3 x ND accumulators, compiled for 512 threads and up to 256 registers: Stokes b0 at 128^3 1.95 ms (512 threads),
+      // 1.89 (256), 2.34 (384) against 1.47 ms by component)
       if (split)
         lrc = owner ? launch(vector_ownblock_kernel<Op, true>) : launch(vector_rowblock_kernel<Op, true>);
     }
