@@ -519,10 +519,52 @@ def main():
     torch.cuda.set_device(dev_index)
     backend = os.environ.get("MPCX_DIST_BACKEND", "nccl")  # gloo: several ranks on one GPU (smoke test of N > 1)
     if world > 1:
+        # A multi-rank run must fail loudly, never hang (RCCL has not carried this exchange on hardware yet):
+        #  * every collective / send-recv has a timeout (the process-group watchdog aborts the rank when it expires),
+        #  * a watchdog thread ends the process after MPCX_BENCH_WATCHDOG_S seconds (default 1500) with a diagnostic JSON line,
+        #  * a pre-flight exchange over the transport (all-reduce + the neighbour send / receive pattern of the interface
+        #    exchange, a few bytes) runs before the minutes of set-up and says what failed if it does.
+        import datetime
+        import threading
+
+        limit = float(os.environ.get("MPCX_BENCH_WATCHDOG_S", 1500))
+
+        def _watchdog():
+            print(json.dumps({"error": f"bench.py rank {rank}: no result after {limit:.0f} s (hung collective or exchange?)",
+                              "n_gpus": world, "transport": backend, "metric": "assembled DoFs/sec", "value": None}), flush=True)
+            os._exit(3)
+
+        wd = threading.Timer(limit, _watchdog)
+        wd.daemon = True
+        wd.start()
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        tmo = datetime.timedelta(seconds=float(os.environ.get("MPCX_DIST_TIMEOUT_S", 180)))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
+        t_pf = time.time()
+        try:
+            cdev = torch.device("cuda", dev_index) if backend == "nccl" else torch.device("cpu")
+            one = torch.ones(1, dtype=torch.int64, device=cdev)
+            dist.all_reduce(one)
+            assert int(one.item()) == world, f"all-reduce over {world} ranks gave {int(one.item())}"
+            sb, rb = torch.full((4,), float(rank), dtype=torch.float64, device=cdev), torch.zeros(4, dtype=torch.float64, device=cdev)
+            ops = []
+            if rank + 1 < world:
+                ops.append(dist.P2POp(dist.isend, sb, rank + 1))
+            if rank > 0:
+                ops.append(dist.P2POp(dist.irecv, rb, rank - 1))
+            for wk in dist.batch_isend_irecv(ops) if ops else []:
+                wk.wait()
+            if cdev.type == "cuda":
+                torch.cuda.synchronize()
+            assert rank == 0 or float(rb[0]) == float(rank - 1), "neighbour send / receive delivered the wrong data"
+            log(f"pre-flight over {backend}: all-reduce + neighbour exchange ok ({time.time() - t_pf:.2f} s)")
+        except Exception as e:  # noqa: BLE001
+            print(json.dumps({"error": f"bench.py rank {rank}: pre-flight exchange over {backend} failed: {e}", "n_gpus": world,
+                              "transport": backend, "metric": "assembled DoFs/sec", "value": None}), flush=True)
+            os._exit(4)
 
     # ---- set-up: mesh, space, constraint, forms (host), pattern (device), matrices -------------------
     t_setup = time.time()
