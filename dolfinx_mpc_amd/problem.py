@@ -152,11 +152,21 @@ def cg(A: MPCMatrix, b: Vector, x: Optional[Vector] = None, rtol: float = 1e-10,
                "converged": bool(converged)}
 
 
+
+def _warn_unused_options(where: str, unused: dict):
+    """solver options this backend does not know are reported, not dropped silently (a PETSc-style ``ksp_rtol`` handed
+    to a routine that spells it ``rtol`` used to vanish)"""
+    if unused:
+        import warnings
+
+        warnings.warn(f"dolfinx_mpc_amd.{where}: unrecognised solver options ignored: {sorted(unused)}", RuntimeWarning, stacklevel=3)
+
 def multigrid_cg(A: MPCMatrix, b: Vector, V, x: Optional[Vector] = None, rtol: float = 1e-10, atol: float = 0.0,
                  max_it: int = 500, **_unused):
     """Solve A x = b by CG preconditioned with a smoothed-aggregation V-cycle built from A and the dof coordinates of
     ``V`` (dolfinx_mpc_amd/amg.py).  Returns (x, info); info also carries the set-up time, the level sizes and the
     operator complexity."""
+    _warn_unused_options("multigrid_cg", _unused)
     import time
 
     import torch
@@ -200,6 +210,7 @@ def fieldsplit_minres(A: Sequence[Sequence[Optional[MPCMatrix]]], b: Sequence[Ve
     identity; ``pc_types[i]``: ``"gamg"`` (one smoothed-aggregation V-cycle, dolfinx_mpc_amd/amg.py), ``"jacobi"`` or
     ``"none"``; default: ``gamg`` for the first block, ``jacobi`` for the others (the reference's demo set-up).
     Returns (list of solution tensors, info)."""
+    _warn_unused_options("fieldsplit_minres", _unused)
     import time
 
     import torch
@@ -457,7 +468,9 @@ class NonlinearProblem:
         return self._b
 
     def assemble_jacobian(self) -> MPCMatrix:
-        """problem.py:26-85 (u already holds the current iterate)"""
+        """problem.py:26-85: the reference's callback copies x into u and imposes the constraint before it assembles
+        (problem.py:60-72), so that a call on its own after changing ``problem.x`` sees the current iterate"""
+        self._assign_u()
         assemble_matrix(self._J, self.mpc, bcs=self.bcs, diagval=1.0, A=self._A)
         return self._A
 
@@ -504,31 +517,39 @@ class NonlinearProblem:
         self._x.array.copy_(torch.from_numpy(np.ascontiguousarray(self._u.x.array, dtype=np.float64)))
         self.info = {"residual_norms": []}
         reason, it = 0, 0
-        f0 = None
-        while True:
-            b = self.assemble_residual()
-            fn = float(torch.linalg.vector_norm(b.array))
-            self.info["residual_norms"].append(fn)
-            if not np.isfinite(fn):
-                reason = -4  # SNES_DIVERGED_FNORM_NAN
-                break
-            f0 = fn if f0 is None else f0
-            if fn < atol:
-                reason = 2
-                break
-            if it > 0 and fn <= rtol * f0:
-                reason = 3
-                break
-            if it >= max_it:
-                reason = -5
-                break
+        b = self.assemble_residual()
+        f0 = fn = float(torch.linalg.vector_norm(b.array))
+        self.info["residual_norms"].append(fn)
+        if not np.isfinite(fn):
+            reason = -4  # SNES_DIVERGED_FNORM_NAN
+        elif fn < atol:
+            reason = 2
+        elif max_it <= 0:
+            reason = -5
+        while reason == 0:
             self.assemble_jacobian()
             dx = self._linear_solve(opts)
             self._x.array.sub_(dx)
             it += 1
-            if float(torch.linalg.vector_norm(dx)) < stol * float(torch.linalg.vector_norm(self._x.array)):
+            # PETSc's SNESConvergedDefault order: the NEW residual first (atol, then rtol), the step size last
+            dxn, xn = float(torch.linalg.vector_norm(dx)), float(torch.linalg.vector_norm(self._x.array))
+            b = self.assemble_residual()
+            fn = float(torch.linalg.vector_norm(b.array))
+            self.info["residual_norms"].append(fn)
+            if not np.isfinite(fn):
+                reason = -4
+                break
+            if fn < atol:
+                reason = 2
+                break
+            if fn <= rtol * f0:
+                reason = 3
+                break
+            if dxn < stol * xn:
                 reason = 4
-                self.assemble_residual()  # leaves u = the final iterate with the constraint imposed
+                break
+            if it >= max_it:
+                reason = -5
                 break
         self._assign_u()
         self.info.update(iterations=it, converged_reason=reason)

@@ -32,7 +32,8 @@ ONE = None
 if "--one" in sys.argv:  # child mode: one rank of one cut in a fresh process (as the N-GPU job runs it), one JSON line
     k = sys.argv.index("--one")
     ONE = (int(sys.argv[k + 1]), int(sys.argv[k + 2]))
-for world in ((ONE[0],) if ONE else (1, 2, 4, 8)):
+WORLDS = tuple(int(v) for v in os.environ.get("MPCX_SLAB_WORLDS", "1,2,4,8").split(","))  # (config 5 at 384^3: "8" -- one GPU cannot hold it)
+for world in ((ONE[0],) if ONE else WORLDS):
     ranks = []
     for rank in ((ONE[1],) if ONE else range(world)):
         if ONE is None:
@@ -102,8 +103,9 @@ for world in ((ONE[0],) if ONE else (1, 2, 4, 8)):
     ndofs = (N + 1) ** 3 if config == 2 else (2 * N + 1) ** 3
     out["worlds"][world] = {"ranks": ranks, "slowest_rank_step_us": slow, "exchange_matrix_us": ex_m, "exchange_vector_us": ex_v,
                             "predicted_step_us": slow + exposed, "predicted_DoFs_per_s": ndofs / ((slow + exposed) * 1e-6)}
-base = out["worlds"][1]["predicted_step_us"]
-for world, d in out["worlds"].items():
-    d["predicted_speedup"] = base / d["predicted_step_us"]
-    d["predicted_efficiency"] = d["predicted_speedup"] / world
+if 1 in out["worlds"]:
+    base = out["worlds"][1]["predicted_step_us"]
+    for world, d in out["worlds"].items():
+        d["predicted_speedup"] = base / d["predicted_step_us"]
+        d["predicted_efficiency"] = d["predicted_speedup"] / world
 print(json.dumps(out, indent=1))
