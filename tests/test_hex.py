@@ -129,8 +129,10 @@ def test_hex_mesh_topology():
     assert V2.element_ndofs == 27 and V2.num_dofs == 7 * 9 * 11
     V3 = fem.functionspace(mesh, ("Lagrange", 3))  # Q3: 64 dofs per cell, four nodes per face in the face's global frame
     assert V3.element_ndofs == 64 and V3.num_dofs == 10 * 13 * 16
+    V4 = fem.functionspace(mesh, ("Lagrange", 4))  # Q4 (round 5): 125 dofs per cell, nine nodes per face
+    assert V4.element_ndofs == 125 and V4.num_dofs == 13 * 17 * 21
     with pytest.raises(NotImplementedError):
-        fem.functionspace(mesh, ("Lagrange", 4))
+        fem.functionspace(mesh, ("Lagrange", 5))
 
 
 def test_tiled_hex_mesh_is_the_same_mesh():
