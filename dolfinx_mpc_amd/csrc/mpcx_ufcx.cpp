@@ -1157,8 +1157,14 @@ int ensure_loaded(UfcxKernel* k)
 // written to a temporary name and renamed, so concurrent processes never read a partial file.
 std::string cache_dir()
 {
+  // MPCX_UFCX_CACHE=<dir> | 0 (off).  Unset (round 5): a per-user directory under the temporary directory -- the reference's
+  // JIT caches by default too (~/.cache/fenics); a form's kernels take 0.5-5 s to compile and every process of a run (bench
+  // children, test workers, the ranks of a multi-GPU job) would otherwise compile them again
   const char* e = std::getenv("MPCX_UFCX_CACHE");
-  return (e && *e && std::string(e) != "0") ? std::string(e) : std::string();
+  if (e && *e)
+    return std::string(e) != "0" ? std::string(e) : std::string();
+  const char* t = std::getenv("TMPDIR");
+  return std::string(t && *t ? t : "/tmp") + "/mpcx_ufcx_cache-" + std::to_string(static_cast<long long>(::getuid()));
 }
 uint64_t fnv1a(const std::string& text, uint64_t h = 1469598103934665603ull)
 {
