@@ -120,15 +120,20 @@ template <int NV>
 __device__ inline void gather_coords(const double* __restrict__ x, const int32_t* __restrict__ x_dofmap, int64_t cell,
                                      double (&cd)[NV * 3])
 {
+#pragma unroll
   for (int i = 0; i < NV; ++i)
   {
     const int64_t v = x_dofmap[cell * NV + i];
+#pragma unroll
     for (int k = 0; k < 3; ++k)
       cd[3 * i + k] = x[3 * v + k];
   }
 }
 
-constexpr int MAX_CSTRIDE = 96; // packed coefficient values per entity the scalar path accepts (three P2^3 fields)
+constexpr int MAX_CSTRIDE = 96;
+// element tensors up to this many entries are kept in registers: every loop over them is unrolled (a rolled loop indexes
+// the tensor at run time and sends it to scratch memory -- round 5: float32 row blocks at 128^3 1.55 -> see DESIGN)
+constexpr int SC_UNROLL_MAX = 144; // packed coefficient values per entity the scalar path accepts (three P2^3 fields)
 
 // element tensor of one entity in W from data of type T (see the header)
 template <class Op, class S>
@@ -137,6 +142,7 @@ __device__ inline bool tabulate_w(typename S::W* A, const typename S::T* w, int 
 {
   using W = typename S::W;
   constexpr int SIZE = Op::SIZE;
+  constexpr int UN = SIZE <= SC_UNROLL_MAX ? SIZE : 1; // unroll count of the loops over the tensor
   constexpr bool ELAST = Op::FORM == MPCX_FORM_ELASTICITY;
   const bool vecconst = Op::RANK1 && k.fn_id == 5; // f = constants[1 : 1 + bs]
   if (cstride > MAX_CSTRIDE)
@@ -153,12 +159,14 @@ __device__ inline bool tabulate_w(typename S::W* A, const typename S::T* w, int 
       for (int i = 0; i < nc; ++i)
         cr[i] = S::load(c + i);
     Op::tabulate(Ar, w ? wr : nullptr, c ? cr : nullptr, cd, lf, k);
+#pragma unroll UN
     for (int i = 0; i < SIZE; ++i)
       A[i] = Ar[i];
     return true;
   }
   else
   {
+#pragma unroll UN
     for (int i = 0; i < SIZE; ++i)
       A[i] = S::zero();
     if constexpr (ELAST)
@@ -170,6 +178,7 @@ __device__ inline bool tabulate_w(typename S::W* A, const typename S::T* w, int 
         cr[1] = part == 0 ? 0.0 : 1.0;
         Op::tabulate(Ar, nullptr, cr, cd, lf, k);
         const W f = S::load(c + part);
+#pragma unroll UN
         for (int i = 0; i < SIZE; ++i)
           A[i] = A[i] + f * Ar[i];
       }
@@ -201,6 +210,7 @@ __device__ inline bool tabulate_w(typename S::W* A, const typename S::T* w, int 
           const int ni = pw + pg;
           const W f = ni == 0 ? W{1.0, 0.0} : (ni == 1 ? W{0.0, 1.0} : W{-1.0, 0.0});
           const W cf = c0 * f;
+#pragma unroll UN
           for (int i = 0; i < SIZE; ++i)
             A[i] = A[i] + cf * Ar[i];
         }
@@ -418,19 +428,24 @@ __global__ void __launch_bounds__(256) matrix_rowblock_scalar_kernel(mpcx_matrix
       continue;
     }
     const uint8_t* __restrict__ po = a.plan.ent_offs + e * (ND0 * ND1);
+    constexpr bool SMALL = Op::SIZE <= SC_UNROLL_MAX;
+#pragma unroll(SMALL ? ND0 : 1)
     for (int i = 0; i < ND0; ++i)
     {
       const int32_t m0 = a.mdofmap0[cell0 * ND0 + i];
+#pragma unroll(SMALL ? BS0 : 1)
       for (int k = 0; k < BS0; ++k)
       {
         const int r = (m0 & SC_DOF_MASK) * BS0 + k;
         if (r < r0 || r >= r1 || ((m0 >> (SC_MASK_SHIFT + k)) & 1))
           continue;
         T* row = s_vals + s_rowlo[r - r0];
+#pragma unroll(SMALL ? ND1 : 1)
         for (int j = 0; j < ND1; ++j)
         {
           const int32_t m1 = a.mdofmap1[cell1 * ND1 + j];
           const int off = int(po[i * ND1 + j]) * BS1;
+#pragma unroll(SMALL ? BS1 : 1)
           for (int q = 0; q < BS1; ++q)
           {
             if ((m1 >> (SC_MASK_SHIFT + q)) & 1)
@@ -495,9 +510,11 @@ __global__ void __launch_bounds__(256) vector_rowblock_scalar_kernel(mpcx_vector
       *fail = 1;
       continue;
     }
+#pragma unroll
     for (int i = 0; i < ND; ++i)
     {
       const int32_t m0 = a.mdofmap[cell0 * ND + i];
+#pragma unroll
       for (int k = 0; k < BS; ++k)
       {
         const int r = (m0 & SC_DOF_MASK) * BS + k;
