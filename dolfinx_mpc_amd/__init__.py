@@ -25,6 +25,9 @@ from .multipointconstraint import MPCData, MultiPointConstraint
 from . import common  # noqa: F401  (Timer, list_timings: the reference's "~MPC: ..." scopes, also roctx ranges)
 from . import utils  # noqa: F401  (dolfinx_mpc.utils: constraint helpers, near-null space, the verification toolkit)
 from .problem import LinearProblem, NonlinearProblem
+from . import _native as _native_mod
+
+_native_mod.start_preload()  # (a no-op without a device or with MPCX_PRELOAD=0)
 
 __all__ = [
     "assemble_matrix",

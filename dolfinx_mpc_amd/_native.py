@@ -622,19 +622,32 @@ def require_gpu():
                 "and there is no CPU fallback for the assembly path."
             )
         _gpu_seen = True
-        _start_preload(torch.cuda.current_device())
+        if _preload_thread is not None and _preload_thread.is_alive():
+            _preload_thread.join()  # (started at import: normally long finished; never run beside the first set-up kernels --
+            # measured: a preload that overlaps the pattern build and the first assembly DOUBLES both, 0.10 + 0.22 -> 0.22 + 0.38 s)
     return torch.device("cuda", torch.cuda.current_device())
 
 
 _preload_thread = None
 
 
-def _start_preload(device_index: int):
-    """load the library's code objects in the background (include/mpcx.h mpcx_preload): the first launch from every
-    translation unit of libmpcx.so loads tens of MB of gfx950 code, which a cold box used to pay inside the first assembly
-    (VERDICT r4 U-3); started once, when the process first asks for its device; MPCX_PRELOAD=0 switches it off"""
+def start_preload():
+    """load the library's code objects -- and those of the torch kernels the plan builders use -- in the background
+    (include/mpcx.h mpcx_preload): the first launch from every translation unit of libmpcx.so loads tens of MB of gfx950 code,
+    which a cold box used to pay inside the first assembly.  Called once when the package is imported on a
+    machine with a device, so that the loads run beside the caller's host-side problem set-up; the device is the one of
+    LOCAL_RANK (the launcher's convention: one rank per GPU), else the current one; MPCX_PRELOAD=0 switches it off"""
     global _preload_thread
-    if _preload_thread is not None or os.environ.get("MPCX_PRELOAD", "1") == "0":
+    if _preload_thread is not None or os.environ.get("MPCX_PRELOAD", "1") == "0" or not os.path.exists(_LIB_PATH):
+        return
+    try:
+        import torch
+
+        if not torch.cuda.is_available():
+            return
+        n = torch.cuda.device_count()
+        device_index = int(os.environ["LOCAL_RANK"]) % max(n, 1) if "LOCAL_RANK" in os.environ else torch.cuda.current_device()
+    except Exception:  # noqa: BLE001
         return
     import threading
 
@@ -644,6 +657,25 @@ def _start_preload(device_index: int):
 
             torch.cuda.set_device(device_index)  # (the current device is per thread)
             lib().mpcx_preload(None)
+            # torch loads the code object of each of ITS kernels at first use as well: the plan builders' small unique /
+            # nonzero / cumsum / repeat_interleave / searchsorted / sort calls cost ~50 ms each in a fresh process (0.15 s of a
+            # 0.6 s first assembly at config 2, tools/first_call_probe.py) -- touch them here, on tiny tensors
+            dev = torch.device("cuda", device_index)
+            for dt in (torch.int32, torch.int64):
+                t = torch.arange(8, device=dev, dtype=dt)
+                torch.unique(t)
+                torch.nonzero(t > 3)
+                torch.cumsum(t, 0)
+                t.sum().item()
+                torch.sort(t)
+                torch.searchsorted(t, t)
+                t[t % 2 == 0]
+                t.max().item()
+            t = torch.arange(8, device=dev, dtype=torch.int64)
+            torch.repeat_interleave(t, t)
+            torch.zeros(8, dtype=torch.uint8, device=dev).to(torch.int64)
+            torch.zeros(8, dtype=torch.float64, device=dev).abs().max().item()
+            torch.cuda.synchronize()
         except Exception:  # noqa: BLE001  (an optimisation only)
             pass
 
