@@ -288,10 +288,22 @@ def renumber(mesh: Mesh, node_new_of_old: np.ndarray, cell_old_of_new: np.ndarra
     new mesh (and the re-indexed facet tags if ``tags`` is given)."""
     perm = np.asarray(node_new_of_old, dtype=np.int64)
     order = np.asarray(cell_old_of_new, dtype=np.int64)
-    x = np.empty_like(mesh.geometry.x)
-    x[perm] = mesh.geometry.x
-    cells = perm[mesh.geometry.dofmap.astype(np.int64)][order]
-    out = Mesh(x, cells.astype(np.int32), mesh.cell_name)
+    out = None
+    if mesh.num_cells >= 1_000_000:
+        # big meshes: the gathers on the device when there is one (include/mpcx.h mpcx_renumber_mesh: the host's fancy indexing
+        # of 4 x 10^8 node ids takes 12 s at 256^3, the device 0.4 s with the transfers)
+        try:
+            from . import locality
+
+            if locality._gpu():
+                out, _inv = locality._renumber(mesh, perm, order)
+        except Exception:  # noqa: BLE001  (no library / no device: the numpy path below)
+            out = None
+    if out is None:
+        x = np.empty_like(mesh.geometry.x)
+        x[perm] = mesh.geometry.x
+        cells = perm[mesh.geometry.dofmap.astype(np.int64)][order]
+        out = Mesh(x, cells.astype(np.int32), mesh.cell_name)
     if tags is None:
         return out
     cell_new_of_old = np.empty(order.size, dtype=np.int64)
