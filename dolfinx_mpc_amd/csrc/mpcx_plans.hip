@@ -248,9 +248,10 @@ template <class IDX>
 __global__ void __launch_bounds__(256)
     permute_values_kernel(int64_t n, const IDX* __restrict__ src, const double* __restrict__ vals2, double* __restrict__ dst)
 {
-  // grid-stride over a BOUNDED grid (round 5): a pure bandwidth kernel streams fastest from ~1024 workgroups on this chip
-  // (the 2 GiB copy probe: 5.9 TB/s against 4.8 from 2048 and more), and a grid of one workgroup per 256 entries (a million
-  // at config 2) takes every wave slot while it drains, so the VALU-bound vector kernel of the same step cannot run beside it
+  // grid-stride; MPCX_PERMUTE_WGS bounds the grid (round 5 experiment: the 2 GiB copy probe streams fastest from ~1024
+  // workgroups, and a million short workgroups might keep the vector kernel of the same step out -- but the shuffled config-2
+  // step measured 5.34 / 5.26 / 5.26 ms with 1024 / 2048 / 4096 workgroups against 5.16 ms unbounded: the gather through
+  // ``src`` is not a streaming read, and the default stays one workgroup per 256 entries)
   const int64_t stride = int64_t(gridDim.x) * blockDim.x;
   for (int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; k < n; k += stride)
     dst[k] = vals2[src[k]];
@@ -261,7 +262,7 @@ inline unsigned permute_grid(int64_t n)
   {
     const char* e = std::getenv("MPCX_PERMUTE_WGS");
     const int v = e ? std::atoi(e) : 0;
-    return v > 0 ? v : 2048;
+    return v > 0 ? v : 0x7fffffff;
   }();
   const int64_t g = (n + 255) / 256;
   return unsigned(g < wgs ? (g > 0 ? g : 1) : wgs);
