@@ -15,6 +15,7 @@
 // (one to four evaluations per entity) and combined -- no second implementation of the integrals.  float32 / complex64:
 // the data is widened, the tensor is computed in fp64 and every scatter-add rounds to the storage type (more accurate than
 // fp32 arithmetic throughout; tolerance stated in tests/test_gpu_scalar_types.py).
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <string>
@@ -382,8 +383,10 @@ __device__ inline void lds_add(typename S::T* p, typename S::W v)
 constexpr int SC_MASK_SHIFT = 28;
 constexpr int SC_DOF_MASK = (1 << SC_MASK_SHIFT) - 1;
 
+constexpr int SC_ROWBLOCK_THREADS = 512; // launch bound; 256 threads are launched (MPCX_SCALAR_THREADS: 512 measured +6 % for
+// float32 and -8 % for the complex types at 128^3, 1024 -- registers capped at 128 -- spills for complex128; round 5)
 template <class Op, class S>
-__global__ void __launch_bounds__(256) matrix_rowblock_scalar_kernel(mpcx_matrix_args_t a, int32_t* __restrict__ fail)
+__global__ void __launch_bounds__(SC_ROWBLOCK_THREADS) matrix_rowblock_scalar_kernel(mpcx_matrix_args_t a, int32_t* __restrict__ fail)
 {
   using T = typename S::T;
   using W = typename S::W;
@@ -473,7 +476,7 @@ __global__ void __launch_bounds__(256) matrix_rowblock_scalar_kernel(mpcx_matrix
 // vector row blocks: the rows of b a workgroup owns live in LDS; halo entities are evaluated by every block they touch;
 // slave rows are masked here and moved to their masters by vector_scalar_kernel<PART 1> over the slave entities
 template <class Op, class S>
-__global__ void __launch_bounds__(256) vector_rowblock_scalar_kernel(mpcx_vector_args_t a, int32_t* __restrict__ fail)
+__global__ void __launch_bounds__(SC_ROWBLOCK_THREADS) vector_rowblock_scalar_kernel(mpcx_vector_args_t a, int32_t* __restrict__ fail)
 {
   using T = typename S::T;
   using W = typename S::W;
@@ -762,6 +765,17 @@ int launch_typed(const Args& a, int64_t n, const char* what)
   return read_fail(flag, stream, what);
 }
 
+inline int sc_rowblock_threads()
+{
+  static const int t = []
+  {
+    const char* e = std::getenv("MPCX_SCALAR_THREADS");
+    const int v = e ? std::atoi(e) : 0;
+    return (v >= 64 && v <= SC_ROWBLOCK_THREADS && v % 64 == 0) ? v : 256;
+  }();
+  return t;
+}
+
 template <class Op, class S>
 struct MatrixK
 {
@@ -772,8 +786,8 @@ struct MatrixK
       const size_t lds = size_t(a.plan.max_nnz) * sizeof(typename S::T) + size_t(a.plan.max_rows + 1) * 4 + 512;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(matrix_rowblock_scalar_kernel<Op, S>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-      hipLaunchKernelGGL((matrix_rowblock_scalar_kernel<Op, S>), dim3(8u * unsigned((a.plan.num_blocks + 7) / 8)), dim3(256), lds, st,
-                         a, flag);
+      hipLaunchKernelGGL((matrix_rowblock_scalar_kernel<Op, S>), dim3(8u * unsigned((a.plan.num_blocks + 7) / 8)),
+                         dim3(sc_rowblock_threads()), lds, st, a, flag);
       if (a.n_slave_entities > 0)
         hipLaunchKernelGGL((matrix_scalar_kernel<Op, S, 1>), dim3(grid_for(a.n_slave_entities, 64)), dim3(64), 0, st, a, flag);
     }
@@ -791,8 +805,8 @@ struct VectorK
       const size_t lds = size_t(a.plan.max_rows) * sizeof(typename S::T) + 512;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vector_rowblock_scalar_kernel<Op, S>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-      hipLaunchKernelGGL((vector_rowblock_scalar_kernel<Op, S>), dim3(8u * unsigned((a.plan.num_blocks + 7) / 8)), dim3(256), lds, st,
-                         a, flag);
+      hipLaunchKernelGGL((vector_rowblock_scalar_kernel<Op, S>), dim3(8u * unsigned((a.plan.num_blocks + 7) / 8)),
+                         dim3(sc_rowblock_threads()), lds, st, a, flag);
       if (a.n_slave_entities > 0)
         hipLaunchKernelGGL((vector_scalar_kernel<Op, S, 1>), dim3(grid_for(a.n_slave_entities, 64)), dim3(64), 0, st, a, flag);
     }
