@@ -229,6 +229,7 @@ class LiftingArgs(C.Structure):
 # every symbol include/mpcx.h declares
 EXPORTS = [
     "mpcx_assemble_matrix",
+    "mpcx_assemble_fused",
     "mpcx_mask_dofmap",
     "mpcx_scatter_offsets",
     "mpcx_cube_records",
@@ -372,6 +373,8 @@ def lib() -> C.CDLL:
     L.mpcx_assemble_matrix.restype = C.c_int
     L.mpcx_assemble_vector.argtypes = [C.POINTER(VectorArgs)]
     L.mpcx_assemble_vector.restype = C.c_int
+    L.mpcx_assemble_fused.argtypes = [C.POINTER(MatrixArgs), C.POINTER(VectorArgs), vp]
+    L.mpcx_assemble_fused.restype = C.c_int
     L.mpcx_apply_lifting.argtypes = [C.POINTER(LiftingArgs)]
     L.mpcx_apply_lifting.restype = C.c_int
     L.mpcx_add_diagonal.argtypes = [i32, vp, vp, vp, vp, i64, dbl, vp]

@@ -2034,6 +2034,218 @@ __global__ void __launch_bounds__(P2CUBE_MAX_THREADS) matrix_p2_cube_kernel(mpcx
 
 } // namespace
 
+// ---------------------------------------------------------------------------------------------------------
+// Config 2's two cluster kernels in ONE launch (mpcx_assemble_fused, include/mpcx.h): the matrix kernel is
+// HBM / LDS bound (VALU issue 0.30) and the vector kernel VALU bound (0.80), but launched one after the other they hardly overlap
+// -- the matrix workgroups take 148 of a CU's 160 KB of LDS, so the vector workgroups wait.  Here a workgroup owns ONE row block
+// for both: the LDS copy of its CSR rows (matrix_cube_affine_kernel<narrow records>: closed form on parallelepiped clusters) AND
+// the LDS copy of its rows of b with their halo (vector_cube_own_kernel: owner-computes), 512 threads; the two workgroups a CU
+// holds start with different halves (by workgroup parity), so that the memory phase of one runs under the arithmetic of the
+// other.  Needs the two plans on the SAME row blocks: plan.block_row0 of the vector arguments is the full list, part_index[bb] =
+// index of row block bb in the matrix launch (its slots: a.plan.block_ent_off) or -1 (row blocks of another record format /
+// cluster shape: their matrix part is launched on its own).  The vector side does every row block.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int FUSED_THREADS = 512;
+// what the fused kernel reads of the two argument blocks (the full structs cost 200 scalar registers: 105 spilled)
+struct FusedMatrix
+{
+  const mpcx_nnz_t* rowptr;
+  double* vals;
+  const double* x;
+  const double* constants;
+  const void* cube_recs;
+  const int64_t* block_ent_off;
+  int32_t max_nnz, max_rows, store_mode;
+};
+struct FusedVector
+{
+  double* b;
+  const double* x;
+  const double* constants;
+  mpcx_kernel_t kernel;
+  const int32_t* block_row0;
+  const int64_t* block_ent_off;
+  const int32_t* block_ents;
+  const int32_t* cube_verts;
+  const int32_t* own_lmap;
+  const int64_t* own_hoff;
+  double* own_spill;
+  int32_t num_blocks;
+};
+template <int FN>
+__global__ void __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) fused_cube_kernel(FusedMatrix a, FusedVector v, const int32_t* __restrict__ part_index)
+{
+  using Op = ElementOp<3, 1, 1, 1, 1, MPCX_FORM_SOURCE, FN>;
+  const int NT = blockDim.x;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int nb = v.num_blocks;
+  const int per = (nb + 7) >> 3;
+  const int bb = (blockIdx.x & 7) * per + (blockIdx.x >> 3); // contiguous runs of row blocks per XCD
+  const int tid = threadIdx.x;
+  const bool live = bb < nb;
+  const int r0 = live ? v.block_row0[bb] : 0, r1 = live ? v.block_row0[bb + 1] : 0;
+  const int j = live ? part_index[bb] : -1; // this row block in the matrix launch
+  const int nrow = r1 - r0;
+  const int64_t nnz0 = live ? a.rowptr[r0] : 0;
+  const int nnzb = (live && j >= 0) ? int(a.rowptr[r1] - nnz0) : 0;
+  double* s_vals = reinterpret_cast<double*>(smem);
+  int32_t* s_rowlo = reinterpret_cast<int32_t*>(s_vals + a.max_nnz);
+  double* s_b = reinterpret_cast<double*>(s_rowlo + ((a.max_rows + 1) & ~1));
+  const int64_t h0 = live ? v.own_hoff[bb] : 0, h1 = live ? v.own_hoff[bb + 1] : 0;
+  const int nown = nrow, nhalo = int(h1 - h0);
+  for (int i = tid; i < nnzb; i += NT)
+    s_vals[i] = 0.0;
+  if (j >= 0)
+    for (int rl = tid; rl < nrow; rl += NT)
+      s_rowlo[rl] = int(a.rowptr[r0 + rl] - nnz0);
+  for (int i = tid; i < nown + nhalo; i += NT)
+    s_b[i] = 0.0;
+  fastmath_init_lds(); // ends in a barrier
+  if (!live)
+    return;
+  const double c0 = a.constants ? a.constants[0] : 1.0;
+  const uint4* __restrict__ recs = static_cast<const uint4*>(a.cube_recs);
+  auto matrix_half = [&]()
+  {
+    if (j < 0)
+      return;
+    const int64_t e0 = a.block_ent_off[j], e1 = a.block_ent_off[j + 1];
+    for (int64_t t = e0 + tid; t < e1; t += NT)
+    {
+      uint4 cur[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        cur[i] = recs[t * 4 + i];
+      const int32_t vv[8] = {int32_t(cur[0].x), int32_t(cur[0].y), int32_t(cur[0].z), int32_t(cur[0].w),
+                             int32_t(cur[1].x), int32_t(cur[1].y), int32_t(cur[1].z), int32_t(cur[1].w)};
+      double j0[3], j1[3], j2[3];
+      {
+        const int64_t n0 = vv[0] & DOF_MASK, n1 = vv[1] & DOF_MASK, n2 = vv[2] & DOF_MASK, n4 = vv[4] & DOF_MASK;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+        {
+          const double x0 = a.x[3 * n0 + r];
+          j0[r] = a.x[3 * n1 + r] - x0;
+          j1[r] = a.x[3 * n2 + r] - x0;
+          j2[r] = a.x[3 * n4 + r] - x0;
+        }
+      }
+      const uint32_t ow[8] = {cur[2].x, cur[2].y, cur[2].z, cur[2].w, cur[3].x, cur[3].y, cur[3].z, cur[3].w};
+      double C0[3], C1[3], C2[3];
+      cross3(j1, j2, C0);
+      cross3(j2, j0, C1);
+      cross3(j0, j1, C2);
+      const double det = j0[0] * C0[0] + j0[1] * C0[1] + j0[2] * C0[2];
+      const double s = c0 / fabs(det);
+      const double M[6] = {s * (C0[0] * C0[0] + C0[1] * C0[1] + C0[2] * C0[2]), s * (C0[0] * C1[0] + C0[1] * C1[1] + C0[2] * C1[2]),
+                           s * (C0[0] * C2[0] + C0[1] * C2[1] + C0[2] * C2[2]), s * (C1[0] * C1[0] + C1[1] * C1[1] + C1[2] * C1[2]),
+                           s * (C1[0] * C2[0] + C1[1] * C2[1] + C1[2] * C2[2]), s * (C2[0] * C2[0] + C2[1] * C2[1] + C2[2] * C2[2])};
+      int base[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+      {
+        const int r = vv[i] & DOF_MASK;
+        const bool mine = r >= r0 && r < r1 && !(vv[i] >> MASK_SHIFT);
+        base[i] = mine ? s_rowlo[mine ? r - r0 : 0] : -1;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int jj = i; jj < 8; ++jj)
+        {
+          if (!fan_coupled(i, jj))
+            continue;
+          double val = 0.0;
+#pragma unroll
+          for (int m = 0; m < 6; ++m)
+          {
+            const double k = FAN_AFFINE.k[m][i][jj];
+            if (k != 0.0)
+              val = fma(k, M[m], val);
+          }
+          if (base[i] >= 0 && !(vv[jj] >> MASK_SHIFT))
+          {
+            const int p = fan_pair_index(i, jj);
+            const int off = int((ow[p >> 3] >> (4 * (p & 7))) & 0xf);
+            __hip_atomic_fetch_add(s_vals + base[i] + off, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          if (i != jj && base[jj] >= 0 && !(vv[i] >> MASK_SHIFT))
+          {
+            const int p = fan_pair_index(jj, i);
+            const int off = int((ow[p >> 3] >> (4 * (p & 7))) & 0xf);
+            __hip_atomic_fetch_add(s_vals + base[jj] + off, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+    }
+  };
+  auto vector_half = [&]()
+  {
+    const int64_t e0 = v.block_ent_off[bb], e1 = v.block_ent_off[bb + 1];
+    const int32_t* __restrict__ ents = v.block_ents;
+    for (int64_t t = e0 + tid; t < e1; t += NT)
+    {
+      const int64_t c = ents[t];
+      int32_t vv[8];
+      {
+        const uint4* p = reinterpret_cast<const uint4*>(v.cube_verts + c * 8);
+        const uint4 w0 = p[0], w1 = p[1];
+        vv[0] = w0.x, vv[1] = w0.y, vv[2] = w0.z, vv[3] = w0.w, vv[4] = w1.x, vv[5] = w1.y, vv[6] = w1.z, vv[7] = w1.w;
+      }
+      double X[8][3];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          X[i][k] = v.x[3 * int64_t(vv[i]) + k];
+      double be8[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        be8[i] = 0.0;
+#pragma unroll
+      for (int tet = 0; tet < 6; ++tet)
+      {
+        double cd[12];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            cd[3 * i + k] = X[fan_vertex(tet, i)][k];
+        double be[4];
+        Op::tabulate(be, nullptr, v.constants, cd, 0, v.kernel);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          be8[fan_vertex(tet, i)] += be[i];
+      }
+      int32_t w[8];
+      {
+        const uint4* p = reinterpret_cast<const uint4*>(v.own_lmap + c * 8);
+        const uint4 w0 = p[0], w1 = p[1];
+        w[0] = w0.x, w[1] = w0.y, w[2] = w0.z, w[3] = w0.w, w[4] = w1.x, w[5] = w1.y, w[6] = w1.z, w[7] = w1.w;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (!(w[i] >> MASK_SHIFT))
+          __hip_atomic_fetch_add(s_b + (w[i] & DOF_MASK), be8[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  };
+  matrix_half();
+  vector_half();
+  __syncthreads();
+  if (j >= 0)
+  {
+    if (a.store_mode)
+      for (int i = tid; i < nnzb; i += NT)
+        a.vals[nnz0 + i] = s_vals[i];
+    else
+      for (int i = tid; i < nnzb; i += NT)
+        a.vals[nnz0 + i] += s_vals[i];
+  }
+  for (int i = tid; i < nown; i += NT)
+    v.b[r0 + i] += s_b[i];
+  for (int i = tid; i < nhalo; i += NT)
+    v.own_spill[h0 + i] = s_b[nown + i];
+}
+
 static int launch_matrix_cubes_elasticity(const mpcx_matrix_args_t& a)
 {
   if (!a.cube_recs || a.plan.num_blocks <= 0 || !a.constants || !a.plan.row_pairs || !a.plan.block_ents)
@@ -2545,4 +2757,55 @@ extern "C" int mpcx_preload_cubes(void* stream)
 {
   hipLaunchKernelGGL(preload_cubes_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream));
   return hipGetLastError() == hipSuccess ? 0 : -100;
+}
+
+extern "C" int mpcx_assemble_fused(const mpcx_matrix_args_t* pa, const mpcx_vector_args_t* pv, const int32_t* part_index)
+{
+  using namespace mpcx;
+  const mpcx_matrix_args_t& a = *pa;
+  const mpcx_vector_args_t& v = *pv;
+  const mpcx_kernel_t& km = a.kernel;
+  const mpcx_kernel_t& kv = v.kernel;
+  if (km.form != MPCX_FORM_STIFFNESS || km.celltype != MPCX_CELL_TETRAHEDRON || km.degree != 1 || km.bs != 1 || km.degree1 != 1
+      || km.bs1 != 1 || km.coeff_degree != 0 || a.coeffs || a.estride != 1 || a.nv != 4 || a.cube_rec_bytes != 64
+      || !(a.cube_flags & 1) || a.cube_rec_index || a.algorithm != MPCX_ALG_CUBE || kv.form != MPCX_FORM_SOURCE
+      || kv.celltype != MPCX_CELL_TETRAHEDRON || kv.degree != 1 || kv.bs != 1 || kv.coeff_degree != 0 || v.coeffs || v.nv != 4
+      || !v.cube_verts || !v.own_lmap || v.algorithm != MPCX_ALG_CUBE || !part_index || a.x != v.x)
+  {
+    mpcx_set_error("mpcx_assemble_fused: scalar P1 stiffness (narrow records, parallelepiped clusters) + scalar P1 source with the "
+                   "owner-computes cluster plan on the same mesh");
+    return -10;
+  }
+  if (v.plan.num_blocks <= 0 || !v.plan.block_row0 || !v.plan.block_ent_off || !v.plan.block_ents || !v.own_hoff || !v.own_spill
+      || !v.own_seg || (v.n_own_rows > 0 && (!v.own_rows || !v.own_src)) || !a.plan.block_ent_off || !a.cube_recs)
+  {
+    mpcx_set_error("mpcx_assemble_fused: incomplete plans");
+    return -5;
+  }
+  const size_t lds = size_t(a.plan.max_nnz) * 8 + size_t((a.plan.max_rows + 1) & ~1) * 4 + size_t(v.plan.max_rows) * 8;
+  if (lds > 160 * 1024)
+  {
+    mpcx_set_error("mpcx_assemble_fused: the two row-block copies exceed 160 KiB of LDS");
+    return -4;
+  }
+  hipStream_t st = static_cast<hipStream_t>(v.stream);
+  const unsigned grid = 8u * unsigned((v.plan.num_blocks + 7) / 8);
+  auto go = [&](auto kernel) -> int
+  {
+    if (int rc = check(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)),
+                       "hipFuncSetAttribute"))
+      return rc;
+    const FusedMatrix fa{a.rowptr, a.vals, a.x, a.constants, a.cube_recs, a.plan.block_ent_off, a.plan.max_nnz, a.plan.max_rows,
+                         a.store_mode};
+    const FusedVector fv{v.b,          v.x,           v.constants, v.kernel,  v.plan.block_row0, v.plan.block_ent_off, v.plan.block_ents,
+                         v.cube_verts, v.own_lmap,    v.own_hoff,  v.own_spill, v.plan.num_blocks};
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(FUSED_THREADS), lds, st, fa, fv, part_index);
+    return check(hipGetLastError(), "fused cluster kernel launch");
+  };
+  if (int rc = kv.fn_id == 1 ? go(fused_cube_kernel<1>) : go(fused_cube_kernel<-1>))
+    return rc;
+  if (v.n_own_rows > 0)
+    if (int rc = launch_vector_spill_reduce(v, 1))
+      return rc;
+  return launch_vector_slave_rows(v);
 }

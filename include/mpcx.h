@@ -582,6 +582,18 @@ typedef struct
 
 int mpcx_assemble_vector(const mpcx_vector_args_t* args);
 
+/* One launch for the matrix AND the vector of the periodic benchmark's forms (scalar P1 stiffness on parallelepiped clusters
+ * with narrow records + scalar P1 source with the owner-computes cluster plan, MPCX_ALG_CUBE both): a workgroup keeps the LDS
+ * copy of one row block of the CSR and of the same rows of b, so that the memory-bound matrix half and the arithmetic-bound
+ * vector half of neighbouring workgroups overlap on a CU (csrc/mpcx_cubes.hip fused_cube_kernel).  The two plans must use the
+ * same row blocks: vargs->plan carries all of them; part_index (DEVICE [vargs->plan.num_blocks]) = index of a row block in the
+ * matrix launch margs (margs->plan.block_ent_off, cube_recs) or -1 for row blocks the caller launches through
+ * mpcx_assemble_matrix on its own (other record format / cluster shape); runs on vargs->stream, followed by the vector's
+ * halo reduction and slave rows.  The reference has no counterpart (it assembles A and b in separate calls:
+ * python/benchmarks/bench_periodic.py:97-108).  MEASURED AND NOT TAKEN by the Python layer: 3.72 ms at 256^3 against 3.50 ms
+ * for the two launches on two streams; tests/test_gpu_fused.py keeps its values checked. */
+int mpcx_assemble_fused(const mpcx_matrix_args_t* margs, const mpcx_vector_args_t* vargs, const int32_t* part_index);
+
 /* ------------------------------------------------------------------------
  * mpcx_apply_lifting: replaces impl::apply_lifting for one integral of one
  * form a[j] (cpp/lifting.h:45-134, :243-397):
