@@ -875,8 +875,10 @@ def main():
         t_first_s = time.time() - t0s
         t_lib_s = time.time() - t0lib
         ts = timed_steps(step_shuffled, args.steps)
-        os.environ["MPCX_TWIN_HANDBACK"] = "lazy"
+        os.environ["MPCX_TWIN_HANDBACK"] = "eager"
         try:
+            ts_eager = timed_steps(step_shuffled, args.steps)
+            os.environ["MPCX_TWIN_HANDBACK"] = "lazy"
             ts_lazy = timed_steps(step_shuffled, args.steps)
             _ = A_s.vals  # (the deferred pass runs here, once)
             torch.cuda.synchronize()
@@ -886,12 +888,16 @@ def main():
                                      "set_up_and_first_step_s": t_first_s,
                                      "set_up_split_s": {"harness_shuffle_on_host": t_shuffle, "harness_space_bc_constraint": t_problem_s,
                                                         "library_pattern_twin_plans_first_step": t_lib_s},
+                                     "handback": "fused: the twin's kernels write through mpcx_matrix_args_t::val_map / "
+                                                 "mpcx_vector_args_t::row_map into the caller's CSR and vector (default)",
+                                     "ms_per_step_eager_pass": ts_eager,
                                      "ms_per_step_lazy_handback": ts_lazy,
                                      "lazy_handback_note": "MPCX_TWIN_HANDBACK=lazy: the values stay in the twin's matrix until A.vals is "
                                                            "read (on-demand pass, as for block-scalar storage); NOT the default",
                                      "note": "the same workload with nodes and cells in random order (a mesh as a file may deliver it), no "
                                              "caller action: assembled on the library's spatially reordered twin, values handed back in "
-                                             "the caller's numbering (dolfinx_mpc_amd/locality.py); includes the permutation pass",
+                                             "the caller's numbering (dolfinx_mpc_amd/locality.py); ms_per_step_eager_pass: with the "
+                                             "value permutation and the vector gather as passes of their own (round 4's hand-back)",
                                      "timings_ms": {"assemble_matrix[A]": hip_time(lambda: dm.assemble_matrix(fa_s, mpc_s, bcs=[bc_s], A=A_s, algorithm=args.alg), reps),
                                                     "assemble_vector[b]": hip_time(lambda: dm.assemble_vector(fl_s, mpc_s, b=b_s), reps)}}
         del A_s, b_s, fa_s, fl_s, mpc_s, Vs, mesh_s

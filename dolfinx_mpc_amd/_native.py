@@ -148,6 +148,10 @@ class MatrixArgs(C.Structure):
         ("cube_cells", C.c_void_p),
         ("cell_info0", C.c_void_p),
         ("cell_info1", C.c_void_p),
+        ("val_map", C.c_void_p),
+        ("val_map_wide", C.c_int32),
+        ("out_map", C.c_void_p),
+        ("out_delta", C.c_void_p),
         ("stream", C.c_void_p),
     ]
 
@@ -187,6 +191,7 @@ class VectorArgs(C.Structure):
         ("n_own_rows", C.c_int64),
         ("cube_cells", C.c_void_p),
         ("cell_info0", C.c_void_p),
+        ("row_map", C.c_void_p),
         ("stream", C.c_void_p),
     ]
 
@@ -222,6 +227,7 @@ class LiftingArgs(C.Structure):
         ("mpc0", MpcT),
         ("cell_info0", C.c_void_p),
         ("cell_info1", C.c_void_p),
+        ("row_map", C.c_void_p),
         ("stream", C.c_void_p),
     ]
 
@@ -273,6 +279,8 @@ EXPORTS = [
     "mpcx_homogenize_scalar",
     "mpcx_csr_permutation",
     "mpcx_permute_values",
+    "mpcx_invert_permutation",
+    "mpcx_write_out_order",
     "mpcx_pair_words",
     "mpcx_pair_records",
     "mpcx_pair_dict_stride",
@@ -282,6 +290,7 @@ EXPORTS = [
     "mpcx_pair_context",
     "mpcx_diag_slot_mask",
     "mpcx_add_diagonal",
+    "mpcx_add_diagonal_mapped",
     "mpcx_assemble_vector",
     "mpcx_apply_lifting",
     "mpcx_backsubstitution",
@@ -379,6 +388,8 @@ def lib() -> C.CDLL:
     L.mpcx_apply_lifting.restype = C.c_int
     L.mpcx_add_diagonal.argtypes = [i32, vp, vp, vp, vp, i64, dbl, vp]
     L.mpcx_add_diagonal.restype = C.c_int
+    L.mpcx_add_diagonal_mapped.argtypes = [i32, vp, vp, vp, vp, i64, dbl, vp, i32, vp]
+    L.mpcx_add_diagonal_mapped.restype = C.c_int
     L.mpcx_backsubstitution.argtypes = [vp, vp, i64, C.POINTER(MpcT), vp]
     L.mpcx_backsubstitution.restype = C.c_int
     L.mpcx_homogenize.argtypes = [vp, vp, i64, vp]
@@ -514,6 +525,10 @@ def lib() -> C.CDLL:
     L.mpcx_csr_permutation.restype = C.c_int
     L.mpcx_permute_values.argtypes = [i64, vp, i32, vp, vp, vp]
     L.mpcx_permute_values.restype = C.c_int
+    L.mpcx_invert_permutation.argtypes = [i64, vp, i32, vp, vp]
+    L.mpcx_invert_permutation.restype = C.c_int
+    L.mpcx_write_out_order.argtypes = [i32, vp, vp, i32, vp, vp, vp, vp]
+    L.mpcx_write_out_order.restype = C.c_int
     L.mpcx_pair_words.argtypes = [i32]
     L.mpcx_pair_words.restype = i32
     L.mpcx_pair_records.argtypes = [i64, vp, i32, vp, vp, vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]

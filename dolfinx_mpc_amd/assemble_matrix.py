@@ -1123,13 +1123,13 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
                 parts, ck, _info, _left = cp
                 t = _native.MatrixArgs.from_buffer_copy(a)  # the imported kernel's call: master contributions only
                 t.algorithm, t.n_entities, t.store_mode = 2, 0, 0
-                t.vals = A.vals.data_ptr()
+                _set_vals(t, A)
                 t.leftover, t.kernel_name, t.block_scalar, t.second = None, name, False, None
                 a.kernel = idv["kernel_builtin"]
                 a.algorithm = 3
                 a.n_slave_entities = 0
                 a.kernel_name = name
-                a.vals = A.vals.data_ptr()
+                _set_vals(a, A)
                 # one launch per kind of row block (all cells parallelepipeds / not), then the master contributions: a chain
                 # of follow-up calls (python attribute ``second``)
                 chain = []
@@ -1166,7 +1166,7 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
                 a.algorithm = 3
                 a.leftover = left if left.size else None
                 a.kernel_name = name
-                a.vals = A.vals.data_ptr()
+                _set_vals(a, A)
                 # one launch per kind of row block (record format, cell shape): a chain of follow-up calls (python attribute
                 # ``second``).  The master contributions ride on the LAST launch: the row blocks are written in store mode, so
                 # they must all be in place before anything is added to them
@@ -1242,8 +1242,22 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
             break
     if not a.block_scalar:
         A._compact_stale = False  # every value is (re)written below: nothing to expand first
-        a.vals = A.vals.data_ptr()
+        _set_vals(a, A)
     return a, keep
+
+
+def _set_vals(a, A: MPCMatrix):
+    """the value array of a launch: A's own, or -- for the locality twin of a caller's matrix (``A._write_through``, set by
+    dolfinx_mpc_amd/locality.py) -- the CALLER's array through the permutation of the two CSRs (mpcx_matrix_args_t::val_map)"""
+    wt = getattr(A, "_write_through", None)
+    if wt is None:
+        a.vals = A.vals.data_ptr()
+    else:
+        target, vmap, wide, omap, odelta = wt
+        a.vals = target.vals.data_ptr()
+        a.val_map, a.val_map_wide = vmap.data_ptr(), int(wide)
+        if odelta is not None:
+            a.out_map, a.out_delta = omap.data_ptr(), odelta.data_ptr()
 
 
 @timed("~MPC: Assemble matrix (C++)")
@@ -1325,6 +1339,8 @@ def _assemble_matrix_on_stream(form: Form, mpc0, mpc1, bcs, diagval, A: MPCMatri
 
     V0, V1 = form.function_spaces
     stream = D.stream_ptr()
+    wt = getattr(A, "_write_through", None)
+    target = A if wt is None else wt[0]  # whose value array the launches write (``_set_vals``)
 
     def prepare(alg):
         """argument blocks of every integral (plans are built / fetched here, nothing is launched)"""
@@ -1367,12 +1383,12 @@ def _assemble_matrix_on_stream(form: Form, mpc0, mpc1, bcs, diagval, A: MPCMatri
     block_scalar = len(calls) == 1 and calls[0][1].block_scalar
     for memset, a, _keep in calls:
         if memset:
-            A.zeroEntries()
+            target.zeroEntries()
         if a.block_scalar and A._compact["ov_val"] is not None:
             A._compact["ov_val"].zero_()
         _native.check(L.mpcx_assemble_matrix(C.byref(a)), "mpcx_assemble_matrix")
     if not zeroed:
-        A.zeroEntries()
+        target.zeroEntries()
     if block_scalar:
         _block_scalar_diagonals(A, form, mpc0, mpc1, bcs, diagval)
         A._compact_stale = True
@@ -1401,7 +1417,13 @@ def _assemble_matrix_on_stream(form: Form, mpc0, mpc1, bcs, diagval, A: MPCMatri
 def _add_diagonal(L, A: MPCMatrix, dofs_ptr, n: int, diagval, stream, form: Form):
     """A[d, d] += diagval for the listed dofs, in the matrix's scalar type"""
     sid = _native.scalar_id(getattr(form, "dtype", np.float64))
-    if sid == 0:
+    wt = getattr(A, "_write_through", None)
+    if wt is not None:
+        target, vmap, wide = wt[:3]
+        _native.check(L.mpcx_add_diagonal_mapped(A.shape[0], A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), target.vals.data_ptr(),
+                                                 dofs_ptr, n, float(diagval), vmap.data_ptr(), int(wide), stream),
+                      "mpcx_add_diagonal_mapped")
+    elif sid == 0:
         _native.check(L.mpcx_add_diagonal(A.shape[0], A.d_rowptr.data_ptr(), A.d_cols.data_ptr(), A.vals.data_ptr(), dofs_ptr, n,
                                           float(diagval), stream), "mpcx_add_diagonal")
     else:

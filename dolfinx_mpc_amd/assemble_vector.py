@@ -277,7 +277,11 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
     m, mkeep = constraint._device()
     idv = D.integral_device(form, i)
     a = _native.VectorArgs()
-    a.b, a.num_dofs = b.array.data_ptr(), b.size
+    wt = getattr(b, "_write_through", None)  # (the locality twin of a caller's vector: mpcx_vector_args_t::row_map)
+    if wt is None:
+        a.b, a.num_dofs = b.array.data_ptr(), b.size
+    else:
+        a.b, a.num_dofs, a.row_map = wt[0].array.data_ptr(), b.size, wt[1].data_ptr()
     a.kernel = idv["kernel"]
     a.x, a.x_dofmap, a.nv = md["x"].data_ptr(), md["x_dofmap"].data_ptr(), form.mesh.geometry.dofmap.shape[1]
     a.estride, a.n_entities = integ.estride, integ.num_entities
@@ -469,7 +473,8 @@ def assemble_vector(form: Form, constraint: MultiPointConstraint, b: Optional[Ve
 def _assemble_vector_on_stream(form: Form, constraint: MultiPointConstraint, b: Vector, alg: int):
     """the body of ``assemble_vector``: zero, then every integral, enqueued on the CURRENT torch stream"""
     L = _native.lib()
-    b.set(0.0)
+    wt = getattr(b, "_write_through", None)
+    (b if wt is None else wt[0]).set(0.0)
     for i, integ in enumerate(form.integrals):
         try:
             a, keep = vector_args(form, i, b, constraint, alg)

@@ -513,10 +513,10 @@ __global__ void __launch_bounds__(CUBE_MAX_THREADS) matrix_cube_kernel(mpcx_matr
   __syncthreads();
   if (a.store_mode)
     for (int i = tid; i < nnzb; i += NT)
-      a.vals[nnz0 + i] = s_vals[i];
+      a.vals[MPCX_OUT_POS(a, nnz0 + i)] = s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
   else
     for (int i = tid; i < nnzb; i += NT)
-      a.vals[nnz0 + i] += s_vals[i];
+      a.vals[MPCX_OUT_POS(a, nnz0 + i)] += s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
 }
 
 // ---------------------------------------------------------------------------
@@ -584,7 +584,7 @@ __global__ void __launch_bounds__(VCUBE_THREADS) vector_cube_kernel(mpcx_vector_
       {
         const int m0 = a.mpc.masters_offsets[d], m1 = a.mpc.masters_offsets[d + 1];
         for (int mi = m0; mi < m1; ++mi)
-          __hip_atomic_fetch_add(a.b + a.mpc.masters[mi], a.mpc.coeffs[mi] * val, __ATOMIC_RELAXED,
+          __hip_atomic_fetch_add(a.b + MPCX_ROW_POS(a, a.mpc.masters[mi]), a.mpc.coeffs[mi] * val, __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_AGENT);
         if (m1 > m0)
           val = 0.0; // be[slave] is cleared once it has been moved (cpp/assemble_vector.h:65)
@@ -605,7 +605,7 @@ __global__ void __launch_bounds__(VCUBE_THREADS) vector_cube_kernel(mpcx_vector_
           h = (h + 1) & (VCUBE_H - 1);
         }
         if (probe == VCUBE_PROBES)
-          __hip_atomic_fetch_add(a.b + d, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(a.b + MPCX_ROW_POS(a, d), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
@@ -614,7 +614,7 @@ __global__ void __launch_bounds__(VCUBE_THREADS) vector_cube_kernel(mpcx_vector_
   {
     const int32_t d = s_key[i];
     if (d >= 0)
-      __hip_atomic_fetch_add(a.b + d, s_val[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(a.b + MPCX_ROW_POS(a, d), s_val[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -695,7 +695,7 @@ __global__ void __launch_bounds__(VCUBE_OWN_THREADS) vector_cube_own_kernel(mpcx
   }
   __syncthreads();
   for (int i = tid; i < nown; i += NT)
-    a.b[r0 + i] += s_b[i];
+    a.b[MPCX_ROW_POS(a, r0 + i)] += s_b[i];
   for (int i = tid; i < nhalo; i += NT)
     a.own_spill[h0 + i] = s_b[nown + i];
 }
@@ -1113,10 +1113,10 @@ __global__ void __launch_bounds__(HEX_MAX_THREADS) matrix_hex_kernel(mpcx_matrix
   __syncthreads();
   if (a.store_mode)
     for (int i = tid; i < nnzb; i += NT)
-      a.vals[nnz0 + i] = s_vals[i];
+      a.vals[MPCX_OUT_POS(a, nnz0 + i)] = s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
   else
     for (int i = tid; i < nnzb; i += NT)
-      a.vals[nnz0 + i] += s_vals[i];
+      a.vals[MPCX_OUT_POS(a, nnz0 + i)] += s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
 }
 
 // vector: scalar Q1 source term c * f v dx over an NQ1^3 Gauss rule, one thread per hexahedron, owner-computes row
@@ -1257,7 +1257,7 @@ __global__ void __launch_bounds__(VCUBE_OWN_THREADS) vector_hex_own_kernel(mpcx_
   }
   __syncthreads();
   for (int i = tid; i < nown; i += NT)
-    a.b[r0 + i] += s_b[i];
+    a.b[MPCX_ROW_POS(a, r0 + i)] += s_b[i];
   for (int i = tid; i < nhalo; i += NT)
     a.own_spill[h0 + i] = s_b[nown + i];
 }
@@ -1449,10 +1449,10 @@ __global__ void __launch_bounds__(CUBE_AFFINE_MAX_THREADS) matrix_cube_affine_ke
   __syncthreads();
   if (a.store_mode)
     for (int i = tid; i < nnzb; i += NT)
-      a.vals[nnz0 + i] = s_vals[i];
+      a.vals[MPCX_OUT_POS(a, nnz0 + i)] = s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
   else
     for (int i = tid; i < nnzb; i += NT)
-      a.vals[nnz0 + i] += s_vals[i];
+      a.vals[MPCX_OUT_POS(a, nnz0 + i)] += s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1643,10 +1643,10 @@ __global__ void __launch_bounds__(CUBE_EL_THREADS) matrix_cube_elasticity_rowpai
   __syncthreads();
   if (a.store_mode)
     for (int i = tid; i < nnzb; i += NT)
-      a.vals[nnz0 + i] = s_vals[i];
+      a.vals[MPCX_OUT_POS(a, nnz0 + i)] = s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
   else
     for (int i = tid; i < nnzb; i += NT)
-      a.vals[nnz0 + i] += s_vals[i];
+      a.vals[MPCX_OUT_POS(a, nnz0 + i)] += s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2026,10 +2026,10 @@ __global__ void __launch_bounds__(P2CUBE_MAX_THREADS) matrix_p2_cube_kernel(mpcx
   __syncthreads();
   if (a.store_mode)
     for (int i = tid; i < nnzb; i += NT)
-      a.vals[nnz0 + i] = s_vals[i];
+      a.vals[MPCX_OUT_POS(a, nnz0 + i)] = s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
   else
     for (int i = tid; i < nnzb; i += NT)
-      a.vals[nnz0 + i] += s_vals[i];
+      a.vals[MPCX_OUT_POS(a, nnz0 + i)] += s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
 }
 
 } // namespace
@@ -2770,7 +2770,7 @@ extern "C" int mpcx_assemble_fused(const mpcx_matrix_args_t* pa, const mpcx_vect
       || km.bs1 != 1 || km.coeff_degree != 0 || a.coeffs || a.estride != 1 || a.nv != 4 || a.cube_rec_bytes != 64
       || !(a.cube_flags & 1) || a.cube_rec_index || a.algorithm != MPCX_ALG_CUBE || kv.form != MPCX_FORM_SOURCE
       || kv.celltype != MPCX_CELL_TETRAHEDRON || kv.degree != 1 || kv.bs != 1 || kv.coeff_degree != 0 || v.coeffs || v.nv != 4
-      || !v.cube_verts || !v.own_lmap || v.algorithm != MPCX_ALG_CUBE || !part_index || a.x != v.x)
+      || !v.cube_verts || !v.own_lmap || v.algorithm != MPCX_ALG_CUBE || !part_index || a.x != v.x || a.val_map || v.row_map)
   {
     mpcx_set_error("mpcx_assemble_fused: scalar P1 stiffness (narrow records, parallelepiped clusters) + scalar P1 source with the "
                    "owner-computes cluster plan on the same mesh");

@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(256) matrix_atomic_kernel(mpcx_matrix_args_t a
       }
       const int64_t pos = csr_find(a.cols, lo, hi, colsd[q]);
       if (pos >= 0)
-        atomic_add_f64(a.vals + pos, Op::get(Ae, p, q));
+        atomic_add_f64(a.vals + MPCX_VAL_POS(a, pos), Op::get(Ae, p, q));
     }
   }
 }
@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(64) matrix_mpc_kernel(mpcx_matrix_args_t a)
           {
             const int64_t pos = csr_find(a.cols, lo, hi, a.mpc1.masters[mj]);
             if (pos >= 0)
-              atomic_add_f64(a.vals + pos, ci * a.mpc1.coeffs[mj] * v);
+              atomic_add_f64(a.vals + MPCX_VAL_POS(a, pos), ci * a.mpc1.coeffs[mj] * v);
           }
         }
         else if (!cbc[q])
@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(64) matrix_mpc_kernel(mpcx_matrix_args_t a)
           // stripped row: slave-slave entries removed (:226-236)
           const int64_t pos = csr_find(a.cols, lo, hi, colsd[q]);
           if (pos >= 0)
-            atomic_add_f64(a.vals + pos, ci * v);
+            atomic_add_f64(a.vals + MPCX_VAL_POS(a, pos), ci * v);
         }
       }
     }
@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(64) matrix_mpc_kernel(mpcx_matrix_args_t a)
           continue;
         const int64_t pos = csr_find(a.cols, a.rowptr[rows[p]], a.rowptr[rows[p] + 1], m);
         if (pos >= 0)
-          atomic_add_f64(a.vals + pos, cj * entry(p, q));
+          atomic_add_f64(a.vals + MPCX_VAL_POS(a, pos), cj * entry(p, q));
       }
     }
   }
@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(64) matrix_mpc_plan_small_kernel(mpcx_matrix_a
   if (a.mpc_plan_out)
     a.mpc_plan_out[t] += sum; // block-scalar storage: the couplings live in an overlay, one entry per target
   else
-    a.vals[a.mpc_plan_tgt[t]] += sum;
+    a.vals[MPCX_VAL_POS(a, a.mpc_plan_tgt[t])] += sum;
 }
 
 template <class Op, int G, bool USE_LAZY> // G lanes share one target position
@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(64) matrix_mpc_plan_kernel(mpcx_matrix_args_t 
     if (a.mpc_plan_out)
       a.mpc_plan_out[t] += sum;
     else
-      a.vals[a.mpc_plan_tgt[t]] += sum;
+      a.vals[MPCX_VAL_POS(a, a.mpc_plan_tgt[t])] += sum;
   }
 }
 
@@ -689,18 +689,18 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
         const int q = e % BS1;
         const double v = (q == k) ? src[e / BS1] : 0.0;
         if (a.store_mode)
-          a.vals[p0 + e] = v;
+          a.vals[MPCX_VAL_POS(a, p0 + e)] = v;
         else if (q == k)
-          a.vals[p0 + e] += v;
+          a.vals[MPCX_VAL_POS(a, p0 + e)] += v;
       }
     }
   }
   else if (a.store_mode)
     for (int i = tid; i < nnzb; i += NT)
-      a.vals[nnz0 + i] = s_vals[i];
+      a.vals[MPCX_OUT_POS(a, nnz0 + i)] = s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
   else
     for (int i = tid; i < nnzb; i += NT)
-      a.vals[nnz0 + i] += s_vals[i];
+      a.vals[MPCX_OUT_POS(a, nnz0 + i)] += s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
 }
 
 // Node-block variant for component-diagonal forms on blocked spaces (S (x) I: vector stiffness / mass, the
@@ -835,9 +835,9 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_nodeblock_kernel(
       const bool keep = q == k && !(masked_block && ((a.slot_mask[gslot0 + lo + sl] >> k) & 1));
       const double v = keep ? s_vals[lo + sl] : 0.0;
       if (a.store_mode)
-        a.vals[p0 + e] = v;
+        a.vals[MPCX_VAL_POS(a, p0 + e)] = v;
       else if (keep)
-        a.vals[p0 + e] += v;
+        a.vals[MPCX_VAL_POS(a, p0 + e)] += v;
     }
   }
 }
@@ -985,18 +985,18 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowpair_kernel(mp
         const int q = e % BS1;
         const double v = (q == k) ? src[e / BS1] : 0.0;
         if (a.store_mode)
-          a.vals[p0 + e] = v;
+          a.vals[MPCX_VAL_POS(a, p0 + e)] = v;
         else if (q == k)
-          a.vals[p0 + e] += v;
+          a.vals[MPCX_VAL_POS(a, p0 + e)] += v;
       }
     }
   }
   else if (a.store_mode)
     for (int i = tid; i < nnzb; i += NT)
-      a.vals[nnz0 + i] = s_vals[i];
+      a.vals[MPCX_OUT_POS(a, nnz0 + i)] = s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
   else
     for (int i = tid; i < nnzb; i += NT)
-      a.vals[nnz0 + i] += s_vals[i];
+      a.vals[MPCX_OUT_POS(a, nnz0 + i)] += s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
 }
 
 // Per-cell rotation of the local (vertex) numbering used by the lean row-block path: cell c lists
@@ -1165,16 +1165,22 @@ pattern_rows_kernel(int32_t num_blocks0, const int64_t* __restrict__ adj_off, co
 }
 
 // ---------------------------------------------------------------------------
+// val_map: the write-out permutation of mpcx_matrix_args_t (NULL: none)
 __global__ void add_diagonal_kernel(const mpcx_nnz_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
-                                    double* vals, const int32_t* __restrict__ dofs, int64_t n, double diagval)
+                                    double* vals, const int32_t* __restrict__ dofs, int64_t n, double diagval,
+                                    const void* __restrict__ val_map, int val_map_wide)
 {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n)
     return;
   const int32_t d = dofs[i];
-  const int64_t pos = csr_find(cols, rowptr[d], rowptr[d + 1], d);
+  int64_t pos = csr_find(cols, rowptr[d], rowptr[d + 1], d);
   if (pos >= 0)
+  {
+    if (val_map)
+      pos = val_map_wide ? static_cast<const int64_t*>(val_map)[pos] : int64_t(static_cast<const uint32_t*>(val_map)[pos]);
     atomic_add_f64(vals + pos, diagval);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1243,7 +1249,7 @@ vector_kernel(mpcx_vector_args_t a)
         {
           const int m0 = a.mpc.masters_offsets[d], m1 = a.mpc.masters_offsets[d + 1];
           for (int mi = m0; mi < m1; ++mi)
-            atomic_add_f64(a.b + a.mpc.masters[mi], a.mpc.coeffs[mi] * v);
+            atomic_add_f64(a.b + MPCX_ROW_POS(a, a.mpc.masters[mi]), a.mpc.coeffs[mi] * v);
           if (m1 > m0)
             v = 0.0; // be[slave] is cleared inside the master loop (assemble_vector.h:65)
         }
@@ -1264,7 +1270,7 @@ vector_kernel(mpcx_vector_args_t a)
             h = (h + 1) & (H - 1);
           }
           if (probe == VectorCfg<N>::PROBES)
-            atomic_add_f64(a.b + d, v);
+            atomic_add_f64(a.b + MPCX_ROW_POS(a, d), v);
         }
       }
     }
@@ -1274,7 +1280,7 @@ vector_kernel(mpcx_vector_args_t a)
   {
     const int32_t d = s_key[i];
     if (d >= 0)
-      atomic_add_f64(a.b + d, s_val[i]);
+      atomic_add_f64(a.b + MPCX_ROW_POS(a, d), s_val[i]);
   }
 }
 
@@ -1453,7 +1459,7 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) vector_rowblock_kernel(m
   }
   __syncthreads();
   for (int i = tid; i < r1 - r0; i += NT)
-    a.b[r0 + i] += s_b[i];
+    a.b[MPCX_ROW_POS(a, r0 + i)] += s_b[i];
 }
 
 // Slave rows of the entities that have any (modify_mpc_vec, cpp/assemble_vector.h:35-69):
@@ -1529,7 +1535,7 @@ __global__ void __launch_bounds__(MAXT) vector_ownblock_kernel(mpcx_vector_args_
   }
   __syncthreads();
   for (int i = tid; i < nown; i += NT)
-    a.b[r0 + i] += s_b[i];
+    a.b[MPCX_ROW_POS(a, r0 + i)] += s_b[i];
   for (int i = tid; i < nhalo; i += NT)
     a.own_spill[h0 * BS + i] = s_b[nown + i];
 }
@@ -1537,7 +1543,8 @@ __global__ void __launch_bounds__(MAXT) vector_ownblock_kernel(mpcx_vector_args_
 // second half of the owner-computes vector path: one thread per (distinct target dof, component)
 __global__ void vector_spill_reduce_kernel(int64_t n_rows, const int32_t* __restrict__ rows,
                                            const int64_t* __restrict__ seg, const int32_t* __restrict__ src,
-                                           const double* __restrict__ spill, int bs, double* __restrict__ b)
+                                           const double* __restrict__ spill, int bs, double* __restrict__ b,
+                                           const int32_t* __restrict__ row_map)
 {
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= n_rows * bs)
@@ -1547,7 +1554,8 @@ __global__ void vector_spill_reduce_kernel(int64_t n_rows, const int32_t* __rest
   double sum = 0.0;
   for (int64_t s = seg[u]; s < seg[u + 1]; ++s)
     sum += spill[int64_t(src[s]) * bs + k];
-  b[int64_t(rows[u]) * bs + k] += sum;
+  const int64_t d = int64_t(rows[u]) * bs + k;
+  b[row_map ? int64_t(row_map[d]) : d] += sum;
 }
 
 // Rows of slave dofs go to their masters (cpp/assemble_vector.h:35-69).  The contributions of a workgroup's entities are
@@ -1583,7 +1591,7 @@ __global__ void __launch_bounds__(VECTOR_MPC_THREADS) vector_mpc_kernel(mpcx_vec
       }
       h = (h + 1) & (VECTOR_MPC_H - 1);
     }
-    atomic_add_f64(a.b + row, v); // (a full neighbourhood of the table: straight to memory)
+    atomic_add_f64(a.b + MPCX_ROW_POS(a, row), v); // (a full neighbourhood of the table: straight to memory)
   };
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t < a.n_slave_entities)
@@ -1621,7 +1629,7 @@ __global__ void __launch_bounds__(VECTOR_MPC_THREADS) vector_mpc_kernel(mpcx_vec
   {
     const int32_t row = s_key[i];
     if (row >= 0)
-      atomic_add_f64(a.b + row, s_val[i]);
+      atomic_add_f64(a.b + MPCX_ROW_POS(a, row), s_val[i]);
   }
 }
 
@@ -1681,12 +1689,12 @@ __global__ void __launch_bounds__(128) lifting_kernel(mpcx_lifting_args_t a)
       {
         const int m0 = a.mpc0.masters_offsets[d], m1 = a.mpc0.masters_offsets[d + 1];
         for (int mi = m0; mi < m1; ++mi)
-          atomic_add_f64(a.b + a.mpc0.masters[mi], a.mpc0.coeffs[mi] * v);
+          atomic_add_f64(a.b + MPCX_ROW_POS(a, a.mpc0.masters[mi]), a.mpc0.coeffs[mi] * v);
         if (m1 > m0)
           v = 0.0;
       }
       if (v != 0.0)
-        atomic_add_f64(a.b + d, v);
+        atomic_add_f64(a.b + MPCX_ROW_POS(a, d), v);
     }
   }
 }
@@ -1897,6 +1905,11 @@ int launch_matrix(const mpcx_matrix_args_t& a)
     if (int rc = check(hipGetLastError(), "matrix kernel launch"))
       return rc;
   }
+  if (a.block_vals && a.val_map)
+  {
+    mpcx_set_error("mpcx_assemble_matrix: val_map with block_vals (block-scalar storage has no CSR write-out to redirect)");
+    return -3;
+  }
   if (a.block_vals && (!a.slot_mask || alg != MPCX_ALG_ROWBLOCK || (a.n_slave_entities > 0 && (!a.mpc_plan_off || !a.mpc_plan_out))))
   {
     mpcx_set_error("mpcx_assemble_matrix: block_vals needs the node-block kernel (slot_mask, MPCX_ALG_ROWBLOCK) and, with slave "
@@ -1943,7 +1956,8 @@ int launch_matrix(const mpcx_matrix_args_t& a)
 int launch_vector_spill_reduce(const mpcx_vector_args_t& a, int bs)
 {
   hipLaunchKernelGGL(vector_spill_reduce_kernel, dim3(grid_for(a.n_own_rows * bs, 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(a.stream), a.n_own_rows, a.own_rows, a.own_seg, a.own_src, a.own_spill, bs, a.b);
+                     static_cast<hipStream_t>(a.stream), a.n_own_rows, a.own_rows, a.own_seg, a.own_src, a.own_spill, bs, a.b,
+                     a.row_map);
   return check(hipGetLastError(), "vector spill-reduce kernel launch");
 }
 
@@ -2250,8 +2264,18 @@ extern "C" int mpcx_add_diagonal(int32_t nrows, const mpcx_nnz_t* rowptr, const 
   (void)nrows;
   if (n == 0)
     return 0;
-  hipLaunchKernelGGL(add_diagonal_kernel, dim3(grid_for(n, 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), rowptr, cols, vals, dofs, n, diagval);
+  return mpcx_add_diagonal_mapped(nrows, rowptr, cols, vals, dofs, n, diagval, nullptr, 0, stream);
+}
+
+extern "C" int mpcx_add_diagonal_mapped(int32_t nrows, const mpcx_nnz_t* rowptr, const int32_t* cols, double* vals,
+                                        const int32_t* dofs, int64_t n, double diagval, const void* val_map, int32_t val_map_wide,
+                                        void* stream)
+{
+  (void)nrows;
+  if (n == 0)
+    return 0;
+  hipLaunchKernelGGL(add_diagonal_kernel, dim3(grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), rowptr, cols, vals,
+                     dofs, n, diagval, val_map, int(val_map_wide));
   return check(hipGetLastError(), "add_diagonal launch");
 }
 

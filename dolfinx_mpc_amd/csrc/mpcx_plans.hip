@@ -256,6 +256,45 @@ __global__ void __launch_bounds__(256)
   for (int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; k < n; k += stride)
     dst[k] = vals2[src[k]];
 }
+template <class IDX>
+__global__ void __launch_bounds__(256) invert_permutation_kernel(int64_t n, const IDX* __restrict__ src, IDX* __restrict__ out)
+{
+  const int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (k < n)
+    out[src[k]] = IDX(k);
+}
+// one thread per row of the launch's CSR: rank of every entry inside the caller's row (mpcx_write_out_order)
+template <class IDX>
+__global__ void __launch_bounds__(256)
+    write_out_order_kernel(int32_t nrows, const mpcx_nnz_t* __restrict__ rowptr, const IDX* __restrict__ val_map,
+                           IDX* __restrict__ out_map, int16_t* __restrict__ out_delta, int32_t* __restrict__ bad)
+{
+  const int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r >= nrows)
+    return;
+  const int64_t rs = rowptr[r], re = rowptr[r + 1];
+  if (re == rs)
+    return;
+  IDX lo = val_map[rs], hi = lo;
+  for (int64_t k = rs + 1; k < re; ++k)
+  {
+    const IDX c = val_map[k];
+    lo = c < lo ? c : lo;
+    hi = c > hi ? c : hi;
+  }
+  if (int64_t(hi - lo) != re - rs - 1 || re - rs > 32767)
+  {
+    *bad = 1;
+    return;
+  }
+  for (int64_t k = rs; k < re; ++k)
+  {
+    const IDX c = val_map[k];
+    const int64_t slot = rs + int64_t(c - lo); // the slot that writes caller position c reads entry k
+    out_map[slot] = c;
+    out_delta[slot] = int16_t(k - slot);
+  }
+}
 inline unsigned permute_grid(int64_t n)
 {
   static const int wgs = []
@@ -298,6 +337,37 @@ extern "C" int mpcx_permute_values(int64_t n, const void* src, int32_t wide, con
     hipLaunchKernelGGL(permute_values_kernel<uint32_t>, dim3(permute_grid(n)), dim3(256), 0, st, n,
                        static_cast<const uint32_t*>(src), vals2, dst);
   return check(hipGetLastError(), "permute_values_kernel launch");
+}
+
+extern "C" int mpcx_write_out_order(int32_t nrows, const mpcx_nnz_t* rowptr, const void* val_map, int32_t wide, void* out_map,
+                                    int16_t* out_delta, int32_t* bad, void* stream)
+{
+  if (nrows <= 0)
+    return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned grid = unsigned((int64_t(nrows) + 255) / 256);
+  if (wide)
+    hipLaunchKernelGGL(write_out_order_kernel<int64_t>, dim3(grid), dim3(256), 0, st, nrows, rowptr,
+                       static_cast<const int64_t*>(val_map), static_cast<int64_t*>(out_map), out_delta, bad);
+  else
+    hipLaunchKernelGGL(write_out_order_kernel<uint32_t>, dim3(grid), dim3(256), 0, st, nrows, rowptr,
+                       static_cast<const uint32_t*>(val_map), static_cast<uint32_t*>(out_map), out_delta, bad);
+  return check(hipGetLastError(), "write_out_order_kernel launch");
+}
+
+extern "C" int mpcx_invert_permutation(int64_t n, const void* src, int32_t wide, void* out, void* stream)
+{
+  if (n <= 0)
+    return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned grid = unsigned((n + 255) / 256);
+  if (wide)
+    hipLaunchKernelGGL(invert_permutation_kernel<int64_t>, dim3(grid), dim3(256), 0, st, n, static_cast<const int64_t*>(src),
+                       static_cast<int64_t*>(out));
+  else
+    hipLaunchKernelGGL(invert_permutation_kernel<uint32_t>, dim3(grid), dim3(256), 0, st, n, static_cast<const uint32_t*>(src),
+                       static_cast<uint32_t*>(out));
+  return check(hipGetLastError(), "invert_permutation_kernel launch");
 }
 
 // ---------------------------------------------------------------------------------------------------------------

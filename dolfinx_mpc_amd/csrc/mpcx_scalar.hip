@@ -908,6 +908,11 @@ int unsupported(const mpcx_kernel_t& k)
 int launch_matrix_scalar(const mpcx_matrix_args_t& a)
 {
   const mpcx_kernel_t& k = a.kernel;
+  if (a.val_map)
+  {
+    mpcx_set_error("mpcx_assemble_matrix: val_map is honoured by the float64 kernels only");
+    return -3;
+  }
   switch (k.form)
   {
   case MPCX_FORM_STIFFNESS:
@@ -938,6 +943,11 @@ int launch_matrix_scalar(const mpcx_matrix_args_t& a)
 int launch_vector_scalar(const mpcx_vector_args_t& a)
 {
   const mpcx_kernel_t& k = a.kernel;
+  if (a.row_map)
+  {
+    mpcx_set_error("mpcx_assemble_vector: row_map is honoured by the float64 kernels only");
+    return -3;
+  }
   switch (k.form)
   {
   case MPCX_FORM_SOURCE:
@@ -956,6 +966,11 @@ int launch_vector_scalar(const mpcx_vector_args_t& a)
 int launch_lifting_scalar(const mpcx_lifting_args_t& a)
 {
   const mpcx_kernel_t& k = a.kernel;
+  if (a.row_map)
+  {
+    mpcx_set_error("mpcx_apply_lifting: row_map is honoured by the float64 kernels only");
+    return -3;
+  }
   switch (k.form)
   {
   case MPCX_FORM_STIFFNESS:

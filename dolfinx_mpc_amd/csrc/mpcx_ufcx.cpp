@@ -149,7 +149,7 @@ __device__ inline void matrix_item(const mpcx_matrix_args_t& a, long long e, dou
         continue;
       const long long pos = csr_find(a.cols, lo, hi, c);
       if (pos >= 0)
-        atomic_add_f64(a.vals + pos, Ae[p * N1 + q]);
+        atomic_add_f64(a.vals + MPCX_VAL_POS(a, pos), Ae[p * N1 + q]);
     }
   }
 }
@@ -204,14 +204,14 @@ __device__ inline void matrix_mpc_item(const mpcx_matrix_args_t& a, long long t,
           {
             const long long pos = csr_find(a.cols, lo, hi, a.mpc1.masters[mj]);
             if (pos >= 0)
-              atomic_add_f64(a.vals + pos, ci * a.mpc1.coeffs[mj] * v);
+              atomic_add_f64(a.vals + MPCX_VAL_POS(a, pos), ci * a.mpc1.coeffs[mj] * v);
           }
         }
         else if (!cbc[q])
         {
           const long long pos = csr_find(a.cols, lo, hi, colsd[q]);
           if (pos >= 0)
-            atomic_add_f64(a.vals + pos, ci * v);
+            atomic_add_f64(a.vals + MPCX_VAL_POS(a, pos), ci * v);
         }
       }
     }
@@ -230,7 +230,7 @@ __device__ inline void matrix_mpc_item(const mpcx_matrix_args_t& a, long long t,
           continue;
         const long long pos = csr_find(a.cols, a.rowptr[rows[p]], a.rowptr[rows[p] + 1], m);
         if (pos >= 0)
-          atomic_add_f64(a.vals + pos, cj * (cbc[q] ? 0.0 : Ae[p * N1 + q]));
+          atomic_add_f64(a.vals + MPCX_VAL_POS(a, pos), cj * (cbc[q] ? 0.0 : Ae[p * N1 + q]));
       }
     }
   }
@@ -273,12 +273,12 @@ __device__ inline void lifting_item(const mpcx_lifting_args_t& a, long long t, d
     {
       const int m0 = a.mpc0.masters_offsets[d], m1 = a.mpc0.masters_offsets[d + 1];
       for (int mi = m0; mi < m1; ++mi)
-        atomic_add_f64(a.b + a.mpc0.masters[mi], a.mpc0.coeffs[mi] * v);
+        atomic_add_f64(a.b + MPCX_ROW_POS(a, a.mpc0.masters[mi]), a.mpc0.coeffs[mi] * v);
       if (m1 > m0)
         v = 0.0;
     }
     if (v != 0.0)
-      atomic_add_f64(a.b + d, v);
+      atomic_add_f64(a.b + MPCX_ROW_POS(a, d), v);
   }
 }
 extern "C" __global__ void __launch_bounds__(64) ufcx_lifting_kernel(mpcx_lifting_args_t a)
@@ -307,12 +307,12 @@ extern "C" __global__ void __launch_bounds__(64) ufcx_vector_kernel(mpcx_vector_
     {
       const int m0 = a.mpc.masters_offsets[d], m1 = a.mpc.masters_offsets[d + 1];
       for (int mi = m0; mi < m1; ++mi)
-        atomic_add_f64(a.b + a.mpc.masters[mi], a.mpc.coeffs[mi] * v);
+        atomic_add_f64(a.b + MPCX_ROW_POS(a, a.mpc.masters[mi]), a.mpc.coeffs[mi] * v);
       if (m1 > m0)
         v = 0.0;
     }
     if (v != 0.0)
-      atomic_add_f64(a.b + d, v);
+      atomic_add_f64(a.b + MPCX_ROW_POS(a, d), v);
   }
 }
 #endif
@@ -506,10 +506,10 @@ extern "C" __global__ void __launch_bounds__(UFCX_RB_THREADS) ufcx_matrix_rowblo
   __syncthreads();
   if (a.store_mode)
     for (int i = tid; i < nnzb; i += NT)
-      a.vals[nnz0 + i] = s_vals[i];
+      a.vals[MPCX_OUT_POS(a, nnz0 + i)] = s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
   else
     for (int i = tid; i < nnzb; i += NT)
-      a.vals[nnz0 + i] += s_vals[i];
+      a.vals[MPCX_OUT_POS(a, nnz0 + i)] += s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
 }
 
 // Master contributions from the plan gathered by target position (mpcx_mpc_plan_device): G lanes share one
@@ -545,7 +545,7 @@ extern "C" __global__ void __launch_bounds__(64) ufcx_matrix_mpc_plan_kernel(mpc
   for (int m = G >> 1; m > 0; m >>= 1)
     sum += __shfl_xor(sum, m, G);
   if (lane == 0)
-    a.vals[a.mpc_plan_tgt[t]] += sum;
+    a.vals[MPCX_VAL_POS(a, a.mpc_plan_tgt[t])] += sum;
 }
 
 // The same with every slave entity tabulated once (slave_tensors + mpc_plan_slot, include/mpcx.h): a thread per slave
@@ -583,7 +583,7 @@ extern "C" __global__ void __launch_bounds__(64) ufcx_matrix_mpc_gather_kernel(m
   for (int m = G >> 1; m > 0; m >>= 1)
     sum += __shfl_xor(sum, m, G);
   if (lane == 0)
-    a.vals[a.mpc_plan_tgt[t]] += sum;
+    a.vals[MPCX_VAL_POS(a, a.mpc_plan_tgt[t])] += sum;
 }
 #endif // !UFCX_BIG
 #else
@@ -647,7 +647,7 @@ extern "C" __global__ void __launch_bounds__(UFCX_RB_THREADS) ufcx_vector_rowblo
   }
   __syncthreads();
   for (int i = tid; i < nown; i += NT)
-    a.b[r0 + i] += s_b[i];
+    a.b[MPCX_ROW_POS(a, r0 + i)] += s_b[i];
   for (int i = tid; i < nhalo; i += NT)
     a.own_spill[h0 * BS0 + i] = s_b[nown + i];
 }
@@ -702,14 +702,14 @@ extern "C" __global__ void __launch_bounds__(64) ufcx_vector_mpc_kernel(mpcx_vec
           h = (h + 1) & (UFCX_VMPC_H - 1);
         }
         if (probe == 32)
-          atomic_add_f64(a.b + row, v);
+          atomic_add_f64(a.b + MPCX_ROW_POS(a, row), v);
       }
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < UFCX_VMPC_H; i += 64)
     if (s_key[i] >= 0)
-      atomic_add_f64(a.b + s_key[i], s_val[i]);
+      atomic_add_f64(a.b + MPCX_ROW_POS(a, s_key[i]), s_val[i]);
 }
 #endif
 )MPCXR";
@@ -901,10 +901,10 @@ __device__ __attribute__((always_inline)) inline void ufcx_matrix_cube_body(cons
   __syncthreads();
   if (a.store_mode)
     for (int i = tid; i < nnzb; i += NT)
-      a.vals[nnz0 + i] = s_vals[i];
+      a.vals[MPCX_OUT_POS(a, nnz0 + i)] = s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
   else
     for (int i = tid; i < nnzb; i += NT)
-      a.vals[nnz0 + i] += s_vals[i];
+      a.vals[MPCX_OUT_POS(a, nnz0 + i)] += s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
 }
 #if UFCX_CUBE_WAVES
 #define UFCX_CUBE_OCC __attribute__((amdgpu_waves_per_eu(UFCX_CUBE_WAVES)))
@@ -1007,7 +1007,7 @@ extern "C" __global__ void __launch_bounds__(UFCX_VCUBE_THREADS) UFCX_VCUBE_OCC 
   }
   __syncthreads();
   for (int i = tid; i < nown; i += NT)
-    a.b[r0 + i] += s_b[i];
+    a.b[MPCX_ROW_POS(a, r0 + i)] += s_b[i];
   for (int i = tid; i < nhalo; i += NT)
     a.own_spill[h0 + i] = s_b[nown + i];
 }
@@ -1262,7 +1262,7 @@ extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
   for (const std::string inc : {"#include <stdint.h>", "#include <stddef.h>"})
     if (auto p = hdr.find(inc); p != std::string::npos)
       hdr.replace(p, inc.size(), "");
-  std::string src = "typedef signed char int8_t;\ntypedef unsigned char uint8_t;\ntypedef unsigned short uint16_t;\n"
+  std::string src = "typedef signed char int8_t;\ntypedef unsigned char uint8_t;\ntypedef short int16_t;\ntypedef unsigned short uint16_t;\n"
                     "typedef int int32_t;\ntypedef unsigned int uint32_t;\ntypedef long long int64_t;\n"
                     "typedef unsigned long long uint64_t;\ntypedef __SIZE_TYPE__ size_t;\n#define restrict __restrict__\n";
   src += hdr;

@@ -408,6 +408,8 @@ def assemble_matrix(tw: Twin, form: Form, mpc0, mpc1, bcs, diagval, A, alg: int)
     caller's stream, so the vector assembly of the same step runs beside it)"""
     import importlib
 
+    import torch
+
     from .la import side_stream
 
     am = importlib.import_module(__package__ + ".assemble_matrix")
@@ -415,11 +417,40 @@ def assemble_matrix(tw: Twin, form: Form, mpc0, mpc1, bcs, diagval, A, alg: int)
     form2, m0, bcs2 = tw.form(form), tw.mpc(mpc0), tw.bcs(bcs)
     m1 = m0 if mpc1 is mpc0 else tw.mpc(mpc1)
     D.mesh_device(form2.mesh)
-    lazy = os.environ.get("MPCX_TWIN_HANDBACK", "eager") == "lazy"
+    mode = os.environ.get("MPCX_TWIN_HANDBACK", "fused")
+    lazy = mode == "lazy"
+    # "fused" (default): the twin's kernels write every value straight to its position in the caller's CSR
+    # (mpcx_matrix_args_t::val_map = the inverse of ``src``): no second pass over the values, and the twin keeps no value
+    # array of its own.  float64 only; a form that takes block-scalar storage keeps its compact values in the twin and is
+    # handed back by the pass below.
+    A2._write_through = None
+    if mode == "fused" and A.dtype == torch.float64 and A._exchange is None:
+        maps = getattr(A2, "_val_map", None)
+        if maps is None:
+            L = _native.lib()
+            inv = torch.empty_like(src)
+            _native.check(L.mpcx_invert_permutation(A.nnz, src.data_ptr(), int(wide), inv.data_ptr(), D.stream_ptr()),
+                          "mpcx_invert_permutation")
+            omap = odelta = None
+            bad = torch.zeros(1, dtype=torch.int32, device=src.device)
+            # MPCX_TWIN_WRITE_ORDER=1: consecutive lanes write consecutive addresses of a caller's row (out_map / out_delta).
+            # Measured and not the default: config 2 shuffled 4.88 ms per step against 4.55 ms with the plain scatter -- the
+            # cost is the random 216-byte row segments in HBM, not the order of the lanes inside them.
+            if os.environ.get("MPCX_TWIN_WRITE_ORDER", "0") == "1":
+                omap, odelta = torch.empty_like(src), torch.empty(max(A.nnz, 1), dtype=torch.int16, device=src.device)
+                _native.check(L.mpcx_write_out_order(A2.shape[0], A2.d_rowptr.data_ptr(), inv.data_ptr(), int(wide), omap.data_ptr(),
+                                                     odelta.data_ptr(), bad.data_ptr(), D.stream_ptr()), "mpcx_write_out_order")
+                if int(bad.item()):
+                    omap = odelta = None  # (the kernels scatter through ``inv``)
+            maps = A2._val_map = (inv, omap, odelta)
+        A2._write_through = (A, maps[0], wide, maps[1], maps[2])
     with side_stream("matrix", A):
         am._assemble_matrix_on_stream(form2, m0, m1, bcs2, diagval, A2, alg)
         A._compact_stale = False
-        if lazy:
+        through, A2._write_through = A2._write_through is not None, None  # (no reference cycle A <-> A2 is left behind)
+        if through and not A2._compact_stale:
+            A._twin_stale = False  # (the values are in place)
+        elif lazy:
             # the values stay in the twin's matrix until somebody reads ``A.vals`` (to_scipy, a solver, an exchange): like
             # block-scalar storage, the pass that writes them to the caller's CSR positions runs on demand, once per assembly
             # (PETSc keeps its own internal ordering behind MatSetValuesLocal as well)
@@ -454,11 +485,23 @@ def assemble_vector(tw: Twin, form: Form, mpc, b, alg: int):
         b2 = b._twin = (tw, Vector(b.size))
     b2 = b2[1]
     form2, m2 = tw.form(form), tw.mpc(mpc)
-    _, _, d_pu = tw.space(mpc.function_space)
+    V2, _, d_pu = tw.space(mpc.function_space)
     D.mesh_device(form2.mesh)
+    # "fused" (default): the twin's kernels add straight into the caller's vector (mpcx_vector_args_t::row_map = the inverse
+    # of the dof permutation); otherwise the twin's vector is gathered into the caller's by a pass of its own
+    b2._write_through = None
+    if os.environ.get("MPCX_TWIN_HANDBACK", "fused") == "fused" and b.array.dtype == torch.float64:
+        rm = getattr(V2, "_row_map", None)
+        if rm is None:
+            rm = torch.empty(d_pu.numel(), dtype=torch.int32, device=d_pu.device)
+            rm[d_pu] = torch.arange(d_pu.numel(), dtype=torch.int32, device=d_pu.device)
+            V2._row_map = rm
+        b2._write_through = (b, rm)
     with side_stream("vector", b):
         av._assemble_vector_on_stream(form2, m2, b2, alg)
-        torch.index_select(b2.array, 0, d_pu, out=b.array)
+        through, b2._write_through = b2._write_through is not None, None
+        if not through:
+            torch.index_select(b2.array, 0, d_pu, out=b.array)
     return b
 
 

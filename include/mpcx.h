@@ -27,8 +27,11 @@ extern "C" {
  * 5: pair records, scalar types;  6: mpcx_matrix_args_t::cube_rec_index (one cluster record per cluster, before ``stream``)
  * 7: cube_cells, last field before ``stream`` of the matrix and the vector argument block: MPCX_ALG_CUBE with imported (UFCx) kernels
  * 8: dof transformations of imported kernels: transform0_name / transform1_name of the descriptor, cell_info0 / cell_info1 of
- *    the three argument blocks (before ``stream``) */
-#define MPCX_VERSION 8
+ *    the three argument blocks (before ``stream``)
+ * 9: mpcx_matrix_args_t::val_map / val_map_wide / out_map / out_delta (before ``stream``), mpcx_add_diagonal_mapped,
+ *    mpcx_invert_permutation, mpcx_write_out_order; mpcx_vector_args_t::row_map,
+ *    mpcx_lifting_args_t::row_map */
+#define MPCX_VERSION 9
 
 /* Offsets into the CSR value / column arrays (rowptr entries, positions): 64-bit, so that one GPU can
  * hold matrices with more than 2^31 - 1 stored entries (Taylor-Hood a00 on 128^3 cells: 4.4 G) -- PETSc's
@@ -339,8 +342,29 @@ typedef struct
    * NULL otherwise */
   const uint32_t* cell_info0;
   const uint32_t* cell_info1;
+  /* Write-out through a permutation (the locality twin, dolfinx_mpc_amd/locality.py): rowptr / cols / every plan describe the
+   * CSR of the launch, and the value of its entry k is written (added) to vals[val_map[k]] -- the caller's CSR of the same
+   * matrix in another row / column numbering -- instead of vals[k].  DEVICE [nnz] uint32 (val_map_wide = 0) or int64 (1);
+   * NULL: vals[k].  Honoured by every float64 matrix kernel (MPCX_VAL_POS); other scalar types reject it. */
+  const void* val_map;
+  int32_t val_map_wide;
+  /* The same permutation in the order the row-block kernels write a block out of LDS (mpcx_write_out_order; optional, NULL:
+   * val_map is used there as well): slot k of the launch's CSR writes the value of entry k + out_delta[k] (an entry of the
+   * same row) to vals[out_map[k]], so that consecutive lanes write consecutive addresses of the caller's row -- val_map
+   * alone scatters the 8-byte values of a row in permuted order (config 2 on the twin: matrix kernel 2.1 ms against
+   * 1.0 ms for the unpermuted write-out).  out_map: the index type of val_map; out_delta: int16. */
+  const void* out_map;
+  const int16_t* out_delta;
   void* stream;
 } mpcx_matrix_args_t;
+#define MPCX_VAL_POS(a, k)                                                                                                        \
+  ((a).val_map ? ((a).val_map_wide ? ((const int64_t*)(a).val_map)[k] : (int64_t)((const uint32_t*)(a).val_map)[k]) : (int64_t)(k))
+/* write-out of LDS slot i of a row block that starts at CSR position nnz0: vals[MPCX_OUT_POS(a, nnz0 + i)] (=, +=) the LDS
+ * value at index MPCX_OUT_SRC(a, nnz0 + i, i) */
+#define MPCX_OUT_POS(a, k)                                                                                                        \
+  ((a).out_delta ? ((a).val_map_wide ? ((const int64_t*)(a).out_map)[k] : (int64_t)((const uint32_t*)(a).out_map)[k])              \
+                 : MPCX_VAL_POS(a, k))
+#define MPCX_OUT_SRC(a, k, i) ((a).out_delta ? (i) + (int)(a).out_delta[k] : (i))
 
 int mpcx_assemble_matrix(const mpcx_matrix_args_t* args);
 
@@ -521,6 +545,9 @@ int mpcx_pair_context(const mpcx_kernel_t* kernel, int64_t n_entities, int32_t e
 int mpcx_add_diagonal(int32_t nrows, const mpcx_nnz_t* rowptr, const int32_t* cols,
                       double* vals, const int32_t* dofs, int64_t n,
                       double diagval, void* stream);
+/* the same for a launch that writes through mpcx_matrix_args_t::val_map: vals[val_map[pos(d,d)]] += diagval */
+int mpcx_add_diagonal_mapped(int32_t nrows, const mpcx_nnz_t* rowptr, const int32_t* cols, double* vals, const int32_t* dofs,
+                             int64_t n, double diagval, const void* val_map, int32_t val_map_wide, void* stream);
 
 /* ------------------------------------------------------------------------
  * mpcx_assemble_vector: replaces dolfinx_mpc::assemble_vector
@@ -577,8 +604,13 @@ typedef struct
    * (0,1,3,7) (0,1,7,5) (0,5,7,4) (0,3,2,7) (0,6,4,7) (0,2,6,7) (see mpcx_matrix_args_t::cube_cells); NULL otherwise */
   const int32_t* cube_cells;
   const uint32_t* cell_info0; /* the same for the linear form's space, cpp/assemble_vector.cpp:184, or NULL */
+  /* write-out through a permutation (the locality twin, as mpcx_matrix_args_t::val_map): everything the launch adds to
+   * entry d of its own numbering goes to b[row_map[d]] -- DEVICE [scalar dofs] int32 -- instead of b[d]; NULL: b[d].
+   * float64 kernels only. */
+  const int32_t* row_map;
   void* stream;
 } mpcx_vector_args_t;
+#define MPCX_ROW_POS(a, d) ((a).row_map ? (int64_t)(a).row_map[d] : (int64_t)(d))
 
 int mpcx_assemble_vector(const mpcx_vector_args_t* args);
 
@@ -619,6 +651,7 @@ typedef struct
   mpcx_mpc_t mpc0;
   const uint32_t* cell_info0; /* as in mpcx_matrix_args_t, or NULL */
   const uint32_t* cell_info1;
+  const int32_t* row_map; /* as in mpcx_vector_args_t, or NULL */
   void* stream;
 } mpcx_lifting_args_t;
 
@@ -901,6 +934,13 @@ int mpcx_csr_permutation(int32_t nrows, const mpcx_nnz_t* rowptr, const int32_t*
                          const int32_t* new_of_old1, const mpcx_nnz_t* rowptr2, const int32_t* cols2, void* src, int32_t wide,
                          int32_t* bad, void* stream);
 int mpcx_permute_values(int64_t n, const void* src, int32_t wide, const double* vals2, double* dst, void* stream);
+/* out[src[k]] = k: the scatter form of the same permutation (mpcx_matrix_args_t::val_map of the twin's launches) */
+int mpcx_invert_permutation(int64_t n, const void* src, int32_t wide, void* out, void* stream);
+/* out_map / out_delta of mpcx_matrix_args_t from val_map (all DEVICE): for every row r of the launch's CSR (rowptr) the
+ * entries are ranked by their position in the caller's row; *bad is set when a row's entries do not fill one contiguous
+ * range of caller positions (not a permutation of whole rows) or a row is longer than 32767 entries. */
+int mpcx_write_out_order(int32_t nrows, const mpcx_nnz_t* rowptr, const void* val_map, int32_t wide, void* out_map,
+                         int16_t* out_delta, int32_t* bad, void* stream);
 /* The twin itself (all pointers DEVICE): mpcx_renumber_mesh: x_out[node_new_of_old[n]] = x[n] (3 coordinates per node),
  * cells_out[c][i] = node_new_of_old[cells[cell_old_of_new[c]][i]], cell_new_of_old[cell_old_of_new[c]] = c.
  * mpcx_dof_permutation: new_of_old[dofmap_old[c][i]] = dofmap_new[cell_new_of_old[c]][i] for every cell c and local dof i

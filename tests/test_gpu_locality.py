@@ -24,9 +24,15 @@ def _close(got, ref, what):
     assert d <= RTOL * scale, f"{what}: max diff {d:.3e} > {RTOL * scale:.3e}"
 
 
+@pytest.mark.parametrize("handback", ["fused", "fused-ordered", "eager"])
 @pytest.mark.parametrize("make", CASES, ids=[f"case{i}" for i in range(len(CASES))])
-def test_twin_assembly_matches_oracle_in_caller_numbering(oracle, make, monkeypatch):
+def test_twin_assembly_matches_oracle_in_caller_numbering(oracle, make, handback, monkeypatch):
+    """fused (default): the twin's kernels write through mpcx_matrix_args_t::val_map / mpcx_vector_args_t::row_map into the
+    caller's CSR and vector (-ordered: the row-block write-outs through out_map / out_delta); eager: passes of their own
+    (mpcx_permute_values, a gather) after the twin's assembly"""
     monkeypatch.setenv("MPCX_AUTO_REORDER", "1")
+    monkeypatch.setenv("MPCX_TWIN_HANDBACK", handback.split("-")[0])
+    monkeypatch.setenv("MPCX_TWIN_WRITE_ORDER", "1" if handback.endswith("ordered") else "0")
     case = make()
     ref = oracle_outputs(oracle, case)
     out = product_outputs(case, algorithm="rowblock")
@@ -117,7 +123,9 @@ def test_lazy_hand_back_defers_the_permutation_until_the_values_are_read(oracle,
     assert abs(S.data - ref.data).max() <= 1e-12 * abs(ref.data).max()
     dm.assemble_matrix(case.a, mpc, bcs=case.bcs, A=A)
     assert A._twin_stale
-    monkeypatch.setenv("MPCX_TWIN_HANDBACK", "eager")
-    dm.assemble_matrix(case.a, mpc, bcs=case.bcs, A=A)
-    assert not A._twin_stale
-    assert abs(A.to_scipy().data - ref.data).max() <= 1e-12 * abs(ref.data).max()
+    for mode in ("eager", "fused"):
+        monkeypatch.setenv("MPCX_TWIN_HANDBACK", mode)
+        A.vals.fill_(-7.0)
+        dm.assemble_matrix(case.a, mpc, bcs=case.bcs, A=A)
+        assert not A._twin_stale
+        assert abs(A.to_scipy().data - ref.data).max() <= 1e-12 * abs(ref.data).max()
