@@ -8,9 +8,11 @@ gather coordinates / dofmap rows of the entities that touch them; without locali
 coordinate costs a 64-128-byte line) and every entity touches as many blocks as it has dofs.  The data has to be laid
 out in a local order physically, so the twin owns reordered copies of the mesh, the dofmaps, the constraint and the
 Dirichlet markers (the same arrays the reference's ``create_*`` calls would hold after DOLFINx's own dof reordering;
-numbering is not part of the reference's contract) and the existing kernels run on them unchanged.  What is added per
-call is one pass that writes the values to the caller's CSR positions (``mpcx_permute_values``: 8 + 8 + 4 bytes per
-entry) and a gather of the vector.
+numbering is not part of the reference's contract) and the existing kernels run on them unchanged.  The values reach the
+caller's numbering inside the kernels: every write of a float64 kernel goes through ``mpcx_matrix_args_t::val_map`` (twin CSR
+position -> caller CSR position) / ``mpcx_vector_args_t::row_map`` (round 5; ``MPCX_TWIN_HANDBACK=eager`` brings back round
+4's passes -- ``mpcx_permute_values``, 8 + 8 + 4 bytes per entry, and a gather of the vector -- which block-scalar storage and
+the other scalar types still use; ``lazy`` defers that pass until the values are read).
 
 The reference's call sequence stays what it is (python/src/dolfinx_mpc/assemble_matrix.py:21-65,
 assemble_vector.py:25-104): the twin is consulted inside ``assemble_matrix`` / ``assemble_vector`` / ``apply_lifting``.
@@ -19,8 +21,8 @@ Switch: ``MPCX_AUTO_REORDER`` = ``0`` off, ``1`` always (tests), unset: meshes o
 (default 50 000) cells without tile hints on one process.
 
 Memory: the twin holds a second copy of the mesh, of every dofmap / constraint / Function it has been shown, and -- per
-matrix -- a second value array with its pattern plus 4 (8 beyond 2^32 entries) bytes per entry for the hand-back index
-(config 2: + 3 GB per matrix).  The copies of Forms, Functions, Dirichlet conditions and constraints live exactly as long
+matrix -- a second pattern plus 2 x 4 (8 beyond 2^32 entries) bytes per entry for the two permutation indices (config 2:
++ 3 GB per matrix; a second value array only with the eager / lazy hand-back).  The copies of Forms, Functions, Dirichlet conditions and constraints live exactly as long
 as the caller's objects do (weak references: a time loop that rebuilds its forms every step does not accumulate twins),
 a matrix's twin as long as the matrix; a (matrix, form) pair the twin could not represent is remembered and not retried."""
 
