@@ -511,12 +511,7 @@ __global__ void __launch_bounds__(CUBE_MAX_THREADS) matrix_cube_kernel(mpcx_matr
     }
   }
   __syncthreads();
-  if (a.store_mode)
-    for (int i = tid; i < nnzb; i += NT)
-      a.vals[MPCX_OUT_POS(a, nnz0 + i)] = s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
-  else
-    for (int i = tid; i < nnzb; i += NT)
-      a.vals[MPCX_OUT_POS(a, nnz0 + i)] += s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
+  MPCX_WRITE_OUT(a, nnz0, nnzb, s_vals, tid, NT);
 }
 
 // ---------------------------------------------------------------------------
@@ -1111,12 +1106,7 @@ __global__ void __launch_bounds__(HEX_MAX_THREADS) matrix_hex_kernel(mpcx_matrix
     }
   }
   __syncthreads();
-  if (a.store_mode)
-    for (int i = tid; i < nnzb; i += NT)
-      a.vals[MPCX_OUT_POS(a, nnz0 + i)] = s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
-  else
-    for (int i = tid; i < nnzb; i += NT)
-      a.vals[MPCX_OUT_POS(a, nnz0 + i)] += s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
+  MPCX_WRITE_OUT(a, nnz0, nnzb, s_vals, tid, NT);
 }
 
 // vector: scalar Q1 source term c * f v dx over an NQ1^3 Gauss rule, one thread per hexahedron, owner-computes row
@@ -1447,12 +1437,7 @@ __global__ void __launch_bounds__(CUBE_AFFINE_MAX_THREADS) matrix_cube_affine_ke
       }
   }
   __syncthreads();
-  if (a.store_mode)
-    for (int i = tid; i < nnzb; i += NT)
-      a.vals[MPCX_OUT_POS(a, nnz0 + i)] = s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
-  else
-    for (int i = tid; i < nnzb; i += NT)
-      a.vals[MPCX_OUT_POS(a, nnz0 + i)] += s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
+  MPCX_WRITE_OUT(a, nnz0, nnzb, s_vals, tid, NT);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1641,12 +1626,7 @@ __global__ void __launch_bounds__(CUBE_EL_THREADS) matrix_cube_elasticity_rowpai
     }
   }
   __syncthreads();
-  if (a.store_mode)
-    for (int i = tid; i < nnzb; i += NT)
-      a.vals[MPCX_OUT_POS(a, nnz0 + i)] = s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
-  else
-    for (int i = tid; i < nnzb; i += NT)
-      a.vals[MPCX_OUT_POS(a, nnz0 + i)] += s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
+  MPCX_WRITE_OUT(a, nnz0, nnzb, s_vals, tid, NT);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2024,12 +2004,7 @@ __global__ void __launch_bounds__(P2CUBE_MAX_THREADS) matrix_p2_cube_kernel(mpcx
     }
   }
   __syncthreads();
-  if (a.store_mode)
-    for (int i = tid; i < nnzb; i += NT)
-      a.vals[MPCX_OUT_POS(a, nnz0 + i)] = s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
-  else
-    for (int i = tid; i < nnzb; i += NT)
-      a.vals[MPCX_OUT_POS(a, nnz0 + i)] += s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
+  MPCX_WRITE_OUT(a, nnz0, nnzb, s_vals, tid, NT);
 }
 
 } // namespace

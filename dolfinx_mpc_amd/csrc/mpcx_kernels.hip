@@ -695,12 +695,8 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
       }
     }
   }
-  else if (a.store_mode)
-    for (int i = tid; i < nnzb; i += NT)
-      a.vals[MPCX_OUT_POS(a, nnz0 + i)] = s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
   else
-    for (int i = tid; i < nnzb; i += NT)
-      a.vals[MPCX_OUT_POS(a, nnz0 + i)] += s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
+    MPCX_WRITE_OUT(a, nnz0, nnzb, s_vals, tid, NT);
 }
 
 // Node-block variant for component-diagonal forms on blocked spaces (S (x) I: vector stiffness / mass, the
@@ -991,12 +987,8 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowpair_kernel(mp
       }
     }
   }
-  else if (a.store_mode)
-    for (int i = tid; i < nnzb; i += NT)
-      a.vals[MPCX_OUT_POS(a, nnz0 + i)] = s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
   else
-    for (int i = tid; i < nnzb; i += NT)
-      a.vals[MPCX_OUT_POS(a, nnz0 + i)] += s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
+    MPCX_WRITE_OUT(a, nnz0, nnzb, s_vals, tid, NT);
 }
 
 // Per-cell rotation of the local (vertex) numbering used by the lean row-block path: cell c lists

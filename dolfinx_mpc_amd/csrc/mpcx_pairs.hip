@@ -334,12 +334,7 @@ __global__ void __launch_bounds__(PAIRS_MAX_THREADS) matrix_pairs_kernel(mpcx_ma
     }
   }
   __syncthreads();
-  if (a.store_mode)
-    for (int i = tid; i < nnzb; i += NT)
-      a.vals[MPCX_OUT_POS(a, nnz0 + i)] = s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
-  else
-    for (int i = tid; i < nnzb; i += NT)
-      a.vals[MPCX_OUT_POS(a, nnz0 + i)] += s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
+  MPCX_WRITE_OUT(a, nnz0, nnzb, s_vals, tid, NT);
 }
 
 // constant-free context of every entity (ElementOp::ctx_store), one thread per entity

@@ -504,12 +504,7 @@ extern "C" __global__ void __launch_bounds__(UFCX_RB_THREADS) ufcx_matrix_rowblo
 #endif
   }
   __syncthreads();
-  if (a.store_mode)
-    for (int i = tid; i < nnzb; i += NT)
-      a.vals[MPCX_OUT_POS(a, nnz0 + i)] = s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
-  else
-    for (int i = tid; i < nnzb; i += NT)
-      a.vals[MPCX_OUT_POS(a, nnz0 + i)] += s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
+  MPCX_WRITE_OUT(a, nnz0, nnzb, s_vals, tid, NT);
 }
 
 // Master contributions from the plan gathered by target position (mpcx_mpc_plan_device): G lanes share one
@@ -899,12 +894,7 @@ __device__ __attribute__((always_inline)) inline void ufcx_matrix_cube_body(cons
     }
   }
   __syncthreads();
-  if (a.store_mode)
-    for (int i = tid; i < nnzb; i += NT)
-      a.vals[MPCX_OUT_POS(a, nnz0 + i)] = s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
-  else
-    for (int i = tid; i < nnzb; i += NT)
-      a.vals[MPCX_OUT_POS(a, nnz0 + i)] += s_vals[MPCX_OUT_SRC(a, nnz0 + i, i)];
+  MPCX_WRITE_OUT(a, nnz0, nnzb, s_vals, tid, NT);
 }
 #if UFCX_CUBE_WAVES
 #define UFCX_CUBE_OCC __attribute__((amdgpu_waves_per_eu(UFCX_CUBE_WAVES)))

@@ -54,6 +54,9 @@ def _async_enabled() -> bool:
     return os.environ.get("MPCX_ASYNC_STREAMS", "1") != "0"
 
 
+_CHAIN_CALLER = __import__("os").environ.get("MPCX_SIDE_CHAIN_CALLER", "0") == "1"  # (A/B switch: round 4's ordering)
+
+
 @contextlib.contextmanager
 def side_stream(kind: str, obj):
     """run the body on the library's ``kind`` ("matrix" / "vector") stream; ``obj`` (an MPCMatrix / Vector) gets the
@@ -90,7 +93,7 @@ def side_stream(kind: str, obj):
     # stream must not wait for it here: the next call's ``side.wait_stream(cur)`` would inherit that wait and chain the
     # vector assembly of step i + 1 behind the matrix hand-back of step i (locality twin, config 2: 5.2 ms per step with the
     # wait, the two streams in lockstep).  Results written by any other stream are waited for as before.
-    if getattr(obj, "_ready_raw", None) != side.cuda_stream:
+    if getattr(obj, "_ready_raw", None) != side.cuda_stream or _CHAIN_CALLER:
         obj._wait_ready()
     side.wait_stream(cur)
     with torch.cuda.stream(side):
