@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import contextlib
 import enum
+import os
 
 import numpy as np
 
@@ -49,12 +50,11 @@ _next_slot = [0]
 
 
 def _async_enabled() -> bool:
-    import os
-
     return os.environ.get("MPCX_ASYNC_STREAMS", "1") != "0"
 
 
-_CHAIN_CALLER = __import__("os").environ.get("MPCX_SIDE_CHAIN_CALLER", "0") == "1"  # (A/B switch: round 4's ordering)
+# A/B switch (round 4's ordering: the caller's stream waits for the previous assembly into the same object)
+_CHAIN_CALLER = os.environ.get("MPCX_SIDE_CHAIN_CALLER", "0") == "1"
 
 
 @contextlib.contextmanager
@@ -71,14 +71,10 @@ def side_stream(kind: str, obj):
     if kind == "matrix":
         slot = getattr(obj, "_side_slot", None)
         if slot is None:
-            import os
-
             slot = obj._side_slot = _next_slot[0] % max(int(os.environ.get("MPCX_MATRIX_STREAMS", 1)), 1)
             _next_slot[0] += 1
     key = (kind, obj.device.index, slot)
     if key not in _side:
-        import os
-
         # HIP stream priority (-1 = high).  The matrix streams are high-priority ones: the short, memory-bound matrix
         # kernels get the slots that free up while the long, VALU-bound vector kernel of the same step runs (config 2:
         # 3.56 -> 3.44 ms per step; vector high: 3.61).  MPCX_MATRIX_STREAM_PRIORITY / MPCX_VECTOR_STREAM_PRIORITY
