@@ -367,8 +367,8 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False, pai
     light = lean and V0.dofmap.bs == 1 and V0.element_ndofs <= 4
     max_rows_cap, max_nnz_cap = ((ROWBLOCK_LIGHT_MAX_ROWS, ROWBLOCK_LIGHT_MAX_NNZ) if light
                                  else (ROWBLOCK_MAX_ROWS, ROWBLOCK_MAX_NNZ))
-    if np.dtype(getattr(form, "dtype", np.float64)).itemsize > 8:
-        max_nnz_cap //= 2  # complex128: 16 bytes per LDS value
+    if np.dtype(getattr(form, "dtype", np.float64)).kind == "c":
+        max_nnz_cap //= 2  # complex: 16 bytes per LDS value (complex64 accumulates in fp64 pairs as well, csrc/mpcx_scalar.hip)
     kf = form.integrals[i].kernel
     # entities of a block ordered by which of their local rows lie inside it (measured: P1 elasticity 1.82 -> 1.49 ms,
     # Taylor-Hood coupling blocks 2.0 -> 1.8, P2 stiffness +1.5 %; the light P1 kernel loses its coordinate locality,

@@ -41,10 +41,14 @@ __device__ inline bool wnonzero(cplx a) { return a.re != 0.0 || a.im != 0.0; }
 __device__ inline bool wnonzero(double a) { return a != 0.0; }
 
 // storage traits: T = element type in memory, W = arithmetic type
+// LT = the type of the LDS copy of a row block: always fp64 (pairs).  ds_add_f32 takes ~116 cycles per wave instruction on
+// gfx950 against ~15 for ds_add_f64 (round 5, SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS of the float32 and complex64 matrix kernels:
+// LDS 86 % busy without bank conflicts), so float32 / complex64 accumulate in fp64 and are rounded once, at the write-out.
 struct SF64
 {
   using T = double;
   using W = double;
+  using LT = double;
   static constexpr bool COMPLEX = false;
   __device__ static W load(const T* p) { return *p; }
   __device__ static void store(T* p, W v) { *p = v; }
@@ -55,6 +59,7 @@ struct SF32
 {
   using T = float;
   using W = double;
+  using LT = double;
   static constexpr bool COMPLEX = false;
   __device__ static W load(const T* p) { return double(*p); }
   __device__ static void store(T* p, W v) { *p = float(v); }
@@ -65,6 +70,7 @@ struct SC128
 {
   using T = double2;
   using W = cplx;
+  using LT = double2;
   static constexpr bool COMPLEX = true;
   __device__ static W load(const T* p) { return {p->x, p->y}; }
   __device__ static void store(T* p, W v) { *p = make_double2(v.re, v.im); }
@@ -80,6 +86,7 @@ struct SC64
 {
   using T = float2;
   using W = cplx;
+  using LT = double2;
   static constexpr bool COMPLEX = true;
   __device__ static W load(const T* p) { return {double(p->x), double(p->y)}; }
   __device__ static void store(T* p, W v) { *p = make_float2(float(v.re), float(v.im)); }
@@ -137,7 +144,10 @@ constexpr int MAX_CSTRIDE = 96;
 constexpr int SC_UNROLL_MAX = 144; // packed coefficient values per entity the scalar path accepts (three P2^3 fields)
 
 // element tensor of one entity in W from data of type T (see the header)
-template <class Op, class S>
+// HASW = false: the form has no coefficient (w is NULL) -- the staging array of the coefficient values, indexed at run time,
+// is what put 800 bytes of scratch memory per lane under every instance (round 5: the row-block kernels are instantiated
+// without it for forms without coefficients)
+template <class Op, class S, bool HASW = true>
 __device__ inline bool tabulate_w(typename S::W* A, const typename S::T* w, int cstride, const typename S::T* c,
                                   const double (&cd)[Op::NV * 3], int lf, const mpcx_kernel_t& k)
 {
@@ -146,20 +156,25 @@ __device__ inline bool tabulate_w(typename S::W* A, const typename S::T* w, int 
   constexpr int UN = SIZE <= SC_UNROLL_MAX ? SIZE : 1; // unroll count of the loops over the tensor
   constexpr bool ELAST = Op::FORM == MPCX_FORM_ELASTICITY;
   const bool vecconst = Op::RANK1 && k.fn_id == 5; // f = constants[1 : 1 + bs]
-  if (cstride > MAX_CSTRIDE)
+  if (HASW && cstride > MAX_CSTRIDE)
     return false;
   double Ar[SIZE];
-  double wr[MAX_CSTRIDE];
+  double wr[HASW ? MAX_CSTRIDE : 1];
   double cr[2 + Op::BS0];
+  if constexpr (!HASW)
+    w = nullptr;
   if constexpr (!S::COMPLEX)
   {
-    for (int i = 0; i < cstride; ++i)
-      wr[i] = S::load(w + i);
+    if constexpr (HASW)
+      for (int i = 0; i < cstride; ++i)
+        wr[i] = S::load(w + i);
     const int nc = ELAST ? 2 : (vecconst ? 1 + Op::BS0 : 1);
-    if (c)
-      for (int i = 0; i < nc; ++i)
-        cr[i] = S::load(c + i);
-    Op::tabulate(Ar, w ? wr : nullptr, c ? cr : nullptr, cd, lf, k);
+    // (a constant trip count and an unconditional pointer: cr stays in registers.  No constants = the factor 1, which is what
+    // ElementOp::tabulate takes for a NULL pointer; the forms that read further constants are never given NULL)
+#pragma unroll
+    for (int i = 0; i < 2 + Op::BS0; ++i)
+      cr[i] = (c && i < nc) ? double(S::load(c + i)) : (i == 0 ? 1.0 : 0.0);
+    Op::tabulate(Ar, w ? wr : nullptr, cr, cd, lf, k);
 #pragma unroll UN
     for (int i = 0; i < SIZE; ++i)
       A[i] = Ar[i];
@@ -193,12 +208,13 @@ __device__ inline bool tabulate_w(typename S::W* A, const typename S::T* w, int 
       for (int pw = 0; pw < nw; ++pw)
         for (int pg = 0; pg < ng; ++pg)
         {
-          if (w)
-            for (int i = 0; i < cstride; ++i)
-            {
-              const W v = S::load(w + i);
-              wr[i] = pw == 0 ? v.re : v.im;
-            }
+          if constexpr (HASW)
+            if (w)
+              for (int i = 0; i < cstride; ++i)
+              {
+                const W v = S::load(w + i);
+                wr[i] = pw == 0 ? v.re : v.im;
+              }
           cr[0] = 1.0;
           if (vecconst && c)
             for (int b = 0; b < Op::BS0; ++b)
@@ -368,16 +384,32 @@ __global__ void __launch_bounds__(64) matrix_scalar_kernel(mpcx_matrix_args_t a,
 // the formulation of matrix_rowblock_kernel without its fp64-only shortcuts (lean path, lazy entries, register tensors).
 // ---------------------------------------------------------------------------------------------------------------
 template <class S>
-__device__ inline void lds_add(typename S::T* p, typename S::W v)
+__device__ inline void lds_add(typename S::LT* p, typename S::W v)
 {
   if constexpr (S::COMPLEX)
   {
-    auto* q = reinterpret_cast<decltype(p->x)*>(p);
-    __hip_atomic_fetch_add(q, decltype(p->x)(v.re), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_add(q + 1, decltype(p->x)(v.im), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    double* q = reinterpret_cast<double*>(p);
+    __hip_atomic_fetch_add(q, v.re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(q + 1, v.im, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   else
-    __hip_atomic_fetch_add(p, typename S::T(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <class S>
+__device__ inline typename S::W lds_load(const typename S::LT* p)
+{
+  if constexpr (S::COMPLEX)
+    return {p->x, p->y};
+  else
+    return *p;
+}
+template <class S>
+__device__ inline void lds_zero(typename S::LT* p)
+{
+  if constexpr (S::COMPLEX)
+    *p = make_double2(0.0, 0.0);
+  else
+    *p = 0.0;
 }
 
 constexpr int SC_MASK_SHIFT = 28;
@@ -385,7 +417,7 @@ constexpr int SC_DOF_MASK = (1 << SC_MASK_SHIFT) - 1;
 
 constexpr int SC_ROWBLOCK_THREADS = 512; // launch bound; 256 threads are launched (MPCX_SCALAR_THREADS: 512 measured +6 % for
 // float32 and -8 % for the complex types at 128^3, 1024 -- registers capped at 128 -- spills for complex128; round 5)
-template <class Op, class S>
+template <class Op, class S, bool HASW>
 __global__ void __launch_bounds__(SC_ROWBLOCK_THREADS) matrix_rowblock_scalar_kernel(mpcx_matrix_args_t a, int32_t* __restrict__ fail)
 {
   using T = typename S::T;
@@ -403,10 +435,11 @@ __global__ void __launch_bounds__(SC_ROWBLOCK_THREADS) matrix_rowblock_scalar_ke
   const int nrow = r1 - r0;
   const int64_t nnz0 = a.rowptr[r0];
   const int nnzb = int(a.rowptr[r1] - nnz0);
-  T* s_vals = reinterpret_cast<T*>(smem);
+  using LT = typename S::LT;
+  LT* s_vals = reinterpret_cast<LT*>(smem);
   int32_t* s_rowlo = reinterpret_cast<int32_t*>(s_vals + a.plan.max_nnz);
   for (int i = tid; i < nnzb; i += NT)
-    S::store(s_vals + i, S::zero());
+    lds_zero<S>(s_vals + i);
   for (int rl = tid; rl <= nrow; rl += NT)
     s_rowlo[rl] = int(a.rowptr[r0 + rl] - nnz0);
   __syncthreads();
@@ -421,33 +454,65 @@ __global__ void __launch_bounds__(SC_ROWBLOCK_THREADS) matrix_rowblock_scalar_ke
     const int64_t cell0 = (a.entities0 ? a.entities0[l] : e);
     const int64_t cell1 = (a.entities1 ? a.entities1[l] : e);
     const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
+    constexpr bool SMALL = Op::SIZE <= SC_UNROLL_MAX;
+    const uint8_t* __restrict__ po = a.plan.ent_offs + e * (ND0 * ND1);
+    // the masked dofmap rows and the scatter offsets of the entity, loaded up front (SMALL: the unrolled case): inside the
+    // row / column tests below every load sat behind a branch and was waited for on its own -- ~40 serialised memory
+    // latencies per P1 entity, 1.3-2.3 ms for the 12.6 M cells of a 128^3 Poisson matrix against 0.27 ms for the float64
+    // row-block kernel (round 5)
+    int32_t m0v[SMALL ? ND0 : 1], m1v[SMALL ? ND1 : 1];
+    uint8_t pov[SMALL ? ND0 * ND1 : 1];
+    if constexpr (SMALL)
+    {
+#pragma unroll
+      for (int i = 0; i < ND0; ++i)
+        m0v[i] = a.mdofmap0[cell0 * ND0 + i];
+#pragma unroll
+      for (int j = 0; j < ND1; ++j)
+        m1v[j] = a.mdofmap1[cell1 * ND1 + j];
+#pragma unroll
+      for (int i = 0; i < ND0 * ND1; ++i)
+        pov[i] = po[i];
+    }
     double cd[NV * 3];
     gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
     W Ae[Op::SIZE];
-    if (!tabulate_w<Op, S>(Ae, coeffs ? coeffs + e * a.cstride : nullptr, a.cstride, reinterpret_cast<const T*>(a.constants), cd, lf,
-                           a.kernel))
+    if (!tabulate_w<Op, S, HASW>(Ae, coeffs ? coeffs + e * a.cstride : nullptr, a.cstride, reinterpret_cast<const T*>(a.constants), cd,
+                                 lf, a.kernel))
     {
       *fail = 1;
       continue;
     }
-    const uint8_t* __restrict__ po = a.plan.ent_offs + e * (ND0 * ND1);
-    constexpr bool SMALL = Op::SIZE <= SC_UNROLL_MAX;
 #pragma unroll(SMALL ? ND0 : 1)
     for (int i = 0; i < ND0; ++i)
     {
-      const int32_t m0 = a.mdofmap0[cell0 * ND0 + i];
+      int32_t m0;
+      if constexpr (SMALL)
+        m0 = m0v[i];
+      else
+        m0 = a.mdofmap0[cell0 * ND0 + i];
 #pragma unroll(SMALL ? BS0 : 1)
       for (int k = 0; k < BS0; ++k)
       {
         const int r = (m0 & SC_DOF_MASK) * BS0 + k;
         if (r < r0 || r >= r1 || ((m0 >> (SC_MASK_SHIFT + k)) & 1))
           continue;
-        T* row = s_vals + s_rowlo[r - r0];
+        LT* row = s_vals + s_rowlo[r - r0];
 #pragma unroll(SMALL ? ND1 : 1)
         for (int j = 0; j < ND1; ++j)
         {
-          const int32_t m1 = a.mdofmap1[cell1 * ND1 + j];
-          const int off = int(po[i * ND1 + j]) * BS1;
+          int32_t m1;
+          int off;
+          if constexpr (SMALL)
+          {
+            m1 = m1v[j];
+            off = int(pov[i * ND1 + j]) * BS1;
+          }
+          else
+          {
+            m1 = a.mdofmap1[cell1 * ND1 + j];
+            off = int(po[i * ND1 + j]) * BS1;
+          }
 #pragma unroll(SMALL ? BS1 : 1)
           for (int q = 0; q < BS1; ++q)
           {
@@ -467,15 +532,15 @@ __global__ void __launch_bounds__(SC_ROWBLOCK_THREADS) matrix_rowblock_scalar_ke
   __syncthreads();
   if (a.store_mode)
     for (int i = tid; i < nnzb; i += NT)
-      vals[nnz0 + i] = s_vals[i];
+      S::store(vals + nnz0 + i, lds_load<S>(s_vals + i));
   else
     for (int i = tid; i < nnzb; i += NT)
-      S::store(vals + nnz0 + i, S::load(vals + nnz0 + i) + S::load(s_vals + i));
+      S::store(vals + nnz0 + i, S::load(vals + nnz0 + i) + lds_load<S>(s_vals + i));
 }
 
 // vector row blocks: the rows of b a workgroup owns live in LDS; halo entities are evaluated by every block they touch;
 // slave rows are masked here and moved to their masters by vector_scalar_kernel<PART 1> over the slave entities
-template <class Op, class S>
+template <class Op, class S, bool HASW>
 __global__ void __launch_bounds__(SC_ROWBLOCK_THREADS) vector_rowblock_scalar_kernel(mpcx_vector_args_t a, int32_t* __restrict__ fail)
 {
   using T = typename S::T;
@@ -490,9 +555,9 @@ __global__ void __launch_bounds__(SC_ROWBLOCK_THREADS) vector_rowblock_scalar_ke
     return;
   const int tid = threadIdx.x, NT = blockDim.x;
   const int r0 = a.plan.block_row0[b], r1 = a.plan.block_row0[b + 1];
-  T* s_b = reinterpret_cast<T*>(smem);
+  typename S::LT* s_b = reinterpret_cast<typename S::LT*>(smem);
   for (int i = tid; i < r1 - r0; i += NT)
-    S::store(s_b + i, S::zero());
+    lds_zero<S>(s_b + i);
   __syncthreads();
   T* bg = reinterpret_cast<T*>(a.b);
   const T* coeffs = reinterpret_cast<const T*>(a.coeffs);
@@ -506,9 +571,13 @@ __global__ void __launch_bounds__(SC_ROWBLOCK_THREADS) vector_rowblock_scalar_ke
     const int lf = a.estride == 2 ? a.entities[l + 1] : 0;
     double cd[NV * 3];
     gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
+    int32_t m0v[ND]; // (loaded before the element vector is formed: see matrix_rowblock_scalar_kernel)
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+      m0v[i] = a.mdofmap[cell0 * ND + i];
     W be[Op::N0];
-    if (!tabulate_w<Op, S>(be, coeffs ? coeffs + e * a.cstride : nullptr, a.cstride, reinterpret_cast<const T*>(a.constants), cd, lf,
-                           a.kernel))
+    if (!tabulate_w<Op, S, HASW>(be, coeffs ? coeffs + e * a.cstride : nullptr, a.cstride, reinterpret_cast<const T*>(a.constants), cd,
+                                 lf, a.kernel))
     {
       *fail = 1;
       continue;
@@ -516,7 +585,7 @@ __global__ void __launch_bounds__(SC_ROWBLOCK_THREADS) vector_rowblock_scalar_ke
 #pragma unroll
     for (int i = 0; i < ND; ++i)
     {
-      const int32_t m0 = a.mdofmap[cell0 * ND + i];
+      const int32_t m0 = m0v[i];
 #pragma unroll
       for (int k = 0; k < BS; ++k)
       {
@@ -529,7 +598,7 @@ __global__ void __launch_bounds__(SC_ROWBLOCK_THREADS) vector_rowblock_scalar_ke
   }
   __syncthreads();
   for (int i = tid; i < r1 - r0; i += NT)
-    S::store(bg + r0 + i, S::load(bg + r0 + i) + S::load(s_b + i));
+    S::store(bg + r0 + i, S::load(bg + r0 + i) + lds_load<S>(s_b + i));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -783,11 +852,16 @@ struct MatrixK
   {
     if (a.algorithm == MPCX_ALG_ROWBLOCK && a.plan.num_blocks > 0)
     {
-      const size_t lds = size_t(a.plan.max_nnz) * sizeof(typename S::T) + size_t(a.plan.max_rows + 1) * 4 + 512;
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(matrix_rowblock_scalar_kernel<Op, S>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-      hipLaunchKernelGGL((matrix_rowblock_scalar_kernel<Op, S>), dim3(8u * unsigned((a.plan.num_blocks + 7) / 8)),
-                         dim3(sc_rowblock_threads()), lds, st, a, flag);
+      const size_t lds = size_t(a.plan.max_nnz) * sizeof(typename S::LT) + size_t(a.plan.max_rows + 1) * 4 + 512;
+      auto go = [&](auto kern)
+      {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        hipLaunchKernelGGL(kern, dim3(8u * unsigned((a.plan.num_blocks + 7) / 8)), dim3(sc_rowblock_threads()), lds, st, a, flag);
+      };
+      if (a.coeffs)
+        go(matrix_rowblock_scalar_kernel<Op, S, true>);
+      else
+        go(matrix_rowblock_scalar_kernel<Op, S, false>);
       if (a.n_slave_entities > 0)
         hipLaunchKernelGGL((matrix_scalar_kernel<Op, S, 1>), dim3(grid_for(a.n_slave_entities, 64)), dim3(64), 0, st, a, flag);
     }
@@ -802,11 +876,16 @@ struct VectorK
   {
     if (a.algorithm == MPCX_ALG_ROWBLOCK && a.plan.num_blocks > 0)
     {
-      const size_t lds = size_t(a.plan.max_rows) * sizeof(typename S::T) + 512;
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vector_rowblock_scalar_kernel<Op, S>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-      hipLaunchKernelGGL((vector_rowblock_scalar_kernel<Op, S>), dim3(8u * unsigned((a.plan.num_blocks + 7) / 8)),
-                         dim3(sc_rowblock_threads()), lds, st, a, flag);
+      const size_t lds = size_t(a.plan.max_rows) * sizeof(typename S::LT) + 512;
+      auto go = [&](auto kern)
+      {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        hipLaunchKernelGGL(kern, dim3(8u * unsigned((a.plan.num_blocks + 7) / 8)), dim3(sc_rowblock_threads()), lds, st, a, flag);
+      };
+      if (a.coeffs)
+        go(vector_rowblock_scalar_kernel<Op, S, true>);
+      else
+        go(vector_rowblock_scalar_kernel<Op, S, false>);
       if (a.n_slave_entities > 0)
         hipLaunchKernelGGL((vector_scalar_kernel<Op, S, 1>), dim3(grid_for(a.n_slave_entities, 64)), dim3(64), 0, st, a, flag);
     }
