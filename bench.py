@@ -404,7 +404,8 @@ def measure_counters(argv_child):
     out = tempfile.mkdtemp(prefix="mpcx_pmc_", dir="/tmp")
     per = {}
     try:
-        for group in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_INSTS_LDS"]):
+        for group in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_INSTS_LDS"],
+                      ["GRBM_GUI_ACTIVE"]):
             tag = group[0]
             cmd = [exe, "--kernel-trace", "--pmc"] + group + ["-d", out, "-o", "p_" + tag, "--", sys.executable,
                                                               os.path.abspath(__file__)] + argv_child
@@ -430,6 +431,10 @@ def measure_counters(argv_child):
     for d in per.values():
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
             d["hbm_bytes"] = int((2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0)
+        if "GRBM_GUI_ACTIVE" in d and d.get("profiled_ms"):
+            # GRBM_GUI_ACTIVE counts the busy cycles of the 8 XCDs: the shader clock the kernel actually ran at (fp64-heavy
+            # kernels are power-limited to ~2.0 GHz on this part, memory-bound ones run at 2.2-2.3; the peak is 2.4)
+            d["clock_GHz"] = d["GRBM_GUI_ACTIVE"] / 8.0 / (d["profiled_ms"] * 1e-3) / 1e9
     return per, {"formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch",
                  "note": "2 x FETCH_SIZE is calibrated on 16 B/lane streaming reads; an upper bound for gather-heavy kernels"}
 
@@ -1028,7 +1033,7 @@ def main():
         j_info["solve_s"] = time.perf_counter() - t0s
         out["solve"] = {"rtol": 1e-8, "gamg_cg": mg_info, "jacobi_cg": j_info}
     if world == 1 and not args.no_traffic and not os.environ.get("MPCX_BENCH_NO_PMC"):
-        log("measuring HBM traffic / VALU instructions of every kernel of the step (rocprofv3 --pmc, three short child runs) ...")
+        log("measuring HBM traffic / VALU instructions of every kernel of the step (rocprofv3 --pmc, four short child runs) ...")
         child_args = ["--config", str(args.config), "--size", str(args.n), "--alg", args.alg, "--steps", "1", "--warmup", "0",
                       "--no-cpu-baseline", "--no-traffic", "--numbering", args.numbering] + (["--ufcx", args.ufcx] if args.ufcx else []) + ["--cell", args.cell] + (["--no-tile"] if args.no_tile else ["--tile"] + [str(v) for v in args.tile])
         per, info = measure_counters(child_args)
@@ -1047,6 +1052,10 @@ def main():
                     # 4 cycles per wave64 VALU instruction, 1024 SIMDs, 2.4 GHz (the judge's arithmetic)
                     ko["valu_issue_frac"] = d["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.4e9 * k["launch_ms"] * 1e-3)
                     ko["valu_instructions"] = d["SQ_INSTS_VALU"]
+                    if d.get("clock_GHz"):
+                        # the same at the clock the kernel ran at under the profiler (the 78.6 TF roof assumes 2.4 GHz)
+                        ko["clock_GHz"] = d["clock_GHz"]
+                        ko["valu_issue_frac_at_clock"] = ko["valu_issue_frac"] * 2.4 / d["clock_GHz"]
                 ko["frac_hbm_executed"] = d["hbm_bytes"] / (k["launch_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS
                 if k is dom:
                     R = out["roofline"]
@@ -1055,6 +1064,10 @@ def main():
                     R["traffic_is"] = "upper bound for gather-heavy kernels (see traffic_source)"
                     R["frac_hbm_executed"] = ko["frac_hbm_executed"]
                     R["valu_issue"] = ko.get("valu_issue_frac")
+                    if ko.get("clock_GHz"):
+                        R["clock_GHz"] = ko["clock_GHz"]
+                        R["valu_issue_at_clock"] = ko["valu_issue_frac_at_clock"]
+                        R["frac_fp64_at_clock"] = R["frac_fp64"] * 2.4 / ko["clock_GHz"] if R.get("frac_fp64") is not None else None
                     if R["valu_issue"] is not None:
                         # the binding resource by the counters: VALU issue slots against executed HBM bytes at the rate the
                         # box's own copy probe reaches

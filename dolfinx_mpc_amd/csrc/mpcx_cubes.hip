@@ -620,9 +620,20 @@ __global__ void __launch_bounds__(VCUBE_THREADS) vector_cube_kernel(mpcx_vector_
 // atomics: b receives every row once from its owner plus the halo sums through vector_spill_reduce_kernel, in a
 // fixed order -- the result is bitwise reproducible up to the order of the LDS adds inside a block.
 constexpr int VCUBE_OWN_THREADS = 256;
+constexpr int VCUBE_OWN_MAX_THREADS = 256; // launch bound of vector_cube_own_kernel (MPCX_VCUBE_THREADS, default 256)
+inline int vcube_own_threads()
+{
+  static const int n = []
+  {
+    const char* e = std::getenv("MPCX_VCUBE_THREADS");
+    const int v = e ? std::atoi(e) : VCUBE_OWN_THREADS;
+    return (v >= 64 && v <= VCUBE_OWN_MAX_THREADS && v % 64 == 0) ? v : VCUBE_OWN_THREADS;
+  }();
+  return n;
+}
 
 template <int FN>
-__global__ void __launch_bounds__(VCUBE_OWN_THREADS) vector_cube_own_kernel(mpcx_vector_args_t a)
+__global__ void __launch_bounds__(VCUBE_OWN_MAX_THREADS) vector_cube_own_kernel(mpcx_vector_args_t a)
 {
   using Op = ElementOp<3, 1, 1, 1, 1, MPCX_FORM_SOURCE, FN>;
   extern __shared__ __align__(16) unsigned char smem[];
@@ -2501,7 +2512,7 @@ int launch_vector_cubes(const mpcx_vector_args_t& a)
                                              int(lds)),
                          "hipFuncSetAttribute"))
         return rc;
-      hipLaunchKernelGGL(kernel, dim3(g), dim3(VCUBE_OWN_THREADS), lds, st, a);
+      hipLaunchKernelGGL(kernel, dim3(g), dim3(vcube_own_threads()), lds, st, a);
       return check(hipGetLastError(), "vector cluster owner kernel launch");
     };
     if (int rc = k.fn_id == 1 ? go(vector_cube_own_kernel<1>) : go(vector_cube_own_kernel<-1>))
