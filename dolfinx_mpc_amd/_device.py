@@ -157,7 +157,7 @@ def ufcx_compile(k, form: Form):
            0 if V1 is None else V1.element_ndofs, 0 if V1 is None else V1.dofmap.bs, nv, tr,
            tuple(os.environ.get(e) for e in _UFCX_COMPILE_ENV))
     if key not in _ufcx_handles:
-        d = _native.UfcxDescT(k.ufcx_source.encode(), k.ufcx_name.encode(), form.rank, V0.element_ndofs, V0.dofmap.bs,
+        d = _native.UfcxDescT(k.ufcx_source.encode(), k.ufcx_name.encode() if k.ufcx_name else None, form.rank, V0.element_ndofs, V0.dofmap.bs,
                               0 if V1 is None else V1.element_ndofs, 0 if V1 is None else V1.dofmap.bs, nv,
                               None if tr[0] is None else tr[0].encode(), None if tr[1] is None else tr[1].encode())
         L = _native.lib()
@@ -176,7 +176,7 @@ def resolve_builtin_twins(form: Form) -> None:
     if getattr(form, "_twins_resolved", False):
         return
     form._twins_resolved = True
-    import os
+    swapped = False
 
     from .fem import Form as _Form
     from .fem import Integral as _Integral
@@ -196,16 +196,22 @@ def resolve_builtin_twins(form: Form) -> None:
                           "the imported text runs", RuntimeWarning, stacklevel=3)
             ok = False
         if ok is None:
-            form._twins_resolved = False  # both kernels gave zero on the sample: undecided, looked at again on the next call
+            # both kernels gave zero on the sample (a constant that is still 0, ...): undecided.  Looked at again on the next
+            # calls, a bounded number of times -- every retry costs two sample assemblies
+            form._twin_retries = getattr(form, "_twin_retries", 0) + 1
+            if form._twin_retries < 4:
+                form._twins_resolved = False
             continue
         if ok:
             integ.kernel_imported = k
             integ.kernel = kb
+            swapped = True
         else:
             warnings.warn(f"dolfinx_mpc_amd: imported kernel '{k.ufcx_name}' does not agree with its stated built-in twin on the "
                           "sample entities; the imported text runs (the fast built-in kernels are not used)", RuntimeWarning, stacklevel=3)
             k.builtin = None
-    form._device.clear()  # argument blocks built for the text are stale
+    if swapped:
+        form._device.clear()  # argument blocks built for the text are stale
 
 
 def _twin_agrees(form, integ, kb, _Form, _Integral) -> bool:
@@ -268,6 +274,20 @@ def integral_device(form: Form, i: int):
             from .quadrature import lagrange_basis
 
             qphi = _to_dev(lagrange_basis(form.mesh.cell_name, 2, k.qpts).reshape(-1), dev)
+        # source forms with an integrand function that is affine in x (constant / linear) on affine simplices: the rule's
+        # moments against the barycentric coordinates (mpcx_kernel_t::vphi) -- the kernels then evaluate f at the vertices
+        # instead of walking the rule (the same sum up to rounding); MPCX_VERTEX_SOURCE=0 keeps the rule
+        vphi = None
+        if (k.form == 2 and integ.itype == "cell" and k.celltype in (1, 2) and k.degree in (1, 2) and k.coeff_degree == 0
+                and k.qwts.size > 0 and os.environ.get("MPCX_VERTEX_SOURCE", "1") != "0"):
+            from .fem import _FN_DEGREE
+            from .quadrature import lagrange_basis
+
+            if _FN_DEGREE.get(k.fn_id, 99) <= 1:
+                cell = form.mesh.cell_name
+                phi = lagrange_basis(cell, k.degree, k.qpts)  # (nq, nd)
+                lam = lagrange_basis(cell, 1, k.qpts)  # (nq, nv)
+                vphi = _to_dev(np.ascontiguousarray(np.einsum("q,qv,qi->vi", k.qwts.astype(np.float64), lam, phi)).reshape(-1), dev)
         # cell integral over cells 0..n-1 in order: the kernels skip the indirection (and nothing is uploaded)
         n = integ.entities.shape[0]
         ident = integ.itype == "cell" and n > 0 and int(integ.entities[0]) == 0 and int(integ.entities[-1]) == n - 1 and \
@@ -284,6 +304,7 @@ def integral_device(form: Form, i: int):
             "fqpts": _to_dev(k.fqpts.astype(np.float64).reshape(-1), dev),
             "fqwts": _to_dev(k.fqwts.astype(np.float64), dev),
             "qphi": qphi,
+            "vphi": vphi,
         }
         d["entities_ptr"] = None if ident else d["entities"].data_ptr()
         d["kernel"] = _native.KernelT(
@@ -291,7 +312,7 @@ def integral_device(form: Form, i: int):
             int(k.qwts.size), int(k.fqwts.size),
             d["qpts"].data_ptr(), d["qwts"].data_ptr(), d["fqpts"].data_ptr(), d["fqwts"].data_ptr(),
             ufcx_compile(k, form) if k.form == 100 else None, None if qphi is None else qphi.data_ptr(),
-            _native.scalar_id(getattr(form, "dtype", np.float64)),
+            _native.scalar_id(getattr(form, "dtype", np.float64)), None if vphi is None else vphi.data_ptr(),
         )
         kb = getattr(k, "builtin", None)
         d["kernel_builtin"] = None
@@ -300,7 +321,7 @@ def integral_device(form: Form, i: int):
             d["kernel_builtin"] = _native.KernelT(
                 kb.form, kb.celltype, kb.degree, kb.bs, kb.degree1 or kb.degree, kb.bs1 or kb.bs, kb.fn_id, kb.coeff_degree,
                 int(kb.qwts.size), 0, d["qpts_b"].data_ptr(), d["qwts_b"].data_ptr(), d["fqpts"].data_ptr(), d["fqwts"].data_ptr(),
-                None, None, 0)
+                None, None, 0, None)
         form._device[key] = d
     d = form._device[key]
     if integ.coefficient is not None:

@@ -35,6 +35,7 @@ class KernelT(C.Structure):
         ("ufcx", C.c_void_p),
         ("qphi", C.c_void_p),
         ("scalar_type", C.c_int32),
+        ("vphi", C.c_void_p),
     ]
 
 
@@ -152,6 +153,7 @@ class MatrixArgs(C.Structure):
         ("val_map_wide", C.c_int32),
         ("out_map", C.c_void_p),
         ("out_delta", C.c_void_p),
+        ("lds_floor", C.c_int32),
         ("stream", C.c_void_p),
     ]
 
@@ -192,6 +194,7 @@ class VectorArgs(C.Structure):
         ("cube_cells", C.c_void_p),
         ("cell_info0", C.c_void_p),
         ("row_map", C.c_void_p),
+        ("lds_floor", C.c_int32),
         ("stream", C.c_void_p),
     ]
 
@@ -332,6 +335,7 @@ EXPORTS = [
     "mpcx_mpc_plan_device",
     "mpcx_compress_offsets",
     "mpcx_ufcx_compile",
+    "mpcx_ufcx_resolve",
     "mpcx_ufcx_code_size",
     "mpcx_ufcx_code",
     "mpcx_ufcx_free",
@@ -568,6 +572,8 @@ def lib() -> C.CDLL:
     L.mpcx_mpc_plan_device.argtypes = [i64, vp, i32, vp, vp, vp, i32, i32, vp, i32, i32, vp, vp, C.POINTER(MpcT),
                                        C.POINTER(MpcT), vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
     L.mpcx_mpc_plan_device.restype = C.c_int
+    L.mpcx_ufcx_resolve.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32]
+    L.mpcx_ufcx_resolve.restype = C.c_int
     L.mpcx_ufcx_compile.argtypes = [C.POINTER(UfcxDescT)]
     L.mpcx_ufcx_compile.restype = vp
     L.mpcx_ufcx_code_size.argtypes = [vp]
@@ -657,6 +663,11 @@ def start_preload():
     LOCAL_RANK (the launcher's convention: one rank per GPU), else the current one; MPCX_PRELOAD=0 switches it off"""
     global _preload_thread
     if _preload_thread is not None or os.environ.get("MPCX_PRELOAD", "1") == "0" or not os.path.exists(_LIB_PATH):
+        return
+    multi = any(int(os.environ.get(v, "1") or 1) > 1 for v in ("WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "SLURM_NTASKS"))
+    if multi and "LOCAL_RANK" not in os.environ:
+        # a launcher that does not say which GPU is this rank's (mpirun / srun use other variables): every rank would create a
+        # context and load code objects on device 0 -- the loads then happen at the first call, on the device the caller selected
         return
     try:
         import torch

@@ -871,12 +871,29 @@ def _leftover_form(form: Form, i: int, left: np.ndarray) -> Form:
     """integral i restricted to the cells outside any cluster (per-cell kernels)"""
     from .fem import Integral
 
-    def build():
-        integ = form.integrals[i]
-        return Form(form.function_spaces, [Integral("cell", np.ascontiguousarray(left, dtype=np.int32), integ.kernel,
-                                                    None, integ.constant)])
+    integ = form.integrals[i]
+    cells = np.ascontiguousarray(left, dtype=np.int32)
 
-    return D.cached(form._device, "leftover", (left,), i, build)
+    def build():
+        # the coefficient travels with the cells (an imported kernel dereferences w[] for every leftover cell as well;
+        # the built-in cluster kernels exclude forms with coefficients): Functions are packed per call for the new
+        # entity list like for any integral (cpp/assemble_matrix.cpp:583-589)
+        co = integ.coefficient
+        return Form(form.function_spaces, [Integral("cell", cells, integ.kernel, None if isinstance(co, np.ndarray) else co,
+                                                    integ.constant)])
+
+    fl = D.cached(form._device, "leftover", (left,), i, build)
+    if isinstance(integ.coefficient, np.ndarray):
+        # a caller-packed array [n_entities][cstride]: the rows of the leftover cells, taken on every call (the caller may
+        # have rewritten the array in place)
+        ents = np.asarray(integ.entities).reshape(integ.num_entities, -1)[:, 0]
+        if ents.size == cells.size or np.array_equal(ents[cells], cells):
+            rows = cells
+        else:
+            order = np.argsort(ents, kind="stable")
+            rows = order[np.searchsorted(ents[order], cells)]
+        fl.integrals[0].coefficient = np.ascontiguousarray(integ.coefficient[rows])  # (compared / uploaded by _device)
+    return fl
 
 
 def _mpc_plan(A: MPCMatrix, form: Form, i: int, mpc0, mpc1, bc0_h, bc1_h, slave_ents_h):
@@ -1103,7 +1120,8 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
                            has_coefficient=integ.coefficient is not None, coeff_degree=kf.coeff_degree,
                            all_cells=idv["entities_ptr"] is None and integ.estride == 1,
                            p1_geometry=s0["dofmap"] is md["x_dofmap"], same=same, tiled=V0.dof_tile_offsets is not None,
-                           builtin_form=(kf.builtin.form if getattr(kf, "builtin", None) is not None else -1))
+                           builtin_form=(kf.builtin.form if getattr(kf, "builtin", None) is not None else -1),
+                           has_transforms=getattr(kf, "ufcx_transforms", None) is not None)
         a.kernel_name = None  # (python attribute) the table entry that was taken
         names = dispatch.candidates(dispatch.MATRIX, ctx, "matrix")
         if _native.scalar_id(getattr(form, "dtype", np.float64)) != 0:
@@ -1381,6 +1399,12 @@ def _assemble_matrix_on_stream(form: Form, mpc0, mpc1, bcs, diagval, A: MPCMatri
         alg = 1
         calls, zeroed = prepare(alg)
     block_scalar = len(calls) == 1 and calls[0][1].block_scalar
+    from . import corun
+
+    if corun.note_matrix_call(A) and alg == 2:
+        # a vector assembly runs beside this call (time loop, benchmark step): the first part of every row-block launch is
+        # capped so that the vector kernel is co-resident on every CU, the rest runs uncapped (dolfinx_mpc_amd/corun.py)
+        calls = corun.split_calls(calls, corun.params())
     for memset, a, _keep in calls:
         if memset:
             target.zeroEntries()

@@ -310,7 +310,8 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
                        nd0=V.element_ndofs, nd1=V.element_ndofs, nq=nq, cell_integral=integ.itype == "cell",
                        has_coefficient=integ.coefficient is not None, coeff_degree=k.coeff_degree,
                        all_cells=idv["entities_ptr"] is None, p1_geometry=sd["dofmap"] is md["x_dofmap"], same=True, tiled=tiled,
-                       builtin_form=(k.builtin.form if getattr(k, "builtin", None) is not None else -1))
+                       builtin_form=(k.builtin.form if getattr(k, "builtin", None) is not None else -1),
+                           has_transforms=getattr(k, "ufcx_transforms", None) is not None)
     # row-block shapes (rows of b one workgroup holds): blocked spaces get the same number of NODES per block (vector P1,
     # contact benchmark: 0.43 -> 0.29 ms); scalar P2 sources with the basis table on a tiled numbering and many-point
     # rules take large blocks (the halo is paid in arithmetic)
@@ -475,6 +476,9 @@ def _assemble_vector_on_stream(form: Form, constraint: MultiPointConstraint, b: 
     L = _native.lib()
     wt = getattr(b, "_write_through", None)
     (b if wt is None else wt[0]).set(0.0)
+    from . import corun
+
+    vfloor = corun.params()["vector_floor"] if corun.note_vector_call(b.device) else 0
     for i, integ in enumerate(form.integrals):
         try:
             a, keep = vector_args(form, i, b, constraint, alg)
@@ -482,6 +486,7 @@ def _assemble_vector_on_stream(form: Form, constraint: MultiPointConstraint, b: 
             if alg != 0:
                 raise
             a, keep = vector_args(form, i, b, constraint, 1)  # 'auto': no plan fits (e.g. 64 nodes per cell) -> per-entity kernel
+        a.lds_floor = vfloor  # (a matrix assembly is in flight on the other stream: dolfinx_mpc_amd/corun.py)
         _native.check(L.mpcx_assemble_vector(C.byref(a)), "mpcx_assemble_vector")
         if a.second is not None:
             _native.check(L.mpcx_assemble_vector(C.byref(a.second)), "mpcx_assemble_vector")

@@ -2391,6 +2391,8 @@ int launch_matrix_cubes(const mpcx_matrix_args_t& a)
   }();
   if (lds_floor > lds && lds_floor <= 160 * 1024)
     lds = lds_floor;
+  if (a.lds_floor > 0 && size_t(a.lds_floor) > lds && a.lds_floor <= 160 * 1024) // per-launch cap (include/mpcx.h)
+    lds = size_t(a.lds_floor);
   const bool narrow = a.cube_rec_bytes == 64;
   if (a.cube_rec_bytes != 0 && a.cube_rec_bytes != 64 && a.cube_rec_bytes != 96)
   {
@@ -2505,6 +2507,8 @@ int launch_vector_cubes(const mpcx_vector_args_t& a)
     }();
     if (lds_floor > lds && lds_floor <= 160 * 1024)
       lds = lds_floor;
+    if (a.lds_floor > 0 && size_t(a.lds_floor) > lds && a.lds_floor <= 160 * 1024)
+      lds = size_t(a.lds_floor);
     const unsigned g = 8u * unsigned((a.plan.num_blocks + 7) / 8);
     auto go = [&](auto kernel) -> int
     {

@@ -712,6 +712,35 @@ struct ElementOp
           for (int d = 0; d < TDIM; ++d)
             J[r][d] = cd[3 * (d + 1) + r] - cd[r];
         const double sd = c0 * adet;
+        if constexpr (FN_ != 1)
+        {
+          if (k.vphi != nullptr)
+          {
+            // f affine in x (include/mpcx.h mpcx_kernel_t::vphi): f at the vertices, then the rule's vertex moments --
+            // the same sum as the loop below up to rounding, NV * ND0 fma per component instead of nq * (ND0 + ~20)
+            double F[BS0][NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+            {
+              const double xv[3] = {cd[3 * v], cd[3 * v + 1], cd[3 * v + 2]};
+#pragma unroll
+              for (int b = 0; b < BS0; ++b)
+                F[b][v] = sd * eval_fn(FN_ >= 0 ? FN_ : k.fn_id, xv, b + comp0, c);
+            }
+#pragma unroll
+            for (int i = 0; i < ND0; ++i)
+#pragma unroll
+              for (int b = 0; b < BS0; ++b)
+              {
+                double s = A[i * BS0 + b];
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+                  s = fma(k.vphi[v * ND0 + i], F[b][v], s);
+                A[i * BS0 + b] = s;
+              }
+            return;
+          }
+        }
         // origin of the affine map (shifted to the Gaussian's centre for the benchmark function, see below)
         double org[3] = {cd[0], cd[1], cd[2]};
         if constexpr (FN_ == 1 && TDIM == 3)

@@ -708,7 +708,7 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
 // masked entries are produced when the block is written out: slot_mask[slot] bit k = "entry (k, k) of this
 // block is zero" (mpcx_diag_slot_mask).  The masked dofmaps are read for their dof ids only.
 template <class Op, bool USE_LAZY>
-__global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_nodeblock_kernel(mpcx_matrix_args_t a)
+__device__ __forceinline__ void nodeblock_body(const mpcx_matrix_args_t& a)
 {
   constexpr int ND0 = Op::ND0, ND1 = Op::ND1, BS = Op::BS0, NV = Op::NV;
   constexpr int NOFF = ND0 * ND1;
@@ -818,24 +818,88 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_nodeblock_kernel(
   // expand: a wave takes whole scalar rows (node nl, component k); row k of a node starts k * L * BS entries after
   // row 0 (L = column blocks of the node's rows).  (A wave per node -- BS * BS * L contiguous entries, 98 % of the
   // lanes busy instead of 66 % -- measured slower: 12.6 against 10.9 ms on the Taylor-Hood velocity block.)
+  // Round 6: RB rows per wave and trip, their LDS reads (row bounds, then values) issued together and waited for once:
+  // with the row-at-a-time loop every row paid three dependent LDS round trips behind the scatter-adds of the CU's other
+  // workgroup, and the write-out ran at half the rate the HBM takes (Taylor-Hood a00, 35.7 GB of values: 13-15 ms).
   const int wave = tid >> 6, lane = tid & 63, nwaves = NT >> 6;
-  for (int rl = wave; rl < nn * BS; rl += nwaves)
+  constexpr int RB = 4;
+  const int nrows = nn * BS;
+  const bool mapped = a.val_map != nullptr;
+  for (int rb = wave * RB; rb < nrows; rb += nwaves * RB)
   {
-    const int nl = rl / BS, k = rl - nl * BS;
-    const int lo = s_rowlo[nl];
-    const int len = (s_rowlo[nl + 1] - lo) * BS;
-    const int64_t p0 = nnz0 + int64_t(lo) * (BS * BS) + int64_t(k) * len;
-    for (int e = lane; e < len; e += 64)
+    int lo[RB], len[RB], kk[RB];
+#pragma unroll
+    for (int u = 0; u < RB; ++u)
     {
-      const int sl = e / BS, q = e - sl * BS;
-      const bool keep = q == k && !(masked_block && ((a.slot_mask[gslot0 + lo + sl] >> k) & 1));
-      const double v = keep ? s_vals[lo + sl] : 0.0;
-      if (a.store_mode)
-        a.vals[MPCX_VAL_POS(a, p0 + e)] = v;
-      else if (keep)
-        a.vals[MPCX_VAL_POS(a, p0 + e)] += v;
+      const int rl = rb + u < nrows ? rb + u : nrows - 1;
+      const int nl = rl / BS;
+      kk[u] = rl - nl * BS;
+      lo[u] = s_rowlo[nl];
+      len[u] = rb + u < nrows ? (s_rowlo[nl + 1] - lo[u]) * BS : 0;
+    }
+    // the first two 64-entry trips of every row in one go (interior P2 rows of a Kuhn mesh: 87 entries)
+    double v[RB][2];
+    bool keep[RB][2];
+#pragma unroll
+    for (int u = 0; u < RB; ++u)
+#pragma unroll
+      for (int it = 0; it < 2; ++it)
+      {
+        const int e = lane + 64 * it;
+        const int sl = e / BS, q = e - sl * BS;
+        keep[u][it] = e < len[u] && q == kk[u];
+        if (keep[u][it] && masked_block)
+          keep[u][it] = !((a.slot_mask[gslot0 + lo[u] + sl] >> kk[u]) & 1);
+        v[u][it] = keep[u][it] ? s_vals[lo[u] + sl] : 0.0;
+      }
+#pragma unroll
+    for (int u = 0; u < RB; ++u)
+    {
+      const int64_t p0 = nnz0 + int64_t(lo[u]) * (BS * BS) + int64_t(kk[u]) * len[u];
+#pragma unroll
+      for (int it = 0; it < 2; ++it)
+      {
+        const int e = lane + 64 * it;
+        if (e >= len[u])
+          continue;
+        const int64_t pos = mapped ? MPCX_VAL_POS(a, p0 + e) : p0 + e;
+        if (a.store_mode)
+          a.vals[pos] = v[u][it];
+        else if (keep[u][it])
+          a.vals[pos] += v[u][it];
+      }
+      for (int e = lane + 128; e < len[u]; e += 64) // long rows (master rows, vertices of high valence)
+      {
+        const int sl = e / BS, q = e - sl * BS;
+        const bool kp = q == kk[u] && !(masked_block && ((a.slot_mask[gslot0 + lo[u] + sl] >> kk[u]) & 1));
+        const double w = kp ? s_vals[lo[u] + sl] : 0.0;
+        const int64_t pos = mapped ? MPCX_VAL_POS(a, p0 + e) : p0 + e;
+        if (a.store_mode)
+          a.vals[pos] = w;
+        else if (kp)
+          a.vals[pos] += w;
+      }
     }
   }
+}
+
+template <class Op, bool USE_LAZY>
+__global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_nodeblock_kernel(mpcx_matrix_args_t a)
+{
+  nodeblock_body<Op, USE_LAZY>(a);
+}
+// Occupancy variants for the CSR-valued write-out (no block_vals): compute and write-out phases of a block are both bound
+// by the latency of a wave's own chain, so the rate follows the number of resident waves, and that is set by the registers
+// (84 for the Taylor-Hood velocity block: 5 waves per SIMD).  WPE waves per SIMD = 2 workgroups of WPE * 128 threads per CU.
+template <class Op, bool USE_LAZY>
+__global__ void __launch_bounds__(768, 6) matrix_nodeblock_w6_kernel(mpcx_matrix_args_t a)
+{
+  nodeblock_body<Op, USE_LAZY>(a);
+}
+template <class Op, bool USE_LAZY>
+__global__ void __launch_bounds__(1024, 8) matrix_nodeblock_w8_kernel(mpcx_matrix_args_t a)
+{
+  nodeblock_body<Op, USE_LAZY>(a);
 }
 
 // set-up for the node-block kernel: one thread per node row
@@ -1771,13 +1835,15 @@ int launch_matrix(const mpcx_matrix_args_t& a)
         return -5;
       }
       // component-diagonal forms keep one value per column block (see the kernel): BS1 times less LDS per row
-      const size_t lds = a.slot_mask ? size_t(a.plan.max_nnz / (Op::BS0 * Op::BS1)) * 8 + size_t(a.plan.max_rows / Op::BS0 + 1) * 4
-                                     : size_t(a.plan.max_nnz / (Op::DIAG ? Op::BS1 : 1)) * 8 + size_t(a.plan.max_rows + 1) * 4;
+      size_t lds = a.slot_mask ? size_t(a.plan.max_nnz / (Op::BS0 * Op::BS1)) * 8 + size_t(a.plan.max_rows / Op::BS0 + 1) * 4
+                               : size_t(a.plan.max_nnz / (Op::DIAG ? Op::BS1 : 1)) * 8 + size_t(a.plan.max_rows + 1) * 4;
       if (lds > 160 * 1024)
       {
         mpcx_set_error("mpcx_assemble_matrix: row-block plan exceeds 160 KiB of LDS");
         return -4;
       }
+      if (a.lds_floor > 0 && size_t(a.lds_floor) > lds && a.lds_floor <= 160 * 1024) // per-launch occupancy cap (include/mpcx.h)
+        lds = size_t(a.lds_floor);
       const unsigned grid = 8u * unsigned((a.plan.num_blocks + 7) / 8);
       // threads per workgroup (two workgroups per CU by the LDS budget of the plan): chosen per kernel
       // below, MPCX_ROWBLOCK_THREADS overrides
@@ -1787,13 +1853,13 @@ int launch_matrix(const mpcx_matrix_args_t& a)
         const int t = e ? std::atoi(e) : 0;
         return (t >= 64 && t <= 1024 && t % 64 == 0) ? t : 0;
       }();
-      auto launch = [&](auto kernel) -> int
+      auto launch = [&](auto kernel, int forced_threads = 0) -> int
       {
         if (int rc = check(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)),
                            "hipFuncSetAttribute"))
           return rc;
-        int threads = env_threads;
+        int threads = forced_threads ? forced_threads : env_threads;
         if (threads == 0)
         {
           hipFuncAttributes attr;
@@ -1808,6 +1874,16 @@ int launch_matrix(const mpcx_matrix_args_t& a)
           // computes while a block is written out (Taylor-Hood a00, 84 registers: 1024 threads 2.98 ms, 512 2.16 ms)
           if ((a.plan.row_pairs || a.slot_mask) && attr.numRegs <= 64)
             threads = 1024;
+          // node blocks expanded to scalar CSR values (no block_vals): the write-out of 9 x the LDS block is the longer
+          // phase and its rate follows the number of waves that issue stores: MPCX_NODEBLOCK_CSR_THREADS (default below)
+          if (a.slot_mask && !a.block_vals)
+          {
+            // (Taylor-Hood a00 at 128^3, 35.7 GB of values: 512 threads 13.2 ms, 768 13.9, 1024 11.4 -- round 3's 10.97 ms was
+            // taken with 1024 before the node-block default became 512 for the block-scalar storage)
+            const char* e = std::getenv("MPCX_NODEBLOCK_CSR_THREADS");
+            const int t = e ? std::atoi(e) : 1024;
+            threads = (t >= 64 && t <= 1024 && t % 64 == 0) ? t : 1024;
+          }
         }
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, stream, a);
         return 0;
@@ -1828,8 +1904,21 @@ int launch_matrix(const mpcx_matrix_args_t& a)
           if constexpr (Op::LAZY)
             lazy = Op::lazy_applies(a.kernel);
           int rc = 0;
+          int variant = 0; // CSR-valued write-out: occupancy variant (MPCX_NODEBLOCK_CSR_VARIANT = 0 | 6 | 8)
+          if (!a.block_vals)
+          {
+            const char* e = std::getenv("MPCX_NODEBLOCK_CSR_VARIANT");
+            variant = e ? std::atoi(e) : 0;
+          }
           if constexpr (Op::LAZY)
-            rc = lazy ? launch(matrix_nodeblock_kernel<Op, true>) : launch(matrix_nodeblock_kernel<Op, false>);
+          {
+            if (lazy && variant == 6)
+              rc = launch(matrix_nodeblock_w6_kernel<Op, true>, 768);
+            else if (lazy && variant == 8)
+              rc = launch(matrix_nodeblock_w8_kernel<Op, true>, 1024);
+            else
+              rc = lazy ? launch(matrix_nodeblock_kernel<Op, true>) : launch(matrix_nodeblock_kernel<Op, false>);
+          }
           else
             rc = launch(matrix_nodeblock_kernel<Op, false>);
           if (rc)
@@ -1974,12 +2063,14 @@ int launch_vector(const mpcx_vector_args_t& a)
       mpcx_set_error("mpcx_assemble_vector: row-block algorithm needs a plan and the slave-masked dofmap");
       return -3;
     }
-    const size_t lds = size_t(a.plan.max_rows) * 8;
+    size_t lds = size_t(a.plan.max_rows) * 8;
     if (lds > 96 * 1024)
     {
       mpcx_set_error("mpcx_assemble_vector: row-block plan exceeds the LDS budget");
       return -4;
     }
+    if (a.lds_floor > 0 && size_t(a.lds_floor) > lds && a.lds_floor <= 160 * 1024)
+      lds = size_t(a.lds_floor);
     const unsigned grid = 8u * unsigned((a.plan.num_blocks + 7) / 8);
     constexpr bool BY_COMPONENT = Op::BS0 > 1 && Op::ND0 >= 6 && Op::FORM == MPCX_FORM_SOURCE;
     bool split = false;
@@ -1993,7 +2084,7 @@ int launch_vector(const mpcx_vector_args_t& a)
         return rc;
       // 512 threads (measured: 1024 threads for the large owner-computes blocks, one workgroup per CU by LDS, lose --
       // P2 source 246^3 5.70 -> 6.26 ms, Stokes b0 1.47 -> 1.60 ms)
-      static const int env_threads = []
+      const int env_threads = []
       {
         const char* e = std::getenv("MPCX_VECTOR_THREADS");
         const int t = e ? std::atoi(e) : 0;

@@ -652,12 +652,15 @@ int launch_pairs(const mpcx_matrix_args_t& a)
     mpcx_set_error("mpcx_assemble_matrix: elasticity needs the constants (mu, lambda)");
     return -8;
   }
-  const size_t lds = size_t(a.plan.max_nnz) * 8 + (Op::BS0 > 1 ? size_t(a.plan.max_rows + 1) * 4 : 0);
+  size_t lds = size_t(a.plan.max_nnz) * 8 + (Op::BS0 > 1 ? size_t(a.plan.max_rows + 1) * 4 : 0);
   if (lds > 160 * 1024)
   {
     mpcx_set_error("mpcx_assemble_matrix: row-block plan exceeds 160 KiB of LDS");
     return -4;
   }
+  const size_t lds_plan = lds; // (the thread count below follows the plan, not a per-launch occupancy cap)
+  if (a.lds_floor > 0 && size_t(a.lds_floor) > lds && a.lds_floor <= 160 * 1024)
+    lds = size_t(a.lds_floor);
   const bool cached = a.pair_ctx != nullptr;
   const bool dictm = a.pair_dict != nullptr;
   auto pick = [&](auto dict_t) -> const void*
@@ -672,7 +675,7 @@ int launch_pairs(const mpcx_matrix_args_t& a)
   // Threads per workgroup: the CU should hold as many waves as the registers allow (8 per SIMD up to 64 VGPRs), spread
   // over the workgroups the LDS of the plan admits -- P2 Poisson 246^3, 37 KB blocks (four per CU): 128 threads 14.0 ms,
   // 256 11.2, 512 9.5; 74 KB blocks: 512 11.2, 1024 10.2; 18 KB blocks with 256 threads 10.0.  MPCX_PAIRS_THREADS overrides.
-  static const int env_threads = []
+  const int env_threads = []
   {
     const char* e = std::getenv("MPCX_PAIRS_THREADS");
     const int t = e ? std::atoi(e) : 0;
@@ -685,7 +688,7 @@ int launch_pairs(const mpcx_matrix_args_t& a)
     if (int rc = check(hipFuncGetAttributes(&attr, kern), "hipFuncGetAttributes"))
       return rc;
     const int per_simd = attr.numRegs <= 64 ? 8 : (attr.numRegs <= 72 ? 7 : (attr.numRegs <= 80 ? 6 : (attr.numRegs <= 96 ? 5 : 4)));
-    const int wgs = int((160 * 1024) / (lds + 1024)) < 1 ? 1 : int((160 * 1024) / (lds + 1024));
+    const int wgs = int((160 * 1024) / (lds_plan + 1024)) < 1 ? 1 : int((160 * 1024) / (lds_plan + 1024));
     threads = 64 * ((4 * per_simd) / (wgs > 16 ? 16 : wgs));
     threads = threads < 128 ? 128 : (threads > PAIRS_MAX_THREADS ? PAIRS_MAX_THREADS : threads);
   }

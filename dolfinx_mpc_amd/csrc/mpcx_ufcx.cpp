@@ -1142,6 +1142,302 @@ int ensure_loaded(UfcxKernel* k)
   return get(&k->vector, "ufcx_vector_kernel");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// FFCx file layout.  What FFCx writes to disk is more than the tabulate_tensor function: after the functions come the
+// descriptor objects DOLFINx reads -- `ufcx_integral integral_<hash> = { ..., .tabulate_tensor_float64 = <function>, ... };`
+// (with `#ifndef __STDC_NO_COMPLEX__` members inside the initialiser), the arrays a form object points to
+// (`finite_element_hashes_form_<hash>`, `form_integral_offsets_...`, `static ufcx_integral* form_integrals_...[] = {&integral_...}`),
+// `ufcx_form form_<hash> = { ..., .form_integrals = form_integrals_form_<hash>, ... };` and an alias
+// `ufcx_form* form_<file>_<name> = &form_<hash>;`.  The reference reaches a kernel only through these objects
+// (cpp/assemble_matrix.cpp:438-439: `a.kernel(IntegralType::cell, i, 0)`, filled by DOLFINx from
+// `form->form_integrals[k]->tabulate_tensor_float64`).  A device compiler has no use for host descriptor objects (C
+// designated initialisers in any order are not C++), so the importer
+//   1. walks the top-level items of the text, records what the objects say (integral -> function, list -> integrals,
+//      form -> list, alias -> form) and the functions the text defines,
+//   2. blanks the descriptor items out (line numbers of the compiler log stay those of the file),
+//   3. resolves the name it was given: a function of the text; else a ufcx_integral object; else a ufcx_form object or
+//      an alias of one (its first integral with a float64 kernel); no name: the file's only ufcx_integral.
+// ---------------------------------------------------------------------------------------------------------------
+struct FfcxObjects
+{
+  std::vector<std::string> functions;                              // functions the text defines
+  std::vector<std::pair<std::string, std::string>> integrals;      // (object, tabulate_tensor_float64 or "")
+  std::vector<std::pair<std::string, std::vector<std::string>>> lists; // (array, the integral objects it points to)
+  std::vector<std::pair<std::string, std::string>> forms;          // (object, .form_integrals array)
+  std::vector<std::pair<std::string, std::string>> aliases;        // (pointer, the form object it points to)
+};
+
+inline bool ident_char(char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9') || c == '_'; }
+
+// identifiers of a piece of text, comments and string literals skipped
+std::vector<std::string> identifiers(const std::string& t)
+{
+  std::vector<std::string> out;
+  for (size_t i = 0; i < t.size();)
+  {
+    if (t.compare(i, 2, "//") == 0)
+    {
+      while (i < t.size() && t[i] != '\n')
+        ++i;
+    }
+    else if (t.compare(i, 2, "/*") == 0)
+    {
+      const size_t e = t.find("*/", i + 2);
+      i = e == std::string::npos ? t.size() : e + 2;
+    }
+    else if (t[i] == '"')
+    {
+      for (++i; i < t.size() && t[i] != '"'; ++i)
+        if (t[i] == '\\')
+          ++i;
+      ++i;
+    }
+    else if (ident_char(t[i]) && !(t[i] >= '0' && t[i] <= '9'))
+    {
+      size_t j = i;
+      while (j < t.size() && ident_char(t[j]))
+        ++j;
+      out.push_back(t.substr(i, j - i));
+      i = j;
+    }
+    else
+      ++i;
+  }
+  return out;
+}
+
+// value of designated member `.member = <identifier>` inside an initialiser ("" if absent or not an identifier: NULL, 0)
+std::string member_value(const std::string& t, const std::string& member)
+{
+  const std::string key = "." + member;
+  for (size_t p = 0; (p = t.find(key, p)) != std::string::npos; p += key.size())
+  {
+    size_t q = p + key.size();
+    if (q < t.size() && ident_char(t[q]))
+      continue; // a longer member name
+    while (q < t.size() && (t[q] == ' ' || t[q] == '\t' || t[q] == '\n'))
+      ++q;
+    if (q >= t.size() || t[q] != '=')
+      continue;
+    ++q;
+    while (q < t.size() && (t[q] == ' ' || t[q] == '\t' || t[q] == '\n' || t[q] == '&'))
+      ++q;
+    size_t e = q;
+    while (e < t.size() && ident_char(t[e]))
+      ++e;
+    const std::string v = t.substr(q, e - q);
+    return (v == "NULL" || v == "0" || v == "nullptr") ? std::string() : v;
+  }
+  return std::string();
+}
+
+void ffcx_scan(std::string& user, FfcxObjects& o)
+{
+  static const char* const prefixes[] = {"finite_element_hashes_", "form_integral_offsets_", "form_integral_ids_", "form_integrals_",
+                                         "original_coefficient_position", "coefficient_names_", "constant_names_", "constant_ranks_",
+                                         "constant_shapes_", "function_spaces_", "enabled_coefficients_"};
+  const size_t n = user.size();
+  size_t i = 0;
+  while (i < n)
+  {
+    // skip white space and comments between items
+    if (user[i] == ' ' || user[i] == '\t' || user[i] == '\n' || user[i] == '\r')
+    {
+      ++i;
+      continue;
+    }
+    if (user.compare(i, 2, "//") == 0)
+    {
+      while (i < n && user[i] != '\n')
+        ++i;
+      continue;
+    }
+    if (user.compare(i, 2, "/*") == 0)
+    {
+      const size_t e = user.find("*/", i + 2);
+      i = e == std::string::npos ? n : e + 2;
+      continue;
+    }
+    if (user[i] == '#') // a preprocessor line between items (continuation lines included): kept
+    {
+      while (i < n && user[i] != '\n')
+      {
+        if (user[i] == '\\' && i + 1 < n && user[i + 1] == '\n')
+          ++i;
+        ++i;
+      }
+      continue;
+    }
+    // one item: up to the ';' at depth 0, or the '}' that closes a function body
+    const size_t start = i;
+    int depth = 0;
+    bool function = false, body = false;
+    size_t first_paren = std::string::npos;
+    char last = 0; // last significant character outside braces
+    for (; i < n; ++i)
+    {
+      const char c = user[i];
+      if (user.compare(i, 2, "//") == 0)
+      {
+        while (i < n && user[i] != '\n')
+          ++i;
+        continue;
+      }
+      if (user.compare(i, 2, "/*") == 0)
+      {
+        const size_t e = user.find("*/", i + 2);
+        i = e == std::string::npos ? n : e + 1;
+        continue;
+      }
+      if (c == '"' || c == '\'')
+      {
+        for (++i; i < n && user[i] != c; ++i)
+          if (user[i] == '\\')
+            ++i;
+        continue;
+      }
+      if (c == '{')
+      {
+        if (depth == 0 && last == ')')
+          function = body = true;
+        ++depth;
+      }
+      else if (c == '}')
+      {
+        --depth;
+        if (depth == 0 && body)
+        {
+          ++i;
+          break;
+        }
+      }
+      else if (c == ';' && depth == 0)
+      {
+        ++i;
+        break;
+      }
+      if (depth == 0 && c == '(' && first_paren == std::string::npos)
+        first_paren = i;
+      if (depth == 0 && c != ' ' && c != '\t' && c != '\n' && c != '\r')
+        last = c;
+    }
+    const std::string item = user.substr(start, i - start);
+    if (function)
+    {
+      if (first_paren != std::string::npos)
+      {
+        size_t e = first_paren;
+        while (e > start && (user[e - 1] == ' ' || user[e - 1] == '\t' || user[e - 1] == '\n'))
+          --e;
+        size_t b = e;
+        while (b > start && ident_char(user[b - 1]))
+          --b;
+        if (e > b)
+          o.functions.push_back(user.substr(b, e - b));
+      }
+      continue;
+    }
+    // a declaration: its declared name = the identifier before '=' (or before ';'), array brackets skipped
+    const size_t eq = item.find('=');
+    std::string decl = item.substr(0, eq == std::string::npos ? item.size() : eq);
+    if (const size_t br = decl.find('['); br != std::string::npos)
+      decl = decl.substr(0, br);
+    const std::vector<std::string> ids = identifiers(decl);
+    const std::string name = ids.empty() ? std::string() : ids.back();
+    const bool pointer = decl.find('*') != std::string::npos;
+    bool mentions_integral = false, mentions_form = false, mentions_ufcx = false;
+    for (const std::string& id : ids)
+    {
+      mentions_integral = mentions_integral || id == "ufcx_integral";
+      mentions_form = mentions_form || id == "ufcx_form";
+      mentions_ufcx = mentions_ufcx || id.compare(0, 5, "ufcx_") == 0;
+    }
+    bool drop = mentions_ufcx;
+    for (const char* pre : prefixes)
+      drop = drop || name.compare(0, std::strlen(pre), pre) == 0;
+    if (!drop || ids.empty() || ids.front() == "typedef")
+      continue;
+    const std::string init = eq == std::string::npos ? std::string() : item.substr(eq + 1);
+    if (mentions_integral && !pointer)
+      o.integrals.emplace_back(name, member_value(init, "tabulate_tensor_float64"));
+    else if (mentions_integral && pointer)
+    {
+      std::vector<std::string> members;
+      for (const std::string& id : identifiers(init))
+        if (id != "NULL")
+          members.push_back(id);
+      o.lists.emplace_back(name, members);
+    }
+    else if (mentions_form && !pointer)
+      o.forms.emplace_back(name, member_value(init, "form_integrals"));
+    else if (mentions_form && pointer)
+    {
+      const std::vector<std::string> t = identifiers(init);
+      o.aliases.emplace_back(name, t.empty() ? std::string() : t.front());
+    }
+    for (size_t q = start; q < i; ++q) // blanked, line structure kept
+      if (user[q] != '\n')
+        user[q] = ' ';
+  }
+}
+
+// the tabulate_tensor function `name` stands for ("" + *err on failure)
+std::string ffcx_resolve(const FfcxObjects& o, const char* name_, std::string* err)
+{
+  const std::string name = name_ ? name_ : "";
+  auto has_fn = [&](const std::string& f) { return std::find(o.functions.begin(), o.functions.end(), f) != o.functions.end(); };
+  auto of_integral = [&](const std::string& obj) -> std::string
+  {
+    for (const auto& p : o.integrals)
+      if (p.first == obj)
+        return p.second;
+    return std::string();
+  };
+  auto of_form = [&](const std::string& form) -> std::string
+  {
+    for (const auto& f : o.forms)
+      if (f.first == form)
+        for (const auto& l : o.lists)
+          if (l.first == f.second)
+            for (const std::string& integral : l.second)
+              if (const std::string fn = of_integral(integral); !fn.empty())
+                return fn;
+    return std::string();
+  };
+  std::string fn;
+  if (name.empty())
+  {
+    if (o.integrals.size() == 1)
+      fn = o.integrals.front().second;
+    else if (o.integrals.empty() && o.functions.size() == 1)
+      fn = o.functions.front();
+    if (fn.empty())
+    {
+      *err = "no function name given and the text does not hold exactly one ufcx_integral object (" + std::to_string(o.integrals.size())
+             + " found): name the function, the ufcx_integral or the ufcx_form";
+      return fn;
+    }
+  }
+  else if (has_fn(name))
+    fn = name;
+  else if (!(fn = of_integral(name)).empty())
+    ;
+  else if (!(fn = of_form(name)).empty())
+    ;
+  else
+    for (const auto& a : o.aliases)
+      if (a.first == name)
+        fn = of_form(a.second);
+  if (fn.empty())
+    *err = "'" + name + "' is neither a function the text defines nor a ufcx_integral / ufcx_form object (or alias) with a float64 kernel";
+  else if (!has_fn(fn))
+  {
+    *err = "the object '" + name + "' names tabulate_tensor_float64 = " + fn + ", which the text does not define";
+    fn.clear();
+  }
+  return fn;
+}
+
 // ---- code objects on disk (opt-in: MPCX_UFCX_CACHE = directory): a form's kernels are then compiled once per (source,
 // element shapes, options, library build), like the reference's FFCx / CFFI JIT cache (~/.cache/fenics).  Files are
 // written to a temporary name and renamed, so concurrent processes never read a partial file.
@@ -1230,6 +1526,8 @@ int launch_blocks(hipFunction_t f, int num_blocks, int threads, size_t lds, cons
     return 0;
   Args copy = a;
   void* params[] = {&copy};
+  if (a.lds_floor > 0 && size_t(a.lds_floor) > lds && a.lds_floor <= 160 * 1024) // per-launch occupancy cap (include/mpcx.h)
+    lds = size_t(a.lds_floor);
   const unsigned grid = 8u * unsigned((num_blocks + 7) / 8);
   return hip_check(hipModuleLaunchKernel(f, grid, 1, 1, unsigned(threads), 1, 1, unsigned(lds), static_cast<hipStream_t>(stream),
                                          params, nullptr),
@@ -1237,9 +1535,35 @@ int launch_blocks(hipFunction_t f, int num_blocks, int threads, size_t lds, cons
 }
 } // namespace
 
+extern "C" int mpcx_ufcx_resolve(const char* source, const char* name, char* out, int32_t out_len)
+{
+  if (!source || !out || out_len <= 0)
+  {
+    mpcx_set_error("mpcx_ufcx_resolve: source and out are required");
+    return -1;
+  }
+  std::string user(source);
+  FfcxObjects objs;
+  ffcx_scan(user, objs);
+  std::string err;
+  const std::string fn = ffcx_resolve(objs, name, &err);
+  if (fn.empty())
+  {
+    mpcx_set_error("mpcx_ufcx_resolve: " + err);
+    return -2;
+  }
+  if (int32_t(fn.size()) + 1 > out_len)
+  {
+    mpcx_set_error("mpcx_ufcx_resolve: out too small");
+    return -3;
+  }
+  std::memcpy(out, fn.c_str(), fn.size() + 1);
+  return 0;
+}
+
 extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
 {
-  if (!d->source || !d->function_name || (d->rank != 1 && d->rank != 2) || d->nd0 <= 0 || d->bs0 <= 0 || d->nv <= 0
+  if (!d->source || (d->rank != 1 && d->rank != 2) || d->nd0 <= 0 || d->bs0 <= 0 || d->nv <= 0
       || (d->rank == 2 && (d->nd1 <= 0 || d->bs1 <= 0)))
   {
     mpcx_set_error("mpcx_ufcx_compile: incomplete descriptor");
@@ -1276,6 +1600,18 @@ extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
     }
     else
       p += 8;
+  }
+  // a whole FFCx file: the descriptor objects behind the functions are read and blanked out, the name resolved through them
+  FfcxObjects objs;
+  ffcx_scan(user, objs);
+  std::string fn_err;
+  std::string fn_name = ffcx_resolve(objs, d->function_name, &fn_err);
+  if (fn_name.empty() && d->function_name && d->function_name[0] && user.find(std::string(d->function_name) + "(") != std::string::npos)
+    fn_name = d->function_name; // (a definition the item walk did not recognise: taken at its word, the compiler decides)
+  if (fn_name.empty())
+  {
+    mpcx_set_error("mpcx_ufcx_compile: " + fn_err);
+    return nullptr;
   }
   // sin / cos / exp of the imported text go to the library's full-range fp64 routines (mpcx_ufcx_math.hpp: <= 2.5 ulp,
   // libm itself outside their fast ranges) unless MPCX_UFCX_LIBM=1 asks for the device libm
@@ -1357,7 +1693,7 @@ extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
   const int small = size <= 144 ? 1 : 0;
   const int big = (d->rank == 2 && size > UFCX_BIG_ENTRIES) ? 1 : 0; // element tensor beyond the per-thread scratch limit
   std::vector<std::string> opts
-      = {"--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-DUFCX_FN=" + std::string(d->function_name), "-DUFCX_BIG=" + std::to_string(big),
+      = {"--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-DUFCX_FN=" + fn_name, "-DUFCX_BIG=" + std::to_string(big),
          "-DUFCX_RB_THREADS=" + std::to_string(rb_threads), "-DUFCX_SMALL=" + std::to_string(small),
          "-DUFCX_RANK=" + std::to_string(d->rank), "-DND0=" + std::to_string(d->nd0), "-DBS0=" + std::to_string(d->bs0),
          "-DND1=" + std::to_string(d->rank == 2 ? d->nd1 : 1), "-DBS1=" + std::to_string(d->rank == 2 ? d->bs1 : 1),

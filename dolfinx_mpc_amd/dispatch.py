@@ -44,6 +44,7 @@ class Ctx:
     same: bool  # test space is trial space, one constraint, one Dirichlet set
     tiled: bool  # the numbering carries tile hints (generators, mesh.reorder_spatial)
     builtin_form: int = -1  # an imported kernel the library also knows as a built-in operator (fem.KernelSpec.builtin): its form id
+    has_transforms: bool = False  # imported kernel with dof transformations (the cluster instances do not carry the hook)
 
 
 @dataclass
@@ -104,7 +105,7 @@ MATRIX: List[Kernel] = [
            "parallelepipeds; 256^3 cells: see DESIGN (generated UFCx kernel in the row blocks: 5.2 ms)"),
     Kernel("ufcx_cube",
            lambda c: (c.form == FORM_UFCX and c.tet and c.d0 == 1 and c.bs0 == 1 and c.d1 == 1 and c.bs1 == 1 and c.same
-                      and c.p1_geometry and c.all_cells and c.cell_integral),
+                      and c.p1_geometry and c.all_cells and c.cell_integral and not c.has_transforms),
            lambda c: True,
            "ufcx_matrix_cube_kernel (hipRTC): the imported tabulate_tensor called six times per cluster, the tensors summed per "
            "vertex pair in registers (no symmetry assumed), 46 scatter-adds per 6 cells; clusters whose cells the mesh lists in "
@@ -156,7 +157,7 @@ VECTOR: List[Kernel] = [
            "fast sin / exp; 256^3 cells, 27 points: see DESIGN (generated UFCx kernel with libm: 4.1 ms)"),
     Kernel("ufcx_cube_own",
            lambda c: (c.form == FORM_UFCX and c.tet and c.d0 == 1 and c.bs0 == 1 and c.p1_geometry and c.all_cells
-                      and c.cell_integral),
+                      and c.cell_integral and not c.has_transforms),
            lambda c: True,
            "ufcx_vector_cube_own_kernel (hipRTC): thread per cluster, six calls of the imported tabulate_tensor, owner-computes "
            "row blocks (8 LDS adds per 6 cells), no device atomics"),

@@ -765,7 +765,7 @@ def form_source(V, fn_id: int = FN_ONE, constant=None, coefficient: Optional[Fun
     return Form([V], [Integral("cell", cells, k, coefficient, _constants(constant))])
 
 
-def form_ufcx(spaces: Sequence[FunctionSpace], source: str, function_name: str, itype: str = "cell", entities=None,
+def form_ufcx(spaces: Sequence[FunctionSpace], source: str, function_name: Optional[str] = None, itype: str = "cell", entities=None,
               coefficient=None, constant=None, builtin: Optional[KernelSpec] = None, dof_transformations=None) -> Form:
     """A form whose element kernel is an imported UFCx ``tabulate_tensor`` given as C SOURCE (what FFCx
     writes to disk; the reference calls the compiled function through a pointer,
@@ -779,6 +779,11 @@ def form_ufcx(spaces: Sequence[FunctionSpace], source: str, function_name: str, 
     gfx950 with hipRTC and runs inside the LDS row-block kernels (or the per-entity kernels with device atomics
     when ``algorithm="atomic"``).
 
+    ``source`` may be a WHOLE FFCx output file (``#include <ufcx.h>``, the functions, then the ``ufcx_integral`` /
+    ``ufcx_form`` objects and the alias ``form_<file>_<name>``): ``function_name`` then names the function, a
+    ``ufcx_integral`` object, a ``ufcx_form`` object or its alias -- the kernel is found through the objects, the way DOLFINx
+    (and through it the reference) finds it -- or is None for a file with one integral (include/mpcx.h mpcx_ufcx_resolve).
+
     ``builtin``: the ``KernelSpec`` of a built-in operator the caller (a form generator) states this text implements.
     On simplices the library CHECKS the statement at first use -- both kernels are evaluated on a sample of the form's
     entities on the device and must agree to 1e-12 of the largest entry -- and, if it holds, runs the built-in operator
@@ -791,7 +796,7 @@ def form_ufcx(spaces: Sequence[FunctionSpace], source: str, function_name: str, 
         ents = _cells_or_all(V0.mesh, entities)
     else:
         ents = np.ascontiguousarray(entities, dtype=np.int32).reshape(-1, 2)
-    k = KernelSpec(FORM_UFCX, _CELL_ID[V0.mesh.cell_name], V0.degree, V0.dofmap.bs, ufcx_source=source, ufcx_name=function_name)
+    k = KernelSpec(FORM_UFCX, _CELL_ID[V0.mesh.cell_name], V0.degree, V0.dofmap.bs, ufcx_source=source, ufcx_name=function_name or "")
     if V1 is not None:
         k.degree1, k.bs1 = V1.degree, V1.dofmap.bs
     k.builtin = builtin

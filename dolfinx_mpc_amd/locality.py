@@ -271,6 +271,10 @@ class Twin:
     def form(self, form: Form) -> Form:
         hit = self._forms.get(form)
         if hit is None:
+            if any(getattr(integ.kernel, "ufcx_transforms", None) is not None for integ in form.integrals):
+                # the cell permutation words depend on the GLOBAL vertex numbering, which the twin changes: such forms are
+                # assembled in the caller's numbering (the callers fall back on PlanNotRepresentable)
+                raise _native.PlanNotRepresentable("imported kernel with dof transformations: no locality twin")
             spaces2 = [self.space(V)[0] for V in form.function_spaces]
             integrals, sources = [], []
             for integ in form.integrals:

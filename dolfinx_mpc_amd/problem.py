@@ -454,10 +454,17 @@ class NonlinearProblem:
         return self._x
 
     def _assign_u(self):
-        """u <- x, then the constraint on the slaves (problem.py:101-113)"""
+        """u <- x, then the constraint on the slaves (problem.py:101-113).  Skipped when neither x nor u changed since the
+        last assignment (the Jacobian callback right after the residual callback of the same Newton iterate: ADVICE r5)"""
+        import torch
+
+        seen = getattr(self, "_assigned", None)
+        if seen is not None and torch.equal(seen[0], self._x.array) and np.array_equal(seen[1], self._u.x.array):
+            return
         self._u.x.array[:] = self._x.numpy()
         self.mpc.homogenize(self._u)
         self.mpc.backsubstitution(self._u)
+        self._assigned = (self._x.array.clone(), np.array(self._u.x.array, copy=True))
 
     def assemble_residual(self) -> Vector:
         """problem.py:88-152"""

@@ -30,8 +30,10 @@ extern "C" {
  *    the three argument blocks (before ``stream``)
  * 9: mpcx_matrix_args_t::val_map / val_map_wide / out_map / out_delta (before ``stream``), mpcx_add_diagonal_mapped,
  *    mpcx_invert_permutation, mpcx_write_out_order; mpcx_vector_args_t::row_map,
- *    mpcx_lifting_args_t::row_map */
-#define MPCX_VERSION 9
+ *    mpcx_lifting_args_t::row_map
+ * 10: lds_floor (before ``stream``) of the matrix and the vector argument block: occupancy cap of one launch, so that a kernel
+ *    of another stream finds room on every CU (co-running matrix and vector assembly); mpcx_kernel_t::vphi (last field) */
+#define MPCX_VERSION 10
 
 /* Offsets into the CSR value / column arrays (rowptr entries, positions): 64-bit, so that one GPU can
  * hold matrices with more than 2^31 - 1 stored entries (Taylor-Hood a00 on 128^3 cells: 4.4 G) -- PETSc's
@@ -102,6 +104,14 @@ typedef struct
    * (csrc/mpcx_scalar.hip: device atomics, no plan, row-side coefficients conjugated for complex T); built-in operators
    * on simplices only. */
   int32_t scalar_type;
+  /* Source forms (MPCX_FORM_SOURCE) whose integrand function is AFFINE in x (constant, linear: fn_id 0, 4, 5) on affine
+   * simplices, without a coefficient, optional: DEVICE [nv][nd], vphi[v][i] = sum_q qwts[q] phi_i(X_q) lambda_v(X_q), the
+   * moments of the cell rule against the barycentric coordinates.  f(x(X_q)) = sum_v f(x_v) lambda_v(X_q) holds exactly
+   * for such f, so sum_q w_q phi_i(X_q) f(x_q) = sum_v vphi[v][i] f(x_v): the kernels evaluate f at the nv vertices and
+   * take nd * nv fma instead of walking the rule -- the SAME number as the quadrature sum up to rounding, whatever the
+   * rule's degree (what FFCx does for piecewise-linear data on affine cells: weights folded into one table; the loop of
+   * cpp/assemble_vector.cpp:65-90 is unchanged).  NULL: the rule is walked. */
+  const double* vphi;
 } mpcx_kernel_t;
 
 /* ------------------------------------------------------------------------
@@ -140,6 +150,15 @@ typedef struct
   const char* transform1_name;
 } mpcx_ufcx_desc_t;
 void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* desc);
+/* ``source`` may be a WHOLE FFCx output file: the functions, then the descriptor objects DOLFINx reads (``ufcx_integral
+ * integral_<hash> = { ..., .tabulate_tensor_float64 = <function>, ... };`` with its ``#ifndef __STDC_NO_COMPLEX__`` members,
+ * the ``form_integrals_...`` arrays, ``ufcx_form form_<hash> = {...};``, the alias ``ufcx_form* form_<file>_<name> = &form_<hash>;``).
+ * The objects are read and left out of the device translation unit; ``function_name`` may then name a function of the text, a
+ * ufcx_integral object, a ufcx_form object or its alias (the form's first integral with a float64 kernel) -- the way the
+ * reference reaches its kernels (cpp/assemble_matrix.cpp:438-439 through DOLFINx's ``form_integrals[k]->tabulate_tensor_float64``);
+ * NULL: the file's only ufcx_integral.  mpcx_ufcx_resolve (HOST, no device, no compilation): the function ``name`` stands for,
+ * NUL-terminated into out[out_len]; 0, or < 0 with mpcx_last_error(). */
+int mpcx_ufcx_resolve(const char* source, const char* name, char* out, int32_t out_len);
 /* 1 if the element tensor (nd0 * bs0 * nd1 * bs1 > 12288 entries, e.g. vector-valued Q3 hexahedra: 192 x 192) does not fit a
  * thread's private memory: such a kernel has the per-entity variants only (MPCX_ALG_ATOMIC, mpc_plan_off == NULL); the tensor
  * of a thread then lives in a slab of a scratch array the library allocates at first launch (256 MiB per kernel) and a
@@ -355,6 +374,13 @@ typedef struct
    * 1.0 ms for the unpermuted write-out).  out_map: the index type of val_map; out_delta: int16. */
   const void* out_map;
   const int16_t* out_delta;
+  /* Occupancy cap of THIS launch (0: none): the row-block / pair / cluster kernel is launched with at least lds_floor bytes
+   * of dynamic LDS per workgroup, so at most floor(160 KiB / lds_floor) of its workgroups share a CU and the rest of the CU
+   * (LDS, wave slots, registers) stays free for a kernel of ANOTHER stream -- the VALU-bound vector kernel of the same
+   * step beside the HBM-bound matrix kernel (dolfinx_mpc_amd/corun.py: the first part of a matrix launch is capped while
+   * a vector assembly is in flight, the rest runs uncapped; sub-ranges of a plan are launched by advancing
+   * plan.block_row0 / plan.block_ent_off and lowering plan.num_blocks).  Kernels without dynamic LDS ignore it. */
+  int32_t lds_floor;
   void* stream;
 } mpcx_matrix_args_t;
 #define MPCX_VAL_POS(a, k)                                                                                                        \
@@ -629,6 +655,7 @@ typedef struct
    * entry d of its own numbering goes to b[row_map[d]] -- DEVICE [scalar dofs] int32 -- instead of b[d]; NULL: b[d].
    * float64 kernels only. */
   const int32_t* row_map;
+  int32_t lds_floor; /* as mpcx_matrix_args_t::lds_floor: minimum dynamic LDS per workgroup of the row-block / cluster launch */
   void* stream;
 } mpcx_vector_args_t;
 #define MPCX_ROW_POS(a, d) ((a).row_map ? (int64_t)(a).row_map[d] : (int64_t)(d))

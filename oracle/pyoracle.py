@@ -251,13 +251,67 @@ def _desc(k):
 _user_libs = {}
 
 
+# The descriptor objects at the end of an FFCx output file, as DOLFINx reads them (declarations: oracle/include/ufcx.h).
+class _UfcxIntegral(C.Structure):
+    _fields_ = [("enabled_coefficients", C.c_void_p), ("tabulate_tensor_float32", C.c_void_p),
+                ("tabulate_tensor_float64", C.c_void_p), ("tabulate_tensor_complex64", C.c_void_p),
+                ("tabulate_tensor_complex128", C.c_void_p), ("needs_facet_permutations", C.c_bool),
+                ("coordinate_element_hash", C.c_uint64), ("domain", C.c_uint8)]
+
+
+class _UfcxForm(C.Structure):
+    _fields_ = [("signature", C.c_char_p), ("rank", C.c_int), ("num_coefficients", C.c_int), ("num_constants", C.c_int),
+                ("original_coefficient_positions", C.POINTER(C.c_int)), ("coefficient_name_map", C.POINTER(C.c_char_p)),
+                ("constant_name_map", C.POINTER(C.c_char_p)), ("finite_element_hashes", C.POINTER(C.c_uint64)),
+                ("form_integrals", C.POINTER(C.POINTER(_UfcxIntegral))), ("form_integral_ids", C.POINTER(C.c_int)),
+                ("form_integral_offsets", C.POINTER(C.c_int))]
+
+
+def _ufcx_kernel_pointer(so, source: str, name: str):
+    """the float64 tabulate_tensor ``name`` stands for, reached the way the reference reaches it: a function of the text, or
+    THROUGH the objects of an FFCx output file -- ``ufcx_integral`` -> ``.tabulate_tensor_float64``; ``ufcx_form`` (or the alias
+    pointer ``form_<file>_<name>``) -> ``form_integrals[k]`` -> the first integral with a float64 kernel (DOLFINx fills
+    ``Form::kernel`` from exactly these members; cpp/assemble_matrix.cpp:438-439 reads it back).  Which kind of symbol a name is
+    comes from its declaration in the text; the VALUES come from the compiled objects."""
+    import re
+
+    def integral_fn(obj: _UfcxIntegral):
+        return obj.tabulate_tensor_float64
+
+    def form_fn(form: _UfcxForm):
+        n = form.form_integral_offsets[4]  # cell | exterior facet | interior facet | vertex: five offsets
+        for i in range(n):
+            fn = integral_fn(form.form_integrals[i].contents)
+            if fn:
+                return fn
+        raise RuntimeError("oracle: the ufcx_form holds no integral with a float64 kernel")
+
+    if not name:
+        objs = re.findall(r"\bufcx_integral\s+(\w+)\s*=", source)
+        if len(objs) != 1:
+            raise RuntimeError(f"oracle: no kernel name given and the text holds {len(objs)} ufcx_integral objects")
+        name = objs[0]
+    if re.search(r"\bufcx_integral\s+%s\s*=" % re.escape(name), source):
+        fn = integral_fn(_UfcxIntegral.in_dll(so, name))
+    elif re.search(r"\bufcx_form\s+%s\s*=" % re.escape(name), source):
+        fn = form_fn(_UfcxForm.in_dll(so, name))
+    elif re.search(r"\bufcx_form\s*\*\s*%s\s*=" % re.escape(name), source):
+        fn = form_fn(C.POINTER(_UfcxForm).in_dll(so, name).contents)
+    else:
+        return getattr(so, name)
+    if not fn:
+        raise RuntimeError(f"oracle: '{name}' has no float64 kernel")
+    return C.c_void_p(fn)
+
+
 def _load_user_kernel(k):
     """UFCx import (fem.FORM_UFCX): the kernel's C source compiled with gcc -- the same text the product
     compiles with hipRTC -- and registered as the oracle's kernel 100."""
     import hashlib
     import tempfile
 
-    key = hashlib.sha256((k.ufcx_source + k.ufcx_name).encode()).hexdigest()[:20]
+    name = k.ufcx_name or ""
+    key = hashlib.sha256((k.ufcx_source + name).encode()).hexdigest()[:20]
     if key not in _user_libs:
         d = os.path.join(tempfile.gettempdir(), "mpcx_oracle_ufcx")
         os.makedirs(d, exist_ok=True)
@@ -268,11 +322,13 @@ def _load_user_kernel(k):
             src, tmp = os.path.join(d, tag + ".c"), os.path.join(d, tag + ".so")
             with open(src, "w") as fh:
                 fh.write("#include <stdint.h>\n#include <math.h>\n" + k.ufcx_source)
-            subprocess.run(["gcc", "-O2", "-std=c99", "-fPIC", "-shared", "-o", tmp, src, "-lm"], check=True)
+            # (-I oracle/include: the minimal ufcx.h a whole FFCx-layout file includes, oracle/include/ufcx.h)
+            subprocess.run(["gcc", "-O2", "-std=c99", "-fPIC", "-shared", "-I", os.path.join(os.path.dirname(os.path.abspath(__file__)), "include"),
+                            "-o", tmp, src, "-lm"], check=True)
             os.replace(tmp, so)
             os.remove(src)
         _user_libs[key] = C.CDLL(so)
-    fn = getattr(_user_libs[key], k.ufcx_name)
+    fn = _ufcx_kernel_pointer(_user_libs[key], k.ufcx_source, name)
     lib().oracle_set_user_kernel(C.cast(fn, C.c_void_p))
     # dof transformations of the element (cpp/assemble_matrix.cpp:507-508): functions of the same text + the cell permutation
     # words of the meshes; reset for kernels without any

@@ -135,3 +135,15 @@ def test_gpu_plan_variants_apply_the_transformations(oracle, monkeypatch, varian
     want = oracle_outputs(oracle, ref)
     out = product_outputs(hooked, algorithm="rowblock")
     _same({k: want[k] for k in out}, out, variant)
+
+
+@pytest.mark.gpu
+def test_locality_twin_leaves_forms_with_transformations_alone(oracle, monkeypatch):
+    """the locality twin renumbers the vertices, the cell permutation words would be stale there --
+    forms whose imported kernel names a dof transformation are assembled in the caller's numbering (the mesh of _cases()
+    has no tile hints, so with MPCX_AUTO_REORDER=1 every other form would go through the twin)"""
+    monkeypatch.setenv("MPCX_AUTO_REORDER", "1")
+    ref, hooked = _cases()
+    want = oracle_outputs(oracle, ref)
+    out = product_outputs(hooked)
+    _same({k: want[k] for k in out}, out, "forced twin")

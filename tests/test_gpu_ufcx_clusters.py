@@ -212,6 +212,51 @@ def test_coefficients_and_constants_through_the_clusters(oracle):
     _check(oracle, case)
 
 
+def _partly_permuted_mesh(fraction=0.3, seed=5):
+    from dolfinx_mpc_amd.mesh import Mesh
+
+    base = case_cube_periodic(6, 1, 0.3, reorder=(2, 2, 2)).mesh
+    rng = np.random.default_rng(seed)
+    cells = base.geometry.dofmap.copy()
+    for g in np.flatnonzero(rng.random(cells.shape[0] // 6) < fraction):
+        c = 6 * g + rng.integers(6)
+        p = rng.permutation(4)
+        while np.array_equal(p, np.arange(4)):
+            p = rng.permutation(4)
+        cells[c] = cells[c][p]
+    mesh = Mesh(base.geometry.x, cells, "tetrahedron")
+    mesh.node_tile_offsets = base.node_tile_offsets
+    return mesh
+
+
+def test_coefficients_reach_the_leftover_cells(oracle):
+    """clusters whose cells use another vertex order are assembled by the per-cell kernels through a
+    form restricted to those cells -- it must carry the coefficient (the imported text reads w[] for every cell):
+    Functions, and a caller-packed array"""
+    from dolfinx_mpc_amd import fem
+
+    mesh = _partly_permuted_mesh()
+    case = _periodic_case(mesh, "ufcx_leftover_coefficient", with_coefficient=True, constant=fem.Constant(0.7))
+    ma, va = _taken(case)
+    assert ma.kernel_name == "ufcx_cube" and ma.leftover is not None and ma.cube_cells
+    assert va.kernel_name == "ufcx_cube_own" and va.leftover is not None
+    _check(oracle, case, "Function coefficient")
+    # the same with the coefficient handed over as an already packed array (dolfinx pack_coefficients layout)
+    packed = np.ascontiguousarray(case.a.integrals[0].coeffs)
+    V = case.V
+    cd = 1
+    from dolfinx_mpc_amd.codegen import BENCH_PERIODIC_F, generate
+    from dolfinx_mpc_amd.quadrature import make_quadrature
+
+    sa, na = generate("stiffness", "tetrahedron", 1, 1, make_quadrature("tetrahedron", 0), coefficient_degree=cd, use_constant=True)
+    sl, nl = generate("source", "tetrahedron", 1, 1, make_quadrature("tetrahedron", 5), fexpr=BENCH_PERIODIC_F, coefficient_degree=cd,
+                      use_constant=True)
+    a2 = fem.form_ufcx([V, V], sa, na, coefficient=packed, constant=fem.Constant(0.7))
+    L2 = fem.form_ufcx([V], sl, nl, coefficient=packed.copy(), constant=fem.Constant(0.7))
+    case2 = Case("ufcx_leftover_packed", V, a2, L2, case.bcs, case.raw)
+    _check(oracle, case2, "packed coefficient")
+
+
 def test_changed_coefficient_values_are_read_on_the_next_call(oracle):
     import dolfinx_mpc_amd as dm
     from dolfinx_mpc_amd import fem
