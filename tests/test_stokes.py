@@ -73,11 +73,41 @@ def test_oracle_rectangular_identities(oracle, dim, n):
     po.compare_mpc_rhs(b0, out["b0"], mv)
 
 
-def _product_blocks(dim, n, alg):
+def _imported(problem, layout):
+    """the same problem with every cell integral as IMPORTED text (tests/ufcx_twin.py: codegen.generate / generate_div; layout
+    "ffcx": inside whole FFCx-layout files, the kernels named by the form aliases)"""
+    from ufcx_twin import twin_form
+
+    V, Q, bcs, raw_v, forms, L0 = problem
+    return V, Q, bcs, raw_v, {k: twin_form(f, layout) for k, f in forms.items()}, twin_form(L0, layout)
+
+
+@pytest.mark.parametrize("layout", ["function", "ffcx"])
+@pytest.mark.parametrize("dim,n", [(2, 3), (3, 2)])
+def test_oracle_imported_taylor_hood_blocks_reproduce_builtin_blocks(oracle, dim, n, layout):
+    """the Taylor-Hood blocks as FFCx-shaped text (round 6: generate_div for p div(v) / div(u) q) through the oracle's function
+    pointer / ufcx objects == the built-in operators"""
+    po = oracle
+    problem = _stokes(dim, n)
+    V, Q, bcs, raw_v, forms, L0 = problem
+    _, _, _, _, tforms, tL0 = _imported(problem, layout)
+    assert all(f.integrals[0].kernel.form == fem.FORM_UFCX for f in tforms.values()) and tL0.integrals[0].kernel.form == fem.FORM_UFCX
+    mv = po.OracleMPC.from_raw(V, *raw_v)
+    mq = po.OracleMPC.from_raw(Q, *empty_raw())
+    mpcs = [mv, mq]
+    for (i, j), f in forms.items():
+        want = po.assemble_matrix(f, mpcs[i], mpcs[j], bcs=bcs)
+        got = po.assemble_matrix(tforms[(i, j)], mpcs[i], mpcs[j], bcs=bcs)
+        assert abs(got - want).max() <= 1e-12 * max(1.0, abs(want).max()), (i, j)
+    want, got = po.assemble_vector(L0, mv), po.assemble_vector(tL0, mv)
+    assert abs(got - want).max() <= 1e-12 * max(1.0, abs(want).max())
+
+
+def _product_blocks(dim, n, alg, layout=None):
     import dolfinx_mpc_amd as dm
     from dolfinx_mpc_amd.la import create_vector
 
-    V, Q, bcs, raw_v, forms, L0 = _stokes(dim, n)
+    V, Q, bcs, raw_v, forms, L0 = _stokes(dim, n) if layout is None else _imported(_stokes(dim, n), layout)
     mv = dm.MultiPointConstraint(V)
     mv.add_constraint(V, *raw_v)
     mv.finalize()
@@ -111,6 +141,23 @@ def _product_blocks(dim, n, alg):
 def test_gpu_stokes_blocks_match_oracle(oracle, dim, n, alg):
     _, _, ref = _oracle_blocks(oracle, dim, n)
     out = _product_blocks(dim, n, alg)
+    for key in [(0, 0), (0, 1), (1, 0)]:
+        assert np.array_equal(out[key].indptr, ref[key].indptr) and np.array_equal(out[key].indices, ref[key].indices)
+        scale = max(1.0, abs(ref[key]).max())
+        assert abs(out[key].data - ref[key].data).max() <= 1e-12 * scale, key
+    for key in ("b0", "b1"):
+        assert abs(out[key] - ref[key]).max() <= 1e-12 * max(1.0, abs(ref[key]).max()), key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["function", "ffcx"])
+@pytest.mark.parametrize("alg", ["atomic", "rowblock"])
+@pytest.mark.parametrize("dim,n", [(2, 3), (3, 2)])
+def test_gpu_imported_taylor_hood_blocks_match_oracle(oracle, dim, n, alg, layout):
+    """config 3's blocks as imported text (N1: the path north_star names, beyond scalar P1): P2^d stiffness, p div(v), div(u) q
+    and the P2^d source through the imported-kernel row blocks / per-entity kernels, against the built-in oracle"""
+    _, _, ref = _oracle_blocks(oracle, dim, n)
+    out = _product_blocks(dim, n, alg, layout)
     for key in [(0, 0), (0, 1), (1, 0)]:
         assert np.array_equal(out[key].indptr, ref[key].indptr) and np.array_equal(out[key].indices, ref[key].indices)
         scale = max(1.0, abs(ref[key]).max())

@@ -27,6 +27,21 @@ def test_oracle_imported_kernels_reproduce_builtin_operators(oracle, make):
         assert abs(o - r).max() <= 1e-12 * max(1.0, abs(r).max()), f"{case.name} {k}"
 
 
+@pytest.mark.parametrize("make", CASES, ids=[f"case{i}" for i in range(len(CASES))])
+def test_oracle_reads_generated_kernels_out_of_ffcx_layout_files(oracle, make):
+    """the same kernels inside whole FFCx-layout files (codegen.ffcx_file: include block, ufcx_integral / ufcx_form objects,
+    alias): the oracle compiles the file against oracle/include/ufcx.h and takes the kernel out of the compiled objects"""
+    case = make()
+    twin = twin_case(case, layout="ffcx")
+    if num_imported(twin) == 0:
+        pytest.skip("no cell integral the generator covers")
+    ref = oracle_outputs(oracle, case)
+    out = oracle_outputs(oracle, twin)
+    for k in ref:
+        r, o = (ref[k].toarray(), out[k].toarray()) if k == "A" else (ref[k], out[k])
+        assert abs(o - r).max() <= 1e-12 * max(1.0, abs(r).max()), f"{case.name} {k}"
+
+
 def test_include_lines_are_dropped_and_functions_inlined():
     """FFCx output starts with #include <math.h> / <stdint.h> / <ufcx.h>: hipRTC has no such headers, the compile
     step drops the lines; helper functions in the text are fine (everything defined there becomes a device
@@ -61,6 +76,24 @@ def test_gpu_imported_kernels_match_builtin_oracle(oracle, make, alg):
     out = product_outputs(twin, algorithm=None if alg == "auto" else alg)
     if "A" in ref:
         assert np.array_equal(out["A"].indptr, ref["A"].indptr) and np.array_equal(out["A"].indices, ref["A"].indices)
+        assert abs(out["A"].data - ref["A"].data).max() <= 1e-12 * max(1.0, abs(ref["A"]).max()), case.name + " A"
+    for k in ("b", "b_lifted"):
+        if k in ref:
+            assert abs(out[k] - ref[k]).max() <= 1e-12 * max(1.0, abs(ref[k]).max()), f"{case.name} {k}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alg", ["atomic", "auto"])
+@pytest.mark.parametrize("make", CASES, ids=[f"case{i}" for i in range(len(CASES))])
+def test_gpu_imported_ffcx_layout_files_match_builtin_oracle(oracle, make, alg):
+    """whole FFCx-layout files through mpcx_ufcx_compile (objects read, blanked, the alias resolved) on both algorithms"""
+    case = make()
+    twin = twin_case(case, layout="ffcx")
+    if num_imported(twin) == 0:
+        pytest.skip("no cell integral the generator covers")
+    ref = oracle_outputs(oracle, case)
+    out = product_outputs(twin, algorithm=None if alg == "auto" else alg)
+    if "A" in ref:
         assert abs(out["A"].data - ref["A"].data).max() <= 1e-12 * max(1.0, abs(ref["A"]).max()), case.name + " A"
     for k in ("b", "b_lifted"):
         if k in ref:
