@@ -986,6 +986,26 @@ def main():
             extra["value_csr_valued"] = w.ndofs_total / (tc * 1e-3)
         finally:
             del os.environ["MPCX_BLOCK_SCALAR"]
+    if subs and not args.ufcx:
+        # the same step replayed from ONE captured HIP graph (dolfinx_mpc_amd/graph.py CapturedStep: no
+        # per-call argument blocks / dispatch look-ups / ~10 launches on the host) -- what a time loop that does not change
+        # values between steps can run; matters where the kernels of a step are short (config 4; a rank's slab at 8 GPUs)
+        try:
+            from dolfinx_mpc_amd.graph import CapturedStep
+
+            g = CapturedStep(step)
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize()
+            t0g2 = time.perf_counter()
+            for _ in range(args.steps):
+                g.replay()
+            torch.cuda.synchronize()
+            extra["ms_per_step_graph"] = 1e3 * (time.perf_counter() - t0g2) / args.steps
+            del g
+        except Exception as e:  # noqa: BLE001
+            extra["ms_per_step_graph"] = None
+            extra["graph_error"] = str(e)[:200]
     step()  # leave consistent A / b
     torch.cuda.synchronize()
     if rank != 0:

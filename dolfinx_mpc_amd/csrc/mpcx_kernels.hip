@@ -888,19 +888,8 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_nodeblock_kernel(
 {
   nodeblock_body<Op, USE_LAZY>(a);
 }
-// Occupancy variants for the CSR-valued write-out (no block_vals): compute and write-out phases of a block are both bound
-// by the latency of a wave's own chain, so the rate follows the number of resident waves, and that is set by the registers
-// (84 for the Taylor-Hood velocity block: 5 waves per SIMD).  WPE waves per SIMD = 2 workgroups of WPE * 128 threads per CU.
-template <class Op, bool USE_LAZY>
-__global__ void __launch_bounds__(768, 6) matrix_nodeblock_w6_kernel(mpcx_matrix_args_t a)
-{
-  nodeblock_body<Op, USE_LAZY>(a);
-}
-template <class Op, bool USE_LAZY>
-__global__ void __launch_bounds__(1024, 8) matrix_nodeblock_w8_kernel(mpcx_matrix_args_t a)
-{
-  nodeblock_body<Op, USE_LAZY>(a);
-}
+// (Round 6, measured and removed: instances capped at 80 / 64 VGPRs so that two workgroups of 768 / 1024 threads share a CU --
+// CSR-valued Taylor-Hood a00: 13.3 / 14.9 ms against 11.3 ms for one 1024-thread workgroup of the 84-register instance.)
 
 // set-up for the node-block kernel: one thread per node row
 __global__ void diag_slot_mask_kernel(int32_t n_nodes, const mpcx_nnz_t* __restrict__ rowptr,
@@ -1596,6 +1585,91 @@ __global__ void __launch_bounds__(MAXT) vector_ownblock_kernel(mpcx_vector_args_
     a.own_spill[h0 * BS + i] = s_b[nown + i];
 }
 
+// Owner-computes blocks for source forms whose integrand function is AFFINE in x (mpcx_kernel_t::vphi: constant / linear f on
+// affine simplices, no coefficient -- the momentum right-hand side of config 3).  With the rule's vertex moments the element
+// vector is NV * ND fma per component and the kernel is a gather / LDS-add problem: no quadrature loop, no 128-register
+// instance, so it runs 1024-thread workgroups (8 waves per SIMD from two resident blocks) and every component in one pass.
+// Round 6: the general instance spent 1.7 ms on 12.6 M P2^3 cells with a tenth of its arithmetic removed -- it is bound by the
+// latency of its per-entity chain (entity -> geometry dofmap -> coordinates -> position table -> LDS), i.e. by resident waves.
+template <class Op>
+__global__ void __launch_bounds__(1024) vector_ownblock_affine_kernel(mpcx_vector_args_t a)
+{
+  constexpr int ND = Op::ND0, BS = Op::BS0, NV = Op::NV, TDIM = Op::TDIM;
+  constexpr int LMASK = (1 << MPCX_MASK_SHIFT) - 1;
+  const int NT = blockDim.x;
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* s_b = reinterpret_cast<double*>(smem);
+  const int nb = a.plan.num_blocks;
+  const int per = (nb + 7) >> 3;
+  const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (b >= nb)
+    return;
+  const int tid = threadIdx.x;
+  const int r0 = a.plan.block_row0[b], r1 = a.plan.block_row0[b + 1];
+  const int64_t h0 = a.own_hoff[b], h1 = a.own_hoff[b + 1];
+  const int nown = r1 - r0, nhalo = int(h1 - h0) * BS;
+  for (int i = tid; i < nown + nhalo; i += NT)
+    s_b[i] = 0.0;
+  __syncthreads();
+  const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  const int32_t* __restrict__ ents = a.plan.block_ents;
+  const double* __restrict__ vphi = a.kernel.vphi;
+  const double c0 = a.constants ? a.constants[0] : 1.0;
+  const int fn = Op::FN >= 0 ? Op::FN : a.kernel.fn_id;
+  for (int64_t t = e0 + tid; t < e1; t += NT)
+  {
+    const int64_t e = ents[t];
+    const int64_t cell = a.entities ? a.entities[e * a.estride] : e;
+    double cd[NV * 3];
+    gather_coords<NV>(a.x, a.x_dofmap, cell, cd);
+    int32_t w[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+      w[i] = a.own_lmap[e * ND + i]; // (independent of the geometry: in flight with it)
+    double det;
+    if constexpr (TDIM == 3)
+    {
+      const double a0 = cd[3] - cd[0], a1 = cd[4] - cd[1], a2 = cd[5] - cd[2];
+      const double b0 = cd[6] - cd[0], b1 = cd[7] - cd[1], b2 = cd[8] - cd[2];
+      const double d0 = cd[9] - cd[0], d1 = cd[10] - cd[1], d2 = cd[11] - cd[2];
+      det = a0 * (b1 * d2 - b2 * d1) - a1 * (b0 * d2 - b2 * d0) + a2 * (b0 * d1 - b1 * d0);
+    }
+    else
+      det = (cd[3] - cd[0]) * (cd[7] - cd[1]) - (cd[4] - cd[1]) * (cd[6] - cd[0]);
+    const double sd = c0 * fabs(det);
+    // one component at a time, rolled: NV function values live, not BS * NV (92 -> ~64 VGPRs for P2^3: two 1024-thread
+    // workgroups per CU)
+#pragma unroll 1
+    for (int k = 0; k < BS; ++k)
+    {
+      double F[NV];
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+      {
+        const double xv[3] = {cd[3 * v], cd[3 * v + 1], cd[3 * v + 2]};
+        // (the affine members of eval_fn only: the sin / exp branches of the general switch set the register count)
+        F[v] = sd * (fn == 4 ? (k + 1) * (1.0 + xv[0] - 2.0 * xv[1] + 0.5 * xv[2]) : (fn == 5 ? a.constants[1 + k] : 1.0));
+      }
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+      {
+        if ((w[i] >> (MPCX_MASK_SHIFT + k)) & 1)
+          continue;
+        double s = 0.0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+          s = fma(vphi[v * ND + i], F[v], s);
+        __hip_atomic_fetch_add(s_b + (w[i] & LMASK) * BS + k, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < nown; i += NT)
+    a.b[MPCX_ROW_POS(a, r0 + i)] += s_b[i];
+  for (int i = tid; i < nhalo; i += NT)
+    a.own_spill[h0 * BS + i] = s_b[nown + i];
+}
+
 // second half of the owner-computes vector path: one thread per (distinct target dof, component)
 __global__ void vector_spill_reduce_kernel(int64_t n_rows, const int32_t* __restrict__ rows,
                                            const int64_t* __restrict__ seg, const int32_t* __restrict__ src,
@@ -1904,21 +1978,8 @@ int launch_matrix(const mpcx_matrix_args_t& a)
           if constexpr (Op::LAZY)
             lazy = Op::lazy_applies(a.kernel);
           int rc = 0;
-          int variant = 0; // CSR-valued write-out: occupancy variant (MPCX_NODEBLOCK_CSR_VARIANT = 0 | 6 | 8)
-          if (!a.block_vals)
-          {
-            const char* e = std::getenv("MPCX_NODEBLOCK_CSR_VARIANT");
-            variant = e ? std::atoi(e) : 0;
-          }
           if constexpr (Op::LAZY)
-          {
-            if (lazy && variant == 6)
-              rc = launch(matrix_nodeblock_w6_kernel<Op, true>, 768);
-            else if (lazy && variant == 8)
-              rc = launch(matrix_nodeblock_w8_kernel<Op, true>, 1024);
-            else
-              rc = lazy ? launch(matrix_nodeblock_kernel<Op, true>) : launch(matrix_nodeblock_kernel<Op, false>);
-          }
+            rc = lazy ? launch(matrix_nodeblock_kernel<Op, true>) : launch(matrix_nodeblock_kernel<Op, false>);
           else
             rc = launch(matrix_nodeblock_kernel<Op, false>);
           if (rc)
@@ -2101,15 +2162,45 @@ int launch_vector(const mpcx_vector_args_t& a)
       mpcx_set_error("mpcx_assemble_vector: incomplete owner-computes plan");
       return -5;
     }
+    bool affine_done = false;
+    if constexpr (Op::FORM == MPCX_FORM_SOURCE && (Op::DEG0 == 1 || Op::DEG0 == 2) && Op::FN != 1)
+    {
+      // integrand function affine in x (mpcx_kernel_t::vphi): the gather / LDS-add instance, 1024 threads
+      // (MPCX_AFFINE_OWNBLOCK=0: the general instance; MPCX_AFFINE_THREADS)
+      static const bool off = []
+      {
+        const char* e = std::getenv("MPCX_AFFINE_OWNBLOCK");
+        return e && e[0] == '0';
+      }();
+      if (owner && a.kernel.vphi && !a.coeffs && a.estride == 1 && a.kernel.coeff_degree == 0 && !off)
+      {
+        auto kernel = vector_ownblock_affine_kernel<Op>;
+        // two resident workgroups per CU (the blocks are ~60 KB of LDS) with as many waves as the registers allow
+        hipFuncAttributes attr;
+        if (int rc = check(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kernel)), "hipFuncGetAttributes"))
+          return rc;
+        const int alloc = ((attr.numRegs + 7) / 8) * 8;
+        const int per_simd = std::max(2, std::min(8, 512 / std::max(alloc, 8)));
+        const char* e = std::getenv("MPCX_AFFINE_THREADS");
+        int threads = e ? std::atoi(e) : std::min(1024, 128 * per_simd);
+        if (threads < 64 || threads > 1024 || threads % 64)
+          threads = 1024;
+        if (int rc = check(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)),
+                           "hipFuncSetAttribute"))
+          return rc;
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, stream, a);
+        affine_done = true;
+      }
+    }
     if constexpr (BY_COMPONENT)
     {
       // (round 5, measured and not kept: all components in ONE pass over the points -- a third of the geometry / point work,
       // 3 x ND accumulators, compiled for 512 threads and up to 256 registers: Stokes b0 at 128^3 1.95 ms (512 threads),
       // 1.89 (256), 2.34 (384) against 1.47 ms by component)
-      if (split)
+      if (split && !affine_done)
         lrc = owner ? launch(vector_ownblock_kernel<Op, true>) : launch(vector_rowblock_kernel<Op, true>);
     }
-    if (!split)
+    if (!split && !affine_done)
       lrc = owner ? launch(vector_ownblock_kernel<Op, false>) : launch(vector_rowblock_kernel<Op, false>);
     if (lrc)
       return lrc;

@@ -458,6 +458,61 @@ extern "C" __global__ void __launch_bounds__(UFCX_RB_THREADS) ufcx_matrix_rowblo
     const int (&m0)[ND0] = cur.m0;
     const int (&m1)[ND1] = cur.m1;
     const unsigned (&ow)[(NOFF + 3) / 4] = cur.ow;
+#if UFCX_ROWWISE
+    // Row by row (element tensors of more than 36 entries, round 6): the imported function is inlined ONCE PER ROW of the tensor
+    // and only that row is read afterwards, so every other entry -- and whatever feeds only them -- is dead code in that copy
+    // (the loops of the text are unrolled: mpcx_ufcx.cpp adds the pragmas): ND1 * BS1 accumulators live instead of N0 * N1
+    // (scalar P2: 330 -> ~80 VGPRs; P2^3: no 7 KB of scratch per thread), and a copy runs only for the rows the entity keeps
+    // in this block (the entities of a block are ordered by that set, so a wave takes the same copies together).
+    _Pragma("unroll")
+    for (int i = 0; i < ND0; ++i)
+    {
+      // one copy per local NODE row: its BS0 component rows come out of the same copy (component-diagonal forms: the same
+      // values, the structural zeros of the other components fold away at compile time) -- a third of the copies and of
+      // the instruction-cache footprint for the Taylor-Hood velocity block
+      const int rn = (m0[i] & DOF_MASK) * BS0;
+      if (rn < r0 || rn >= r1 || ((m0[i] >> MASK_SHIFT) & ((1 << BS0) - 1)) == ((1 << BS0) - 1))
+        continue;
+      double Ar[N0 * N1];
+      _Pragma("unroll")
+      for (int z = 0; z < BS0 * N1; ++z)
+        Ar[i * BS0 * N1 + z] = 0.0; // (the other rows stay unset: nothing reads them)
+      {
+        // the coordinates of THIS copy behind an empty asm: the copies must not share their geometry / basis-gradient
+        // temporaries (hoisted in front of the row tests they would all be live at once: 512 VGPRs + spills for scalar P2)
+        double cr[NV * 3];
+        _Pragma("unroll")
+        for (int z = 0; z < NV * 3; ++z)
+        {
+          cr[z] = cd[z];
+          asm volatile("" : "+v"(cr[z]));
+        }
+        const unsigned char perm = 0;
+        ufcx_rw::UFCX_FN(Ar, a.coeffs ? a.coeffs + e * a.cstride : (const double*)0, a.constants, cr, &lf, &perm, (void*)0);
+      }
+      _Pragma("unroll")
+      for (int k = 0; k < BS0; ++k)
+      {
+        if ((m0[i] >> (MASK_SHIFT + k)) & 1)
+          continue;
+        const int base = s_rowlo[rn + k - r0];
+        _Pragma("unroll")
+        for (int j = 0; j < ND1; ++j)
+        {
+          const int off = (int)((ow[(i * ND1 + j) >> 2] >> (8 * ((i * ND1 + j) & 3))) & 0xff) * BS1;
+          _Pragma("unroll")
+          for (int q = 0; q < BS1; ++q)
+          {
+            if ((m1[j] >> (MASK_SHIFT + q)) & 1)
+              continue;
+            const double v = Ar[(i * BS0 + k) * N1 + j * BS1 + q];
+            if (v != 0.0)
+              __hip_atomic_fetch_add(s_vals + base + off + q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+    }
+#else
     double Ae[N0 * N1];
     UFCX_UNROLL
     for (int i = 0; i < N0 * N1; ++i)
@@ -499,6 +554,7 @@ extern "C" __global__ void __launch_bounds__(UFCX_RB_THREADS) ufcx_matrix_rowblo
         }
       }
     }
+#endif // UFCX_ROWWISE
 #if UFCX_PIPE
     cur = nxt;
 #endif
@@ -1653,7 +1709,39 @@ extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
     src += "#pragma clang fp reciprocal(on)\n";
   else if (fp == "fast") // + reassociation, and (compile options below) no NaN / infinity / signed-zero semantics: what -ffast-math
     src += "#pragma clang fp reciprocal(on) reassociate(on)\n"; // gives an FFCx kernel built with cffi_extra_compile_args=["-Ofast"]
-  src += user;
+  // row-wise mode of the row-block matrix kernel (element tensors of more than 36 entries, no dof transformations): the text's
+  // loops must be unrolled so that the entries of the tensor become independent values and the unused rows of a copy are
+  // eliminated -- a `#pragma unroll` in front of every for statement of the text (MPCX_UFCX_ROWWISE=0 switches the mode off)
+  const int tensor_size = d->rank == 2 ? d->nd0 * d->bs0 * d->nd1 * d->bs1 : 0;
+  const bool has_tr = (d->transform0_name && d->transform0_name[0]) || (d->transform1_name && d->transform1_name[0]);
+  const char* rw_env = std::getenv("MPCX_UFCX_ROWWISE");
+  // (simplices, up to 30 x 30 -- Taylor-Hood velocity block: the copies of larger / tensor-product elements, 27 x 27 for Q2
+  // hexahedra with the geometry inside a 27-point loop, take minutes to compile and gain less)
+  const bool rowwise = d->rank == 2 && tensor_size > 36 && tensor_size <= 900 && d->nd0 * d->bs0 <= 30 && d->nv <= 4 && !has_tr
+                       && !(rw_env && rw_env[0] == '0');
+  if (rowwise)
+  {
+    std::string t;
+    t.reserve(user.size() + 4096);
+    for (size_t i = 0; i < user.size(); ++i)
+    {
+      if (user.compare(i, 3, "for") == 0 && (i == 0 || !ident_char(user[i - 1])) && i + 3 < user.size() && !ident_char(user[i + 3]))
+      {
+        size_t q = i + 3;
+        while (q < user.size() && (user[q] == ' ' || user[q] == '\t'))
+          ++q;
+        if (q < user.size() && user[q] == '(')
+          t += "_Pragma(\"unroll\") ";
+      }
+      t += user[i];
+    }
+    // a SECOND copy of the text, in a namespace of its own: the per-entity / plan / lifting kernels of this translation unit
+    // keep the text as it is (fully unrolled, a 900-entry tensor would be 900 live values there)
+    src += user;
+    src += "\nnamespace ufcx_rw {\n" + t + "\n}\n";
+  }
+  else
+    src += user;
   src += "\n#undef sin\n#undef cos\n#undef exp\n";
   src += "\n#pragma clang attribute pop\n";
   src += "#pragma clang force_cuda_host_device end\n";
@@ -1689,12 +1777,19 @@ extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
   // element tensors up to 36 entries (P1 scalar, P1 x P1 on triangles / tets, bs <= ...): 512 threads, 128 VGPRs;
   // up to 144 entries: fully unrolled at 256 threads (256 VGPRs); larger ones stay rolled in private memory
   const int size = d->rank == 2 ? d->nd0 * d->bs0 * d->nd1 * d->bs1 : d->nd0 * d->bs0;
-  const int rb_threads = (d->rank == 1 || size <= 36) ? 512 : 256;
+  // (row-wise copies: ~90-150 VGPRs instead of 300+: three waves per SIMD from two resident workgroups; MPCX_UFCX_RB_THREADS overrides)
+  // (measured, round 6: scalar P2 stiffness text 246^3: 256 threads 26.5 ms, 384 / 512 37 ms (the copies then spill); P1^3
+  // elasticity text (144 entries): 512 threads 1.61 ms, 384 1.96, whole tensor at 256 1.73)
+  // (few, short copies -- vector P1: 512 threads; ten or more copies -- P2: 256)
+  int rb_threads = (d->rank == 1 || size <= 36) ? 512 : ((rowwise && d->nd0 <= 4) ? 512 : 256);
+  if (const int t = env_int("MPCX_UFCX_RB_THREADS", 0); t >= 64 && t <= 1024 && t % 64 == 0)
+    rb_threads = t;
   const int small = size <= 144 ? 1 : 0;
   const int big = (d->rank == 2 && size > UFCX_BIG_ENTRIES) ? 1 : 0; // element tensor beyond the per-thread scratch limit
   std::vector<std::string> opts
       = {"--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-DUFCX_FN=" + fn_name, "-DUFCX_BIG=" + std::to_string(big),
          "-DUFCX_RB_THREADS=" + std::to_string(rb_threads), "-DUFCX_SMALL=" + std::to_string(small),
+         "-DUFCX_ROWWISE=" + std::to_string(rowwise ? 1 : 0),
          "-DUFCX_RANK=" + std::to_string(d->rank), "-DND0=" + std::to_string(d->nd0), "-DBS0=" + std::to_string(d->bs0),
          "-DND1=" + std::to_string(d->rank == 2 ? d->nd1 : 1), "-DBS1=" + std::to_string(d->rank == 2 ? d->bs1 : 1),
          "-DNV=" + std::to_string(d->nv), "-DUFCX_CUBE=" + std::to_string(cube ? 1 : 0),
@@ -1705,6 +1800,12 @@ extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
     opts.push_back("-DUFCX_T0=" + std::string(d->transform0_name));
   if (d->rank == 2 && d->transform1_name && d->transform1_name[0])
     opts.push_back("-DUFCX_T1=" + std::string(d->transform1_name));
+  if (rowwise)
+  {
+    // (the unrolled nests of a copy are large before the dead rows go: no size limit on the pragma)
+    opts.push_back("-mllvm");
+    opts.push_back("-pragma-unroll-threshold=1000000");
+  }
   if (fp == "fast" || fp == "finite")
   {
     opts.push_back("-fno-signed-zeros");

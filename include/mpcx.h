@@ -871,6 +871,56 @@ int64_t mpcx_cell_plan_num_slots(const mpcx_cell_plan_t* plan);
 int32_t mpcx_cell_plan_num_blocks(const mpcx_cell_plan_t* plan);
 void mpcx_cell_plan_destroy(mpcx_cell_plan_t* plan);
 
+/* The plans of the other workloads behind ONE call each, in device memory the library allocates (round 6; for callers without
+ * torch -- examples/mpcx_driver_blocks.cpp assembles BASELINE configs[2] and [4] with them).  All pointers DEVICE unless said
+ * otherwise; rowptr_host: the CSR offsets on the HOST; row_hints: HOST, preferred cuts (first row of every numbering tile) or NULL.
+ *
+ * mpcx_pairs_plan_*: matrix_pairs_kernel (plan.row_pairs == 2: scalar P2 stiffness, elasticity, the Taylor-Hood coupling blocks --
+ *   cell integrals of operators with a compact context, no coefficient): row ranges, the (entity, local row) pairs of every block
+ *   ordered by (local row, round-robin over the row dofs), ONE record per pair (mpcx_pair_records), the column-masked dofmap and the
+ *   per-entity contexts (mpcx_pair_context; x == NULL: none, the kernel then recomputes them per pair).  entities: cells of the
+ *   integral or NULL (entity e is cell e), borrowed for the plan's lifetime.  mpcx_pairs_plan_update_geometry recomputes the
+ *   contexts after the mesh moved.  _fill sets plan, pair_recs, pair_ctx, mdofmap1, algorithm.  -21: a field of a record overflows
+ *   (use mpcx_cell_plan_create), -10: the operator has no compact context.
+ * mpcx_nodeblock_plan_*: matrix_nodeblock_kernel (component-diagonal forms on blocked spaces, bs = 2 / 3, test space == trial space:
+ *   the Taylor-Hood velocity block): the per-cell plan with max_rows / max_nnz counted per NODE row (the kernel keeps one LDS value
+ *   per bs x bs block) + the slot masks (mpcx_diag_slot_mask).  _fill sets plan, mdofmap0 / 1, slot_mask, algorithm; block_vals stays
+ *   the caller's choice.  -21: the pattern is not made of whole blocks.
+ * mpcx_master_plan_*: the master contributions of the slave entities gathered by target position (mpcx_matrix_args_t::mpc_plan_*),
+ *   built on the device: mpcx_mpc_plan_device count -> scan -> fill -> stable sort by position -> run lengths.  diag != 0:
+ *   component-diagonal form.  _fill sets the mpc_plan_* fields and mpc_plan_group (slave_entities / n_slave_entities stay the
+ *   caller's). */
+typedef struct mpcx_pairs_plan mpcx_pairs_plan_t;
+int mpcx_pairs_plan_create(int32_t nrows, const mpcx_nnz_t* rowptr, const mpcx_nnz_t* rowptr_host, const int32_t* cols,
+                           int64_t n_entities, const int32_t* entities, int64_t num_cells, const int32_t* dofmap0, int32_t nd0,
+                           int32_t bs0, const int8_t* bc0, const int8_t* is_slave0, const int32_t* dofmap1, int32_t nd1, int32_t bs1,
+                           const int8_t* bc1, const int8_t* is_slave1, int32_t max_rows, int32_t max_nnz, const int32_t* row_hints,
+                           int32_t n_hints, const mpcx_kernel_t* kernel, const double* x, const int32_t* x_dofmap, int32_t nv,
+                           void* stream, mpcx_pairs_plan_t** plan);
+int mpcx_pairs_plan_update_geometry(mpcx_pairs_plan_t* plan, const mpcx_kernel_t* kernel, const double* x, const int32_t* x_dofmap,
+                                    int32_t nv, void* stream);
+int mpcx_pairs_plan_fill(const mpcx_pairs_plan_t* plan, mpcx_matrix_args_t* args);
+int64_t mpcx_pairs_plan_num_pairs(const mpcx_pairs_plan_t* plan);
+int32_t mpcx_pairs_plan_num_blocks(const mpcx_pairs_plan_t* plan);
+void mpcx_pairs_plan_destroy(mpcx_pairs_plan_t* plan);
+typedef struct mpcx_nodeblock_plan mpcx_nodeblock_plan_t;
+int mpcx_nodeblock_plan_create(int32_t nrows, const mpcx_nnz_t* rowptr, const mpcx_nnz_t* rowptr_host, const int32_t* cols,
+                               int64_t n_entities, int32_t estride, const int32_t* entities, int64_t num_cells, const int32_t* dofmap,
+                               int32_t nd, int32_t bs, const int8_t* bc, const int8_t* is_slave, int32_t max_rows, int32_t max_nnz,
+                               const int32_t* row_hints, int32_t n_hints, void* stream, mpcx_nodeblock_plan_t** plan);
+int mpcx_nodeblock_plan_fill(const mpcx_nodeblock_plan_t* plan, mpcx_matrix_args_t* args);
+void mpcx_nodeblock_plan_destroy(mpcx_nodeblock_plan_t* plan);
+typedef struct mpcx_master_plan mpcx_master_plan_t;
+int mpcx_master_plan_create(int64_t n_slave_entities, const int32_t* slave_entities, int32_t estride, const int32_t* entities0,
+                            const int32_t* entities1, const int32_t* dofmap0, int32_t nd0, int32_t bs0, const int32_t* dofmap1,
+                            int32_t nd1, int32_t bs1, const int8_t* bc0, const int8_t* bc1, const mpcx_mpc_t* mpc0,
+                            const mpcx_mpc_t* mpc1, const mpcx_nnz_t* rowptr, const int32_t* cols, int32_t diag, void* stream,
+                            mpcx_master_plan_t** plan);
+int mpcx_master_plan_fill(const mpcx_master_plan_t* plan, mpcx_matrix_args_t* args);
+int64_t mpcx_master_plan_num_targets(const mpcx_master_plan_t* plan);
+int64_t mpcx_master_plan_num_tuples(const mpcx_master_plan_t* plan);
+void mpcx_master_plan_destroy(mpcx_master_plan_t* plan);
+
 /* Row-block plan for MPCX_ALG_ROWBLOCK: contiguous row ranges with at most
  * max_rows rows / max_nnz nonzeros, and for each block the entities whose
  * test-space cell has a dof in it.  `row_hints` (sorted row indices, may be

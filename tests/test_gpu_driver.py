@@ -215,3 +215,97 @@ def test_driver_binary_links_only_the_library_and_hip():
     libs = [ln.split()[0] for ln in out.splitlines() if "=>" in ln or ln.strip().startswith("/")]
     assert any(name.startswith("libmpcx.so") for name in libs) and any(name.startswith("libamdhip64") for name in libs)
     assert not any("torch" in name or "python" in name for name in libs), libs
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Round 6: ``dolfinx_mpc_amd/mpcx_driver_blocks`` (examples/mpcx_driver_blocks.cpp) -- the other workloads behind the C ABI
+# alone: pair-record, node-block, per-cell and master-contribution plans each from ONE library call (mpcx_pairs_plan_create,
+# mpcx_nodeblock_plan_create, mpcx_cell_plan_create, mpcx_master_plan_create), blocks over one or two spaces.
+# ---------------------------------------------------------------------------------------------------------
+DRIVER_BLOCKS = os.path.join(ROOT, "dolfinx_mpc_amd", "mpcx_driver_blocks")
+
+
+def _space_arrays(k, V, raw, bcs):
+    markers = np.zeros(V.num_dofs, dtype=np.int8)
+    values = np.zeros(V.num_dofs, dtype=np.float64)
+    for bc in bcs:
+        if V.contains(bc.function_space):
+            bc.mark_dofs(markers)
+            bc.set(values, None, 1.0)
+    sl, ms, co, ow, off = raw
+    p = f"s{k}"
+    return {p + "_shape": np.array([V.element_ndofs, V.dofmap.bs, V.num_dofs], dtype=np.int32),
+            p + "_dofmap": V.dofmap.list.astype(np.int32).reshape(-1), p + "_slaves": np.asarray(sl, np.int32),
+            p + "_masters": np.asarray(ms, np.int64), p + "_coeffs": np.asarray(co, np.float64), p + "_owners": np.asarray(ow, np.int32),
+            p + "_offsets": np.asarray(off, np.int32), p + "_bc_markers": markers, p + "_bc_values": values}
+
+
+def _vector_arrays(k, space, form, rows):
+    from dolfinx_mpc_amd.quadrature import lagrange_basis
+
+    integ = form.integrals[0]
+    kk = integ.kernel
+    d = {f"v{k}_space": np.array([space, rows], dtype=np.int32)}
+    d.update(_kernel_arrays(f"v{k}", integ))
+    if kk.degree == 2:
+        d[f"v{k}_qphi"] = lagrange_basis(form.mesh.cell_name, 2, kk.qpts).reshape(-1)
+    return d
+
+
+def _run_blocks(tmp_path, arrays):
+    assert os.path.exists(DRIVER_BLOCKS), "mpcx_driver_blocks is built by __graft_entry__.build() (make -C dolfinx_mpc_amd/csrc)"
+    pin, pout = str(tmp_path / "problem.bin"), str(tmp_path / "result.bin")
+    write_bundle(pin, arrays)
+    run = subprocess.run([DRIVER_BLOCKS, pin, pout, "2"], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    return read_bundle(pout), run.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [1, 0], ids=["pair records", "per-cell row blocks"])
+def test_blocks_driver_config5_p2_poisson(oracle, tmp_path, kind):
+    """BASELINE configs[4] at test size (scalar P2, periodic + Dirichlet walls) without Python: pattern, pair-record plan,
+    device master plan, owner-computes vector -- against the oracle (pattern bit for bit, values 1e-12)"""
+    case = case_cube_periodic(6, 2, 0.0, reorder=(2, 2, 2))
+    V = case.V
+    arrays = {"x": V.mesh.geometry.x.reshape(-1), "cells": V.mesh.geometry.dofmap.astype(np.int32).reshape(-1)}
+    arrays.update(_space_arrays(0, V, case.raw, case.bcs))
+    arrays.update({"b0_spaces": np.array([0, 0, kind], dtype=np.int32), "b0_params": np.array([96, 4608], dtype=np.int32)})
+    arrays.update(_kernel_arrays("b0", case.a.integrals[0]))
+    arrays.update(_vector_arrays(0, 0, case.L, 1024))
+    res, log = _run_blocks(tmp_path, arrays)
+    ref = oracle_outputs(oracle, case)
+    refA = ref["A"].tocsr()
+    refA.sort_indices()
+    assert np.array_equal(res["A0_rowptr"], refA.indptr) and np.array_equal(res["A0_cols"], refA.indices)
+    assert abs(res["A0_vals"] - refA.data).max() <= 1e-12 * abs(refA.data).max()
+    assert abs(res["b0"] - ref["b"]).max() <= 1e-12 * max(1.0, abs(ref["b"]).max())
+
+
+@pytest.mark.gpu
+def test_blocks_driver_config3_taylor_hood(oracle, tmp_path):
+    """the Taylor-Hood blocks of BASELINE configs[2] at test size without Python: a00 through the node-block plan (CSR values),
+    a01 / a10 through pair records (rectangular, two constraints), b0 -- against the oracle's nest assembly"""
+    from problems import empty_raw, stokes_slip_problem
+
+    po = oracle
+    V, Q, bcs, raw_v, forms, L0 = stokes_slip_problem(3, 3)
+    arrays = {"x": V.mesh.geometry.x.reshape(-1), "cells": V.mesh.geometry.dofmap.astype(np.int32).reshape(-1)}
+    arrays.update(_space_arrays(0, V, raw_v, bcs))
+    arrays.update(_space_arrays(1, Q, empty_raw(), bcs))
+    for k, ((i, j), kind, prm) in enumerate((((0, 0), 2, (96, 4608)), ((0, 1), 1, (96, 2304)), ((1, 0), 1, (96, 2304)))):
+        arrays[f"b{k}_spaces"] = np.array([i, j, kind], dtype=np.int32)
+        arrays[f"b{k}_params"] = np.array(prm, dtype=np.int32)
+        arrays.update(_kernel_arrays(f"b{k}", forms[(i, j)].integrals[0]))
+    arrays.update(_vector_arrays(0, 0, L0, 1536))
+    res, log = _run_blocks(tmp_path, arrays)
+    mv = po.OracleMPC.from_raw(V, *raw_v)
+    mq = po.OracleMPC.from_raw(Q, *empty_raw())
+    mpcs = [mv, mq]
+    for k, (i, j) in enumerate(((0, 0), (0, 1), (1, 0))):
+        ref = po.assemble_matrix(forms[(i, j)], mpcs[i], mpcs[j], bcs=bcs).tocsr()
+        ref.sort_indices()
+        assert np.array_equal(res[f"A{k}_rowptr"], ref.indptr) and np.array_equal(res[f"A{k}_cols"], ref.indices), (i, j)
+        assert abs(res[f"A{k}_vals"] - ref.data).max() <= 1e-12 * max(1.0, abs(ref.data).max()), (i, j)
+    b0 = po.assemble_vector(L0, mv)
+    assert abs(res["b0"] - b0).max() <= 1e-12 * max(1.0, abs(b0).max())

@@ -93,7 +93,24 @@ def main():
     for _ in range(3):
         both()
     torch.cuda.synchronize()
-    arms = [("matrix alone", mat, {"MPCX_CORUN": "0"}), ("vector alone", vec, {"MPCX_CORUN": "0"}),
+    big = torch.empty(1 << 28, dtype=torch.float64, device="cuda")
+    big2 = torch.empty_like(big)
+    small = torch.empty(1 << 20, dtype=torch.float64, device="cuda")
+
+    def copy():
+        big2.copy_(big)
+
+    def light():
+        for _ in range(50):
+            small.add_(1.0)
+
+    try:
+        r = subprocess.run(["rocm-smi", "--showmaxpower", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=20)
+        print("# rocm-smi --showmaxpower:", r.stdout.strip()[:400], flush=True)
+    except Exception as e:  # noqa: BLE001
+        print("# rocm-smi --showmaxpower failed:", e, flush=True)
+    arms = [("device copy 2 GiB (HBM streaming only)", copy, {"MPCX_CORUN": "0"}), ("tiny kernels (launch-bound)", light, {"MPCX_CORUN": "0"}),
+            ("matrix alone", mat, {"MPCX_CORUN": "0"}), ("vector alone", vec, {"MPCX_CORUN": "0"}),
             ("both, two streams", both, {"MPCX_CORUN": "0"}),
             ("both, matrix capped (co-resident)", both, {"MPCX_CORUN": "1", "MPCX_CORUN_FRAC": "0.999", "MPCX_CORUN_MATRIX_WGS": "3"})]
     av = sys.modules["dolfinx_mpc_amd.assemble_vector"]
