@@ -751,6 +751,8 @@ def main():
         if entry == "atomic" and f.integrals[0].kernel.form == 100:
             entry = "ufcx_atomic"
         kname = dispatch.FUNCTION[("vector", entry)]  # (owner-computes entries: + spill-reduce and slave-row kernels, timed together)
+        if entry == "ownblock" and vargs.kernel.vphi and os.environ.get("MPCX_AFFINE_OWNBLOCK", "1") != "0":
+            kname = "vector_ownblock_affine_kernel"  # integrand function affine in x: the gather / LDS-add instance (round 6)
         k = {"kernel": f"{kname}[{label}]", "call": f"assemble_vector[{label}]", "launch_ms": tk,
              "algorithmic_bytes": int(nbytes), "pmc_name": kname}
         k["fp64_flops"] = algorithmic_flops(f.integrals[0], V0) * f.integrals[0].num_entities

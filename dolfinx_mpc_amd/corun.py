@@ -67,6 +67,7 @@ def note_matrix_call(A):
     """called by assemble_matrix before it enqueues: returns True if this assembly should be launched in two parts"""
     m = mode()
     if m in ("0", "off", "no"):
+        _last_matrix.clear()
         return False
     dev = getattr(A.device, "index", 0)
     met = getattr(A, "_corun_met", None)
@@ -79,8 +80,15 @@ def note_matrix_call(A):
 
 def note_vector_call(device):
     """called by assemble_vector before it enqueues: is a matrix assembly of this device still in flight?"""
+    m = mode()
+    if m in ("0", "off", "no"):
+        return False  # (nothing is looked at: an event query is not allowed while a stream is being captured into a graph)
+    if m in ("1", "on", "always"):
+        return True
+    import torch
+
     A = _last_matrix.get(getattr(device, "index", 0))
-    if A is None:
+    if A is None or torch.cuda.is_current_stream_capturing():
         return False
     ev = getattr(A, "_ready", None)
     try:
@@ -89,7 +97,7 @@ def note_vector_call(device):
         running = False
     if running:
         A._corun_met = True
-    return running or mode() in ("1", "on", "always")
+    return running
 
 
 def splittable(a) -> bool:

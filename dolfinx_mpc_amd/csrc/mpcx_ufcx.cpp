@@ -1717,8 +1717,8 @@ extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
   const char* rw_env = std::getenv("MPCX_UFCX_ROWWISE");
   // (simplices, up to 30 x 30 -- Taylor-Hood velocity block: the copies of larger / tensor-product elements, 27 x 27 for Q2
   // hexahedra with the geometry inside a 27-point loop, take minutes to compile and gain less)
-  const bool rowwise = d->rank == 2 && tensor_size > 36 && tensor_size <= 900 && d->nd0 * d->bs0 <= 30 && d->nv <= 4 && !has_tr
-                       && !(rw_env && rw_env[0] == '0');
+  const bool rowwise = d->rank == 2 && tensor_size > 36 && tensor_size <= 900 && d->nd0 <= 10 && d->nd1 <= 10 && d->nd0 * d->bs0 <= 30
+                       && d->nv <= 4 && !has_tr && !(rw_env && rw_env[0] == '0');
   if (rowwise)
   {
     std::string t;
@@ -1731,7 +1731,32 @@ extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
         while (q < user.size() && (user[q] == ' ' || user[q] == '\t'))
           ++q;
         if (q < user.size() && user[q] == '(')
-          t += "_Pragma(\"unroll\") ";
+        {
+          // only loops with a literal bound of at most 16 trips (`...; X < N; ...`): the dof / component / geometry loops of an
+          // element of up to ten nodes -- a 45-point quadrature loop stays rolled (it does not index the tensor)
+          const size_t semi = user.find(';', q);
+          const size_t lt = semi == std::string::npos ? std::string::npos : user.find('<', semi);
+          const size_t semi2 = semi == std::string::npos ? std::string::npos : user.find(';', semi + 1);
+          long bound = -1;
+          if (lt != std::string::npos && semi2 != std::string::npos && lt < semi2)
+          {
+            size_t b = lt + 1;
+            if (b < user.size() && user[b] == '=')
+              ++b;
+            while (b < user.size() && user[b] == ' ')
+              ++b;
+            size_t e = b;
+            while (e < user.size() && user[e] >= '0' && user[e] <= '9')
+              ++e;
+            size_t f = e;
+            while (f < user.size() && user[f] == ' ')
+              ++f;
+            if (e > b && f == semi2)
+              bound = std::atol(user.substr(b, e - b).c_str());
+          }
+          if (bound >= 0 && bound <= 16)
+            t += "_Pragma(\"unroll\") ";
+        }
       }
       t += user[i];
     }

@@ -278,6 +278,27 @@ def test_small_cases_vector_kernel_variants(oracle, make, env, monkeypatch):
             _close(out[k], ref[k], RTOL_B, f"{case.name} {k} [{env}]")
 
 
+@pytest.mark.parametrize("env", ["MPCX_VERTEX_SOURCE=0", "MPCX_AFFINE_OWNBLOCK=0", "MPCX_AFFINE_THREADS=256"])
+@pytest.mark.parametrize("make", CASES, ids=[f"case{i}" for i in range(len(CASES))])
+def test_affine_source_paths(oracle, make, env, monkeypatch):
+    """Source forms whose integrand function is affine in x (constant / linear: the body forces of the Stokes, contact and
+    elasticity cases): round 6 evaluates them from the rule's vertex moments (mpcx_kernel_t::vphi) -- inside the general
+    kernels and, with an owner-computes plan, in vector_ownblock_affine_kernel.  With the owner-computes plan forced: the rule
+    walked (MPCX_VERTEX_SOURCE=0), the moments inside the general instance (MPCX_AFFINE_OWNBLOCK=0), the dedicated kernel with
+    another thread count -- all against the oracle, which always walks the rule (cpp/assemble_vector.cpp:65-90)."""
+    case = make()
+    if case.L is None:
+        pytest.skip("no linear form")
+    k, v = env.split("=")
+    monkeypatch.setenv(k, v)
+    monkeypatch.setenv("MPCX_VECTOR_OWNER", "1")
+    ref = oracle_outputs(oracle, case)
+    out = product_outputs(case, algorithm="rowblock")
+    for key in ("b", "b_lifted"):
+        if key in ref:
+            _close(out[key], ref[key], RTOL_B, f"{case.name} {key}")
+
+
 @pytest.mark.parametrize("env", ["MPCX_VCUBE_OWNER=0", "MPCX_VCUBE_OWNER=1", "MPCX_VCUBE_ROWS=256", "MPCX_CLUSTER_DETECT=consecutive",
                                  "MPCX_CUBE_NARROW=0", "MPCX_CUBE_MAX_ROWS=64", "MPCX_OWNER_PLAN=torch"])
 @pytest.mark.parametrize("n,reorder,bc", [(4, None, 0.0), (6, (2, 2, 2), 2.3), (9, (4, 4, 4), 0.0)])
