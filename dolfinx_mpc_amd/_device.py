@@ -143,7 +143,7 @@ def space_device(V: FunctionSpace):
 _ufcx_handles = {}
 # switches read by mpcx_ufcx_compile (csrc/mpcx_ufcx.cpp): part of the handle cache key
 _UFCX_COMPILE_ENV = ("MPCX_UFCX_FP", "MPCX_UFCX_LIBM", "MPCX_UFCX_CUBE_THREADS", "MPCX_UFCX_CUBE_PIPE", "MPCX_UFCX_CUBE_WAVES",
-                     "MPCX_UFCX_VCUBE_THREADS", "MPCX_UFCX_VCUBE_WAVES")
+                     "MPCX_UFCX_VCUBE_THREADS", "MPCX_UFCX_VCUBE_WAVES", "MPCX_UFCX_ROWWISE", "MPCX_UFCX_RB_THREADS")
 
 
 def ufcx_compile(k, form: Form):

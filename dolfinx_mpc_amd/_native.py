@@ -258,6 +258,7 @@ EXPORTS = [
     "mpcx_cluster_plan_part",
     "mpcx_cluster_plan_destroy",
     "mpcx_ufcx_big_tensor",
+    "mpcx_ufcx_rowwise",
     "mpcx_cell_plan_create",
     "mpcx_cell_plan_fill",
     "mpcx_cell_plan_num_slots",
@@ -505,6 +506,8 @@ def lib() -> C.CDLL:
     L.mpcx_cell_plan_create.restype = C.c_int
     L.mpcx_ufcx_big_tensor.argtypes = [vp]
     L.mpcx_ufcx_big_tensor.restype = C.c_int
+    L.mpcx_ufcx_rowwise.argtypes = [vp]
+    L.mpcx_ufcx_rowwise.restype = C.c_int
     L.mpcx_cell_plan_fill.argtypes = [vp, vp]
     L.mpcx_cell_plan_fill.restype = C.c_int
     L.mpcx_cell_plan_num_slots.argtypes = [vp]

@@ -1205,6 +1205,23 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
                     u.second = v
                 keep += [ck]
                 return a, keep
+            if name == "ufcx_pairs":
+                # imported text with row-wise copies (csrc/mpcx_ufcx.cpp): pair records, no cached context
+                if not _native.lib().mpcx_ufcx_rowwise(idv["kernel"].ufcx) or os.environ.get("MPCX_UFCX_PAIRS", "1") == "0":
+                    continue
+                try:
+                    plan, pk, _info = _pairs_plan(A, form, i, V0, V1, bc0, bc1, mpc0, mpc1)
+                except _native.PlanNotRepresentable:
+                    continue
+                if pk[3] is not None:  # (dictionary-compressed records, MPCX_PAIRS_DICT=1: the imported-text kernel reads full ones)
+                    continue
+                md1 = _masked_dofmap(form, V1, bc1, mpc1, 1)
+                a.plan = plan
+                a.pair_recs, a.pair_ctx, a.pair_dict = pk[2].data_ptr(), None, None
+                a.mdofmap1 = md1.data_ptr()
+                a.kernel_name = name
+                keep += [pk, md1]
+                break
             if name == "pairs":
                 # pair records + cached contexts (csrc/mpcx_pairs.hip): nothing else is read per entity
                 try:

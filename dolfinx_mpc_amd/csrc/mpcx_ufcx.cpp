@@ -563,6 +563,142 @@ extern "C" __global__ void __launch_bounds__(UFCX_RB_THREADS) ufcx_matrix_rowblo
   MPCX_WRITE_OUT(a, nnz0, nnzb, s_vals, tid, NT);
 }
 
+#if UFCX_ROWWISE
+// Pair records for imported text (round 6; plan.row_pairs == 2, the records of mpcx_pair_records, no cached context -- a
+// black-box function has none): the unit of work is one (entity, local NODE row) pair whose rows lie in the block, read from
+// ONE coalesced record; the pairs of a block are ordered by local row, so a wave runs ONE of the row-wise copies of the text
+// (ufcx_matrix_rowblock_kernel above runs, per visit of an entity, the copies of all rows the entity keeps, and a wave the
+// union over its lanes), no lane is masked, and masked dofmaps / offset tables are not read.  The geometry is gathered per pair.
+#define UFCX_PW (1 + (ND1 + 2 + 3) / 4)
+extern "C" __global__ void __launch_bounds__(UFCX_RB_THREADS) ufcx_matrix_pairs_kernel(mpcx_matrix_args_t a)
+{
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int NT = blockDim.x;
+  const int nb = a.plan.num_blocks;
+  const int per = (nb + 7) >> 3;
+  const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (b >= nb)
+    return;
+  const int tid = threadIdx.x;
+  const int r0 = a.plan.block_row0[b], r1 = a.plan.block_row0[b + 1];
+  const long long nnz0 = a.rowptr[r0];
+  const int nnzb = (int)(a.rowptr[r1] - nnz0);
+  double* s_vals = (double*)smem;
+  int* s_rowlo = (int*)(s_vals + a.plan.max_nnz); // BS0 > 1 only
+  for (int i = tid; i < nnzb; i += NT)
+    s_vals[i] = 0.0;
+#if BS0 > 1
+  for (int rl = tid; rl <= r1 - r0; rl += NT)
+    s_rowlo[rl] = (int)(a.rowptr[r0 + rl] - nnz0);
+#endif
+  __syncthreads();
+  const long long e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  const unsigned* __restrict__ recs = a.pair_recs;
+  for (long long t = e0 + tid; t < e1; t += NT)
+  {
+    unsigned w[UFCX_PW];
+#if UFCX_PW == 4
+    {
+      const uint4 v = *(const uint4*)(recs + t * 4);
+      w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
+    }
+#else
+#pragma unroll
+    for (int q = 0; q < UFCX_PW; ++q)
+      w[q] = recs[t * UFCX_PW + q];
+#endif
+    const unsigned w0 = w[0];
+    const long long e = w0 & ((1u << 27) - 1);
+    const int irow = (int)((w0 >> 27) & 15u);
+    const unsigned slot = w[1] & 0xffffu;
+#if BS0 == 1
+    if (slot == 0xffffu)
+      continue; // Dirichlet / slave row: stays zero
+#endif
+    const long long cell = a.entities ? a.entities[e * a.estride] : e;
+    double cd[NV * 3];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+    {
+      const long long n = a.x_dofmap[cell * NV + v];
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        cd[3 * v + k] = a.x[3 * n + k];
+    }
+    unsigned cm0 = 0, cm1 = 0; // bit j * BS1 + q (low / high 32): column (j, q) is masked
+    if (w0 >> 31)
+    {
+      const long long cell1 = a.entities1 ? a.entities1[e * a.estride] : e;
+#pragma unroll
+      for (int j = 0; j < ND1; ++j)
+      {
+        const unsigned m = (unsigned)a.mdofmap1[cell1 * ND1 + j] >> MASK_SHIFT;
+#pragma unroll
+        for (int q = 0; q < BS1; ++q)
+        {
+          const int bit = j * BS1 + q;
+          if (bit < 32)
+            cm0 |= ((m >> q) & 1u) << bit;
+          else
+            cm1 |= ((m >> q) & 1u) << (bit - 32);
+        }
+      }
+    }
+    const int lf = 0;
+    _Pragma("unroll")
+    for (int I = 0; I < ND0; ++I)
+    {
+      if (irow != I)
+        continue;
+      double Ar[N0 * N1];
+      _Pragma("unroll")
+      for (int z = 0; z < BS0 * N1; ++z)
+        Ar[I * BS0 * N1 + z] = 0.0;
+      {
+        double cr[NV * 3];
+        _Pragma("unroll")
+        for (int z = 0; z < NV * 3; ++z)
+        {
+          cr[z] = cd[z];
+          asm volatile("" : "+v"(cr[z]));
+        }
+        const unsigned char perm = 0;
+        ufcx_rw::UFCX_FN(Ar, a.coeffs ? a.coeffs + e * a.cstride : (const double*)0, a.constants, cr, &lf, &perm, (void*)0);
+      }
+      _Pragma("unroll")
+      for (int k = 0; k < BS0; ++k)
+      {
+        int base;
+#if BS0 == 1
+        base = (int)slot;
+#else
+        if ((slot >> (13 + k)) & 1u)
+          continue;
+        base = s_rowlo[(int)(slot & 0x1fffu) * BS0 + k];
+#endif
+        _Pragma("unroll")
+        for (int j = 0; j < ND1; ++j)
+        {
+          const int off = (int)((w[(6 + j) >> 2] >> (8 * ((6 + j) & 3))) & 0xffu) * BS1;
+          _Pragma("unroll")
+          for (int q = 0; q < BS1; ++q)
+          {
+            const int bit = j * BS1 + q;
+            if (bit < 32 ? ((cm0 >> bit) & 1u) : ((cm1 >> (bit - 32)) & 1u))
+              continue;
+            const double v = Ar[(I * BS0 + k) * N1 + j * BS1 + q];
+            if (v != 0.0)
+              __hip_atomic_fetch_add(s_vals + base + off + q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  MPCX_WRITE_OUT(a, nnz0, nnzb, s_vals, tid, NT);
+}
+#endif // UFCX_ROWWISE
+
 // Master contributions from the plan gathered by target position (mpcx_mpc_plan_device): G lanes share one
 // target and stride over its tuples; a lane tabulates an entity once for its consecutive tuples (the plan
 // lists a target's tuples by entity).  No device atomics, no CSR searches.
@@ -1106,6 +1242,8 @@ struct UfcxKernel
   hipFunction_t matrix = nullptr, matrix_mpc = nullptr, lifting = nullptr, vector = nullptr;
   hipFunction_t matrix_rowblock = nullptr, matrix_mpc_plan = nullptr, vector_rowblock = nullptr, vector_mpc = nullptr;
   hipFunction_t slave_tensors = nullptr, matrix_mpc_gather = nullptr;
+  bool rowwise = false;                 // row-wise copies of the text compiled in: ufcx_matrix_pairs_kernel exists
+  hipFunction_t matrix_pairs = nullptr;
   bool t0 = false, t1 = false; // compiled with dof transformations: the calls need cell_info0 / cell_info1
   // scalar P1 on tetrahedra: the cluster kernels (MPCX_ALG_CUBE)
   bool cube = false;
@@ -1173,6 +1311,9 @@ int ensure_loaded(UfcxKernel* k)
       return rc;
     if (int rc = get(&k->matrix_rowblock, "ufcx_matrix_rowblock_kernel"))
       return rc;
+    if (k->rowwise)
+      if (int rc = get(&k->matrix_pairs, "ufcx_matrix_pairs_kernel"))
+        return rc;
     if (int rc = get(&k->matrix_mpc_plan, "ufcx_matrix_mpc_plan_kernel"))
       return rc;
     if (int rc = get(&k->slave_tensors, "ufcx_slave_tensors_kernel"))
@@ -1591,6 +1732,8 @@ int launch_blocks(hipFunction_t f, int num_blocks, int threads, size_t lds, cons
 }
 } // namespace
 
+extern "C" int mpcx_ufcx_rowwise(void* handle) { return handle && static_cast<UfcxKernel*>(handle)->rowwise ? 1 : 0; }
+
 extern "C" int mpcx_ufcx_resolve(const char* source, const char* name, char* out, int32_t out_len)
 {
   if (!source || !out || out_len <= 0)
@@ -1840,6 +1983,7 @@ extern "C" void* mpcx_ufcx_compile(const mpcx_ufcx_desc_t* d)
   {
     auto* k = new UfcxKernel;
     k->rb_threads = rb_threads;
+    k->rowwise = rowwise;
     k->cube = cube && !big;
     k->cube_threads = d->rank == 2 ? cube_threads : vcube_threads;
     k->big = big != 0;
@@ -1988,6 +2132,31 @@ int launch_matrix_ufcx(const mpcx_matrix_args_t& a)
     }
     if (int rc = launch_blocks(a.cube_rec_bytes == 64 ? k->matrix_cube_narrow : k->matrix_cube_wide, a.plan.num_blocks,
                                k->cube_threads, lds, a, a.stream))
+      return rc;
+  }
+  else if (alg == MPCX_ALG_ROWBLOCK && a.n_entities > 0 && a.plan.row_pairs == 2)
+  {
+    // pair records (mpcx_pair_records; no cached contexts): the row-wise copies of the text, one pair per lane
+    if (!k->rowwise || !k->matrix_pairs)
+    {
+      mpcx_set_error("mpcx_assemble_matrix (UFCx, pair records): this kernel was not compiled with row-wise copies (element tensors of "
+                     "37 .. 900 entries on simplices of up to ten nodes, no dof transformations; mpcx_ufcx_rowwise tells)");
+      return -8;
+    }
+    if (a.plan.num_blocks <= 0 || !a.pair_recs || !a.plan.block_row0 || !a.plan.block_ent_off || a.estride != 1 || a.pair_dict
+        || !a.mdofmap1)
+    {
+      mpcx_set_error("mpcx_assemble_matrix (UFCx, pair records): needs full records (mpcx_pair_records, no dictionary), the row "
+                     "blocks, the column-masked dofmap (mdofmap1) and a cell integral");
+      return -5;
+    }
+    const size_t lds = size_t(a.plan.max_nnz) * 8 + (a.bs0 > 1 ? size_t(a.plan.max_rows + 1) * 4 : 0);
+    if (lds > 160 * 1024)
+    {
+      mpcx_set_error("mpcx_assemble_matrix: row-block plan exceeds 160 KiB of LDS");
+      return -4;
+    }
+    if (int rc = launch_blocks(k->matrix_pairs, a.plan.num_blocks, k->rb_threads, lds, a, a.stream))
       return rc;
   }
   else if (alg == MPCX_ALG_ROWBLOCK && a.n_entities > 0)

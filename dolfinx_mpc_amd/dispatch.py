@@ -110,6 +110,16 @@ MATRIX: List[Kernel] = [
            "ufcx_matrix_cube_kernel (hipRTC): the imported tabulate_tensor called six times per cluster, the tensors summed per "
            "vertex pair in registers (no symmetry assumed), 46 scatter-adds per 6 cells; clusters whose cells the mesh lists in "
            "another vertex order, and cells in no cluster, through ufcx_rowblock"),
+    Kernel("ufcx_pairs",
+           lambda c: (c.form == FORM_UFCX and c.cell_integral and not c.has_transforms and c.nd0 <= 10 and c.nd1 <= 10
+                      and 36 < c.nd0 * c.bs0 * c.nd1 * c.bs1 <= 900 and c.nd0 * c.bs0 <= 30 and c.bs0 <= 3),
+           lambda c: c.bs0 == 1 and c.bs1 == 1,
+           "ufcx_matrix_pairs_kernel (hipRTC, round 6): pair records for imported text -- one (entity, node row) pair per lane, a "
+           "wave runs ONE row-wise copy of the text (the unused rows of the tensor are dead code in a copy); needs a kernel compiled "
+           "with row-wise copies (mpcx_ufcx_rowwise).  Default for scalar spaces: P2 stiffness text 246^3 21.2 ms vs 26.7 ms "
+           "(row-wise copies inside ufcx_rowblock) vs 42 ms (whole tensor per visit); NOT for blocked spaces: P2^3 stiffness text "
+           "128^3 89 ms vs 24 ms, P1^3 elasticity text 1.90 vs 1.46 ms (the geometry is gathered per pair, a pair carries bs rows "
+           "of bs x the columns), p div(v) 2.5 vs 2.8 ms, div(u) q 2.9 vs 2.0 ms"),
     Kernel("ufcx_rowblock", lambda c: c.form == FORM_UFCX, lambda c: True,
            "imported tabulate_tensor inside the LDS row-block kernel (hipRTC); config 2 with tests/ufcx/laplace_p1_tet.c: 2.32 ms "
            "vs 1.75 ms built-in, vs ~50 ms thread-per-entity atomics"),
@@ -185,7 +195,7 @@ FUNCTION = {
     ("matrix", "p2_cube"): "matrix_p2_cube_kernel", ("matrix", "hex_cube"): "matrix_hex_kernel", ("vector", "hex_own"): "vector_hex_own_kernel",
     ("matrix", "ufcx_cube"): "ufcx_matrix_cube_narrow_kernel", ("vector", "ufcx_cube_own"): "ufcx_vector_cube_own_kernel",
     ("matrix", "cube"): "matrix_cube_kernel", ("matrix", "cube_el"): "matrix_cube_elasticity_rowpair_kernel", ("matrix", "ufcx_rowblock"): "ufcx_matrix_rowblock_kernel",
-    ("matrix", "pairs"): "matrix_pairs_kernel", ("matrix", "rowpair"): "matrix_rowpair_kernel", ("matrix", "nodeblock"): "matrix_nodeblock_kernel",
+    ("matrix", "pairs"): "matrix_pairs_kernel", ("matrix", "ufcx_pairs"): "ufcx_matrix_pairs_kernel", ("matrix", "rowpair"): "matrix_rowpair_kernel", ("matrix", "nodeblock"): "matrix_nodeblock_kernel",
     ("matrix", "rowblock_lean"): "matrix_rowblock_kernel", ("matrix", "rowblock"): "matrix_rowblock_kernel",
     ("matrix", "atomic"): "matrix_atomic_kernel", ("matrix", "ufcx_atomic"): "ufcx_matrix_kernel",
     ("vector", "cube_own"): "vector_cube_own_kernel", ("vector", "cube_hash"): "vector_cube_kernel",

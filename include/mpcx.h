@@ -165,6 +165,12 @@ int mpcx_ufcx_resolve(const char* source, const char* name, char* out, int32_t o
  * bounded grid strides over the entities.  Launches of ONE handle must not overlap on several streams beyond one matrix, one
  * master-contribution and one lifting launch. */
 int mpcx_ufcx_big_tensor(void* handle);
+/* 1 if the kernel was compiled with ROW-WISE copies of the text (bilinear forms with an element tensor of 37 .. 900 entries on
+ * simplices of up to ten nodes per cell, no dof transformations; round 6): the imported function is inlined once per local node
+ * row and only that row is kept -- the row-block kernel then runs a copy per row an entity keeps in the block, and
+ * MPCX_ALG_ROWBLOCK also takes PAIR RECORDS (plan.row_pairs == 2, pair_recs of mpcx_pair_records, pair_ctx = pair_dict = NULL,
+ * mdofmap1; mpcx_pairs_plan_create with x = NULL builds all of it): one (entity, node row) pair per lane, a wave runs one copy. */
+int mpcx_ufcx_rowwise(void* handle);
 int64_t mpcx_ufcx_code_size(void* handle); /* bytes of the gfx950 code object */
 int mpcx_ufcx_code(void* handle, void* out); /* HOST out[mpcx_ufcx_code_size]: the code object (inspection, caching) */
 void mpcx_ufcx_free(void* handle);

@@ -83,6 +83,41 @@ def test_gpu_imported_kernels_match_builtin_oracle(oracle, make, alg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("env", ["MPCX_UFCX_PAIRS=0", "MPCX_UFCX_ROWWISE=0", "MPCX_UFCX_RB_THREADS=128", "MPCX_FORCE_KERNEL=matrix=ufcx_pairs"])
+@pytest.mark.parametrize("make", CASES, ids=[f"case{i}" for i in range(len(CASES))])
+def test_gpu_imported_kernels_rowwise_variants(oracle, make, env, monkeypatch):
+    """round 6: element tensors of more than 36 entries on simplices run ROW-WISE copies of the text, by default from pair
+    records (ufcx_matrix_pairs_kernel); the other routes stay tested: row-wise copies inside the per-cell row blocks
+    (MPCX_UFCX_PAIRS=0), the whole tensor per visit (MPCX_UFCX_ROWWISE=0), another workgroup size"""
+    k, v = env.split("=", 1)
+    monkeypatch.setenv(k, v)
+    case = make()
+    twin = twin_case(case)
+    if num_imported(twin) == 0 or twin.a is None:
+        pytest.skip("no bilinear cell integral the generator covers")
+    ref = oracle_outputs(oracle, case)
+    out = product_outputs(twin, algorithm="rowblock")
+    assert abs(out["A"].data - ref["A"].data).max() <= 1e-12 * max(1.0, abs(ref["A"]).max()), case.name + " A"
+
+
+@pytest.mark.gpu
+def test_gpu_pair_records_are_the_default_for_imported_p2(oracle):
+    """the dispatch takes ufcx_pairs for a scalar P2 stiffness text (100 entries) and ufcx_cube for P1"""
+    import importlib
+
+    import dolfinx_mpc_amd as dm
+    from problems import case_cube_periodic, product_mpc
+
+    am = importlib.import_module("dolfinx_mpc_amd.assemble_matrix")
+    for degree, want in ((2, "ufcx_pairs"), (1, "ufcx_cube")):
+        twin = twin_case(case_cube_periodic(4, degree, 0.0, reorder=(2, 2, 2)))
+        mpc = product_mpc(twin)
+        A = dm.create_matrix(twin.a, mpc)
+        ma, _k = am.matrix_args(twin.a, 0, A, mpc, mpc, twin.bcs, 2, 1)
+        assert ma.kernel_name == want, (degree, ma.kernel_name)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("alg", ["atomic", "auto"])
 @pytest.mark.parametrize("make", CASES, ids=[f"case{i}" for i in range(len(CASES))])
 def test_gpu_imported_ffcx_layout_files_match_builtin_oracle(oracle, make, alg):
