@@ -30,6 +30,8 @@ HEX_MAX_NNZ = int(os.environ.get("MPCX_HEX_MAX_NNZ", 9216))
 # -> 2 workgroups of 512 threads per CU is the fastest shape for P1)
 ROWBLOCK_MAX_NNZ = int(os.environ.get("MPCX_ROWBLOCK_MAX_NNZ", 9216))
 ROWBLOCK_MAX_ROWS = int(os.environ.get("MPCX_ROWBLOCK_MAX_ROWS", 512))
+# node blocks that the launch expands to scalar CSR values (MPCX_BLOCK_SCALAR=0, or no overlay to add into): slots per block
+NODEBLOCK_CSR_MAX_SLOTS = int(os.environ.get("MPCX_NODEBLOCK_CSR_MAX_SLOTS", 8192))
 # the lean scalar P1 kernel needs 64 VGPRs only: half-size blocks (half tiles of an 8x8x8 numbering) put
 # four workgroups of 512 threads on a CU -- 1.75 ms against 1.82 ms at config 2 (sweep in DESIGN.md section 5)
 ROWBLOCK_LIGHT_MAX_NNZ = int(os.environ.get("MPCX_ROWBLOCK_LIGHT_MAX_NNZ", 4608))
@@ -363,7 +365,8 @@ def _slot_mask(A: MPCMatrix, form: Form, V0, V1, bc0, bc1, mpc0, mpc1):
     return D.cached(A._plans, "slot_mask", (V0, V1, mpc0, mpc1, bc0, bc1), 0, build, maxsize=4)
 
 
-def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False, pairs: bool = False, nodeblock: bool = False):
+def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False, pairs: bool = False, nodeblock: bool = False,
+                   csr_valued: bool = False):
     light = lean and V0.dofmap.bs == 1 and V0.element_ndofs <= 4
     max_rows_cap, max_nnz_cap = ((ROWBLOCK_LIGHT_MAX_ROWS, ROWBLOCK_LIGHT_MAX_NNZ) if light
                                  else (ROWBLOCK_MAX_ROWS, ROWBLOCK_MAX_NNZ))
@@ -377,6 +380,10 @@ def _rowblock_plan(A: MPCMatrix, form: Form, i: int, V0, lean: bool = False, pai
     if nodeblock:
         # component-diagonal forms, node-block kernel: one LDS value per bs x bs block (matrix_nodeblock_kernel)
         group_rows = True
+        if csr_valued:
+            # expanded to scalar CSR values by the launch: the write-out reads the masks from an LDS copy (one more byte per
+            # slot) and is the long phase.  Taylor-Hood a00 128^3, 1024 threads: 9216 slots 9.8 ms, 8192 9.0, 6144 9.4, 4608 9.7
+            max_nnz_cap = min(max_nnz_cap, NODEBLOCK_CSR_MAX_SLOTS)
         max_rows_cap, max_nnz_cap = max_rows_cap * V0.dofmap.bs, max_nnz_cap * V0.dofmap.bs ** 2
     elif (kf.form in (0, 1, 4) and V0.dofmap.bs > 1 and not os.environ.get("MPCX_NO_DIAG_COMPACT")
           and _native.scalar_id(getattr(form, "dtype", np.float64)) == 0):
@@ -1266,7 +1273,8 @@ def matrix_args(form: Form, i: int, A: MPCMatrix, mpc0, mpc1, bcs, alg: int, sto
                     a.block_scalar = True
             elif name == "rowblock_lean":
                 lean = True
-            plan, pk, _info = _rowblock_plan(A, form, i, V0, lean, pairs, smask is not None)
+            plan, pk, _info = _rowblock_plan(A, form, i, V0, lean, pairs, smask is not None,
+                                             csr_valued=smask is not None and not a.block_scalar)
             a.plan = plan
             a.lean = int(lean)
             md0 = _masked_dofmap(form, V0, bc0, mpc0, 0, lean)

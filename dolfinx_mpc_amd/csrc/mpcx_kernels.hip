@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <string>
+#include <type_traits>
 
 namespace mpcx
 {
@@ -707,6 +708,17 @@ __global__ void __launch_bounds__(ROWBLOCK_MAX_THREADS) matrix_rowblock_kernel(m
 // per-row layout above) and the halo shrinks accordingly.  The bs x bs blocks, their structural zeros and the
 // masked entries are produced when the block is written out: slot_mask[slot] bit k = "entry (k, k) of this
 // block is zero" (mpcx_diag_slot_mask).  The masked dofmaps are read for their dof ids only.
+// LDS of a node-block launch that expands to scalar CSR values: the block's values, its row offsets and -- when it fits --
+// one mask byte per slot (host and device agree through this function)
+__host__ __device__ inline bool nodeblock_stage_mask(int64_t max_nnz, int64_t max_rows, int bs)
+{
+  const int64_t slots = max_nnz / (int64_t(bs) * bs);
+  return slots * 8 + (max_rows / bs + 1) * 4 + ((slots + 3) & ~int64_t(3)) <= 160 * 1024;
+}
+// (A/B switch of the node-block write-out, read once: the argument block has no spare field for an experiment)
+__device__ __constant__ int g_nodeblock_narrow_stores = 0;
+__device__ inline bool nodeblock_narrow_stores() { return g_nodeblock_narrow_stores == 1; }
+
 template <class Op, bool USE_LAZY>
 __device__ __forceinline__ void nodeblock_body(const mpcx_matrix_args_t& a)
 {
@@ -731,14 +743,39 @@ __device__ __forceinline__ void nodeblock_body(const mpcx_matrix_args_t& a)
     s_vals[i] = 0.0;
   for (int nl = tid; nl <= nn; nl += NT)
     s_rowlo[nl] = int((a.rowptr[int64_t(n0 + nl) * BS] - nnz0) / (BS * BS));
-  // most blocks hold no Dirichlet / slave dof at all: they write their values out without looking at the masks
-  // (a global load inside the store loop put its latency on every row)
   const int64_t gslot0 = nnz0 / (BS * BS);
   int any = 0;
-  if (!a.block_vals) // (block-scalar storage leaves the masks to the consumers)
+  // The write-out reads the masks from LDS when the copy fits (nodeblock_stage_mask).  Their loads are issued HERE and
+  // consumed after the entity loop (MW words per thread stay in registers): with one resident workgroup per CU nothing hides
+  // a load that the next barrier waits for, and a block has one trip of the entity loop to hide it behind.
+  uint8_t* s_mask = reinterpret_cast<uint8_t*>(s_rowlo + a.plan.max_rows / BS + 1); // [max_nnz / BS^2, rounded up to 4]
+  const bool stage_mask = nodeblock_stage_mask(a.plan.max_nnz, a.plan.max_rows, BS);
+  constexpr int MW = 4;
+  const bool late_mask = !a.block_vals && stage_mask && slots <= 4 * MW * NT;
+  uint32_t mw[MW] = {};
+  if (late_mask)
+  {
+    const uint8_t* gm = a.slot_mask + gslot0;
+#pragma unroll
+    for (int j = 0; j < MW; ++j)
+    {
+      const int o = 4 * (tid + j * NT);
+      if (o + 4 <= slots)
+        __builtin_memcpy(&mw[j], gm + o, 4); // (any byte alignment: unaligned access mode)
+      else
+        for (int q = 0; o + q < slots; ++q)
+          mw[j] |= uint32_t(gm[o + q]) << (8 * q);
+    }
+  }
+  else if (!a.block_vals) // (block-scalar storage leaves the masks to the consumers)
     for (int i = tid; i < slots; i += NT)
-      any |= a.slot_mask[gslot0 + i];
-  const bool masked_block = __syncthreads_or(any) != 0;
+    {
+      const uint8_t m = a.slot_mask[gslot0 + i];
+      any |= m;
+      if (stage_mask)
+        s_mask[i] = m;
+    }
+  __syncthreads();
 
   const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
   const int32_t* __restrict__ ents = a.plan.block_ents;
@@ -802,7 +839,19 @@ __device__ __forceinline__ void nodeblock_body(const mpcx_matrix_args_t& a)
       }
     }
   }
-  __syncthreads();
+  if (late_mask)
+  {
+#pragma unroll
+    for (int j = 0; j < MW; ++j)
+    {
+      const int o = 4 * (tid + j * NT);
+      any |= int(mw[j]);
+      if (o < slots)
+        *reinterpret_cast<uint32_t*>(s_mask + o) = mw[j];
+    }
+  }
+  // most blocks hold no Dirichlet / slave dof at all: they write their values out without looking at the masks
+  const bool masked_block = __syncthreads_or(any) != 0;
   if (a.block_vals)
   {
     // block-scalar storage: the block's values as they are, one per bs x bs block; masks and structural zeros are
@@ -825,6 +874,87 @@ __device__ __forceinline__ void nodeblock_body(const mpcx_matrix_args_t& a)
   constexpr int RB = 4;
   const int nrows = nn * BS;
   const bool mapped = a.val_map != nullptr;
+  if (a.store_mode && !mapped && !nodeblock_narrow_stores() && (!masked_block || stage_mask))
+  {
+    // store mode, the launch's own CSR.  A lane holds TWO neighbouring entries of a row and issues one 16-byte store (rows
+    // start on 8-byte boundaries).  Everything about a row is wave-uniform and kept in scalar registers (row bounds through
+    // readfirstlane); at most one of a lane's two entries is a (k, k) entry, so a row costs ONE unconditional LDS read, two
+    // selects and the store -- no branch per entry.  (The first version of this loop evaluated every entry behind its own
+    // exec-mask branch, ~300 instructions per trip of four rows.)  The masks of a block with Dirichlet / slave dofs come
+    // from LDS: a global load inside this loop would wait for every store issued before it (one in-order counter on gfx9).
+    // Taylor-Hood a00 at 128^3 (34.9 GB of values), 1024 threads, blocks of 9216 slots, taken apart with probe switches:
+    // entity loop alone 3.1 ms, write-out alone 8.9 ms, both 10.1 ms; the same bytes in the same row pattern from a
+    // kernel without global loads (tools/probes/store_pattern.hip, pattern D): 6.4 ms = 5.5 TB/s, memset 5.8 ms.  What
+    // separates 8.9 from 6.4 is the chain of dependent loads at the head of every block (block bounds -> row offsets ->
+    // entity list -> dofmaps -> coordinates) behind the other CUs' stores, with ONE resident workgroup per CU (88 VGPRs);
+    // two of 512 threads overlap it and lose more than they gain (10.0 against 9.2 ms with blocks of 8192 slots).
+    typedef double __attribute__((ext_vector_type(2), aligned(8))) double2_a8;
+    static_assert(BS >= 2, "blocked spaces only");
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    double* const out = a.vals + nnz0;
+    auto rows = [&](auto masked_c)
+    {
+      constexpr bool MASKED = decltype(masked_c)::value;
+      for (int rb = swave * RB; rb < nrows; rb += nwaves * RB)
+      {
+        int lo[RB], len[RB], kk[RB];
+#pragma unroll
+        for (int u = 0; u < RB; ++u)
+        {
+          const int rl = rb + u < nrows ? rb + u : nrows - 1;
+          const int nl = rl / BS;
+          kk[u] = rl - nl * BS;
+          lo[u] = __builtin_amdgcn_readfirstlane(s_rowlo[nl]);
+          const int hi = __builtin_amdgcn_readfirstlane(s_rowlo[nl + 1]);
+          len[u] = rb + u < nrows ? (hi - lo[u]) * BS : 0;
+        }
+        int maxlen = 0;
+#pragma unroll
+        for (int u = 0; u < RB; ++u)
+          maxlen = len[u] > maxlen ? len[u] : maxlen;
+        for (int base = 0; base < maxlen; base += 128) // (base > 0: vertex rows of P2 spaces, master rows)
+        {
+          const int e0 = base + 2 * lane;
+          const int c0 = e0 / BS, r0 = e0 - c0 * BS;
+          const int r1 = r0 + 1 == BS ? 0 : r0 + 1;
+          const int c1 = r0 + 1 == BS ? c0 + 1 : c0;
+          double val[RB];
+          [[maybe_unused]] int mk[RB];
+#pragma unroll
+          for (int u = 0; u < RB; ++u)
+          {
+            int p = lo[u] + (r0 == kk[u] ? c0 : c1);
+            p = p < slots ? p : slots - 1;
+            val[u] = s_vals[p];
+            if constexpr (MASKED)
+              mk[u] = s_mask[p];
+          }
+#pragma unroll
+          for (int u = 0; u < RB; ++u)
+          {
+            if (base >= len[u]) // (uniform)
+              continue;
+            double w = val[u];
+            if constexpr (MASKED)
+              w = ((mk[u] >> kk[u]) & 1) ? 0.0 : w;
+            double2_a8 v;
+            v.x = r0 == kk[u] ? w : 0.0;
+            v.y = r1 == kk[u] ? w : 0.0;
+            double* row = out + (int64_t(lo[u]) * (BS * BS) + int64_t(kk[u]) * len[u]);
+            if (e0 + 1 < len[u])
+              *reinterpret_cast<double2_a8*>(row + e0) = v;
+            else if (e0 < len[u])
+              row[e0] = v.x;
+          }
+        }
+      }
+    };
+    if (masked_block)
+      rows(std::true_type{});
+    else
+      rows(std::false_type{});
+    return;
+  }
   for (int rb = wave * RB; rb < nrows; rb += nwaves * RB)
   {
     int lo[RB], len[RB], kk[RB];
@@ -1911,6 +2041,8 @@ int launch_matrix(const mpcx_matrix_args_t& a)
       // component-diagonal forms keep one value per column block (see the kernel): BS1 times less LDS per row
       size_t lds = a.slot_mask ? size_t(a.plan.max_nnz / (Op::BS0 * Op::BS1)) * 8 + size_t(a.plan.max_rows / Op::BS0 + 1) * 4
                                : size_t(a.plan.max_nnz / (Op::DIAG ? Op::BS1 : 1)) * 8 + size_t(a.plan.max_rows + 1) * 4;
+      if (a.slot_mask && !a.block_vals && nodeblock_stage_mask(a.plan.max_nnz, a.plan.max_rows, Op::BS0))
+        lds += (size_t(a.plan.max_nnz / (Op::BS0 * Op::BS1)) + 3) & ~size_t(3); // the block's mask bytes (read by the write-out)
       if (lds > 160 * 1024)
       {
         mpcx_set_error("mpcx_assemble_matrix: row-block plan exceeds 160 KiB of LDS");
@@ -1948,12 +2080,21 @@ int launch_matrix(const mpcx_matrix_args_t& a)
           // computes while a block is written out (Taylor-Hood a00, 84 registers: 1024 threads 2.98 ms, 512 2.16 ms)
           if ((a.plan.row_pairs || a.slot_mask) && attr.numRegs <= 64)
             threads = 1024;
+          static const bool narrow_set = []
+          {
+            const char* e = std::getenv("MPCX_NODEBLOCK_NARROW_STORES");
+            const int v = (e && e[0] == '1') ? 1 : 0; // 1: the general loop below (8-byte stores) for every block
+            if (v)
+              (void)hipMemcpyToSymbol(HIP_SYMBOL(g_nodeblock_narrow_stores), &v, sizeof(int));
+            return true;
+          }();
+          (void)narrow_set;
           // node blocks expanded to scalar CSR values (no block_vals): the write-out of 9 x the LDS block is the longer
           // phase and its rate follows the number of waves that issue stores: MPCX_NODEBLOCK_CSR_THREADS (default below)
           if (a.slot_mask && !a.block_vals)
           {
-            // (Taylor-Hood a00 at 128^3, 35.7 GB of values: 512 threads 13.2 ms, 768 13.9, 1024 11.4 -- round 3's 10.97 ms was
-            // taken with 1024 before the node-block default became 512 for the block-scalar storage)
+            // (Taylor-Hood a00 at 128^3, 34.9 GB of values, blocks of 8192 slots: 1024 threads 9.0-9.2 ms, 512 10.0; before the
+            // 16-byte stores, the branch-free row loop and the masks in LDS: 1024 11.3 ms, 768 13.9, 512 13.2)
             const char* e = std::getenv("MPCX_NODEBLOCK_CSR_THREADS");
             const int t = e ? std::atoi(e) : 1024;
             threads = (t >= 64 && t <= 1024 && t % 64 == 0) ? t : 1024;

@@ -351,6 +351,75 @@ __global__ void block_expand_kernel(int32_t n_nodes, const mpcx_nnz_t* __restric
   }
 }
 
+// The same for bs = 2, 3 as a stream: a wave takes RB consecutive scalar rows, a lane two neighbouring entries of each and
+// one 16-byte store (rows start on 8-byte boundaries); the row bounds are wave-uniform scalar loads, the loads of the RB rows
+// are issued together.  32.7 GB of values (Taylor-Hood a00 at 128^3) in MPCX_EXPAND_WIDE=0: the kernel above.
+template <int BS>
+__global__ __launch_bounds__(256) void block_expand_wide_kernel(int64_t nrows, const mpcx_nnz_t* __restrict__ rowptr,
+                                                                const double* __restrict__ block_vals,
+                                                                const uint8_t* __restrict__ slot_mask, double* __restrict__ vals)
+{
+  typedef double __attribute__((ext_vector_type(2), aligned(8))) double2_a8;
+  constexpr int RB = 4;
+  const int64_t wave = int64_t(blockIdx.x) * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int64_t row0 = wave * RB;
+  if (row0 >= nrows)
+    return;
+  int64_t p0[RB], slot0[RB];
+  int len[RB], kk[RB];
+#pragma unroll
+  for (int u = 0; u < RB; ++u)
+  {
+    const int64_t row = row0 + u < nrows ? row0 + u : nrows - 1;
+    const int64_t n = row / BS;
+    kk[u] = int(row - n * BS);
+    p0[u] = rowptr[row];
+    len[u] = row0 + u < nrows ? int(rowptr[row + 1] - p0[u]) : 0;
+    slot0[u] = rowptr[n * BS] / (BS * BS);
+  }
+  auto value = [&](int u, int e) -> double
+  {
+    const int sl = e / BS, q = e - sl * BS;
+    if (e >= len[u] || q != kk[u])
+      return 0.0;
+    return ((slot_mask[slot0[u] + sl] >> kk[u]) & 1) ? 0.0 : block_vals[slot0[u] + sl];
+  };
+  double v0[RB], v1[RB];
+#pragma unroll
+  for (int u = 0; u < RB; ++u)
+  {
+    v0[u] = value(u, 2 * lane);
+    v1[u] = value(u, 2 * lane + 1);
+  }
+#pragma unroll
+  for (int u = 0; u < RB; ++u)
+  {
+    double* row = vals + p0[u];
+    const int e = 2 * lane;
+    if (e + 1 < len[u])
+    {
+      double2_a8 w;
+      w.x = v0[u], w.y = v1[u];
+      *reinterpret_cast<double2_a8*>(row + e) = w;
+    }
+    else if (e < len[u])
+      row[e] = v0[u];
+    for (int f = e + 128; f < len[u]; f += 128) // long rows
+    {
+      const double x0 = value(u, f), x1 = value(u, f + 1);
+      if (f + 1 < len[u])
+      {
+        double2_a8 w;
+        w.x = x0, w.y = x1;
+        *reinterpret_cast<double2_a8*>(row + f) = w;
+      }
+      else
+        row[f] = x0;
+    }
+  }
+}
+
 // y(n, k) = sum over the blocks of node row n: (bit k of the mask clear) s * x(col block, k); a group of 8 lanes per row
 __global__ void spmv_blockscalar_kernel(int32_t n_nodes, const mpcx_nnz_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
                                         int bs, const double* __restrict__ block_vals, const uint8_t* __restrict__ slot_mask,
@@ -412,6 +481,24 @@ extern "C" int mpcx_block_expand(int32_t n_nodes, const mpcx_nnz_t* rowptr, int3
 {
   if (n_nodes == 0)
     return 0;
+  static const bool wide = []
+  {
+    const char* e = std::getenv("MPCX_EXPAND_WIDE");
+    return !(e && e[0] == '0');
+  }();
+  if (wide && (bs == 2 || bs == 3))
+  {
+    const int64_t nrows = int64_t(n_nodes) * bs;
+    const int64_t waves = (nrows + 3) / 4;
+    const dim3 grid(unsigned((waves + 3) / 4));
+    if (bs == 2)
+      hipLaunchKernelGGL(block_expand_wide_kernel<2>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), nrows, rowptr,
+                         block_vals, slot_mask, vals);
+    else
+      hipLaunchKernelGGL(block_expand_wide_kernel<3>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), nrows, rowptr,
+                         block_vals, slot_mask, vals);
+    return check(hipGetLastError(), "block_expand launch");
+  }
   const int64_t threads = int64_t(n_nodes) * bs * 64;
   hipLaunchKernelGGL(block_expand_kernel, dim3(grid_for(threads, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n_nodes,
                      rowptr, int(bs), block_vals, slot_mask, vals);
