@@ -353,14 +353,15 @@ __global__ void block_expand_kernel(int32_t n_nodes, const mpcx_nnz_t* __restric
 
 // The same for bs = 2, 3 as a stream: a wave takes RB consecutive scalar rows, a lane two neighbouring entries of each and
 // one 16-byte store (rows start on 8-byte boundaries); the row bounds are wave-uniform scalar loads, the loads of the RB rows
-// are issued together.  32.7 GB of values (Taylor-Hood a00 at 128^3) in MPCX_EXPAND_WIDE=0: the kernel above.
+// are issued together.  MPCX_EXPAND_WIDE=0: the kernel above.
+constexpr int EXPAND_RB = 4; // rows per wave (34.9 GB of Taylor-Hood a00 at 128^3: 13.2 ms; 8 rows 14.8; the row-at-a-time kernel 23.9)
 template <int BS>
 __global__ __launch_bounds__(256) void block_expand_wide_kernel(int64_t nrows, const mpcx_nnz_t* __restrict__ rowptr,
                                                                 const double* __restrict__ block_vals,
                                                                 const uint8_t* __restrict__ slot_mask, double* __restrict__ vals)
 {
   typedef double __attribute__((ext_vector_type(2), aligned(8))) double2_a8;
-  constexpr int RB = 4;
+  constexpr int RB = EXPAND_RB;
   const int64_t wave = int64_t(blockIdx.x) * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int64_t row0 = wave * RB;
@@ -378,44 +379,47 @@ __global__ __launch_bounds__(256) void block_expand_wide_kernel(int64_t nrows, c
     len[u] = row0 + u < nrows ? int(rowptr[row + 1] - p0[u]) : 0;
     slot0[u] = rowptr[n * BS] / (BS * BS);
   }
-  auto value = [&](int u, int e) -> double
-  {
-    const int sl = e / BS, q = e - sl * BS;
-    if (e >= len[u] || q != kk[u])
-      return 0.0;
-    return ((slot_mask[slot0[u] + sl] >> kk[u]) & 1) ? 0.0 : block_vals[slot0[u] + sl];
-  };
-  double v0[RB], v1[RB];
+  // at most one of a lane's two entries is a (k, k) entry: one value and one mask byte per lane and row, both loaded
+  // unconditionally (index clamped to the row) so that the loads of the RB rows are in flight together
+  int maxlen = 0;
 #pragma unroll
   for (int u = 0; u < RB; ++u)
+    maxlen = len[u] > maxlen ? len[u] : maxlen;
+  for (int base = 0; base < maxlen; base += 128)
   {
-    v0[u] = value(u, 2 * lane);
-    v1[u] = value(u, 2 * lane + 1);
-  }
+    const int e0 = base + 2 * lane;
+    const int c0 = e0 / BS, r0 = e0 - c0 * BS;
+    const int r1 = r0 + 1 == BS ? 0 : r0 + 1;
+    const int c1 = r0 + 1 == BS ? c0 + 1 : c0;
+    double val[RB];
+    int mk[RB];
 #pragma unroll
-  for (int u = 0; u < RB; ++u)
-  {
-    double* row = vals + p0[u];
-    const int e = 2 * lane;
-    if (e + 1 < len[u])
+    for (int u = 0; u < RB; ++u)
     {
-      double2_a8 w;
-      w.x = v0[u], w.y = v1[u];
-      *reinterpret_cast<double2_a8*>(row + e) = w;
-    }
-    else if (e < len[u])
-      row[e] = v0[u];
-    for (int f = e + 128; f < len[u]; f += 128) // long rows
-    {
-      const double x0 = value(u, f), x1 = value(u, f + 1);
-      if (f + 1 < len[u])
+      int c = r0 == kk[u] ? c0 : c1;
+      const int last = len[u] / BS - 1;
+      c = c < last ? c : last;
+      val[u] = 0.0, mk[u] = 0;
+      if (last >= 0) // (uniform)
       {
-        double2_a8 w;
-        w.x = x0, w.y = x1;
-        *reinterpret_cast<double2_a8*>(row + f) = w;
+        val[u] = block_vals[slot0[u] + c];
+        mk[u] = slot_mask[slot0[u] + c];
       }
-      else
-        row[f] = x0;
+    }
+#pragma unroll
+    for (int u = 0; u < RB; ++u)
+    {
+      if (base >= len[u]) // (uniform)
+        continue;
+      const double w = ((mk[u] >> kk[u]) & 1) ? 0.0 : val[u];
+      double2_a8 v;
+      v.x = r0 == kk[u] ? w : 0.0;
+      v.y = r1 == kk[u] ? w : 0.0;
+      double* row = vals + p0[u];
+      if (e0 + 1 < len[u])
+        *reinterpret_cast<double2_a8*>(row + e0) = v;
+      else if (e0 < len[u])
+        row[e0] = v.x;
     }
   }
 }
@@ -489,7 +493,7 @@ extern "C" int mpcx_block_expand(int32_t n_nodes, const mpcx_nnz_t* rowptr, int3
   if (wide && (bs == 2 || bs == 3))
   {
     const int64_t nrows = int64_t(n_nodes) * bs;
-    const int64_t waves = (nrows + 3) / 4;
+    const int64_t waves = (nrows + EXPAND_RB - 1) / EXPAND_RB;
     const dim3 grid(unsigned((waves + 3) / 4));
     if (bs == 2)
       hipLaunchKernelGGL(block_expand_wide_kernel<2>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), nrows, rowptr,
