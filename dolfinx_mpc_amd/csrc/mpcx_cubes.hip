@@ -20,6 +20,7 @@
 #include <string>
 #include <type_traits>
 
+#include "mpcx_box14.hpp"
 #include "mpcx_fan.hpp"
 
 namespace mpcx
@@ -619,6 +620,90 @@ __global__ void __launch_bounds__(VCUBE_THREADS) vector_cube_kernel(mpcx_vector_
 // flag in bit 28: skipped here, vector_mpc_kernel moves those rows to their masters).  No hash table, no device
 // atomics: b receives every row once from its owner plus the halo sums through vector_spill_reduce_kernel, in a
 // fixed order -- the result is bitwise reproducible up to the order of the LDS adds inside a block.
+// ---- axis-aligned boxes and the 14-point rule: the right-hand side on a tensor grid -------------------------------------
+// The 84 quadrature points of the six tetrahedra of a box lie on 19 x 19 x 19 coordinates (csrc/mpcx_box14.hpp, generated from
+// the rule and the fan).  The benchmark's right-hand side (eval_fn case 1, python/benchmarks/bench_periodic.py:85-89) is
+//     f = x sin(5 pi y) + g(x - 0.9) g(y - 0.5) g(z - 0.1),   g(t) = exp(-t^2 / 0.02),
+// a sum of products of univariate factors: 19 sines and 3 x 19 exponentials per box instead of 84 + 84, and two
+// multiplications and one fma per point.  Same points, same weights, same sum as Op::tabulate -- the factors of the Gaussian
+// are rounded separately (a few ulp of its value).  Taken when the kernel data hold exactly this rule, no coefficient, and the
+// eight vertices of the cluster are the corners of a box (compared exactly: tensor grids give identical coordinates);
+// every other cluster takes the per-tetrahedron loop.  MPCX_BOX_GRID=0 switches it off.
+__constant__ mpcx_box14::Tables c_box14 = mpcx_box14::TABLES;
+__device__ __constant__ int g_box14_enable = 1;
+
+__device__ inline bool box14_rule(const mpcx_kernel_t& k) // (wave-uniform)
+{
+  if (!g_box14_enable || k.nq != mpcx_box14::NQ || k.coeff_degree != 0 || !k.qpts || !k.qwts)
+    return false;
+  bool ok = true;
+#pragma unroll
+  for (int q = 0; q < mpcx_box14::NQ; ++q)
+  {
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+      ok &= k.qpts[3 * q + d] == mpcx_box14::XQ[q][d];
+    ok &= k.qwts[q] == mpcx_box14::WQ[q];
+  }
+  return ok;
+}
+
+__device__ inline bool box14_is_box(const double (&X)[8][3])
+{
+  bool box = true;
+#pragma unroll
+  for (int v = 1; v < 7; ++v)
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+      box &= X[v][d] == (((v >> d) & 1) ? X[7][d] : X[0][d]);
+  return box;
+}
+
+__device__ inline void box14_source_fn1(const double (&X)[8][3], double c0, double (&be8)[8])
+{
+  using namespace mpcx_box14;
+  const FmConsts FK = g_fm_consts; // polynomial coefficients in scalar registers
+  const double H[3] = {X[7][0] - X[0][0], X[7][1] - X[0][1], X[7][2] - X[0][2]};
+  const double org[3] = {X[0][0] - 0.9, X[0][1] - 0.5, X[0][2] - 0.1}; // relative to the centre of the Gaussian
+  double gx[NG], gy[NG], gz[NG], sy[NG];
+#pragma unroll
+  for (int j = 0; j < NG; ++j)
+  {
+    const double e = c_box14.grid[j];
+    const double x = fma(H[0], e, org[0]), y = fma(H[1], e, org[1]), z = fma(H[2], e, org[2]);
+    gx[j] = fast_exp_nonpos_k(-(x * x) * (1.0 / 0.02), FK);
+    gy[j] = fast_exp_nonpos_k(-(y * y) * (1.0 / 0.02), FK);
+    gz[j] = fast_exp_nonpos_k(-(z * z) * (1.0 / 0.02), FK);
+    sy[j] = fast_sinpi_k(fma(5.0, y, 2.5), FK); // 5 y = 5 (y - 0.5) + 2.5
+  }
+  const double sd = c0 * fabs(H[0] * H[1] * H[2]);
+  const double wsd[3] = {c_box14.wu[0] * sd, c_box14.wu[1] * sd, c_box14.wu[2] * sd};
+#pragma unroll
+  for (int t = 0; t < 6; ++t)
+  {
+    double S = 0.0, SX[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      const int ix = IDX[t][q][0], iy = IDX[t][q][1], iz = IDX[t][q][2];
+      const double xq = fma(H[0], c_box14.grid[ix], X[0][0]);
+      const double f = wsd[WIDX[q]] * fma(xq, sy[iy], gx[ix] * gy[iy] * gz[iz]);
+      S += f;
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        SX[d] = fma(f, c_box14.lam[LIDX[q][d]], SX[d]);
+    }
+    double s0 = S;
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+    {
+      s0 -= SX[d];
+      be8[fan_vertex(t, d + 1)] += SX[d];
+    }
+    be8[fan_vertex(t, 0)] += s0;
+  }
+}
+
 constexpr int VCUBE_OWN_THREADS = 256;
 constexpr int VCUBE_OWN_MAX_THREADS = 256; // launch bound of vector_cube_own_kernel (MPCX_VCUBE_THREADS, default 256)
 inline int vcube_own_threads()
@@ -653,6 +738,9 @@ __global__ void __launch_bounds__(VCUBE_OWN_MAX_THREADS) vector_cube_own_kernel(
     return;
   const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
   const int32_t* __restrict__ ents = a.plan.block_ents;
+  [[maybe_unused]] bool grid_rule = false;
+  if constexpr (FN == 1)
+    grid_rule = box14_rule(a.kernel);
   for (int64_t t = e0 + tid; t < e1; t += NT)
   {
     const int64_t c = ents[t];
@@ -672,20 +760,31 @@ __global__ void __launch_bounds__(VCUBE_OWN_MAX_THREADS) vector_cube_own_kernel(
 #pragma unroll
     for (int i = 0; i < 8; ++i)
       be8[i] = 0.0;
-#pragma unroll
-    for (int tet = 0; tet < 6; ++tet)
+    bool on_grid = false;
+    if constexpr (FN == 1)
+      on_grid = grid_rule && box14_is_box(X);
+    if (on_grid)
     {
-      double cd[12];
+      if constexpr (FN == 1)
+        box14_source_fn1(X, a.constants ? a.constants[0] : 1.0, be8);
+    }
+    else
+    {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int tet = 0; tet < 6; ++tet)
+      {
+        double cd[12];
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-          cd[3 * i + k] = X[fan_vertex(tet, i)][k];
-      double be[4];
-      Op::tabulate(be, nullptr, a.constants, cd, 0, a.kernel);
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        be8[fan_vertex(tet, i)] += be[i];
+          for (int k = 0; k < 3; ++k)
+            cd[3 * i + k] = X[fan_vertex(tet, i)][k];
+        double be[4];
+        Op::tabulate(be, nullptr, a.constants, cd, 0, a.kernel);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          be8[fan_vertex(tet, i)] += be[i];
+      }
     }
     // LDS positions of the eight vertices (read after the quadrature: eight registers less across it)
     int32_t w[8];
@@ -2519,6 +2618,18 @@ int launch_vector_cubes(const mpcx_vector_args_t& a)
       hipLaunchKernelGGL(kernel, dim3(g), dim3(vcube_own_threads()), lds, st, a);
       return check(hipGetLastError(), "vector cluster owner kernel launch");
     };
+    {
+      // MPCX_BOX_GRID=0: point by point on every cluster (read per launch: the parity tests run both in one process)
+      static int grid_on = 1;
+      const char* e = std::getenv("MPCX_BOX_GRID");
+      const int want = (e && e[0] == '0') ? 0 : 1;
+      if (want != grid_on)
+      {
+        if (int rc = check(hipMemcpyToSymbol(HIP_SYMBOL(g_box14_enable), &want, sizeof(int)), "hipMemcpyToSymbol"))
+          return rc;
+        grid_on = want;
+      }
+    }
     if (int rc = k.fn_id == 1 ? go(vector_cube_own_kernel<1>) : go(vector_cube_own_kernel<-1>))
       return rc;
     if (a.n_own_rows > 0)

@@ -315,6 +315,51 @@ def test_cluster_vector_kernel_variants(oracle, n, reorder, bc, env, monkeypatch
     _close(out["A"].data, ref["A"].data, RTOL_A, f"{case.name} A [{env}]")
 
 
+@pytest.mark.parametrize("grid", ["1", "0"])
+@pytest.mark.parametrize("shape", ["cube", "stretched", "mirrored", "half_warped", "warped"])
+def test_cluster_vector_on_the_tensor_grid_of_a_box(oracle, shape, grid, monkeypatch):
+    """the benchmark's right-hand side on clusters that are axis-aligned boxes is evaluated factor by factor on the 19
+    coordinates per axis the 14-point rule puts into a box (csrc/mpcx_box14.hpp; MPCX_BOX_GRID=0: point by point): cubes,
+    boxes with three different edges, a mirrored numbering (negative edge), a mesh where only some clusters are boxes and
+    one where none is -- all against the oracle, and the two evaluations against each other"""
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import fem
+    from dolfinx_mpc_amd.mesh import create_unit_cube
+    from problems import Case, _walls_yz, periodic_raw
+
+    monkeypatch.setenv("MPCX_BOX_GRID", grid)
+    if shape in ("half_warped", "warped"):
+        case = case_cube_periodic(6, 1, 0.0, reorder=(2, 2, 2), warp="half" if shape == "half_warped" else True)
+    else:
+        mesh = create_unit_cube(6, 5, 7, reorder=(2, 2, 2))
+        x = mesh.geometry.x.copy()
+        if shape == "stretched":
+            x[:, 1] *= 0.7
+            x[:, 2] = 0.05 + 1.3 * x[:, 2]
+        elif shape == "mirrored":
+            x[:, 1] = 1.0 - x[:, 1]
+        mesh.geometry.x = x
+        V = fem.functionspace(mesh, ("Lagrange", 1))
+        bc = fem.dirichletbc(0.0, fem.locate_dofs_geometrical(V, _walls_yz), V)
+        case = Case("box_" + shape, V, fem.form_stiffness(V), fem.form_source(V, fem.FN_BENCH_PERIODIC), [bc], periodic_raw(V, [bc]))
+    ref = oracle_outputs(oracle, case)
+    mpc = product_mpc(case)
+    import importlib
+
+    from dolfinx_mpc_amd.la import create_vector
+
+    av = importlib.import_module("dolfinx_mpc_amd.assemble_vector")
+    assert av.vector_args(case.L, 0, create_vector(case.V), mpc, 0)[0].kernel_name == "cube_own", "the cluster kernel was expected to run"
+    got = dm.assemble_vector(case.L, mpc).numpy().copy()
+    _close(got, ref["b"], RTOL_B, f"{case.name} b [MPCX_BOX_GRID={grid}]")
+    if grid == "1":
+        monkeypatch.setenv("MPCX_BOX_GRID", "0")
+        other = dm.assemble_vector(case.L, mpc).numpy()
+        assert abs(other - got).max() <= 1e-14 * abs(ref["b"]).max()
+        if shape in ("cube", "stretched", "mirrored"):
+            assert not np.array_equal(other, got), "the two evaluations round differently: the switch had no effect"
+
+
 def test_cluster_plan_uses_narrow_and_wide_records(oracle):
     """the cluster plan keeps 64-byte records (4-bit offsets) for row blocks whose rows have at most 16 entries before
     any cluster column and 96-byte records for the blocks with fat rows (the periodic master rows): both formats are
