@@ -194,6 +194,11 @@ class VectorArgs(C.Structure):
         ("cube_cells", C.c_void_p),
         ("cell_info0", C.c_void_p),
         ("row_map", C.c_void_p),
+        ("grid_idx", C.c_void_p),
+        ("grid_iv", C.c_void_p),
+        ("grid_tab", C.c_void_p),
+        ("grid_n", C.c_int32 * 3),
+        ("grid_stage", C.c_int32),
         ("lds_floor", C.c_int32),
         ("stream", C.c_void_p),
     ]

@@ -268,6 +268,74 @@ def _vector_cube_owner_plan(mesh, V, d_verts, constraint, left: np.ndarray, slav
     return D.cached(mesh._device, "vcube_own", (d_verts, constraint, left), VCUBE_OWNER_ROWS, build, maxsize=2)
 
 
+def _cluster_grid(mesh, d_verts):
+    """The tensor grid under a mesh of axis-aligned box clusters (include/mpcx.h mpcx_vector_args_t::grid_*): per axis the
+    distinct intervals (coordinate of corner 0, coordinate of corner 7) of the clusters and, per cluster, which interval it
+    sits on along x, y, z.  None when a cluster is not a box with its eight vertices in corner order (compared exactly, as the
+    kernel's own per-cluster check does), or when the intervals are not few against the clusters (no tensor structure: the
+    tables would cost what they save).  Geometry only -- cached per (clusters, geometry version); every value of the
+    right-hand side is still computed inside each launch."""
+    import torch
+
+    def build():
+        x = D.mesh_device(mesh)["x"].view(-1, 3)
+        v = d_verts.long()
+        n = v.shape[0]
+        X0, X7 = x[v[:, 0]], x[v[:, 7]]
+        for c in range(1, 7):
+            xc = x[v[:, c]]
+            for d in range(3):
+                if not bool((xc[:, d] == (X7[:, d] if (c >> d) & 1 else X0[:, d])).all()):
+                    return None
+        idx = torch.zeros((n, 4), dtype=torch.int32, device=x.device)
+        ivs, ns = [], []
+        for d in range(3):
+            lo_u, lo_i = torch.unique(X0[:, d], return_inverse=True)
+            hi_u, hi_i = torch.unique(X7[:, d], return_inverse=True)
+            pair_u, pair_i = torch.unique(lo_i * hi_u.numel() + hi_i, return_inverse=True)
+            idx[:, d] = pair_i.to(torch.int32)
+            ivs.append(torch.stack([lo_u[pair_u // hi_u.numel()], hi_u[pair_u % hi_u.numel()]], dim=1))
+            ns.append(int(pair_u.numel()))
+        if sum(ns) > max(4096, n // 8):
+            return None
+        return idx.contiguous(), torch.cat(ivs).contiguous(), tuple(ns)
+
+    return D.cached(mesh._device, "vcube_grid", (d_verts,), (mesh.geometry.version,), build, maxsize=2)
+
+
+GRID_CAP = (64, 32, 32)  # rows per axis a block stages in LDS (csrc/mpcx_cubes.hip GRID_CAP)
+
+
+def _blocks_fit(pk, idx, ns) -> bool:
+    """do the clusters of every block of an owner plan sit on at most GRID_CAP distinct intervals per axis?"""
+    import torch
+
+    off, ents = pk[1], pk[2]
+    n = off.numel() - 1
+    if n <= 0 or ents.numel() == 0 or max(ns) > 8192:
+        return False
+    blk = torch.repeat_interleave(torch.arange(n, device=ents.device), (off[1:] - off[:-1]).long())
+    e = ents.long()
+    for d in range(3):
+        u = torch.unique(blk * ns[d] + idx[:, d][e].long())
+        if int(torch.bincount(u // ns[d], minlength=n).max().item()) > GRID_CAP[d]:
+            return False
+    return True
+
+
+def _grid_rule(k) -> bool:
+    """does the kernel data hold the 14-point rule the tensor-grid tables are generated for (csrc/mpcx_box14.hpp)?"""
+    from .quadrature import make_quadrature
+
+    if k.qwts is None or k.qwts.size != 14:
+        return False
+    p, w = make_quadrature("tetrahedron", 5)
+    return bool(np.array_equal(np.asarray(k.qpts).reshape(-1), p.reshape(-1)) and np.array_equal(np.asarray(k.qwts), w))
+
+
+GRID_ROW = 40  # MPCX_GRID_ROW of include/mpcx.h
+
+
 def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint, alg: int, allow_cubes: bool = True):
     """Fill the C-ABI argument block of ``mpcx_assemble_vector`` for integral i; returns (args, keep-alive)."""
     V = form.function_spaces[0]
@@ -388,6 +456,24 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
                 a.own_src, a.own_rows, a.own_seg, a.n_own_rows = pk[6].data_ptr(), pk[7].data_ptr(), pk[8].data_ptr(), n_own
                 a.slave_entities, a.n_slave_entities = d_slaves.data_ptr(), d_slaves.numel()
                 keep += [pk, d_slaves]
+                if (name == "cube_own" and k.form == 2 and k.fn_id == 1 and k.coeff_degree == 0 and integ.coefficient is None
+                        and os.environ.get("MPCX_BOX_GRID", "1") != "0" and os.environ.get("MPCX_TENSOR_GRID", "1") != "0"
+                        and _grid_rule(k)):
+                    # the benchmark's right-hand side on box clusters of a tensor grid: its univariate factors once per
+                    # interval and launch instead of 84 sines and exponentials per cluster (csrc/mpcx_cubes.hip)
+                    grid = _cluster_grid(form.mesh, d_verts)
+                    if grid is not None:
+                        import torch
+
+                        tab = D.cached(form._device, "grid_tab", (grid[0],), i,
+                                       lambda: torch.empty(sum(grid[2]) * GRID_ROW, dtype=torch.float64, device=grid[0].device))
+                        a.grid_idx, a.grid_iv, a.grid_tab = grid[0].data_ptr(), grid[1].data_ptr(), tab.data_ptr()
+                        a.grid_n[0], a.grid_n[1], a.grid_n[2] = grid[2]
+                        # do the intervals under every block's clusters fit the LDS copy the blocks keep of their rows?
+                        a.grid_stage = D.cached(form._device, "grid_stage", (grid[0], pk), i,
+                                                lambda: int(_blocks_fit(pk, grid[0], grid[2])))
+                        a.tensor_grid = True  # (python attribute)
+                        keep += [grid, tab]
             a.algorithm = 3
             a.cube_verts, a.n_cubes = d_verts.data_ptr(), d_verts.shape[0]
             a.leftover = left if left.size else None

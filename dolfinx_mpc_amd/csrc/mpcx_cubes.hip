@@ -632,9 +632,9 @@ __global__ void __launch_bounds__(VCUBE_THREADS) vector_cube_kernel(mpcx_vector_
 __constant__ mpcx_box14::Tables c_box14 = mpcx_box14::TABLES;
 __device__ __constant__ int g_box14_enable = 1;
 
-__device__ inline bool box14_rule(const mpcx_kernel_t& k) // (wave-uniform)
+__device__ inline bool box14_rule(const mpcx_kernel_t& k, bool honour_switch = true) // (wave-uniform)
 {
-  if (!g_box14_enable || k.nq != mpcx_box14::NQ || k.coeff_degree != 0 || !k.qpts || !k.qwts)
+  if ((honour_switch && !g_box14_enable) || k.nq != mpcx_box14::NQ || k.coeff_degree != 0 || !k.qpts || !k.qwts)
     return false;
   bool ok = true;
 #pragma unroll
@@ -702,6 +702,45 @@ __device__ inline void box14_source_fn1(const double (&X)[8][3], double c0, doub
     }
     be8[fan_vertex(t, 0)] += s0;
   }
+}
+
+// ---- ... and clusters on a tensor grid of intervals (mpcx_vector_args_t::grid_*): the factors once per interval ----------
+// A mesh of boxes whose corners lie on a tensor grid (every box mesh a generator makes) repeats the same 19 coordinates per
+// axis in every cluster of a row / column / layer.  The launch first evaluates the univariate factors for every INTERVAL
+// (box_grid_tables_kernel: (n_x + n_y + n_z) * 19 points -- 256^3 clusters: 14.6 k points instead of 1.4 G), the cluster
+// kernel then reads three rows of the table and spends two multiplications and five fma per quadrature point; it never
+// touches the coordinates.  Row of interval r (MPCX_GRID_ROW = 40 doubles): [0, 19) factor A, [20, 39) factor B, [19] = |h|:
+//   x: A = g(x - 0.9) |h| c0,  B = x |h| c0;   y: A = g(y - 0.5) |h|,  B = sin(5 pi y) |h|;   z: A = g(z - 0.1) |h|
+// so that  f |det| c0 = B_x B_y |h_z| + A_x A_y A_z  at the point (j_x, j_y, j_z).
+__global__ void __launch_bounds__(256) box_grid_tables_kernel(int n0, int n1, int n2, const double* __restrict__ iv,
+                                                              double* __restrict__ tab, const double* constants,
+                                                              mpcx_kernel_t k)
+{
+  fastmath_init_lds(); // ends in a barrier
+  if (!box14_rule(k, false))
+    __builtin_trap(); // the caller promised the rule of csrc/mpcx_box14.hpp (include/mpcx.h): fail loudly
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = i / 20, j = i - r * 20;
+  if (r >= n0 + n1 + n2)
+    return;
+  const int d = r < n0 ? 0 : (r < n0 + n1 ? 1 : 2);
+  const double lo = iv[2 * r], hi = iv[2 * r + 1];
+  const double h = hi - lo, ah = fabs(h);
+  double* row = tab + int64_t(r) * MPCX_GRID_ROW;
+  if (j == 19)
+  {
+    row[19] = ah;
+    row[39] = 0.0;
+    return;
+  }
+  const FmConsts FK = g_fm_consts;
+  const double e = c_box14.grid[j];
+  const double centre = d == 0 ? 0.9 : (d == 1 ? 0.5 : 0.1);
+  const double t = fma(h, e, lo - centre); // relative to the centre of the Gaussian, as the per-point evaluation does
+  const double g = fast_exp_nonpos_k(-(t * t) * (1.0 / 0.02), FK);
+  const double sc = d == 0 ? ah * (constants ? constants[0] : 1.0) : ah;
+  row[j] = g * sc;
+  row[20 + j] = d == 0 ? (t + 0.9) * sc : (d == 1 ? fast_sinpi_k(fma(5.0, t, 2.5), FK) * sc : 0.0);
 }
 
 constexpr int VCUBE_OWN_THREADS = 256;
@@ -803,6 +842,214 @@ __global__ void __launch_bounds__(VCUBE_OWN_MAX_THREADS) vector_cube_own_kernel(
     a.b[MPCX_ROW_POS(a, r0 + i)] += s_b[i];
   for (int i = tid; i < nhalo; i += NT)
     a.own_spill[h0 + i] = s_b[nown + i];
+}
+
+// The cluster kernel of the tensor-grid plan: owner-computes row blocks as vector_cube_own_kernel, one thread per cluster,
+// no coordinates, no transcendental function (box_grid_tables_kernel ran before it on the same stream).
+// Rows of the table a block keeps in LDS (mpcx_vector_args_t::grid_stage): the intervals its clusters sit on, per axis.
+// A tile of the numbering spans a few intervals per axis; the rows are found with a bitmap over the intervals of the axis
+// (GRID_MAXN of them at most), so a block whose clusters sit in two places (the end of one row of tiles and the start of the
+// next) stages its two groups of rows like any other.
+constexpr int GRID_CAP[3] = {64, 32, 32};
+constexpr int GRID_ROWS_LDS = GRID_CAP[0] + GRID_CAP[1] + GRID_CAP[2];
+constexpr int GRID_MAXN = 8192, GRID_WORDS = GRID_MAXN / 32;
+constexpr size_t GRID_LDS_BYTES = size_t(GRID_ROWS_LDS) * MPCX_GRID_ROW * 8 + 3 * GRID_WORDS * 4 * 2 + GRID_ROWS_LDS * 4;
+
+template <bool STAGED>
+__device__ __forceinline__ void vector_cube_grid_body(const mpcx_vector_args_t& a)
+{
+  using namespace mpcx_box14;
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* s_b = reinterpret_cast<double*>(smem);
+  const int NT = blockDim.x;
+  const int nb = a.plan.num_blocks;
+  const int per = (nb + 7) >> 3;
+  const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (b >= nb)
+    return;
+  const int tid = threadIdx.x;
+  const int r0 = a.plan.block_row0[b], r1 = a.plan.block_row0[b + 1];
+  const int64_t h0 = a.own_hoff[b], h1 = a.own_hoff[b + 1];
+  const int nown = r1 - r0, nhalo = int(h1 - h0);
+  for (int i = tid; i < nown + nhalo; i += NT)
+    s_b[i] = 0.0;
+  const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  const int32_t* __restrict__ ents = a.plan.block_ents;
+  const double* __restrict__ tabx = a.grid_tab;
+  const double* __restrict__ taby = tabx + int64_t(a.grid_n[0]) * MPCX_GRID_ROW;
+  const double* __restrict__ tabz = taby + int64_t(a.grid_n[1]) * MPCX_GRID_ROW;
+  // LDS behind the block's rows of b: staged rows (x, y, z), then per axis a bitmap over its intervals, the number of set bits
+  // before every word of it, and the interval of every staged row
+  double* s_rows = s_b + ((a.plan.max_rows + 1) & ~1);
+  uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_rows + GRID_ROWS_LDS * MPCX_GRID_ROW); // [3][GRID_WORDS]
+  int* s_wpre = reinterpret_cast<int*>(s_bits + 3 * GRID_WORDS);                            // [3][GRID_WORDS]
+  int* s_rowof = s_wpre + 3 * GRID_WORDS;                                                   // [GRID_ROWS_LDS]
+  if constexpr (STAGED)
+  {
+    for (int i = tid; i < 3 * GRID_WORDS; i += NT)
+      s_bits[i] = 0;
+    __syncthreads();
+    for (int64_t t = e0 + tid; t < e1; t += NT)
+    {
+      const int4 idx = reinterpret_cast<const int4*>(a.grid_idx)[ents[t]];
+      atomicOr(&s_bits[idx.x >> 5], 1u << (idx.x & 31));
+      atomicOr(&s_bits[GRID_WORDS + (idx.y >> 5)], 1u << (idx.y & 31));
+      atomicOr(&s_bits[2 * GRID_WORDS + (idx.z >> 5)], 1u << (idx.z & 31));
+    }
+    __syncthreads();
+    if (tid < 3) // (a few words per axis on a tensor grid: a serial count)
+    {
+      const int nw = (a.grid_n[tid] + 31) >> 5;
+      int run = 0;
+      for (int w = 0; w < nw; ++w)
+      {
+        s_wpre[tid * GRID_WORDS + w] = run;
+        run += __popc(s_bits[tid * GRID_WORDS + w]);
+      }
+      if (run > GRID_CAP[tid])
+        __builtin_trap(); // mpcx_vector_args_t::grid_stage promised that the rows of every block fit
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+    {
+      const int base = d == 0 ? 0 : (d == 1 ? GRID_CAP[0] : GRID_CAP[0] + GRID_CAP[1]);
+      for (int r = tid; r < a.grid_n[d]; r += NT)
+      {
+        const uint32_t word = s_bits[d * GRID_WORDS + (r >> 5)];
+        if ((word >> (r & 31)) & 1)
+          s_rowof[base + s_wpre[d * GRID_WORDS + (r >> 5)] + __popc(word & ((1u << (r & 31)) - 1))] = r;
+      }
+    }
+    __syncthreads();
+    {
+      const int nsx = s_wpre[((a.grid_n[0] + 31) >> 5) - 1] + __popc(s_bits[((a.grid_n[0] + 31) >> 5) - 1]);
+      const int nsy = s_wpre[GRID_WORDS + ((a.grid_n[1] + 31) >> 5) - 1] + __popc(s_bits[GRID_WORDS + ((a.grid_n[1] + 31) >> 5) - 1]);
+      const int nsz = s_wpre[2 * GRID_WORDS + ((a.grid_n[2] + 31) >> 5) - 1]
+                      + __popc(s_bits[2 * GRID_WORDS + ((a.grid_n[2] + 31) >> 5) - 1]);
+      for (int i = tid; i < GRID_ROWS_LDS * MPCX_GRID_ROW; i += NT)
+      {
+        const int slot = i / MPCX_GRID_ROW, j = i - slot * MPCX_GRID_ROW;
+        const int d = slot < GRID_CAP[0] ? 0 : (slot < GRID_CAP[0] + GRID_CAP[1] ? 1 : 2);
+        const int local = slot - (d == 0 ? 0 : (d == 1 ? GRID_CAP[0] : GRID_CAP[0] + GRID_CAP[1]));
+        if (local < (d == 0 ? nsx : (d == 1 ? nsy : nsz)))
+          s_rows[i] = (d == 0 ? tabx : (d == 1 ? taby : tabz))[int64_t(s_rowof[slot]) * MPCX_GRID_ROW + j];
+      }
+    }
+  }
+  __syncthreads();
+  // staged row of interval i of axis d
+  auto slot = [&](int d, int i) -> int
+  {
+    const uint32_t word = s_bits[d * GRID_WORDS + (i >> 5)];
+    return (d == 0 ? 0 : (d == 1 ? GRID_CAP[0] : GRID_CAP[0] + GRID_CAP[1])) + s_wpre[d * GRID_WORDS + (i >> 5)]
+           + __popc(word & ((1u << (i & 31)) - 1));
+  };
+  for (int64_t t = e0 + tid; t < e1; t += NT)
+  {
+    const int64_t c = ents[t];
+    const int4 idx = reinterpret_cast<const int4*>(a.grid_idx)[c];
+    const double* __restrict__ rx = STAGED ? s_rows + slot(0, idx.x) * MPCX_GRID_ROW : tabx + int64_t(idx.x) * MPCX_GRID_ROW;
+    const double* __restrict__ ry = STAGED ? s_rows + slot(1, idx.y) * MPCX_GRID_ROW : taby + int64_t(idx.y) * MPCX_GRID_ROW;
+    const double* __restrict__ rz = STAGED ? s_rows + slot(2, idx.z) * MPCX_GRID_ROW : tabz + int64_t(idx.z) * MPCX_GRID_ROW;
+    double gy[NG + 1], sy[NG + 1], gz[NG + 1]; // (rows are 16-byte aligned: pairs; gz[NG] = |h_z|)
+    if constexpr (STAGED)
+    {
+      typedef double __attribute__((ext_vector_type(2))) pair_t;
+      typedef const __attribute__((address_space(3))) pair_t lds_pair_t;
+      const unsigned ly = unsigned(reinterpret_cast<uintptr_t>(ry)), lz = unsigned(reinterpret_cast<uintptr_t>(rz));
+#pragma unroll
+      for (int j = 0; j < NG + 1; j += 2)
+      {
+        const pair_t u = *reinterpret_cast<lds_pair_t*>(ly + 8 * j);
+        const pair_t v = *reinterpret_cast<lds_pair_t*>(ly + 8 * (20 + j));
+        const pair_t w = *reinterpret_cast<lds_pair_t*>(lz + 8 * j);
+        gy[j] = u.x, gy[j + 1] = u.y, sy[j] = v.x, sy[j + 1] = v.y, gz[j] = w.x, gz[j + 1] = w.y;
+      }
+    }
+    else
+    {
+#pragma unroll
+      for (int j = 0; j < NG + 1; j += 2)
+      {
+        const double2 u = *reinterpret_cast<const double2*>(ry + j);
+        const double2 v = *reinterpret_cast<const double2*>(ry + 20 + j);
+        const double2 w = *reinterpret_cast<const double2*>(rz + j);
+        gy[j] = u.x, gy[j + 1] = u.y, sy[j] = v.x, sy[j + 1] = v.y, gz[j] = w.x, gz[j + 1] = w.y;
+      }
+    }
+    const double hz = gz[NG];
+    double be8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      be8[i] = 0.0;
+    // plane by plane in x: the two factors in x of a plane are loaded one plane ahead (the opaque address keeps the compiler
+    // from loading all 38 at once, and the product order from forming the 84 products g_y g_z before the first plane:
+    // either put the kernel above 256 registers)
+    [[maybe_unused]] const double* rxp = rx;
+    [[maybe_unused]] unsigned rxl = 0; // (LDS byte address of the row)
+    if constexpr (STAGED)
+      rxl = unsigned(reinterpret_cast<uintptr_t>(rx));
+    auto plane = [&](int j, double& g, double& x)
+    {
+      if constexpr (STAGED)
+      {
+        asm volatile("" : "+v"(rxl));
+        g = *reinterpret_cast<const __attribute__((address_space(3))) double*>(rxl + 8 * j);
+        x = *reinterpret_cast<const __attribute__((address_space(3))) double*>(rxl + 8 * (20 + j));
+      }
+      else
+      {
+        asm volatile("" : "+v"(rxp));
+        g = rxp[j], x = rxp[20 + j];
+      }
+    };
+    double gxn, xqn;
+    plane(0, gxn, xqn);
+#pragma unroll
+    for (int j = 0; j < NG; ++j)
+    {
+      const double gxj = gxn;
+      const double xq = xqn * hz;
+      if (j + 1 < NG)
+        plane(j + 1, gxn, xqn);
+#pragma unroll
+      for (int tet = 0; tet < 6; ++tet)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+        {
+          if (IDX[tet][q][0] != j) // (compile-time: the loops are unrolled)
+            continue;
+          const int iy = IDX[tet][q][1], iz = IDX[tet][q][2];
+          const double f = fma(xq, sy[iy], (gxj * gy[iy]) * gz[iz]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            be8[fan_vertex(tet, i)] = fma(f, c_box14.wl[WLIDX[q][i]], be8[fan_vertex(tet, i)]);
+        }
+    }
+    int32_t w[8];
+    {
+      const uint4* p = reinterpret_cast<const uint4*>(a.own_lmap + c * 8);
+      const uint4 w0 = p[0], w1 = p[1];
+      w[0] = w0.x, w[1] = w0.y, w[2] = w0.z, w[3] = w0.w, w[4] = w1.x, w[5] = w1.y, w[6] = w1.z, w[7] = w1.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (!(w[i] >> MASK_SHIFT))
+        __hip_atomic_fetch_add(s_b + (w[i] & DOF_MASK), be8[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __syncthreads();
+  for (int i = tid; i < nown; i += NT)
+    a.b[MPCX_ROW_POS(a, r0 + i)] += s_b[i];
+  for (int i = tid; i < nhalo; i += NT)
+    a.own_spill[h0 + i] = s_b[nown + i];
+}
+// (a budget of 168 registers -- three waves per SIMD -- spills the tail of the tables: 3.9 against 1.2 ms)
+template <bool STAGED>
+__global__ void __launch_bounds__(VCUBE_OWN_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
+vector_cube_grid_kernel(mpcx_vector_args_t a)
+{
+  vector_cube_grid_body<STAGED>(a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2609,6 +2856,15 @@ int launch_vector_cubes(const mpcx_vector_args_t& a)
     if (a.lds_floor > 0 && size_t(a.lds_floor) > lds && a.lds_floor <= 160 * 1024)
       lds = size_t(a.lds_floor);
     const unsigned g = 8u * unsigned((a.plan.num_blocks + 7) / 8);
+    bool grid_staged = false;
+    if (a.grid_idx != nullptr)
+    {
+      const char* e = std::getenv("MPCX_GRID_STAGE"); // (0: every cluster reads the table itself)
+      grid_staged = a.grid_stage != 0 && a.grid_n[0] <= GRID_MAXN && a.grid_n[1] <= GRID_MAXN && a.grid_n[2] <= GRID_MAXN
+                    && !(e && e[0] == '0');
+      if (grid_staged)
+        lds = ((lds + 15) & ~size_t(15)) + GRID_LDS_BYTES; // the block's rows of the table (vector_cube_grid_body)
+    }
     auto go = [&](auto kernel) -> int
     {
       if (int rc = check(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2630,7 +2886,20 @@ int launch_vector_cubes(const mpcx_vector_args_t& a)
         grid_on = want;
       }
     }
-    if (int rc = k.fn_id == 1 ? go(vector_cube_own_kernel<1>) : go(vector_cube_own_kernel<-1>))
+    if (a.grid_idx != nullptr)
+    {
+      if (k.fn_id != 1 || !a.grid_iv || !a.grid_tab || a.grid_n[0] <= 0 || a.grid_n[1] <= 0 || a.grid_n[2] <= 0)
+      {
+        mpcx_set_error("mpcx_assemble_vector: grid_idx needs kernel.fn_id = 1, grid_iv, grid_tab and three interval counts");
+        return -8;
+      }
+      const int rows = a.grid_n[0] + a.grid_n[1] + a.grid_n[2];
+      hipLaunchKernelGGL(box_grid_tables_kernel, dim3(unsigned((int64_t(rows) * 20 + 255) / 256)), dim3(256), 0, st, a.grid_n[0],
+                         a.grid_n[1], a.grid_n[2], a.grid_iv, a.grid_tab, a.constants, k);
+      if (int rc = grid_staged ? go(vector_cube_grid_kernel<true>) : go(vector_cube_grid_kernel<false>))
+        return rc;
+    }
+    else if (int rc = k.fn_id == 1 ? go(vector_cube_own_kernel<1>) : go(vector_cube_own_kernel<-1>))
       return rc;
     if (a.n_own_rows > 0)
       if (int rc = launch_vector_spill_reduce(a, 1))

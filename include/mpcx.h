@@ -33,7 +33,7 @@ extern "C" {
  *    mpcx_lifting_args_t::row_map
  * 10: lds_floor (before ``stream``) of the matrix and the vector argument block: occupancy cap of one launch, so that a kernel
  *    of another stream finds room on every CU (co-running matrix and vector assembly); mpcx_kernel_t::vphi (last field) */
-#define MPCX_VERSION 10
+#define MPCX_VERSION 11
 
 /* Offsets into the CSR value / column arrays (rowptr entries, positions): 64-bit, so that one GPU can
  * hold matrices with more than 2^31 - 1 stored entries (Taylor-Hood a00 on 128^3 cells: 4.4 G) -- PETSc's
@@ -661,9 +661,27 @@ typedef struct
    * entry d of its own numbering goes to b[row_map[d]] -- DEVICE [scalar dofs] int32 -- instead of b[d]; NULL: b[d].
    * float64 kernels only. */
   const int32_t* row_map;
+  /* MPCX_ALG_CUBE, owner-computes, kernel.fn_id = 1 (python/benchmarks/bench_periodic.py:85-89) with the 14-point rule of
+   * degree 5 as kernel.qpts / qwts (the values of csrc/mpcx_box14.hpp; the launch compares and traps on a mismatch), every
+   * cluster an axis-aligned box: the clusters on a TENSOR GRID of intervals (optional; grid_idx = NULL: every cluster from
+   * its own vertices).  Interval i of axis d is (grid_iv[2 r], grid_iv[2 r + 1]) = (coordinate of corner 0, of corner 7),
+   * r = i + grid_n[0] (d >= 1) + grid_n[1] (d = 2); grid_idx DEVICE [n_cubes][4] = the intervals (x, y, z, unused) of every
+   * cluster.  The launch first fills grid_tab (DEVICE scratch, MPCX_GRID_ROW doubles per interval) with the univariate
+   * factors of the right-hand side at the 19 coordinates the rule puts into an interval -- f = x sin(5 pi y) + g(x) g(y) g(z)
+   * is a sum of products of them -- and the cluster kernel reads them instead of evaluating 84 sines and exponentials per
+   * cluster: (n_x + n_y + n_z) * 19 evaluations per factor and LAUNCH (nothing is kept between launches).
+   * grid_stage != 0: the caller has checked that the clusters of every block of `plan` sit on at most 64 / 32 / 32 distinct
+   * x / y / z intervals (a tile of the numbering does): the blocks then keep their rows of the table in LDS (the launch
+   * traps if a block does not fit); 0: every cluster reads the table itself. */
+  const int32_t* grid_idx;
+  const double* grid_iv;
+  double* grid_tab;
+  int32_t grid_n[3];
+  int32_t grid_stage;
   int32_t lds_floor; /* as mpcx_matrix_args_t::lds_floor: minimum dynamic LDS per workgroup of the row-block / cluster launch */
   void* stream;
 } mpcx_vector_args_t;
+#define MPCX_GRID_ROW 40 /* doubles per interval of mpcx_vector_args_t::grid_tab */
 #define MPCX_ROW_POS(a, d) ((a).row_map ? (int64_t)(a).row_map[d] : (int64_t)(d))
 
 int mpcx_assemble_vector(const mpcx_vector_args_t* args);

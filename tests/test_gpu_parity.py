@@ -315,19 +315,29 @@ def test_cluster_vector_kernel_variants(oracle, n, reorder, bc, env, monkeypatch
     _close(out["A"].data, ref["A"].data, RTOL_A, f"{case.name} A [{env}]")
 
 
-@pytest.mark.parametrize("grid", ["1", "0"])
+@pytest.mark.parametrize("mode", ["tensor", "box", "points"])
 @pytest.mark.parametrize("shape", ["cube", "stretched", "mirrored", "half_warped", "warped"])
-def test_cluster_vector_on_the_tensor_grid_of_a_box(oracle, shape, grid, monkeypatch):
-    """the benchmark's right-hand side on clusters that are axis-aligned boxes is evaluated factor by factor on the 19
-    coordinates per axis the 14-point rule puts into a box (csrc/mpcx_box14.hpp; MPCX_BOX_GRID=0: point by point): cubes,
-    boxes with three different edges, a mirrored numbering (negative edge), a mesh where only some clusters are boxes and
-    one where none is -- all against the oracle, and the two evaluations against each other"""
+def test_cluster_vector_on_the_tensor_grid_of_a_box(oracle, shape, mode, monkeypatch):
+    """the benchmark's right-hand side on clusters that are axis-aligned boxes: (tensor) its univariate factors from a table
+    filled once per launch and interval of the mesh's tensor grid (mpcx_vector_args_t::grid_*), (box, MPCX_TENSOR_GRID=0)
+    evaluated per cluster on the 19 coordinates per axis the 14-point rule puts into a box (csrc/mpcx_box14.hpp), (points,
+    MPCX_BOX_GRID=0) point by point.  Cubes, boxes with three different edges, a mirrored numbering (negative edge), a mesh
+    where only some clusters are boxes and one where none is -- all against the oracle, and the evaluations against each other"""
+    import importlib
+
     import dolfinx_mpc_amd as dm
     from dolfinx_mpc_amd import fem
+    from dolfinx_mpc_amd.la import create_vector
     from dolfinx_mpc_amd.mesh import create_unit_cube
     from problems import Case, _walls_yz, periodic_raw
 
-    monkeypatch.setenv("MPCX_BOX_GRID", grid)
+    env = {"tensor": ("1", "1"), "box": ("1", "0"), "points": ("0", "0")}
+
+    def select(m):
+        monkeypatch.setenv("MPCX_BOX_GRID", env[m][0])
+        monkeypatch.setenv("MPCX_TENSOR_GRID", env[m][1])
+
+    select(mode)
     if shape in ("half_warped", "warped"):
         case = case_cube_periodic(6, 1, 0.0, reorder=(2, 2, 2), warp="half" if shape == "half_warped" else True)
     else:
@@ -341,23 +351,40 @@ def test_cluster_vector_on_the_tensor_grid_of_a_box(oracle, shape, grid, monkeyp
         mesh.geometry.x = x
         V = fem.functionspace(mesh, ("Lagrange", 1))
         bc = fem.dirichletbc(0.0, fem.locate_dofs_geometrical(V, _walls_yz), V)
-        case = Case("box_" + shape, V, fem.form_stiffness(V), fem.form_source(V, fem.FN_BENCH_PERIODIC), [bc], periodic_raw(V, [bc]))
+        case = Case("box_" + shape, V, fem.form_stiffness(V, constant=1.3), fem.form_source(V, fem.FN_BENCH_PERIODIC, constant=0.7),
+                    [bc], periodic_raw(V, [bc]))
     ref = oracle_outputs(oracle, case)
     mpc = product_mpc(case)
-    import importlib
-
-    from dolfinx_mpc_amd.la import create_vector
-
     av = importlib.import_module("dolfinx_mpc_amd.assemble_vector")
-    assert av.vector_args(case.L, 0, create_vector(case.V), mpc, 0)[0].kernel_name == "cube_own", "the cluster kernel was expected to run"
+    args = av.vector_args(case.L, 0, create_vector(case.V), mpc, 0)[0]
+    assert args.kernel_name == "cube_own", "the cluster kernel was expected to run"
+    boxes = shape in ("cube", "stretched", "mirrored")
+    assert bool(args.grid_idx) == (mode == "tensor" and boxes), "tensor-grid tables: exactly on meshes of boxes"
     got = dm.assemble_vector(case.L, mpc).numpy().copy()
-    _close(got, ref["b"], RTOL_B, f"{case.name} b [MPCX_BOX_GRID={grid}]")
-    if grid == "1":
-        monkeypatch.setenv("MPCX_BOX_GRID", "0")
+    _close(got, ref["b"], RTOL_B, f"{case.name} b [{mode}]")
+    if mode != "points":
+        select("points")
         other = dm.assemble_vector(case.L, mpc).numpy()
         assert abs(other - got).max() <= 1e-14 * abs(ref["b"]).max()
-        if shape in ("cube", "stretched", "mirrored"):
-            assert not np.array_equal(other, got), "the two evaluations round differently: the switch had no effect"
+        if boxes:
+            assert not np.array_equal(other, got), "the evaluations round differently: the switch had no effect"
+    if mode == "tensor" and boxes:
+        # moving the mesh rebuilds the intervals (geometry version in the cache key); a mesh that is no longer made of
+        # boxes drops back to the per-cluster evaluation
+        select("tensor")
+        x = case.V.mesh.geometry.x.copy()
+        x[:, 0] = x[:, 0] * (1.0 + 0.25 * x[:, 0])  # still a tensor grid, no longer uniform in x
+        case.V.mesh.geometry.x = x
+        ref2 = oracle_outputs(oracle, case)
+        args = av.vector_args(case.L, 0, create_vector(case.V), mpc, 0)[0]
+        assert bool(args.grid_idx)
+        _close(dm.assemble_vector(case.L, mpc).numpy(), ref2["b"], RTOL_B, f"{case.name} b after the mesh moved")
+        x[:, 1] += 0.02 * np.sin(3.0 * x[:, 0])  # sheared: no boxes
+        case.V.mesh.geometry.x = x
+        ref3 = oracle_outputs(oracle, case)
+        args = av.vector_args(case.L, 0, create_vector(case.V), mpc, 0)[0]
+        assert not bool(args.grid_idx)
+        _close(dm.assemble_vector(case.L, mpc).numpy(), ref3["b"], RTOL_B, f"{case.name} b after the mesh was sheared")
 
 
 def test_cluster_plan_uses_narrow_and_wide_records(oracle):

@@ -47,6 +47,7 @@ def test_ctypes_structs_match_header_field_order():
         for decl in body.split(";"):
             decl = decl.strip()
             if decl:
+                decl = re.sub(r"\[[^\]]*\]\s*$", "", decl)  # (arrays: int32_t grid_n[3])
                 names.append(re.findall(r"([A-Za-z_0-9]+)\s*$", decl)[0])
         return names
 

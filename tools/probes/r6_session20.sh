@@ -1,0 +1,15 @@
+#!/bin/bash
+# round 6, session 20: config 2's right-hand side from per-interval tables of the mesh's tensor grid
+cd /root/repo
+mkdir -p gpurun_out/r6s20
+timeout 1500 python -m pytest tests/test_gpu_parity.py -q -x -m gpu -k "tensor_grid or cluster_vector" > gpurun_out/r6s20/tests.txt 2>&1
+tail -5 gpurun_out/r6s20/tests.txt
+for mode in "MPCX_VGRID_WAVES=2" "MPCX_VGRID_WAVES=3" "MPCX_TENSOR_GRID=0" "MPCX_BOX_GRID=0"; do
+  echo "== $mode"
+  env $mode timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-traffic --no-sub-records --cpu-allcores 0 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        r=json.loads(l); print(r['ms_per_step'], r['value'], r.get('roofline',{}).get('launch_ms'), r.get('roofline',{}).get('kernel'))
+"
+done 2>&1 | tee gpurun_out/r6s20/bench.txt
