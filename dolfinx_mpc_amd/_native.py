@@ -198,7 +198,7 @@ class VectorArgs(C.Structure):
         ("grid_iv", C.c_void_p),
         ("grid_tab", C.c_void_p),
         ("grid_n", C.c_int32 * 3),
-        ("grid_stage", C.c_int32),
+        ("grid_block_rows", C.c_void_p),
         ("lds_floor", C.c_int32),
         ("stream", C.c_void_p),
     ]

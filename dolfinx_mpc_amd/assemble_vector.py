@@ -303,24 +303,38 @@ def _cluster_grid(mesh, d_verts):
     return D.cached(mesh._device, "vcube_grid", (d_verts,), (mesh.geometry.version,), build, maxsize=2)
 
 
-GRID_CAP = (64, 32, 32)  # rows per axis a block stages in LDS (csrc/mpcx_cubes.hip GRID_CAP)
+GRID_BLOCK_ROWS = 128  # MPCX_GRID_BLOCK_ROWS of include/mpcx.h
 
 
-def _blocks_fit(pk, idx, ns) -> bool:
-    """do the clusters of every block of an owner plan sit on at most GRID_CAP distinct intervals per axis?"""
+def _block_rows(pk, idx, ns):
+    """Per block of an owner plan the table rows its clusters need, and per cluster the positions of its three rows in the
+    list of its block (mpcx_vector_args_t::grid_block_rows): (block_rows [nb][128] int32, local idx [n][4] int32), or None
+    when a block needs more than 128 rows (no tiles in the numbering: the clusters then read the table itself)."""
     import torch
 
     off, ents = pk[1], pk[2]
-    n = off.numel() - 1
-    if n <= 0 or ents.numel() == 0 or max(ns) > 8192:
-        return False
-    blk = torch.repeat_interleave(torch.arange(n, device=ents.device), (off[1:] - off[:-1]).long())
-    e = ents.long()
+    nb = off.numel() - 1
+    if nb <= 0 or ents.numel() == 0:
+        return None
+    dev = ents.device
+    blk = torch.repeat_interleave(torch.arange(nb, device=dev), (off[1:] - off[:-1]).long())
+    of_cluster = torch.zeros(idx.shape[0], dtype=torch.int64, device=dev)
+    of_cluster[ents.long()] = blk
+    ntot = sum(ns)
+    key = torch.cat([of_cluster * ntot + (idx[:, d].long() + sum(ns[:d])) for d in range(3)])  # (block, table row) pairs
+    uniq, inv = torch.unique(key, return_inverse=True)  # sorted: the rows of a block are consecutive, x then y then z
+    ublk = uniq // ntot
+    counts = torch.bincount(ublk, minlength=nb)
+    if int(counts.max().item()) > GRID_BLOCK_ROWS:
+        return None
+    starts = torch.cumsum(counts, 0) - counts
+    rows = torch.full((nb, GRID_BLOCK_ROWS), -1, dtype=torch.int32, device=dev)
+    rows[ublk, torch.arange(uniq.numel(), device=dev) - starts[ublk]] = (uniq % ntot).to(torch.int32)
+    n = idx.shape[0]
+    local = torch.zeros((n, 4), dtype=torch.int32, device=dev)
     for d in range(3):
-        u = torch.unique(blk * ns[d] + idx[:, d][e].long())
-        if int(torch.bincount(u // ns[d], minlength=n).max().item()) > GRID_CAP[d]:
-            return False
-    return True
+        local[:, d] = (inv[d * n:(d + 1) * n] - starts[of_cluster]).to(torch.int32)
+    return rows.contiguous(), local.contiguous()
 
 
 def _grid_rule(k) -> bool:
@@ -469,9 +483,14 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
                                        lambda: torch.empty(sum(grid[2]) * GRID_ROW, dtype=torch.float64, device=grid[0].device))
                         a.grid_idx, a.grid_iv, a.grid_tab = grid[0].data_ptr(), grid[1].data_ptr(), tab.data_ptr()
                         a.grid_n[0], a.grid_n[1], a.grid_n[2] = grid[2]
-                        # do the intervals under every block's clusters fit the LDS copy the blocks keep of their rows?
-                        a.grid_stage = D.cached(form._device, "grid_stage", (grid[0], pk), i,
-                                                lambda: int(_blocks_fit(pk, grid[0], grid[2])))
+                        # the rows of the table every block needs (kept in LDS by the blocks), the clusters numbered by them
+                        staged = None
+                        if os.environ.get("MPCX_GRID_STAGE", "1") != "0":
+                            staged = D.cached(form._device, "grid_block_rows", (grid[0], pk), i,
+                                              lambda: _block_rows(pk, grid[0], grid[2]))
+                        if staged is not None:
+                            a.grid_block_rows, a.grid_idx = staged[0].data_ptr(), staged[1].data_ptr()
+                            keep += [staged]
                         a.tensor_grid = True  # (python attribute)
                         keep += [grid, tab]
             a.algorithm = 3

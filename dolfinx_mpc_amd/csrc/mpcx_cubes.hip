@@ -846,14 +846,13 @@ __global__ void __launch_bounds__(VCUBE_OWN_MAX_THREADS) vector_cube_own_kernel(
 
 // The cluster kernel of the tensor-grid plan: owner-computes row blocks as vector_cube_own_kernel, one thread per cluster,
 // no coordinates, no transcendental function (box_grid_tables_kernel ran before it on the same stream).
-// Rows of the table a block keeps in LDS (mpcx_vector_args_t::grid_stage): the intervals its clusters sit on, per axis.
-// A tile of the numbering spans a few intervals per axis; the rows are found with a bitmap over the intervals of the axis
-// (GRID_MAXN of them at most), so a block whose clusters sit in two places (the end of one row of tiles and the start of the
-// next) stages its two groups of rows like any other.
-constexpr int GRID_CAP[3] = {64, 32, 32};
-constexpr int GRID_ROWS_LDS = GRID_CAP[0] + GRID_CAP[1] + GRID_CAP[2];
-constexpr int GRID_MAXN = 8192, GRID_WORDS = GRID_MAXN / 32;
-constexpr size_t GRID_LDS_BYTES = size_t(GRID_ROWS_LDS) * MPCX_GRID_ROW * 8 + 3 * GRID_WORDS * 4 * 2 + GRID_ROWS_LDS * 4;
+// Rows of the table a block keeps in LDS (mpcx_vector_args_t::grid_block_rows): the intervals its clusters sit on, per axis
+// -- a tile of the numbering spans a few of them.  The plan lists them per block and numbers the clusters' intervals by
+// their LDS row, so a block whose clusters sit in two places (the end of one row of tiles and the start of the next) stages
+// its two groups of rows like any other.  Rows of 42 doubles in LDS: with the table's 40 (80 dwords, 16 mod 32) the rows of
+// a wave's clusters fall on two groups of banks; 84 dwords = 20 mod 32 puts eight rows on eight groups of four banks.
+constexpr int GRID_LROW = 42;
+constexpr size_t GRID_LDS_BYTES = size_t(MPCX_GRID_BLOCK_ROWS) * GRID_LROW * 8;
 
 template <bool STAGED>
 __device__ __forceinline__ void vector_cube_grid_body(const mpcx_vector_args_t& a)
@@ -878,80 +877,47 @@ __device__ __forceinline__ void vector_cube_grid_body(const mpcx_vector_args_t& 
   const double* __restrict__ tabx = a.grid_tab;
   const double* __restrict__ taby = tabx + int64_t(a.grid_n[0]) * MPCX_GRID_ROW;
   const double* __restrict__ tabz = taby + int64_t(a.grid_n[1]) * MPCX_GRID_ROW;
-  // LDS behind the block's rows of b: staged rows (x, y, z), then per axis a bitmap over its intervals, the number of set bits
-  // before every word of it, and the interval of every staged row
+  // LDS behind the block's rows of b: the rows of the table the plan lists for the block
   double* s_rows = s_b + ((a.plan.max_rows + 1) & ~1);
-  uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_rows + GRID_ROWS_LDS * MPCX_GRID_ROW); // [3][GRID_WORDS]
-  int* s_wpre = reinterpret_cast<int*>(s_bits + 3 * GRID_WORDS);                            // [3][GRID_WORDS]
-  int* s_rowof = s_wpre + 3 * GRID_WORDS;                                                   // [GRID_ROWS_LDS]
   if constexpr (STAGED)
   {
-    for (int i = tid; i < 3 * GRID_WORDS; i += NT)
-      s_bits[i] = 0;
-    __syncthreads();
-    for (int64_t t = e0 + tid; t < e1; t += NT)
+    const int32_t* __restrict__ br = a.grid_block_rows + int64_t(b) * MPCX_GRID_BLOCK_ROWS;
+    for (int i = tid; i < MPCX_GRID_BLOCK_ROWS * MPCX_GRID_ROW; i += NT)
     {
-      const int4 idx = reinterpret_cast<const int4*>(a.grid_idx)[ents[t]];
-      atomicOr(&s_bits[idx.x >> 5], 1u << (idx.x & 31));
-      atomicOr(&s_bits[GRID_WORDS + (idx.y >> 5)], 1u << (idx.y & 31));
-      atomicOr(&s_bits[2 * GRID_WORDS + (idx.z >> 5)], 1u << (idx.z & 31));
-    }
-    __syncthreads();
-    if (tid < 3) // (a few words per axis on a tensor grid: a serial count)
-    {
-      const int nw = (a.grid_n[tid] + 31) >> 5;
-      int run = 0;
-      for (int w = 0; w < nw; ++w)
-      {
-        s_wpre[tid * GRID_WORDS + w] = run;
-        run += __popc(s_bits[tid * GRID_WORDS + w]);
-      }
-      if (run > GRID_CAP[tid])
-        __builtin_trap(); // mpcx_vector_args_t::grid_stage promised that the rows of every block fit
-    }
-    __syncthreads();
-#pragma unroll
-    for (int d = 0; d < 3; ++d)
-    {
-      const int base = d == 0 ? 0 : (d == 1 ? GRID_CAP[0] : GRID_CAP[0] + GRID_CAP[1]);
-      for (int r = tid; r < a.grid_n[d]; r += NT)
-      {
-        const uint32_t word = s_bits[d * GRID_WORDS + (r >> 5)];
-        if ((word >> (r & 31)) & 1)
-          s_rowof[base + s_wpre[d * GRID_WORDS + (r >> 5)] + __popc(word & ((1u << (r & 31)) - 1))] = r;
-      }
-    }
-    __syncthreads();
-    {
-      const int nsx = s_wpre[((a.grid_n[0] + 31) >> 5) - 1] + __popc(s_bits[((a.grid_n[0] + 31) >> 5) - 1]);
-      const int nsy = s_wpre[GRID_WORDS + ((a.grid_n[1] + 31) >> 5) - 1] + __popc(s_bits[GRID_WORDS + ((a.grid_n[1] + 31) >> 5) - 1]);
-      const int nsz = s_wpre[2 * GRID_WORDS + ((a.grid_n[2] + 31) >> 5) - 1]
-                      + __popc(s_bits[2 * GRID_WORDS + ((a.grid_n[2] + 31) >> 5) - 1]);
-      for (int i = tid; i < GRID_ROWS_LDS * MPCX_GRID_ROW; i += NT)
-      {
-        const int slot = i / MPCX_GRID_ROW, j = i - slot * MPCX_GRID_ROW;
-        const int d = slot < GRID_CAP[0] ? 0 : (slot < GRID_CAP[0] + GRID_CAP[1] ? 1 : 2);
-        const int local = slot - (d == 0 ? 0 : (d == 1 ? GRID_CAP[0] : GRID_CAP[0] + GRID_CAP[1]));
-        if (local < (d == 0 ? nsx : (d == 1 ? nsy : nsz)))
-          s_rows[i] = (d == 0 ? tabx : (d == 1 ? taby : tabz))[int64_t(s_rowof[slot]) * MPCX_GRID_ROW + j];
-      }
+      const int slot = i / MPCX_GRID_ROW, j = i - slot * MPCX_GRID_ROW;
+      const int r = br[slot];
+      if (r >= 0)
+        s_rows[slot * GRID_LROW + j] = tabx[int64_t(r) * MPCX_GRID_ROW + j];
     }
   }
   __syncthreads();
-  // staged row of interval i of axis d
-  auto slot = [&](int d, int i) -> int
+  // the cluster id and the intervals of a thread's NEXT cluster are loaded while it works on the current one, the LDS
+  // positions of the current one before its arithmetic: one exposed round trip per cluster instead of three
+  int64_t cn = 0;
+  int4 idxn = {0, 0, 0, 0};
+  if (e0 + tid < e1)
   {
-    const uint32_t word = s_bits[d * GRID_WORDS + (i >> 5)];
-    return (d == 0 ? 0 : (d == 1 ? GRID_CAP[0] : GRID_CAP[0] + GRID_CAP[1])) + s_wpre[d * GRID_WORDS + (i >> 5)]
-           + __popc(word & ((1u << (i & 31)) - 1));
-  };
+    cn = ents[e0 + tid];
+    idxn = reinterpret_cast<const int4*>(a.grid_idx)[cn];
+  }
   for (int64_t t = e0 + tid; t < e1; t += NT)
   {
-    const int64_t c = ents[t];
-    const int4 idx = reinterpret_cast<const int4*>(a.grid_idx)[c];
-    const double* __restrict__ rx = STAGED ? s_rows + slot(0, idx.x) * MPCX_GRID_ROW : tabx + int64_t(idx.x) * MPCX_GRID_ROW;
-    const double* __restrict__ ry = STAGED ? s_rows + slot(1, idx.y) * MPCX_GRID_ROW : taby + int64_t(idx.y) * MPCX_GRID_ROW;
-    const double* __restrict__ rz = STAGED ? s_rows + slot(2, idx.z) * MPCX_GRID_ROW : tabz + int64_t(idx.z) * MPCX_GRID_ROW;
+    const int64_t c = cn;
+    const int4 idx = idxn;
+    int32_t w[8];
+    {
+      const uint4* p = reinterpret_cast<const uint4*>(a.own_lmap + c * 8);
+      const uint4 w0 = p[0], w1 = p[1];
+      w[0] = w0.x, w[1] = w0.y, w[2] = w0.z, w[3] = w0.w, w[4] = w1.x, w[5] = w1.y, w[6] = w1.z, w[7] = w1.w;
+    }
+    if (t + NT < e1)
+    {
+      cn = ents[t + NT];
+      idxn = reinterpret_cast<const int4*>(a.grid_idx)[cn];
+    }
+    const double* __restrict__ rx = STAGED ? s_rows + idx.x * GRID_LROW : tabx + int64_t(idx.x) * MPCX_GRID_ROW;
+    const double* __restrict__ ry = STAGED ? s_rows + idx.y * GRID_LROW : taby + int64_t(idx.y) * MPCX_GRID_ROW;
+    const double* __restrict__ rz = STAGED ? s_rows + idx.z * GRID_LROW : tabz + int64_t(idx.z) * MPCX_GRID_ROW;
     double gy[NG + 1], sy[NG + 1], gz[NG + 1]; // (rows are 16-byte aligned: pairs; gz[NG] = |h_z|)
     if constexpr (STAGED)
     {
@@ -1027,11 +993,34 @@ __device__ __forceinline__ void vector_cube_grid_body(const mpcx_vector_args_t& 
             be8[fan_vertex(tet, i)] = fma(f, c_box14.wl[WLIDX[q][i]], be8[fan_vertex(tet, i)]);
         }
     }
-    int32_t w[8];
+    // Neighbouring clusters share vertices, and neighbouring lanes usually hold neighbouring clusters (a tile lists its
+    // clusters row by row): a lane hands the sums of the vertices it shares with the lane one / eight to its right (the
+    // next cluster in x / in y of a tile eight clusters wide) over to that lane instead of adding them to LDS itself --
+    // whenever the LDS positions agree, whatever the order of the list.  Interior clusters are left with two LDS adds out
+    // of eight: the fp64 LDS adds (about 90 cycles each with their bank conflicts) kept the LDS pipe of a CU busy half of
+    // the kernel's time and the table reads of the other waves behind them.
+    if (__ballot(1) == ~0ull) // (full waves only: lane shifts)
     {
-      const uint4* p = reinterpret_cast<const uint4*>(a.own_lmap + c * 8);
-      const uint4 w0 = p[0], w1 = p[1];
-      w[0] = w0.x, w[1] = w0.y, w[2] = w0.z, w[3] = w0.w, w[4] = w1.x, w[5] = w1.y, w[6] = w1.z, w[7] = w1.w;
+      auto fold = [&](auto shr_c, auto shl_c, int dst, int src)
+      {
+        constexpr int SHR = decltype(shr_c)::value, SHL = decltype(shl_c)::value;
+        const int wl_ = __builtin_amdgcn_update_dpp(-1, w[src], SHR, 0xf, 0xf, false); // (no lane to the left in the row: -1)
+        const unsigned long long v = __double_as_longlong(be8[src]);
+        const int lo = __builtin_amdgcn_update_dpp(0, int(unsigned(v)), SHR, 0xf, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, int(unsigned(v >> 32)), SHR, 0xf, 0xf, false);
+        const bool take = wl_ == w[dst] && !(w[dst] >> MASK_SHIFT);
+        if (take)
+          be8[dst] += __longlong_as_double((long long)((unsigned long long)unsigned(hi) << 32 | unsigned(lo)));
+        const int given = __builtin_amdgcn_update_dpp(0, int(take), SHL, 0xf, 0xf, false);
+        if (given)
+          w[src] = -1; // (flag bits set: skipped below)
+      };
+      constexpr std::integral_constant<int, 0x111> X_SHR{}; // row_shr:1 / row_shl:1 / row_shr:8 / row_shl:8
+      constexpr std::integral_constant<int, 0x101> X_SHL{};
+      constexpr std::integral_constant<int, 0x118> Y_SHR{};
+      constexpr std::integral_constant<int, 0x108> Y_SHL{};
+      fold(X_SHR, X_SHL, 0, 1), fold(X_SHR, X_SHL, 2, 3), fold(X_SHR, X_SHL, 4, 5), fold(X_SHR, X_SHL, 6, 7);
+      fold(Y_SHR, Y_SHL, 0, 2), fold(Y_SHR, Y_SHL, 1, 3), fold(Y_SHR, Y_SHL, 4, 6), fold(Y_SHR, Y_SHL, 5, 7);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -2859,9 +2848,7 @@ int launch_vector_cubes(const mpcx_vector_args_t& a)
     bool grid_staged = false;
     if (a.grid_idx != nullptr)
     {
-      const char* e = std::getenv("MPCX_GRID_STAGE"); // (0: every cluster reads the table itself)
-      grid_staged = a.grid_stage != 0 && a.grid_n[0] <= GRID_MAXN && a.grid_n[1] <= GRID_MAXN && a.grid_n[2] <= GRID_MAXN
-                    && !(e && e[0] == '0');
+      grid_staged = a.grid_block_rows != nullptr;
       if (grid_staged)
         lds = ((lds + 15) & ~size_t(15)) + GRID_LDS_BYTES; // the block's rows of the table (vector_cube_grid_body)
     }

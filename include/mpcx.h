@@ -670,18 +670,21 @@ typedef struct
    * factors of the right-hand side at the 19 coordinates the rule puts into an interval -- f = x sin(5 pi y) + g(x) g(y) g(z)
    * is a sum of products of them -- and the cluster kernel reads them instead of evaluating 84 sines and exponentials per
    * cluster: (n_x + n_y + n_z) * 19 evaluations per factor and LAUNCH (nothing is kept between launches).
-   * grid_stage != 0: the caller has checked that the clusters of every block of `plan` sit on at most 64 / 32 / 32 distinct
-   * x / y / z intervals (a tile of the numbering does): the blocks then keep their rows of the table in LDS (the launch
-   * traps if a block does not fit); 0: every cluster reads the table itself. */
+   * grid_block_rows (optional): when the clusters of every block of `plan` sit on few intervals (a tile of the numbering
+   * does) the blocks keep their rows of the table in LDS: DEVICE [num_blocks][MPCX_GRID_BLOCK_ROWS] lists, per block, the
+   * table rows r (as above) it needs, -1 = unused -- and grid_idx then holds, per cluster, the POSITIONS of its three rows
+   * in the list of the block that owns it instead of interval numbers.  NULL: grid_idx holds interval numbers and every
+   * cluster reads the table itself. */
   const int32_t* grid_idx;
   const double* grid_iv;
   double* grid_tab;
   int32_t grid_n[3];
-  int32_t grid_stage;
+  const int32_t* grid_block_rows;
   int32_t lds_floor; /* as mpcx_matrix_args_t::lds_floor: minimum dynamic LDS per workgroup of the row-block / cluster launch */
   void* stream;
 } mpcx_vector_args_t;
 #define MPCX_GRID_ROW 40 /* doubles per interval of mpcx_vector_args_t::grid_tab */
+#define MPCX_GRID_BLOCK_ROWS 128 /* table rows a block can keep in LDS (mpcx_vector_args_t::grid_block_rows) */
 #define MPCX_ROW_POS(a, d) ((a).row_map ? (int64_t)(a).row_map[d] : (int64_t)(d))
 
 int mpcx_assemble_vector(const mpcx_vector_args_t* args);
