@@ -199,6 +199,7 @@ class VectorArgs(C.Structure):
         ("grid_tab", C.c_void_p),
         ("grid_n", C.c_int32 * 3),
         ("grid_block_rows", C.c_void_p),
+        ("grid_block_rows_max", C.c_int32),
         ("lds_floor", C.c_int32),
         ("stream", C.c_void_p),
     ]

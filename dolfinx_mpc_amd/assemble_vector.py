@@ -334,7 +334,7 @@ def _block_rows(pk, idx, ns):
     local = torch.zeros((n, 4), dtype=torch.int32, device=dev)
     for d in range(3):
         local[:, d] = (inv[d * n:(d + 1) * n] - starts[of_cluster]).to(torch.int32)
-    return rows.contiguous(), local.contiguous()
+    return rows.contiguous(), local.contiguous(), int(counts.max().item())
 
 
 def _grid_rule(k) -> bool:
@@ -490,6 +490,7 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
                                               lambda: _block_rows(pk, grid[0], grid[2]))
                         if staged is not None:
                             a.grid_block_rows, a.grid_idx = staged[0].data_ptr(), staged[1].data_ptr()
+                            a.grid_block_rows_max = staged[2]
                             keep += [staged]
                         a.tensor_grid = True  # (python attribute)
                         keep += [grid, tab]

@@ -852,7 +852,6 @@ __global__ void __launch_bounds__(VCUBE_OWN_MAX_THREADS) vector_cube_own_kernel(
 // its two groups of rows like any other.  Rows of 42 doubles in LDS: with the table's 40 (80 dwords, 16 mod 32) the rows of
 // a wave's clusters fall on two groups of banks; 84 dwords = 20 mod 32 puts eight rows on eight groups of four banks.
 constexpr int GRID_LROW = 42;
-constexpr size_t GRID_LDS_BYTES = size_t(MPCX_GRID_BLOCK_ROWS) * GRID_LROW * 8;
 
 template <bool STAGED>
 __device__ __forceinline__ void vector_cube_grid_body(const mpcx_vector_args_t& a)
@@ -882,7 +881,9 @@ __device__ __forceinline__ void vector_cube_grid_body(const mpcx_vector_args_t& 
   if constexpr (STAGED)
   {
     const int32_t* __restrict__ br = a.grid_block_rows + int64_t(b) * MPCX_GRID_BLOCK_ROWS;
-    for (int i = tid; i < MPCX_GRID_BLOCK_ROWS * MPCX_GRID_ROW; i += NT)
+    const int nslots = (a.grid_block_rows_max > 0 && a.grid_block_rows_max <= MPCX_GRID_BLOCK_ROWS) ? a.grid_block_rows_max
+                                                                                                      : MPCX_GRID_BLOCK_ROWS;
+    for (int i = tid; i < nslots * MPCX_GRID_ROW; i += NT)
     {
       const int slot = i / MPCX_GRID_ROW, j = i - slot * MPCX_GRID_ROW;
       const int r = br[slot];
@@ -2850,7 +2851,12 @@ int launch_vector_cubes(const mpcx_vector_args_t& a)
     {
       grid_staged = a.grid_block_rows != nullptr;
       if (grid_staged)
-        lds = ((lds + 15) & ~size_t(15)) + GRID_LDS_BYTES; // the block's rows of the table (vector_cube_grid_body)
+      {
+        // the block's rows of the table (vector_cube_grid_body): as many as the longest list needs
+        const int rows = (a.grid_block_rows_max > 0 && a.grid_block_rows_max <= MPCX_GRID_BLOCK_ROWS) ? a.grid_block_rows_max
+                                                                                                        : MPCX_GRID_BLOCK_ROWS;
+        lds = ((lds + 15) & ~size_t(15)) + size_t(rows) * GRID_LROW * 8;
+      }
     }
     auto go = [&](auto kernel) -> int
     {

@@ -673,13 +673,14 @@ typedef struct
    * grid_block_rows (optional): when the clusters of every block of `plan` sit on few intervals (a tile of the numbering
    * does) the blocks keep their rows of the table in LDS: DEVICE [num_blocks][MPCX_GRID_BLOCK_ROWS] lists, per block, the
    * table rows r (as above) it needs, -1 = unused -- and grid_idx then holds, per cluster, the POSITIONS of its three rows
-   * in the list of the block that owns it instead of interval numbers.  NULL: grid_idx holds interval numbers and every
-   * cluster reads the table itself. */
+   * in the list of the block that owns it instead of interval numbers; grid_block_rows_max = the longest list (LDS is sized
+   * by it; 0: MPCX_GRID_BLOCK_ROWS).  NULL: grid_idx holds interval numbers and every cluster reads the table itself. */
   const int32_t* grid_idx;
   const double* grid_iv;
   double* grid_tab;
   int32_t grid_n[3];
   const int32_t* grid_block_rows;
+  int32_t grid_block_rows_max;
   int32_t lds_floor; /* as mpcx_matrix_args_t::lds_floor: minimum dynamic LDS per workgroup of the row-block / cluster launch */
   void* stream;
 } mpcx_vector_args_t;
