@@ -756,6 +756,18 @@ def main():
         k = {"kernel": f"{kname}[{label}]", "call": f"assemble_vector[{label}]", "launch_ms": tk,
              "algorithmic_bytes": int(nbytes), "pmc_name": kname}
         k["fp64_flops"] = algorithmic_flops(f.integrals[0], V0) * f.integrals[0].num_entities
+        if bool(getattr(vargs, "grid_idx", None)):
+            # the right-hand side from per-interval tables of the mesh's tensor grid (mpcx_vector_args_t::grid_*): the kernel
+            # reads 16 B of plan per cluster more and no coordinates, and does 12 flops per quadrature point (two products
+            # and an fma for f, four fma into the vertex sums) -- that count, not the quadrature formulation's ~1e3 flops per
+            # cell with a sine and an exponential per point, so that the fp64 fraction does not credit arithmetic the
+            # kernel does not do
+            kname = "vector_cube_grid_kernel"
+            k["kernel"], k["pmc_name"] = f"{kname}[{label}]", kname
+            k["fp64_flops"] = 12.0 * 14 * f.integrals[0].num_entities
+            k["algorithmic_bytes"] = int(4 * nc / 6 * (1 + 4 + 8) + 9 * V0.num_dofs)  # per cluster: list entry, intervals, LDS positions
+            k["note"] = ("tensor-grid evaluation: fp64_flops counts what the kernel executes (12 per point); the quadrature "
+                         "formulation a form compiler emits would be %.3g flops per launch" % (algorithmic_flops(f.integrals[0], V0) * nc))
         kernels.append(k)
         del keep
     for k in kernels:

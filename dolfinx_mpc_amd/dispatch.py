@@ -153,7 +153,10 @@ VECTOR: List[Kernel] = [
                       and c.cell_integral and c.all_cells and c.p1_geometry),
            lambda c: True,
            "vector_cube_own_kernel: thread per cluster, owner-computes row blocks, no device atomics; config 2: 2.75 ms "
-           "(deterministic) vs 2.82 ms (cube_hash) vs 3.24 ms (ownblock)"),
+           "(deterministic) vs 2.82 ms (cube_hash) vs 3.24 ms (ownblock).  Round 6, the benchmark's right-hand side with the "
+           "14-point rule: clusters that are axis-aligned boxes evaluate its univariate factors on the 19 coordinates per axis "
+           "the rule puts into a box (1.5 ms); on a tensor-grid mesh vector_cube_grid_kernel reads them from a table filled per "
+           "launch and interval (mpcx_vector_args_t::grid_*: 0.55 ms)"),
     Kernel("cube_hash",
            lambda c: (c.form == FORM_SOURCE and c.tet and c.d0 == 1 and c.bs0 == 1 and c.coeff_degree == 0 and not c.has_coefficient
                       and c.cell_integral and c.all_cells and c.p1_geometry),
