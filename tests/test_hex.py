@@ -212,18 +212,21 @@ def test_oracle_constrained_operators_on_hexahedra(oracle, make):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("alg", ["auto", "rowblock", "atomic", "generated", "no_affine"])
+@pytest.mark.parametrize("alg", ["auto", "rowblock", "atomic", "generated", "no_affine", "points"])
 @pytest.mark.parametrize("make", HEX_CASES, ids=[f"hex{i}" for i in range(len(HEX_CASES))])
 def test_gpu_hexahedra_match_oracle(oracle, make, alg, monkeypatch):
     """auto: the built-in hexahedron kernels where they apply (scalar stiffness / source forms without coefficient: slots
-    of (row block, cell), thread per cell) + the generated kernels for the constrained cells and everything else;
+    of (row block, cell), thread per cell; box cells evaluate the benchmark's right-hand side factor by factor on the
+    tensor grid of their Gauss points) + the generated kernels for the constrained cells and everything else;
     rowblock: built-in matrix kernel, generated vector kernel; generated: the generated kernels everywhere
-    (MPCX_NO_CUBE); no_affine: the quadrature path of the built-in matrix kernel also on parallelepipeds"""
+    (MPCX_NO_CUBE); no_affine: the quadrature path of the built-in matrix kernel also on parallelepipeds; points: the
+    right-hand side point by point on box cells too (MPCX_BOX_GRID=0)"""
     if alg == "generated":
         monkeypatch.setenv("MPCX_NO_CUBE", "1")
     if alg == "no_affine":
         monkeypatch.setenv("MPCX_HEX_NO_AFFINE", "1")
-    if alg in ("generated", "no_affine"):
+    monkeypatch.setenv("MPCX_BOX_GRID", "0" if alg == "points" else "1")
+    if alg in ("generated", "no_affine", "points"):
         alg = "auto"
     case = make()
     ref = oracle_outputs(oracle, case)
