@@ -194,6 +194,7 @@ class VectorArgs(C.Structure):
         ("cube_cells", C.c_void_p),
         ("cell_info0", C.c_void_p),
         ("row_map", C.c_void_p),
+        ("cube_boxes", C.c_int32),
         ("grid_idx", C.c_void_p),
         ("grid_iv", C.c_void_p),
         ("grid_tab", C.c_void_p),
@@ -284,6 +285,11 @@ EXPORTS = [
     "mpcx_master_plan_num_targets",
     "mpcx_master_plan_num_tuples",
     "mpcx_master_plan_destroy",
+    "mpcx_grid_plan_create",
+    "mpcx_grid_plan_fill",
+    "mpcx_grid_plan_num_intervals",
+    "mpcx_grid_plan_block_rows",
+    "mpcx_grid_plan_destroy",
     "mpcx_owner_plan_create",
     "mpcx_owner_plan_fill",
     "mpcx_owner_plan_destroy",
@@ -629,6 +635,16 @@ def lib() -> C.CDLL:
     L.mpcx_cg_step.restype = C.c_int
     L.mpcx_last_error.argtypes = []
     L.mpcx_last_error.restype = C.c_char_p
+    L.mpcx_grid_plan_create.argtypes = [vp, i64, vp, C.POINTER(RowBlockPlanT), vp, C.POINTER(vp)]
+    L.mpcx_grid_plan_create.restype = C.c_int
+    L.mpcx_grid_plan_fill.argtypes = [vp, C.POINTER(VectorArgs)]
+    L.mpcx_grid_plan_fill.restype = C.c_int
+    L.mpcx_grid_plan_num_intervals.argtypes = [vp, i32]
+    L.mpcx_grid_plan_num_intervals.restype = i32
+    L.mpcx_grid_plan_block_rows.argtypes = [vp]
+    L.mpcx_grid_plan_block_rows.restype = i32
+    L.mpcx_grid_plan_destroy.argtypes = [vp]
+    L.mpcx_grid_plan_destroy.restype = None
     L.mpcx_version.argtypes = []
     L.mpcx_version.restype = C.c_int
     L.mpcx_preload.argtypes = [vp]

@@ -271,9 +271,9 @@ def _vector_cube_owner_plan(mesh, V, d_verts, constraint, left: np.ndarray, slav
 def _cluster_grid(mesh, d_verts):
     """The tensor grid under a mesh of axis-aligned box clusters (include/mpcx.h mpcx_vector_args_t::grid_*): per axis the
     distinct intervals (coordinate of corner 0, coordinate of corner 7) of the clusters and, per cluster, which interval it
-    sits on along x, y, z.  None when a cluster is not a box with its eight vertices in corner order (compared exactly, as the
-    kernel's own per-cluster check does), or when the intervals are not few against the clusters (no tensor structure: the
-    tables would cost what they save).  Geometry only -- cached per (clusters, geometry version); every value of the
+    sits on along x, y, z.  Returns (fraction of clusters that are boxes, grid); the grid is None when a cluster is not a
+    box with its eight vertices in corner order (compared exactly, as the kernel's own per-cluster check does), or when the
+    intervals are not few against the clusters (no tensor structure: the tables would cost what they save).  Geometry only -- cached per (clusters, geometry version); every value of the
     right-hand side is still computed inside each launch."""
     import torch
 
@@ -282,11 +282,14 @@ def _cluster_grid(mesh, d_verts):
         v = d_verts.long()
         n = v.shape[0]
         X0, X7 = x[v[:, 0]], x[v[:, 7]]
+        box = torch.ones(n, dtype=torch.bool, device=x.device)
         for c in range(1, 7):
             xc = x[v[:, c]]
             for d in range(3):
-                if not bool((xc[:, d] == (X7[:, d] if (c >> d) & 1 else X0[:, d])).all()):
-                    return None
+                box &= xc[:, d] == (X7[:, d] if (c >> d) & 1 else X0[:, d])
+        frac = float(box.sum(dtype=torch.int64).item()) / max(n, 1)
+        if frac < 1.0:
+            return frac, None
         idx = torch.zeros((n, 4), dtype=torch.int32, device=x.device)
         ivs, ns = [], []
         for d in range(3):
@@ -297,8 +300,8 @@ def _cluster_grid(mesh, d_verts):
             ivs.append(torch.stack([lo_u[pair_u // hi_u.numel()], hi_u[pair_u % hi_u.numel()]], dim=1))
             ns.append(int(pair_u.numel()))
         if sum(ns) > max(4096, n // 8):
-            return None
-        return idx.contiguous(), torch.cat(ivs).contiguous(), tuple(ns)
+            return frac, None
+        return frac, (idx.contiguous(), torch.cat(ivs).contiguous(), tuple(ns))
 
     return D.cached(mesh._device, "vcube_grid", (d_verts,), (mesh.geometry.version,), build, maxsize=2)
 
@@ -471,12 +474,13 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
                 a.slave_entities, a.n_slave_entities = d_slaves.data_ptr(), d_slaves.numel()
                 keep += [pk, d_slaves]
                 if (name == "cube_own" and k.form == 2 and k.fn_id == 1 and k.coeff_degree == 0 and integ.coefficient is None
-                        and os.environ.get("MPCX_BOX_GRID", "1") != "0" and os.environ.get("MPCX_TENSOR_GRID", "1") != "0"
-                        and _grid_rule(k)):
+                        and os.environ.get("MPCX_BOX_GRID", "1") != "0" and _grid_rule(k)):
                     # the benchmark's right-hand side on box clusters of a tensor grid: its univariate factors once per
                     # interval and launch instead of 84 sines and exponentials per cluster (csrc/mpcx_cubes.hip)
-                    grid = _cluster_grid(form.mesh, d_verts)
-                    if grid is not None:
+                    boxes, grid = _cluster_grid(form.mesh, d_verts)
+                    # (a mesh with few boxes takes the lighter instance that evaluates every cluster point by point)
+                    a.cube_boxes = int(boxes >= 0.25)
+                    if grid is not None and os.environ.get("MPCX_TENSOR_GRID", "1") != "0":
                         import torch
 
                         tab = D.cached(form._device, "grid_tab", (grid[0],), i,

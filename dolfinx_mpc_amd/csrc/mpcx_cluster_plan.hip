@@ -1150,6 +1150,265 @@ extern "C" int64_t mpcx_master_plan_num_targets(const mpcx_master_plan_t* p) { r
 extern "C" int64_t mpcx_master_plan_num_tuples(const mpcx_master_plan_t* p) { return p ? p->tuples : 0; }
 extern "C" void mpcx_master_plan_destroy(mpcx_master_plan_t* p) { delete p; }
 
+// ---- the tensor grid under a mesh of box clusters (mpcx_vector_args_t::grid_*), built on the device -----------------------
+namespace
+{
+// doubles as signed 64-bit keys of the same order (-0.0 and +0.0 differ: a mesh does not hold both for one coordinate)
+__device__ inline int64_t ordered_key(double v)
+{
+  const int64_t b = __double_as_longlong(v);
+  return b >= 0 ? b : b ^ 0x7fffffffffffffffLL;
+}
+// per cluster: is it an axis-aligned box with its vertices in corner order (compared exactly, as the cluster kernel does)?
+// keys[d][c] = its low corner coordinate as a sortable key, hi[d][c] = the high corner's
+__global__ void grid_box_keys_kernel(int64_t n, const int32_t* __restrict__ verts, const double* __restrict__ x, int64_t* __restrict__ keys,
+                                     double* __restrict__ hi, int32_t* __restrict__ not_box)
+{
+  const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (c >= n)
+    return;
+  double X[8][3];
+  for (int v = 0; v < 8; ++v)
+    for (int d = 0; d < 3; ++d)
+      X[v][d] = x[3 * int64_t(verts[8 * c + v]) + d];
+  bool box = true;
+  for (int v = 1; v < 7; ++v)
+    for (int d = 0; d < 3; ++d)
+      box &= X[v][d] == (((v >> d) & 1) ? X[7][d] : X[0][d]);
+  if (!box)
+    *not_box = 1;
+  for (int d = 0; d < 3; ++d)
+  {
+    keys[d * n + c] = ordered_key(X[0][d]);
+    hi[d * n + c] = X[7][d];
+  }
+}
+// sorted by key: head[i] = 1 where a new interval starts; an interval must have ONE high end (else: no tensor grid)
+__global__ void grid_heads_kernel(int64_t n, const int64_t* __restrict__ skeys, const int32_t* __restrict__ order, const double* __restrict__ hi,
+                                  int32_t* __restrict__ head, int32_t* __restrict__ bad)
+{
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const bool h = i == 0 || skeys[i] != skeys[i - 1];
+  head[i] = h ? 1 : 0;
+  if (!h && hi != nullptr && hi[order[i]] != hi[order[i - 1]])
+    *bad = 1;
+}
+// interval of every cluster along one axis (written into column d of idx), and the interval table
+__global__ void grid_assign_kernel(int64_t n, const int32_t* __restrict__ order, const int32_t* __restrict__ head, const int32_t* __restrict__ excl,
+                                   const double* __restrict__ x, const int32_t* __restrict__ verts, const double* __restrict__ hi, int d,
+                                   int32_t* __restrict__ idx, double* __restrict__ iv)
+{
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const int32_t r = excl[i] + head[i] - 1;
+  const int64_t c = order[i];
+  idx[4 * c + d] = r;
+  if (head[i])
+  {
+    iv[2 * r] = x[3 * int64_t(verts[8 * c]) + d];
+    iv[2 * r + 1] = hi[c];
+  }
+}
+// (block << 32 | table row) of every (cluster, axis) of the plan's lists
+__global__ void grid_block_keys_kernel(int64_t nents, int32_t nb, const int64_t* __restrict__ ent_off, const int32_t* __restrict__ ents,
+                                       const int32_t* __restrict__ idx, int32_t off1, int32_t off2, int64_t* __restrict__ keys)
+{
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= nents)
+    return;
+  int lo = 0, hi = nb; // the block whose list holds position t
+  while (hi - lo > 1)
+  {
+    const int mid = (lo + hi) >> 1;
+    if (ent_off[mid] <= t)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  const int64_t c = ents[t];
+  keys[t] = (int64_t(lo) << 32) | int64_t(idx[4 * c]);
+  keys[nents + t] = (int64_t(lo) << 32) | int64_t(off1 + idx[4 * c + 1]);
+  keys[2 * nents + t] = (int64_t(lo) << 32) | int64_t(off2 + idx[4 * c + 2]);
+}
+// sorted (block, row) pairs: position of every pair in its block's list; the lists themselves
+__global__ void grid_block_rows_kernel(int64_t n3, int64_t nents, const int64_t* __restrict__ skeys, const int32_t* __restrict__ order,
+                                       const int32_t* __restrict__ head, const int32_t* __restrict__ excl, const int64_t* __restrict__ first,
+                                       const int32_t* __restrict__ ents, int32_t* __restrict__ rows, int32_t* __restrict__ local,
+                                       int32_t* __restrict__ longest)
+{
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n3)
+    return;
+  const int64_t key = skeys[i];
+  const int32_t b = int32_t(key >> 32);
+  const int64_t f = first[b];
+  const int32_t slot = (excl[i] + head[i] - 1) - (excl[f] + head[f] - 1);
+  const int32_t p = order[i]; // position in the concatenated (axis, list position) array
+  const int d = int(p / nents);
+  const int64_t c = ents[p - d * nents];
+  local[4 * c + d] = slot;
+  if (head[i])
+  {
+    if (slot < MPCX_GRID_BLOCK_ROWS)
+      rows[int64_t(b) * MPCX_GRID_BLOCK_ROWS + slot] = int32_t(key & 0xffffffff);
+    atomicMax(longest, slot + 1);
+  }
+}
+__global__ void fill_i32_kernel(int64_t n, int32_t v, int32_t* out)
+{
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n)
+    out[i] = v;
+}
+} // namespace
+
+struct mpcx_grid_plan
+{
+  Dev idx, iv, tab, rows, local;
+  int32_t n[3] = {0, 0, 0};
+  int32_t longest = 0; // 0: no block lists (grid_idx = interval numbers)
+};
+
+extern "C" int mpcx_grid_plan_create(const int32_t* cube_verts, int64_t n_cubes, const double* x, const mpcx_rowblock_plan_t* plan,
+                                     void* stream, mpcx_grid_plan_t** out)
+{
+  if (!out || !cube_verts || !x || n_cubes <= 0 || n_cubes * 3 >= (int64_t(1) << 31))
+  {
+    mpcx_set_error("mpcx_grid_plan_create: invalid arguments");
+    return -1;
+  }
+  *out = nullptr;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t n = n_cubes;
+  auto g = std::make_unique<mpcx_grid_plan>();
+  Dev keys, hi, flag, skeys, iota, order, head, excl;
+  if (keys.alloc(size_t(3 * n) * 8) || hi.alloc(size_t(3 * n) * 8) || flag.alloc(16) || skeys.alloc(size_t(n) * 8) || iota.alloc(size_t(n) * 4)
+      || order.alloc(size_t(n) * 4) || head.alloc(size_t(n) * 4) || excl.alloc(size_t(n) * 4) || g->idx.alloc(size_t(n) * 16))
+    return -100;
+  if (hip_ok(hipMemsetAsync(flag.p, 0, 16, st), "hipMemsetAsync") || hip_ok(hipMemsetAsync(g->idx.p, 0, size_t(n) * 16, st), "hipMemsetAsync"))
+    return -100;
+  hipLaunchKernelGGL(grid_box_keys_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, n, cube_verts, x, keys.as<int64_t>(), hi.as<double>(),
+                     flag.as<int32_t>());
+  hipLaunchKernelGGL(iota_i32, dim3(grid_for(n, 256)), dim3(256), 0, st, n, iota.as<int32_t>());
+  int32_t bad[2] = {0, 0};
+  if (hip_ok(hipMemcpyAsync(bad, flag.p, 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync") || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+    return -100;
+  if (bad[0])
+    return 1; // a cluster that is not a box in corner order: no plan (*out stays NULL), not an error
+  Dev ivd[3];
+  for (int d = 0; d < 3; ++d)
+  {
+    if (int rc = with_temp([&](void* t, size_t* b) { return mpcx_sort_pairs_i64_i32(keys.as<int64_t>() + d * n, skeys.as<int64_t>(), iota.as<int32_t>(),
+                                                                                    order.as<int32_t>(), n, 0, 64, t, b, stream); }))
+      return rc;
+    hipLaunchKernelGGL(grid_heads_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, n, skeys.as<int64_t>(), order.as<int32_t>(),
+                       hi.as<double>() + d * n, head.as<int32_t>(), flag.as<int32_t>() + 1);
+    if (int rc = with_temp([&](void* t, size_t* b) { return mpcx_scan_exclusive_i32(head.as<int32_t>(), n, excl.as<int32_t>(), t, b, stream); }))
+      return rc;
+    int32_t last[2] = {0, 0};
+    if (hip_ok(hipMemcpyAsync(&last[0], excl.as<int32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync")
+        || hip_ok(hipMemcpyAsync(&last[1], head.as<int32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync")
+        || hip_ok(hipMemcpyAsync(&bad[1], flag.as<int32_t>() + 1, 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync")
+        || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+      return -100;
+    if (bad[1])
+      return 1; // two clusters start at one coordinate and end at different ones: no tensor grid
+    g->n[d] = last[0] + last[1];
+    if (ivd[d].alloc(size_t(g->n[d]) * 16))
+      return -100;
+    hipLaunchKernelGGL(grid_assign_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, n, order.as<int32_t>(), head.as<int32_t>(), excl.as<int32_t>(),
+                       x, cube_verts, hi.as<double>() + d * n, d, g->idx.as<int32_t>(), ivd[d].as<double>());
+  }
+  const int64_t ntot = int64_t(g->n[0]) + g->n[1] + g->n[2];
+  if (ntot > std::max<int64_t>(4096, n / 8))
+    return 1; // intervals are not few against the clusters: the tables would cost what they save
+  if (g->iv.alloc(size_t(ntot) * 16) || g->tab.alloc(size_t(ntot) * MPCX_GRID_ROW * 8))
+    return -100;
+  for (int d = 0, o = 0; d < 3; o += g->n[d], ++d)
+    if (hip_ok(hipMemcpyAsync(g->iv.as<double>() + 2 * o, ivd[d].p, size_t(g->n[d]) * 16, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync"))
+      return -100;
+  // per block of the owner plan the rows it needs, the clusters numbered by them (optional)
+  if (plan && plan->num_blocks > 0 && plan->block_ent_off && plan->block_ents)
+  {
+    const int32_t nb = plan->num_blocks;
+    int64_t nents = 0;
+    if (hip_ok(hipMemcpyAsync(&nents, plan->block_ent_off + nb, 8, hipMemcpyDeviceToHost, st), "hipMemcpyAsync")
+        || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+      return -100;
+    const int64_t n3 = 3 * nents;
+    if (nents > 0 && n3 < (int64_t(1) << 31))
+    {
+      Dev bkeys, bskeys, biota, border, bhead, bexcl, first, longest, rows, local;
+      if (bkeys.alloc(size_t(n3) * 8) || bskeys.alloc(size_t(n3) * 8) || biota.alloc(size_t(n3) * 4) || border.alloc(size_t(n3) * 4)
+          || bhead.alloc(size_t(n3) * 4) || bexcl.alloc(size_t(n3) * 4) || first.alloc(size_t(nb + 1) * 8) || longest.alloc(16)
+          || rows.alloc(size_t(nb) * MPCX_GRID_BLOCK_ROWS * 4) || local.alloc(size_t(n) * 16))
+        return -100;
+      if (hip_ok(hipMemsetAsync(longest.p, 0, 16, st), "hipMemsetAsync") || hip_ok(hipMemsetAsync(local.p, 0, size_t(n) * 16, st), "hipMemsetAsync"))
+        return -100;
+      hipLaunchKernelGGL(fill_i32_kernel, dim3(grid_for(int64_t(nb) * MPCX_GRID_BLOCK_ROWS, 256)), dim3(256), 0, st,
+                         int64_t(nb) * MPCX_GRID_BLOCK_ROWS, -1, rows.as<int32_t>());
+      hipLaunchKernelGGL(grid_block_keys_kernel, dim3(grid_for(nents, 256)), dim3(256), 0, st, nents, nb, plan->block_ent_off, plan->block_ents,
+                         g->idx.as<int32_t>(), g->n[0], g->n[0] + g->n[1], bkeys.as<int64_t>());
+      hipLaunchKernelGGL(iota_i32, dim3(grid_for(n3, 256)), dim3(256), 0, st, n3, biota.as<int32_t>());
+      if (int rc = with_temp([&](void* t, size_t* b) { return mpcx_sort_pairs_i64_i32(bkeys.as<int64_t>(), bskeys.as<int64_t>(), biota.as<int32_t>(),
+                                                                                      border.as<int32_t>(), n3, 0, 64, t, b, stream); }))
+        return rc;
+      hipLaunchKernelGGL(grid_heads_kernel, dim3(grid_for(n3, 256)), dim3(256), 0, st, n3, bskeys.as<int64_t>(), border.as<int32_t>(),
+                         static_cast<const double*>(nullptr), bhead.as<int32_t>(), static_cast<int32_t*>(nullptr));
+      if (int rc = with_temp([&](void* t, size_t* b) { return mpcx_scan_exclusive_i32(bhead.as<int32_t>(), n3, bexcl.as<int32_t>(), t, b, stream); }))
+        return rc;
+      if (int rc = mpcx_segment_offsets(bskeys.as<int64_t>(), n3, 32, nb, first.as<int64_t>(), stream))
+        return rc;
+      hipLaunchKernelGGL(grid_block_rows_kernel, dim3(grid_for(n3, 256)), dim3(256), 0, st, n3, nents, bskeys.as<int64_t>(), border.as<int32_t>(),
+                         bhead.as<int32_t>(), bexcl.as<int32_t>(), first.as<int64_t>(), plan->block_ents, rows.as<int32_t>(), local.as<int32_t>(),
+                         longest.as<int32_t>());
+      int32_t lg = 0;
+      if (hip_ok(hipMemcpyAsync(&lg, longest.p, 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync") || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+        return -100;
+      if (lg > 0 && lg <= MPCX_GRID_BLOCK_ROWS)
+      {
+        g->longest = lg;
+        g->rows = std::move(rows);
+        g->local = std::move(local);
+      }
+    }
+  }
+  if (hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+    return -100;
+  *out = g.release();
+  return 0;
+}
+extern "C" int mpcx_grid_plan_fill(const mpcx_grid_plan_t* p, mpcx_vector_args_t* a)
+{
+  if (!p || !a)
+  {
+    mpcx_set_error("mpcx_grid_plan_fill: invalid arguments");
+    return -1;
+  }
+  a->grid_iv = p->iv.as<double>();
+  a->grid_tab = p->tab.as<double>();
+  a->grid_n[0] = p->n[0], a->grid_n[1] = p->n[1], a->grid_n[2] = p->n[2];
+  if (p->longest > 0)
+  {
+    a->grid_idx = p->local.as<int32_t>();
+    a->grid_block_rows = p->rows.as<int32_t>();
+    a->grid_block_rows_max = p->longest;
+  }
+  else
+  {
+    a->grid_idx = p->idx.as<int32_t>();
+    a->grid_block_rows = nullptr;
+    a->grid_block_rows_max = 0;
+  }
+  return 0;
+}
+extern "C" int32_t mpcx_grid_plan_num_intervals(const mpcx_grid_plan_t* p, int32_t axis) { return (p && axis >= 0 && axis < 3) ? p->n[axis] : 0; }
+extern "C" int32_t mpcx_grid_plan_block_rows(const mpcx_grid_plan_t* p) { return p ? p->longest : 0; }
+extern "C" void mpcx_grid_plan_destroy(mpcx_grid_plan_t* p) { delete p; }
+
 // (mpcx_preload, csrc/mpcx_kernels.hip: the first launch from a translation unit loads its code object)
 namespace
 {

@@ -770,7 +770,7 @@ inline int vcube_own_threads()
   return n;
 }
 
-template <int FN>
+template <int FN, bool BOXES = false> // BOXES (FN = 1): the instance that looks for box clusters (247 instead of 151 registers)
 __global__ void __launch_bounds__(VCUBE_OWN_MAX_THREADS) vector_cube_own_kernel(mpcx_vector_args_t a)
 {
   using Op = ElementOp<3, 1, 1, 1, 1, MPCX_FORM_SOURCE, FN>;
@@ -792,7 +792,7 @@ __global__ void __launch_bounds__(VCUBE_OWN_MAX_THREADS) vector_cube_own_kernel(
   const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
   const int32_t* __restrict__ ents = a.plan.block_ents;
   [[maybe_unused]] bool grid_rule = false;
-  if constexpr (FN == 1)
+  if constexpr (FN == 1 && BOXES)
     grid_rule = box14_rule(a.kernel);
   for (int64_t t = e0 + tid; t < e1; t += NT)
   {
@@ -814,11 +814,11 @@ __global__ void __launch_bounds__(VCUBE_OWN_MAX_THREADS) vector_cube_own_kernel(
     for (int i = 0; i < 8; ++i)
       be8[i] = 0.0;
     bool on_grid = false;
-    if constexpr (FN == 1)
+    if constexpr (FN == 1 && BOXES)
       on_grid = grid_rule && box14_is_box(X);
     if (on_grid)
     {
-      if constexpr (FN == 1)
+      if constexpr (FN == 1 && BOXES)
         box14_source_fn1(X, a.constants ? a.constants[0] : 1.0, be8);
     }
     else
@@ -1157,13 +1157,53 @@ __global__ void fan_canonical_kernel(int64_t n, int32_t* __restrict__ verts, con
     hex_coefficients(X, c);
     return hex_is_parallelepiped(c);
   };
+  // Round 6: an axis-aligned box gets its corners in the order of the coordinate axes as well (corner 1 = the x neighbour of
+  // corner 0, 2 = y, 4 = z): the six tetrahedra of the fan are the six orders of adding the three edge vectors, so any
+  // permutation of the axes maps the fan onto itself -- and the box paths of the vector kernels (box14_source_fn1, the
+  // tensor-grid plan) tell a box by exactly this numbering.  A mesh with shuffled cells leaves the ring walk at any of them.
+  auto box_axes = [&](int32_t (&u)[8])
+  {
+    double X0[3], E[3][3];
+    for (int r = 0; r < 3; ++r)
+      X0[r] = x[3 * int64_t(u[0]) + r];
+    const int corner[3] = {1, 2, 4};
+    int axis[3];
+    for (int k = 0; k < 3; ++k)
+    {
+      int nz = 0;
+      axis[k] = 0;
+      for (int r = 0; r < 3; ++r)
+      {
+        E[k][r] = x[3 * int64_t(u[corner[k]]) + r] - X0[r];
+        if (E[k][r] != 0.0)
+          ++nz, axis[k] = r;
+      }
+      if (nz != 1)
+        return;
+    }
+    if (axis[0] == axis[1] || axis[0] == axis[2] || axis[1] == axis[2] || (axis[0] == 0 && axis[1] == 1))
+      return; // not a box, or already in axis order
+    int32_t t[8];
+    for (int i = 0; i < 8; ++i)
+      t[((i & 1) << axis[0]) | (((i >> 1) & 1) << axis[1]) | (((i >> 2) & 1) << axis[2])] = u[i];
+    for (int i = 0; i < 8; ++i)
+      u[i] = t[i];
+  };
   if (is_par(v))
+  {
+    box_axes(v);
+    for (int i = 0; i < 8; ++i)
+      verts[p * 8 + i] = v[i];
     return;
+  }
   // ring 1-3-2-6-4-5 turned by one: new 1 = old 3, new 3 = old 2, new 2 = old 6, new 6 = old 4, new 4 = old 5, new 5 = old 1
-  const int32_t w[8] = {v[0], v[3], v[6], v[2], v[5], v[1], v[4], v[7]};
+  int32_t w[8] = {v[0], v[3], v[6], v[2], v[5], v[1], v[4], v[7]};
   if (is_par(w))
+  {
+    box_axes(w);
     for (int i = 0; i < 8; ++i)
       verts[p * 8 + i] = w[i];
+  }
 }
 // Imported (UFCx) element kernels are called with a cell's vertices in the order the mesh lists them: a quadrature rule
 // need not be symmetric, so a permuted call is another approximation of the integral.  The cluster kernels built round an
@@ -2959,7 +2999,8 @@ int launch_vector_cubes(const mpcx_vector_args_t& a)
       if (int rc = grid_staged ? go(vector_cube_grid_kernel<true>) : go(vector_cube_grid_kernel<false>))
         return rc;
     }
-    else if (int rc = k.fn_id == 1 ? go(vector_cube_own_kernel<1>) : go(vector_cube_own_kernel<-1>))
+    else if (int rc = k.fn_id == 1 ? (a.cube_boxes ? go(vector_cube_own_kernel<1, true>) : go(vector_cube_own_kernel<1, false>))
+                                   : go(vector_cube_own_kernel<-1>))
       return rc;
     if (a.n_own_rows > 0)
       if (int rc = launch_vector_spill_reduce(a, 1))

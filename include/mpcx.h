@@ -675,6 +675,11 @@ typedef struct
    * table rows r (as above) it needs, -1 = unused -- and grid_idx then holds, per cluster, the POSITIONS of its three rows
    * in the list of the block that owns it instead of interval numbers; grid_block_rows_max = the longest list (LDS is sized
    * by it; 0: MPCX_GRID_BLOCK_ROWS).  NULL: grid_idx holds interval numbers and every cluster reads the table itself. */
+  /* MPCX_ALG_CUBE, owner-computes, kernel.fn_id = 1: nonzero = many clusters are axis-aligned boxes with their vertices in
+   * corner order (mpcx_cluster_canonical numbers them so): the launch takes the instance that checks every cluster and
+   * evaluates boxes factor by factor (csrc/mpcx_cubes.hip box14_source_fn1); 0: every cluster point by point (the lighter
+   * instance: a mesh without boxes runs a third faster on it) */
+  int32_t cube_boxes;
   const int32_t* grid_idx;
   const double* grid_iv;
   double* grid_tab;
@@ -1092,6 +1097,23 @@ int mpcx_hbm_probe(const void* src, void* dst, int64_t bytes, int32_t mode, void
 
 /* misc */
 const char* mpcx_last_error(void);
+/* The tensor grid under a mesh of axis-aligned box clusters (mpcx_vector_args_t::grid_*), built on the DEVICE in
+ * library-owned memory: per axis the distinct intervals (coordinate of corner 0, of corner 7) the clusters sit on -- a cluster
+ * list sorted by its low corner, one high corner per low corner --, per cluster its three intervals, the scratch table of the
+ * launches, and, when `plan` (the owner-computes plan of the vector call: num_blocks / block_ent_off / block_ents) is given and
+ * every block needs at most MPCX_GRID_BLOCK_ROWS rows, the rows per block with the clusters numbered by them.
+ * Returns 0 and *out = the plan; 1 and *out = NULL when the mesh has no such grid (a cluster that is not a box with its
+ * vertices in corner order, two clusters that start at one coordinate and end at different ones, or more intervals than
+ * max(4096, clusters / 8)): the caller then leaves grid_idx NULL; negative: error.  Geometry only -- rebuild when the mesh
+ * moves.  cube_verts / x: DEVICE, as mpcx_vector_args_t::cube_verts / x.  The torch twin: assemble_vector._cluster_grid. */
+typedef struct mpcx_grid_plan mpcx_grid_plan_t;
+int mpcx_grid_plan_create(const int32_t* cube_verts, int64_t n_cubes, const double* x, const mpcx_rowblock_plan_t* plan, void* stream,
+                          mpcx_grid_plan_t** out);
+int mpcx_grid_plan_fill(const mpcx_grid_plan_t* plan, mpcx_vector_args_t* args); /* grid_idx, grid_iv, grid_tab, grid_n, grid_block_rows(_max) */
+int32_t mpcx_grid_plan_num_intervals(const mpcx_grid_plan_t* plan, int32_t axis);
+int32_t mpcx_grid_plan_block_rows(const mpcx_grid_plan_t* plan); /* longest block list; 0: the clusters read the table itself */
+void mpcx_grid_plan_destroy(mpcx_grid_plan_t* plan);
+
 int mpcx_version(void);
 /* Load the library's code objects now (one empty kernel per translation unit on `stream`, then a stream synchronisation)
  * instead of at the first assembly call; optional, idempotent, thread-safe. */

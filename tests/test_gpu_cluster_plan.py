@@ -176,3 +176,69 @@ def test_owner_plan_from_the_c_abi_equals_the_torch_allocated_plan(oracle, kwarg
         assert abs(b2.numpy() - ref).max() <= 1e-12 * max(1.0, abs(ref).max())
     finally:
         L.mpcx_owner_plan_destroy(h)
+
+
+@pytest.mark.parametrize("shape", ["tiled", "untiled", "stretched", "warped"])
+def test_grid_plan_from_the_c_abi_equals_the_torch_built_plan(oracle, shape):
+    """mpcx_grid_plan_create (the tensor grid under a mesh of box clusters, in library-owned memory) against
+    assemble_vector._cluster_grid / _block_rows, array by array; the vector assembled from it against the oracle; a mesh whose
+    clusters are not boxes has no grid (return code 1, no plan)"""
+    import torch
+
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import _device as D
+    from dolfinx_mpc_amd import _native, fem
+    from dolfinx_mpc_amd.la import create_vector
+    from dolfinx_mpc_amd.mesh import create_unit_cube
+    from problems import Case, _walls_yz, periodic_raw
+
+    av = importlib.import_module("dolfinx_mpc_amd.assemble_vector")
+    if shape == "warped":
+        case = case_cube_periodic(8, 1, 0.0, reorder=(4, 4, 4), warp=True)
+    else:
+        mesh = create_unit_cube(12, 9, 10, reorder=None if shape == "untiled" else (4, 4, 4))
+        if shape == "stretched":
+            x = mesh.geometry.x.copy()
+            x[:, 0] = x[:, 0] * (1.0 + 0.3 * x[:, 0] * (1.0 - x[:, 0]))  # (not uniform; the faces x = 0, 1 stay)
+            x[:, 2] = 1.0 - 0.8 * x[:, 2]  # (mirrored: the clusters' corner 7 lies below corner 0 in z)
+            mesh.geometry.x = x
+        V = fem.functionspace(mesh, ("Lagrange", 1))
+        bc = fem.dirichletbc(0.0, fem.locate_dofs_geometrical(V, _walls_yz), V)
+        case = Case("grid_" + shape, V, fem.form_stiffness(V), fem.form_source(V, fem.FN_BENCH_PERIODIC, constant=1.1), [bc],
+                    periodic_raw(V, [bc]))
+    mpc = product_mpc(case)
+    args, keep = av.vector_args(case.L, 0, create_vector(case.V), mpc, 0)
+    assert args.kernel_name == "cube_own"
+    L = _native.lib()
+    h = C.c_void_p()
+    rc = L.mpcx_grid_plan_create(args.cube_verts, int(args.n_cubes), args.x, C.byref(args.plan), D.stream_ptr(), C.byref(h))
+    if shape == "warped":
+        assert rc == 1 and not h and not bool(args.grid_idx)
+        return
+    _native.check(rc, "mpcx_grid_plan_create")
+    try:
+        assert bool(args.grid_idx)
+        nc = int(args.n_cubes)
+        ns = [L.mpcx_grid_plan_num_intervals(h, d) for d in range(3)]
+        assert ns == [int(args.grid_n[d]) for d in range(3)]
+        a2 = _native.VectorArgs.from_buffer_copy(args)
+        _native.check(L.mpcx_grid_plan_fill(h, C.byref(a2)), "mpcx_grid_plan_fill")
+        assert np.array_equal(_dev_array(a2.grid_iv, 2 * sum(ns), np.float64), _dev_array(args.grid_iv, 2 * sum(ns), np.float64))
+        assert bool(a2.grid_block_rows) == bool(args.grid_block_rows)
+        assert int(a2.grid_block_rows_max) == int(args.grid_block_rows_max) == L.mpcx_grid_plan_block_rows(h)
+        got_idx, ref_idx = _dev_array(a2.grid_idx, 4 * nc, np.int32).reshape(nc, 4), _dev_array(args.grid_idx, 4 * nc, np.int32).reshape(nc, 4)
+        assert np.array_equal(got_idx[:, :3], ref_idx[:, :3])
+        if bool(args.grid_block_rows):
+            nb = int(args.plan.num_blocks)
+            assert np.array_equal(_dev_array(a2.grid_block_rows, 128 * nb, np.int32), _dev_array(args.grid_block_rows, 128 * nb, np.int32))
+        b2 = create_vector(case.V)
+        a2.b = b2.array.data_ptr()
+        _native.check(L.mpcx_assemble_vector(C.byref(a2)), "mpcx_assemble_vector")
+        torch.cuda.synchronize()
+        ref = oracle_outputs(oracle, case)["b"]
+        # (the launch alone: the rows of slave dofs go to their masters in the same call; Dirichlet rows are the wrapper's)
+        got = dm.assemble_vector(case.L, mpc).numpy()
+        assert abs(got - ref).max() <= 1e-12 * max(1.0, abs(ref).max())
+        assert abs(b2.numpy() - got).max() <= 1e-13 * max(1.0, abs(ref).max())
+    finally:
+        L.mpcx_grid_plan_destroy(h)

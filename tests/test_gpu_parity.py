@@ -316,7 +316,7 @@ def test_cluster_vector_kernel_variants(oracle, n, reorder, bc, env, monkeypatch
 
 
 @pytest.mark.parametrize("mode", ["tensor", "box", "points"])
-@pytest.mark.parametrize("shape", ["cube", "stretched", "mirrored", "half_warped", "warped"])
+@pytest.mark.parametrize("shape", ["cube", "stretched", "mirrored", "shuffled", "half_warped", "warped"])
 def test_cluster_vector_on_the_tensor_grid_of_a_box(oracle, shape, mode, monkeypatch):
     """the benchmark's right-hand side on clusters that are axis-aligned boxes: (tensor) its univariate factors from a table
     filled once per launch and interval of the mesh's tensor grid (mpcx_vector_args_t::grid_*), (box, MPCX_TENSOR_GRID=0)
@@ -340,6 +340,10 @@ def test_cluster_vector_on_the_tensor_grid_of_a_box(oracle, shape, mode, monkeyp
     select(mode)
     if shape in ("half_warped", "warped"):
         case = case_cube_periodic(6, 1, 0.0, reorder=(2, 2, 2), warp="half" if shape == "half_warped" else True)
+    elif shape == "shuffled":
+        # nodes and cells in random order: the clusters are found from topology with their ring started anywhere, and
+        # numbered along the coordinate axes by mpcx_cluster_canonical -- boxes all the same
+        case = case_cube_periodic(7, 1, 0.0, numbering="shuffled")
     else:
         mesh = create_unit_cube(6, 5, 7, reorder=(2, 2, 2))
         x = mesh.geometry.x.copy()
@@ -358,7 +362,8 @@ def test_cluster_vector_on_the_tensor_grid_of_a_box(oracle, shape, mode, monkeyp
     av = importlib.import_module("dolfinx_mpc_amd.assemble_vector")
     args = av.vector_args(case.L, 0, create_vector(case.V), mpc, 0)[0]
     assert args.kernel_name == "cube_own", "the cluster kernel was expected to run"
-    boxes = shape in ("cube", "stretched", "mirrored")
+    boxes = shape in ("cube", "stretched", "mirrored", "shuffled")
+    assert int(args.cube_boxes) == (0 if (mode == "points" or shape == "warped") else 1)
     assert bool(args.grid_idx) == (mode == "tensor" and boxes), "tensor-grid tables: exactly on meshes of boxes"
     got = dm.assemble_vector(case.L, mpc).numpy().copy()
     _close(got, ref["b"], RTOL_B, f"{case.name} b [{mode}]")
