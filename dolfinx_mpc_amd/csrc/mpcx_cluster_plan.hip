@@ -12,6 +12,7 @@
 #include "mpcx_internal.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <memory>
@@ -1284,15 +1285,26 @@ extern "C" int mpcx_grid_plan_create(const int32_t* cube_verts, int64_t n_cubes,
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int64_t n = n_cubes;
   auto g = std::make_unique<mpcx_grid_plan>();
+  const bool debug = std::getenv("MPCX_GRID_PLAN_DEBUG") != nullptr;
+  auto stage = [&](const char* what)
+  {
+    if (debug)
+    {
+      const hipError_t e = hipStreamSynchronize(st);
+      std::fprintf(stderr, "mpcx_grid_plan_create: %s -> %s\n", what, hipGetErrorString(e));
+    }
+  };
   Dev keys, hi, flag, skeys, iota, order, head, excl;
   if (keys.alloc(size_t(3 * n) * 8) || hi.alloc(size_t(3 * n) * 8) || flag.alloc(16) || skeys.alloc(size_t(n) * 8) || iota.alloc(size_t(n) * 4)
-      || order.alloc(size_t(n) * 4) || head.alloc(size_t(n) * 4) || excl.alloc(size_t(n) * 4) || g->idx.alloc(size_t(n) * 16))
+      || order.alloc(size_t(n) * 4) || head.alloc(size_t(n) * 4) || excl.alloc(size_t(n + 1) * 4) /* (+ the total) */
+      || g->idx.alloc(size_t(n) * 16))
     return -100;
   if (hip_ok(hipMemsetAsync(flag.p, 0, 16, st), "hipMemsetAsync") || hip_ok(hipMemsetAsync(g->idx.p, 0, size_t(n) * 16, st), "hipMemsetAsync"))
     return -100;
   hipLaunchKernelGGL(grid_box_keys_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, n, cube_verts, x, keys.as<int64_t>(), hi.as<double>(),
                      flag.as<int32_t>());
   hipLaunchKernelGGL(iota_i32, dim3(grid_for(n, 256)), dim3(256), 0, st, n, iota.as<int32_t>());
+  stage("box keys");
   int32_t bad[2] = {0, 0};
   if (hip_ok(hipMemcpyAsync(bad, flag.p, 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync") || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
     return -100;
@@ -1304,10 +1316,13 @@ extern "C" int mpcx_grid_plan_create(const int32_t* cube_verts, int64_t n_cubes,
     if (int rc = with_temp([&](void* t, size_t* b) { return mpcx_sort_pairs_i64_i32(keys.as<int64_t>() + d * n, skeys.as<int64_t>(), iota.as<int32_t>(),
                                                                                     order.as<int32_t>(), n, 0, 64, t, b, stream); }))
       return rc;
+    stage("axis sort");
     hipLaunchKernelGGL(grid_heads_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, n, skeys.as<int64_t>(), order.as<int32_t>(),
                        hi.as<double>() + d * n, head.as<int32_t>(), flag.as<int32_t>() + 1);
+    stage("axis heads");
     if (int rc = with_temp([&](void* t, size_t* b) { return mpcx_scan_exclusive_i32(head.as<int32_t>(), n, excl.as<int32_t>(), t, b, stream); }))
       return rc;
+    stage("axis scan");
     int32_t last[2] = {0, 0};
     if (hip_ok(hipMemcpyAsync(&last[0], excl.as<int32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync")
         || hip_ok(hipMemcpyAsync(&last[1], head.as<int32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync")
@@ -1321,6 +1336,7 @@ extern "C" int mpcx_grid_plan_create(const int32_t* cube_verts, int64_t n_cubes,
       return -100;
     hipLaunchKernelGGL(grid_assign_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, n, order.as<int32_t>(), head.as<int32_t>(), excl.as<int32_t>(),
                        x, cube_verts, hi.as<double>() + d * n, d, g->idx.as<int32_t>(), ivd[d].as<double>());
+    stage("axis");
   }
   const int64_t ntot = int64_t(g->n[0]) + g->n[1] + g->n[2];
   if (ntot > std::max<int64_t>(4096, n / 8))
@@ -1343,7 +1359,7 @@ extern "C" int mpcx_grid_plan_create(const int32_t* cube_verts, int64_t n_cubes,
     {
       Dev bkeys, bskeys, biota, border, bhead, bexcl, first, longest, rows, local;
       if (bkeys.alloc(size_t(n3) * 8) || bskeys.alloc(size_t(n3) * 8) || biota.alloc(size_t(n3) * 4) || border.alloc(size_t(n3) * 4)
-          || bhead.alloc(size_t(n3) * 4) || bexcl.alloc(size_t(n3) * 4) || first.alloc(size_t(nb + 1) * 8) || longest.alloc(16)
+          || bhead.alloc(size_t(n3) * 4) || bexcl.alloc(size_t(n3 + 1) * 4) || first.alloc(size_t(nb + 1) * 8) || longest.alloc(16)
           || rows.alloc(size_t(nb) * MPCX_GRID_BLOCK_ROWS * 4) || local.alloc(size_t(n) * 16))
         return -100;
       if (hip_ok(hipMemsetAsync(longest.p, 0, 16, st), "hipMemsetAsync") || hip_ok(hipMemsetAsync(local.p, 0, size_t(n) * 16, st), "hipMemsetAsync"))
@@ -1352,6 +1368,7 @@ extern "C" int mpcx_grid_plan_create(const int32_t* cube_verts, int64_t n_cubes,
                          int64_t(nb) * MPCX_GRID_BLOCK_ROWS, -1, rows.as<int32_t>());
       hipLaunchKernelGGL(grid_block_keys_kernel, dim3(grid_for(nents, 256)), dim3(256), 0, st, nents, nb, plan->block_ent_off, plan->block_ents,
                          g->idx.as<int32_t>(), g->n[0], g->n[0] + g->n[1], bkeys.as<int64_t>());
+      stage("block keys");
       hipLaunchKernelGGL(iota_i32, dim3(grid_for(n3, 256)), dim3(256), 0, st, n3, biota.as<int32_t>());
       if (int rc = with_temp([&](void* t, size_t* b) { return mpcx_sort_pairs_i64_i32(bkeys.as<int64_t>(), bskeys.as<int64_t>(), biota.as<int32_t>(),
                                                                                       border.as<int32_t>(), n3, 0, 64, t, b, stream); }))
@@ -1360,11 +1377,14 @@ extern "C" int mpcx_grid_plan_create(const int32_t* cube_verts, int64_t n_cubes,
                          static_cast<const double*>(nullptr), bhead.as<int32_t>(), static_cast<int32_t*>(nullptr));
       if (int rc = with_temp([&](void* t, size_t* b) { return mpcx_scan_exclusive_i32(bhead.as<int32_t>(), n3, bexcl.as<int32_t>(), t, b, stream); }))
         return rc;
+      stage("block sort + heads + scan");
       if (int rc = mpcx_segment_offsets(bskeys.as<int64_t>(), n3, 32, nb, first.as<int64_t>(), stream))
         return rc;
+      stage("segment offsets");
       hipLaunchKernelGGL(grid_block_rows_kernel, dim3(grid_for(n3, 256)), dim3(256), 0, st, n3, nents, bskeys.as<int64_t>(), border.as<int32_t>(),
                          bhead.as<int32_t>(), bexcl.as<int32_t>(), first.as<int64_t>(), plan->block_ents, rows.as<int32_t>(), local.as<int32_t>(),
                          longest.as<int32_t>());
+      stage("block rows");
       int32_t lg = 0;
       if (hip_ok(hipMemcpyAsync(&lg, longest.p, 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync") || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
         return -100;

@@ -6,7 +6,7 @@
 // from hipMalloc --
 //     mpcx_mpc_finalize -> mpcx_cell_to_slaves -> mpcx_pattern_build                       (host set-up)
 //     mpcx_cluster_plan_create (+ mpcx_cell_plan_create for cells outside the clusters) -> mpcx_assemble_matrix -> mpcx_add_diagonal
-//     mpcx_mask_dofmap -> mpcx_owner_plan_create -> mpcx_assemble_vector (+ leftover cells)
+//     mpcx_mask_dofmap -> mpcx_owner_plan_create (-> mpcx_grid_plan_create) -> mpcx_assemble_vector (+ leftover cells)
 //     mpcx_apply_lifting, set_bc
 // -- and writes the CSR matrix and the vector.  tests/test_gpu_driver.py compares them with the Python host layer's
 // result on the same problem (same kernels underneath, so to rounding of the summation order).
@@ -165,6 +165,19 @@ int main(int argc, char** argv)
       mpcx_check(mpcx_mask_dofmap(mpcx_cluster_plan_verts(cplan), n_clusters, 8, 1, nullptr, mpc.is_slave, 0, mrow, stream), "mpcx_mask_dofmap");
       mpcx_check(mpcx_owner_plan_create(n_clusters, 8, mrow, 1, ndofs, vrows, hints, n_hints, 12288, stream, &oplan), "mpcx_owner_plan_create");
     }
+    // the benchmark's right-hand side (kernel.fn_id 1, 14-point rule) on a mesh of box clusters: the tensor grid under the
+    // clusters, so that every launch evaluates the univariate factors once per interval (mpcx_vector_args_t::grid_*);
+    // return code 1 = the mesh has no such grid (the clusters are then evaluated one by one)
+    mpcx_grid_plan_t* gplan = nullptr;
+    if (oplan && Kvec.fn_id == 1 && Kvec.nq == 14 && Kvec.coeff_degree == 0 && !std::getenv("MPCX_DRIVER_NO_GRID"))
+    {
+      mpcx_vector_args_t tmp;
+      std::memset(&tmp, 0, sizeof(tmp));
+      mpcx_check(mpcx_owner_plan_fill(oplan, &tmp), "mpcx_owner_plan_fill");
+      const int rc = mpcx_grid_plan_create(mpcx_cluster_plan_verts(cplan), n_clusters, d_x, &tmp.plan, stream, &gplan);
+      if (rc < 0)
+        mpcx_check(rc, "mpcx_grid_plan_create");
+    }
     // master contributions of the slave cells gathered by target position (mpcx_matrix_args_t::mpc_plan_*): the host
     // builder is enough for a thin slave layer; without it the kernel searches the CSR rows itself (device atomics)
     const mpcx_nnz_t* d_plan_tgt = nullptr;
@@ -282,6 +295,9 @@ int main(int argc, char** argv)
         v.algorithm = MPCX_ALG_CUBE;
         v.cube_verts = mpcx_cluster_plan_verts(cplan), v.n_cubes = n_clusters;
         v.slave_entities = d_slave_cells_cluster, v.n_slave_entities = int64_t(slave_cells_cluster.size());
+        v.cube_boxes = 1; // (box clusters factor by factor; clusters that are no boxes point by point)
+        if (gplan)
+          mpcx_check(mpcx_grid_plan_fill(gplan, &v), "mpcx_grid_plan_fill");
         mpcx_check(mpcx_assemble_vector(&v), "mpcx_assemble_vector (clusters)");
       }
       if (n_left > 0 || !oplan)
@@ -336,6 +352,8 @@ int main(int argc, char** argv)
                 "plans %.3f s, step %.3f ms\n",
                 (long long)ndofs, (long long)n_cells, (long long)nnz, n_slaves, (long long)n_clusters, (long long)n_left, t_host, t_upload,
                 t_plans, 1e3 * t_steps / steps);
+    if (gplan)
+      mpcx_grid_plan_destroy(gplan);
     if (oplan)
       mpcx_owner_plan_destroy(oplan);
     if (oplan_cells)
