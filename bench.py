@@ -756,7 +756,17 @@ def main():
         k = {"kernel": f"{kname}[{label}]", "call": f"assemble_vector[{label}]", "launch_ms": tk,
              "algorithmic_bytes": int(nbytes), "pmc_name": kname}
         k["fp64_flops"] = algorithmic_flops(f.integrals[0], V0) * f.integrals[0].num_entities
-        if bool(getattr(vargs, "grid_idx", None)):
+        if bool(getattr(vargs, "grid_J", None)):
+            # the same per cell (vector_cell_grid_kernel: any rule, P1 / P2): ND + 3 fma and a product per point, plus 16 B of plan
+            # per cell; priced by what it executes
+            kname = "vector_cell_grid_kernel"
+            k["kernel"], k["pmc_name"] = f"{kname}[{label}]", kname
+            nqv = int(f.integrals[0].kernel.qwts.size)
+            k["fp64_flops"] = (2.0 * V0.element_ndofs + 8.0) * nqv * nc
+            k["algorithmic_bytes"] = int(nc * (4 + 16 + 4 * V0.element_ndofs) + 9 * V0.num_dofs)
+            k["note"] = ("tensor-grid evaluation per cell: fp64_flops counts what the kernel executes; the quadrature formulation a form "
+                         "compiler emits would be %.3g flops per launch" % (algorithmic_flops(f.integrals[0], V0) * nc))
+        elif bool(getattr(vargs, "grid_idx", None)):
             # the right-hand side from per-interval tables of the mesh's tensor grid (mpcx_vector_args_t::grid_*): the kernel
             # reads 16 B of plan per cluster more and no coordinates, and does 12 flops per quadrature point (two products
             # and an fma for f, four fma into the vertex sums) -- that count, not the quadrature formulation's ~1e3 flops per

@@ -201,6 +201,9 @@ class VectorArgs(C.Structure):
         ("grid_n", C.c_int32 * 3),
         ("grid_block_rows", C.c_void_p),
         ("grid_block_rows_max", C.c_int32),
+        ("grid_eta", C.c_void_p),
+        ("grid_J", C.c_void_p),
+        ("grid_ng", C.c_int32),
         ("lds_floor", C.c_int32),
         ("stream", C.c_void_p),
     ]

@@ -340,6 +340,72 @@ def _block_rows(pk, idx, ns):
     return rows.contiguous(), local.contiguous(), int(counts.max().item())
 
 
+def _cell_grid(form, i, V, pk):
+    """The per-cell twin of ``_cluster_grid`` (include/mpcx.h mpcx_vector_args_t::grid_eta / grid_J): for a scalar P1 / P2 source
+    form over ALL cells of a tetrahedral mesh whose cells have their vertices on two values per axis (every cell of a box mesh),
+    the tensor grid of intervals, per cell its three table rows (positions in the list of the block of the owner plan ``pk``
+    that evaluates it) and which vertices lie on the high side per axis, the distinct sums of barycentric coordinates the rule
+    produces (``eta``) and the table (point, vertex subset) -> eta.  None when a cell is not of that kind, the intervals are not
+    few, or a block needs more than GRID_BLOCK_ROWS rows.  Geometry + rule only; cached per (plan, geometry version)."""
+    import torch
+
+    mesh = form.mesh
+    k = form.integrals[i].kernel
+
+    def build():
+        md = D.mesh_device(mesh)
+        x = md["x"].view(-1, 3)
+        dm = md["x_dofmap"].view(-1, 4).long()
+        n = dm.shape[0]
+        X = x[dm]  # (n, 4, 3)
+        lo, hi = X.min(dim=1).values, X.max(dim=1).values
+        on_hi = X == hi[:, None, :]
+        if not bool((on_hi | (X == lo[:, None, :])).all()) or bool((hi == lo).any()):
+            return None
+        e1, e2, e3 = X[:, 1] - X[:, 0], X[:, 2] - X[:, 0], X[:, 3] - X[:, 0]
+        det = (e1 * torch.cross(e2, e3, dim=1)).sum(dim=1).abs()
+        ratio = det / (hi - lo).prod(dim=1)
+        cfac = torch.round(ratio)
+        if not bool(((ratio - cfac).abs() < 1e-9).all()) or not bool(((cfac >= 1) & (cfac <= 3)).all()):
+            return None
+        bits = torch.tensor([1, 2, 4, 8], device=x.device, dtype=torch.int64)
+        masks = (on_hi.long() * bits[None, :, None]).sum(dim=1)  # (n, 3): vertices on the high side per axis
+        # the rule: sums of the barycentric coordinates over every vertex subset
+        q = np.asarray(k.qpts, dtype=np.float64).reshape(-1, 3)
+        lam = np.concatenate([1.0 - q.sum(axis=1, keepdims=True), q], axis=1)  # (nq, 4), vertex 0 first
+        sub = np.array([[(m >> v) & 1 for v in range(4)] for m in range(16)], dtype=np.float64)  # (16, 4)
+        sums = lam @ sub.T  # (nq, 16)
+        inner = sums[:, 1:15]
+        eta = np.unique(np.round(inner.ravel(), 13))
+        if eta.size > 250:
+            return None
+        J = np.zeros((q.shape[0], 16), dtype=np.uint8)
+        J[:, 1:15] = np.abs(inner[..., None] - eta).argmin(axis=-1)
+        eta = np.array([inner[J[:, 1:15] == j].mean() for j in range(eta.size)])
+        idx = torch.zeros((n, 4), dtype=torch.int32, device=x.device)
+        ivs, ns = [], []
+        for d in range(3):
+            lo_u, lo_i = torch.unique(lo[:, d], return_inverse=True)
+            hi_u, hi_i = torch.unique(hi[:, d], return_inverse=True)
+            pair_u, pair_i = torch.unique(lo_i * hi_u.numel() + hi_i, return_inverse=True)
+            idx[:, d] = pair_i.to(torch.int32)
+            ivs.append(torch.stack([lo_u[pair_u // hi_u.numel()], hi_u[pair_u % hi_u.numel()]], dim=1))
+            ns.append(int(pair_u.numel()))
+        if sum(ns) > max(4096, n // 32):
+            return None
+        staged = _block_rows(pk, idx, tuple(ns))
+        if staged is None:
+            return None
+        rows, local, longest = staged
+        local[:, 3] = (masks[:, 0] | (masks[:, 1] << 4) | (masks[:, 2] << 8) | (cfac.long() << 12)).to(torch.int32)
+        ngp = (eta.size + 1) & ~1
+        tab = torch.empty(sum(ns) * (2 * ngp + 2), dtype=torch.float64, device=x.device)
+        return dict(rec=local.contiguous(), rows=rows, longest=longest, iv=torch.cat(ivs).contiguous(), ns=tuple(ns), tab=tab,
+                    eta=D._to_dev(eta, x.device), J=D._to_dev(J.reshape(-1), x.device), ng=int(eta.size))
+
+    return D.cached(form._device, "cell_grid", (pk,), (i, mesh.geometry.version), build, maxsize=2)
+
+
 def _grid_rule(k) -> bool:
     """does the kernel data hold the 14-point rule the tensor-grid tables are generated for (csrc/mpcx_box14.hpp)?"""
     from .quadrature import make_quadrature
@@ -520,6 +586,20 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
             plan, pk, n_own = own
             a.own_lmap, a.own_hoff, a.own_spill = pk[3].data_ptr(), pk[4].data_ptr(), pk[5].data_ptr()
             a.own_src, a.own_rows, a.own_seg, a.n_own_rows = pk[6].data_ptr(), pk[7].data_ptr(), pk[8].data_ptr(), n_own
+            if (name == "ownblock" and k.form == 2 and k.fn_id == 1 and k.coeff_degree == 0 and integ.coefficient is None
+                    and integ.itype == "cell" and k.celltype == 2 and V.dofmap.bs == 1 and V.degree in (1, 2)
+                    and idv["entities_ptr"] is None and form.mesh.geometry.dofmap.shape[1] == 4
+                    and (V.degree == 1 or bool(idv["kernel"].qphi))
+                    and os.environ.get("MPCX_BOX_GRID", "1") != "0" and os.environ.get("MPCX_CELL_GRID", "1") != "0"):
+                # the benchmark's right-hand side on the cells of a box mesh: its univariate factors once per interval and
+                # launch instead of a sine and an exponential per quadrature point (csrc/mpcx_kernels.hip vector_cell_grid_kernel)
+                cg = _cell_grid(form, i, V, pk)
+                if cg is not None:
+                    a.grid_idx, a.grid_iv, a.grid_tab = cg["rec"].data_ptr(), cg["iv"].data_ptr(), cg["tab"].data_ptr()
+                    a.grid_n[0], a.grid_n[1], a.grid_n[2] = cg["ns"]
+                    a.grid_block_rows, a.grid_block_rows_max = cg["rows"].data_ptr(), cg["longest"]
+                    a.grid_eta, a.grid_J, a.grid_ng = cg["eta"].data_ptr(), cg["J"].data_ptr(), cg["ng"]
+                    keep += [cg]
         else:  # "rowblock" / "ufcx_rowblock": halo entities evaluated by every block they touch
             plan, pk = _vector_plan(form, i, V, nrows_blk)
         _, slave_ents = _slave_entities(form, i, constraint, constraint)

@@ -1715,6 +1715,132 @@ __global__ void __launch_bounds__(MAXT) vector_ownblock_kernel(mpcx_vector_args_
     a.own_spill[h0 * BS + i] = s_b[nown + i];
 }
 
+// ---- the benchmark's right-hand side per CELL from per-interval tables (mpcx_vector_args_t::grid_eta / grid_J) --------------
+// The cluster kernel of csrc/mpcx_cubes.hip (vector_cube_grid_kernel) covers scalar P1 on clusters with the 14-point rule through
+// generated index tables.  This one is data driven -- any rule, P1 or P2, one thread per cell: a simplex of a box mesh has its
+// vertices on two values per axis, so the coordinate of quadrature point q along axis d is lo_d + h_d eta with eta the sum of the
+// barycentric coordinates of the vertices on the high side, one of a few dozen values for all (q, subset).  The launch fills the
+// table of the univariate factors per interval (cell_grid_tables_kernel), a block stages the rows of its cells in LDS, and a
+// point costs three byte reads (which eta per axis), five value reads and ND + 3 fma instead of a sine, an exponential and
+// the affine map.  Row of interval r (2 NGP + 2 doubles, NGP = grid_ng rounded up to even): [0, NGP) g(t), [NGP, 2 NGP) t (axis
+// x) / sin(5 pi t) (axis y), [2 NGP] = |h|.
+__global__ void __launch_bounds__(256) cell_grid_tables_kernel(int n0, int n1, int n2, const double* __restrict__ iv, double* __restrict__ tab,
+                                                               const double* __restrict__ eta, int ng)
+{
+  fastmath_init_lds(); // ends in a barrier
+  const int ngp = (ng + 1) & ~1, stride = 2 * ngp + 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = i / (ngp + 1), j = i - r * (ngp + 1);
+  if (r >= n0 + n1 + n2)
+    return;
+  const int d = r < n0 ? 0 : (r < n0 + n1 ? 1 : 2);
+  const double lo = iv[2 * r], hi = iv[2 * r + 1], h = hi - lo;
+  double* row = tab + int64_t(r) * stride;
+  if (j == ngp)
+  {
+    row[2 * ngp] = fabs(h);
+    row[2 * ngp + 1] = 0.0;
+    return;
+  }
+  if (j >= ng)
+  {
+    row[j] = 0.0, row[ngp + j] = 0.0;
+    return;
+  }
+  const FmConsts FK = g_fm_consts;
+  const double centre = d == 0 ? 0.9 : (d == 1 ? 0.5 : 0.1);
+  const double t = fma(h, eta[j], lo - centre); // relative to the centre of the Gaussian, as eval_fn case 1 does
+  row[j] = fast_exp_nonpos_k(-(t * t) * (1.0 / 0.02), FK);
+  row[ngp + j] = d == 0 ? t + 0.9 : (d == 1 ? fast_sinpi_k(fma(5.0, t, 2.5), FK) : 0.0);
+}
+
+template <int ND>
+__global__ void __launch_bounds__(1024) vector_cell_grid_kernel(mpcx_vector_args_t a)
+{
+  constexpr int LMASK = (1 << MPCX_MASK_SHIFT) - 1;
+  const int NT = blockDim.x;
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* s_b = reinterpret_cast<double*>(smem); // [max_rows]: own rows, then halo rows
+  const int nb = a.plan.num_blocks;
+  const int per = (nb + 7) >> 3;
+  const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (b >= nb)
+    return;
+  const int tid = threadIdx.x;
+  const int r0 = a.plan.block_row0[b], r1 = a.plan.block_row0[b + 1];
+  const int64_t h0 = a.own_hoff[b], h1 = a.own_hoff[b + 1];
+  const int nown = r1 - r0, nhalo = int(h1 - h0);
+  for (int i = tid; i < nown + nhalo; i += NT)
+    s_b[i] = 0.0;
+  const int ng = a.grid_ng, ngp = (ng + 1) & ~1, stride = 2 * ngp + 2;
+  const int lrow = stride + 2; // (LDS rows two doubles longer: rows of different intervals on different banks)
+  const int nq = a.kernel.nq;
+  const int nslots = a.grid_block_rows_max;
+  double* s_rows = s_b + ((a.plan.max_rows + 1) & ~1);             // [nslots][lrow]
+  uint8_t* s_J = reinterpret_cast<uint8_t*>(s_rows + nslots * lrow); // [nq][16]
+  {
+    const int32_t* __restrict__ br = a.grid_block_rows + int64_t(b) * MPCX_GRID_BLOCK_ROWS;
+    for (int i = tid; i < nslots * stride; i += NT)
+    {
+      const int slot = i / stride, j = i - slot * stride;
+      const int r = br[slot];
+      if (r >= 0)
+        s_rows[slot * lrow + j] = a.grid_tab[int64_t(r) * stride + j];
+    }
+    for (int i = tid; i < nq * 16; i += NT)
+      s_J[i] = a.grid_J[i];
+  }
+  __syncthreads();
+  const double c0 = a.constants ? a.constants[0] : 1.0;
+  const int64_t e0 = a.plan.block_ent_off[b], e1 = a.plan.block_ent_off[b + 1];
+  const int32_t* __restrict__ ents = a.plan.block_ents;
+  for (int64_t t = e0 + tid; t < e1; t += NT)
+  {
+    const int64_t e = ents[t];
+    const int4 rec = reinterpret_cast<const int4*>(a.grid_idx)[e];
+    const double* __restrict__ rx = s_rows + rec.x * lrow;
+    const double* __restrict__ ry = s_rows + rec.y * lrow;
+    const double* __restrict__ rz = s_rows + rec.z * lrow;
+    const int mx = rec.w & 15, my = (rec.w >> 4) & 15, mz = (rec.w >> 8) & 15;
+    const double vol = c0 * double(rec.w >> 12) * (rx[2 * ngp] * ry[2 * ngp] * rz[2 * ngp]);
+    double acc[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+      acc[i] = 0.0;
+    for (int q = 0; q < nq; ++q)
+    {
+      const int jx = s_J[q * 16 + mx], jy = s_J[q * 16 + my], jz = s_J[q * 16 + mz];
+      const double f = (a.kernel.qwts[q] * vol) * fma(rx[ngp + jx], ry[ngp + jy], rx[jx] * ry[jy] * rz[jz]);
+      if constexpr (ND == 4)
+      {
+        const double X0 = a.kernel.qpts[3 * q], X1 = a.kernel.qpts[3 * q + 1], X2 = a.kernel.qpts[3 * q + 2];
+        acc[0] = fma(f, 1.0 - X0 - X1 - X2, acc[0]);
+        acc[1] = fma(f, X0, acc[1]);
+        acc[2] = fma(f, X1, acc[2]);
+        acc[3] = fma(f, X2, acc[3]);
+      }
+      else
+      {
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+          acc[i] = fma(f, a.kernel.qphi[q * ND + i], acc[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+    {
+      const int32_t w = a.own_lmap[e * ND + i];
+      if (!((w >> MPCX_MASK_SHIFT) & 1))
+        __hip_atomic_fetch_add(s_b + (w & LMASK), acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < nown; i += NT)
+    a.b[MPCX_ROW_POS(a, r0 + i)] += s_b[i];
+  for (int i = tid; i < nhalo; i += NT)
+    a.own_spill[h0 + i] = s_b[nown + i];
+}
+
 // Owner-computes blocks for source forms whose integrand function is AFFINE in x (mpcx_kernel_t::vphi: constant / linear f on
 // affine simplices, no coefficient -- the momentum right-hand side of config 3).  With the rule's vertex moments the element
 // vector is NV * ND fma per component and the kernel is a gather / LDS-add problem: no quadrature loop, no 128-register
@@ -2304,6 +2430,39 @@ int launch_vector(const mpcx_vector_args_t& a)
       return -5;
     }
     bool affine_done = false;
+    if constexpr (Op::FORM == MPCX_FORM_SOURCE && (Op::DEG0 == 1 || Op::DEG0 == 2) && Op::BS0 == 1 && Op::TDIM == 3 && Op::FN == 1)
+    {
+      // the right-hand side from per-interval tables of the mesh's tensor grid, per cell (mpcx_vector_args_t::grid_eta / grid_J)
+      if (owner && a.grid_idx && a.grid_J)
+      {
+        if (!a.grid_eta || !a.grid_iv || !a.grid_tab || !a.grid_block_rows || a.grid_ng <= 0 || a.grid_block_rows_max <= 0 || a.coeffs
+            || a.estride != 1 || a.entities || a.kernel.coeff_degree != 0 || a.kernel.nq <= 0 || (Op::DEG0 == 2 && !a.kernel.qphi))
+        {
+          mpcx_set_error("mpcx_assemble_vector: grid_J needs grid_eta / grid_iv / grid_tab / grid_block_rows, all cells, no coefficient");
+          return -8;
+        }
+        const int ngp = (a.grid_ng + 1) & ~1, stride = 2 * ngp + 2;
+        const int rows = a.grid_n[0] + a.grid_n[1] + a.grid_n[2];
+        hipLaunchKernelGGL(cell_grid_tables_kernel, dim3(unsigned((int64_t(rows) * (ngp + 1) + 255) / 256)), dim3(256), 0, stream, a.grid_n[0],
+                           a.grid_n[1], a.grid_n[2], a.grid_iv, a.grid_tab, a.grid_eta, a.grid_ng);
+        const size_t glds = ((lds + 15) & ~size_t(15)) + size_t(a.grid_block_rows_max) * (stride + 2) * 8 + size_t(a.kernel.nq) * 16;
+        if (glds > 160 * 1024)
+        {
+          mpcx_set_error("mpcx_assemble_vector: the blocks' table rows do not fit LDS beside their rows of b");
+          return -4;
+        }
+        auto kernel = vector_cell_grid_kernel<Op::ND0>;
+        if (int rc = check(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(glds)),
+                           "hipFuncSetAttribute"))
+          return rc;
+        const char* e = std::getenv("MPCX_CELL_GRID_THREADS");
+        int threads = e ? std::atoi(e) : 1024;
+        if (threads < 64 || threads > 1024 || threads % 64)
+          threads = 1024;
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), glds, stream, a);
+        affine_done = true;
+      }
+    }
     if constexpr (Op::FORM == MPCX_FORM_SOURCE && (Op::DEG0 == 1 || Op::DEG0 == 2) && Op::FN != 1)
     {
       // integrand function affine in x (mpcx_kernel_t::vphi): the gather / LDS-add instance, 1024 threads

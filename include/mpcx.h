@@ -686,6 +686,16 @@ typedef struct
   int32_t grid_n[3];
   const int32_t* grid_block_rows;
   int32_t grid_block_rows_max;
+  /* The same per CELL (MPCX_ALG_ROWBLOCK, owner-computes, scalar P1 / P2 source with kernel.fn_id = 1, any rule, no
+   * coefficient): a simplex whose vertices take two values per axis (every cell of a box mesh) has its quadrature points at
+   * x_d = lo_d + h_d eta, eta = the sum of the barycentric coordinates of the vertices on the high side -- one of grid_ng
+   * values grid_eta (DEVICE [grid_ng]) for every point q and vertex subset m: grid_J (DEVICE [nq][16] bytes).  grid_idx then
+   * holds per cell (row_x, row_y, row_z, masks), rows = positions in its block's list (grid_block_rows is required),
+   * masks = m_x | m_y << 4 | m_z << 8 | (|det J| / (h_x h_y h_z)) << 12; rows of the table: 2 * ((grid_ng + 1) & ~1) + 2
+   * doubles.  NULL: not used. */
+  const double* grid_eta;
+  const uint8_t* grid_J;
+  int32_t grid_ng;
   int32_t lds_floor; /* as mpcx_matrix_args_t::lds_floor: minimum dynamic LDS per workgroup of the row-block / cluster launch */
   void* stream;
 } mpcx_vector_args_t;

@@ -392,6 +392,36 @@ def test_cluster_vector_on_the_tensor_grid_of_a_box(oracle, shape, mode, monkeyp
         _close(dm.assemble_vector(case.L, mpc).numpy(), ref3["b"], RTOL_B, f"{case.name} b after the mesh was sheared")
 
 
+@pytest.mark.parametrize("degree,warp,env", [(2, False, None), (2, False, "MPCX_VECTOR_OWNER_ROWS=512"), (1, False, "MPCX_FORCE_KERNEL=vector=ownblock"),
+                                             (2, "half", None), (2, True, None)])
+def test_cell_vector_from_the_tensor_grid_tables(oracle, degree, warp, env, monkeypatch):
+    """the benchmark's right-hand side per cell from per-interval tables (mpcx_vector_args_t::grid_eta / grid_J, any rule): scalar
+    P2 on a box mesh (24-point rule), small blocks (several row lists), P1 through the per-cell owner blocks (14-point rule), and
+    meshes with warped cells (no grid: point by point) -- against the oracle, and against the point-by-point evaluation"""
+    import importlib
+
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd.la import create_vector
+
+    if env:
+        monkeypatch.setenv(*env.split("=", 1))
+    case = case_cube_periodic(5, degree, 0.0, reorder=(2, 2, 2), warp=warp)
+    ref = oracle_outputs(oracle, case)
+    mpc = product_mpc(case)
+    av = importlib.import_module("dolfinx_mpc_amd.assemble_vector")
+    args = av.vector_args(case.L, 0, create_vector(case.V), mpc, 0)[0]
+    assert args.kernel_name == "ownblock"
+    assert bool(args.grid_J) == (not warp), "per-cell tables: exactly on meshes whose cells are cells of boxes"
+    got = dm.assemble_vector(case.L, mpc).numpy().copy()
+    _close(got, ref["b"], RTOL_B, f"{case.name} b")
+    monkeypatch.setenv("MPCX_CELL_GRID", "0")
+    assert not bool(av.vector_args(case.L, 0, create_vector(case.V), mpc, 0)[0].grid_J)
+    other = dm.assemble_vector(case.L, mpc).numpy()
+    assert abs(other - got).max() <= 1e-14 * abs(ref["b"]).max()
+    if not warp:
+        assert not np.array_equal(other, got), "the evaluations round differently: the switch had no effect"
+
+
 def test_cluster_plan_uses_narrow_and_wide_records(oracle):
     """the cluster plan keeps 64-byte records (4-bit offsets) for row blocks whose rows have at most 16 entries before
     any cluster column and 96-byte records for the blocks with fat rows (the periodic master rows): both formats are
