@@ -340,6 +340,25 @@ def _block_rows(pk, idx, ns):
     return rows.contiguous(), local.contiguous(), int(counts.max().item())
 
 
+def rule_subset_table(qpts):
+    """For a quadrature rule on the reference tetrahedron: the distinct sums of the barycentric coordinates of a point over a
+    proper vertex subset (``eta``, ascending) and ``J[q][m]`` = which of them point q has for subset m (bit v = vertex v, vertex 0
+    = the origin; m = 0 and 15 unused).  A cell of a box mesh has, along every axis, some of its vertices on the low and the
+    others on the high side of its interval: the coordinate of point q is lo + (hi - lo) eta[J[q][m]], m = the high ones.
+    None for rules with more than 250 distinct sums (one byte per entry)."""
+    q = np.asarray(qpts, dtype=np.float64).reshape(-1, 3)
+    lam = np.concatenate([1.0 - q.sum(axis=1, keepdims=True), q], axis=1)  # (nq, 4), vertex 0 first
+    sub = np.array([[(m >> v) & 1 for v in range(4)] for m in range(16)], dtype=np.float64)  # (16, 4)
+    inner = (lam @ sub.T)[:, 1:15]
+    eta = np.unique(np.round(inner.ravel(), 13))
+    if eta.size > 250:
+        return None
+    J = np.zeros((q.shape[0], 16), dtype=np.uint8)
+    J[:, 1:15] = np.abs(inner[..., None] - eta).argmin(axis=-1)
+    eta = np.array([inner[J[:, 1:15] == j].mean() for j in range(eta.size)])
+    return eta, J
+
+
 def _cell_grid(form, i, V, pk):
     """The per-cell twin of ``_cluster_grid`` (include/mpcx.h mpcx_vector_args_t::grid_eta / grid_J): for a scalar P1 / P2 source
     form over ALL cells of a tetrahedral mesh whose cells have their vertices on two values per axis (every cell of a box mesh),
@@ -370,18 +389,10 @@ def _cell_grid(form, i, V, pk):
             return None
         bits = torch.tensor([1, 2, 4, 8], device=x.device, dtype=torch.int64)
         masks = (on_hi.long() * bits[None, :, None]).sum(dim=1)  # (n, 3): vertices on the high side per axis
-        # the rule: sums of the barycentric coordinates over every vertex subset
-        q = np.asarray(k.qpts, dtype=np.float64).reshape(-1, 3)
-        lam = np.concatenate([1.0 - q.sum(axis=1, keepdims=True), q], axis=1)  # (nq, 4), vertex 0 first
-        sub = np.array([[(m >> v) & 1 for v in range(4)] for m in range(16)], dtype=np.float64)  # (16, 4)
-        sums = lam @ sub.T  # (nq, 16)
-        inner = sums[:, 1:15]
-        eta = np.unique(np.round(inner.ravel(), 13))
-        if eta.size > 250:
+        table = rule_subset_table(k.qpts)
+        if table is None:
             return None
-        J = np.zeros((q.shape[0], 16), dtype=np.uint8)
-        J[:, 1:15] = np.abs(inner[..., None] - eta).argmin(axis=-1)
-        eta = np.array([inner[J[:, 1:15] == j].mean() for j in range(eta.size)])
+        eta, J = table
         idx = torch.zeros((n, 4), dtype=torch.int32, device=x.device)
         ivs, ns = [], []
         for d in range(3):
