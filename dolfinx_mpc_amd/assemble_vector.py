@@ -374,41 +374,61 @@ def _cell_grid(form, i, V, pk):
     def build():
         md = D.mesh_device(mesh)
         x = md["x"].view(-1, 3)
-        dm = md["x_dofmap"].view(-1, 4).long()
+        dm = md["x_dofmap"].view(-1, 4)
         n = dm.shape[0]
-        X = x[dm]  # (n, 4, 3)
-        lo, hi = X.min(dim=1).values, X.max(dim=1).values
-        on_hi = X == hi[:, None, :]
-        if not bool((on_hi | (X == lo[:, None, :])).all()) or bool((hi == lo).any()):
-            return None
-        e1, e2, e3 = X[:, 1] - X[:, 0], X[:, 2] - X[:, 0], X[:, 3] - X[:, 0]
-        det = (e1 * torch.cross(e2, e3, dim=1)).sum(dim=1).abs()
-        ratio = det / (hi - lo).prod(dim=1)
-        cfac = torch.round(ratio)
-        if not bool(((ratio - cfac).abs() < 1e-9).all()) or not bool(((cfac >= 1) & (cfac <= 3)).all()):
-            return None
-        bits = torch.tensor([1, 2, 4, 8], device=x.device, dtype=torch.int64)
-        masks = (on_hi.long() * bits[None, :, None]).sum(dim=1)  # (n, 3): vertices on the high side per axis
         table = rule_subset_table(k.qpts)
         if table is None:
             return None
         eta, J = table
+        # axis by axis (a few n-vectors at a time: config 5 holds 89 M cells, and the counters of bench.py are taken by a second
+        # process beside the first)
         idx = torch.zeros((n, 4), dtype=torch.int32, device=x.device)
-        ivs, ns = [], []
+        masks, ivs, ns = [], [], []
+        vids = [dm[:, v].long() for v in range(4)]
         for d in range(3):
-            lo_u, lo_i = torch.unique(lo[:, d], return_inverse=True)
-            hi_u, hi_i = torch.unique(hi[:, d], return_inverse=True)
+            xd = x[:, d].contiguous()
+            c = [xd[vids[v]] for v in range(4)]
+            lo = torch.minimum(torch.minimum(c[0], c[1]), torch.minimum(c[2], c[3]))
+            hi = torch.maximum(torch.maximum(c[0], c[1]), torch.maximum(c[2], c[3]))
+            m = torch.zeros(n, dtype=torch.int32, device=x.device)
+            ok = hi > lo
+            for v in range(4):
+                on_hi = c[v] == hi
+                ok &= on_hi | (c[v] == lo)
+                m |= on_hi.to(torch.int32) << v
+            if not bool(ok.all()):
+                return None
+            del c, ok
+            masks.append(m)
+            lo_u, lo_i = torch.unique(lo, return_inverse=True)
+            hi_u, hi_i = torch.unique(hi, return_inverse=True)
+            del lo, hi
             pair_u, pair_i = torch.unique(lo_i * hi_u.numel() + hi_i, return_inverse=True)
+            del lo_i, hi_i
             idx[:, d] = pair_i.to(torch.int32)
+            del pair_i
             ivs.append(torch.stack([lo_u[pair_u // hi_u.numel()], hi_u[pair_u % hi_u.numel()]], dim=1))
             ns.append(int(pair_u.numel()))
+        del vids
         if sum(ns) > max(4096, n // 32):
             return None
+        # |det J| / (h_x h_y h_z) = |det| of the 0 / 1 matrix "vertex v on the high side of axis d" (edges from vertex 0):
+        # 1 for the tetrahedra of a Kuhn cut, 2 for the central one of a five-cell cut, 0 = flat
+        def col(d):
+            b = [((masks[d] >> v) & 1) for v in range(4)]
+            return [b[v] - b[0] for v in (1, 2, 3)]
+
+        a_, b_, c_ = col(0), col(1), col(2)  # a_[v]: entry (edge v, axis 0) ...
+        det = (a_[0] * (b_[1] * c_[2] - b_[2] * c_[1]) - a_[1] * (b_[0] * c_[2] - b_[2] * c_[0]) + a_[2] * (b_[0] * c_[1] - b_[1] * c_[0])).abs()
+        del a_, b_, c_
+        if not bool((det >= 1).all()):
+            return None
+        cfac = det
         staged = _block_rows(pk, idx, tuple(ns))
         if staged is None:
             return None
         rows, local, longest = staged
-        local[:, 3] = (masks[:, 0] | (masks[:, 1] << 4) | (masks[:, 2] << 8) | (cfac.long() << 12)).to(torch.int32)
+        local[:, 3] = masks[0] | (masks[1] << 4) | (masks[2] << 8) | (cfac << 12)
         ngp = (eta.size + 1) & ~1
         tab = torch.empty(sum(ns) * (2 * ngp + 2), dtype=torch.float64, device=x.device)
         return dict(rec=local.contiguous(), rows=rows, longest=longest, iv=torch.cat(ivs).contiguous(), ns=tuple(ns), tab=tab,
