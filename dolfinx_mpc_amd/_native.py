@@ -204,6 +204,7 @@ class VectorArgs(C.Structure):
         ("grid_eta", C.c_void_p),
         ("grid_J", C.c_void_p),
         ("grid_ng", C.c_int32),
+        ("grid_ntypes", C.c_int32),
         ("lds_floor", C.c_int32),
         ("stream", C.c_void_p),
     ]

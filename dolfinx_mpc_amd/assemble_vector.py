@@ -428,11 +428,23 @@ def _cell_grid(form, i, V, pk):
         if staged is None:
             return None
         rows, local, longest = staged
-        local[:, 3] = masks[0] | (masks[1] << 4) | (masks[2] << 8) | (cfac << 12)
+        # cell types: which vertices lie on the high side per axis (+ the determinant factor); per type and point the three
+        # indices into eta in one word
+        if eta.size > 255:
+            return None
+        tkey = masks[0] | (masks[1] << 4) | (masks[2] << 8)
+        types, tid = torch.unique(tkey, return_inverse=True)
+        if types.numel() * J.shape[0] > 4096:
+            return None
+        local[:, 3] = tid.to(torch.int32) | (cfac << 16)
+        th = types.cpu().numpy().astype(np.int64)
+        Jw = (J[:, th & 15].astype(np.uint32) | (J[:, (th >> 4) & 15].astype(np.uint32) << 8)
+              | (J[:, (th >> 8) & 15].astype(np.uint32) << 16)).T.copy()  # (ntypes, nq)
         ngp = (eta.size + 1) & ~1
         tab = torch.empty(sum(ns) * (2 * ngp + 2), dtype=torch.float64, device=x.device)
         return dict(rec=local.contiguous(), rows=rows, longest=longest, iv=torch.cat(ivs).contiguous(), ns=tuple(ns), tab=tab,
-                    eta=D._to_dev(eta, x.device), J=D._to_dev(J.reshape(-1), x.device), ng=int(eta.size))
+                    eta=D._to_dev(eta, x.device), J=D._to_dev(Jw.reshape(-1).view(np.int32), x.device), ng=int(eta.size),
+                    ntypes=int(types.numel()))
 
     return D.cached(form._device, "cell_grid", (pk,), (i, mesh.geometry.version), build, maxsize=2)
 
@@ -629,7 +641,7 @@ def vector_args(form: Form, i: int, b: Vector, constraint: MultiPointConstraint,
                     a.grid_idx, a.grid_iv, a.grid_tab = cg["rec"].data_ptr(), cg["iv"].data_ptr(), cg["tab"].data_ptr()
                     a.grid_n[0], a.grid_n[1], a.grid_n[2] = cg["ns"]
                     a.grid_block_rows, a.grid_block_rows_max = cg["rows"].data_ptr(), cg["longest"]
-                    a.grid_eta, a.grid_J, a.grid_ng = cg["eta"].data_ptr(), cg["J"].data_ptr(), cg["ng"]
+                    a.grid_eta, a.grid_J, a.grid_ng, a.grid_ntypes = cg["eta"].data_ptr(), cg["J"].data_ptr(), cg["ng"], cg["ntypes"]
                     keep += [cg]
         else:  # "rowblock" / "ufcx_rowblock": halo entities evaluated by every block they touch
             plan, pk = _vector_plan(form, i, V, nrows_blk)

@@ -1721,9 +1721,10 @@ __global__ void __launch_bounds__(MAXT) vector_ownblock_kernel(mpcx_vector_args_
 // vertices on two values per axis, so the coordinate of quadrature point q along axis d is lo_d + h_d eta with eta the sum of the
 // barycentric coordinates of the vertices on the high side, one of a few dozen values for all (q, subset).  The launch fills the
 // table of the univariate factors per interval (cell_grid_tables_kernel), a block stages the rows of its cells in LDS, and a
-// point costs three byte reads (which eta per axis), five value reads and ND + 3 fma instead of a sine, an exponential and
-// the affine map.  Row of interval r (2 NGP + 2 doubles, NGP = grid_ng rounded up to even): [0, NGP) g(t), [NGP, 2 NGP) t (axis
-// x) / sin(5 pi t) (axis y), [2 NGP] = |h|.
+// point costs one word (which eta per axis, by the cell's TYPE = which vertices lie high per axis: a box mesh has a handful),
+// two pairs and a value from the rows and ND + 3 fma instead of a sine, an exponential and the affine map.  Row of interval r
+// (2 NGP + 2 doubles, NGP = grid_ng rounded up to even): pairs (g(t_j), t_j) on axis x, (g(t_j), sin(5 pi t_j)) on y, (g(t_j), 0)
+// on z, j < grid_ng; [2 NGP] = |h|.
 __global__ void __launch_bounds__(256) cell_grid_tables_kernel(int n0, int n1, int n2, const double* __restrict__ iv, double* __restrict__ tab,
                                                                const double* __restrict__ eta, int ng)
 {
@@ -1744,20 +1745,21 @@ __global__ void __launch_bounds__(256) cell_grid_tables_kernel(int n0, int n1, i
   }
   if (j >= ng)
   {
-    row[j] = 0.0, row[ngp + j] = 0.0;
+    row[2 * j] = 0.0, row[2 * j + 1] = 0.0;
     return;
   }
   const FmConsts FK = g_fm_consts;
   const double centre = d == 0 ? 0.9 : (d == 1 ? 0.5 : 0.1);
   const double t = fma(h, eta[j], lo - centre); // relative to the centre of the Gaussian, as eval_fn case 1 does
-  row[j] = fast_exp_nonpos_k(-(t * t) * (1.0 / 0.02), FK);
-  row[ngp + j] = d == 0 ? t + 0.9 : (d == 1 ? fast_sinpi_k(fma(5.0, t, 2.5), FK) : 0.0);
+  row[2 * j] = fast_exp_nonpos_k(-(t * t) * (1.0 / 0.02), FK);
+  row[2 * j + 1] = d == 0 ? t + 0.9 : (d == 1 ? fast_sinpi_k(fma(5.0, t, 2.5), FK) : 0.0);
 }
 
 template <int ND>
 __global__ void __launch_bounds__(1024) vector_cell_grid_kernel(mpcx_vector_args_t a)
 {
   constexpr int LMASK = (1 << MPCX_MASK_SHIFT) - 1;
+  typedef double __attribute__((ext_vector_type(2))) pair_t;
   const int NT = blockDim.x;
   extern __shared__ __align__(16) unsigned char smem[];
   double* s_b = reinterpret_cast<double*>(smem); // [max_rows]: own rows, then halo rows
@@ -1776,8 +1778,8 @@ __global__ void __launch_bounds__(1024) vector_cell_grid_kernel(mpcx_vector_args
   const int lrow = stride + 2; // (LDS rows two doubles longer: rows of different intervals on different banks)
   const int nq = a.kernel.nq;
   const int nslots = a.grid_block_rows_max;
-  double* s_rows = s_b + ((a.plan.max_rows + 1) & ~1);             // [nslots][lrow]
-  uint8_t* s_J = reinterpret_cast<uint8_t*>(s_rows + nslots * lrow); // [nq][16]
+  double* s_rows = s_b + ((a.plan.max_rows + 1) & ~1);                 // [nslots][lrow]
+  uint32_t* s_J = reinterpret_cast<uint32_t*>(s_rows + nslots * lrow); // [grid_ntypes][nq]: eta index per axis, one byte each
   {
     const int32_t* __restrict__ br = a.grid_block_rows + int64_t(b) * MPCX_GRID_BLOCK_ROWS;
     for (int i = tid; i < nslots * stride; i += NT)
@@ -1787,8 +1789,9 @@ __global__ void __launch_bounds__(1024) vector_cell_grid_kernel(mpcx_vector_args
       if (r >= 0)
         s_rows[slot * lrow + j] = a.grid_tab[int64_t(r) * stride + j];
     }
-    for (int i = tid; i < nq * 16; i += NT)
-      s_J[i] = a.grid_J[i];
+    const uint32_t* __restrict__ gj = reinterpret_cast<const uint32_t*>(a.grid_J);
+    for (int i = tid; i < a.grid_ntypes * nq; i += NT)
+      s_J[i] = gj[i];
   }
   __syncthreads();
   const double c0 = a.constants ? a.constants[0] : 1.0;
@@ -1801,16 +1804,19 @@ __global__ void __launch_bounds__(1024) vector_cell_grid_kernel(mpcx_vector_args
     const double* __restrict__ rx = s_rows + rec.x * lrow;
     const double* __restrict__ ry = s_rows + rec.y * lrow;
     const double* __restrict__ rz = s_rows + rec.z * lrow;
-    const int mx = rec.w & 15, my = (rec.w >> 4) & 15, mz = (rec.w >> 8) & 15;
-    const double vol = c0 * double(rec.w >> 12) * (rx[2 * ngp] * ry[2 * ngp] * rz[2 * ngp]);
+    const uint32_t* __restrict__ jt = s_J + (rec.w & 0xffff) * nq;
+    const double vol = c0 * double(rec.w >> 16) * (rx[2 * ngp] * ry[2 * ngp] * rz[2 * ngp]);
     double acc[ND];
 #pragma unroll
     for (int i = 0; i < ND; ++i)
       acc[i] = 0.0;
     for (int q = 0; q < nq; ++q)
     {
-      const int jx = s_J[q * 16 + mx], jy = s_J[q * 16 + my], jz = s_J[q * 16 + mz];
-      const double f = (a.kernel.qwts[q] * vol) * fma(rx[ngp + jx], ry[ngp + jy], rx[jx] * ry[jy] * rz[jz]);
+      const uint32_t j = jt[q];
+      const pair_t px = *reinterpret_cast<const pair_t*>(rx + 2 * (j & 0xff));
+      const pair_t py = *reinterpret_cast<const pair_t*>(ry + 2 * ((j >> 8) & 0xff));
+      const double gz = rz[2 * ((j >> 16) & 0xff)];
+      const double f = (a.kernel.qwts[q] * vol) * fma(px.y, py.y, px.x * py.x * gz);
       if constexpr (ND == 4)
       {
         const double X0 = a.kernel.qpts[3 * q], X1 = a.kernel.qpts[3 * q + 1], X2 = a.kernel.qpts[3 * q + 2];
@@ -2435,7 +2441,8 @@ int launch_vector(const mpcx_vector_args_t& a)
       // the right-hand side from per-interval tables of the mesh's tensor grid, per cell (mpcx_vector_args_t::grid_eta / grid_J)
       if (owner && a.grid_idx && a.grid_J)
       {
-        if (!a.grid_eta || !a.grid_iv || !a.grid_tab || !a.grid_block_rows || a.grid_ng <= 0 || a.grid_block_rows_max <= 0 || a.coeffs
+        if (!a.grid_eta || !a.grid_iv || !a.grid_tab || !a.grid_block_rows || a.grid_ng <= 0 || a.grid_ng > 255 || a.grid_ntypes <= 0
+            || a.grid_ntypes > 65535 || a.grid_block_rows_max <= 0 || a.coeffs
             || a.estride != 1 || a.entities || a.kernel.coeff_degree != 0 || a.kernel.nq <= 0 || (Op::DEG0 == 2 && !a.kernel.qphi))
         {
           mpcx_set_error("mpcx_assemble_vector: grid_J needs grid_eta / grid_iv / grid_tab / grid_block_rows, all cells, no coefficient");
@@ -2445,7 +2452,8 @@ int launch_vector(const mpcx_vector_args_t& a)
         const int rows = a.grid_n[0] + a.grid_n[1] + a.grid_n[2];
         hipLaunchKernelGGL(cell_grid_tables_kernel, dim3(unsigned((int64_t(rows) * (ngp + 1) + 255) / 256)), dim3(256), 0, stream, a.grid_n[0],
                            a.grid_n[1], a.grid_n[2], a.grid_iv, a.grid_tab, a.grid_eta, a.grid_ng);
-        const size_t glds = ((lds + 15) & ~size_t(15)) + size_t(a.grid_block_rows_max) * (stride + 2) * 8 + size_t(a.kernel.nq) * 16;
+        const size_t glds = ((lds + 15) & ~size_t(15)) + size_t(a.grid_block_rows_max) * (stride + 2) * 8
+                            + size_t(a.grid_ntypes) * a.kernel.nq * 4;
         if (glds > 160 * 1024)
         {
           mpcx_set_error("mpcx_assemble_vector: the blocks' table rows do not fit LDS beside their rows of b");

@@ -689,13 +689,15 @@ typedef struct
   /* The same per CELL (MPCX_ALG_ROWBLOCK, owner-computes, scalar P1 / P2 source with kernel.fn_id = 1, any rule, no
    * coefficient): a simplex whose vertices take two values per axis (every cell of a box mesh) has its quadrature points at
    * x_d = lo_d + h_d eta, eta = the sum of the barycentric coordinates of the vertices on the high side -- one of grid_ng
-   * values grid_eta (DEVICE [grid_ng]) for every point q and vertex subset m: grid_J (DEVICE [nq][16] bytes).  grid_idx then
-   * holds per cell (row_x, row_y, row_z, masks), rows = positions in its block's list (grid_block_rows is required),
-   * masks = m_x | m_y << 4 | m_z << 8 | (|det J| / (h_x h_y h_z)) << 12; rows of the table: 2 * ((grid_ng + 1) & ~1) + 2
-   * doubles.  NULL: not used. */
+   * (<= 255) values grid_eta (DEVICE [grid_ng]) for every point q and vertex subset.  Cells with the same subsets per axis
+   * and the same |det J| / (h_x h_y h_z) are of one TYPE (a box mesh has a handful): grid_J DEVICE [grid_ntypes][nq] words,
+   * the index of eta along x | y << 8 | z << 16 for point q of a cell of that type.  grid_idx then holds per cell (row_x, row_y,
+   * row_z, type | (|det J| / (h_x h_y h_z)) << 16), rows = positions in its block's list (grid_block_rows is required); rows of
+   * the table: 2 * ((grid_ng + 1) & ~1) + 2 doubles.  NULL: not used. */
   const double* grid_eta;
-  const uint8_t* grid_J;
+  const uint32_t* grid_J;
   int32_t grid_ng;
+  int32_t grid_ntypes;
   int32_t lds_floor; /* as mpcx_matrix_args_t::lds_floor: minimum dynamic LDS per workgroup of the row-block / cluster launch */
   void* stream;
 } mpcx_vector_args_t;
