@@ -294,6 +294,9 @@ EXPORTS = [
     "mpcx_grid_plan_num_intervals",
     "mpcx_grid_plan_block_rows",
     "mpcx_grid_plan_destroy",
+    "mpcx_cell_grid_plan_create",
+    "mpcx_cell_grid_plan_fill",
+    "mpcx_cell_grid_plan_destroy",
     "mpcx_owner_plan_create",
     "mpcx_owner_plan_fill",
     "mpcx_owner_plan_destroy",
@@ -649,6 +652,12 @@ def lib() -> C.CDLL:
     L.mpcx_grid_plan_block_rows.restype = i32
     L.mpcx_grid_plan_destroy.argtypes = [vp]
     L.mpcx_grid_plan_destroy.restype = None
+    L.mpcx_cell_grid_plan_create.argtypes = [vp, i64, vp, C.POINTER(RowBlockPlanT), vp, i32, vp, C.POINTER(vp)]
+    L.mpcx_cell_grid_plan_create.restype = C.c_int
+    L.mpcx_cell_grid_plan_fill.argtypes = [vp, C.POINTER(VectorArgs)]
+    L.mpcx_cell_grid_plan_fill.restype = C.c_int
+    L.mpcx_cell_grid_plan_destroy.argtypes = [vp]
+    L.mpcx_cell_grid_plan_destroy.restype = None
     L.mpcx_version.argtypes = []
     L.mpcx_version.restype = C.c_int
     L.mpcx_preload.argtypes = [vp]

@@ -12,6 +12,7 @@
 #include "mpcx_internal.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <hip/hip_runtime.h>
@@ -1163,7 +1164,7 @@ __device__ inline int64_t ordered_key(double v)
 // per cluster: is it an axis-aligned box with its vertices in corner order (compared exactly, as the cluster kernel does)?
 // keys[d][c] = its low corner coordinate as a sortable key, hi[d][c] = the high corner's
 __global__ void grid_box_keys_kernel(int64_t n, const int32_t* __restrict__ verts, const double* __restrict__ x, int64_t* __restrict__ keys,
-                                     double* __restrict__ hi, int32_t* __restrict__ not_box)
+                                     double* __restrict__ lo, double* __restrict__ hi, int32_t* __restrict__ not_box)
 {
   const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (c >= n)
@@ -1181,6 +1182,7 @@ __global__ void grid_box_keys_kernel(int64_t n, const int32_t* __restrict__ vert
   for (int d = 0; d < 3; ++d)
   {
     keys[d * n + c] = ordered_key(X[0][d]);
+    lo[d * n + c] = X[0][d];
     hi[d * n + c] = X[7][d];
   }
 }
@@ -1198,8 +1200,8 @@ __global__ void grid_heads_kernel(int64_t n, const int64_t* __restrict__ skeys, 
 }
 // interval of every cluster along one axis (written into column d of idx), and the interval table
 __global__ void grid_assign_kernel(int64_t n, const int32_t* __restrict__ order, const int32_t* __restrict__ head, const int32_t* __restrict__ excl,
-                                   const double* __restrict__ x, const int32_t* __restrict__ verts, const double* __restrict__ hi, int d,
-                                   int32_t* __restrict__ idx, double* __restrict__ iv)
+                                   const double* __restrict__ lo, const double* __restrict__ hi, int d, int32_t* __restrict__ idx,
+                                   double* __restrict__ iv)
 {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n)
@@ -1209,7 +1211,7 @@ __global__ void grid_assign_kernel(int64_t n, const int32_t* __restrict__ order,
   idx[4 * c + d] = r;
   if (head[i])
   {
-    iv[2 * r] = x[3 * int64_t(verts[8 * c]) + d];
+    iv[2 * r] = lo[c];
     iv[2 * r + 1] = hi[c];
   }
 }
@@ -1266,6 +1268,90 @@ __global__ void fill_i32_kernel(int64_t n, int32_t v, int32_t* out)
 }
 } // namespace
 
+// Per block of an owner-computes plan the table rows its work items need (<= MPCX_GRID_BLOCK_ROWS, ascending), and the items'
+// three rows as positions in the list of their block: rows [num_blocks][MPCX_GRID_BLOCK_ROWS] (-1 = unused), local [n][4]
+// (column 3 left 0), longest = the longest list -- or 0 with empty outputs when a block needs more rows (or no plan is given).
+static int grid_block_lists(int64_t n, const int32_t* idx, int32_t n0, int32_t n1, const mpcx_rowblock_plan_t* plan, void* stream, Dev& rows_out,
+                            Dev& local_out, int32_t& longest_out)
+{
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  longest_out = 0;
+  if (!(plan && plan->num_blocks > 0 && plan->block_ent_off && plan->block_ents))
+    return 0;
+  const int32_t nb = plan->num_blocks;
+  int64_t nents = 0;
+  if (hip_ok(hipMemcpyAsync(&nents, plan->block_ent_off + nb, 8, hipMemcpyDeviceToHost, st), "hipMemcpyAsync")
+      || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+    return -100;
+  const int64_t n3 = 3 * nents;
+  if (nents <= 0 || n3 >= (int64_t(1) << 31))
+    return 0;
+  Dev bkeys, bskeys, biota, border, bhead, bexcl, first, longest, rows, local;
+  if (bkeys.alloc(size_t(n3) * 8) || bskeys.alloc(size_t(n3) * 8) || biota.alloc(size_t(n3) * 4) || border.alloc(size_t(n3) * 4)
+      || bhead.alloc(size_t(n3) * 4) || bexcl.alloc(size_t(n3 + 1) * 4) || first.alloc(size_t(nb + 1) * 8) || longest.alloc(16)
+      || rows.alloc(size_t(nb) * MPCX_GRID_BLOCK_ROWS * 4) || local.alloc(size_t(n) * 16))
+    return -100;
+  if (hip_ok(hipMemsetAsync(longest.p, 0, 16, st), "hipMemsetAsync") || hip_ok(hipMemsetAsync(local.p, 0, size_t(n) * 16, st), "hipMemsetAsync"))
+    return -100;
+  hipLaunchKernelGGL(fill_i32_kernel, dim3(grid_for(int64_t(nb) * MPCX_GRID_BLOCK_ROWS, 256)), dim3(256), 0, st,
+                     int64_t(nb) * MPCX_GRID_BLOCK_ROWS, -1, rows.as<int32_t>());
+  hipLaunchKernelGGL(grid_block_keys_kernel, dim3(grid_for(nents, 256)), dim3(256), 0, st, nents, nb, plan->block_ent_off, plan->block_ents, idx,
+                     n0, n0 + n1, bkeys.as<int64_t>());
+  hipLaunchKernelGGL(iota_i32, dim3(grid_for(n3, 256)), dim3(256), 0, st, n3, biota.as<int32_t>());
+  if (int rc = with_temp([&](void* t, size_t* b) { return mpcx_sort_pairs_i64_i32(bkeys.as<int64_t>(), bskeys.as<int64_t>(), biota.as<int32_t>(),
+                                                                                  border.as<int32_t>(), n3, 0, 64, t, b, stream); }))
+    return rc;
+  hipLaunchKernelGGL(grid_heads_kernel, dim3(grid_for(n3, 256)), dim3(256), 0, st, n3, bskeys.as<int64_t>(), border.as<int32_t>(),
+                     static_cast<const double*>(nullptr), bhead.as<int32_t>(), static_cast<int32_t*>(nullptr));
+  if (int rc = with_temp([&](void* t, size_t* b) { return mpcx_scan_exclusive_i32(bhead.as<int32_t>(), n3, bexcl.as<int32_t>(), t, b, stream); }))
+    return rc;
+  if (int rc = mpcx_segment_offsets(bskeys.as<int64_t>(), n3, 32, nb, first.as<int64_t>(), stream))
+    return rc;
+  hipLaunchKernelGGL(grid_block_rows_kernel, dim3(grid_for(n3, 256)), dim3(256), 0, st, n3, nents, bskeys.as<int64_t>(), border.as<int32_t>(),
+                     bhead.as<int32_t>(), bexcl.as<int32_t>(), first.as<int64_t>(), plan->block_ents, rows.as<int32_t>(), local.as<int32_t>(),
+                     longest.as<int32_t>());
+  int32_t lg = 0;
+  if (hip_ok(hipMemcpyAsync(&lg, longest.p, 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync") || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+    return -100;
+  if (lg > 0 && lg <= MPCX_GRID_BLOCK_ROWS)
+  {
+    longest_out = lg;
+    rows_out = std::move(rows);
+    local_out = std::move(local);
+  }
+  return 0;
+}
+
+// One axis of the tensor grid: work items sorted by the low end of their interval (keys = ordered_key(lo)); every low end must
+// come with ONE high end.  Writes the interval of every item into column d of idx, the intervals (lo, hi) into ivd, their
+// number into nd.  Returns 1 when two items start at one coordinate and end at different ones (no tensor grid).
+static int grid_axis(int64_t n, const int64_t* keys, const double* lo, const double* hi, int d, int32_t* idx, Dev& ivd, int32_t& nd, Dev& skeys,
+                     Dev& iota, Dev& order, Dev& head, Dev& excl, Dev& flag, void* stream)
+{
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hip_ok(hipMemsetAsync(flag.p, 0, 16, st), "hipMemsetAsync"))
+    return -100;
+  if (int rc = with_temp([&](void* t, size_t* b) { return mpcx_sort_pairs_i64_i32(keys, skeys.as<int64_t>(), iota.as<int32_t>(), order.as<int32_t>(), n,
+                                                                                  0, 64, t, b, stream); }))
+    return rc;
+  hipLaunchKernelGGL(grid_heads_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, n, skeys.as<int64_t>(), order.as<int32_t>(), hi, head.as<int32_t>(),
+                     flag.as<int32_t>());
+  if (int rc = with_temp([&](void* t, size_t* b) { return mpcx_scan_exclusive_i32(head.as<int32_t>(), n, excl.as<int32_t>(), t, b, stream); }))
+    return rc;
+  int32_t total = 0, bad = 0;
+  if (hip_ok(hipMemcpyAsync(&total, excl.as<int32_t>() + n, 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync")
+      || hip_ok(hipMemcpyAsync(&bad, flag.p, 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync") || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+    return -100;
+  if (bad)
+    return 1;
+  nd = total;
+  if (ivd.alloc(size_t(nd) * 16))
+    return -100;
+  hipLaunchKernelGGL(grid_assign_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, n, order.as<int32_t>(), head.as<int32_t>(), excl.as<int32_t>(), lo, hi,
+                     d, idx, ivd.as<double>());
+  return 0;
+}
+
 struct mpcx_grid_plan
 {
   Dev idx, iv, tab, rows, local;
@@ -1294,48 +1380,28 @@ extern "C" int mpcx_grid_plan_create(const int32_t* cube_verts, int64_t n_cubes,
       std::fprintf(stderr, "mpcx_grid_plan_create: %s -> %s\n", what, hipGetErrorString(e));
     }
   };
-  Dev keys, hi, flag, skeys, iota, order, head, excl;
-  if (keys.alloc(size_t(3 * n) * 8) || hi.alloc(size_t(3 * n) * 8) || flag.alloc(16) || skeys.alloc(size_t(n) * 8) || iota.alloc(size_t(n) * 4)
-      || order.alloc(size_t(n) * 4) || head.alloc(size_t(n) * 4) || excl.alloc(size_t(n + 1) * 4) /* (+ the total) */
+  Dev keys, lo, hi, flag, skeys, iota, order, head, excl;
+  if (keys.alloc(size_t(3 * n) * 8) || lo.alloc(size_t(3 * n) * 8) || hi.alloc(size_t(3 * n) * 8) || flag.alloc(16) || skeys.alloc(size_t(n) * 8)
+      || iota.alloc(size_t(n) * 4) || order.alloc(size_t(n) * 4) || head.alloc(size_t(n) * 4) || excl.alloc(size_t(n + 1) * 4) /* (+ the total) */
       || g->idx.alloc(size_t(n) * 16))
     return -100;
   if (hip_ok(hipMemsetAsync(flag.p, 0, 16, st), "hipMemsetAsync") || hip_ok(hipMemsetAsync(g->idx.p, 0, size_t(n) * 16, st), "hipMemsetAsync"))
     return -100;
-  hipLaunchKernelGGL(grid_box_keys_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, n, cube_verts, x, keys.as<int64_t>(), hi.as<double>(),
-                     flag.as<int32_t>());
+  hipLaunchKernelGGL(grid_box_keys_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, n, cube_verts, x, keys.as<int64_t>(), lo.as<double>(),
+                     hi.as<double>(), flag.as<int32_t>());
   hipLaunchKernelGGL(iota_i32, dim3(grid_for(n, 256)), dim3(256), 0, st, n, iota.as<int32_t>());
   stage("box keys");
-  int32_t bad[2] = {0, 0};
-  if (hip_ok(hipMemcpyAsync(bad, flag.p, 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync") || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+  int32_t not_box = 0;
+  if (hip_ok(hipMemcpyAsync(&not_box, flag.p, 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync") || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
     return -100;
-  if (bad[0])
+  if (not_box)
     return 1; // a cluster that is not a box in corner order: no plan (*out stays NULL), not an error
   Dev ivd[3];
   for (int d = 0; d < 3; ++d)
   {
-    if (int rc = with_temp([&](void* t, size_t* b) { return mpcx_sort_pairs_i64_i32(keys.as<int64_t>() + d * n, skeys.as<int64_t>(), iota.as<int32_t>(),
-                                                                                    order.as<int32_t>(), n, 0, 64, t, b, stream); }))
-      return rc;
-    stage("axis sort");
-    hipLaunchKernelGGL(grid_heads_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, n, skeys.as<int64_t>(), order.as<int32_t>(),
-                       hi.as<double>() + d * n, head.as<int32_t>(), flag.as<int32_t>() + 1);
-    stage("axis heads");
-    if (int rc = with_temp([&](void* t, size_t* b) { return mpcx_scan_exclusive_i32(head.as<int32_t>(), n, excl.as<int32_t>(), t, b, stream); }))
-      return rc;
-    stage("axis scan");
-    int32_t last[2] = {0, 0};
-    if (hip_ok(hipMemcpyAsync(&last[0], excl.as<int32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync")
-        || hip_ok(hipMemcpyAsync(&last[1], head.as<int32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync")
-        || hip_ok(hipMemcpyAsync(&bad[1], flag.as<int32_t>() + 1, 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync")
-        || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
-      return -100;
-    if (bad[1])
-      return 1; // two clusters start at one coordinate and end at different ones: no tensor grid
-    g->n[d] = last[0] + last[1];
-    if (ivd[d].alloc(size_t(g->n[d]) * 16))
-      return -100;
-    hipLaunchKernelGGL(grid_assign_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, n, order.as<int32_t>(), head.as<int32_t>(), excl.as<int32_t>(),
-                       x, cube_verts, hi.as<double>() + d * n, d, g->idx.as<int32_t>(), ivd[d].as<double>());
+    if (int rc = grid_axis(n, keys.as<int64_t>() + d * n, lo.as<double>() + d * n, hi.as<double>() + d * n, d, g->idx.as<int32_t>(), ivd[d], g->n[d],
+                           skeys, iota, order, head, excl, flag, stream))
+      return rc; // (1: two clusters start at one coordinate and end at different ones -- no tensor grid)
     stage("axis");
   }
   const int64_t ntot = int64_t(g->n[0]) + g->n[1] + g->n[2];
@@ -1347,60 +1413,218 @@ extern "C" int mpcx_grid_plan_create(const int32_t* cube_verts, int64_t n_cubes,
     if (hip_ok(hipMemcpyAsync(g->iv.as<double>() + 2 * o, ivd[d].p, size_t(g->n[d]) * 16, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync"))
       return -100;
   // per block of the owner plan the rows it needs, the clusters numbered by them (optional)
-  if (plan && plan->num_blocks > 0 && plan->block_ent_off && plan->block_ents)
-  {
-    const int32_t nb = plan->num_blocks;
-    int64_t nents = 0;
-    if (hip_ok(hipMemcpyAsync(&nents, plan->block_ent_off + nb, 8, hipMemcpyDeviceToHost, st), "hipMemcpyAsync")
-        || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
-      return -100;
-    const int64_t n3 = 3 * nents;
-    if (nents > 0 && n3 < (int64_t(1) << 31))
-    {
-      Dev bkeys, bskeys, biota, border, bhead, bexcl, first, longest, rows, local;
-      if (bkeys.alloc(size_t(n3) * 8) || bskeys.alloc(size_t(n3) * 8) || biota.alloc(size_t(n3) * 4) || border.alloc(size_t(n3) * 4)
-          || bhead.alloc(size_t(n3) * 4) || bexcl.alloc(size_t(n3 + 1) * 4) || first.alloc(size_t(nb + 1) * 8) || longest.alloc(16)
-          || rows.alloc(size_t(nb) * MPCX_GRID_BLOCK_ROWS * 4) || local.alloc(size_t(n) * 16))
-        return -100;
-      if (hip_ok(hipMemsetAsync(longest.p, 0, 16, st), "hipMemsetAsync") || hip_ok(hipMemsetAsync(local.p, 0, size_t(n) * 16, st), "hipMemsetAsync"))
-        return -100;
-      hipLaunchKernelGGL(fill_i32_kernel, dim3(grid_for(int64_t(nb) * MPCX_GRID_BLOCK_ROWS, 256)), dim3(256), 0, st,
-                         int64_t(nb) * MPCX_GRID_BLOCK_ROWS, -1, rows.as<int32_t>());
-      hipLaunchKernelGGL(grid_block_keys_kernel, dim3(grid_for(nents, 256)), dim3(256), 0, st, nents, nb, plan->block_ent_off, plan->block_ents,
-                         g->idx.as<int32_t>(), g->n[0], g->n[0] + g->n[1], bkeys.as<int64_t>());
-      stage("block keys");
-      hipLaunchKernelGGL(iota_i32, dim3(grid_for(n3, 256)), dim3(256), 0, st, n3, biota.as<int32_t>());
-      if (int rc = with_temp([&](void* t, size_t* b) { return mpcx_sort_pairs_i64_i32(bkeys.as<int64_t>(), bskeys.as<int64_t>(), biota.as<int32_t>(),
-                                                                                      border.as<int32_t>(), n3, 0, 64, t, b, stream); }))
-        return rc;
-      hipLaunchKernelGGL(grid_heads_kernel, dim3(grid_for(n3, 256)), dim3(256), 0, st, n3, bskeys.as<int64_t>(), border.as<int32_t>(),
-                         static_cast<const double*>(nullptr), bhead.as<int32_t>(), static_cast<int32_t*>(nullptr));
-      if (int rc = with_temp([&](void* t, size_t* b) { return mpcx_scan_exclusive_i32(bhead.as<int32_t>(), n3, bexcl.as<int32_t>(), t, b, stream); }))
-        return rc;
-      stage("block sort + heads + scan");
-      if (int rc = mpcx_segment_offsets(bskeys.as<int64_t>(), n3, 32, nb, first.as<int64_t>(), stream))
-        return rc;
-      stage("segment offsets");
-      hipLaunchKernelGGL(grid_block_rows_kernel, dim3(grid_for(n3, 256)), dim3(256), 0, st, n3, nents, bskeys.as<int64_t>(), border.as<int32_t>(),
-                         bhead.as<int32_t>(), bexcl.as<int32_t>(), first.as<int64_t>(), plan->block_ents, rows.as<int32_t>(), local.as<int32_t>(),
-                         longest.as<int32_t>());
-      stage("block rows");
-      int32_t lg = 0;
-      if (hip_ok(hipMemcpyAsync(&lg, longest.p, 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync") || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
-        return -100;
-      if (lg > 0 && lg <= MPCX_GRID_BLOCK_ROWS)
-      {
-        g->longest = lg;
-        g->rows = std::move(rows);
-        g->local = std::move(local);
-      }
-    }
-  }
+  if (int rc = grid_block_lists(n, g->idx.as<int32_t>(), g->n[0], g->n[1], plan, stream, g->rows, g->local, g->longest))
+    return rc;
   if (hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
     return -100;
   *out = g.release();
   return 0;
 }
+// ---- the same per CELL (mpcx_vector_args_t::grid_eta / grid_J): simplices with their vertices on two values per axis -----------
+namespace
+{
+// per cell and axis: low / high end of its interval, which vertices lie on the high end; *bad when a vertex lies on neither
+__global__ void cell_box_keys_kernel(int64_t n, const int32_t* __restrict__ cells, const double* __restrict__ x, int64_t* __restrict__ keys,
+                                     double* __restrict__ lo, double* __restrict__ hi, int32_t* __restrict__ tkey, int32_t* __restrict__ cfac,
+                                     int32_t* __restrict__ seen, int32_t* __restrict__ bad)
+{
+  const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (c >= n)
+    return;
+  double X[4][3];
+  for (int v = 0; v < 4; ++v)
+    for (int d = 0; d < 3; ++d)
+      X[v][d] = x[3 * int64_t(cells[4 * c + v]) + d];
+  int m[3];
+  bool ok = true;
+  for (int d = 0; d < 3; ++d)
+  {
+    const double l = fmin(fmin(X[0][d], X[1][d]), fmin(X[2][d], X[3][d])), h = fmax(fmax(X[0][d], X[1][d]), fmax(X[2][d], X[3][d]));
+    m[d] = 0;
+    for (int v = 0; v < 4; ++v)
+    {
+      ok &= X[v][d] == l || X[v][d] == h;
+      m[d] |= (X[v][d] == h ? 1 : 0) << v;
+    }
+    ok &= h > l;
+    keys[d * n + c] = ordered_key(l);
+    lo[d * n + c] = l;
+    hi[d * n + c] = h;
+  }
+  // |det J| / (h_x h_y h_z): the determinant of the 0 / 1 matrix "vertex on the high side" (edges from vertex 0)
+  int e[3][3];
+  for (int v = 1; v < 4; ++v)
+    for (int d = 0; d < 3; ++d)
+      e[v - 1][d] = ((m[d] >> v) & 1) - (m[d] & 1);
+  int det = e[0][0] * (e[1][1] * e[2][2] - e[1][2] * e[2][1]) - e[0][1] * (e[1][0] * e[2][2] - e[1][2] * e[2][0])
+            + e[0][2] * (e[1][0] * e[2][1] - e[1][1] * e[2][0]);
+  det = det < 0 ? -det : det;
+  ok &= det >= 1;
+  if (!ok)
+    *bad = 1;
+  const int key = m[0] | (m[1] << 4) | (m[2] << 8);
+  tkey[c] = key;
+  cfac[c] = det;
+  seen[key] = 1;
+}
+__global__ void cell_types_kernel(int64_t n, const int32_t* __restrict__ tkey, const int32_t* __restrict__ cfac, const int32_t* __restrict__ type_of,
+                                  int32_t* __restrict__ rec)
+{
+  const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (c < n)
+    rec[4 * c + 3] = type_of[tkey[c]] | (cfac[c] << 16);
+}
+} // namespace
+
+struct mpcx_cell_grid_plan
+{
+  Dev iv, tab, rows, rec, eta, J;
+  int32_t n[3] = {0, 0, 0};
+  int32_t longest = 0, ng = 0, ntypes = 0;
+};
+
+extern "C" int mpcx_cell_grid_plan_create(const int32_t* cells, int64_t n_cells, const double* x, const mpcx_rowblock_plan_t* plan,
+                                          const double* qpts_host, int32_t nq, void* stream, mpcx_cell_grid_plan_t** out)
+{
+  if (!out || !cells || !x || !plan || !qpts_host || nq <= 0 || n_cells <= 0 || n_cells * 3 >= (int64_t(1) << 31))
+  {
+    mpcx_set_error("mpcx_cell_grid_plan_create: invalid arguments");
+    return -1;
+  }
+  *out = nullptr;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t n = n_cells;
+  auto g = std::make_unique<mpcx_cell_grid_plan>();
+  // the rule: sums of the barycentric coordinates of a point over every proper vertex subset (assemble_vector.rule_subset_table)
+  std::vector<double> sums(size_t(nq) * 14), eta;
+  for (int q = 0; q < nq; ++q)
+  {
+    const double lam[4] = {1.0 - qpts_host[3 * q] - qpts_host[3 * q + 1] - qpts_host[3 * q + 2], qpts_host[3 * q], qpts_host[3 * q + 1],
+                           qpts_host[3 * q + 2]};
+    for (int m = 1; m < 15; ++m)
+    {
+      double v = 0.0;
+      for (int k = 0; k < 4; ++k)
+        if ((m >> k) & 1)
+          v += lam[k];
+      sums[size_t(q) * 14 + (m - 1)] = v;
+    }
+  }
+  {
+    std::vector<double> sorted(sums);
+    std::sort(sorted.begin(), sorted.end());
+    std::vector<double> acc;
+    std::vector<int> cnt;
+    for (double v : sorted)
+      if (acc.empty() || v - acc.back() / cnt.back() > 5e-14)
+        acc.push_back(v), cnt.push_back(1);
+      else
+        acc.back() += v, ++cnt.back();
+    for (size_t k = 0; k < acc.size(); ++k)
+      eta.push_back(acc[k] / cnt[k]);
+  }
+  if (eta.size() > 255)
+    return 1;
+  auto eta_index = [&](double v)
+  {
+    size_t best = 0;
+    for (size_t k = 1; k < eta.size(); ++k)
+      if (std::fabs(eta[k] - v) < std::fabs(eta[best] - v))
+        best = k;
+    return uint32_t(best);
+  };
+  Dev keys, lo, hi, flag, skeys, iota, order, head, excl, tkey, cfac, seen, idx;
+  if (keys.alloc(size_t(3 * n) * 8) || lo.alloc(size_t(3 * n) * 8) || hi.alloc(size_t(3 * n) * 8) || flag.alloc(16) || skeys.alloc(size_t(n) * 8)
+      || iota.alloc(size_t(n) * 4) || order.alloc(size_t(n) * 4) || head.alloc(size_t(n) * 4) || excl.alloc(size_t(n + 1) * 4)
+      || tkey.alloc(size_t(n) * 4) || cfac.alloc(size_t(n) * 4) || seen.alloc(4096 * 4) || idx.alloc(size_t(n) * 16))
+    return -100;
+  if (hip_ok(hipMemsetAsync(flag.p, 0, 16, st), "hipMemsetAsync") || hip_ok(hipMemsetAsync(seen.p, 0, 4096 * 4, st), "hipMemsetAsync")
+      || hip_ok(hipMemsetAsync(idx.p, 0, size_t(n) * 16, st), "hipMemsetAsync"))
+    return -100;
+  hipLaunchKernelGGL(cell_box_keys_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, n, cells, x, keys.as<int64_t>(), lo.as<double>(), hi.as<double>(),
+                     tkey.as<int32_t>(), cfac.as<int32_t>(), seen.as<int32_t>(), flag.as<int32_t>());
+  hipLaunchKernelGGL(iota_i32, dim3(grid_for(n, 256)), dim3(256), 0, st, n, iota.as<int32_t>());
+  int32_t bad = 0;
+  std::vector<int32_t> seen_h(4096);
+  if (hip_ok(hipMemcpyAsync(&bad, flag.p, 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync")
+      || hip_ok(hipMemcpyAsync(seen_h.data(), seen.p, 4096 * 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync")
+      || hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+    return -100;
+  if (bad)
+    return 1; // a cell with a vertex between the ends of its interval (not a cell of a box), or a flat one
+  Dev ivd[3];
+  for (int d = 0; d < 3; ++d)
+    if (int rc = grid_axis(n, keys.as<int64_t>() + d * n, lo.as<double>() + d * n, hi.as<double>() + d * n, d, idx.as<int32_t>(), ivd[d], g->n[d], skeys,
+                           iota, order, head, excl, flag, stream))
+      return rc;
+  const int64_t ntot = int64_t(g->n[0]) + g->n[1] + g->n[2];
+  if (ntot > std::max<int64_t>(4096, n / 32))
+    return 1;
+  if (int rc = grid_block_lists(n, idx.as<int32_t>(), g->n[0], g->n[1], plan, stream, g->rows, g->rec, g->longest))
+    return rc;
+  if (g->longest == 0)
+    return 1; // a block needs more rows than it can stage: the per-cell launch has no other way to the table
+  // cell types (ascending by their mask word) and the index word of every (type, point)
+  std::vector<int32_t> type_of(4096, 0);
+  std::vector<uint32_t> Jw;
+  for (int key = 0; key < 4096; ++key)
+    if (seen_h[key])
+    {
+      type_of[key] = g->ntypes++;
+      for (int q = 0; q < nq; ++q)
+      {
+        uint32_t w = 0;
+        for (int d = 0; d < 3; ++d)
+        {
+          const int m = (key >> (4 * d)) & 15;
+          w |= (m >= 1 && m <= 14 ? eta_index(sums[size_t(q) * 14 + (m - 1)]) : 0u) << (8 * d);
+        }
+        Jw.push_back(w);
+      }
+    }
+  if (size_t(g->ntypes) * nq > 4096)
+    return 1;
+  g->ng = int32_t(eta.size());
+  const int ngp = (g->ng + 1) & ~1;
+  Dev type_dev;
+  if (type_dev.alloc(4096 * 4) || g->eta.alloc(eta.size() * 8) || g->J.alloc(Jw.size() * 4) || g->iv.alloc(size_t(ntot) * 16)
+      || g->tab.alloc(size_t(ntot) * (2 * ngp + 2) * 8))
+    return -100;
+  if (hip_ok(hipMemcpyAsync(type_dev.p, type_of.data(), 4096 * 4, hipMemcpyHostToDevice, st), "hipMemcpyAsync")
+      || hip_ok(hipMemcpyAsync(g->eta.p, eta.data(), eta.size() * 8, hipMemcpyHostToDevice, st), "hipMemcpyAsync")
+      || hip_ok(hipMemcpyAsync(g->J.p, Jw.data(), Jw.size() * 4, hipMemcpyHostToDevice, st), "hipMemcpyAsync"))
+    return -100;
+  for (int d = 0, o = 0; d < 3; o += g->n[d], ++d)
+    if (hip_ok(hipMemcpyAsync(g->iv.as<double>() + 2 * o, ivd[d].p, size_t(g->n[d]) * 16, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync"))
+      return -100;
+  hipLaunchKernelGGL(cell_types_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, n, tkey.as<int32_t>(), cfac.as<int32_t>(), type_dev.as<int32_t>(),
+                     g->rec.as<int32_t>());
+  if (hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize")) // (the host buffers above are read by the copies until here)
+    return -100;
+  *out = g.release();
+  return 0;
+}
+extern "C" int mpcx_cell_grid_plan_fill(const mpcx_cell_grid_plan_t* p, mpcx_vector_args_t* a)
+{
+  if (!p || !a)
+  {
+    mpcx_set_error("mpcx_cell_grid_plan_fill: invalid arguments");
+    return -1;
+  }
+  a->grid_idx = p->rec.as<int32_t>();
+  a->grid_iv = p->iv.as<double>();
+  a->grid_tab = p->tab.as<double>();
+  a->grid_n[0] = p->n[0], a->grid_n[1] = p->n[1], a->grid_n[2] = p->n[2];
+  a->grid_block_rows = p->rows.as<int32_t>();
+  a->grid_block_rows_max = p->longest;
+  a->grid_eta = p->eta.as<double>();
+  a->grid_J = p->J.as<uint32_t>();
+  a->grid_ng = p->ng;
+  a->grid_ntypes = p->ntypes;
+  return 0;
+}
+extern "C" void mpcx_cell_grid_plan_destroy(mpcx_cell_grid_plan_t* p) { delete p; }
+
 extern "C" int mpcx_grid_plan_fill(const mpcx_grid_plan_t* p, mpcx_vector_args_t* a)
 {
   if (!p || !a)

@@ -1126,6 +1126,18 @@ int32_t mpcx_grid_plan_num_intervals(const mpcx_grid_plan_t* plan, int32_t axis)
 int32_t mpcx_grid_plan_block_rows(const mpcx_grid_plan_t* plan); /* longest block list; 0: the clusters read the table itself */
 void mpcx_grid_plan_destroy(mpcx_grid_plan_t* plan);
 
+/* The per-cell twin (mpcx_vector_args_t::grid_eta / grid_J / grid_ntypes, with grid_idx, grid_iv, grid_tab, grid_n and
+ * grid_block_rows) for the owner-computes launch over ALL cells of a tetrahedral mesh: cells [n_cells][4] vertex ids and x DEVICE,
+ * plan = the owner-computes plan of the vector call (its lists hold cells), qpts_host HOST [nq][3] the rule of the form.
+ * Returns 0 and the plan; 1 and *out = NULL when the mesh is not of that kind (a cell with a vertex between the ends of its
+ * interval or a flat cell, no tensor grid, a block that needs more than MPCX_GRID_BLOCK_ROWS rows, a rule with more than 255 sums);
+ * negative: error.  The torch twin: assemble_vector._cell_grid. */
+typedef struct mpcx_cell_grid_plan mpcx_cell_grid_plan_t;
+int mpcx_cell_grid_plan_create(const int32_t* cells, int64_t n_cells, const double* x, const mpcx_rowblock_plan_t* plan,
+                               const double* qpts_host, int32_t nq, void* stream, mpcx_cell_grid_plan_t** out);
+int mpcx_cell_grid_plan_fill(const mpcx_cell_grid_plan_t* plan, mpcx_vector_args_t* args);
+void mpcx_cell_grid_plan_destroy(mpcx_cell_grid_plan_t* plan);
+
 int mpcx_version(void);
 /* Load the library's code objects now (one empty kernel per translation unit on `stream`, then a stream synchronisation)
  * instead of at the first assembly call; optional, idempotent, thread-safe. */

@@ -242,3 +242,62 @@ def test_grid_plan_from_the_c_abi_equals_the_torch_built_plan(oracle, shape):
         assert abs(b2.numpy() - got).max() <= 1e-13 * max(1.0, abs(ref).max())
     finally:
         L.mpcx_grid_plan_destroy(h)
+
+
+@pytest.mark.parametrize("degree,warp", [(2, False), (1, False), (2, True)])
+def test_cell_grid_plan_from_the_c_abi_equals_the_torch_built_plan(oracle, degree, warp, monkeypatch):
+    """mpcx_cell_grid_plan_create (per-cell tensor-grid tables in library-owned memory: intervals, rows per block, cell types, the
+    rule's subset sums) against assemble_vector._cell_grid, array by array; the vector assembled from it against the product's;
+    a mesh with warped cells has no such plan (return code 1)"""
+    import torch
+
+    import dolfinx_mpc_amd as dm
+    from dolfinx_mpc_amd import _device as D
+    from dolfinx_mpc_amd import _native
+    from dolfinx_mpc_amd.la import create_vector
+
+    av = importlib.import_module("dolfinx_mpc_amd.assemble_vector")
+    if degree == 1:
+        monkeypatch.setenv("MPCX_FORCE_KERNEL", "vector=ownblock")
+    case = case_cube_periodic(6, degree, 0.0, reorder=(2, 2, 2), warp=warp)
+    mpc = product_mpc(case)
+    args, keep = av.vector_args(case.L, 0, create_vector(case.V), mpc, 0)
+    assert args.kernel_name == "ownblock"
+    L = _native.lib()
+    md = D.mesh_device(case.V.mesh)
+    q = np.ascontiguousarray(case.L.integrals[0].kernel.qpts, dtype=np.float64).reshape(-1)
+    h = C.c_void_p()
+    rc = L.mpcx_cell_grid_plan_create(md["x_dofmap"].data_ptr(), case.V.mesh.num_cells, md["x"].data_ptr(), C.byref(args.plan), q.ctypes.data,
+                                      q.size // 3, D.stream_ptr(), C.byref(h))
+    if warp:
+        assert rc == 1 and not h and not bool(args.grid_J)
+        return
+    _native.check(rc, "mpcx_cell_grid_plan_create")
+    try:
+        assert bool(args.grid_J)
+        a2 = _native.VectorArgs.from_buffer_copy(args)
+        a2.grid_idx = a2.grid_J = a2.grid_eta = a2.grid_iv = a2.grid_tab = a2.grid_block_rows = None
+        _native.check(L.mpcx_cell_grid_plan_fill(h, C.byref(a2)), "mpcx_cell_grid_plan_fill")
+        n = case.V.mesh.num_cells
+        ns = [int(a2.grid_n[d]) for d in range(3)]
+        assert ns == [int(args.grid_n[d]) for d in range(3)]
+        assert (int(a2.grid_ng), int(a2.grid_ntypes), int(a2.grid_block_rows_max)) == (int(args.grid_ng), int(args.grid_ntypes),
+                                                                                         int(args.grid_block_rows_max))
+        assert np.array_equal(_dev_array(a2.grid_iv, 2 * sum(ns), np.float64), _dev_array(args.grid_iv, 2 * sum(ns), np.float64))
+        assert np.allclose(_dev_array(a2.grid_eta, int(a2.grid_ng), np.float64), _dev_array(args.grid_eta, int(args.grid_ng), np.float64),
+                           rtol=0, atol=1e-15)
+        nj = int(a2.grid_ntypes) * (q.size // 3)
+        assert np.array_equal(_dev_array(a2.grid_J, nj, np.int32), _dev_array(args.grid_J, nj, np.int32))
+        assert np.array_equal(_dev_array(a2.grid_idx, 4 * n, np.int32), _dev_array(args.grid_idx, 4 * n, np.int32))
+        nb = int(args.plan.num_blocks)
+        assert np.array_equal(_dev_array(a2.grid_block_rows, 128 * nb, np.int32), _dev_array(args.grid_block_rows, 128 * nb, np.int32))
+        b2 = create_vector(case.V)
+        a2.b = b2.array.data_ptr()
+        _native.check(L.mpcx_assemble_vector(C.byref(a2)), "mpcx_assemble_vector")
+        torch.cuda.synchronize()
+        got = dm.assemble_vector(case.L, mpc).numpy()
+        ref = oracle_outputs(oracle, case)["b"]
+        assert abs(got - ref).max() <= 1e-12 * max(1.0, abs(ref).max())
+        assert abs(b2.numpy() - got).max() <= 1e-13 * max(1.0, abs(ref).max())
+    finally:
+        L.mpcx_cell_grid_plan_destroy(h)
