@@ -10,7 +10,7 @@
 //     mpcx_pairs_plan_create | mpcx_nodeblock_plan_create | mpcx_cell_plan_create           (row-block plan by block kind)
 //     mpcx_master_plan_create                                                               (master contributions, on the device)
 //     mpcx_assemble_matrix (+ mpcx_add_diagonal for square blocks)
-//     mpcx_mask_dofmap -> mpcx_owner_plan_create -> mpcx_assemble_vector
+//     mpcx_mask_dofmap -> mpcx_owner_plan_create (-> mpcx_cell_grid_plan_create) -> mpcx_assemble_vector
 // and writes every block's CSR and every vector.  tests/test_gpu_driver.py compares them with the oracle.
 //
 //     mpcx_driver_blocks problem.bin result.bin [steps]
@@ -235,6 +235,7 @@ int main(int argc, char** argv)
       const double* constants = nullptr;
       double* d_b = nullptr;
       Handle<mpcx_owner_plan_t, mpcx_owner_plan_destroy> plan;
+      Handle<mpcx_cell_grid_plan_t, mpcx_cell_grid_plan_destroy> grid; // (the benchmark's right-hand side on cells of a box mesh)
     };
     std::vector<std::unique_ptr<Vec>> vecs;
     for (int k = 0; in.count("v" + std::to_string(k) + "_space"); ++k)
@@ -253,6 +254,20 @@ int main(int argc, char** argv)
       int32_t* mrow = dev.alloc<int32_t>(size_t(n_cells) * size_t(S.nd));
       mpcx_check(mpcx_mask_dofmap(S.d_dofmap, n_cells, S.nd, S.bs, nullptr, S.mpc.is_slave, 0, mrow, stream), "mpcx_mask_dofmap");
       mpcx_check(mpcx_owner_plan_create(n_cells, S.nd, mrow, S.bs, S.ndofs, sp[1], nullptr, 0, 12288, stream, &V->plan.p), "mpcx_owner_plan_create");
+      // kernel.fn_id 1 (python/benchmarks/bench_periodic.py:85-89) on a scalar P1 / P2 space: per-interval tables of its univariate
+      // factors instead of a sine and an exponential per quadrature point, when the cells are cells of a box mesh
+      // (mpcx_vector_args_t::grid_eta / grid_J; return code 1 = they are not: point by point)
+      if (V->K.form == MPCX_FORM_SOURCE && V->K.fn_id == 1 && V->K.celltype == 2 && V->K.coeff_degree == 0 && S.bs == 1 && (S.nd == 4 || S.nd == 10)
+          && !std::getenv("MPCX_DRIVER_NO_GRID"))
+      {
+        const Array& q = need(in, (p + "_qpts").c_str());
+        mpcx_vector_args_t tmp;
+        std::memset(&tmp, 0, sizeof(tmp));
+        mpcx_check(mpcx_owner_plan_fill(V->plan.p, &tmp), "mpcx_owner_plan_fill");
+        const int rc = mpcx_cell_grid_plan_create(d_cells, n_cells, d_x, &tmp.plan, q.as<double>(), int32_t(q.n / 3), stream, &V->grid.p);
+        if (rc < 0)
+          mpcx_check(rc, "mpcx_cell_grid_plan_create");
+      }
       vecs.push_back(std::move(V));
     }
     hip_check(hipDeviceSynchronize(), "set-up");
@@ -317,6 +332,8 @@ int main(int argc, char** argv)
         mpcx_check(mpcx_owner_plan_fill(V.plan.p, &v), "mpcx_owner_plan_fill");
         v.algorithm = MPCX_ALG_ROWBLOCK;
         v.slave_entities = S.d_slave_cells, v.n_slave_entities = int64_t(S.slave_cells.size());
+        if (V.grid.p)
+          mpcx_check(mpcx_cell_grid_plan_fill(V.grid.p, &v), "mpcx_cell_grid_plan_fill");
         mpcx_check(mpcx_assemble_vector(&v), "mpcx_assemble_vector");
       }
       hip_check(hipDeviceSynchronize(), "step");

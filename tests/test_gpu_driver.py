@@ -252,11 +252,12 @@ def _vector_arrays(k, space, form, rows):
     return d
 
 
-def _run_blocks(tmp_path, arrays):
+def _run_blocks(tmp_path, arrays, env=None):
     assert os.path.exists(DRIVER_BLOCKS), "mpcx_driver_blocks is built by __graft_entry__.build() (make -C dolfinx_mpc_amd/csrc)"
     pin, pout = str(tmp_path / "problem.bin"), str(tmp_path / "result.bin")
     write_bundle(pin, arrays)
-    run = subprocess.run([DRIVER_BLOCKS, pin, pout, "2"], capture_output=True, text=True, timeout=600)
+    run = subprocess.run([DRIVER_BLOCKS, pin, pout, "2"], capture_output=True, text=True, timeout=600,
+                         env=None if env is None else dict(os.environ, **env))
     assert run.returncode == 0, run.stdout + run.stderr
     return read_bundle(pout), run.stdout
 
@@ -280,6 +281,10 @@ def test_blocks_driver_config5_p2_poisson(oracle, tmp_path, kind):
     assert np.array_equal(res["A0_rowptr"], refA.indptr) and np.array_equal(res["A0_cols"], refA.indices)
     assert abs(res["A0_vals"] - refA.data).max() <= 1e-12 * abs(refA.data).max()
     assert abs(res["b0"] - ref["b"]).max() <= 1e-12 * max(1.0, abs(ref["b"]).max())
+    if kind == 1:
+        # the right-hand side came from per-interval tables (mpcx_cell_grid_plan_create); point by point it rounds differently
+        res2, _log = _run_blocks(tmp_path, arrays, env={"MPCX_DRIVER_NO_GRID": "1"})
+        assert abs(res2["b0"] - res["b0"]).max() <= 1e-14 * abs(ref["b"]).max() and not np.array_equal(res2["b0"], res["b0"])
 
 
 @pytest.mark.gpu
